@@ -1,0 +1,316 @@
+/*
+ * rptr_hip.h -- C ABI of the MI355X-native wavefront path-tracing backend.
+ *
+ * This is the drop-in boundary for the reference's PT_MEGAKERNEL / RQ_CLOSEST /
+ * PROCESS_SAMPLES hot path.  Everything a `RenderBackend` implementation
+ * (reference: librender/render_backend.h:68-116) needs from the device side is
+ * reachable through the entry points below; signatures carry plain pointers and
+ * sizes only.  The reference-side adapter (`RenderHip : RenderBackend`) that a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RPTR_E_* code; nothing
+ *     throws across the ABI.  rptr_hip_last_error() returns a human-readable
+ *     message for the most recent failure on that handle (or the global one
+ *     when the handle is NULL).
+ *   - all calls for one handle come from one thread (reference:
+ *     render_backend.h has no concurrent entry points, SURVEY 8b "Threading").
+ *   - host arrays passed to rptr_hip_set_scene are borrowed for the duration
+ *     of the call only (reference: Scene is destroyed right after set_scene,
+ *     app.cpp:150-175).
+ *   - there is NO CPU fallback: without a HIP device every compute entry point
+ *     fails with RPTR_E_NO_DEVICE.
+ *
+ * POD structs are bit-compatible with the reference's shared C++/GLSL structs;
+ * the file:line of each is cited next to it.
+ */
+#ifndef RPTR_HIP_H
+#define RPTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPTR_OK 0
+#define RPTR_E_INVALID (-1)    /* bad argument / call order                        */
+#define RPTR_E_NO_DEVICE (-2)  /* no HIP device / HIP runtime error                */
+#define RPTR_E_NOMEM (-3)
+#define RPTR_E_UNSUPPORTED (-4)/* feature of the reference not built yet           */
+#define RPTR_E_HIP (-5)        /* a HIP call failed, see rptr_hip_last_error       */
+
+/* ---- compile-time constants of the path (librender/render_params.glsl.h:16-18) */
+#define RPTR_MAX_PATH_DEPTH 9
+#define RPTR_DEFAULT_RR_PATH_DEPTH 2
+#define RPTR_BINNED_LIGHTS_BIN_MAX_SIZE 16
+#define RPTR_RAY_EPSILON 0.000005f /* vulkan/gpu_params.glsl:27-29 */
+
+/* material flags, rendering/bsdfs/base_material.h.glsl:7-11 */
+#define RPTR_BASE_MATERIAL_NOALPHA 0x01
+#define RPTR_BASE_MATERIAL_ONESIDED 0x02
+#define RPTR_BASE_MATERIAL_VOLUME 0x04
+#define RPTR_BASE_MATERIAL_EXTENDED 0x08
+#define RPTR_BASE_MATERIAL_NEURAL 0x10
+
+/* geometry flags, rendering/rt/geometry.h.glsl:66-70 */
+#define RPTR_GEOMETRY_FLAGS_NOALPHA 0x01
+#define RPTR_GEOMETRY_FLAGS_IMPLICIT_INDICES 0x02
+
+/* integrator variants of this backend (reference: RenderBackend::variant_names).
+ * GLTF   = what PT_MEGAKERNEL ships: glTF metallic-roughness BSDF, 2 lobes
+ *          (rendering/bsdfs/gltf_bsdf.glsl, GLTF_SUPPORT_TRANSMISSION off).
+ * SIMPLE = Lambert-only material (rendering/bsdfs/simple_bsdf.glsl), the
+ *          "diffuse-only BSDF" of BASELINE.json configs[1].                     */
+#define RPTR_VARIANT_GLTF 0
+#define RPTR_VARIANT_SIMPLE 1
+
+/* rendering/bsdfs/base_material.h.glsl:13-34 -- 80 bytes */
+typedef struct RptrBaseMaterial {
+    float base_color[3];
+    int32_t normal_map;
+    uint32_t flags;
+    float roughness;
+    float specular;
+    float metallic;
+    float sheen;
+    float sheen_tint;
+    float clearcoat;
+    float clearcoat_gloss;
+    float ior;
+    float specular_transmission;
+    float anisotropy;
+    float specular_tint;
+    float transmission_color[3];
+    float emission_intensity;
+} RptrBaseMaterial;
+
+/* rendering/lights/tri.h.glsl:13-26 -- 48 bytes */
+typedef struct RptrTriLightData {
+    float v0[3];
+    float v1[3];
+    float v2[3];
+    float radiance[3];
+} RptrTriLightData;
+
+/* librender/render_params.glsl.h:165-170 -- 32 bytes */
+typedef struct RptrRenderRayQuery {
+    float origin[3];
+    int32_t mode_or_data;
+    float dir[3];
+    float t_max;
+} RptrRenderRayQuery;
+
+/* librender/render_params.glsl.h:123-128 -- 16 bytes */
+typedef struct RptrLightSamplingConfig {
+    float light_mis_angle;
+    int32_t bin_size;
+    float min_perceived_receiver_dist;
+    float min_radiance;
+} RptrLightSamplingConfig;
+
+/* librender/render_params.glsl.h:130-155 -- 80 bytes */
+typedef struct RptrRenderParams {
+    int32_t batch_spp;
+    int32_t max_path_depth;
+    int32_t rr_path_depth;
+    int32_t glossy_only_mode;
+    float aperture_radius;
+    float focus_distance;
+    float pixel_radius;
+    float variance_radius;
+    int32_t output_channel;
+    int32_t output_moment;
+    float exposure;
+    int32_t early_tone_mapping_mode;
+    int32_t reprojection_mode;
+    int32_t spp_accumulation_window;
+    int32_t enable_raster_taa;
+    int32_t render_upscale_factor;
+    float focal_length;
+    int32_t _pad3, _pad4, _pad5;
+} RptrRenderParams;
+
+/* rendering/lights/sky_model_arhosek/sky_model.h.glsl:7-10 -- 160 bytes */
+typedef struct RptrSkyModelParams {
+    float configs[9][4];
+    float radiances[4];
+} RptrSkyModelParams;
+
+/* the scene-wide constants of vulkan/gpu_params.glsl:120-131 (SceneParams) that
+ * the host fills in update_config/update_sky_light (vulkan/render_sky.cpp:25-72).
+ * light_count / bin bookkeeping is derived by the backend from set_scene.       */
+typedef struct RptrSceneParams {
+    RptrSkyModelParams sky_params;
+    float sun_dir[3];
+    float sun_cos_angle;
+    float sun_radiance[4]; /* .w = probability of picking the sun in NEE          */
+    float normal_z_scale;
+    int32_t _pad[3];
+} RptrSceneParams;
+
+/* librender/render_backend.h:26-31 (RenderCameraParams) */
+typedef struct RptrCamera {
+    float pos[3];
+    float dir[3];
+    float up[3];
+    float fovy; /* degrees */
+} RptrCamera;
+
+/* one geometry of a mesh: unrolled, quantized vertex streams
+ * (REQUIRE_UNROLLED_VERTICES / QUANTIZED_* of vulkan/gpu_params.glsl:7-9;
+ *  stream layout = librender/quantize.h:7-35, librender/dequantize.glsl:8-48). */
+typedef struct RptrGeometryDesc {
+    const uint64_t *qpos;    /* 3*num_tris, 21 bit/axis                           */
+    const uint64_t *qnrm_uv; /* 3*num_tris, lo32 = oct normal, hi32 = uv; or NULL */
+    uint32_t num_tris;
+    uint32_t has_normals;
+    uint32_t has_uvs;
+    float quantized_scaling[3];
+    float quantized_offset[3];
+} RptrGeometryDesc;
+
+/* a mesh = one bottom-level acceleration structure (librender/mesh.h:43-72) */
+typedef struct RptrMeshDesc {
+    uint32_t first_geometry;
+    uint32_t num_geometries;
+    uint32_t dynamic; /* !=0: vertices may be updated + refit (Mesh::Dynamic)    */
+} RptrMeshDesc;
+
+/* a mesh with a material assignment (librender/mesh.h:78-108, ParameterizedMesh) */
+typedef struct RptrParameterizedMeshDesc {
+    uint32_t mesh;
+    const int32_t *material_offsets; /* one per geometry of the mesh             */
+    const uint8_t *tri_material_ids; /* all triangles of the mesh, or NULL       */
+} RptrParameterizedMeshDesc;
+
+/* librender/mesh.h:112-116 (Instance) with the transform already dequantized;
+ * row-major 3x4 object-to-world like VkAccelerationStructureInstanceKHR
+ * (vulkan/render_vulkan.cpp:1262-1268).                                         */
+typedef struct RptrInstanceDesc {
+    float transform[12];
+    uint32_t parameterized_mesh;
+} RptrInstanceDesc;
+
+typedef struct RptrSceneDesc {
+    const RptrGeometryDesc *geometries;
+    uint32_t num_geometries;
+    const RptrMeshDesc *meshes;
+    uint32_t num_meshes;
+    const RptrParameterizedMeshDesc *parameterized_meshes;
+    uint32_t num_parameterized_meshes;
+    const RptrInstanceDesc *instances;
+    uint32_t num_instances;
+    const RptrBaseMaterial *materials;
+    uint32_t num_materials;
+    /* emitters already collected + bin-equalised on the host
+     * (librender/lights.cpp:14-90,220-349) */
+    const RptrTriLightData *lights;
+    uint32_t num_lights;
+} RptrSceneDesc;
+
+/* device selection + multi-GPU tile assignment.  The frame is cut
+ * into horizontal stripes of `stripe_rows` rows; stripe s belongs to rank
+ * s % world_size.  A rank only allocates and renders its own rows. */
+typedef struct RptrCreateInfo {
+    int32_t device_ordinal; /* hipSetDevice                                      */
+    int32_t rank;
+    int32_t world_size;
+    int32_t stripe_rows;    /* 0 -> default 32                                   */
+    void *stream;           /* hipStream_t to launch on, NULL -> backend-owned   */
+} RptrCreateInfo;
+
+typedef struct RptrStats {
+    float render_time_ms;      /* GPU time of the last render call (hipEvents)   */
+    float extend_time_ms;      /* sum over closest-hit traversal launches        */
+    float connect_time_ms;     /* sum over shadow traversal launches             */
+    float shade_time_ms;       /* raygen+sort+shade+resolve                      */
+    uint64_t rays_closest;     /* +1 per closest query (pt_megakernel.glsl:440)  */
+    uint64_t rays_shadow;      /* +1 per issued shadow query (:223-227)          */
+    uint64_t nodes_visited;    /* only when count_traversal was requested        */
+    uint64_t tris_tested;
+    uint64_t hits_shaded;
+    int32_t spp;               /* accumulated samples per pixel                  */
+    int32_t launches_extend;
+    int32_t launches_connect;
+    int32_t _pad;
+    uint64_t device_bytes_allocated;
+} RptrStats;
+
+typedef struct rptr_hip rptr_hip_t;
+
+/* ---- lifetime (≙ create_backend_function, render_backend.h:118-119) */
+int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out);
+void rptr_hip_destroy(rptr_hip_t *h);
+const char *rptr_hip_last_error(const rptr_hip_t *h);
+const char *rptr_hip_name(void); /* RenderBackend::name() */
+int rptr_hip_set_stream(rptr_hip_t *h, void *hip_stream);
+
+/* ---- RenderBackend::initialize(fb_w, fb_h) (render_vulkan.cpp:246-370) */
+int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height);
+
+/* ---- RenderBackend::set_scene (render_vulkan.cpp:1554-1644): uploads geometry,
+ * builds bottom/top level BVH2, uploads materials + binned lights */
+int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *scene);
+
+/* ---- dynamic meshes: replace the float positions of one geometry and refit
+ * (≙ BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354) */
+int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices);
+int rptr_hip_refit(rptr_hip_t *h);
+
+/* ---- RenderBackend::params / lighting_params / update_config
+ * (render_backend.h:69-76, render_vulkan.cpp:2943-2959) */
+int rptr_hip_set_params(rptr_hip_t *h, const RptrRenderParams *params,
+                        const RptrSceneParams *scene_params,
+                        const RptrLightSamplingConfig *lighting_params);
+
+/* ---- begin_frame + draw_frame + end_frame for `spp` samples per pixel
+ * (render_vulkan.cpp:1919-2178).  Equivalent to `spp` reference frames with
+ * batch_spp = 1: sample_index = frame_id .. frame_id+spp-1, each folded into
+ * the accumulation buffer by the running mean of process_samples.comp:116-132.
+ * reset_accumulation != 0 -> frame_offset += frame_id; frame_id = 0
+ * (render_vulkan.cpp:1937-1941).  count_traversal != 0 additionally counts BVH
+ * node visits / triangle tests (slower; for roofline accounting only). */
+int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp,
+                    int reset_accumulation, int count_traversal, RptrStats *out_stats);
+
+/* ---- RenderGraphic::get_framebuffer_size / readback_framebuffer
+ * (util/display/render_graphic.h:26-37, render_vulkan.cpp:2256-2287).
+ * The float read-back returns the RGBA32F accumulation buffer (what
+ * --validation writes); rows owned by other ranks are left untouched.
+ * Returns the number of floats a full frame needs in *out_count. */
+int rptr_hip_get_framebuffer_size(const rptr_hip_t *h, uint32_t out_whc[3]);
+int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats);
+int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes);
+
+/* ---- multi-GPU: this rank's rows, packed top-to-bottom, for the RCCL gather.
+ * rptr_hip_tile_rows writes up to `cap` (first_row,num_rows) pairs for `rank`
+ * and returns the number of stripes; rptr_hip_copy_tile_to_device copies this
+ * rank's packed rows (float4 per pixel) into a caller-owned DEVICE buffer on
+ * the backend's stream. */
+int rptr_hip_tile_rows(const rptr_hip_t *h, int rank, int32_t *first_and_count, int cap);
+int rptr_hip_local_pixel_count(const rptr_hip_t *h, uint64_t *out_pixels);
+int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes);
+
+/* ---- enable_ray_queries / render_ray_queries with the RQ_CLOSEST kernel
+ * (render_backend.h:101-102, vulkan/rt_intersect.comp:31-68): n queries ->
+ * n x float4 (bary.x, bary.y, bits(instance_custom_index + geometry_index),
+ * bits(primitive_index)); miss = (-1,-1,bits(-1),bits(-1)); mode_or_data < 0
+ * leaves the result slot untouched. Host pointers. */
+int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4);
+
+/* ---- test/diagnostic access to the acceleration structure (node format in
+ * DESIGN.md): copies out the flattened BVH so the oracle can traverse the very
+ * same tree and count the very same node visits. Pass NULL buffers to query
+ * sizes. */
+int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris,
+                        void *instances, size_t *n_instances);
+
+/* ---- stats() (render_vulkan.cpp:2229-2243) */
+int rptr_hip_stats(const rptr_hip_t *h, RptrStats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPTR_HIP_H */

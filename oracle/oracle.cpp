@@ -1,0 +1,745 @@
+// TEST INFRASTRUCTURE -- never linked into, imported by or executed from the
+// product (realtimepathtracingresearchframework_amd/). Only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file.
+//
+// oracle.cpp -- CPU restatement of the reference's PT_MEGAKERNEL integrator
+// (vulkan/pt_megakernel.glsl:275-737), its accumulate/process_samples resolve
+// (vulkan/accumulate.glsl:44-74, vulkan/process_samples.comp:69-200) and the
+// RQ_CLOSEST batch query (vulkan/rt_intersect.comp:31-68), one path at a time,
+// in the reference's control flow. Scalar code, std::thread over rows: this is
+// also the "Embree-style scalar traversal" CPU baseline of BASELINE.md.
+//
+// Parity status (see DESIGN.md "Oracle"): RNG pinned by the SURVEY 8(a2)
+// known answer; sky/sun parameters pinned by oracle/_ref (the reference's own
+// sky_model.cpp compiled as is); BVH/intersection and the remaining shading
+// arithmetic have no reference golden values -> "parity unpinned", guarded by
+// brute force and by domain properties in tests/.
+#include "obvh.h"
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+using namespace orc;
+
+namespace {
+
+struct ViewParams { // the subset of vulkan/gpu_params.glsl:61-87 the path reads
+    uint32_t frame_offset;
+    uint32_t dims_x, dims_y;
+    vec3 cam_pos, cam_du, cam_dv, cam_dir_top_left;
+};
+
+// vulkan/render_vulkan.cpp:2880-2896 (host side of a3)
+static void compute_view(const RptrCamera &c, int W, int H, ViewParams &vp) {
+    vec3 pos(c.pos[0], c.pos[1], c.pos[2]), dir(c.dir[0], c.dir[1], c.dir[2]), up(c.up[0], c.up[1], c.up[2]);
+    float plane_y = 2.f * tanf((0.5f * c.fovy) * 0.01745329251994329576923690768489f);
+    float aspect = static_cast<float>(W) / H;
+    float plane_x = plane_y * aspect;
+    const vec3 dir_du = normalize(cross(dir, up)) * plane_x;
+    const vec3 dir_dv = -normalize(cross(dir_du, dir)) * plane_y;
+    const vec3 dir_top_left = dir - 0.5f * dir_du - 0.5f * dir_dv;
+    vp.cam_pos = pos;
+    vp.cam_du = dir_du;
+    vp.cam_dv = dir_dv;
+    vp.cam_dir_top_left = dir_top_left;
+    vp.dims_x = W;
+    vp.dims_y = H;
+}
+
+struct Scene {
+    SceneView view;
+    Bvh own;
+    Bvh imported;
+    bool own_built = false, has_imported = false;
+    std::vector<std::array<float, 12>> inst_w2o; // per scene instance, oracle's own inverse
+    std::vector<RptrTriLightData> lights;        // padded by one zeroed bin (see sample_tri_lights)
+    int num_lights = 0;
+};
+
+struct Frame {
+    const Scene *sc;
+    const Bvh *bvh; // nullptr -> brute force
+    RptrRenderParams rp;
+    RptrSceneParams sp;
+    RptrLightSamplingConfig lc;
+    ViewParams vp;
+    bool count;
+};
+
+struct PathCounters {
+    uint64_t rays_closest = 0, rays_shadow = 0, hits = 0;
+    TraceCounters tc_closest, tc_shadow;
+};
+
+static inline bool trace_closest(const Frame &f, const Ray &r, Hit &h, PathCounters &pc) {
+    pc.rays_closest++;
+    if (f.bvh) return traverse<false>(*f.bvh, r, h, f.count ? &pc.tc_closest : nullptr);
+    return brute_force<false>(f.sc->view, r, h);
+}
+static inline bool trace_any(const Frame &f, const Ray &r, PathCounters &pc) {
+    pc.rays_shadow++;
+    Hit h;
+    if (f.bvh) return traverse<true>(*f.bvh, r, h, f.count ? &pc.tc_shadow : nullptr);
+    return brute_force<true>(f.sc->view, r, h);
+}
+
+// vulkan/geometry.glsl:76-78
+static inline float geometry_scale_to_tmin(vec3 orig, float geometry_scale) { return (length(orig) + geometry_scale) * RPTR_RAY_EPSILON; }
+
+// vulkan/pt_megakernel.glsl:216-272 (opaque geometry: every synthetic material is NOALPHA)
+static inline bool raytrace_test_visibility(const Frame &f, float geometry_scale, const vec3 from, const vec3 dir, float dist, PathCounters &pc) {
+    float epsilon = geometry_scale_to_tmin(from, geometry_scale);
+    if (dist - 2.f * epsilon > 0.0f) {
+        Ray r{from, dir, epsilon, dist - epsilon};
+        return !trace_any(f, r, pc);
+    }
+    return true;
+}
+
+// rendering/mc/nee_interface.glsl:46-48 + lights_sun.glsl:17-21
+static inline float eval_direct_sun_light_pdf(const Frame &f) { return f.sp.sun_radiance[3] * sample_sun_dir_pdf(f.sp.sun_cos_angle); }
+
+static inline int binned_lights_bin_count(const Frame &f) { // pt_megakernel.glsl:103
+    return (f.sc->num_lights + (f.lc.bin_size - 1)) / f.lc.bin_size;
+}
+// rendering/mc/lights_linear.glsl:129-137
+static inline float approx_tri_lights_pdf(const Frame &f, float approx_solid_angle) {
+    int num_bins = binned_lights_bin_count(f);
+    return 1.0f / (float(num_bins) * approx_solid_angle);
+}
+// rendering/mc/nee_interface.glsl:52-61
+static inline float wpdf_direct_light(const Frame &f, float approx_solid_angle) {
+    return (1.0f - f.sp.sun_radiance[3]) * approx_tri_lights_pdf(f, approx_solid_angle);
+}
+
+// vulkan/pt_megakernel.glsl:113-149
+static vec3 compute_sky_illum(const Frame &f, vec3 ray_dir, float prev_bsdf_pdf) {
+    vec3 sun_dir(f.sp.sun_dir[0], f.sp.sun_dir[1], f.sp.sun_dir[2]);
+    vec3 dir = ray_dir;
+    float ocean_coeff = 1.0f;
+    if (dir.y <= 0.0f) {
+        dir.y = -dir.y;
+        ocean_coeff = 0.7f * pow5(fmaxf(1.0f - fabsf(dir.y), 0.0f));
+    }
+    vec3 atmosphere_illum = vmax(skymodel_radiance(f.sp.sky_params, sun_dir, dir), vec3(0.0f)) * ocean_coeff;
+    vec3 sun_illum;
+    if (dot(dir, sun_dir) >= f.sp.sun_cos_angle)
+        sun_illum = vec3(f.sp.sun_radiance[0], f.sp.sun_radiance[1], f.sp.sun_radiance[2]) * ocean_coeff;
+    else
+        sun_illum = vec3(0.0f);
+    vec3 illum = vec3(0.0f);
+    illum += vabs(atmosphere_illum);
+    float light_pdf = eval_direct_sun_light_pdf(f);
+    float w = nee_mis_heuristic(1.f, prev_bsdf_pdf, 1.f, light_pdf);
+    illum += w * vabs(sun_illum);
+    return illum;
+}
+
+// rendering/mc/lights_linear.glsl:19-127 (BINNED_LIGHTS_BIN_MAX_SIZE = 16, solid angle sampling)
+static vec3 sample_tri_lights(const Frame &f, const vec3 hit_p, const vec3 hit_n, vec2 dir_sample, vec2 sel_sample, vec3 &light_dir,
+                              float &light_dist, float &pdf, float &mis_wpdf) {
+    const RptrTriLightData *lights = f.sc->lights.data();
+    int num_lights = f.sc->num_lights;
+    const int BIN = f.lc.bin_size;
+    int num_bins = binned_lights_bin_count(f);
+    sel_sample.x *= float(num_bins);
+    int bin_id = int(uint32_t(sel_sample.x));
+    bin_id = std::min(bin_id, num_bins - 1);
+    float sel_p = 1.0f / float(num_bins);
+    sel_sample.x -= float(bin_id);
+    float light_contributions[RPTR_BINNED_LIGHTS_BIN_MAX_SIZE];
+    float total_contrib = 0.0f;
+    const float MIN_IRRADIANCE = 6.2e-4f * 0.001f;
+    int bin_end = std::min(BIN * (bin_id + 1), num_lights);
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
+        int light_id = BIN * bin_id + i;
+        if (!(light_id < bin_end)) break;
+        TriLight light = decode_tri_light(lights[light_id]);
+        light.v0 -= hit_p;
+        light.v1 -= hit_p;
+        light.v2 -= hit_p;
+        bool front_facing = is_tri_facing_forward(light.v0, light.v1, light.v2);
+        float contrib = luminance(light.radiance);
+        if ((dot(light.v0, hit_n) > 0.0f || dot(light.v1, hit_n) > 0.0f || dot(light.v2, hit_n) > 0.0f) && front_facing) {
+            light.v0 = normalize(light.v0);
+            light.v1 = normalize(light.v1);
+            light.v2 = normalize(light.v2);
+            contrib *= approx_triangle_solid_angle(light.v0, light.v1, light.v2);
+        } else
+            contrib = 0.0f;
+        contrib += MIN_IRRADIANCE;
+        light_contributions[i] = contrib;
+        total_contrib += contrib;
+    }
+    float p = 0.0f;
+    float t = 0.0f;
+    int light_id = 0;
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
+        light_id = BIN * bin_id + i;
+        if (!(light_id < bin_end)) break;
+        p = light_contributions[i] / total_contrib;
+        t += p;
+        if (sel_sample.y < t) break;
+    }
+    sel_p *= p;
+    // note: the reference may leave light_id == bin_end here (one past the
+    // bin) when rounding keeps sel_sample.y >= t; the light buffer is padded
+    // with one zeroed bin so that read is defined and identical everywhere.
+    TriLight light = decode_tri_light(lights[light_id]);
+    vec3 d0 = normalize(light.v0 - hit_p);
+    vec3 d1 = normalize(light.v1 - hit_p);
+    vec3 d2 = normalize(light.v2 - hit_p);
+    vec3 tri_parameters;
+    float polygon_solid_angle = triangle_solid_angle(d0, d1, d2, tri_parameters);
+    light_dir = sample_solid_angle_polygon(d0, d1, d2, polygon_solid_angle, tri_parameters, dir_sample);
+    pdf = 1.0f / polygon_solid_angle;
+    vec3 e0 = light.v1 - light.v0;
+    vec3 e1 = light.v2 - light.v0;
+    vec3 e_n = cross(e0, e1);
+    light_dist = dot(light.v0 - hit_p, e_n) / dot(light_dir, e_n);
+    mis_wpdf = 2.0f * light_dist * light_dist / fabsf(dot(light_dir, e_n));
+    pdf *= sel_p;
+    mis_wpdf /= float(num_bins);
+    return 1.0f * light.radiance / pdf;
+}
+
+// rendering/mc/nee.glsl:32-90
+template <class MAT>
+static vec3 sample_direct_light(const Frame &f, float geometry_scale, const MAT &mat, const InteractionPoint &hit, const vec3 w_o,
+                                vec2 dir_sample, vec2 sel_sample, PathCounters &pc) {
+    vec3 illum = vec3(0.0f);
+    vec3 light_dir;
+    float light_dist = 2.e16f;
+    float light_pdf = 0.0f;
+    float mis_pdf = 0.0f;
+    const float sun_w = f.sp.sun_radiance[3];
+    vec3 sun_dir(f.sp.sun_dir[0], f.sp.sun_dir[1], f.sp.sun_dir[2]);
+    if (sel_sample.x <= sun_w) {
+        sel_sample.x /= sun_w;
+        // lights_sun.glsl:8-16
+        light_dir = sample_sun_dir(sun_dir, f.sp.sun_cos_angle, dir_sample);
+        light_pdf = sample_sun_dir_pdf(f.sp.sun_cos_angle);
+        illum += (vec3(1.0f) / light_pdf) * (vec3(f.sp.sun_radiance[0], f.sp.sun_radiance[1], f.sp.sun_radiance[2]) / sun_w);
+        light_pdf *= sun_w;
+        mis_pdf = light_pdf;
+    } else {
+        sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
+        float tri_mis_wpdf = 0.0f;
+        illum += sample_tri_lights(f, hit.p, hit.n, dir_sample, sel_sample, light_dir, light_dist, light_pdf, tri_mis_wpdf) / (1.0f - sun_w);
+        light_pdf *= 1.0f - sun_w;
+        if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
+    }
+    if (light_pdf > 0.0f && dot(light_dir, hit.gn) * dot(light_dir, hit.n) > 0.0f) {
+        bool visibility = raytrace_test_visibility(f, geometry_scale, hit.p, light_dir, light_dist, pc);
+        float bsdf_pdf = eval_bsdf_wpdf(mat, hit, w_o, light_dir);
+        if (bsdf_pdf >= 0.0f && visibility) {
+            vec3 bsdf = eval_bsdf(mat, hit, w_o, light_dir);
+            float w = nee_mis_heuristic(1.f, mis_pdf, 1.f, bsdf_pdf);
+            illum = illum * ((w * fabsf(dot(light_dir, hit.n))) * bsdf);
+            return illum;
+        }
+    }
+    return vec3(0.0f);
+}
+
+enum { SHADING_RESULT_TERMINATE = -1, SHADING_RESULT_BOUNCE = 1 };
+struct ShadingSampleState { // rendering/mc/shading_interface.glsl:15-22
+    int bounce;
+    int output_channel;
+    float prev_bounce_pdf;
+};
+
+// rendering/mc/shade_base_material.glsl:14-96
+template <class MAT>
+static int shade_base_material(const Frame &f, float geometry_scale, ShadingSampleState &state, vec3 &illum, vec3 &path_throughput,
+                               const RptrBaseMaterial &params, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
+                               LCGRand &rng, vec3 &w_i, PathCounters &pc) {
+    MAT mat;
+    vec3 emit_radiance;
+    unpack_material(mat, emit_radiance, params);
+    vec3 scatter_throughput = path_throughput;
+    if (state.output_channel == 0 && !all_equal(emit_radiance, vec3(0.0f))) {
+        float light_pdf = wpdf_direct_light(f, approx_solid_angle);
+        float w = nee_mis_heuristic(1.f, state.prev_bounce_pdf, 1.f, light_pdf);
+        illum += w * scatter_throughput * emit_radiance;
+    }
+    if (state.output_channel != 0) {
+        float reliability = powf(0.25f, float(state.bounce));
+        if (state.output_channel == 1)
+            illum += scatter_throughput * mat.base_color * reliability;
+        else if (state.output_channel == 2)
+            illum += interaction.n * reliability;
+        else if (state.output_channel == 3)
+            illum += interaction.p * reliability;
+    }
+    if (state.bounce + 1 >= f.rp.max_path_depth) return SHADING_RESULT_TERMINATE;
+    if (state.output_channel == 0) {
+        // GLSL evaluates constructor arguments left to right: position sample first, then selection
+        vec2 pos_sample = random_float2(rng);
+        vec2 sel_sample = random_float2(rng);
+        illum += scatter_throughput * sample_direct_light(f, geometry_scale, mat, interaction, w_o, pos_sample, sel_sample, pc);
+    }
+    if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) return SHADING_RESULT_TERMINATE;
+    vec2 bsdfLobeSample = random_float2(rng);
+    vec2 bsdfDirSample = random_float2(rng);
+    float sampling_pdf = 0.0f, mis_pdf = 0.0f;
+    vec3 bsdf = sample_bsdf(mat, interaction, w_o, w_i, sampling_pdf, mis_pdf, bsdfDirSample, bsdfLobeSample);
+    ++state.bounce;
+    // note: when sample_bsdf bails out early the reference leaves mis_pdf
+    // undefined, but bsdf == 0 then terminates regardless.
+    if (all_equal(bsdf, vec3(0.f)) || mis_pdf == 0.f || !(dot(w_i, interaction.n) * dot(w_i, interaction.gn) > 0.0f))
+        return SHADING_RESULT_TERMINATE;
+    path_throughput *= bsdf;
+    state.prev_bounce_pdf = mis_pdf;
+    return SHADING_RESULT_BOUNCE;
+}
+
+// vulkan/pt_megakernel.glsl:310-737 for one pixel sample
+template <class MAT>
+static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_index, PathCounters &pc) {
+    const Scene &sc = *f.sc;
+    LCGRand rng = get_lcg_rng(sample_index, f.vp.frame_offset, px, py, f.vp.dims_x);
+    vec2 point = vec2(px + 0.5f, py + 0.5f);
+    if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng) - vec2(0.5f));
+    point = point / vec2((float)f.vp.dims_x, (float)f.vp.dims_y);
+    vec3 ray_origin = f.vp.cam_pos;
+    vec3 ray_dir = normalize(point.x * f.vp.cam_du + point.y * f.vp.cam_dv + f.vp.cam_dir_top_left);
+    float t_min = 0;
+    float t_max = 2.e32f;
+    float total_t = 0.0f;
+    vec3 illum = vec3(0.f);
+    vec3 path_throughput = vec3(1.f);
+    ShadingSampleState shading_state{0, f.rp.output_channel, 2.e16f};
+    for (int b = 0; b < f.rp.max_path_depth; ++b) {
+        Hit h;
+        Ray r{ray_origin, ray_dir, t_min, t_max};
+        bool found = trace_closest(f, r, h, pc);
+        if (!found) {
+            illum += path_throughput * compute_sky_illum(f, ray_dir, shading_state.prev_bounce_pdf);
+            break;
+        }
+        pc.hits++;
+        // :495-572 RECOMPUTE_HIT_ATTRIBUTES
+        const RptrInstanceDesc &inst = sc.view.desc->instances[h.inst];
+        int geometryIdx = sc.view.pmesh_geom_base[inst.parameterized_mesh] + h.geom;
+        const GeomRecord &geom = sc.view.geoms[geometryIdx];
+        vec3 v0, v1, v2;
+        geom_tri(*geom.g, h.prim, v0, v1, v2);
+        mat3 verts(v0, v1, v2);
+        mat3 normals;
+        mat3x2 uvs;
+        bool has_normals = geom.g->has_normals != 0 && geom.g->qnrm_uv, has_uvs = geom.g->has_uvs != 0 && geom.g->qnrm_uv;
+        if (has_normals || has_uvs) {
+            uint64_t a = geom.g->qnrm_uv[3 * h.prim + 0], bq = geom.g->qnrm_uv[3 * h.prim + 1], c = geom.g->qnrm_uv[3 * h.prim + 2];
+            if (has_normals) normals = mat3(dequantize_normal(uint32_t(a)), dequantize_normal(uint32_t(bq)), dequantize_normal(uint32_t(c)));
+            if (has_uvs) {
+                uvs.c[0] = dequantize_uv(uint32_t(a >> 32));
+                uvs.c[1] = dequantize_uv(uint32_t(bq >> 32));
+                uvs.c[2] = dequantize_uv(uint32_t(c >> 32));
+            }
+        }
+        const float *w2o = sc.inst_w2o[h.inst].data();
+        // transpose(mat3(world_to_object)): columns of the transpose = rows of world_to_object
+        mat3 normals_to_world(vec3(w2o[0], w2o[1], w2o[2]), vec3(w2o[4], w2o[5], w2o[6]), vec3(w2o[8], w2o[9], w2o[10]));
+        RTHit hit = calc_hit_attributes(h.t, h.prim, vec2(h.u, h.v), verts, normals_to_world, normals, has_normals, uvs, has_uvs,
+                                        geom.material_id, geom.mat_ids);
+        // :578-580
+        float approx_tri_solid_angle = length(hit.geo_normal);
+        hit.geo_normal /= approx_tri_solid_angle;
+        approx_tri_solid_angle *= fabsf(dot(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
+        // :585,605 (texture footprint itself is dead without textured parameters)
+        total_t += hit.dist;
+        float geometry_scale = total_t;
+        const vec3 w_o = -ray_dir;
+        InteractionPoint interaction;
+        interaction.p = ray_origin + hit.dist * ray_dir;
+        interaction.instanceId = h.inst;
+        interaction.primitiveId = h.prim;
+        interaction.gn = hit.geo_normal;
+        interaction.n = hit.normal;
+        const RptrBaseMaterial &mparams = sc.view.desc->materials[hit.material_id];
+        uint32_t material_flags = mparams.flags;
+        // :624-633
+        if (dot(w_o, interaction.gn) < 0.0f) {
+            if ((material_flags & RPTR_BASE_MATERIAL_VOLUME) != 0) {
+                interaction.p = ray_origin;
+                hit.dist = 0.0f;
+            } else if ((material_flags & RPTR_BASE_MATERIAL_ONESIDED) == 0) {
+                interaction.n = -interaction.n;
+                interaction.gn = -interaction.gn;
+            }
+        }
+        // :634-654 normal mapping: normal_map must be -1 (no textures in this build)
+        // :656-668
+        {
+            float nw = dot(w_o, interaction.n);
+            float gnw = dot(w_o, interaction.gn);
+            if (nw * gnw <= 0.0f) {
+                float blend = gnw / (gnw - nw);
+                interaction.n = normalize(mix(interaction.gn, interaction.n, blend - ORC_EPSILON));
+            }
+        }
+        // :677-678
+        interaction.v_y = normalize(cross(interaction.n, hit.tangent));
+        interaction.v_x = cross(interaction.v_y, interaction.n);
+        vec3 w_i;
+        int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams,
+                                                      approx_tri_solid_angle, w_o, interaction, rng, w_i, pc);
+        if (shading_result == SHADING_RESULT_TERMINATE) break;
+        // :703-709
+        ray_dir = w_i;
+        ray_origin = interaction.p;
+        t_min = geometry_scale_to_tmin(ray_origin, total_t);
+        t_max = 1e20f;
+        // :713-730
+        if (shading_state.bounce >= f.rp.rr_path_depth) {
+            float prefix_weight = fmaxf(path_throughput.x, fmaxf(path_throughput.y, path_throughput.z));
+            float rr_prob = prefix_weight;
+            float rr_sample = lcg_randomf(rng);
+            if (shading_state.bounce > 6)
+                rr_prob = fminf(0.95f, rr_prob);
+            else
+                rr_prob = fminf(1.0f, rr_prob);
+            if (rr_sample < rr_prob)
+                path_throughput /= rr_prob;
+            else
+                break;
+        }
+    }
+    return vec4(illum, shading_state.bounce == 0 ? 0.0f : 1.0f);
+}
+
+} // namespace
+
+// =============================================================== C API (ctypes)
+extern "C" {
+
+struct OrcRenderArgs {
+    int32_t width, height;
+    int32_t row_begin, row_end; // rows [row_begin,row_end) are rendered, the rest untouched
+    int32_t variant;            // RPTR_VARIANT_*
+    int32_t sample_begin;       // frame_id of the first sample (0 after reset)
+    int32_t spp;
+    uint32_t frame_offset;
+    int32_t bvh_mode;           // 0 own BVH, 1 brute force, 2 imported BVH
+    int32_t n_threads;          // <=0: hardware_concurrency
+    int32_t count_traversal;
+    int32_t _pad;
+    RptrCamera camera;
+    RptrRenderParams params;
+    RptrSceneParams scene_params;
+    RptrLightSamplingConfig lighting;
+};
+struct OrcRenderStats {
+    uint64_t rays_closest, rays_shadow, hits_shaded;
+    uint64_t nodes_closest, tris_closest, nodes_shadow, tris_shadow;
+    double seconds;
+    int32_t threads;
+    int32_t _pad;
+};
+
+void *orc_scene_create(const RptrSceneDesc *desc) {
+    Scene *s = new Scene();
+    s->view.init(desc);
+    s->inst_w2o.resize(desc->num_instances);
+    for (uint32_t i = 0; i < desc->num_instances; ++i) invert_affine(desc->instances[i].transform, s->inst_w2o[i].data());
+    s->num_lights = (int)desc->num_lights;
+    s->lights.assign(desc->lights, desc->lights + desc->num_lights);
+    RptrTriLightData z;
+    memset(&z, 0, sizeof(z));
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE + 1; ++i) s->lights.push_back(z);
+    return s;
+}
+void orc_scene_destroy(void *p) { delete (Scene *)p; }
+
+static void ensure_own(Scene *s) {
+    if (!s->own_built) {
+        build_bvh(s->view, s->own);
+        s->own_built = true;
+    }
+}
+int orc_scene_build_bvh(void *p, uint64_t *out_counts /*nodes,tris,insts*/) {
+    Scene *s = (Scene *)p;
+    ensure_own(s);
+    if (out_counts) {
+        out_counts[0] = s->own.nodes.size();
+        out_counts[1] = s->own.tris.size();
+        out_counts[2] = s->own.insts.size();
+    }
+    return 0;
+}
+int orc_scene_import_bvh(void *p, const RptrBvhNode *nodes, size_t n_nodes, const RptrBvhTri *tris, size_t n_tris,
+                         const RptrBvhInstance *insts, size_t n_insts) {
+    Scene *s = (Scene *)p;
+    s->imported.nodes.assign(nodes, nodes + n_nodes);
+    s->imported.tris.assign(tris, tris + n_tris);
+    s->imported.insts.assign(insts, insts + n_insts);
+    s->has_imported = true;
+    return 0;
+}
+static const Bvh *pick_bvh(Scene *s, int mode) {
+    if (mode == 1) return nullptr;
+    if (mode == 2) return s->has_imported ? &s->imported : nullptr;
+    ensure_own(s);
+    return &s->own;
+}
+
+// vulkan/rt_intersect.comp:31-68. counters: [nodes, tris] accumulated when non-NULL.
+int orc_trace(void *p, int bvh_mode, const RptrRenderRayQuery *q, int n, float *out4, uint64_t *counters) {
+    Scene *s = (Scene *)p;
+    if (bvh_mode == 2 && !s->has_imported) return -1;
+    const Bvh *bvh = pick_bvh(s, bvh_mode);
+    TraceCounters tc;
+    for (int i = 0; i < n; ++i) {
+        vec3 o(q[i].origin[0], q[i].origin[1], q[i].origin[2]), d(q[i].dir[0], q[i].dir[1], q[i].dir[2]);
+        if (q[i].mode_or_data < 0) continue;
+        Ray r{o, d, RPTR_RAY_EPSILON * length(o), q[i].t_max};
+        Hit h;
+        bool found = bvh ? traverse<false>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<false>(s->view, r, h);
+        if (!found) {
+            out4[4 * i + 0] = -1.0f;
+            out4[4 * i + 1] = -1.0f;
+            out4[4 * i + 2] = bits_float(0xFFFFFFFFu);
+            out4[4 * i + 3] = bits_float(0xFFFFFFFFu);
+        } else {
+            const RptrInstanceDesc &inst = s->view.desc->instances[h.inst];
+            int custom = s->view.pmesh_geom_base[inst.parameterized_mesh];
+            out4[4 * i + 0] = h.u;
+            out4[4 * i + 1] = h.v;
+            out4[4 * i + 2] = bits_float(uint32_t(custom + h.geom));
+            out4[4 * i + 3] = bits_float(uint32_t(h.prim));
+        }
+    }
+    if (counters) {
+        counters[0] += tc.nodes;
+        counters[1] += tc.tris;
+    }
+    return 0;
+}
+
+// full-interval variant for traversal tests: explicit t_min, returns t as well; any_hit!=0 -> out[0]=1/0
+int orc_trace_ex(void *p, int bvh_mode, int any_hit, const float *o3, const float *d3, const float *tmin, const float *tmax, int n,
+                 float *out_tuv, int32_t *out_ids /*inst,geom,prim*/, uint64_t *counters) {
+    Scene *s = (Scene *)p;
+    if (bvh_mode == 2 && !s->has_imported) return -1;
+    const Bvh *bvh = pick_bvh(s, bvh_mode);
+    TraceCounters tc;
+    for (int i = 0; i < n; ++i) {
+        Ray r{vec3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), vec3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmin[i], tmax[i]};
+        Hit h;
+        bool found;
+        if (any_hit)
+            found = bvh ? traverse<true>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<true>(s->view, r, h);
+        else
+            found = bvh ? traverse<false>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<false>(s->view, r, h);
+        if (any_hit) {
+            out_ids[3 * i] = found ? 1 : 0;
+            out_ids[3 * i + 1] = out_ids[3 * i + 2] = 0;
+            out_tuv[3 * i] = out_tuv[3 * i + 1] = out_tuv[3 * i + 2] = 0;
+        } else {
+            out_tuv[3 * i] = found ? h.t : -1.0f;
+            out_tuv[3 * i + 1] = h.u;
+            out_tuv[3 * i + 2] = h.v;
+            out_ids[3 * i] = h.inst;
+            out_ids[3 * i + 1] = h.geom;
+            out_ids[3 * i + 2] = h.prim;
+        }
+    }
+    if (counters) {
+        counters[0] += tc.nodes;
+        counters[1] += tc.tris;
+    }
+    return 0;
+}
+
+// Renders args->spp samples into `accum` (RGBA32F, width*height*4): sample s
+// (absolute index sample_begin+s) is folded with the running mean of
+// process_samples.comp:116-132:  hist += (new - hist) / (index + 1); index 0
+// overwrites (accumulate.glsl:68-73 + sample_base_index == 0).
+int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats) {
+    Scene *s = (Scene *)p;
+    if (a->bvh_mode == 2 && !s->has_imported) return -1;
+    Frame f;
+    f.sc = s;
+    f.bvh = pick_bvh(s, a->bvh_mode);
+    f.rp = a->params;
+    f.sp = a->scene_params;
+    f.lc = a->lighting;
+    f.count = a->count_traversal != 0;
+    compute_view(a->camera, a->width, a->height, f.vp);
+    f.vp.frame_offset = a->frame_offset;
+    for (uint32_t m = 0; m < s->view.desc->num_materials; ++m)
+        if (s->view.desc->materials[m].normal_map != -1) return -4; // textures unsupported
+    int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    std::atomic<int> next_row(a->row_begin);
+    std::vector<PathCounters> pcs(nt);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        PathCounters &pc = pcs[tid];
+        for (;;) {
+            int y = next_row.fetch_add(1);
+            if (y >= a->row_end) break;
+            for (int x = 0; x < a->width; ++x) {
+                float *px = accum + 4 * ((size_t)y * a->width + x);
+                for (int si = 0; si < a->spp; ++si) {
+                    uint32_t sample_index = uint32_t(a->sample_begin + si);
+                    vec4 c = (a->variant == RPTR_VARIANT_SIMPLE) ? main_spp<SimpleMaterial>(f, x, y, sample_index, pc)
+                                                                 : main_spp<GLTFMaterial>(f, x, y, sample_index, pc);
+                    if (sample_index == 0) {
+                        px[0] = c.x; px[1] = c.y; px[2] = c.z; px[3] = c.w;
+                    } else {
+                        float denom = float(int(sample_index) + 1);
+                        px[0] += (c.x - px[0]) / denom;
+                        px[1] += (c.y - px[1]) / denom;
+                        px[2] += (c.z - px[2]) / denom;
+                        px[3] += (c.w - px[3]) / denom;
+                    }
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        for (auto &pc : pcs) {
+            stats->rays_closest += pc.rays_closest;
+            stats->rays_shadow += pc.rays_shadow;
+            stats->hits_shaded += pc.hits;
+            stats->nodes_closest += pc.tc_closest.nodes;
+            stats->tris_closest += pc.tc_closest.tris;
+            stats->nodes_shadow += pc.tc_shadow.nodes;
+            stats->tris_shadow += pc.tc_shadow.tris;
+        }
+        stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+        stats->threads = nt;
+    }
+    return 0;
+}
+
+// process_samples.comp:143-190: exposure, sRGB, RGBA8 (alpha < 0 pixels skipped)
+int orc_resolve_u8(const float *accum, int n_pixels, float exposure, unsigned char *out) {
+    for (int i = 0; i < n_pixels; ++i) {
+        vec4 c(accum[4 * i], accum[4 * i + 1], accum[4 * i + 2], fminf(accum[4 * i + 3], 1.0f));
+        if (!(c.w >= 0.0f)) continue;
+        float e = exp2f(exposure);
+        float r = linear_to_srgb(c.x * e), g = linear_to_srgb(c.y * e), b = linear_to_srgb(c.z * e);
+        auto q = [](float v) { // imageStore to rgba8: unorm conversion, round to nearest
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            return (unsigned char)(v * 255.0f + 0.5f);
+        };
+        out[4 * i] = q(r); out[4 * i + 1] = q(g); out[4 * i + 2] = q(b); out[4 * i + 3] = q(c.w);
+    }
+    return 0;
+}
+
+// ---- function-level probes (numpy drives these for unit/property tests) ----
+void orc_rng_probe(uint32_t index, uint32_t frame, uint32_t px, uint32_t py, uint32_t dimx, uint32_t *state, float *floats, int n) {
+    LCGRand r = get_lcg_rng(index, frame, px, py, dimx);
+    *state = r.state;
+    for (int i = 0; i < n; ++i) floats[i] = lcg_randomf(r);
+}
+void orc_quantize_positions(const float *xyz, int n, const float extent[3], const float base[3], uint64_t *out) {
+    for (int i = 0; i < n; ++i)
+        out[i] = quantize_position(vec3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), vec3(extent[0], extent[1], extent[2]), vec3(base[0], base[1], base[2]));
+}
+void orc_dequantize_positions(const uint64_t *q, int n, const float scaling[3], const float offset[3], float *xyz) {
+    for (int i = 0; i < n; ++i) {
+        vec3 v = dequantize_position(q[i], vec3(scaling[0], scaling[1], scaling[2]), vec3(offset[0], offset[1], offset[2]));
+        xyz[3 * i] = v.x; xyz[3 * i + 1] = v.y; xyz[3 * i + 2] = v.z;
+    }
+}
+void orc_quantize_normal_uv(const float *nrm, const float *uv, int n, uint64_t *out) {
+    for (int i = 0; i < n; ++i) {
+        uint32_t qn = nrm ? quantize_normal(vec3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2])) : 0u;
+        uint32_t qu = uv ? quantize_uv(vec2(uv[2 * i], uv[2 * i + 1])) : 0u;
+        out[i] = uint64_t(qn) | (uint64_t(qu) << 32);
+    }
+}
+void orc_dequantize_normal_uv(const uint64_t *q, int n, float *nrm, float *uv) {
+    for (int i = 0; i < n; ++i) {
+        vec3 v = dequantize_normal(uint32_t(q[i]));
+        vec2 u = dequantize_uv(uint32_t(q[i] >> 32));
+        nrm[3 * i] = v.x; nrm[3 * i + 1] = v.y; nrm[3 * i + 2] = v.z;
+        uv[2 * i] = u.x; uv[2 * i + 1] = u.y;
+    }
+}
+// sample_gltf_brdf / gltf_bsdf / gltf_wpdf for n (n, w_o, u_dir, u_lobe) tuples with one material
+void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *u4, int n, float *wi3, float *weight3,
+                     float *pdf, float *mis_pdf, float *f3, float *wpdf) {
+    GLTFMaterial mat;
+    vec3 emit;
+    unpack_material(mat, emit, *m);
+    for (int i = 0; i < n; ++i) {
+        vec3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
+        vec3 vx, vy;
+        ortho_basis(vx, vy, nn);
+        vec3 wi(0, 0, 0);
+        float p = 0, mp = 0;
+        vec3 w = sample_gltf_brdf(mat, nn, wo, wi, p, mp, vec2(u4[4 * i], u4[4 * i + 1]), vec2(u4[4 * i + 2], u4[4 * i + 3]), vx, vy);
+        wi3[3 * i] = wi.x; wi3[3 * i + 1] = wi.y; wi3[3 * i + 2] = wi.z;
+        weight3[3 * i] = w.x; weight3[3 * i + 1] = w.y; weight3[3 * i + 2] = w.z;
+        pdf[i] = p;
+        mis_pdf[i] = mp;
+        vec3 fv = (p > 0) ? gltf_bsdf(mat, nn, wo, wi) : vec3(0.0f);
+        f3[3 * i] = fv.x; f3[3 * i + 1] = fv.y; f3[3 * i + 2] = fv.z;
+        wpdf[i] = (p > 0) ? gltf_wpdf(mat, nn, wo, wi) : 0.0f;
+    }
+}
+// evaluate gltf_bsdf and gltf_wpdf for explicit directions
+void orc_gltf_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
+    GLTFMaterial mat;
+    vec3 emit;
+    unpack_material(mat, emit, *m);
+    for (int i = 0; i < n; ++i) {
+        vec3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+        vec3 fv = gltf_bsdf(mat, nn, wo, wi);
+        f3[3 * i] = fv.x; f3[3 * i + 1] = fv.y; f3[3 * i + 2] = fv.z;
+        wpdf[i] = gltf_wpdf(mat, nn, wo, wi);
+    }
+}
+void orc_sky_radiance(const RptrSkyModelParams *sky, const float sun_dir[3], const float *dirs3, int n, float *out3) {
+    for (int i = 0; i < n; ++i) {
+        vec3 r = skymodel_radiance(*sky, vec3(sun_dir[0], sun_dir[1], sun_dir[2]), vec3(dirs3[3 * i], dirs3[3 * i + 1], dirs3[3 * i + 2]));
+        out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+    }
+}
+void orc_sample_sun(const float sun_dir[3], float cos_radius, const float *u2, int n, float *dirs3, float *pdf) {
+    for (int i = 0; i < n; ++i) {
+        vec3 d = sample_sun_dir(vec3(sun_dir[0], sun_dir[1], sun_dir[2]), cos_radius, vec2(u2[2 * i], u2[2 * i + 1]));
+        dirs3[3 * i] = d.x; dirs3[3 * i + 1] = d.y; dirs3[3 * i + 2] = d.z;
+    }
+    *pdf = sample_sun_dir_pdf(cos_radius);
+}
+// sample_tri_lights for n shading points (bin_size from cfg)
+void orc_sample_tri_lights(void *p, const RptrLightSamplingConfig *cfg, const float *p3, const float *n3, const float *u4, int n,
+                           float *radiance_over_pdf3, float *dir3, float *dist, float *pdf, float *mis_wpdf) {
+    Scene *s = (Scene *)p;
+    Frame f;
+    f.sc = s;
+    f.lc = *cfg;
+    for (int i = 0; i < n; ++i) {
+        vec3 ld;
+        float d = 0, pd = 0, mw = 0;
+        vec3 L = sample_tri_lights(f, vec3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]), vec3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]),
+                                   vec2(u4[4 * i], u4[4 * i + 1]), vec2(u4[4 * i + 2], u4[4 * i + 3]), ld, d, pd, mw);
+        radiance_over_pdf3[3 * i] = L.x; radiance_over_pdf3[3 * i + 1] = L.y; radiance_over_pdf3[3 * i + 2] = L.z;
+        dir3[3 * i] = ld.x; dir3[3 * i + 1] = ld.y; dir3[3 * i + 2] = ld.z;
+        dist[i] = d; pdf[i] = pd; mis_wpdf[i] = mw;
+    }
+}
+void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,dv,top_left*/) {
+    ViewParams vp;
+    compute_view(*c, W, H, vp);
+    const vec3 *v[4] = {&vp.cam_pos, &vp.cam_du, &vp.cam_dv, &vp.cam_dir_top_left};
+    for (int i = 0; i < 4; ++i) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
+}
+int orc_hw_threads(void) { return (int)std::thread::hardware_concurrency(); }
+
+} // extern "C"

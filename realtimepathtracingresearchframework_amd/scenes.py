@@ -1,0 +1,491 @@
+"""Procedural scenes for the configurations of BASELINE.json and the
+host-side scene container that mirrors the reference's `Scene` closely enough
+to drive `set_scene` (librender/scene.h:48-108, mesh.h:10-116).
+
+Vertex streams are produced exactly in the reference's storage format:
+unrolled (3 vertices per triangle, no index buffer), positions quantised to
+21 bit/axis in a u64, normals oct-encoded 16+16 bit, uvs 16+16 bit
+(librender/quantize.h:7-42, restated here in float32 numpy arithmetic).
+"""
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import abi
+from . import lights as L
+
+f32 = np.float32
+
+
+# ------------------------------------------------------------------ quantisation (librender/quantize.h)
+def quantize_positions(p, extent, base):
+    """quantize.h:7-11 for an (n,3) float32 array -> (n,) uint64."""
+    p = np.asarray(p, dtype=f32)
+    extent = np.asarray(extent, dtype=f32)
+    base = np.asarray(base, dtype=f32)
+    q = ((p - base).astype(f32) * f32(0x200000)).astype(f32) / extent
+    q = q.astype(f32)
+    u = np.minimum(q.astype(np.uint32), np.uint32(0x1FFFFF)).astype(np.uint64)
+    return u[:, 0] | (u[:, 1] << np.uint64(21)) | (u[:, 2] << np.uint64(42))
+
+
+def dequantization_scaling(extent):  # quantize.h:13-15
+    return (np.asarray(extent, dtype=f32) / f32(0x200000)).astype(f32)
+
+
+def dequantization_offset(base, extent):  # quantize.h:16-18
+    return (np.asarray(base, dtype=f32) + (np.asarray(extent, dtype=f32) * f32(0.5)).astype(f32) / f32(0x200000)).astype(f32)
+
+
+def dequantize_positions(q, scaling, offset):
+    """librender/dequantize.glsl:8-21."""
+    q = np.asarray(q, dtype=np.uint64)
+    m = np.uint64(0x1FFFFF)
+    x = (q & m).astype(f32)
+    y = ((q >> np.uint64(21)) & m).astype(f32)
+    z = ((q >> np.uint64(42)) & m).astype(f32)
+    v = np.stack([x, y, z], axis=1)
+    return (v * np.asarray(scaling, dtype=f32) + np.asarray(offset, dtype=f32)).astype(f32)
+
+
+def quantize_normals(n):
+    """quantize.h:21-35 -> (n,) uint32."""
+    n = np.asarray(n, dtype=f32)
+    nl1 = (np.abs(n[:, 0]) + np.abs(n[:, 1])).astype(f32) + np.abs(n[:, 2])
+    pn = (n[:, :2] / nl1[:, None]).astype(f32)
+    fold = n[:, 2] <= 0
+    sx = np.where(pn[:, 0] >= 0, f32(1), f32(-1))
+    sy = np.where(pn[:, 1] >= 0, f32(1), f32(-1))
+    fx = ((f32(1) - np.abs(pn[:, 1])).astype(f32) * sx).astype(f32)
+    fy = ((f32(1) - np.abs(pn[:, 0])).astype(f32) * sy).astype(f32)
+    px = np.where(fold, fx, pn[:, 0]).astype(f32) * f32(0x8000)
+    py = np.where(fold, fy, pn[:, 1]).astype(f32) * f32(0x8000)
+    ix = np.clip(px.astype(np.int32), -0x7FFF, 0x7FFF)
+    iy = np.clip(py.astype(np.int32), -0x7FFF, 0x7FFF)
+    ux = (0x8000 + ix).astype(np.uint32)
+    uy = (0x8000 + iy).astype(np.uint32)
+    return ux | (uy << np.uint32(16))
+
+
+def quantize_uvs(uv):
+    """quantize.h:38-42 with safety_offset = 0 -> (n,) uint32."""
+    uv = np.asarray(uv, dtype=f32)
+    k = f32(f32(0xFFFF) / f32(8.0))
+    sx = (uv[:, 0] * k).astype(f32)
+    sy = ((f32(1.0) - uv[:, 1]).astype(f32) * k).astype(f32)
+    ux = (f32(0.5) + sx).astype(f32).astype(np.int64).astype(np.uint32) & np.uint32(0xFFFF)
+    uy = (f32(0.5) + sy).astype(f32).astype(np.int64).astype(np.uint32) & np.uint32(0xFFFF)
+    return ux | (uy << np.uint32(16))
+
+
+# ------------------------------------------------------------------ scene container
+@dataclass
+class Geometry:
+    qpos: np.ndarray                     # (3*num_tris,) uint64
+    qnrm_uv: Optional[np.ndarray]        # (3*num_tris,) uint64 or None
+    num_tris: int
+    has_normals: bool
+    has_uvs: bool
+    scaling: np.ndarray
+    offset: np.ndarray
+
+
+@dataclass
+class Mesh:
+    first_geometry: int
+    num_geometries: int
+    dynamic: bool = False
+
+
+@dataclass
+class ParameterizedMesh:
+    mesh: int
+    material_offsets: np.ndarray                 # int32 per geometry
+    tri_material_ids: Optional[np.ndarray] = None  # uint8 over all triangles of the mesh
+
+
+@dataclass
+class Instance:
+    transform: np.ndarray  # (3,4) float32 object->world
+    pmesh: int
+
+
+@dataclass
+class SceneConfig:  # librender/render_params.glsl.h:157-162
+    bump_scale: float = 1.0
+    sun_dir: tuple = (0.0, 1.0, 0.0)
+    turbidity: float = 3.0
+    albedo: tuple = (0.2, 0.2, 0.2)
+
+
+@dataclass
+class Scene:
+    name: str
+    geometries: List[Geometry] = field(default_factory=list)
+    meshes: List[Mesh] = field(default_factory=list)
+    pmeshes: List[ParameterizedMesh] = field(default_factory=list)
+    instances: List[Instance] = field(default_factory=list)
+    materials: List[abi.BaseMaterial] = field(default_factory=list)
+    lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 4, 3), dtype=f32))  # binned TriLightData
+    camera: dict = field(default_factory=dict)
+    config: SceneConfig = field(default_factory=SceneConfig)
+    sky_key: str = ""
+    _keep: list = field(default_factory=list, repr=False)
+
+    def num_tris(self):
+        return sum(g.num_tris for g in self.geometries)
+
+    def num_instanced_tris(self):
+        n = 0
+        for inst in self.instances:
+            m = self.meshes[self.pmeshes[inst.pmesh].mesh]
+            n += sum(self.geometries[m.first_geometry + j].num_tris for j in range(m.num_geometries))
+        return n
+
+    def prepare_lights(self, lighting: abi.LightSamplingConfig = None):
+        """≙ RenderBinnedLightsVulkan::update_scene_from_backend (render_binned_lights.cpp:68-87)."""
+        lighting = lighting or abi.LightSamplingConfig.default()
+        em = L.collect_emitters(self)
+        em, _ = L.update_light_sampling(em, lighting.min_perceived_receiver_dist, lighting.min_radiance, lighting.bin_size)
+        self.lights = em
+        return self
+
+    def desc(self) -> abi.SceneDesc:
+        """Builds the flat RptrSceneDesc; arrays stay alive as long as self does."""
+        keep = []
+        G = (abi.GeometryDesc * max(1, len(self.geometries)))()
+        for i, g in enumerate(self.geometries):
+            qpos = np.ascontiguousarray(g.qpos, dtype=np.uint64)
+            keep.append(qpos)
+            G[i].qpos = qpos.ctypes.data
+            if g.qnrm_uv is not None:
+                qn = np.ascontiguousarray(g.qnrm_uv, dtype=np.uint64)
+                keep.append(qn)
+                G[i].qnrm_uv = qn.ctypes.data
+            else:
+                G[i].qnrm_uv = None
+            G[i].num_tris = g.num_tris
+            G[i].has_normals = 1 if g.has_normals else 0
+            G[i].has_uvs = 1 if g.has_uvs else 0
+            G[i].quantized_scaling[:] = [float(x) for x in g.scaling]
+            G[i].quantized_offset[:] = [float(x) for x in g.offset]
+        M = (abi.MeshDesc * max(1, len(self.meshes)))()
+        for i, m in enumerate(self.meshes):
+            M[i].first_geometry, M[i].num_geometries, M[i].dynamic = m.first_geometry, m.num_geometries, 1 if m.dynamic else 0
+        P = (abi.ParameterizedMeshDesc * max(1, len(self.pmeshes)))()
+        for i, p in enumerate(self.pmeshes):
+            mo = np.ascontiguousarray(p.material_offsets, dtype=np.int32)
+            keep.append(mo)
+            P[i].mesh = p.mesh
+            P[i].material_offsets = mo.ctypes.data
+            if p.tri_material_ids is not None:
+                ti = np.ascontiguousarray(p.tri_material_ids, dtype=np.uint8)
+                keep.append(ti)
+                P[i].tri_material_ids = ti.ctypes.data
+            else:
+                P[i].tri_material_ids = None
+        I = (abi.InstanceDesc * max(1, len(self.instances)))()
+        for i, inst in enumerate(self.instances):
+            I[i].transform[:] = [float(x) for x in np.asarray(inst.transform, dtype=f32).reshape(-1)]
+            I[i].parameterized_mesh = inst.pmesh
+        MAT = (abi.BaseMaterial * max(1, len(self.materials)))(*self.materials)
+        nl = len(self.lights)
+        LT = (abi.TriLightData * max(1, nl))()
+        if nl:
+            C.memmove(LT, np.ascontiguousarray(self.lights, dtype=f32).ctypes.data, nl * 48)
+        d = abi.SceneDesc()
+        d.geometries, d.num_geometries = G, len(self.geometries)
+        d.meshes, d.num_meshes = M, len(self.meshes)
+        d.parameterized_meshes, d.num_parameterized_meshes = P, len(self.pmeshes)
+        d.instances, d.num_instances = I, len(self.instances)
+        d.materials, d.num_materials = MAT, len(self.materials)
+        d.lights, d.num_lights = LT, nl
+        keep += [G, M, P, I, MAT, LT]
+        self._keep = keep
+        return d
+
+    def camera_params(self) -> abi.Camera:
+        """eye/center/up/fov -> RenderCameraParams like the app does (pos, dir = normalize(center-eye), up)."""
+        eye = np.asarray(self.camera["eye"], dtype=f32)
+        center = np.asarray(self.camera["center"], dtype=f32)
+        up = np.asarray(self.camera["up"], dtype=f32)
+        d = (center - eye).astype(f32)
+        d = (d * f32(f32(1.0) / np.sqrt(f32(np.dot(d, d))))).astype(f32)
+        cam = abi.Camera()
+        cam.pos[:] = [float(x) for x in eye]
+        cam.dir[:] = [float(x) for x in d]
+        cam.up[:] = [float(x) for x in up]
+        cam.fovy = float(self.camera["fov"])
+        return cam
+
+    def scene_params(self) -> abi.SceneParams:
+        """≙ update_config + update_sky_light (render_vulkan.cpp:2954-2959, render_sky.cpp:25-72).
+
+        The Hosek-Wilkie fit needs the reference's data tables; the fitted
+        SkyModelParams/sun radiance for the synthetic configs are golden vectors
+        generated from the reference's own sky_model.cpp (tests/golden/sky_params.json,
+        script tests/golden/gen_sky_fixture.py)."""
+        sky = load_sky_fixture(self.sky_key, has_lights=len(self.lights) > 0)
+        sp = abi.SceneParams()
+        for i in range(9):
+            sp.sky_params.configs[i][:] = sky["configs"][i]
+        sp.sky_params.radiances[:] = sky["radiances"]
+        sp.sun_dir[:] = sky["sun_dir"]
+        sp.sun_cos_angle = sky["sun_cos_angle"]
+        sp.sun_radiance[:] = sky["sun_radiance"]
+        sp.normal_z_scale = 1.0 / self.config.bump_scale
+        return sp
+
+
+_SKY_CACHE = None
+
+
+def sky_fixture_path():
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sky_params.json")
+
+
+def load_sky_fixture(key, has_lights):
+    global _SKY_CACHE
+    if _SKY_CACHE is None:
+        with open(sky_fixture_path()) as f:
+            _SKY_CACHE = json.load(f)
+    e = _SKY_CACHE["entries"][key]
+    out = dict(e)
+    # render_sky.cpp:67-70: .w = 0.5 with triangle lights, 1.0 without
+    out["sun_radiance"] = list(e["sun_radiance_lights" if has_lights else "sun_radiance_nolights"])
+    return out
+
+
+# sky configurations used by the synthetic scenes (sun_dir, turbidity, albedo)
+SKY_CONFIGS = {
+    "default": dict(sun_dir=(0.0, 1.0, 0.0), turbidity=3.0, albedo=(0.2, 0.2, 0.2)),
+    "grid": dict(sun_dir=(0.3, 0.8, 0.5), turbidity=3.0, albedo=(0.2, 0.2, 0.2)),
+    "low_sun": dict(sun_dir=(0.8, 0.25, 0.3), turbidity=5.0, albedo=(0.3, 0.3, 0.3)),
+    "forest": dict(sun_dir=(-0.4, 0.7, 0.3), turbidity=2.5, albedo=(0.15, 0.2, 0.1)),
+    "night": dict(sun_dir=(0.2, -0.3, 0.9), turbidity=3.0, albedo=(0.2, 0.2, 0.2)),
+}
+
+
+def _add_mesh(scene: Scene, tris_xyz, normals=None, uvs=None, dynamic=False):
+    """tris_xyz: (n,3,3) float32 world/object positions -> one mesh with one geometry."""
+    tris_xyz = np.asarray(tris_xyz, dtype=f32)
+    flat = tris_xyz.reshape(-1, 3)
+    lo = flat.min(axis=0).astype(f32)
+    hi = flat.max(axis=0).astype(f32)
+    extent = (hi - lo).astype(f32)
+    extent = np.where(extent > 0, extent, f32(1e-3)).astype(f32)  # flat meshes: avoid 0 extent
+    qpos = quantize_positions(flat, extent, lo)
+    qnu = None
+    if normals is not None or uvs is not None:
+        qn = quantize_normals(np.asarray(normals, dtype=f32).reshape(-1, 3)) if normals is not None else np.zeros(len(flat), np.uint32)
+        qu = quantize_uvs(np.asarray(uvs, dtype=f32).reshape(-1, 2)) if uvs is not None else np.zeros(len(flat), np.uint32)
+        qnu = qn.astype(np.uint64) | (qu.astype(np.uint64) << np.uint64(32))
+    g = Geometry(qpos=qpos, qnrm_uv=qnu, num_tris=len(tris_xyz), has_normals=normals is not None, has_uvs=uvs is not None,
+                 scaling=dequantization_scaling(extent), offset=dequantization_offset(lo, extent))
+    scene.geometries.append(g)
+    scene.meshes.append(Mesh(first_geometry=len(scene.geometries) - 1, num_geometries=1, dynamic=dynamic))
+    return len(scene.meshes) - 1
+
+
+IDENTITY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], dtype=f32)
+
+
+def _quad(a, b, c, d):
+    """two triangles (a,b,c), (a,c,d)"""
+    return [[a, b, c], [a, c, d]]
+
+
+# ------------------------------------------------------------------ C1: Cornell box, 32 triangles
+def cornell32() -> Scene:
+    """unit box [-1,1]^3: 5 walls (10 tris) + short & tall box without
+    bottoms (2x10) + ceiling light quad (2) = 32 triangles; emission 15."""
+    s = Scene(name="cornell32")
+    T = []
+    mats = []
+    W, R, Gm, Lm = 0, 1, 2, 3
+    # floor (y=-1), ceiling (y=1), back (z=-1): white; left (x=-1): red; right (x=1): green. Normals face inward.
+    T += _quad((-1, -1, -1), (-1, -1, 1), (1, -1, 1), (1, -1, -1)); mats += [W, W]
+    T += _quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)); mats += [W, W]
+    T += _quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)); mats += [W, W]
+    T += _quad((-1, -1, -1), (-1, 1, -1), (-1, 1, 1), (-1, -1, 1)); mats += [R, R]
+    T += _quad((1, -1, -1), (1, -1, 1), (1, 1, 1), (1, 1, -1)); mats += [Gm, Gm]
+
+    def box(cx, cz, half, h, angle):
+        ca, sa = np.cos(angle), np.sin(angle)
+        base = []
+        for dx, dz in ((-1, -1), (1, -1), (1, 1), (-1, 1)):
+            x, z = dx * half, dz * half
+            base.append((cx + ca * x - sa * z, cz + sa * x + ca * z))
+        y0, y1 = -1.0, -1.0 + h
+        out = []
+        for k in range(4):
+            (x0, z0), (x1, z1) = base[k], base[(k + 1) % 4]
+            out += _quad((x1, y0, z1), (x0, y0, z0), (x0, y1, z0), (x1, y1, z1))
+        out += _quad((base[0][0], y1, base[0][1]), (base[3][0], y1, base[3][1]), (base[2][0], y1, base[2][1]), (base[1][0], y1, base[1][1]))
+        return out
+    T += box(0.35, 0.3, 0.3, 0.6, 0.3); mats += [W] * 10
+    T += box(-0.35, -0.3, 0.3, 1.2, -0.3); mats += [W] * 10
+    T += _quad((-0.25, 0.995, -0.25), (0.25, 0.995, -0.25), (0.25, 0.995, 0.25), (-0.25, 0.995, 0.25)); mats += [Lm, Lm]
+    assert len(T) == 32
+    mesh = _add_mesh(s, np.array(T, dtype=f32))
+    s.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=np.array(mats, np.uint8)))
+    s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=0))
+    s.materials = [
+        abi.make_material((0.73, 0.73, 0.73)),
+        abi.make_material((0.65, 0.05, 0.05)),
+        abi.make_material((0.12, 0.45, 0.15)),
+        abi.make_material((1.0, 1.0, 1.0), emission_intensity=15.0),
+    ]
+    s.camera = dict(eye=(0, 0, 3.4), center=(0, 0, 0), up=(0, 1, 0), fov=40.0)
+    s.config = SceneConfig(**{k: v for k, v in SKY_CONFIGS["default"].items()})
+    s.sky_key = "default"
+    s.prepare_lights()
+    return s
+
+
+# ------------------------------------------------------------------ value-noise fbm (scene definition, deterministic)
+def _hash2(ix, iz, seed):
+    h = (ix.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ (iz.astype(np.uint32) * np.uint32(0x85EBCA77)) ^ np.uint32(seed)
+    h ^= h >> np.uint32(16)
+    h = h * np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h = h * np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return (h >> np.uint32(8)).astype(np.float64) / float(1 << 24)
+
+
+def fbm(x, z, seed=1234, octaves=4):
+    """4 octaves of hashed value noise, base cell 10 units, in float64 (scene definition only)."""
+    total = np.zeros_like(x, dtype=np.float64)
+    amp, freq = 1.0, 0.1
+    for o in range(octaves):
+        fx, fz = x * freq, z * freq
+        ix, iz = np.floor(fx), np.floor(fz)
+        tx, tz = fx - ix, fz - iz
+        sx, sz = tx * tx * (3 - 2 * tx), tz * tz * (3 - 2 * tz)
+        ix, iz = ix.astype(np.int64), iz.astype(np.int64)
+        a = _hash2(ix, iz, seed + o)
+        b = _hash2(ix + 1, iz, seed + o)
+        c = _hash2(ix, iz + 1, seed + o)
+        d = _hash2(ix + 1, iz + 1, seed + o)
+        total += amp * ((a * (1 - sx) + b * sx) * (1 - sz) + (c * (1 - sx) + d * sx) * sz - 0.5)
+        amp *= 0.5
+        freq *= 2.0
+    return total
+
+
+def _heightfield(nx, nz, x0, x1, z0, z1, height_fn):
+    """(nx x nz) quads -> (2*nx*nz, 3, 3) tris, per-vertex normals and uvs (unrolled)."""
+    xs = np.linspace(x0, x1, nx + 1)
+    zs = np.linspace(z0, z1, nz + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = height_fn(X, Z)
+    # normals from central differences of the analytic height function
+    e = 1e-3 * max(x1 - x0, z1 - z0) / max(nx, nz) * 10
+    dYdx = (height_fn(X + e, Z) - height_fn(X - e, Z)) / (2 * e)
+    dYdz = (height_fn(X, Z + e) - height_fn(X, Z - e)) / (2 * e)
+    N = np.stack([-dYdx, np.ones_like(dYdx), -dYdz], axis=-1)
+    N /= np.linalg.norm(N, axis=-1, keepdims=True)
+    P = np.stack([X, Y, Z], axis=-1)
+    UV = np.stack([(X - x0) / (x1 - x0) * 7.5, (Z - z0) / (z1 - z0) * 7.5], axis=-1)
+
+    def tri_attr(A):
+        a00, a10, a01, a11 = A[:-1, :-1], A[1:, :-1], A[:-1, 1:], A[1:, 1:]
+        t0 = np.stack([a00, a01, a11], axis=2)  # CCW seen from +y
+        t1 = np.stack([a00, a11, a10], axis=2)
+        return np.stack([t0, t1], axis=2).reshape(-1, 3, A.shape[-1])
+    return tri_attr(P).astype(f32), tri_attr(N).astype(f32), tri_attr(UV).astype(f32)
+
+
+GRID_MATERIALS = [
+    # (base_color, roughness, metallic) for the 8 slots of C2/C3
+    ((0.70, 0.65, 0.55), 0.9, 0.0), ((0.35, 0.55, 0.25), 0.7, 0.0), ((0.55, 0.45, 0.35), 0.5, 0.0), ((0.80, 0.80, 0.82), 0.3, 1.0),
+    ((0.25, 0.35, 0.60), 0.1, 0.0), ((0.90, 0.75, 0.30), 0.2, 1.0), ((0.60, 0.30, 0.25), 0.6, 0.0), ((0.85, 0.85, 0.85), 0.4, 0.0),
+]
+
+
+def grid(nx=1000, nz=500, with_emitters=False, name=None, deform_t=None) -> Scene:
+    """nx x nz quad height field (2*nx*nz triangles) over
+    [-50,50]x[-25,25], y = 2*fbm(x,z; seed 1234, 4 octaves), 8 material slots by
+    hashed 32x32-quad patches. with_emitters adds 256 emissive quads (C3).
+    deform_t (C5): y += 0.5*sin(0.4*x + 2*pi*t)."""
+    s = Scene(name=name or ("grid%dx%d" % (nx, nz)))
+
+    def h(X, Z):
+        y = 2.0 * fbm(X, Z)
+        if deform_t is not None:
+            y = y + 0.5 * np.sin(0.4 * X + 2 * np.pi * deform_t)
+        return y
+    P, N, UV = _heightfield(nx, nz, -50.0, 50.0, -25.0, 25.0, h)
+    mesh = _add_mesh(s, P, N, UV, dynamic=deform_t is not None)
+    qi, qj = np.meshgrid(np.arange(nx), np.arange(nz), indexing="ij")
+    slot = (_hash2(qi // 32, qj // 32, 77) * 8).astype(np.int64) % 8
+    tri_mat = np.repeat(slot.reshape(-1), 2).astype(np.uint8)
+    s.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=tri_mat))
+    s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=0))
+    s.materials = [abi.make_material(c, roughness=r, metallic=m) for (c, r, m) in GRID_MATERIALS]
+    if with_emitters:
+        T = []
+        for i in range(16):
+            for j in range(16):
+                cx = -45.0 + 90.0 * (i + 0.5) / 16
+                cz = -22.0 + 44.0 * (j + 0.5) / 16
+                hs = 0.4
+                # facing down (-y): emitters radiate from their front side
+                T += _quad((cx - hs, 6.0, cz - hs), (cx + hs, 6.0, cz - hs), (cx + hs, 6.0, cz + hs), (cx - hs, 6.0, cz + hs))
+        em = _add_mesh(s, np.array(T, dtype=f32))
+        s.materials.append(abi.make_material((1.0, 0.9, 0.7), emission_intensity=20.0))
+        s.pmeshes.append(ParameterizedMesh(mesh=em, material_offsets=np.array([len(s.materials) - 1], np.int32)))
+        s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=1))
+    s.camera = dict(eye=(0, 12, 40), center=(0, 0, 0), up=(0, 1, 0), fov=65.0)
+    s.config = SceneConfig(**SKY_CONFIGS["grid"])
+    s.sky_key = "grid"
+    s.prepare_lights()
+    return s
+
+
+def grid_1m():
+    """BASELINE.json configs[1]: procedural 1M-triangle mesh."""
+    return grid(1000, 500, name="grid-1M")
+
+
+def grid_1m_lights():
+    """BASELINE.json configs[2]: same mesh + 512 emissive triangles."""
+    return grid(1000, 500, with_emitters=True, name="grid-1M-lights")
+
+
+# ------------------------------------------------------------------ small test scenes
+def two_level_test(n_inst=12, seed=5) -> Scene:
+    """A few small meshes instanced with random rigid transforms + uniform scale (two-level BVH test)."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name="two_level_test")
+    # mesh 0: bumpy patch with normals/uvs; mesh 1: tetra-ish blob without normals
+    P, N, UV = _heightfield(12, 12, -1.0, 1.0, -1.0, 1.0, lambda X, Z: 0.3 * np.sin(3 * X) * np.cos(2 * Z))
+    m0 = _add_mesh(s, P, N, UV)
+    pts = rng.normal(size=(40, 3, 3)).astype(f32) * 0.6
+    m1 = _add_mesh(s, pts)
+    s.materials = [abi.make_material((0.8, 0.3, 0.3), roughness=0.5), abi.make_material((0.3, 0.8, 0.3), roughness=0.2, metallic=1.0),
+                   abi.make_material((0.3, 0.3, 0.8), roughness=0.8), abi.make_material((1, 1, 1), emission_intensity=8.0)]
+    s.pmeshes.append(ParameterizedMesh(mesh=m0, material_offsets=np.array([0], np.int32),
+                                       tri_material_ids=(np.arange(288) % 3).astype(np.uint8)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m1, material_offsets=np.array([2], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m1, material_offsets=np.array([3], np.int32)))
+    for i in range(n_inst):
+        ang = rng.uniform(0, 2 * np.pi)
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        sc = rng.uniform(0.6, 1.6)
+        t = rng.uniform(-4, 4, size=3)
+        M = np.concatenate([Rm * sc, t[:, None]], axis=1).astype(f32)
+        s.instances.append(Instance(transform=M, pmesh=int(i % 3)))
+    s.camera = dict(eye=(0, 2, 12), center=(0, 0, 0), up=(0, 1, 0), fov=50.0)
+    s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s

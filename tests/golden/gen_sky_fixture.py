@@ -1,0 +1,48 @@
+"""Generates tests/golden/sky_params.json from the reference's own Hosek-Wilkie
+fit (rendering/lights/sky_model_arhosek/sky_model.cpp compiled unmodified into
+oracle/_ref/libsky_ref.so; driver oracle/ref_sky_driver.cpp restates
+vulkan/render_sky.cpp:25-72). Run in the build container only:
+
+    make -C oracle ref && python tests/golden/gen_sky_fixture.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from realtimepathtracingresearchframework_amd.scenes import SKY_CONFIGS  # noqa: E402
+
+
+class RefSkyOut(C.Structure):
+    _fields_ = [("configs", (C.c_float * 4) * 9), ("radiances", C.c_float * 4), ("sun_dir", C.c_float * 3),
+                ("sun_cos_angle", C.c_float), ("sun_radiance", C.c_float * 4)]
+
+
+def main():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsky_ref.so"))
+    lib.ref_update_sky_light.argtypes = [C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_int, C.POINTER(RefSkyOut)]
+    entries = {}
+    for key, cfg in SKY_CONFIGS.items():
+        e = {"input": cfg}
+        for tag, lc in (("nolights", 0), ("lights", 1)):
+            out = RefSkyOut()
+            sd = (C.c_float * 3)(*cfg["sun_dir"])
+            al = (C.c_float * 3)(*cfg["albedo"])
+            lib.ref_update_sky_light(sd, cfg["turbidity"], al, lc, C.byref(out))
+            e["configs"] = [[float(out.configs[i][j]) for j in range(4)] for i in range(9)]
+            e["radiances"] = [float(x) for x in out.radiances]
+            e["sun_dir"] = [float(x) for x in out.sun_dir]
+            e["sun_cos_angle"] = float(out.sun_cos_angle)
+            e["sun_radiance_" + tag] = [float(x) for x in out.sun_radiance]
+        entries[key] = e
+    doc = {"generator": "tests/golden/gen_sky_fixture.py", "source": "oracle/_ref/libsky_ref.so <- reference sky_model.cpp + render_sky.cpp:25-72",
+           "entries": entries}
+    with open(os.path.join(ROOT, "tests", "golden", "sky_params.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+    print("wrote", len(entries), "entries")
+
+
+if __name__ == "__main__":
+    main()

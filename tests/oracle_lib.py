@@ -1,0 +1,153 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE: imported only from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from realtimepathtracingresearchframework_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class OrcRenderArgs(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+        ("variant", C.c_int32), ("sample_begin", C.c_int32), ("spp", C.c_int32), ("frame_offset", C.c_uint32),
+        ("bvh_mode", C.c_int32), ("n_threads", C.c_int32), ("count_traversal", C.c_int32), ("_pad", C.c_int32),
+        ("camera", abi.Camera), ("params", abi.RenderParams), ("scene_params", abi.SceneParams), ("lighting", abi.LightSamplingConfig),
+    ]
+
+
+class OrcRenderStats(C.Structure):
+    _fields_ = [
+        ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("hits_shaded", C.c_uint64),
+        ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64), ("nodes_shadow", C.c_uint64), ("tris_shadow", C.c_uint64),
+        ("seconds", C.c_double), ("threads", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
+BVH_OWN, BVH_BRUTE, BVH_IMPORTED = 0, 1, 2
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_scene_create.restype = C.c_void_p
+        L.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_build_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orc_scene_import_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_trace_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats)]
+        L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
+        L.orc_hw_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleScene:
+    """Owns an oracle scene handle for a realtimepathtracingresearchframework_amd.scenes.Scene."""
+
+    def __init__(self, scene):
+        self.scene = scene
+        self._desc = scene.desc()
+        self.h = lib().orc_scene_create(C.byref(self._desc))
+
+    def close(self):
+        if self.h:
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_bvh(self):
+        c = (C.c_uint64 * 3)()
+        lib().orc_scene_build_bvh(self.h, c)
+        return tuple(int(x) for x in c)
+
+    def import_bvh(self, nodes, tris, insts):
+        self._bvh_keep = (nodes, tris, insts)
+        return lib().orc_scene_import_bvh(self.h, _p(nodes), nodes.size * nodes.itemsize // 64, _p(tris), tris.size * tris.itemsize // 48,
+                                          _p(insts), insts.size * insts.itemsize // 128)
+
+    def trace(self, queries, bvh_mode=BVH_OWN, count=False):
+        """queries: structured array/bytes of RenderRayQuery (n,8) float32 view. Returns (n,4) float32 [, (nodes,tris)]."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((len(q), 4), dtype=np.float32)
+        cnt = np.zeros(2, dtype=np.uint64)
+        rc = lib().orc_trace(self.h, bvh_mode, _p(q), len(q), _p(out), _p(cnt) if count else None)
+        assert rc == 0
+        return (out, (int(cnt[0]), int(cnt[1]))) if count else out
+
+    def trace_ex(self, o, d, tmin, tmax, any_hit=False, bvh_mode=BVH_OWN, count=False):
+        o = np.ascontiguousarray(o, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        n = len(o)
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float32), (n,)))
+        tuv = np.zeros((n, 3), dtype=np.float32)
+        ids = np.zeros((n, 3), dtype=np.int32)
+        cnt = np.zeros(2, dtype=np.uint64)
+        rc = lib().orc_trace_ex(self.h, bvh_mode, 1 if any_hit else 0, _p(o), _p(d), _p(tmin), _p(tmax), n, _p(tuv), _p(ids),
+                                _p(cnt) if count else None)
+        assert rc == 0
+        return (tuv, ids, (int(cnt[0]), int(cnt[1]))) if count else (tuv, ids)
+
+    def render(self, width, height, spp, variant=abi.VARIANT_GLTF, params=None, lighting=None, rows=None, sample_begin=0,
+               frame_offset=0, bvh_mode=BVH_OWN, threads=0, count=False, accum=None, camera=None, scene_params=None):
+        a = OrcRenderArgs()
+        a.width, a.height = width, height
+        a.row_begin, a.row_end = rows if rows else (0, height)
+        a.variant = variant
+        a.sample_begin, a.spp, a.frame_offset = sample_begin, spp, frame_offset
+        a.bvh_mode, a.n_threads, a.count_traversal = bvh_mode, threads, 1 if count else 0
+        a.camera = camera or self.scene.camera_params()
+        a.params = params or abi.RenderParams.default()
+        a.scene_params = scene_params or self.scene.scene_params()
+        a.lighting = lighting or abi.LightSamplingConfig.default()
+        if accum is None:
+            accum = np.zeros((height, width, 4), dtype=np.float32)
+        st = OrcRenderStats()
+        rc = lib().orc_render(self.h, C.byref(a), _p(accum), C.byref(st))
+        assert rc == 0, "orc_render failed: %d" % rc
+        return accum, st
+
+
+def resolve_u8(accum, exposure=0.0):
+    out = np.zeros(accum.shape[:2] + (4,), dtype=np.uint8)
+    lib().orc_resolve_u8(_p(np.ascontiguousarray(accum)), accum.shape[0] * accum.shape[1], exposure, _p(out))
+    return out
+
+
+def rng_probe(index, frame, px, py, dimx, n=8):
+    st = C.c_uint32()
+    fl = np.zeros(n, dtype=np.float32)
+    lib().orc_rng_probe(index, frame, px, py, dimx, C.byref(st), _p(fl), n)
+    return st.value, fl
