@@ -25,6 +25,9 @@ using namespace orc;
 
 namespace {
 
+int g_debug_px = -1, g_debug_py = -1;
+thread_local bool g_debug_on = false;
+
 struct ViewParams { // the subset of vulkan/gpu_params.glsl:61-87 the path reads
     uint32_t frame_offset;
     uint32_t dims_x, dims_y;
@@ -231,6 +234,9 @@ static vec3 sample_direct_light(const Frame &f, float geometry_scale, const MAT 
         light_pdf *= 1.0f - sun_w;
         if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
     }
+    if (g_debug_on)
+        fprintf(stderr, "  nee: sel=(%g,%g) light_dir=(%g,%g,%g) dist=%g pdf=%g mis=%g illum=(%g,%g,%g)\n", sel_sample.x, sel_sample.y, light_dir.x, light_dir.y,
+                light_dir.z, light_dist, light_pdf, mis_pdf, illum.x, illum.y, illum.z);
     if (light_pdf > 0.0f && dot(light_dir, hit.gn) * dot(light_dir, hit.n) > 0.0f) {
         bool visibility = raytrace_test_visibility(f, geometry_scale, hit.p, light_dir, light_dist, pc);
         float bsdf_pdf = eval_bsdf_wpdf(mat, hit, w_o, light_dir);
@@ -385,6 +391,11 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
         interaction.v_y = normalize(cross(interaction.n, hit.tangent));
         interaction.v_x = cross(interaction.v_y, interaction.n);
         vec3 w_i;
+        g_debug_on = (g_debug_px == (int)px && g_debug_py == (int)py);
+        if (g_debug_on)
+            fprintf(stderr, "[b%d] t=%g uv=(%g,%g) inst=%d geom=%d prim=%d mat=%d p=(%g,%g,%g) n=(%g,%g,%g) gn=(%g,%g,%g) tan=(%g,%g,%g) thr=(%g,%g,%g) illum=(%g,%g,%g) sa=%g\n", b, h.t, h.u, h.v,
+                    h.inst, h.geom, h.prim, hit.material_id, interaction.p.x, interaction.p.y, interaction.p.z, interaction.n.x, interaction.n.y,
+                    interaction.n.z, interaction.gn.x, interaction.gn.y, interaction.gn.z, hit.tangent.x, hit.tangent.y, hit.tangent.z, path_throughput.x, path_throughput.y, path_throughput.z, illum.x, illum.y, illum.z, approx_tri_solid_angle);
         int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams,
                                                       approx_tri_solid_angle, w_o, interaction, rng, w_i, pc);
         if (shading_result == SHADING_RESULT_TERMINATE) break;
@@ -740,6 +751,7 @@ void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,d
     const vec3 *v[4] = {&vp.cam_pos, &vp.cam_du, &vp.cam_dv, &vp.cam_dir_top_left};
     for (int i = 0; i < 4; ++i) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
 }
+void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 int orc_hw_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 } // extern "C"

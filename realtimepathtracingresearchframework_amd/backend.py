@@ -1,0 +1,260 @@
+"""`RenderHip`: Python mirror of the reference's `RenderBackend` plugin surface
+(librender/render_backend.h:68-116) over the C ABI of librptr_hip.so.
+
+Same method names, argument meaning and error behaviour as the reference
+interface for the hot path: failures raise (the reference throws
+`logged_exception`, util/error_io.h:27-29), `configure_for` returns a bool,
+read-backs return the element count or 0 when the buffer is too small
+(render_vulkan.cpp:2256-2275). No compute happens in Python; without the HIP
+library or without a GPU every compute call raises `BackendError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .build import LIB_PATH
+
+
+class BackendError(RuntimeError):
+    """≙ logged_exception (util/error_io.h:27-29)."""
+
+    def __init__(self, code, msg):
+        super().__init__("rptr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads librptr_hip.so and declares every prototype of include/rptr_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise BackendError(abi.RPTR_E_NO_DEVICE, "%s is missing: build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int
+    L.rptr_hip_create.argtypes = [C.POINTER(abi.CreateInfo), C.POINTER(vp)]
+    L.rptr_hip_destroy.argtypes = [vp]
+    L.rptr_hip_destroy.restype = None
+    L.rptr_hip_last_error.argtypes = [vp]
+    L.rptr_hip_last_error.restype = C.c_char_p
+    L.rptr_hip_name.restype = C.c_char_p
+    L.rptr_hip_set_stream.argtypes = [vp, vp]
+    L.rptr_hip_initialize.argtypes = [vp, i32, i32]
+    L.rptr_hip_set_scene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
+    L.rptr_hip_update_vertices.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
+    L.rptr_hip_refit.argtypes = [vp]
+    L.rptr_hip_set_params.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.SceneParams), C.POINTER(abi.LightSamplingConfig)]
+    L.rptr_hip_render.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(abi.Stats)]
+    L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_tile_rows.argtypes = [vp, i32, vp, i32]
+    L.rptr_hip_local_pixel_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rptr_hip_copy_tile_to_device.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_trace.argtypes = [vp, vp, i32, vp]
+    L.rptr_hip_export_bvh.argtypes = [vp, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
+    L.rptr_hip_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    for name in abi.EXPORTED_SYMBOLS:
+        getattr(L, name)  # AttributeError if the library lacks a declared symbol
+    _lib = L
+    return L
+
+
+class RenderStats:  # librender/render_backend.h:15-24
+    def __init__(self, s: abi.Stats = None):
+        self.render_time = s.render_time_ms if s else 0.0
+        rays = (s.rays_closest + s.rays_shadow) if s else 0
+        self.rays_per_second = rays / (self.render_time * 1e-3) if s and self.render_time > 0 else -1.0
+        self.spp = s.spp if s else 0
+        self.frame_stats_delay = 0
+        self.has_valid_frame_stats = bool(s and s.render_time_ms > 0)
+        self.total_device_bytes_allocated = s.device_bytes_allocated if s else 0
+        self.raw = s
+
+
+class RenderConfiguration:  # librender/render_backend.h:33-40
+    def __init__(self, camera: abi.Camera, active_variant=0, reset_accumulation=False, freeze_frame=False, time=0.0):
+        self.camera = camera
+        self.time = time
+        self.active_variant = active_variant
+        self.reset_accumulation = reset_accumulation
+        self.freeze_frame = freeze_frame
+
+
+class RenderHip:
+    """Drop-in shaped like `struct RenderBackend` (render_backend.h:68-116)."""
+
+    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None):
+        self._L = load_library()
+        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream)
+        h = C.c_void_p()
+        rc = self._L.rptr_hip_create(C.byref(info), C.byref(h))
+        if rc != 0:
+            raise BackendError(rc, self._L.rptr_hip_last_error(None).decode())
+        self._h = h
+        # public data members the app mutates directly (render_backend.h:69-76)
+        self.params = abi.RenderParams.default()
+        self.lighting_params = abi.LightSamplingConfig.default()
+        self.scene_params = None
+        self.camera = None
+        self.reset_accumulation = False
+        self.freeze_frame = False
+        self.rank, self.world_size = rank, world_size
+        self._variant = abi.VARIANT_GLTF
+        self._stats = None
+        self._fb_dims = (0, 0)
+        self._spp_per_frame = 1
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rptr_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BackendError(rc, self._L.rptr_hip_last_error(self._h).decode())
+
+    # ---- RenderBackend virtuals
+    def name(self):
+        return self._L.rptr_hip_name().decode()
+
+    def variant_names(self):
+        return list(abi.VARIANT_NAMES)
+
+    def variant_index(self, name):
+        return abi.VARIANT_NAMES.index(name) if name in abi.VARIANT_NAMES else -1
+
+    def initialize(self, fb_width, fb_height):
+        self._check(self._L.rptr_hip_initialize(self._h, fb_width, fb_height))
+        self._fb_dims = (fb_width, fb_height)
+
+    def set_scene(self, scene):
+        """scene: realtimepathtracingresearchframework_amd.scenes.Scene (≙ const Scene&)."""
+        desc = scene.desc()
+        self._check(self._L.rptr_hip_set_scene(self._h, C.byref(desc)))
+        self.update_config(scene)
+
+    def update_config(self, scene_or_params):
+        """≙ update_config(SceneConfig): sky/sun fit + normal_z_scale (render_vulkan.cpp:2954-2959)."""
+        sp = scene_or_params if isinstance(scene_or_params, abi.SceneParams) else scene_or_params.scene_params()
+        self.scene_params = sp
+
+    def configure_for(self, options=None, variant_idx=0):
+        if variant_idx not in (abi.VARIANT_GLTF, abi.VARIANT_SIMPLE):
+            return False
+        self._variant = variant_idx
+        return True
+
+    def _push_params(self):
+        self._check(self._L.rptr_hip_set_params(self._h, C.byref(self.params), C.byref(self.scene_params) if self.scene_params else None,
+                                                C.byref(self.lighting_params)))
+
+    def begin_frame(self, cmd_stream, config: RenderConfiguration):
+        self.camera = config.camera
+        self.reset_accumulation = config.reset_accumulation
+        self.freeze_frame = config.freeze_frame
+        self.configure_for(None, config.active_variant)
+
+    def draw_frame(self, cmd_stream=None, variant_idx=None, spp=None, count_traversal=False):
+        """One reference frame = params.batch_spp samples; `spp` renders that many frames' worth at once."""
+        if variant_idx is not None:
+            self.configure_for(None, variant_idx)
+        self._push_params()
+        st = abi.Stats()
+        n = spp if spp is not None else max(1, self.params.batch_spp)
+        self._check(self._L.rptr_hip_render(self._h, C.byref(self.camera), self._variant, n, 1 if self.reset_accumulation else 0,
+                                            1 if count_traversal else 0, C.byref(st)))
+        self.reset_accumulation = False
+        self._stats = st
+
+    def end_frame(self, cmd_stream=None, variant_idx=0):
+        pass  # resolve (process_samples) is sequenced inside draw_frame on the same stream
+
+    def render(self, config: RenderConfiguration, spp=1, count_traversal=False):
+        """≙ RenderBackend::render(config): begin_frame + draw_frame + end_frame."""
+        self.begin_frame(None, config)
+        self.draw_frame(None, spp=spp, count_traversal=count_traversal)
+        self.end_frame(None)
+        return self.stats()
+
+    def stats(self):
+        return RenderStats(self._stats)
+
+    def flush_pipeline(self):
+        pass
+
+    # ---- RenderGraphic
+    def get_framebuffer_size(self):
+        whc = (C.c_uint32 * 3)()
+        self._check(self._L.rptr_hip_get_framebuffer_size(self._h, whc))
+        return tuple(int(x) for x in whc)
+
+    def readback_framebuffer(self, buffer: np.ndarray):
+        """float32 buffer -> accumulation buffer (RGBA32F); uint8 buffer -> sRGB RGBA8. Returns #elements or 0."""
+        w, hgt, c = self.get_framebuffer_size()
+        need = w * hgt * c
+        if buffer.size < need:
+            return 0
+        if buffer.dtype == np.float32:
+            self._check(self._L.rptr_hip_readback_f32(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
+        elif buffer.dtype == np.uint8:
+            self._check(self._L.rptr_hip_readback_u8(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
+        else:
+            raise TypeError("readback_framebuffer: float32 or uint8 buffer expected")
+        return need
+
+    # ---- ray queries (RQ_CLOSEST)
+    def enable_ray_queries(self, max_queries=512 * 512, max_queries_per_pixel=0):
+        self._max_queries = max_queries
+
+    def render_ray_queries(self, queries: np.ndarray, results: np.ndarray = None):
+        """queries: (n,8) float32 view of RenderRayQuery[n]; returns (n,4) float32 in rt_intersect layout."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
+        if results is None:
+            results = np.zeros((len(q), 4), dtype=np.float32)
+        self._check(self._L.rptr_hip_trace(self._h, q.ctypes.data_as(C.c_void_p), len(q), results.ctypes.data_as(C.c_void_p)))
+        return results
+
+    # ---- multi-GPU helpers
+    def tile_rows(self, rank=None):
+        rank = self.rank if rank is None else rank
+        n = self._L.rptr_hip_tile_rows(self._h, rank, None, 0)
+        buf = (C.c_int32 * (2 * max(n, 1)))()
+        self._L.rptr_hip_tile_rows(self._h, rank, buf, n)
+        return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+    def local_pixel_count(self):
+        v = C.c_uint64()
+        self._check(self._L.rptr_hip_local_pixel_count(self._h, C.byref(v)))
+        return int(v.value)
+
+    def copy_tile_to_device(self, device_ptr, n_bytes):
+        self._check(self._L.rptr_hip_copy_tile_to_device(self._h, C.c_void_p(device_ptr), n_bytes))
+
+    def set_stream(self, hip_stream):
+        self._check(self._L.rptr_hip_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # ---- diagnostics
+    def export_bvh(self):
+        nn, nt, ni = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.rptr_hip_export_bvh(self._h, None, C.byref(nn), None, C.byref(nt), None, C.byref(ni)))
+        nodes = np.zeros(max(nn.value, 1) * 16, dtype=np.float32)
+        tris = np.zeros(max(nt.value, 1) * 12, dtype=np.float32)
+        insts = np.zeros(max(ni.value, 1) * 32, dtype=np.float32)
+        self._check(self._L.rptr_hip_export_bvh(self._h, nodes.ctypes.data_as(C.c_void_p), C.byref(nn), tris.ctypes.data_as(C.c_void_p),
+                                                C.byref(nt), insts.ctypes.data_as(C.c_void_p), C.byref(ni)))
+        return nodes[:nn.value * 16], tris[:nt.value * 12], insts[:ni.value * 32]

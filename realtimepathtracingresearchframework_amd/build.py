@@ -1,0 +1,50 @@
+"""Builds librptr_hip.so (the C-ABI shared library) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build
+container; the resulting .so travels with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "librptr_hip.so")
+SOURCES = ["rptr_hip.hip", "bvh_build.cpp"]
+HEADERS = ["kernels.h", "dtraverse.h", "dshade.h", "dmath.h", "bvh_build.h", "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
+
+# -ffp-contract=off: fused multiply-adds only where the reference writes fma()
+# itself; keeps images bit-reproducible across launches/tilings and comparable
+# with the CPU oracle (DESIGN.md "Numerics").
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP backend cannot be built (there is no CPU fallback)")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in SOURCES + HEADERS:
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return False
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force=True, verbose=True)

@@ -1,0 +1,34 @@
+// bvh_build.h -- host-side BVH2 construction for the HIP backend.
+//
+// Stands in for the driver's vkCmdBuildAccelerationStructuresKHR that the
+// reference calls through vulkan/vulkanrt_utils.h:83-105 (BLAS per mesh, static
+// meshes with PREFER_FAST_TRACE: render_vulkan.cpp:942-952; TLAS over instances:
+// :1219-1321). Binned SAH, multi-threaded over subtrees; output is the flat
+// two-children-per-node layout of include/rptr_bvh.h.
+#pragma once
+#include "../../include/rptr_bvh.h"
+#include <cstdint>
+#include <vector>
+
+namespace rptr {
+
+struct BuildPrim {
+    float lo[3], hi[3];
+};
+
+struct BuiltTree {
+    std::vector<RptrBvhNode> nodes; // root = nodes[0]; child indices relative to this vector
+    std::vector<uint32_t> order;    // leaf order -> input primitive index; leaves reference ranges of it
+    float lo[3], hi[3];             // root bounds
+    int depth = 0;
+};
+
+// max_leaf: maximum primitives per leaf; max_depth: hard bound on tree depth
+// (median splits below it). threads <= 0 -> hardware_concurrency.
+void build_bvh2(const BuildPrim *prims, uint32_t n, uint32_t max_leaf, int max_depth, int threads, BuiltTree &out);
+
+// bottom-up refit of node boxes from new primitive bounds given in LEAF order
+// (prims[i] corresponds to order[i]); host fallback used by tests.
+void refit_bvh2(BuiltTree &tree, const BuildPrim *prims_leaf_order);
+
+} // namespace rptr

@@ -1,0 +1,654 @@
+// dshade.h -- device-side shading library of the wavefront path tracer.
+//
+// HIP restatement (gfx950, wave64) of the parts of the reference's shader
+// library that PT_MEGAKERNEL executes per path vertex. Reference locations are
+// cited per function (paths relative to the reference checkout). Differences
+// from the GLSL text that are deliberate:
+//   * GLTF_SUPPORT_TRANSMISSION is off (as in the shipped PT_MEGAKERNEL build),
+//     so the component sampler has 2 lobes;
+//   * standard textures are the 1x1 texels holding the literal BaseMaterial
+//     values (no texture units on this path yet -> normal_map must be -1);
+//   * pow(x,5) is ((x*x)*(x*x))*x and pow(x,1.5) is x*sqrt(x).
+#pragma once
+#include "../../include/rptr_bvh.h"
+#include "../../include/rptr_hip.h"
+#include "dmath.h"
+
+#define RP_PI 3.14159265358979323846f
+#define RP_1_PI 0.318309886183790671538f
+#define RP_EPSILON 0.0001f // rendering/defaults.glsl:14-16
+
+// ------------------------------------------------------------------ device scene tables
+#define RP_GEOM_HAS_NORMALS 1u
+#define RP_GEOM_HAS_UVS 2u
+#define RP_GEOM_DYNAMIC 4u
+
+// ≙ RenderMeshParams (rendering/rt/geometry.h.glsl:72-91), one per (parameterized mesh, geometry)
+struct RpGeomRecord { // 64 bytes
+    const uint64_t *qpos;
+    const uint64_t *qnrm_uv;
+    const uint8_t *mat_ids; // per-triangle ids of this geometry or NULL
+    const float *dyn_pos;   // float positions of dynamic meshes (GEOMETRY_FLAGS_DYNAMIC) or NULL
+    float scaling[3];
+    int32_t material_id; // >= 0, or -1-offset when mat_ids is used (render_vulkan.cpp:2812-2815)
+    float offset[3];
+    uint32_t flags;
+};
+
+struct RpScene {
+    const RptrBvhNode *nodes;
+    const RptrBvhTri *tris;
+    const RptrBvhInstance *insts;
+    const RpGeomRecord *geoms;
+    const RptrBaseMaterial *materials;
+    const RptrTriLightData *lights; // padded with one zeroed bin
+    int32_t num_lights;
+    int32_t num_materials;
+};
+
+// the per-frame constants: RenderParams + SceneParams + ViewParams subset
+// (vulkan/gpu_params.glsl:61-87,120-131) + this backend's tile mapping
+struct RpFrame {
+    RptrRenderParams rp;
+    RptrSceneParams sp;
+    RptrLightSamplingConfig lc;
+    float cam_pos[3];
+    uint32_t frame_offset;
+    float cam_du[3];
+    uint32_t sample_base; // sample_index of sample slot 0 of this batch
+    float cam_dv[3];
+    int32_t batch_spp;    // sample slots in flight
+    float cam_dir_top_left[3];
+    int32_t variant;
+    int32_t width, height;       // full frame
+    int32_t local_rows;          // rows owned by this rank
+    int32_t tiles_x, tiles_y;    // 8x8 pixel tiles over the local image
+    int32_t npix_padded;         // tiles_x*tiles_y*64
+    int32_t rank, world, stripe_rows;
+    int32_t num_bins;            // SCENE_GET_BINNED_LIGHTS_BIN_COUNT (pt_megakernel.glsl:103)
+};
+
+// local tiled slot -> local pixel; false for padding lanes
+RP_DEV bool rp_slot_to_local(const RpFrame &f, uint32_t slot, int &lx, int &ly) {
+    uint32_t tile = slot >> 6, in = slot & 63u;
+    int tx = int(tile % uint32_t(f.tiles_x)), ty = int(tile / uint32_t(f.tiles_x));
+    lx = tx * 8 + int(in & 7u);
+    ly = ty * 8 + int(in >> 3);
+    return lx < f.width && ly < f.local_rows;
+}
+RP_DEV uint32_t rp_local_to_slot(const RpFrame &f, int lx, int ly) {
+    return (uint32_t(ly >> 3) * uint32_t(f.tiles_x) + uint32_t(lx >> 3)) * 64u + uint32_t((ly & 7) * 8 + (lx & 7));
+}
+// local row -> frame row (stripe s of `stripe_rows` rows belongs to rank s % world)
+RP_DEV int rp_local_row_to_global(const RpFrame &f, int ly) {
+    int stripe_local = ly / f.stripe_rows;
+    return (stripe_local * f.world + f.rank) * f.stripe_rows + (ly - stripe_local * f.stripe_rows);
+}
+
+// ------------------------------------------------------------------ RNG (a2)
+// rendering/pointsets/hashing.glsl:11-39
+RP_DEV uint32_t rp_murmur_mix(uint32_t hash, uint32_t k) {
+    k *= 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    hash ^= k;
+    hash = ((hash << 13) | (hash >> 19)) * 5u + 0xe6546b64u;
+    return hash;
+}
+RP_DEV uint32_t rp_murmur_finalize(uint32_t hash) {
+    hash ^= hash >> 16;
+    hash *= 0x85ebca6bu;
+    hash ^= hash >> 13;
+    hash *= 0xc2b2ae35u;
+    hash ^= hash >> 16;
+    return hash;
+}
+// rendering/pointsets/lcg_rng.glsl:28-39
+RP_DEV uint32_t rp_rng_seed(uint32_t index, uint32_t frame, uint32_t px, uint32_t py, uint32_t dimx) {
+    uint32_t s = rp_murmur_mix(frame, px + py * dimx);
+    s = rp_murmur_mix(s, index);
+    return rp_murmur_finalize(s);
+}
+// rendering/pointsets/lcg_rng.glsl:15-26; float(u32) * 2^-32 == ldexp(float(u32), -32), may be exactly 1.0f
+RP_DEV float rp_randf(uint32_t &state) {
+    state = state * 1664525u + 1013904223u;
+    return float(state) * 2.3283064365386962890625e-10f;
+}
+RP_DEV V2 rp_rand2(uint32_t &state) { // rendering/defaults.glsl:29-35
+    V2 r;
+    r.x = rp_randf(state);
+    r.y = rp_randf(state);
+    return r;
+}
+
+// ------------------------------------------------------------------ util.glsl
+RP_DEV void rp_ortho_basis(V3 &v_x, V3 &v_y, V3 n) { // rendering/util.glsl:73-87
+    v_y = v3(0, 0, 0);
+    if (n.x < 0.6f && n.x > -0.6f)
+        v_y.x = 1.f;
+    else if (n.y < 0.6f && n.y > -0.6f)
+        v_y.y = 1.f;
+    else if (n.z < 0.6f && n.z > -0.6f)
+        v_y.z = 1.f;
+    else
+        v_y.x = 1.f;
+    v_x = norm3(cross3(v_y, n));
+    v_y = norm3(cross3(n, v_x));
+}
+RP_DEV float rp_cos_half_angle(float c) { return (1.0f + c) / sqrtf(2.0f + 2.0f * c); } // util.glsl:120-122
+RP_DEV float rp_mix_fma(float x, float y, float a) { return fmaf(a, y, fmaf(-a, x, x)); }   // util.glsl:151-153
+RP_DEV float rp_linear_to_srgb(float x) {                                                  // util.glsl:19-28
+    return (x <= 0.0031308f) ? 12.92f * x : 1.055f * powf(fmaxf(fabsf(x), 1.192092896e-07f), 1.f / 2.4f) - 0.055f;
+}
+
+// ------------------------------------------------------------------ dequantisation (a6, a7)
+RP_DEV V3 rp_dequantize_position(uint64_t w, V3 scaling, V3 offset) { // librender/dequantize.glsl:8-21
+    V3 q = v3(float(uint32_t(w) & 0x1FFFFFu), float(uint32_t(w >> 21) & 0x1FFFFFu), float(uint32_t(w >> 42) & 0x1FFFFFu));
+    return q * scaling + offset;
+}
+RP_DEV V3 rp_dequantize_normal(uint32_t word) { // librender/dequantize.glsl:23-41
+    V2 n = v2(float(int(word & 0xFFFFu) - 0x8000), float(int(word >> 16) - 0x8000)) / float(0x7FFF);
+    float nl1 = fabsf(n.x) + fabsf(n.y);
+    if (nl1 >= 1.0f)
+        n = (v2(1.0f, 1.0f) - v2(fabsf(n.y), fabsf(n.x))) * v2(n.x >= 0.0f ? 1.0f : -1.0f, n.y >= 0.0f ? 1.0f : -1.0f);
+    return norm3(v3(n.x, n.y, 1.0f - nl1));
+}
+RP_DEV V2 rp_dequantize_uv(uint32_t word) { // librender/dequantize.glsl:43-48
+    return v2(0.0f, 1.0f) + v2(float(int(word & 0xFFFFu)), float(-int(word >> 16))) * (8.0f / float(0xFFFFu));
+}
+
+// ------------------------------------------------------------------ hit attributes (a7)
+struct RpHit { // rendering/rt/hit.glsl:12-23
+    V3 normal;
+    float dist;
+    V3 geo_normal;
+    int material_id;
+    V3 tangent;
+    float bitangent_l;
+};
+RP_DEV int rp_hit_material_id(const RpGeomRecord &g, uint32_t prim) { // rendering/rt/hit.glsl:49-56
+    if (g.material_id < 0)
+        return int(g.mat_ids[prim]) - g.material_id - 1;
+    return g.material_id;
+}
+RP_DEV void rp_geom_tri(const RpGeomRecord &g, uint32_t prim, V3 &a, V3 &b, V3 &c) {
+    if (g.flags & RP_GEOM_DYNAMIC) { // pt_megakernel.glsl:526-529
+        const float *p = g.dyn_pos + 9ull * prim;
+        a = v3(p[0], p[1], p[2]);
+        b = v3(p[3], p[4], p[5]);
+        c = v3(p[6], p[7], p[8]);
+        return;
+    }
+    V3 sc = ld3(g.scaling), of = ld3(g.offset);
+    const uint64_t *q = g.qpos + 3ull * prim;
+    a = rp_dequantize_position(q[0], sc, of);
+    b = rp_dequantize_position(q[1], sc, of);
+    c = rp_dequantize_position(q[2], sc, of);
+}
+// rendering/rt/hit.glsl:58-128 via the quantised overload :162-203
+RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t prim, float bu, float bv, const M3 &normals_to_world) {
+    RpHit h;
+    h.dist = ray_t;
+    V3 va, vb, vc;
+    rp_geom_tri(g, prim, va, vb, vc);
+    V3 gn = cross3(vb - va, vc - va);
+    V3 n = gn;
+    const V3 bary = v3(1.f - bu - bv, bu, bv);
+    const bool has_normals = (g.flags & RP_GEOM_HAS_NORMALS) != 0, has_uvs = (g.flags & RP_GEOM_HAS_UVS) != 0;
+    uint64_t qa = 0, qb = 0, qc = 0;
+    if (has_normals || has_uvs) {
+        const uint64_t *q = g.qnrm_uv + 3ull * prim;
+        qa = q[0];
+        qb = q[1];
+        qc = q[2];
+    }
+    if (has_normals) {
+        M3 nm{rp_dequantize_normal(uint32_t(qa)), rp_dequantize_normal(uint32_t(qb)), rp_dequantize_normal(uint32_t(qc))};
+        n = mul(nm, bary);
+        if (dot3(n, gn) < 0.0f) gn = -gn;
+    }
+    h.geo_normal = gn * 0.5f;
+    h.normal = n;
+    h.material_id = rp_hit_material_id(g, prim);
+    bool requires_tangent = true;
+    h.geo_normal = mul(normals_to_world, h.geo_normal);
+    h.normal = norm3(mul(normals_to_world, h.normal));
+    if (has_uvs) {
+        V2 uva = rp_dequantize_uv(uint32_t(qa >> 32)), uvb = rp_dequantize_uv(uint32_t(qb >> 32)), uvc = rp_dequantize_uv(uint32_t(qc >> 32));
+        float posframe_det = len3(gn);
+        V3 frame_n = gn / (posframe_det * posframe_det);
+        V3 dp2perp = cross3(vc - va, frame_n);
+        V3 dp1perp = cross3(frame_n, vb - va);
+        V2 duv1 = uvb - uva, duv2 = uvc - uva;
+        V3 T = dp2perp * duv1.x + dp1perp * duv2.x;
+        V3 B = dp2perp * duv1.y + dp1perp * duv2.y;
+        T = mul(normals_to_world, T);
+        B = mul(normals_to_world, B);
+        float Tlen = len3(T);
+        if (Tlen > 0.0f && !isinf(Tlen) && !isnan(Tlen)) {
+            h.tangent = T;
+            h.bitangent_l = dot3(norm3(cross3(h.geo_normal, T)), B);
+            requires_tangent = false;
+        }
+    }
+    if (requires_tangent) {
+        h.tangent = norm3(mul(normals_to_world, cross3(vc - va, gn)));
+        h.bitangent_l = 1.0f;
+    }
+    return h;
+}
+
+// ------------------------------------------------------------------ materials (a9)
+struct RpMaterial { // GLTFMaterial (gltf_bsdf.glsl:15-35) / SimpleMaterial (simple_bsdf.glsl:18-28)
+    V3 base_color;
+    float metallic, specular, roughness, ior;
+    uint32_t flags;
+};
+// rendering/rt/material_textures.glsl:95-135 with 1x1 literal standard texels
+template <int VARIANT>
+RP_DEV void rp_unpack_material(RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p) {
+    const float alpha = 1.0f;
+    V3 bc = v3(p.base_color[0], p.base_color[1], p.base_color[2]);
+    m.base_color = bc / alpha;
+    if (VARIANT == RPTR_VARIANT_SIMPLE) { // simple_bsdf.glsl:31-39
+        m.roughness = 1.0f;
+        m.ior = 1.0f;
+        m.metallic = 0.0f;
+        m.specular = 0.0f;
+    } else {
+        m.specular = p.specular;
+        m.roughness = p.roughness;
+        m.metallic = p.metallic;
+        m.ior = p.ior;
+    }
+    emitter_radiance = bc * p.emission_intensity;
+    if (p.emission_intensity != 0.0f) m.base_color = v3s(0.0f);
+    m.flags = p.flags;
+}
+
+// ------------------------------------------------------------------ glTF BSDF (a14), rendering/bsdfs/gltf_bsdf.glsl
+RP_DEV float rp_schlick_weight(float c) { return pow5f(clamp1(1.f - c, 0.f, 1.f)); }                     // :172-174
+RP_DEV float rp_gtr_2(float cos_theta_h, float alpha) {                                                  // :194-198
+    float a2 = alpha * alpha;
+    return RP_1_PI * a2 / pow2f(1.f + (a2 - 1.f) * cos_theta_h * cos_theta_h);
+}
+RP_DEV float rp_smith_den1(float n_dot_o, float a2) { return fabsf(n_dot_o) + sqrtf(a2 + (1.0f - a2) * n_dot_o * n_dot_o); } // :200-202
+RP_DEV float rp_smith_ggx(float n_dot_o, float n_dot_i, float alpha_g) {                                 // :207-212
+    float a = alpha_g * alpha_g;
+    float den_shad = rp_smith_den1(n_dot_i, a);
+    float den_mask = rp_smith_den1(n_dot_o, a);
+    return 1.f / (den_shad * den_mask);
+}
+RP_DEV V3 rp_to_pipe_sample(V2 U) { // :216-222
+    float phi = 2.0f * RP_PI * U.x;
+    return v3(cosf(phi), sinf(phi), U.y);
+}
+RP_DEV V3 rp_sample_sphere(V3 UP) { // :225-229
+    float cos_theta = UP.z * 2.0f - 1.0f;
+    float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    return v3(sin_theta * UP.x, sin_theta * UP.y, cos_theta);
+}
+RP_DEV V3 rp_sample_gtr_2_vndf(V3 w_o_local, float alpha, V3 UP) { // :233-250
+    V3 wiStd = norm3(v3(alpha * w_o_local.x, alpha * w_o_local.y, w_o_local.z));
+    float z = fmaf((1.0f - UP.z), (1.0f + wiStd.z), -wiStd.z);
+    float sinTheta = sqrtf(clamp1(1.0f - z * z, 0.0f, 1.0f));
+    float x = sinTheta * UP.x;
+    float y = sinTheta * UP.y;
+    V3 wmStd = v3(x, y, z) + wiStd;
+    V3 wm = v3(wmStd.x * alpha, wmStd.y * alpha, fmaxf(0.0f, wmStd.z));
+    float wmL = len3(wm);
+    return wm / wmL;
+}
+RP_DEV float rp_gtr_2_vndf_pdf(float n_dot_o, float cos_theta_h, float alpha) { // :253-257
+    return rp_gtr_2(cos_theta_h, alpha) * (0.5f / rp_smith_den1(n_dot_o, alpha * alpha));
+}
+RP_DEV V3 rp_gltf_diffuse_basecolor(const RpMaterial &m) { return (1.0f - m.metallic) * m.base_color; } // :259-261
+RP_DEV V3 rp_gltf_specular_basecolor(const RpMaterial &m, float ior) {                                  // :263-273
+    V3 dielectric_base = v3s(pow2f((ior - 1.0f) / (ior + 1.0f)));
+    return mix3(dielectric_base, m.base_color, m.metallic);
+}
+RP_DEV float rp_gltf_specular_alpha(const RpMaterial &m) { return fmaxf(m.roughness * m.roughness, 0.002f); } // :275-277
+RP_DEV float rp_gltf_schlick_weight(float local_o_dot_h, float ior) {                                       // :284-292
+    float f_weight = rp_schlick_weight(local_o_dot_h);
+    if (ior < 1.0f) {
+        float cos_critical = sqrtf(1.0f - ior * ior);
+        f_weight = mixf(f_weight, 1.0f, fminf((1.0f - local_o_dot_h) / (1.0f - cos_critical), 1.0f));
+    }
+    return f_weight;
+}
+RP_DEV V3 rp_gltf_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :294-359
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    if (i_dot_n * o_dot_n < 0.0f) return v3s(0.0f);
+    V3 w_h = norm3(w_i + w_o);
+    float o_dot_h = dot3(w_o, w_h);
+    V3 diffuse = rp_gltf_diffuse_basecolor(m) * RP_1_PI;
+    V3 specular = v3s(0.0f);
+    if (m.ior > 1.0f) {
+        V3 f0 = rp_gltf_specular_basecolor(m, m.ior);
+        float specular_alpha = rp_gltf_specular_alpha(m);
+        float specular_refl = rp_gtr_2(dot3(n, w_h), specular_alpha);
+        specular_refl *= rp_smith_ggx(o_dot_n, i_dot_n, specular_alpha);
+        float f_weight = rp_gltf_schlick_weight(fabsf(o_dot_h), ior);
+        V3 F = mix3(f0, v3s(1.0f), f_weight);
+        diffuse = diffuse * (v3s(1.0f) - F);
+        specular = specular_refl * F;
+    }
+    return diffuse + specular;
+}
+struct RpLobes {
+    float w0, w1;
+};
+RP_DEV RpLobes rp_gltf_component_sampler(const RpMaterial &m, float o_dot_h_x, float o_dot_h_y, float vis_x, float vis_y) { // :366-394
+    RpLobes c;
+    float specular_base_lum = luminance3(rp_gltf_specular_basecolor(m, m.ior));
+    float F0 = mixf(specular_base_lum, 1.0f, rp_gltf_schlick_weight(o_dot_h_x, 1.0f));
+    float F1 = mixf(specular_base_lum, 1.0f, rp_gltf_schlick_weight(o_dot_h_y, 1.0f));
+    c.w0 = (1.0f - F0) * vis_x * (1.0f - m.metallic) * luminance3(rp_gltf_diffuse_basecolor(m));
+    c.w1 = F1 * vis_y;
+    float weight_sum = 0.0f;
+    weight_sum += c.w0;
+    weight_sum += c.w1;
+    if (weight_sum > 0.0f) {
+        c.w0 /= weight_sum;
+        c.w1 /= weight_sum;
+    } else
+        c.w0 = 1.0f;
+    return c;
+}
+RP_DEV float rp_gltf_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :414-494
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    float pdf = RP_1_PI * fabsf(i_dot_n);
+    if (m.ior > 1.0f) {
+        if (i_dot_n * o_dot_n < 0.0f) return 0.0f;
+        V3 w_h = norm3(w_i + w_o);
+        float o_dot_h = dot3(w_o, w_h);
+        float cos_theta_h = dot3(w_h, n);
+        float specular_alpha = rp_gltf_specular_alpha(m);
+        float vis_y = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, specular_alpha * specular_alpha);
+        RpLobes c = rp_gltf_component_sampler(m, fabsf(o_dot_h), fabsf(o_dot_h), 1.0f, vis_y);
+        float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        pdf *= c.w0;
+        pdf += specular * c.w1;
+    }
+    return pdf;
+}
+// :496-645. Returns f*|cos|/pdf; pdf == 0 signals "no sample".
+RP_DEV V3 rp_sample_gltf_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, float &pdf, float &mis_wpdf, V2 rng_sample, V2 fresnel_sample,
+                              V3 v_x, V3 v_y) {
+    M3 frame{v_x, v_y, n};
+    V3 w_o_local = mul_t(frame, w_o);
+    float o_dot_n = w_o_local.z;
+    mis_wpdf = 0.0f;
+    if (o_dot_n < 0.0f) {
+        pdf = 0.0f;
+        return v3s(0.0f);
+    }
+    V3 UP = rp_to_pipe_sample(rng_sample);
+    V3 w_i_diffuse = norm3(n + rp_sample_sphere(UP));
+    float specular_alpha = rp_gltf_specular_alpha(m);
+    int component = 0;
+    RpLobes lobes{0.0f, 0.0f};
+    V3 w_h_specular_local = v3s(0.0f);
+    if (m.ior > 1.0f) {
+        float odh_x = rp_cos_half_angle(dot3(w_o, w_i_diffuse));
+        w_h_specular_local = rp_sample_gtr_2_vndf(w_o_local, specular_alpha, UP);
+        float odh_y = dot3(w_o_local, w_h_specular_local);
+        float spec_i_dot_n_local = reflect3(-w_o_local, w_h_specular_local).z;
+        float vis_y = spec_i_dot_n_local > 0.0f ? 2.0f * spec_i_dot_n_local / rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha) : 0.0f;
+        lobes = rp_gltf_component_sampler(m, odh_x, odh_y, 1.0f, vis_y);
+        // glft_sample_reuse_component (:395-409), 2 components, only the index is used afterwards
+        float rnd = fresnel_sample.x;
+        float next_base = 0.0f;
+        if (lobes.w0 > 0.0f && rnd >= next_base) component = 0;
+        next_base += lobes.w0;
+        if (lobes.w1 > 0.0f && rnd >= next_base) component = 1;
+    }
+    float cos_theta_h;
+    if (component == 0) {
+        w_i = w_i_diffuse;
+        V3 w_h = norm3(w_i + w_o);
+        cos_theta_h = dot3(n, w_h);
+    } else {
+        V3 w_h = w_h_specular_local;
+        cos_theta_h = w_h.z;
+        w_h = mul(frame, w_h);
+        w_i = reflect3(-w_o, w_h);
+    }
+    float i_dot_n = dot3(n, w_i);
+    if (!(i_dot_n > 0.0f)) {
+        pdf = 0.0f;
+        return v3s(0.0f);
+    }
+    pdf = RP_1_PI * fabsf(i_dot_n);
+    if (m.ior > 1.0f) {
+        pdf *= lobes.w0;
+        float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        pdf += specular * lobes.w1;
+    }
+    if (!(pdf > 0.0f)) return v3s(0.0f);
+    V3 result = rp_gltf_bsdf(m, n, w_o, w_i);
+    mis_wpdf = rp_gltf_wpdf(m, n, w_o, w_i);
+    return result * fabsf(i_dot_n) / pdf;
+}
+
+// ------------------------------------------------------------------ Lambert BSDF, rendering/bsdfs/simple_bsdf.glsl
+RP_DEV V3 rp_simple_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :44-59
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    V3 diffuse = m.base_color * RP_1_PI;
+    if (i_dot_n * o_dot_n < 0.0f) return v3s(0.0f);
+    return diffuse;
+}
+RP_DEV float rp_simple_pdf(V3 n, V3 w_o, V3 w_i) { // :68-83
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    float pdf = RP_1_PI * fabsf(i_dot_n);
+    if (i_dot_n * o_dot_n < 0.0f) return 0.0f;
+    return pdf;
+}
+RP_DEV V3 rp_sample_simple_brdf(const RpMaterial &m, V3 n, V3 &w_i, float &pdf, float &mis_pdf, V2 rnd) { // :61-66,85-94
+    float phi = 2.0f * RP_PI * rnd.x;
+    float cos_theta = rnd.y * 2.0f - 1.0f;
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    V3 sph = v3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+    w_i = norm3(n + sph);
+    float i_dot_n = dot3(n, w_i);
+    pdf = mis_pdf = RP_1_PI * fabsf(i_dot_n);
+    return m.base_color;
+}
+
+// material registration (gltf_bsdf.glsl:649-655, simple_bsdf.glsl:98-104)
+template <int VARIANT>
+RP_DEV V3 rp_eval_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) {
+    return VARIANT == RPTR_VARIANT_SIMPLE ? rp_simple_bsdf(m, n, w_o, w_i) : rp_gltf_bsdf(m, n, w_o, w_i);
+}
+template <int VARIANT>
+RP_DEV float rp_eval_bsdf_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) {
+    return VARIANT == RPTR_VARIANT_SIMPLE ? rp_simple_pdf(n, w_o, w_i) : rp_gltf_wpdf(m, n, w_o, w_i);
+}
+
+// ------------------------------------------------------------------ triangle lights (a12), rendering/lights/tri.glsl
+RP_DEV float rp_fast_positive_atan(float y) { // :58-74
+    float rx, ry, rz;
+    rx = (fabsf(y) > 1.0f) ? (1.0f / fabsf(y)) : fabsf(y);
+    ry = rx * rx;
+    rz = fmaf(ry, 0.02083509974181652f, -0.08513300120830536f);
+    rz = fmaf(ry, rz, 0.18014100193977356f);
+    rz = fmaf(ry, rz, -0.3302994966506958f);
+    ry = fmaf(ry, rz, 0.9998660087585449f);
+    rz = fmaf(-2.0f * ry, rx, float(0.5f * RP_PI));
+    rz = (fabsf(y) > 1.0f) ? rz : 0.0f;
+    rx = fmaf(rx, ry, rz);
+    return (y < 0.0f) ? (RP_PI - rx) : rx;
+}
+RP_DEV float rp_half_tri_solid_angle_tan(V3 v0, V3 v1, V3 v2, V3 &tp) { // :83-113
+    float householder_sign = (v0.x > 0.0f) ? -1.0f : 1.0f;
+    float hs = 1.0f / (fabsf(v0.x) + 1.0f);
+    float hy = v0.y * hs, hz = v0.z * hs;
+    float dot_0_1 = dot3(v0, v1);
+    float dot_0_2 = dot3(v1, v2);
+    float dot_1_2 = dot3(v0, v2);
+    float dh0 = fmaf(-householder_sign, v1.x, dot_0_1);
+    float dh2 = fmaf(-householder_sign, v2.x, dot_1_2);
+    float m00 = fmaf(-dh0, hy, v1.y), m01 = fmaf(-dh0, hz, v1.z);
+    float m10 = fmaf(-dh2, hy, v2.y), m11 = fmaf(-dh2, hz, v2.z);
+    float simplex_volume = fabsf(m00 * m11 - m10 * m01);
+    float dot_0_2_plus_1_2 = dot_0_2 + dot_1_2;
+    float one_plus_dot_0_1 = 1.0f + dot_0_1;
+    tp = v3(simplex_volume, dot_0_2_plus_1_2, one_plus_dot_0_1);
+    return simplex_volume / (one_plus_dot_0_1 + dot_0_2_plus_1_2);
+}
+RP_DEV V3 rp_sample_solid_angle_polygon(V3 v0, V3 v1, V3 v2, float solid_angle, V3 params, V2 rnd) { // :132-152
+    float sub = solid_angle * rnd.x;
+    V3 vert0 = v1, vert1 = v0, vert2 = v2;
+    float cs = cosf(0.5f * sub), sn = sinf(0.5f * sub);
+    V3 offset = vert0 * (params.x * cs - params.y * sn) + vert2 * (params.z * sn);
+    float k = 2.0f * (dot3(vert0, offset) / dot3(offset, offset));
+    V3 new_vertex_2 = v3(fmaf(k, offset.x, -vert0.x), fmaf(k, offset.y, -vert0.y), fmaf(k, offset.z, -vert0.z));
+    float s2 = dot3(vert1, new_vertex_2);
+    float s = rp_mix_fma(1.0f, s2, rnd.y);
+    float denominator = fmaf(-s2, s2, 1.0f);
+    float t_normed = sqrtf(fmaf(-s, s, 1.0f) / denominator);
+    t_normed = (denominator > 0.0f) ? t_normed : rnd.y;
+    return fmaf(-t_normed, s2, s) * vert1 + t_normed * new_vertex_2;
+}
+RP_DEV void rp_load_light(const RptrTriLightData *lights, int id, V3 &a, V3 &b, V3 &c, V3 &rad) {
+    // 48 bytes = 3 x float4
+    const float4 *p = reinterpret_cast<const float4 *>(lights + id);
+    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+    a = v3(q0.x, q0.y, q0.z);
+    b = v3(q0.w, q1.x, q1.y);
+    c = v3(q1.z, q1.w, q2.x);
+    rad = v3(q2.y, q2.z, q2.w);
+}
+// rendering/mc/lights_linear.glsl:19-127 (binned RIS, solid-angle sampling)
+RP_DEV V3 rp_sample_tri_lights(const RpScene &sc, const RpFrame &f, V3 hit_p, V3 hit_n, V2 dir_sample, V2 sel_sample, V3 &light_dir,
+                               float &light_dist, float &pdf, float &mis_wpdf) {
+    const int num_lights = sc.num_lights;
+    const int BIN = f.lc.bin_size;
+    const int num_bins = f.num_bins;
+    sel_sample.x *= float(num_bins);
+    int bin_id = int(uint32_t(sel_sample.x));
+    bin_id = min(bin_id, num_bins - 1);
+    float sel_p = 1.0f / float(num_bins);
+    float contributions[RPTR_BINNED_LIGHTS_BIN_MAX_SIZE];
+    float total_contrib = 0.0f;
+    const float MIN_IRRADIANCE = 6.2e-4f * 0.001f;
+    const int bin_begin = BIN * bin_id;
+    const int bin_end = min(BIN * (bin_id + 1), num_lights);
+#pragma unroll
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
+        int light_id = bin_begin + i;
+        float contrib = 0.0f;
+        if (light_id < bin_end) {
+            V3 a, b, c, rad;
+            rp_load_light(sc.lights, light_id, a, b, c, rad);
+            a = a - hit_p;
+            b = b - hit_p;
+            c = c - hit_p;
+            bool front_facing = dot3(cross3(a, b), c) < 0.0f; // tri.glsl:21-23
+            contrib = luminance3(rad);
+            if ((dot3(a, hit_n) > 0.0f || dot3(b, hit_n) > 0.0f || dot3(c, hit_n) > 0.0f) && front_facing) {
+                a = norm3(a);
+                b = norm3(b);
+                c = norm3(c);
+                V3 tp;
+                contrib *= 2.0f * rp_fast_positive_atan(rp_half_tri_solid_angle_tan(a, b, c, tp));
+            } else
+                contrib = 0.0f;
+            contrib += MIN_IRRADIANCE;
+            total_contrib += contrib;
+        }
+        contributions[i] = contrib;
+    }
+    float p = 0.0f, t = 0.0f;
+    int light_id = bin_begin;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
+        if (!done) {
+            light_id = bin_begin + i;
+            if (!(light_id < bin_end)) {
+                done = true;
+            } else {
+                p = contributions[i] / total_contrib;
+                t += p;
+                if (sel_sample.y < t) done = true;
+            }
+        }
+    }
+    sel_p *= p;
+    V3 l0, l1, l2, lrad;
+    rp_load_light(sc.lights, light_id, l0, l1, l2, lrad); // may be bin_end: zero-padded
+    V3 d0 = norm3(l0 - hit_p);
+    V3 d1 = norm3(l1 - hit_p);
+    V3 d2 = norm3(l2 - hit_p);
+    V3 tp;
+    float polygon_solid_angle = 2.0f * rp_fast_positive_atan(rp_half_tri_solid_angle_tan(d0, d1, d2, tp));
+    light_dir = rp_sample_solid_angle_polygon(d0, d1, d2, polygon_solid_angle, tp, dir_sample);
+    pdf = 1.0f / polygon_solid_angle;
+    V3 e_n = cross3(l1 - l0, l2 - l0);
+    light_dist = dot3(l0 - hit_p, e_n) / dot3(light_dir, e_n);
+    mis_wpdf = 2.0f * light_dist * light_dist / fabsf(dot3(light_dir, e_n));
+    pdf *= sel_p;
+    mis_wpdf /= float(num_bins);
+    return 1.0f * lrad / pdf;
+}
+
+// ------------------------------------------------------------------ sun + sky (a11, a15)
+RP_DEV V3 rp_sample_sun_dir(V3 sun_dir, float cos_radius, V2 s) { // rendering/lights/sun.glsl:9-15
+    float phi = 2.0f * RP_PI * s.x;
+    float cosTheta = mixf(1.0f, cos_radius, s.y);
+    float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    V3 vx, vy;
+    rp_ortho_basis(vx, vy, sun_dir);
+    M3 fr{vx, vy, sun_dir};
+    return mul(fr, v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta));
+}
+RP_DEV float rp_sun_dir_pdf(float cos_radius) { return 1.0f / (2.0f * RP_PI * (1.0f - cos_radius)); } // sun.glsl:17-20
+RP_DEV float rp_nee_mis(float pdf_f, float pdf_g) { return pdf_f / (pdf_f + pdf_g); }                 // nee_interface.glsl:11-15 (n=1)
+
+// rendering/lights/sky_model_arhosek/sky_model.glsl:40-59
+RP_DEV V3 rp_skymodel_radiance(const RptrSkyModelParams &st, V3 sun_dir, V3 view_dir) {
+    float cosTheta = clamp1(view_dir.y, 0.0f, 1.0f);
+    float cosGamma = clamp1(dot3(view_dir, sun_dir), -1.0f, 1.0f);
+    float gamma = acosf(cosTheta);
+#define RP_CFG(i) v3(st.configs[i][0], st.configs[i][1], st.configs[i][2])
+    V3 c4g = RP_CFG(4) * gamma;
+    V3 expM = v3(expf(c4g.x), expf(c4g.y), expf(c4g.z));
+    float rayM = cosGamma * cosGamma;
+    V3 c8 = RP_CFG(8);
+    V3 mie_base = v3s(1.0f) + c8 * c8 - 2.0f * c8 * cosGamma;
+    V3 mie_den = v3(mie_base.x * sqrtf(mie_base.x), mie_base.y * sqrtf(mie_base.y), mie_base.z * sqrtf(mie_base.z));
+    V3 mieM = v3s(1.0f + cosGamma * cosGamma) / mie_den;
+    float zenith = sqrtf(cosTheta);
+    V3 c1d = RP_CFG(1) / (cosTheta + 0.01f);
+    V3 e1 = v3(expf(c1d.x), expf(c1d.y), expf(c1d.z));
+    V3 coeffs = (v3s(1.0f) + RP_CFG(0) * e1) * ((((RP_CFG(2) + RP_CFG(3) * expM) + RP_CFG(5) * rayM) + RP_CFG(6) * mieM) + RP_CFG(7) * zenith);
+#undef RP_CFG
+    return coeffs * v3(st.radiances[0], st.radiances[1], st.radiances[2]) * 0.01f;
+}
+// vulkan/pt_megakernel.glsl:113-149
+RP_DEV V3 rp_compute_sky_illum(const RpFrame &f, V3 ray_dir, float prev_bsdf_pdf) {
+    V3 sun_dir = ld3(f.sp.sun_dir);
+    V3 dir = ray_dir;
+    float ocean_coeff = 1.0f;
+    if (dir.y <= 0.0f) {
+        dir.y = -dir.y;
+        ocean_coeff = 0.7f * pow5f(fmaxf(1.0f - fabsf(dir.y), 0.0f));
+    }
+    V3 atmosphere = max3(rp_skymodel_radiance(f.sp.sky_params, sun_dir, dir), v3s(0.0f)) * ocean_coeff;
+    V3 sun_illum = v3s(0.0f);
+    if (dot3(dir, sun_dir) >= f.sp.sun_cos_angle) sun_illum = ld3(f.sp.sun_radiance) * ocean_coeff;
+    V3 illum = v3s(0.0f);
+    illum = illum + abs3(atmosphere);
+    float light_pdf = f.sp.sun_radiance[3] * rp_sun_dir_pdf(f.sp.sun_cos_angle);
+    float w = rp_nee_mis(prev_bsdf_pdf, light_pdf);
+    illum = illum + w * abs3(sun_illum);
+    return illum;
+}
+// vulkan/geometry.glsl:76-78
+RP_DEV float rp_geometry_scale_to_tmin(V3 orig, float geometry_scale) { return (len3(orig) + geometry_scale) * RPTR_RAY_EPSILON; }

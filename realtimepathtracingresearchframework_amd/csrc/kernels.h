@@ -1,0 +1,537 @@
+// kernels.h -- the wavefront stages that replace the reference's megakernel.
+//
+//   raygen   pt_megakernel.glsl:310-325   camera rays, RNG seeding, path state init
+//   extend   pt_megakernel.glsl:440-475   closest-hit queries      (persistent waves)
+//   sort     (new)                        regroup hit paths by material id
+//   shade    pt_megakernel.glsl:480-730   miss/sky, hit attributes, emitter MIS, NEE
+//                                         sampling, BSDF sampling, Russian roulette
+//   connect  pt_megakernel.glsl:216-272   shadow queries + NEE accumulation (persistent)
+//   resolve  accumulate.glsl:44-74 + process_samples.comp:69-200
+//   trace    rt_intersect.comp:31-68      RQ_CLOSEST batch query
+//
+// Path state is SoA, indexed by path id = sample_slot * npix_padded + tiled pixel
+// slot. Every kernel reads its work count from device memory, so one frame is a
+// fixed launch sequence without host round trips. Queue appends use one atomic
+// per wave (ballot + mbcnt prefix).
+#pragma once
+#include "dtraverse.h"
+
+struct RpPathState {
+    float4 *ray_o;   // origin.xyz, t_min
+    float4 *ray_d;   // dir.xyz, t_max
+    float4 *thr;     // throughput.xyz, prev_bounce_pdf
+    float4 *illum;   // illum.xyz, bits(bounce)
+    float2 *rng_tt;  // bits(rng state), total_t
+    float4 *hit_tuv; // t, u, v, bits(prim)
+    int2 *hit_ids;   // inst_idx, geom
+};
+struct RpShadowQueue {
+    float4 *o;       // origin.xyz, t_min
+    float4 *d;       // dir.xyz, t_max
+    float4 *contrib; // radiance to add if visible .xyz, bits(path)
+};
+// device-side counters, one block of them per frame
+struct RpCounters {
+    uint32_t queue_count[2]; // ping-pong ray queues
+    uint32_t shadow_count;
+    uint32_t cursor_extend;
+    uint32_t cursor_connect;
+    uint32_t _pad[3];
+    unsigned long long rays_closest, rays_shadow, nodes, tris, hits_shaded;
+    uint32_t stack_overflow;
+    uint32_t _pad2;
+};
+
+#define RP_SORT_MAX_KEYS 1024
+
+// ---- wave64 helpers
+RP_DEV uint32_t rp_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// appends `flag` lanes to a queue with one atomic per wave; returns slot (valid only where flag)
+RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
+    const unsigned long long mask = __ballot(flag);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = rp_lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (int(lane) == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+RP_DEV uint32_t rp_wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// ------------------------------------------------------------------ raygen
+__global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, uint32_t *queue, RpCounters *ctr) {
+    const uint32_t total = uint32_t(f.batch_spp) * uint32_t(f.npix_padded);
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < ((total + 63u) & ~63u); p += gridDim.x * blockDim.x) {
+        bool valid = p < total;
+        int lx = 0, ly = 0;
+        uint32_t slot = 0, sslot = 0;
+        if (valid) {
+            sslot = p / uint32_t(f.npix_padded);
+            slot = p - sslot * uint32_t(f.npix_padded);
+            valid = rp_slot_to_local(f, slot, lx, ly);
+        }
+        int gy = 0;
+        if (valid) {
+            gy = rp_local_row_to_global(f, ly);
+            valid = gy < f.height;
+        }
+        if (valid) {
+            // pt_megakernel.glsl:314-325
+            const uint32_t sample_index = f.sample_base + sslot;
+            uint32_t rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+            V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
+            if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
+            point = v2(point.x / float(f.width), point.y / float(f.height));
+            V3 dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
+            ps.ray_o[p] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], 0.0f);
+            ps.ray_d[p] = f4(dir, 2.e32f);
+            ps.thr[p] = make_float4(1.f, 1.f, 1.f, 2.e16f); // init_shading_sample_state, shading_interface.glsl:20-22
+            ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+            ps.rng_tt[p] = make_float2(__uint_as_float(rng), 0.0f);
+        } else if (p < total) {
+            ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+        }
+        const uint32_t at = rp_wave_append(&ctr->queue_count[0], valid);
+        if (valid) queue[at] = p;
+    }
+}
+
+// ------------------------------------------------------------------ extend (closest hit), persistent waves
+template <bool COUNT>
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
+                                                                 RpCounters *ctr, int *gstack) {
+    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+    RpStack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.gstride = gridDim.x * blockDim.x;
+    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
+    st.sp = 0;
+    const uint32_t n = *count_ptr;
+    const uint32_t lane = rp_lane_id();
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->cursor_extend, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const uint32_t p = queue[i];
+            const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+            RpHitRec h;
+            rp_traverse<false, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
+            ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+            ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+        }
+    }
+    if (COUNT) {
+        n_nodes = rp_wave_sum_u32(n_nodes);
+        n_tris = rp_wave_sum_u32(n_tris);
+        if (lane == 0) {
+            atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+            atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ connect (shadow rays), persistent waves
+template <bool COUNT>
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, RpPathState ps, RpShadowQueue sq, RpCounters *ctr, int *gstack) {
+    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+    RpStack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.gstride = gridDim.x * blockDim.x;
+    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
+    st.sp = 0;
+    const uint32_t n = ctr->shadow_count;
+    const uint32_t lane = rp_lane_id();
+    uint32_t n_nodes = 0, n_tris = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->cursor_connect, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {
+            const float4 o = sq.o[i], d = sq.d[i];
+            RpHitRec h;
+            const bool occluded = rp_traverse<true, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
+            if (!occluded) {
+                const float4 c = sq.contrib[i];
+                const uint32_t p = __float_as_uint(c.w);
+                float4 il = ps.illum[p];
+                il.x += c.x;
+                il.y += c.y;
+                il.z += c.z;
+                ps.illum[p] = il;
+            }
+        }
+    }
+    if (COUNT) {
+        n_nodes = rp_wave_sum_u32(n_nodes);
+        n_tris = rp_wave_sum_u32(n_tris);
+        if (lane == 0) {
+            atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
+            atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sort by material
+// key 0 = miss, 1 + min(material id, K-2) otherwise
+RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpPathState &ps, uint32_t p, int num_keys) {
+    const int2 ids = ps.hit_ids[p];
+    if (ids.x < 0) return 0u;
+    const int prim = __float_as_int(ps.hit_tuv[p].w);
+    const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[25]; // RptrBvhInstance::geometry_base
+    const RpGeomRecord &g = sc.geoms[geometry_base + ids.y];
+    const int mid = rp_hit_material_id(g, uint32_t(prim));
+    return 1u + uint32_t(min(mid, num_keys - 2));
+}
+__global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
+                                                       uint32_t *keys, uint32_t *hist, int num_keys) {
+    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
+    __syncthreads();
+    const uint32_t n = *count_ptr;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t key = rp_sort_key(sc, ps, queue[i], num_keys);
+        keys[i] = key;
+        atomicAdd(&lh[key], 1u);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
+        if (lh[k]) atomicAdd(&hist[k], lh[k]);
+}
+// single block: exclusive scan of hist -> base, zero the cursors
+__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *hist, uint32_t *base, uint32_t *cursor, int num_keys) {
+    __shared__ uint32_t s[RP_SORT_MAX_KEYS];
+    const int t = threadIdx.x;
+    s[t] = t < num_keys ? hist[t] : 0u;
+    __syncthreads();
+    for (int off = 1; off < RP_SORT_MAX_KEYS; off <<= 1) {
+        uint32_t v = t >= off ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    if (t < num_keys) {
+        base[t] = s[t] - hist[t];
+        cursor[t] = 0u;
+        hist[t] = 0u; // ready for the next bounce
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_sort_scatter(const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
+                                                         const uint32_t *base, uint32_t *cursor, uint32_t *order) {
+    const uint32_t n = *count_ptr;
+    const uint32_t lane = rp_lane_id();
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys[i] : 0xFFFFFFFFu;
+        uint32_t pos = 0;
+        // wave-level multi-split: one atomic per distinct key per wave
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = __shfl(key, leader);
+            const unsigned long long same = __ballot(valid && key == k);
+            uint32_t b = 0;
+            if (int(lane) == leader) b = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
+            b = __shfl(b, leader);
+            if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (valid) order[base[key] + pos] = queue[i];
+    }
+}
+
+// ------------------------------------------------------------------ shade
+template <int VARIANT>
+__global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowQueue sq, const uint32_t *order,
+                                                  const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, RpCounters *ctr) {
+    const uint32_t n = *count_ptr;
+    const uint32_t n_round = (n + 63u) & ~63u;
+    uint32_t my_closest = 0, my_shadow = 0, my_hits = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool alive = false;       // path continues with a new ray
+        bool has_shadow = false;  // a shadow query is issued
+        uint32_t p = 0;
+        float4 sh_o, sh_d, sh_c;
+        if (i < n) {
+            p = order[i];
+            my_closest++;
+            const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
+            float4 thr4 = ps.thr[p];
+            float4 il4 = ps.illum[p];
+            const float2 rt = ps.rng_tt[p];
+            uint32_t rng = __float_as_uint(rt.x);
+            float total_t = rt.y;
+            const float4 hit4 = ps.hit_tuv[p];
+            const int2 ids = ps.hit_ids[p];
+            V3 ray_origin = xyz(ro4), ray_dir = xyz(rd4);
+            V3 throughput = xyz(thr4), illum = xyz(il4);
+            float prev_bounce_pdf = thr4.w;
+            int bounce = __float_as_int(il4.w);
+            if (ids.x < 0) {
+                // miss: pt_megakernel.glsl:480-489
+                illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
+                ps.illum[p] = f4(illum, __int_as_float(bounce));
+            } else {
+                my_hits++;
+                // ---- hit attributes, pt_megakernel.glsl:495-572
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
+                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
+                const RpGeomRecord g = sc.geoms[meta.y + ids.y];
+                const uint32_t prim = uint32_t(__float_as_int(hit4.w));
+                // transpose(mat3(world_to_object)): its columns are the rows of world_to_object
+                const M3 n2w{v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z)};
+                RpHit hit = rp_calc_hit_attributes(g, hit4.x, prim, hit4.y, hit4.z, n2w);
+                // :578-580
+                float approx_tri_solid_angle = len3(hit.geo_normal);
+                hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
+                approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
+                // :585,605
+                total_t += hit.dist;
+                const float geometry_scale = total_t;
+                const V3 w_o = -ray_dir;
+                V3 ip_p = ray_origin + hit.dist * ray_dir;
+                V3 gn = hit.geo_normal, nn = hit.normal;
+                const RptrBaseMaterial mp = sc.materials[hit.material_id];
+                // :624-633
+                if (dot3(w_o, gn) < 0.0f) {
+                    if ((mp.flags & RPTR_BASE_MATERIAL_VOLUME) != 0) {
+                        ip_p = ray_origin;
+                        hit.dist = 0.0f;
+                    } else if ((mp.flags & RPTR_BASE_MATERIAL_ONESIDED) == 0) {
+                        nn = -nn;
+                        gn = -gn;
+                    }
+                }
+                // :656-668
+                {
+                    const float nw = dot3(w_o, nn);
+                    const float gnw = dot3(w_o, gn);
+                    if (nw * gnw <= 0.0f) {
+                        const float blend = gnw / (gnw - nw);
+                        nn = norm3(mix3(gn, nn, blend - RP_EPSILON));
+                    }
+                }
+                // :677-678
+                const V3 v_y = norm3(cross3(nn, hit.tangent));
+                const V3 v_x = cross3(v_y, nn);
+
+                // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
+                RpMaterial mat;
+                V3 emit;
+                rp_unpack_material<VARIANT>(mat, emit, mp);
+                const V3 scatter_throughput = throughput;
+                const int output_channel = f.rp.output_channel;
+                if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
+                    // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
+                    const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));
+                    const float w = rp_nee_mis(prev_bounce_pdf, light_pdf);
+                    illum = illum + w * scatter_throughput * emit;
+                }
+                if (output_channel != 0) {
+                    const float reliability = powf(0.25f, float(bounce));
+                    if (output_channel == 1)
+                        illum = illum + scatter_throughput * mat.base_color * reliability;
+                    else if (output_channel == 2)
+                        illum = illum + nn * reliability;
+                    else if (output_channel == 3)
+                        illum = illum + ip_p * reliability;
+                }
+                bool terminate = (bounce + 1 >= f.rp.max_path_depth);
+                if (!terminate) {
+                    if (output_channel == 0) {
+                        // ---- sample_direct_light, rendering/mc/nee.glsl:32-90
+                        const V2 dir_sample = rp_rand2(rng);
+                        V2 sel_sample = rp_rand2(rng);
+                        V3 nee = v3s(0.0f);
+                        V3 light_dir = v3s(0.0f);
+                        float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
+                        const float sun_w = f.sp.sun_radiance[3];
+                        if (sel_sample.x <= sun_w) {
+                            sel_sample.x /= sun_w;
+                            light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
+                            light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
+                            nee = nee + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
+                            light_pdf *= sun_w;
+                            mis_pdf = light_pdf;
+                        } else {
+                            sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
+                            float tri_mis_wpdf = 0.0f;
+                            nee = nee + rp_sample_tri_lights(sc, f, ip_p, nn, dir_sample, sel_sample, light_dir, light_dist, light_pdf, tri_mis_wpdf) /
+                                            (1.0f - sun_w);
+                            light_pdf *= 1.0f - sun_w;
+                            if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
+                        }
+                        if (light_pdf > 0.0f && dot3(light_dir, gn) * dot3(light_dir, nn) > 0.0f) {
+                            // raytrace_test_visibility is deferred to the connect stage; everything that
+                            // does not depend on its answer is evaluated here (nee.glsl:73-84)
+                            const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
+                            const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
+                            const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
+                            if (needs_ray) my_shadow++;
+                            if (bsdf_pdf >= 0.0f) {
+                                const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
+                                const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
+                                nee = nee * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
+                                const V3 c = scatter_throughput * nee;
+                                if (needs_ray) {
+                                    has_shadow = true;
+                                    sh_o = f4(ip_p, epsilon);
+                                    sh_d = f4(light_dir, light_dist - epsilon);
+                                    sh_c = f4(c, __uint_as_float(p));
+                                } else
+                                    illum = illum + c; // visibility defaults to true
+                            } else if (needs_ray) {
+                                // the reference still traces this ray (its result is unused): count it,
+                                // but there is nothing to connect
+                            }
+                        }
+                    }
+                    if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
+                }
+                if (!terminate) {
+                    const V2 lobe_sample = rp_rand2(rng);
+                    const V2 dir_sample = rp_rand2(rng);
+                    V3 w_i = v3s(0.0f);
+                    float sampling_pdf = 0.0f, mis_pdf = 0.0f;
+                    V3 bsdf;
+                    if (VARIANT == RPTR_VARIANT_SIMPLE)
+                        bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample);
+                    else
+                        bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample, lobe_sample, v_x, v_y);
+                    ++bounce;
+                    if (eq3(bsdf, v3s(0.f)) || mis_pdf == 0.f || !(dot3(w_i, nn) * dot3(w_i, gn) > 0.0f))
+                        terminate = true;
+                    else {
+                        throughput = throughput * bsdf;
+                        prev_bounce_pdf = mis_pdf;
+                        // pt_megakernel.glsl:703-709
+                        ray_dir = w_i;
+                        ray_origin = ip_p;
+                        const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
+                        // :713-730 Russian roulette
+                        bool survive = true;
+                        if (bounce >= f.rp.rr_path_depth) {
+                            const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
+                            float rr_prob = prefix_weight;
+                            const float rr_sample = rp_randf(rng);
+                            rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
+                            if (rr_sample < rr_prob)
+                                throughput = throughput / rr_prob;
+                            else
+                                survive = false;
+                        }
+                        // the loop bound of pt_megakernel.glsl:417: no further iteration after max_path_depth
+                        if (survive) {
+                            alive = true;
+                            ps.ray_o[p] = f4(ray_origin, t_min);
+                            ps.ray_d[p] = f4(ray_dir, 1e20f);
+                            ps.thr[p] = f4(throughput, prev_bounce_pdf);
+                            ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
+                        }
+                    }
+                }
+                ps.illum[p] = f4(illum, __int_as_float(bounce));
+            }
+        }
+        const uint32_t at = rp_wave_append(next_count, alive);
+        if (alive) next_queue[at] = p;
+        const uint32_t sat = rp_wave_append(&ctr->shadow_count, has_shadow);
+        if (has_shadow) {
+            sq.o[sat] = sh_o;
+            sq.d[sat] = sh_d;
+            sq.contrib[sat] = sh_c;
+        }
+    }
+    my_closest = rp_wave_sum_u32(my_closest);
+    my_shadow = rp_wave_sum_u32(my_shadow);
+    my_hits = rp_wave_sum_u32(my_hits);
+    if (rp_lane_id() == 0) {
+        if (my_closest) atomicAdd(&ctr->rays_closest, (unsigned long long)my_closest);
+        if (my_shadow) atomicAdd(&ctr->rays_shadow, (unsigned long long)my_shadow);
+        if (my_hits) atomicAdd(&ctr->hits_shaded, (unsigned long long)my_hits);
+    }
+}
+
+// between bounces: reset what the next bounce appends to
+__global__ void rp_k_next_bounce(RpCounters *ctr, int next_out /* queue index the coming shade writes */) {
+    ctr->queue_count[next_out] = 0;
+    ctr->shadow_count = 0;
+    ctr->cursor_extend = 0;
+    ctr->cursor_connect = 0;
+}
+
+// ------------------------------------------------------------------ resolve
+// accumulate.glsl:68-73 (store this sample) + process_samples.comp:116-132 (running mean into the
+// history) + :143-190 (exposure, sRGB, RGBA8). One thread per local pixel, samples folded in order.
+__global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb) {
+    const int npix = f.width * f.local_rows;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const int ly = i / f.width, lx = i - ly * f.width;
+        if (rp_local_row_to_global(f, ly) >= f.height) continue;
+        const uint32_t slot = rp_local_to_slot(f, lx, ly);
+        float4 acc = accum[i];
+        for (int s = 0; s < f.batch_spp; ++s) {
+            const float4 il = ps.illum[size_t(s) * size_t(f.npix_padded) + slot];
+            const float4 c = make_float4(il.x, il.y, il.z, __float_as_int(il.w) == 0 ? 0.0f : 1.0f); // pt_megakernel.glsl:736
+            const uint32_t sample_index = f.sample_base + uint32_t(s);
+            if (sample_index == 0)
+                acc = c;
+            else {
+                const float denom = float(int(sample_index) + 1);
+                acc.x += (c.x - acc.x) / denom;
+                acc.y += (c.y - acc.y) / denom;
+                acc.z += (c.z - acc.z) / denom;
+                acc.w += (c.w - acc.w) / denom;
+            }
+        }
+        accum[i] = acc;
+        float4 o = acc;
+        o.w = fminf(o.w, 1.0f);
+        if (o.w >= 0.0f) {
+            const float e = exp2f(f.rp.exposure);
+            const float r = rp_linear_to_srgb(o.x * e), g = rp_linear_to_srgb(o.y * e), b = rp_linear_to_srgb(o.z * e);
+            fb[i] = make_uchar4((unsigned char)(clamp1(r, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(g, 0.f, 1.f) * 255.0f + 0.5f),
+                                (unsigned char)(clamp1(b, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RQ_CLOSEST, vulkan/rt_intersect.comp:31-68
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, int n, float4 *results, int *gstack) {
+    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+    RpStack st;
+    st.lds = lds_stack + threadIdx.x;
+    st.gstride = gridDim.x * blockDim.x;
+    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
+    st.sp = 0;
+    uint32_t nn = 0, nt = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 *qp = reinterpret_cast<const float4 *>(queries + i);
+        const float4 q0 = qp[0], q1 = qp[1];
+        const V3 o = v3(q0.x, q0.y, q0.z), d = v3(q1.x, q1.y, q1.z);
+        if (__float_as_int(q0.w) < 0) continue;
+        const float t_min = RPTR_RAY_EPSILON * len3(o);
+        RpHitRec h;
+        const bool found = rp_traverse<false, false>(sc, o, d, t_min, q1.w, h, st, nn, nt);
+        float4 r;
+        if (!found)
+            r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
+        else {
+            const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[25];
+            r = make_float4(h.u, h.v, __int_as_float(geometry_base + h.geom), __int_as_float(h.prim));
+        }
+        results[i] = r;
+    }
+}

@@ -1,0 +1,902 @@
+// rptr_hip.hip -- C ABI of the MI355X wavefront path tracer (include/rptr_hip.h).
+//
+// Host side of the backend: owns device memory, builds the acceleration
+// structures, sequences the wavefront stages on one HIP stream and does the
+// frame bookkeeping of RenderVulkan::begin_frame/draw_frame/end_frame
+// (vulkan/render_vulkan.cpp:1919-2178). There is no CPU rendering fallback: every
+// compute entry point fails with RPTR_E_NO_DEVICE / RPTR_E_HIP when no GPU works.
+#include "../../include/rptr_hip.h"
+
+#include "bvh_build.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct MeshRt { // one bottom-level structure
+    int node_base = 0;  // absolute index of the root in the shared node array
+    int node_count = 0;
+    int tri_base = 0;
+    int tri_count = 0;
+    float lo[3], hi[3];
+    bool dynamic = false;
+    rptr::BuiltTree tree; // kept for dynamic meshes (host refit fallback / leaf order)
+};
+
+} // namespace
+
+struct rptr_hip {
+    std::string last_error;
+    int device = 0;
+    int rank = 0, world = 1, stripe_rows = 32;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 0;
+    size_t bytes_allocated = 0;
+    std::vector<void *> allocations;
+
+    // frame
+    int width = 0, height = 0, local_rows = 0;
+    int tiles_x = 0, tiles_y = 0, npix_padded = 0;
+    int max_batch_spp = 0;
+    uint32_t frame_id = 0, frame_offset = 0;
+    int accumulated_spp = 0;
+
+    RptrRenderParams params;
+    RptrSceneParams scene_params;
+    RptrLightSamplingConfig lighting;
+    bool have_params = false;
+
+    // scene
+    bool have_scene = false;
+    RpScene dscene;
+    std::vector<RptrBvhNode> h_nodes;
+    std::vector<RptrBvhTri> h_tris;
+    std::vector<RptrBvhInstance> h_insts;
+    std::vector<MeshRt> meshes;
+    std::vector<void *> scene_allocs;
+    int num_lights = 0, num_materials = 0;
+
+    // device buffers (frame sized)
+    RpPathState ps;
+    RpShadowQueue sq;
+    uint32_t *queue[2] = {nullptr, nullptr};
+    uint32_t *order = nullptr, *keys = nullptr;
+    uint32_t *hist = nullptr, *bin_base = nullptr, *bin_cursor = nullptr;
+    RpCounters *counters = nullptr;
+    int *gstack = nullptr;
+    float4 *accum = nullptr;
+    uchar4 *fb = nullptr;
+    size_t path_capacity = 0;
+    int persistent_blocks = 0;
+
+    // options (environment, read once)
+    bool use_sort = true;
+    bool stage_timing = true;
+
+    RptrStats stats;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(rptr_hip *h, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->last_error = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess) return fail(h, RPTR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    h->bytes_allocated += bytes;
+    (track ? track : &h->allocations)->push_back(p);
+    *out = reinterpret_cast<T *>(p);
+    return RPTR_OK;
+}
+
+void free_list(std::vector<void *> &v) {
+    for (void *p : v) (void)hipFree(p);
+    v.clear();
+}
+
+// rows owned by `rank`: stripes s with s % world == rank
+int local_row_count(int height, int stripe_rows, int rank, int world) {
+    int n_stripes = (height + stripe_rows - 1) / stripe_rows;
+    int rows = 0;
+    for (int s = rank; s < n_stripes; s += world) rows += std::min(stripe_rows, height - s * stripe_rows);
+    return rows;
+}
+
+// inverse of a row-major 3x4 affine transform; cofactors in double, rounded once
+void invert_affine(const float m[12], float out[12]) {
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], hh = m[9], i = m[10];
+    double A = e * i - f * hh, B = -(d * i - f * g), C = d * hh - e * g;
+    double det = a * A + b * B + c * C;
+    double id = 1.0 / det;
+    double r[9] = {A * id, -(b * i - c * hh) * id, (b * f - c * e) * id, B * id, (a * i - c * g) * id, -(a * f - c * d) * id,
+                   C * id, -(a * hh - b * g) * id, (a * e - b * d) * id};
+    double tx = m[3], ty = m[7], tz = m[11];
+    for (int k = 0; k < 3; ++k) {
+        out[4 * k + 0] = (float)r[3 * k + 0];
+        out[4 * k + 1] = (float)r[3 * k + 1];
+        out[4 * k + 2] = (float)r[3 * k + 2];
+        out[4 * k + 3] = (float)(-(r[3 * k + 0] * tx + r[3 * k + 1] * ty + r[3 * k + 2] * tz));
+    }
+}
+
+// librender/dequantize.glsl:8-21 on the host: the BLAS is built from dequantised
+// floats exactly as the reference feeds them to the driver (render_vulkan.cpp:698-711)
+inline void dequantize_position(uint64_t w, const float sc[3], const float of[3], float out[3]) {
+    out[0] = float(uint32_t(w) & 0x1FFFFFu) * sc[0] + of[0];
+    out[1] = float(uint32_t(w >> 21) & 0x1FFFFFu) * sc[1] + of[1];
+    out[2] = float(uint32_t(w >> 42) & 0x1FFFFFu) * sc[2] + of[2];
+}
+
+hipEvent_t next_event(rptr_hip *h, size_t &cursor) {
+    if (cursor >= h->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[cursor++];
+}
+
+int grid_for(const rptr_hip *h, size_t n, int per_cu = 8) {
+    size_t blocks = (n + 255) / 256;
+    size_t cap = (size_t)h->num_cus * per_cu;
+    return (int)std::max<size_t>(1, std::min(blocks, cap));
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rptr_hip_name(void) { return "HIP wavefront path tracer (gfx950)"; }
+
+const char *rptr_hip_last_error(const rptr_hip_t *h) { return h ? h->last_error.c_str() : g_last_error.c_str(); }
+
+int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
+    if (!out) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, RPTR_E_NO_DEVICE, "no HIP device available (%s); this backend has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    rptr_hip *h = new rptr_hip();
+    memset(&h->stats, 0, sizeof(h->stats));
+    memset(&h->ps, 0, sizeof(h->ps));
+    memset(&h->sq, 0, sizeof(h->sq));
+    memset(&h->dscene, 0, sizeof(h->dscene));
+    h->device = info ? info->device_ordinal : 0;
+    h->rank = info ? info->rank : 0;
+    h->world = info && info->world_size > 0 ? info->world_size : 1;
+    h->stripe_rows = info && info->stripe_rows > 0 ? info->stripe_rows : 32;
+    if (h->stripe_rows % 8 != 0) {
+        delete h;
+        return fail(nullptr, RPTR_E_INVALID, "stripe_rows must be a multiple of 8");
+    }
+    if (h->device < 0 || h->device >= n_dev || h->rank < 0 || h->rank >= h->world) {
+        delete h;
+        return fail(nullptr, RPTR_E_INVALID, "bad device ordinal %d (of %d) or rank %d/%d", h->device, n_dev, h->rank, h->world);
+    }
+    if (hipSetDevice(h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, RPTR_E_NO_DEVICE, "hipSetDevice(%d) failed", info ? info->device_ordinal : 0);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+        delete h;
+        return fail(nullptr, RPTR_E_NO_DEVICE, "hipGetDeviceProperties failed");
+    }
+    h->num_cus = prop.multiProcessorCount;
+    if (info && info->stream) {
+        h->stream = (hipStream_t)info->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    (void)hipEventCreate(&h->ev_begin);
+    (void)hipEventCreate(&h->ev_end);
+    // defaults of RenderParams / LightSamplingConfig (librender/render_params.glsl.h:123-155)
+    memset(&h->params, 0, sizeof(h->params));
+    h->params.batch_spp = 1;
+    h->params.max_path_depth = RPTR_MAX_PATH_DEPTH;
+    h->params.rr_path_depth = RPTR_DEFAULT_RR_PATH_DEPTH;
+    h->params.focus_distance = 2.5f;
+    h->params.pixel_radius = 1.0f;
+    h->params.variance_radius = 4.0f;
+    h->params.early_tone_mapping_mode = -1;
+    h->params.spp_accumulation_window = 8;
+    h->params.render_upscale_factor = 1;
+    h->params.focal_length = 35.0f;
+    h->lighting = RptrLightSamplingConfig{0.0f, 16, 15.0f, 0.0f};
+    memset(&h->scene_params, 0, sizeof(h->scene_params));
+    h->scene_params.sun_dir[1] = 1.0f;
+    h->scene_params.sun_cos_angle = 0.99998933f;
+    h->scene_params.sun_radiance[3] = 1.0f;
+    h->scene_params.normal_z_scale = 1.0f;
+    if (const char *s = getenv("RPTR_SORT")) h->use_sort = atoi(s) != 0;
+    if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = atoi(s) != 0;
+    *out = h;
+    return RPTR_OK;
+}
+
+void rptr_hip_destroy(rptr_hip_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_list(h->allocations);
+    free_list(h->scene_allocs);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rptr_hip_set_stream(rptr_hip_t *h, void *hip_stream) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    (void)hipStreamSynchronize(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    h->own_stream = false;
+    if (hip_stream)
+        h->stream = (hipStream_t)hip_stream;
+    else {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RPTR_OK;
+}
+
+int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (fb_width <= 0 || fb_height <= 0) return fail(h, RPTR_E_INVALID, "bad framebuffer size %dx%d", fb_width, fb_height);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (void *p : h->allocations) (void)hipFree(p);
+    h->allocations.clear();
+    h->width = fb_width;
+    h->height = fb_height;
+    h->local_rows = local_row_count(fb_height, h->stripe_rows, h->rank, h->world);
+    h->tiles_x = (fb_width + 7) / 8;
+    h->tiles_y = (std::max(h->local_rows, 1) + 7) / 8;
+    h->npix_padded = h->tiles_x * h->tiles_y * 64;
+    // sample slots in flight: as many as fit a ~6 GiB path-state budget, at most 16
+    const size_t bytes_per_path = 16 * 5 + 8 + 8 + 3 * 16 + 4 * 4;
+    size_t budget = (size_t)6 << 30;
+    if (const char *s = getenv("RPTR_PATH_BUDGET_MB")) budget = (size_t)atoll(s) << 20;
+    int mb = (int)std::min<size_t>(16, std::max<size_t>(1, budget / (bytes_per_path * (size_t)h->npix_padded)));
+    if (const char *s = getenv("RPTR_MAX_BATCH_SPP")) mb = std::max(1, atoi(s));
+    h->max_batch_spp = mb;
+    const size_t cap = (size_t)h->npix_padded * mb;
+    h->path_capacity = cap;
+    int rc;
+    if ((rc = dev_alloc(h, &h->ps.ray_o, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.ray_d, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.thr, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.illum, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.rng_tt, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.hit_tuv, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->ps.hit_ids, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sq.o, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sq.d, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sq.contrib, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->queue[0], cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->queue[1], cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->order, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->keys, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->bin_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->bin_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->counters, 1, nullptr))) return rc;
+    const size_t npix_local = (size_t)h->width * std::max(h->local_rows, 1);
+    if ((rc = dev_alloc(h, &h->accum, npix_local, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->fb, npix_local, nullptr))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->accum, 0, npix_local * sizeof(float4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->fb, 0, npix_local * sizeof(uchar4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
+    // persistent traversal kernels: as many blocks as are co-resident
+    int occ = 0;
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false>, RP_TRAVERSE_BLOCK, 0));
+    occ = std::max(1, std::min(occ, 8));
+    if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
+    h->persistent_blocks = h->num_cus * occ;
+    const size_t stack_threads = (size_t)h->persistent_blocks * RP_TRAVERSE_BLOCK;
+    if ((rc = dev_alloc(h, &h->gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+    h->frame_id = 0;
+    h->frame_offset = 0;
+    h->accumulated_spp = 0;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return RPTR_OK;
+}
+
+int rptr_hip_set_params(rptr_hip_t *h, const RptrRenderParams *params, const RptrSceneParams *scene_params,
+                        const RptrLightSamplingConfig *lighting_params) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (params) {
+        if (params->max_path_depth < 1 || params->max_path_depth > 64) return fail(h, RPTR_E_INVALID, "max_path_depth out of range");
+        h->params = *params;
+    }
+    if (scene_params) h->scene_params = *scene_params;
+    if (lighting_params) {
+        if (lighting_params->bin_size < 1 || lighting_params->bin_size > RPTR_BINNED_LIGHTS_BIN_MAX_SIZE)
+            return fail(h, RPTR_E_INVALID, "bin_size must be in [1,%d]", RPTR_BINNED_LIGHTS_BIN_MAX_SIZE);
+        h->lighting = *lighting_params;
+    }
+    h->have_params = true;
+    return RPTR_OK;
+}
+
+int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
+    if (!h || !s) return fail(h, RPTR_E_INVALID, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (void *p : h->scene_allocs) {
+        (void)hipFree(p);
+    }
+    h->scene_allocs.clear();
+    h->have_scene = false;
+    // ---- validation (what the reference host rejects or this build does not cover yet)
+    for (uint32_t m = 0; m < s->num_materials; ++m) {
+        const RptrBaseMaterial &mat = s->materials[m];
+        if (mat.normal_map != -1) return fail(h, RPTR_E_UNSUPPORTED, "material %u: normal maps / textures are not supported yet", m);
+        if ((mat.flags & RPTR_BASE_MATERIAL_NOALPHA) == 0)
+            return fail(h, RPTR_E_UNSUPPORTED, "material %u: alpha-tested materials are not supported yet (set BASE_MATERIAL_NOALPHA)", m);
+        const uint32_t bits[4] = {0, 0, 0, 0};
+        (void)bits;
+        uint32_t u;
+        const float vals[5] = {mat.base_color[0], mat.roughness, mat.specular, mat.metallic, mat.ior};
+        for (float v : vals) {
+            memcpy(&u, &v, 4);
+            if (u & 0x80000000u) return fail(h, RPTR_E_UNSUPPORTED, "material %u: textured parameters are not supported yet", m);
+        }
+    }
+    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p)
+        if (s->parameterized_meshes[p].mesh >= s->num_meshes) return fail(h, RPTR_E_INVALID, "parameterized mesh %u: bad mesh index", p);
+    for (uint32_t i = 0; i < s->num_instances; ++i)
+        if (s->instances[i].parameterized_mesh >= s->num_parameterized_meshes) return fail(h, RPTR_E_INVALID, "instance %u: bad mesh", i);
+
+    int rc;
+    // ---- upload vertex streams, one allocation per stream
+    std::vector<const uint64_t *> d_qpos(s->num_geometries, nullptr), d_qnu(s->num_geometries, nullptr);
+    for (uint32_t g = 0; g < s->num_geometries; ++g) {
+        const RptrGeometryDesc &gd = s->geometries[g];
+        uint64_t *dp = nullptr;
+        if ((rc = dev_alloc(h, &dp, (size_t)gd.num_tris * 3, &h->scene_allocs))) return rc;
+        if (gd.num_tris) HIP_TRY(h, hipMemcpy(dp, gd.qpos, (size_t)gd.num_tris * 24, hipMemcpyHostToDevice));
+        d_qpos[g] = dp;
+        if (gd.qnrm_uv && (gd.has_normals || gd.has_uvs)) {
+            uint64_t *dn = nullptr;
+            if ((rc = dev_alloc(h, &dn, (size_t)gd.num_tris * 3, &h->scene_allocs))) return rc;
+            if (gd.num_tris) HIP_TRY(h, hipMemcpy(dn, gd.qnrm_uv, (size_t)gd.num_tris * 24, hipMemcpyHostToDevice));
+            d_qnu[g] = dn;
+        }
+    }
+    // ---- geometry records per (parameterized mesh, geometry): instanced_geometry[] (render_vulkan.cpp:2748-2850)
+    std::vector<RpGeomRecord> geoms;
+    std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
+    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p) {
+        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[p];
+        const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+        pmesh_base[p] = (int)geoms.size();
+        size_t total_tris = 0;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) total_tris += s->geometries[mesh.first_geometry + j].num_tris;
+        uint8_t *d_ids = nullptr;
+        if (pm.tri_material_ids) {
+            if ((rc = dev_alloc(h, &d_ids, total_tris, &h->scene_allocs))) return rc;
+            if (total_tris) HIP_TRY(h, hipMemcpy(d_ids, pm.tri_material_ids, total_tris, hipMemcpyHostToDevice));
+        }
+        size_t prim_offset = 0;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const uint32_t gi = mesh.first_geometry + j;
+            const RptrGeometryDesc &gd = s->geometries[gi];
+            RpGeomRecord r;
+            memset(&r, 0, sizeof(r));
+            r.qpos = d_qpos[gi];
+            r.qnrm_uv = d_qnu[gi];
+            r.mat_ids = d_ids ? d_ids + prim_offset : nullptr;
+            r.dyn_pos = nullptr;
+            memcpy(r.scaling, gd.quantized_scaling, 12);
+            memcpy(r.offset, gd.quantized_offset, 12);
+            r.material_id = d_ids ? -1 - pm.material_offsets[j] : pm.material_offsets[j];
+            r.flags = (gd.has_normals && d_qnu[gi] ? RP_GEOM_HAS_NORMALS : 0u) | (gd.has_uvs && d_qnu[gi] ? RP_GEOM_HAS_UVS : 0u);
+            // material index range check
+            const int max_local = d_ids ? 255 : 0;
+            if (pm.material_offsets[j] < 0 || (uint32_t)(pm.material_offsets[j]) >= s->num_materials)
+                return fail(h, RPTR_E_INVALID, "parameterized mesh %u geometry %u: material offset out of range", p, j);
+            (void)max_local;
+            geoms.push_back(r);
+            prim_offset += gd.num_tris;
+        }
+    }
+    // ---- bottom-level BVHs (one per mesh), built from dequantised floats
+    h->h_nodes.clear();
+    h->h_tris.clear();
+    h->h_insts.clear();
+    h->meshes.assign(s->num_meshes, MeshRt());
+    std::vector<RptrBvhNode> blas_nodes; // relocated behind the TLAS afterwards
+    for (uint32_t m = 0; m < s->num_meshes; ++m) {
+        const RptrMeshDesc &mesh = s->meshes[m];
+        std::vector<rptr::BuildPrim> prims;
+        std::vector<RptrBvhTri> mtris;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
+            for (uint32_t t = 0; t < gd.num_tris; ++t) {
+                float v[3][3];
+                for (int k = 0; k < 3; ++k) dequantize_position(gd.qpos[3 * (size_t)t + k], gd.quantized_scaling, gd.quantized_offset, v[k]);
+                RptrBvhTri tri;
+                rptr::BuildPrim bp;
+                for (int k = 0; k < 3; ++k) {
+                    tri.v0[k] = v[0][k];
+                    tri.e1[k] = v[1][k] - v[0][k];
+                    tri.e2[k] = v[2][k] - v[0][k];
+                    bp.lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
+                    bp.hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+                }
+                tri.prim = t;
+                tri.geom = j;
+                tri._pad = 0;
+                mtris.push_back(tri);
+                prims.push_back(bp);
+            }
+        }
+        MeshRt &mr = h->meshes[m];
+        mr.dynamic = mesh.dynamic != 0;
+        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, mr.tree);
+        mr.node_base = (int)blas_nodes.size();
+        mr.node_count = (int)mr.tree.nodes.size();
+        mr.tri_base = (int)h->h_tris.size();
+        mr.tri_count = (int)mtris.size();
+        memcpy(mr.lo, mr.tree.lo, 12);
+        memcpy(mr.hi, mr.tree.hi, 12);
+        for (uint32_t id : mr.tree.order) h->h_tris.push_back(mtris[id]);
+        for (RptrBvhNode nd : mr.tree.nodes) {
+            if (nd.child0 >= 0) nd.child0 += mr.node_base; else nd.child0 = ~((~nd.child0) + mr.tri_base);
+            if (nd.child1 >= 0) nd.child1 += mr.node_base; else nd.child1 = ~((~nd.child1) + mr.tri_base);
+            blas_nodes.push_back(nd);
+        }
+        if (!mr.dynamic) {
+            mr.tree.nodes.clear();
+            mr.tree.nodes.shrink_to_fit();
+        }
+    }
+    // ---- top level over instance bounds (1 instance per leaf)
+    std::vector<rptr::BuildPrim> iprims(s->num_instances);
+    std::vector<RptrBvhInstance> insts(s->num_instances);
+    for (uint32_t i = 0; i < s->num_instances; ++i) {
+        const RptrInstanceDesc &in = s->instances[i];
+        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
+        const MeshRt &mr = h->meshes[pm.mesh];
+        RptrBvhInstance bi;
+        memset(&bi, 0, sizeof(bi));
+        memcpy(bi.object_to_world, in.transform, 48);
+        invert_affine(in.transform, bi.world_to_object);
+        bi.blas_root = mr.node_base; // relocated below
+        bi.geometry_base = pmesh_base[in.parameterized_mesh];
+        bi.instance_id = (int)i;
+        insts[i] = bi;
+        rptr::BuildPrim &bp = iprims[i];
+        for (int k = 0; k < 3; ++k) {
+            bp.lo[k] = INFINITY;
+            bp.hi[k] = -INFINITY;
+        }
+        for (int c = 0; c < 8; ++c) {
+            const float p[3] = {c & 1 ? mr.hi[0] : mr.lo[0], c & 2 ? mr.hi[1] : mr.lo[1], c & 4 ? mr.hi[2] : mr.lo[2]};
+            const float *M = in.transform;
+            for (int r = 0; r < 3; ++r) {
+                const float w = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
+                bp.lo[r] = std::fmin(bp.lo[r], w);
+                bp.hi[r] = std::fmax(bp.hi[r], w);
+            }
+        }
+    }
+    rptr::BuiltTree tlas;
+    rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
+    const int reloc = (int)tlas.nodes.size();
+    h->h_nodes = tlas.nodes; // TLAS leaf 'first' already indexes the reordered instance array
+    for (RptrBvhNode nd : blas_nodes) {
+        if (nd.child0 >= 0) nd.child0 += reloc;
+        if (nd.child1 >= 0) nd.child1 += reloc;
+        h->h_nodes.push_back(nd);
+    }
+    for (MeshRt &mr : h->meshes) mr.node_base += reloc;
+    h->h_insts.resize(s->num_instances);
+    for (uint32_t k = 0; k < s->num_instances; ++k) {
+        h->h_insts[k] = insts[tlas.order[k]];
+        h->h_insts[k].blas_root += reloc;
+    }
+    // ---- upload
+    RptrBvhNode *d_nodes = nullptr;
+    RptrBvhTri *d_tris = nullptr;
+    RptrBvhInstance *d_insts = nullptr;
+    RpGeomRecord *d_geoms = nullptr;
+    RptrBaseMaterial *d_mats = nullptr;
+    RptrTriLightData *d_lights = nullptr;
+    if ((rc = dev_alloc(h, &d_nodes, h->h_nodes.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &d_tris, h->h_tris.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &d_insts, h->h_insts.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &d_geoms, geoms.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &d_mats, s->num_materials, &h->scene_allocs))) return rc;
+    // light buffer padded with one zeroed bin (+1): sample_tri_lights may read light_id == bin_end
+    const size_t light_cap = (size_t)s->num_lights + RPTR_BINNED_LIGHTS_BIN_MAX_SIZE + 1;
+    if ((rc = dev_alloc(h, &d_lights, light_cap, &h->scene_allocs))) return rc;
+    HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode), hipMemcpyHostToDevice));
+    if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(d_tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyHostToDevice));
+    if (!h->h_insts.empty())
+        HIP_TRY(h, hipMemcpy(d_insts, h->h_insts.data(), h->h_insts.size() * sizeof(RptrBvhInstance), hipMemcpyHostToDevice));
+    if (!geoms.empty()) HIP_TRY(h, hipMemcpy(d_geoms, geoms.data(), geoms.size() * sizeof(RpGeomRecord), hipMemcpyHostToDevice));
+    if (s->num_materials) HIP_TRY(h, hipMemcpy(d_mats, s->materials, s->num_materials * sizeof(RptrBaseMaterial), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemset(d_lights, 0, light_cap * sizeof(RptrTriLightData)));
+    if (s->num_lights) HIP_TRY(h, hipMemcpy(d_lights, s->lights, s->num_lights * sizeof(RptrTriLightData), hipMemcpyHostToDevice));
+    h->dscene.nodes = d_nodes;
+    h->dscene.tris = d_tris;
+    h->dscene.insts = d_insts;
+    h->dscene.geoms = d_geoms;
+    h->dscene.materials = d_mats;
+    h->dscene.lights = d_lights;
+    h->dscene.num_lights = (int)s->num_lights;
+    h->dscene.num_materials = (int)s->num_materials;
+    h->num_lights = (int)s->num_lights;
+    h->num_materials = (int)s->num_materials;
+    h->have_scene = true;
+    // a new scene restarts accumulation (Shell::set_scene -> reset, libapp/shell.cpp:96-126)
+    h->frame_offset += h->frame_id;
+    h->frame_id = 0;
+    return RPTR_OK;
+}
+
+int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t, const float *, uint32_t) {
+    return fail(h, RPTR_E_UNSUPPORTED, "dynamic meshes (update_vertices/refit) are not built yet");
+}
+int rptr_hip_refit(rptr_hip_t *h) { return fail(h, RPTR_E_UNSUPPORTED, "dynamic meshes (update_vertices/refit) are not built yet"); }
+
+// host part of a3: vulkan/render_vulkan.cpp:2880-2896
+static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    auto normalize = [](float v[3]) {
+        float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+        v[0] *= inv;
+        v[1] *= inv;
+        v[2] *= inv;
+    };
+    const float plane_y = 2.f * tanf((0.5f * c.fovy) * 0.01745329251994329576923690768489f);
+    const float aspect = static_cast<float>(W) / H;
+    const float plane_x = plane_y * aspect;
+    float du[3], dv[3];
+    cross(c.dir, c.up, du);
+    normalize(du);
+    for (int k = 0; k < 3; ++k) du[k] *= plane_x;
+    cross(du, c.dir, dv);
+    normalize(dv);
+    for (int k = 0; k < 3; ++k) dv[k] = -dv[k] * plane_y;
+    for (int k = 0; k < 3; ++k) {
+        f.cam_pos[k] = c.pos[k];
+        f.cam_du[k] = du[k];
+        f.cam_dv[k] = dv[k];
+        f.cam_dir_top_left[k] = c.dir[k] - 0.5f * du[k] - 0.5f * dv[k];
+    }
+}
+
+extern "C++" {
+template <int VARIANT>
+static void launch_shade(rptr_hip *h, const RpFrame &f, const uint32_t *order, int in, int out) {
+    const int grid = grid_for(h, h->path_capacity);
+    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, h->stream, h->dscene, f, h->ps, h->sq, order,
+                       &h->counters->queue_count[in], h->queue[out], &h->counters->queue_count[out], h->counters);
+}
+} // extern "C++"
+
+int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation, int count_traversal,
+                    RptrStats *out_stats) {
+    if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "render before set_scene");
+    if (h->width == 0) return fail(h, RPTR_E_INVALID, "render before initialize");
+    if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE) return fail(h, RPTR_E_INVALID, "unknown variant %d", variant);
+    if (spp < 1) return fail(h, RPTR_E_INVALID, "spp must be >= 1");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // begin_frame: render_vulkan.cpp:1937-1941
+    if (reset_accumulation) {
+        h->frame_offset += h->frame_id;
+        h->frame_id = 0;
+    }
+    RpFrame f;
+    memset(&f, 0, sizeof(f));
+    f.rp = h->params;
+    f.sp = h->scene_params;
+    f.lc = h->lighting;
+    compute_view(*camera, h->width, h->height, f);
+    f.frame_offset = h->frame_offset;
+    f.variant = variant;
+    f.width = h->width;
+    f.height = h->height;
+    f.local_rows = h->local_rows;
+    f.tiles_x = h->tiles_x;
+    f.tiles_y = h->tiles_y;
+    f.npix_padded = h->npix_padded;
+    f.rank = h->rank;
+    f.world = h->world;
+    f.stripe_rows = h->stripe_rows;
+    f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
+    const int num_keys = std::min(h->num_materials + 1, RP_SORT_MAX_KEYS);
+
+    size_t ev_cursor = 0;
+    struct Span {
+        hipEvent_t a, b;
+        int kind; // 0 extend, 1 connect, 2 other
+    };
+    std::vector<Span> spans;
+    auto timed = [&](int kind, auto &&launch) {
+        if (h->stage_timing) {
+            hipEvent_t a = next_event(h, ev_cursor), b = next_event(h, ev_cursor);
+            (void)hipEventRecord(a, h->stream);
+            launch();
+            (void)hipEventRecord(b, h->stream);
+            spans.push_back({a, b, kind});
+        } else
+            launch();
+    };
+
+    HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
+    RpCounters zero;
+    memset(&zero, 0, sizeof(zero));
+    int launches_extend = 0, launches_connect = 0;
+    RpCounters totals;
+    memset(&totals, 0, sizeof(totals));
+    std::vector<RpCounters> batch_counters;
+    batch_counters.reserve((size_t)spp);
+    int remaining = spp;
+    const bool local_work = h->local_rows > 0;
+    while (remaining > 0) {
+        const int batch = std::min(remaining, h->max_batch_spp);
+        f.sample_base = h->frame_id;
+        f.batch_spp = batch;
+        if (local_work) {
+            HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(RpCounters), h->stream));
+            const size_t total = (size_t)batch * h->npix_padded;
+            timed(2, [&] {
+                hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, h->stream, f, h->ps, h->queue[0], h->counters);
+            });
+            for (int b = 0; b < h->params.max_path_depth; ++b) {
+                const int in = b & 1, out = in ^ 1;
+                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, out);
+                timed(0, [&] {
+                    if (count_traversal)
+                        hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
+                                           h->queue[in], &h->counters->queue_count[in], h->counters, h->gstack);
+                    else
+                        hipLaunchKernelGGL(rp_k_extend<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
+                                           h->queue[in], &h->counters->queue_count[in], h->counters, h->gstack);
+                });
+                launches_extend++;
+                const uint32_t *order = h->queue[in];
+                if (h->use_sort) {
+                    timed(2, [&] {
+                        const int grid = grid_for(h, total);
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(grid), dim3(256), 0, h->stream, h->dscene, h->ps, h->queue[in],
+                                           &h->counters->queue_count[in], h->keys, h->hist, num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(RP_SORT_MAX_KEYS), 0, h->stream, h->hist, h->bin_base, h->bin_cursor,
+                                           num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(grid), dim3(256), 0, h->stream, h->queue[in], &h->counters->queue_count[in],
+                                           h->keys, h->bin_base, h->bin_cursor, h->order);
+                    });
+                    order = h->order;
+                }
+                timed(2, [&] {
+                    if (variant == RPTR_VARIANT_SIMPLE)
+                        launch_shade<RPTR_VARIANT_SIMPLE>(h, f, order, in, out);
+                    else
+                        launch_shade<RPTR_VARIANT_GLTF>(h, f, order, in, out);
+                });
+                timed(1, [&] {
+                    if (count_traversal)
+                        hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
+                                           h->sq, h->counters, h->gstack);
+                    else
+                        hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
+                                           h->sq, h->counters, h->gstack);
+                });
+                launches_connect++;
+            }
+            timed(2, [&] {
+                const size_t npix = (size_t)h->width * h->local_rows;
+                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, h->stream, f, h->ps, h->accum, h->fb);
+            });
+            batch_counters.emplace_back();
+            HIP_TRY(h, hipMemcpyAsync(&batch_counters.back(), h->counters, sizeof(RpCounters), hipMemcpyDeviceToHost, h->stream));
+            // the host copy above must land before the next batch's memset: batches are few, sync here
+            if (remaining - batch > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+        // end_frame: render_vulkan.cpp:2152-2154
+        h->accumulated_spp = int(h->frame_id) + batch;
+        h->frame_id += (uint32_t)batch;
+        remaining -= batch;
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipGetLastError());
+    RptrStats &st = h->stats;
+    memset(&st, 0, sizeof(st));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev_begin, h->ev_end);
+    st.render_time_ms = ms;
+    for (const Span &sp : spans) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, sp.a, sp.b);
+        if (sp.kind == 0) st.extend_time_ms += t;
+        else if (sp.kind == 1) st.connect_time_ms += t;
+        else st.shade_time_ms += t;
+    }
+    for (const RpCounters &c : batch_counters) {
+        st.rays_closest += c.rays_closest;
+        st.rays_shadow += c.rays_shadow;
+        st.nodes_visited += c.nodes;
+        st.tris_tested += c.tris;
+        st.hits_shaded += c.hits_shaded;
+    }
+    st.spp = h->accumulated_spp;
+    st.launches_extend = launches_extend;
+    st.launches_connect = launches_connect;
+    st.device_bytes_allocated = h->bytes_allocated;
+    if (out_stats) *out_stats = st;
+    return RPTR_OK;
+}
+
+int rptr_hip_stats(const rptr_hip_t *h, RptrStats *out) {
+    if (!h || !out) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    *out = h->stats;
+    return RPTR_OK;
+}
+
+int rptr_hip_get_framebuffer_size(const rptr_hip_t *h, uint32_t out_whc[3]) {
+    if (!h || !out_whc) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    out_whc[0] = (uint32_t)h->width;
+    out_whc[1] = (uint32_t)h->height;
+    out_whc[2] = 4;
+    return RPTR_OK;
+}
+
+int rptr_hip_tile_rows(const rptr_hip_t *h, int rank, int32_t *first_and_count, int cap) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    const int n_stripes = (h->height + h->stripe_rows - 1) / h->stripe_rows;
+    int n = 0;
+    for (int s = rank; s < n_stripes; s += h->world) {
+        if (first_and_count && n < cap) {
+            first_and_count[2 * n] = s * h->stripe_rows;
+            first_and_count[2 * n + 1] = std::min(h->stripe_rows, h->height - s * h->stripe_rows);
+        }
+        ++n;
+    }
+    return n;
+}
+
+int rptr_hip_local_pixel_count(const rptr_hip_t *h, uint64_t *out_pixels) {
+    if (!h || !out_pixels) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    *out_pixels = (uint64_t)h->width * (uint64_t)h->local_rows;
+    return RPTR_OK;
+}
+
+int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes) {
+    if (!h || !device_dst) return fail(h, RPTR_E_INVALID, "NULL argument");
+    const size_t need = (size_t)h->width * h->local_rows * sizeof(float4);
+    if (n_bytes < need) return fail(h, RPTR_E_INVALID, "destination too small: %zu < %zu", n_bytes, need);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (need) HIP_TRY(h, hipMemcpyAsync(device_dst, h->accum, need, hipMemcpyDeviceToDevice, h->stream));
+    return RPTR_OK;
+}
+
+extern "C++" {
+template <class T>
+static int readback_rows(rptr_hip *h, const T *dev_local, T *host_full, size_t n_elems_host) {
+    const size_t need = (size_t)h->width * h->height;
+    if (n_elems_host < need) return fail(h, RPTR_E_INVALID, "read-back buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<T> tmp((size_t)h->width * std::max(h->local_rows, 1));
+    if (h->local_rows)
+        HIP_TRY(h, hipMemcpyAsync(tmp.data(), dev_local, (size_t)h->width * h->local_rows * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int n_stripes = (h->height + h->stripe_rows - 1) / h->stripe_rows;
+    int local_row = 0;
+    for (int s = h->rank; s < n_stripes; s += h->world) {
+        const int first = s * h->stripe_rows, cnt = std::min(h->stripe_rows, h->height - first);
+        memcpy(host_full + (size_t)first * h->width, tmp.data() + (size_t)local_row * h->width, (size_t)cnt * h->width * sizeof(T));
+        local_row += cnt;
+    }
+    return RPTR_OK;
+}
+} // extern "C++"
+
+int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
+    if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
+    return readback_rows<float4>(h, h->accum, reinterpret_cast<float4 *>(rgba), n_floats / 4);
+}
+int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
+    if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
+    return readback_rows<uchar4>(h, h->fb, reinterpret_cast<uchar4 *>(rgba), n_bytes / 4);
+}
+
+int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4) {
+    if (!h || !queries || !out4 || n < 0) return fail(h, RPTR_E_INVALID, "bad argument");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "trace before set_scene");
+    if (!h->gstack) return fail(h, RPTR_E_INVALID, "trace before initialize");
+    if (n == 0) return RPTR_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    RptrRenderRayQuery *dq = nullptr;
+    float4 *dr = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&dq, (size_t)n * sizeof(RptrRenderRayQuery)));
+    if (hipMalloc((void **)&dr, (size_t)n * sizeof(float4)) != hipSuccess) {
+        (void)hipFree(dq);
+        return fail(h, RPTR_E_NOMEM, "hipMalloc failed");
+    }
+    int rc = RPTR_OK;
+    do {
+        if (hipMemcpyAsync(dq, queries, (size_t)n * sizeof(RptrRenderRayQuery), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(dr, out4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            rc = fail(h, RPTR_E_HIP, "upload failed");
+            break;
+        }
+        const int grid = std::min(h->persistent_blocks, (n + RP_TRAVERSE_BLOCK - 1) / RP_TRAVERSE_BLOCK);
+        hipLaunchKernelGGL(rp_k_trace, dim3(grid), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, n, dr, h->gstack);
+        if (hipMemcpyAsync(out4, dr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            rc = fail(h, RPTR_E_HIP, "trace kernel failed");
+            break;
+        }
+    } while (0);
+    (void)hipFree(dq);
+    (void)hipFree(dr);
+    return rc;
+}
+
+int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances, size_t *n_instances) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "export before set_scene");
+    if (nodes && n_nodes && *n_nodes >= h->h_nodes.size()) memcpy(nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode));
+    if (tris && n_tris && *n_tris >= h->h_tris.size()) memcpy(tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri));
+    if (instances && n_instances && *n_instances >= h->h_insts.size())
+        memcpy(instances, h->h_insts.data(), h->h_insts.size() * sizeof(RptrBvhInstance));
+    if (n_nodes) *n_nodes = h->h_nodes.size();
+    if (n_tris) *n_tris = h->h_tris.size();
+    if (n_instances) *n_instances = h->h_insts.size();
+    return RPTR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.build()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The HIP C-ABI library; GPU tests fail loudly when it is missing (no fallback)."""
+    from realtimepathtracingresearchframework_amd import backend
+    return backend.load_library()
