@@ -79,4 +79,20 @@ int ref_update_sky_light(const float sun_dir_in[3], float turbidity, const float
     return 0;
 }
 
+// Reference evaluation of the RGB sky (sky_model.cpp:644-658): used to pin the
+// GLSL restatement of skymodel_radiance for sun-at-zenith configurations, where
+// the shader's gamma (it uses the zenith angle, sky_model.glsl:48) coincides
+// with the sun angle the C code expects.
+int ref_sky_radiance(const float sun_dir_in[3], float turbidity, const float albedo[3], const double *theta, const double *gamma, int n,
+                     double *out_rgb) {
+    float l = std::sqrt(sun_dir_in[0] * sun_dir_in[0] + sun_dir_in[1] * sun_dir_in[1] + sun_dir_in[2] * sun_dir_in[2]);
+    float sun_y = sun_dir_in[1] * (1.0f / l);
+    ArHosekSkyModelState state;
+    float albedo_avg = albedo[0] * 0.3333f + albedo[1] * 0.3333f + albedo[2] * 0.3333f;
+    arhosek_rgb_skymodelstate_alloc_init(turbidity, albedo_avg, sun_y, &state);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) out_rgb[3 * i + c] = arhosek_tristim_skymodel_radiance(&state, theta[i], gamma[i], c);
+    return 0;
+}
+
 } // extern "C"

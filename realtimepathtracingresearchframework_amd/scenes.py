@@ -391,7 +391,8 @@ def _heightfield(nx, nz, x0, x1, z0, z1, height_fn):
     N = np.stack([-dYdx, np.ones_like(dYdx), -dYdz], axis=-1)
     N /= np.linalg.norm(N, axis=-1, keepdims=True)
     P = np.stack([X, Y, Z], axis=-1)
-    UV = np.stack([(X - x0) / (x1 - x0) * 7.5, (Z - z0) / (z1 - z0) * 7.5], axis=-1)
+    # representable uv range of quantize_uv: u in [0,8), v in (-7,1] (16 bit over 8 units, quantize.h:38-42)
+    UV = np.stack([(X - x0) / (x1 - x0) * 7.5, 1.0 - (Z - z0) / (z1 - z0) * 7.5], axis=-1)
 
     def tri_attr(A):
         a00, a10, a01, a11 = A[:-1, :-1], A[1:, :-1], A[:-1, 1:], A[1:, 1:]

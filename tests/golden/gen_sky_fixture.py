@@ -37,6 +37,18 @@ def main():
             e["sun_cos_angle"] = float(out.sun_cos_angle)
             e["sun_radiance_" + tag] = [float(x) for x in out.sun_radiance]
         entries[key] = e
+    # evaluation golden vectors for the sun-at-zenith config: the reference's C evaluation
+    # (arhosek_tristim_skymodel_radiance) on directions where theta == gamma
+    import numpy as np
+    lib.ref_sky_radiance.argtypes = [C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    cfg = SKY_CONFIGS["default"]
+    cos_t = np.linspace(0.0, 1.0, 33)
+    theta = np.arccos(cos_t)
+    out = np.zeros((len(theta), 3))
+    lib.ref_sky_radiance((C.c_float * 3)(*cfg["sun_dir"]), cfg["turbidity"], (C.c_float * 3)(*cfg["albedo"]),
+                         theta.ctypes.data, theta.ctypes.data, len(theta), out.ctypes.data)
+    entries["default"]["eval_cos_theta"] = [float(x) for x in cos_t]
+    entries["default"]["eval_rgb_times_100"] = [[float(v) for v in row] for row in out]
     doc = {"generator": "tests/golden/gen_sky_fixture.py", "source": "oracle/_ref/libsky_ref.so <- reference sky_model.cpp + render_sky.cpp:25-72",
            "entries": entries}
     with open(os.path.join(ROOT, "tests", "golden", "sky_params.json"), "w") as f:

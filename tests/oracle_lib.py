@@ -97,10 +97,11 @@ class OracleScene:
         return lib().orc_scene_import_bvh(self.h, _p(nodes), nodes.size * nodes.itemsize // 64, _p(tris), tris.size * tris.itemsize // 48,
                                           _p(insts), insts.size * insts.itemsize // 128)
 
-    def trace(self, queries, bvh_mode=BVH_OWN, count=False):
-        """queries: structured array/bytes of RenderRayQuery (n,8) float32 view. Returns (n,4) float32 [, (nodes,tris)]."""
+    def trace(self, queries, bvh_mode=BVH_OWN, count=False, out=None):
+        """queries: (n,8) float32 view of RenderRayQuery[n]. Returns (n,4) float32 [, (nodes,tris)]."""
         q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
-        out = np.zeros((len(q), 4), dtype=np.float32)
+        if out is None:
+            out = np.zeros((len(q), 4), dtype=np.float32)
         cnt = np.zeros(2, dtype=np.uint64)
         rc = lib().orc_trace(self.h, bvh_mode, _p(q), len(q), _p(out), _p(cnt) if count else None)
         assert rc == 0
