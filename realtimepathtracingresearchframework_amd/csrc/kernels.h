@@ -11,8 +11,12 @@
 //
 // Path state is SoA, indexed by path id = sample_slot * npix_padded + tiled pixel
 // slot. Every kernel reads its work count from device memory, so one frame is a
-// fixed launch sequence without host round trips. Queue appends use one atomic
-// per wave (ballot + mbcnt prefix).
+// fixed launch sequence without host round trips.
+//
+// Queue discipline (one device word sustains only ~88 atomics/us on MI355X, see
+// MI355X_MICROARCH.md "dequeue"): producers compact into an LDS staging buffer
+// with wave-level ballot + mbcnt prefix sums and publish a whole 1024-entry chunk
+// with ONE global atomic; persistent consumers pull 256 entries per atomic.
 #pragma once
 #include "dtraverse.h"
 
@@ -25,10 +29,13 @@ struct RpPathState {
     float4 *hit_tuv; // t, u, v, bits(prim)
     int2 *hit_ids;   // inst_idx, geom
 };
-struct RpShadowQueue {
+// shadow rays live at the slot of their path (at most one per path and bounce);
+// the shadow queue itself only carries path ids
+struct RpShadowRays {
     float4 *o;       // origin.xyz, t_min
     float4 *d;       // dir.xyz, t_max
-    float4 *contrib; // radiance to add if visible .xyz, bits(path)
+    float4 *contrib; // radiance to add if visible .xyz
+    uint32_t *ids;   // compacted path ids
 };
 // device-side counters, one block of them per frame
 struct RpCounters {
@@ -43,10 +50,13 @@ struct RpCounters {
 };
 
 #define RP_SORT_MAX_KEYS 1024
+#define RP_SORT_BLOCKS 512
+#define RP_CHUNK 1024     // entries a producer block publishes per global atomic
+#define RP_FETCH 256      // entries a consumer wave pulls per global atomic
 
 // ---- wave64 helpers
 RP_DEV uint32_t rp_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-// appends `flag` lanes to a queue with one atomic per wave; returns slot (valid only where flag)
+// reserves one slot per flagged lane with one atomic per wave (counter may live in LDS or global memory)
 RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
     const unsigned long long mask = __ballot(flag);
     if (mask == 0ull) return 0u;
@@ -62,42 +72,61 @@ RP_DEV uint32_t rp_wave_sum_u32(uint32_t v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+// publishes `n_local` staged ids from LDS to a global queue: one atomic per block
+RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *queue, uint32_t *counter, uint32_t *s_base) {
+    if (threadIdx.x == 0) *s_base = n_local ? atomicAdd(counter, n_local) : 0u;
+    __syncthreads();
+    const uint32_t base = *s_base;
+    for (uint32_t j = threadIdx.x; j < n_local; j += blockDim.x) queue[base + j] = staged[j];
+}
 
 // ------------------------------------------------------------------ raygen
 __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, uint32_t *queue, RpCounters *ctr) {
+    __shared__ uint32_t s_ids[RP_CHUNK];
+    __shared__ uint32_t s_n, s_base;
     const uint32_t total = uint32_t(f.batch_spp) * uint32_t(f.npix_padded);
-    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < ((total + 63u) & ~63u); p += gridDim.x * blockDim.x) {
-        bool valid = p < total;
-        int lx = 0, ly = 0;
-        uint32_t slot = 0, sslot = 0;
-        if (valid) {
-            sslot = p / uint32_t(f.npix_padded);
-            slot = p - sslot * uint32_t(f.npix_padded);
-            valid = rp_slot_to_local(f, slot, lx, ly);
+    const uint32_t nchunks = (total + RP_CHUNK - 1) / RP_CHUNK;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t k = 0; k < RP_CHUNK / 256; ++k) {
+            const uint32_t p = chunk * RP_CHUNK + k * 256 + threadIdx.x;
+            bool valid = p < total;
+            int lx = 0, ly = 0;
+            uint32_t slot = 0, sslot = 0;
+            if (valid) {
+                sslot = p / uint32_t(f.npix_padded);
+                slot = p - sslot * uint32_t(f.npix_padded);
+                valid = rp_slot_to_local(f, slot, lx, ly);
+            }
+            int gy = 0;
+            if (valid) {
+                gy = rp_local_row_to_global(f, ly);
+                valid = gy < f.height;
+            }
+            if (valid) {
+                // pt_megakernel.glsl:314-325
+                const uint32_t sample_index = f.sample_base + sslot;
+                uint32_t rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+                V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
+                if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
+                point = v2(point.x / float(f.width), point.y / float(f.height));
+                V3 dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
+                ps.ray_o[p] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], 0.0f);
+                ps.ray_d[p] = f4(dir, 2.e32f);
+                ps.thr[p] = make_float4(1.f, 1.f, 1.f, 2.e16f); // init_shading_sample_state, shading_interface.glsl:20-22
+                ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                ps.rng_tt[p] = make_float2(__uint_as_float(rng), 0.0f);
+            } else if (p < total) {
+                ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+            }
+            const uint32_t at = rp_wave_append(&s_n, valid);
+            if (valid) s_ids[at] = p;
         }
-        int gy = 0;
-        if (valid) {
-            gy = rp_local_row_to_global(f, ly);
-            valid = gy < f.height;
-        }
-        if (valid) {
-            // pt_megakernel.glsl:314-325
-            const uint32_t sample_index = f.sample_base + sslot;
-            uint32_t rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
-            V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
-            if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
-            point = v2(point.x / float(f.width), point.y / float(f.height));
-            V3 dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
-            ps.ray_o[p] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], 0.0f);
-            ps.ray_d[p] = f4(dir, 2.e32f);
-            ps.thr[p] = make_float4(1.f, 1.f, 1.f, 2.e16f); // init_shading_sample_state, shading_interface.glsl:20-22
-            ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-            ps.rng_tt[p] = make_float2(__uint_as_float(rng), 0.0f);
-        } else if (p < total) {
-            ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-        }
-        const uint32_t at = rp_wave_append(&ctr->queue_count[0], valid);
-        if (valid) queue[at] = p;
+        __syncthreads();
+        rp_block_flush(s_ids, s_n, queue, &ctr->queue_count[0], &s_base);
+        __syncthreads();
     }
 }
 
@@ -116,17 +145,20 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpP
     uint32_t n_nodes = 0, n_tris = 0;
     for (;;) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->cursor_extend, 64u);
+        if (lane == 0) base = atomicAdd(&ctr->cursor_extend, (uint32_t)RP_FETCH);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const uint32_t p = queue[i];
-            const float4 o = ps.ray_o[p], d = ps.ray_d[p];
-            RpHitRec h;
-            rp_traverse<false, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
-            ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-            ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+#pragma unroll 1
+        for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            if (i < n) {
+                const uint32_t p = queue[i];
+                const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+                RpHitRec h;
+                rp_traverse<false, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
+                ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+                ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+            }
         }
     }
     if (COUNT) {
@@ -141,7 +173,7 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpP
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 template <bool COUNT>
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, RpPathState ps, RpShadowQueue sq, RpCounters *ctr, int *gstack) {
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpCounters *ctr, int *gstack) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
     RpStack st;
     st.lds = lds_stack + threadIdx.x;
@@ -153,22 +185,25 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, Rp
     uint32_t n_nodes = 0, n_tris = 0;
     for (;;) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->cursor_connect, 64u);
+        if (lane == 0) base = atomicAdd(&ctr->cursor_connect, (uint32_t)RP_FETCH);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
-        const uint32_t i = base + lane;
-        if (i < n) {
-            const float4 o = sq.o[i], d = sq.d[i];
-            RpHitRec h;
-            const bool occluded = rp_traverse<true, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
-            if (!occluded) {
-                const float4 c = sq.contrib[i];
-                const uint32_t p = __float_as_uint(c.w);
-                float4 il = ps.illum[p];
-                il.x += c.x;
-                il.y += c.y;
-                il.z += c.z;
-                ps.illum[p] = il;
+#pragma unroll 1
+        for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            if (i < n) {
+                const uint32_t p = sq.ids[i];
+                const float4 o = sq.o[p], d = sq.d[p];
+                RpHitRec h;
+                const bool occluded = rp_traverse<true, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
+                if (!occluded) {
+                    const float4 c = sq.contrib[p];
+                    float4 il = ps.illum[p];
+                    il.x += c.x;
+                    il.y += c.y;
+                    il.z += c.z;
+                    ps.illum[p] = il;
+                }
             }
         }
     }
@@ -183,6 +218,10 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, Rp
 }
 
 // ------------------------------------------------------------------ sort by material
+// A counting sort over the ray queue with no global atomics: RP_SORT_BLOCKS blocks
+// each own a contiguous slice of the queue; count -> per-(key, block) histogram,
+// scan -> exclusive offsets in key-major order, scatter -> wave-level multi-split
+// (ballot per distinct key, mbcnt rank) against per-block LDS cursors.
 // key 0 = miss, 1 + min(material id, K-2) otherwise
 RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpPathState &ps, uint32_t p, int num_keys) {
     const int2 ids = ps.hit_ids[p];
@@ -193,274 +232,313 @@ RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpPathState &ps, uint32_t p
     const int mid = rp_hit_material_id(g, uint32_t(prim));
     return 1u + uint32_t(min(mid, num_keys - 2));
 }
+RP_DEV void rp_sort_slice(uint32_t n, uint32_t &begin, uint32_t &end) {
+    uint32_t per = (n + RP_SORT_BLOCKS - 1) / RP_SORT_BLOCKS;
+    per = (per + 255u) & ~255u;
+    begin = min(n, blockIdx.x * per);
+    end = min(n, begin + per);
+}
+// adds, per distinct key present in the wave, the number of lanes holding it to cursor[key];
+// returns the lane's rank inside its key group plus the group's previous cursor value
+RP_DEV uint32_t rp_wave_multisplit(uint32_t *cursor, uint32_t key, bool valid) {
+    const uint32_t lane = rp_lane_id();
+    uint32_t pos = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = __shfl(key, leader);
+        const unsigned long long same = __ballot(valid && key == k);
+        uint32_t b = 0;
+        if (int(lane) == leader) b = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
+        b = __shfl(b, leader);
+        if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return pos;
+}
 __global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                                       uint32_t *keys, uint32_t *hist, int num_keys) {
+                                                       uint32_t *keys, uint32_t *block_hist, int num_keys) {
     __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
     for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
     __syncthreads();
-    const uint32_t n = *count_ptr;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t key = rp_sort_key(sc, ps, queue[i], num_keys);
-        keys[i] = key;
-        atomicAdd(&lh[key], 1u);
+    uint32_t begin, end;
+    rp_sort_slice(*count_ptr, begin, end);
+    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
+        const bool valid = i < end;
+        uint32_t key = 0;
+        if (valid) {
+            key = rp_sort_key(sc, ps, queue[i], num_keys);
+            keys[i] = key;
+        }
+        (void)rp_wave_multisplit(lh, key, valid);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
-        if (lh[k]) atomicAdd(&hist[k], lh[k]);
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) block_hist[k * RP_SORT_BLOCKS + blockIdx.x] = lh[k];
 }
-// single block: exclusive scan of hist -> base, zero the cursors
-__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *hist, uint32_t *base, uint32_t *cursor, int num_keys) {
-    __shared__ uint32_t s[RP_SORT_MAX_KEYS];
-    const int t = threadIdx.x;
-    s[t] = t < num_keys ? hist[t] : 0u;
+// single block: in-place exclusive scan over num_keys * RP_SORT_BLOCKS counters (key-major)
+__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *block_hist, int num_keys) {
+    __shared__ uint32_t partial[1024];
+    const uint32_t total = uint32_t(num_keys) * RP_SORT_BLOCKS;
+    const uint32_t per = (total + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = min(total, b + per);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += block_hist[i];
+    partial[threadIdx.x] = sum;
     __syncthreads();
-    for (int off = 1; off < RP_SORT_MAX_KEYS; off <<= 1) {
-        uint32_t v = t >= off ? s[t - off] : 0u;
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = int(threadIdx.x) >= off ? partial[threadIdx.x - off] : 0u;
         __syncthreads();
-        s[t] += v;
+        partial[threadIdx.x] += v;
         __syncthreads();
     }
-    if (t < num_keys) {
-        base[t] = s[t] - hist[t];
-        cursor[t] = 0u;
-        hist[t] = 0u; // ready for the next bounce
+    uint32_t run = partial[threadIdx.x] - sum;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t c = block_hist[i];
+        block_hist[i] = run;
+        run += c;
     }
 }
 __global__ __launch_bounds__(256) void rp_k_sort_scatter(const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
-                                                         const uint32_t *base, uint32_t *cursor, uint32_t *order) {
-    const uint32_t n = *count_ptr;
-    const uint32_t lane = rp_lane_id();
-    const uint32_t n_round = (n + 63u) & ~63u;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
-        const bool valid = i < n;
-        const uint32_t key = valid ? keys[i] : 0xFFFFFFFFu;
-        uint32_t pos = 0;
-        // wave-level multi-split: one atomic per distinct key per wave
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t k = __shfl(key, leader);
-            const unsigned long long same = __ballot(valid && key == k);
-            uint32_t b = 0;
-            if (int(lane) == leader) b = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
-            b = __shfl(b, leader);
-            if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            todo &= ~same;
-        }
-        if (valid) order[base[key] + pos] = queue[i];
+                                                         const uint32_t *block_offsets, uint32_t *order, int num_keys) {
+    __shared__ uint32_t cur[RP_SORT_MAX_KEYS];
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) cur[k] = block_offsets[k * RP_SORT_BLOCKS + blockIdx.x];
+    __syncthreads();
+    uint32_t begin, end;
+    rp_sort_slice(*count_ptr, begin, end);
+    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
+        const bool valid = i < end;
+        const uint32_t key = valid ? keys[i] : 0u;
+        const uint32_t pos = rp_wave_multisplit(cur, key, valid);
+        if (valid) order[pos] = queue[i];
     }
 }
 
 // ------------------------------------------------------------------ shade
 template <int VARIANT>
-__global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowQueue sq, const uint32_t *order,
+__global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, RpCounters *ctr) {
+    __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
+    __shared__ uint32_t s_nn, s_ns, s_base;
+    __shared__ uint32_t s_stat[3];
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     const uint32_t n = *count_ptr;
-    const uint32_t n_round = (n + 63u) & ~63u;
+    const uint32_t nchunks = (n + RP_CHUNK - 1) / RP_CHUNK;
     uint32_t my_closest = 0, my_shadow = 0, my_hits = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
-        bool alive = false;       // path continues with a new ray
-        bool has_shadow = false;  // a shadow query is issued
-        uint32_t p = 0;
-        float4 sh_o, sh_d, sh_c;
-        if (i < n) {
-            p = order[i];
-            my_closest++;
-            const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
-            float4 thr4 = ps.thr[p];
-            float4 il4 = ps.illum[p];
-            const float2 rt = ps.rng_tt[p];
-            uint32_t rng = __float_as_uint(rt.x);
-            float total_t = rt.y;
-            const float4 hit4 = ps.hit_tuv[p];
-            const int2 ids = ps.hit_ids[p];
-            V3 ray_origin = xyz(ro4), ray_dir = xyz(rd4);
-            V3 throughput = xyz(thr4), illum = xyz(il4);
-            float prev_bounce_pdf = thr4.w;
-            int bounce = __float_as_int(il4.w);
-            if (ids.x < 0) {
-                // miss: pt_megakernel.glsl:480-489
-                illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
-                ps.illum[p] = f4(illum, __int_as_float(bounce));
-            } else {
-                my_hits++;
-                // ---- hit attributes, pt_megakernel.glsl:495-572
-                const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
-                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-                const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
-                const RpGeomRecord g = sc.geoms[meta.y + ids.y];
-                const uint32_t prim = uint32_t(__float_as_int(hit4.w));
-                // transpose(mat3(world_to_object)): its columns are the rows of world_to_object
-                const M3 n2w{v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z)};
-                RpHit hit = rp_calc_hit_attributes(g, hit4.x, prim, hit4.y, hit4.z, n2w);
-                // :578-580
-                float approx_tri_solid_angle = len3(hit.geo_normal);
-                hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
-                approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
-                // :585,605
-                total_t += hit.dist;
-                const float geometry_scale = total_t;
-                const V3 w_o = -ray_dir;
-                V3 ip_p = ray_origin + hit.dist * ray_dir;
-                V3 gn = hit.geo_normal, nn = hit.normal;
-                const RptrBaseMaterial mp = sc.materials[hit.material_id];
-                // :624-633
-                if (dot3(w_o, gn) < 0.0f) {
-                    if ((mp.flags & RPTR_BASE_MATERIAL_VOLUME) != 0) {
-                        ip_p = ray_origin;
-                        hit.dist = 0.0f;
-                    } else if ((mp.flags & RPTR_BASE_MATERIAL_ONESIDED) == 0) {
-                        nn = -nn;
-                        gn = -gn;
-                    }
-                }
-                // :656-668
-                {
-                    const float nw = dot3(w_o, nn);
-                    const float gnw = dot3(w_o, gn);
-                    if (nw * gnw <= 0.0f) {
-                        const float blend = gnw / (gnw - nw);
-                        nn = norm3(mix3(gn, nn, blend - RP_EPSILON));
-                    }
-                }
-                // :677-678
-                const V3 v_y = norm3(cross3(nn, hit.tangent));
-                const V3 v_x = cross3(v_y, nn);
-
-                // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
-                RpMaterial mat;
-                V3 emit;
-                rp_unpack_material<VARIANT>(mat, emit, mp);
-                const V3 scatter_throughput = throughput;
-                const int output_channel = f.rp.output_channel;
-                if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
-                    // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
-                    const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));
-                    const float w = rp_nee_mis(prev_bounce_pdf, light_pdf);
-                    illum = illum + w * scatter_throughput * emit;
-                }
-                if (output_channel != 0) {
-                    const float reliability = powf(0.25f, float(bounce));
-                    if (output_channel == 1)
-                        illum = illum + scatter_throughput * mat.base_color * reliability;
-                    else if (output_channel == 2)
-                        illum = illum + nn * reliability;
-                    else if (output_channel == 3)
-                        illum = illum + ip_p * reliability;
-                }
-                bool terminate = (bounce + 1 >= f.rp.max_path_depth);
-                if (!terminate) {
-                    if (output_channel == 0) {
-                        // ---- sample_direct_light, rendering/mc/nee.glsl:32-90
-                        const V2 dir_sample = rp_rand2(rng);
-                        V2 sel_sample = rp_rand2(rng);
-                        V3 nee = v3s(0.0f);
-                        V3 light_dir = v3s(0.0f);
-                        float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
-                        const float sun_w = f.sp.sun_radiance[3];
-                        if (sel_sample.x <= sun_w) {
-                            sel_sample.x /= sun_w;
-                            light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
-                            light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
-                            nee = nee + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
-                            light_pdf *= sun_w;
-                            mis_pdf = light_pdf;
-                        } else {
-                            sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
-                            float tri_mis_wpdf = 0.0f;
-                            nee = nee + rp_sample_tri_lights(sc, f, ip_p, nn, dir_sample, sel_sample, light_dir, light_dist, light_pdf, tri_mis_wpdf) /
-                                            (1.0f - sun_w);
-                            light_pdf *= 1.0f - sun_w;
-                            if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x == 0) {
+            s_nn = 0;
+            s_ns = 0;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
+            const uint32_t i = chunk * RP_CHUNK + kk * 256 + threadIdx.x;
+            bool alive = false;      // path continues with a new ray
+            bool has_shadow = false; // a shadow query is issued
+            uint32_t p = 0;
+            if (i < n) {
+                p = order[i];
+                my_closest++;
+                const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
+                float4 thr4 = ps.thr[p];
+                float4 il4 = ps.illum[p];
+                const float2 rt = ps.rng_tt[p];
+                uint32_t rng = __float_as_uint(rt.x);
+                float total_t = rt.y;
+                const float4 hit4 = ps.hit_tuv[p];
+                const int2 ids = ps.hit_ids[p];
+                V3 ray_origin = xyz(ro4), ray_dir = xyz(rd4);
+                V3 throughput = xyz(thr4), illum = xyz(il4);
+                float prev_bounce_pdf = thr4.w;
+                int bounce = __float_as_int(il4.w);
+                if (ids.x < 0) {
+                    // miss: pt_megakernel.glsl:480-489
+                    illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
+                    ps.illum[p] = f4(illum, __int_as_float(bounce));
+                } else {
+                    my_hits++;
+                    // ---- hit attributes, pt_megakernel.glsl:495-572
+                    const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
+                    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                    const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
+                    const RpGeomRecord g = sc.geoms[meta.y + ids.y];
+                    const uint32_t prim = uint32_t(__float_as_int(hit4.w));
+                    // transpose(mat3(world_to_object)): its columns are the rows of world_to_object
+                    const M3 n2w{v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z)};
+                    RpHit hit = rp_calc_hit_attributes(g, hit4.x, prim, hit4.y, hit4.z, n2w);
+                    // :578-580
+                    float approx_tri_solid_angle = len3(hit.geo_normal);
+                    hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
+                    approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
+                    // :585,605
+                    total_t += hit.dist;
+                    const float geometry_scale = total_t;
+                    const V3 w_o = -ray_dir;
+                    V3 ip_p = ray_origin + hit.dist * ray_dir;
+                    V3 gn = hit.geo_normal, nn = hit.normal;
+                    const RptrBaseMaterial mp = sc.materials[hit.material_id];
+                    // :624-633
+                    if (dot3(w_o, gn) < 0.0f) {
+                        if ((mp.flags & RPTR_BASE_MATERIAL_VOLUME) != 0) {
+                            ip_p = ray_origin;
+                            hit.dist = 0.0f;
+                        } else if ((mp.flags & RPTR_BASE_MATERIAL_ONESIDED) == 0) {
+                            nn = -nn;
+                            gn = -gn;
                         }
-                        if (light_pdf > 0.0f && dot3(light_dir, gn) * dot3(light_dir, nn) > 0.0f) {
-                            // raytrace_test_visibility is deferred to the connect stage; everything that
-                            // does not depend on its answer is evaluated here (nee.glsl:73-84)
-                            const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
-                            const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
-                            const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
-                            if (needs_ray) my_shadow++;
-                            if (bsdf_pdf >= 0.0f) {
-                                const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
-                                const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
-                                nee = nee * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
-                                const V3 c = scatter_throughput * nee;
-                                if (needs_ray) {
-                                    has_shadow = true;
-                                    sh_o = f4(ip_p, epsilon);
-                                    sh_d = f4(light_dir, light_dist - epsilon);
-                                    sh_c = f4(c, __uint_as_float(p));
-                                } else
-                                    illum = illum + c; // visibility defaults to true
-                            } else if (needs_ray) {
-                                // the reference still traces this ray (its result is unused): count it,
-                                // but there is nothing to connect
+                    }
+                    // :656-668
+                    {
+                        const float nw = dot3(w_o, nn);
+                        const float gnw = dot3(w_o, gn);
+                        if (nw * gnw <= 0.0f) {
+                            const float blend = gnw / (gnw - nw);
+                            nn = norm3(mix3(gn, nn, blend - RP_EPSILON));
+                        }
+                    }
+                    // :677-678
+                    const V3 v_y = norm3(cross3(nn, hit.tangent));
+                    const V3 v_x = cross3(v_y, nn);
+
+                    // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
+                    RpMaterial mat;
+                    V3 emit;
+                    rp_unpack_material<VARIANT>(mat, emit, mp);
+                    const V3 scatter_throughput = throughput;
+                    const int output_channel = f.rp.output_channel;
+                    if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
+                        // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
+                        const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));
+                        const float w = rp_nee_mis(prev_bounce_pdf, light_pdf);
+                        illum = illum + w * scatter_throughput * emit;
+                    }
+                    if (output_channel != 0) {
+                        const float reliability = powf(0.25f, float(bounce));
+                        if (output_channel == 1)
+                            illum = illum + scatter_throughput * mat.base_color * reliability;
+                        else if (output_channel == 2)
+                            illum = illum + nn * reliability;
+                        else if (output_channel == 3)
+                            illum = illum + ip_p * reliability;
+                    }
+                    bool terminate = (bounce + 1 >= f.rp.max_path_depth);
+                    if (!terminate) {
+                        if (output_channel == 0) {
+                            // ---- sample_direct_light, rendering/mc/nee.glsl:32-90
+                            const V2 dir_sample = rp_rand2(rng);
+                            V2 sel_sample = rp_rand2(rng);
+                            V3 nee = v3s(0.0f);
+                            V3 light_dir = v3s(0.0f);
+                            float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
+                            const float sun_w = f.sp.sun_radiance[3];
+                            if (sel_sample.x <= sun_w) {
+                                sel_sample.x /= sun_w;
+                                light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
+                                light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
+                                nee = nee + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
+                                light_pdf *= sun_w;
+                                mis_pdf = light_pdf;
+                            } else {
+                                sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
+                                float tri_mis_wpdf = 0.0f;
+                                nee = nee + rp_sample_tri_lights(sc, f, ip_p, nn, dir_sample, sel_sample, light_dir, light_dist, light_pdf,
+                                                                 tri_mis_wpdf) /
+                                                (1.0f - sun_w);
+                                light_pdf *= 1.0f - sun_w;
+                                if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
+                            }
+                            if (light_pdf > 0.0f && dot3(light_dir, gn) * dot3(light_dir, nn) > 0.0f) {
+                                // raytrace_test_visibility is deferred to the connect stage; everything that
+                                // does not depend on its answer is evaluated here (nee.glsl:73-84)
+                                const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
+                                const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
+                                const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
+                                if (needs_ray) my_shadow++; // the reference traces it even when bsdf_pdf < 0
+                                if (bsdf_pdf >= 0.0f) {
+                                    const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
+                                    const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
+                                    nee = nee * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
+                                    const V3 c = scatter_throughput * nee;
+                                    if (needs_ray) {
+                                        has_shadow = true;
+                                        sq.o[p] = f4(ip_p, epsilon);
+                                        sq.d[p] = f4(light_dir, light_dist - epsilon);
+                                        sq.contrib[p] = f4(c, 0.0f);
+                                    } else
+                                        illum = illum + c; // visibility defaults to true
+                                }
+                            }
+                        }
+                        if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
+                    }
+                    if (!terminate) {
+                        const V2 lobe_sample = rp_rand2(rng);
+                        const V2 dir_sample = rp_rand2(rng);
+                        V3 w_i = v3s(0.0f);
+                        float sampling_pdf = 0.0f, mis_pdf = 0.0f;
+                        V3 bsdf;
+                        if (VARIANT == RPTR_VARIANT_SIMPLE)
+                            bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample);
+                        else
+                            bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample, lobe_sample, v_x, v_y);
+                        ++bounce;
+                        if (eq3(bsdf, v3s(0.f)) || mis_pdf == 0.f || !(dot3(w_i, nn) * dot3(w_i, gn) > 0.0f))
+                            terminate = true;
+                        else {
+                            throughput = throughput * bsdf;
+                            prev_bounce_pdf = mis_pdf;
+                            // pt_megakernel.glsl:703-709
+                            ray_dir = w_i;
+                            ray_origin = ip_p;
+                            const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
+                            // :713-730 Russian roulette
+                            bool survive = true;
+                            if (bounce >= f.rp.rr_path_depth) {
+                                const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
+                                float rr_prob = prefix_weight;
+                                const float rr_sample = rp_randf(rng);
+                                rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
+                                if (rr_sample < rr_prob)
+                                    throughput = throughput / rr_prob;
+                                else
+                                    survive = false;
+                            }
+                            if (survive) {
+                                alive = true;
+                                ps.ray_o[p] = f4(ray_origin, t_min);
+                                ps.ray_d[p] = f4(ray_dir, 1e20f);
+                                ps.thr[p] = f4(throughput, prev_bounce_pdf);
+                                ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
                             }
                         }
                     }
-                    if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
+                    ps.illum[p] = f4(illum, __int_as_float(bounce));
                 }
-                if (!terminate) {
-                    const V2 lobe_sample = rp_rand2(rng);
-                    const V2 dir_sample = rp_rand2(rng);
-                    V3 w_i = v3s(0.0f);
-                    float sampling_pdf = 0.0f, mis_pdf = 0.0f;
-                    V3 bsdf;
-                    if (VARIANT == RPTR_VARIANT_SIMPLE)
-                        bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample);
-                    else
-                        bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample, lobe_sample, v_x, v_y);
-                    ++bounce;
-                    if (eq3(bsdf, v3s(0.f)) || mis_pdf == 0.f || !(dot3(w_i, nn) * dot3(w_i, gn) > 0.0f))
-                        terminate = true;
-                    else {
-                        throughput = throughput * bsdf;
-                        prev_bounce_pdf = mis_pdf;
-                        // pt_megakernel.glsl:703-709
-                        ray_dir = w_i;
-                        ray_origin = ip_p;
-                        const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
-                        // :713-730 Russian roulette
-                        bool survive = true;
-                        if (bounce >= f.rp.rr_path_depth) {
-                            const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
-                            float rr_prob = prefix_weight;
-                            const float rr_sample = rp_randf(rng);
-                            rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
-                            if (rr_sample < rr_prob)
-                                throughput = throughput / rr_prob;
-                            else
-                                survive = false;
-                        }
-                        // the loop bound of pt_megakernel.glsl:417: no further iteration after max_path_depth
-                        if (survive) {
-                            alive = true;
-                            ps.ray_o[p] = f4(ray_origin, t_min);
-                            ps.ray_d[p] = f4(ray_dir, 1e20f);
-                            ps.thr[p] = f4(throughput, prev_bounce_pdf);
-                            ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
-                        }
-                    }
-                }
-                ps.illum[p] = f4(illum, __int_as_float(bounce));
             }
+            const uint32_t at = rp_wave_append(&s_nn, alive);
+            if (alive) s_next[at] = p;
+            const uint32_t sat = rp_wave_append(&s_ns, has_shadow);
+            if (has_shadow) s_shadow[sat] = p;
         }
-        const uint32_t at = rp_wave_append(next_count, alive);
-        if (alive) next_queue[at] = p;
-        const uint32_t sat = rp_wave_append(&ctr->shadow_count, has_shadow);
-        if (has_shadow) {
-            sq.o[sat] = sh_o;
-            sq.d[sat] = sh_d;
-            sq.contrib[sat] = sh_c;
-        }
+        __syncthreads();
+        rp_block_flush(s_next, s_nn, next_queue, next_count, &s_base);
+        __syncthreads();
+        rp_block_flush(s_shadow, s_ns, sq.ids, &ctr->shadow_count, &s_base);
+        __syncthreads();
     }
     my_closest = rp_wave_sum_u32(my_closest);
     my_shadow = rp_wave_sum_u32(my_shadow);
     my_hits = rp_wave_sum_u32(my_hits);
     if (rp_lane_id() == 0) {
-        if (my_closest) atomicAdd(&ctr->rays_closest, (unsigned long long)my_closest);
-        if (my_shadow) atomicAdd(&ctr->rays_shadow, (unsigned long long)my_shadow);
-        if (my_hits) atomicAdd(&ctr->hits_shaded, (unsigned long long)my_hits);
+        atomicAdd(&s_stat[0], my_closest);
+        atomicAdd(&s_stat[1], my_shadow);
+        atomicAdd(&s_stat[2], my_hits);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_stat[0]) atomicAdd(&ctr->rays_closest, (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&ctr->rays_shadow, (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&ctr->hits_shaded, (unsigned long long)s_stat[2]);
     }
 }
 

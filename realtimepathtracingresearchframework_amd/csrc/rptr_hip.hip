@@ -74,10 +74,10 @@ struct rptr_hip {
 
     // device buffers (frame sized)
     RpPathState ps;
-    RpShadowQueue sq;
+    RpShadowRays sq;
     uint32_t *queue[2] = {nullptr, nullptr};
     uint32_t *order = nullptr, *keys = nullptr;
-    uint32_t *hist = nullptr, *bin_base = nullptr, *bin_cursor = nullptr;
+    uint32_t *block_hist = nullptr;
     RpCounters *counters = nullptr;
     int *gstack = nullptr;
     float4 *accum = nullptr;
@@ -297,7 +297,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->tiles_y = (std::max(h->local_rows, 1) + 7) / 8;
     h->npix_padded = h->tiles_x * h->tiles_y * 64;
     // sample slots in flight: as many as fit a ~6 GiB path-state budget, at most 16
-    const size_t bytes_per_path = 16 * 5 + 8 + 8 + 3 * 16 + 4 * 4;
+    const size_t bytes_per_path = 16 * 5 + 8 + 8 + 3 * 16 + 5 * 4;
     size_t budget = (size_t)6 << 30;
     if (const char *s = getenv("RPTR_PATH_BUDGET_MB")) budget = (size_t)atoll(s) << 20;
     int mb = (int)std::min<size_t>(16, std::max<size_t>(1, budget / (bytes_per_path * (size_t)h->npix_padded)));
@@ -316,20 +316,18 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if ((rc = dev_alloc(h, &h->sq.o, cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->sq.d, cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->sq.contrib, cap, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sq.ids, cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->queue[0], cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->queue[1], cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->order, cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->keys, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->bin_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->bin_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->block_hist, (size_t)RP_SORT_MAX_KEYS * RP_SORT_BLOCKS, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->counters, 1, nullptr))) return rc;
     const size_t npix_local = (size_t)h->width * std::max(h->local_rows, 1);
     if ((rc = dev_alloc(h, &h->accum, npix_local, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->fb, npix_local, nullptr))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->accum, 0, npix_local * sizeof(float4), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->fb, 0, npix_local * sizeof(uchar4), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false>, RP_TRAVERSE_BLOCK, 0));
@@ -710,13 +708,11 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
                 const uint32_t *order = h->queue[in];
                 if (h->use_sort) {
                     timed(2, [&] {
-                        const int grid = grid_for(h, total);
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(grid), dim3(256), 0, h->stream, h->dscene, h->ps, h->queue[in],
-                                           &h->counters->queue_count[in], h->keys, h->hist, num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(RP_SORT_MAX_KEYS), 0, h->stream, h->hist, h->bin_base, h->bin_cursor,
-                                           num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(grid), dim3(256), 0, h->stream, h->queue[in], &h->counters->queue_count[in],
-                                           h->keys, h->bin_base, h->bin_cursor, h->order);
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->dscene, h->ps, h->queue[in],
+                                           &h->counters->queue_count[in], h->keys, h->block_hist, num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, h->stream, h->block_hist, num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->queue[in],
+                                           &h->counters->queue_count[in], h->keys, h->block_hist, h->order, num_keys);
                     });
                     order = h->order;
                 }
