@@ -9,9 +9,11 @@
  *   - a node stores the AABBs of BOTH children (Aila/Laine style), so one
  *     64-byte fetch decides both slab tests;
  *   - child >= 0 : inner node index (absolute, into the shared node array)
- *     child <  0 : leaf. first = ~child; count in cnt0/cnt1.
- *                  In the TLAS a leaf lists `count` RptrBvhInstance records,
- *                  in a BLAS it lists `count` RptrBvhTri records.
+ *     child <  0 : leaf, packed so that it can sit on the traversal stack as is:
+ *                  v = -2 - child; first = v >> 3; count = v & 7
+ *                  (RPTR_BVH_LEAF(first,count) / RPTR_BVH_LEAF_FIRST / _COUNT);
+ *                  cnt0/cnt1 repeat the count. In the TLAS a leaf lists `count`
+ *                  (0 or 1) RptrBvhInstance records, in a BLAS `count` RptrBvhTri.
  *   - an empty child (count == 0 leaf) has an inverted box (lo=+inf, hi=-inf).
  */
 #ifndef RPTR_BVH_H
@@ -22,7 +24,10 @@
 extern "C" {
 #endif
 
-#define RPTR_BVH_MAX_LEAF_TRIS 4
+#define RPTR_BVH_MAX_LEAF_TRIS 4 /* must stay <= 7 (3 count bits) */
+#define RPTR_BVH_LEAF(first, count) (-2 - (int32_t)((uint32_t)(first) * 8u + (uint32_t)(count)))
+#define RPTR_BVH_LEAF_FIRST(child) ((int32_t)((uint32_t)(-2 - (child)) >> 3))
+#define RPTR_BVH_LEAF_COUNT(child) ((int32_t)((uint32_t)(-2 - (child)) & 7u))
 #define RPTR_BVH_STACK_DEPTH 64
 
 typedef struct RptrBvhNode { /* 64 bytes */

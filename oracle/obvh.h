@@ -263,7 +263,7 @@ static int flatten(const std::vector<TmpNode> &tmp, std::vector<RptrBvhNode> &no
         float *lo = which ? n.lo1 : n.lo0, *hi = which ? n.hi1 : n.hi0;
         for (int k = 0; k < 3; ++k) { lo[k] = tmp[tmp_idx].lo[k]; hi[k] = tmp[tmp_idx].hi[k]; }
         if (is_leaf(tmp_idx)) {
-            (which ? n.child1 : n.child0) = ~(int32_t)(leaf_base + tmp[tmp_idx].first);
+            (which ? n.child1 : n.child0) = RPTR_BVH_LEAF(leaf_base + tmp[tmp_idx].first, tmp[tmp_idx].count);
             (which ? n.cnt1 : n.cnt0) = (int32_t)tmp[tmp_idx].count;
         } else {
             (which ? n.child1 : n.child0) = out_idx;
@@ -274,7 +274,7 @@ static int flatten(const std::vector<TmpNode> &tmp, std::vector<RptrBvhNode> &no
         RptrBvhNode n;
         set_child(n, 0, 0, -1);
         box_init(n.lo1, n.hi1);
-        n.child1 = ~0;
+        n.child1 = RPTR_BVH_LEAF(0, 0);
         n.cnt1 = 0;
         nodes[root_out] = n;
         return root_out;
@@ -392,11 +392,21 @@ static void build_bvh(const SceneView &sv, Bvh &bvh) {
 }
 
 // ------------------------------------------------------------------ traversal
-// One algorithm, closest or any-hit; defines the canonical visit order:
-//  at a node: slab-test both children against [tmin, best.t]; handle the
-//  nearer one first (tie -> child 0); a leaf child is intersected on the spot,
-//  an inner child becomes the next node (near) or is pushed (far); the far
-//  child is re-tested against the possibly shortened best.t.
+// One algorithm, closest or any-hit; it defines the canonical visit order (and
+// with it the node / triangle counts of the roofline model):
+//   * work items are inner nodes (>= 0), leaves (encoded <= -2) and the
+//     instance-exit sentinel; the current item is processed, then the next one
+//     is popped from the stack;
+//   * inner node: fetch, slab-test both children against [t_min, best_t]; if both
+//     are hit, the farther one is pushed and the nearer one becomes current
+//     (tie -> child 0 is nearer); if one is hit it becomes current;
+//   * BLAS leaf: every triangle of the leaf is tested; TLAS leaf (one instance):
+//     the ray is transformed into object space, the sentinel is pushed and the
+//     instance's root becomes current.
+static inline void decode_leaf(int enc, int &first, int &count) {
+    first = RPTR_BVH_LEAF_FIRST(enc);
+    count = RPTR_BVH_LEAF_COUNT(enc);
+}
 template <bool ANY>
 static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
     best.t = ray.tmax;
@@ -412,37 +422,45 @@ static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *c
     const RptrBvhInstance *cur_inst = nullptr;
     int cur = 0;
     for (;;) {
-        // cur >= 0: inner node to visit
-        const RptrBvhNode &n = nodes[cur];
-        if (cnt) cnt->nodes++;
-        float tn0, tn1;
-        bool h0 = slab(n.lo0, n.hi0, o, id, ray.tmin, best.t, tn0);
-        bool h1 = slab(n.lo1, n.hi1, o, id, ray.tmin, best.t, tn1);
-        int next = -1; // -1: pop
-        bool have_next = false;
-        for (int pass = 0; pass < 2; ++pass) {
-            bool first_is_1 = h1 && (!h0 || tn1 < tn0);
-            int which = (pass == 0) ? (first_is_1 ? 1 : 0) : (first_is_1 ? 0 : 1);
-            bool hit = which ? h1 : h0;
-            if (!hit) continue;
-            float tn = which ? tn1 : tn0;
-            if (pass == 1 && !(tn <= best.t * 1.0000005f)) continue;
-            int child = which ? n.child1 : n.child0;
-            int count = which ? n.cnt1 : n.cnt0;
-            if (child >= 0) {
-                if (!have_next) { next = child; have_next = true; }
-                else stack[sp++] = child;
-            } else if (cur_inst == nullptr) {
-                // TLAS leaf: `count` instances (count <= 1 by construction)
-                int first = ~child;
+        bool pop = false;
+        if (cur >= 0) {
+            const RptrBvhNode &n = nodes[cur];
+            if (cnt) cnt->nodes++;
+            float tn0, tn1;
+            const bool h0 = slab(n.lo0, n.hi0, o, id, ray.tmin, best.t, tn0);
+            const bool h1 = slab(n.lo1, n.hi1, o, id, ray.tmin, best.t, tn1);
+            const int c0 = n.child0, c1 = n.child1;
+            if (h0 && h1) {
+                const bool near1 = tn1 < tn0;
+                stack[sp++] = near1 ? c0 : c1;
+                cur = near1 ? c1 : c0;
+            } else if (h0)
+                cur = c0;
+            else if (h1)
+                cur = c1;
+            else
+                pop = true;
+        } else if (cur == SENTINEL) {
+            cur_inst = nullptr;
+            o = ray.o;
+            d = ray.d;
+            id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+            pop = true;
+        } else {
+            int first, count;
+            decode_leaf(cur, first, count);
+            if (cur_inst == nullptr) {
                 if (count > 0) {
-                    // defer: treat as a node to "enter"; encode as negative-with-offset on the stack
-                    int enc = -(first + 2); // <= -2
-                    if (!have_next) { next = enc; have_next = true; }
-                    else stack[sp++] = enc;
-                }
+                    cur_inst = &bvh.insts[first];
+                    if (cnt) cnt->nodes += 2; // 128-byte instance record = 2 node-sized fetches
+                    o = xform_point(cur_inst->world_to_object, ray.o);
+                    d = xform_dir(cur_inst->world_to_object, ray.d);
+                    id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+                    stack[sp++] = SENTINEL;
+                    cur = cur_inst->blas_root;
+                } else
+                    pop = true;
             } else {
-                int first = ~child;
                 for (int k = 0; k < count; ++k) {
                     const RptrBvhTri &tr = bvh.tris[first + k];
                     if (cnt) cnt->tris++;
@@ -451,40 +469,20 @@ static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *c
                                       vec3(tr.e2[0], tr.e2[1], tr.e2[2]), t, u, v))
                         continue;
                     if (!(t > ray.tmin)) continue;
-                    int ii = cur_inst->instance_id;
-                    bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii, (int)tr.geom, (int)tr.prim, best));
+                    const int ii = cur_inst->instance_id;
+                    const bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii, (int)tr.geom, (int)tr.prim, best));
                     if (!accept) continue;
                     best.t = t; best.u = u; best.v = v;
                     best.inst = ii; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
                     best.lo = o; best.ld = d;
                     if (ANY) return true;
                 }
+                pop = true;
             }
         }
-        // advance
-        for (;;) {
-            if (!have_next) {
-                if (sp == 0) return best.inst >= 0;
-                next = stack[--sp];
-            }
-            have_next = false;
-            if (next >= 0) { cur = next; break; }
-            if (next == SENTINEL) {
-                cur_inst = nullptr;
-                o = ray.o; d = ray.d;
-                id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-                continue;
-            }
-            // enter instance
-            int ii = -next - 2;
-            cur_inst = &bvh.insts[ii];
-            if (cnt) cnt->nodes += 2; // 128-byte instance record = 2 node-sized fetches
-            o = xform_point(cur_inst->world_to_object, ray.o);
-            d = xform_dir(cur_inst->world_to_object, ray.d);
-            id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-            stack[sp++] = SENTINEL;
-            cur = cur_inst->blas_root;
-            break;
+        if (pop) {
+            if (sp == 0) return best.inst >= 0;
+            cur = stack[--sp];
         }
     }
 }

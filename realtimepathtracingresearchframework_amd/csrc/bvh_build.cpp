@@ -204,7 +204,7 @@ void build_bvh2(const BuildPrim *prims, uint32_t n, uint32_t max_leaf, int max_d
         memcpy(lo, tmp[t].box.lo, 12);
         memcpy(hi, tmp[t].box.hi, 12);
         if (leaf(t)) {
-            (which ? nd.child1 : nd.child0) = ~(int32_t)tmp[t].first;
+            (which ? nd.child1 : nd.child0) = RPTR_BVH_LEAF(tmp[t].first, tmp[t].count);
             (which ? nd.cnt1 : nd.cnt0) = (int32_t)tmp[t].count;
         } else {
             (which ? nd.child1 : nd.child0) = out_idx;
@@ -222,7 +222,7 @@ void build_bvh2(const BuildPrim *prims, uint32_t n, uint32_t max_leaf, int max_d
             nd.lo1[k] = INFINITY;
             nd.hi1[k] = -INFINITY;
         }
-        nd.child1 = ~0;
+        nd.child1 = RPTR_BVH_LEAF(0, 0);
         nd.cnt1 = 0;
         out.nodes[0] = nd;
         out.depth = 1;
@@ -271,7 +271,7 @@ void refit_bvh2(BuiltTree &tree, const BuildPrim *p) {
             if (child >= 0)
                 b = nb[child];
             else
-                for (int32_t k = 0; k < cnt; ++k) b.grow(p[(~child) + k].lo, p[(~child) + k].hi);
+                for (int32_t k = 0; k < cnt; ++k) b.grow(p[RPTR_BVH_LEAF_FIRST(child) + k].lo, p[RPTR_BVH_LEAF_FIRST(child) + k].hi);
             memcpy(w ? nd.lo1 : nd.lo0, b.lo, 12);
             memcpy(w ? nd.hi1 : nd.hi0, b.hi, 12);
             if (w == 0)

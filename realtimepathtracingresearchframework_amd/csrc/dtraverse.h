@@ -8,11 +8,16 @@
 // smallest t with ties resolved to the smallest (instance, geometry, primitive)
 // triple, which makes the result independent of tree shape and visit order.
 //
-// Visit order (it defines the node/triangle counts of the roofline model): at a
-// node both child boxes are slab-tested against [t_min, best_t]; the nearer
-// child is handled first (tie -> child 0); a leaf child is intersected on the
-// spot, an inner child becomes the next node (near) or is pushed (far); the far
-// child is re-tested against the possibly shortened best_t.
+// Visit order (it defines the node/triangle counts of the roofline model; the
+// CPU oracle walks the exported tree in exactly this order): work items are
+// inner nodes (>= 0), packed leaves (<= -2, include/rptr_bvh.h) and the
+// instance-exit sentinel. Inner node: slab-test both child boxes against
+// [t_min, best_t]; both hit -> push the farther, continue with the nearer
+// (tie -> child 0); BLAS leaf: test all its triangles; TLAS leaf: transform the
+// ray, push the sentinel, continue at the instance's root.
+//
+// The loop is "while-while": a wave stays in the node loop while any lane has an
+// inner node, then handles leaves, so triangle code is not issued per node.
 //
 // Stack: the first RP_LDS_STACK entries of each lane live in LDS (column layout
 // [level][thread]: conflict-free ds_read_b32/ds_write_b32), deeper entries
@@ -21,8 +26,11 @@
 #include "dshade.h"
 
 #define RP_TRAVERSE_BLOCK 256
+#ifndef RP_LDS_STACK
 #define RP_LDS_STACK 24
+#endif
 #define RP_SENTINEL INT32_MIN
+#define RP_EXIT (INT32_MIN + 1)
 
 struct RpHitRec {
     float t, u, v;
@@ -78,114 +86,101 @@ RP_DEV bool rp_traverse(const RpScene &sc, V3 ro, V3 rd, float tmin, float tmax,
     best.geom = -1;
     int best_inst_id = -1;
     st.sp = 0;
+    st.push(RP_EXIT);
     V3 o = ro, d = rd;
     V3 id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
     int cur_inst = -1, cur_inst_id = -1;
     int cur = 0;
     for (;;) {
-        const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
-        const float4 a = np[0], b = np[1], c = np[2];
-        const int4 k = *reinterpret_cast<const int4 *>(np + 3);
-        if (COUNT) n_nodes++;
-        float tn0, tn1;
-        const bool h0 = rp_slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), o, id, tmin, best.t, tn0);
-        const bool h1 = rp_slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), o, id, tmin, best.t, tn1);
-        const bool first1 = h1 && (!h0 || tn1 < tn0);
-        int next = 0;
-        bool have_next = false;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const bool which = (pass == 0) ? first1 : !first1;
-            const bool hit = which ? h1 : h0;
-            const float tn = which ? tn1 : tn0;
-            if (hit && (pass == 0 || tn <= best.t * 1.0000005f)) {
-                const int child = which ? k.y : k.x;
-                const int count = which ? k.w : k.z;
-                int cand = child;
-                bool descend = child >= 0;
-                if (!descend && cur_inst < 0) { // TLAS leaf: enter the instance later
-                    descend = count > 0;
-                    cand = -((~child) + 2);
-                }
-                if (descend) {
-                    if (!have_next) {
-                        next = cand;
-                        have_next = true;
-                    } else
-                        st.push(cand);
-                } else if (cur_inst >= 0) {
-                    const int first = ~child;
-                    for (int i = 0; i < count; ++i) {
-                        const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (first + i));
-                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                        if (COUNT) n_tris++;
-                        const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
-                        const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
-                        // canonical Moeller-Trumbore (operation order = oracle/obvh.h mt_intersect)
-                        const V3 p = cross3(d, e2);
-                        const float det = dot3(e1, p);
-                        if (det == 0.0f) continue;
-                        const float inv = 1.0f / det;
-                        const V3 tv = o - v0;
-                        const float u = dot3(tv, p) * inv;
-                        if (!(u >= 0.0f && u <= 1.0f)) continue;
-                        const V3 q = cross3(tv, e1);
-                        const float v = dot3(d, q) * inv;
-                        if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-                        const float t = dot3(e2, q) * inv;
-                        if (!(t > tmin)) continue;
-                        bool accept = t < best.t;
-                        if (!accept && t == best.t && best.inst_idx >= 0) {
-                            if (cur_inst_id != best_inst_id)
-                                accept = cur_inst_id < best_inst_id;
-                            else if (geom != best.geom)
-                                accept = geom < best.geom;
-                            else
-                                accept = prim < best.prim;
-                        }
-                        if (!accept) continue;
-                        best.t = t;
-                        best.u = u;
-                        best.v = v;
-                        best.prim = prim;
-                        best.geom = geom;
-                        best.inst_idx = cur_inst;
-                        best_inst_id = cur_inst_id;
-                        if (ANY) return true;
-                    }
-                }
-            }
+        // ---- inner nodes
+        while (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int4 k = *reinterpret_cast<const int4 *>(np + 3);
+            if (COUNT) n_nodes++;
+            float tn0, tn1;
+            const bool h0 = rp_slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), o, id, tmin, best.t, tn0);
+            const bool h1 = rp_slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), o, id, tmin, best.t, tn1);
+            if (h0 && h1) {
+                const bool near1 = tn1 < tn0;
+                st.push(near1 ? k.x : k.y);
+                cur = near1 ? k.y : k.x;
+            } else if (h0)
+                cur = k.x;
+            else if (h1)
+                cur = k.y;
+            else
+                cur = st.pop();
         }
-        for (;;) {
-            if (!have_next) {
-                if (st.sp == 0) return best.inst_idx >= 0;
-                next = st.pop();
-            }
-            have_next = false;
-            if (next >= 0) {
-                cur = next;
-                break;
-            }
-            if (next == RP_SENTINEL) {
-                cur_inst = -1;
-                cur_inst_id = -1;
-                o = ro;
-                d = rd;
-                id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
-                continue;
-            }
-            cur_inst = -next - 2;
-            const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + cur_inst);
-            const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-            const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
-            if (COUNT) n_nodes += 2; // 128-byte instance record
-            o = rp_xform_point(r0, r1, r2, ro);
-            d = rp_xform_dir(r0, r1, r2, rd);
+        if (cur == RP_EXIT) break;
+        if (cur == RP_SENTINEL) {
+            cur_inst = -1;
+            cur_inst_id = -1;
+            o = ro;
+            d = rd;
             id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
-            cur_inst_id = meta.z;
-            st.push(RP_SENTINEL);
-            cur = meta.x;
-            break;
+            cur = st.pop();
+            continue;
         }
+        const int first = RPTR_BVH_LEAF_FIRST(cur), count = RPTR_BVH_LEAF_COUNT(cur);
+        if (cur_inst < 0) {
+            // ---- TLAS leaf: enter the instance
+            if (count > 0) {
+                cur_inst = first;
+                const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + cur_inst);
+                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
+                if (COUNT) n_nodes += 2; // 128-byte instance record
+                o = rp_xform_point(r0, r1, r2, ro);
+                d = rp_xform_dir(r0, r1, r2, rd);
+                id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
+                cur_inst_id = meta.z;
+                st.push(RP_SENTINEL);
+                cur = meta.x;
+            } else
+                cur = st.pop();
+            continue;
+        }
+        // ---- BLAS leaf
+        for (int i = 0; i < count; ++i) {
+            const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (first + i));
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            if (COUNT) n_tris++;
+            const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
+            const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
+            // canonical Moeller-Trumbore (operation order = oracle/obvh.h mt_intersect)
+            const V3 p = cross3(d, e2);
+            const float det = dot3(e1, p);
+            if (det == 0.0f) continue;
+            const float inv = 1.0f / det;
+            const V3 tv = o - v0;
+            const float u = dot3(tv, p) * inv;
+            if (!(u >= 0.0f && u <= 1.0f)) continue;
+            const V3 q = cross3(tv, e1);
+            const float v = dot3(d, q) * inv;
+            if (!(v >= 0.0f && u + v <= 1.0f)) continue;
+            const float t = dot3(e2, q) * inv;
+            if (!(t > tmin)) continue;
+            bool accept = t < best.t;
+            if (!accept && t == best.t && best.inst_idx >= 0) {
+                if (cur_inst_id != best_inst_id)
+                    accept = cur_inst_id < best_inst_id;
+                else if (geom != best.geom)
+                    accept = geom < best.geom;
+                else
+                    accept = prim < best.prim;
+            }
+            if (!accept) continue;
+            best.t = t;
+            best.u = u;
+            best.v = v;
+            best.prim = prim;
+            best.geom = geom;
+            best.inst_idx = cur_inst;
+            best_inst_id = cur_inst_id;
+            if (ANY) return true;
+        }
+        cur = st.pop();
     }
+    return best.inst_idx >= 0;
 }

@@ -67,6 +67,11 @@ RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+RP_DEV uint32_t rp_wave_fetch(uint32_t *cursor, uint32_t lane) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (uint32_t)RP_FETCH);
+    return __builtin_amdgcn_readfirstlane(base);
+}
 RP_DEV uint32_t rp_wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -143,10 +148,10 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpP
     const uint32_t n = *count_ptr;
     const uint32_t lane = rp_lane_id();
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->cursor_extend, (uint32_t)RP_FETCH);
-        base = __builtin_amdgcn_readfirstlane(base);
+    // first chunk is assigned statically (no atomic at all when there is little work),
+    // later chunks come from the shared cursor, which starts behind the static ones
+    uint32_t base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RP_FETCH;
+    for (;; base = rp_wave_fetch(&ctr->cursor_extend, lane)) {
         if (base >= n) break;
 #pragma unroll 1
         for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
@@ -183,10 +188,10 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, Rp
     const uint32_t n = ctr->shadow_count;
     const uint32_t lane = rp_lane_id();
     uint32_t n_nodes = 0, n_tris = 0;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->cursor_connect, (uint32_t)RP_FETCH);
-        base = __builtin_amdgcn_readfirstlane(base);
+    // first chunk is assigned statically (no atomic at all when there is little work),
+    // later chunks come from the shared cursor, which starts behind the static ones
+    uint32_t base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RP_FETCH;
+    for (;; base = rp_wave_fetch(&ctr->cursor_connect, lane)) {
         if (base >= n) break;
 #pragma unroll 1
         for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
@@ -543,11 +548,11 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
 }
 
 // between bounces: reset what the next bounce appends to
-__global__ void rp_k_next_bounce(RpCounters *ctr, int next_out /* queue index the coming shade writes */) {
+__global__ void rp_k_next_bounce(RpCounters *ctr, int next_out /* queue index the coming shade writes */, uint32_t persistent_waves) {
     ctr->queue_count[next_out] = 0;
     ctr->shadow_count = 0;
-    ctr->cursor_extend = 0;
-    ctr->cursor_connect = 0;
+    ctr->cursor_extend = persistent_waves * RP_FETCH;
+    ctr->cursor_connect = persistent_waves * RP_FETCH;
 }
 
 // ------------------------------------------------------------------ resolve

@@ -484,8 +484,8 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         memcpy(mr.hi, mr.tree.hi, 12);
         for (uint32_t id : mr.tree.order) h->h_tris.push_back(mtris[id]);
         for (RptrBvhNode nd : mr.tree.nodes) {
-            if (nd.child0 >= 0) nd.child0 += mr.node_base; else nd.child0 = ~((~nd.child0) + mr.tri_base);
-            if (nd.child1 >= 0) nd.child1 += mr.node_base; else nd.child1 = ~((~nd.child1) + mr.tri_base);
+            if (nd.child0 >= 0) nd.child0 += mr.node_base; else nd.child0 = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(nd.child0) + mr.tri_base, nd.cnt0);
+            if (nd.child1 >= 0) nd.child1 += mr.node_base; else nd.child1 = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(nd.child1) + mr.tri_base, nd.cnt1);
             blas_nodes.push_back(nd);
         }
         if (!mr.dynamic) {
@@ -695,7 +695,8 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
             });
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
-                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, out);
+                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, out,
+                                   (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
                 timed(0, [&] {
                     if (count_traversal)
                         hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,

@@ -39,8 +39,8 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    """(Re)builds liboracle.so when it is missing or older than its sources (make decides)."""
+    subprocess.check_call(["make", "-C", ORACLE_DIR] + (["-B"] if force else []) + ["liboracle.so"], stdout=subprocess.DEVNULL)
 
 
 def lib():
