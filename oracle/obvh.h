@@ -8,8 +8,8 @@
 // bit for bit, independent of the tree:
 //   - Moeller-Trumbore in the object space of the mesh, on the dequantised
 //     float positions (the reference feeds dequantised floats to the BLAS
-//     build, render_vulkan.cpp:698-711), operations in the order written in
-//     mt_intersect() below, no fma contraction;
+//     build, render_vulkan.cpp:698-711), operations exactly as written in
+//     mt_intersect() below (explicit fmaf, nothing else contracted);
 //   - a hit is accepted for t_min < t < t_max; barycentrics (u,v) weight
 //     vertex 1 and 2 (rendering/rt/hit.glsl:70);
 //   - closest hit = smallest t; equal t is resolved towards the smallest
@@ -45,6 +45,8 @@ struct Hit {
 struct TraceCounters {
     uint64_t nodes = 0, tris = 0;
 };
+// optional per-node visit histogram (diagnostics: which part of the tree is hot)
+static uint32_t *g_node_hist = nullptr;
 
 static inline bool hit_key_less(int inst, int geom, int prim, const Hit &h) {
     if (h.inst < 0) return true;
@@ -53,20 +55,30 @@ static inline bool hit_key_less(int inst, int geom, int prim, const Hit &h) {
     return prim < h.prim;
 }
 
-// canonical ray/triangle test (see header). Returns true and t,u,v when the
-// supporting plane is hit inside the triangle; the caller applies the interval.
+// canonical ray/triangle test (see header): Moeller-Trumbore with explicit fused
+// multiply-adds (one rounding per dot/cross term, identical on host and device)
+// and a division-free inside test; the reciprocal of the determinant is only
+// formed for triangles whose plane hit lies inside. Returns true and t,u,v; the
+// caller applies the ray interval.
+static inline float dot_fma(const vec3 a, const vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline vec3 cross_fma(const vec3 a, const vec3 b) {
+    return vec3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
+}
 static inline bool mt_intersect(const vec3 o, const vec3 d, const vec3 v0, const vec3 e1, const vec3 e2, float &t, float &u, float &v) {
-    const vec3 p = cross(d, e2);
-    const float det = dot(e1, p);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
+    const vec3 p = cross_fma(d, e2);
+    const float det = dot_fma(e1, p);
     const vec3 tv = o - v0;
-    u = dot(tv, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
-    const vec3 q = cross(tv, e1);
-    v = dot(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    t = dot(e2, q) * inv;
+    const float un = dot_fma(tv, p);
+    const vec3 q = cross_fma(tv, e1);
+    const float vn = dot_fma(d, q);
+    const float ad = fabsf(det);
+    const bool neg = std::signbit(det);
+    const float us = neg ? -un : un, vs = neg ? -vn : vn;
+    if (!(us >= 0.0f && vs >= 0.0f && us + vs <= ad && ad > 0.0f)) return false;
+    const float inv = 1.0f / det;
+    t = dot_fma(e2, q) * inv;
+    u = un * inv;
+    v = vn * inv;
     return true;
 }
 
@@ -426,6 +438,7 @@ static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *c
         if (cur >= 0) {
             const RptrBvhNode &n = nodes[cur];
             if (cnt) cnt->nodes++;
+            if (g_node_hist) __atomic_fetch_add(&g_node_hist[cur], 1u, __ATOMIC_RELAXED);
             float tn0, tn1;
             const bool h0 = slab(n.lo0, n.hi0, o, id, ray.tmin, best.t, tn0);
             const bool h1 = slab(n.lo1, n.hi1, o, id, ray.tmin, best.t, tn1);

@@ -752,6 +752,16 @@ void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,d
     for (int i = 0; i < 4; ++i) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
+void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }
+// copies out the oracle-built tree (sizes first with NULL buffers)
+int orc_scene_export_bvh(void *p, RptrBvhNode *nodes, RptrBvhTri *tris, RptrBvhInstance *insts) {
+    Scene *s = (Scene *)p;
+    ensure_own(s);
+    if (nodes) memcpy(nodes, s->own.nodes.data(), s->own.nodes.size() * sizeof(RptrBvhNode));
+    if (tris) memcpy(tris, s->own.tris.data(), s->own.tris.size() * sizeof(RptrBvhTri));
+    if (insts) memcpy(insts, s->own.insts.data(), s->own.insts.size() * sizeof(RptrBvhInstance));
+    return 0;
+}
 int orc_hw_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 } // extern "C"

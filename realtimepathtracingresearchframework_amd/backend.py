@@ -33,7 +33,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("RPTR_HIP_LIB") or LIB_PATH  # RPTR_HIP_LIB: A/B builds of the same ABI (tools/ab.sh)
     if not os.path.exists(path):
         raise BackendError(abi.RPTR_E_NO_DEVICE, "%s is missing: build it with __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)

@@ -44,6 +44,8 @@ struct RpScene {
     const RptrTriLightData *lights; // padded with one zeroed bin
     int32_t num_lights;
     int32_t num_materials;
+    uint32_t num_nodes;
+    uint32_t _pad;
 };
 
 // the per-frame constants: RenderParams + SceneParams + ViewParams subset
@@ -66,6 +68,13 @@ struct RpFrame {
     int32_t npix_padded;         // tiles_x*tiles_y*64
     int32_t rank, world, stripe_rows;
     int32_t num_bins;            // SCENE_GET_BINNED_LIGHTS_BIN_COUNT (pt_megakernel.glsl:103)
+    // regrouping pass (kernels.h "sort"): hit-cell grid over the scene bounds
+    float sort_lo[3];
+    int32_t sort_groups;         // material groups
+    float sort_scale[3];         // cells per world unit and axis
+    int32_t sort_cells;          // cells per material group = 2^(sum of sort_bits)
+    int32_t sort_bits[3];
+    int32_t sort_num_keys;       // 1 + sort_groups * sort_cells
 };
 
 // local tiled slot -> local pixel; false for padding lanes

@@ -27,7 +27,17 @@
 
 #define RP_TRAVERSE_BLOCK 256
 #ifndef RP_LDS_STACK
-#define RP_LDS_STACK 24
+#define RP_LDS_STACK 16
+#endif
+// waves per SIMD the traversal kernels are compiled for (bounds the VGPR budget)
+#ifndef RP_TRAVERSE_WAVES
+#define RP_TRAVERSE_WAVES 5
+#endif
+#define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
+// nodes staged in LDS per workgroup: the first RP_LDS_NODES nodes of the array (the host puts
+// the top of the hierarchy there in breadth-first order); 0 disables staging
+#ifndef RP_LDS_NODES
+#define RP_LDS_NODES 64
 #endif
 #define RP_SENTINEL INT32_MIN
 #define RP_EXIT (INT32_MIN + 1)
@@ -76,111 +86,303 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
     return v3((r0.x * d.x + r0.y * d.y) + r0.z * d.z, (r1.x * d.x + r1.y * d.y) + r1.z * d.z, (r2.x * d.x + r2.y * d.y) + r2.z * d.z);
 }
 
-template <bool ANY, bool COUNT>
-RP_DEV bool rp_traverse(const RpScene &sc, V3 ro, V3 rd, float tmin, float tmax, RpHitRec &best, RpStack &st, uint32_t &n_nodes,
-                        uint32_t &n_tris) {
-    best.t = tmax;
-    best.u = best.v = 0.0f;
-    best.prim = -1;
-    best.inst_idx = -1;
-    best.geom = -1;
-    int best_inst_id = -1;
-    st.sp = 0;
-    st.push(RP_EXIT);
-    V3 o = ro, d = rd;
-    V3 id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
-    int cur_inst = -1, cur_inst_id = -1;
-    int cur = 0;
+// ------------------------------------------------------------------ wave traversal engine
+// Persistent waves with ray refill: a wave owns a pool of RP_FETCH queue entries
+// (the first pool is assigned statically, later ones come from one shared
+// cursor, one atomic per pool). Every lane runs an independent traversal state
+// machine; when RP_REFILL_MIN or more lanes have finished their ray, the idle
+// lanes take the next pool entries (ballot + mbcnt rank, no atomics), so short
+// rays do not leave lanes idle while the longest ray of the wave finishes.
+//   Load(i, o, d, tmin, tmax)  fetches queue entry i
+//   Done(i, hit)               consumes the result of entry i
+//
+// The kernels are instruction-issue bound (profiles/r01_notes.md), so the node step
+// is written for instruction count: packed v_pk_add/v_pk_mul for the 12 slab planes
+// (operands pre-rotated into the (x,y) (z,x) (y,z) pairs in which the 12 floats of
+// a node arrive), 32-bit node offsets (saddr loads), select instead of branch for
+// the child choice, and leaf triangles fetched two at a time before testing.
+#ifndef RP_REFILL_MIN
+#define RP_REFILL_MIN 48
+#endif
+#define RP_FETCH 256 // queue entries a wave pulls per global atomic
+
+typedef float rp_f2 __attribute__((ext_vector_type(2)));
+RP_DEV rp_f2 rp_mk2(float x, float y) { return rp_f2{x, y}; }
+
+RP_DEV uint32_t rp_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+RP_DEV float rp_dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+RP_DEV V3 rp_cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))); }
+
+#ifdef RP_PROF
+__device__ unsigned long long rp_prof[8];
+#endif
+template <bool ANY, bool COUNT, class Load, class Done>
+RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, uint32_t &n_nodes,
+                          uint32_t &n_tris) {
+    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+#if RP_LDS_NODES > 0
+    __shared__ float4 lds_nodes[RP_LDS_NODES * 4];
+#endif
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gstride = gridDim.x * blockDim.x;
+    int *const glob = gstack + (blockIdx.x * blockDim.x + tid);
+    const uint32_t lane = rp_lane_id();
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // wave-uniform pool of queue entries
+    uint32_t pool_next = ((blockIdx.x * blockDim.x + tid) >> 6) * RP_FETCH;
+    uint32_t pool_end = min(n, pool_next + (uint32_t)RP_FETCH);
+    bool more = pool_next < n; // the shared cursor starts behind every static pool
+#if RP_LDS_NODES > 0
+    // stage the top of the tree (block-uniform decision: the whole block has work or none of it
+    // does only approximately, so every wave of a block with any work takes part)
+    const uint32_t block_first = ((blockIdx.x * blockDim.x) >> 6) * RP_FETCH;
+    if (block_first >= n) return;
+    {
+        const uint32_t nstage = min((uint32_t)RP_LDS_NODES, sc.num_nodes) * 4u;
+        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+        for (uint32_t i = tid; i < nstage; i += RP_TRAVERSE_BLOCK) lds_nodes[i] = src[i];
+        __syncthreads();
+    }
+    const int lds_limit = (int)min((uint32_t)RP_LDS_NODES, sc.num_nodes);
+#endif
+    if (!more) return;
+    // per-lane traversal state
+    int cur = RP_EXIT, sp = 0;
+    bool active = false; // lane holds a ray whose result has not been consumed yet
+    uint32_t my_i = 0;
+    V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
+    rp_f2 op0 = rp_mk2(0, 0), op1 = op0, op2 = op0, ip0 = op0, ip1 = op0, ip2 = op0; // (x,y) (z,x) (y,z) pairs of origin and 1/dir
+    float tmin = 0.f;
+    RpHitRec best;
+    best.t = 0.f;
+    best.u = best.v = 0.f;
+    best.prim = best.inst_idx = best.geom = -1;
+    int best_inst_id = -1, cur_inst = -1, cur_inst_id = -1;
+    auto push = [&](int v) {
+        if (sp < RP_LDS_STACK)
+            lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = v;
+        else
+            glob[size_t(sp - RP_LDS_STACK) * gstride] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> int {
+        --sp;
+        int v;
+        if (sp < RP_LDS_STACK)
+            v = lds_stack[sp * RP_TRAVERSE_BLOCK + tid]; // ds_read_b32; kept apart from the spill path so it is not a flat load
+        else // an atomic (relaxed) load cannot be merged with the LDS read into one flat load
+            v = __hip_atomic_load(glob + size_t(sp - RP_LDS_STACK) * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        return v;
+    };
+    auto set_ray = [&](V3 no, V3 nd) {
+        o = no;
+        d = nd;
+        const V3 id = v3(rp_safe_rcp(nd.x), rp_safe_rcp(nd.y), rp_safe_rcp(nd.z));
+        op0 = rp_mk2(no.x, no.y);
+        op1 = rp_mk2(no.z, no.x);
+        op2 = rp_mk2(no.y, no.z);
+        ip0 = rp_mk2(id.x, id.y);
+        ip1 = rp_mk2(id.z, id.x);
+        ip2 = rp_mk2(id.y, id.z);
+    };
+    const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
+    const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
     for (;;) {
-        // ---- inner nodes
-        while (cur >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int4 k = *reinterpret_cast<const int4 *>(np + 3);
-            if (COUNT) n_nodes++;
-            float tn0, tn1;
-            const bool h0 = rp_slab(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), o, id, tmin, best.t, tn0);
-            const bool h1 = rp_slab(v3(b.z, b.w, c.x), v3(c.y, c.z, c.w), o, id, tmin, best.t, tn1);
-            if (h0 && h1) {
-                const bool near1 = tn1 < tn0;
-                st.push(near1 ? k.x : k.y);
-                cur = near1 ? k.y : k.x;
-            } else if (h0)
-                cur = k.x;
-            else if (h1)
-                cur = k.y;
-            else
-                cur = st.pop();
+        // ---- refill idle lanes
+        const bool idle = cur == RP_EXIT;
+        const unsigned long long idle_mask = __ballot(idle);
+        const uint32_t nidle = (uint32_t)__popcll(idle_mask);
+        if (nidle >= RP_REFILL_MIN) {
+            if (pool_next >= pool_end && more) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)RP_FETCH);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base < n) {
+                    pool_next = base;
+                    pool_end = min(n, base + (uint32_t)RP_FETCH);
+                } else
+                    more = false;
+            }
+            const uint32_t avail = pool_end - pool_next;
+            if (avail > 0) {
+                const uint32_t rank = (uint32_t)__popcll(idle_mask & lane_lt);
+                if (idle && rank < avail) {
+                    my_i = pool_next + rank;
+                    float tmax;
+                    load(my_i, ro, rd, tmin, tmax);
+                    set_ray(ro, rd);
+                    best.t = tmax;
+                    best.u = best.v = 0.0f;
+                    best.prim = best.geom = best.inst_idx = -1;
+                    best_inst_id = -1;
+                    cur_inst = cur_inst_id = -1;
+                    sp = 0;
+                    push(RP_EXIT);
+                    cur = 0;
+                    active = true;
+                }
+                pool_next += min(nidle, avail);
+            } else if (nidle == 64u)
+                break; // nothing in flight, nothing left to fetch
         }
-        if (cur == RP_EXIT) break;
+        // ---- inner nodes
+#ifdef RP_PROF
+        const long long prof_t0 = __builtin_readcyclecounter();
+        uint32_t prof_it = 0;
+#endif
+        while (cur >= 0) {
+#ifdef RP_PROF
+            prof_it++;
+#endif
+            float4 a, b, c;
+            int2 k;
+#if RP_LDS_NODES > 0
+            if (cur < lds_limit) { // top of the tree: LDS (ds_read_b128), keeps these lanes off the L1/TA path
+                const float4 *ln = lds_nodes + (uint32_t(cur) << 2);
+                a = ln[0];
+                b = ln[1];
+                c = ln[2];
+                const float4 kk = ln[3];
+                k = make_int2(__float_as_int(kk.x), __float_as_int(kk.y));
+            } else
+#endif
+            {
+                const char *np = node_base + (uint32_t(cur) << 6);
+                a = *reinterpret_cast<const float4 *>(np);
+                b = *reinterpret_cast<const float4 *>(np + 16);
+                c = *reinterpret_cast<const float4 *>(np + 32);
+                k = *reinterpret_cast<const int2 *>(np + 48);
+            }
+            if (COUNT) n_nodes++;
+            // the 12 plane distances (lo - o) * (1/d), two per instruction
+            const rp_f2 p0 = (rp_mk2(a.x, a.y) - op0) * ip0; // lo0.x lo0.y
+            const rp_f2 p1 = (rp_mk2(a.z, a.w) - op1) * ip1; // lo0.z hi0.x
+            const rp_f2 p2 = (rp_mk2(b.x, b.y) - op2) * ip2; // hi0.y hi0.z
+            const rp_f2 p3 = (rp_mk2(b.z, b.w) - op0) * ip0; // lo1.x lo1.y
+            const rp_f2 p4 = (rp_mk2(c.x, c.y) - op1) * ip1; // lo1.z hi1.x
+            const rp_f2 p5 = (rp_mk2(c.z, c.w) - op2) * ip2; // hi1.y hi1.z
+            const float tn0 = fmaxf(fmaxf(fminf(p0.x, p1.y), fminf(p0.y, p2.x)), fmaxf(fminf(p1.x, p2.y), tmin));
+            const float tf0 = fminf(fminf(fmaxf(p0.x, p1.y), fmaxf(p0.y, p2.x)), fminf(fmaxf(p1.x, p2.y), best.t));
+            const float tn1 = fmaxf(fmaxf(fminf(p3.x, p4.y), fminf(p3.y, p5.x)), fmaxf(fminf(p4.x, p5.y), tmin));
+            const float tf1 = fminf(fminf(fmaxf(p3.x, p4.y), fmaxf(p3.y, p5.x)), fminf(fmaxf(p4.x, p5.y), best.t));
+            const bool h0 = tn0 <= tf0 * 1.0000005f;
+            const bool h1 = tn1 <= tf1 * 1.0000005f;
+            const bool both = h0 && h1;
+            const bool near1 = both ? (tn1 < tn0) : h1;
+            int nxt = near1 ? k.y : k.x;
+            if (both) push(near1 ? k.x : k.y);
+            if (!(h0 || h1)) nxt = pop();
+            cur = nxt;
+        }
+#ifdef RP_PROF
+        {
+            const long long prof_t1 = __builtin_readcyclecounter();
+            uint32_t mx = prof_it;
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+            uint32_t sm = prof_it;
+            for (int off = 32; off > 0; off >>= 1) sm += (uint32_t)__shfl_xor((int)sm, off);
+            if (lane == 0) {
+                atomicAdd(&rp_prof[0], (unsigned long long)(prof_t1 - prof_t0)); // node-phase cycles (per wave)
+                atomicAdd(&rp_prof[1], (unsigned long long)mx);                  // node-phase wave iterations
+                atomicAdd(&rp_prof[2], (unsigned long long)sm);                  // node-phase lane iterations
+                atomicAdd(&rp_prof[3], 1ull);                                    // phases
+            }
+        }
+        const long long prof_t2 = __builtin_readcyclecounter();
+#endif
+        // ---- one leaf / sentinel item
         if (cur == RP_SENTINEL) {
             cur_inst = -1;
             cur_inst_id = -1;
-            o = ro;
-            d = rd;
-            id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
-            cur = st.pop();
-            continue;
-        }
-        const int first = RPTR_BVH_LEAF_FIRST(cur), count = RPTR_BVH_LEAF_COUNT(cur);
-        if (cur_inst < 0) {
-            // ---- TLAS leaf: enter the instance
-            if (count > 0) {
-                cur_inst = first;
-                const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + cur_inst);
-                const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-                const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
-                if (COUNT) n_nodes += 2; // 128-byte instance record
-                o = rp_xform_point(r0, r1, r2, ro);
-                d = rp_xform_dir(r0, r1, r2, rd);
-                id = v3(rp_safe_rcp(d.x), rp_safe_rcp(d.y), rp_safe_rcp(d.z));
-                cur_inst_id = meta.z;
-                st.push(RP_SENTINEL);
-                cur = meta.x;
-            } else
-                cur = st.pop();
-            continue;
-        }
-        // ---- BLAS leaf
-        for (int i = 0; i < count; ++i) {
-            const float4 *tp = reinterpret_cast<const float4 *>(sc.tris + (first + i));
-            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-            if (COUNT) n_tris++;
-            const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
-            const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
-            // canonical Moeller-Trumbore (operation order = oracle/obvh.h mt_intersect)
-            const V3 p = cross3(d, e2);
-            const float det = dot3(e1, p);
-            if (det == 0.0f) continue;
-            const float inv = 1.0f / det;
-            const V3 tv = o - v0;
-            const float u = dot3(tv, p) * inv;
-            if (!(u >= 0.0f && u <= 1.0f)) continue;
-            const V3 q = cross3(tv, e1);
-            const float v = dot3(d, q) * inv;
-            if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-            const float t = dot3(e2, q) * inv;
-            if (!(t > tmin)) continue;
-            bool accept = t < best.t;
-            if (!accept && t == best.t && best.inst_idx >= 0) {
-                if (cur_inst_id != best_inst_id)
-                    accept = cur_inst_id < best_inst_id;
-                else if (geom != best.geom)
-                    accept = geom < best.geom;
-                else
-                    accept = prim < best.prim;
+            set_ray(ro, rd);
+            cur = pop();
+        } else if (cur != RP_EXIT) {
+            const int first = RPTR_BVH_LEAF_FIRST(cur), count = RPTR_BVH_LEAF_COUNT(cur);
+            if (cur_inst < 0) {
+                // TLAS leaf: enter the instance
+                if (count > 0) {
+                    cur_inst = first;
+                    const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + cur_inst);
+                    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+                    const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
+                    if (COUNT) n_nodes += 2; // 128-byte instance record
+                    set_ray(rp_xform_point(r0, r1, r2, ro), rp_xform_dir(r0, r1, r2, rd));
+                    cur_inst_id = meta.z;
+                    push(RP_SENTINEL);
+                    cur = meta.x;
+                } else
+                    cur = pop();
+            } else {
+                // BLAS leaf: triangles are fetched two at a time, then tested (canonical
+                // Moeller-Trumbore = oracle/obvh.h mt_intersect, same operations bit for bit)
+                bool any_hit = false;
+                const char *tp = tri_base + uint32_t(first) * 48u;
+#pragma unroll 1
+                for (int i0 = 0; i0 < count; i0 += 2) {
+                    const bool two = i0 + 1 < count;
+                    const float4 qa0 = *reinterpret_cast<const float4 *>(tp), qa1 = *reinterpret_cast<const float4 *>(tp + 16),
+                                 qa2 = *reinterpret_cast<const float4 *>(tp + 32);
+                    float4 qb0 = qa0, qb1 = qa1, qb2 = qa2;
+                    if (two) {
+                        qb0 = *reinterpret_cast<const float4 *>(tp + 48);
+                        qb1 = *reinterpret_cast<const float4 *>(tp + 64);
+                        qb2 = *reinterpret_cast<const float4 *>(tp + 80);
+                    }
+                    tp += 96;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (j == 1 && !two) break;
+                        const float4 q0 = j ? qb0 : qa0, q1 = j ? qb1 : qa1, q2 = j ? qb2 : qa2;
+                        if (COUNT) n_tris++;
+                        const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
+                        const V3 p = rp_cross_fma(d, e2);
+                        const float det = rp_dot_fma(e1, p);
+                        const V3 tv = o - v0;
+                        const float un = rp_dot_fma(tv, p);
+                        const V3 q = rp_cross_fma(tv, e1);
+                        const float vn = rp_dot_fma(d, q);
+                        const float ad = fabsf(det);
+                        const bool neg = det < 0.0f || (det == 0.0f && __float_as_int(det) < 0);
+                        const float us = neg ? -un : un, vs = neg ? -vn : vn;
+                        if (us >= 0.0f && vs >= 0.0f && us + vs <= ad && ad > 0.0f) {
+                            const float inv = 1.0f / det;
+                            const float t = rp_dot_fma(e2, q) * inv;
+                            if (t > tmin) {
+                                const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
+                                bool accept = t < best.t;
+                                if (!accept && t == best.t && best.inst_idx >= 0) {
+                                    if (cur_inst_id != best_inst_id)
+                                        accept = cur_inst_id < best_inst_id;
+                                    else if (geom != best.geom)
+                                        accept = geom < best.geom;
+                                    else
+                                        accept = prim < best.prim;
+                                }
+                                if (accept) {
+                                    best.t = t;
+                                    best.u = un * inv;
+                                    best.v = vn * inv;
+                                    best.prim = prim;
+                                    best.geom = geom;
+                                    best.inst_idx = cur_inst;
+                                    best_inst_id = cur_inst_id;
+                                    any_hit = true;
+                                }
+                            }
+                        }
+                    }
+                    if (ANY && any_hit) break;
+                }
+                cur = (ANY && any_hit) ? RP_EXIT : pop();
             }
-            if (!accept) continue;
-            best.t = t;
-            best.u = u;
-            best.v = v;
-            best.prim = prim;
-            best.geom = geom;
-            best.inst_idx = cur_inst;
-            best_inst_id = cur_inst_id;
-            if (ANY) return true;
         }
-        cur = st.pop();
+        if (active && cur == RP_EXIT) {
+            done(my_i, best);
+            active = false;
+        }
+#ifdef RP_PROF
+        if (lane == 0) atomicAdd(&rp_prof[4], (unsigned long long)(__builtin_readcyclecounter() - prof_t2)); // leaf+done cycles
+#endif
     }
-    return best.inst_idx >= 0;
 }

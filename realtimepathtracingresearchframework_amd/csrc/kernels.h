@@ -49,13 +49,12 @@ struct RpCounters {
     uint32_t _pad2;
 };
 
-#define RP_SORT_MAX_KEYS 1024
+#define RP_SORT_MAX_KEYS 16384 // bins of the regrouping pass (64 KiB of LDS per block)
 #define RP_SORT_BLOCKS 512
+#define RP_SORT_MIN_N 32768u   // below this many paths the regrouping pass is skipped
 #define RP_CHUNK 1024     // entries a producer block publishes per global atomic
-#define RP_FETCH 256      // entries a consumer wave pulls per global atomic
 
 // ---- wave64 helpers
-RP_DEV uint32_t rp_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 // reserves one slot per flagged lane with one atomic per wave (counter may live in LDS or global memory)
 RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
     const unsigned long long mask = __ballot(flag);
@@ -66,11 +65,6 @@ RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
     if (int(lane) == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-}
-RP_DEV uint32_t rp_wave_fetch(uint32_t *cursor, uint32_t lane) {
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(cursor, (uint32_t)RP_FETCH);
-    return __builtin_amdgcn_readfirstlane(base);
 }
 RP_DEV uint32_t rp_wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -137,39 +131,27 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, ui
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
 template <bool COUNT>
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                                                 RpCounters *ctr, int *gstack) {
-    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
-    RpStack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.gstride = gridDim.x * blockDim.x;
-    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
-    st.sp = 0;
-    const uint32_t n = *count_ptr;
-    const uint32_t lane = rp_lane_id();
+__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
+                                               RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
-    // first chunk is assigned statically (no atomic at all when there is little work),
-    // later chunks come from the shared cursor, which starts behind the static ones
-    uint32_t base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RP_FETCH;
-    for (;; base = rp_wave_fetch(&ctr->cursor_extend, lane)) {
-        if (base >= n) break;
-#pragma unroll 1
-        for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
-            const uint32_t i = base + k * 64 + lane;
-            if (i < n) {
-                const uint32_t p = queue[i];
-                const float4 o = ps.ray_o[p], d = ps.ray_d[p];
-                RpHitRec h;
-                rp_traverse<false, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
-                ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-                ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
-            }
-        }
-    }
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
+        const uint32_t p = queue[i];
+        const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+        ro = xyz(o);
+        rd = xyz(d);
+        tmin = o.w;
+        tmax = d.w;
+    };
+    auto done = [&](uint32_t i, const RpHitRec &h) {
+        const uint32_t p = queue[i];
+        ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+        ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+    };
+    rp_wave_trace<false, COUNT>(sc, *count_ptr, &ctr->cursor_extend, gstack, load, done, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
-        if (lane == 0) {
+        if (rp_lane_id() == 0) {
             atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
             atomicAdd(&ctr->tris, (unsigned long long)n_tris);
         }
@@ -178,64 +160,66 @@ __global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_extend(RpScene sc, RpP
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 template <bool COUNT>
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpCounters *ctr, int *gstack) {
-    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
-    RpStack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.gstride = gridDim.x * blockDim.x;
-    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
-    st.sp = 0;
-    const uint32_t n = ctr->shadow_count;
-    const uint32_t lane = rp_lane_id();
+__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
-    // first chunk is assigned statically (no atomic at all when there is little work),
-    // later chunks come from the shared cursor, which starts behind the static ones
-    uint32_t base = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * RP_FETCH;
-    for (;; base = rp_wave_fetch(&ctr->cursor_connect, lane)) {
-        if (base >= n) break;
-#pragma unroll 1
-        for (uint32_t k = 0; k < RP_FETCH / 64; ++k) {
-            const uint32_t i = base + k * 64 + lane;
-            if (i < n) {
-                const uint32_t p = sq.ids[i];
-                const float4 o = sq.o[p], d = sq.d[p];
-                RpHitRec h;
-                const bool occluded = rp_traverse<true, COUNT>(sc, xyz(o), xyz(d), o.w, d.w, h, st, n_nodes, n_tris);
-                if (!occluded) {
-                    const float4 c = sq.contrib[p];
-                    float4 il = ps.illum[p];
-                    il.x += c.x;
-                    il.y += c.y;
-                    il.z += c.z;
-                    ps.illum[p] = il;
-                }
-            }
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
+        const uint32_t p = sq.ids[i];
+        const float4 o = sq.o[p], d = sq.d[p];
+        ro = xyz(o);
+        rd = xyz(d);
+        tmin = o.w;
+        tmax = d.w;
+    };
+    auto done = [&](uint32_t i, const RpHitRec &h) {
+        if (h.inst_idx < 0) { // visible: NEE contribution arrives (nee.glsl:76-84)
+            const uint32_t p = sq.ids[i];
+            const float4 c = sq.contrib[p];
+            float4 il = ps.illum[p];
+            il.x += c.x;
+            il.y += c.y;
+            il.z += c.z;
+            ps.illum[p] = il;
         }
-    }
+    };
+    rp_wave_trace<true, COUNT>(sc, ctr->shadow_count, &ctr->cursor_connect, gstack, load, done, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
-        if (lane == 0) {
+        if (rp_lane_id() == 0) {
             atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
             atomicAdd(&ctr->tris, (unsigned long long)n_tris);
         }
     }
 }
 
-// ------------------------------------------------------------------ sort by material
-// A counting sort over the ray queue with no global atomics: RP_SORT_BLOCKS blocks
-// each own a contiguous slice of the queue; count -> per-(key, block) histogram,
-// scan -> exclusive offsets in key-major order, scatter -> wave-level multi-split
-// (ballot per distinct key, mbcnt rank) against per-block LDS cursors.
-// key 0 = miss, 1 + min(material id, K-2) otherwise
-RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpPathState &ps, uint32_t p, int num_keys) {
+// ------------------------------------------------------------------ sort by material and hit cell
+// Regroups the paths that were just extended so that a wave shades one material and
+// -- just as important on this machine -- neighbouring hit points: the shadow rays
+// and continuation rays it emits then start close together and share BVH nodes,
+// which is what the L1 path (64 B/clk/CU, one distinct line per clock) rewards.
+//   key 0                     = miss
+//   1 + group*cells + cell    = hit; group = material id % groups, cell = position
+//                               of the hit in a grid over the scene bounds
+// One counting-sort pass with up to RP_SORT_MAX_KEYS bins: block-local LDS
+// histograms (wave ballot aggregation for the dominant keys, ds_add for the rest),
+// one global add per non-empty (block, bin), single-block scan, and a scatter that
+// reserves a contiguous range per (block, bin).
+RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpFrame &f, const RpPathState &ps, uint32_t p) {
     const int2 ids = ps.hit_ids[p];
     if (ids.x < 0) return 0u;
-    const int prim = __float_as_int(ps.hit_tuv[p].w);
+    const float4 hit = ps.hit_tuv[p];
+    const int prim = __float_as_int(hit.w);
     const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[25]; // RptrBvhInstance::geometry_base
     const RpGeomRecord &g = sc.geoms[geometry_base + ids.y];
     const int mid = rp_hit_material_id(g, uint32_t(prim));
-    return 1u + uint32_t(min(mid, num_keys - 2));
+    const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+    const float px = o.x + hit.x * d.x, py = o.y + hit.x * d.y, pz = o.z + hit.x * d.z;
+    const int cx = min(max(int((px - f.sort_lo[0]) * f.sort_scale[0]), 0), (1 << f.sort_bits[0]) - 1);
+    const int cy = min(max(int((py - f.sort_lo[1]) * f.sort_scale[1]), 0), (1 << f.sort_bits[1]) - 1);
+    const int cz = min(max(int((pz - f.sort_lo[2]) * f.sort_scale[2]), 0), (1 << f.sort_bits[2]) - 1);
+    const uint32_t cell = (uint32_t(cx) << (f.sort_bits[1] + f.sort_bits[2])) | (uint32_t(cy) << f.sort_bits[2]) | uint32_t(cz);
+    const uint32_t group = uint32_t(mid) % uint32_t(f.sort_groups);
+    return 1u + group * uint32_t(f.sort_cells) + cell;
 }
 RP_DEV void rp_sort_slice(uint32_t n, uint32_t &begin, uint32_t &end) {
     uint32_t per = (n + RP_SORT_BLOCKS - 1) / RP_SORT_BLOCKS;
@@ -243,51 +227,57 @@ RP_DEV void rp_sort_slice(uint32_t n, uint32_t &begin, uint32_t &end) {
     begin = min(n, blockIdx.x * per);
     end = min(n, begin + per);
 }
-// adds, per distinct key present in the wave, the number of lanes holding it to cursor[key];
-// returns the lane's rank inside its key group plus the group's previous cursor value
-RP_DEV uint32_t rp_wave_multisplit(uint32_t *cursor, uint32_t key, bool valid) {
+// table[key] += 1 for every valid lane; returns the previous value seen by the lane (its slot).
+// The two most common keys of the wave are handled with ballot + one LDS add each.
+RP_DEV uint32_t rp_lds_take(uint32_t *table, uint32_t key, bool valid) {
     const uint32_t lane = rp_lane_id();
     uint32_t pos = 0;
     unsigned long long todo = __ballot(valid);
-    while (todo) {
+#pragma unroll 1
+    for (int it = 0; it < 2 && todo; ++it) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t k = __shfl(key, leader);
         const unsigned long long same = __ballot(valid && key == k);
         uint32_t b = 0;
-        if (int(lane) == leader) b = atomicAdd(&cursor[k], (uint32_t)__popcll(same));
+        if (int(lane) == leader) b = atomicAdd(&table[k], (uint32_t)__popcll(same));
         b = __shfl(b, leader);
         if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
         todo &= ~same;
     }
+    if ((todo >> lane) & 1ull) pos = atomicAdd(&table[key], 1u);
     return pos;
 }
-__global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                                       uint32_t *keys, uint32_t *block_hist, int num_keys) {
+__global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
+                                                       uint32_t *keys, uint32_t *hist) {
     __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
+    const uint32_t n = *count_ptr;
+    if (n < RP_SORT_MIN_N) return;
+    const int num_keys = f.sort_num_keys;
     for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
     __syncthreads();
     uint32_t begin, end;
-    rp_sort_slice(*count_ptr, begin, end);
+    rp_sort_slice(n, begin, end);
     for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
         const bool valid = i < end;
         uint32_t key = 0;
         if (valid) {
-            key = rp_sort_key(sc, ps, queue[i], num_keys);
+            key = rp_sort_key(sc, f, ps, queue[i]);
             keys[i] = key;
         }
-        (void)rp_wave_multisplit(lh, key, valid);
+        (void)rp_lds_take(lh, key, valid);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) block_hist[k * RP_SORT_BLOCKS + blockIdx.x] = lh[k];
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
+        if (lh[k]) atomicAdd(&hist[k], lh[k]);
 }
-// single block: in-place exclusive scan over num_keys * RP_SORT_BLOCKS counters (key-major)
-__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *block_hist, int num_keys) {
+// single block: exclusive scan of hist -> base; clears hist and the scatter cursors for the next bounce
+__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *hist, uint32_t *base, uint32_t *cursor, int num_keys) {
     __shared__ uint32_t partial[1024];
-    const uint32_t total = uint32_t(num_keys) * RP_SORT_BLOCKS;
+    const uint32_t total = uint32_t(num_keys);
     const uint32_t per = (total + 1023u) / 1024u;
     const uint32_t b = threadIdx.x * per, e = min(total, b + per);
     uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += block_hist[i];
+    for (uint32_t i = b; i < e; ++i) sum += hist[i];
     partial[threadIdx.x] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -298,22 +288,42 @@ __global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *block_hist, int
     }
     uint32_t run = partial[threadIdx.x] - sum;
     for (uint32_t i = b; i < e; ++i) {
-        const uint32_t c = block_hist[i];
-        block_hist[i] = run;
+        const uint32_t c = hist[i];
+        base[i] = run;
+        hist[i] = 0;
+        cursor[i] = 0;
         run += c;
     }
 }
-__global__ __launch_bounds__(256) void rp_k_sort_scatter(const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
-                                                         const uint32_t *block_offsets, uint32_t *order, int num_keys) {
-    __shared__ uint32_t cur[RP_SORT_MAX_KEYS];
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) cur[k] = block_offsets[k * RP_SORT_BLOCKS + blockIdx.x];
-    __syncthreads();
+__global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
+                                                         const uint32_t *base, uint32_t *cursor, uint32_t *order) {
+    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
+    const uint32_t n = *count_ptr;
     uint32_t begin, end;
-    rp_sort_slice(*count_ptr, begin, end);
+    rp_sort_slice(n, begin, end);
+    if (n < RP_SORT_MIN_N) { // too few paths for regrouping to pay: keep the queue order
+        for (uint32_t i = begin + threadIdx.x; i < end; i += 256) order[i] = queue[i];
+        return;
+    }
+    const int num_keys = f.sort_num_keys;
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
+    __syncthreads();
+    // pass A: this block's histogram of its slice
     for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
         const bool valid = i < end;
-        const uint32_t key = valid ? keys[i] : 0u;
-        const uint32_t pos = rp_wave_multisplit(cur, key, valid);
+        (void)rp_lds_take(lh, valid ? keys[i] : 0u, valid);
+    }
+    __syncthreads();
+    // reserve one contiguous output range per non-empty bin of this block
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) {
+        const uint32_t c = lh[k];
+        if (c) lh[k] = base[k] + atomicAdd(&cursor[k], c);
+    }
+    __syncthreads();
+    // pass B: scatter
+    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
+        const bool valid = i < end;
+        const uint32_t pos = rp_lds_take(lh, valid ? keys[i] : 0u, valid);
         if (valid) order[pos] = queue[i];
     }
 }
@@ -592,29 +602,27 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
 }
 
 // ------------------------------------------------------------------ RQ_CLOSEST, vulkan/rt_intersect.comp:31-68
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK) void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, int n, float4 *results, int *gstack) {
-    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
-    RpStack st;
-    st.lds = lds_stack + threadIdx.x;
-    st.gstride = gridDim.x * blockDim.x;
-    st.glob = gstack + (blockIdx.x * blockDim.x + threadIdx.x);
-    st.sp = 0;
+__global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, uint32_t n, float4 *results, uint32_t *cursor,
+                                              int *gstack) {
     uint32_t nn = 0, nt = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const float4 *qp = reinterpret_cast<const float4 *>(queries + i);
         const float4 q0 = qp[0], q1 = qp[1];
-        const V3 o = v3(q0.x, q0.y, q0.z), d = v3(q1.x, q1.y, q1.z);
-        if (__float_as_int(q0.w) < 0) continue;
-        const float t_min = RPTR_RAY_EPSILON * len3(o);
-        RpHitRec h;
-        const bool found = rp_traverse<false, false>(sc, o, d, t_min, q1.w, h, st, nn, nt);
+        ro = v3(q0.x, q0.y, q0.z);
+        rd = v3(q1.x, q1.y, q1.z);
+        tmin = RPTR_RAY_EPSILON * len3(ro);              // rt_intersect.comp:40
+        tmax = __float_as_int(q0.w) < 0 ? -1.0f : q1.w;  // mode < 0: skipped query, empty interval
+    };
+    auto done = [&](uint32_t i, const RpHitRec &h) {
+        if (queries[i].mode_or_data < 0) return; // slot stays untouched (rt_intersect.comp:43-44)
         float4 r;
-        if (!found)
+        if (h.inst_idx < 0)
             r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
         else {
             const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[25];
             r = make_float4(h.u, h.v, __int_as_float(geometry_base + h.geom), __int_as_float(h.prim));
         }
         results[i] = r;
-    }
+    };
+    rp_wave_trace<false, false>(sc, n, cursor, gstack, load, done, nn, nt);
 }

@@ -77,7 +77,8 @@ struct rptr_hip {
     RpShadowRays sq;
     uint32_t *queue[2] = {nullptr, nullptr};
     uint32_t *order = nullptr, *keys = nullptr;
-    uint32_t *block_hist = nullptr;
+    uint32_t *sort_hist = nullptr, *sort_base = nullptr, *sort_cursor = nullptr;
+    float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
     RpCounters *counters = nullptr;
     int *gstack = nullptr;
     float4 *accum = nullptr;
@@ -86,7 +87,7 @@ struct rptr_hip {
     int persistent_blocks = 0;
 
     // options (environment, read once)
-    bool use_sort = true;
+    int use_sort = -1; // -1 auto (glTF variant with several materials), 0 off, 1 on (RPTR_SORT)
     bool stage_timing = true;
 
     RptrStats stats;
@@ -250,7 +251,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     h->scene_params.sun_cos_angle = 0.99998933f;
     h->scene_params.sun_radiance[3] = 1.0f;
     h->scene_params.normal_z_scale = 1.0f;
-    if (const char *s = getenv("RPTR_SORT")) h->use_sort = atoi(s) != 0;
+    if (const char *s = getenv("RPTR_SORT")) h->use_sort = atoi(s) != 0 ? 1 : 0;
     if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = atoi(s) != 0;
     *out = h;
     return RPTR_OK;
@@ -321,7 +322,11 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if ((rc = dev_alloc(h, &h->queue[1], cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->order, cap, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->keys, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->block_hist, (size_t)RP_SORT_MAX_KEYS * RP_SORT_BLOCKS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sort_hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sort_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    if ((rc = dev_alloc(h, &h->sort_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
+    HIP_TRY(h, hipMemsetAsync(h->sort_hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->sort_cursor, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
     if ((rc = dev_alloc(h, &h->counters, 1, nullptr))) return rc;
     const size_t npix_local = (size_t)h->width * std::max(h->local_rows, 1);
     if ((rc = dev_alloc(h, &h->accum, npix_local, nullptr))) return rc;
@@ -525,6 +530,10 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     }
     rptr::BuiltTree tlas;
     rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
+    for (int k = 0; k < 3; ++k) {
+        h->scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
+        h->scene_hi[k] = std::isfinite(tlas.hi[k]) ? tlas.hi[k] : 1.0f;
+    }
     const int reloc = (int)tlas.nodes.size();
     h->h_nodes = tlas.nodes; // TLAS leaf 'first' already indexes the reordered instance array
     for (RptrBvhNode nd : blas_nodes) {
@@ -537,6 +546,49 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     for (uint32_t k = 0; k < s->num_instances; ++k) {
         h->h_insts[k] = insts[tlas.order[k]];
         h->h_insts[k].blas_root += reloc;
+    }
+    // ---- hoist the top of the hierarchy to the front of the node array: the first
+    // RP_LDS_NODES nodes in breadth-first order (through TLAS leaves into the BLAS roots)
+    // are the ones the traversal kernels stage in LDS
+    {
+        const size_t nn = h->h_nodes.size();
+        const size_t K = std::min<size_t>(RP_LDS_NODES, nn);
+        std::vector<int32_t> bfs;
+        bfs.reserve(K);
+        std::vector<char> seen(nn, 0);
+        std::vector<std::pair<int32_t, bool>> frontier{{0, true}}; // (node, in TLAS)
+        seen[0] = 1;
+        for (size_t head = 0; head < frontier.size() && bfs.size() < K; ++head) {
+            const int32_t ni = frontier[head].first;
+            const bool in_tlas = frontier[head].second;
+            bfs.push_back(ni);
+            const RptrBvhNode &nd = h->h_nodes[ni];
+            for (int w = 0; w < 2; ++w) {
+                const int32_t c = w ? nd.child1 : nd.child0;
+                const int32_t cnt = w ? nd.cnt1 : nd.cnt0;
+                if (c >= 0) {
+                    if (!seen[c]) { seen[c] = 1; frontier.push_back({c, in_tlas}); }
+                } else if (in_tlas && cnt > 0) {
+                    const int32_t r = h->h_insts[RPTR_BVH_LEAF_FIRST(c)].blas_root;
+                    if (!seen[r]) { seen[r] = 1; frontier.push_back({r, false}); }
+                }
+            }
+        }
+        std::vector<int32_t> new_index(nn, -1);
+        for (size_t i = 0; i < bfs.size(); ++i) new_index[bfs[i]] = (int32_t)i;
+        int32_t next = (int32_t)bfs.size();
+        for (size_t i = 0; i < nn; ++i)
+            if (new_index[i] < 0) new_index[i] = next++;
+        std::vector<RptrBvhNode> reordered(nn);
+        for (size_t i = 0; i < nn; ++i) {
+            RptrBvhNode nd = h->h_nodes[i];
+            if (nd.child0 >= 0) nd.child0 = new_index[nd.child0];
+            if (nd.child1 >= 0) nd.child1 = new_index[nd.child1];
+            reordered[new_index[i]] = nd;
+        }
+        h->h_nodes.swap(reordered);
+        for (RptrBvhInstance &bi : h->h_insts) bi.blas_root = new_index[bi.blas_root];
+        for (MeshRt &mr : h->meshes) mr.node_base = -1; // node ranges are no longer contiguous
     }
     // ---- upload
     RptrBvhNode *d_nodes = nullptr;
@@ -569,6 +621,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->dscene.lights = d_lights;
     h->dscene.num_lights = (int)s->num_lights;
     h->dscene.num_materials = (int)s->num_materials;
+    h->dscene.num_nodes = (uint32_t)h->h_nodes.size();
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
     h->have_scene = true;
@@ -654,8 +707,34 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
     f.world = h->world;
     f.stripe_rows = h->stripe_rows;
     f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
-    const int num_keys = std::min(h->num_materials + 1, RP_SORT_MAX_KEYS);
+    // regrouping grid: material groups x hit cells, bits handed to the longest remaining axis
+    {
+        const int groups = std::max(1, std::min(h->num_materials, 15));
+        int cell_bits = 0;
+        while ((1 + groups * (2 << cell_bits)) <= RP_SORT_MAX_KEYS) ++cell_bits;
+        if (const char *s = getenv("RPTR_SORT_CELL_BITS")) cell_bits = std::max(0, std::min(cell_bits, atoi(s)));
+        float ext[3];
+        for (int k = 0; k < 3; ++k) ext[k] = std::max(h->scene_hi[k] - h->scene_lo[k], 1e-20f);
+        int bits[3] = {0, 0, 0};
+        for (int b = 0; b < cell_bits; ++b) {
+            int ax = 0;
+            for (int k = 1; k < 3; ++k)
+                if (ext[k] / float(1 << bits[k]) > ext[ax] / float(1 << bits[ax])) ax = k;
+            bits[ax]++;
+        }
+        f.sort_groups = groups;
+        f.sort_cells = 1 << cell_bits;
+        f.sort_num_keys = 1 + groups * f.sort_cells;
+        for (int k = 0; k < 3; ++k) {
+            f.sort_lo[k] = h->scene_lo[k];
+            f.sort_bits[k] = bits[k];
+            f.sort_scale[k] = float(1 << bits[k]) / ext[k];
+        }
+    }
 
+    // the regrouping pass costs ~0.4 ms per 1080p x 4 spp frame; it pays when shading diverges
+    // by material (glTF lobes), not for the Lambert-only variant (profiles/r01_notes.md)
+    const bool do_sort = h->use_sort < 0 ? (variant == RPTR_VARIANT_GLTF && h->num_materials > 1) : h->use_sort != 0;
     size_t ev_cursor = 0;
     struct Span {
         hipEvent_t a, b;
@@ -707,13 +786,14 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
                 });
                 launches_extend++;
                 const uint32_t *order = h->queue[in];
-                if (h->use_sort) {
+                if (do_sort) {
                     timed(2, [&] {
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->dscene, h->ps, h->queue[in],
-                                           &h->counters->queue_count[in], h->keys, h->block_hist, num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, h->stream, h->block_hist, num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->queue[in],
-                                           &h->counters->queue_count[in], h->keys, h->block_hist, h->order, num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->dscene, f, h->ps, h->queue[in],
+                                           &h->counters->queue_count[in], h->keys, h->sort_hist);
+                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, h->stream, h->sort_hist, h->sort_base, h->sort_cursor,
+                                           f.sort_num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, f, h->queue[in],
+                                           &h->counters->queue_count[in], h->keys, h->sort_base, h->sort_cursor, h->order);
                     });
                     order = h->order;
                 }
@@ -749,6 +829,17 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
     }
     HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+#ifdef RP_PROF
+    {
+        unsigned long long pr[8];
+        HIP_TRY(h, hipMemcpyFromSymbol(pr, HIP_SYMBOL(rp_prof), sizeof(pr)));
+        fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
+                pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
+                double(pr[1]) / double(pr[3] ? pr[3] : 1), double(pr[4]) / double(pr[3] ? pr[3] : 1));
+        memset(pr, 0, sizeof(pr));
+        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
+    }
+#endif
     HIP_TRY(h, hipGetLastError());
     RptrStats &st = h->stats;
     memset(&st, 0, sizeof(st));
@@ -870,8 +961,11 @@ int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, floa
             rc = fail(h, RPTR_E_HIP, "upload failed");
             break;
         }
-        const int grid = std::min(h->persistent_blocks, (n + RP_TRAVERSE_BLOCK - 1) / RP_TRAVERSE_BLOCK);
-        hipLaunchKernelGGL(rp_k_trace, dim3(grid), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, n, dr, h->gstack);
+        // cursor_extend doubles as the pool cursor of the query kernel (same stream, no overlap with a frame)
+        hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, 0,
+                           (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
+        hipLaunchKernelGGL(rp_k_trace, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
+                           &h->counters->cursor_extend, h->gstack);
         if (hipMemcpyAsync(out4, dr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
             rc = fail(h, RPTR_E_HIP, "trace kernel failed");

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of library variants: tools/ab.sh <lib.so> [<lib.so> ...]  (bench.py, no CPU baseline), prints ms/frame + stage split
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+for lib in "$@"; do
+  RPTR_HIP_LIB=$lib python $R/bench.py --no-cpu-baseline --steps 8 --warmup 2 ${BENCH_ARGS:-} 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); s=d['roofline']['stage_ms_per_step']
+        print('%-40s ms/step %.3f  Mrays/s %.0f  extend %.3f connect %.3f other %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['extend'], s['connect'], s['shade_sort_raygen_resolve']))
+"
+done

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $OUT/bench.log 2>&1
 cp $(find /tmp/prof_$TAG -name "*kernel_stats*") $OUT/ 2>/dev/null
 grep '^{' $OUT/bench.log | tail -1
 python3 - "$OUT" <<'PY'
