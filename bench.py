@@ -4,7 +4,7 @@ tracer on BASELINE.json configs[1]: procedural 1M-triangle mesh, 1920x1080,
 4 spp, diffuse-only BSDF, sun + sky.
 
 One "step" = one frame = 4 samples per pixel through the whole hot path
-(raygen -> {extend, sort, shade, connect} x max_path_depth -> resolve), with the
+(raygen -> {extend, [sort], shade, connect} x max_path_depth -> resolve), with the
 scene resident in HBM. For --gpus N the frame is sharded by 32-row screen
 stripes (stripe s -> rank s % N, no data-path collective while rendering) and
 the tile radiance is gathered to rank 0 over RCCL at the end of every step
@@ -12,7 +12,7 @@ the tile radiance is gathered to rank 0 over RCCL at the end of every step
 
 Rank 0 prints ONE JSON line (contract in the task description) carrying
 `roofline` (dominant kernel = closest-hit traversal `rp_k_extend`) and, at N=1,
-`cpu_baseline` (the CPU oracle timed on a bounded sample of the same frame).
+`cpu_baseline` (the CPU oracle timed on the same frame on all host cores).
 """
 import argparse
 import json
@@ -23,29 +23,28 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
-# struct sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
+# record sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
 HIT_BYTES = 24      # hit_tuv (float4) + hit_ids (int2) written per closest query
-NODE_BYTES = 64     # RptrBvhNode
-TRI_BYTES = 48      # RptrBvhTri
 QUEUE_BYTES = 4     # path id read from the ray queue
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, MI355X_MICROARCH.md
+NODE_BYTES = 64     # RptrBvhNode (an instance record, 128 B, counts as two)
+TRI_BYTES = 48      # RptrBvhTri
+SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-write for a visible shadow ray
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--grid", type=str, default="1000x500", help="quads of the height field (2 tris each)")
+    ap.add_argument("--grid", type=str, default="1000x500", help="quads of the height field (2 triangles each)")
     ap.add_argument("--variant", type=str, default="diffuse", choices=["diffuse", "gltf"])
+    ap.add_argument("--lights", action="store_true", help="configs[2]: add the 512 emissive triangles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=24, help="rows of the frame the CPU baseline renders")
     return ap.parse_args()
 
 
@@ -54,13 +53,13 @@ def main():
     import torch
     import torch.distributed as dist
     from realtimepathtracingresearchframework_amd import abi, backend, scenes
+    from realtimepathtracingresearchframework_amd.distributed import TileGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -70,39 +69,28 @@ def main():
 
     nx, nz = (int(v) for v in args.grid.split("x"))
     t0 = time.time()
-    scene = scenes.grid(nx, nz, name="grid-%dk" % (2 * nx * nz // 1000))
+    scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000))
     t_scene = time.time() - t0
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
 
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream  # the kernels run on torch's current stream
     r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=32, stream=stream)
     r.initialize(W, H)
     t0 = time.time()
     r.set_scene(scene)
     t_build = time.time() - t0
     cam = scene.camera_params()
-
-    # gather plumbing: every rank contributes its packed rows, padded to the largest tile
-    tile_rows = [r.tile_rows(k) for k in range(world)]
-    tile_pixels = [sum(c for _, c in rows) * W for rows in tile_rows]
-    max_tile = max(tile_pixels)
-    tile = torch.zeros((max_tile, 4), dtype=torch.float32, device="cuda")
-    gathered = [torch.zeros_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+    gather = TileGather(W, H, 32, rank, world, device="cuda")
+    my_bytes = r.local_pixel_count() * 16
 
     def step(count=False):
         cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
         st = r.render(cfg, spp=spp, count_traversal=count)
-        if world > 1:
-            r.copy_tile_to_device(tile.data_ptr(), tile.numel() * 4)
-            dist.gather(tile, gathered, dst=0)
-            if rank == 0:
-                for k in range(world):
-                    off = 0
-                    for first, cnt in tile_rows[k]:
-                        frame[first:first + cnt] = gathered[k][off:off + cnt * W].view(cnt, W, 4)
-                        off += cnt * W
+        if world > 1:  # the path's one collective: tile radiance -> rank 0
+            if my_bytes:
+                r.copy_tile_to_device(gather.tile.data_ptr(), my_bytes)
+            gather.gather()
         return st
 
     for _ in range(args.warmup):
@@ -111,13 +99,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
-    ext_ms = con_ms = shade_ms = gpu_ms = 0.0
+    ext_ms = con_ms = other_ms = gpu_ms = 0.0
     rays = 0
     for _ in range(args.steps):
         st = step()
         ext_ms += st.raw.extend_time_ms
         con_ms += st.raw.connect_time_ms
-        shade_ms += st.raw.shade_time_ms
+        other_ms += st.raw.shade_time_ms
         gpu_ms += st.raw.render_time_ms
         rays += st.raw.rays_closest + st.raw.rays_shadow
     if world > 1:
@@ -125,23 +113,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
 
-    # one untimed instrumented step: node/triangle visit counts of this rank's rays
-    stc = step(count=True)
-    counts = dict(rays_closest=int(stc.raw.rays_closest), rays_shadow=int(stc.raw.rays_shadow), nodes=int(stc.raw.nodes_visited),
-                  tris=int(stc.raw.tris_tested), hits=int(stc.raw.hits_shaded))
-    # split of node/tri visits between closest and shadow queries is not tracked on the device:
-    # a second instrumented run would be needed; the model below charges extend+connect together.
+    # one untimed instrumented step: node / triangle visits of this rank's queries (counted, not modelled)
+    stc = step(count=True).raw
+    cnt = dict(rays_closest=int(stc.rays_closest), rays_shadow=int(stc.rays_shadow), hits=int(stc.hits_shaded),
+               nodes_closest=int(stc.nodes_closest), tris_closest=int(stc.tris_closest),
+               nodes_shadow=int(stc.nodes_visited - stc.nodes_closest), tris_shadow=int(stc.tris_tested - stc.tris_closest))
+    launches_extend = int(stc.launches_extend)
 
     if world > 1:
-        t = torch.tensor([elapsed, float(rays), ext_ms, con_ms, shade_ms, gpu_ms], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        rays = int(tsum[1])
-        ext_ms, con_ms, shade_ms, gpu_ms = (float(tmax[i]) for i in (2, 3, 4, 5))
-
+        t = torch.tensor([elapsed, ext_ms, con_ms, other_ms, gpu_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ext_ms, con_ms, other_ms, gpu_ms = (float(v) for v in t)
+        tr = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        rays = int(tr[0])
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -150,51 +135,60 @@ def main():
     K = args.steps
     ms_per_step = elapsed * 1e3 / K
     mrays = rays / elapsed / 1e6
-    # ---- roofline of the dominant kernels (traversal: extend + connect share one code path)
-    trav_bytes = ((counts["rays_closest"] * (RAY_BYTES + HIT_BYTES + QUEUE_BYTES) + counts["rays_shadow"] * (RAY_BYTES + 16 + 4))
-                  + counts["nodes"] * NODE_BYTES + counts["tris"] * TRI_BYTES)
-    trav_ms = (ext_ms + con_ms) / K
-    achieved = trav_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+    # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH2 traversal), rank 0's share
+    ext_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt["nodes_closest"] * NODE_BYTES
+                 + cnt["tris_closest"] * TRI_BYTES)
+    con_bytes = (cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
+                 + cnt["tris_shadow"] * TRI_BYTES)
+    ext_ms_step = ext_ms / K
+    achieved = ext_bytes / (ext_ms_step * 1e-3) / 1e9 if ext_ms_step > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("traversal_hbm_bytes_per_step")
+            traffic = json.load(open(pmc)).get("rp_k_extend_hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "rp_k_extend+rp_k_connect (BVH2 traversal)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "algorithmic_bytes_per_step": int(trav_bytes), "kernel_ms_per_step": round(trav_ms, 4),
-        "launches_per_step": int(stc.raw.launches_extend + stc.raw.launches_connect),
-        "counts_per_step": counts,
-        "stage_ms_per_step": {"extend": round(ext_ms / K, 4), "connect": round(con_ms / K, 4), "shade_sort_raygen_resolve": round(shade_ms / K, 4),
-                              "gpu_total": round(gpu_ms / K, 4)},
+        "bound": "hbm", "kernel": "rp_k_extend<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
+        "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,
+        "connect": {"kernel": "rp_k_connect<false>", "achieved": round(con_bytes / (con_ms / K * 1e-3) / 1e9, 2) if con_ms > 0 else 0.0,
+                    "algorithmic_bytes_per_step": int(con_bytes), "ms_per_step": round(con_ms / K, 4)},
+        "counts_per_step": cnt,
+        "stage_ms_per_step": {"extend": round(ext_ms_step, 4), "connect": round(con_ms / K, 4),
+                              "raygen_sort_shade_resolve": round(other_ms / K, 4), "gpu_total": round(gpu_ms / K, 4)},
     }
+    bsdf = "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"
+    which = "configs[2]" if args.lights else "configs[1]"
     out = {
         "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: procedural %d-triangle height field, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9"
-                   % (scene.num_tris(), W, H, spp, "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"),
+        "config": {"workload": "%s: procedural %d-triangle height field%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9"
+                   % (which, scene.num_tris(), " + 512 emissive triangles (binned-RIS NEE)" if args.lights else "", W, H, spp, bsdf),
                    "parallelism": "tile%d" % world, "stripe_rows": 32, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,
     }
 
-    # ---- CPU baseline: the oracle on a bounded sample (a band of rows) of the same frame, all host cores
+    # ---- CPU baseline: the oracle on the same frame, all host cores (a rate; 1 warm-up band + the full frame)
     if world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         osc = O.OracleScene(scene)
         osc.build_bvh()
-        rows = (max(0, H // 2 - args.cpu_rows // 2), min(H, H // 2 - args.cpu_rows // 2 + args.cpu_rows))
+        osc.render(W, H, 1, variant=variant, rows=(H // 2, H // 2 + 8), threads=0)  # warm-up
+        cores = O.lib().orc_hw_threads()
+        # bounded sample: the whole frame when there are many cores, a centred band of rows otherwise (~10-30 core-seconds)
+        rows = (0, H) if cores >= 32 else (H // 2 - H // 8, H // 2 + H // 8)
         _, ost = osc.render(W, H, spp, variant=variant, rows=rows, threads=0)
         cpu_rays = ost.rays_closest + ost.rays_shadow
         out["cpu_baseline"] = {
             "value": round(cpu_rays / ost.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(ost.threads), "kind": "port",
-            "sample": "rows %d..%d of the same %dx%d frame at %d spp (%d rays, %.2f s), oracle/liboracle.so scalar BVH2 traversal + shading, "
-                      "std::thread over rows" % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, ost.seconds),
+            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH2 traversal + "
+                      "shading, std::thread over rows)" % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, ost.seconds),
         }
     print(json.dumps(out))
     if world > 1:

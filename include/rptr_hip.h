@@ -228,9 +228,11 @@ typedef struct RptrStats {
     float shade_time_ms;       /* raygen+sort+shade+resolve                      */
     uint64_t rays_closest;     /* +1 per closest query (pt_megakernel.glsl:440)  */
     uint64_t rays_shadow;      /* +1 per issued shadow query (:223-227)          */
-    uint64_t nodes_visited;    /* only when count_traversal was requested        */
-    uint64_t tris_tested;
+    uint64_t nodes_visited;    /* only when count_traversal was requested: all   */
+    uint64_t tris_tested;      /* queries (closest + shadow)                     */
     uint64_t hits_shaded;
+    uint64_t nodes_closest;    /* the closest-hit share of nodes_visited         */
+    uint64_t tris_closest;
     int32_t spp;               /* accumulated samples per pixel                  */
     int32_t launches_extend;
     int32_t launches_connect;

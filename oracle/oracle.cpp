@@ -585,15 +585,21 @@ int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *st
         if (s->view.desc->materials[m].normal_map != -1) return -4; // textures unsupported
     int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
-    std::atomic<int> next_row(a->row_begin);
+    // work items: 64-pixel segments of a row, handed out through one atomic counter
+    const int SEG = 64;
+    const int segs_per_row = (a->width + SEG - 1) / SEG;
+    const long long n_items = (long long)(a->row_end - a->row_begin) * segs_per_row;
+    std::atomic<long long> next_item(0);
     std::vector<PathCounters> pcs(nt);
     auto t0 = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
-        PathCounters &pc = pcs[tid];
+        PathCounters pc; // thread-local (no false sharing), merged at the end
         for (;;) {
-            int y = next_row.fetch_add(1);
-            if (y >= a->row_end) break;
-            for (int x = 0; x < a->width; ++x) {
+            const long long item = next_item.fetch_add(1);
+            if (item >= n_items) break;
+            const int y = a->row_begin + int(item / segs_per_row);
+            const int x0 = int(item % segs_per_row) * SEG, x1 = std::min(a->width, x0 + SEG);
+            for (int x = x0; x < x1; ++x) {
                 float *px = accum + 4 * ((size_t)y * a->width + x);
                 for (int si = 0; si < a->spp; ++si) {
                     uint32_t sample_index = uint32_t(a->sample_begin + si);
@@ -611,6 +617,7 @@ int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *st
                 }
             }
         }
+        pcs[tid] = pc;
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(worker, t);

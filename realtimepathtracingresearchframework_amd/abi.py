@@ -170,7 +170,7 @@ class Stats(C.Structure):
     _fields_ = [
         ("render_time_ms", C.c_float), ("extend_time_ms", C.c_float), ("connect_time_ms", C.c_float), ("shade_time_ms", C.c_float),
         ("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-        ("hits_shaded", C.c_uint64),
+        ("hits_shaded", C.c_uint64), ("nodes_closest", C.c_uint64), ("tris_closest", C.c_uint64),
         ("spp", C.c_int32), ("launches_extend", C.c_int32), ("launches_connect", C.c_int32), ("_pad", C.c_int32),
         ("device_bytes_allocated", C.c_uint64),
     ]

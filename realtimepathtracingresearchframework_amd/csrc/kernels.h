@@ -44,7 +44,7 @@ struct RpCounters {
     uint32_t cursor_extend;
     uint32_t cursor_connect;
     uint32_t _pad[3];
-    unsigned long long rays_closest, rays_shadow, nodes, tris, hits_shaded;
+    unsigned long long rays_closest, rays_shadow, nodes, tris, hits_shaded, nodes_shadow, tris_shadow;
     uint32_t stack_overflow;
     uint32_t _pad2;
 };
@@ -186,8 +186,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpSh
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
         if (rp_lane_id() == 0) {
-            atomicAdd(&ctr->nodes, (unsigned long long)n_nodes);
-            atomicAdd(&ctr->tris, (unsigned long long)n_tris);
+            atomicAdd(&ctr->nodes_shadow, (unsigned long long)n_nodes);
+            atomicAdd(&ctr->tris_shadow, (unsigned long long)n_tris);
         }
     }
 }

@@ -856,8 +856,10 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
     for (const RpCounters &c : batch_counters) {
         st.rays_closest += c.rays_closest;
         st.rays_shadow += c.rays_shadow;
-        st.nodes_visited += c.nodes;
-        st.tris_tested += c.tris;
+        st.nodes_visited += c.nodes + c.nodes_shadow;
+        st.tris_tested += c.tris + c.tris_shadow;
+        st.nodes_closest += c.nodes;
+        st.tris_closest += c.tris;
         st.hits_shaded += c.hits_shaded;
     }
     st.spp = h->accumulated_spp;

@@ -1,0 +1,149 @@
+// render_hip.hpp -- C++ host class over the C ABI, shaped like the reference's
+// `struct RenderBackend` (librender/render_backend.h:68-116) so that the adapter a
+// maintainer adds on the reference side is a thin subclass shim:
+// same method names, same argument meaning, same error convention (failures throw
+// a std::runtime_error like `logged_exception`, util/error_io.h:27-29; read-backs
+// return the element count or 0, render_vulkan.cpp:2256-2275; configure_for
+// returns bool). glm-free: vectors are float[3].
+#pragma once
+#include "../../include/rptr_hip.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace rptr {
+
+struct RenderStats { // librender/render_backend.h:15-24
+    float render_time = 0;
+    float rays_per_second = 0;
+    int spp = 0;
+    short frame_stats_delay = 0;
+    bool has_valid_frame_stats = true;
+    size_t total_device_bytes_allocated = 0;
+};
+
+struct RenderCameraParams { // librender/render_backend.h:26-31
+    float pos[3], dir[3], up[3];
+    float fovy;
+};
+
+struct RenderConfiguration { // librender/render_backend.h:33-40
+    RenderCameraParams camera;
+    double time = 0.0;
+    int active_variant = 0;
+    bool reset_accumulation = false;
+    bool freeze_frame = false;
+};
+
+class RenderHip {
+public:
+    // public data members the app mutates directly (render_backend.h:69-76)
+    RptrRenderParams params;
+    RptrLightSamplingConfig lighting_params;
+    RenderCameraParams camera;
+    bool reset_accumulation = false;
+    bool freeze_frame = false;
+
+    explicit RenderHip(int device_ordinal = 0, int rank = 0, int world_size = 1, int stripe_rows = 32, void *hip_stream = nullptr) {
+        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream};
+        int rc = rptr_hip_create(&info, &h_);
+        if (rc != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_create: ") + rptr_hip_last_error(nullptr));
+        params = RptrRenderParams{1, RPTR_MAX_PATH_DEPTH, RPTR_DEFAULT_RR_PATH_DEPTH, 0, 0.f, 2.5f, 1.f, 4.f, 0, 0, 0.f, -1, 0, 8, 0, 1, 35.f, 0, 0, 0};
+        lighting_params = RptrLightSamplingConfig{0.f, 16, 15.f, 0.f};
+    }
+    ~RenderHip() { rptr_hip_destroy(h_); }
+    RenderHip(const RenderHip &) = delete;
+    RenderHip &operator=(const RenderHip &) = delete;
+
+    std::string name() const { return rptr_hip_name(); }
+    std::vector<std::string> variant_names() const { return {"wavefront-gltf", "wavefront-diffuse"}; }
+
+    void initialize(const int fb_width, const int fb_height) { check(rptr_hip_initialize(h_, fb_width, fb_height)); }
+    // set_scene(const Scene&): the adapter flattens Scene into RptrSceneDesc
+    void set_scene(const RptrSceneDesc &scene) { check(rptr_hip_set_scene(h_, &scene)); }
+    // update_config(SceneConfig): the adapter runs the reference's Hosek fit and passes the result
+    void update_config(const RptrSceneParams &scene_params) { scene_params_ = scene_params; have_scene_params_ = true; }
+    bool configure_for(int variant_idx) {
+        if (variant_idx != RPTR_VARIANT_GLTF && variant_idx != RPTR_VARIANT_SIMPLE) return false;
+        variant_ = variant_idx;
+        return true;
+    }
+
+    void begin_frame(const RenderConfiguration &config) { // render_backend.cpp:17-23
+        camera = config.camera;
+        reset_accumulation = config.reset_accumulation;
+        freeze_frame = config.freeze_frame;
+        configure_for(config.active_variant);
+    }
+    void draw_frame(int spp = 0) {
+        check(rptr_hip_set_params(h_, &params, have_scene_params_ ? &scene_params_ : nullptr, &lighting_params));
+        RptrCamera cam;
+        for (int k = 0; k < 3; ++k) {
+            cam.pos[k] = camera.pos[k];
+            cam.dir[k] = camera.dir[k];
+            cam.up[k] = camera.up[k];
+        }
+        cam.fovy = camera.fovy;
+        check(rptr_hip_render(h_, &cam, variant_, spp > 0 ? spp : (params.batch_spp > 0 ? params.batch_spp : 1), reset_accumulation ? 1 : 0, 0,
+                              &last_));
+        reset_accumulation = false;
+    }
+    void end_frame() {} // process_samples is sequenced inside draw_frame on the same stream
+    RenderStats render(const RenderConfiguration &config, int spp = 0) {
+        begin_frame(config);
+        draw_frame(spp);
+        end_frame();
+        return stats();
+    }
+    RenderStats stats() const { // render_vulkan.cpp:2229-2243 (rays_per_second is filled here; the reference leaves -1)
+        RenderStats s;
+        s.render_time = last_.render_time_ms;
+        s.has_valid_frame_stats = last_.render_time_ms != 0.0f;
+        s.rays_per_second = s.has_valid_frame_stats ? float(double(last_.rays_closest + last_.rays_shadow) / (last_.render_time_ms * 1e-3)) : -1.f;
+        s.spp = last_.spp;
+        s.total_device_bytes_allocated = (size_t)last_.device_bytes_allocated;
+        return s;
+    }
+
+    void get_framebuffer_size(uint32_t whc[3]) const { check(rptr_hip_get_framebuffer_size(h_, whc)); }
+    size_t readback_framebuffer(size_t buffer_size, float *buffer) { // RGBA32F accumulation buffer
+        uint32_t whc[3];
+        get_framebuffer_size(whc);
+        const size_t need = size_t(whc[0]) * whc[1] * 4;
+        if (buffer_size < need) return 0;
+        check(rptr_hip_readback_f32(h_, buffer, buffer_size));
+        return need;
+    }
+    size_t readback_framebuffer(size_t buffer_size, unsigned char *buffer) { // sRGB RGBA8
+        uint32_t whc[3];
+        get_framebuffer_size(whc);
+        const size_t need = size_t(whc[0]) * whc[1] * 4;
+        if (buffer_size < need) return 0;
+        check(rptr_hip_readback_u8(h_, buffer, buffer_size));
+        return need;
+    }
+
+    // enable_ray_queries / render_ray_queries with RQ_CLOSEST (render_backend.h:101-102)
+    void enable_ray_queries(const int max_queries, const int = 0) { max_queries_ = max_queries; }
+    bool render_ray_queries(const RptrRenderRayQuery *queries, int num_queries, float *results4) {
+        if (num_queries > max_queries_) return false;
+        check(rptr_hip_trace(h_, queries, num_queries, results4));
+        return true;
+    }
+    rptr_hip_t *handle() { return h_; }
+
+private:
+    void check(int rc) const {
+        if (rc != RPTR_OK) throw std::runtime_error(std::string("rptr_hip: ") + rptr_hip_last_error(h_));
+    }
+    rptr_hip_t *h_ = nullptr;
+    RptrSceneParams scene_params_{};
+    bool have_scene_params_ = false;
+    int variant_ = RPTR_VARIANT_GLTF;
+    int max_queries_ = 512 * 512;
+    RptrStats last_{};
+};
+
+} // namespace rptr

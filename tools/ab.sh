@@ -7,6 +7,6 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); s=d['roofline']['stage_ms_per_step']
-        print('%-40s ms/step %.3f  Mrays/s %.0f  extend %.3f connect %.3f other %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['extend'], s['connect'], s['shade_sort_raygen_resolve']))
+        print('%-40s ms/step %.3f  Mrays/s %.0f  extend %.3f connect %.3f other %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['extend'], s['connect'], s['raygen_sort_shade_resolve']))
 "
 done
