@@ -48,6 +48,18 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cpu_budget(hw_threads):
+    """Threads for the CPU baseline: the container's CPU quota (cgroup cpu.max) x2 for SMT, capped by the hardware threads.
+    (The GPU box shows 256 hardware threads but grants 16 CPUs; 256 threads run 2x slower than 32 there.)"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, min(hw_threads, 2 * int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, hw_threads)
+
+
 def main():
     args = parse_args()
     import torch
@@ -180,10 +192,10 @@ def main():
         osc = O.OracleScene(scene)
         osc.build_bvh()
         osc.render(W, H, 1, variant=variant, rows=(H // 2, H // 2 + 8), threads=0)  # warm-up
-        cores = O.lib().orc_hw_threads()
+        cores = host_cpu_budget(O.lib().orc_hw_threads())
         # bounded sample: the whole frame when there are many cores, a centred band of rows otherwise (~10-30 core-seconds)
-        rows = (0, H) if cores >= 32 else (H // 2 - H // 8, H // 2 + H // 8)
-        _, ost = osc.render(W, H, spp, variant=variant, rows=rows, threads=0)
+        rows = (0, H) if cores >= 16 else (H // 2 - H // 8, H // 2 + H // 8)
+        _, ost = osc.render(W, H, spp, variant=variant, rows=rows, threads=cores)
         cpu_rays = ost.rays_closest + ost.rays_shadow
         out["cpu_baseline"] = {
             "value": round(cpu_rays / ost.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(ost.threads), "kind": "port",

@@ -87,7 +87,7 @@ struct rptr_hip {
     int persistent_blocks = 0;
 
     // options (environment, read once)
-    int use_sort = -1; // -1 auto (glTF variant with several materials), 0 off, 1 on (RPTR_SORT)
+    int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
     bool stage_timing = true;
 
     RptrStats stats;
@@ -732,9 +732,10 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
         }
     }
 
-    // the regrouping pass costs ~0.4 ms per 1080p x 4 spp frame; it pays when shading diverges
-    // by material (glTF lobes), not for the Lambert-only variant (profiles/r01_notes.md)
-    const bool do_sort = h->use_sort < 0 ? (variant == RPTR_VARIANT_GLTF && h->num_materials > 1) : h->use_sort != 0;
+    // the regrouping pass costs ~0.4 ms per 1080p x 4 spp frame and makes shade up to 1.8x faster per bounce,
+    // but neither on configs[1] (Lambert) nor on configs[2] (glTF + area lights) does that pay for the pass
+    // (profiles/r01_notes.md): it is opt-in (RPTR_SORT=1)
+    const bool do_sort = h->use_sort > 0;
     size_t ev_cursor = 0;
     struct Span {
         hipEvent_t a, b;

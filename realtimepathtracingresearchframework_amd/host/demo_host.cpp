@@ -42,6 +42,12 @@ int main() {
         RptrSceneDesc scene{&g, 1, &mesh, 1, &pm, 1, &inst, 1, &m, 1, nullptr, 0};
         backend.initialize(64, 64);
         backend.set_scene(scene);
+        RptrSceneParams sp{}; // a bare sun (no sky fit here: that is the reference's Hosek code)
+        sp.sun_dir[0] = 0.30151134f; sp.sun_dir[1] = 0.80403025f; sp.sun_dir[2] = 0.50251891f;
+        sp.sun_cos_angle = 0.99998933f;
+        sp.sun_radiance[0] = 25000.f; sp.sun_radiance[1] = 21000.f; sp.sun_radiance[2] = 16000.f; sp.sun_radiance[3] = 1.0f;
+        sp.normal_z_scale = 1.0f;
+        backend.update_config(sp);
         rptr::RenderConfiguration cfg{};
         const float pos[3] = {0, 0.5f, 4}, dir[3] = {0, -0.1f, -1}, up[3] = {0, 1, 0};
         std::memcpy(cfg.camera.pos, pos, 12);

@@ -127,9 +127,10 @@ def test_small_batches_equal_large_batches(small_scenes, monkeypatch):
 
 def test_material_sort_does_not_change_the_image(small_scenes, monkeypatch):
     s = small_scenes["grid_lights"]
-    a, sa, _ = gpu_render(s, 160, 90, 2, abi.VARIANT_GLTF)
+    monkeypatch.setenv("RPTR_SORT", "1")
+    a, sa, _ = gpu_render(s, 320, 180, 2, abi.VARIANT_GLTF)   # > RP_SORT_MIN_N paths: the regrouping pass really runs
     monkeypatch.setenv("RPTR_SORT", "0")
-    b, sb, _ = gpu_render(s, 160, 90, 2, abi.VARIANT_GLTF)
+    b, sb, _ = gpu_render(s, 320, 180, 2, abi.VARIANT_GLTF)
     assert np.array_equal(a, b) and sa.raw.rays_shadow == sb.raw.rays_shadow
 
 
