@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--grid", type=str, default="1000x500", help="quads of the height field (2 triangles each)")
     ap.add_argument("--variant", type=str, default="diffuse", choices=["diffuse", "gltf"])
     ap.add_argument("--lights", action="store_true", help="configs[2]: add the 512 emissive triangles")
+    ap.add_argument("--scene", type=str, default="grid", choices=["grid", "forest"],
+                    help="forest = SURVEY 8d C4: 10 tree meshes x 10k triangles, 1000 instances (10M instanced triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -81,7 +83,10 @@ def main():
 
     nx, nz = (int(v) for v in args.grid.split("x"))
     t0 = time.time()
-    scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000))
+    if args.scene == "forest":
+        scene = scenes.forest()
+    else:
+        scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000))
     t_scene = time.time() - t0
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
@@ -174,12 +179,17 @@ def main():
     }
     bsdf = "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"
     which = "configs[2]" if args.lights else "configs[1]"
+    if args.scene == "forest":
+        what = "C4: instanced forest, %d unique / %d instanced triangles, %d instances" % (scene.num_tris(), scene.num_instanced_tris(),
+                                                                                          len(scene.instances))
+    else:
+        what = "%s: procedural %d-triangle height field%s" % (which, scene.num_tris(),
+                                                              " + 512 emissive triangles (binned-RIS NEE)" if args.lights else "")
     out = {
         "metric": "Mrays/s", "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%s: procedural %d-triangle height field%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9"
-                   % (which, scene.num_tris(), " + 512 emissive triangles (binned-RIS NEE)" if args.lights else "", W, H, spp, bsdf),
+        "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
                    "parallelism": "tile%d" % world, "stripe_rows": 32, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,

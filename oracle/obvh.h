@@ -130,8 +130,12 @@ struct SceneView {
     const RptrSceneDesc *desc = nullptr;
     std::vector<GeomRecord> geoms;         // instanced_geometry[]
     std::vector<int> pmesh_geom_base;      // render_mesh_base_offset per parameterized mesh
+    // float positions of dynamic-mesh geometries (Geometry.dynamic_vertices, pt_megakernel.glsl:526-529),
+    // indexed by global geometry; empty = read the quantised stream
+    std::vector<std::vector<float>> dyn_pos;
     void init(const RptrSceneDesc *s) {
         desc = s;
+        dyn_pos.assign(s->num_geometries, {});
         geoms.clear();
         pmesh_geom_base.clear();
         for (uint32_t pm = 0; pm < s->num_parameterized_meshes; ++pm) {
@@ -157,7 +161,15 @@ struct SceneView {
     }
 };
 
-static inline void geom_tri(const RptrGeometryDesc &g, uint32_t prim, vec3 &v0, vec3 &v1, vec3 &v2) {
+static inline void geom_tri(const SceneView &view, const RptrGeometryDesc &g, uint32_t prim, vec3 &v0, vec3 &v1, vec3 &v2) {
+    const std::vector<float> &dyn = view.dyn_pos[&g - view.desc->geometries];
+    if (!dyn.empty()) {
+        const float *p = &dyn[9 * (size_t)prim];
+        v0 = vec3(p[0], p[1], p[2]);
+        v1 = vec3(p[3], p[4], p[5]);
+        v2 = vec3(p[6], p[7], p[8]);
+        return;
+    }
     vec3 sc(g.quantized_scaling[0], g.quantized_scaling[1], g.quantized_scaling[2]);
     vec3 of(g.quantized_offset[0], g.quantized_offset[1], g.quantized_offset[2]);
     v0 = dequantize_position(g.qpos[3 * prim + 0], sc, of);
@@ -328,7 +340,7 @@ static void build_bvh(const SceneView &sv, Bvh &bvh) {
             const auto &g = s->geometries[mesh.first_geometry + j];
             for (uint32_t p = 0; p < g.num_tris; ++p) {
                 vec3 v0, v1, v2;
-                geom_tri(g, p, v0, v1, v2);
+                geom_tri(sv, g, p, v0, v1, v2);
                 RptrBvhTri t;
                 vec3 e1 = v1 - v0, e2 = v2 - v0;
                 t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
@@ -518,7 +530,7 @@ static bool brute_force(const SceneView &sv, const Ray &ray, Hit &best) {
             const auto &g = s->geometries[mesh.first_geometry + j];
             for (uint32_t p = 0; p < g.num_tris; ++p) {
                 vec3 v0, v1, v2;
-                geom_tri(g, p, v0, v1, v2);
+                geom_tri(sv, g, p, v0, v1, v2);
                 float t, u, v;
                 if (!mt_intersect(o, d, v0, v1 - v0, v2 - v0, t, u, v)) continue;
                 if (!(t > ray.tmin)) continue;

@@ -332,7 +332,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
         int geometryIdx = sc.view.pmesh_geom_base[inst.parameterized_mesh] + h.geom;
         const GeomRecord &geom = sc.view.geoms[geometryIdx];
         vec3 v0, v1, v2;
-        geom_tri(*geom.g, h.prim, v0, v1, v2);
+        geom_tri(sc.view, *geom.g, h.prim, v0, v1, v2);
         mat3 verts(v0, v1, v2);
         mat3 normals;
         mat3x2 uvs;
@@ -464,6 +464,15 @@ void *orc_scene_create(const RptrSceneDesc *desc) {
     return s;
 }
 void orc_scene_destroy(void *p) { delete (Scene *)p; }
+// Dynamic meshes: replace the positions of one geometry by floats (9 per triangle). The oracle's own BVH is
+// REBUILT from scratch on next use (the device refits; closest-hit results must not depend on the topology).
+int orc_scene_set_dynamic_vertices(void *p, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
+    Scene *s = (Scene *)p;
+    if (geometry >= s->view.desc->num_geometries || num_vertices != 3u * s->view.desc->geometries[geometry].num_tris) return -1;
+    s->view.dyn_pos[geometry].assign(xyz, xyz + 3 * (size_t)num_vertices);
+    s->own_built = false;
+    return 0;
+}
 
 static void ensure_own(Scene *s) {
     if (!s->own_built) {

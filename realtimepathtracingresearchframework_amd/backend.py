@@ -242,6 +242,15 @@ class RenderHip:
         self._check(self._L.rptr_hip_local_pixel_count(self._h, C.byref(v)))
         return int(v.value)
 
+    # ---- dynamic meshes (Mesh::Dynamic vertex buffers + BLAS update / TLAS refit, render_vulkan.cpp:942-952,1323-1354)
+    def update_vertices(self, geometry, xyz: np.ndarray):
+        """Replace the float positions of one geometry of a dynamic mesh: xyz is (3*num_tris, 3) float32 (unrolled)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self._L.rptr_hip_update_vertices(self._h, int(geometry), xyz.ctypes.data_as(C.c_void_p), xyz.shape[0]))
+
+    def refit(self):
+        self._check(self._L.rptr_hip_refit(self._h))
+
     def copy_tile_to_device(self, device_ptr, n_bytes):
         self._check(self._L.rptr_hip_copy_tile_to_device(self._h, C.c_void_p(device_ptr), n_bytes))
 

@@ -626,3 +626,92 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
     };
     rp_wave_trace<false, false>(sc, n, cursor, gstack, load, done, nn, nt);
 }
+
+// ------------------------------------------------------------------ refit (dynamic meshes)
+// Stands in for the driver's acceleration-structure UPDATE builds (vulkan/vulkanrt_utils.h:83-105,
+// enqueue_refit): triangles are re-derived from the float vertex buffer, node boxes are recomputed
+// bottom-up one height level per launch, instance bounds from the BLAS roots, then the TLAS levels.
+// tri_box: bounds of the three VERTICES (what the builder bounds, bvh_build.cpp), kept for the node pass
+__global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *tri_box, uint32_t begin, uint32_t count,
+                                                       const float *const *geom_dyn) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        RptrBvhTri t = tris[begin + i];
+        const float *p = geom_dyn[t.geom] + 9ull * t.prim;
+        float *b = tri_box + 6ull * (begin + i);
+        for (int k = 0; k < 3; ++k) {
+            t.v0[k] = p[k];
+            t.e1[k] = p[3 + k] - p[k];
+            t.e2[k] = p[6 + k] - p[k];
+            b[k] = fminf(p[k], fminf(p[3 + k], p[6 + k]));
+            b[3 + k] = fmaxf(p[k], fmaxf(p[3 + k], p[6 + k]));
+        }
+        tris[begin + i] = t;
+    }
+}
+RP_DEV void rp_box_of_child(const RptrBvhNode *nodes, const float *tri_box, const float *inst_box, bool tlas, int child, float lo[3], float hi[3]) {
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = INFINITY;
+        hi[k] = -INFINITY;
+    }
+    if (child >= 0) {
+        const RptrBvhNode &c = nodes[child];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(c.lo0[k], c.lo1[k]);
+            hi[k] = fmaxf(c.hi0[k], c.hi1[k]);
+        }
+    } else {
+        const int first = RPTR_BVH_LEAF_FIRST(child), count = RPTR_BVH_LEAF_COUNT(child);
+        for (int i = 0; i < count; ++i) {
+            const float *b = (tlas ? inst_box : tri_box) + 6ull * (first + i);
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = fminf(lo[k], b[k]);
+                hi[k] = fmaxf(hi[k], b[3 + k]);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvhNode *nodes, const float *tri_box, const float *inst_box, const uint32_t *list,
+                                                        uint32_t begin, uint32_t end) {
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
+        const uint32_t e = list[i];
+        const bool tlas = (e >> 31) != 0;
+        RptrBvhNode &n = nodes[e & 0x7FFFFFFFu];
+        float lo[3], hi[3];
+        rp_box_of_child(nodes, tri_box, inst_box, tlas, n.child0, lo, hi);
+        for (int k = 0; k < 3; ++k) {
+            n.lo0[k] = lo[k];
+            n.hi0[k] = hi[k];
+        }
+        rp_box_of_child(nodes, tri_box, inst_box, tlas, n.child1, lo, hi);
+        for (int k = 0; k < 3; ++k) {
+            n.lo1[k] = lo[k];
+            n.hi1[k] = hi[k];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_refit_instances(const RptrBvhNode *nodes, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const RptrBvhInstance &in = insts[i];
+        const RptrBvhNode &r = nodes[in.blas_root];
+        float mlo[3], mhi[3], lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            mlo[k] = fminf(r.lo0[k], r.lo1[k]);
+            mhi[k] = fmaxf(r.hi0[k], r.hi1[k]);
+            lo[k] = INFINITY;
+            hi[k] = -INFINITY;
+        }
+        const float *M = in.object_to_world;
+        for (int c = 0; c < 8; ++c) {
+            const float p[3] = {c & 1 ? mhi[0] : mlo[0], c & 2 ? mhi[1] : mlo[1], c & 4 ? mhi[2] : mlo[2]};
+            for (int rr = 0; rr < 3; ++rr) {
+                const float w = ((M[4 * rr] * p[0] + M[4 * rr + 1] * p[1]) + M[4 * rr + 2] * p[2]) + M[4 * rr + 3];
+                lo[rr] = fminf(lo[rr], w);
+                hi[rr] = fmaxf(hi[rr], w);
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            inst_box[6 * i + k] = lo[k];
+            inst_box[6 * i + 3 + k] = hi[k];
+        }
+    }
+}

@@ -11,6 +11,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -71,6 +72,18 @@ struct rptr_hip {
     std::vector<MeshRt> meshes;
     std::vector<void *> scene_allocs;
     int num_lights = 0, num_materials = 0;
+    // dynamic meshes (Mesh::Dynamic: float vertex buffer + BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354)
+    std::vector<float *> d_dynpos;          // per global geometry: device float positions (9 per triangle) or NULL
+    std::vector<uint32_t> geom_tris;        // per global geometry: triangle count
+    std::vector<int> geom_mesh;             // per global geometry: owning mesh
+    std::vector<char> mesh_dirty;
+    std::vector<const float **> d_mesh_dyn; // per mesh: device table of its geometries' dyn_pos pointers
+    std::vector<int> mesh_root;             // per mesh: absolute node index of the BLAS root
+    uint32_t *d_refit_list = nullptr;       // node indices, bit 31 = TLAS node
+    std::vector<std::array<uint32_t, 2>> refit_levels_blas, refit_levels_tlas; // [begin, end) per height
+    float *d_inst_box = nullptr;
+    float *d_tri_box = nullptr;             // bounds of every BLAS triangle of the dynamic meshes (indexed like tris)
+    bool host_bvh_stale = false;
 
     // device buffers (frame sized)
     RpPathState ps;
@@ -410,6 +423,37 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             d_qnu[g] = dn;
         }
     }
+    // ---- dynamic meshes keep full-precision float positions next to the quantised stream
+    h->d_dynpos.assign(s->num_geometries, nullptr);
+    h->geom_tris.assign(s->num_geometries, 0);
+    h->geom_mesh.assign(s->num_geometries, -1);
+    h->mesh_dirty.assign(s->num_meshes, 0);
+    h->d_mesh_dyn.assign(s->num_meshes, nullptr);
+    for (uint32_t m = 0; m < s->num_meshes; ++m) {
+        const RptrMeshDesc &mesh = s->meshes[m];
+        std::vector<const float *> table(mesh.num_geometries, nullptr);
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const uint32_t gi = mesh.first_geometry + j;
+            const RptrGeometryDesc &gd = s->geometries[gi];
+            h->geom_tris[gi] = gd.num_tris;
+            h->geom_mesh[gi] = (int)m;
+            if (!mesh.dynamic) continue;
+            std::vector<float> pos((size_t)gd.num_tris * 9);
+            for (size_t v = 0; v < (size_t)gd.num_tris * 3; ++v) dequantize_position(gd.qpos[v], gd.quantized_scaling, gd.quantized_offset, &pos[3 * v]);
+            float *dp = nullptr;
+            if ((rc = dev_alloc(h, &dp, pos.size(), &h->scene_allocs))) return rc;
+            if (!pos.empty()) HIP_TRY(h, hipMemcpy(dp, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice));
+            h->d_dynpos[gi] = dp;
+            table[j] = dp;
+        }
+        if (mesh.dynamic) {
+            const float **dt = nullptr;
+            if ((rc = dev_alloc(h, &dt, table.size(), &h->scene_allocs))) return rc;
+            if (!table.empty()) HIP_TRY(h, hipMemcpy(dt, table.data(), table.size() * sizeof(float *), hipMemcpyHostToDevice));
+            h->d_mesh_dyn[m] = dt;
+            h->mesh_dirty[m] = 2;
+        }
+    }
     // ---- geometry records per (parameterized mesh, geometry): instanced_geometry[] (render_vulkan.cpp:2748-2850)
     std::vector<RpGeomRecord> geoms;
     std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
@@ -433,11 +477,12 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             r.qpos = d_qpos[gi];
             r.qnrm_uv = d_qnu[gi];
             r.mat_ids = d_ids ? d_ids + prim_offset : nullptr;
-            r.dyn_pos = nullptr;
+            r.dyn_pos = h->d_dynpos[gi];
             memcpy(r.scaling, gd.quantized_scaling, 12);
             memcpy(r.offset, gd.quantized_offset, 12);
             r.material_id = d_ids ? -1 - pm.material_offsets[j] : pm.material_offsets[j];
-            r.flags = (gd.has_normals && d_qnu[gi] ? RP_GEOM_HAS_NORMALS : 0u) | (gd.has_uvs && d_qnu[gi] ? RP_GEOM_HAS_UVS : 0u);
+            r.flags = (gd.has_normals && d_qnu[gi] ? RP_GEOM_HAS_NORMALS : 0u) | (gd.has_uvs && d_qnu[gi] ? RP_GEOM_HAS_UVS : 0u) |
+                      (h->d_dynpos[gi] ? RP_GEOM_DYNAMIC : 0u);
             // material index range check
             const int max_local = d_ids ? 255 : 0;
             if (pm.material_offsets[j] < 0 || (uint32_t)(pm.material_offsets[j]) >= s->num_materials)
@@ -588,7 +633,50 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         }
         h->h_nodes.swap(reordered);
         for (RptrBvhInstance &bi : h->h_insts) bi.blas_root = new_index[bi.blas_root];
+        h->mesh_root.assign(h->meshes.size(), -1);
+        for (size_t m = 0; m < h->meshes.size(); ++m) h->mesh_root[m] = new_index[h->meshes[m].node_base];
         for (MeshRt &mr : h->meshes) mr.node_base = -1; // node ranges are no longer contiguous
+    }
+    // ---- refit schedule: nodes of the dynamic meshes by height (children before parents), then the TLAS by height
+    std::vector<uint32_t> refit_list;
+    h->refit_levels_blas.clear();
+    h->refit_levels_tlas.clear();
+    {
+        const size_t nn = h->h_nodes.size();
+        std::vector<int> height(nn, -1);
+        auto collect = [&](int root, bool tlas, std::vector<std::vector<uint32_t>> &by_height) {
+            // iterative post-order: height = 1 + max(height of inner children), 0 for nodes with leaf children only
+            std::vector<std::pair<int, int>> st{{root, 0}};
+            while (!st.empty()) {
+                auto [n, phase] = st.back();
+                st.pop_back();
+                const RptrBvhNode &nd = h->h_nodes[n];
+                if (phase == 0) {
+                    st.push_back({n, 1});
+                    if (nd.child0 >= 0) st.push_back({nd.child0, 0});
+                    if (nd.child1 >= 0) st.push_back({nd.child1, 0});
+                } else {
+                    int hgt = 0;
+                    if (nd.child0 >= 0) hgt = std::max(hgt, height[nd.child0] + 1);
+                    if (nd.child1 >= 0) hgt = std::max(hgt, height[nd.child1] + 1);
+                    height[n] = hgt;
+                    if ((size_t)hgt >= by_height.size()) by_height.resize(hgt + 1);
+                    by_height[hgt].push_back((uint32_t)n | (tlas ? 0x80000000u : 0u));
+                }
+            }
+        };
+        std::vector<std::vector<uint32_t>> blas_levels, tlas_levels;
+        for (size_t m = 0; m < h->meshes.size(); ++m)
+            if (h->meshes[m].dynamic) collect(h->mesh_root[m], false, blas_levels);
+        collect(0, true, tlas_levels);
+        for (auto &lv : blas_levels) {
+            h->refit_levels_blas.push_back({(uint32_t)refit_list.size(), (uint32_t)(refit_list.size() + lv.size())});
+            refit_list.insert(refit_list.end(), lv.begin(), lv.end());
+        }
+        for (auto &lv : tlas_levels) {
+            h->refit_levels_tlas.push_back({(uint32_t)refit_list.size(), (uint32_t)(refit_list.size() + lv.size())});
+            refit_list.insert(refit_list.end(), lv.begin(), lv.end());
+        }
     }
     // ---- upload
     RptrBvhNode *d_nodes = nullptr;
@@ -605,6 +693,12 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     // light buffer padded with one zeroed bin (+1): sample_tri_lights may read light_id == bin_end
     const size_t light_cap = (size_t)s->num_lights + RPTR_BINNED_LIGHTS_BIN_MAX_SIZE + 1;
     if ((rc = dev_alloc(h, &d_lights, light_cap, &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &h->d_refit_list, refit_list.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &h->d_inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
+    h->d_tri_box = nullptr;
+    if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->d_tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
+    if (!refit_list.empty()) HIP_TRY(h, hipMemcpy(h->d_refit_list, refit_list.data(), refit_list.size() * 4, hipMemcpyHostToDevice));
+    h->host_bvh_stale = false;
     HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode), hipMemcpyHostToDevice));
     if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(d_tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyHostToDevice));
     if (!h->h_insts.empty())
@@ -631,10 +725,54 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     return RPTR_OK;
 }
 
-int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t, const float *, uint32_t) {
-    return fail(h, RPTR_E_UNSUPPORTED, "dynamic meshes (update_vertices/refit) are not built yet");
+int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
+    if (!h || !xyz) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "update_vertices before set_scene");
+    if (geometry >= h->d_dynpos.size() || !h->d_dynpos[geometry])
+        return fail(h, RPTR_E_INVALID, "geometry %u does not belong to a dynamic mesh (RptrMeshDesc.dynamic)", geometry);
+    if (num_vertices != 3u * h->geom_tris[geometry])
+        return fail(h, RPTR_E_INVALID, "geometry %u has %u unrolled vertices, got %u", geometry, 3u * h->geom_tris[geometry], num_vertices);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_dynpos[geometry], xyz, (size_t)num_vertices * 12, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the host array is only borrowed for the call
+    h->mesh_dirty[h->geom_mesh[geometry]] = 1;
+    return RPTR_OK;
 }
-int rptr_hip_refit(rptr_hip_t *h) { return fail(h, RPTR_E_UNSUPPORTED, "dynamic meshes (update_vertices/refit) are not built yet"); }
+
+// ≙ BLAS update (VK_BUILD_ACCELERATION_STRUCTURE_MODE_UPDATE) of the dirty dynamic meshes + TLAS refit
+// (render_vulkan.cpp:1323-1354, executed at the top of draw_frame :2165): topology is kept, triangles and all
+// boxes are recomputed on the device, level by level from the leaves up.
+int rptr_hip_refit(rptr_hip_t *h) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "refit before set_scene");
+    HIP_TRY(h, hipSetDevice(h->device));
+    bool any = false;
+    RptrBvhTri *tris = const_cast<RptrBvhTri *>(h->dscene.tris);
+    RptrBvhNode *nodes = const_cast<RptrBvhNode *>(h->dscene.nodes);
+    RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(h->dscene.insts);
+    for (size_t m = 0; m < h->meshes.size(); ++m) any = any || h->mesh_dirty[m] == 1;
+    if (!any) return RPTR_OK;
+    for (size_t m = 0; m < h->meshes.size(); ++m) {
+        if (!h->mesh_dirty[m]) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
+        const MeshRt &mr = h->meshes[m];
+        if (mr.tri_count)
+            hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, h->stream, tris, h->d_tri_box,
+                               (uint32_t)mr.tri_base, (uint32_t)mr.tri_count, h->d_mesh_dyn[m]);
+        h->mesh_dirty[m] = 0;
+    }
+    // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
+    for (auto &lv : h->refit_levels_blas)
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_tri_box, h->d_inst_box, h->d_refit_list,
+                           lv[0], lv[1]);
+    const uint32_t ni = (uint32_t)h->h_insts.size();
+    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, h->stream, nodes, insts, h->d_inst_box, ni);
+    for (auto &lv : h->refit_levels_tlas)
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_tri_box, h->d_inst_box, h->d_refit_list,
+                           lv[0], lv[1]);
+    HIP_TRY(h, hipGetLastError());
+    h->host_bvh_stale = true;
+    return RPTR_OK;
+}
 
 // host part of a3: vulkan/render_vulkan.cpp:2880-2896
 static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
@@ -983,6 +1121,13 @@ int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, floa
 int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances, size_t *n_instances) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "export before set_scene");
+    if (h->host_bvh_stale) { // a refit happened on the device: refresh the host mirror first
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(h->h_nodes.data(), h->dscene.nodes, h->h_nodes.size() * sizeof(RptrBvhNode), hipMemcpyDeviceToHost));
+        if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(h->h_tris.data(), h->dscene.tris, h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyDeviceToHost));
+        h->host_bvh_stale = false;
+    }
     if (nodes && n_nodes && *n_nodes >= h->h_nodes.size()) memcpy(nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode));
     if (tris && n_tris && *n_tris >= h->h_tris.size()) memcpy(tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri));
     if (instances && n_instances && *n_instances >= h->h_insts.size())

@@ -449,6 +449,15 @@ def grid(nx=1000, nz=500, with_emitters=False, name=None, deform_t=None) -> Scen
     return s
 
 
+def grid_positions(nx, nz, deform_t):
+    """Unrolled float32 positions (6*nx*nz, 3) of grid(nx, nz) at animation time deform_t: what the app
+    writes into the dynamic vertex buffer each frame (C5). Same vertex order as grid()'s geometry 0."""
+    def h(X, Z):
+        return 2.0 * fbm(X, Z) + 0.5 * np.sin(0.4 * X + 2 * np.pi * deform_t)
+    P, _, _ = _heightfield(nx, nz, -50.0, 50.0, -25.0, 25.0, h)
+    return np.ascontiguousarray(np.asarray(P, dtype=f32).reshape(-1, 3))
+
+
 def grid_1m():
     """BASELINE.json configs[1]: procedural 1M-triangle mesh."""
     return grid(1000, 500, name="grid-1M")
@@ -488,5 +497,90 @@ def two_level_test(n_inst=12, seed=5) -> Scene:
     s.camera = dict(eye=(0, 2, 12), center=(0, 0, 0), up=(0, 1, 0), fov=50.0)
     s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
     s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s
+
+
+# ------------------------------------------------------------------ C4: instanced forest
+def _tree_mesh(seed, target_tris=10000):
+    """A procedural tree (recursive branching prisms + leaf quads) with exactly `target_tris` triangles.
+    Returns (tris (n,3,3) float32, per-triangle material id 0 = bark, 1 = leaf)."""
+    rng = np.random.default_rng(seed)
+    tris, mats = [], []
+
+    def prism(p0, p1, r0, r1, sides=5):
+        axis = p1 - p0
+        axis /= np.linalg.norm(axis)
+        ref = np.array([1.0, 0, 0]) if abs(axis[0]) < 0.9 else np.array([0, 1.0, 0])
+        u = np.cross(axis, ref)
+        u /= np.linalg.norm(u)
+        v = np.cross(axis, u)
+        ang = np.linspace(0, 2 * np.pi, sides, endpoint=False)
+        ring0 = [p0 + r0 * (np.cos(a) * u + np.sin(a) * v) for a in ang]
+        ring1 = [p1 + r1 * (np.cos(a) * u + np.sin(a) * v) for a in ang]
+        for k in range(sides):
+            a, b, c, d = ring0[k], ring0[(k + 1) % sides], ring1[(k + 1) % sides], ring1[k]
+            tris.extend([[a, b, c], [a, c, d]])
+            mats.extend([0, 0])
+
+    def leaf(p, size):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        ref = np.array([0, 1.0, 0]) if abs(n[1]) < 0.9 else np.array([1.0, 0, 0])
+        u = np.cross(n, ref)
+        u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+        a, b, c, d = p - size * u - size * v, p + size * u - size * v, p + size * u + size * v, p - size * u + size * v
+        tris.extend([[a, b, c], [a, c, d]])
+        mats.extend([1, 1])
+
+    tips = []
+
+    def grow(p, d, length, radius, depth):
+        q = p + d * length
+        prism(p, q, radius, radius * 0.7)
+        if depth == 0 or len(tris) > target_tris * 0.45:
+            tips.append((q, length))
+            return
+        for _ in range(int(rng.integers(2, 4))):
+            nd = d + rng.normal(size=3) * 0.55
+            nd[1] = abs(nd[1]) * 0.6 + 0.25
+            nd /= np.linalg.norm(nd)
+            grow(q, nd, length * rng.uniform(0.62, 0.8), radius * 0.65, depth - 1)
+    grow(np.zeros(3), np.array([0, 1.0, 0]), 1.6, 0.16, 7)
+    while len(tris) < target_tris:
+        tip, length = tips[int(rng.integers(len(tips)))]
+        leaf(tip + rng.normal(size=3) * length * 0.6, rng.uniform(0.05, 0.12))
+    return np.array(tris[:target_tris], dtype=f32), np.array(mats[:target_tris], dtype=np.uint8)
+
+
+def forest(n_meshes=10, tris_per_tree=10000, n_instances=1000, name="forest-10M") -> Scene:
+    """n_meshes tree meshes x tris_per_tree triangles, n_instances instances on a jittered grid
+    (seed 77, random yaw, uniform scale 0.8-1.3 -- the reference's transform model: translation, uniform scale,
+    rotation, ext/libvkr/src/vkr.c:1346-1411) + a 2-triangle ground: 10 000 002 instanced triangles by default."""
+    s = Scene(name=name)
+    s.materials = [abi.make_material((0.35, 0.25, 0.15), roughness=0.8), abi.make_material((0.2, 0.5, 0.15), roughness=0.6),
+                   abi.make_material((0.45, 0.4, 0.3), roughness=0.9)]
+    for m in range(n_meshes):
+        T, mat = _tree_mesh(m + 1, tris_per_tree)
+        mesh = _add_mesh(s, T)
+        s.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=mat))
+    half = 2.2 * np.sqrt(n_instances) / 2
+    g = _add_mesh(s, np.array(_quad((-half, 0, -half), (-half, 0, half), (half, 0, half), (half, 0, -half)), dtype=f32))
+    s.pmeshes.append(ParameterizedMesh(mesh=g, material_offsets=np.array([2], np.int32)))
+    rng = np.random.default_rng(77)
+    side = int(np.ceil(np.sqrt(n_instances)))
+    for i in range(n_instances):
+        gx, gz = i % side, i // side
+        x = (gx + 0.5 + rng.uniform(-0.35, 0.35)) / side * 2 * half - half
+        z = (gz + 0.5 + rng.uniform(-0.35, 0.35)) / side * 2 * half - half
+        yaw, sc = rng.uniform(0, 2 * np.pi), rng.uniform(0.8, 1.3)
+        c, sn = np.cos(yaw) * sc, np.sin(yaw) * sc
+        M = np.array([[c, 0, sn, x], [0, sc, 0, 0], [-sn, 0, c, z]], dtype=f32)
+        s.instances.append(Instance(transform=M, pmesh=i % n_meshes))
+    s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=n_meshes))
+    s.camera = dict(eye=(0, 6, half * 0.9), center=(0, 2, 0), up=(0, 1, 0), fov=60.0)
+    s.config = SceneConfig(**SKY_CONFIGS["forest"])
+    s.sky_key = "forest"
     s.prepare_lights()
     return s

@@ -53,6 +53,7 @@ def lib():
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_build_bvh.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.orc_scene_import_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_scene_set_dynamic_vertices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_trace_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
@@ -91,6 +92,11 @@ class OracleScene:
         c = (C.c_uint64 * 3)()
         lib().orc_scene_build_bvh(self.h, c)
         return tuple(int(x) for x in c)
+
+    def set_dynamic_vertices(self, geometry, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        rc = lib().orc_scene_set_dynamic_vertices(self.h, int(geometry), _p(xyz), xyz.shape[0])
+        assert rc == 0, "orc_scene_set_dynamic_vertices(%d) rejected %d vertices" % (geometry, xyz.shape[0])
 
     def import_bvh(self, nodes, tris, insts):
         self._bvh_keep = (nodes, tris, insts)

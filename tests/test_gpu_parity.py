@@ -242,3 +242,49 @@ def test_full_size_queries_sorted_and_consistent(grid_1m):
     prim = res[hit, 3].view(np.int32)
     assert prim.min() >= 0 and prim.max() < 1000000
     r.close()
+
+
+# ---------------------------------------------------------------- instanced forest
+def test_small_forest_trace_and_image_parity():
+    """two-level hierarchy with overlapping instances of shared meshes: 4 meshes x 400 triangles, 36 instances."""
+    s = scenes.forest(n_meshes=4, tris_per_tree=400, n_instances=36, name="forest-small")
+    W, H, spp = 160, 90, 2
+    img, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, count=True, keep=True)
+    osc = O.OracleScene(s)
+    q = random_queries(np.random.default_rng(8), 20000, -7, 7)
+    q[:, 1] = np.abs(q[:, 1]) + 0.2
+    res = r.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).mean() > 0.3
+    osc.import_bvh(*r.export_bvh())
+    ref_img, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, bvh_mode=O.BVH_IMPORTED, count=True)
+    rmse, same, _ = image_error(img, ref_img)
+    assert same and rmse < RMSE_TOL
+    assert st.raw.nodes_visited == ost.nodes_closest + ost.nodes_shadow and st.raw.tris_tested == ost.tris_closest + ost.tris_shadow
+    r.close()
+
+
+def test_full_forest_10m_instanced_triangles():
+    """C4 at full size: 10 meshes x 10k triangles, 1000 instances + ground = 10 000 002 instanced triangles. Properties:
+    deterministic, every hit names a valid (geometry, primitive), and a band of rows equals the oracle."""
+    s = scenes.forest()
+    assert s.num_instanced_tris() == 10_000_002
+    W, H = 1920, 1080
+    a, sa, r = gpu_render(s, W, H, 1, abi.VARIANT_GLTF, keep=True)
+    q = random_queries(np.random.default_rng(5), 1 << 18, -30, 30)
+    q[:, 1] = np.abs(q[:, 1]) * 0.3 + 0.5
+    res = r.render_ray_queries(q)
+    hit = res[:, 0] >= 0
+    assert hit.mean() > 0.5
+    geom, prim = res[hit, 2].view(np.int32), res[hit, 3].view(np.int32)   # instanced-geometry index: 10 trees + ground
+    assert geom.min() >= 0 and geom.max() <= 10 and prim.min() >= 0 and prim.max() < 10000
+    assert (res[hit, 0] + res[hit, 1] <= 1.0 + 1e-6).all()
+    r.close()
+    b, sb, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF)
+    assert np.array_equal(a, b) and sa.raw.rays_closest == sb.raw.rays_closest and np.isfinite(a).all()
+    rows = (600, 606)
+    osc = O.OracleScene(s)
+    ref, _ = osc.render(W, H, 1, variant=abi.VARIANT_GLTF, rows=rows)
+    rmse, same, _ = image_error(a[rows[0]:rows[1]], ref[rows[0]:rows[1]])
+    assert same and rmse < RMSE_TOL

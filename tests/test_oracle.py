@@ -310,3 +310,29 @@ def test_cornell_lights_are_the_two_ceiling_triangles():
     assert s.num_tris() == 32 and len(s.lights) == 2
     assert np.allclose(s.lights[:, 3], 15.0)
     assert np.allclose(s.lights[:, :3, 1], 0.995, atol=1e-5)
+
+
+def test_dynamic_vertices_rebuild_equals_brute_force():
+    """orc_scene_set_dynamic_vertices: float positions override the quantised stream in the builder, the brute-force
+    loop and the hit attributes (pt_megakernel.glsl:526-529)."""
+    s = scenes.grid(24, 12, deform_t=0.0)
+    osc = O.OracleScene(s)
+    rng = np.random.default_rng(2)
+    n = 4000
+    o = rng.uniform(-55, 55, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(3, 8, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:, 1] = -np.abs(d[:, 1])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    before = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_OWN)[0]
+    P = scenes.grid_positions(24, 12, 0.3)
+    osc.set_dynamic_vertices(0, P)
+    tuv_b, ids_b = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_BRUTE)
+    tuv_t, ids_t = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_OWN)
+    assert np.array_equal(tuv_b.view(np.uint32), tuv_t.view(np.uint32)) and np.array_equal(ids_b, ids_t)
+    assert not np.array_equal(before, tuv_t) and (ids_t[:, 0] >= 0).sum() > 1000
+    # hit points lie on the deformed surface: y(hit) within the new vertex range of the hit triangle
+    hit = ids_t[:, 0] >= 0
+    y = o[hit, 1] + tuv_t[hit, 0] * d[hit, 1]
+    tri = P.reshape(-1, 3, 3)[ids_t[hit, 2]]
+    assert (y >= tri[:, :, 1].min(axis=1) - 1e-3).all() and (y <= tri[:, :, 1].max(axis=1) + 1e-3).all()
