@@ -301,6 +301,13 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
  * bits(primitive_index)); miss = (-1,-1,bits(-1),bits(-1)); mode_or_data < 0
  * leaves the result slot untouched. Host pointers. */
 int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4);
+/* diagnostic twin: also returns, per query, the node and triangle visits of the traversal
+ * (visits2[2*i], visits2[2*i+1]; may be NULL) -- the counts behind the roofline's algorithmic bytes,
+ * checked ray by ray against the oracle walking the exported tree. tmin (NULL = the RQ_CLOSEST rule
+ * eps*|origin|) gives explicit interval starts; any_hit != 0 runs the occlusion traversal of the
+ * shadow rays instead (out4[4*i] = 1 if anything is hit in (tmin, t_max)). No reference counterpart. */
+int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4, uint32_t *visits2,
+                           const float *tmin, int any_hit);
 
 /* ---- test/diagnostic access to the acceleration structure (node format in
  * DESIGN.md): copies out the flattened BVH so the oracle can traverse the very

@@ -76,13 +76,25 @@ struct PathCounters {
     TraceCounters tc_closest, tc_shadow;
 };
 
+// diagnostic ray log (single-threaded renders only): 9 floats per ray = o, tmin, d, tmax, any(0/1)
+static float *g_ray_log = nullptr;
+static size_t g_ray_log_cap = 0, g_ray_log_n = 0;
+static inline void log_ray(const Ray &r, bool any) {
+    if (!g_ray_log || g_ray_log_n >= g_ray_log_cap) return;
+    float *p = g_ray_log + 9 * g_ray_log_n++;
+    p[0] = r.o.x; p[1] = r.o.y; p[2] = r.o.z; p[3] = r.tmin;
+    p[4] = r.d.x; p[5] = r.d.y; p[6] = r.d.z; p[7] = r.tmax;
+    p[8] = any ? 1.0f : 0.0f;
+}
 static inline bool trace_closest(const Frame &f, const Ray &r, Hit &h, PathCounters &pc) {
     pc.rays_closest++;
+    log_ray(r, false);
     if (f.bvh) return traverse<false>(*f.bvh, r, h, f.count ? &pc.tc_closest : nullptr);
     return brute_force<false>(f.sc->view, r, h);
 }
 static inline bool trace_any(const Frame &f, const Ray &r, PathCounters &pc) {
     pc.rays_shadow++;
+    log_ray(r, true);
     Hit h;
     if (f.bvh) return traverse<true>(*f.bvh, r, h, f.count ? &pc.tc_shadow : nullptr);
     return brute_force<true>(f.sc->view, r, h);
@@ -507,8 +519,16 @@ static const Bvh *pick_bvh(Scene *s, int mode) {
 }
 
 // vulkan/rt_intersect.comp:31-68. counters: [nodes, tris] accumulated when non-NULL.
+static int trace_queries(Scene *s, int bvh_mode, const RptrRenderRayQuery *q, int n, float *out4, uint64_t *counters, uint32_t *per_ray);
 int orc_trace(void *p, int bvh_mode, const RptrRenderRayQuery *q, int n, float *out4, uint64_t *counters) {
-    Scene *s = (Scene *)p;
+    return trace_queries((Scene *)p, bvh_mode, q, n, out4, counters, nullptr);
+}
+// same, plus per-query visit counts (per_ray[2*i] = nodes, [2*i+1] = triangles) of the canonical traversal order
+int orc_trace_counts(void *p, int bvh_mode, const RptrRenderRayQuery *q, int n, float *out4, uint32_t *per_ray) {
+    uint64_t total[2] = {0, 0};
+    return trace_queries((Scene *)p, bvh_mode, q, n, out4, total, per_ray);
+}
+static int trace_queries(Scene *s, int bvh_mode, const RptrRenderRayQuery *q, int n, float *out4, uint64_t *counters, uint32_t *per_ray) {
     if (bvh_mode == 2 && !s->has_imported) return -1;
     const Bvh *bvh = pick_bvh(s, bvh_mode);
     TraceCounters tc;
@@ -517,7 +537,12 @@ int orc_trace(void *p, int bvh_mode, const RptrRenderRayQuery *q, int n, float *
         if (q[i].mode_or_data < 0) continue;
         Ray r{o, d, RPTR_RAY_EPSILON * length(o), q[i].t_max};
         Hit h;
+        const uint64_t n0 = tc.nodes, t0 = tc.tris;
         bool found = bvh ? traverse<false>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<false>(s->view, r, h);
+        if (per_ray) {
+            per_ray[2 * i] = uint32_t(tc.nodes - n0);
+            per_ray[2 * i + 1] = uint32_t(tc.tris - t0);
+        }
         if (!found) {
             out4[4 * i + 0] = -1.0f;
             out4[4 * i + 1] = -1.0f;
@@ -540,9 +565,17 @@ int orc_trace(void *p, int bvh_mode, const RptrRenderRayQuery *q, int n, float *
 }
 
 // full-interval variant for traversal tests: explicit t_min, returns t as well; any_hit!=0 -> out[0]=1/0
+int orc_trace_ex_counts(void *p, int bvh_mode, int any_hit, const float *o3, const float *d3, const float *tmin, const float *tmax, int n,
+                        float *out_tuv, int32_t *out_ids, uint64_t *counters, uint32_t *per_ray);
 int orc_trace_ex(void *p, int bvh_mode, int any_hit, const float *o3, const float *d3, const float *tmin, const float *tmax, int n,
                  float *out_tuv, int32_t *out_ids /*inst,geom,prim*/, uint64_t *counters) {
+    return orc_trace_ex_counts(p, bvh_mode, any_hit, o3, d3, tmin, tmax, n, out_tuv, out_ids, counters, nullptr);
+}
+int orc_trace_ex_counts(void *p, int bvh_mode, int any_hit, const float *o3, const float *d3, const float *tmin, const float *tmax, int n,
+                        float *out_tuv, int32_t *out_ids, uint64_t *counters, uint32_t *per_ray) {
     Scene *s = (Scene *)p;
+    uint64_t local[2] = {0, 0};
+    if (per_ray && !counters) counters = local;
     if (bvh_mode == 2 && !s->has_imported) return -1;
     const Bvh *bvh = pick_bvh(s, bvh_mode);
     TraceCounters tc;
@@ -550,10 +583,15 @@ int orc_trace_ex(void *p, int bvh_mode, int any_hit, const float *o3, const floa
         Ray r{vec3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), vec3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]), tmin[i], tmax[i]};
         Hit h;
         bool found;
+        const uint64_t n0 = tc.nodes, t0 = tc.tris;
         if (any_hit)
             found = bvh ? traverse<true>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<true>(s->view, r, h);
         else
             found = bvh ? traverse<false>(*bvh, r, h, counters ? &tc : nullptr) : brute_force<false>(s->view, r, h);
+        if (per_ray) {
+            per_ray[2 * i] = uint32_t(tc.nodes - n0);
+            per_ray[2 * i + 1] = uint32_t(tc.tris - t0);
+        }
         if (any_hit) {
             out_ids[3 * i] = found ? 1 : 0;
             out_ids[3 * i + 1] = out_ids[3 * i + 2] = 0;
@@ -769,6 +807,14 @@ void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,d
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }
+// every ray of the following single-threaded orc_render calls is appended to buf (9 floats each); returns the count so far
+size_t orc_set_ray_log(float *buf, size_t cap_rays) {
+    const size_t n = g_ray_log_n;
+    g_ray_log = buf;
+    g_ray_log_cap = cap_rays;
+    g_ray_log_n = 0;
+    return n;
+}
 // copies out the oracle-built tree (sizes first with NULL buffers)
 int orc_scene_export_bvh(void *p, RptrBvhNode *nodes, RptrBvhTri *tris, RptrBvhInstance *insts) {
     Scene *s = (Scene *)p;

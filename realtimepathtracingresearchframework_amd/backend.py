@@ -59,6 +59,7 @@ def load_library(path=None):
     L.rptr_hip_local_pixel_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_copy_tile_to_device.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_trace.argtypes = [vp, vp, i32, vp]
+    L.rptr_hip_trace_counted.argtypes = [vp, vp, i32, vp, vp, vp, i32]
     L.rptr_hip_export_bvh.argtypes = [vp, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.rptr_hip_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     for name in abi.EXPORTED_SYMBOLS:
@@ -228,6 +229,18 @@ class RenderHip:
             results = np.zeros((len(q), 4), dtype=np.float32)
         self._check(self._L.rptr_hip_trace(self._h, q.ctypes.data_as(C.c_void_p), len(q), results.ctypes.data_as(C.c_void_p)))
         return results
+
+    def trace_counted(self, queries: np.ndarray, tmin: np.ndarray = None, any_hit=False):
+        """diagnostic: (results (n,4) float32, visits (n,2) uint32 = nodes, triangles per query); tmin: explicit interval
+        starts; any_hit: the shadow-ray traversal (results[:,0] = 1 if occluded)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
+        results = np.zeros((len(q), 4), dtype=np.float32)
+        visits = np.zeros((len(q), 2), dtype=np.uint32)
+        tm = None if tmin is None else np.ascontiguousarray(tmin, dtype=np.float32)
+        self._check(self._L.rptr_hip_trace_counted(self._h, q.ctypes.data_as(C.c_void_p), len(q), results.ctypes.data_as(C.c_void_p),
+                                                   visits.ctypes.data_as(C.c_void_p), None if tm is None else tm.ctypes.data_as(C.c_void_p),
+                                                   1 if any_hit else 0))
+        return results, visits
 
     # ---- multi-GPU helpers
     def tile_rows(self, rank=None):

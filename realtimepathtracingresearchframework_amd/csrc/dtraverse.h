@@ -332,7 +332,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     tp += 96;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (j == 1 && !two) break;
+                        if (j == 1 && (!two || (ANY && any_hit))) break; // occlusion: the first accepted hit ends the query
                         const float4 q0 = j ? qb0 : qa0, q1 = j ? qb1 : qa1, q2 = j ? qb2 : qa2;
                         if (COUNT) n_tris++;
                         const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);

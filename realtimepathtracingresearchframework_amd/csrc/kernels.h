@@ -602,21 +602,31 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
 }
 
 // ------------------------------------------------------------------ RQ_CLOSEST, vulkan/rt_intersect.comp:31-68
+// COUNT: also writes per-query visit counts (nodes, triangles) -- the diagnostic behind rptr_hip_trace_counted
+// ANY (diagnostic only): occlusion query over (tmin_arr[i], t_max), result.x = 1 when anything is hit
+template <bool COUNT, bool ANY>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, uint32_t n, float4 *results, uint32_t *cursor,
-                                              int *gstack) {
-    uint32_t nn = 0, nt = 0;
+                                              int *gstack, uint2 *per_ray, const float *tmin_arr) {
+    uint32_t nn = 0, nt = 0, nn_prev = 0, nt_prev = 0;
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const float4 *qp = reinterpret_cast<const float4 *>(queries + i);
         const float4 q0 = qp[0], q1 = qp[1];
         ro = v3(q0.x, q0.y, q0.z);
         rd = v3(q1.x, q1.y, q1.z);
-        tmin = RPTR_RAY_EPSILON * len3(ro);              // rt_intersect.comp:40
+        tmin = tmin_arr ? tmin_arr[i] : RPTR_RAY_EPSILON * len3(ro); // rt_intersect.comp:40
         tmax = __float_as_int(q0.w) < 0 ? -1.0f : q1.w;  // mode < 0: skipped query, empty interval
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
+        if (COUNT && per_ray) { // the lane's counters run across its queries: report the difference
+            per_ray[i] = make_uint2(nn - nn_prev, nt - nt_prev);
+            nn_prev = nn;
+            nt_prev = nt;
+        }
         if (queries[i].mode_or_data < 0) return; // slot stays untouched (rt_intersect.comp:43-44)
         float4 r;
-        if (h.inst_idx < 0)
+        if (ANY)
+            r = make_float4(h.inst_idx < 0 ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f);
+        else if (h.inst_idx < 0)
             r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
         else {
             const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[25];
@@ -624,7 +634,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
         }
         results[i] = r;
     };
-    rp_wave_trace<false, false>(sc, n, cursor, gstack, load, done, nn, nt);
+    rp_wave_trace<ANY, COUNT>(sc, n, cursor, gstack, load, done, nn, nt);
 }
 
 // ------------------------------------------------------------------ refit (dynamic meshes)

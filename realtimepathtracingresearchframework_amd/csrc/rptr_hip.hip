@@ -1083,6 +1083,10 @@ int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
 }
 
 int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4) {
+    return rptr_hip_trace_counted(h, queries, n, out4, nullptr, nullptr, 0);
+}
+
+int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4, uint32_t *visits2, const float *tmin, int any_hit) {
     if (!h || !queries || !out4 || n < 0) return fail(h, RPTR_E_INVALID, "bad argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "trace before set_scene");
     if (!h->gstack) return fail(h, RPTR_E_INVALID, "trace before initialize");
@@ -1090,24 +1094,39 @@ int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, floa
     HIP_TRY(h, hipSetDevice(h->device));
     RptrRenderRayQuery *dq = nullptr;
     float4 *dr = nullptr;
+    uint2 *dv = nullptr;
+    float *dt = nullptr;
     HIP_TRY(h, hipMalloc((void **)&dq, (size_t)n * sizeof(RptrRenderRayQuery)));
-    if (hipMalloc((void **)&dr, (size_t)n * sizeof(float4)) != hipSuccess) {
+    if (hipMalloc((void **)&dr, (size_t)n * sizeof(float4)) != hipSuccess || (visits2 && hipMalloc((void **)&dv, (size_t)n * sizeof(uint2)) != hipSuccess) ||
+        (tmin && hipMalloc((void **)&dt, (size_t)n * sizeof(float)) != hipSuccess)) {
         (void)hipFree(dq);
+        (void)hipFree(dr);
+        (void)hipFree(dv);
         return fail(h, RPTR_E_NOMEM, "hipMalloc failed");
     }
     int rc = RPTR_OK;
     do {
         if (hipMemcpyAsync(dq, queries, (size_t)n * sizeof(RptrRenderRayQuery), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-            hipMemcpyAsync(dr, out4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+            hipMemcpyAsync(dr, out4, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            (tmin && hipMemcpyAsync(dt, tmin, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream) != hipSuccess)) {
             rc = fail(h, RPTR_E_HIP, "upload failed");
             break;
         }
         // cursor_extend doubles as the pool cursor of the query kernel (same stream, no overlap with a frame)
         hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, 0,
                            (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
-        hipLaunchKernelGGL(rp_k_trace, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
-                           &h->counters->cursor_extend, h->gstack);
-        if (hipMemcpyAsync(out4, dr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
+                               &h->counters->cursor_extend, h->gstack, dv, dt);
+        };
+        if (any_hit)
+            launch(rp_k_trace<true, true>);
+        else if (visits2)
+            launch(rp_k_trace<true, false>);
+        else
+            launch(rp_k_trace<false, false>);
+        if ((visits2 && hipMemcpyAsync(visits2, dv, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
+            hipMemcpyAsync(out4, dr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
             rc = fail(h, RPTR_E_HIP, "trace kernel failed");
             break;
@@ -1115,6 +1134,8 @@ int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, floa
     } while (0);
     (void)hipFree(dq);
     (void)hipFree(dr);
+    (void)hipFree(dv);
+    (void)hipFree(dt);
     return rc;
 }
 

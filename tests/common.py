@@ -44,3 +44,32 @@ def random_queries(rng, n, lo, hi, t_max=1e20):
     q[:, 4:7] = d
     q[:, 7] = t_max
     return q
+
+
+def assert_ray_visit_parity(r, osc, W, H, spp, variant, max_rays=1 << 21):
+    """Every ray of an oracle render (closest-hit AND occlusion rays, with their real intervals) is replayed through the
+    device traversal: results and per-ray node / triangle visit counts must equal the oracle walking the exported tree.
+    (Counts of a whole GPU render can differ from the oracle's by a few visits: libm differences of an ulp in a sampled
+    direction change that ray's walk. Ray by ray on identical inputs the walk is exact.)"""
+    osc.import_bvh(*r.export_bvh())
+    _, st, rays = osc.render_logged(W, H, spp, max_rays, variant=variant, bvh_mode=O.BVH_IMPORTED, count=True)
+    assert len(rays) == st.rays_closest + st.rays_shadow
+    total = np.zeros(2, np.uint64)
+    for any_hit in (False, True):
+        sel = rays[rays[:, 8] == (1.0 if any_hit else 0.0)]
+        q = np.zeros((len(sel), 8), np.float32)
+        q[:, 0:3], q[:, 4:7], q[:, 7] = sel[:, 0:3], sel[:, 4:7], sel[:, 7]
+        res, vis = r.trace_counted(q, tmin=sel[:, 3], any_hit=any_hit)
+        tuv, ids, rv = osc.trace_ex_counts(sel[:, 0:3], sel[:, 4:7], sel[:, 3], sel[:, 7], any_hit=any_hit)
+        assert np.array_equal(vis, rv), "%d of %d %s rays walk differently" % ((vis != rv).any(axis=1).sum(), len(sel),
+                                                                             "occlusion" if any_hit else "closest-hit")
+        if any_hit:
+            assert np.array_equal(res[:, 0] != 0, ids[:, 0] != 0)
+        else:
+            hit = ids[:, 0] >= 0
+            assert np.array_equal(res[:, 0] >= 0, hit)
+            assert np.array_equal(res[hit, 0:2].view(np.uint32), tuv[hit, 1:3].view(np.uint32))
+            assert np.array_equal(res[hit, 3].view(np.int32), ids[hit, 2])
+        total += vis.sum(axis=0, dtype=np.uint64)
+    assert int(total[0]) == st.nodes_closest + st.nodes_shadow and int(total[1]) == st.tris_closest + st.tris_shadow
+    return st

@@ -55,6 +55,11 @@ def lib():
         L.orc_scene_import_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.orc_scene_set_dynamic_vertices.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_trace_ex_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_ray_log.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_set_ray_log.restype = C.c_size_t
+        L.orc_trace_counts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_trace_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats)]
@@ -103,6 +108,15 @@ class OracleScene:
         return lib().orc_scene_import_bvh(self.h, _p(nodes), nodes.size * nodes.itemsize // 64, _p(tris), tris.size * tris.itemsize // 48,
                                           _p(insts), insts.size * insts.itemsize // 128)
 
+    def trace_counts(self, queries, bvh_mode=BVH_IMPORTED):
+        """(results (n,4), visits (n,2) uint32): per-query node / triangle visits of the canonical traversal order."""
+        q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros((len(q), 4), dtype=np.float32)
+        visits = np.zeros((len(q), 2), dtype=np.uint32)
+        rc = lib().orc_trace_counts(self.h, bvh_mode, _p(q), len(q), _p(out), _p(visits))
+        assert rc == 0
+        return out, visits
+
     def trace(self, queries, bvh_mode=BVH_OWN, count=False, out=None):
         """queries: (n,8) float32 view of RenderRayQuery[n]. Returns (n,4) float32 [, (nodes,tris)]."""
         q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 8)
@@ -126,6 +140,30 @@ class OracleScene:
                                 _p(cnt) if count else None)
         assert rc == 0
         return (tuv, ids, (int(cnt[0]), int(cnt[1]))) if count else (tuv, ids)
+
+    def trace_ex_counts(self, o, d, tmin, tmax, any_hit=False, bvh_mode=BVH_IMPORTED):
+        """like trace_ex, plus per-ray visits (n,2) uint32."""
+        o = np.ascontiguousarray(o, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        n = len(o)
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float32), (n,)))
+        tuv = np.zeros((n, 3), dtype=np.float32)
+        ids = np.zeros((n, 3), dtype=np.int32)
+        visits = np.zeros((n, 2), dtype=np.uint32)
+        rc = lib().orc_trace_ex_counts(self.h, bvh_mode, 1 if any_hit else 0, _p(o), _p(d), _p(tmin), _p(tmax), n, _p(tuv), _p(ids), None, _p(visits))
+        assert rc == 0
+        return tuv, ids, visits
+
+    def render_logged(self, width, height, spp, max_rays, **kw):
+        """single-threaded render that records every ray: returns (accum, stats, rays (n,9) = o,tmin,d,tmax,any)."""
+        buf = np.zeros((max_rays, 9), dtype=np.float32)
+        lib().orc_set_ray_log(_p(buf), max_rays)
+        try:
+            accum, st = self.render(width, height, spp, threads=1, **kw)
+        finally:
+            n = lib().orc_set_ray_log(None, 0)
+        return accum, st, buf[:n]
 
     def render(self, width, height, spp, variant=abi.VARIANT_GLTF, params=None, lighting=None, rows=None, sample_begin=0,
                frame_offset=0, bvh_mode=BVH_OWN, threads=0, count=False, accum=None, camera=None, scene_params=None):
