@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--lights", action="store_true", help="configs[2]: add the 512 emissive triangles")
     ap.add_argument("--scene", type=str, default="grid", choices=["grid", "forest"],
                     help="forest = SURVEY 8d C4: 10 tree meshes x 10k triangles, 1000 instances (10M instanced triangles)")
+    ap.add_argument("--animate", action="store_true",
+                    help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
+                         "(inside the timed region) and renders")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -86,7 +89,8 @@ def main():
     if args.scene == "forest":
         scene = scenes.forest()
     else:
-        scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000))
+        scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000),
+                            deform_t=0.0 if args.animate else None)
     t_scene = time.time() - t0
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
@@ -101,7 +105,29 @@ def main():
     gather = TileGather(W, H, 32, rank, world, device="cuda")
     my_bytes = r.local_pixel_count() * 16
 
+    anim = None
+    if args.animate:
+        # stand-in for the reference's animation compute shader: y = y0 + 0.5 sin(0.4 x + 2 pi t), written by a torch
+        # elementwise kernel on the same stream, then handed over device-to-device
+        g0 = scene.geometries[0]
+        base = torch.from_numpy(scenes.dequantize_positions(g0.qpos, g0.scaling, g0.offset)).cuda()
+        anim = {"base": base, "cur": base.clone(), "frame": 0, "refit_ms": 0.0, "ev": []}
+
+    def animate():
+        t = 0.02 * anim["frame"]
+        anim["frame"] += 1
+        cur, b = anim["cur"], anim["base"]
+        torch.add(b[:, 1], torch.sin(b[:, 0] * 0.4 + 6.283185307179586 * t), alpha=0.5, out=cur[:, 1])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
+        r.refit()
+        e1.record()
+        anim["ev"].append((e0, e1))
+
     def step(count=False):
+        if anim is not None:
+            animate()
         cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
         st = r.render(cfg, spp=spp, count_traversal=count)
         if world > 1:  # the path's one collective: tile radiance -> rank 0
@@ -112,6 +138,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if anim is not None:
+        anim["ev"].clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -129,6 +157,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
+    refit_ms = sum(a.elapsed_time(b) for a, b in anim["ev"]) / max(len(anim["ev"]), 1) if anim is not None else None
 
     # one untimed instrumented step: node / triangle visits of this rank's queries (counted, not modelled)
     stc = step(count=True).raw
@@ -177,11 +206,15 @@ def main():
         "stage_ms_per_step": {"extend": round(ext_ms_step, 4), "connect": round(con_ms / K, 4),
                               "raygen_sort_shade_resolve": round(other_ms / K, 4), "gpu_total": round(gpu_ms / K, 4)},
     }
+    if refit_ms is not None:
+        roofline["stage_ms_per_step"]["update_vertices_and_refit"] = round(refit_ms, 4)
     bsdf = "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"
     which = "configs[2]" if args.lights else "configs[1]"
     if args.scene == "forest":
         what = "C4: instanced forest, %d unique / %d instanced triangles, %d instances" % (scene.num_tris(), scene.num_instanced_tris(),
                                                                                           len(scene.instances))
+    elif args.animate:
+        what = "C5: animated %d-triangle height field (dynamic mesh, device-side vertex animation + BVH refit every frame)" % scene.num_tris()
     else:
         what = "%s: procedural %d-triangle height field%s" % (which, scene.num_tris(),
                                                               " + 512 emissive triangles (binned-RIS NEE)" if args.lights else "")

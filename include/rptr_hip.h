@@ -259,6 +259,9 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *scene);
 /* ---- dynamic meshes: replace the float positions of one geometry and refit
  * (≙ BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354) */
 int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices);
+/* same with a DEVICE source (the reference animates with a compute shader that writes the float vertex
+ * buffer, render_vulkan.cpp:2834-2840): a device-to-device copy ordered on the backend's stream */
+int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const float *device_xyz, uint32_t num_vertices);
 int rptr_hip_refit(rptr_hip_t *h);
 
 /* ---- RenderBackend::params / lighting_params / update_config

@@ -10,6 +10,7 @@ library or without a GPU every compute call raises `BackendError`.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -37,6 +38,14 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise BackendError(abi.RPTR_E_NO_DEVICE, "%s is missing: build it with __graft_entry__.build() "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # PyTorch-ROCm bundles its own HIP runtime under the same soname as /opt/rocm's. Whichever is loaded first serves
+    # the whole process, and torch fails with "No HIP GPUs are available" when it finds the system one already loaded.
+    # The tile gather (distributed.py) needs torch in the same process, so torch's libraries go first when it is installed.
+    if "torch" not in sys.modules and os.environ.get("RPTR_SKIP_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     vp, i32 = C.c_void_p, C.c_int
     L.rptr_hip_create.argtypes = [C.POINTER(abi.CreateInfo), C.POINTER(vp)]
@@ -49,6 +58,7 @@ def load_library(path=None):
     L.rptr_hip_initialize.argtypes = [vp, i32, i32]
     L.rptr_hip_set_scene.argtypes = [vp, C.POINTER(abi.SceneDesc)]
     L.rptr_hip_update_vertices.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
+    L.rptr_hip_update_vertices_device.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
     L.rptr_hip_refit.argtypes = [vp]
     L.rptr_hip_set_params.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.SceneParams), C.POINTER(abi.LightSamplingConfig)]
     L.rptr_hip_render.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(abi.Stats)]
@@ -260,6 +270,10 @@ class RenderHip:
         """Replace the float positions of one geometry of a dynamic mesh: xyz is (3*num_tris, 3) float32 (unrolled)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
         self._check(self._L.rptr_hip_update_vertices(self._h, int(geometry), xyz.ctypes.data_as(C.c_void_p), xyz.shape[0]))
+
+    def update_vertices_device(self, geometry, device_ptr, num_vertices):
+        """same from a device buffer (float32 xyz per unrolled vertex) written on the backend's stream."""
+        self._check(self._L.rptr_hip_update_vertices_device(self._h, int(geometry), C.c_void_p(device_ptr), int(num_vertices)))
 
     def refit(self):
         self._check(self._L.rptr_hip_refit(self._h))

@@ -725,7 +725,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     return RPTR_OK;
 }
 
-int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
+static int update_vertices_common(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices, bool device_src) {
     if (!h || !xyz) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "update_vertices before set_scene");
     if (geometry >= h->d_dynpos.size() || !h->d_dynpos[geometry])
@@ -733,10 +733,19 @@ int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz,
     if (num_vertices != 3u * h->geom_tris[geometry])
         return fail(h, RPTR_E_INVALID, "geometry %u has %u unrolled vertices, got %u", geometry, 3u * h->geom_tris[geometry], num_vertices);
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_dynpos[geometry], xyz, (size_t)num_vertices * 12, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream)); // the host array is only borrowed for the call
+    HIP_TRY(h, hipMemcpyAsync(h->d_dynpos[geometry], xyz, (size_t)num_vertices * 12, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              h->stream));
+    if (!device_src) HIP_TRY(h, hipStreamSynchronize(h->stream)); // the host array is only borrowed for the call
     h->mesh_dirty[h->geom_mesh[geometry]] = 1;
     return RPTR_OK;
+}
+int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
+    return update_vertices_common(h, geometry, xyz, num_vertices, false);
+}
+// the reference animates on the device (a compute shader writes float_vertex_buf, render_vulkan.cpp:2834-2840):
+// same call with a DEVICE source, ordered on the backend's stream, no host synchronisation
+int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const float *device_xyz, uint32_t num_vertices) {
+    return update_vertices_common(h, geometry, device_xyz, num_vertices, true);
 }
 
 // ≙ BLAS update (VK_BUILD_ACCELERATION_STRUCTURE_MODE_UPDATE) of the dirty dynamic meshes + TLAS refit

@@ -67,6 +67,9 @@ public:
     void update_config(const RptrSceneParams &scene_params) { scene_params_ = scene_params; have_scene_params_ = true; }
     // dynamic meshes: float positions of one geometry (3 per unrolled vertex), then BLAS update + TLAS refit
     void update_vertices(uint32_t geometry, const float *xyz, uint32_t num_vertices) { check(rptr_hip_update_vertices(h_, geometry, xyz, num_vertices)); }
+    void update_vertices_device(uint32_t geometry, const float *device_xyz, uint32_t num_vertices) {
+        check(rptr_hip_update_vertices_device(h_, geometry, device_xyz, num_vertices));
+    }
     void refit() { check(rptr_hip_refit(h_)); }
     bool configure_for(int variant_idx) {
         if (variant_idx != RPTR_VARIANT_GLTF && variant_idx != RPTR_VARIANT_SIMPLE) return false;

@@ -168,3 +168,25 @@ def test_update_vertices_error_convention(dyn_grid):
     with pytest.raises(backend.BackendError):        # geometry out of range
         r.update_vertices(7, np.zeros((3, 3), np.float32))
     r.close()
+
+
+def test_device_source_update_equals_host_source_update(dyn_grid):
+    """rptr_hip_update_vertices_device: the animation lives on the GPU (torch tensor here, a compute shader in the reference)."""
+    import torch
+    P = scenes.grid_positions(NX, NZ, 0.25)
+    q = _grid_queries(8000, 9)
+    out = []
+    for device_src in (False, True):
+        r = backend.RenderHip(stream=torch.cuda.current_stream().cuda_stream)
+        r.initialize(64, 64)
+        r.set_scene(dyn_grid)
+        if device_src:
+            t = torch.from_numpy(P).cuda()
+            r.update_vertices_device(0, t.data_ptr(), t.shape[0])
+        else:
+            r.update_vertices(0, P)
+        r.refit()
+        out.append((r.render_ray_queries(q).copy(), [x.copy() for x in r.export_bvh()]))
+        r.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(out[0][1], out[1][1]))
