@@ -4,17 +4,21 @@
  * The layout is part of the diagnostic ABI (rptr_hip_export_bvh) so that the
  * test oracle can walk the very same tree; see DESIGN.md "Data layout in HBM".
  *
- * Two-level BVH2:
+ * Two-level, 4-wide, compressed (what the device traverses: RptrBvh4Node):
  *   - one node array holds the TLAS (root = node 0) followed by every BLAS;
- *   - a node stores the AABBs of BOTH children (Aila/Laine style), so one
- *     64-byte fetch decides both slab tests;
+ *   - a 64-byte node holds the boxes of up to FOUR children, quantised to 8 bits per plane on a
+ *     per-node grid: plane = origin[a] + q * 2^(exp[a]-127). One 64-byte fetch decides four slab
+ *     tests (the traversal is bound by the number of divergent fetches);
  *   - child >= 0 : inner node index (absolute, into the shared node array)
- *     child <  0 : leaf, packed so that it can sit on the traversal stack as is:
+ *     child <= -2: leaf, packed so that it can sit on the traversal stack as is:
  *                  v = -2 - child; first = v >> 3; count = v & 7
- *                  (RPTR_BVH_LEAF(first,count) / RPTR_BVH_LEAF_FIRST / _COUNT);
- *                  cnt0/cnt1 repeat the count. In the TLAS a leaf lists `count`
- *                  (0 or 1) RptrBvhInstance records, in a BLAS `count` RptrBvhTri.
- *   - an empty child (count == 0 leaf) has an inverted box (lo=+inf, hi=-inf).
+ *                  (RPTR_BVH_LEAF(first,count) / RPTR_BVH_LEAF_FIRST / _COUNT).
+ *                  In the TLAS a leaf lists `count` (1) RptrBvhInstance records, in a BLAS
+ *                  `count` (1..RPTR_BVH_MAX_LEAF_TRIS) RptrBvhTri;
+ *     child == RPTR_BVH4_EMPTY: unused slot (its box is inverted: qlo = 255, qhi = 0).
+ *
+ * RptrBvhNode (2-wide, float boxes of both children) is the intermediate form of the host builder
+ * (csrc/bvh_build.h) and of the test oracle's own tree; the device never sees it.
  */
 #ifndef RPTR_BVH_H
 #define RPTR_BVH_H
@@ -36,6 +40,17 @@ typedef struct RptrBvhNode { /* 64 bytes */
     int32_t child0, child1;
     int32_t cnt0, cnt1;
 } RptrBvhNode;
+
+#define RPTR_BVH4_EMPTY (INT32_MIN + 2)
+typedef struct RptrBvh4Node { /* 64 bytes, four 16-byte loads */
+    float origin[3];   /* lower corner of the node's box                                         */
+    uint8_t exp[3];    /* biased float exponents of the grid steps: step[a] = 2^(exp[a]-127)     */
+    uint8_t _pad0;
+    uint8_t qlo[3][4]; /* [axis][child]: lower planes, rounded down                              */
+    uint8_t qhi[3][4]; /* [axis][child]: upper planes, rounded up                                */
+    int32_t child[4];
+    uint32_t _pad1[2];
+} RptrBvh4Node;
 
 /* Moeller-Trumbore ready triangle, object space of its mesh: 48 bytes */
 typedef struct RptrBvhTri {

@@ -179,7 +179,8 @@ static inline void geom_tri(const SceneView &view, const RptrGeometryDesc &g, ui
 
 // ------------------------------------------------------------------ BVH container (own build or imported)
 struct Bvh {
-    std::vector<RptrBvhNode> nodes;
+    std::vector<RptrBvhNode> nodes;   // the oracle's own tree: 2-wide, float boxes
+    std::vector<RptrBvh4Node> nodes4; // a tree imported from the device (rptr_hip_export_bvh): 4-wide, 8-bit boxes
     std::vector<RptrBvhTri> tris;
     std::vector<RptrBvhInstance> insts;
 };
@@ -432,7 +433,15 @@ static inline void decode_leaf(int enc, int &first, int &count) {
     count = RPTR_BVH_LEAF_COUNT(enc);
 }
 template <bool ANY>
+static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt);
+template <bool ANY>
+static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt);
+template <bool ANY>
 static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
+    return bvh.nodes4.empty() ? traverse2<ANY>(bvh, ray, best, cnt) : traverse4<ANY>(bvh, ray, best, cnt);
+}
+template <bool ANY>
+static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
     best.t = ray.tmax;
     best.inst = -1;
     best.u = best.v = 0;
@@ -499,6 +508,103 @@ static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *c
                     if (!accept) continue;
                     best.t = t; best.u = u; best.v = v;
                     best.inst = ii; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
+                    best.lo = o; best.ld = d;
+                    if (ANY) return true;
+                }
+                pop = true;
+            }
+        }
+        if (pop) {
+            if (sp == 0) return best.inst >= 0;
+            cur = stack[--sp];
+        }
+    }
+}
+
+// The device's tree (include/rptr_bvh.h RptrBvh4Node), walked in the device's canonical order
+// (csrc/dtraverse.h header): per node the four child boxes are tested on the node's 8-bit grid with
+// t = fma(q, A, B), A = step/d, B = (origin - o)/d; hit children are ordered by
+// key = (bits(t_near) & 0x7FFFFFFC) | slot ascending; the first is visited next, the others are pushed
+// so that the nearest pops first. Leaves, instances and the triangle test are those of traverse2.
+template <bool ANY>
+static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
+    best.t = ray.tmax;
+    best.inst = -1;
+    best.u = best.v = 0;
+    best.geom = best.prim = -1;
+    const RptrBvh4Node *nodes = bvh.nodes4.data();
+    int stack[4 * RPTR_BVH_STACK_DEPTH];
+    int sp = 0;
+    const int SENTINEL = INT32_MIN;
+    vec3 o = ray.o, d = ray.d;
+    vec3 id(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const RptrBvhInstance *cur_inst = nullptr;
+    int cur = 0;
+    for (;;) {
+        bool pop = false;
+        if (cur >= 0) {
+            const RptrBvh4Node &n = nodes[cur];
+            if (cnt) cnt->nodes++;
+            if (g_node_hist) __atomic_fetch_add(&g_node_hist[cur], 1u, __ATOMIC_RELAXED);
+            const float oo[3] = {o.x, o.y, o.z}, ii[3] = {id.x, id.y, id.z};
+            float A[3], B[3];
+            for (int a = 0; a < 3; ++a) {
+                A[a] = bits_float(uint32_t(n.exp[a]) << 23) * ii[a];
+                B[a] = (n.origin[a] - oo[a]) * ii[a];
+            }
+            uint32_t key[4];
+            for (int k = 0; k < 4; ++k) {
+                float tl[3], th[3];
+                for (int a = 0; a < 3; ++a) {
+                    tl[a] = fmaf((float)n.qlo[a][k], A[a], B[a]);
+                    th[a] = fmaf((float)n.qhi[a][k], A[a], B[a]);
+                }
+                const float tn = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fmaxf(fminf(tl[2], th[2]), ray.tmin));
+                const float tf = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fminf(fmaxf(tl[2], th[2]), best.t));
+                const bool hit = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
+                key[k] = hit ? ((float_bits(tn) & 0x7FFFFFFCu) | uint32_t(k)) : 0xFFFFFFFFu;
+            }
+            std::sort(key, key + 4);
+            for (int k = 3; k >= 1; --k)
+                if (key[k] != 0xFFFFFFFFu) stack[sp++] = n.child[key[k] & 3u];
+            if (key[0] != 0xFFFFFFFFu)
+                cur = n.child[key[0] & 3u];
+            else
+                pop = true;
+        } else if (cur == SENTINEL) {
+            cur_inst = nullptr;
+            o = ray.o;
+            d = ray.d;
+            id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+            pop = true;
+        } else {
+            int first, count;
+            decode_leaf(cur, first, count);
+            if (cur_inst == nullptr) {
+                if (count > 0) {
+                    cur_inst = &bvh.insts[first];
+                    if (cnt) cnt->nodes += 2; // 128-byte instance record = 2 node-sized fetches
+                    o = xform_point(cur_inst->world_to_object, ray.o);
+                    d = xform_dir(cur_inst->world_to_object, ray.d);
+                    id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+                    stack[sp++] = SENTINEL;
+                    cur = cur_inst->blas_root;
+                } else
+                    pop = true;
+            } else {
+                for (int k = 0; k < count; ++k) {
+                    const RptrBvhTri &tr = bvh.tris[first + k];
+                    if (cnt) cnt->tris++;
+                    float t, u, v;
+                    if (!mt_intersect(o, d, vec3(tr.v0[0], tr.v0[1], tr.v0[2]), vec3(tr.e1[0], tr.e1[1], tr.e1[2]),
+                                      vec3(tr.e2[0], tr.e2[1], tr.e2[2]), t, u, v))
+                        continue;
+                    if (!(t > ray.tmin)) continue;
+                    const int ii2 = cur_inst->instance_id;
+                    const bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii2, (int)tr.geom, (int)tr.prim, best));
+                    if (!accept) continue;
+                    best.t = t; best.u = u; best.v = v;
+                    best.inst = ii2; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
                     best.lo = o; best.ld = d;
                     if (ANY) return true;
                 }

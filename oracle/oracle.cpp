@@ -502,10 +502,10 @@ int orc_scene_build_bvh(void *p, uint64_t *out_counts /*nodes,tris,insts*/) {
     }
     return 0;
 }
-int orc_scene_import_bvh(void *p, const RptrBvhNode *nodes, size_t n_nodes, const RptrBvhTri *tris, size_t n_tris,
+int orc_scene_import_bvh(void *p, const RptrBvh4Node *nodes, size_t n_nodes, const RptrBvhTri *tris, size_t n_tris,
                          const RptrBvhInstance *insts, size_t n_insts) {
     Scene *s = (Scene *)p;
-    s->imported.nodes.assign(nodes, nodes + n_nodes);
+    s->imported.nodes4.assign(nodes, nodes + n_nodes);
     s->imported.tris.assign(tris, tris + n_tris);
     s->imported.insts.assign(insts, insts + n_insts);
     s->has_imported = true;

@@ -286,4 +286,80 @@ void refit_bvh2(BuiltTree &tree, const BuildPrim *p) {
     }
 }
 
+// ------------------------------------------------------------------ BVH2 -> BVH4
+void collapse_bvh4(const BuiltTree &t, Wide4Tree &out) {
+    out.nodes.clear();
+    memcpy(out.lo, t.lo, 12);
+    memcpy(out.hi, t.hi, 12);
+    if (t.nodes.empty()) {
+        Wide4 w;
+        memset(&w, 0, sizeof(w));
+        for (int k = 0; k < 4; ++k) w.child[k] = RPTR_BVH4_EMPTY;
+        out.nodes.push_back(w);
+        return;
+    }
+    struct Slot {
+        int32_t ref;
+        float lo[3], hi[3];
+    };
+    auto area = [](const Slot &s) {
+        const float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto children_of = [&](int32_t n, std::vector<Slot> &dst, size_t at) {
+        const RptrBvhNode &nd = t.nodes[n];
+        size_t pos = at;
+        for (int w = 0; w < 2; ++w) {
+            const int32_t c = w ? nd.child1 : nd.child0;
+            if (c < 0 && RPTR_BVH_LEAF_COUNT(c) == 0) continue; // empty half of a degenerate node
+            Slot s;
+            s.ref = c;
+            memcpy(s.lo, w ? nd.lo1 : nd.lo0, 12);
+            memcpy(s.hi, w ? nd.hi1 : nd.hi0, 12);
+            dst.insert(dst.begin() + pos, s);
+            ++pos;
+        }
+    };
+    std::vector<int32_t> queue{0}; // binary node behind every wide node, breadth first
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        std::vector<Slot> slots;
+        children_of(queue[qi], slots, 0);
+        while (slots.size() < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (size_t i = 0; i < slots.size(); ++i)
+                if (slots[i].ref >= 0) {
+                    const float a = area(slots[i]);
+                    if (a > best) {
+                        best = a;
+                        pick = (int)i;
+                    }
+                }
+            if (pick < 0) break;
+            const int32_t n = slots[pick].ref;
+            slots.erase(slots.begin() + pick);
+            children_of(n, slots, (size_t)pick);
+        }
+        Wide4 w;
+        memset(&w, 0, sizeof(w));
+        for (int k = 0; k < 4; ++k) {
+            w.child[k] = RPTR_BVH4_EMPTY;
+            for (int a = 0; a < 3; ++a) {
+                w.box.lo[k][a] = INFINITY;
+                w.box.hi[k][a] = -INFINITY;
+            }
+        }
+        for (size_t k = 0; k < slots.size(); ++k) {
+            memcpy(w.box.lo[k], slots[k].lo, 12);
+            memcpy(w.box.hi[k], slots[k].hi, 12);
+            if (slots[k].ref >= 0) {
+                w.child[k] = (int32_t)queue.size();
+                queue.push_back(slots[k].ref);
+            } else
+                w.child[k] = slots[k].ref;
+        }
+        out.nodes.push_back(w);
+    }
+}
+
 } // namespace rptr

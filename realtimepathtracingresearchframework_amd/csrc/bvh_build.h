@@ -7,6 +7,7 @@
 // two-children-per-node layout of include/rptr_bvh.h.
 #pragma once
 #include "../../include/rptr_bvh.h"
+#include "bvh4.h"
 #include <cstdint>
 #include <vector>
 
@@ -30,5 +31,18 @@ void build_bvh2(const BuildPrim *prims, uint32_t n, uint32_t max_leaf, int max_d
 // bottom-up refit of node boxes from new primitive bounds given in LEAF order
 // (prims[i] corresponds to order[i]); host fallback used by tests.
 void refit_bvh2(BuiltTree &tree, const BuildPrim *prims_leaf_order);
+
+// ---- 4-wide form (what the device traverses)
+struct Wide4 {
+    RpBox4 box;       // float boxes of the children
+    int32_t child[4]; // >= 0: index into Wide4Tree::nodes; <= -2: packed leaf (first relative to `order`); RPTR_BVH4_EMPTY
+};
+struct Wide4Tree {
+    std::vector<Wide4> nodes; // root = nodes[0], breadth-first order
+    float lo[3], hi[3];
+};
+// Collapses the binary tree: a node adopts its grandchildren, largest box first, until it has four
+// children (Wald et al. style). Leaves and the primitive order are kept.
+void collapse_bvh4(const BuiltTree &tree, Wide4Tree &out);
 
 } // namespace rptr

@@ -36,7 +36,7 @@ struct RpGeomRecord { // 64 bytes
 };
 
 struct RpScene {
-    const RptrBvhNode *nodes;
+    const RptrBvh4Node *nodes;
     const RptrBvhTri *tris;
     const RptrBvhInstance *insts;
     const RpGeomRecord *geoms;

@@ -1,4 +1,4 @@
-// dtraverse.h -- two-level BVH2 traversal + Moeller-Trumbore for gfx950.
+// dtraverse.h -- two-level traversal of the compressed 4-wide BVH + Moeller-Trumbore for gfx950.
 //
 // Replaces what the reference gets from the Vulkan driver / RT hardware:
 // rayQueryProceedEXT loops at vulkan/pt_megakernel.glsl:440-475 (closest hit),
@@ -11,10 +11,12 @@
 // Visit order (it defines the node/triangle counts of the roofline model; the
 // CPU oracle walks the exported tree in exactly this order): work items are
 // inner nodes (>= 0), packed leaves (<= -2, include/rptr_bvh.h) and the
-// instance-exit sentinel. Inner node: slab-test both child boxes against
-// [t_min, best_t]; both hit -> push the farther, continue with the nearer
-// (tie -> child 0); BLAS leaf: test all its triangles; TLAS leaf: transform the
-// ray, push the sentinel, continue at the instance's root.
+// instance-exit sentinel. Inner node: slab-test the four child boxes against
+// [t_min, best_t] on the node's 8-bit grid (t = fma(q, step/d, (origin-o)/d));
+// the hit children are ordered by key = (bits(t_near) & ~3) | slot, ascending;
+// continue with the first, push the others so that the nearest pops first.
+// BLAS leaf: test all its triangles; TLAS leaf: transform the ray, push the
+// sentinel, continue at the instance's root.
 //
 // The loop is "while-while": a wave stays in the node loop while any lane has an
 // inner node, then handles leaves, so triangle code is not issued per node.
@@ -23,6 +25,7 @@
 // [level][thread]: conflict-free ds_read_b32/ds_write_b32), deeper entries
 // spill to a per-thread slice of a global scratch buffer.
 #pragma once
+#include "bvh4.h"
 #include "dshade.h"
 
 #define RP_TRAVERSE_BLOCK 256
@@ -34,11 +37,6 @@
 #define RP_TRAVERSE_WAVES 5
 #endif
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
-// nodes staged in LDS per workgroup: the first RP_LDS_NODES nodes of the array (the host puts
-// the top of the hierarchy there in breadth-first order); 0 disables staging
-#ifndef RP_LDS_NODES
-#define RP_LDS_NODES 64
-#endif
 #define RP_SENTINEL INT32_MIN
 #define RP_EXIT (INT32_MIN + 1)
 
@@ -121,9 +119,6 @@ template <bool ANY, bool COUNT, class Load, class Done>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, uint32_t &n_nodes,
                           uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
-#if RP_LDS_NODES > 0
-    __shared__ float4 lds_nodes[RP_LDS_NODES * 4];
-#endif
     const uint32_t tid = threadIdx.x;
     const uint32_t gstride = gridDim.x * blockDim.x;
     int *const glob = gstack + (blockIdx.x * blockDim.x + tid);
@@ -133,26 +128,13 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     uint32_t pool_next = ((blockIdx.x * blockDim.x + tid) >> 6) * RP_FETCH;
     uint32_t pool_end = min(n, pool_next + (uint32_t)RP_FETCH);
     bool more = pool_next < n; // the shared cursor starts behind every static pool
-#if RP_LDS_NODES > 0
-    // stage the top of the tree (block-uniform decision: the whole block has work or none of it
-    // does only approximately, so every wave of a block with any work takes part)
-    const uint32_t block_first = ((blockIdx.x * blockDim.x) >> 6) * RP_FETCH;
-    if (block_first >= n) return;
-    {
-        const uint32_t nstage = min((uint32_t)RP_LDS_NODES, sc.num_nodes) * 4u;
-        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
-        for (uint32_t i = tid; i < nstage; i += RP_TRAVERSE_BLOCK) lds_nodes[i] = src[i];
-        __syncthreads();
-    }
-    const int lds_limit = (int)min((uint32_t)RP_LDS_NODES, sc.num_nodes);
-#endif
     if (!more) return;
     // per-lane traversal state
     int cur = RP_EXIT, sp = 0;
     bool active = false; // lane holds a ray whose result has not been consumed yet
     uint32_t my_i = 0;
     V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
-    rp_f2 op0 = rp_mk2(0, 0), op1 = op0, op2 = op0, ip0 = op0, ip1 = op0, ip2 = op0; // (x,y) (z,x) (y,z) pairs of origin and 1/dir
+    V3 inv = v3s(0.f); // 1/dir of the ray in the current space
     float tmin = 0.f;
     RpHitRec best;
     best.t = 0.f;
@@ -178,13 +160,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     auto set_ray = [&](V3 no, V3 nd) {
         o = no;
         d = nd;
-        const V3 id = v3(rp_safe_rcp(nd.x), rp_safe_rcp(nd.y), rp_safe_rcp(nd.z));
-        op0 = rp_mk2(no.x, no.y);
-        op1 = rp_mk2(no.z, no.x);
-        op2 = rp_mk2(no.y, no.z);
-        ip0 = rp_mk2(id.x, id.y);
-        ip1 = rp_mk2(id.z, id.x);
-        ip2 = rp_mk2(id.y, id.z);
+        inv = v3(rp_safe_rcp(nd.x), rp_safe_rcp(nd.y), rp_safe_rcp(nd.z));
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
@@ -235,44 +211,50 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
 #ifdef RP_PROF
             prof_it++;
 #endif
-            float4 a, b, c;
-            int2 k;
-#if RP_LDS_NODES > 0
-            if (cur < lds_limit) { // top of the tree: LDS (ds_read_b128), keeps these lanes off the L1/TA path
-                const float4 *ln = lds_nodes + (uint32_t(cur) << 2);
-                a = ln[0];
-                b = ln[1];
-                c = ln[2];
-                const float4 kk = ln[3];
-                k = make_int2(__float_as_int(kk.x), __float_as_int(kk.y));
-            } else
-#endif
-            {
-                const char *np = node_base + (uint32_t(cur) << 6);
-                a = *reinterpret_cast<const float4 *>(np);
-                b = *reinterpret_cast<const float4 *>(np + 16);
-                c = *reinterpret_cast<const float4 *>(np + 32);
-                k = *reinterpret_cast<const int2 *>(np + 48);
-            }
+            const char *np = node_base + (uint32_t(cur) << 6);
+            const float4 n0 = *reinterpret_cast<const float4 *>(np);      // origin.xyz, exp bytes
+            const uint4 n1 = *reinterpret_cast<const uint4 *>(np + 16);   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
+            const uint4 n2 = *reinterpret_cast<const uint4 *>(np + 32);   // qhi.y qhi.z child0 child1
+            const uint2 n3 = *reinterpret_cast<const uint2 *>(np + 48);   // child2 child3
             if (COUNT) n_nodes++;
-            // the 12 plane distances (lo - o) * (1/d), two per instruction
-            const rp_f2 p0 = (rp_mk2(a.x, a.y) - op0) * ip0; // lo0.x lo0.y
-            const rp_f2 p1 = (rp_mk2(a.z, a.w) - op1) * ip1; // lo0.z hi0.x
-            const rp_f2 p2 = (rp_mk2(b.x, b.y) - op2) * ip2; // hi0.y hi0.z
-            const rp_f2 p3 = (rp_mk2(b.z, b.w) - op0) * ip0; // lo1.x lo1.y
-            const rp_f2 p4 = (rp_mk2(c.x, c.y) - op1) * ip1; // lo1.z hi1.x
-            const rp_f2 p5 = (rp_mk2(c.z, c.w) - op2) * ip2; // hi1.y hi1.z
-            const float tn0 = fmaxf(fmaxf(fminf(p0.x, p1.y), fminf(p0.y, p2.x)), fmaxf(fminf(p1.x, p2.y), tmin));
-            const float tf0 = fminf(fminf(fmaxf(p0.x, p1.y), fmaxf(p0.y, p2.x)), fminf(fmaxf(p1.x, p2.y), best.t));
-            const float tn1 = fmaxf(fmaxf(fminf(p3.x, p4.y), fminf(p3.y, p5.x)), fmaxf(fminf(p4.x, p5.y), tmin));
-            const float tf1 = fminf(fminf(fmaxf(p3.x, p4.y), fmaxf(p3.y, p5.x)), fminf(fmaxf(p4.x, p5.y), best.t));
-            const bool h0 = tn0 <= tf0 * 1.0000005f;
-            const bool h1 = tn1 <= tf1 * 1.0000005f;
-            const bool both = h0 && h1;
-            const bool near1 = both ? (tn1 < tn0) : h1;
-            int nxt = near1 ? k.y : k.x;
-            if (both) push(near1 ? k.x : k.y);
-            if (!(h0 || h1)) nxt = pop();
+            const uint32_t ex = __float_as_uint(n0.w);
+            // plane distance t = q * A + B with A = step / d, B = (origin - o) / d
+            const float ax = __uint_as_float((ex & 0xFFu) << 23) * inv.x, ay = __uint_as_float((ex & 0xFF00u) << 15) * inv.y,
+                        az = __uint_as_float((ex & 0xFF0000u) << 7) * inv.z;
+            const float bx = (n0.x - o.x) * inv.x, by = (n0.y - o.y) * inv.y, bz = (n0.z - o.z) * inv.z;
+            uint32_t key[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lx = fmaf((float)((n1.x >> (8 * k)) & 0xFFu), ax, bx), hx = fmaf((float)((n1.w >> (8 * k)) & 0xFFu), ax, bx);
+                const float ly = fmaf((float)((n1.y >> (8 * k)) & 0xFFu), ay, by), hy = fmaf((float)((n2.x >> (8 * k)) & 0xFFu), ay, by);
+                const float lz = fmaf((float)((n1.z >> (8 * k)) & 0xFFu), az, bz), hz = fmaf((float)((n2.y >> (8 * k)) & 0xFFu), az, bz);
+                const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
+                const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), best.t));
+                const int ck = k == 0 ? (int)n2.z : k == 1 ? (int)n2.w : k == 2 ? (int)n3.x : (int)n3.y;
+                const bool hit = ck != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
+                key[k] = hit ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+            }
+            // sort the four keys ascending (5 comparators); misses (~0) end up last
+#define RP_CSWAP(i, j)                          \
+    {                                           \
+        const uint32_t lo_ = min(key[i], key[j]); \
+        key[j] = max(key[i], key[j]);           \
+        key[i] = lo_;                           \
+    }
+            RP_CSWAP(0, 1) RP_CSWAP(2, 3) RP_CSWAP(0, 2) RP_CSWAP(1, 3) RP_CSWAP(1, 2)
+#undef RP_CSWAP
+            auto child_of = [&](uint32_t kk) -> int {
+                const uint32_t slot = kk & 3u;
+                return slot == 0 ? (int)n2.z : slot == 1 ? (int)n2.w : slot == 2 ? (int)n3.x : (int)n3.y;
+            };
+            if (key[3] != 0xFFFFFFFFu) push(child_of(key[3]));
+            if (key[2] != 0xFFFFFFFFu) push(child_of(key[2]));
+            if (key[1] != 0xFFFFFFFFu) push(child_of(key[1]));
+            int nxt;
+            if (key[0] != 0xFFFFFFFFu)
+                nxt = child_of(key[0]);
+            else
+                nxt = pop();
             cur = nxt;
         }
 #ifdef RP_PROF

@@ -658,61 +658,59 @@ __global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *
         tris[begin + i] = t;
     }
 }
-RP_DEV void rp_box_of_child(const RptrBvhNode *nodes, const float *tri_box, const float *inst_box, bool tlas, int child, float lo[3], float hi[3]) {
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = INFINITY;
-        hi[k] = -INFINITY;
-    }
-    if (child >= 0) {
-        const RptrBvhNode &c = nodes[child];
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(c.lo0[k], c.lo1[k]);
-            hi[k] = fmaxf(c.hi0[k], c.hi1[k]);
-        }
-    } else {
-        const int first = RPTR_BVH_LEAF_FIRST(child), count = RPTR_BVH_LEAF_COUNT(child);
-        for (int i = 0; i < count; ++i) {
-            const float *b = (tlas ? inst_box : tri_box) + 6ull * (first + i);
-            for (int k = 0; k < 3; ++k) {
-                lo[k] = fminf(lo[k], b[k]);
-                hi[k] = fmaxf(hi[k], b[3 + k]);
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvhNode *nodes, const float *tri_box, const float *inst_box, const uint32_t *list,
-                                                        uint32_t begin, uint32_t end) {
+// one height level of nodes: child boxes from the triangle / instance bounds (leaves) or from the exact float
+// bounds of the child nodes (node_box, written by the level below), then the shared encoder (bvh4.h)
+__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box,
+                                                        const uint32_t *list, uint32_t begin, uint32_t end) {
     for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
         const uint32_t e = list[i];
         const bool tlas = (e >> 31) != 0;
-        RptrBvhNode &n = nodes[e & 0x7FFFFFFFu];
-        float lo[3], hi[3];
-        rp_box_of_child(nodes, tri_box, inst_box, tlas, n.child0, lo, hi);
-        for (int k = 0; k < 3; ++k) {
-            n.lo0[k] = lo[k];
-            n.hi0[k] = hi[k];
+        const uint32_t ni = e & 0x7FFFFFFFu;
+        int32_t child[4];
+        RpBox4 b;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t c = nodes[ni].child[k];
+            child[k] = c;
+            for (int a = 0; a < 3; ++a) {
+                b.lo[k][a] = INFINITY;
+                b.hi[k][a] = -INFINITY;
+            }
+            if (c == RPTR_BVH4_EMPTY) continue;
+            if (c >= 0) {
+                const float *nb = node_box + 6ull * c;
+                for (int a = 0; a < 3; ++a) {
+                    b.lo[k][a] = nb[a];
+                    b.hi[k][a] = nb[3 + a];
+                }
+            } else {
+                const int first = RPTR_BVH_LEAF_FIRST(c), count = RPTR_BVH_LEAF_COUNT(c);
+                for (int j = 0; j < count; ++j) {
+                    const float *lb = (tlas ? inst_box : tri_box) + 6ull * (first + j);
+                    for (int a = 0; a < 3; ++a) {
+                        b.lo[k][a] = fminf(b.lo[k][a], lb[a]);
+                        b.hi[k][a] = fmaxf(b.hi[k][a], lb[3 + a]);
+                    }
+                }
+            }
         }
-        rp_box_of_child(nodes, tri_box, inst_box, tlas, n.child1, lo, hi);
-        for (int k = 0; k < 3; ++k) {
-            n.lo1[k] = lo[k];
-            n.hi1[k] = hi[k];
-        }
+        RptrBvh4Node n;
+        float *nb = node_box + 6ull * ni;
+        rp_bvh4_encode(b, child, &n, nb, nb + 3);
+        nodes[ni] = n;
     }
 }
-__global__ __launch_bounds__(256) void rp_k_refit_instances(const RptrBvhNode *nodes, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
+__global__ __launch_bounds__(256) void rp_k_refit_instances(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const RptrBvhInstance &in = insts[i];
-        const RptrBvhNode &r = nodes[in.blas_root];
-        float mlo[3], mhi[3], lo[3], hi[3];
+        const float *mb = node_box + 6ull * in.blas_root; // exact bounds of the mesh
+        float lo[3], hi[3];
         for (int k = 0; k < 3; ++k) {
-            mlo[k] = fminf(r.lo0[k], r.lo1[k]);
-            mhi[k] = fmaxf(r.hi0[k], r.hi1[k]);
             lo[k] = INFINITY;
             hi[k] = -INFINITY;
         }
         const float *M = in.object_to_world;
         for (int c = 0; c < 8; ++c) {
-            const float p[3] = {c & 1 ? mhi[0] : mlo[0], c & 2 ? mhi[1] : mlo[1], c & 4 ? mhi[2] : mlo[2]};
+            const float p[3] = {c & 1 ? mb[3] : mb[0], c & 2 ? mb[4] : mb[1], c & 4 ? mb[5] : mb[2]};
             for (int rr = 0; rr < 3; ++rr) {
                 const float w = ((M[4 * rr] * p[0] + M[4 * rr + 1] * p[1]) + M[4 * rr + 2] * p[2]) + M[4 * rr + 3];
                 lo[rr] = fminf(lo[rr], w);

@@ -36,7 +36,6 @@ struct MeshRt { // one bottom-level structure
     int tri_count = 0;
     float lo[3], hi[3];
     bool dynamic = false;
-    rptr::BuiltTree tree; // kept for dynamic meshes (host refit fallback / leaf order)
 };
 
 } // namespace
@@ -66,7 +65,10 @@ struct rptr_hip {
     // scene
     bool have_scene = false;
     RpScene dscene;
-    std::vector<RptrBvhNode> h_nodes;
+    std::vector<RptrBvh4Node> h_nodes;
+    std::vector<std::array<float, 6>> h_node_box; // exact float bounds of every node
+    int num_tlas_nodes = 0;
+    float *d_node_box = nullptr;
     std::vector<RptrBvhTri> h_tris;
     std::vector<RptrBvhInstance> h_insts;
     std::vector<MeshRt> meshes;
@@ -497,7 +499,29 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->h_tris.clear();
     h->h_insts.clear();
     h->meshes.assign(s->num_meshes, MeshRt());
-    std::vector<RptrBvhNode> blas_nodes; // relocated behind the TLAS afterwards
+    std::vector<RptrBvh4Node> blas_nodes;          // relocated behind the TLAS afterwards
+    std::vector<std::array<float, 6>> blas_boxes;  // exact float bounds per node (refit + instance bounds)
+    // encodes a wide tree into 64-byte nodes; inner child indices get `node_shift`, leaf ranges `first_shift`
+    auto encode_tree = [](const rptr::Wide4Tree &wt, int node_shift, int first_shift, std::vector<RptrBvh4Node> &dst,
+                          std::vector<std::array<float, 6>> &boxes) {
+        for (const rptr::Wide4 &w : wt.nodes) {
+            int32_t child[4];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t c = w.child[k];
+                if (c == RPTR_BVH4_EMPTY)
+                    child[k] = c;
+                else if (c >= 0)
+                    child[k] = c + node_shift;
+                else
+                    child[k] = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(c) + first_shift, RPTR_BVH_LEAF_COUNT(c));
+            }
+            RptrBvh4Node n;
+            std::array<float, 6> nb;
+            rp_bvh4_encode(w.box, child, &n, nb.data(), nb.data() + 3);
+            dst.push_back(n);
+            boxes.push_back(nb);
+        }
+    };
     for (uint32_t m = 0; m < s->num_meshes; ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
         std::vector<rptr::BuildPrim> prims;
@@ -525,23 +549,18 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         }
         MeshRt &mr = h->meshes[m];
         mr.dynamic = mesh.dynamic != 0;
-        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, mr.tree);
+        rptr::BuiltTree tree;
+        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
+        rptr::Wide4Tree wide;
+        rptr::collapse_bvh4(tree, wide);
         mr.node_base = (int)blas_nodes.size();
-        mr.node_count = (int)mr.tree.nodes.size();
+        mr.node_count = (int)wide.nodes.size();
         mr.tri_base = (int)h->h_tris.size();
         mr.tri_count = (int)mtris.size();
-        memcpy(mr.lo, mr.tree.lo, 12);
-        memcpy(mr.hi, mr.tree.hi, 12);
-        for (uint32_t id : mr.tree.order) h->h_tris.push_back(mtris[id]);
-        for (RptrBvhNode nd : mr.tree.nodes) {
-            if (nd.child0 >= 0) nd.child0 += mr.node_base; else nd.child0 = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(nd.child0) + mr.tri_base, nd.cnt0);
-            if (nd.child1 >= 0) nd.child1 += mr.node_base; else nd.child1 = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(nd.child1) + mr.tri_base, nd.cnt1);
-            blas_nodes.push_back(nd);
-        }
-        if (!mr.dynamic) {
-            mr.tree.nodes.clear();
-            mr.tree.nodes.shrink_to_fit();
-        }
+        memcpy(mr.lo, tree.lo, 12);
+        memcpy(mr.hi, tree.hi, 12);
+        for (uint32_t id : tree.order) h->h_tris.push_back(mtris[id]);
+        encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
     }
     // ---- top level over instance bounds (1 instance per leaf)
     std::vector<rptr::BuildPrim> iprims(s->num_instances);
@@ -575,67 +594,33 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     }
     rptr::BuiltTree tlas;
     rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
+    rptr::Wide4Tree tlas_wide;
+    rptr::collapse_bvh4(tlas, tlas_wide);
     for (int k = 0; k < 3; ++k) {
         h->scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
         h->scene_hi[k] = std::isfinite(tlas.hi[k]) ? tlas.hi[k] : 1.0f;
     }
-    const int reloc = (int)tlas.nodes.size();
-    h->h_nodes = tlas.nodes; // TLAS leaf 'first' already indexes the reordered instance array
-    for (RptrBvhNode nd : blas_nodes) {
-        if (nd.child0 >= 0) nd.child0 += reloc;
-        if (nd.child1 >= 0) nd.child1 += reloc;
+    const int reloc = (int)tlas_wide.nodes.size();
+    h->num_tlas_nodes = reloc;
+    h->h_nodes.clear();
+    h->h_node_box.clear();
+    encode_tree(tlas_wide, 0, 0, h->h_nodes, h->h_node_box); // TLAS leaf 'first' already indexes the reordered instance array
+    for (size_t i = 0; i < blas_nodes.size(); ++i) {
+        RptrBvh4Node nd = blas_nodes[i];
+        for (int k = 0; k < 4; ++k)
+            if (nd.child[k] >= 0) nd.child[k] += reloc;
         h->h_nodes.push_back(nd);
+        h->h_node_box.push_back(blas_boxes[i]);
     }
-    for (MeshRt &mr : h->meshes) mr.node_base += reloc;
+    h->mesh_root.assign(h->meshes.size(), -1);
+    for (size_t m = 0; m < h->meshes.size(); ++m) {
+        h->meshes[m].node_base += reloc;
+        h->mesh_root[m] = h->meshes[m].node_base;
+    }
     h->h_insts.resize(s->num_instances);
     for (uint32_t k = 0; k < s->num_instances; ++k) {
         h->h_insts[k] = insts[tlas.order[k]];
         h->h_insts[k].blas_root += reloc;
-    }
-    // ---- hoist the top of the hierarchy to the front of the node array: the first
-    // RP_LDS_NODES nodes in breadth-first order (through TLAS leaves into the BLAS roots)
-    // are the ones the traversal kernels stage in LDS
-    {
-        const size_t nn = h->h_nodes.size();
-        const size_t K = std::min<size_t>(RP_LDS_NODES, nn);
-        std::vector<int32_t> bfs;
-        bfs.reserve(K);
-        std::vector<char> seen(nn, 0);
-        std::vector<std::pair<int32_t, bool>> frontier{{0, true}}; // (node, in TLAS)
-        seen[0] = 1;
-        for (size_t head = 0; head < frontier.size() && bfs.size() < K; ++head) {
-            const int32_t ni = frontier[head].first;
-            const bool in_tlas = frontier[head].second;
-            bfs.push_back(ni);
-            const RptrBvhNode &nd = h->h_nodes[ni];
-            for (int w = 0; w < 2; ++w) {
-                const int32_t c = w ? nd.child1 : nd.child0;
-                const int32_t cnt = w ? nd.cnt1 : nd.cnt0;
-                if (c >= 0) {
-                    if (!seen[c]) { seen[c] = 1; frontier.push_back({c, in_tlas}); }
-                } else if (in_tlas && cnt > 0) {
-                    const int32_t r = h->h_insts[RPTR_BVH_LEAF_FIRST(c)].blas_root;
-                    if (!seen[r]) { seen[r] = 1; frontier.push_back({r, false}); }
-                }
-            }
-        }
-        std::vector<int32_t> new_index(nn, -1);
-        for (size_t i = 0; i < bfs.size(); ++i) new_index[bfs[i]] = (int32_t)i;
-        int32_t next = (int32_t)bfs.size();
-        for (size_t i = 0; i < nn; ++i)
-            if (new_index[i] < 0) new_index[i] = next++;
-        std::vector<RptrBvhNode> reordered(nn);
-        for (size_t i = 0; i < nn; ++i) {
-            RptrBvhNode nd = h->h_nodes[i];
-            if (nd.child0 >= 0) nd.child0 = new_index[nd.child0];
-            if (nd.child1 >= 0) nd.child1 = new_index[nd.child1];
-            reordered[new_index[i]] = nd;
-        }
-        h->h_nodes.swap(reordered);
-        for (RptrBvhInstance &bi : h->h_insts) bi.blas_root = new_index[bi.blas_root];
-        h->mesh_root.assign(h->meshes.size(), -1);
-        for (size_t m = 0; m < h->meshes.size(); ++m) h->mesh_root[m] = new_index[h->meshes[m].node_base];
-        for (MeshRt &mr : h->meshes) mr.node_base = -1; // node ranges are no longer contiguous
     }
     // ---- refit schedule: nodes of the dynamic meshes by height (children before parents), then the TLAS by height
     std::vector<uint32_t> refit_list;
@@ -644,24 +629,24 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     {
         const size_t nn = h->h_nodes.size();
         std::vector<int> height(nn, -1);
-        auto collect = [&](int root, bool tlas, std::vector<std::vector<uint32_t>> &by_height) {
+        auto collect = [&](int root, bool tlas_part, std::vector<std::vector<uint32_t>> &by_height) {
             // iterative post-order: height = 1 + max(height of inner children), 0 for nodes with leaf children only
             std::vector<std::pair<int, int>> st{{root, 0}};
             while (!st.empty()) {
                 auto [n, phase] = st.back();
                 st.pop_back();
-                const RptrBvhNode &nd = h->h_nodes[n];
+                const RptrBvh4Node &nd = h->h_nodes[n];
                 if (phase == 0) {
                     st.push_back({n, 1});
-                    if (nd.child0 >= 0) st.push_back({nd.child0, 0});
-                    if (nd.child1 >= 0) st.push_back({nd.child1, 0});
+                    for (int k = 0; k < 4; ++k)
+                        if (nd.child[k] >= 0) st.push_back({nd.child[k], 0});
                 } else {
                     int hgt = 0;
-                    if (nd.child0 >= 0) hgt = std::max(hgt, height[nd.child0] + 1);
-                    if (nd.child1 >= 0) hgt = std::max(hgt, height[nd.child1] + 1);
+                    for (int k = 0; k < 4; ++k)
+                        if (nd.child[k] >= 0) hgt = std::max(hgt, height[nd.child[k]] + 1);
                     height[n] = hgt;
                     if ((size_t)hgt >= by_height.size()) by_height.resize(hgt + 1);
-                    by_height[hgt].push_back((uint32_t)n | (tlas ? 0x80000000u : 0u));
+                    by_height[hgt].push_back((uint32_t)n | (tlas_part ? 0x80000000u : 0u));
                 }
             }
         };
@@ -679,7 +664,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         }
     }
     // ---- upload
-    RptrBvhNode *d_nodes = nullptr;
+    RptrBvh4Node *d_nodes = nullptr;
     RptrBvhTri *d_tris = nullptr;
     RptrBvhInstance *d_insts = nullptr;
     RpGeomRecord *d_geoms = nullptr;
@@ -699,7 +684,9 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->d_tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
     if (!refit_list.empty()) HIP_TRY(h, hipMemcpy(h->d_refit_list, refit_list.data(), refit_list.size() * 4, hipMemcpyHostToDevice));
     h->host_bvh_stale = false;
-    HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(h, &h->d_node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
+    HIP_TRY(h, hipMemcpy(h->d_node_box, h->h_node_box.data(), h->h_node_box.size() * 24, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyHostToDevice));
     if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(d_tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyHostToDevice));
     if (!h->h_insts.empty())
         HIP_TRY(h, hipMemcpy(d_insts, h->h_insts.data(), h->h_insts.size() * sizeof(RptrBvhInstance), hipMemcpyHostToDevice));
@@ -757,7 +744,7 @@ int rptr_hip_refit(rptr_hip_t *h) {
     HIP_TRY(h, hipSetDevice(h->device));
     bool any = false;
     RptrBvhTri *tris = const_cast<RptrBvhTri *>(h->dscene.tris);
-    RptrBvhNode *nodes = const_cast<RptrBvhNode *>(h->dscene.nodes);
+    RptrBvh4Node *nodes = const_cast<RptrBvh4Node *>(h->dscene.nodes);
     RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(h->dscene.insts);
     for (size_t m = 0; m < h->meshes.size(); ++m) any = any || h->mesh_dirty[m] == 1;
     if (!any) return RPTR_OK;
@@ -771,13 +758,13 @@ int rptr_hip_refit(rptr_hip_t *h) {
     }
     // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
     for (auto &lv : h->refit_levels_blas)
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_tri_box, h->d_inst_box, h->d_refit_list,
-                           lv[0], lv[1]);
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_node_box, h->d_tri_box, h->d_inst_box,
+                           h->d_refit_list, lv[0], lv[1]);
     const uint32_t ni = (uint32_t)h->h_insts.size();
-    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, h->stream, nodes, insts, h->d_inst_box, ni);
+    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, h->stream, h->d_node_box, insts, h->d_inst_box, ni);
     for (auto &lv : h->refit_levels_tlas)
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_tri_box, h->d_inst_box, h->d_refit_list,
-                           lv[0], lv[1]);
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_node_box, h->d_tri_box, h->d_inst_box,
+                           h->d_refit_list, lv[0], lv[1]);
     HIP_TRY(h, hipGetLastError());
     h->host_bvh_stale = true;
     return RPTR_OK;
@@ -1154,11 +1141,11 @@ int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris,
     if (h->host_bvh_stale) { // a refit happened on the device: refresh the host mirror first
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipMemcpy(h->h_nodes.data(), h->dscene.nodes, h->h_nodes.size() * sizeof(RptrBvhNode), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(h->h_nodes.data(), h->dscene.nodes, h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyDeviceToHost));
         if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(h->h_tris.data(), h->dscene.tris, h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyDeviceToHost));
         h->host_bvh_stale = false;
     }
-    if (nodes && n_nodes && *n_nodes >= h->h_nodes.size()) memcpy(nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvhNode));
+    if (nodes && n_nodes && *n_nodes >= h->h_nodes.size()) memcpy(nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvh4Node));
     if (tris && n_tris && *n_tris >= h->h_tris.size()) memcpy(tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri));
     if (instances && n_instances && *n_instances >= h->h_insts.size())
         memcpy(instances, h->h_insts.data(), h->h_insts.size() * sizeof(RptrBvhInstance));

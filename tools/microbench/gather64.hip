@@ -15,13 +15,13 @@ __global__ __launch_bounds__(256) void chase(const float4 *__restrict__ nodes, u
     float acc = 0.f;
     if ((int)(threadIdx.x & 63u) >= active_lanes) steps = 0;
     for (int s = 0; s < steps; ++s) {
-        const float4 *np = nodes + (size_t)cur * 4;
+        const float4 *np = nodes + (size_t)cur * NLOADS; // record stride = record size
         float4 a = np[0];
         float4 b = NLOADS > 1 ? np[1] : a;
         float4 c = NLOADS > 2 ? np[2] : a;
         float4 d = NLOADS > 3 ? np[3] : a;
         acc += a.x + b.y + c.z;
-        uint32_t nxt = __float_as_uint(NLOADS > 3 ? d.w : a.w);
+        uint32_t nxt = __float_as_uint(NLOADS > 3 ? d.w : (NLOADS > 1 ? b.w : a.w));
         cur = (nxt + (coherent ? 0u : (tid & 63u) * 40503u)) & mask;
     }
     out[tid] = cur + (uint32_t)acc;
@@ -37,8 +37,7 @@ int main() {
         for (int k = 0; k < 4; ++k) h[i * 4 + k] = make_float4(1.f, 2.f, 3.f, 0.f);
         x = x * 1664525u + 1013904223u;
         uint32_t nxt = x >> 4;
-        memcpy(&h[i * 4 + 3].w, &nxt, 4);
-        memcpy(&h[i * 4 + 0].w, &nxt, 4);
+        for (int k = 0; k < 4; ++k) memcpy(&h[i * 4 + k].w, &nxt, 4);
     }
     float4 *d; hipMalloc(&d, max_nodes * 64); hipMemcpy(d, h.data(), max_nodes * 64, hipMemcpyHostToDevice);
     uint32_t *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
@@ -46,9 +45,9 @@ int main() {
     const int steps = 2000;
     printf("CUs %d\n", cus);
     for (int coherent = 0; coherent < 1; ++coherent)
-    for (int nl : {4})
-    for (int active_lanes : {64, 32, 16, 8, 1})
-    for (size_t ws_nodes : {size_t(1) << 12, size_t(1) << 19}) {
+    for (int nl : {4, 2})
+    for (int active_lanes : {64, 26})
+    for (size_t ws_nodes : {size_t(1) << 12, size_t(1) << 19, size_t(1) << 21}) {
         for (int bpc : {1, 5, 8}) {
             int grid = cus * bpc;
             auto launch = [&]() {
@@ -61,7 +60,7 @@ int main() {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double fetches = (double)grid * 256 * steps;
             printf("active %2d %s loads/lane %d  ws %8.2f MiB  blocks/CU %d : %7.1f ns/step  %7.2f Gfetch/s  %7.2f TB/s\n", active_lanes, coherent ? "wave-uniform" : "divergent   ", nl,
-                   ws_nodes * 64.0 / 1048576, bpc, ms * 1e6 / steps, fetches / ms / 1e6, fetches * nl * 16 / ms / 1e9);
+                   ws_nodes * 16.0 * nl / 1048576, bpc, ms * 1e6 / steps, fetches / ms / 1e6, fetches * nl * 16 / ms / 1e9);
         }
     }
     return 0;
