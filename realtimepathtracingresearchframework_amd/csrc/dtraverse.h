@@ -30,13 +30,17 @@
 
 #define RP_TRAVERSE_BLOCK 256
 #ifndef RP_LDS_STACK
-#define RP_LDS_STACK 16
+#define RP_LDS_STACK 24
 #endif
 // waves per SIMD the traversal kernels are compiled for (bounds the VGPR budget)
 #ifndef RP_TRAVERSE_WAVES
 #define RP_TRAVERSE_WAVES 5
 #endif
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
+// the node phase ends early when fewer than RP_NODE_MIN lanes are still at inner nodes and some lane waits with a leaf
+#ifndef RP_NODE_MIN
+#define RP_NODE_MIN 10
+#endif
 #define RP_SENTINEL INT32_MIN
 #define RP_EXIT (INT32_MIN + 1)
 
@@ -135,6 +139,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     uint32_t my_i = 0;
     V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
     V3 inv = v3s(0.f); // 1/dir of the ray in the current space
+    bool neg_x = false, neg_y = false, neg_z = false;
     float tmin = 0.f;
     RpHitRec best;
     best.t = 0.f;
@@ -161,6 +166,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         o = no;
         d = nd;
         inv = v3(rp_safe_rcp(nd.x), rp_safe_rcp(nd.y), rp_safe_rcp(nd.z));
+        neg_x = __float_as_int(inv.x) < 0;
+        neg_y = __float_as_int(inv.y) < 0;
+        neg_z = __float_as_int(inv.z) < 0;
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
@@ -204,10 +212,19 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         }
         // ---- inner nodes
 #ifdef RP_PROF
-        const long long prof_t0 = __builtin_readcyclecounter();
+        const long long prof_t0 = wall_clock64();
         uint32_t prof_it = 0;
+        const uint32_t prof_idle0 = (uint32_t)__popcll(__ballot(cur == RP_EXIT));
+        const uint32_t prof_node0 = (uint32_t)__popcll(__ballot(cur >= 0));
 #endif
-        while (cur >= 0) {
+        // node phase: keeps stepping while at least RP_NODE_MIN lanes are at an inner node (or nobody waits with a leaf)
+        for (;;) {
+            const unsigned long long want_node = __ballot(cur >= 0);
+            if (want_node == 0ull) break;
+#if RP_NODE_MIN > 1
+            if ((uint32_t)__popcll(want_node) < (uint32_t)RP_NODE_MIN && __ballot(cur < 0 && cur != RP_EXIT) != 0ull) break;
+#endif
+            if (cur >= 0) {
 #ifdef RP_PROF
             prof_it++;
 #endif
@@ -222,44 +239,61 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const float ax = __uint_as_float((ex & 0xFFu) << 23) * inv.x, ay = __uint_as_float((ex & 0xFF00u) << 15) * inv.y,
                         az = __uint_as_float((ex & 0xFF0000u) << 7) * inv.z;
             const float bx = (n0.x - o.x) * inv.x, by = (n0.y - o.y) * inv.y, bz = (n0.z - o.z) * inv.z;
+            // entry / exit planes by the sign of the direction (= min / max of the two plane distances, since
+            // qlo <= qhi and the step is positive), selected once for the four children of a dword
+            const uint32_t qnx = neg_x ? n1.w : n1.x, qfx = neg_x ? n1.x : n1.w;
+            const uint32_t qny = neg_y ? n2.x : n1.y, qfy = neg_y ? n1.y : n2.x;
+            const uint32_t qnz = neg_z ? n2.y : n1.z, qfz = neg_z ? n1.z : n2.y;
+            const rp_f2 ax2 = rp_mk2(ax, ax), ay2 = rp_mk2(ay, ay), az2 = rp_mk2(az, az);
+            const rp_f2 bx2 = rp_mk2(bx, bx), by2 = rp_mk2(by, by), bz2 = rp_mk2(bz, bz);
+            const float tfar_max = best.t;
             uint32_t key[4];
+            int ref[4] = {(int)n2.z, (int)n2.w, (int)n3.x, (int)n3.y};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float lx = fmaf((float)((n1.x >> (8 * k)) & 0xFFu), ax, bx), hx = fmaf((float)((n1.w >> (8 * k)) & 0xFFu), ax, bx);
-                const float ly = fmaf((float)((n1.y >> (8 * k)) & 0xFFu), ay, by), hy = fmaf((float)((n2.x >> (8 * k)) & 0xFFu), ay, by);
-                const float lz = fmaf((float)((n1.z >> (8 * k)) & 0xFFu), az, bz), hz = fmaf((float)((n2.y >> (8 * k)) & 0xFFu), az, bz);
-                const float tn = fmaxf(fmaxf(fminf(lx, hx), fminf(ly, hy)), fmaxf(fminf(lz, hz), tmin));
-                const float tf = fminf(fminf(fmaxf(lx, hx), fmaxf(ly, hy)), fminf(fmaxf(lz, hz), best.t));
-                const int ck = k == 0 ? (int)n2.z : k == 1 ? (int)n2.w : k == 2 ? (int)n3.x : (int)n3.y;
-                const bool hit = ck != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
+                // (near, far) pairs: one packed fma per axis
+                const rp_f2 tx = __builtin_elementwise_fma(rp_mk2((float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu)), ax2, bx2);
+                const rp_f2 ty = __builtin_elementwise_fma(rp_mk2((float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu)), ay2, by2);
+                const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
+                const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+                const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
+                const bool hit = ref[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
                 key[k] = hit ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
             }
-            // sort the four keys ascending (5 comparators); misses (~0) end up last
-#define RP_CSWAP(i, j)                          \
-    {                                           \
-        const uint32_t lo_ = min(key[i], key[j]); \
-        key[j] = max(key[i], key[j]);           \
-        key[i] = lo_;                           \
+            // sort (key, child) ascending by key with 5 compare-exchanges; misses (~0) end up last
+#define RP_CSWAP(i, j)                               \
+    {                                                \
+        const bool sw_ = key[j] < key[i];            \
+        const uint32_t ka_ = key[i], kb_ = key[j];   \
+        const int ra_ = ref[i], rb_ = ref[j];        \
+        key[i] = sw_ ? kb_ : ka_;                    \
+        key[j] = sw_ ? ka_ : kb_;                    \
+        ref[i] = sw_ ? rb_ : ra_;                    \
+        ref[j] = sw_ ? ra_ : rb_;                    \
     }
             RP_CSWAP(0, 1) RP_CSWAP(2, 3) RP_CSWAP(0, 2) RP_CSWAP(1, 3) RP_CSWAP(1, 2)
 #undef RP_CSWAP
-            auto child_of = [&](uint32_t kk) -> int {
-                const uint32_t slot = kk & 3u;
-                return slot == 0 ? (int)n2.z : slot == 1 ? (int)n2.w : slot == 2 ? (int)n3.x : (int)n3.y;
-            };
-            if (key[3] != 0xFFFFFFFFu) push(child_of(key[3]));
-            if (key[2] != 0xFFFFFFFFu) push(child_of(key[2]));
-            if (key[1] != 0xFFFFFFFFu) push(child_of(key[1]));
-            int nxt;
-            if (key[0] != 0xFFFFFFFFu)
-                nxt = child_of(key[0]);
-            else
-                nxt = pop();
+            const bool v1 = key[1] != 0xFFFFFFFFu, v2 = key[2] != 0xFFFFFFFFu, v3 = key[3] != 0xFFFFFFFFu;
+            if (__builtin_expect(__any(sp > RP_LDS_STACK - 3), 0)) { // rare: some lane is about to leave the LDS part of its stack
+                if (v3) push(ref[3]);
+                if (v2) push(ref[2]);
+                if (v1) push(ref[1]);
+            } else { // branch-free: write, then advance only for real entries (farthest first, so the nearest pops first)
+                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[3];
+                sp += v3 ? 1 : 0;
+                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[2];
+                sp += v2 ? 1 : 0;
+                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[1];
+                sp += v1 ? 1 : 0;
+            }
+            int nxt = ref[0];
+            if (key[0] == 0xFFFFFFFFu) nxt = pop();
             cur = nxt;
+            }
         }
 #ifdef RP_PROF
         {
-            const long long prof_t1 = __builtin_readcyclecounter();
+            const long long prof_t1 = wall_clock64();
             uint32_t mx = prof_it;
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
             uint32_t sm = prof_it;
@@ -269,9 +303,12 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 atomicAdd(&rp_prof[1], (unsigned long long)mx);                  // node-phase wave iterations
                 atomicAdd(&rp_prof[2], (unsigned long long)sm);                  // node-phase lane iterations
                 atomicAdd(&rp_prof[3], 1ull);                                    // phases
+                atomicAdd(&rp_prof[5], (unsigned long long)mx * prof_idle0);                     // lane-iterations idle from the start of the phase
+                atomicAdd(&rp_prof[6], (unsigned long long)mx * (64u - prof_idle0 - prof_node0)); // ... holding a leaf from the start
+                atomicAdd(&rp_prof[7], (unsigned long long)mx * prof_node0 - sm);                // ... dropped out during the phase
             }
         }
-        const long long prof_t2 = __builtin_readcyclecounter();
+        const long long prof_t2 = wall_clock64();
 #endif
         // ---- one leaf / sentinel item
         if (cur == RP_SENTINEL) {
@@ -279,7 +316,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             cur_inst_id = -1;
             set_ray(ro, rd);
             cur = pop();
-        } else if (cur != RP_EXIT) {
+        } else if (cur < 0 && cur != RP_EXIT) {
             const int first = RPTR_BVH_LEAF_FIRST(cur), count = RPTR_BVH_LEAF_COUNT(cur);
             if (cur_inst < 0) {
                 // TLAS leaf: enter the instance
@@ -364,7 +401,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             active = false;
         }
 #ifdef RP_PROF
-        if (lane == 0) atomicAdd(&rp_prof[4], (unsigned long long)(__builtin_readcyclecounter() - prof_t2)); // leaf+done cycles
+        if (lane == 0) atomicAdd(&rp_prof[4], (unsigned long long)(wall_clock64() - prof_t2)); // leaf+done time (100 MHz ticks)
 #endif
     }
 }

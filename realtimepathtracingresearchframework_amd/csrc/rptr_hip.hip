@@ -971,6 +971,9 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
         fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
                 pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
                 double(pr[1]) / double(pr[3] ? pr[3] : 1), double(pr[4]) / double(pr[3] ? pr[3] : 1));
+        fprintf(stderr, "[RP_PROF] lost lane-iterations: idle-at-entry %.3f leaf-at-entry %.3f dropped-out %.3f (fractions of 64*wave-iters)\n",
+                double(pr[5]) / (64.0 * double(pr[1] ? pr[1] : 1)), double(pr[6]) / (64.0 * double(pr[1] ? pr[1] : 1)),
+                double(pr[7]) / (64.0 * double(pr[1] ? pr[1] : 1)));
         memset(pr, 0, sizeof(pr));
         HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
     }
