@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define RPTR_BVH_MAX_LEAF_TRIS 4 /* must stay <= 7 (3 count bits) */
+#ifndef RPTR_BVH_MAX_LEAF_TRIS
+#define RPTR_BVH_MAX_LEAF_TRIS 4
+#endif /* must stay <= 7 (3 count bits) */
 #define RPTR_BVH_LEAF(first, count) (-2 - (int32_t)((uint32_t)(first) * 8u + (uint32_t)(count)))
 #define RPTR_BVH_LEAF_FIRST(child) ((int32_t)((uint32_t)(-2 - (child)) >> 3))
 #define RPTR_BVH_LEAF_COUNT(child) ((int32_t)((uint32_t)(-2 - (child)) & 7u))
@@ -65,11 +67,11 @@ typedef struct RptrBvhTri {
 /* 128 bytes */
 typedef struct RptrBvhInstance {
     float world_to_object[12]; /* row-major 3x4                                  */
-    float object_to_world[12]; /* row-major 3x4                                  */
     int32_t blas_root;         /* absolute node index of the mesh's root         */
     int32_t geometry_base;     /* instanceCustomIndex = render_mesh_base_offset  */
     int32_t instance_id;       /* rayQueryGetIntersectionInstanceIdEXT            */
-    int32_t flags;
+    int32_t flags;             /* (the traversal reads the first 64 bytes)       */
+    float object_to_world[12]; /* row-major 3x4 (refit: instance bounds)         */
     int32_t _pad[4];
 } RptrBvhInstance;
 

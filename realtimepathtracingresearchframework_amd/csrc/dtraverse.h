@@ -41,6 +41,10 @@
 #ifndef RP_NODE_MIN
 #define RP_NODE_MIN 10
 #endif
+// ... and at least RP_LEAF_MIN lanes wait with a leaf
+#ifndef RP_LEAF_MIN
+#define RP_LEAF_MIN 1
+#endif
 #define RP_SENTINEL INT32_MIN
 #define RP_EXIT (INT32_MIN + 1)
 
@@ -117,7 +121,7 @@ RP_DEV float rp_dot_fma(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x *
 RP_DEV V3 rp_cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y))); }
 
 #ifdef RP_PROF
-__device__ unsigned long long rp_prof[8];
+__device__ unsigned long long rp_prof[16];
 #endif
 template <bool ANY, bool COUNT, class Load, class Done>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, uint32_t &n_nodes,
@@ -172,7 +176,11 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
+    const char *const inst_base = reinterpret_cast<const char *>(sc.insts);
     for (;;) {
+#ifdef RP_PROF
+        const long long prof_tr = wall_clock64();
+#endif
         // ---- refill idle lanes
         const bool idle = cur == RP_EXIT;
         const unsigned long long idle_mask = __ballot(idle);
@@ -213,6 +221,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         // ---- inner nodes
 #ifdef RP_PROF
         const long long prof_t0 = wall_clock64();
+        if (lane == 0) atomicAdd(&rp_prof[8], (unsigned long long)(prof_t0 - prof_tr)); // refill section
         uint32_t prof_it = 0;
         const uint32_t prof_idle0 = (uint32_t)__popcll(__ballot(cur == RP_EXIT));
         const uint32_t prof_node0 = (uint32_t)__popcll(__ballot(cur >= 0));
@@ -222,12 +231,18 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const unsigned long long want_node = __ballot(cur >= 0);
             if (want_node == 0ull) break;
 #if RP_NODE_MIN > 1
-            if ((uint32_t)__popcll(want_node) < (uint32_t)RP_NODE_MIN && __ballot(cur < 0 && cur != RP_EXIT) != 0ull) break;
+            if ((uint32_t)__popcll(want_node) < (uint32_t)RP_NODE_MIN &&
+                (uint32_t)__popcll(__ballot(cur < 0 && cur != RP_EXIT)) >= (uint32_t)RP_LEAF_MIN)
+                break;
 #endif
             if (cur >= 0) {
 #ifdef RP_PROF
             prof_it++;
 #endif
+            // the whole wave takes the generic stack path when some lane is within 3 entries of the end of its LDS part
+            const bool stack_slow = __any(sp > RP_LDS_STACK - 3);
+            int top = 0;
+            if (!stack_slow) top = lds_stack[(sp - 1) * RP_TRAVERSE_BLOCK + tid]; // read ahead: the item a miss would pop
             const char *np = node_base + (uint32_t(cur) << 6);
             const float4 n0 = *reinterpret_cast<const float4 *>(np);      // origin.xyz, exp bytes
             const uint4 n1 = *reinterpret_cast<const uint4 *>(np + 16);   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
@@ -273,21 +288,24 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     }
             RP_CSWAP(0, 1) RP_CSWAP(2, 3) RP_CSWAP(0, 2) RP_CSWAP(1, 3) RP_CSWAP(1, 2)
 #undef RP_CSWAP
-            const bool v1 = key[1] != 0xFFFFFFFFu, v2 = key[2] != 0xFFFFFFFFu, v3 = key[3] != 0xFFFFFFFFu;
-            if (__builtin_expect(__any(sp > RP_LDS_STACK - 3), 0)) { // rare: some lane is about to leave the LDS part of its stack
+            const bool v0 = key[0] != 0xFFFFFFFFu, v1 = key[1] != 0xFFFFFFFFu, v2 = key[2] != 0xFFFFFFFFu, v3 = key[3] != 0xFFFFFFFFu;
+            int nxt;
+            if (__builtin_expect(stack_slow, 0)) { // rare: some lane is about to leave the LDS part of its stack
                 if (v3) push(ref[3]);
                 if (v2) push(ref[2]);
                 if (v1) push(ref[1]);
-            } else { // branch-free: write, then advance only for real entries (farthest first, so the nearest pops first)
+                nxt = v0 ? ref[0] : pop();
+            } else { // branch-free: write, then advance only for real entries (farthest first, so the nearest pops first);
+                     // no child hit = no push, and the entry read ahead from the top of the stack is the next item
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[3];
                 sp += v3 ? 1 : 0;
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[2];
                 sp += v2 ? 1 : 0;
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[1];
                 sp += v1 ? 1 : 0;
+                nxt = v0 ? ref[0] : top;
+                sp -= v0 ? 0 : 1;
             }
-            int nxt = ref[0];
-            if (key[0] == 0xFFFFFFFFu) nxt = pop();
             cur = nxt;
             }
         }
@@ -309,49 +327,51 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             }
         }
         const long long prof_t2 = wall_clock64();
+        {
+            const bool isleaf = cur < 0 && cur != RP_EXIT;
+            const uint32_t n_tri = (uint32_t)__popcll(__ballot(isleaf && cur_inst >= 0)), n_inst = (uint32_t)__popcll(__ballot(isleaf && cur_inst < 0));
+            if (lane == 0) {
+                atomicAdd(&rp_prof[9], (unsigned long long)n_tri);
+                atomicAdd(&rp_prof[10], (unsigned long long)n_inst);
+                atomicAdd(&rp_prof[11], (unsigned long long)(n_tri ? 1 : 0));
+                atomicAdd(&rp_prof[12], (unsigned long long)(n_inst ? 1 : 0));
+            }
+        }
 #endif
-        // ---- one leaf / sentinel item
+        // ---- one leaf / sentinel item. A BLAS leaf (two triangles = 96 bytes) and a TLAS leaf (the first 64 bytes of
+        // an instance record) are fetched by the same six loads, so that a phase with both kinds costs one round trip.
         if (cur == RP_SENTINEL) {
             cur_inst = -1;
             cur_inst_id = -1;
             set_ray(ro, rd);
             cur = pop();
         } else if (cur < 0 && cur != RP_EXIT) {
-            const int first = RPTR_BVH_LEAF_FIRST(cur), count = RPTR_BVH_LEAF_COUNT(cur);
-            if (cur_inst < 0) {
-                // TLAS leaf: enter the instance
+            const int first = RPTR_BVH_LEAF_FIRST(cur);
+            int count = RPTR_BVH_LEAF_COUNT(cur);
+            const bool is_inst = cur_inst < 0;
+            const char *lp = is_inst ? inst_base + (size_t)(uint32_t)first * sizeof(RptrBvhInstance) : tri_base + (size_t)(uint32_t)first * 48u;
+            float4 qa0 = *reinterpret_cast<const float4 *>(lp), qa1 = *reinterpret_cast<const float4 *>(lp + 16),
+                   qa2 = *reinterpret_cast<const float4 *>(lp + 32), qb0 = *reinterpret_cast<const float4 *>(lp + 48),
+                   qb1 = *reinterpret_cast<const float4 *>(lp + 64), qb2 = *reinterpret_cast<const float4 *>(lp + 80);
+            if (is_inst) {
+                // TLAS leaf: enter the instance (rows of world_to_object, then blas_root / geometry_base / instance_id / flags)
                 if (count > 0) {
                     cur_inst = first;
-                    const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + cur_inst);
-                    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-                    const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
                     if (COUNT) n_nodes += 2; // 128-byte instance record
-                    set_ray(rp_xform_point(r0, r1, r2, ro), rp_xform_dir(r0, r1, r2, rd));
-                    cur_inst_id = meta.z;
+                    set_ray(rp_xform_point(qa0, qa1, qa2, ro), rp_xform_dir(qa0, qa1, qa2, rd));
+                    cur_inst_id = __float_as_int(qb0.z);
                     push(RP_SENTINEL);
-                    cur = meta.x;
+                    cur = __float_as_int(qb0.x);
                 } else
                     cur = pop();
             } else {
-                // BLAS leaf: triangles are fetched two at a time, then tested (canonical
-                // Moeller-Trumbore = oracle/obvh.h mt_intersect, same operations bit for bit)
+                // BLAS leaf: canonical Moeller-Trumbore = oracle/obvh.h mt_intersect, same operations bit for bit
                 bool any_hit = false;
-                const char *tp = tri_base + uint32_t(first) * 48u;
 #pragma unroll 1
-                for (int i0 = 0; i0 < count; i0 += 2) {
-                    const bool two = i0 + 1 < count;
-                    const float4 qa0 = *reinterpret_cast<const float4 *>(tp), qa1 = *reinterpret_cast<const float4 *>(tp + 16),
-                                 qa2 = *reinterpret_cast<const float4 *>(tp + 32);
-                    float4 qb0 = qa0, qb1 = qa1, qb2 = qa2;
-                    if (two) {
-                        qb0 = *reinterpret_cast<const float4 *>(tp + 48);
-                        qb1 = *reinterpret_cast<const float4 *>(tp + 64);
-                        qb2 = *reinterpret_cast<const float4 *>(tp + 80);
-                    }
-                    tp += 96;
+                for (;;) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (j == 1 && (!two || (ANY && any_hit))) break; // occlusion: the first accepted hit ends the query
+                        if (j == 1 && (count < 2 || (ANY && any_hit))) break; // occlusion: the first accepted hit ends the query
                         const float4 q0 = j ? qb0 : qa0, q1 = j ? qb1 : qa1, q2 = j ? qb2 : qa2;
                         if (COUNT) n_tris++;
                         const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
@@ -365,8 +385,8 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         const bool neg = det < 0.0f || (det == 0.0f && __float_as_int(det) < 0);
                         const float us = neg ? -un : un, vs = neg ? -vn : vn;
                         if (us >= 0.0f && vs >= 0.0f && us + vs <= ad && ad > 0.0f) {
-                            const float inv = 1.0f / det;
-                            const float t = rp_dot_fma(e2, q) * inv;
+                            const float inv_det = 1.0f / det;
+                            const float t = rp_dot_fma(e2, q) * inv_det;
                             if (t > tmin) {
                                 const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
                                 bool accept = t < best.t;
@@ -380,8 +400,8 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                 }
                                 if (accept) {
                                     best.t = t;
-                                    best.u = un * inv;
-                                    best.v = vn * inv;
+                                    best.u = un * inv_det;
+                                    best.v = vn * inv_det;
                                     best.prim = prim;
                                     best.geom = geom;
                                     best.inst_idx = cur_inst;
@@ -391,7 +411,15 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                             }
                         }
                     }
-                    if (ANY && any_hit) break;
+                    count -= 2;
+                    if (count <= 0 || (ANY && any_hit)) break;
+                    lp += 96; // leaves with more than two triangles: next pair
+                    qa0 = *reinterpret_cast<const float4 *>(lp);
+                    qa1 = *reinterpret_cast<const float4 *>(lp + 16);
+                    qa2 = *reinterpret_cast<const float4 *>(lp + 32);
+                    qb0 = *reinterpret_cast<const float4 *>(lp + 48);
+                    qb1 = *reinterpret_cast<const float4 *>(lp + 64);
+                    qb2 = *reinterpret_cast<const float4 *>(lp + 80);
                 }
                 cur = (ANY && any_hit) ? RP_EXIT : pop();
             }

@@ -209,7 +209,7 @@ RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpFrame &f, const RpPathSta
     if (ids.x < 0) return 0u;
     const float4 hit = ps.hit_tuv[p];
     const int prim = __float_as_int(hit.w);
-    const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[25]; // RptrBvhInstance::geometry_base
+    const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[13]; // RptrBvhInstance::geometry_base
     const RpGeomRecord &g = sc.geoms[geometry_base + ids.y];
     const int mid = rp_hit_material_id(g, uint32_t(prim));
     const float4 o = ps.ray_o[p], d = ps.ray_d[p];
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
                     // ---- hit attributes, pt_megakernel.glsl:495-572
                     const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
                     const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-                    const int4 meta = *reinterpret_cast<const int4 *>(ip + 6);
+                    const int4 meta = *reinterpret_cast<const int4 *>(ip + 3);
                     const RpGeomRecord g = sc.geoms[meta.y + ids.y];
                     const uint32_t prim = uint32_t(__float_as_int(hit4.w));
                     // transpose(mat3(world_to_object)): its columns are the rows of world_to_object
@@ -629,7 +629,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
         else if (h.inst_idx < 0)
             r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
         else {
-            const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[25];
+            const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[13];
             r = make_float4(h.u, h.v, __int_as_float(geometry_base + h.geom), __int_as_float(h.prim));
         }
         results[i] = r;

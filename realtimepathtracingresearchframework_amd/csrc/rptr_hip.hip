@@ -671,7 +671,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     RptrBaseMaterial *d_mats = nullptr;
     RptrTriLightData *d_lights = nullptr;
     if ((rc = dev_alloc(h, &d_nodes, h->h_nodes.size(), &h->scene_allocs))) return rc;
-    if ((rc = dev_alloc(h, &d_tris, h->h_tris.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &d_tris, h->h_tris.size() + 2, &h->scene_allocs))) return rc; // +2: a leaf is fetched as whole pairs
     if ((rc = dev_alloc(h, &d_insts, h->h_insts.size(), &h->scene_allocs))) return rc;
     if ((rc = dev_alloc(h, &d_geoms, geoms.size(), &h->scene_allocs))) return rc;
     if ((rc = dev_alloc(h, &d_mats, s->num_materials, &h->scene_allocs))) return rc;
@@ -966,7 +966,7 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
     HIP_TRY(h, hipStreamSynchronize(h->stream));
 #ifdef RP_PROF
     {
-        unsigned long long pr[8];
+        unsigned long long pr[16];
         HIP_TRY(h, hipMemcpyFromSymbol(pr, HIP_SYMBOL(rp_prof), sizeof(pr)));
         fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
                 pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
@@ -974,6 +974,9 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
         fprintf(stderr, "[RP_PROF] lost lane-iterations: idle-at-entry %.3f leaf-at-entry %.3f dropped-out %.3f (fractions of 64*wave-iters)\n",
                 double(pr[5]) / (64.0 * double(pr[1] ? pr[1] : 1)), double(pr[6]) / (64.0 * double(pr[1] ? pr[1] : 1)),
                 double(pr[7]) / (64.0 * double(pr[1] ? pr[1] : 1)));
+        fprintf(stderr, "[RP_PROF] time: node %.3g leaf+done %.3g refill %.3g | per phase: tri lanes %.2f (in %.2f of phases) instance lanes %.2f (in %.2f of phases)\n",
+                double(pr[0]), double(pr[4]), double(pr[8]), double(pr[9]) / double(pr[3] ? pr[3] : 1), double(pr[11]) / double(pr[3] ? pr[3] : 1),
+                double(pr[10]) / double(pr[3] ? pr[3] : 1), double(pr[12]) / double(pr[3] ? pr[3] : 1));
         memset(pr, 0, sizeof(pr));
         HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
     }
