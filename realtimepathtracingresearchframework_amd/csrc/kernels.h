@@ -561,8 +561,8 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
 __global__ void rp_k_next_bounce(RpCounters *ctr, int next_out /* queue index the coming shade writes */, uint32_t persistent_waves) {
     ctr->queue_count[next_out] = 0;
     ctr->shadow_count = 0;
-    ctr->cursor_extend = persistent_waves * RP_FETCH;
-    ctr->cursor_connect = persistent_waves * RP_FETCH;
+    ctr->cursor_extend = 0; // entries handed out behind the static first pools (dtraverse.h)
+    ctr->cursor_connect = 0;
 }
 
 // ------------------------------------------------------------------ resolve
