@@ -432,6 +432,7 @@ static inline void decode_leaf(int enc, int &first, int &count) {
     first = RPTR_BVH_LEAF_FIRST(enc);
     count = RPTR_BVH_LEAF_COUNT(enc);
 }
+static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
 template <bool ANY>
 static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt);
 template <bool ANY>
@@ -565,6 +566,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 key[k] = hit ? ((float_bits(tn) & 0x7FFFFFFCu) | uint32_t(k)) : 0xFFFFFFFFu;
             }
             std::sort(key, key + 4);
+            if (g_dead_visits && key[0] == 0xFFFFFFFFu) __atomic_fetch_add(g_dead_visits, 1ull, __ATOMIC_RELAXED);
             for (int k = 3; k >= 1; --k)
                 if (key[k] != 0xFFFFFFFFu) stack[sp++] = n.child[key[k] & 3u];
             if (key[0] != 0xFFFFFFFFu)

@@ -807,6 +807,7 @@ void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,d
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }
+void orc_set_dead_visit_counter(unsigned long long *c) { g_dead_visits = c; }
 // every ray of the following single-threaded orc_render calls is appended to buf (9 floats each); returns the count so far
 size_t orc_set_ray_log(float *buf, size_t cap_rays) {
     const size_t n = g_ray_log_n;
