@@ -34,7 +34,7 @@ extern "C" {
 #define RPTR_BVH_LEAF(first, count) (-2 - (int32_t)((uint32_t)(first) * 8u + (uint32_t)(count)))
 #define RPTR_BVH_LEAF_FIRST(child) ((int32_t)((uint32_t)(-2 - (child)) >> 3))
 #define RPTR_BVH_LEAF_COUNT(child) ((int32_t)((uint32_t)(-2 - (child)) & 7u))
-#define RPTR_BVH_STACK_DEPTH 64
+#define RPTR_BVH_STACK_DEPTH 128 /* spill entries per thread behind the LDS part of the traversal stack */
 
 typedef struct RptrBvhNode { /* 64 bytes */
     float lo0[3], hi0[3];

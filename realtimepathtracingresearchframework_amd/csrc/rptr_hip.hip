@@ -622,6 +622,29 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         h->h_insts[k] = insts[tlas.order[k]];
         h->h_insts[k].blas_root += reloc;
     }
+    // ---- the traversal stack must hold the worst case of this tree: per node (children - 1) siblings plus whatever
+    // its deepest child needs; + the exit marker, + the instance-exit sentinel between the two levels
+    {
+        const size_t nn = h->h_nodes.size();
+        std::vector<int> need(nn, 0);
+        for (int64_t i = (int64_t)nn - 1; i >= 0; --i) { // children sit behind their parents (breadth-first order per tree)
+            const RptrBvh4Node &nd = h->h_nodes[i];
+            int nchild = 0, deepest = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
+                ++nchild;
+                if (nd.child[k] >= 0) deepest = std::max(deepest, need[nd.child[k]]);
+            }
+            need[i] = std::max(0, nchild - 1) + deepest;
+        }
+        int blas_need = 0;
+        for (size_t m = 0; m < h->meshes.size(); ++m) blas_need = std::max(blas_need, need[h->mesh_root[m]]);
+        const int total = 1 + need[0] + 1 + blas_need;
+        const int capacity = RP_LDS_STACK + RPTR_BVH_STACK_DEPTH;
+        if (total > capacity)
+            return fail(h, RPTR_E_UNSUPPORTED, "the acceleration structure of this scene needs a traversal stack of %d entries (limit %d)", total,
+                        capacity);
+    }
     // ---- refit schedule: nodes of the dynamic meshes by height (children before parents), then the TLAS by height
     std::vector<uint32_t> refit_list;
     h->refit_levels_blas.clear();
