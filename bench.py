@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--animate", action="store_true",
                     help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
                          "(inside the timed region) and renders")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="diagnostic (single GPU): render only rank 0's stripes of an N-rank tile split, no gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -96,7 +100,11 @@ def main():
     W, H, spp = args.width, args.height, args.spp
 
     stream = torch.cuda.current_stream().cuda_stream  # the kernels run on torch's current stream
-    r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=32, stream=stream)
+    fif = 1 if args.animate else max(1, args.frames_in_flight)  # a refit per frame needs the previous frame finished
+    if args.emulate_world > 1:
+        r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=32, stream=stream, frames_in_flight=fif)
+    else:
+        r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=32, stream=stream, frames_in_flight=fif)
     r.initialize(W, H)
     t0 = time.time()
     r.set_scene(scene)
@@ -125,17 +133,37 @@ def main():
         e1.record()
         anim["ev"].append((e0, e1))
 
-    def step(count=False):
-        if anim is not None:
-            animate()
-        cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
-        st = r.render(cfg, spp=spp, count_traversal=count)
-        if world > 1:  # the path's one collective: tile radiance -> rank 0
+    def finish(ticket):
+        """collect one queued frame; N > 1: the path's one collective, tile radiance -> rank 0"""
+        st = r.wait(ticket)
+        if world > 1:
             if my_bytes:
                 r.copy_tile_to_device(gather.tile.data_ptr(), my_bytes)
             gather.gather()
         return st
 
+    def step(count=False):
+        """one synchronous frame (warm-up and the instrumented pass)"""
+        if anim is not None:
+            animate()
+        cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
+        return finish(r.render_async(cfg, spp=spp, count_traversal=count))
+
+    def timed_steps(k, on_stats):
+        """k frames with up to `fif` of them in flight; every frame is submitted, rendered, collected (and gathered)
+        inside the caller's timed region"""
+        queue = []
+        for _ in range(k):
+            if anim is not None:
+                animate()
+            cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
+            queue.append(r.render_async(cfg, spp=spp))
+            if len(queue) >= fif:
+                on_stats(finish(queue.pop(0)))
+        while queue:
+            on_stats(finish(queue.pop(0)))
+
+    r.set_stage_timing(1)  # timed region: HIP events around every closest-hit traversal launch (the roofline kernel) only
     for _ in range(args.warmup):
         step()
     if anim is not None:
@@ -144,22 +172,34 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
-    ext_ms = con_ms = other_ms = gpu_ms = 0.0
-    rays = 0
-    for _ in range(args.steps):
-        st = step()
-        ext_ms += st.raw.extend_time_ms
-        con_ms += st.raw.connect_time_ms
-        other_ms += st.raw.shade_time_ms
-        gpu_ms += st.raw.render_time_ms
-        rays += st.raw.rays_closest + st.raw.rays_shadow
+    acc = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0, rays=0)
+
+    def on_stats(st):
+        acc["ext"] += st.raw.extend_time_ms
+        acc["con"] += st.raw.connect_time_ms
+        acc["other"] += st.raw.shade_time_ms
+        acc["gpu"] += st.raw.render_time_ms
+        acc["rays"] += st.raw.rays_closest + st.raw.rays_shadow
+
+    timed_steps(args.steps, on_stats)
+    ext_ms, con_ms, other_ms, gpu_ms, rays = acc["ext"], acc["con"], acc["other"], acc["gpu"], acc["rays"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
     refit_ms = sum(a.elapsed_time(b) for a, b in anim["ev"]) / max(len(anim["ev"]), 1) if anim is not None else None
 
-    # one untimed instrumented step: node / triangle visits of this rank's queries (counted, not modelled)
+    # untimed, one frame at a time: (1) events around every stage -> the stage split without overlap between frames,
+    # (2) one instrumented step: node / triangle visits of this rank's queries (counted, not modelled)
+    r.set_stage_timing(2)
+    serial = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0)
+    n_serial = max(3, min(10, args.steps))
+    for _ in range(n_serial):
+        st = step().raw
+        serial["ext"] += st.extend_time_ms / n_serial
+        serial["con"] += st.connect_time_ms / n_serial
+        serial["other"] += st.shade_time_ms / n_serial
+        serial["gpu"] += st.render_time_ms / n_serial
     stc = step(count=True).raw
     cnt = dict(rays_closest=int(stc.rays_closest), rays_shadow=int(stc.rays_shadow), hits=int(stc.hits_shaded),
                nodes_closest=int(stc.nodes_closest), tris_closest=int(stc.tris_closest),
@@ -167,9 +207,9 @@ def main():
     launches_extend = int(stc.launches_extend)
 
     if world > 1:
-        t = torch.tensor([elapsed, ext_ms, con_ms, other_ms, gpu_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ext_ms, con_ms, other_ms, gpu_ms = (float(v) for v in t)
+        elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"] = (float(v) for v in t)
         tr = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         rays = int(tr[0])
@@ -181,13 +221,14 @@ def main():
     K = args.steps
     ms_per_step = elapsed * 1e3 / K
     mrays = rays / elapsed / 1e6
-    # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH2 traversal), rank 0's share
+    # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share
     ext_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt["nodes_closest"] * NODE_BYTES
                  + cnt["tris_closest"] * TRI_BYTES)
     con_bytes = (cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
                  + cnt["tris_shadow"] * TRI_BYTES)
-    ext_ms_step = ext_ms / K
+    ext_ms_step = ext_ms / K  # HIP events in the timed region; with frames in flight the launches of different frames overlap
     achieved = ext_bytes / (ext_ms_step * 1e-3) / 1e9 if ext_ms_step > 0 else 0.0
+    achieved_serial = ext_bytes / (serial["ext"] * 1e-3) / 1e9 if serial["ext"] > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -200,14 +241,20 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
         "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,
-        "connect": {"kernel": "rp_k_connect<false>", "achieved": round(con_bytes / (con_ms / K * 1e-3) / 1e9, 2) if con_ms > 0 else 0.0,
-                    "algorithmic_bytes_per_step": int(con_bytes), "ms_per_step": round(con_ms / K, 4)},
+        "note": "achieved/launch_ms: HIP events over the timed region (%d frames in flight: launches of neighbouring frames share the GPU); "
+                "one_frame_at_a_time: the same kernel with no other frame on the GPU" % fif,
+        "one_frame_at_a_time": {"achieved": round(achieved_serial, 2), "frac": round(achieved_serial / HBM_PEAK_GBS, 5),
+                                "launch_ms": round(serial["ext"] / max(launches_extend, 1), 5), "frames": n_serial,
+                                "stage_ms_per_step": {"extend": round(serial["ext"], 4), "connect": round(serial["con"], 4),
+                                                      "raygen_sort_shade_resolve": round(serial["other"], 4),
+                                                      "gpu_total": round(serial["gpu"], 4)},
+                                "connect": {"kernel": "rp_k_connect<false>",
+                                            "achieved": round(con_bytes / (serial["con"] * 1e-3) / 1e9, 2) if serial["con"] > 0 else 0.0,
+                                            "algorithmic_bytes_per_step": int(con_bytes)}},
         "counts_per_step": cnt,
-        "stage_ms_per_step": {"extend": round(ext_ms_step, 4), "connect": round(con_ms / K, 4),
-                              "raygen_sort_shade_resolve": round(other_ms / K, 4), "gpu_total": round(gpu_ms / K, 4)},
     }
     if refit_ms is not None:
-        roofline["stage_ms_per_step"]["update_vertices_and_refit"] = round(refit_ms, 4)
+        roofline["update_vertices_and_refit_ms"] = round(refit_ms, 4)
     bsdf = "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"
     which = "configs[2]" if args.lights else "configs[1]"
     if args.scene == "forest":
@@ -223,13 +270,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
-                   "parallelism": "tile%d" % world, "stripe_rows": 32, "rays_per_step": rays // K,
+                   "frames_in_flight": fif,
+                   "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": 32, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,
     }
 
     # ---- CPU baseline: the oracle on the same frame, all host cores (a rate; 1 warm-up band + the full frame)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         osc = O.OracleScene(scene)
@@ -242,7 +290,7 @@ def main():
         cpu_rays = ost.rays_closest + ost.rays_shadow
         out["cpu_baseline"] = {
             "value": round(cpu_rays / ost.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(ost.threads), "kind": "port",
-            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH2 traversal + "
+            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH4 traversal + "
                       "shading, std::thread over rows)" % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, ost.seconds),
         }
     print(json.dumps(out))

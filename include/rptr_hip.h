@@ -219,6 +219,9 @@ typedef struct RptrCreateInfo {
     int32_t world_size;
     int32_t stripe_rows;    /* 0 -> default 32                                   */
     void *stream;           /* hipStream_t to launch on, NULL -> backend-owned   */
+    int32_t frames_in_flight; /* 0/1: frames run one after the other on `stream`; 2..8: that many frame contexts with
+                               * their own streams, see rptr_hip_render_async                                  */
+    int32_t _pad;
 } RptrCreateInfo;
 
 typedef struct RptrStats {
@@ -279,6 +282,21 @@ int rptr_hip_set_params(rptr_hip_t *h, const RptrRenderParams *params,
  * node visits / triangle tests (slower; for roofline accounting only). */
 int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp,
                     int reset_accumulation, int count_traversal, RptrStats *out_stats);
+
+/* Frames in flight (≙ the reference's swap-chain frames, `RenderStats.frame_stats_delay`,
+ * librender/render_backend.h:15-24): rptr_hip_render_async queues a frame on the next free frame context and
+ * returns; rptr_hip_wait blocks until that frame is done and returns its stats. A wavefront frame ends in a
+ * latency-bound tail (late bounces carry few rays); with 2-3 frames in flight the tail of one frame overlaps the
+ * head of the next. Resolves run in submission order into the one accumulation buffer; read-backs and
+ * rptr_hip_copy_tile_to_device return the image of the frame that was waited for last. With frames_in_flight N,
+ * at most N tickets can be outstanding (RPTR_E_INVALID otherwise); rptr_hip_render = async + wait, after waiting
+ * for everything still in flight, and so do set_scene / update_vertices / refit / trace. */
+int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation,
+                          int count_traversal, uint64_t *out_ticket);
+int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats);
+/* hipEvent pairs recorded per frame for RptrStats.*_time_ms: 0 none (render_time_ms only), 1 around the closest-hit
+ * traversal launches (extend_time_ms), 2 every stage (default; ~0.1 ms per 1080p frame of launch gaps). */
+int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
 
 /* ---- RenderGraphic::get_framebuffer_size / readback_framebuffer
  * (util/display/render_graphic.h:26-37, render_vulkan.cpp:2256-2287).

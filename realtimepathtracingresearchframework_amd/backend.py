@@ -62,6 +62,9 @@ def load_library(path=None):
     L.rptr_hip_refit.argtypes = [vp]
     L.rptr_hip_set_params.argtypes = [vp, C.POINTER(abi.RenderParams), C.POINTER(abi.SceneParams), C.POINTER(abi.LightSamplingConfig)]
     L.rptr_hip_render.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(abi.Stats)]
+    L.rptr_hip_render_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(C.c_uint64)]
+    L.rptr_hip_wait.argtypes = [vp, C.c_uint64, C.POINTER(abi.Stats)]
+    L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
@@ -102,9 +105,10 @@ class RenderConfiguration:  # librender/render_backend.h:33-40
 class RenderHip:
     """Drop-in shaped like `struct RenderBackend` (render_backend.h:68-116)."""
 
-    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None):
+    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None, frames_in_flight=1):
         self._L = load_library()
-        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream)
+        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream, frames_in_flight, 0)
+        self.frames_in_flight = max(1, frames_in_flight)
         h = C.c_void_p()
         rc = self._L.rptr_hip_create(C.byref(info), C.byref(h))
         if rc != 0:
@@ -191,6 +195,27 @@ class RenderHip:
                                             1 if count_traversal else 0, C.byref(st)))
         self.reset_accumulation = False
         self._stats = st
+
+    # ---- frames in flight: queue a frame, collect it later (the tail of one frame overlaps the head of the next)
+    def render_async(self, config: RenderConfiguration, spp=1, count_traversal=False):
+        """begin_frame + an asynchronous draw_frame; returns the ticket to hand to wait()."""
+        self.begin_frame(None, config)
+        self._push_params()
+        ticket = C.c_uint64(0)
+        self._check(self._L.rptr_hip_render_async(self._h, C.byref(self.camera), self._variant, spp, 1 if self.reset_accumulation else 0,
+                                                  1 if count_traversal else 0, C.byref(ticket)))
+        self.reset_accumulation = False
+        return int(ticket.value)
+
+    def wait(self, ticket):
+        st = abi.Stats()
+        self._check(self._L.rptr_hip_wait(self._h, C.c_uint64(ticket), C.byref(st)))
+        self._stats = st
+        return self.stats()
+
+    def set_stage_timing(self, level):
+        """0: no per-stage events, 1: around the closest-hit traversal launches, 2: every stage (default)."""
+        self._check(self._L.rptr_hip_set_stage_timing(self._h, int(level)))
 
     def end_frame(self, cmd_stream=None, variant_idx=0):
         pass  # resolve (process_samples) is sequenced inside draw_frame on the same stream

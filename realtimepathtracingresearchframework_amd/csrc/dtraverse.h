@@ -110,7 +110,13 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_REFILL_MIN
 #define RP_REFILL_MIN 48
 #endif
-#define RP_FETCH 256 // queue entries a wave pulls per global atomic (upper bound; small launches take 64..256)
+#ifndef RP_FETCH_DIV
+#define RP_FETCH_DIV 1u // a wave is dealt about 1/RP_FETCH_DIV of its fair share at a time
+#endif
+#ifndef RP_FETCH
+#define RP_FETCH 256
+#endif
+#define RP_FETCH_DOC // queue entries a wave pulls per global atomic (upper bound; small launches take 64..256)
 
 typedef float rp_f2 __attribute__((ext_vector_type(2)));
 RP_DEV rp_f2 rp_mk2(float x, float y) { return rp_f2{x, y}; }
@@ -136,7 +142,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     // pool size: the queue is dealt out in 64..RP_FETCH entries per wave so that a short queue (late bounces) still
     // spreads over as many waves as it has 64-entry groups instead of 256 entries per wave on a quarter of the SIMDs
     const uint32_t nwaves = gstride >> 6;
-    const uint32_t fetch = min((uint32_t)RP_FETCH, max(64u, ((n + nwaves - 1u) / nwaves + 63u) & ~63u));
+    const uint32_t fetch = min((uint32_t)RP_FETCH, max(64u, ((n + nwaves * RP_FETCH_DIV - 1u) / (nwaves * RP_FETCH_DIV) + 63u) & ~63u));
     uint32_t pool_next = ((blockIdx.x * blockDim.x + tid) >> 6) * fetch;
     uint32_t pool_end = min(n, pool_next + fetch);
     bool more = pool_next < n; // the shared cursor starts behind every static pool

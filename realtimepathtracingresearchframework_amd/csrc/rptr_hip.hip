@@ -38,6 +38,38 @@ struct MeshRt { // one bottom-level structure
     bool dynamic = false;
 };
 
+struct Span {
+    hipEvent_t a, b;
+    int kind; // 0 extend, 1 connect, 2 other
+};
+
+// Everything one frame in flight owns: its stream, path state, queues, counters, stack scratch, events.
+// frames_in_flight == 1: the single context runs on the backend's stream (rptr_hip.stream) and resolves straight
+// into the accumulation buffer. > 1: every context has its own stream; the latency-bound tail of frame i (late
+// bounces) overlaps the head of frame i+1, resolves stay ordered, and each context keeps a copy of the image it produced.
+struct FrameCtx {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    RpPathState ps;
+    RpShadowRays sq;
+    uint32_t *queue[2] = {nullptr, nullptr};
+    uint32_t *order = nullptr, *keys = nullptr;
+    uint32_t *sort_hist = nullptr, *sort_base = nullptr, *sort_cursor = nullptr;
+    RpCounters *counters = nullptr;
+    RpCounters *host_counters = nullptr; // pinned
+    int *gstack = nullptr;
+    float4 *out_accum = nullptr; // frames_in_flight > 1: the image after this frame's resolve
+    uchar4 *out_fb = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dep = nullptr, ev_resolved = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    // the frame in flight on this context
+    bool pending = false;
+    uint64_t ticket = 0;
+    std::vector<Span> spans;
+    RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
+    int launches_extend = 0, launches_connect = 0, spp_after = 0;
+};
+
 } // namespace
 
 struct rptr_hip {
@@ -88,14 +120,12 @@ struct rptr_hip {
     bool host_bvh_stale = false;
 
     // device buffers (frame sized)
-    RpPathState ps;
-    RpShadowRays sq;
-    uint32_t *queue[2] = {nullptr, nullptr};
-    uint32_t *order = nullptr, *keys = nullptr;
-    uint32_t *sort_hist = nullptr, *sort_base = nullptr, *sort_cursor = nullptr;
+    std::vector<FrameCtx> ctx;      // frames in flight (RptrCreateInfo.frames_in_flight, at least 1)
+    uint64_t next_ticket = 1;
+    int next_ctx = 0;
+    int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
+    hipEvent_t last_resolved = nullptr; // resolve of the most recently submitted frame (resolves run in submission order)
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
-    RpCounters *counters = nullptr;
-    int *gstack = nullptr;
     float4 *accum = nullptr;
     uchar4 *fb = nullptr;
     size_t path_capacity = 0;
@@ -103,11 +133,9 @@ struct rptr_hip {
 
     // options (environment, read once)
     int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
-    bool stage_timing = true;
+    int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
 
     RptrStats stats;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -179,13 +207,13 @@ inline void dequantize_position(uint64_t w, const float sc[3], const float of[3]
     out[2] = float(uint32_t(w >> 42) & 0x1FFFFFu) * sc[2] + of[2];
 }
 
-hipEvent_t next_event(rptr_hip *h, size_t &cursor) {
-    if (cursor >= h->ev_pool.size()) {
+hipEvent_t next_event(FrameCtx &c, size_t &cursor) {
+    if (cursor >= c.ev_pool.size()) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
-        h->ev_pool.push_back(e);
+        c.ev_pool.push_back(e);
     }
-    return h->ev_pool[cursor++];
+    return c.ev_pool[cursor++];
 }
 
 int grid_for(const rptr_hip *h, size_t n, int per_cu = 8) {
@@ -195,6 +223,10 @@ int grid_for(const rptr_hip *h, size_t n, int per_cu = 8) {
 }
 
 } // namespace
+
+extern "C++" {
+static int drain(rptr_hip *h);
+}
 
 extern "C" {
 
@@ -212,8 +244,6 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     rptr_hip *h = new rptr_hip();
     memset(&h->stats, 0, sizeof(h->stats));
-    memset(&h->ps, 0, sizeof(h->ps));
-    memset(&h->sq, 0, sizeof(h->sq));
     memset(&h->dscene, 0, sizeof(h->dscene));
     h->device = info ? info->device_ordinal : 0;
     h->rank = info ? info->rank : 0;
@@ -246,8 +276,35 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         }
         h->own_stream = true;
     }
-    (void)hipEventCreate(&h->ev_begin);
-    (void)hipEventCreate(&h->ev_end);
+    {
+        int fif = info ? info->frames_in_flight : 1;
+        if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) fif = atoi(s);
+        fif = std::max(1, std::min(fif, 8));
+        if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
+        h->ctx.resize((size_t)fif);
+        for (FrameCtx &c : h->ctx) {
+            memset(&c.ps, 0, sizeof(c.ps));
+            memset(&c.sq, 0, sizeof(c.sq));
+            memset(&c.earlier_batches, 0, sizeof(c.earlier_batches));
+            if (fif == 1)
+                c.stream = h->stream;
+            else {
+                if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
+                    delete h;
+                    return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
+                }
+                c.own_stream = true;
+            }
+            (void)hipEventCreate(&c.ev_begin);
+            (void)hipEventCreate(&c.ev_end);
+            (void)hipEventCreateWithFlags(&c.ev_dep, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c.ev_resolved, hipEventDisableTiming);
+            if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess) {
+                delete h;
+                return fail(nullptr, RPTR_E_NOMEM, "hipHostMalloc failed");
+            }
+        }
+    }
     // defaults of RenderParams / LightSamplingConfig (librender/render_params.glsl.h:123-155)
     memset(&h->params, 0, sizeof(h->params));
     h->params.batch_spp = 1;
@@ -267,7 +324,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     h->scene_params.sun_radiance[3] = 1.0f;
     h->scene_params.normal_z_scale = 1.0f;
     if (const char *s = getenv("RPTR_SORT")) h->use_sort = atoi(s) != 0 ? 1 : 0;
-    if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = atoi(s) != 0;
+    if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = std::max(0, std::min(2, atoi(s)));
     *out = h;
     return RPTR_OK;
 }
@@ -275,18 +332,25 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
 void rptr_hip_destroy(rptr_hip_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    for (FrameCtx &c : h->ctx) (void)hipStreamSynchronize(c.stream);
     (void)hipStreamSynchronize(h->stream);
     free_list(h->allocations);
     free_list(h->scene_allocs);
-    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
-    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    for (FrameCtx &c : h->ctx) {
+        for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved})
+            if (e) (void)hipEventDestroy(e);
+        if (c.host_counters) (void)hipHostFree(c.host_counters);
+        if (c.own_stream) (void)hipStreamDestroy(c.stream);
+    }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
 int rptr_hip_set_stream(rptr_hip_t *h, void *hip_stream) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    int rc = drain(h);
+    if (rc) return rc;
     (void)hipStreamSynchronize(h->stream);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     h->own_stream = false;
@@ -296,6 +360,7 @@ int rptr_hip_set_stream(rptr_hip_t *h, void *hip_stream) {
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
     }
+    if (h->ctx.size() == 1) h->ctx[0].stream = h->stream;
     return RPTR_OK;
 }
 
@@ -303,6 +368,10 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (fb_width <= 0 || fb_height <= 0) return fail(h, RPTR_E_INVALID, "bad framebuffer size %dx%d", fb_width, fb_height);
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        int rc0 = drain(h);
+        if (rc0) return rc0;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (void *p : h->allocations) (void)hipFree(p);
     h->allocations.clear();
@@ -312,7 +381,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->tiles_x = (fb_width + 7) / 8;
     h->tiles_y = (std::max(h->local_rows, 1) + 7) / 8;
     h->npix_padded = h->tiles_x * h->tiles_y * 64;
-    // sample slots in flight: as many as fit a ~6 GiB path-state budget, at most 16
+    // sample slots in flight: as many as fit a ~6 GiB path-state budget per frame context (288 GB of HBM), at most 16
     const size_t bytes_per_path = 16 * 5 + 8 + 8 + 3 * 16 + 5 * 4;
     size_t budget = (size_t)6 << 30;
     if (const char *s = getenv("RPTR_PATH_BUDGET_MB")) budget = (size_t)atoll(s) << 20;
@@ -322,32 +391,45 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     const size_t cap = (size_t)h->npix_padded * mb;
     h->path_capacity = cap;
     int rc;
-    if ((rc = dev_alloc(h, &h->ps.ray_o, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.ray_d, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.thr, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.illum, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.rng_tt, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.hit_tuv, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->ps.hit_ids, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sq.o, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sq.d, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sq.contrib, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sq.ids, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->queue[0], cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->queue[1], cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->order, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->keys, cap, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sort_hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sort_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
-    if ((rc = dev_alloc(h, &h->sort_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
-    HIP_TRY(h, hipMemsetAsync(h->sort_hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->sort_cursor, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
-    if ((rc = dev_alloc(h, &h->counters, 1, nullptr))) return rc;
+    for (FrameCtx &c : h->ctx) {
+        if ((rc = dev_alloc(h, &c.ps.ray_o, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.ray_d, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.thr, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.illum, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.rng_tt, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.hit_tuv, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.ps.hit_ids, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.sq.o, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.sq.d, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.sq.contrib, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.sq.ids, cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.queue[0], cap, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.queue[1], cap, nullptr))) return rc;
+        if (h->use_sort) {
+            if ((rc = dev_alloc(h, &c.order, cap, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.keys, cap, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.sort_hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.sort_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.sort_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
+            HIP_TRY(h, hipMemsetAsync(c.sort_hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
+            HIP_TRY(h, hipMemsetAsync(c.sort_cursor, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
+        }
+        if ((rc = dev_alloc(h, &c.counters, 1, nullptr))) return rc;
+    }
     const size_t npix_local = (size_t)h->width * std::max(h->local_rows, 1);
     if ((rc = dev_alloc(h, &h->accum, npix_local, nullptr))) return rc;
     if ((rc = dev_alloc(h, &h->fb, npix_local, nullptr))) return rc;
     HIP_TRY(h, hipMemsetAsync(h->accum, 0, npix_local * sizeof(float4), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->fb, 0, npix_local * sizeof(uchar4), h->stream));
+    if (h->ctx.size() > 1)
+        for (FrameCtx &c : h->ctx) {
+            if ((rc = dev_alloc(h, &c.out_accum, npix_local, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.out_fb, npix_local, nullptr))) return rc;
+            HIP_TRY(h, hipMemsetAsync(c.out_accum, 0, npix_local * sizeof(float4), h->stream));
+            HIP_TRY(h, hipMemsetAsync(c.out_fb, 0, npix_local * sizeof(uchar4), h->stream));
+        }
+    h->output_ctx = -1;
+    h->last_resolved = nullptr;
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false>, RP_TRAVERSE_BLOCK, 0));
@@ -355,7 +437,8 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
     const size_t stack_threads = (size_t)h->persistent_blocks * RP_TRAVERSE_BLOCK;
-    if ((rc = dev_alloc(h, &h->gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+    for (FrameCtx &c : h->ctx)
+        if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
     h->frame_id = 0;
     h->frame_offset = 0;
     h->accumulated_spp = 0;
@@ -383,6 +466,10 @@ int rptr_hip_set_params(rptr_hip_t *h, const RptrRenderParams *params, const Rpt
 int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     if (!h || !s) return fail(h, RPTR_E_INVALID, "NULL argument");
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        int rc0 = drain(h);
+        if (rc0) return rc0;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (void *p : h->scene_allocs) {
         (void)hipFree(p);
@@ -738,6 +825,10 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
 static int update_vertices_common(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices, bool device_src) {
     if (!h || !xyz) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "update_vertices before set_scene");
+    {
+        int rc0 = drain(h); // frames in flight still read the vertex buffer and the tree
+        if (rc0) return rc0;
+    }
     if (geometry >= h->d_dynpos.size() || !h->d_dynpos[geometry])
         return fail(h, RPTR_E_INVALID, "geometry %u does not belong to a dynamic mesh (RptrMeshDesc.dynamic)", geometry);
     if (num_vertices != 3u * h->geom_tris[geometry])
@@ -765,6 +856,10 @@ int rptr_hip_refit(rptr_hip_t *h) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "refit before set_scene");
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        int rc0 = drain(h);
+        if (rc0) return rc0;
+    }
     bool any = false;
     RptrBvhTri *tris = const_cast<RptrBvhTri *>(h->dscene.tris);
     RptrBvh4Node *nodes = const_cast<RptrBvh4Node *>(h->dscene.nodes);
@@ -826,21 +921,102 @@ static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
 
 extern "C++" {
 template <int VARIANT>
-static void launch_shade(rptr_hip *h, const RpFrame &f, const uint32_t *order, int in, int out) {
+static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint32_t *order, int in, int out) {
     const int grid = grid_for(h, h->path_capacity);
-    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, h->stream, h->dscene, f, h->ps, h->sq, order,
-                       &h->counters->queue_count[in], h->queue[out], &h->counters->queue_count[out], h->counters);
+    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->queue_count[in],
+                       c.queue[out], &c.counters->queue_count[out], c.counters);
+}
+
+static void add_counters(RpCounters &dst, const RpCounters &c) {
+    dst.rays_closest += c.rays_closest;
+    dst.rays_shadow += c.rays_shadow;
+    dst.nodes += c.nodes;
+    dst.tris += c.tris;
+    dst.nodes_shadow += c.nodes_shadow;
+    dst.tris_shadow += c.tris_shadow;
+    dst.hits_shaded += c.hits_shaded;
+}
+
+// waits for the frame in flight on `c` and turns its events / counters into RptrStats
+static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
+    if (!c.pending) return fail(h, RPTR_E_INVALID, "no frame in flight on this context");
+    // work queued on the backend's stream from here on (tile copies, read-backs) sees this frame; joining at collection
+    // time, not at submission, is what lets the next frame's dependency event pass while this frame still runs
+    if (h->ctx.size() > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, c.ev_end, 0));
+    HIP_TRY(h, hipEventSynchronize(c.ev_end));
+    c.pending = false;
+#ifdef RP_PROF
+    {
+        unsigned long long pr[16];
+        HIP_TRY(h, hipMemcpyFromSymbol(pr, HIP_SYMBOL(rp_prof), sizeof(pr)));
+        fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
+                pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
+                double(pr[1]) / double(pr[3] ? pr[3] : 1), double(pr[4]) / double(pr[3] ? pr[3] : 1));
+        fprintf(stderr, "[RP_PROF] lost lane-iterations: idle-at-entry %.3f leaf-at-entry %.3f dropped-out %.3f (fractions of 64*wave-iters)\n",
+                double(pr[5]) / (64.0 * double(pr[1] ? pr[1] : 1)), double(pr[6]) / (64.0 * double(pr[1] ? pr[1] : 1)),
+                double(pr[7]) / (64.0 * double(pr[1] ? pr[1] : 1)));
+        fprintf(stderr, "[RP_PROF] time: node %.3g leaf+done %.3g refill %.3g | per phase: tri lanes %.2f (in %.2f of phases) instance lanes %.2f (in %.2f of phases)\n",
+                double(pr[0]), double(pr[4]), double(pr[8]), double(pr[9]) / double(pr[3] ? pr[3] : 1), double(pr[11]) / double(pr[3] ? pr[3] : 1),
+                double(pr[10]) / double(pr[3] ? pr[3] : 1), double(pr[12]) / double(pr[3] ? pr[3] : 1));
+        memset(pr, 0, sizeof(pr));
+        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
+    }
+#endif
+    RptrStats &st = h->stats;
+    memset(&st, 0, sizeof(st));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c.ev_begin, c.ev_end);
+    st.render_time_ms = ms;
+    for (const Span &sp : c.spans) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, sp.a, sp.b);
+        if (sp.kind == 0) st.extend_time_ms += t;
+        else if (sp.kind == 1) st.connect_time_ms += t;
+        else st.shade_time_ms += t;
+    }
+    RpCounters tot = c.earlier_batches;
+    if (h->local_rows > 0) add_counters(tot, *c.host_counters);
+    st.rays_closest = tot.rays_closest;
+    st.rays_shadow = tot.rays_shadow;
+    st.nodes_visited = tot.nodes + tot.nodes_shadow;
+    st.tris_tested = tot.tris + tot.tris_shadow;
+    st.nodes_closest = tot.nodes;
+    st.tris_closest = tot.tris;
+    st.hits_shaded = tot.hits_shaded;
+    st.spp = c.spp_after;
+    st.launches_extend = c.launches_extend;
+    st.launches_connect = c.launches_connect;
+    st.device_bytes_allocated = h->bytes_allocated;
+    if (h->ctx.size() > 1) h->output_ctx = (int)(&c - h->ctx.data());
+    if (out_stats) *out_stats = st;
+    return RPTR_OK;
+}
+
+// every frame in flight is waited for (its stats are dropped): before anything that touches shared state
+static int drain(rptr_hip *h) {
+    for (FrameCtx &c : h->ctx)
+        if (c.pending) {
+            int rc = finish_frame(h, c, nullptr);
+            if (rc) return rc;
+        }
+    return RPTR_OK;
 }
 } // extern "C++"
 
-int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation, int count_traversal,
-                    RptrStats *out_stats) {
+int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation, int count_traversal,
+                          uint64_t *out_ticket) {
     if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "render before set_scene");
     if (h->width == 0) return fail(h, RPTR_E_INVALID, "render before initialize");
     if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE) return fail(h, RPTR_E_INVALID, "unknown variant %d", variant);
     if (spp < 1) return fail(h, RPTR_E_INVALID, "spp must be >= 1");
     HIP_TRY(h, hipSetDevice(h->device));
+    FrameCtx &c = h->ctx[(size_t)h->next_ctx];
+    if (c.pending)
+        return fail(h, RPTR_E_INVALID, "all %zu frames in flight are busy: rptr_hip_wait for ticket %llu first", h->ctx.size(),
+                    (unsigned long long)c.ticket);
+    h->next_ctx = (h->next_ctx + 1) % (int)h->ctx.size();
+    const bool multi = h->ctx.size() > 1;
     // begin_frame: render_vulkan.cpp:1937-1941
     if (reset_accumulation) {
         h->frame_offset += h->frame_id;
@@ -889,35 +1065,32 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
         }
     }
 
+
     // the regrouping pass costs ~0.4 ms per 1080p x 4 spp frame and makes shade up to 1.8x faster per bounce,
     // but neither on configs[1] (Lambert) nor on configs[2] (glTF + area lights) does that pay for the pass
     // (profiles/r01_notes.md): it is opt-in (RPTR_SORT=1)
     const bool do_sort = h->use_sort > 0;
     size_t ev_cursor = 0;
-    struct Span {
-        hipEvent_t a, b;
-        int kind; // 0 extend, 1 connect, 2 other
-    };
-    std::vector<Span> spans;
+    c.spans.clear();
     auto timed = [&](int kind, auto &&launch) {
-        if (h->stage_timing) {
-            hipEvent_t a = next_event(h, ev_cursor), b = next_event(h, ev_cursor);
-            (void)hipEventRecord(a, h->stream);
+        if (h->stage_timing >= 2 || (h->stage_timing == 1 && kind == 0)) {
+            hipEvent_t a = next_event(c, ev_cursor), b = next_event(c, ev_cursor);
+            (void)hipEventRecord(a, c.stream);
             launch();
-            (void)hipEventRecord(b, h->stream);
-            spans.push_back({a, b, kind});
+            (void)hipEventRecord(b, c.stream);
+            c.spans.push_back({a, b, kind});
         } else
             launch();
     };
 
-    HIP_TRY(h, hipEventRecord(h->ev_begin, h->stream));
-    RpCounters zero;
-    memset(&zero, 0, sizeof(zero));
-    int launches_extend = 0, launches_connect = 0;
-    RpCounters totals;
-    memset(&totals, 0, sizeof(totals));
-    std::vector<RpCounters> batch_counters;
-    batch_counters.reserve((size_t)spp);
+    if (multi) { // whatever the caller queued on the backend's stream (vertex updates, refit) comes first
+        HIP_TRY(h, hipEventRecord(c.ev_dep, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_dep, 0));
+    }
+    HIP_TRY(h, hipEventRecord(c.ev_begin, c.stream));
+    c.launches_extend = c.launches_connect = 0;
+    memset(&c.earlier_batches, 0, sizeof(c.earlier_batches));
+    memset(c.host_counters, 0, sizeof(RpCounters));
     int remaining = spp;
     const bool local_work = h->local_rows > 0;
     while (remaining > 0) {
@@ -925,113 +1098,107 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
         f.sample_base = h->frame_id;
         f.batch_spp = batch;
         if (local_work) {
-            HIP_TRY(h, hipMemsetAsync(h->counters, 0, sizeof(RpCounters), h->stream));
+            HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
             const size_t total = (size_t)batch * h->npix_padded;
-            timed(2, [&] {
-                hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, h->stream, f, h->ps, h->queue[0], h->counters);
-            });
+            timed(2, [&] { hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, c.ps, c.queue[0], c.counters); });
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
-                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, out,
+                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, c.stream, c.counters, out,
                                    (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
                 timed(0, [&] {
                     if (count_traversal)
-                        hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
-                                           h->queue[in], &h->counters->queue_count[in], h->counters, h->gstack);
+                        hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
+                                           c.queue[in], &c.counters->queue_count[in], c.counters, c.gstack);
                     else
-                        hipLaunchKernelGGL(rp_k_extend<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
-                                           h->queue[in], &h->counters->queue_count[in], h->counters, h->gstack);
+                        hipLaunchKernelGGL(rp_k_extend<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
+                                           c.queue[in], &c.counters->queue_count[in], c.counters, c.gstack);
                 });
-                launches_extend++;
-                const uint32_t *order = h->queue[in];
+                c.launches_extend++;
+                const uint32_t *order = c.queue[in];
                 if (do_sort) {
                     timed(2, [&] {
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, h->dscene, f, h->ps, h->queue[in],
-                                           &h->counters->queue_count[in], h->keys, h->sort_hist);
-                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, h->stream, h->sort_hist, h->sort_base, h->sort_cursor,
-                                           f.sort_num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, h->stream, f, h->queue[in],
-                                           &h->counters->queue_count[in], h->keys, h->sort_base, h->sort_cursor, h->order);
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.queue[in],
+                                           &c.counters->queue_count[in], c.keys, c.sort_hist);
+                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
+                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, c.queue[in],
+                                           &c.counters->queue_count[in], c.keys, c.sort_base, c.sort_cursor, c.order);
                     });
-                    order = h->order;
+                    order = c.order;
                 }
                 timed(2, [&] {
                     if (variant == RPTR_VARIANT_SIMPLE)
-                        launch_shade<RPTR_VARIANT_SIMPLE>(h, f, order, in, out);
+                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, f, order, in, out);
                     else
-                        launch_shade<RPTR_VARIANT_GLTF>(h, f, order, in, out);
+                        launch_shade<RPTR_VARIANT_GLTF>(h, c, f, order, in, out);
                 });
                 timed(1, [&] {
                     if (count_traversal)
-                        hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
-                                           h->sq, h->counters, h->gstack);
+                        hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
+                                           c.counters, c.gstack);
                     else
-                        hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, h->ps,
-                                           h->sq, h->counters, h->gstack);
+                        hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
+                                           c.counters, c.gstack);
                 });
-                launches_connect++;
+                c.launches_connect++;
             }
+            // resolves fold into one history buffer: they run in submission order across the contexts
+            if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             timed(2, [&] {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, h->stream, f, h->ps, h->accum, h->fb);
+                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, c.stream, f, c.ps, h->accum, h->fb);
             });
-            batch_counters.emplace_back();
-            HIP_TRY(h, hipMemcpyAsync(&batch_counters.back(), h->counters, sizeof(RpCounters), hipMemcpyDeviceToHost, h->stream));
+            if (multi) { // keep the image this frame produced: the next frame's resolve overwrites the shared buffers
+                const size_t npix = (size_t)h->width * h->local_rows;
+                HIP_TRY(h, hipMemcpyAsync(c.out_accum, h->accum, npix * sizeof(float4), hipMemcpyDeviceToDevice, c.stream));
+                HIP_TRY(h, hipMemcpyAsync(c.out_fb, h->fb, npix * sizeof(uchar4), hipMemcpyDeviceToDevice, c.stream));
+                HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
+                h->last_resolved = c.ev_resolved;
+            }
+            HIP_TRY(h, hipMemcpyAsync(c.host_counters, c.counters, sizeof(RpCounters), hipMemcpyDeviceToHost, c.stream));
             // the host copy above must land before the next batch's memset: batches are few, sync here
-            if (remaining - batch > 0) HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (remaining - batch > 0) {
+                HIP_TRY(h, hipStreamSynchronize(c.stream));
+                add_counters(c.earlier_batches, *c.host_counters);
+                memset(c.host_counters, 0, sizeof(RpCounters));
+            }
         }
         // end_frame: render_vulkan.cpp:2152-2154
         h->accumulated_spp = int(h->frame_id) + batch;
         h->frame_id += (uint32_t)batch;
         remaining -= batch;
     }
-    HIP_TRY(h, hipEventRecord(h->ev_end, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-#ifdef RP_PROF
-    {
-        unsigned long long pr[16];
-        HIP_TRY(h, hipMemcpyFromSymbol(pr, HIP_SYMBOL(rp_prof), sizeof(pr)));
-        fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
-                pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
-                double(pr[1]) / double(pr[3] ? pr[3] : 1), double(pr[4]) / double(pr[3] ? pr[3] : 1));
-        fprintf(stderr, "[RP_PROF] lost lane-iterations: idle-at-entry %.3f leaf-at-entry %.3f dropped-out %.3f (fractions of 64*wave-iters)\n",
-                double(pr[5]) / (64.0 * double(pr[1] ? pr[1] : 1)), double(pr[6]) / (64.0 * double(pr[1] ? pr[1] : 1)),
-                double(pr[7]) / (64.0 * double(pr[1] ? pr[1] : 1)));
-        fprintf(stderr, "[RP_PROF] time: node %.3g leaf+done %.3g refill %.3g | per phase: tri lanes %.2f (in %.2f of phases) instance lanes %.2f (in %.2f of phases)\n",
-                double(pr[0]), double(pr[4]), double(pr[8]), double(pr[9]) / double(pr[3] ? pr[3] : 1), double(pr[11]) / double(pr[3] ? pr[3] : 1),
-                double(pr[10]) / double(pr[3] ? pr[3] : 1), double(pr[12]) / double(pr[3] ? pr[3] : 1));
-        memset(pr, 0, sizeof(pr));
-        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
-    }
-#endif
+    HIP_TRY(h, hipEventRecord(c.ev_end, c.stream));
     HIP_TRY(h, hipGetLastError());
-    RptrStats &st = h->stats;
-    memset(&st, 0, sizeof(st));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, h->ev_begin, h->ev_end);
-    st.render_time_ms = ms;
-    for (const Span &sp : spans) {
-        float t = 0.f;
-        (void)hipEventElapsedTime(&t, sp.a, sp.b);
-        if (sp.kind == 0) st.extend_time_ms += t;
-        else if (sp.kind == 1) st.connect_time_ms += t;
-        else st.shade_time_ms += t;
-    }
-    for (const RpCounters &c : batch_counters) {
-        st.rays_closest += c.rays_closest;
-        st.rays_shadow += c.rays_shadow;
-        st.nodes_visited += c.nodes + c.nodes_shadow;
-        st.tris_tested += c.tris + c.tris_shadow;
-        st.nodes_closest += c.nodes;
-        st.tris_closest += c.tris;
-        st.hits_shaded += c.hits_shaded;
-    }
-    st.spp = h->accumulated_spp;
-    st.launches_extend = launches_extend;
-    st.launches_connect = launches_connect;
-    st.device_bytes_allocated = h->bytes_allocated;
-    if (out_stats) *out_stats = st;
+    c.spp_after = h->accumulated_spp;
+    c.pending = true;
+    c.ticket = h->next_ticket++;
+    if (out_ticket) *out_ticket = c.ticket;
     return RPTR_OK;
+}
+
+int rptr_hip_set_stage_timing(rptr_hip_t *h, int level) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (level < 0 || level > 2) return fail(h, RPTR_E_INVALID, "stage timing level %d (0 none, 1 extend only, 2 all stages)", level);
+    h->stage_timing = level;
+    return RPTR_OK;
+}
+
+int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    HIP_TRY(h, hipSetDevice(h->device));
+    for (FrameCtx &c : h->ctx)
+        if (c.pending && c.ticket == ticket) return finish_frame(h, c, out_stats);
+    return fail(h, RPTR_E_INVALID, "ticket %llu is not in flight", (unsigned long long)ticket);
+}
+
+int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation, int count_traversal,
+                    RptrStats *out_stats) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    int rc = drain(h); // a synchronous frame goes behind whatever is still in flight
+    if (rc) return rc;
+    uint64_t ticket = 0;
+    if ((rc = rptr_hip_render_async(h, camera, variant, spp, reset_accumulation, count_traversal, &ticket))) return rc;
+    return rptr_hip_wait(h, ticket, out_stats);
 }
 
 int rptr_hip_stats(const rptr_hip_t *h, RptrStats *out) {
@@ -1073,7 +1240,9 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
     const size_t need = (size_t)h->width * h->local_rows * sizeof(float4);
     if (n_bytes < need) return fail(h, RPTR_E_INVALID, "destination too small: %zu < %zu", n_bytes, need);
     HIP_TRY(h, hipSetDevice(h->device));
-    if (need) HIP_TRY(h, hipMemcpyAsync(device_dst, h->accum, need, hipMemcpyDeviceToDevice, h->stream));
+    // frames in flight: the image of the frame that was waited for last (its context keeps a copy)
+    const float4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum;
+    if (need) HIP_TRY(h, hipMemcpyAsync(device_dst, src, need, hipMemcpyDeviceToDevice, h->stream));
     return RPTR_OK;
 }
 
@@ -1100,11 +1269,13 @@ static int readback_rows(rptr_hip *h, const T *dev_local, T *host_full, size_t n
 
 int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
-    return readback_rows<float4>(h, h->accum, reinterpret_cast<float4 *>(rgba), n_floats / 4);
+    return readback_rows<float4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum, reinterpret_cast<float4 *>(rgba),
+                                 n_floats / 4);
 }
 int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
-    return readback_rows<uchar4>(h, h->fb, reinterpret_cast<uchar4 *>(rgba), n_bytes / 4);
+    return readback_rows<uchar4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb : h->fb, reinterpret_cast<uchar4 *>(rgba),
+                                 n_bytes / 4);
 }
 
 int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4) {
@@ -1114,7 +1285,11 @@ int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, floa
 int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4, uint32_t *visits2, const float *tmin, int any_hit) {
     if (!h || !queries || !out4 || n < 0) return fail(h, RPTR_E_INVALID, "bad argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "trace before set_scene");
-    if (!h->gstack) return fail(h, RPTR_E_INVALID, "trace before initialize");
+    if (!h->ctx[0].gstack) return fail(h, RPTR_E_INVALID, "trace before initialize");
+    {
+        int rc0 = drain(h); // the query kernel borrows context 0's cursor and stack scratch
+        if (rc0) return rc0;
+    }
     if (n == 0) return RPTR_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     RptrRenderRayQuery *dq = nullptr;
@@ -1138,11 +1313,11 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
             break;
         }
         // cursor_extend doubles as the pool cursor of the query kernel (same stream, no overlap with a frame)
-        hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->counters, 0,
+        hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->ctx[0].counters, 0,
                            (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
-                               &h->counters->cursor_extend, h->gstack, dv, dt);
+                               &h->ctx[0].counters->cursor_extend, h->ctx[0].gstack, dv, dt);
         };
         if (any_hit)
             launch(rp_k_trace<true, true>);

@@ -46,8 +46,9 @@ public:
     bool reset_accumulation = false;
     bool freeze_frame = false;
 
-    explicit RenderHip(int device_ordinal = 0, int rank = 0, int world_size = 1, int stripe_rows = 32, void *hip_stream = nullptr) {
-        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream};
+    explicit RenderHip(int device_ordinal = 0, int rank = 0, int world_size = 1, int stripe_rows = 32, void *hip_stream = nullptr,
+                       int frames_in_flight = 1) {
+        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream, frames_in_flight, 0};
         int rc = rptr_hip_create(&info, &h_);
         if (rc != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_create: ") + rptr_hip_last_error(nullptr));
         params = RptrRenderParams{1, RPTR_MAX_PATH_DEPTH, RPTR_DEFAULT_RR_PATH_DEPTH, 0, 0.f, 2.5f, 1.f, 4.f, 0, 0, 0.f, -1, 0, 8, 0, 1, 35.f, 0, 0, 0};
@@ -95,6 +96,27 @@ public:
         check(rptr_hip_render(h_, &cam, variant_, spp > 0 ? spp : (params.batch_spp > 0 ? params.batch_spp : 1), reset_accumulation ? 1 : 0, 0,
                               &last_));
         reset_accumulation = false;
+    }
+    // frames in flight: begin_frame + asynchronous draw_frame, collected with wait(ticket)
+    uint64_t render_async(const RenderConfiguration &config, int spp = 0) {
+        begin_frame(config);
+        check(rptr_hip_set_params(h_, &params, have_scene_params_ ? &scene_params_ : nullptr, &lighting_params));
+        RptrCamera cam;
+        for (int k = 0; k < 3; ++k) {
+            cam.pos[k] = camera.pos[k];
+            cam.dir[k] = camera.dir[k];
+            cam.up[k] = camera.up[k];
+        }
+        cam.fovy = camera.fovy;
+        uint64_t ticket = 0;
+        check(rptr_hip_render_async(h_, &cam, variant_, spp > 0 ? spp : (params.batch_spp > 0 ? params.batch_spp : 1), reset_accumulation ? 1 : 0, 0,
+                                    &ticket));
+        reset_accumulation = false;
+        return ticket;
+    }
+    RenderStats wait(uint64_t ticket) {
+        check(rptr_hip_wait(h_, ticket, &last_));
+        return stats();
     }
     void end_frame() {} // process_samples is sequenced inside draw_frame on the same stream
     RenderStats render(const RenderConfiguration &config, int spp = 0) {

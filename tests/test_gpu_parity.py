@@ -301,3 +301,65 @@ def test_full_forest_10m_instanced_triangles():
     ref, _ = osc.render(W, H, 1, variant=abi.VARIANT_GLTF, rows=rows)
     rmse, same, _ = image_error(a[rows[0]:rows[1]], ref[rows[0]:rows[1]])
     assert same and rmse < RMSE_TOL
+
+
+# ---------------------------------------------------------------- frames in flight
+def test_frames_in_flight_give_the_same_images_in_the_same_order(small_scenes):
+    """3 frame contexts: a progressive sequence (reset, then two accumulating frames, then a reset with another camera)
+    queued back to back equals the same sequence rendered one frame at a time, image by image, bit for bit."""
+    s = small_scenes["grid_lights"]
+    W, H = 160, 90
+    cam_a = s.camera_params()
+    cam_b = s.camera_params()
+    cam_b.pos[0] += 3.0
+    seq = [(cam_a, True, 1), (cam_a, False, 2), (cam_a, False, 1), (cam_b, True, 2), (cam_b, False, 1)]
+
+    def run(fif):
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(s)
+        images, stats, queue = [], [], []
+        def collect():
+            st = r.wait(queue.pop(0))
+            img = np.zeros((H, W, 4), np.float32)
+            assert r.readback_framebuffer(img) == W * H * 4
+            images.append(img)
+            stats.append((st.raw.rays_closest, st.raw.rays_shadow, st.raw.spp))
+        for cam, reset, spp in seq:
+            cfg = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=reset)
+            queue.append(r.render_async(cfg, spp=spp))
+            if len(queue) >= fif:
+                collect()
+        while queue:
+            collect()
+        with pytest.raises(backend.BackendError):
+            r.wait(12345)                      # not in flight
+        r.close()
+        return images, stats
+
+    ref_images, ref_stats = run(1)
+    images, stats = run(3)
+    assert stats == ref_stats
+    for a, b in zip(images, ref_images):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert not np.array_equal(ref_images[0], ref_images[1])
+
+
+def test_more_tickets_than_contexts_is_an_error(small_scenes):
+    s = small_scenes["cornell"]
+    r = backend.RenderHip(frames_in_flight=2)
+    r.initialize(64, 64)
+    r.set_scene(s)
+    cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    t1 = r.render_async(cfg, spp=1)
+    t2 = r.render_async(cfg, spp=1)
+    with pytest.raises(backend.BackendError):
+        r.render_async(cfg, spp=1)
+    r.wait(t1)
+    t3 = r.render_async(cfg, spp=1)
+    # a synchronous call drains whatever is still queued and then renders
+    st = r.render(cfg, spp=1)
+    assert st.raw.rays_closest > 0
+    with pytest.raises(backend.BackendError):
+        r.wait(t2)
+    r.close()

@@ -6,7 +6,7 @@ for lib in "$@"; do
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); s=d['roofline']['stage_ms_per_step']
-        print('%-40s ms/step %.3f  Mrays/s %.0f  extend %.3f connect %.3f other %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['extend'], s['connect'], s['raygen_sort_shade_resolve']))
+        d=json.loads(l); s=d['roofline']['one_frame_at_a_time']['stage_ms_per_step']
+        print('%-40s ms/step %.3f  Mrays/s %.0f | one frame at a time: total %.3f extend %.3f connect %.3f other %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['gpu_total'], s['extend'], s['connect'], s['raygen_sort_shade_resolve']))
 "
 done
