@@ -38,12 +38,17 @@ struct RpShadowRays {
     uint32_t *ids;   // compacted path ids
 };
 // device-side counters, one block of them per frame
-struct RpCounters {
-    uint32_t queue_count[2]; // ping-pong ray queues
-    uint32_t shadow_count;
-    uint32_t cursor_extend;
+// queue heads of one bounce. They live in per-bounce slots that one memset per frame zeroes, so nothing has to be
+// reset between the launches of a frame (a reset kernel per bounce was 9 launches and ~32 us per frame).
+struct RpBounceCounters {
+    uint32_t queue_count;    // rays this bounce extends (written by raygen / the previous bounce's shade)
+    uint32_t shadow_count;   // shadow rays this bounce's shade emitted
+    uint32_t cursor_extend;  // entries handed out behind the static first pools (dtraverse.h)
     uint32_t cursor_connect;
-    uint32_t _pad[3];
+};
+#define RP_MAX_BOUNCES 64 // RptrRenderParams.max_path_depth is validated against it
+struct RpCounters {
+    RpBounceCounters bounce[RP_MAX_BOUNCES + 1];
     unsigned long long rays_closest, rays_shadow, nodes, tris, hits_shaded, nodes_shadow, tris_shadow;
     uint32_t stack_overflow;
     uint32_t _pad2;
@@ -124,15 +129,15 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, ui
             if (valid) s_ids[at] = p;
         }
         __syncthreads();
-        rp_block_flush(s_ids, s_n, queue, &ctr->queue_count[0], &s_base);
+        rp_block_flush(s_ids, s_n, queue, &ctr->bounce[0].queue_count, &s_base);
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
 template <bool COUNT>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                               RpCounters *ctr, int *gstack) {
+__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+                                               int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const uint32_t p = queue[i];
@@ -147,7 +152,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const
         ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
     };
-    rp_wave_trace<false, COUNT>(sc, *count_ptr, &ctr->cursor_extend, gstack, load, done, n_nodes, n_tris);
+    rp_wave_trace<false, COUNT>(sc, bc->queue_count, &bc->cursor_extend, gstack, load, done, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -160,7 +165,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 template <bool COUNT>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpCounters *ctr, int *gstack) {
+__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const uint32_t p = sq.ids[i];
@@ -181,7 +186,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpSh
             ps.illum[p] = il;
         }
     };
-    rp_wave_trace<true, COUNT>(sc, ctr->shadow_count, &ctr->cursor_connect, gstack, load, done, n_nodes, n_tris);
+    rp_wave_trace<true, COUNT>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -331,7 +336,8 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 // ------------------------------------------------------------------ shade
 template <int VARIANT>
 __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
-                                                  const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, RpCounters *ctr) {
+                                                  const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
+                                                  RpCounters *ctr) {
     __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
         __syncthreads();
         rp_block_flush(s_next, s_nn, next_queue, next_count, &s_base);
         __syncthreads();
-        rp_block_flush(s_shadow, s_ns, sq.ids, &ctr->shadow_count, &s_base);
+        rp_block_flush(s_shadow, s_ns, sq.ids, shadow_count, &s_base);
         __syncthreads();
     }
     my_closest = rp_wave_sum_u32(my_closest);
@@ -557,13 +563,8 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
     }
 }
 
-// between bounces: reset what the next bounce appends to
-__global__ void rp_k_next_bounce(RpCounters *ctr, int next_out /* queue index the coming shade writes */, uint32_t persistent_waves) {
-    ctr->queue_count[next_out] = 0;
-    ctr->shadow_count = 0;
-    ctr->cursor_extend = 0; // entries handed out behind the static first pools (dtraverse.h)
-    ctr->cursor_connect = 0;
-}
+// the query kernel (rp_k_trace) borrows a pool cursor: reset it
+__global__ void rp_k_reset_u32(uint32_t *p) { *p = 0; }
 
 // ------------------------------------------------------------------ resolve
 // accumulate.glsl:68-73 (store this sample) + process_samples.comp:116-132 (running mean into the

@@ -450,7 +450,7 @@ int rptr_hip_set_params(rptr_hip_t *h, const RptrRenderParams *params, const Rpt
                         const RptrLightSamplingConfig *lighting_params) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (params) {
-        if (params->max_path_depth < 1 || params->max_path_depth > 64) return fail(h, RPTR_E_INVALID, "max_path_depth out of range");
+        if (params->max_path_depth < 1 || params->max_path_depth > RP_MAX_BOUNCES) return fail(h, RPTR_E_INVALID, "max_path_depth out of range");
         h->params = *params;
     }
     if (scene_params) h->scene_params = *scene_params;
@@ -921,10 +921,10 @@ static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
 
 extern "C++" {
 template <int VARIANT>
-static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint32_t *order, int in, int out) {
+static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     const int grid = grid_for(h, h->path_capacity);
-    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->queue_count[in],
-                       c.queue[out], &c.counters->queue_count[out], c.counters);
+    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
+                       c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
 }
 
 static void add_counters(RpCounters &dst, const RpCounters &c) {
@@ -1103,41 +1103,40 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             timed(2, [&] { hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, c.ps, c.queue[0], c.counters); });
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
-                hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, c.stream, c.counters, out,
-                                   (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
+                RpBounceCounters *bc = &c.counters->bounce[b];
                 timed(0, [&] {
                     if (count_traversal)
                         hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
-                                           c.queue[in], &c.counters->queue_count[in], c.counters, c.gstack);
+                                           c.queue[in], bc, c.counters, c.gstack);
                     else
                         hipLaunchKernelGGL(rp_k_extend<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
-                                           c.queue[in], &c.counters->queue_count[in], c.counters, c.gstack);
+                                           c.queue[in], bc, c.counters, c.gstack);
                 });
                 c.launches_extend++;
                 const uint32_t *order = c.queue[in];
                 if (do_sort) {
                     timed(2, [&] {
                         hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.queue[in],
-                                           &c.counters->queue_count[in], c.keys, c.sort_hist);
+                                           &bc->queue_count, c.keys, c.sort_hist);
                         hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
                         hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, c.queue[in],
-                                           &c.counters->queue_count[in], c.keys, c.sort_base, c.sort_cursor, c.order);
+                                           &bc->queue_count, c.keys, c.sort_base, c.sort_cursor, c.order);
                     });
                     order = c.order;
                 }
                 timed(2, [&] {
                     if (variant == RPTR_VARIANT_SIMPLE)
-                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, f, order, in, out);
+                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, f, order, b, out);
                     else
-                        launch_shade<RPTR_VARIANT_GLTF>(h, c, f, order, in, out);
+                        launch_shade<RPTR_VARIANT_GLTF>(h, c, f, order, b, out);
                 });
                 timed(1, [&] {
                     if (count_traversal)
                         hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
-                                           c.counters, c.gstack);
+                                           bc, c.counters, c.gstack);
                     else
                         hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
-                                           c.counters, c.gstack);
+                                           bc, c.counters, c.gstack);
                 });
                 c.launches_connect++;
             }
@@ -1313,11 +1312,10 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
             break;
         }
         // cursor_extend doubles as the pool cursor of the query kernel (same stream, no overlap with a frame)
-        hipLaunchKernelGGL(rp_k_next_bounce, dim3(1), dim3(1), 0, h->stream, h->ctx[0].counters, 0,
-                           (uint32_t)(h->persistent_blocks * (RP_TRAVERSE_BLOCK / 64)));
+        hipLaunchKernelGGL(rp_k_reset_u32, dim3(1), dim3(1), 0, h->stream, &h->ctx[0].counters->bounce[0].cursor_extend);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
-                               &h->ctx[0].counters->cursor_extend, h->ctx[0].gstack, dv, dt);
+                               &h->ctx[0].counters->bounce[0].cursor_extend, h->ctx[0].gstack, dv, dt);
         };
         if (any_hit)
             launch(rp_k_trace<true, true>);
