@@ -222,7 +222,8 @@ def main():
     ms_per_step = elapsed * 1e3 / K
     mrays = rays / elapsed / 1e6
     # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share
-    ext_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt["nodes_closest"] * NODE_BYTES
+    primary = r.local_pixel_count() * spp  # the first launch computes its camera rays instead of reading them
+    ext_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * RAY_BYTES + cnt["nodes_closest"] * NODE_BYTES
                  + cnt["tris_closest"] * TRI_BYTES)
     con_bytes = (cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
                  + cnt["tris_shadow"] * TRI_BYTES)
@@ -237,7 +238,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "rp_k_extend<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "rp_k_extend<false, *> (first bounce: <false, true>, later bounces: <false, false>)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
         "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,

@@ -85,7 +85,27 @@ RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *q
 }
 
 // ------------------------------------------------------------------ raygen
-__global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, uint32_t *queue, RpCounters *ctr) {
+// The camera ray of path p (pt_megakernel.glsl:314-325 + :330-352 pinhole branch): a pure function of the frame
+// constants and the path id, so nothing of it is stored -- the first extend and the first shade both call it
+// (saves writing and re-reading 72 bytes of path state per pixel sample). Returns false for padding slots.
+RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir) {
+    const uint32_t sslot = p / uint32_t(f.npix_padded);
+    const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
+    int lx = 0, ly = 0;
+    if (!rp_slot_to_local(f, slot, lx, ly)) return false;
+    const int gy = rp_local_row_to_global(f, ly);
+    if (gy >= f.height) return false;
+    const uint32_t sample_index = f.sample_base + sslot;
+    rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+    V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
+    if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
+    point = v2(point.x / float(f.width), point.y / float(f.height));
+    dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
+    return true;
+}
+
+// queue of the first bounce: the ids of the pixel samples that exist (tile padding and rows beyond the frame drop out)
+__global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, uint32_t *queue, RpCounters *ctr) {
     __shared__ uint32_t s_ids[RP_CHUNK];
     __shared__ uint32_t s_n, s_base;
     const uint32_t total = uint32_t(f.batch_spp) * uint32_t(f.npix_padded);
@@ -97,33 +117,11 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, ui
         for (uint32_t k = 0; k < RP_CHUNK / 256; ++k) {
             const uint32_t p = chunk * RP_CHUNK + k * 256 + threadIdx.x;
             bool valid = p < total;
-            int lx = 0, ly = 0;
-            uint32_t slot = 0, sslot = 0;
             if (valid) {
-                sslot = p / uint32_t(f.npix_padded);
-                slot = p - sslot * uint32_t(f.npix_padded);
-                valid = rp_slot_to_local(f, slot, lx, ly);
-            }
-            int gy = 0;
-            if (valid) {
-                gy = rp_local_row_to_global(f, ly);
-                valid = gy < f.height;
-            }
-            if (valid) {
-                // pt_megakernel.glsl:314-325
-                const uint32_t sample_index = f.sample_base + sslot;
-                uint32_t rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
-                V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
-                if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
-                point = v2(point.x / float(f.width), point.y / float(f.height));
-                V3 dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
-                ps.ray_o[p] = make_float4(f.cam_pos[0], f.cam_pos[1], f.cam_pos[2], 0.0f);
-                ps.ray_d[p] = f4(dir, 2.e32f);
-                ps.thr[p] = make_float4(1.f, 1.f, 1.f, 2.e16f); // init_shading_sample_state, shading_interface.glsl:20-22
-                ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-                ps.rng_tt[p] = make_float2(__uint_as_float(rng), 0.0f);
-            } else if (p < total) {
-                ps.illum[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                const uint32_t sslot = p / uint32_t(f.npix_padded);
+                const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
+                int lx = 0, ly = 0;
+                valid = rp_slot_to_local(f, slot, lx, ly) && rp_local_row_to_global(f, ly) < f.height;
             }
             const uint32_t at = rp_wave_append(&s_n, valid);
             if (valid) s_ids[at] = p;
@@ -135,17 +133,26 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, RpPathState ps, ui
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
-template <bool COUNT>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+// FIRST: bounce 0, the rays are the camera rays (computed, not loaded)
+template <bool COUNT, bool FIRST>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const uint32_t p = queue[i];
-        const float4 o = ps.ray_o[p], d = ps.ray_d[p];
-        ro = xyz(o);
-        rd = xyz(d);
-        tmin = o.w;
-        tmax = d.w;
+        if (FIRST) {
+            uint32_t rng;
+            (void)rp_primary_ray(f, p, rng, rd); // the queue holds existing pixel samples only
+            ro = ld3(f.cam_pos);
+            tmin = 0.0f;
+            tmax = 2.e32f;
+        } else {
+            const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+            ro = xyz(o);
+            rd = xyz(d);
+            tmin = o.w;
+            tmax = d.w;
+        }
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
         const uint32_t p = queue[i];
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 }
 
 // ------------------------------------------------------------------ shade
-template <int VARIANT>
+template <int VARIANT, bool FIRST>
 __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
@@ -360,18 +367,34 @@ __global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathS
             if (i < n) {
                 p = order[i];
                 my_closest++;
-                const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
-                float4 thr4 = ps.thr[p];
-                float4 il4 = ps.illum[p];
-                const float2 rt = ps.rng_tt[p];
-                uint32_t rng = __float_as_uint(rt.x);
-                float total_t = rt.y;
+                uint32_t rng;
+                float total_t, prev_bounce_pdf;
+                V3 ray_origin, ray_dir, throughput, illum;
+                int bounce;
+                if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
+                    (void)rp_primary_ray(f, p, rng, ray_dir);
+                    ray_origin = ld3(f.cam_pos);
+                    throughput = v3s(1.0f);
+                    illum = v3s(0.0f);
+                    prev_bounce_pdf = 2.e16f;
+                    total_t = 0.0f;
+                    bounce = 0;
+                } else {
+                    const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
+                    const float4 thr4 = ps.thr[p];
+                    const float4 il4 = ps.illum[p];
+                    const float2 rt = ps.rng_tt[p];
+                    rng = __float_as_uint(rt.x);
+                    total_t = rt.y;
+                    ray_origin = xyz(ro4);
+                    ray_dir = xyz(rd4);
+                    throughput = xyz(thr4);
+                    illum = xyz(il4);
+                    prev_bounce_pdf = thr4.w;
+                    bounce = __float_as_int(il4.w);
+                }
                 const float4 hit4 = ps.hit_tuv[p];
                 const int2 ids = ps.hit_ids[p];
-                V3 ray_origin = xyz(ro4), ray_dir = xyz(rd4);
-                V3 throughput = xyz(thr4), illum = xyz(il4);
-                float prev_bounce_pdf = thr4.w;
-                int bounce = __float_as_int(il4.w);
                 if (ids.x < 0) {
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);

@@ -432,7 +432,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->last_resolved = nullptr;
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false>, RP_TRAVERSE_BLOCK, 0));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false>, RP_TRAVERSE_BLOCK, 0));
     occ = std::max(1, std::min(occ, 8));
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
@@ -923,8 +923,14 @@ extern "C++" {
 template <int VARIANT>
 static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     const int grid = grid_for(h, h->path_capacity);
-    hipLaunchKernelGGL(rp_k_shade<VARIANT>, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
-                       c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
+                           c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
+    };
+    if (bounce == 0)
+        go(rp_k_shade<VARIANT, true>);
+    else
+        go(rp_k_shade<VARIANT, false>);
 }
 
 static void add_counters(RpCounters &dst, const RpCounters &c) {
@@ -1100,17 +1106,19 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
         if (local_work) {
             HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
             const size_t total = (size_t)batch * h->npix_padded;
-            timed(2, [&] { hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, c.ps, c.queue[0], c.counters); });
+            timed(2, [&] { hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, c.queue[0], c.counters); });
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 timed(0, [&] {
-                    if (count_traversal)
-                        hipLaunchKernelGGL(rp_k_extend<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
-                                           c.queue[in], bc, c.counters, c.gstack);
+                    auto go = [&](auto kernel) {
+                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, f, c.ps, c.queue[in], bc,
+                                           c.counters, c.gstack);
+                    };
+                    if (b == 0)
+                        count_traversal ? go(rp_k_extend<true, true>) : go(rp_k_extend<false, true>);
                     else
-                        hipLaunchKernelGGL(rp_k_extend<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps,
-                                           c.queue[in], bc, c.counters, c.gstack);
+                        count_traversal ? go(rp_k_extend<true, false>) : go(rp_k_extend<false, false>);
                 });
                 c.launches_extend++;
                 const uint32_t *order = c.queue[in];
