@@ -46,5 +46,26 @@ def build_library(force=False, verbose=False, extra_flags=()):
     return LIB_PATH
 
 
+HOST_TOOLS = {"rptr_validate": "rptr_validate.cpp", "demo_host": "demo_host.cpp"}
+BIN_DIR = os.path.join(HERE, "bin")
+
+
+def build_host_tools(verbose=False):
+    """The C++ host programs over the C ABI (g++, no HIP headers): bin/rptr_validate (headless --validation run that
+    writes .pfm), bin/demo_host."""
+    os.makedirs(BIN_DIR, exist_ok=True)
+    out = []
+    for name, src in HOST_TOOLS.items():
+        exe = os.path.join(BIN_DIR, name)
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HERE, "host", src), "-o", exe, "-L" + HERE, "-lrptr_hip",
+               "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        out.append(exe)
+    return out
+
+
 if __name__ == "__main__":
     build_library(force=True, verbose=True)
+    build_host_tools(verbose=True)

@@ -136,6 +136,43 @@ class Scene:
     sky_key: str = ""
     _keep: list = field(default_factory=list, repr=False)
 
+    def dump(self, path, render_params: abi.RenderParams = None, lighting: abi.LightSamplingConfig = None):
+        """Writes the scene as a flat little-endian file for the C++ host tools (host/scene_dump.hpp documents the
+        layout): what a reference-side adapter would hand over from its own `Scene` (stand-in for the .vks loader)."""
+        import struct
+        rp = render_params or abi.RenderParams.default()
+        lc = lighting or abi.LightSamplingConfig.default()
+        with open(path, "wb") as f:
+            f.write(b"RPSC1\0\0\0")
+            f.write(struct.pack("<6I", len(self.geometries), len(self.meshes), len(self.pmeshes), len(self.instances), len(self.materials),
+                                len(self.lights)))
+            for g in self.geometries:
+                f.write(struct.pack("<3I", g.num_tris, 1 if g.has_normals else 0, 1 if g.has_uvs else 0))
+                f.write(np.asarray(g.scaling, dtype=f32).tobytes() + np.asarray(g.offset, dtype=f32).tobytes())
+                f.write(struct.pack("<I", 0 if g.qnrm_uv is None else 1))
+                f.write(np.ascontiguousarray(g.qpos, dtype=np.uint64).tobytes())
+                if g.qnrm_uv is not None:
+                    f.write(np.ascontiguousarray(g.qnrm_uv, dtype=np.uint64).tobytes())
+            for m in self.meshes:
+                f.write(struct.pack("<3I", m.first_geometry, m.num_geometries, 1 if m.dynamic else 0))
+            for pm in self.pmeshes:
+                mo = np.ascontiguousarray(pm.material_offsets, dtype=np.int32)
+                f.write(struct.pack("<2I", pm.mesh, len(mo)) + mo.tobytes())
+                ti = None if pm.tri_material_ids is None else np.ascontiguousarray(pm.tri_material_ids, dtype=np.uint8)
+                f.write(struct.pack("<I", 0 if ti is None else len(ti)))
+                if ti is not None:
+                    f.write(ti.tobytes())
+            for inst in self.instances:
+                f.write(np.asarray(inst.transform, dtype=f32).reshape(12).tobytes() + struct.pack("<I", inst.pmesh))
+            for m in self.materials:
+                f.write(bytes(m))
+            if len(self.lights):
+                f.write(np.ascontiguousarray(self.lights, dtype=f32).tobytes())
+            f.write(bytes(self.camera_params()))
+            f.write(bytes(self.scene_params()))
+            f.write(bytes(rp))
+            f.write(bytes(lc))
+
     def num_tris(self):
         return sum(g.num_tris for g in self.geometries)
 
