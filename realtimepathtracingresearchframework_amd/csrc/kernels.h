@@ -341,8 +341,11 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 }
 
 // ------------------------------------------------------------------ shade
+#ifndef RP_SHADE_WAVES
+#define RP_SHADE_WAVES 4 // minimum waves per SIMD the shade kernels are compiled for (bounds their VGPR budget)
+#endif
 template <int VARIANT, bool FIRST>
-__global__ __launch_bounds__(256) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
+__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
     __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
