@@ -291,7 +291,7 @@ def main():
         cpu_rays = ost.rays_closest + ost.rays_shadow
         out["cpu_baseline"] = {
             "value": round(cpu_rays / ost.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(ost.threads), "kind": "port",
-            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH4 traversal + "
+            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH2 traversal + "
                       "shading, std::thread over rows)" % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, ost.seconds),
         }
     print(json.dumps(out))

@@ -337,6 +337,13 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
 int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris,
                         void *instances, size_t *n_instances);
 
+/* ---- the host half of set_scene on its own: builds the same acceleration structure (binned SAH per mesh, top
+ * level over the instance bounds, 4-wide collapse, 64-byte encoding) WITHOUT a device or a handle. Two calls like
+ * rptr_hip_export_bvh (NULL buffers to query sizes). out_stack_need: worst-case traversal stack entries of the tree.
+ * Test/diagnostic entry: the CPU test suite walks this tree with the oracle. */
+int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris,
+                            void *instances, size_t *n_instances, int32_t *out_stack_need);
+
 /* ---- stats() (render_vulkan.cpp:2229-2243) */
 int rptr_hip_stats(const rptr_hip_t *h, RptrStats *out);
 

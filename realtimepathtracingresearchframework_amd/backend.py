@@ -71,6 +71,8 @@ def load_library(path=None):
     L.rptr_hip_tile_rows.argtypes = [vp, i32, vp, i32]
     L.rptr_hip_local_pixel_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_copy_tile_to_device.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_build_bvh_host.argtypes = [C.POINTER(abi.SceneDesc), vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp,
+                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     L.rptr_hip_trace.argtypes = [vp, vp, i32, vp]
     L.rptr_hip_trace_counted.argtypes = [vp, vp, i32, vp, vp, vp, i32]
     L.rptr_hip_export_bvh.argtypes = [vp, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
@@ -79,6 +81,25 @@ def load_library(path=None):
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
     return L
+
+
+def build_bvh_host(scene):
+    """The acceleration structure set_scene would build, made on the host alone (no GPU needed): returns
+    (nodes, tris, instances, stack_need) as float32 views of RptrBvh4Node / RptrBvhTri / RptrBvhInstance arrays."""
+    L = load_library()
+    desc = scene.desc()
+    nn, nt, ni, need = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0), C.c_int32(0)
+    rc = L.rptr_hip_build_bvh_host(C.byref(desc), None, C.byref(nn), None, C.byref(nt), None, C.byref(ni), C.byref(need))
+    if rc != 0:
+        raise BackendError(rc, L.rptr_hip_last_error(None).decode())
+    nodes = np.zeros(max(nn.value, 1) * 16, dtype=np.float32)
+    tris = np.zeros(max(nt.value, 1) * 12, dtype=np.float32)
+    insts = np.zeros(max(ni.value, 1) * 32, dtype=np.float32)
+    rc = L.rptr_hip_build_bvh_host(C.byref(desc), nodes.ctypes.data_as(C.c_void_p), C.byref(nn), tris.ctypes.data_as(C.c_void_p), C.byref(nt),
+                                   insts.ctypes.data_as(C.c_void_p), C.byref(ni), C.byref(need))
+    if rc != 0:
+        raise BackendError(rc, L.rptr_hip_last_error(None).decode())
+    return nodes[:nn.value * 16], tris[:nt.value * 12], insts[:ni.value * 32], int(need.value)
 
 
 class RenderStats:  # librender/render_backend.h:15-24

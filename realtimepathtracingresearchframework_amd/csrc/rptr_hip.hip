@@ -225,6 +225,182 @@ int grid_for(const rptr_hip *h, size_t n, int per_cu = 8) {
 } // namespace
 
 extern "C++" {
+// ------------------------------------------------------------------ host side of the acceleration structure
+// Everything of set_scene that needs no device: per-mesh binned-SAH trees from the dequantised triangles, the
+// top level over the instance bounds, the 4-wide collapse, the 64-byte encoding, and the worst-case stack need.
+// Also reachable without a GPU through rptr_hip_build_bvh_host (CPU tests walk this tree with the oracle).
+struct HostBvh {
+    std::vector<RptrBvh4Node> nodes;
+    std::vector<std::array<float, 6>> node_box;
+    std::vector<RptrBvhTri> tris;
+    std::vector<RptrBvhInstance> insts;
+    std::vector<MeshRt> meshes;
+    std::vector<int> mesh_root;
+    int num_tlas_nodes = 0;
+    float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
+    int stack_need = 0;
+};
+
+static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
+    // instanceCustomIndex of every parameterized mesh = number of geometries before it (render_vulkan.cpp:2748-2850)
+    std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
+    {
+        int at = 0;
+        for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p) {
+            pmesh_base[p] = at;
+            at += (int)s->meshes[s->parameterized_meshes[p].mesh].num_geometries;
+        }
+    }
+    // ---- bottom-level BVHs (one per mesh), built from dequantised floats
+    B.nodes.clear();
+    B.tris.clear();
+    B.insts.clear();
+    B.meshes.assign(s->num_meshes, MeshRt());
+    std::vector<RptrBvh4Node> blas_nodes;          // relocated behind the TLAS afterwards
+    std::vector<std::array<float, 6>> blas_boxes;  // exact float bounds per node (refit + instance bounds)
+    // encodes a wide tree into 64-byte nodes; inner child indices get `node_shift`, leaf ranges `first_shift`
+    auto encode_tree = [](const rptr::Wide4Tree &wt, int node_shift, int first_shift, std::vector<RptrBvh4Node> &dst,
+                          std::vector<std::array<float, 6>> &boxes) {
+        for (const rptr::Wide4 &w : wt.nodes) {
+            int32_t child[4];
+            for (int k = 0; k < 4; ++k) {
+                const int32_t c = w.child[k];
+                if (c == RPTR_BVH4_EMPTY)
+                    child[k] = c;
+                else if (c >= 0)
+                    child[k] = c + node_shift;
+                else
+                    child[k] = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(c) + first_shift, RPTR_BVH_LEAF_COUNT(c));
+            }
+            RptrBvh4Node n;
+            std::array<float, 6> nb;
+            rp_bvh4_encode(w.box, child, &n, nb.data(), nb.data() + 3);
+            dst.push_back(n);
+            boxes.push_back(nb);
+        }
+    };
+    for (uint32_t m = 0; m < s->num_meshes; ++m) {
+        const RptrMeshDesc &mesh = s->meshes[m];
+        std::vector<rptr::BuildPrim> prims;
+        std::vector<RptrBvhTri> mtris;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
+            for (uint32_t t = 0; t < gd.num_tris; ++t) {
+                float v[3][3];
+                for (int k = 0; k < 3; ++k) dequantize_position(gd.qpos[3 * (size_t)t + k], gd.quantized_scaling, gd.quantized_offset, v[k]);
+                RptrBvhTri tri;
+                rptr::BuildPrim bp;
+                for (int k = 0; k < 3; ++k) {
+                    tri.v0[k] = v[0][k];
+                    tri.e1[k] = v[1][k] - v[0][k];
+                    tri.e2[k] = v[2][k] - v[0][k];
+                    bp.lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
+                    bp.hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
+                }
+                tri.prim = t;
+                tri.geom = j;
+                tri._pad = 0;
+                mtris.push_back(tri);
+                prims.push_back(bp);
+            }
+        }
+        MeshRt &mr = B.meshes[m];
+        mr.dynamic = mesh.dynamic != 0;
+        rptr::BuiltTree tree;
+        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
+        rptr::Wide4Tree wide;
+        rptr::collapse_bvh4(tree, wide);
+        mr.node_base = (int)blas_nodes.size();
+        mr.node_count = (int)wide.nodes.size();
+        mr.tri_base = (int)B.tris.size();
+        mr.tri_count = (int)mtris.size();
+        memcpy(mr.lo, tree.lo, 12);
+        memcpy(mr.hi, tree.hi, 12);
+        for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
+        encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
+    }
+    // ---- top level over instance bounds (1 instance per leaf)
+    std::vector<rptr::BuildPrim> iprims(s->num_instances);
+    std::vector<RptrBvhInstance> insts(s->num_instances);
+    for (uint32_t i = 0; i < s->num_instances; ++i) {
+        const RptrInstanceDesc &in = s->instances[i];
+        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
+        const MeshRt &mr = B.meshes[pm.mesh];
+        RptrBvhInstance bi;
+        memset(&bi, 0, sizeof(bi));
+        memcpy(bi.object_to_world, in.transform, 48);
+        invert_affine(in.transform, bi.world_to_object);
+        bi.blas_root = mr.node_base; // relocated below
+        bi.geometry_base = pmesh_base[in.parameterized_mesh];
+        bi.instance_id = (int)i;
+        insts[i] = bi;
+        rptr::BuildPrim &bp = iprims[i];
+        for (int k = 0; k < 3; ++k) {
+            bp.lo[k] = INFINITY;
+            bp.hi[k] = -INFINITY;
+        }
+        for (int c = 0; c < 8; ++c) {
+            const float p[3] = {c & 1 ? mr.hi[0] : mr.lo[0], c & 2 ? mr.hi[1] : mr.lo[1], c & 4 ? mr.hi[2] : mr.lo[2]};
+            const float *M = in.transform;
+            for (int r = 0; r < 3; ++r) {
+                const float w = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
+                bp.lo[r] = std::fmin(bp.lo[r], w);
+                bp.hi[r] = std::fmax(bp.hi[r], w);
+            }
+        }
+    }
+    rptr::BuiltTree tlas;
+    rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
+    rptr::Wide4Tree tlas_wide;
+    rptr::collapse_bvh4(tlas, tlas_wide);
+    for (int k = 0; k < 3; ++k) {
+        B.scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
+        B.scene_hi[k] = std::isfinite(tlas.hi[k]) ? tlas.hi[k] : 1.0f;
+    }
+    const int reloc = (int)tlas_wide.nodes.size();
+    B.num_tlas_nodes = reloc;
+    B.nodes.clear();
+    B.node_box.clear();
+    encode_tree(tlas_wide, 0, 0, B.nodes, B.node_box); // TLAS leaf 'first' already indexes the reordered instance array
+    for (size_t i = 0; i < blas_nodes.size(); ++i) {
+        RptrBvh4Node nd = blas_nodes[i];
+        for (int k = 0; k < 4; ++k)
+            if (nd.child[k] >= 0) nd.child[k] += reloc;
+        B.nodes.push_back(nd);
+        B.node_box.push_back(blas_boxes[i]);
+    }
+    B.mesh_root.assign(B.meshes.size(), -1);
+    for (size_t m = 0; m < B.meshes.size(); ++m) {
+        B.meshes[m].node_base += reloc;
+        B.mesh_root[m] = B.meshes[m].node_base;
+    }
+    B.insts.resize(s->num_instances);
+    for (uint32_t k = 0; k < s->num_instances; ++k) {
+        B.insts[k] = insts[tlas.order[k]];
+        B.insts[k].blas_root += reloc;
+    }
+    // ---- the traversal stack must hold the worst case of this tree: per node (children - 1) siblings plus whatever
+    // its deepest child needs; + the exit marker, + the instance-exit sentinel between the two levels
+    {
+        const size_t nn = B.nodes.size();
+        std::vector<int> need(nn, 0);
+        for (int64_t i = (int64_t)nn - 1; i >= 0; --i) { // children sit behind their parents (breadth-first order per tree)
+            const RptrBvh4Node &nd = B.nodes[i];
+            int nchild = 0, deepest = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
+                ++nchild;
+                if (nd.child[k] >= 0) deepest = std::max(deepest, need[nd.child[k]]);
+            }
+            need[i] = std::max(0, nchild - 1) + deepest;
+        }
+        int blas_need = 0;
+        for (size_t m = 0; m < B.meshes.size(); ++m) blas_need = std::max(blas_need, need[B.mesh_root[m]]);
+        const int total = 1 + need[0] + 1 + blas_need;
+        B.stack_need = total;
+    }
+}
+
 static int drain(rptr_hip *h);
 }
 
@@ -581,157 +757,24 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             prim_offset += gd.num_tris;
         }
     }
-    // ---- bottom-level BVHs (one per mesh), built from dequantised floats
-    h->h_nodes.clear();
-    h->h_tris.clear();
-    h->h_insts.clear();
-    h->meshes.assign(s->num_meshes, MeshRt());
-    std::vector<RptrBvh4Node> blas_nodes;          // relocated behind the TLAS afterwards
-    std::vector<std::array<float, 6>> blas_boxes;  // exact float bounds per node (refit + instance bounds)
-    // encodes a wide tree into 64-byte nodes; inner child indices get `node_shift`, leaf ranges `first_shift`
-    auto encode_tree = [](const rptr::Wide4Tree &wt, int node_shift, int first_shift, std::vector<RptrBvh4Node> &dst,
-                          std::vector<std::array<float, 6>> &boxes) {
-        for (const rptr::Wide4 &w : wt.nodes) {
-            int32_t child[4];
-            for (int k = 0; k < 4; ++k) {
-                const int32_t c = w.child[k];
-                if (c == RPTR_BVH4_EMPTY)
-                    child[k] = c;
-                else if (c >= 0)
-                    child[k] = c + node_shift;
-                else
-                    child[k] = RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(c) + first_shift, RPTR_BVH_LEAF_COUNT(c));
-            }
-            RptrBvh4Node n;
-            std::array<float, 6> nb;
-            rp_bvh4_encode(w.box, child, &n, nb.data(), nb.data() + 3);
-            dst.push_back(n);
-            boxes.push_back(nb);
-        }
-    };
-    for (uint32_t m = 0; m < s->num_meshes; ++m) {
-        const RptrMeshDesc &mesh = s->meshes[m];
-        std::vector<rptr::BuildPrim> prims;
-        std::vector<RptrBvhTri> mtris;
-        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
-            const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
-            for (uint32_t t = 0; t < gd.num_tris; ++t) {
-                float v[3][3];
-                for (int k = 0; k < 3; ++k) dequantize_position(gd.qpos[3 * (size_t)t + k], gd.quantized_scaling, gd.quantized_offset, v[k]);
-                RptrBvhTri tri;
-                rptr::BuildPrim bp;
-                for (int k = 0; k < 3; ++k) {
-                    tri.v0[k] = v[0][k];
-                    tri.e1[k] = v[1][k] - v[0][k];
-                    tri.e2[k] = v[2][k] - v[0][k];
-                    bp.lo[k] = std::fmin(v[0][k], std::fmin(v[1][k], v[2][k]));
-                    bp.hi[k] = std::fmax(v[0][k], std::fmax(v[1][k], v[2][k]));
-                }
-                tri.prim = t;
-                tri.geom = j;
-                tri._pad = 0;
-                mtris.push_back(tri);
-                prims.push_back(bp);
-            }
-        }
-        MeshRt &mr = h->meshes[m];
-        mr.dynamic = mesh.dynamic != 0;
-        rptr::BuiltTree tree;
-        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
-        rptr::Wide4Tree wide;
-        rptr::collapse_bvh4(tree, wide);
-        mr.node_base = (int)blas_nodes.size();
-        mr.node_count = (int)wide.nodes.size();
-        mr.tri_base = (int)h->h_tris.size();
-        mr.tri_count = (int)mtris.size();
-        memcpy(mr.lo, tree.lo, 12);
-        memcpy(mr.hi, tree.hi, 12);
-        for (uint32_t id : tree.order) h->h_tris.push_back(mtris[id]);
-        encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
-    }
-    // ---- top level over instance bounds (1 instance per leaf)
-    std::vector<rptr::BuildPrim> iprims(s->num_instances);
-    std::vector<RptrBvhInstance> insts(s->num_instances);
-    for (uint32_t i = 0; i < s->num_instances; ++i) {
-        const RptrInstanceDesc &in = s->instances[i];
-        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
-        const MeshRt &mr = h->meshes[pm.mesh];
-        RptrBvhInstance bi;
-        memset(&bi, 0, sizeof(bi));
-        memcpy(bi.object_to_world, in.transform, 48);
-        invert_affine(in.transform, bi.world_to_object);
-        bi.blas_root = mr.node_base; // relocated below
-        bi.geometry_base = pmesh_base[in.parameterized_mesh];
-        bi.instance_id = (int)i;
-        insts[i] = bi;
-        rptr::BuildPrim &bp = iprims[i];
-        for (int k = 0; k < 3; ++k) {
-            bp.lo[k] = INFINITY;
-            bp.hi[k] = -INFINITY;
-        }
-        for (int c = 0; c < 8; ++c) {
-            const float p[3] = {c & 1 ? mr.hi[0] : mr.lo[0], c & 2 ? mr.hi[1] : mr.lo[1], c & 4 ? mr.hi[2] : mr.lo[2]};
-            const float *M = in.transform;
-            for (int r = 0; r < 3; ++r) {
-                const float w = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
-                bp.lo[r] = std::fmin(bp.lo[r], w);
-                bp.hi[r] = std::fmax(bp.hi[r], w);
-            }
-        }
-    }
-    rptr::BuiltTree tlas;
-    rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
-    rptr::Wide4Tree tlas_wide;
-    rptr::collapse_bvh4(tlas, tlas_wide);
-    for (int k = 0; k < 3; ++k) {
-        h->scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
-        h->scene_hi[k] = std::isfinite(tlas.hi[k]) ? tlas.hi[k] : 1.0f;
-    }
-    const int reloc = (int)tlas_wide.nodes.size();
-    h->num_tlas_nodes = reloc;
-    h->h_nodes.clear();
-    h->h_node_box.clear();
-    encode_tree(tlas_wide, 0, 0, h->h_nodes, h->h_node_box); // TLAS leaf 'first' already indexes the reordered instance array
-    for (size_t i = 0; i < blas_nodes.size(); ++i) {
-        RptrBvh4Node nd = blas_nodes[i];
-        for (int k = 0; k < 4; ++k)
-            if (nd.child[k] >= 0) nd.child[k] += reloc;
-        h->h_nodes.push_back(nd);
-        h->h_node_box.push_back(blas_boxes[i]);
-    }
-    h->mesh_root.assign(h->meshes.size(), -1);
-    for (size_t m = 0; m < h->meshes.size(); ++m) {
-        h->meshes[m].node_base += reloc;
-        h->mesh_root[m] = h->meshes[m].node_base;
-    }
-    h->h_insts.resize(s->num_instances);
-    for (uint32_t k = 0; k < s->num_instances; ++k) {
-        h->h_insts[k] = insts[tlas.order[k]];
-        h->h_insts[k].blas_root += reloc;
-    }
-    // ---- the traversal stack must hold the worst case of this tree: per node (children - 1) siblings plus whatever
-    // its deepest child needs; + the exit marker, + the instance-exit sentinel between the two levels
+    // ---- acceleration structure (host part, no device involved)
+    HostBvh B;
+    build_host_bvh(s, B);
     {
-        const size_t nn = h->h_nodes.size();
-        std::vector<int> need(nn, 0);
-        for (int64_t i = (int64_t)nn - 1; i >= 0; --i) { // children sit behind their parents (breadth-first order per tree)
-            const RptrBvh4Node &nd = h->h_nodes[i];
-            int nchild = 0, deepest = 0;
-            for (int k = 0; k < 4; ++k) {
-                if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
-                ++nchild;
-                if (nd.child[k] >= 0) deepest = std::max(deepest, need[nd.child[k]]);
-            }
-            need[i] = std::max(0, nchild - 1) + deepest;
-        }
-        int blas_need = 0;
-        for (size_t m = 0; m < h->meshes.size(); ++m) blas_need = std::max(blas_need, need[h->mesh_root[m]]);
-        const int total = 1 + need[0] + 1 + blas_need;
         const int capacity = RP_LDS_STACK + RPTR_BVH_STACK_DEPTH;
-        if (total > capacity)
-            return fail(h, RPTR_E_UNSUPPORTED, "the acceleration structure of this scene needs a traversal stack of %d entries (limit %d)", total,
-                        capacity);
+        if (B.stack_need > capacity)
+            return fail(h, RPTR_E_UNSUPPORTED, "the acceleration structure of this scene needs a traversal stack of %d entries (limit %d)",
+                        B.stack_need, capacity);
     }
+    h->h_nodes = std::move(B.nodes);
+    h->h_node_box = std::move(B.node_box);
+    h->h_tris = std::move(B.tris);
+    h->h_insts = std::move(B.insts);
+    h->meshes = std::move(B.meshes);
+    h->mesh_root = std::move(B.mesh_root);
+    h->num_tlas_nodes = B.num_tlas_nodes;
+    memcpy(h->scene_lo, B.scene_lo, 12);
+    memcpy(h->scene_hi, B.scene_hi, 12);
     // ---- refit schedule: nodes of the dynamic meshes by height (children before parents), then the TLAS by height
     std::vector<uint32_t> refit_list;
     h->refit_levels_blas.clear();
@@ -1343,6 +1386,25 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
     (void)hipFree(dv);
     (void)hipFree(dt);
     return rc;
+}
+
+int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances,
+                            size_t *n_instances, int32_t *out_stack_need) {
+    if (!scene) return fail(nullptr, RPTR_E_INVALID, "NULL scene");
+    for (uint32_t p = 0; p < scene->num_parameterized_meshes; ++p)
+        if (scene->parameterized_meshes[p].mesh >= scene->num_meshes) return fail(nullptr, RPTR_E_INVALID, "parameterized mesh %u: bad mesh index", p);
+    for (uint32_t i = 0; i < scene->num_instances; ++i)
+        if (scene->instances[i].parameterized_mesh >= scene->num_parameterized_meshes) return fail(nullptr, RPTR_E_INVALID, "instance %u: bad mesh", i);
+    HostBvh B;
+    build_host_bvh(scene, B);
+    if (nodes && n_nodes && *n_nodes >= B.nodes.size()) memcpy(nodes, B.nodes.data(), B.nodes.size() * sizeof(RptrBvh4Node));
+    if (tris && n_tris && *n_tris >= B.tris.size()) memcpy(tris, B.tris.data(), B.tris.size() * sizeof(RptrBvhTri));
+    if (instances && n_instances && *n_instances >= B.insts.size()) memcpy(instances, B.insts.data(), B.insts.size() * sizeof(RptrBvhInstance));
+    if (n_nodes) *n_nodes = B.nodes.size();
+    if (n_tris) *n_tris = B.tris.size();
+    if (n_instances) *n_instances = B.insts.size();
+    if (out_stack_need) *out_stack_need = B.stack_need;
+    return RPTR_OK;
 }
 
 int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances, size_t *n_instances) {

@@ -1,11 +1,12 @@
 """Reads a rocprofv3 kernel trace CSV: GPU busy fraction (union of kernel intervals), mean concurrency, per-kernel totals
-over the steady-state part of the run (the last 60 % of the trace)."""
+over a window of the trace (fractions given as argv[2], argv[3]; default the last 60 %)."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:44]) for r in rows)
 t0, t1 = ev[0][0], max(e[1] for e in ev)
-lo = t0 + int(0.4 * (t1 - t0))
-ev = [e for e in ev if e[0] >= lo]
+a, b = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.4, 1.0)
+lo, hi = t0 + int(a * (t1 - t0)), t0 + int(b * (t1 - t0))
+ev = [e for e in ev if lo <= e[0] <= hi]
 span = max(e[1] for e in ev) - ev[0][0]
 busy, cur_s, cur_e = 0, None, None
 for s, e, _ in ev:
