@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
 HIT_BYTES = 24      # hit_tuv (float4) + hit_ids (int2) written per closest query
 QUEUE_BYTES = 4     # path id read from the ray queue
-NODE_BYTES = 64     # RptrBvhNode (an instance record, 128 B, counts as two)
+NODE_BYTES = 64     # RptrBvh4Node (an instance record, 128 B, counts as two)
 TRI_BYTES = 48      # RptrBvhTri
 SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-write for a visible shadow ray
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)

@@ -256,7 +256,7 @@ int rptr_hip_set_stream(rptr_hip_t *h, void *hip_stream);
 int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height);
 
 /* ---- RenderBackend::set_scene (render_vulkan.cpp:1554-1644): uploads geometry,
- * builds bottom/top level BVH2, uploads materials + binned lights */
+ * builds the bottom/top level acceleration structure (include/rptr_bvh.h), uploads materials + binned lights */
 int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *scene);
 
 /* ---- dynamic meshes: replace the float positions of one geometry and refit

@@ -1,4 +1,4 @@
-// bvh_build.h -- host-side BVH2 construction for the HIP backend.
+// bvh_build.h -- host-side construction of the acceleration structure: binary binned-SAH build + 4-wide collapse.
 //
 // Stands in for the driver's vkCmdBuildAccelerationStructuresKHR that the
 // reference calls through vulkan/vulkanrt_utils.h:83-105 (BLAS per mesh, static

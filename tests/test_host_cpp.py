@@ -24,7 +24,7 @@ def _build_demo(tmp_path):
 def test_header_is_valid_c(tmp_path):
     src = tmp_path / "abi.c"
     src.write_text('#include "rptr_hip.h"\n#include "rptr_bvh.h"\n'
-                   'int main(void){ return sizeof(RptrBaseMaterial)==80 && sizeof(RptrBvhNode)==64 && sizeof(RptrTriLightData)==48 ? 0 : 1; }\n')
+                   'int main(void){ return sizeof(RptrBaseMaterial)==80 && sizeof(RptrBvhNode)==64 && sizeof(RptrBvh4Node)==64 && sizeof(RptrBvhInstance)==128 && sizeof(RptrTriLightData)==48 ? 0 : 1; }\n')
     exe = str(tmp_path / "abi_c")
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
     assert subprocess.call([exe]) == 0
