@@ -110,6 +110,12 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_REFILL_MIN
 #define RP_REFILL_MIN 48
 #endif
+#ifndef RP_REFILL_MIN_ANY // the same thresholds for occlusion queries (tuned separately)
+#define RP_REFILL_MIN_ANY RP_REFILL_MIN
+#endif
+#ifndef RP_NODE_MIN_ANY
+#define RP_NODE_MIN_ANY RP_NODE_MIN
+#endif
 #ifndef RP_FETCH_DIV
 #define RP_FETCH_DIV 1u // a wave is dealt about 1/RP_FETCH_DIV of its fair share at a time
 #endif
@@ -195,7 +201,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         const bool idle = cur == RP_EXIT;
         const unsigned long long idle_mask = __ballot(idle);
         const uint32_t nidle = (uint32_t)__popcll(idle_mask);
-        if (nidle >= RP_REFILL_MIN) {
+        if (nidle >= (uint32_t)(ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN)) {
             if (pool_next >= pool_end && more) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, fetch); // the cursor counts entries handed out behind the static pools
@@ -241,7 +247,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const unsigned long long want_node = __ballot(cur >= 0);
             if (want_node == 0ull) break;
 #if RP_NODE_MIN > 1
-            if ((uint32_t)__popcll(want_node) < (uint32_t)RP_NODE_MIN &&
+            if ((uint32_t)__popcll(want_node) < (uint32_t)(ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN) &&
                 (uint32_t)__popcll(__ballot(cur < 0 && cur != RP_EXIT)) >= (uint32_t)RP_LEAF_MIN)
                 break;
 #endif
