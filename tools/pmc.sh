@@ -21,10 +21,11 @@ for r in rows:
     key=(r['Dispatch_Id'])
     if key not in seen: seen.add(key); calls[k]+=1
 names=sorted({r['Counter_Name'] for r in rows})
-with open(sys.argv[2],'w') as f:
-    f.write('kernel,calls,'+','.join(names)+'\n')
+with open(sys.argv[2],'w',newline='') as f:
+    w=csv.writer(f)  # kernel names contain commas (rp_k_extend<false, true>)
+    w.writerow(['kernel','calls']+names)
     for k in sorted(agg, key=lambda k:-calls[k]):
         if not k.startswith(('void rp_k','rp_k')): continue
-        f.write(k+','+str(calls[k])+','+','.join('%.6g'%(agg[k][n]) for n in names)+'\n')
+        w.writerow([k,calls[k]]+['%.6g'%(agg[k][n]) for n in names])
         print('%-42s calls %4d '%(k,calls[k])+' '.join('%s=%.4g'%(n,agg[k][n]) for n in names))
 PY
