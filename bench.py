@@ -53,6 +53,9 @@ def parse_args():
                     help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic (single GPU): render only rank 0's stripes of an N-rank tile split, no gather")
+    ap.add_argument("--dist-backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: test rig for the N>1 control flow on a box with fewer GPUs than ranks (tiles are staged through the host)")
+    ap.add_argument("--same-device", action="store_true", help="test rig: every rank renders on cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -78,7 +81,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
@@ -86,7 +89,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     nx, nz = (int(v) for v in args.grid.split("x"))
     t0 = time.time()
@@ -110,7 +116,9 @@ def main():
     r.set_scene(scene)
     t_build = time.time() - t0
     cam = scene.camera_params()
-    gather = TileGather(W, H, 32, rank, world, device="cuda")
+    on_host = world > 1 and args.dist_backend == "gloo"
+    gather = TileGather(W, H, 32, rank, world, device="cpu" if on_host else "cuda")
+    stage = torch.zeros_like(gather.tile, device="cuda") if on_host else None  # gloo rig: device tile -> host tile
     my_bytes = r.local_pixel_count() * 16
 
     anim = None
@@ -138,7 +146,9 @@ def main():
         st = r.wait(ticket)
         if world > 1:
             if my_bytes:
-                r.copy_tile_to_device(gather.tile.data_ptr(), my_bytes)
+                r.copy_tile_to_device((stage if on_host else gather.tile).data_ptr(), my_bytes)
+            if on_host:
+                gather.tile.copy_(stage)  # synchronising device-to-host copy on the current stream
             gather.gather()
         return st
 
@@ -207,10 +217,11 @@ def main():
     launches_extend = int(stc.launches_extend)
 
     if world > 1:
-        t = torch.tensor([elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"]], dtype=torch.float64, device="cuda")
+        rdev = "cpu" if on_host else "cuda"
+        t = torch.tensor([elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"]], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"] = (float(v) for v in t)
-        tr = torch.tensor([float(rays)], dtype=torch.float64, device="cuda")
+        tr = torch.tensor([float(rays)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         rays = int(tr[0])
     if rank != 0:

@@ -7,6 +7,8 @@ benchmark's full size. Tolerances:
   * ray / node / triangle counts: equal up to branch flips caused by those ulps
     (relative 1e-3), exactly equal when traversing identical rays.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -363,3 +365,25 @@ def test_more_tickets_than_contexts_is_an_error(small_scenes):
     with pytest.raises(backend.BackendError):
         r.wait(t2)
     r.close()
+
+
+# ---------------------------------------------------------------- bench.py's N > 1 control flow on one GPU
+def test_bench_two_ranks_on_one_gpu_with_gloo(tmp_path):
+    """torch.distributed.run with 2 ranks, both rendering their stripes on cuda:0, tiles gathered over gloo: the same loop
+    the driver runs with RCCL on N GPUs (frames in flight, wait, tile copy, gather, max-over-ranks timing, one JSON line)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--grid", "100x50", "--width", "320", "--height", "180",
+           "--dist-backend", "gloo", "--same-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["rays_per_step"] > 320 * 180 * 4   # both ranks' rays are summed
+    assert "cpu_baseline" not in d
