@@ -58,6 +58,11 @@ struct FrameCtx {
     RpCounters *counters = nullptr;
     RpCounters *host_counters = nullptr; // pinned
     int *gstack = nullptr;
+    // the shadow rays of bounce b and the closest-hit rays of bounce b+1 only depend on shade(b): connect runs on a side
+    // stream next to the following extend (two latency-bound launches overlap), shade(b+1) waits for both
+    hipStream_t side = nullptr;
+    int *gstack_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     float4 *out_accum = nullptr; // frames_in_flight > 1: the image after this frame's resolve
     uchar4 *out_fb = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dep = nullptr, ev_resolved = nullptr;
@@ -132,6 +137,7 @@ struct rptr_hip {
     int persistent_blocks = 0;
 
     // options (environment, read once)
+    int side_connect = 0; // opt-in (RPTR_SIDE_CONNECT=1): connect(b) on a side stream next to extend(b+1)
     int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
 
@@ -452,6 +458,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         }
         h->own_stream = true;
     }
+    if (const char *s = getenv("RPTR_SIDE_CONNECT")) h->side_connect = atoi(s) != 0 ? 1 : 0;
     {
         int fif = info ? info->frames_in_flight : 1;
         if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) fif = atoi(s);
@@ -475,6 +482,12 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
             (void)hipEventCreate(&c.ev_end);
             (void)hipEventCreateWithFlags(&c.ev_dep, hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&c.ev_resolved, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming);
+            if (h->side_connect && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) {
+                delete h;
+                return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
+            }
             if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess) {
                 delete h;
                 return fail(nullptr, RPTR_E_NOMEM, "hipHostMalloc failed");
@@ -514,7 +527,11 @@ void rptr_hip_destroy(rptr_hip_t *h) {
     free_list(h->scene_allocs);
     for (FrameCtx &c : h->ctx) {
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved})
+        if (c.side) {
+            (void)hipStreamSynchronize(c.side);
+            (void)hipStreamDestroy(c.side);
+        }
+        for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved, c.ev_fork, c.ev_side})
             if (e) (void)hipEventDestroy(e);
         if (c.host_counters) (void)hipHostFree(c.host_counters);
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
@@ -613,8 +630,10 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
     const size_t stack_threads = (size_t)h->persistent_blocks * RP_TRAVERSE_BLOCK;
-    for (FrameCtx &c : h->ctx)
+    for (FrameCtx &c : h->ctx) {
         if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+        if (c.side && (rc = dev_alloc(h, &c.gstack_side, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+    }
     h->frame_id = 0;
     h->frame_offset = 0;
     h->accumulated_spp = 0;
@@ -1121,16 +1140,18 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     const bool do_sort = h->use_sort > 0;
     size_t ev_cursor = 0;
     c.spans.clear();
-    auto timed = [&](int kind, auto &&launch) {
+    auto timed_on = [&](hipStream_t st, int kind, auto &&launch) {
         if (h->stage_timing >= 2 || (h->stage_timing == 1 && kind == 0)) {
             hipEvent_t a = next_event(c, ev_cursor), b = next_event(c, ev_cursor);
-            (void)hipEventRecord(a, c.stream);
+            (void)hipEventRecord(a, st);
             launch();
-            (void)hipEventRecord(b, c.stream);
+            (void)hipEventRecord(b, st);
             c.spans.push_back({a, b, kind});
         } else
             launch();
     };
+    auto timed = [&](int kind, auto &&launch) { timed_on(c.stream, kind, launch); };
+    const bool side = c.side != nullptr;
 
     if (multi) { // whatever the caller queued on the backend's stream (vertex updates, refit) comes first
         HIP_TRY(h, hipEventRecord(c.ev_dep, h->stream));
@@ -1175,22 +1196,33 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                     });
                     order = c.order;
                 }
+                if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) wrote illum, frees the shadow queue
                 timed(2, [&] {
                     if (variant == RPTR_VARIANT_SIMPLE)
                         launch_shade<RPTR_VARIANT_SIMPLE>(h, c, f, order, b, out);
                     else
                         launch_shade<RPTR_VARIANT_GLTF>(h, c, f, order, b, out);
                 });
-                timed(1, [&] {
-                    if (count_traversal)
-                        hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
-                                           bc, c.counters, c.gstack);
-                    else
-                        hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, c.ps, c.sq,
-                                           bc, c.counters, c.gstack);
-                });
+                {
+                    hipStream_t cs = side ? c.side : c.stream;
+                    int *stack = side ? c.gstack_side : c.gstack;
+                    if (side) { // fork: the side stream sees shade(b)
+                        HIP_TRY(h, hipEventRecord(c.ev_fork, c.stream));
+                        HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
+                    }
+                    timed_on(cs, 1, [&] {
+                        if (count_traversal)
+                            hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, h->dscene, c.ps, c.sq, bc,
+                                               c.counters, stack);
+                        else
+                            hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, h->dscene, c.ps, c.sq, bc,
+                                               c.counters, stack);
+                    });
+                    if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
+                }
                 c.launches_connect++;
             }
+            if (side) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // the last connect
             // resolves fold into one history buffer: they run in submission order across the contexts
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             timed(2, [&] {
