@@ -344,7 +344,9 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 #ifndef RP_SHADE_WAVES
 #define RP_SHADE_WAVES 4 // minimum waves per SIMD the shade kernels are compiled for (bounds their VGPR budget)
 #endif
-template <int VARIANT, bool FIRST>
+// LIGHTS = false: the scene has no emissive triangles, every NEE sample goes to the sun (sun_radiance.w == 1,
+// vulkan/render_sky.cpp:68-71) and the binned-RIS code is compiled out (fewer registers, smaller kernel)
+template <int VARIANT, bool FIRST, bool LIGHTS>
 __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                             V3 light_dir = v3s(0.0f);
                             float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
                             const float sun_w = f.sp.sun_radiance[3];
-                            if (sel_sample.x <= sun_w) {
+                            if (!LIGHTS || sel_sample.x <= sun_w) {
                                 sel_sample.x /= sun_w;
                                 light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
                                 light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);

@@ -989,10 +989,12 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint3
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
                            c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
     };
+    // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
+    const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
     if (bounce == 0)
-        go(rp_k_shade<VARIANT, true>);
+        lights ? go(rp_k_shade<VARIANT, true, true>) : go(rp_k_shade<VARIANT, true, false>);
     else
-        go(rp_k_shade<VARIANT, false>);
+        lights ? go(rp_k_shade<VARIANT, false, true>) : go(rp_k_shade<VARIANT, false, false>);
 }
 
 static void add_counters(RpCounters &dst, const RpCounters &c) {
