@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <array>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,6 +126,13 @@ struct rptr_hip {
     bool host_bvh_stale = false;
 
     // device buffers (frame sized)
+    // queue of the first bounce: the ids of the pixel samples that exist. It only depends on the frame size, the tiling and
+    // the number of sample slots of the batch, so it is built once per batch size (rp_k_raygen) and shared, read-only
+    struct FirstQueue {
+        uint32_t *ids = nullptr;
+        uint32_t count = 0;
+    };
+    std::map<int, FirstQueue> first_queue;
     std::vector<FrameCtx> ctx;      // frames in flight (RptrCreateInfo.frames_in_flight, at least 1)
     uint64_t next_ticket = 1;
     int next_ctx = 0;
@@ -568,6 +576,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (void *p : h->allocations) (void)hipFree(p);
     h->allocations.clear();
+    h->first_queue.clear();
     h->width = fb_width;
     h->height = fb_height;
     h->local_rows = local_row_count(fb_height, h->stripe_rows, h->rank, h->world);
@@ -1171,15 +1180,29 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
         f.batch_spp = batch;
         if (local_work) {
             HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
-            const size_t total = (size_t)batch * h->npix_padded;
-            timed(2, [&] { hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, c.queue[0], c.counters); });
+            auto fq = h->first_queue.find(batch);
+            if (fq == h->first_queue.end()) { // first frame with this batch size: build the list (synchronous, once)
+                rptr_hip::FirstQueue q;
+                const size_t total = (size_t)batch * h->npix_padded;
+                int rc2 = dev_alloc(h, &q.ids, total, nullptr);
+                if (rc2) return rc2;
+                RpCounters *tmp = nullptr;
+                if ((rc2 = dev_alloc(h, &tmp, 1, nullptr))) return rc2;
+                HIP_TRY(h, hipMemsetAsync(tmp, 0, sizeof(RpCounters), c.stream));
+                hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, q.ids, tmp);
+                HIP_TRY(h, hipMemcpyAsync(&q.count, &tmp->bounce[0].queue_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+                HIP_TRY(h, hipStreamSynchronize(c.stream));
+                fq = h->first_queue.emplace(batch, q).first;
+            }
+            const uint32_t *first_ids = fq->second.ids;
+            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)fq->second.count, 1, c.stream));
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 timed(0, [&] {
                     auto go = [&](auto kernel) {
-                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, f, c.ps, c.queue[in], bc,
-                                           c.counters, c.gstack);
+                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, f, c.ps,
+                                           b == 0 ? first_ids : c.queue[in], bc, c.counters, c.gstack);
                     };
                     if (b == 0)
                         count_traversal ? go(rp_k_extend<true, true>) : go(rp_k_extend<false, true>);
@@ -1187,13 +1210,14 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         count_traversal ? go(rp_k_extend<true, false>) : go(rp_k_extend<false, false>);
                 });
                 c.launches_extend++;
-                const uint32_t *order = c.queue[in];
+                const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
+                const uint32_t *order = in_queue;
                 if (do_sort) {
                     timed(2, [&] {
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.queue[in],
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, h->dscene, f, c.ps, in_queue,
                                            &bc->queue_count, c.keys, c.sort_hist);
                         hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, c.queue[in],
+                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, in_queue,
                                            &bc->queue_count, c.keys, c.sort_base, c.sort_cursor, c.order);
                     });
                     order = c.order;
