@@ -597,7 +597,8 @@ __global__ void rp_k_reset_u32(uint32_t *p) { *p = 0; }
 // ------------------------------------------------------------------ resolve
 // accumulate.glsl:68-73 (store this sample) + process_samples.comp:116-132 (running mean into the
 // history) + :143-190 (exposure, sRGB, RGBA8). One thread per local pixel, samples folded in order.
-__global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb) {
+// out_accum / out_fb (frames in flight, else NULL): a second copy of what this frame leaves in accum / fb
+__global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb, float4 *out_accum, uchar4 *out_fb) {
     const int npix = f.width * f.local_rows;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         const int ly = i / f.width, lx = i - ly * f.width;
@@ -619,14 +620,18 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
             }
         }
         accum[i] = acc;
+        if (out_accum) out_accum[i] = acc;
         float4 o = acc;
         o.w = fminf(o.w, 1.0f);
         if (o.w >= 0.0f) {
             const float e = exp2f(f.rp.exposure);
             const float r = rp_linear_to_srgb(o.x * e), g = rp_linear_to_srgb(o.y * e), b = rp_linear_to_srgb(o.z * e);
-            fb[i] = make_uchar4((unsigned char)(clamp1(r, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(g, 0.f, 1.f) * 255.0f + 0.5f),
-                                (unsigned char)(clamp1(b, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
-        }
+            const uchar4 px = make_uchar4((unsigned char)(clamp1(r, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(g, 0.f, 1.f) * 255.0f + 0.5f),
+                                          (unsigned char)(clamp1(b, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
+            fb[i] = px;
+            if (out_fb) out_fb[i] = px;
+        } else if (out_fb)
+            out_fb[i] = fb[i];
     }
 }
 

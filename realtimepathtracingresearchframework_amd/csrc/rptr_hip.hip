@@ -1253,12 +1253,9 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             timed(2, [&] {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, c.stream, f, c.ps, h->accum, h->fb);
+                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, c.stream, f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
             });
-            if (multi) { // keep the image this frame produced: the next frame's resolve overwrites the shared buffers
-                const size_t npix = (size_t)h->width * h->local_rows;
-                HIP_TRY(h, hipMemcpyAsync(c.out_accum, h->accum, npix * sizeof(float4), hipMemcpyDeviceToDevice, c.stream));
-                HIP_TRY(h, hipMemcpyAsync(c.out_fb, h->fb, npix * sizeof(uchar4), hipMemcpyDeviceToDevice, c.stream));
+            if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
                 h->last_resolved = c.ev_resolved;
             }
