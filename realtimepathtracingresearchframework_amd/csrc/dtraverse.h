@@ -116,6 +116,12 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_NODE_MIN_ANY
 #define RP_NODE_MIN_ANY RP_NODE_MIN
 #endif
+#ifndef RP_NODE_MIN_FIRST // ... and for the camera rays of the first bounce
+#define RP_NODE_MIN_FIRST RP_NODE_MIN
+#endif
+#ifndef RP_REFILL_MIN_FIRST
+#define RP_REFILL_MIN_FIRST RP_REFILL_MIN
+#endif
 #ifndef RP_FETCH_DIV
 #define RP_FETCH_DIV 1u // a wave is dealt about 1/RP_FETCH_DIV of its fair share at a time
 #endif
@@ -135,7 +141,8 @@ RP_DEV V3 rp_cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(b.y * a.z)), fma
 #ifdef RP_PROF
 __device__ unsigned long long rp_prof[16];
 #endif
-template <bool ANY, bool COUNT, class Load, class Done>
+template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN), class Load,
+          class Done>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, uint32_t &n_nodes,
                           uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
@@ -201,7 +208,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         const bool idle = cur == RP_EXIT;
         const unsigned long long idle_mask = __ballot(idle);
         const uint32_t nidle = (uint32_t)__popcll(idle_mask);
-        if (nidle >= (uint32_t)(ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN)) {
+        if (nidle >= (uint32_t)REFILL_MIN) {
             if (pool_next >= pool_end && more) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, fetch); // the cursor counts entries handed out behind the static pools
@@ -247,7 +254,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const unsigned long long want_node = __ballot(cur >= 0);
             if (want_node == 0ull) break;
 #if RP_NODE_MIN > 1
-            if ((uint32_t)__popcll(want_node) < (uint32_t)(ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN) &&
+            if ((uint32_t)__popcll(want_node) < (uint32_t)NODE_MIN &&
                 (uint32_t)__popcll(__ballot(cur < 0 && cur != RP_EXIT)) >= (uint32_t)RP_LEAF_MIN)
                 break;
 #endif

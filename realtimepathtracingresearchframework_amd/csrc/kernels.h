@@ -159,7 +159,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
         ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
     };
-    rp_wave_trace<false, COUNT>(sc, bc->queue_count, &bc->cursor_extend, gstack, load, done, n_nodes, n_tris);
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN)>(sc, bc->queue_count, &bc->cursor_extend, gstack, load,
+                                                                                                                        done, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
