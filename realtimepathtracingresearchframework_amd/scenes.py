@@ -621,3 +621,46 @@ def forest(n_meshes=10, tris_per_tree=10000, n_instances=1000, name="forest-10M"
     s.sky_key = "forest"
     s.prepare_lights()
     return s
+
+
+# ------------------------------------------------------------------ fuzz scenes (tests)
+def soup(seed, n_meshes=3, tris_per_mesh=200, n_instances=9, degenerate=True) -> Scene:
+    """Random triangle soups with the awkward cases a builder / intersector has to survive: slivers, zero-area and
+    duplicated triangles, coincident vertices, wildly different triangle sizes, axis-aligned flat meshes, instance
+    transforms with non-uniform scale, shear and mirroring. Materials are plain diffuse; no emitters."""
+    rng = np.random.default_rng(seed)
+    s = Scene(name="soup-%d" % seed)
+    s.materials = [abi.make_material((0.7, 0.7, 0.7), roughness=0.8), abi.make_material((0.3, 0.6, 0.8), roughness=0.3, metallic=1.0)]
+    for m in range(n_meshes):
+        n = tris_per_mesh
+        c = rng.uniform(-1, 1, (n, 1, 3))
+        size = np.exp(rng.uniform(np.log(1e-3), np.log(0.8), (n, 1, 1)))
+        T = (c + rng.normal(size=(n, 3, 3)) * size).astype(f32)
+        if degenerate:
+            T[0, 1] = T[0, 0]                        # two coincident vertices
+            T[1] = T[1, 0]                           # a point
+            T[2, 2] = (T[2, 0] + T[2, 1]) / 2        # collinear (zero area up to rounding)
+            T[3] = T[4]                              # duplicate triangle
+            T[5:15, :, m % 3] = T[5, 0, m % 3]       # a patch of axis-aligned (flat) triangles
+        if m == n_meshes - 1:
+            T[:, :, 1] = 0.25                        # one mesh entirely flat: zero extent on an axis
+        mesh = _add_mesh(s, T)
+        ids = rng.integers(0, 2, n).astype(np.uint8)
+        s.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=ids))
+    for i in range(n_instances):
+        A = rng.normal(size=(3, 3))
+        q, _ = np.linalg.qr(A)
+        scale = np.diag(np.exp(rng.uniform(np.log(0.3), np.log(2.5), 3)))          # non-uniform
+        shear = np.eye(3)
+        shear[0, 1] = rng.uniform(-0.5, 0.5)
+        M3 = q @ scale @ shear
+        if i % 3 == 2:
+            M3[:, 0] = -M3[:, 0]                                                    # mirrored (negative determinant)
+        t = rng.uniform(-3, 3, 3)
+        M = np.concatenate([M3, t[:, None]], axis=1).astype(f32)
+        s.instances.append(Instance(transform=M, pmesh=int(i % n_meshes)))
+    s.camera = dict(eye=(0, 1, 9), center=(0, 0, 0), up=(0, 1, 0), fov=55.0)
+    s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s

@@ -105,3 +105,19 @@ def test_host_build_rejects_bad_indices():
     s.instances[0].pmesh = 99
     with pytest.raises(backend.BackendError):
         backend.build_bvh_host(s)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_fuzz_soups_host_tree_equals_brute_force(seed):
+    """slivers, zero-area and duplicate triangles, flat meshes, sheared / mirrored / non-uniformly scaled instances"""
+    s = scenes.soup(seed)
+    nodes, tris, insts, need = backend.build_bvh_host(s)
+    osc = O.OracleScene(s)
+    osc.import_bvh(nodes, tris, insts)
+    o, d = _rays(5000, 100 + seed, -5, 5)
+    tuv_b, ids_b = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_BRUTE)
+    tuv_t, ids_t = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+    assert np.array_equal(tuv_b.view(np.uint32), tuv_t.view(np.uint32)) and np.array_equal(ids_b, ids_t)
+    tuv_o, ids_o = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_OWN)   # the oracle's own 2-wide float tree agrees too
+    assert np.array_equal(tuv_b.view(np.uint32), tuv_o.view(np.uint32)) and np.array_equal(ids_b, ids_o)
+    assert (ids_b[:, 0] >= 0).sum() > 200

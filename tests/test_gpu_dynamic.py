@@ -190,3 +190,33 @@ def test_device_source_update_equals_host_source_update(dyn_grid):
         r.close()
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
     assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(out[0][1], out[1][1]))
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_refit_of_soups(seed):
+    """every mesh dynamic; vertices jump far, some triangles collapse to points, one mesh becomes flat: refit (topology of the
+    ORIGINAL build) must still give brute-force answers, with sheared / mirrored instances on top"""
+    s = scenes.soup(seed)
+    for m in s.meshes:
+        m.dynamic = True
+    r = backend.RenderHip()
+    r.initialize(64, 64)
+    r.set_scene(s)
+    osc = O.OracleScene(s)
+    rng = np.random.default_rng(seed)
+    for gi, g in enumerate(s.geometries):
+        P = scenes.dequantize_positions(g.qpos, g.scaling, g.offset)
+        P = (P + rng.normal(size=P.shape) * 0.3).astype(np.float32)      # far from where the tree was built
+        P[0:3] = P[0]                                                      # a triangle collapsed to a point
+        if gi == 0:
+            P[:, 2] = 0.5                                                  # the whole geometry flattened
+        r.update_vertices(gi, P)
+        osc.set_dynamic_vertices(gi, P)
+    r.refit()
+    q = random_queries(np.random.default_rng(seed + 1), 20000, -6, 6)
+    res = r.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
+    r.close()

@@ -387,3 +387,26 @@ def test_bench_two_ranks_on_one_gpu_with_gloo(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["rays_per_step"] > 320 * 180 * 4   # both ranks' rays are summed
     assert "cpu_baseline" not in d
+
+
+# ---------------------------------------------------------------- fuzz
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_soups_trace_and_image(seed):
+    """degenerate triangles, flat meshes, sheared / mirrored instances: ray queries bit-exact vs brute force, every ray of a
+    frame walks the exported tree like the oracle, image within tolerance"""
+    s = scenes.soup(seed)
+    r = backend.RenderHip()
+    r.initialize(96, 64)
+    r.set_scene(s)
+    q = random_queries(np.random.default_rng(seed), 20000, -5, 5)
+    res = r.render_ray_queries(q)
+    osc = O.OracleScene(s)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    assert_ray_visit_parity(r, osc, 96, 64, 1, abi.VARIANT_GLTF)
+    img, _, _ = gpu_render(s, 96, 64, 2, abi.VARIANT_GLTF, renderer=r)
+    ref_img, _ = osc.render(96, 64, 2, variant=abi.VARIANT_GLTF)
+    rmse, same, _ = image_error(img, ref_img)
+    assert same and rmse < RMSE_TOL
+    r.close()
