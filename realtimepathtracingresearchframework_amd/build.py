@@ -46,13 +46,13 @@ def build_library(force=False, verbose=False, extra_flags=()):
     return LIB_PATH
 
 
-HOST_TOOLS = {"rptr_validate": "rptr_validate.cpp", "demo_host": "demo_host.cpp"}
+HOST_TOOLS = {"rptr_hip": "rptr_cli.cpp", "demo_host": "demo_host.cpp"}
 BIN_DIR = os.path.join(HERE, "bin")
 
 
 def build_host_tools(verbose=False):
-    """The C++ host programs over the C ABI (g++, no HIP headers): bin/rptr_validate (headless --validation run that
-    writes .pfm), bin/demo_host."""
+    """The C++ host programs over the C ABI (g++, no HIP headers): bin/rptr_hip (the reference's headless --validation / --profiling runs:
+    .pfm images, profiling CSV), bin/demo_host."""
     os.makedirs(BIN_DIR, exist_ok=True)
     out = []
     for name, src in HOST_TOOLS.items():

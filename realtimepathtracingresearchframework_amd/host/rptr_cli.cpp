@@ -1,0 +1,217 @@
+// rptr_cli.cpp -- the reference's headless run modes through the C ABI (binary: bin/rptr_hip):
+//
+//   rptr_hip <scene.rpsc> --validation <prefix> [--validation-spp n] [--img w h] [--pfm]
+//   rptr_hip <scene.rpsc> --profiling <csv prefix> [--profiling-fps f] [--profiling-img <prefix>] [--profiling-frames n]
+//            [--animate-wave amplitude kx]
+//   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame]
+//
+// Flag names, file names and the CSV header are the reference's (cmdline.cpp:10-104,296-474; libapp/app_state.cpp:218-255,
+// 291-322,464-498; libapp/benchmark_info.cpp:69-124; util/write_image.cpp:34-64):
+//  * validation mode renders at time 0, one frame = params.batch_spp samples, accumulates until --validation-spp and writes
+//    the float accumulation buffer as <prefix>_%04d.pfm (accumulated spp in the name); n < 1 = after every frame;
+//  * profiling mode advances time by 1/fps per frame (non-realtime), appends one CSV row per frame to <prefix>.csv with the
+//    header frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms, and writes <img prefix>_%04d.pfm once per
+//    second of animation time. The reference ends at its last keyframe; here a keyframe is one second and
+//    --profiling-frames (default 60) ends the run.
+//  * --animate-wave a k (profiling mode, scenes whose mesh 0 is dynamic): y = y0 + a sin(k x + 2 pi t) on geometry 0 before
+//    every frame, followed by rptr_hip_refit -- SURVEY 8d C5 (the reference animates with a compute shader,
+//    render_vulkan.cpp:2834-2840; per-frame BLAS update + TLAS refit :1323-1354).
+// The scene comes from a dump file (scene_dump.hpp) instead of a .vks.
+#include "render_hip.hpp"
+#include "scene_dump.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static bool write_pfm(const std::string &prefix, unsigned width, unsigned height, unsigned channels, const float *pixels) {
+    if (width == 0 || height == 0 || channels < 3 || !pixels) return false;
+    const std::string path = prefix + ".pfm";
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "PF\n%i %i\n-1.0\n", width, height);
+    std::vector<float> rgb((size_t)width * height * 3);
+    for (unsigned y = 0; y < height; ++y) // the file stores the bottom row first
+        for (unsigned x = 0; x < width; ++x)
+            for (unsigned j = 0; j < 3; ++j) rgb[((size_t)width * (height - y - 1) + x) * 3 + j] = pixels[((size_t)width * y + x) * channels + j];
+    const bool ok = std::fwrite(rgb.data(), sizeof(float), rgb.size(), f) == rgb.size();
+    std::fclose(f);
+    return ok;
+}
+
+static void save_pfm(rptr::RenderHip &backend, const std::string &prefix, int number, int width, int height, std::vector<float> &img) {
+    if (backend.readback_framebuffer(img.size(), img.data()) != img.size()) throw std::runtime_error("read-back failed");
+    char name[32];
+    std::snprintf(name, sizeof(name), "_%04d", number);
+    if (!write_pfm(prefix + name, (unsigned)width, (unsigned)height, 4, img.data())) throw std::runtime_error("cannot write " + prefix + name + ".pfm");
+}
+
+int main(int argc, char **argv) {
+    std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix;
+    int target_spp = 1, width = 256, height = 256, variant = RPTR_VARIANT_GLTF, batch_spp = 1, profiling_frames = 60;
+    float profiling_fps = 60.f, wave_amp = 0.f, wave_k = 0.f;
+    float eye[3], center[3], up[3] = {0, 1, 0}, fov = 0.f;
+    bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto need = [&](int k) {
+            if (i + k >= argc) {
+                std::fprintf(stderr, "%s needs %d argument(s)\n", a.c_str(), k);
+                std::exit(2);
+            }
+        };
+        auto vec3 = [&](float *v) {
+            need(3);
+            for (int k = 0; k < 3; ++k) v[k] = (float)std::atof(argv[++i]);
+        };
+        if (a == "--validation") { need(1); validation_prefix = argv[++i]; validation = true; }
+        else if (a == "--validation-spp") { need(1); target_spp = std::atoi(argv[++i]); }
+        else if (a == "--profiling") { need(1); csv_prefix = argv[++i]; profiling = true; }
+        else if (a == "--profiling-fps") { need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; }
+        else if (a == "--profiling-img") { need(1); profiling_img_prefix = argv[++i]; }
+        else if (a == "--profiling-frames") { need(1); profiling_frames = std::atoi(argv[++i]); }
+        else if (a == "--animate-wave") { need(2); wave_amp = (float)std::atof(argv[++i]); wave_k = (float)std::atof(argv[++i]); }
+        else if (a == "--img") { need(2); width = std::atoi(argv[++i]); height = std::atoi(argv[++i]); }
+        else if (a == "--eye") { vec3(eye); got_eye = true; }
+        else if (a == "--center") { vec3(center); got_center = true; }
+        else if (a == "--up") { vec3(up); got_up = true; }
+        else if (a == "--fov") { need(1); fov = (float)std::atof(argv[++i]); }
+        else if (a == "--batch-spp") { need(1); batch_spp = std::atoi(argv[++i]); }
+        else if (a == "--variant") { need(1); variant = std::strcmp(argv[++i], "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : RPTR_VARIANT_GLTF; }
+        else if (a == "--every-frame") every_frame = true;
+        else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
+        else if (a == "--pfm") {} // the only image format of this tool
+        else if (a[0] != '-') scene_path = a;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (describe && !scene_path.empty()) {
+        try {
+            const rptr::SceneDump s = rptr::SceneDump::load(scene_path);
+            unsigned long long tris = 0, qsum = 0;
+            for (size_t i = 0; i < s.geometries.size(); ++i) {
+                tris += s.geometries[i].num_tris;
+                for (uint64_t q : s.qpos[i]) qsum += q & 0xFFFFFFull;
+            }
+            std::printf("geometries %zu meshes %zu parameterized_meshes %zu instances %zu materials %zu lights %zu triangles %llu qsum %llu fovy %.6f "
+                        "max_path_depth %d bin_size %d sun_w %.6f\n",
+                        s.geometries.size(), s.meshes.size(), s.pmeshes.size(), s.instances.size(), s.materials.size(), s.lights.size(), tris, qsum,
+                        s.camera.fovy, s.render_params.max_path_depth, s.lighting.bin_size, s.scene_params.sun_radiance[3]);
+            return 0;
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "rptr_hip: %s\n", e.what());
+            return 3;
+        }
+    }
+    if (validation && target_spp < 1) { // "< 1: write after every frame" -- needs an end here: one frame
+        every_frame = true;
+        target_spp = 1;
+    }
+    if (scene_path.empty() || validation == profiling || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
+        std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
+                             "[--profiling-img <prefix>] [--profiling-frames n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
+                             "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--pfm]\n"
+                             "validation mode and profiling mode are mutually exclusive (cmdline.cpp:479-486)\n");
+        return 2;
+    }
+    try {
+        rptr::SceneDump scene = rptr::SceneDump::load(scene_path);
+        rptr::RenderHip backend;
+        backend.initialize(width, height);
+        backend.set_scene(scene.desc());
+        backend.params = scene.render_params;
+        backend.params.batch_spp = batch_spp;
+        backend.lighting_params = scene.lighting;
+        backend.update_config(scene.scene_params);
+        rptr::RenderConfiguration cfg{};
+        std::memcpy(cfg.camera.pos, scene.camera.pos, 12);
+        std::memcpy(cfg.camera.dir, scene.camera.dir, 12);
+        std::memcpy(cfg.camera.up, scene.camera.up, 12);
+        cfg.camera.fovy = scene.camera.fovy;
+        if (got_eye) std::memcpy(cfg.camera.pos, eye, 12);
+        if (got_center || got_eye) { // OrientedCamera: the view direction is center - eye, normalised
+            float c[3] = {0, 0, 0};
+            if (got_center) std::memcpy(c, center, 12);
+            else for (int k = 0; k < 3; ++k) c[k] = scene.camera.pos[k] + scene.camera.dir[k];
+            float d[3], len = 0;
+            for (int k = 0; k < 3; ++k) { d[k] = c[k] - cfg.camera.pos[k]; len += d[k] * d[k]; }
+            len = std::sqrt(len);
+            if (len > 0) for (int k = 0; k < 3; ++k) cfg.camera.dir[k] = d[k] / len;
+        }
+        if (got_up) std::memcpy(cfg.camera.up, up, 12);
+        if (fov > 0) cfg.camera.fovy = fov;
+        cfg.active_variant = variant;
+        cfg.reset_accumulation = true; // frame 0 of the accumulation (app.cpp: reset on scene load)
+        std::vector<float> img((size_t)width * height * 4);
+
+        if (validation) {
+            int accumulated = 0;
+            double gpu_ms = 0.0;
+            while (accumulated < target_spp) {
+                const rptr::RenderStats st = backend.render(cfg); // params.batch_spp samples
+                cfg.reset_accumulation = false;
+                accumulated = st.spp;
+                gpu_ms += st.render_time;
+                if (accumulated >= target_spp || every_frame) save_pfm(backend, validation_prefix, accumulated, width, height, img);
+            }
+            std::printf("%s: %d spp in %.3f ms GPU time -> %s_%04d.pfm\n", backend.name().c_str(), accumulated, gpu_ms, validation_prefix.c_str(), accumulated);
+            return 0;
+        }
+
+        // ---- profiling mode
+        std::vector<float> base, cur; // --animate-wave: float positions of geometry 0 at rest
+        if (wave_amp != 0.f) {
+            if (scene.meshes.empty() || !scene.meshes[0].dynamic) throw std::runtime_error("--animate-wave needs a scene whose mesh 0 is dynamic");
+            const RptrGeometryDesc &g = scene.geometries[scene.meshes[0].first_geometry];
+            base.resize((size_t)g.num_tris * 9);
+            for (size_t v = 0; v < (size_t)g.num_tris * 3; ++v) { // librender/dequantize.glsl:8-21
+                const uint64_t w = g.qpos[v];
+                base[3 * v + 0] = float(uint32_t(w) & 0x1FFFFFu) * g.quantized_scaling[0] + g.quantized_offset[0];
+                base[3 * v + 1] = float(uint32_t(w >> 21) & 0x1FFFFFu) * g.quantized_scaling[1] + g.quantized_offset[1];
+                base[3 * v + 2] = float(uint32_t(w >> 42) & 0x1FFFFFu) * g.quantized_scaling[2] + g.quantized_offset[2];
+            }
+            cur = base;
+        }
+        const std::string csv_path = csv_prefix + ".csv";
+        FILE *csv = std::fopen(csv_path.c_str(), "w");
+        if (!csv) throw std::runtime_error("cannot open " + csv_path);
+        std::fprintf(csv, "frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms\n");
+        const float dt = 1.f / profiling_fps;
+        double current_time = 0.0, gpu_ms = 0.0;
+        int frames_accumulated = 0;
+        auto last = std::chrono::steady_clock::now();
+        for (int frame = 0; frame < profiling_frames; ++frame) {
+            if (!base.empty()) { // the geometry moves: new vertices, refit, and the accumulation starts over
+                const float phase = 6.283185307179586f * (float)current_time;
+                for (size_t v = 0; v < base.size() / 3; ++v) cur[3 * v + 1] = base[3 * v + 1] + wave_amp * std::sin(wave_k * base[3 * v] + phase);
+                backend.update_vertices(scene.meshes[0].first_geometry, cur.data(), (uint32_t)(cur.size() / 3));
+                backend.refit();
+                cfg.reset_accumulation = true;
+            }
+            if (cfg.reset_accumulation) frames_accumulated = 0;
+            const rptr::RenderStats st = backend.render(cfg);
+            cfg.reset_accumulation = false;
+            ++frames_accumulated;
+            gpu_ms += st.render_time;
+            const auto now = std::chrono::steady_clock::now();
+            const double app_ms = std::chrono::duration<double, std::milli>(now - last).count();
+            last = now;
+            const int keyframe = (int)std::floor(current_time) + 1;
+            std::fprintf(csv, "%d,%d,%d,%g,%g\n", frame + 1, keyframe, frames_accumulated, st.render_time, app_ms);
+            // once per second of animation time, at the end of the keyframe (libapp/app_state.cpp:484-493)
+            if (!profiling_img_prefix.empty() && (current_time + dt) >= std::ceil(current_time))
+                save_pfm(backend, profiling_img_prefix, keyframe, width, height, img);
+            current_time += dt;
+        }
+        std::fclose(csv);
+        std::printf("%s: %d frames at %.3g fps animation time, %.3f ms GPU time per frame -> %s\n", backend.name().c_str(), profiling_frames, profiling_fps,
+                    gpu_ms / profiling_frames, csv_path.c_str());
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "rptr_hip: %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}
