@@ -105,7 +105,12 @@ def main():
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
 
-    stream = torch.cuda.current_stream().cuda_stream  # the kernels run on torch's current stream
+    # one explicit stream for torch AND the backend: the tile copy, the gather and the animation kernel are ordered with the
+    # frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream":
+    # the tile copy would then run unordered with the gather.)
+    torch_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(torch_stream)
+    stream = torch_stream.cuda_stream
     fif = 1 if args.animate else max(1, args.frames_in_flight)  # a refit per frame needs the previous frame finished
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=32, stream=stream, frames_in_flight=fif)
