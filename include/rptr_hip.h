@@ -213,6 +213,8 @@ typedef struct RptrSceneDesc {
 /* device selection + multi-GPU tile assignment.  The frame is cut
  * into horizontal stripes of `stripe_rows` rows; stripe s belongs to rank
  * s % world_size.  A rank only allocates and renders its own rows. */
+/* Threading: a handle is not thread-safe; calls on ONE handle must come from one thread at a time (different handles are
+ * independent). Everything is asynchronous to the host only where said so (rptr_hip_render_async, *_device copies). */
 typedef struct RptrCreateInfo {
     int32_t device_ordinal; /* hipSetDevice                                      */
     int32_t rank;
