@@ -111,7 +111,7 @@ def main():
     torch_stream = torch.cuda.Stream()
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
-    fif = 1 if args.animate else max(1, args.frames_in_flight)  # a refit per frame needs the previous frame finished
+    fif = max(1, args.frames_in_flight)  # (with a dynamic scene every frame context refits its own copy of the tree)
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=32, stream=stream, frames_in_flight=fif)
     else:

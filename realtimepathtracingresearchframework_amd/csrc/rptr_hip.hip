@@ -39,6 +39,21 @@ struct MeshRt { // one bottom-level structure
     bool dynamic = false;
 };
 
+// The part of the device scene a refit rewrites. The master set belongs to the handle (vertex updates, refit, ray
+// queries and export work on it). When the scene has dynamic meshes AND several frames are in flight, every frame
+// context owns another set, brought up to date (vertex copy + refit) when a frame is submitted on it: a frame that is
+// still rendering never sees its tree or vertices change.
+struct SceneCopy {
+    RpScene dscene;                        // what the kernels get (static arrays are shared between all copies)
+    RptrBvh4Node *nodes = nullptr;
+    RptrBvhTri *tris = nullptr;
+    float *node_box = nullptr, *tri_box = nullptr, *inst_box = nullptr;
+    std::vector<float *> dynpos;            // per global geometry: float positions (9 per triangle) or NULL
+    std::vector<const float **> mesh_dyn;   // per mesh: device table of its geometries' dynpos pointers
+    std::vector<char> mesh_dirty;           // 0 clean, 1 new vertices, 2 dynamic but triangle bounds never written
+    uint64_t version = 0;                   // rptr_hip.refit_version this copy reflects
+};
+
 struct Span {
     hipEvent_t a, b;
     int kind; // 0 extend, 1 connect, 2 other
@@ -102,27 +117,23 @@ struct rptr_hip {
 
     // scene
     bool have_scene = false;
-    RpScene dscene;
     std::vector<RptrBvh4Node> h_nodes;
     std::vector<std::array<float, 6>> h_node_box; // exact float bounds of every node
     int num_tlas_nodes = 0;
-    float *d_node_box = nullptr;
     std::vector<RptrBvhTri> h_tris;
     std::vector<RptrBvhInstance> h_insts;
     std::vector<MeshRt> meshes;
     std::vector<void *> scene_allocs;
     int num_lights = 0, num_materials = 0;
     // dynamic meshes (Mesh::Dynamic: float vertex buffer + BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354)
-    std::vector<float *> d_dynpos;          // per global geometry: device float positions (9 per triangle) or NULL
+    SceneCopy master;                       // dscene + the refit targets of the handle
+    std::vector<SceneCopy> ctx_scene;       // one per frame context when the scene is dynamic and frames_in_flight > 1
+    uint64_t refit_version = 0;             // bumped by every rptr_hip_refit that changed something
     std::vector<uint32_t> geom_tris;        // per global geometry: triangle count
     std::vector<int> geom_mesh;             // per global geometry: owning mesh
-    std::vector<char> mesh_dirty;
-    std::vector<const float **> d_mesh_dyn; // per mesh: device table of its geometries' dyn_pos pointers
     std::vector<int> mesh_root;             // per mesh: absolute node index of the BLAS root
     uint32_t *d_refit_list = nullptr;       // node indices, bit 31 = TLAS node
     std::vector<std::array<uint32_t, 2>> refit_levels_blas, refit_levels_tlas; // [begin, end) per height
-    float *d_inst_box = nullptr;
-    float *d_tri_box = nullptr;             // bounds of every BLAS triangle of the dynamic meshes (indexed like tris)
     bool host_bvh_stale = false;
 
     // device buffers (frame sized)
@@ -434,7 +445,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     rptr_hip *h = new rptr_hip();
     memset(&h->stats, 0, sizeof(h->stats));
-    memset(&h->dscene, 0, sizeof(h->dscene));
+    memset(&h->master.dscene, 0, sizeof(h->master.dscene));
     h->device = info ? info->device_ordinal : 0;
     h->rank = info ? info->rank : 0;
     h->world = info && info->world_size > 0 ? info->world_size : 1;
@@ -717,11 +728,11 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         }
     }
     // ---- dynamic meshes keep full-precision float positions next to the quantised stream
-    h->d_dynpos.assign(s->num_geometries, nullptr);
+    h->master.dynpos.assign(s->num_geometries, nullptr);
     h->geom_tris.assign(s->num_geometries, 0);
     h->geom_mesh.assign(s->num_geometries, -1);
-    h->mesh_dirty.assign(s->num_meshes, 0);
-    h->d_mesh_dyn.assign(s->num_meshes, nullptr);
+    h->master.mesh_dirty.assign(s->num_meshes, 0);
+    h->master.mesh_dyn.assign(s->num_meshes, nullptr);
     for (uint32_t m = 0; m < s->num_meshes; ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
         std::vector<const float *> table(mesh.num_geometries, nullptr);
@@ -736,15 +747,15 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             float *dp = nullptr;
             if ((rc = dev_alloc(h, &dp, pos.size(), &h->scene_allocs))) return rc;
             if (!pos.empty()) HIP_TRY(h, hipMemcpy(dp, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice));
-            h->d_dynpos[gi] = dp;
+            h->master.dynpos[gi] = dp;
             table[j] = dp;
         }
         if (mesh.dynamic) {
             const float **dt = nullptr;
             if ((rc = dev_alloc(h, &dt, table.size(), &h->scene_allocs))) return rc;
             if (!table.empty()) HIP_TRY(h, hipMemcpy(dt, table.data(), table.size() * sizeof(float *), hipMemcpyHostToDevice));
-            h->d_mesh_dyn[m] = dt;
-            h->mesh_dirty[m] = 2;
+            h->master.mesh_dyn[m] = dt;
+            h->master.mesh_dirty[m] = 2;
         }
     }
     // ---- geometry records per (parameterized mesh, geometry): instanced_geometry[] (render_vulkan.cpp:2748-2850)
@@ -770,12 +781,12 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             r.qpos = d_qpos[gi];
             r.qnrm_uv = d_qnu[gi];
             r.mat_ids = d_ids ? d_ids + prim_offset : nullptr;
-            r.dyn_pos = h->d_dynpos[gi];
+            r.dyn_pos = h->master.dynpos[gi];
             memcpy(r.scaling, gd.quantized_scaling, 12);
             memcpy(r.offset, gd.quantized_offset, 12);
             r.material_id = d_ids ? -1 - pm.material_offsets[j] : pm.material_offsets[j];
             r.flags = (gd.has_normals && d_qnu[gi] ? RP_GEOM_HAS_NORMALS : 0u) | (gd.has_uvs && d_qnu[gi] ? RP_GEOM_HAS_UVS : 0u) |
-                      (h->d_dynpos[gi] ? RP_GEOM_DYNAMIC : 0u);
+                      (h->master.dynpos[gi] ? RP_GEOM_DYNAMIC : 0u);
             // material index range check
             const int max_local = d_ids ? 255 : 0;
             if (pm.material_offsets[j] < 0 || (uint32_t)(pm.material_offsets[j]) >= s->num_materials)
@@ -860,13 +871,13 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     const size_t light_cap = (size_t)s->num_lights + RPTR_BINNED_LIGHTS_BIN_MAX_SIZE + 1;
     if ((rc = dev_alloc(h, &d_lights, light_cap, &h->scene_allocs))) return rc;
     if ((rc = dev_alloc(h, &h->d_refit_list, refit_list.size(), &h->scene_allocs))) return rc;
-    if ((rc = dev_alloc(h, &h->d_inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
-    h->d_tri_box = nullptr;
-    if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->d_tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
+    if ((rc = dev_alloc(h, &h->master.inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
+    h->master.tri_box = nullptr;
+    if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->master.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
     if (!refit_list.empty()) HIP_TRY(h, hipMemcpy(h->d_refit_list, refit_list.data(), refit_list.size() * 4, hipMemcpyHostToDevice));
     h->host_bvh_stale = false;
-    if ((rc = dev_alloc(h, &h->d_node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
-    HIP_TRY(h, hipMemcpy(h->d_node_box, h->h_node_box.data(), h->h_node_box.size() * 24, hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(h, &h->master.node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
+    HIP_TRY(h, hipMemcpy(h->master.node_box, h->h_node_box.data(), h->h_node_box.size() * 24, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyHostToDevice));
     if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(d_tris, h->h_tris.data(), h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyHostToDevice));
     if (!h->h_insts.empty())
@@ -875,17 +886,73 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     if (s->num_materials) HIP_TRY(h, hipMemcpy(d_mats, s->materials, s->num_materials * sizeof(RptrBaseMaterial), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemset(d_lights, 0, light_cap * sizeof(RptrTriLightData)));
     if (s->num_lights) HIP_TRY(h, hipMemcpy(d_lights, s->lights, s->num_lights * sizeof(RptrTriLightData), hipMemcpyHostToDevice));
-    h->dscene.nodes = d_nodes;
-    h->dscene.tris = d_tris;
-    h->dscene.insts = d_insts;
-    h->dscene.geoms = d_geoms;
-    h->dscene.materials = d_mats;
-    h->dscene.lights = d_lights;
-    h->dscene.num_lights = (int)s->num_lights;
-    h->dscene.num_materials = (int)s->num_materials;
-    h->dscene.num_nodes = (uint32_t)h->h_nodes.size();
+    h->master.nodes = d_nodes;
+    h->master.tris = d_tris;
+    h->master.version = h->refit_version;
+    h->master.dscene.nodes = d_nodes;
+    h->master.dscene.tris = d_tris;
+    h->master.dscene.insts = d_insts;
+    h->master.dscene.geoms = d_geoms;
+    h->master.dscene.materials = d_mats;
+    h->master.dscene.lights = d_lights;
+    h->master.dscene.num_lights = (int)s->num_lights;
+    h->master.dscene.num_materials = (int)s->num_materials;
+    h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
+    // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites
+    h->ctx_scene.clear();
+    if (!h->refit_levels_blas.empty() && h->ctx.size() > 1) {
+        h->ctx_scene.resize(h->ctx.size());
+        for (SceneCopy &sc : h->ctx_scene) {
+            sc.dscene = h->master.dscene;
+            sc.mesh_dirty.assign(s->num_meshes, 0);
+            sc.dynpos.assign(s->num_geometries, nullptr);
+            sc.mesh_dyn.assign(s->num_meshes, nullptr);
+            if ((rc = dev_alloc(h, &sc.nodes, h->h_nodes.size(), &h->scene_allocs))) return rc;
+            if ((rc = dev_alloc(h, &sc.tris, h->h_tris.size() + 2, &h->scene_allocs))) return rc;
+            if ((rc = dev_alloc(h, &sc.node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
+            if ((rc = dev_alloc(h, &sc.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
+            if ((rc = dev_alloc(h, &sc.inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
+            HIP_TRY(h, hipMemcpy(sc.nodes, d_nodes, h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyDeviceToDevice));
+            if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(sc.tris, d_tris, h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyDeviceToDevice));
+            HIP_TRY(h, hipMemcpy(sc.node_box, h->master.node_box, h->h_node_box.size() * 24, hipMemcpyDeviceToDevice));
+            std::vector<RpGeomRecord> cgeoms = geoms; // same records, pointing at this copy's float positions
+            for (uint32_t m = 0; m < s->num_meshes; ++m) {
+                const RptrMeshDesc &mesh = s->meshes[m];
+                if (!mesh.dynamic) continue;
+                std::vector<const float *> table(mesh.num_geometries, nullptr);
+                for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+                    const uint32_t gi = mesh.first_geometry + j;
+                    const size_t nfl = (size_t)s->geometries[gi].num_tris * 9;
+                    float *dp = nullptr;
+                    if ((rc = dev_alloc(h, &dp, nfl, &h->scene_allocs))) return rc;
+                    if (nfl) HIP_TRY(h, hipMemcpy(dp, h->master.dynpos[gi], nfl * sizeof(float), hipMemcpyDeviceToDevice));
+                    sc.dynpos[gi] = dp;
+                    table[j] = dp;
+                }
+                const float **dt = nullptr;
+                if ((rc = dev_alloc(h, &dt, table.size(), &h->scene_allocs))) return rc;
+                if (!table.empty()) HIP_TRY(h, hipMemcpy(dt, table.data(), table.size() * sizeof(float *), hipMemcpyHostToDevice));
+                sc.mesh_dyn[m] = dt;
+                sc.mesh_dirty[m] = 2;
+            }
+            for (RpGeomRecord &r : cgeoms)
+                if (r.dyn_pos)
+                    for (uint32_t gi = 0; gi < s->num_geometries; ++gi)
+                        if (r.dyn_pos == h->master.dynpos[gi]) {
+                            r.dyn_pos = sc.dynpos[gi];
+                            break;
+                        }
+            RpGeomRecord *cg = nullptr;
+            if ((rc = dev_alloc(h, &cg, cgeoms.size(), &h->scene_allocs))) return rc;
+            if (!cgeoms.empty()) HIP_TRY(h, hipMemcpy(cg, cgeoms.data(), cgeoms.size() * sizeof(RpGeomRecord), hipMemcpyHostToDevice));
+            sc.dscene.nodes = sc.nodes;
+            sc.dscene.tris = sc.tris;
+            sc.dscene.geoms = cg;
+            sc.version = h->refit_version;
+        }
+    }
     h->have_scene = true;
     // a new scene restarts accumulation (Shell::set_scene -> reset, libapp/shell.cpp:96-126)
     h->frame_offset += h->frame_id;
@@ -896,19 +963,19 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
 static int update_vertices_common(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices, bool device_src) {
     if (!h || !xyz) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "update_vertices before set_scene");
-    {
-        int rc0 = drain(h); // frames in flight still read the vertex buffer and the tree
+    if (h->ctx_scene.empty()) { // frames in flight read the master vertex buffer and tree
+        int rc0 = drain(h);
         if (rc0) return rc0;
     }
-    if (geometry >= h->d_dynpos.size() || !h->d_dynpos[geometry])
+    if (geometry >= h->master.dynpos.size() || !h->master.dynpos[geometry])
         return fail(h, RPTR_E_INVALID, "geometry %u does not belong to a dynamic mesh (RptrMeshDesc.dynamic)", geometry);
     if (num_vertices != 3u * h->geom_tris[geometry])
         return fail(h, RPTR_E_INVALID, "geometry %u has %u unrolled vertices, got %u", geometry, 3u * h->geom_tris[geometry], num_vertices);
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(h->d_dynpos[geometry], xyz, (size_t)num_vertices * 12, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+    HIP_TRY(h, hipMemcpyAsync(h->master.dynpos[geometry], xyz, (size_t)num_vertices * 12, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                               h->stream));
     if (!device_src) HIP_TRY(h, hipStreamSynchronize(h->stream)); // the host array is only borrowed for the call
-    h->mesh_dirty[h->geom_mesh[geometry]] = 1;
+    h->master.mesh_dirty[h->geom_mesh[geometry]] = 1;
     return RPTR_OK;
 }
 int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
@@ -923,39 +990,49 @@ int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const floa
 // ≙ BLAS update (VK_BUILD_ACCELERATION_STRUCTURE_MODE_UPDATE) of the dirty dynamic meshes + TLAS refit
 // (render_vulkan.cpp:1323-1354, executed at the top of draw_frame :2165): topology is kept, triangles and all
 // boxes are recomputed on the device, level by level from the leaves up.
+extern "C++" {
+// refits one copy of the mutable scene on stream `st`; all_dynamic: treat every dynamic mesh as changed
+static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipStream_t st) {
+    bool any = all_dynamic && !h->refit_levels_blas.empty();
+    for (size_t m = 0; m < h->meshes.size(); ++m) any = any || sc.mesh_dirty[m] == 1;
+    if (!any) return false;
+    for (size_t m = 0; m < h->meshes.size(); ++m) {
+        const MeshRt &mr = h->meshes[m];
+        if (!mr.dynamic) continue;
+        if (!all_dynamic && !sc.mesh_dirty[m]) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
+        if (mr.tri_count)
+            hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.tris, sc.tri_box, (uint32_t)mr.tri_base,
+                               (uint32_t)mr.tri_count, sc.mesh_dyn[m]);
+        sc.mesh_dirty[m] = 0;
+    }
+    // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
+    RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
+    for (auto &lv : h->refit_levels_blas)
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
+                           h->d_refit_list, lv[0], lv[1]);
+    const uint32_t ni = (uint32_t)h->h_insts.size();
+    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
+    for (auto &lv : h->refit_levels_tlas)
+        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
+                           h->d_refit_list, lv[0], lv[1]);
+    return true;
+}
+} // extern "C++"
+
 int rptr_hip_refit(rptr_hip_t *h) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "refit before set_scene");
     HIP_TRY(h, hipSetDevice(h->device));
-    {
+    if (h->ctx_scene.empty()) { // frames in flight read the master set
         int rc0 = drain(h);
         if (rc0) return rc0;
     }
-    bool any = false;
-    RptrBvhTri *tris = const_cast<RptrBvhTri *>(h->dscene.tris);
-    RptrBvh4Node *nodes = const_cast<RptrBvh4Node *>(h->dscene.nodes);
-    RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(h->dscene.insts);
-    for (size_t m = 0; m < h->meshes.size(); ++m) any = any || h->mesh_dirty[m] == 1;
-    if (!any) return RPTR_OK;
-    for (size_t m = 0; m < h->meshes.size(); ++m) {
-        if (!h->mesh_dirty[m]) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
-        const MeshRt &mr = h->meshes[m];
-        if (mr.tri_count)
-            hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, h->stream, tris, h->d_tri_box,
-                               (uint32_t)mr.tri_base, (uint32_t)mr.tri_count, h->d_mesh_dyn[m]);
-        h->mesh_dirty[m] = 0;
+    if (refit_scene_copy(h, h->master, false, h->stream)) {
+        HIP_TRY(h, hipGetLastError());
+        h->host_bvh_stale = true;
+        h->refit_version++; // the frame contexts' own sets follow when their next frame is submitted
+        h->master.version = h->refit_version;
     }
-    // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
-    for (auto &lv : h->refit_levels_blas)
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_node_box, h->d_tri_box, h->d_inst_box,
-                           h->d_refit_list, lv[0], lv[1]);
-    const uint32_t ni = (uint32_t)h->h_insts.size();
-    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, h->stream, h->d_node_box, insts, h->d_inst_box, ni);
-    for (auto &lv : h->refit_levels_tlas)
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, h->stream, nodes, h->d_node_box, h->d_tri_box, h->d_inst_box,
-                           h->d_refit_list, lv[0], lv[1]);
-    HIP_TRY(h, hipGetLastError());
-    h->host_bvh_stale = true;
     return RPTR_OK;
 }
 
@@ -992,10 +1069,10 @@ static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
 
 extern "C++" {
 template <int VARIANT>
-static void launch_shade(rptr_hip *h, FrameCtx &c, const RpFrame &f, const uint32_t *order, int bounce, int out) {
+static void launch_shade(rptr_hip *h, FrameCtx &c, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     const int grid = grid_for(h, h->path_capacity);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, c.stream, h->dscene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, c.stream, scene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
                            c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
     };
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
@@ -1164,6 +1241,17 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     auto timed = [&](int kind, auto &&launch) { timed_on(c.stream, kind, launch); };
     const bool side = c.side != nullptr;
 
+    SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
+    if (!h->ctx_scene.empty() && scn.version != h->refit_version) {
+        // this context's own tree / vertices follow the master set: copy the float positions, refit (on the backend's
+        // stream, behind the caller's updates; this context is idle, the others keep rendering from their own sets)
+        for (size_t gi = 0; gi < scn.dynpos.size(); ++gi)
+            if (scn.dynpos[gi])
+                HIP_TRY(h, hipMemcpyAsync(scn.dynpos[gi], h->master.dynpos[gi], (size_t)h->geom_tris[gi] * 9 * sizeof(float), hipMemcpyDeviceToDevice,
+                                          h->stream));
+        (void)refit_scene_copy(h, scn, true, h->stream);
+        scn.version = h->refit_version;
+    }
     if (multi) { // whatever the caller queued on the backend's stream (vertex updates, refit) comes first
         HIP_TRY(h, hipEventRecord(c.ev_dep, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_dep, 0));
@@ -1201,7 +1289,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 timed(0, [&] {
                     auto go = [&](auto kernel) {
-                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, h->dscene, f, c.ps,
+                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, scn.dscene, f, c.ps,
                                            b == 0 ? first_ids : c.queue[in], bc, c.counters, c.gstack);
                     };
                     if (b == 0)
@@ -1214,7 +1302,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                 const uint32_t *order = in_queue;
                 if (do_sort) {
                     timed(2, [&] {
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, h->dscene, f, c.ps, in_queue,
+                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, scn.dscene, f, c.ps, in_queue,
                                            &bc->queue_count, c.keys, c.sort_hist);
                         hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
                         hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, in_queue,
@@ -1225,9 +1313,9 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                 if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) wrote illum, frees the shadow queue
                 timed(2, [&] {
                     if (variant == RPTR_VARIANT_SIMPLE)
-                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, f, order, b, out);
+                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, scn.dscene, f, order, b, out);
                     else
-                        launch_shade<RPTR_VARIANT_GLTF>(h, c, f, order, b, out);
+                        launch_shade<RPTR_VARIANT_GLTF>(h, c, scn.dscene, f, order, b, out);
                 });
                 {
                     hipStream_t cs = side ? c.side : c.stream;
@@ -1238,10 +1326,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                     }
                     timed_on(cs, 1, [&] {
                         if (count_traversal)
-                            hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, h->dscene, c.ps, c.sq, bc,
+                            hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, c.ps, c.sq, bc,
                                                c.counters, stack);
                         else
-                            hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, h->dscene, c.ps, c.sq, bc,
+                            hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, c.ps, c.sq, bc,
                                                c.counters, stack);
                     });
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
@@ -1420,7 +1508,7 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
         // cursor_extend doubles as the pool cursor of the query kernel (same stream, no overlap with a frame)
         hipLaunchKernelGGL(rp_k_reset_u32, dim3(1), dim3(1), 0, h->stream, &h->ctx[0].counters->bounce[0].cursor_extend);
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->dscene, dq, (uint32_t)n, dr,
+            hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->master.dscene, dq, (uint32_t)n, dr,
                                &h->ctx[0].counters->bounce[0].cursor_extend, h->ctx[0].gstack, dv, dt);
         };
         if (any_hit)
@@ -1468,8 +1556,8 @@ int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris,
     if (h->host_bvh_stale) { // a refit happened on the device: refresh the host mirror first
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipMemcpy(h->h_nodes.data(), h->dscene.nodes, h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyDeviceToHost));
-        if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(h->h_tris.data(), h->dscene.tris, h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(h->h_nodes.data(), h->master.dscene.nodes, h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyDeviceToHost));
+        if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(h->h_tris.data(), h->master.dscene.tris, h->h_tris.size() * sizeof(RptrBvhTri), hipMemcpyDeviceToHost));
         h->host_bvh_stale = false;
     }
     if (nodes && n_nodes && *n_nodes >= h->h_nodes.size()) memcpy(nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvh4Node));

@@ -220,3 +220,53 @@ def test_fuzz_refit_of_soups(seed):
     assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
     assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
     r.close()
+
+
+def test_animated_frames_in_flight_equal_one_at_a_time(dyn_grid):
+    """3 frame contexts on a dynamic scene: every context keeps its own tree and float vertices, brought up to date when a
+    frame is submitted on it. A sequence (update, refit, frame)x5 queued back to back gives the same images as the same
+    sequence rendered one frame at a time -- also when only every other frame is preceded by an update."""
+    W, H = 128, 72
+    times = [0.1, None, 0.35, 0.35, 0.6]        # None: no update before this frame (static continuation)
+
+    def run(fif):
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(dyn_grid)
+        cam = dyn_grid.camera_params()
+        images, queue = [], []
+        def collect():
+            r.wait(queue.pop(0))
+            img = np.zeros((H, W, 4), np.float32)
+            r.readback_framebuffer(img)
+            images.append(img)
+        for t in times:
+            if t is not None:
+                r.update_vertices(0, scenes.grid_positions(NX, NZ, t))
+                r.refit()
+            cfg = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
+            queue.append(r.render_async(cfg, spp=1))
+            if len(queue) >= fif:
+                collect()
+        while queue:
+            collect()
+        # ray queries work on the handle's own (master) tree: current after the last refit
+        q = _grid_queries(4000, 5)
+        res = r.render_ray_queries(q).copy()
+        r.close()
+        return images, res
+
+    ref_images, ref_q = run(1)
+    images, q3 = run(3)
+    for a, b in zip(images, ref_images):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(q3.view(np.uint32), ref_q.view(np.uint32))
+    assert not np.array_equal(ref_images[0], ref_images[2])     # the surface really moved
+    # reset_accumulation re-seeds every frame (frame_offset advances), so even frames of the same geometry differ in noise
+    assert not np.array_equal(ref_images[2], ref_images[3])
+    # oracle check of the last frame: geometry of t = 0.6, frame_offset = 4 resets so far
+    osc = O.OracleScene(dyn_grid)
+    osc.set_dynamic_vertices(0, scenes.grid_positions(NX, NZ, 0.6))
+    ref, _ = osc.render(W, H, 1, variant=abi.VARIANT_SIMPLE, frame_offset=4)
+    rmse, same, _ = image_error(images[-1], ref)
+    assert same and rmse < RMSE_TOL
