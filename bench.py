@@ -248,7 +248,10 @@ def main():
     achieved_serial = ext_bytes / (serial["ext"] * 1e-3) / 1e9 if serial["ext"] > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    # the committed PMC passes were taken on the default workload (configs[1], one GPU): no figure for anything else
+    default_workload = (args.scene == "grid" and args.grid == "1000x500" and args.variant == "diffuse" and not args.lights and not args.animate
+                        and (W, H, spp) == (1920, 1080, 4) and world == 1 and args.emulate_world <= 1)
+    if default_workload and os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("rp_k_extend_hbm_bytes_per_launch")
         except Exception:
@@ -256,6 +259,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "rp_k_extend<false, *> (first bounce: <false, true>, later bounces: <false, false>)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per "
+                          "launch averaged over the 9 launches of a frame" if traffic is not None else None,
         "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
         "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,
         "note": "achieved/launch_ms: HIP events over the timed region (%d frames in flight: launches of neighbouring frames share the GPU); "
