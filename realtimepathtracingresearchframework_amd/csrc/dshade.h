@@ -533,63 +533,74 @@ RP_DEV void rp_load_light(const RptrTriLightData *lights, int id, V3 &a, V3 &b, 
     c = v3(q1.z, q1.w, q2.x);
     rad = v3(q2.y, q2.z, q2.w);
 }
-// rendering/mc/lights_linear.glsl:19-127 (binned RIS, solid-angle sampling)
-RP_DEV V3 rp_sample_tri_lights(const RpScene &sc, const RpFrame &f, V3 hit_p, V3 hit_n, V2 dir_sample, V2 sel_sample, V3 &light_dir,
-                               float &light_dist, float &pdf, float &mis_wpdf) {
-    const int num_lights = sc.num_lights;
-    const int BIN = f.lc.bin_size;
+// rendering/mc/lights_linear.glsl:19-127 (binned RIS, solid-angle sampling), in three parts so that the expensive one --
+// the approximate contribution of every light of the chosen bin -- can be evaluated by any lane of the wave
+// (kernels.h: the lanes of a wave share the candidates of all their tri-light samples; results are bit-identical to
+// the straight loop because each contribution is the same arithmetic and the owner sums them in the same order).
+struct RpLightBin { // :21-36
+    int bin_begin, bin_end;
+    float sel_p;
+};
+RP_DEV RpLightBin rp_choose_light_bin(const RpScene &sc, const RpFrame &f, float sel_x) {
     const int num_bins = f.num_bins;
-    sel_sample.x *= float(num_bins);
-    int bin_id = int(uint32_t(sel_sample.x));
+    sel_x *= float(num_bins);
+    int bin_id = int(uint32_t(sel_x));
     bin_id = min(bin_id, num_bins - 1);
-    float sel_p = 1.0f / float(num_bins);
-    float contributions[RPTR_BINNED_LIGHTS_BIN_MAX_SIZE];
-    float total_contrib = 0.0f;
+    RpLightBin b;
+    b.sel_p = 1.0f / float(num_bins);
+    b.bin_begin = f.lc.bin_size * bin_id;
+    b.bin_end = min(f.lc.bin_size * (bin_id + 1), sc.num_lights);
+    return b;
+}
+// :41-66 the approximate (unshadowed, solid-angle) contribution of one light to hit_p; 0 for ids beyond the bin
+RP_DEV float rp_tri_light_contribution(const RpScene &sc, int light_id, int bin_end, V3 hit_p, V3 hit_n) {
     const float MIN_IRRADIANCE = 6.2e-4f * 0.001f;
-    const int bin_begin = BIN * bin_id;
-    const int bin_end = min(BIN * (bin_id + 1), num_lights);
-#pragma unroll
-    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
-        int light_id = bin_begin + i;
-        float contrib = 0.0f;
-        if (light_id < bin_end) {
-            V3 a, b, c, rad;
-            rp_load_light(sc.lights, light_id, a, b, c, rad);
-            a = a - hit_p;
-            b = b - hit_p;
-            c = c - hit_p;
-            bool front_facing = dot3(cross3(a, b), c) < 0.0f; // tri.glsl:21-23
-            contrib = luminance3(rad);
-            if ((dot3(a, hit_n) > 0.0f || dot3(b, hit_n) > 0.0f || dot3(c, hit_n) > 0.0f) && front_facing) {
-                a = norm3(a);
-                b = norm3(b);
-                c = norm3(c);
-                V3 tp;
-                contrib *= 2.0f * rp_fast_positive_atan(rp_half_tri_solid_angle_tan(a, b, c, tp));
-            } else
-                contrib = 0.0f;
-            contrib += MIN_IRRADIANCE;
-            total_contrib += contrib;
-        }
-        contributions[i] = contrib;
+    float contrib = 0.0f;
+    if (light_id < bin_end) {
+        V3 a, b, c, rad;
+        rp_load_light(sc.lights, light_id, a, b, c, rad);
+        a = a - hit_p;
+        b = b - hit_p;
+        c = c - hit_p;
+        bool front_facing = dot3(cross3(a, b), c) < 0.0f; // tri.glsl:21-23
+        contrib = luminance3(rad);
+        if ((dot3(a, hit_n) > 0.0f || dot3(b, hit_n) > 0.0f || dot3(c, hit_n) > 0.0f) && front_facing) {
+            a = norm3(a);
+            b = norm3(b);
+            c = norm3(c);
+            V3 tp;
+            contrib *= 2.0f * rp_fast_positive_atan(rp_half_tri_solid_angle_tan(a, b, c, tp));
+        } else
+            contrib = 0.0f;
+        contrib += MIN_IRRADIANCE;
     }
+    return contrib;
+}
+// :68-127 selection among the bin's contributions (read through `contribution(i)`, i = 0..15 in order) + solid-angle sample
+template <class Contribution>
+RP_DEV V3 rp_finish_tri_light_sample(const RpScene &sc, const RpFrame &f, const RpLightBin &bin, Contribution contribution, V3 hit_p, V2 dir_sample,
+                                     float sel_y, V3 &light_dir, float &light_dist, float &pdf, float &mis_wpdf) {
+    float total_contrib = 0.0f;
+#pragma unroll
+    for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i)
+        if (bin.bin_begin + i < bin.bin_end) total_contrib += contribution(i);
     float p = 0.0f, t = 0.0f;
-    int light_id = bin_begin;
+    int light_id = bin.bin_begin;
     bool done = false;
 #pragma unroll
     for (int i = 0; i < RPTR_BINNED_LIGHTS_BIN_MAX_SIZE; ++i) {
         if (!done) {
-            light_id = bin_begin + i;
-            if (!(light_id < bin_end)) {
+            light_id = bin.bin_begin + i;
+            if (!(light_id < bin.bin_end)) {
                 done = true;
             } else {
-                p = contributions[i] / total_contrib;
+                p = contribution(i) / total_contrib;
                 t += p;
-                if (sel_sample.y < t) done = true;
+                if (sel_y < t) done = true;
             }
         }
     }
-    sel_p *= p;
+    const float sel_p = bin.sel_p * p;
     V3 l0, l1, l2, lrad;
     rp_load_light(sc.lights, light_id, l0, l1, l2, lrad); // may be bin_end: zero-padded
     V3 d0 = norm3(l0 - hit_p);
@@ -603,7 +614,7 @@ RP_DEV V3 rp_sample_tri_lights(const RpScene &sc, const RpFrame &f, V3 hit_p, V3
     light_dist = dot3(l0 - hit_p, e_n) / dot3(light_dir, e_n);
     mis_wpdf = 2.0f * light_dist * light_dist / fabsf(dot3(light_dir, e_n));
     pdf *= sel_p;
-    mis_wpdf /= float(num_bins);
+    mis_wpdf /= float(f.num_bins);
     return 1.0f * lrad / pdf;
 }
 

@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
     __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
+    // per wave: the tri-light requests of its lanes (hit point, normal, bin) and the contributions of their bins
+    __shared__ float s_ris_req[LIGHTS ? (256 / 64) * 64 * 8 : 1];
+    __shared__ float s_ris_contrib[LIGHTS ? (256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE : 1];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     const uint32_t n = *count_ptr;
     const uint32_t nchunks = (n + RP_CHUNK - 1) / RP_CHUNK;
@@ -370,13 +373,29 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
             bool alive = false;      // path continues with a new ray
             bool has_shadow = false; // a shadow query is issued
             uint32_t p = 0;
+            // The body runs in three stretches with the whole wave converged in between, so that the binned-RIS
+            // candidates of all tri-light samples of the wave can be spread over all 64 lanes (A: up to the choice of
+            // the light kind; cooperative candidate evaluation; B: next-event estimation; C: BSDF sample + state).
+            bool hit_lane = false;  // this lane shades a hit
+            bool nee = false;       // ... and samples direct light
+            bool nee_tri = false;   // ... from the triangle lights (needs the bin's contributions)
+            bool terminate = false;
+            uint32_t rng = 0;
+            float total_t = 0.f, prev_bounce_pdf = 0.f, geometry_scale = 0.f;
+            V3 ray_origin = v3s(0.f), ray_dir = v3s(0.f), throughput = v3s(0.f), illum = v3s(0.f), scatter_throughput = v3s(0.f);
+            V3 ip_p = v3s(0.f), gn = v3s(0.f), nn = v3s(0.f), w_o = v3s(0.f), v_x = v3s(0.f), v_y = v3s(0.f);
+            int bounce = 0;
+            RpMaterial mat;
+            V2 dir_sample = v2(0.f, 0.f), sel_sample = v2(0.f, 0.f);
+            RpLightBin bin;
+            bin.bin_begin = bin.bin_end = 0;
+            bin.sel_p = 0.f;
+            const int output_channel = f.rp.output_channel;
+            const float sun_w = f.sp.sun_radiance[3];
+            // ---------------- A
             if (i < n) {
                 p = order[i];
                 my_closest++;
-                uint32_t rng;
-                float total_t, prev_bounce_pdf;
-                V3 ray_origin, ray_dir, throughput, illum;
-                int bounce;
                 if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
                     (void)rp_primary_ray(f, p, rng, ray_dir);
                     ray_origin = ld3(f.cam_pos);
@@ -406,6 +425,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
                     ps.illum[p] = f4(illum, __int_as_float(bounce));
                 } else {
+                    hit_lane = true;
                     my_hits++;
                     // ---- hit attributes, pt_megakernel.glsl:495-572
                     const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
@@ -422,10 +442,11 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                     approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
                     // :585,605
                     total_t += hit.dist;
-                    const float geometry_scale = total_t;
-                    const V3 w_o = -ray_dir;
-                    V3 ip_p = ray_origin + hit.dist * ray_dir;
-                    V3 gn = hit.geo_normal, nn = hit.normal;
+                    geometry_scale = total_t;
+                    w_o = -ray_dir;
+                    ip_p = ray_origin + hit.dist * ray_dir;
+                    gn = hit.geo_normal;
+                    nn = hit.normal;
                     const RptrBaseMaterial mp = sc.materials[hit.material_id];
                     // :624-633
                     if (dot3(w_o, gn) < 0.0f) {
@@ -447,15 +468,13 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                         }
                     }
                     // :677-678
-                    const V3 v_y = norm3(cross3(nn, hit.tangent));
-                    const V3 v_x = cross3(v_y, nn);
+                    v_y = norm3(cross3(nn, hit.tangent));
+                    v_x = cross3(v_y, nn);
 
                     // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
-                    RpMaterial mat;
                     V3 emit;
                     rp_unpack_material<VARIANT>(mat, emit, mp);
-                    const V3 scatter_throughput = throughput;
-                    const int output_channel = f.rp.output_channel;
+                    scatter_throughput = throughput;
                     if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
                         // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
                         const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));
@@ -471,99 +490,143 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                         else if (output_channel == 3)
                             illum = illum + ip_p * reliability;
                     }
-                    bool terminate = (bounce + 1 >= f.rp.max_path_depth);
-                    if (!terminate) {
-                        if (output_channel == 0) {
-                            // ---- sample_direct_light, rendering/mc/nee.glsl:32-90
-                            const V2 dir_sample = rp_rand2(rng);
-                            V2 sel_sample = rp_rand2(rng);
-                            V3 nee = v3s(0.0f);
-                            V3 light_dir = v3s(0.0f);
-                            float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
-                            const float sun_w = f.sp.sun_radiance[3];
-                            if (!LIGHTS || sel_sample.x <= sun_w) {
-                                sel_sample.x /= sun_w;
-                                light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
-                                light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
-                                nee = nee + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
-                                light_pdf *= sun_w;
-                                mis_pdf = light_pdf;
-                            } else {
-                                sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
-                                float tri_mis_wpdf = 0.0f;
-                                nee = nee + rp_sample_tri_lights(sc, f, ip_p, nn, dir_sample, sel_sample, light_dir, light_dist, light_pdf,
-                                                                 tri_mis_wpdf) /
-                                                (1.0f - sun_w);
-                                light_pdf *= 1.0f - sun_w;
-                                if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
-                            }
-                            if (light_pdf > 0.0f && dot3(light_dir, gn) * dot3(light_dir, nn) > 0.0f) {
-                                // raytrace_test_visibility is deferred to the connect stage; everything that
-                                // does not depend on its answer is evaluated here (nee.glsl:73-84)
-                                const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
-                                const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
-                                const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
-                                if (needs_ray) my_shadow++; // the reference traces it even when bsdf_pdf < 0
-                                if (bsdf_pdf >= 0.0f) {
-                                    const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
-                                    const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
-                                    nee = nee * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
-                                    const V3 c = scatter_throughput * nee;
-                                    if (needs_ray) {
-                                        has_shadow = true;
-                                        sq.o[p] = f4(ip_p, epsilon);
-                                        sq.d[p] = f4(light_dir, light_dist - epsilon);
-                                        sq.contrib[p] = f4(c, 0.0f);
-                                    } else
-                                        illum = illum + c; // visibility defaults to true
-                                }
-                            }
-                        }
-                        if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
-                    }
-                    if (!terminate) {
-                        const V2 lobe_sample = rp_rand2(rng);
-                        const V2 dir_sample = rp_rand2(rng);
-                        V3 w_i = v3s(0.0f);
-                        float sampling_pdf = 0.0f, mis_pdf = 0.0f;
-                        V3 bsdf;
-                        if (VARIANT == RPTR_VARIANT_SIMPLE)
-                            bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample);
-                        else
-                            bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample, lobe_sample, v_x, v_y);
-                        ++bounce;
-                        if (eq3(bsdf, v3s(0.f)) || mis_pdf == 0.f || !(dot3(w_i, nn) * dot3(w_i, gn) > 0.0f))
-                            terminate = true;
-                        else {
-                            throughput = throughput * bsdf;
-                            prev_bounce_pdf = mis_pdf;
-                            // pt_megakernel.glsl:703-709
-                            ray_dir = w_i;
-                            ray_origin = ip_p;
-                            const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
-                            // :713-730 Russian roulette
-                            bool survive = true;
-                            if (bounce >= f.rp.rr_path_depth) {
-                                const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
-                                float rr_prob = prefix_weight;
-                                const float rr_sample = rp_randf(rng);
-                                rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
-                                if (rr_sample < rr_prob)
-                                    throughput = throughput / rr_prob;
-                                else
-                                    survive = false;
-                            }
-                            if (survive) {
-                                alive = true;
-                                ps.ray_o[p] = f4(ray_origin, t_min);
-                                ps.ray_d[p] = f4(ray_dir, 1e20f);
-                                ps.thr[p] = f4(throughput, prev_bounce_pdf);
-                                ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
-                            }
+                    terminate = (bounce + 1 >= f.rp.max_path_depth);
+                    if (!terminate && output_channel == 0) {
+                        // ---- sample_direct_light, rendering/mc/nee.glsl:32-90: the random numbers and the kind of light
+                        nee = true;
+                        dir_sample = rp_rand2(rng);
+                        sel_sample = rp_rand2(rng);
+                        if (LIGHTS && !(sel_sample.x <= sun_w)) {
+                            nee_tri = true;
+                            sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
+                            bin = rp_choose_light_bin(sc, f, sel_sample.x);
                         }
                     }
-                    ps.illum[p] = f4(illum, __int_as_float(bounce));
                 }
+            }
+            // ---------------- the bin contributions of every tri-light sample of this wave, 64 candidates at a time
+            const float *my_contrib = nullptr;
+            if (LIGHTS) {
+                const unsigned long long want = __ballot(nee_tri);
+                if (want != 0ull) {
+                    const uint32_t lane = rp_lane_id();
+                    float *wreq = s_ris_req + (threadIdx.x >> 6) * (64 * 8);
+                    float *wcon = s_ris_contrib + (threadIdx.x >> 6) * (64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE);
+                    const uint32_t rank = (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    const uint32_t nreq = (uint32_t)__popcll(want);
+                    if (nee_tri) {
+                        float *q = wreq + rank * 8;
+                        q[0] = ip_p.x;
+                        q[1] = ip_p.y;
+                        q[2] = ip_p.z;
+                        q[3] = nn.x;
+                        q[4] = nn.y;
+                        q[5] = nn.z;
+                        q[6] = __int_as_float(bin.bin_begin);
+                        q[7] = __int_as_float(bin.bin_end);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t jobs = nreq * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE;
+                    for (uint32_t j = lane; j < jobs; j += 64u) {
+                        const uint32_t qi = j / RPTR_BINNED_LIGHTS_BIN_MAX_SIZE, ci = j % RPTR_BINNED_LIGHTS_BIN_MAX_SIZE;
+                        const float *q = wreq + qi * 8;
+                        const V3 hp = v3(q[0], q[1], q[2]), hn = v3(q[3], q[4], q[5]);
+                        const int bb = __float_as_int(q[6]), be = __float_as_int(q[7]);
+                        wcon[j] = rp_tri_light_contribution(sc, bb + (int)ci, be, hp, hn);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    my_contrib = wcon + rank * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE;
+                }
+            }
+            // ---------------- B: next-event estimation
+            if (nee) {
+                V3 nee_l = v3s(0.0f);
+                V3 light_dir = v3s(0.0f);
+                float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
+                if (!nee_tri) {
+                    sel_sample.x /= sun_w;
+                    light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
+                    light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
+                    nee_l = nee_l + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
+                    light_pdf *= sun_w;
+                    mis_pdf = light_pdf;
+                } else {
+                    float tri_mis_wpdf = 0.0f;
+                    nee_l = nee_l + rp_finish_tri_light_sample(sc, f, bin, [&](int ci) { return my_contrib[ci]; }, ip_p, dir_sample, sel_sample.y, light_dir,
+                                                               light_dist, light_pdf, tri_mis_wpdf) /
+                                        (1.0f - sun_w);
+                    light_pdf *= 1.0f - sun_w;
+                    if (mis_pdf == 0.0f) mis_pdf = tri_mis_wpdf * (1.0f - sun_w);
+                }
+                if (light_pdf > 0.0f && dot3(light_dir, gn) * dot3(light_dir, nn) > 0.0f) {
+                    // raytrace_test_visibility is deferred to the connect stage; everything that
+                    // does not depend on its answer is evaluated here (nee.glsl:73-84)
+                    const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
+                    const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
+                    const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
+                    if (needs_ray) my_shadow++; // the reference traces it even when bsdf_pdf < 0
+                    if (bsdf_pdf >= 0.0f) {
+                        const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
+                        const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
+                        nee_l = nee_l * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
+                        const V3 c = scatter_throughput * nee_l;
+                        if (needs_ray) {
+                            has_shadow = true;
+                            sq.o[p] = f4(ip_p, epsilon);
+                            sq.d[p] = f4(light_dir, light_dist - epsilon);
+                            sq.contrib[p] = f4(c, 0.0f);
+                        } else
+                            illum = illum + c; // visibility defaults to true
+                    }
+                }
+            }
+            // ---------------- C: continuation
+            if (hit_lane) {
+                if (!terminate && f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
+                if (!terminate) {
+                    const V2 lobe_sample = rp_rand2(rng);
+                    const V2 dir_sample2 = rp_rand2(rng);
+                    V3 w_i = v3s(0.0f);
+                    float sampling_pdf = 0.0f, mis_pdf = 0.0f;
+                    V3 bsdf;
+                    if (VARIANT == RPTR_VARIANT_SIMPLE)
+                        bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample2);
+                    else
+                        bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample2, lobe_sample, v_x, v_y);
+                    ++bounce;
+                    if (eq3(bsdf, v3s(0.f)) || mis_pdf == 0.f || !(dot3(w_i, nn) * dot3(w_i, gn) > 0.0f))
+                        terminate = true;
+                    else {
+                        throughput = throughput * bsdf;
+                        prev_bounce_pdf = mis_pdf;
+                        // pt_megakernel.glsl:703-709
+                        ray_dir = w_i;
+                        ray_origin = ip_p;
+                        const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
+                        // :713-730 Russian roulette
+                        bool survive = true;
+                        if (bounce >= f.rp.rr_path_depth) {
+                            const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
+                            float rr_prob = prefix_weight;
+                            const float rr_sample = rp_randf(rng);
+                            rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
+                            if (rr_sample < rr_prob)
+                                throughput = throughput / rr_prob;
+                            else
+                                survive = false;
+                        }
+                        if (survive) {
+                            alive = true;
+                            ps.ray_o[p] = f4(ray_origin, t_min);
+                            ps.ray_d[p] = f4(ray_dir, 1e20f);
+                            ps.thr[p] = f4(throughput, prev_bounce_pdf);
+                            ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
+                        }
+                    }
+                }
+                ps.illum[p] = f4(illum, __int_as_float(bounce));
             }
             const uint32_t at = rp_wave_append(&s_nn, alive);
             if (alive) s_next[at] = p;
