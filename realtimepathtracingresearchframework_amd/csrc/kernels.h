@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
     __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
+    __shared__ uint32_t s_list[RP_CHUNK]; // path ids of the chunk, hits first
+    __shared__ uint32_t s_nhit, s_nmiss;
     // per wave: the tri-light requests of its lanes (hit point, normal, bin) and the contributions of their bins
     __shared__ float s_ris_req[LIGHTS ? (256 / 64) * 64 * 8 : 1];
     __shared__ float s_ris_contrib[LIGHTS ? (256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE : 1];
@@ -365,11 +367,32 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
         if (threadIdx.x == 0) {
             s_nn = 0;
             s_ns = 0;
+            s_nhit = 0;
+            s_nmiss = 0;
         }
         __syncthreads();
+        // regroup the chunk: hits from the front of s_list, misses from its back, so that the waves below shade either
+        // hits or misses (one mixed wave per chunk at most) instead of running both code paths with half their lanes
 #pragma unroll 1
         for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
             const uint32_t i = chunk * RP_CHUNK + kk * 256 + threadIdx.x;
+            const bool valid = i < n;
+            uint32_t pp = 0;
+            bool is_hit = false;
+            if (valid) {
+                pp = order[i];
+                is_hit = ps.hit_ids[pp].x >= 0;
+            }
+            const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
+            if (valid && is_hit) s_list[ah] = pp;
+            const uint32_t am = rp_wave_append(&s_nmiss, valid && !is_hit);
+            if (valid && !is_hit) s_list[RP_CHUNK - 1 - am] = pp;
+        }
+        __syncthreads();
+        const uint32_t chunk_hits = s_nhit, chunk_n = s_nhit + s_nmiss;
+#pragma unroll 1
+        for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
+            const uint32_t il = kk * 256 + threadIdx.x; // position in the regrouped chunk
             bool alive = false;      // path continues with a new ray
             bool has_shadow = false; // a shadow query is issued
             uint32_t p = 0;
@@ -393,8 +416,8 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
             const int output_channel = f.rp.output_channel;
             const float sun_w = f.sp.sun_radiance[3];
             // ---------------- A
-            if (i < n) {
-                p = order[i];
+            if (il < chunk_n) {
+                p = il < chunk_hits ? s_list[il] : s_list[RP_CHUNK - 1 - (il - chunk_hits)];
                 my_closest++;
                 if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
                     (void)rp_primary_ray(f, p, rng, ray_dir);
