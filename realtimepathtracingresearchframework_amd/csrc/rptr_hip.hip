@@ -344,34 +344,78 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
         encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
     }
-    // ---- top level over instance bounds (1 instance per leaf)
-    std::vector<rptr::BuildPrim> iprims(s->num_instances);
-    std::vector<RptrBvhInstance> insts(s->num_instances);
+    // ---- top level over instance bounds (1 instance record per leaf). Partial re-braiding: when many instances overlap
+    // (a forest), one box per instance makes rays enter instance after instance just to leave them at the first nodes.
+    // An instance is then represented by up to `braid` records that share transform and ids but start at different
+    // sub-roots of its bottom-level tree (the cut is opened largest box first, only through nodes whose children are all
+    // inner nodes), each with the world box of its own subtree.
+    int braid = s->num_instances >= 16 ? 4 : 1;
+    if (const char *e = getenv("RPTR_REBRAID")) braid = std::max(1, std::min(64, atoi(e)));
+    std::vector<rptr::BuildPrim> iprims;
+    std::vector<RptrBvhInstance> insts;
+    iprims.reserve((size_t)s->num_instances * braid);
+    insts.reserve((size_t)s->num_instances * braid);
+    std::vector<std::vector<int>> mesh_cut(B.meshes.size()); // per mesh: the sub-roots (absolute BLAS node indices, before relocation)
+    for (size_t m = 0; m < B.meshes.size(); ++m) {
+        std::vector<int> cut{B.meshes[m].node_base};
+        auto area = [&](int n) {
+            const std::array<float, 6> &b = blas_boxes[n];
+            const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        while ((int)cut.size() < braid) {
+            int pick = -1;
+            float best = -1.0f;
+            for (size_t i = 0; i < cut.size(); ++i) {
+                const RptrBvh4Node &nd = blas_nodes[cut[i]];
+                int inner = 0, other = 0;
+                for (int k = 0; k < 4; ++k) {
+                    if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
+                    (nd.child[k] >= 0 ? inner : other)++;
+                }
+                if (inner < 2 || other > 0 || (int)cut.size() - 1 + inner > braid) continue; // leaves below it / would overshoot
+                const float a = area(cut[i]);
+                if (a > best) {
+                    best = a;
+                    pick = (int)i;
+                }
+            }
+            if (pick < 0) break;
+            const RptrBvh4Node nd = blas_nodes[cut[pick]];
+            cut.erase(cut.begin() + pick);
+            for (int k = 0; k < 4; ++k)
+                if (nd.child[k] >= 0) cut.push_back(nd.child[k]);
+        }
+        mesh_cut[m] = cut;
+    }
     for (uint32_t i = 0; i < s->num_instances; ++i) {
         const RptrInstanceDesc &in = s->instances[i];
         const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
-        const MeshRt &mr = B.meshes[pm.mesh];
         RptrBvhInstance bi;
         memset(&bi, 0, sizeof(bi));
         memcpy(bi.object_to_world, in.transform, 48);
         invert_affine(in.transform, bi.world_to_object);
-        bi.blas_root = mr.node_base; // relocated below
         bi.geometry_base = pmesh_base[in.parameterized_mesh];
         bi.instance_id = (int)i;
-        insts[i] = bi;
-        rptr::BuildPrim &bp = iprims[i];
-        for (int k = 0; k < 3; ++k) {
-            bp.lo[k] = INFINITY;
-            bp.hi[k] = -INFINITY;
-        }
-        for (int c = 0; c < 8; ++c) {
-            const float p[3] = {c & 1 ? mr.hi[0] : mr.lo[0], c & 2 ? mr.hi[1] : mr.lo[1], c & 4 ? mr.hi[2] : mr.lo[2]};
-            const float *M = in.transform;
-            for (int r = 0; r < 3; ++r) {
-                const float w = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
-                bp.lo[r] = std::fmin(bp.lo[r], w);
-                bp.hi[r] = std::fmax(bp.hi[r], w);
+        for (int sub : mesh_cut[pm.mesh]) {
+            bi.blas_root = sub; // relocated below
+            insts.push_back(bi);
+            const std::array<float, 6> &mb = blas_boxes[sub]; // exact bounds of the subtree (= the mesh for the root)
+            rptr::BuildPrim bp;
+            for (int k = 0; k < 3; ++k) {
+                bp.lo[k] = INFINITY;
+                bp.hi[k] = -INFINITY;
             }
+            for (int c = 0; c < 8; ++c) {
+                const float p[3] = {c & 1 ? mb[3] : mb[0], c & 2 ? mb[4] : mb[1], c & 4 ? mb[5] : mb[2]};
+                const float *M = in.transform;
+                for (int r = 0; r < 3; ++r) {
+                    const float w = ((M[4 * r] * p[0] + M[4 * r + 1] * p[1]) + M[4 * r + 2] * p[2]) + M[4 * r + 3];
+                    bp.lo[r] = std::fmin(bp.lo[r], w);
+                    bp.hi[r] = std::fmax(bp.hi[r], w);
+                }
+            }
+            iprims.push_back(bp);
         }
     }
     rptr::BuiltTree tlas;
@@ -399,8 +443,8 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         B.meshes[m].node_base += reloc;
         B.mesh_root[m] = B.meshes[m].node_base;
     }
-    B.insts.resize(s->num_instances);
-    for (uint32_t k = 0; k < s->num_instances; ++k) {
+    B.insts.resize(insts.size());
+    for (size_t k = 0; k < insts.size(); ++k) {
         B.insts[k] = insts[tlas.order[k]];
         B.insts[k].blas_root += reloc;
     }

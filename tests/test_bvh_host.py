@@ -121,3 +121,27 @@ def test_fuzz_soups_host_tree_equals_brute_force(seed):
     tuv_o, ids_o = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_OWN)   # the oracle's own 2-wide float tree agrees too
     assert np.array_equal(tuv_b.view(np.uint32), tuv_o.view(np.uint32)) and np.array_equal(ids_b, ids_o)
     assert (ids_b[:, 0] >= 0).sum() > 200
+
+
+@pytest.mark.parametrize("braid", [4, 9])
+def test_rebraided_instances_give_the_same_answers(monkeypatch, braid):
+    """Partial re-braiding: an instance is represented by several records that start at sub-roots of its bottom-level tree.
+    More records than instances, same hits (instance ids in the answers are those of the scene), same occlusion."""
+    s = scenes.forest(n_meshes=3, tris_per_tree=300, n_instances=25, name="f")
+    monkeypatch.setenv("RPTR_REBRAID", "1")
+    _, _, insts1, _ = backend.build_bvh_host(s)
+    monkeypatch.setenv("RPTR_REBRAID", str(braid))
+    nodes, tris, insts, need = backend.build_bvh_host(s)
+    n_records = insts.size // 32
+    assert insts1.size // 32 == len(s.instances) and len(s.instances) < n_records <= braid * len(s.instances)
+    ids = insts.view(np.int32).reshape(-1, 32)[:, 14]          # RptrBvhInstance.instance_id
+    assert set(ids.tolist()) == set(range(len(s.instances)))
+    osc = O.OracleScene(s)
+    osc.import_bvh(nodes, tris, insts)
+    o, d = _rays(6000, 9, -6, 6)
+    tuv_b, ids_b = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_BRUTE)
+    tuv_t, ids_t = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+    assert np.array_equal(tuv_b.view(np.uint32), tuv_t.view(np.uint32)) and np.array_equal(ids_b, ids_t)
+    any_b = osc.trace_ex(o, d, 1e-4, 3.0, any_hit=True, bvh_mode=O.BVH_BRUTE)[1][:, 0]
+    any_t = osc.trace_ex(o, d, 1e-4, 3.0, any_hit=True, bvh_mode=O.BVH_IMPORTED)[1][:, 0]
+    assert np.array_equal(any_b, any_t)
