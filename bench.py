@@ -51,6 +51,9 @@ def parse_args():
                          "(inside the timed region) and renders")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head")
+    ap.add_argument("--stripe-rows", type=int, default=8,
+                    help="rows per screen stripe of the tile split (multiple of 8); stripe s belongs to rank s %% N. 1080 rows in 8-row "
+                         "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic (single GPU): render only rank 0's stripes of an N-rank tile split, no gather")
     ap.add_argument("--dist-backend", type=str, default="nccl", choices=["nccl", "gloo"],
@@ -113,16 +116,16 @@ def main():
     stream = torch_stream.cuda_stream
     fif = max(1, args.frames_in_flight)  # (with a dynamic scene every frame context refits its own copy of the tree)
     if args.emulate_world > 1:
-        r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=32, stream=stream, frames_in_flight=fif)
+        r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     else:
-        r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=32, stream=stream, frames_in_flight=fif)
+        r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     r.initialize(W, H)
     t0 = time.time()
     r.set_scene(scene)
     t_build = time.time() - t0
     cam = scene.camera_params()
     on_host = world > 1 and args.dist_backend == "gloo"
-    gather = TileGather(W, H, 32, rank, world, device="cpu" if on_host else "cuda")
+    gather = TileGather(W, H, args.stripe_rows, rank, world, device="cpu" if on_host else "cuda")
     stage = torch.zeros_like(gather.tile, device="cuda") if on_host else None  # gloo rig: device tile -> host tile
     my_bytes = r.local_pixel_count() * 16
 
@@ -293,7 +296,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
                    "frames_in_flight": fif,
-                   "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": 32, "rays_per_step": rays // K,
+                   "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,
     }
