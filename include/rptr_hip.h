@@ -193,6 +193,21 @@ typedef struct RptrInstanceDesc {
     uint32_t parameterized_mesh;
 } RptrInstanceDesc;
 
+/* A texture: RGBA8, row 0 first, sampled like the reference's material sampler (render_vulkan.cpp:1657-1670: linear filter,
+ * REPEAT addressing) at mip level 0 (textureLod(..., 0), rendering/rt/material_textures.glsl:37-60 with NO_TEXTURE_GRAD);
+ * srgb != 0: the colour channels are sRGB-encoded (VK_FORMAT_R8G8B8A8_SRGB), alpha is linear. A float material parameter
+ * with its sign bit set is a texture handle (rendering/bsdfs/texture_channel_mask.h): bits 0..28 = index into
+ * RptrSceneDesc.textures, bits 29..30 = channel for scalar parameters. */
+#define RPTR_TEXTURED_PARAM_MASK 0x80000000u
+#define RPTR_TEXTURE_ID(bits) ((bits) & 0x1fffffffu)
+#define RPTR_TEXTURE_CHANNEL(bits) (((bits) >> 29) & 0x3u)
+typedef struct RptrTextureDesc {
+    const uint8_t *rgba8;
+    uint32_t width, height;
+    uint32_t srgb;
+    uint32_t _pad;
+} RptrTextureDesc;
+
 typedef struct RptrSceneDesc {
     const RptrGeometryDesc *geometries;
     uint32_t num_geometries;
@@ -208,6 +223,9 @@ typedef struct RptrSceneDesc {
      * (librender/lights.cpp:14-90,220-349) */
     const RptrTriLightData *lights;
     uint32_t num_lights;
+    /* textures referenced by textured material parameters and normal_map (may be NULL / 0) */
+    const RptrTextureDesc *textures;
+    uint32_t num_textures;
 } RptrSceneDesc;
 
 /* device selection + multi-GPU tile assignment.  The frame is cut

@@ -53,6 +53,7 @@ static void compute_view(const RptrCamera &c, int W, int H, ViewParams &vp) {
 
 struct Scene {
     SceneView view;
+    TextureTable textures;
     Bvh own;
     Bvh imported;
     bool own_built = false, has_imported = false;
@@ -272,11 +273,11 @@ struct ShadingSampleState { // rendering/mc/shading_interface.glsl:15-22
 // rendering/mc/shade_base_material.glsl:14-96
 template <class MAT>
 static int shade_base_material(const Frame &f, float geometry_scale, ShadingSampleState &state, vec3 &illum, vec3 &path_throughput,
-                               const RptrBaseMaterial &params, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
+                               const RptrBaseMaterial &params, vec2 hit_uv, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
                                LCGRand &rng, vec3 &w_i, PathCounters &pc) {
     MAT mat;
     vec3 emit_radiance;
-    unpack_material(mat, emit_radiance, params);
+    unpack_material(f.sc->textures, mat, emit_radiance, params, hit_uv);
     vec3 scatter_throughput = path_throughput;
     if (state.output_channel == 0 && !all_equal(emit_radiance, vec3(0.0f))) {
         float light_pdf = wpdf_direct_light(f, approx_solid_angle);
@@ -389,7 +390,19 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
                 interaction.gn = -interaction.gn;
             }
         }
-        // :634-654 normal mapping: normal_map must be -1 (no textures in this build)
+        // :634-654 normal mapping
+        if (mparams.normal_map != -1) {
+            vec3 t_y = normalize(cross(hit.normal, hit.tangent));
+            vec3 t_x = cross(t_y, hit.normal);
+            t_x = t_x * length(hit.tangent);
+            t_y = t_y * hit.bitangent_l;
+            const vec4 tx = texture_lod0(sc.textures, mparams.normal_map, hit.uv);
+            vec3 map_nrm(2.0f * tx.x - 1.0f, 2.0f * tx.y - 1.0f, 1.0f * tx.z - 0.0f);
+            // Z encoding might be unclear, just reconstruct
+            map_nrm.z = sqrtf(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
+            const vec3 t_z = f.sp.normal_z_scale * interaction.n;
+            interaction.n = normalize((t_x * map_nrm.x + t_y * map_nrm.y) + t_z * map_nrm.z);
+        }
         // :656-668
         {
             float nw = dot(w_o, interaction.n);
@@ -408,7 +421,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
             fprintf(stderr, "[b%d] t=%g uv=(%g,%g) inst=%d geom=%d prim=%d mat=%d p=(%g,%g,%g) n=(%g,%g,%g) gn=(%g,%g,%g) tan=(%g,%g,%g) thr=(%g,%g,%g) illum=(%g,%g,%g) sa=%g\n", b, h.t, h.u, h.v,
                     h.inst, h.geom, h.prim, hit.material_id, interaction.p.x, interaction.p.y, interaction.p.z, interaction.n.x, interaction.n.y,
                     interaction.n.z, interaction.gn.x, interaction.gn.y, interaction.gn.z, hit.tangent.x, hit.tangent.y, hit.tangent.z, path_throughput.x, path_throughput.y, path_throughput.z, illum.x, illum.y, illum.z, approx_tri_solid_angle);
-        int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams,
+        int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams, hit.uv,
                                                       approx_tri_solid_angle, w_o, interaction, rng, w_i, pc);
         if (shading_result == SHADING_RESULT_TERMINATE) break;
         // :703-709
@@ -466,6 +479,8 @@ struct OrcRenderStats {
 void *orc_scene_create(const RptrSceneDesc *desc) {
     Scene *s = new Scene();
     s->view.init(desc);
+    s->textures.textures = desc->textures;
+    s->textures.num_textures = desc->num_textures;
     s->inst_w2o.resize(desc->num_instances);
     for (uint32_t i = 0; i < desc->num_instances; ++i) invert_affine(desc->instances[i].transform, s->inst_w2o[i].data());
     s->num_lights = (int)desc->num_lights;
@@ -629,7 +644,7 @@ int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *st
     compute_view(a->camera, a->width, a->height, f.vp);
     f.vp.frame_offset = a->frame_offset;
     for (uint32_t m = 0; m < s->view.desc->num_materials; ++m)
-        if (s->view.desc->materials[m].normal_map != -1) return -4; // textures unsupported
+        if (s->view.desc->materials[m].normal_map != -1 && (uint32_t)s->view.desc->materials[m].normal_map >= s->view.desc->num_textures) return -4;
     int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     // work items: 64-pixel segments of a row, handed out through one atomic counter
@@ -740,7 +755,8 @@ void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo
                      float *pdf, float *mis_pdf, float *f3, float *wpdf) {
     GLTFMaterial mat;
     vec3 emit;
-    unpack_material(mat, emit, *m);
+    static const TextureTable no_textures; // probes take untextured materials
+    unpack_material(no_textures, mat, emit, *m, vec2(0, 0));
     for (int i = 0; i < n; ++i) {
         vec3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]);
         vec3 vx, vy;
@@ -761,7 +777,8 @@ void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo
 void orc_gltf_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
     GLTFMaterial mat;
     vec3 emit;
-    unpack_material(mat, emit, *m);
+    static const TextureTable no_textures; // probes take untextured materials
+    unpack_material(no_textures, mat, emit, *m, vec2(0, 0));
     for (int i = 0; i < n; ++i) {
         vec3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
         vec3 fv = gltf_bsdf(mat, nn, wo, wi);
@@ -804,6 +821,14 @@ void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,d
     compute_view(*c, W, H, vp);
     const vec3 *v[4] = {&vp.cam_pos, &vp.cam_du, &vp.cam_dv, &vp.cam_dir_top_left};
     for (int i = 0; i < 4; ++i) { out12[3 * i] = v[i]->x; out12[3 * i + 1] = v[i]->y; out12[3 * i + 2] = v[i]->z; }
+}
+// probe: n samples of texture `tex_id` of the scene at uv (2 floats each) -> rgba (4 floats each)
+void orc_texture_probe(void *p, int tex_id, const float *uv, int n, float *out4) {
+    Scene *s = (Scene *)p;
+    for (int i = 0; i < n; ++i) {
+        const vec4 c = texture_lod0(s->textures, tex_id, vec2(uv[2 * i], uv[2 * i + 1]));
+        out4[4 * i] = c.x; out4[4 * i + 1] = c.y; out4[4 * i + 2] = c.z; out4[4 * i + 3] = c.w;
+    }
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }

@@ -250,33 +250,93 @@ struct SimpleMaterial {
     float ior;
     uint32_t flags;
 };
-// rendering/rt/material_textures.glsl:95-135 with every standard texture being
-// the 1x1 texel that holds the literal BaseMaterial values (alpha = 1):
-// texel = (p.base_color, 1); specular texel = (p.specular, p.roughness, p.metallic).
-static inline float unpack_material(GLTFMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p) {
-    float alpha = 1.0f;
-    mat.base_color = vec3(p.base_color[0], p.base_color[1], p.base_color[2]);
+// ---- textures: textureLod(sampler2D, uv, 0) with the reference's material sampler (render_vulkan.cpp:1657-1670: linear
+// filter, REPEAT addressing), restated in software. Texel centres at (i + 0.5) / size, bilinear weights in float, unorm
+// byte / 255, sRGB decode (IEC 61966-2-1) per texel before filtering. The reference runs this on the GPU's texture unit,
+// whose fixed-point weights are not specified bit for bit: "parity unpinned", tolerance-level agreement only.
+struct TextureTable {
+    const RptrTextureDesc *textures = nullptr;
+    uint32_t num_textures = 0;
+    float srgb_lut[256];
+    TextureTable() {
+        for (int i = 0; i < 256; ++i) {
+            const float c = float(i) / 255.0f;
+            srgb_lut[i] = c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f);
+        }
+    }
+};
+static inline vec4 fetch_texel(const TextureTable &tt, const RptrTextureDesc &t, int ix, int iy) {
+    const uint8_t *c = t.rgba8 + 4 * ((size_t)iy * t.width + (size_t)ix);
+    if (t.srgb) return vec4(tt.srgb_lut[c[0]], tt.srgb_lut[c[1]], tt.srgb_lut[c[2]], float(c[3]) / 255.0f);
+    return vec4(float(c[0]) / 255.0f, float(c[1]) / 255.0f, float(c[2]) / 255.0f, float(c[3]) / 255.0f);
+}
+static inline int wrap_repeat(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+static inline vec4 texture_lod0(const TextureTable &tt, int tex_id, vec2 uv) {
+    const RptrTextureDesc &t = tt.textures[tex_id];
+    const int w = (int)t.width, h = (int)t.height;
+    const float x = uv.x * float(w) - 0.5f, y = uv.y * float(h) - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int ix0 = wrap_repeat(int(x0), w), ix1 = wrap_repeat(int(x0) + 1, w);
+    const int iy0 = wrap_repeat(int(y0), h), iy1 = wrap_repeat(int(y0) + 1, h);
+    const vec4 c00 = fetch_texel(tt, t, ix0, iy0), c10 = fetch_texel(tt, t, ix1, iy0), c01 = fetch_texel(tt, t, ix0, iy1),
+               c11 = fetch_texel(tt, t, ix1, iy1);
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const vec4 top(c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx);
+    const vec4 bot(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
+    return vec4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
+}
+// rendering/rt/material_textures.glsl:37-60 (NO_TEXTURE_GRAD: textureLod with bias 0)
+static inline bool is_textured_param(float x) { return (float_bits(x) & RPTR_TEXTURED_PARAM_MASK) != 0u; }
+static inline vec4 textured_color_param(const TextureTable &tt, vec4 x, vec2 uv) {
+    const uint32_t mask = float_bits(x.x);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) return texture_lod0(tt, int(RPTR_TEXTURE_ID(mask)), uv);
+    return x;
+}
+static inline float textured_scalar_param(const TextureTable &tt, float x, vec2 uv) {
+    const uint32_t mask = float_bits(x);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) {
+        const vec4 t = texture_lod0(tt, int(RPTR_TEXTURE_ID(mask)), uv);
+        const uint32_t ch = RPTR_TEXTURE_CHANNEL(mask);
+        return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
+    }
+    return x;
+}
+// rendering/rt/material_textures.glsl:95-135, non-unrolled standard textures (a parameter is a literal or a texture handle);
+// PREMULTIPLIED_BASE_COLOR_ALPHA is defined (vulkan/gpu_params.glsl:12)
+static inline float unpack_material(const TextureTable &tt, GLTFMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+    const vec4 texel = textured_color_param(tt, vec4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f), uv);
+    float alpha = texel.w;
+    mat.base_color = vec3(texel.x, texel.y, texel.z);
     if (alpha > 0.001f)
         mat.base_color /= alpha;
-    mat.specular = p.specular;
-    mat.roughness = p.roughness;
-    mat.metallic = p.metallic;
-    mat.ior = p.ior;
+    mat.specular = textured_scalar_param(tt, p.specular, uv);
+    mat.roughness = textured_scalar_param(tt, p.roughness, uv);
+    mat.metallic = textured_scalar_param(tt, p.metallic, uv);
+    mat.ior = textured_scalar_param(tt, p.ior, uv);
     emitter_radiance = vec3(p.base_color[0], p.base_color[1], p.base_color[2]) * p.emission_intensity;
-    if (p.emission_intensity != 0.0f)
+    if (p.emission_intensity != 0.0f) {
+        if (is_textured_param(p.base_color[0])) emitter_radiance = mat.base_color * p.emission_intensity;
         mat.base_color = vec3(0.0f);
+    }
     mat.flags = p.flags; // load_material, gltf_bsdf.glsl:38-62
     return alpha;
 }
 // same with SIMPLIFIED_MATERIAL (simple_bsdf.glsl:14-16,31-39)
-static inline float unpack_material(SimpleMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p) {
-    float alpha = 1.0f;
-    mat.base_color = vec3(p.base_color[0], p.base_color[1], p.base_color[2]);
+static inline float unpack_material(const TextureTable &tt, SimpleMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+    const vec4 texel = textured_color_param(tt, vec4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f), uv);
+    float alpha = texel.w;
+    mat.base_color = vec3(texel.x, texel.y, texel.z);
     if (alpha > 0.001f)
         mat.base_color /= alpha;
     emitter_radiance = vec3(p.base_color[0], p.base_color[1], p.base_color[2]) * p.emission_intensity;
-    if (p.emission_intensity != 0.0f)
+    if (p.emission_intensity != 0.0f) {
+        if (is_textured_param(p.base_color[0])) emitter_radiance = mat.base_color * p.emission_intensity;
         mat.base_color = vec3(0.0f);
+    }
     mat.roughness = 1.0f;
     mat.ior = 1.0f;
     mat.flags = p.flags;

@@ -150,6 +150,25 @@ class InstanceDesc(C.Structure):
     _fields_ = [("transform", C.c_float * 12), ("parameterized_mesh", C.c_uint32)]
 
 
+class TextureDesc(C.Structure):  # include/rptr_hip.h RptrTextureDesc
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("srgb", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+def textured_param(texture_id, channel=0):
+    """The float whose bits say "read this parameter from a texture" (rendering/bsdfs/texture_channel_mask.h): sign bit,
+    channel in bits 29..30 (scalar parameters), texture index in bits 0..28. Returned as a Python float that converts back to
+    exactly these bits when stored into a c_float (NaN payloads survive the float32 round trip only by luck, so this goes
+    through struct pack/unpack of the float32 itself)."""
+    import struct
+    bits = 0x80000000 | ((channel & 3) << 29) | (texture_id & 0x1FFFFFFF)
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+def set_float_bits(carray, index, bits):
+    """writes raw bits into element `index` of a ctypes float array (Python floats cannot carry every NaN payload)"""
+    C.cast(carray, C.POINTER(C.c_uint32))[index] = bits & 0xFFFFFFFF
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("geometries", C.POINTER(GeometryDesc)), ("num_geometries", C.c_uint32),
@@ -158,6 +177,7 @@ class SceneDesc(C.Structure):
         ("instances", C.POINTER(InstanceDesc)), ("num_instances", C.c_uint32),
         ("materials", C.POINTER(BaseMaterial)), ("num_materials", C.c_uint32),
         ("lights", C.POINTER(TriLightData)), ("num_lights", C.c_uint32),
+        ("textures", C.POINTER(TextureDesc)), ("num_textures", C.c_uint32),
     ]
 
 

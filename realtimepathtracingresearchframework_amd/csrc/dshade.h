@@ -35,6 +35,13 @@ struct RpGeomRecord { // 64 bytes
     uint32_t flags;
 };
 
+struct RpTexture { // RptrTextureDesc on the device
+    const uchar4 *texels;
+    int width, height;
+    int srgb;
+    int _pad;
+};
+
 struct RpScene {
     const RptrBvh4Node *nodes;
     const RptrBvhTri *tris;
@@ -45,7 +52,9 @@ struct RpScene {
     int32_t num_lights;
     int32_t num_materials;
     uint32_t num_nodes;
-    uint32_t _pad;
+    int32_t num_textures;
+    const RpTexture *textures;
+    const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)
 };
 
 // the per-frame constants: RenderParams + SceneParams + ViewParams subset
@@ -174,6 +183,7 @@ struct RpHit { // rendering/rt/hit.glsl:12-23
     int material_id;
     V3 tangent;
     float bitangent_l;
+    V2 uv;
 };
 RP_DEV int rp_hit_material_id(const RpGeomRecord &g, uint32_t prim) { // rendering/rt/hit.glsl:49-56
     if (g.material_id < 0)
@@ -222,8 +232,10 @@ RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t
     bool requires_tangent = true;
     h.geo_normal = mul(normals_to_world, h.geo_normal);
     h.normal = norm3(mul(normals_to_world, h.normal));
+    h.uv = v2(0.0f, 0.0f);
     if (has_uvs) {
         V2 uva = rp_dequantize_uv(uint32_t(qa >> 32)), uvb = rp_dequantize_uv(uint32_t(qb >> 32)), uvc = rp_dequantize_uv(uint32_t(qc >> 32));
+        h.uv = v2((uva.x * bary.x + uvb.x * bary.y) + uvc.x * bary.z, (uva.y * bary.x + uvb.y * bary.y) + uvc.y * bary.z); // uvs * bary
         float posframe_det = len3(gn);
         V3 frame_n = gn / (posframe_det * posframe_det);
         V3 dp2perp = cross3(vc - va, frame_n);
@@ -253,25 +265,72 @@ struct RpMaterial { // GLTFMaterial (gltf_bsdf.glsl:15-35) / SimpleMaterial (sim
     float metallic, specular, roughness, ior;
     uint32_t flags;
 };
-// rendering/rt/material_textures.glsl:95-135 with 1x1 literal standard texels
-template <int VARIANT>
-RP_DEV void rp_unpack_material(RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p) {
-    const float alpha = 1.0f;
-    V3 bc = v3(p.base_color[0], p.base_color[1], p.base_color[2]);
-    m.base_color = bc / alpha;
+// ---- texture sampling: textureLod(sampler2D, uv, 0) of the reference's material sampler (linear filter, REPEAT,
+// render_vulkan.cpp:1657-1670), in software: texel centres at (i + 0.5) / size, bilinear weights in float,
+// unorm byte / 255, sRGB decode per texel through the host-computed table before filtering (as the hardware does)
+RP_DEV float4 rp_texel(const RpScene &sc, const RpTexture &t, int ix, int iy) {
+    const uchar4 c = t.texels[(size_t)iy * (size_t)t.width + (size_t)ix];
+    if (t.srgb) return make_float4(sc.srgb_lut[c.x], sc.srgb_lut[c.y], sc.srgb_lut[c.z], float(c.w) / 255.0f);
+    return make_float4(float(c.x) / 255.0f, float(c.y) / 255.0f, float(c.z) / 255.0f, float(c.w) / 255.0f);
+}
+RP_DEV int rp_wrap_repeat(int i, int n) {
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+RP_DEV float4 rp_texture_lod0(const RpScene &sc, int tex_id, V2 uv) {
+    const RpTexture t = sc.textures[tex_id];
+    const float x = uv.x * float(t.width) - 0.5f, y = uv.y * float(t.height) - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int ix0 = rp_wrap_repeat(int(x0), t.width), ix1 = rp_wrap_repeat(int(x0) + 1, t.width);
+    const int iy0 = rp_wrap_repeat(int(y0), t.height), iy1 = rp_wrap_repeat(int(y0) + 1, t.height);
+    const float4 c00 = rp_texel(sc, t, ix0, iy0), c10 = rp_texel(sc, t, ix1, iy0), c01 = rp_texel(sc, t, ix0, iy1), c11 = rp_texel(sc, t, ix1, iy1);
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    const float4 top = make_float4(c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx);
+    const float4 bot = make_float4(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
+    return make_float4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
+}
+// rendering/rt/material_textures.glsl:37-60
+RP_DEV bool rp_is_textured(float x) { return (__float_as_uint(x) & RPTR_TEXTURED_PARAM_MASK) != 0u; }
+RP_DEV float4 rp_textured_color_param(const RpScene &sc, float4 x, V2 uv) {
+    const uint32_t mask = __float_as_uint(x.x);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) return rp_texture_lod0(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+    return x;
+}
+RP_DEV float rp_textured_scalar_param(const RpScene &sc, float x, V2 uv) {
+    const uint32_t mask = __float_as_uint(x);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) {
+        const float4 t = rp_texture_lod0(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+        const uint32_t ch = RPTR_TEXTURE_CHANNEL(mask);
+        return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
+    }
+    return x;
+}
+// rendering/rt/material_textures.glsl:95-135 (non-unrolled standard textures: a parameter is a literal or a texture handle;
+// PREMULTIPLIED_BASE_COLOR_ALPHA is defined, vulkan/gpu_params.glsl:12)
+template <int VARIANT, bool TEX>
+RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p, V2 uv) {
+    const float4 literal = make_float4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f);
+    const float4 texel = TEX ? rp_textured_color_param(sc, literal, uv) : literal;
+    const float alpha = texel.w;
+    m.base_color = v3(texel.x, texel.y, texel.z);
+    if (alpha > 0.001f) m.base_color = m.base_color / alpha;
     if (VARIANT == RPTR_VARIANT_SIMPLE) { // simple_bsdf.glsl:31-39
         m.roughness = 1.0f;
         m.ior = 1.0f;
         m.metallic = 0.0f;
         m.specular = 0.0f;
     } else {
-        m.specular = p.specular;
-        m.roughness = p.roughness;
-        m.metallic = p.metallic;
-        m.ior = p.ior;
+        m.specular = TEX ? rp_textured_scalar_param(sc, p.specular, uv) : p.specular;
+        m.roughness = TEX ? rp_textured_scalar_param(sc, p.roughness, uv) : p.roughness;
+        m.metallic = TEX ? rp_textured_scalar_param(sc, p.metallic, uv) : p.metallic;
+        m.ior = TEX ? rp_textured_scalar_param(sc, p.ior, uv) : p.ior;
     }
-    emitter_radiance = bc * p.emission_intensity;
-    if (p.emission_intensity != 0.0f) m.base_color = v3s(0.0f);
+    emitter_radiance = v3(p.base_color[0], p.base_color[1], p.base_color[2]) * p.emission_intensity;
+    if (p.emission_intensity != 0.0f) {
+        if (TEX && rp_is_textured(p.base_color[0])) emitter_radiance = m.base_color * p.emission_intensity;
+        m.base_color = v3s(0.0f);
+    }
     m.flags = p.flags;
 }
 

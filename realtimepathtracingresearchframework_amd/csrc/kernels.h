@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 #endif
 // LIGHTS = false: the scene has no emissive triangles, every NEE sample goes to the sun (sun_radiance.w == 1,
 // vulkan/render_sky.cpp:68-71) and the binned-RIS code is compiled out (fewer registers, smaller kernel)
-template <int VARIANT, bool FIRST, bool LIGHTS>
+// TEX = false: no material of the scene reads a texture (textured parameters, normal maps): sampling code compiled out
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX>
 __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
@@ -481,6 +482,18 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                             gn = -gn;
                         }
                     }
+                    // :634-654 normal mapping
+                    if (TEX && mp.normal_map != -1) {
+                        V3 t_y = norm3(cross3(hit.normal, hit.tangent));
+                        V3 t_x = cross3(t_y, hit.normal);
+                        t_x = t_x * len3(hit.tangent);
+                        t_y = t_y * hit.bitangent_l;
+                        const float4 tx = rp_texture_lod0(sc, mp.normal_map, hit.uv);
+                        V3 map_nrm = v3(2.0f * tx.x - 1.0f, 2.0f * tx.y - 1.0f, 1.0f * tx.z - 0.0f);
+                        map_nrm.z = sqrtf(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
+                        const V3 t_z = f.sp.normal_z_scale * nn;
+                        nn = norm3((t_x * map_nrm.x + t_y * map_nrm.y) + t_z * map_nrm.z);
+                    }
                     // :656-668
                     {
                         const float nw = dot3(w_o, nn);
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
 
                     // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
                     V3 emit;
-                    rp_unpack_material<VARIANT>(mat, emit, mp);
+                    rp_unpack_material<VARIANT, TEX>(sc, mat, emit, mp, hit.uv);
                     scatter_throughput = throughput;
                     if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
                         // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137

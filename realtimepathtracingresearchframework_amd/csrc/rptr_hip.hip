@@ -125,6 +125,7 @@ struct rptr_hip {
     std::vector<MeshRt> meshes;
     std::vector<void *> scene_allocs;
     int num_lights = 0, num_materials = 0;
+    bool uses_textures = false; // some material has a textured parameter or a normal map
     // dynamic meshes (Mesh::Dynamic: float vertex buffer + BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354)
     SceneCopy master;                       // dscene + the refit targets of the handle
     std::vector<SceneCopy> ctx_scene;       // one per frame context when the scene is dynamic and frames_in_flight > 1
@@ -736,18 +737,27 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->scene_allocs.clear();
     h->have_scene = false;
     // ---- validation (what the reference host rejects or this build does not cover yet)
+    if (s->num_textures && !s->textures) return fail(h, RPTR_E_INVALID, "num_textures = %u but textures is NULL", s->num_textures);
+    for (uint32_t t = 0; t < s->num_textures; ++t)
+        if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].width > 16384 || s->textures[t].height > 16384)
+            return fail(h, RPTR_E_INVALID, "texture %u: bad size or NULL data", t);
+    h->uses_textures = false;
     for (uint32_t m = 0; m < s->num_materials; ++m) {
         const RptrBaseMaterial &mat = s->materials[m];
-        if (mat.normal_map != -1) return fail(h, RPTR_E_UNSUPPORTED, "material %u: normal maps / textures are not supported yet", m);
+        if (mat.normal_map != -1) h->uses_textures = true;
+        if (mat.normal_map != -1 && (mat.normal_map < 0 || (uint32_t)mat.normal_map >= s->num_textures))
+            return fail(h, RPTR_E_INVALID, "material %u: normal_map %d is not a texture of this scene (%u textures)", m, mat.normal_map, s->num_textures);
+        // alpha-tested geometry: the reference's test is stochastic and draws random numbers in the driver's candidate order
+        // (pt_megakernel.glsl:153-212); not built
         if ((mat.flags & RPTR_BASE_MATERIAL_NOALPHA) == 0)
             return fail(h, RPTR_E_UNSUPPORTED, "material %u: alpha-tested materials are not supported yet (set BASE_MATERIAL_NOALPHA)", m);
-        const uint32_t bits[4] = {0, 0, 0, 0};
-        (void)bits;
-        uint32_t u;
         const float vals[5] = {mat.base_color[0], mat.roughness, mat.specular, mat.metallic, mat.ior};
         for (float v : vals) {
+            uint32_t u;
             memcpy(&u, &v, 4);
-            if (u & 0x80000000u) return fail(h, RPTR_E_UNSUPPORTED, "material %u: textured parameters are not supported yet", m);
+            if (u & RPTR_TEXTURED_PARAM_MASK) h->uses_textures = true;
+            if ((u & RPTR_TEXTURED_PARAM_MASK) && RPTR_TEXTURE_ID(u) >= s->num_textures)
+                return fail(h, RPTR_E_INVALID, "material %u: textured parameter refers to texture %u of %u", m, RPTR_TEXTURE_ID(u), s->num_textures);
         }
     }
     for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p)
@@ -756,6 +766,33 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         if (s->instances[i].parameterized_mesh >= s->num_parameterized_meshes) return fail(h, RPTR_E_INVALID, "instance %u: bad mesh", i);
 
     int rc;
+    // ---- textures (RGBA8) + the sRGB decode table
+    RpTexture *d_textures = nullptr;
+    float *d_srgb_lut = nullptr;
+    {
+        std::vector<RpTexture> tex(s->num_textures);
+        for (uint32_t t = 0; t < s->num_textures; ++t) {
+            const RptrTextureDesc &td = s->textures[t];
+            uchar4 *dt = nullptr;
+            const size_t n = (size_t)td.width * td.height;
+            if ((rc = dev_alloc(h, &dt, n, &h->scene_allocs))) return rc;
+            HIP_TRY(h, hipMemcpy(dt, td.rgba8, n * 4, hipMemcpyHostToDevice));
+            tex[t].texels = dt;
+            tex[t].width = (int)td.width;
+            tex[t].height = (int)td.height;
+            tex[t].srgb = td.srgb ? 1 : 0;
+            tex[t]._pad = 0;
+        }
+        if ((rc = dev_alloc(h, &d_textures, std::max<size_t>(1, tex.size()), &h->scene_allocs))) return rc;
+        if (!tex.empty()) HIP_TRY(h, hipMemcpy(d_textures, tex.data(), tex.size() * sizeof(RpTexture), hipMemcpyHostToDevice));
+        float lut[256]; // IEC 61966-2-1 decode of an 8-bit code (what a VK_FORMAT_*_SRGB fetch returns before filtering)
+        for (int i = 0; i < 256; ++i) {
+            const float c = float(i) / 255.0f;
+            lut[i] = c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f);
+        }
+        if ((rc = dev_alloc(h, &d_srgb_lut, 256, &h->scene_allocs))) return rc;
+        HIP_TRY(h, hipMemcpy(d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    }
     // ---- upload vertex streams, one allocation per stream
     std::vector<const uint64_t *> d_qpos(s->num_geometries, nullptr), d_qnu(s->num_geometries, nullptr);
     for (uint32_t g = 0; g < s->num_geometries; ++g) {
@@ -942,6 +979,9 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_lights = (int)s->num_lights;
     h->master.dscene.num_materials = (int)s->num_materials;
     h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
+    h->master.dscene.num_textures = (int)s->num_textures;
+    h->master.dscene.textures = d_textures;
+    h->master.dscene.srgb_lut = d_srgb_lut;
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
     // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites
@@ -1121,10 +1161,18 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, const RpScene &scene, const R
     };
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
-    if (bounce == 0)
-        lights ? go(rp_k_shade<VARIANT, true, true>) : go(rp_k_shade<VARIANT, true, false>);
-    else
-        lights ? go(rp_k_shade<VARIANT, false, true>) : go(rp_k_shade<VARIANT, false, false>);
+    const bool tex = h->uses_textures;
+    if (bounce == 0) {
+        if (tex)
+            lights ? go(rp_k_shade<VARIANT, true, true, true>) : go(rp_k_shade<VARIANT, true, false, true>);
+        else
+            lights ? go(rp_k_shade<VARIANT, true, true, false>) : go(rp_k_shade<VARIANT, true, false, false>);
+    } else {
+        if (tex)
+            lights ? go(rp_k_shade<VARIANT, false, true, true>) : go(rp_k_shade<VARIANT, false, false, true>);
+        else
+            lights ? go(rp_k_shade<VARIANT, false, true, false>) : go(rp_k_shade<VARIANT, false, false, false>);
+    }
 }
 
 static void add_counters(RpCounters &dst, const RpCounters &c) {

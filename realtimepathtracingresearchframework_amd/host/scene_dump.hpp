@@ -7,7 +7,8 @@
 // has_attribute_stream; u64 qpos[3*num_tris]; u64 qnrm_uv[3*num_tris] if present; per mesh: u32 first_geometry,
 // num_geometries, dynamic; per parameterized mesh: u32 mesh, n; i32 material_offsets[n]; u32 n_ids; u8 ids[n_ids];
 // per instance: f32 transform[12], u32 parameterized_mesh; RptrBaseMaterial[]; RptrTriLightData[]; then RptrCamera,
-// RptrSceneParams, RptrRenderParams, RptrLightSamplingConfig.
+// RptrSceneParams, RptrRenderParams, RptrLightSamplingConfig; optionally u32 num_textures and per texture u32 width,
+// height, srgb + width*height RGBA8 texels.
 #pragma once
 #include "../../include/rptr_hip.h"
 
@@ -33,6 +34,8 @@ struct SceneDump {
     RptrSceneParams scene_params{};
     RptrRenderParams render_params{};
     RptrLightSamplingConfig lighting{};
+    std::vector<std::vector<uint8_t>> texels;
+    std::vector<RptrTextureDesc> textures;
 
     RptrSceneDesc desc() const {
         RptrSceneDesc d{};
@@ -48,6 +51,8 @@ struct SceneDump {
         d.num_materials = (uint32_t)materials.size();
         d.lights = lights.empty() ? nullptr : lights.data();
         d.num_lights = (uint32_t)lights.size();
+        d.textures = textures.empty() ? nullptr : textures.data();
+        d.num_textures = (uint32_t)textures.size();
         return d;
     }
 
@@ -128,6 +133,22 @@ struct SceneDump {
         rd(&s.scene_params, sizeof(s.scene_params));
         rd(&s.render_params, sizeof(s.render_params));
         rd(&s.lighting, sizeof(s.lighting));
+        uint32_t ntex = 0; // optional trailing section: u32 count, per texture u32 width, height, srgb + RGBA8 rows
+        if (std::fread(&ntex, 4, 1, f) == 1 && ntex) {
+            s.texels.resize(ntex);
+            s.textures.resize(ntex);
+            for (uint32_t i = 0; i < ntex; ++i) {
+                uint32_t h3[3];
+                rd(h3, sizeof(h3));
+                s.texels[i].resize((size_t)h3[0] * h3[1] * 4);
+                rd(s.texels[i].data(), s.texels[i].size());
+                s.textures[i].rgba8 = s.texels[i].data();
+                s.textures[i].width = h3[0];
+                s.textures[i].height = h3[1];
+                s.textures[i].srgb = h3[2];
+                s.textures[i]._pad = 0;
+            }
+        }
         std::fclose(f);
         return s;
     }

@@ -123,6 +123,12 @@ class SceneConfig:  # librender/render_params.glsl.h:157-162
 
 
 @dataclass
+class Texture:
+    rgba: np.ndarray  # (height, width, 4) uint8, row 0 first
+    srgb: bool = False
+
+
+@dataclass
 class Scene:
     name: str
     geometries: List[Geometry] = field(default_factory=list)
@@ -131,6 +137,7 @@ class Scene:
     instances: List[Instance] = field(default_factory=list)
     materials: List[abi.BaseMaterial] = field(default_factory=list)
     lights: np.ndarray = field(default_factory=lambda: np.zeros((0, 4, 3), dtype=f32))  # binned TriLightData
+    textures: List[Texture] = field(default_factory=list)
     camera: dict = field(default_factory=dict)
     config: SceneConfig = field(default_factory=SceneConfig)
     sky_key: str = ""
@@ -172,6 +179,11 @@ class Scene:
             f.write(bytes(self.scene_params()))
             f.write(bytes(rp))
             f.write(bytes(lc))
+            f.write(struct.pack("<I", len(self.textures)))  # optional trailing section (absent in files without textures)
+            for t in self.textures:
+                px = np.ascontiguousarray(t.rgba, dtype=np.uint8)
+                f.write(struct.pack("<3I", px.shape[1], px.shape[0], 1 if t.srgb else 0))
+                f.write(px.tobytes())
 
     def num_tris(self):
         return sum(g.num_tris for g in self.geometries)
@@ -241,7 +253,16 @@ class Scene:
         d.instances, d.num_instances = I, len(self.instances)
         d.materials, d.num_materials = MAT, len(self.materials)
         d.lights, d.num_lights = LT, nl
-        keep += [G, M, P, I, MAT, LT]
+        TX = (abi.TextureDesc * max(1, len(self.textures)))()
+        for i, t in enumerate(self.textures):
+            px = np.ascontiguousarray(t.rgba, dtype=np.uint8)
+            assert px.ndim == 3 and px.shape[2] == 4
+            keep.append(px)
+            TX[i].rgba8 = px.ctypes.data
+            TX[i].height, TX[i].width = px.shape[0], px.shape[1]
+            TX[i].srgb = 1 if t.srgb else 0
+        d.textures, d.num_textures = TX, len(self.textures)
+        keep += [G, M, P, I, MAT, LT, TX]
         self._keep = keep
         return d
 
@@ -660,6 +681,68 @@ def soup(seed, n_meshes=3, tris_per_mesh=200, n_instances=9, degenerate=True) ->
         M = np.concatenate([M3, t[:, None]], axis=1).astype(f32)
         s.instances.append(Instance(transform=M, pmesh=int(i % n_meshes)))
     s.camera = dict(eye=(0, 1, 9), center=(0, 0, 0), up=(0, 1, 0), fov=55.0)
+    s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s
+
+
+# ------------------------------------------------------------------ textured materials (a8 / a9)
+def textured_test(nx=24, nz=24) -> Scene:
+    """A bumpy patch and a flat quad whose materials read their parameters from textures: sRGB base colour (checker with a
+    gradient), a linear "specular / roughness / metallic" texture read per channel, and a tangent-space normal map (sinusoidal
+    dimples); plus a small emissive quad whose emission colour is textured and an untextured wall. UVs tile 3x over the patch
+    (REPEAT addressing)."""
+    s = Scene(name="textured_test")
+    rng = np.random.default_rng(3)
+    # texture 0: base colour, sRGB, 16x8 (non-square on purpose)
+    yy, xx = np.meshgrid(np.arange(8), np.arange(16), indexing="ij")
+    chk = ((xx // 2 + yy // 2) % 2).astype(np.float32)
+    base = np.stack([60 + 180 * chk, 40 + 12 * xx, 220 - 20 * yy, np.full_like(chk, 255)], axis=2)
+    s.textures.append(Texture(rgba=base.astype(np.uint8), srgb=True))
+    # texture 1: specular (r), roughness (g), metallic (b), linear, 8x8 noise
+    spec = rng.integers(0, 256, (8, 8, 4)).astype(np.uint8)
+    spec[..., 1] = np.clip(spec[..., 1], 40, 230)
+    spec[..., 2] = np.where(spec[..., 2] > 128, 255, 0)
+    spec[..., 3] = 255
+    s.textures.append(Texture(rgba=spec, srgb=False))
+    # texture 2: normal map, linear, 32x32 dimples
+    v, u = np.meshgrid((np.arange(32) + 0.5) / 32, (np.arange(32) + 0.5) / 32, indexing="ij")
+    nxm = 0.45 * np.sin(2 * np.pi * 2 * u)
+    nym = 0.45 * np.cos(2 * np.pi * 3 * v)
+    nzm = np.sqrt(np.maximum(1 - nxm * nxm - nym * nym, 0))
+    nm = np.stack([nxm * 0.5 + 0.5, nym * 0.5 + 0.5, nzm, np.ones_like(nzm)], axis=2)
+    s.textures.append(Texture(rgba=np.clip(np.round(nm * 255), 0, 255).astype(np.uint8), srgb=False))
+    # texture 3: emission colour, sRGB, 2x2
+    s.textures.append(Texture(rgba=np.array([[[255, 200, 120, 255], [255, 240, 200, 255]], [[240, 160, 90, 255], [255, 255, 255, 255]]], np.uint8), srgb=True))
+
+    P, N, UV = _heightfield(nx, nz, -2.0, 2.0, -2.0, 2.0, lambda X, Z: 0.25 * np.sin(1.7 * X) * np.cos(1.3 * Z))
+    UV = (np.asarray(UV, dtype=f32).reshape(-1, 2) * f32(3.0)).reshape(np.asarray(UV).shape)   # tile the textures 3x
+    m0 = _add_mesh(s, P, N, UV)
+    flat = np.array(_quad((-2, 0.9, -2), (2, 0.9, -2), (2, 2.5, -2.4), (-2, 2.5, -2.4)), dtype=f32)
+    fuv = np.array([[[0, 0], [2, 0], [2, 1]], [[0, 0], [2, 1], [0, 1]]], dtype=f32)
+    fn = np.tile(np.array([0, 0.243, 0.970], dtype=f32), (2, 3, 1))
+    m1 = _add_mesh(s, flat, fn, fuv)
+    em = np.array(_quad((-0.6, 2.2, 0.8), (0.6, 2.2, 0.8), (0.6, 2.2, -0.2), (-0.6, 2.2, -0.2)), dtype=f32)
+    euv = np.array([[[0, 0], [1, 0], [1, 1]], [[0, 0], [1, 1], [0, 1]]], dtype=f32)
+    m2 = _add_mesh(s, em, np.tile(np.array([0, -1, 0], dtype=f32), (2, 3, 1)), euv)
+
+    def textured(normal_map=-1, emission=0.0, base_tex=0, spec_tex=None):
+        m = abi.make_material((0.8, 0.8, 0.8), roughness=0.5, emission_intensity=emission)
+        abi.set_float_bits(m.base_color, 0, 0x80000000 | base_tex)
+        m.normal_map = normal_map
+        if spec_tex is not None:
+            for fieldname, ch in (("specular", 0), ("roughness", 1), ("metallic", 2)):
+                setattr(m, fieldname, abi.textured_param(spec_tex, ch))
+        return m
+    s.materials = [textured(normal_map=2, spec_tex=1), textured(normal_map=-1), textured(emission=12.0, base_tex=3),
+                   abi.make_material((0.7, 0.7, 0.75), roughness=0.6)]
+    s.pmeshes.append(ParameterizedMesh(mesh=m0, material_offsets=np.array([0], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m1, material_offsets=np.array([1], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m2, material_offsets=np.array([2], np.int32)))
+    for k in range(3):
+        s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=k))
+    s.camera = dict(eye=(0.3, 1.6, 4.2), center=(0, 0.5, 0), up=(0, 1, 0), fov=50.0)
     s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
     s.sky_key = "low_sun"
     s.prepare_lights()

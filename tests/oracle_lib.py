@@ -65,6 +65,7 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats)]
         L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
+        L.orc_texture_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_hw_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -97,6 +98,12 @@ class OracleScene:
         c = (C.c_uint64 * 3)()
         lib().orc_scene_build_bvh(self.h, c)
         return tuple(int(x) for x in c)
+
+    def texture_probe(self, tex_id, uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        lib().orc_texture_probe(self.h, int(tex_id), _p(uv), len(uv), _p(out))
+        return out
 
     def set_dynamic_vertices(self, geometry, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

@@ -201,7 +201,12 @@ def test_error_convention(small_scenes):
         r.render(backend.RenderConfiguration(small_scenes["cornell"].camera_params()), spp=1)  # before set_scene
     r.initialize(32, 32)
     bad = scenes.cornell32()
-    bad.materials[0].normal_map = 3
+    bad.materials[0].normal_map = 3                          # not a texture of the scene
+    with pytest.raises(backend.BackendError) as e:
+        r.set_scene(bad)
+    assert e.value.code == abi.RPTR_E_INVALID
+    bad = scenes.cornell32()
+    bad.materials[0].flags &= ~abi.BASE_MATERIAL_NOALPHA     # alpha-tested geometry is not built
     with pytest.raises(backend.BackendError) as e:
         r.set_scene(bad)
     assert e.value.code == abi.RPTR_E_UNSUPPORTED
@@ -409,4 +414,43 @@ def test_fuzz_soups_trace_and_image(seed):
     ref_img, _ = osc.render(96, 64, 2, variant=abi.VARIANT_GLTF)
     rmse, same, _ = image_error(img, ref_img)
     assert same and rmse < RMSE_TOL
+    r.close()
+
+
+# ---------------------------------------------------------------- textured materials (a8 / a9)
+@pytest.mark.parametrize("variant", [abi.VARIANT_GLTF, abi.VARIANT_SIMPLE])
+def test_textured_materials_and_normal_map_image_parity(variant):
+    """base colour (sRGB), specular / roughness / metallic channels, a tangent-space normal map and a textured emitter:
+    image within tolerance of the oracle, ray counts equal, and the textures do matter"""
+    s = scenes.textured_test()
+    W, H, spp = 160, 120, 4
+    img, st, _ = gpu_render(s, W, H, spp, variant)
+    ref, ost = O.OracleScene(s).render(W, H, spp, variant=variant)
+    rmse, same, _ = image_error(img, ref)
+    assert same and rmse < RMSE_TOL
+    assert st.raw.rays_closest == ost.rays_closest and abs(int(st.raw.rays_shadow) - ost.rays_shadow) <= 1e-3 * ost.rays_shadow
+    plain = scenes.textured_test()
+    for m in plain.materials:
+        m.normal_map = -1
+    img2, _, _ = gpu_render(plain, W, H, spp, variant)
+    assert image_error(img, img2)[0] > 10 * RMSE_TOL
+
+
+def test_texture_handles_are_validated():
+    s = scenes.textured_test()
+    s.materials[0].normal_map = 9
+    r = backend.RenderHip()
+    r.initialize(32, 32)
+    with pytest.raises(backend.BackendError) as e:
+        r.set_scene(s)
+    assert e.value.code == abi.RPTR_E_INVALID
+    s = scenes.textured_test()
+    abi.set_float_bits(s.materials[1].base_color, 0, 0x80000000 | 77)
+    with pytest.raises(backend.BackendError):
+        r.set_scene(s)
+    s = scenes.textured_test()
+    s.materials[0].flags &= ~abi.BASE_MATERIAL_NOALPHA        # alpha-tested geometry is not built
+    with pytest.raises(backend.BackendError) as e:
+        r.set_scene(s)
+    assert e.value.code == abi.RPTR_E_UNSUPPORTED
     r.close()

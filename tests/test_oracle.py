@@ -336,3 +336,48 @@ def test_dynamic_vertices_rebuild_equals_brute_force():
     y = o[hit, 1] + tuv_t[hit, 0] * d[hit, 1]
     tri = P.reshape(-1, 3, 3)[ids_t[hit, 2]]
     assert (y >= tri[:, :, 1].min(axis=1) - 1e-3).all() and (y <= tri[:, :, 1].max(axis=1) + 1e-3).all()
+
+
+# ---------------------------------------------------------------- textures (a8 / a9)
+def test_texture_sampling_semantics():
+    """textureLod(.., 0) with linear filter + REPEAT: texel centres reproduce the texels, the midpoint of two texels is
+    their mean, coordinates wrap, sRGB textures are decoded before filtering (alpha stays linear)."""
+    s = scenes.textured_test()
+    osc = O.OracleScene(s)
+    t0, t1 = s.textures[0].rgba, s.textures[1].rgba           # 16x8 sRGB, 8x8 linear
+    h, w = t1.shape[:2]
+    iy, ix = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    centres = np.stack([(ix + 0.5) / w, (iy + 0.5) / h], axis=2).reshape(-1, 2)
+    got = osc.texture_probe(1, centres).reshape(h, w, 4)
+    assert np.array_equal(got, t1.astype(np.float32) / np.float32(255.0))
+    # wrap: +3 / -2 periods (up to the rounding of the coordinate itself)
+    assert np.allclose(osc.texture_probe(1, centres + np.array([3.0, -2.0])).reshape(h, w, 4), got, atol=2e-6)
+    # midpoint between texel (0,0) and (1,0)
+    mid = osc.texture_probe(1, [[1.0 / w, 0.5 / h]])[0]
+    assert np.allclose(mid, (t1[0, 0].astype(np.float32) + t1[0, 1].astype(np.float32)) / 510.0, atol=1e-6)
+    # across the border: texel (w-1, 0) and (0, 0)
+    edge = osc.texture_probe(1, [[0.0, 0.5 / h]])[0]
+    assert np.allclose(edge, (t1[0, -1].astype(np.float32) + t1[0, 0].astype(np.float32)) / 510.0, atol=1e-6)
+    # sRGB decode at texel centres
+    h0, w0 = t0.shape[:2]
+    c = osc.texture_probe(0, [[(3 + 0.5) / w0, (2 + 0.5) / h0]])[0]
+    e = t0[2, 3].astype(np.float64) / 255.0
+    lin = np.where(e <= 0.04045, e / 12.92, ((e + 0.055) / 1.055) ** 2.4)
+    assert np.allclose(c[:3], lin[:3], rtol=1e-5) and c[3] == 1.0
+    assert np.array_equal(osc.texture_probe(0, [[0.5 / w0, 0.5 / h0]])[0, 3:], [1.0])
+
+
+def test_textured_parameters_change_the_render_and_bad_handles_are_rejected():
+    s = scenes.textured_test()
+    osc = O.OracleScene(s)
+    img, _ = osc.render(96, 72, 2, variant=abi.VARIANT_GLTF)
+    assert np.isfinite(img).all()
+    flat = scenes.textured_test()
+    for m in flat.materials:                    # same scene without the normal map
+        m.normal_map = -1
+    img2, _ = O.OracleScene(flat).render(96, 72, 2, variant=abi.VARIANT_GLTF)
+    assert not np.array_equal(img, img2)
+    bad = scenes.textured_test()
+    bad.materials[0].normal_map = 17            # not a texture of the scene
+    with pytest.raises(AssertionError):
+        O.OracleScene(bad).render(32, 32, 1)

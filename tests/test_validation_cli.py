@@ -109,6 +109,22 @@ def test_cli_rejects_bad_mode_combinations(tmp_path):
 
 
 @pytest.mark.gpu
+def test_textured_scene_through_the_dump_and_the_cli(tmp_path):
+    """textures travel in the scene dump: the C++ host renders the textured scene like the Python mirror, bit for bit"""
+    from common import gpu_render
+    exe = _build_cli(tmp_path)
+    s = scenes.textured_test()
+    path = str(tmp_path / "tex.rpsc")
+    s.dump(path)
+    prefix = str(tmp_path / "tex")
+    p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", "2", "--img", "96", "72", "--pfm"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    img = read_pfm(prefix + "_0002.pfm")
+    ref, _, _ = gpu_render(s, 96, 72, 2, abi.VARIANT_GLTF)
+    assert np.array_equal(img.view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_profiling_mode_csv_images_and_camera_flags(tmp_path):
     """profiling mode on a static scene: one CSV row per frame with the reference's header, frames accumulate, an image per
     second of animation time; --eye/--center/--fov move the camera (compared with the Python mirror)."""
