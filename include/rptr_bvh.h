@@ -61,8 +61,10 @@ typedef struct RptrBvhTri {
     float e2[3]; /* v2 - v0 */
     uint32_t prim;     /* primitive index inside its geometry                    */
     uint32_t geom;     /* geometry index inside its mesh (rayQuery GeometryIndex) */
-    uint32_t _pad;
+    uint32_t flags;    /* RPTR_BVH_TRI_ALPHA: some parameterized mesh gives this triangle a material without
+                          BASE_MATERIAL_NOALPHA, i.e. a hit is a candidate for the alpha test (pt_megakernel.glsl:153-212) */
 } RptrBvhTri;
+#define RPTR_BVH_TRI_ALPHA 1u
 
 /* 128 bytes */
 typedef struct RptrBvhInstance {

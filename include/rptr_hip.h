@@ -47,7 +47,9 @@ extern "C" {
 #define RPTR_BINNED_LIGHTS_BIN_MAX_SIZE 16
 #define RPTR_RAY_EPSILON 0.000005f /* vulkan/gpu_params.glsl:27-29 */
 
-/* material flags, rendering/bsdfs/base_material.h.glsl:7-11 */
+/* material flags, rendering/bsdfs/base_material.h.glsl:7-11. A material WITHOUT NOALPHA is alpha-tested: every hit
+ * candidate on it goes through the reference's any-hit test (vulkan/pt_megakernel.glsl:153-212) with the alpha channel of
+ * its base colour texture (1 for a literal colour). */
 #define RPTR_BASE_MATERIAL_NOALPHA 0x01
 #define RPTR_BASE_MATERIAL_ONESIDED 0x02
 #define RPTR_BASE_MATERIAL_VOLUME 0x04

@@ -333,6 +333,20 @@ static void build_bvh(const SceneView &sv, Bvh &bvh) {
     std::vector<RptrBvhNode> blas_nodes;
     std::vector<int> mesh_root(s->num_meshes, -1);
     std::vector<std::array<float, 6>> mesh_box(s->num_meshes);
+    // RPTR_BVH_TRI_ALPHA (include/rptr_bvh.h): the triangle has a material without BASE_MATERIAL_NOALPHA in some
+    // parameterized mesh of its mesh
+    std::vector<std::vector<uint8_t>> tri_alpha(s->num_meshes);
+    for (uint32_t pm = 0; pm < s->num_parameterized_meshes; ++pm) {
+        const auto &p = s->parameterized_meshes[pm];
+        const auto &mesh = s->meshes[p.mesh];
+        size_t at = 0;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j)
+            for (uint32_t t = 0; t < s->geometries[mesh.first_geometry + j].num_tris; ++t, ++at) {
+                if (tri_alpha[p.mesh].size() <= at) tri_alpha[p.mesh].resize(at + 1, 0);
+                const long mid = (long)p.material_offsets[j] + (p.tri_material_ids ? (long)p.tri_material_ids[at] : 0);
+                if (mid >= 0 && mid < (long)s->num_materials && !(s->materials[mid].flags & RPTR_BASE_MATERIAL_NOALPHA)) tri_alpha[p.mesh][at] = 1;
+            }
+    }
     for (uint32_t m = 0; m < s->num_meshes; ++m) {
         const auto &mesh = s->meshes[m];
         std::vector<BuildRef> refs;
@@ -347,7 +361,8 @@ static void build_bvh(const SceneView &sv, Bvh &bvh) {
                 t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
                 t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z;
                 t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z;
-                t.prim = p; t.geom = j; t._pad = 0;
+                t.prim = p; t.geom = j;
+                t.flags = (mtris.size() < tri_alpha[m].size() && tri_alpha[m][mtris.size()]) ? RPTR_BVH_TRI_ALPHA : 0u;
                 BuildRef r;
                 for (int k = 0; k < 3; ++k) {
                     r.lo[k] = fminf(v0[k], fminf(v1[k], v2[k]));
@@ -433,16 +448,24 @@ static inline void decode_leaf(int enc, int &first, int &count) {
     count = RPTR_BVH_LEAF_COUNT(enc);
 }
 static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
+// The reference's any-hit stage (vulkan/pt_megakernel.glsl:153-212, generate_candidate_hit): called for every hit of a
+// triangle flagged RPTR_BVH_TRI_ALPHA that the query would otherwise accept, in the canonical order of this traversal;
+// true = the candidate is ignored and the traversal goes on. The reference leaves the order in which candidates turn up
+// to the driver ("parity unpinned"); oracle and device agree on the order below.
+struct AlphaTest {
+    virtual bool reject(const RptrBvhInstance &inst, const RptrBvhTri &tri, float t, float u, float v) = 0;
+    virtual ~AlphaTest() {}
+};
 template <bool ANY>
-static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt);
+static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha);
 template <bool ANY>
-static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt);
+static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha);
 template <bool ANY>
-static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
-    return bvh.nodes4.empty() ? traverse2<ANY>(bvh, ray, best, cnt) : traverse4<ANY>(bvh, ray, best, cnt);
+static bool traverse(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha = nullptr) {
+    return bvh.nodes4.empty() ? traverse2<ANY>(bvh, ray, best, cnt, alpha) : traverse4<ANY>(bvh, ray, best, cnt, alpha);
 }
 template <bool ANY>
-static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
+static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha) {
     best.t = ray.tmax;
     best.inst = -1;
     best.u = best.v = 0;
@@ -507,6 +530,7 @@ static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                     const int ii = cur_inst->instance_id;
                     const bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii, (int)tr.geom, (int)tr.prim, best));
                     if (!accept) continue;
+                    if (alpha && (tr.flags & RPTR_BVH_TRI_ALPHA) && alpha->reject(*cur_inst, tr, t, u, v)) continue;
                     best.t = t; best.u = u; best.v = v;
                     best.inst = ii; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
                     best.lo = o; best.ld = d;
@@ -528,7 +552,7 @@ static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
 // key = (bits(t_near) & 0x7FFFFFFC) | slot ascending; the first is visited next, the others are pushed
 // so that the nearest pops first. Leaves, instances and the triangle test are those of traverse2.
 template <bool ANY>
-static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt) {
+static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha) {
     best.t = ray.tmax;
     best.inst = -1;
     best.u = best.v = 0;
@@ -605,6 +629,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                     const int ii2 = cur_inst->instance_id;
                     const bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii2, (int)tr.geom, (int)tr.prim, best));
                     if (!accept) continue;
+                    if (alpha && (tr.flags & RPTR_BVH_TRI_ALPHA) && alpha->reject(*cur_inst, tr, t, u, v)) continue;
                     best.t = t; best.u = u; best.v = v;
                     best.inst = ii2; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
                     best.lo = o; best.ld = d;

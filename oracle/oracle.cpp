@@ -30,6 +30,7 @@ thread_local bool g_debug_on = false;
 
 struct ViewParams { // the subset of vulkan/gpu_params.glsl:61-87 the path reads
     uint32_t frame_offset;
+    uint32_t frame_id; // samples accumulated before this frame (render_vulkan.cpp:2913)
     uint32_t dims_x, dims_y;
     vec3 cam_pos, cam_du, cam_dv, cam_dir_top_left;
 };
@@ -60,8 +61,11 @@ struct Scene {
     std::vector<std::array<float, 12>> inst_w2o; // per scene instance, oracle's own inverse
     std::vector<RptrTriLightData> lights;        // padded by one zeroed bin (see sample_tri_lights)
     int num_lights = 0;
+    bool alpha_test = false; // some material lacks BASE_MATERIAL_NOALPHA
 };
 
+struct Frame;
+struct PathCounters;
 struct Frame {
     const Scene *sc;
     const Bvh *bvh; // nullptr -> brute force
@@ -75,6 +79,8 @@ struct Frame {
 struct PathCounters {
     uint64_t rays_closest = 0, rays_shadow = 0, hits = 0;
     TraceCounters tc_closest, tc_shadow;
+    uint32_t px = 0, py = 0;   // gl_GlobalInvocationID.xy of the pixel sample being traced (alpha test of shadow rays)
+    LCGRand *path_rng = nullptr; // the path's generator (alpha test of closest-hit queries: `#define alpha_rng rng`)
 };
 
 // diagnostic ray log (single-threaded renders only): 9 floats per ray = o, tmin, d, tmax, any(0/1)
@@ -87,24 +93,73 @@ static inline void log_ray(const Ray &r, bool any) {
     p[4] = r.d.x; p[5] = r.d.y; p[6] = r.d.z; p[7] = r.tmax;
     p[8] = any ? 1.0f : 0.0f;
 }
+// vulkan/pt_megakernel.glsl:153-212 generate_candidate_hit: uv of the candidate (calc_hit_attributes, hit.glsl:99-101),
+// its material, alpha of the base colour parameter (material_textures.glsl:137-145), then the stochastic test
+static bool candidate_rejected(const Scene &sc, const RptrBvhInstance &inst, const RptrBvhTri &tri, float u, float v, LCGRand &alpha_rng) {
+    const RptrInstanceDesc &idesc = sc.view.desc->instances[inst.instance_id];
+    const GeomRecord &geom = sc.view.geoms[sc.view.pmesh_geom_base[idesc.parameterized_mesh] + (int)tri.geom];
+    const int material_id = calc_hit_material_id(geom.material_id, geom.mat_ids, tri.prim);
+    const RptrBaseMaterial &mat_params = sc.view.desc->materials[material_id];
+    if ((mat_params.flags & RPTR_BASE_MATERIAL_NOALPHA) != 0) return false;
+    float alpha = 1.0f; // vec4(p.base_color, 1.0f).a for a literal colour
+    const uint32_t mask = float_bits(mat_params.base_color[0]);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) {
+        vec2 uv(0, 0);
+        if (geom.g->has_uvs != 0 && geom.g->qnrm_uv) {
+            mat3x2 uvs;
+            for (int k = 0; k < 3; ++k) uvs.c[k] = dequantize_uv(uint32_t(geom.g->qnrm_uv[3 * (size_t)tri.prim + k] >> 32));
+            uv = uvs * vec3(1.f - u - v, u, v);
+        }
+        alpha = texture_lod0(sc.textures, (int)RPTR_TEXTURE_ID(mask), uv).w;
+    }
+    if (!(alpha > 0.0f) || (alpha < 1.0f && lcg_randomf(alpha_rng) > alpha)) return true;
+    return false;
+}
+struct ClosestAlpha : AlphaTest { // :446-472: the candidates of a closest-hit query draw from the path's generator
+    const Scene &sc;
+    LCGRand &rng;
+    ClosestAlpha(const Scene &s, LCGRand &r) : sc(s), rng(r) {}
+    bool reject(const RptrBvhInstance &inst, const RptrBvhTri &tri, float, float u, float v) override { return candidate_rejected(sc, inst, tri, u, v, rng); }
+};
+struct ShadowAlpha : AlphaTest { // :251-262: a generator per candidate, seeded from (primitive ^ frame_id, instance ^ frame_offset, pixel)
+    const Frame &f;
+    uint32_t px, py;
+    ShadowAlpha(const Frame &fr, uint32_t x, uint32_t y) : f(fr), px(x), py(y) {}
+    bool reject(const RptrBvhInstance &inst, const RptrBvhTri &tri, float, float u, float v) override {
+        LCGRand alpha_rng = get_lcg_rng(tri.prim ^ f.vp.frame_id, uint32_t(inst.instance_id) ^ f.vp.frame_offset, px, py, f.vp.dims_x);
+        return candidate_rejected(*f.sc, inst, tri, u, v, alpha_rng);
+    }
+};
 static inline bool trace_closest(const Frame &f, const Ray &r, Hit &h, PathCounters &pc) {
     pc.rays_closest++;
     log_ray(r, false);
-    if (f.bvh) return traverse<false>(*f.bvh, r, h, f.count ? &pc.tc_closest : nullptr);
-    return brute_force<false>(f.sc->view, r, h);
+    if (f.bvh) {
+        if (f.sc->alpha_test && pc.path_rng) {
+            ClosestAlpha a(*f.sc, *pc.path_rng);
+            return traverse<false>(*f.bvh, r, h, f.count ? &pc.tc_closest : nullptr, &a);
+        }
+        return traverse<false>(*f.bvh, r, h, f.count ? &pc.tc_closest : nullptr);
+    }
+    return brute_force<false>(f.sc->view, r, h); // opaque scenes only
 }
 static inline bool trace_any(const Frame &f, const Ray &r, PathCounters &pc) {
     pc.rays_shadow++;
     log_ray(r, true);
     Hit h;
-    if (f.bvh) return traverse<true>(*f.bvh, r, h, f.count ? &pc.tc_shadow : nullptr);
-    return brute_force<true>(f.sc->view, r, h);
+    if (f.bvh) {
+        if (f.sc->alpha_test) {
+            ShadowAlpha a(f, pc.px, pc.py);
+            return traverse<true>(*f.bvh, r, h, f.count ? &pc.tc_shadow : nullptr, &a);
+        }
+        return traverse<true>(*f.bvh, r, h, f.count ? &pc.tc_shadow : nullptr);
+    }
+    return brute_force<true>(f.sc->view, r, h); // opaque scenes only
 }
 
 // vulkan/geometry.glsl:76-78
 static inline float geometry_scale_to_tmin(vec3 orig, float geometry_scale) { return (length(orig) + geometry_scale) * RPTR_RAY_EPSILON; }
 
-// vulkan/pt_megakernel.glsl:216-272 (opaque geometry: every synthetic material is NOALPHA)
+// vulkan/pt_megakernel.glsl:216-272 (the candidate loop with the alpha test is trace_any + ShadowAlpha)
 static inline bool raytrace_test_visibility(const Frame &f, float geometry_scale, const vec3 from, const vec3 dir, float dist, PathCounters &pc) {
     float epsilon = geometry_scale_to_tmin(from, geometry_scale);
     if (dist - 2.f * epsilon > 0.0f) {
@@ -320,6 +375,9 @@ template <class MAT>
 static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_index, PathCounters &pc) {
     const Scene &sc = *f.sc;
     LCGRand rng = get_lcg_rng(sample_index, f.vp.frame_offset, px, py, f.vp.dims_x);
+    pc.px = px;
+    pc.py = py;
+    pc.path_rng = &rng;
     vec2 point = vec2(px + 0.5f, py + 0.5f);
     if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng) - vec2(0.5f));
     point = point / vec2((float)f.vp.dims_x, (float)f.vp.dims_y);
@@ -484,6 +542,8 @@ void *orc_scene_create(const RptrSceneDesc *desc) {
     s->inst_w2o.resize(desc->num_instances);
     for (uint32_t i = 0; i < desc->num_instances; ++i) invert_affine(desc->instances[i].transform, s->inst_w2o[i].data());
     s->num_lights = (int)desc->num_lights;
+    for (uint32_t m = 0; m < desc->num_materials; ++m)
+        if (!(desc->materials[m].flags & RPTR_BASE_MATERIAL_NOALPHA)) s->alpha_test = true;
     s->lights.assign(desc->lights, desc->lights + desc->num_lights);
     RptrTriLightData z;
     memset(&z, 0, sizeof(z));
@@ -643,6 +703,7 @@ int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *st
     f.count = a->count_traversal != 0;
     compute_view(a->camera, a->width, a->height, f.vp);
     f.vp.frame_offset = a->frame_offset;
+    f.vp.frame_id = uint32_t(a->sample_begin);
     for (uint32_t m = 0; m < s->view.desc->num_materials; ++m)
         if (s->view.desc->materials[m].normal_map != -1 && (uint32_t)s->view.desc->materials[m].normal_map >= s->view.desc->num_textures) return -4;
     int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();

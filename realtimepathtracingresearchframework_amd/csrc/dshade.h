@@ -77,6 +77,8 @@ struct RpFrame {
     int32_t npix_padded;         // tiles_x*tiles_y*64
     int32_t rank, world, stripe_rows;
     int32_t num_bins;            // SCENE_GET_BINNED_LIGHTS_BIN_COUNT (pt_megakernel.glsl:103)
+    int32_t alpha_test;          // the scene has alpha-tested materials: the first extend hands its generator on in the path state
+    uint32_t frame_id;           // view_params.frame_id: samples accumulated before this render call (render_vulkan.cpp:2913)
     // regrouping pass (kernels.h "sort"): hit-cell grid over the scene bounds
     float sort_lo[3];
     int32_t sort_groups;         // material groups
@@ -204,6 +206,14 @@ RP_DEV void rp_geom_tri(const RpGeomRecord &g, uint32_t prim, V3 &a, V3 &b, V3 &
     b = rp_dequantize_position(q[1], sc, of);
     c = rp_dequantize_position(q[2], sc, of);
 }
+// the uv part of calc_hit_attributes alone (hit.glsl:99-101): what the alpha test of a candidate needs
+RP_DEV V2 rp_hit_uv(const RpGeomRecord &g, uint32_t prim, float bu, float bv) {
+    if ((g.flags & RP_GEOM_HAS_UVS) == 0) return v2(0.0f, 0.0f);
+    const V3 bary = v3(1.f - bu - bv, bu, bv);
+    const uint64_t *q = g.qnrm_uv + 3ull * prim;
+    const V2 uva = rp_dequantize_uv(uint32_t(q[0] >> 32)), uvb = rp_dequantize_uv(uint32_t(q[1] >> 32)), uvc = rp_dequantize_uv(uint32_t(q[2] >> 32));
+    return v2((uva.x * bary.x + uvb.x * bary.y) + uvc.x * bary.z, (uva.y * bary.x + uvb.y * bary.y) + uvc.y * bary.z);
+}
 // rendering/rt/hit.glsl:58-128 via the quantised overload :162-203
 RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t prim, float bu, float bv, const M3 &normals_to_world) {
     RpHit h;
@@ -305,6 +315,21 @@ RP_DEV float rp_textured_scalar_param(const RpScene &sc, float x, V2 uv) {
         return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
     }
     return x;
+}
+// The any-hit test of a candidate (pt_megakernel.glsl:153-212 generate_candidate_hit + material_textures.glsl:137-145
+// get_material_alpha = the alpha of the base colour parameter at the hit's uv, 1 for a literal colour): true = the
+// candidate is ignored. A fractional alpha draws one number from `rng` -- the path's own generator for closest-hit
+// queries (RNG_VARIANT_UNIFORM: `#define alpha_rng rng`, :354-358), a generator seeded per candidate for shadow rays.
+RP_DEV bool rp_alpha_rejects(const RpScene &sc, int inst_idx, int geom, int prim, float bu, float bv, uint32_t &rng) {
+    const int geometry_base = reinterpret_cast<const int *>(sc.insts + inst_idx)[13]; // RptrBvhInstance::geometry_base
+    const RpGeomRecord &g = sc.geoms[geometry_base + geom];
+    const RptrBaseMaterial &m = sc.materials[rp_hit_material_id(g, uint32_t(prim))];
+    if ((m.flags & RPTR_BASE_MATERIAL_NOALPHA) != 0u) return false;
+    const uint32_t mask = __float_as_uint(m.base_color[0]);
+    float alpha = 1.0f;
+    if (mask & RPTR_TEXTURED_PARAM_MASK) alpha = rp_texture_lod0(sc, int(RPTR_TEXTURE_ID(mask)), rp_hit_uv(g, uint32_t(prim), bu, bv)).w;
+    if (!(alpha > 0.0f)) return true;
+    return alpha < 1.0f && rp_randf(rng) > alpha;
 }
 // rendering/rt/material_textures.glsl:95-135 (non-unrolled standard textures: a parameter is a literal or a texture handle;
 // PREMULTIPLIED_BASE_COLOR_ALPHA is defined, vulkan/gpu_params.glsl:12)

@@ -101,6 +101,9 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 // rays do not leave lanes idle while the longest ray of the wave finishes.
 //   Load(i, o, d, tmin, tmax)  fetches queue entry i
 //   Done(i, hit)               consumes the result of entry i
+//   Alpha(i, inst_idx, inst_id, geom, prim, u, v) -> true = ignore this candidate (ALPHA only: the reference's
+//                              any-hit test of alpha-tested materials, pt_megakernel.glsl:153-212); called for the
+//                              hits of triangles flagged RPTR_BVH_TRI_ALPHA that would otherwise be accepted
 //
 // The kernels are instruction-issue bound (profiles/r01_notes.md), so the node step
 // is written for instruction count: packed v_pk_add/v_pk_mul for the 12 slab planes
@@ -141,10 +144,13 @@ RP_DEV V3 rp_cross_fma(V3 a, V3 b) { return v3(fmaf(a.y, b.z, -(b.y * a.z)), fma
 #ifdef RP_PROF
 __device__ unsigned long long rp_prof[16];
 #endif
-template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN), class Load,
-          class Done>
-RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, uint32_t &n_nodes,
-                          uint32_t &n_tris) {
+struct RpNoAlpha {
+    RP_DEV bool operator()(uint32_t, int, int, int, int, float, float) const { return false; }
+};
+template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN),
+          bool ALPHA = false, class Load, class Done, class Alpha>
+RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
+                          uint32_t &n_nodes, uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
     const uint32_t tid = threadIdx.x;
     const uint32_t gstride = gridDim.x * blockDim.x;
@@ -420,6 +426,10 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                         accept = geom < best.geom;
                                     else
                                         accept = prim < best.prim;
+                                }
+                                if (ALPHA) {
+                                    if (accept && (__float_as_uint(q2.w) & RPTR_BVH_TRI_ALPHA) != 0u)
+                                        accept = !alpha(my_i, cur_inst, cur_inst_id, geom, prim, un * inv_det, vn * inv_det);
                                 }
                                 if (accept) {
                                     best.t = t;

@@ -134,10 +134,13 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, uint32_t *queue, R
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
 // FIRST: bounce 0, the rays are the camera rays (computed, not loaded)
-template <bool COUNT, bool FIRST>
+// ALPHA: the scene has alpha-tested materials. The test of a candidate may draw from the path's generator
+// (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
+template <bool COUNT, bool FIRST, bool ALPHA>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
+    uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const uint32_t p = queue[i];
         if (FIRST) {
@@ -146,21 +149,32 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
             ro = ld3(f.cam_pos);
             tmin = 0.0f;
             tmax = 2.e32f;
+            if (ALPHA) lane_rng = rng;
         } else {
             const float4 o = ps.ray_o[p], d = ps.ray_d[p];
             ro = xyz(o);
             rd = xyz(d);
             tmin = o.w;
             tmax = d.w;
+            if (ALPHA) lane_rng = lane_rng_in = __float_as_uint(ps.rng_tt[p].x);
         }
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
         const uint32_t p = queue[i];
         ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+        if (ALPHA) {
+            if (FIRST)
+                ps.rng_tt[p] = make_float2(__uint_as_float(lane_rng), 0.0f); // the first shade takes it from here (f.alpha_test)
+            else if (lane_rng != lane_rng_in)
+                reinterpret_cast<float *>(ps.rng_tt + p)[0] = __uint_as_float(lane_rng);
+        }
     };
-    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN)>(sc, bc->queue_count, &bc->cursor_extend, gstack, load,
-                                                                                                                        done, n_nodes, n_tris);
+    auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
+        return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, lane_rng);
+    };
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA>(
+        sc, bc->queue_count, &bc->cursor_extend, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -172,9 +186,21 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
 }
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
-template <bool COUNT>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+// ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
+// instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
+template <bool COUNT, bool ALPHA>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
+    auto alpha = [&](uint32_t i, int inst_idx, int inst_id, int geom, int prim, float u, float v) -> bool {
+        const uint32_t p = sq.ids[i];
+        const uint32_t sslot = p / uint32_t(f.npix_padded);
+        const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
+        int lx = 0, ly = 0;
+        (void)rp_slot_to_local(f, slot, lx, ly);
+        const int gy = rp_local_row_to_global(f, ly);
+        uint32_t rng = rp_rng_seed(uint32_t(prim) ^ f.frame_id, uint32_t(inst_id) ^ f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+        return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, rng);
+    };
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
         const uint32_t p = sq.ids[i];
         const float4 o = sq.o[p], d = sq.d[p];
@@ -194,7 +220,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpPathState ps, RpSh
             ps.illum[p] = il;
         }
     };
-    rp_wave_trace<true, COUNT>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, n_nodes, n_tris);
+    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, alpha, n_nodes,
+                                                                            n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -422,6 +449,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                 my_closest++;
                 if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
                     (void)rp_primary_ray(f, p, rng, ray_dir);
+                    if (f.alpha_test) rng = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
                     ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
                     illum = v3s(0.0f);
@@ -768,7 +796,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
         }
         results[i] = r;
     };
-    rp_wave_trace<ANY, COUNT>(sc, n, cursor, gstack, load, done, nn, nt);
+    rp_wave_trace<ANY, COUNT>(sc, n, cursor, gstack, load, done, RpNoAlpha(), nn, nt); // ray queries see opaque geometry
 }
 
 // ------------------------------------------------------------------ refit (dynamic meshes)

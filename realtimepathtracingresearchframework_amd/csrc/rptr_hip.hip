@@ -125,7 +125,8 @@ struct rptr_hip {
     std::vector<MeshRt> meshes;
     std::vector<void *> scene_allocs;
     int num_lights = 0, num_materials = 0;
-    bool uses_textures = false; // some material has a textured parameter or a normal map
+    bool uses_textures = false;
+    bool uses_alpha = false; // some material lacks BASE_MATERIAL_NOALPHA: extend/connect run the any-hit alpha test // some material has a textured parameter or a normal map
     // dynamic meshes (Mesh::Dynamic: float vertex buffer + BLAS update + TLAS refit, render_vulkan.cpp:942-952,1323-1354)
     SceneCopy master;                       // dscene + the refit targets of the handle
     std::vector<SceneCopy> ctx_scene;       // one per frame context when the scene is dynamic and frames_in_flight > 1
@@ -305,6 +306,25 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
             boxes.push_back(nb);
         }
     };
+    // candidates of the alpha test: a triangle is flagged when some parameterized mesh of its mesh assigns it a material
+    // without BASE_MATERIAL_NOALPHA (the material is per parameterized mesh, the BLAS per mesh; the test itself looks
+    // the material up again, kernels.h rp_alpha_rejects)
+    std::vector<std::vector<uint8_t>> tri_alpha(s->num_meshes);
+    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p) {
+        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[p];
+        const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+        std::vector<uint8_t> &fl = tri_alpha[pm.mesh];
+        size_t off = 0;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const uint32_t nt = s->geometries[mesh.first_geometry + j].num_tris;
+            if (fl.size() < off + nt) fl.resize(off + nt, 0);
+            for (uint32_t t = 0; t < nt; ++t) {
+                const int64_t mid = (int64_t)pm.material_offsets[j] + (pm.tri_material_ids ? (int64_t)pm.tri_material_ids[off + t] : 0);
+                if (mid >= 0 && mid < (int64_t)s->num_materials && (s->materials[mid].flags & RPTR_BASE_MATERIAL_NOALPHA) == 0) fl[off + t] = 1;
+            }
+            off += nt;
+        }
+    }
     for (uint32_t m = 0; m < s->num_meshes; ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
         std::vector<rptr::BuildPrim> prims;
@@ -325,7 +345,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
                 }
                 tri.prim = t;
                 tri.geom = j;
-                tri._pad = 0;
+                tri.flags = (mtris.size() < tri_alpha[m].size() && tri_alpha[m][mtris.size()]) ? RPTR_BVH_TRI_ALPHA : 0u;
                 mtris.push_back(tri);
                 prims.push_back(bp);
             }
@@ -690,7 +710,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->last_resolved = nullptr;
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false>, RP_TRAVERSE_BLOCK, 0));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false>, RP_TRAVERSE_BLOCK, 0));
     occ = std::max(1, std::min(occ, 8));
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
@@ -742,15 +762,13 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].width > 16384 || s->textures[t].height > 16384)
             return fail(h, RPTR_E_INVALID, "texture %u: bad size or NULL data", t);
     h->uses_textures = false;
+    h->uses_alpha = false;
     for (uint32_t m = 0; m < s->num_materials; ++m) {
         const RptrBaseMaterial &mat = s->materials[m];
         if (mat.normal_map != -1) h->uses_textures = true;
         if (mat.normal_map != -1 && (mat.normal_map < 0 || (uint32_t)mat.normal_map >= s->num_textures))
             return fail(h, RPTR_E_INVALID, "material %u: normal_map %d is not a texture of this scene (%u textures)", m, mat.normal_map, s->num_textures);
-        // alpha-tested geometry: the reference's test is stochastic and draws random numbers in the driver's candidate order
-        // (pt_megakernel.glsl:153-212); not built
-        if ((mat.flags & RPTR_BASE_MATERIAL_NOALPHA) == 0)
-            return fail(h, RPTR_E_UNSUPPORTED, "material %u: alpha-tested materials are not supported yet (set BASE_MATERIAL_NOALPHA)", m);
+        if ((mat.flags & RPTR_BASE_MATERIAL_NOALPHA) == 0) h->uses_alpha = true; // alpha test of hit candidates (kernels.h ALPHA)
         const float vals[5] = {mat.base_color[0], mat.roughness, mat.specular, mat.metallic, mat.ior};
         for (float v : vals) {
             uint32_t u;
@@ -1354,6 +1372,8 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     memset(c.host_counters, 0, sizeof(RpCounters));
     int remaining = spp;
     const bool local_work = h->local_rows > 0;
+    f.frame_id = h->frame_id; // the whole call is one frame of the reference (its batch_spp = spp), whatever the internal batches
+    f.alpha_test = h->uses_alpha ? 1 : 0;
     while (remaining > 0) {
         const int batch = std::min(remaining, h->max_batch_spp);
         f.sample_base = h->frame_id;
@@ -1384,10 +1404,15 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, scn.dscene, f, c.ps,
                                            b == 0 ? first_ids : c.queue[in], bc, c.counters, c.gstack);
                     };
-                    if (b == 0)
-                        count_traversal ? go(rp_k_extend<true, true>) : go(rp_k_extend<false, true>);
+                    if (h->uses_alpha) {
+                        if (b == 0)
+                            count_traversal ? go(rp_k_extend<true, true, true>) : go(rp_k_extend<false, true, true>);
+                        else
+                            count_traversal ? go(rp_k_extend<true, false, true>) : go(rp_k_extend<false, false, true>);
+                    } else if (b == 0)
+                        count_traversal ? go(rp_k_extend<true, true, false>) : go(rp_k_extend<false, true, false>);
                     else
-                        count_traversal ? go(rp_k_extend<true, false>) : go(rp_k_extend<false, false>);
+                        count_traversal ? go(rp_k_extend<true, false, false>) : go(rp_k_extend<false, false, false>);
                 });
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
@@ -1417,12 +1442,14 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
                     }
                     timed_on(cs, 1, [&] {
-                        if (count_traversal)
-                            hipLaunchKernelGGL(rp_k_connect<true>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, c.ps, c.sq, bc,
-                                               c.counters, stack);
+                        auto go = [&](auto kernel) {
+                            hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, f, c.ps, c.sq, bc, c.counters,
+                                               stack);
+                        };
+                        if (h->uses_alpha)
+                            count_traversal ? go(rp_k_connect<true, true>) : go(rp_k_connect<false, true>);
                         else
-                            hipLaunchKernelGGL(rp_k_connect<false>, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, c.ps, c.sq, bc,
-                                               c.counters, stack);
+                            count_traversal ? go(rp_k_connect<true, false>) : go(rp_k_connect<false, false>);
                     });
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }

@@ -747,3 +747,79 @@ def textured_test(nx=24, nz=24) -> Scene:
     s.sky_key = "low_sun"
     s.prepare_lights()
     return s
+
+
+def alpha_test() -> Scene:
+    """Alpha-tested geometry (materials without BASE_MATERIAL_NOALPHA; vulkan/pt_megakernel.glsl:153-212): three
+    "foliage" screens behind each other whose base colour texture carries cut-outs (alpha 0), solid texels (alpha 1)
+    and a band of fractional alphas (the stochastic branch of the test), two of them instances of one parameterized mesh;
+    a screen with per-triangle materials of which only one is alpha-tested; an untextured alpha-tested quad (literal
+    colour: alpha 1, always accepted); floor, back wall and an area light so that shadow rays cross the screens."""
+    s = Scene(name="alpha_test")
+    # texture 0: 16x16 RGBA, sRGB colours; alpha: discs cut out, a fractional band, the rest solid
+    yy, xx = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    r2 = ((xx % 8) - 3.5) ** 2 + ((yy % 8) - 3.5) ** 2
+    alpha = np.where(r2 < 6.0, 0, 255).astype(np.int32)
+    alpha[6:10, :] = np.clip(16 * xx[6:10, :] + 8, 0, 255)       # a horizontal band of fractional alphas
+    col = np.stack([80 + 10 * xx, 200 - 8 * yy, 60 + 5 * (xx + yy)], axis=2)
+    s.textures.append(Texture(rgba=np.concatenate([col, alpha[..., None]], axis=2).astype(np.uint8), srgb=True))
+    # texture 1: 4x4, mostly transparent with fractional texels (bilinear filtering makes almost every sample fractional)
+    t1 = np.zeros((4, 4, 4), np.int32)
+    t1[..., 0] = 230
+    t1[..., 1] = 120
+    t1[..., 2] = 40
+    t1[..., 3] = np.array([[0, 90, 255, 40], [200, 0, 130, 255], [255, 60, 0, 180], [20, 255, 110, 0]])
+    s.textures.append(Texture(rgba=t1.astype(np.uint8), srgb=True))
+
+    def screen(z, y0=0.0, y1=2.0, x0=-1.5, x1=1.5, tiles=2.0, cells=1):
+        T, U = [], []
+        for i in range(cells):
+            for j in range(cells):
+                ax0, ax1 = x0 + (x1 - x0) * i / cells, x0 + (x1 - x0) * (i + 1) / cells
+                ay0, ay1 = y0 + (y1 - y0) * j / cells, y0 + (y1 - y0) * (j + 1) / cells
+                u0, u1 = tiles * i / cells, tiles * (i + 1) / cells
+                v0, v1 = tiles * j / cells, tiles * (j + 1) / cells
+                T += _quad((ax0, ay0, z), (ax1, ay0, z), (ax1, ay1, z), (ax0, ay1, z))
+                U += [[[u0, v0], [u1, v0], [u1, v1]], [[u0, v0], [u1, v1], [u0, v1]]]
+        T = np.array(T, dtype=f32)
+        return T, np.tile(np.array([0, 0, 1], dtype=f32), (len(T), 3, 1)), np.array(U, dtype=f32)
+
+    m_screen = _add_mesh(s, *screen(0.0, cells=2))                       # instanced twice (z = 0.9 and z = 0.3 by transform)
+    m_third = _add_mesh(s, *screen(-0.4, tiles=1.0))                    # texture 1
+    m_mixed = _add_mesh(s, *screen(1.5, y0=0.0, y1=0.8, x0=-1.5, x1=1.5, tiles=3.0, cells=3))  # per-triangle materials
+    m_lit = _add_mesh(s, *screen(1.9, y0=0.0, y1=0.5, x0=-0.5, x1=0.5))   # alpha-tested material with a literal colour
+    floor = np.array(_quad((-3, 0, -3), (3, 0, -3), (3, 0, 3), (-3, 0, 3)), dtype=f32)
+    wall = np.array(_quad((-3, 0, -1.2), (3, 0, -1.2), (3, 3, -1.2), (-3, 3, -1.2)), dtype=f32)
+    m_room = _add_mesh(s, np.concatenate([floor, wall]))
+    em = np.array(_quad((-0.5, 2.6, 2.4), (0.5, 2.6, 2.4), (0.5, 2.6, 1.6), (-0.5, 2.6, 1.6)), dtype=f32)
+    m_light = _add_mesh(s, em)
+
+    def cutout(tex):
+        m = abi.make_material((0.8, 0.8, 0.8), roughness=0.7, flags=0)   # no BASE_MATERIAL_NOALPHA
+        abi.set_float_bits(m.base_color, 0, 0x80000000 | tex)
+        return m
+    s.materials = [cutout(0), cutout(1), abi.make_material((0.2, 0.3, 0.8), roughness=0.4),
+                   abi.make_material((0.9, 0.5, 0.1), roughness=0.9, flags=0),
+                   abi.make_material((0.75, 0.75, 0.75)), abi.make_material((1.0, 1.0, 1.0), emission_intensity=25.0)]
+    s.pmeshes.append(ParameterizedMesh(mesh=m_screen, material_offsets=np.array([0], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m_third, material_offsets=np.array([1], np.int32)))
+    mixed_ids = np.array([0, 0, 2, 2, 1, 1, 2, 0, 0, 2, 2, 1, 1, 0, 2, 2, 0, 1], np.uint8)   # materials 0 / 1 (cut-outs) and 2 (opaque)
+    s.pmeshes.append(ParameterizedMesh(mesh=m_mixed, material_offsets=np.array([0], np.int32), tri_material_ids=mixed_ids))
+    s.pmeshes.append(ParameterizedMesh(mesh=m_lit, material_offsets=np.array([3], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m_room, material_offsets=np.array([4], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m_light, material_offsets=np.array([5], np.int32)))
+
+    def shifted(dx, dy, dz, sx=1.0):
+        t = IDENTITY.copy()
+        t[0, 0] = sx
+        t[:, 3] = (dx, dy, dz)
+        return t
+    s.instances.append(Instance(transform=shifted(0.0, 0.0, 0.9), pmesh=0))
+    s.instances.append(Instance(transform=shifted(0.35, 0.1, 0.3, sx=0.9), pmesh=0))
+    for k in range(1, 6):
+        s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=k))
+    s.camera = dict(eye=(0.4, 1.3, 4.6), center=(0, 0.9, 0), up=(0, 1, 0), fov=45.0)
+    s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s

@@ -145,3 +145,20 @@ def test_rebraided_instances_give_the_same_answers(monkeypatch, braid):
     any_b = osc.trace_ex(o, d, 1e-4, 3.0, any_hit=True, bvh_mode=O.BVH_BRUTE)[1][:, 0]
     any_t = osc.trace_ex(o, d, 1e-4, 3.0, any_hit=True, bvh_mode=O.BVH_IMPORTED)[1][:, 0]
     assert np.array_equal(any_b, any_t)
+
+
+def test_alpha_flags_of_the_host_built_tree():
+    """RPTR_BVH_TRI_ALPHA marks exactly the triangles that some parameterized mesh gives an alpha-tested material"""
+    s = scenes.alpha_test()
+    nodes, tris, insts, _ = backend.build_bvh_host(s)
+    t = np.frombuffer(np.ascontiguousarray(tris).tobytes(), dtype=np.uint32).reshape(-1, 12)
+    flags = t[:, 11]
+    expect = 8 + 2 + int(np.isin(s.pmeshes[2].tri_material_ids, (0, 1)).sum()) + 2        # screens, mixed, literal quad
+    assert int(flags.sum()) == expect and set(np.unique(flags)) <= {0, 1}
+    # the oracle walking this tree gives the oracle's own image (closest hits and the candidates met before them agree)
+    osc = O.OracleScene(s)
+    own, _ = osc.render(80, 60, 2)
+    osc.import_bvh(nodes, tris, insts)
+    imp, _ = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED)
+    rmse = float(np.sqrt(np.mean((own[..., :3] - imp[..., :3]).astype(np.float64) ** 2)))
+    assert rmse < 0.05

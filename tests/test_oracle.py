@@ -381,3 +381,51 @@ def test_textured_parameters_change_the_render_and_bad_handles_are_rejected():
     bad.materials[0].normal_map = 17            # not a texture of the scene
     with pytest.raises(AssertionError):
         O.OracleScene(bad).render(32, 32, 1)
+
+
+# ---------------------------------------------------------------- alpha-tested geometry (a5)
+def test_alpha_test_semantics():
+    """pt_megakernel.glsl:153-212: alpha 1 everywhere = opaque (no candidate rejected, no number drawn); alpha 0 everywhere =
+    the geometry is not there; fractional alphas lie in between; NOALPHA materials are never tested."""
+    W, H, spp = 96, 72, 4
+    base = scenes.alpha_test()
+    img, st = O.OracleScene(base).render(W, H, spp)
+    assert np.isfinite(img).all()
+
+    def variant(alpha=None, noalpha=False, drop_cutouts=False):
+        s = scenes.alpha_test()
+        if alpha is not None:
+            for t in s.textures:
+                t.rgba[..., 3] = alpha
+        if noalpha:
+            for m in s.materials:
+                m.flags |= abi.BASE_MATERIAL_NOALPHA
+        if drop_cutouts:       # instances 0..2 use the textured cut-out materials only (screens); 3 = per-triangle mix, stays
+            s.instances = s.instances[3:]
+        return s
+    opaque_tex, _ = O.OracleScene(variant(alpha=255)).render(W, H, spp)
+    opaque_flag, _ = O.OracleScene(variant(alpha=255, noalpha=True)).render(W, H, spp)
+    assert np.array_equal(opaque_tex, opaque_flag)
+    # NOALPHA wins over the texture's alpha channel
+    flagged, _ = O.OracleScene(variant(noalpha=True)).render(W, H, spp)
+    assert np.array_equal(flagged[..., :3] > -1, opaque_flag[..., :3] > -1) and not np.array_equal(flagged, img)
+    # the image with cut-outs differs from both extremes
+    assert not np.array_equal(img, opaque_tex)
+
+
+def test_fully_transparent_screens_equal_the_scene_without_them():
+    """alpha 0: every candidate of the screens is ignored and no random number is consumed, so the paths are those of the
+    scene without the screens (closest hits do not depend on the tree; the per-triangle-material screen is kept in both)"""
+    W, H, spp = 96, 72, 2
+    a = scenes.alpha_test()
+    for t in a.textures:
+        t.rgba[..., 3] = 0
+    a.instances = [a.instances[i] for i in (0, 1, 2, 4, 5, 6)]      # without the mixed screen (it has an opaque material)
+    a.prepare_lights()
+    b = scenes.alpha_test()
+    b.instances = [b.instances[i] for i in (4, 5, 6)]                # literal-colour quad, room, light
+    b.prepare_lights()
+    ia, _ = O.OracleScene(a).render(W, H, spp)
+    ib, _ = O.OracleScene(b).render(W, H, spp)
+    # instance ids differ between the two scenes, which only enters the seeds of rejected-or-not shadow candidates: none here
+    assert np.array_equal(ia, ib)
