@@ -164,6 +164,12 @@ def textured_param(texture_id, channel=0):
     return struct.unpack("<f", struct.pack("<I", bits))[0]
 
 
+def float_bits(value):
+    """the bits of `value` as a float32 (to look at a material parameter that may be a texture handle)"""
+    import struct
+    return struct.unpack("<I", struct.pack("<f", value))[0]
+
+
 def set_float_bits(carray, index, bits):
     """writes raw bits into element `index` of a ctypes float array (Python floats cannot carry every NaN payload)"""
     C.cast(carray, C.POINTER(C.c_uint32))[index] = bits & 0xFFFFFFFF

@@ -349,6 +349,22 @@ def _add_mesh(scene: Scene, tris_xyz, normals=None, uvs=None, dynamic=False):
     return len(scene.meshes) - 1
 
 
+def _add_mesh_segments(scene: Scene, segments):
+    """one mesh with one geometry per entry of `segments` ((n,3,3) positions each), all on the quantisation grid of the whole
+    mesh (what a multi-segment .vks mesh looks like, ext/libvkr/src/vkr.h:189-214); flat normals and zero uvs are left out"""
+    allp = np.concatenate([np.asarray(t, dtype=f32).reshape(-1, 3) for t in segments])
+    lo = allp.min(axis=0).astype(f32)
+    extent = (allp.max(axis=0) - lo).astype(f32)
+    extent = np.where(extent > 0, extent, f32(1e-3)).astype(f32)
+    first = len(scene.geometries)
+    for t in segments:
+        t = np.asarray(t, dtype=f32)
+        scene.geometries.append(Geometry(qpos=quantize_positions(t.reshape(-1, 3), extent, lo), qnrm_uv=None, num_tris=len(t), has_normals=False,
+                                         has_uvs=False, scaling=dequantization_scaling(extent), offset=dequantization_offset(lo, extent)))
+    scene.meshes.append(Mesh(first_geometry=first, num_geometries=len(segments)))
+    return len(scene.meshes) - 1
+
+
 IDENTITY = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], dtype=f32)
 
 
@@ -790,7 +806,7 @@ def alpha_test() -> Scene:
     m_lit = _add_mesh(s, *screen(1.9, y0=0.0, y1=0.5, x0=-0.5, x1=0.5))   # alpha-tested material with a literal colour
     floor = np.array(_quad((-3, 0, -3), (3, 0, -3), (3, 0, 3), (-3, 0, 3)), dtype=f32)
     wall = np.array(_quad((-3, 0, -1.2), (3, 0, -1.2), (3, 3, -1.2), (-3, 3, -1.2)), dtype=f32)
-    m_room = _add_mesh(s, np.concatenate([floor, wall]))
+    m_room = _add_mesh_segments(s, [floor, wall])                          # two segments with a material each
     em = np.array(_quad((-0.5, 2.6, 2.4), (0.5, 2.6, 2.4), (0.5, 2.6, 1.6), (-0.5, 2.6, 1.6)), dtype=f32)
     m_light = _add_mesh(s, em)
 
@@ -806,16 +822,17 @@ def alpha_test() -> Scene:
     mixed_ids = np.array([0, 0, 2, 2, 1, 1, 2, 0, 0, 2, 2, 1, 1, 0, 2, 2, 0, 1], np.uint8)   # materials 0 / 1 (cut-outs) and 2 (opaque)
     s.pmeshes.append(ParameterizedMesh(mesh=m_mixed, material_offsets=np.array([0], np.int32), tri_material_ids=mixed_ids))
     s.pmeshes.append(ParameterizedMesh(mesh=m_lit, material_offsets=np.array([3], np.int32)))
-    s.pmeshes.append(ParameterizedMesh(mesh=m_room, material_offsets=np.array([4], np.int32)))
+    s.pmeshes.append(ParameterizedMesh(mesh=m_room, material_offsets=np.array([4, 2], np.int32)))
     s.pmeshes.append(ParameterizedMesh(mesh=m_light, material_offsets=np.array([5], np.int32)))
 
-    def shifted(dx, dy, dz, sx=1.0):
-        t = IDENTITY.copy()
-        t[0, 0] = sx
+    def placed(dx, dy, dz, scale=1.0, yaw=0.0):      # rotation about y x uniform scale: what a .vks instance can hold
+        c, sn = np.cos(yaw), np.sin(yaw)
+        t = np.zeros((3, 4), f32)
+        t[:, :3] = (scale * np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]])).astype(f32)
         t[:, 3] = (dx, dy, dz)
         return t
-    s.instances.append(Instance(transform=shifted(0.0, 0.0, 0.9), pmesh=0))
-    s.instances.append(Instance(transform=shifted(0.35, 0.1, 0.3, sx=0.9), pmesh=0))
+    s.instances.append(Instance(transform=placed(0.0, 0.0, 0.9), pmesh=0))
+    s.instances.append(Instance(transform=placed(0.35, 0.1, 0.3, scale=0.9, yaw=0.2), pmesh=0))
     for k in range(1, 6):
         s.instances.append(Instance(transform=IDENTITY.copy(), pmesh=k))
     s.camera = dict(eye=(0.4, 1.3, 4.6), center=(0, 0.9, 0), up=(0, 1, 0), fov=45.0)

@@ -1,0 +1,97 @@
+"""Generates the .vks fixtures: a small scene written by realtimepathtracingresearchframework_amd/vks.py
+(tests/golden/vks/alpha_v4.vks, alpha_v3.vks + their texture directories) and, next to each, what the REFERENCE's reader
+makes of it (oracle/_ref/libvkr_ref.so = ext/libvkr/src/vkr.c compiled unmodified + oracle/ref_vkr_driver.c) as
+<name>.ref.json; plus tests/golden/vkr_quantization.json: random inputs and the reference's outputs of
+vkr_dequantize_vertices / vkr_dequantize_normal_uv / vkr_quantize_transform / vkr_dequantize_transform.
+Run in the build container only:
+
+    make -C oracle ref && python tests/golden/gen_vks_fixture.py
+"""
+import ctypes as C
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from realtimepathtracingresearchframework_amd import scenes, vks  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "vks")
+
+
+def ref_lib():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libvkr_ref.so"))
+    lib.ref_vkr_dump.argtypes = [C.c_char_p, C.c_char_p]
+    lib.ref_vkr_last_error.restype = C.c_char_p
+    lib.vkr_dequantize_vertices.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vkr_dequantize_normal_uv.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.vkr_quantize_transform.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vkr_dequantize_transform.argtypes = [C.c_void_p, C.c_void_p]
+    return lib
+
+
+def random_similarity(rng):
+    """float[4][3] = rotation x uniform scale (sometimes mirrored) + translation"""
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    s = float(rng.uniform(0.2, 5.0)) * (-1.0 if rng.random() < 0.25 else 1.0)
+    m = np.zeros((4, 3), np.float32)
+    m[:3] = (r * s).astype(np.float32)
+    m[3] = rng.uniform(-100, 100, 3).astype(np.float32)
+    return m
+
+
+def main():
+    lib = ref_lib()
+    if os.path.isdir(OUT):
+        shutil.rmtree(OUT)
+    os.makedirs(OUT)
+    s = scenes.alpha_test()
+    for version in (4, 3):
+        path = os.path.join(OUT, "alpha_v%d.vks" % version)
+        vks.write_vks(path, s, version=version)
+        rc = lib.ref_vkr_dump(path.encode(), (path[:-4] + ".ref.json").encode())
+        assert rc == 0, (rc, lib.ref_vkr_last_error())
+        d = json.load(open(path[:-4] + ".ref.json"))
+        d["textureDir"] = os.path.relpath(d["textureDir"], OUT)          # machine-independent
+        json.dump(d, open(path[:-4] + ".ref.json", "w"), indent=1)
+    rng = np.random.default_rng(20240917)
+    n = 256
+    vq = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    scale = np.array([3.5e-5, 1.25e-4, 7.0e-6], np.float32)
+    offset = np.array([-12.5, 3.0, 100.25], np.float32)
+    pos = np.zeros((n, 3), np.float32)
+    lib.vkr_dequantize_vertices(vq.ctypes.data, n, scale.ctypes.data, offset.ctypes.data, pos.ctypes.data)
+    nq = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    nq[:8] = [0x80008000, 0x8000FFFF, 0xFFFF8000, 0x00018000, 0x80000001, 0xFFFFFFFF00000000 | 0x7FFF7FFF, 0x0001000180008000, 0xFFFF0000C000C000]
+    nrm = np.zeros((n, 3), np.float32)
+    uv = np.zeros((n, 2), np.float32)
+    lib.vkr_dequantize_normal_uv(nq.ctypes.data, n, nrm.ctypes.data, uv.ctypes.data)
+    mats, packed, back = [], [], []
+    for _ in range(64):
+        m = random_similarity(rng)
+        q = np.zeros(24, np.uint8)
+        lib.vkr_quantize_transform(q.ctypes.data, m.ctypes.data)
+        b = np.zeros((4, 3), np.float32)
+        lib.vkr_dequantize_transform(b.ctypes.data, q.ctypes.data)
+        mats.append(m.view(np.uint32).reshape(-1).tolist())
+        packed.append(q.tolist())
+        back.append(b.view(np.uint32).reshape(-1).tolist())
+    json.dump({"note": "floats as uint32 bit patterns; outputs from the reference's libvkr (ext/libvkr/src/vkr.c:1223-1411)",
+               "vertex_q": [int(x) for x in vq], "vertex_scale": scale.view(np.uint32).tolist(), "vertex_offset": offset.view(np.uint32).tolist(),
+               "vertex_out": pos.view(np.uint32).reshape(-1).tolist(),
+               "normal_uv_q": [int(x) for x in nq], "normal_out": nrm.view(np.uint32).reshape(-1).tolist(), "uv_out": uv.view(np.uint32).reshape(-1).tolist(),
+               "transform_in": mats, "transform_packed": packed, "transform_out": back},
+              open(os.path.join(ROOT, "tests", "golden", "vkr_quantization.json"), "w"))
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

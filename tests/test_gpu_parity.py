@@ -512,3 +512,26 @@ def test_alpha_textures_that_are_opaque_change_nothing():
     ia, _, _ = gpu_render(a, 128, 96, 2, abi.VARIANT_GLTF)
     ib, _, _ = gpu_render(b, 128, 96, 2, abi.VARIANT_GLTF)
     assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
+
+
+# ---------------------------------------------------------------- .vks assets
+@pytest.mark.parametrize("version", [3, 4])
+def test_vks_scene_renders_like_the_oracle(version):
+    """a .vks file + its texture directory (tests/golden/vks, written by vks.py, accepted by the reference's reader) loaded the
+    way Scene::load_vkrs does -- every material textured, normal-mapped and, for the RGBA8 colour textures, alpha-tested"""
+    import os
+    from realtimepathtracingresearchframework_amd import vks
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vks", "alpha_v%d.vks" % version)
+    s = vks.read_vks(path)
+    src = scenes.alpha_test()
+    s.camera, s.config, s.sky_key = src.camera, src.config, src.sky_key
+    assert len(s.textures) == 3 * len(s.materials) and all(m.normal_map >= 0 for m in s.materials)
+    W, H, spp = 160, 120, 4
+    img, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
+    osc = _oracle_on_device_tree(s, r)
+    ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, bvh_mode=O.BVH_IMPORTED)
+    r.close()
+    rmse, same, _ = image_error(img, ref)
+    assert same and rmse < RMSE_TOL
+    assert abs(int(st.raw.rays_closest) - ost.rays_closest) <= 1e-3 * ost.rays_closest
+

@@ -1,0 +1,258 @@
+"""`.vks` / `.vkt` I/O against the reference's own reader: fixtures under tests/golden/vks were written
+by realtimepathtracingresearchframework_amd/vks.py and read back by ext/libvkr/src/vkr.c compiled unmodified
+(oracle/_ref/libvkr_ref.so; generator tests/golden/gen_vks_fixture.py). When that library is present (build container,
+and the GPU box, where the prebuilt .so travels) the comparison is also made live on freshly written scenes."""
+import ctypes as C
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from realtimepathtracingresearchframework_amd import abi, scenes, vks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libvkr_ref.so")
+
+
+def _bits(x):
+    return np.ascontiguousarray(np.asarray(x, np.float32)).view(np.uint32)
+
+
+def _compare_with_dump(path, ref):
+    v = vks.read_vks_header(path)
+    for key in ("version", "flags", "headerSize", "dataOffset", "numMaterials", "numTriangles", "numMeshes", "numInstances", "numLodGroups",
+                "numFrames", "numStaticTransforms", "numAnimatedTransforms"):
+        assert v[key] == ref[key], key
+    if v["version"] >= 4:
+        assert v["animationOffset"] == ref["animationOffset"]
+    assert len(v["meshes"]) == len(ref["meshes"])
+    for m, r in zip(v["meshes"], ref["meshes"]):
+        assert _bits(m["vertexScale"]).tolist() == r["vertexScale"] and _bits(m["vertexOffset"]).tolist() == r["vertexOffset"]
+        for key in ("name", "flags", "numSegments", "materialIdBufferBase", "numMaterialsInRange", "numTriangles", "lodGroup", "vertexBufferOffset",
+                    "normalUvBufferOffset", "materialIdBufferOffset", "materialIdSize", "indexBufferOffset", "segmentNumTriangles",
+                    "segmentMaterialBaseOffsets"):
+            assert m[key] == r[key], key
+    assert [(i["name"], i["meshId"], i["transformIndex"], i["flags"]) for i in v["instances"]] == [
+        (i["name"], i["meshId"], i["transformIndex"], i["flags"]) for i in ref["instances"]]
+    assert [(g["numLevelsOfDetail"], g["meshIds"]) for g in v["lodGroups"]] == [(g["numLevelsOfDetail"], g["meshIds"]) for g in ref["lodGroups"]]
+    assert v["materialNames"] == [m["name"] for m in ref["materials"]]
+    tdir = vks.texture_dir(path)
+    for name, r in zip(v["materialNames"], ref["materials"]):
+        m = vks._load_material_files(tdir, name)
+        for key in ("emissionIntensity", "specularTransmission", "iorEta", "iorK", "translucency"):
+            assert int(_bits(m[key]).reshape(-1)[0]) == r[key], (name, key)
+        assert _bits(m["emitterBaseColor"]).tolist() == r["emitterBaseColor"]
+        for mine, theirs in (("texBaseColor", "texBaseColor"), ("texNormal", "texNormal"), ("texSpecular", "texSpecular")):
+            assert (m[mine] is None) == (r[theirs] is None), (name, mine)
+            if m[mine] is not None:
+                assert m[mine][0].shape[:2] == (r[theirs]["height"], r[theirs]["width"]) and m[mine][1] == r[theirs]["format"]
+    # the transform table as the reference dequantises it
+    assert len(ref["transforms"]) == v["numStaticTransforms"]
+    for k, r in enumerate(ref["transforms"]):
+        mine = vks.dequantize_transform(v["transforms"][24 * k:24 * k + 24])
+        assert _bits(mine).reshape(-1).tolist() == r, "transform %d" % k
+    return v
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_reader_reproduces_the_reference_readers_dump(version):
+    path = os.path.join(GOLD, "vks", "alpha_v%d.vks" % version)
+    ref = json.load(open(path[:-4] + ".ref.json"))
+    v = _compare_with_dump(path, ref)
+    assert v["version"] == version and v["numMeshes"] == 6 and v["numInstances"] == 7
+
+
+def test_quantization_matches_the_reference_vectors():
+    """vkr_dequantize_vertices / _normal_uv / vkr_(de)quantize_transform outputs (fixture from the reference's libvkr) pin the
+    oracle's dequantisation (rows a6 / a7) and this module's transform codec. libvkr returns .vks space: x mirrored, y and z
+    swapped, normals not normalised (vkr.c:1223-1258); the v coordinate is NOT compared: libvkr computes
+    8/65535 * (1 - qv) where the shader (dequantize.glsl:43-48) computes 1 - qv * 8/65535."""
+    g = json.load(open(os.path.join(GOLD, "vkr_quantization.json")))
+    q = np.array(g["vertex_q"], np.uint64)
+    scale = np.array(g["vertex_scale"], np.uint32).view(np.float32)
+    offset = np.array(g["vertex_offset"], np.uint32).view(np.float32)
+    ref = np.array(g["vertex_out"], np.uint32).view(np.float32).reshape(-1, 3)
+    mine = np.zeros((len(q), 3), np.float32)
+    O.lib().orc_dequantize_positions(q.ctypes.data_as(C.c_void_p), len(q), scale.ctypes.data_as(C.c_void_p), offset.ctypes.data_as(C.c_void_p),
+                                     mine.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(_bits(-mine[:, 0]), _bits(ref[:, 0]))
+    assert np.array_equal(_bits(mine[:, 2]), _bits(ref[:, 1])) and np.array_equal(_bits(mine[:, 1]), _bits(ref[:, 2]))
+    assert np.array_equal(scenes.dequantize_positions(q, scale, offset), mine)
+    nq = np.array(g["normal_uv_q"], np.uint64)
+    rn = np.array(g["normal_out"], np.uint32).view(np.float32).reshape(-1, 3)
+    ruv = np.array(g["uv_out"], np.uint32).view(np.float32).reshape(-1, 2)
+    nrm = np.zeros((len(nq), 3), np.float32)
+    uv = np.zeros((len(nq), 2), np.float32)
+    O.lib().orc_dequantize_normal_uv(nq.ctypes.data_as(C.c_void_p), len(nq), nrm.ctypes.data_as(C.c_void_p), uv.ctypes.data_as(C.c_void_p))
+    flipped = np.stack([-rn[:, 0], rn[:, 2], rn[:, 1]], axis=1).astype(np.float64)      # back into the shader's axes
+    ln = np.linalg.norm(flipped, axis=1, keepdims=True)
+    ok = ln[:, 0] > 0
+    assert ok.sum() > 200 and np.allclose(nrm[ok], (flipped / np.where(ln > 0, ln, 1))[ok], atol=2e-7)
+    assert np.array_equal(_bits(uv[:, 0]), _bits(ruv[:, 0]))
+    for m_in, packed, out in zip(g["transform_in"], g["transform_packed"], g["transform_out"]):
+        m = np.array(m_in, np.uint32).view(np.float32).reshape(4, 3)
+        assert list(vks.quantize_transform(m)) == packed
+        assert _bits(vks.dequantize_transform(bytes(packed))).reshape(-1).tolist() == out
+
+
+def test_block_decoders_known_answers():
+    """BC1 / BC4 block layouts: hand-assembled blocks"""
+    # c0 = pure red (0xF800) > c1 = pure blue (0x001F): four-colour mode; texel t uses palette entry t % 4
+    idx = sum((t % 4) << (2 * t) for t in range(16))
+    block = bytes([0x00, 0xF8, 0x1F, 0x00]) + idx.to_bytes(4, "little")
+    img = vks.decode_texture(block, 4, 4, vks.FMT_BC1_RGB_UNORM)
+    assert img[0].tolist() == [[255, 0, 0, 255], [0, 0, 255, 255], [170, 0, 85, 255], [85, 0, 170, 255]]
+    # swapped endpoints: three-colour mode, entry 2 = the mean, entry 3 = transparent black (opaque black for the RGB formats)
+    block = bytes([0x1F, 0x00, 0x00, 0xF8]) + idx.to_bytes(4, "little")
+    a = vks.decode_texture(block, 4, 4, vks.FMT_BC1_RGBA_UNORM)
+    assert a[0].tolist() == [[0, 0, 255, 255], [255, 0, 0, 255], [128, 0, 128, 255], [0, 0, 0, 0]]
+    assert vks.decode_texture(block, 4, 4, vks.FMT_BC1_RGB_UNORM)[0, 3].tolist() == [0, 0, 0, 255]
+    # BC4: a0 = 255 > a1 = 0 -> eight values; texel t uses entry t % 8
+    bits = sum((t % 8) << (3 * t) for t in range(16))
+    alpha = bytes([255, 0]) + bits.to_bytes(6, "little")
+    img = vks.decode_texture(alpha + bytes([0x00, 0xF8, 0x00, 0xF8, 0, 0, 0, 0]), 4, 4, vks.FMT_BC3_UNORM)
+    assert img[..., 3].reshape(-1)[:8].tolist() == [255, 0, 219, 182, 146, 109, 73, 36] and (img[..., 0] == 255).all()
+    # a0 <= a1: six values + 0 and 255
+    alpha = bytes([10, 60]) + bits.to_bytes(6, "little")
+    rg = vks.decode_texture(alpha + alpha, 4, 4, vks.FMT_BC5_UNORM)
+    assert rg[..., 0].reshape(-1)[:8].tolist() == [10, 60, 20, 30, 40, 50, 0, 255] and (rg[..., 2] == 0).all() and (rg[..., 3] == 255).all()
+    # a 6x5 image pads to 2x2 blocks and crops back
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (5, 6, 4)).astype(np.uint8)
+    back = vks.decode_texture(vks.encode_bc5(src), 6, 5, vks.FMT_BC5_UNORM)
+    assert back.shape == (5, 6, 4) and np.abs(back[..., :2].astype(int) - src[..., :2].astype(int)).max() <= 255 // 14 + 1
+
+
+def test_block_encoders_round_trip():
+    flat = np.tile(np.array([200, 100, 50, 255], np.uint8), (4, 4, 1))
+    assert np.array_equal(vks.decode_texture(vks.encode_bc5(flat), 4, 4, vks.FMT_BC5_UNORM)[..., :2], flat[..., :2])       # 8-bit endpoints: exact
+    d = vks.decode_texture(vks.encode_bc1(flat), 4, 4, vks.FMT_BC1_RGB_UNORM).astype(int) - flat.astype(int)
+    assert np.abs(d[..., 0]).max() <= 4 and np.abs(d[..., 1]).max() <= 2 and np.abs(d[..., 2]).max() <= 4                 # 5:6:5 endpoints
+    yy, xx = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    ramp = np.stack([xx * 30, 20 + xx * 25, 10 + xx * 15, 40 + yy * 25], axis=2).astype(np.uint8)     # colours along one line per block
+    d3 = vks.decode_texture(vks.encode_bc3(ramp), 8, 8, vks.FMT_BC3_UNORM).astype(int) - ramp.astype(int)
+    assert np.abs(d3[..., 3]).max() <= 8 and np.abs(d3[..., :3]).max() <= 40
+
+
+def _same_streams(a, b):
+    assert len(a.pmeshes) == len(b.pmeshes)
+    for pa, pb in zip(a.pmeshes, b.pmeshes):
+        ma, mb = a.meshes[pa.mesh], b.meshes[pb.mesh]
+        assert ma.num_geometries == mb.num_geometries
+        assert np.array_equal(pa.material_offsets, pb.material_offsets)
+        assert (pa.tri_material_ids is None) == (pb.tri_material_ids is None)
+        if pa.tri_material_ids is not None:
+            assert np.array_equal(pa.tri_material_ids, pb.tri_material_ids)
+        for j in range(ma.num_geometries):
+            ga, gb = a.geometries[ma.first_geometry + j], b.geometries[mb.first_geometry + j]
+            assert np.array_equal(ga.qpos, gb.qpos) and np.array_equal(_bits(ga.scaling), _bits(gb.scaling)) and np.array_equal(_bits(ga.offset), _bits(gb.offset))
+            if ga.qnrm_uv is not None and ga.has_normals and ga.has_uvs:
+                assert np.array_equal(ga.qnrm_uv, gb.qnrm_uv)
+
+
+@pytest.mark.parametrize("name", ["alpha_test", "textured_test", "cornell32", "two_level_test"])
+@pytest.mark.parametrize("version", [3, 4])
+def test_write_then_read_keeps_the_scene(tmp_path, name, version):
+    s = getattr(scenes, name)()
+    path = str(tmp_path / (name + ".vks"))
+    vks.write_vks(path, s, version=version)
+    r = vks.read_vks(path)
+    _same_streams(s, r)
+    assert len(r.instances) == len(s.instances)
+    for ia, ib in zip(s.instances, r.instances):
+        assert ia.pmesh == ib.pmesh
+        scale = max(1.0, float(np.abs(ia.transform).max()))
+        assert np.allclose(ia.transform, ib.transform, atol=2e-4 * scale)       # 16-bit quaternion
+    assert len(r.materials) == len(s.materials) and len(r.textures) == 3 * len(s.materials)
+    for ma, mb in zip(s.materials, r.materials):
+        assert (ma.flags & abi.BASE_MATERIAL_NOALPHA) == (mb.flags & abi.BASE_MATERIAL_NOALPHA)
+        assert mb.emission_intensity == pytest.approx(ma.emission_intensity) and mb.ior == pytest.approx(ma.ior)
+        # roughness / metallic come back as channels 1 / 2 of the material's third texture, base colour as its first
+        tid = abi.float_bits(mb.base_color[0]) & 0x1FFFFFFF if abi.float_bits(mb.base_color[0]) & 0x80000000 else None
+        if ma.emission_intensity == 0:
+            assert tid is not None and r.textures[tid].srgb
+        spec = r.textures[abi.float_bits(mb.roughness) & 0x1FFFFFFF]
+        if not (abi.float_bits(ma.roughness) & 0x80000000):
+            assert abs(int(spec.rgba[0, 0, 1]) - ma.roughness * 255) <= 3 and abs(int(spec.rgba[0, 0, 2]) - ma.metallic * 255) <= 5
+    # the same emitters are found again
+    assert len(r.lights) == len(s.lights)
+    # and the scene renders: the image equals the original's up to what the format cannot hold (5:6:5 colours, the default
+    # normal texel, rounded transforms) -- compared in the mean
+    r.camera, r.config, r.sky_key = s.camera, s.config, s.sky_key
+    a, _ = O.OracleScene(s).render(64, 48, 8)
+    b, _ = O.OracleScene(r).render(64, 48, 8)
+    fa, fb = a[..., :3][np.isfinite(a[..., :3])], b[..., :3][np.isfinite(b[..., :3])]
+    assert abs(float(fa.mean()) - float(fb.mean())) < 0.05 * float(fa.mean()) + 0.01
+
+
+def test_unrepresentable_scenes_are_refused(tmp_path):
+    s = scenes.cornell32()
+    s.instances[0].transform = s.instances[0].transform.copy()
+    s.instances[0].transform[0, 0] = 2.0                      # non-uniform scale
+    with pytest.raises(vks.VksError):
+        vks.write_vks(str(tmp_path / "x.vks"), s)
+
+
+def test_reader_errors(tmp_path):
+    """the reader's failure cases (vkr.c:781-1101): not a .vks file, unsupported version, truncated, inconsistent offsets"""
+    good = open(os.path.join(GOLD, "vks", "alpha_v4.vks"), "rb").read()
+
+    def attempt(data):
+        p = str(tmp_path / "t.vks")
+        open(p, "wb").write(data)
+        return p
+    with pytest.raises(vks.VksError):
+        vks.read_vks_header(attempt(b"\0" * 64))
+    with pytest.raises(vks.VksError):
+        vks.read_vks_header(attempt(good[:4] + (9).to_bytes(4, "little") + good[8:]))
+    with pytest.raises(vks.VksError):
+        vks.read_vks_header(attempt(good[:200]))
+    broken = bytearray(good)
+    broken[16:24] = (12345).to_bytes(8, "little")             # headerSize
+    with pytest.raises(vks.VksError):
+        vks.read_vks_header(attempt(bytes(broken)))
+    assert vks.read_vkt(str(tmp_path / "missing.vkt")) is None
+
+
+# ---------------------------------------------------------------- live against the reference's reader
+needs_ref = pytest.mark.skipif(not os.path.isfile(REF_LIB), reason="oracle/_ref/libvkr_ref.so not built (needs the reference checkout)")
+
+
+def _ref():
+    lib = C.CDLL(REF_LIB)
+    lib.ref_vkr_dump.argtypes = [C.c_char_p, C.c_char_p]
+    return lib
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["cornell32", "textured_test", "two_level_test", "alpha_test"])
+@pytest.mark.parametrize("version", [3, 4])
+def test_written_files_are_read_identically_by_the_reference(tmp_path, name, version):
+    s = getattr(scenes, name)()
+    path = str(tmp_path / (name + ".vks"))
+    vks.write_vks(path, s, version=version)
+    out = str(tmp_path / "dump.json")
+    assert _ref().ref_vkr_dump(path.encode(), out.encode()) == 0
+    _compare_with_dump(path, json.load(open(out)))
+
+
+@needs_ref
+def test_reference_and_reader_reject_the_same_files(tmp_path):
+    good = open(os.path.join(GOLD, "vks", "alpha_v4.vks"), "rb").read()
+    shutil.copytree(os.path.join(GOLD, "vks", "alpha_v4_textures"), str(tmp_path / "t_textures"))
+    cases = {"magic": b"\1" + good[1:], "version": good[:4] + (7).to_bytes(4, "little") + good[8:], "truncated": good[:300],
+             "header_size": good[:16] + (999).to_bytes(8, "little") + good[24:], "good": good}
+    for tag, data in cases.items():
+        p = str(tmp_path / "t.vks")
+        open(p, "wb").write(data)
+        rc = _ref().ref_vkr_dump(p.encode(), str(tmp_path / "d.json").encode())
+        try:
+            vks.read_vks_header(p)
+            mine_ok = True
+        except vks.VksError:
+            mine_ok = False
+        assert mine_ok == (rc == 0), tag
