@@ -30,7 +30,7 @@ def main():
         w = write.get(k, (calls, 0.0))[1]
         doc["kernels"][k] = {"launches": calls, "fetch_kib_raw": f, "write_kib_raw": w,
                              "hbm_bytes_per_launch": (2 * f + w) * 1024 / max(calls, 1)}
-    ext = [v for k, v in doc["kernels"].items() if "rp_k_extend<false" in k]  # <false, true> (first bounce) + <false, false>
+    ext = [v for k, v in doc["kernels"].items() if "rp_k_extend<false" in k]  # <false, true, ALPHA> (first bounce) + <false, false, ALPHA>
     if ext:
         doc["rp_k_extend_hbm_bytes_per_launch"] = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ext) /
                                                    max(sum(v["launches"] for v in ext), 1))

@@ -23,7 +23,7 @@ import csv,sys,glob,collections
 for fn in glob.glob(sys.argv[1]+'/*kernel_trace.csv'):
     rows=[r for r in csv.DictReader(open(fn))]
     ext=[r for r in rows if 'rp_k_extend<false' in r['Kernel_Name']]
-    con=[r for r in rows if 'rp_k_connect<false>' in r['Kernel_Name']]
+    con=[r for r in rows if 'rp_k_connect<false' in r['Kernel_Name']]
     sh=[r for r in rows if 'rp_k_shade' in r['Kernel_Name']]
     def d(r): return (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
     print('extend  last 9 (us):', ' '.join('%.0f'%d(r) for r in ext[-18:-9]))
