@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <array>
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 namespace orc {
@@ -447,6 +448,7 @@ static inline void decode_leaf(int enc, int &first, int &count) {
     first = RPTR_BVH_LEAF_FIRST(enc);
     count = RPTR_BVH_LEAF_COUNT(enc);
 }
+static bool g_no_single_instance = getenv("RPTR_NO_SINGLE_INSTANCE") != nullptr; // same switch as the device library
 static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
 // The reference's any-hit stage (vulkan/pt_megakernel.glsl:153-212, generate_candidate_hit): called for every hit of a
 // triangle flagged RPTR_BVH_TRI_ALPHA that the query would otherwise accept, in the canonical order of this traversal;
@@ -565,6 +567,14 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
     vec3 id(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const RptrBvhInstance *cur_inst = nullptr;
     int cur = 0;
+    if (bvh.insts.size() == 1 && !g_no_single_instance) {
+        // the device's shortcut for scenes with one instance record (csrc/dtraverse.h): start inside the instance
+        cur_inst = &bvh.insts[0];
+        o = xform_point(cur_inst->world_to_object, ray.o);
+        d = xform_dir(cur_inst->world_to_object, ray.d);
+        id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+        cur = cur_inst->blas_root;
+    }
     for (;;) {
         bool pop = false;
         if (cur >= 0) {

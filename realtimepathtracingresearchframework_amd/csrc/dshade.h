@@ -52,6 +52,7 @@ struct RpScene {
     int32_t num_lights;
     int32_t num_materials;
     uint32_t num_nodes;
+    int32_t single_instance; // the top level holds one instance record: queries start inside it (dtraverse.h)
     int32_t num_textures;
     const RpTexture *textures;
     const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)

@@ -232,15 +232,27 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     my_i = pool_next + rank;
                     float tmax;
                     load(my_i, ro, rd, tmin, tmax);
-                    set_ray(ro, rd);
                     best.t = tmax;
                     best.u = best.v = 0.0f;
                     best.prim = best.geom = best.inst_idx = -1;
                     best_inst_id = -1;
-                    cur_inst = cur_inst_id = -1;
                     sp = 0;
                     push(RP_EXIT);
-                    cur = 0;
+                    if (sc.single_instance) {
+                        // one instance record in the whole scene: the query starts inside it, at the root of its bottom-level
+                        // tree -- no top-level node, no instance leaf and no sentinel to come back to (same arithmetic as
+                        // entering the instance through its leaf; oracle/obvh.h traverse4 takes the same shortcut)
+                        const float4 *ip = reinterpret_cast<const float4 *>(sc.insts);
+                        const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], meta = ip[3];
+                        set_ray(rp_xform_point(w0, w1, w2, ro), rp_xform_dir(w0, w1, w2, rd));
+                        cur_inst = 0;
+                        cur_inst_id = __float_as_int(meta.z);
+                        cur = __float_as_int(meta.x);
+                    } else {
+                        set_ray(ro, rd);
+                        cur_inst = cur_inst_id = -1;
+                        cur = 0;
+                    }
                     active = true;
                 }
                 pool_next += min(nidle, avail);

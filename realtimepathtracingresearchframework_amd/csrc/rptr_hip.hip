@@ -997,6 +997,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_lights = (int)s->num_lights;
     h->master.dscene.num_materials = (int)s->num_materials;
     h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
+    h->master.dscene.single_instance = (h->h_insts.size() == 1 && !getenv("RPTR_NO_SINGLE_INSTANCE")) ? 1 : 0;
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
     h->master.dscene.srgb_lut = d_srgb_lut;
