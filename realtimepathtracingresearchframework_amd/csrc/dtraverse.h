@@ -148,7 +148,7 @@ struct RpNoAlpha {
     RP_DEV bool operator()(uint32_t, int, int, int, int, float, float) const { return false; }
 };
 template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN),
-          bool ALPHA = false, class Load, class Done, class Alpha>
+          bool ALPHA = false, bool SINGLE = false, class Load, class Done, class Alpha>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
                           uint32_t &n_nodes, uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
@@ -238,7 +238,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     best_inst_id = -1;
                     sp = 0;
                     push(RP_EXIT);
-                    if (sc.single_instance) {
+                    if (SINGLE) {
                         // one instance record in the whole scene: the query starts inside it, at the root of its bottom-level
                         // tree -- no top-level node, no instance leaf and no sentinel to come back to (same arithmetic as
                         // entering the instance through its leaf; oracle/obvh.h traverse4 takes the same shortcut)
@@ -381,7 +381,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
 #endif
         // ---- one leaf / sentinel item. A BLAS leaf (two triangles = 96 bytes) and a TLAS leaf (the first 64 bytes of
         // an instance record) are fetched by the same six loads, so that a phase with both kinds costs one round trip.
-        if (cur == RP_SENTINEL) {
+        if (!SINGLE && cur == RP_SENTINEL) {
             cur_inst = -1;
             cur_inst_id = -1;
             set_ray(ro, rd);
@@ -389,7 +389,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         } else if (cur < 0 && cur != RP_EXIT) {
             const int first = RPTR_BVH_LEAF_FIRST(cur);
             int count = RPTR_BVH_LEAF_COUNT(cur);
-            const bool is_inst = cur_inst < 0;
+            const bool is_inst = !SINGLE && cur_inst < 0;
             const char *lp = is_inst ? inst_base + (size_t)(uint32_t)first * sizeof(RptrBvhInstance) : tri_base + (size_t)(uint32_t)first * 48u;
             float4 qa0 = *reinterpret_cast<const float4 *>(lp), qa1 = *reinterpret_cast<const float4 *>(lp + 16),
                    qa2 = *reinterpret_cast<const float4 *>(lp + 32), qb0 = *reinterpret_cast<const float4 *>(lp + 48),

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, uint32_t *queue, R
 // FIRST: bounce 0, the rays are the camera rays (computed, not loaded)
 // ALPHA: the scene has alpha-tested materials. The test of a candidate may draw from the path's generator
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
-template <bool COUNT, bool FIRST, bool ALPHA>
+// SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
@@ -173,7 +174,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, lane_rng);
     };
-    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA>(
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE>(
         sc, bc->queue_count, &bc->cursor_extend, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
@@ -188,7 +189,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 // ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
 // instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
-template <bool COUNT, bool ALPHA>
+template <bool COUNT, bool ALPHA, bool SINGLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto alpha = [&](uint32_t i, int inst_idx, int inst_id, int geom, int prim, float u, float v) -> bool {
@@ -220,7 +221,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
             ps.illum[p] = il;
         }
     };
-    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, alpha, n_nodes,
+    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, alpha, n_nodes,
                                                                             n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
@@ -766,7 +767,7 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
 // ------------------------------------------------------------------ RQ_CLOSEST, vulkan/rt_intersect.comp:31-68
 // COUNT: also writes per-query visit counts (nodes, triangles) -- the diagnostic behind rptr_hip_trace_counted
 // ANY (diagnostic only): occlusion query over (tmin_arr[i], t_max), result.x = 1 when anything is hit
-template <bool COUNT, bool ANY>
+template <bool COUNT, bool ANY, bool SINGLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, uint32_t n, float4 *results, uint32_t *cursor,
                                               int *gstack, uint2 *per_ray, const float *tmin_arr) {
     uint32_t nn = 0, nt = 0, nn_prev = 0, nt_prev = 0;
@@ -796,7 +797,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
         }
         results[i] = r;
     };
-    rp_wave_trace<ANY, COUNT>(sc, n, cursor, gstack, load, done, RpNoAlpha(), nn, nt); // ray queries see opaque geometry
+    // ray queries see opaque geometry
+    rp_wave_trace<ANY, COUNT, (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN), false, SINGLE>(sc, n, cursor, gstack, load, done, RpNoAlpha(), nn, nt);
 }
 
 // ------------------------------------------------------------------ refit (dynamic meshes)

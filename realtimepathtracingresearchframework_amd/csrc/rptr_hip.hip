@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -710,7 +711,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->last_resolved = nullptr;
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false>, RP_TRAVERSE_BLOCK, 0));
+    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false, false>, RP_TRAVERSE_BLOCK, 0));
     occ = std::max(1, std::min(occ, 8));
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
@@ -1171,6 +1172,15 @@ static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
 }
 
 extern "C++" {
+// runtime flag -> template argument: f(std::true_type) or f(std::false_type)
+template <class F>
+static inline void pick(bool v, F &&f) {
+    if (v)
+        f(std::true_type());
+    else
+        f(std::false_type());
+}
+
 template <int VARIANT>
 static void launch_shade(rptr_hip *h, FrameCtx &c, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     const int grid = grid_for(h, h->path_capacity);
@@ -1375,6 +1385,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     const bool local_work = h->local_rows > 0;
     f.frame_id = h->frame_id; // the whole call is one frame of the reference (its batch_spp = spp), whatever the internal batches
     f.alpha_test = h->uses_alpha ? 1 : 0;
+    const bool single = h->master.dscene.single_instance != 0;
     while (remaining > 0) {
         const int batch = std::min(remaining, h->max_batch_spp);
         f.sample_base = h->frame_id;
@@ -1405,15 +1416,13 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, scn.dscene, f, c.ps,
                                            b == 0 ? first_ids : c.queue[in], bc, c.counters, c.gstack);
                     };
-                    if (h->uses_alpha) {
-                        if (b == 0)
-                            count_traversal ? go(rp_k_extend<true, true, true>) : go(rp_k_extend<false, true, true>);
-                        else
-                            count_traversal ? go(rp_k_extend<true, false, true>) : go(rp_k_extend<false, false, true>);
-                    } else if (b == 0)
-                        count_traversal ? go(rp_k_extend<true, true, false>) : go(rp_k_extend<false, true, false>);
-                    else
-                        count_traversal ? go(rp_k_extend<true, false, false>) : go(rp_k_extend<false, false, false>);
+                    pick(count_traversal, [&](auto C) {
+                        pick(b == 0, [&](auto F) {
+                            pick(h->uses_alpha, [&](auto A) {
+                                pick(single, [&](auto S) { go(rp_k_extend<decltype(C)::value, decltype(F)::value, decltype(A)::value, decltype(S)::value>); });
+                            });
+                        });
+                    });
                 });
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
@@ -1447,10 +1456,11 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                             hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, f, c.ps, c.sq, bc, c.counters,
                                                stack);
                         };
-                        if (h->uses_alpha)
-                            count_traversal ? go(rp_k_connect<true, true>) : go(rp_k_connect<false, true>);
-                        else
-                            count_traversal ? go(rp_k_connect<true, false>) : go(rp_k_connect<false, false>);
+                        pick(count_traversal, [&](auto C) {
+                            pick(h->uses_alpha, [&](auto A) {
+                                pick(single, [&](auto S) { go(rp_k_connect<decltype(C)::value, decltype(A)::value, decltype(S)::value>); });
+                            });
+                        });
                     });
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }
@@ -1631,12 +1641,14 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
             hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, h->stream, h->master.dscene, dq, (uint32_t)n, dr,
                                &h->ctx[0].counters->bounce[0].cursor_extend, h->ctx[0].gstack, dv, dt);
         };
-        if (any_hit)
-            launch(rp_k_trace<true, true>);
-        else if (visits2)
-            launch(rp_k_trace<true, false>);
-        else
-            launch(rp_k_trace<false, false>);
+        pick(h->master.dscene.single_instance != 0, [&](auto S) {
+            if (any_hit)
+                launch(rp_k_trace<true, true, decltype(S)::value>);
+            else if (visits2)
+                launch(rp_k_trace<true, false, decltype(S)::value>);
+            else
+                launch(rp_k_trace<false, false, decltype(S)::value>);
+        });
         if ((visits2 && hipMemcpyAsync(visits2, dv, (size_t)n * sizeof(uint2), hipMemcpyDeviceToHost, h->stream) != hipSuccess) ||
             hipMemcpyAsync(out4, dr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
