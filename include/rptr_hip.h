@@ -328,6 +328,16 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
 int rptr_hip_get_framebuffer_size(const rptr_hip_t *h, uint32_t out_whc[3]);
 int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats);
 int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes);
+/* RenderGraphic::readback_aov (util/display/render_graphic.h:12-17,40; vulkan/render_vulkan.cpp:2290-2294): the RGBA16F AOV image
+ * `aov_index` of the last finished frame, width*height*4 halfs (rows of other ranks stay untouched): 0 albedo.rgb + roughness
+ * (1 when ior == 1), 1 shading normal + distance to the camera, 2 screen-space motion.xy + jitter.xy (motion of the hit point
+ * between the previous frame's view and this one; no per-vertex motion, jitter 0). Written at bounce 0 by the first sample of a
+ * frame (the reference lets every sample of the batch store to the pixel, vulkan/accumulate.glsl:76-103). RPTR_AOVS=0 in the
+ * environment at create time switches them off. */
+#define RPTR_AOV_ALBEDO_ROUGHNESS 0
+#define RPTR_AOV_NORMAL_DEPTH 1
+#define RPTR_AOV_MOTION_JITTER 2
+int rptr_hip_readback_aov(rptr_hip_t *h, int aov_index, uint16_t *rgba16f, size_t n_halfs);
 
 /* ---- multi-GPU: this rank's rows, packed top-to-bottom, for the RCCL gather.
  * rptr_hip_tile_rows writes up to `cap` (first_row,num_rows) pairs for `rank`

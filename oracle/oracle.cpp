@@ -32,6 +32,9 @@ struct ViewParams { // the subset of vulkan/gpu_params.glsl:61-87 the path reads
     uint32_t frame_offset;
     uint32_t frame_id; // samples accumulated before this frame (render_vulkan.cpp:2913)
     uint32_t dims_x, dims_y;
+    // VP / VP_reference (render_vulkan.cpp:2926-2931) reduced to what the x, y and w rows need: world -> view (3x4, row-major)
+    // and the two scale factors of glm::infinitePerspective (clip = (P00 v.x, -P11 v.y, ., -v.z))
+    float view[12], view_ref[12], proj[2], proj_ref[2];
     vec3 cam_pos, cam_du, cam_dv, cam_dir_top_left;
 };
 
@@ -51,6 +54,28 @@ static void compute_view(const RptrCamera &c, int W, int H, ViewParams &vp) {
     vp.dims_x = W;
     vp.dims_y = H;
 }
+// The x, y, w rows of VP = GLToVulkan * glm::infinitePerspective(radians(fovy), aspect, 0.5f) * inverse(mat4(mat4x3(cross(dir, up),
+// up, -dir, pos))) (render_vulkan.cpp:2926-2931; GLM 0.9.9.8 is not in the image: its published formulas restated, the
+// arithmetic order inside glm::inverse is not reproduced -- AOV motion vectors are tolerance-level, "parity unpinned")
+static void compute_view_projection(const RptrCamera &c, int W, int H, float view[12], float proj[2]) {
+    vec3 pos(c.pos[0], c.pos[1], c.pos[2]), dir(c.dir[0], c.dir[1], c.dir[2]), up(c.up[0], c.up[1], c.up[2]);
+    const vec3 cx = cross(dir, up), cy = up, cz = -dir; // the columns of camera-to-world
+    // rows of the inverse of [cx cy cz] by cofactors
+    const vec3 r0 = cross(cy, cz), r1 = cross(cz, cx), r2 = cross(cx, cy);
+    const float inv_det = 1.0f / dot(cx, r0);
+    const vec3 rows[3] = {r0 * inv_det, r1 * inv_det, r2 * inv_det};
+    for (int r = 0; r < 3; ++r) {
+        view[4 * r + 0] = rows[r].x;
+        view[4 * r + 1] = rows[r].y;
+        view[4 * r + 2] = rows[r].z;
+        view[4 * r + 3] = -dot(rows[r], pos);
+    }
+    const float z_near = 0.5f, aspect = static_cast<float>(W) / H;
+    const float range = tanf((c.fovy * 0.01745329251994329576923690768489f) / 2.0f) * z_near;
+    const float left = -range * aspect, right = range * aspect, bottom = -range, top = range;
+    proj[0] = (2.0f * z_near) / (right - left);
+    proj[1] = (2.0f * z_near) / (top - bottom);
+}
 
 struct Scene {
     SceneView view;
@@ -64,6 +89,37 @@ struct Scene {
     bool alpha_test = false; // some material lacks BASE_MATERIAL_NOALPHA
 };
 
+// AOV images of a frame (vulkan/accumulate.glsl:76-103): RGBA16F, written by the first sample of the frame at bounce 0
+struct AovOut {
+    uint16_t *albedo_roughness, *normal_depth, *motion_jitter;
+};
+// float -> IEEE half, round to nearest even (what an RGBA16F image store does on this hardware)
+static inline uint16_t float_to_half(float f) {
+    const uint32_t x = float_bits(f);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t mant = x & 0x7FFFFFu;
+    const int32_t exp = int32_t((x >> 23) & 0xFFu);
+    if (exp == 0xFF) return uint16_t(sign | 0x7C00u | (mant ? (0x200u | (mant >> 13)) : 0u));
+    const int32_t e = exp - 127 + 15;
+    if (e >= 0x1F) return uint16_t(sign | 0x7C00u);
+    if (e <= 0) {
+        if (e < -10) return uint16_t(sign);
+        const uint32_t m = mant | 0x800000u;
+        const int shift = 14 - e;
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return uint16_t(sign | h);
+    }
+    uint32_t h = (uint32_t(e) << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h; // may carry into the exponent: that is the right result
+    return uint16_t(sign | h);
+}
+static inline void store_half4(uint16_t *img, size_t pixel, float a, float b, float c, float d) {
+    uint16_t *o = img + 4 * pixel;
+    o[0] = float_to_half(a); o[1] = float_to_half(b); o[2] = float_to_half(c); o[3] = float_to_half(d);
+}
 struct Frame;
 struct PathCounters;
 struct Frame {
@@ -74,13 +130,36 @@ struct Frame {
     RptrLightSamplingConfig lc;
     ViewParams vp;
     bool count;
+    const AovOut *aov = nullptr;
 };
+// vulkan/accumulate.glsl:76-87 store_motion_jitter_aovs (motion_vector = 0: no dynamic-mesh motion; screen_jitter = 0 without raster TAA)
+static inline void project(const float view[12], const float proj[2], vec3 p, float &x, float &y, float &w) {
+    const float vx = ((view[0] * p.x + view[1] * p.y) + view[2] * p.z) + view[3];
+    const float vy = ((view[4] * p.x + view[5] * p.y) + view[6] * p.z) + view[7];
+    const float vz = ((view[8] * p.x + view[9] * p.y) + view[10] * p.z) + view[11];
+    x = proj[0] * vx;
+    y = -(proj[1] * vy);
+    w = -vz;
+}
+static void store_geometry_aovs(const Frame &f, size_t pixel, vec3 normal, vec3 hit_point) { // :89-96
+    float depth = length(hit_point - f.vp.cam_pos);
+    store_half4(f.aov->normal_depth, pixel, normal.x, normal.y, normal.z, depth);
+    float rx, ry, rw, cx, cy, cw;
+    project(f.vp.view_ref, f.vp.proj_ref, hit_point, rx, ry, rw);
+    project(f.vp.view, f.vp.proj, hit_point, cx, cy, cw);
+    const float rd = fmaxf(rw, 0.0f), cd = fmaxf(cw, 0.0f);
+    store_half4(f.aov->motion_jitter, pixel, rx / rd - cx / cd, ry / rd - cy / cd, 0.0f, 0.0f);
+}
+static void store_material_aovs(const Frame &f, size_t pixel, vec3 albedo, float roughness, float ior) { // :98-103
+    store_half4(f.aov->albedo_roughness, pixel, albedo.x, albedo.y, albedo.z, ior != 1.0f ? roughness : 1.0f);
+}
 
 struct PathCounters {
     uint64_t rays_closest = 0, rays_shadow = 0, hits = 0;
     TraceCounters tc_closest, tc_shadow;
     uint32_t px = 0, py = 0;   // gl_GlobalInvocationID.xy of the pixel sample being traced (alpha test of shadow rays)
     LCGRand *path_rng = nullptr; // the path's generator (alpha test of closest-hit queries: `#define alpha_rng rng`)
+    long long aov_pixel = -1;    // >= 0: this pixel sample writes the AOVs (first sample of the frame)
 };
 
 // diagnostic ray log (single-threaded renders only): 9 floats per ray = o, tmin, d, tmax, any(0/1)
@@ -334,6 +413,8 @@ static int shade_base_material(const Frame &f, float geometry_scale, ShadingSamp
     vec3 emit_radiance;
     unpack_material(f.sc->textures, mat, emit_radiance, params, hit_uv);
     vec3 scatter_throughput = path_throughput;
+    if (state.bounce == 0 && pc.aov_pixel >= 0) // :28-31
+        store_material_aovs(f, (size_t)pc.aov_pixel, path_throughput * mat.base_color, mat.roughness, mat.ior);
     if (state.output_channel == 0 && !all_equal(emit_radiance, vec3(0.0f))) {
         float light_pdf = wpdf_direct_light(f, approx_solid_angle);
         float w = nee_mis_heuristic(1.f, state.prev_bounce_pdf, 1.f, light_pdf);
@@ -378,6 +459,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
     pc.px = px;
     pc.py = py;
     pc.path_rng = &rng;
+    pc.aov_pixel = (f.aov && sample_index == f.vp.frame_id) ? (long long)py * f.vp.dims_x + px : -1;
     vec2 point = vec2(px + 0.5f, py + 0.5f);
     if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng) - vec2(0.5f));
     point = point / vec2((float)f.vp.dims_x, (float)f.vp.dims_y);
@@ -395,6 +477,10 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
         bool found = trace_closest(f, r, h, pc);
         if (!found) {
             illum += path_throughput * compute_sky_illum(f, ray_dir, shading_state.prev_bounce_pdf);
+            if (shading_state.bounce == 0 && pc.aov_pixel >= 0) { // :482-487
+                store_geometry_aovs(f, (size_t)pc.aov_pixel, vec3(0.0f), vec3(2.e32f));
+                store_material_aovs(f, (size_t)pc.aov_pixel, vec3(0.0f), 1.0f, 1.0f);
+            }
             break;
         }
         pc.hits++;
@@ -470,6 +556,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
                 interaction.n = normalize(mix(interaction.gn, interaction.n, blend - ORC_EPSILON));
             }
         }
+        if (shading_state.bounce == 0 && pc.aov_pixel >= 0) store_geometry_aovs(f, (size_t)pc.aov_pixel, interaction.n, interaction.p); // :670-673
         // :677-678
         interaction.v_y = normalize(cross(interaction.n, hit.tangent));
         interaction.v_x = cross(interaction.v_y, interaction.n);
@@ -691,7 +778,16 @@ int orc_trace_ex_counts(void *p, int bvh_mode, int any_hit, const float *o3, con
 // (absolute index sample_begin+s) is folded with the running mean of
 // process_samples.comp:116-132:  hist += (new - hist) / (index + 1); index 0
 // overwrites (accumulate.glsl:68-73 + sample_base_index == 0).
-int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats) {
+static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats, const AovOut *aov, const RptrCamera *prev_camera);
+int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats) { return render_impl(p, a, accum, stats, nullptr, nullptr); }
+// same, and the first sample of the frame (index sample_begin) writes the three RGBA16F AOV images (width*height*4 halfs each;
+// RenderGraphic::AOVBufferIndex order). prev_camera: the view of the previous frame (VP_reference), NULL = the same view.
+int orc_render_aovs(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats, const RptrCamera *prev_camera, uint16_t *albedo_roughness,
+                    uint16_t *normal_depth, uint16_t *motion_jitter) {
+    AovOut out{albedo_roughness, normal_depth, motion_jitter};
+    return render_impl(p, a, accum, stats, &out, prev_camera);
+}
+static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *stats, const AovOut *aov, const RptrCamera *prev_camera) {
     Scene *s = (Scene *)p;
     if (a->bvh_mode == 2 && !s->has_imported) return -1;
     Frame f;
@@ -704,6 +800,9 @@ int orc_render(void *p, const OrcRenderArgs *a, float *accum, OrcRenderStats *st
     compute_view(a->camera, a->width, a->height, f.vp);
     f.vp.frame_offset = a->frame_offset;
     f.vp.frame_id = uint32_t(a->sample_begin);
+    f.aov = aov;
+    compute_view_projection(a->camera, a->width, a->height, f.vp.view, f.vp.proj);
+    compute_view_projection(prev_camera ? *prev_camera : a->camera, a->width, a->height, f.vp.view_ref, f.vp.proj_ref);
     for (uint32_t m = 0; m < s->view.desc->num_materials; ++m)
         if (s->view.desc->materials[m].normal_map != -1 && (uint32_t)s->view.desc->materials[m].normal_map >= s->view.desc->num_textures) return -4;
     int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();

@@ -68,6 +68,7 @@ def load_library(path=None):
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_readback_aov.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_tile_rows.argtypes = [vp, i32, vp, i32]
     L.rptr_hip_local_pixel_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_copy_tile_to_device.argtypes = [vp, vp, C.c_size_t]
@@ -275,6 +276,17 @@ class RenderHip:
             self._check(self._L.rptr_hip_readback_u8(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
         else:
             raise TypeError("readback_framebuffer: float32 or uint8 buffer expected")
+        return need
+
+    AOVAlbedoRoughnessIndex, AOVNormalDepthIndex, AOVMotionJitterIndex = 0, 1, 2   # RenderGraphic::AOVBufferIndex
+
+    def readback_aov(self, aov_index, buffer: np.ndarray):
+        """RenderGraphic::readback_aov (render_graphic.h:40): float16 (or uint16) buffer of width*height*4 -> #elements or 0"""
+        w, hgt, c = self.get_framebuffer_size()
+        need = w * hgt * c
+        if buffer.size < need or buffer.dtype.itemsize != 2:
+            return 0
+        self._check(self._L.rptr_hip_readback_aov(self._h, int(aov_index), buffer.ctypes.data_as(C.c_void_p), buffer.size))
         return need
 
     # ---- ray queries (RQ_CLOSEST)

@@ -80,6 +80,12 @@ struct RpFrame {
     int32_t num_bins;            // SCENE_GET_BINNED_LIGHTS_BIN_COUNT (pt_megakernel.glsl:103)
     int32_t alpha_test;          // the scene has alpha-tested materials: the first extend hands its generator on in the path state
     uint32_t frame_id;           // view_params.frame_id: samples accumulated before this render call (render_vulkan.cpp:2913)
+    // AOV images (vulkan/accumulate.glsl:76-103; RGBA16F, local pixels row by row), NULL = off. The first sample of a frame
+    // writes them at bounce 0.
+    uint2 *aov_albedo_roughness, *aov_normal_depth, *aov_motion_jitter;
+    // x / y / w rows of VP and VP_reference (render_vulkan.cpp:2926-2931): world -> view (3x4 row-major) and the two scale
+    // factors of the infinite perspective, clip = (P00 v.x, -P11 v.y, ., -v.z)
+    float view[12], view_ref[12], proj[2], proj_ref[2];
     // regrouping pass (kernels.h "sort"): hit-cell grid over the scene bounds
     float sort_lo[3];
     int32_t sort_groups;         // material groups
@@ -104,6 +110,36 @@ RP_DEV uint32_t rp_local_to_slot(const RpFrame &f, int lx, int ly) {
 RP_DEV int rp_local_row_to_global(const RpFrame &f, int ly) {
     int stripe_local = ly / f.stripe_rows;
     return (stripe_local * f.world + f.rank) * f.stripe_rows + (ly - stripe_local * f.stripe_rows);
+}
+
+// ------------------------------------------------------------------ AOV stores (vulkan/accumulate.glsl:76-103)
+RP_DEV uint2 rp_half4(float a, float b, float c, float d) { // RGBA16F texel, round to nearest even
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b, hc = (_Float16)c, hd = (_Float16)d;
+    uint16_t ua, ub, uc, ud;
+    __builtin_memcpy(&ua, &ha, 2);
+    __builtin_memcpy(&ub, &hb, 2);
+    __builtin_memcpy(&uc, &hc, 2);
+    __builtin_memcpy(&ud, &hd, 2);
+    return make_uint2(uint32_t(ua) | (uint32_t(ub) << 16), uint32_t(uc) | (uint32_t(ud) << 16));
+}
+RP_DEV void rp_project(const float *view, const float *proj, V3 p, float &x, float &y, float &w) {
+    const float vx = ((view[0] * p.x + view[1] * p.y) + view[2] * p.z) + view[3];
+    const float vy = ((view[4] * p.x + view[5] * p.y) + view[6] * p.z) + view[7];
+    const float vz = ((view[8] * p.x + view[9] * p.y) + view[10] * p.z) + view[11];
+    x = proj[0] * vx;
+    y = -(proj[1] * vy);
+    w = -vz;
+}
+RP_DEV void rp_store_geometry_aovs(const RpFrame &f, int pixel, V3 normal, V3 hit_point) { // :76-96 (motion_vector = 0, screen_jitter = 0)
+    f.aov_normal_depth[pixel] = rp_half4(normal.x, normal.y, normal.z, len3(hit_point - ld3(f.cam_pos)));
+    float rx, ry, rw, cx, cy, cw;
+    rp_project(f.view_ref, f.proj_ref, hit_point, rx, ry, rw);
+    rp_project(f.view, f.proj, hit_point, cx, cy, cw);
+    const float rd = fmaxf(rw, 0.0f), cd = fmaxf(cw, 0.0f);
+    f.aov_motion_jitter[pixel] = rp_half4(rx / rd - cx / cd, ry / rd - cy / cd, 0.0f, 0.0f);
+}
+RP_DEV void rp_store_material_aovs(const RpFrame &f, int pixel, V3 albedo, float roughness, float ior) { // :98-103
+    f.aov_albedo_roughness[pixel] = rp_half4(albedo.x, albedo.y, albedo.z, ior != 1.0f ? roughness : 1.0f);
 }
 
 // ------------------------------------------------------------------ RNG (a2)

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
             V3 ray_origin = v3s(0.f), ray_dir = v3s(0.f), throughput = v3s(0.f), illum = v3s(0.f), scatter_throughput = v3s(0.f);
             V3 ip_p = v3s(0.f), gn = v3s(0.f), nn = v3s(0.f), w_o = v3s(0.f), v_x = v3s(0.f), v_y = v3s(0.f);
             int bounce = 0;
+            int aov_px = -1; // FIRST: local pixel whose AOVs this path writes
             RpMaterial mat;
             V2 dir_sample = v2(0.f, 0.f), sel_sample = v2(0.f, 0.f);
             RpLightBin bin;
@@ -451,6 +452,14 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                 if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
                     (void)rp_primary_ray(f, p, rng, ray_dir);
                     if (f.alpha_test) rng = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
+                    if (f.aov_albedo_roughness) { // the first sample of the frame writes the AOVs
+                        const uint32_t sslot = p / uint32_t(f.npix_padded);
+                        if (f.sample_base + sslot == f.frame_id) {
+                            int lx = 0, ly = 0;
+                            (void)rp_slot_to_local(f, p - sslot * uint32_t(f.npix_padded), lx, ly);
+                            aov_px = ly * f.width + lx;
+                        }
+                    }
                     ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
                     illum = v3s(0.0f);
@@ -477,6 +486,10 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
                     ps.illum[p] = f4(illum, __int_as_float(bounce));
+                    if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:482-487
+                        rp_store_geometry_aovs(f, aov_px, v3s(0.0f), v3s(2.e32f));
+                        rp_store_material_aovs(f, aov_px, v3s(0.0f), 1.0f, 1.0f);
+                    }
                 } else {
                     hit_lane = true;
                     my_hits++;
@@ -540,6 +553,10 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
                     V3 emit;
                     rp_unpack_material<VARIANT, TEX>(sc, mat, emit, mp, hit.uv);
                     scatter_throughput = throughput;
+                    if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:670-673, shade_base_material.glsl:28-31
+                        rp_store_geometry_aovs(f, aov_px, nn, ip_p);
+                        rp_store_material_aovs(f, aov_px, throughput * mat.base_color, mat.roughness, mat.ior);
+                    }
                     if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
                         // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
                         const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));

@@ -82,6 +82,7 @@ struct FrameCtx {
     hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     float4 *out_accum = nullptr; // frames_in_flight > 1: the image after this frame's resolve
     uchar4 *out_fb = nullptr;
+    uint2 *aov[3] = {nullptr, nullptr, nullptr}; // RGBA16F albedo+roughness, normal+depth, motion+jitter of this context's last frame
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dep = nullptr, ev_resolved = nullptr;
     std::vector<hipEvent_t> ev_pool;
     // the frame in flight on this context
@@ -151,6 +152,10 @@ struct rptr_hip {
     uint64_t next_ticket = 1;
     int next_ctx = 0;
     int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
+    int aov_ctx = 0;                // the context whose AOV images readback_aov returns (last finished frame)
+    bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
+    RptrCamera prev_camera;         // the previous frame's view (VP_reference)
+    bool have_prev_camera = false;
     hipEvent_t last_resolved = nullptr; // resolve of the most recently submitted frame (resolves run in submission order)
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
     float4 *accum = nullptr;
@@ -550,6 +555,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         fif = std::max(1, std::min(fif, 8));
         if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
         h->ctx.resize((size_t)fif);
+        if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
         for (FrameCtx &c : h->ctx) {
             memset(&c.ps, 0, sizeof(c.ps));
             memset(&c.sq, 0, sizeof(c.sq));
@@ -709,6 +715,13 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         }
     h->output_ctx = -1;
     h->last_resolved = nullptr;
+    h->aov_ctx = 0;
+    if (h->aovs)
+        for (FrameCtx &c : h->ctx)
+            for (int k = 0; k < 3; ++k) {
+                if ((rc = dev_alloc(h, &c.aov[k], npix_local, nullptr))) return rc;
+                HIP_TRY(h, hipMemsetAsync(c.aov[k], 0, npix_local * sizeof(uint2), h->stream));
+            }
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false, false>, RP_TRAVERSE_BLOCK, 0));
@@ -1171,6 +1184,35 @@ static void compute_view(const RptrCamera &c, int W, int H, RpFrame &f) {
     }
 }
 
+// x / y / w rows of VP (render_vulkan.cpp:2926-2931): inverse of the camera-to-world matrix with columns cross(dir, up), up, -dir,
+// pos; glm::infinitePerspective(radians(fovy), aspect, 0.5f) contributes P00 and P11 (GLM's published formulas)
+static void compute_view_projection(const RptrCamera &c, int W, int H, float view[12], float proj[2]) {
+    auto cross = [](const float a[3], const float b[3], float o[3]) {
+        o[0] = a[1] * b[2] - b[1] * a[2];
+        o[1] = a[2] * b[0] - b[2] * a[0];
+        o[2] = a[0] * b[1] - b[0] * a[1];
+    };
+    auto dot = [](const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; };
+    float cx[3], cz[3] = {-c.dir[0], -c.dir[1], -c.dir[2]}, r[3][3];
+    cross(c.dir, c.up, cx);
+    cross(c.up, cz, r[0]);
+    cross(cz, cx, r[1]);
+    cross(cx, c.up, r[2]);
+    const float inv_det = 1.0f / dot(cx, r[0]);
+    for (int k = 0; k < 3; ++k) {
+        for (int j = 0; j < 3; ++j) r[k][j] *= inv_det;
+        view[4 * k + 0] = r[k][0];
+        view[4 * k + 1] = r[k][1];
+        view[4 * k + 2] = r[k][2];
+        view[4 * k + 3] = -dot(r[k], c.pos);
+    }
+    const float z_near = 0.5f, aspect = static_cast<float>(W) / H;
+    const float range = tanf((c.fovy * 0.01745329251994329576923690768489f) / 2.0f) * z_near;
+    const float left = -range * aspect, right = range * aspect, bottom = -range, top = range;
+    proj[0] = (2.0f * z_near) / (right - left);
+    proj[1] = (2.0f * z_near) / (top - bottom);
+}
+
 extern "C++" {
 // runtime flag -> template argument: f(std::true_type) or f(std::false_type)
 template <class F>
@@ -1265,6 +1307,7 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
     st.launches_connect = c.launches_connect;
     st.device_bytes_allocated = h->bytes_allocated;
     if (h->ctx.size() > 1) h->output_ctx = (int)(&c - h->ctx.data());
+    h->aov_ctx = (int)(&c - h->ctx.data());
     if (out_stats) *out_stats = st;
     return RPTR_OK;
 }
@@ -1305,6 +1348,13 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     f.sp = h->scene_params;
     f.lc = h->lighting;
     compute_view(*camera, h->width, h->height, f);
+    compute_view_projection(*camera, h->width, h->height, f.view, f.proj);
+    compute_view_projection(h->have_prev_camera ? h->prev_camera : *camera, h->width, h->height, f.view_ref, f.proj_ref);
+    h->prev_camera = *camera;
+    h->have_prev_camera = true;
+    f.aov_albedo_roughness = c.aov[0];
+    f.aov_normal_depth = c.aov[1];
+    f.aov_motion_jitter = c.aov[2];
     f.frame_offset = h->frame_offset;
     f.variant = variant;
     f.width = h->width;
@@ -1599,6 +1649,14 @@ int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
     return readback_rows<uchar4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb : h->fb, reinterpret_cast<uchar4 *>(rgba),
                                  n_bytes / 4);
+}
+
+int rptr_hip_readback_aov(rptr_hip_t *h, int aov_index, uint16_t *rgba16f, size_t n_halfs) {
+    if (!h || !rgba16f) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (aov_index < 0 || aov_index >= 3) return fail(h, RPTR_E_INVALID, "AOV index %d (0 albedo+roughness, 1 normal+depth, 2 motion+jitter)", aov_index);
+    const FrameCtx &c = h->ctx[(size_t)h->aov_ctx];
+    if (!c.aov[aov_index]) return fail(h, RPTR_E_INVALID, "AOV images are switched off (RPTR_AOVS=0) or initialize() has not run");
+    return readback_rows<uint2>(h, c.aov[aov_index], reinterpret_cast<uint2 *>(rgba16f), n_halfs / 4);
 }
 
 int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4) {

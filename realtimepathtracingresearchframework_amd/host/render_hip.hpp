@@ -153,6 +153,17 @@ public:
         return need;
     }
 
+    // RenderGraphic::readback_aov (util/display/render_graphic.h:12-17,40): RGBA16F, the reference's AOVBufferIndex order
+    enum AOVBufferIndex { AOVAlbedoRoughnessIndex = 0, AOVNormalDepthIndex, AOVMotionJitterIndex, AOVBufferCount };
+    size_t readback_aov(AOVBufferIndex aov_index, size_t buffer_size, uint16_t *buffer, bool /*force_refresh*/ = false) {
+        uint32_t whc[3];
+        get_framebuffer_size(whc);
+        const size_t need = size_t(whc[0]) * whc[1] * 4;
+        if (buffer_size < need) return 0;
+        check(rptr_hip_readback_aov(h_, int(aov_index), buffer, buffer_size));
+        return need;
+    }
+
     // enable_ray_queries / render_ray_queries with RQ_CLOSEST (render_backend.h:101-102)
     void enable_ray_queries(const int max_queries, const int = 0) { max_queries_ = max_queries; }
     bool render_ray_queries(const RptrRenderRayQuery *queries, int num_queries, float *results4) {

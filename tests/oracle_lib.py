@@ -63,6 +63,8 @@ def lib():
         L.orc_trace_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats)]
+        L.orc_render_aovs.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
         L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
         L.orc_texture_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -173,7 +175,10 @@ class OracleScene:
         return accum, st, buf[:n]
 
     def render(self, width, height, spp, variant=abi.VARIANT_GLTF, params=None, lighting=None, rows=None, sample_begin=0,
-               frame_offset=0, bvh_mode=BVH_OWN, threads=0, count=False, accum=None, camera=None, scene_params=None):
+               frame_offset=0, bvh_mode=BVH_OWN, threads=0, count=False, accum=None, camera=None, scene_params=None, aovs=False,
+               prev_camera=None):
+        """aovs=True: returns (accum, stats, [albedo_roughness, normal_depth, motion_jitter]) with the three float16 (h, w, 4) AOV
+        images the first sample of the frame writes (prev_camera: the previous frame's view, default = the same view)"""
         a = OrcRenderArgs()
         a.width, a.height = width, height
         a.row_begin, a.row_end = rows if rows else (0, height)
@@ -187,6 +192,12 @@ class OracleScene:
         if accum is None:
             accum = np.zeros((height, width, 4), dtype=np.float32)
         st = OrcRenderStats()
+        if aovs:
+            imgs = [np.zeros((height, width, 4), dtype=np.float16) for _ in range(3)]
+            rc = lib().orc_render_aovs(self.h, C.byref(a), _p(accum), C.byref(st), C.byref(prev_camera) if prev_camera is not None else None,
+                                       _p(imgs[0]), _p(imgs[1]), _p(imgs[2]))
+            assert rc == 0, "orc_render_aovs failed: %d" % rc
+            return accum, st, imgs
         rc = lib().orc_render(self.h, C.byref(a), _p(accum), C.byref(st))
         assert rc == 0, "orc_render failed: %d" % rc
         return accum, st

@@ -535,3 +535,75 @@ def test_vks_scene_renders_like_the_oracle(version):
     assert same and rmse < RMSE_TOL
     assert abs(int(st.raw.rays_closest) - ost.rays_closest) <= 1e-3 * ost.rays_closest
 
+
+
+# ---------------------------------------------------------------- AOV images (RenderGraphic::readback_aov)
+def _aov_close(a, b, what):
+    """float16 images: the same finite / non-finite pattern and values within two half ulps (the floats behind them differ by
+    libm ulps between host and device; an RGBA16F store rounds them)"""
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    fa, fb = np.isfinite(a32), np.isfinite(b32)
+    assert (fa == fb).mean() > 0.9995, what
+    both = fa & fb
+    err = np.abs(a32[both] - b32[both])
+    tol = 2.0 ** -9 * np.maximum(np.abs(b32[both]), 2.0 ** -5)
+    assert (err <= tol).mean() > 0.999, (what, float(err.max()))
+
+
+@pytest.mark.parametrize("variant", [abi.VARIANT_GLTF, abi.VARIANT_SIMPLE])
+def test_aov_images_match_the_oracle(variant):
+    s = scenes.textured_test()
+    W, H, spp = 160, 120, 2
+    img, st, r = gpu_render(s, W, H, spp, variant, keep=True)
+    ref, _, aovs = O.OracleScene(s).render(W, H, spp, variant=variant, aovs=True)
+    for k, name in enumerate(("albedo_roughness", "normal_depth", "motion_jitter")):
+        got = np.zeros((H, W, 4), np.float16)
+        assert r.readback_aov(k, got) == W * H * 4
+        _aov_close(got, aovs[k], name)
+    # the next frame accumulates; its first sample (index 2) writes the AOVs again, the view did not move
+    img2, _, _ = gpu_render(s, W, H, spp, variant, reset=False, renderer=r)
+    _, _, aovs2 = O.OracleScene(s).render(W, H, spp, variant=variant, sample_begin=spp, accum=ref.copy(), aovs=True)
+    got = np.zeros((H, W, 4), np.float16)
+    r.readback_aov(r.AOVNormalDepthIndex, got)
+    _aov_close(got, aovs2[1], "normal_depth of the second frame")
+    assert r.readback_aov(0, np.zeros(10, np.float16)) == 0          # too small -> 0
+    with pytest.raises(backend.BackendError):
+        r.readback_aov(5, got)
+    r.close()
+
+
+def test_aov_motion_and_tiles():
+    """a moved camera shows up in the motion AOV; a stripe-split frame returns its own rows only"""
+    s = scenes.textured_test()
+    W, H = 96, 80
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    prev = s.camera_params()
+    prev.pos[0] -= 0.25
+    r.render(backend.RenderConfiguration(prev, active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1)
+    r.render(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1)
+    got = np.zeros((H, W, 4), np.float16)
+    r.readback_aov(r.AOVMotionJitterIndex, got)
+    # the reset before the second frame moved frame_offset on by the one sample of the first (render_vulkan.cpp:1937-1941)
+    _, _, aovs = O.OracleScene(s).render(W, H, 1, aovs=True, prev_camera=prev, frame_offset=1)
+    hit = np.isfinite(aovs[1].astype(np.float32)[..., 3])       # sky pixels project the point (2e32, 2e32, 2e32): inf - inf, not compared
+    _aov_close(got[hit], aovs[2][hit], "motion_jitter")
+    assert np.abs(got.astype(np.float32)[hit][:, 0]).max() > 0.01
+    r.close()
+    full = np.zeros((H, W, 4), np.float16)
+    parts = np.zeros((H, W, 4), np.float16)
+    rf = backend.RenderHip()
+    rf.initialize(W, H)
+    rf.set_scene(s)
+    rf.render(backend.RenderConfiguration(s.camera_params(), reset_accumulation=True), spp=2)
+    rf.readback_aov(1, full)
+    rf.close()
+    for rank in range(2):
+        rr = backend.RenderHip(rank=rank, world_size=2, stripe_rows=8)
+        rr.initialize(W, H)
+        rr.set_scene(s)
+        rr.render(backend.RenderConfiguration(s.camera_params(), reset_accumulation=True), spp=2)
+        rr.readback_aov(1, parts)
+        rr.close()
+    assert np.array_equal(full.view(np.uint16), parts.view(np.uint16))

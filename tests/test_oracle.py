@@ -429,3 +429,52 @@ def test_fully_transparent_screens_equal_the_scene_without_them():
     ib, _ = O.OracleScene(b).render(W, H, spp)
     # instance ids differ between the two scenes, which only enters the seeds of rejected-or-not shadow candidates: none here
     assert np.array_equal(ia, ib)
+
+
+# ---------------------------------------------------------------- AOV images (vulkan/accumulate.glsl:76-103)
+def test_aov_semantics():
+    s = scenes.textured_test()
+    W, H = 96, 72
+    osc = O.OracleScene(s)
+    img, _, (albedo, normal, motion) = osc.render(W, H, 2, aovs=True)
+    plain, _ = osc.render(W, H, 2)
+    assert np.array_equal(img, plain)                                  # writing AOVs does not disturb the image
+    n = normal.astype(np.float32)
+    hit = np.isfinite(n[..., 3])
+    assert 0.5 < hit.mean() < 1.0                                      # sky pixels: depth = |2e32 - cam| overflows to inf, normal 0
+    assert np.all(n[~hit][:, :3] == 0) and np.all(albedo.astype(np.float32)[~hit] == [0, 0, 0, 1])
+    assert np.allclose(np.linalg.norm(n[hit][:, :3], axis=1), 1.0, atol=2e-3)
+    a = albedo.astype(np.float32)[hit]
+    assert a[:, :3].min() >= 0 and a[:, :3].max() <= 1.0 and 0 < a[:, 3].min() and a[:, 3].max() <= 1.0
+    # depth is the distance of the first hit from the camera: compare with a ray query through the pixel centre is off by the
+    # jitter, so only bound it by the scene size
+    assert n[hit][:, 3].min() > 0.5 and n[hit][:, 3].max() < 20
+    # static view: no motion
+    m = motion.astype(np.float32)
+    assert np.all(m[hit] == 0)
+    # the SIMPLE variant reports roughness 1 (ior == 1)
+    _, _, (albedo_s, _, _) = osc.render(W, H, 1, variant=abi.VARIANT_SIMPLE, aovs=True)
+    assert np.all(albedo_s.astype(np.float32)[hit][:, 3] == 1.0)
+    # only the first sample of a frame writes: a frame that starts at sample 2 writes its own AOVs (another jitter)
+    _, _, (_, normal2, _) = osc.render(W, H, 1, sample_begin=2, aovs=True, accum=img.copy())
+    assert not np.array_equal(normal2, normal)
+
+
+def test_aov_motion_vectors_follow_the_previous_view():
+    """motion.xy = projection of the hit point with the previous frame's VP minus its projection with this frame's
+    (accumulate.glsl:76-87), in the clip units of render_vulkan.cpp:2926-2931 (x to the right, y down after GLToVulkan)"""
+    s = scenes.textured_test()
+    W, H = 64, 48
+    cam = s.camera_params()
+    prev = s.camera_params()
+    prev.pos[0] -= 0.25                                                # the camera moved 0.25 to the right since the last frame
+    _, _, (_, normal, motion) = O.OracleScene(s).render(W, H, 1, aovs=True, prev_camera=prev)
+    m, n = motion.astype(np.float32), normal.astype(np.float32)
+    hit = np.isfinite(n[..., 3])
+    # points in front of a camera that moved right appear further right in the previous view... (they moved left on screen)
+    assert (m[hit][:, 0] > 0).mean() > 0.99 and np.abs(m[hit][:, 1]).max() < 0.05
+    # nearer points move more: motion.x ~ P00 * 0.25 / view depth
+    depth_order = np.argsort(n[hit][:, 3])
+    near, far = m[hit][depth_order[:200], 0].mean(), m[hit][depth_order[-200:], 0].mean()
+    assert near > far > 0
+    assert np.all(m[..., 2:] == 0)
