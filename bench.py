@@ -260,7 +260,7 @@ def main():
         except Exception:
             traffic = None
     roofline = {
-        "bound": "hbm", "kernel": "rp_k_extend<false, FIRST, false> (first bounce: <false, true, false>, later bounces: <false, false, false>)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": "rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE> (first bounce: FIRST=true, later bounces: FIRST=false; SINGLE=true for scenes with one instance)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per "
                           "launch averaged over the 9 launches of a frame" if traffic is not None else None,
@@ -273,7 +273,7 @@ def main():
                                 "stage_ms_per_step": {"extend": round(serial["ext"], 4), "connect": round(serial["con"], 4),
                                                       "raygen_sort_shade_resolve": round(serial["other"], 4),
                                                       "gpu_total": round(serial["gpu"], 4)},
-                                "connect": {"kernel": "rp_k_connect<false, false>",
+                                "connect": {"kernel": "rp_k_connect<COUNT=false, ALPHA=false, SINGLE>",
                                             "achieved": round(con_bytes / (serial["con"] * 1e-3) / 1e9, 2) if serial["con"] > 0 else 0.0,
                                             "algorithmic_bytes_per_step": int(con_bytes)}},
         "counts_per_step": cnt,

@@ -570,6 +570,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
     if (bvh.insts.size() == 1 && !g_no_single_instance) {
         // the device's shortcut for scenes with one instance record (csrc/dtraverse.h): start inside the instance
         cur_inst = &bvh.insts[0];
+        if (cnt) cnt->nodes++; // the first 64 bytes of the instance record
         o = xform_point(cur_inst->world_to_object, ray.o);
         d = xform_dir(cur_inst->world_to_object, ray.d);
         id = vec3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));

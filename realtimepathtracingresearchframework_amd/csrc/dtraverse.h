@@ -244,6 +244,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         // entering the instance through its leaf; oracle/obvh.h traverse4 takes the same shortcut)
                         const float4 *ip = reinterpret_cast<const float4 *>(sc.insts);
                         const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], meta = ip[3];
+                        if (COUNT) n_nodes++; // the 64 bytes of the instance record every query still reads
                         set_ray(rp_xform_point(w0, w1, w2, ro), rp_xform_dir(w0, w1, w2, rd));
                         cur_inst = 0;
                         cur_inst_id = __float_as_int(meta.z);

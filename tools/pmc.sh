@@ -16,7 +16,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
 seen=set()
 for r in rows:
-    k=r['Kernel_Name'].split('(')[0][:40]
+    k=r['Kernel_Name'].split('(')[0]
     agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
     key=(r['Dispatch_Id'])
     if key not in seen: seen.add(key); calls[k]+=1
@@ -27,5 +27,5 @@ with open(sys.argv[2],'w',newline='') as f:
     for k in sorted(agg, key=lambda k:-calls[k]):
         if not k.startswith(('void rp_k','rp_k')): continue
         w.writerow([k,calls[k]]+['%.6g'%(agg[k][n]) for n in names])
-        print('%-42s calls %4d '%(k,calls[k])+' '.join('%s=%.4g'%(n,agg[k][n]) for n in names))
+        print('%-50s calls %4d '%(k,calls[k])+' '.join('%s=%.4g'%(n,agg[k][n]) for n in names))
 PY
