@@ -765,3 +765,39 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
             with open(tdir + nm + "_SpecularTransmission.txt", "w") as f:
                 f.write("%.9g\n%.9g\n0\n0\n" % (float(mat.specular_transmission), float(mat.ior)))
     return names
+
+
+# ------------------------------------------------------------------ command line: .vks -> flat scene dump for the C++ host tools
+def main(argv=None):
+    """python -m realtimepathtracingresearchframework_amd.vks scene.vks --dump scene.rpsc [--eye x y z --center x y z --up x y z
+    --fov f] [--sky KEY]: loads a .vks scene the way the reference does and writes the flat file `bin/rptr_hip` reads
+    (host/scene_dump.hpp), i.e. what a reference-side adapter would hand to the backend after its own `Scene` load."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m realtimepathtracingresearchframework_amd.vks", description=main.__doc__)
+    ap.add_argument("vks")
+    ap.add_argument("--dump", required=True, help="output path of the flat scene file")
+    ap.add_argument("--eye", type=float, nargs=3)
+    ap.add_argument("--center", type=float, nargs=3)
+    ap.add_argument("--up", type=float, nargs=3)
+    ap.add_argument("--fov", type=float)
+    ap.add_argument("--sky", default="default", choices=sorted(SKY_CONFIGS), help="sky configuration (scenes.SKY_CONFIGS)")
+    ap.add_argument("--ignore-textures", action="store_true")
+    args = ap.parse_args(argv)
+    s = read_vks(args.vks, ignore_textures=args.ignore_textures)
+    cam = dict(s.camera)
+    for key in ("eye", "center", "up"):
+        if getattr(args, key) is not None:
+            cam[key] = tuple(getattr(args, key))
+    if args.fov is not None:
+        cam["fov"] = args.fov
+    s.camera = cam
+    s.config = SceneConfig(**SKY_CONFIGS[args.sky])
+    s.sky_key = args.sky
+    s.dump(args.dump)
+    print("%s: %d meshes, %d instances, %d triangles, %d materials, %d textures, %d emitters -> %s" % (
+        args.vks, len(s.meshes), len(s.instances), s.num_tris(), len(s.materials), len(s.textures), len(s.lights), args.dump))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
