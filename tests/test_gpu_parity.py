@@ -607,3 +607,19 @@ def test_aov_motion_and_tiles():
         rr.readback_aov(1, parts)
         rr.close()
     assert np.array_equal(full.view(np.uint16), parts.view(np.uint16))
+
+
+def test_empty_scene_is_all_sky():
+    """a scene without instances (an empty top level): every query misses, the image is the sky model"""
+    s = scenes.cornell32()
+    s.instances = []
+    s.prepare_lights()
+    img, st, r = gpu_render(s, 64, 48, 2, abi.VARIANT_GLTF, keep=True)
+    ref, ost = O.OracleScene(s).render(64, 48, 2)
+    rmse, same, _ = image_error(img, ref)
+    assert same and rmse < RMSE_TOL and st.raw.rays_closest == 64 * 48 * 2 == ost.rays_closest and st.raw.rays_shadow == 0
+    q = np.zeros((5, 8), np.float32)
+    q[:, 6], q[:, 7] = 1.0, 1e20
+    res = r.render_ray_queries(q)
+    assert (res[:, 0] == -1).all() and (res[:, 2].view(np.int32) == -1).all()
+    r.close()
