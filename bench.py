@@ -181,7 +181,7 @@ def main():
         while queue:
             on_stats(finish(queue.pop(0)))
 
-    r.set_stage_timing(1)  # timed region: HIP events around every closest-hit traversal launch (the roofline kernel) only
+    r.set_stage_timing(int(os.environ.get("BENCH_STAGE_TIMING", "1")))  # timed region: HIP events around every closest-hit traversal launch (the roofline kernel) only
     for _ in range(args.warmup):
         step()
     if anim is not None:

@@ -9,6 +9,7 @@
 
 #include "bvh_build.h"
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <array>
@@ -1410,6 +1411,16 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             launch();
     };
     auto timed = [&](int kind, auto &&launch) { timed_on(c.stream, kind, launch); };
+    // a stage that is ONE kernel: its start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL), no extra
+    // barrier packets in the queue -- the command processor's packet rate is what bounds small frames (profiles/r01_notes.md)
+    auto timed_kernel = [&](hipStream_t st, int kind, auto kernel, dim3 grid, dim3 block, auto... args) {
+        if (h->stage_timing >= 2 || (h->stage_timing == 1 && kind == 0)) {
+            hipEvent_t a = next_event(c, ev_cursor), b = next_event(c, ev_cursor);
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, st, a, b, 0, args...);
+            c.spans.push_back({a, b, kind});
+        } else
+            hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
+    };
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
@@ -1461,10 +1472,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
-                timed(0, [&] {
+                {
                     auto go = [&](auto kernel) {
-                        hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, c.stream, scn.dscene, f, c.ps,
-                                           b == 0 ? first_ids : c.queue[in], bc, c.counters, c.gstack);
+                        timed_kernel(c.stream, 0, kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), scn.dscene, f, c.ps,
+                                     b == 0 ? first_ids : (const uint32_t *)c.queue[in], bc, c.counters, c.gstack);
                     };
                     pick(count_traversal, [&](auto C) {
                         pick(b == 0, [&](auto F) {
@@ -1473,7 +1484,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                             });
                         });
                     });
-                });
+                }
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
                 const uint32_t *order = in_queue;
@@ -1501,17 +1512,16 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         HIP_TRY(h, hipEventRecord(c.ev_fork, c.stream));
                         HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
                     }
-                    timed_on(cs, 1, [&] {
+                    {
                         auto go = [&](auto kernel) {
-                            hipLaunchKernelGGL(kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, cs, scn.dscene, f, c.ps, c.sq, bc, c.counters,
-                                               stack);
+                            timed_kernel(cs, 1, kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), scn.dscene, f, c.ps, c.sq, bc, c.counters, stack);
                         };
                         pick(count_traversal, [&](auto C) {
                             pick(h->uses_alpha, [&](auto A) {
                                 pick(single, [&](auto S) { go(rp_k_connect<decltype(C)::value, decltype(A)::value, decltype(S)::value>); });
                             });
                         });
-                    });
+                    }
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }
                 c.launches_connect++;
@@ -1519,10 +1529,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             if (side) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // the last connect
             // resolves fold into one history buffer: they run in submission order across the contexts
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
-            timed(2, [&] {
+            {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                hipLaunchKernelGGL(rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), 0, c.stream, f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
-            });
+                timed_kernel(c.stream, 2, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
+            }
             if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
                 h->last_resolved = c.ev_resolved;

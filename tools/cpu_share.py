@@ -6,14 +6,15 @@ import torch
 from realtimepathtracingresearchframework_amd import abi, backend, scenes
 s = scenes.grid_1m()
 W, H, spp = 1920, 1080, 4
+FIF = int(os.environ.get("FIF", "3"))
 for world in (1, 8):
-    r = backend.RenderHip(rank=0, world_size=world, stripe_rows=32, stream=torch.cuda.current_stream().cuda_stream, frames_in_flight=3)
+    r = backend.RenderHip(rank=0, world_size=world, stripe_rows=8, stream=torch.cuda.current_stream().cuda_stream, frames_in_flight=FIF)
     r.initialize(W, H); r.set_scene(s); r.set_stage_timing(1)
     cam = s.camera_params()
     q = []
     for _ in range(6):
         q.append(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=spp))
-        if len(q) >= 3: r.wait(q.pop(0))
+        if len(q) >= FIF: r.wait(q.pop(0))
     while q: r.wait(q.pop(0))
     K = 200; ts = tw = 0.0
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -21,7 +22,7 @@ for world in (1, 8):
         a = time.perf_counter()
         q.append(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=spp))
         b = time.perf_counter(); ts += b - a
-        if len(q) >= 3:
+        if len(q) >= FIF:
             r.wait(q.pop(0)); tw += time.perf_counter() - b
     while q: r.wait(q.pop(0))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
