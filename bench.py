@@ -190,9 +190,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
-    acc = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0, rays=0)
+    acc = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0, rays=0, launches=0)
 
     def on_stats(st):
+        acc["launches"] = int(st.raw.launches_extend)  # stand-alone closest-hit launches per frame (the rest runs in the tail kernel)
         acc["ext"] += st.raw.extend_time_ms
         acc["con"] += st.raw.connect_time_ms
         acc["other"] += st.raw.shade_time_ms
@@ -218,11 +219,30 @@ def main():
         serial["con"] += st.connect_time_ms / n_serial
         serial["other"] += st.shade_time_ms / n_serial
         serial["gpu"] += st.render_time_ms / n_serial
-    stc = step(count=True).raw
-    cnt = dict(rays_closest=int(stc.rays_closest), rays_shadow=int(stc.rays_shadow), hits=int(stc.hits_shaded),
-               nodes_closest=int(stc.nodes_closest), tris_closest=int(stc.tris_closest),
-               nodes_shadow=int(stc.nodes_visited - stc.nodes_closest), tris_shadow=int(stc.tris_tested - stc.tris_closest))
-    launches_extend = int(stc.launches_extend)
+    def counted(depth=None):
+        """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
+        full = r.params.max_path_depth
+        if depth is not None:
+            r.params.max_path_depth = depth
+        try:
+            stc = step(count=True).raw
+        finally:
+            r.params.max_path_depth = full
+        return dict(rays_closest=int(stc.rays_closest), rays_shadow=int(stc.rays_shadow), hits=int(stc.hits_shaded),
+                    nodes_closest=int(stc.nodes_closest), tris_closest=int(stc.tris_closest),
+                    nodes_shadow=int(stc.nodes_visited - stc.nodes_closest), tris_shadow=int(stc.tris_tested - stc.tris_closest),
+                    launches=int(stc.launches_extend))
+    cnt = counted()
+    max_depth = cnt.pop("launches")
+    # The timed frames hand the late bounces to the tail kernel: `launches_extend` stand-alone closest-hit launches (bounces
+    # 0..k-1) and as many shadow-ray launches per frame. Their work, counted exactly: the closest-hit queries of a frame cut at k
+    # bounces, the shadow queries of a frame cut at k+1 (the last bounce of a path issues no shadow ray).
+    launches_extend = acc["launches"] if acc["launches"] > 0 else max_depth
+    if launches_extend < max_depth:
+        cnt_ext = counted(launches_extend)
+        cnt_con = counted(launches_extend + 1)
+    else:
+        cnt_ext = cnt_con = cnt
 
     if world > 1:
         rdev = "cpu" if on_host else "cuda"
@@ -242,10 +262,10 @@ def main():
     mrays = rays / elapsed / 1e6
     # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share
     primary = r.local_pixel_count() * spp  # the first launch computes its camera rays instead of reading them
-    ext_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * RAY_BYTES + cnt["nodes_closest"] * NODE_BYTES
-                 + cnt["tris_closest"] * TRI_BYTES)
-    con_bytes = (cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
-                 + cnt["tris_shadow"] * TRI_BYTES)
+    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * RAY_BYTES + cnt_ext["nodes_closest"] * NODE_BYTES
+                 + cnt_ext["tris_closest"] * TRI_BYTES)
+    con_bytes = (cnt_con["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt_con["nodes_shadow"] * NODE_BYTES
+                 + cnt_con["tris_shadow"] * TRI_BYTES)
     ext_ms_step = ext_ms / K  # HIP events in the timed region; with frames in flight the launches of different frames overlap
     achieved = ext_bytes / (ext_ms_step * 1e-3) / 1e9 if ext_ms_step > 0 else 0.0
     achieved_serial = ext_bytes / (serial["ext"] * 1e-3) / 1e9 if serial["ext"] > 0 else 0.0
@@ -263,7 +283,7 @@ def main():
         "bound": "hbm", "kernel": "rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE> (first bounce: FIRST=true, later bounces: FIRST=false; SINGLE=true for scenes with one instance)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per "
-                          "launch averaged over the 9 launches of a frame" if traffic is not None else None,
+                          "launch averaged over the stand-alone closest-hit launches of a frame" if traffic is not None else None,
         "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
         "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,
         "note": "achieved/launch_ms: HIP events over the timed region (%d frames in flight: launches of neighbouring frames share the GPU); "
@@ -277,6 +297,12 @@ def main():
                                             "achieved": round(con_bytes / (serial["con"] * 1e-3) / 1e9, 2) if serial["con"] > 0 else 0.0,
                                             "algorithmic_bytes_per_step": int(con_bytes)}},
         "counts_per_step": cnt,
+        "tail": {"from_bounce": launches_extend, "max_path_depth": max_depth,
+                 "note": "bounces >= from_bounce run in one rp_k_tail launch per frame (its time is part of raygen_sort_shade_resolve); the "
+                         "roofline figures cover the stand-alone launches of bounces < from_bounce",
+                 "standalone_counts": {"rays_closest": cnt_ext["rays_closest"], "nodes_closest": cnt_ext["nodes_closest"],
+                                       "tris_closest": cnt_ext["tris_closest"], "rays_shadow": cnt_con["rays_shadow"],
+                                       "nodes_shadow": cnt_con["nodes_shadow"], "tris_shadow": cnt_con["tris_shadow"]}} if launches_extend < max_depth else None,
     }
     if refit_ms is not None:
         roofline["update_vertices_and_refit_ms"] = round(refit_ms, 4)

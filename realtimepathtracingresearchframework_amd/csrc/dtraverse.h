@@ -148,7 +148,7 @@ struct RpNoAlpha {
     RP_DEV bool operator()(uint32_t, int, int, int, int, float, float) const { return false; }
 };
 template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN),
-          bool ALPHA = false, bool SINGLE = false, class Load, class Done, class Alpha>
+          bool ALPHA = false, bool SINGLE = false, bool LOCAL = false, class Load, class Done, class Alpha>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
                           uint32_t &n_nodes, uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
@@ -160,9 +160,12 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     // wave-uniform pool of queue entries
     // pool size: the queue is dealt out in 64..RP_FETCH entries per wave so that a short queue (late bounces) still
     // spreads over as many waves as it has 64-entry groups instead of 256 entries per wave on a quarter of the SIMDs
-    const uint32_t nwaves = gstride >> 6;
-    const uint32_t fetch = min((uint32_t)RP_FETCH, max(64u, ((n + nwaves * RP_FETCH_DIV - 1u) / (nwaves * RP_FETCH_DIV) + 63u) & ~63u));
-    uint32_t pool_next = ((blockIdx.x * blockDim.x + tid) >> 6) * fetch;
+    // LOCAL: the queue belongs to this block alone (the tail kernel's block-local lists, kernels.h rp_k_tail): pools are dealt
+    // to the block's own waves, `cursor` is a word in LDS
+    const uint32_t nwaves = LOCAL ? (blockDim.x >> 6) : (gstride >> 6);
+    const uint32_t fetch =
+        LOCAL ? 64u : min((uint32_t)RP_FETCH, max(64u, ((n + nwaves * RP_FETCH_DIV - 1u) / (nwaves * RP_FETCH_DIV) + 63u) & ~63u));
+    uint32_t pool_next = ((LOCAL ? tid : (blockIdx.x * blockDim.x + tid)) >> 6) * fetch;
     uint32_t pool_end = min(n, pool_next + fetch);
     bool more = pool_next < n; // the shared cursor starts behind every static pool
     if (!more) return;

@@ -137,9 +137,10 @@ __global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, uint32_t *queue, R
 // ALPHA: the scene has alpha-tested materials. The test of a candidate may draw from the path's generator
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
 // SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
-                                               int *gstack) {
+// LOCAL: `queue` / `cursor` are a block-local list and its cursor in LDS (rp_k_tail).
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL>
+RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const uint32_t *queue, uint32_t n, uint32_t *cursor, RpCounters *ctr,
+                           int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
@@ -174,8 +175,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, lane_rng);
     };
-    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE>(
-        sc, bc->queue_count, &bc->cursor_extend, gstack, load, done, alpha, n_nodes, n_tris);
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE, LOCAL>(
+        sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -185,15 +186,22 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
         }
     }
 }
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+                                               int *gstack) {
+    rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
+}
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 // ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
 // instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
-template <bool COUNT, bool ALPHA, bool SINGLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+// ids: the compacted path ids of the shadow rays (sq.ids, or the tail kernel's block-local list: LOCAL)
+template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL>
+RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *ids, uint32_t n, uint32_t *cursor,
+                            RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto alpha = [&](uint32_t i, int inst_idx, int inst_id, int geom, int prim, float u, float v) -> bool {
-        const uint32_t p = sq.ids[i];
+        const uint32_t p = ids[i];
         const uint32_t sslot = p / uint32_t(f.npix_padded);
         const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
         int lx = 0, ly = 0;
@@ -203,7 +211,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, rng);
     };
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
-        const uint32_t p = sq.ids[i];
+        const uint32_t p = ids[i];
         const float4 o = sq.o[p], d = sq.d[p];
         ro = xyz(o);
         rd = xyz(d);
@@ -212,7 +220,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
         if (h.inst_idx < 0) { // visible: NEE contribution arrives (nee.glsl:76-84)
-            const uint32_t p = sq.ids[i];
+            const uint32_t p = ids[i];
             const float4 c = sq.contrib[p];
             float4 il = ps.illum[p];
             il.x += c.x;
@@ -221,8 +229,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
             ps.illum[p] = il;
         }
     };
-    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE>(sc, bc->shadow_count, &bc->cursor_connect, gstack, load, done, alpha, n_nodes,
-                                                                            n_tris);
+    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -231,6 +238,10 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
             atomicAdd(&ctr->tris_shadow, (unsigned long long)n_tris);
         }
     }
+}
+template <bool COUNT, bool ALPHA, bool SINGLE>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+    rp_connect_body<COUNT, ALPHA, SINGLE, false>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
 }
 
 // ------------------------------------------------------------------ sort by material and hit cell
@@ -376,10 +387,12 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 // LIGHTS = false: the scene has no emissive triangles, every NEE sample goes to the sun (sun_radiance.w == 1,
 // vulkan/render_sky.cpp:68-71) and the binned-RIS code is compiled out (fewer registers, smaller kernel)
 // TEX = false: no material of the scene reads a texture (textured parameters, normal maps): sampling code compiled out
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX>
-__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
-                                                  const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
-                                                  RpCounters *ctr) {
+// LOCAL (rp_k_tail): `order` is a block-local list of n <= RP_CHUNK path ids; the survivors and the shadow rays are not
+// published to the global queues but left in shared memory for the caller (local_next / local_shadow, counts in n_next / n_shadow)
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL>
+RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
+                          uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
+                          uint32_t *&local_shadow, uint32_t &n_shadow) {
     __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
@@ -389,10 +402,16 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
     __shared__ float s_ris_req[LIGHTS ? (256 / 64) * 64 * 8 : 1];
     __shared__ float s_ris_contrib[LIGHTS ? (256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE : 1];
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
-    const uint32_t n = *count_ptr;
+    if (LOCAL) {
+        if (threadIdx.x == 0) {
+            s_nn = 0;
+            s_ns = 0;
+        }
+        __syncthreads(); // the body runs once per bounce in the tail kernel: the previous call's readers are done
+    }
     const uint32_t nchunks = (n + RP_CHUNK - 1) / RP_CHUNK;
     uint32_t my_closest = 0, my_shadow = 0, my_hits = 0;
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint32_t chunk = LOCAL ? 0u : blockIdx.x; chunk < nchunks; chunk += LOCAL ? nchunks : gridDim.x) {
         if (threadIdx.x == 0) {
             s_nn = 0;
             s_ns = 0;
@@ -716,10 +735,12 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
             if (has_shadow) s_shadow[sat] = p;
         }
         __syncthreads();
-        rp_block_flush(s_next, s_nn, next_queue, next_count, &s_base);
-        __syncthreads();
-        rp_block_flush(s_shadow, s_ns, sq.ids, shadow_count, &s_base);
-        __syncthreads();
+        if (!LOCAL) {
+            rp_block_flush(s_next, s_nn, next_queue, next_count, &s_base);
+            __syncthreads();
+            rp_block_flush(s_shadow, s_ns, sq.ids, shadow_count, &s_base);
+            __syncthreads();
+        }
     }
     my_closest = rp_wave_sum_u32(my_closest);
     my_shadow = rp_wave_sum_u32(my_shadow);
@@ -734,6 +755,55 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
         if (s_stat[0]) atomicAdd(&ctr->rays_closest, (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&ctr->rays_shadow, (unsigned long long)s_stat[1]);
         if (s_stat[2]) atomicAdd(&ctr->hits_shaded, (unsigned long long)s_stat[2]);
+    }
+    if (LOCAL) {
+        local_next = s_next;
+        local_shadow = s_shadow;
+        n_next = s_nn;
+        n_shadow = s_ns;
+    }
+}
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX>
+__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
+                                                  const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
+                                                  RpCounters *ctr) {
+    uint32_t *ln = nullptr, *ls = nullptr;
+    uint32_t nn = 0, ns = 0;
+    rp_shade_body<VARIANT, FIRST, LIGHTS, TEX, false>(sc, f, ps, sq, order, *count_ptr, next_queue, next_count, shadow_count, ctr, ln, nn, ls, ns);
+}
+
+// ------------------------------------------------------------------ tail: the late bounces of a frame in ONE launch
+// From some bounce on a frame's queues hold a few thousand paths, and what a bounce then costs is its three launches
+// (a command-processor packet each, ~14 us when several frames are in flight: profiles/r01_notes.md), not its rays. Paths are
+// independent, so the rest of the frame needs no grid-wide step: a block takes RP_TAIL_CHUNK paths of the bounce's queue and runs
+// them to the end -- extend, shade, connect per bounce on block-local lists in LDS, the same device code as the stand-alone
+// kernels (results are bit-identical, tests/test_gpu_parity.py) -- before it takes the next chunk.
+#define RP_TAIL_CHUNK 256
+template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE>
+__global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
+                                                    int first_bounce, int *gstack) {
+    __shared__ uint32_t s_cur[RP_TAIL_CHUNK];
+    __shared__ uint32_t s_cursor[2];
+    const uint32_t n_total = ctr->bounce[first_bounce].queue_count;
+    const uint32_t nchunks = (n_total + RP_TAIL_CHUNK - 1) / RP_TAIL_CHUNK;
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        uint32_t n = min((uint32_t)RP_TAIL_CHUNK, n_total - chunk * RP_TAIL_CHUNK);
+        __syncthreads(); // the previous chunk is done with s_cur
+        if (threadIdx.x < n) s_cur[threadIdx.x] = queue[chunk * RP_TAIL_CHUNK + threadIdx.x];
+        for (int b = first_bounce; b < f.rp.max_path_depth && n > 0; ++b) {
+            if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
+            __syncthreads();
+            rp_extend_body<false, false, ALPHA, SINGLE, true>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack);
+            __syncthreads();
+            uint32_t *next = nullptr, *shadow = nullptr;
+            uint32_t n_next = 0, n_shadow = 0;
+            rp_shade_body<VARIANT, false, LIGHTS, TEX, true>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow);
+            __syncthreads();
+            rp_connect_body<false, ALPHA, SINGLE, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack);
+            __syncthreads();
+            if (threadIdx.x < n_next) s_cur[threadIdx.x] = next[threadIdx.x]; // survivors: at most n <= RP_TAIL_CHUNK
+            n = n_next;
+        }
     }
 }
 

@@ -92,6 +92,7 @@ struct FrameCtx {
     std::vector<Span> spans;
     RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
     int launches_extend = 0, launches_connect = 0, spp_after = 0;
+    int tail_from = 0; // the bounce at which this context's last frame handed over to the tail kernel (= max depth: no tail)
 };
 
 } // namespace
@@ -154,6 +155,10 @@ struct rptr_hip {
     int next_ctx = 0;
     int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
     int aov_ctx = 0;                // the context whose AOV images readback_aov returns (last finished frame)
+    int tail_mode = -1;             // RPTR_TAIL_BOUNCE: -1 adaptive, 0 off, k > 0: the tail kernel takes over at bounce k
+    int tail_adaptive = 1 << 30;    // adaptive choice for the next frame (from the queue lengths of the last finished frame)
+    int tail_blocks = 0;
+    int tail_threshold = 65536;     // RPTR_TAIL_THRESHOLD: queue length below which a bounce goes to the tail kernel
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
     RptrCamera prev_camera;         // the previous frame's view (VP_reference)
     bool have_prev_camera = false;
@@ -557,6 +562,8 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
         h->ctx.resize((size_t)fif);
         if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
+        if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
+        if (const char *s = getenv("RPTR_TAIL_THRESHOLD")) h->tail_threshold = std::max(0, atoi(s));
         for (FrameCtx &c : h->ctx) {
             memset(&c.ps, 0, sizeof(c.ps));
             memset(&c.sq, 0, sizeof(c.sq));
@@ -729,6 +736,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     occ = std::max(1, std::min(occ, 8));
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
+    h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
     const size_t stack_threads = (size_t)h->persistent_blocks * RP_TRAVERSE_BLOCK;
     for (FrameCtx &c : h->ctx) {
         if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
@@ -1309,6 +1317,20 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
     st.device_bytes_allocated = h->bytes_allocated;
     if (h->ctx.size() > 1) h->output_ctx = (int)(&c - h->ctx.data());
     h->aov_ctx = (int)(&c - h->ctx.data());
+    if (h->local_rows > 0) {
+        // where the next frame hands over to the tail kernel: the first bounce whose queue was short in this frame. Queue
+        // lengths are known up to the bounce the tail took over at (it does not publish its block-local lists), so the
+        // hand-over moves later by one bounce per frame at most
+        const int depth = h->params.max_path_depth, used = std::min(c.tail_from, depth);
+        int next = depth;
+        for (int b = 1; b <= std::min(used, depth - 1); ++b)
+            if (c.host_counters->bounce[b].queue_count <= (uint32_t)h->tail_threshold) {
+                next = b;
+                break;
+            }
+        if (next == depth && used < depth) next = std::min(depth, used + 1);
+        h->tail_adaptive = next;
+    }
     if (out_stats) *out_stats = st;
     return RPTR_OK;
 }
@@ -1469,9 +1491,34 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             }
             const uint32_t *first_ids = fq->second.ids;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)fq->second.count, 1, c.stream));
+            // the late bounces in one launch (kernels.h rp_k_tail); counting, the regrouping pass and the side stream keep the
+            // stand-alone kernels
+            int tail_from = h->params.max_path_depth;
+            if (h->tail_mode != 0 && !count_traversal && !do_sort && !side)
+                tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
+            c.tail_from = tail_from;
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
+                if (b == tail_from) {
+                    const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
+                    const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
+                    auto go = [&](auto kernel) {
+                        timed_kernel(c.stream, 2, kernel, dim3(h->tail_blocks), dim3(256), scn.dscene, f, c.ps, c.sq, (const uint32_t *)c.queue[in], c.counters, b,
+                                     c.gstack);
+                    };
+                    pick(variant == RPTR_VARIANT_SIMPLE, [&](auto V) {
+                        pick(lights, [&](auto L) {
+                            pick(full, [&](auto F) {
+                                pick(single, [&](auto S) {
+                                    constexpr int VAR = decltype(V)::value ? RPTR_VARIANT_SIMPLE : RPTR_VARIANT_GLTF;
+                                    go(rp_k_tail<VAR, decltype(L)::value, decltype(F)::value, decltype(F)::value, decltype(S)::value>);
+                                });
+                            });
+                        });
+                    });
+                    break;
+                }
                 {
                     auto go = [&](auto kernel) {
                         timed_kernel(c.stream, 0, kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), scn.dscene, f, c.ps,

@@ -623,3 +623,36 @@ def test_empty_scene_is_all_sky():
     res = r.render_ray_queries(q)
     assert (res[:, 0] == -1).all() and (res[:, 2].view(np.int32) == -1).all()
     r.close()
+
+
+# ---------------------------------------------------------------- tail kernel (late bounces in one launch)
+@pytest.mark.parametrize("scene_name,variant", [("two_level_test", abi.VARIANT_GLTF), ("alpha_test", abi.VARIANT_GLTF), ("cornell32", abi.VARIANT_SIMPLE)])
+def test_tail_kernel_is_bit_identical_to_the_standalone_launches(scene_name, variant):
+    """rp_k_tail runs extend / shade / connect of the late bounces on block-local lists: same device code, same bits, wherever
+    the hand-over happens (fixed bounce 1..4, or chosen from the previous frame's queue lengths)"""
+    import os
+    s = getattr(scenes, scene_name)()
+    W, H, spp = 96, 72, 3
+    images = {}
+    for mode in ("0", "1", "2", "4", "-1"):
+        os.environ["RPTR_TAIL_BOUNCE"] = mode
+        os.environ["RPTR_TAIL_THRESHOLD"] = "100000000"     # adaptive: hand over as early as it may
+        try:
+            r = backend.RenderHip()
+            r.initialize(W, H)
+            r.set_scene(s)
+            frames = []
+            for k in range(3):                               # three accumulating frames: the adaptive mode settles after the first
+                img, st, _ = gpu_render(s, W, H, spp, variant, reset=(k == 0), renderer=r)
+                frames.append((img.copy(), int(st.raw.launches_extend), int(st.raw.rays_closest), int(st.raw.rays_shadow)))
+            r.close()
+        finally:
+            del os.environ["RPTR_TAIL_BOUNCE"], os.environ["RPTR_TAIL_THRESHOLD"]
+        images[mode] = frames
+    depth = abi.RenderParams.default().max_path_depth
+    assert [f[1] for f in images["0"]] == [depth] * 3 and [f[1] for f in images["2"]] == [2] * 3
+    assert images["-1"][0][1] == depth and images["-1"][2][1] == 1          # first frame without a tail, then from bounce 1
+    for mode in ("1", "2", "4", "-1"):
+        for a, b in zip(images["0"], images[mode]):
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), mode
+            assert a[2:] == b[2:], mode                                      # the same rays were traced
