@@ -241,8 +241,10 @@ typedef struct RptrCreateInfo {
     int32_t world_size;
     int32_t stripe_rows;    /* 0 -> default 32                                   */
     void *stream;           /* hipStream_t to launch on, NULL -> backend-owned   */
-    int32_t frames_in_flight; /* 0/1: frames run one after the other on `stream`; 2..8: that many frame contexts with
-                               * their own streams, see rptr_hip_render_async                                  */
+    int32_t frames_in_flight; /* 0/1: frames run one after the other on `stream`; 2..16: that many frame contexts with
+                               * their own streams, see rptr_hip_render_async. Every context's stream wants a hardware
+                               * queue of its own: start the process with GPU_MAX_HW_QUEUES >= frames_in_flight + 1
+                               * (HIP runtime variable, default 4; streams that share a queue serialise).          */
     int32_t _pad;
 } RptrCreateInfo;
 

@@ -558,7 +558,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     {
         int fif = info ? info->frames_in_flight : 1;
         if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) fif = atoi(s);
-        fif = std::max(1, std::min(fif, 8));
+        fif = std::max(1, std::min(fif, 16));
         if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
         h->ctx.resize((size_t)fif);
         if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
