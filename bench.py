@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 # One hardware queue per HIP stream: every frame context of the backend owns a stream, and two streams that share a hardware
 # queue serialise (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 queues by default; measured: 7 contexts on 4 queues
 # 0.34 ms per 1/8 frame, on 8 queues 0.29 ms). Read by the runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # 7 frame contexts + the caller's stream + RCCL's
 
 # record sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query

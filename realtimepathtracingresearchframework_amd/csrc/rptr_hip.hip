@@ -786,6 +786,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             return fail(h, RPTR_E_INVALID, "texture %u: bad size or NULL data", t);
     h->uses_textures = false;
     h->uses_alpha = false;
+    h->tail_adaptive = 1 << 30; // the first frame of a scene shows the queue lengths of every bounce
     for (uint32_t m = 0; m < s->num_materials; ++m) {
         const RptrBaseMaterial &mat = s->materials[m];
         if (mat.normal_map != -1) h->uses_textures = true;
@@ -1328,7 +1329,8 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
                 next = b;
                 break;
             }
-        if (next == depth && used < depth) next = std::min(depth, used + 1);
+        if (next == depth && used < depth) // the tail's own queue was long: one bounce later, or (far too long) a frame without a tail to see all queues again
+            next = c.host_counters->bounce[used].queue_count > 4u * (uint32_t)h->tail_threshold ? depth : std::min(depth, used + 1);
         h->tail_adaptive = next;
     }
     if (out_stats) *out_stats = st;
