@@ -1493,16 +1493,16 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             }
             const uint32_t *first_ids = fq->second.ids;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)fq->second.count, 1, c.stream));
-            // the late bounces in one launch (kernels.h rp_k_tail); counting, the regrouping pass and the side stream keep the
-            // stand-alone kernels
+            // the late bounces in one launch (kernels.h rp_k_tail); counting and the regrouping pass keep the stand-alone kernels
             int tail_from = h->params.max_path_depth;
-            if (h->tail_mode != 0 && !count_traversal && !do_sort && !side)
+            if (h->tail_mode != 0 && !count_traversal && !do_sort)
                 tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
             c.tail_from = tail_from;
             for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 if (b == tail_from) {
+                    if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) on the side stream
                     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
                     auto go = [&](auto kernel) {
