@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--lights", action="store_true", help="configs[2]: add the 512 emissive triangles")
     ap.add_argument("--scene", type=str, default="grid", choices=["grid", "forest"],
                     help="forest = SURVEY 8d C4: 10 tree meshes x 10k triangles, 1000 instances (10M instanced triangles)")
+    ap.add_argument("--flatten", type=int, default=-1,
+                    help="RPTR_FLATTEN: build a static multi-instance scene as one world-space tree (memory for speed). Default: on "
+                         "for --scene forest (10 M instanced triangles = 0.6 GB), off otherwise")
     ap.add_argument("--animate", action="store_true",
                     help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
                          "(inside the timed region) and renders")
@@ -117,6 +120,8 @@ def main():
     # one explicit stream for torch AND the backend: the tile copy, the gather and the animation kernel are ordered with the
     # frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream":
     # the tile copy would then run unordered with the gather.)
+    flatten = args.flatten if args.flatten >= 0 else (1 if args.scene == "forest" else 0)
+    os.environ["RPTR_FLATTEN"] = str(flatten)
     torch_stream = torch.cuda.Stream()
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
@@ -328,7 +333,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
-                   "frames_in_flight": fif,
+                   "frames_in_flight": fif, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,

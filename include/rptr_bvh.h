@@ -61,10 +61,15 @@ typedef struct RptrBvhTri {
     float e2[3]; /* v2 - v0 */
     uint32_t prim;     /* primitive index inside its geometry                    */
     uint32_t geom;     /* geometry index inside its mesh (rayQuery GeometryIndex) */
-    uint32_t flags;    /* RPTR_BVH_TRI_ALPHA: some parameterized mesh gives this triangle a material without
-                          BASE_MATERIAL_NOALPHA, i.e. a hit is a candidate for the alpha test (pt_megakernel.glsl:153-212) */
+    uint32_t flags;    /* bit 0, RPTR_BVH_TRI_ALPHA: some parameterized mesh gives this triangle a material without
+                          BASE_MATERIAL_NOALPHA, i.e. a hit is a candidate for the alpha test (pt_megakernel.glsl:153-212);
+                          bits 8..31: 0, or (flattened scenes, RPTR_FLATTEN) the index of the triangle's own instance record
+                          in the instance array: the triangle is stored in world space and a hit belongs to that instance,
+                          not to the one being traversed */
 } RptrBvhTri;
 #define RPTR_BVH_TRI_ALPHA 1u
+#define RPTR_BVH_TRI_INSTANCE(flags) ((uint32_t)(flags) >> 8)
+#define RPTR_BVH_INSTANCE_FLAT 1 /* RptrBvhInstance.flags: the one record a flattened scene's top level refers to */
 
 /* 128 bytes */
 typedef struct RptrBvhInstance {

@@ -567,7 +567,8 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
     vec3 id(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const RptrBvhInstance *cur_inst = nullptr;
     int cur = 0;
-    if (bvh.insts.size() == 1 && !g_no_single_instance) {
+    // (a flattened scene keeps the scene's own instance records behind the one its top level refers to: rptr_bvh.h)
+    if ((bvh.insts.size() == 1 || (!bvh.insts.empty() && (bvh.insts[0].flags & RPTR_BVH_INSTANCE_FLAT))) && !g_no_single_instance) {
         // the device's shortcut for scenes with one instance record (csrc/dtraverse.h): start inside the instance
         cur_inst = &bvh.insts[0];
         if (cnt) cnt->nodes++; // the first 64 bytes of the instance record
@@ -637,10 +638,13 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                                       vec3(tr.e2[0], tr.e2[1], tr.e2[2]), t, u, v))
                         continue;
                     if (!(t > ray.tmin)) continue;
-                    const int ii2 = cur_inst->instance_id;
+                    // a world-space triangle of a flattened scene names its own instance record
+                    const uint32_t rec = RPTR_BVH_TRI_INSTANCE(tr.flags);
+                    const RptrBvhInstance &tri_inst = rec ? bvh.insts[rec] : *cur_inst;
+                    const int ii2 = tri_inst.instance_id;
                     const bool accept = (t < best.t) || (t == best.t && best.inst >= 0 && hit_key_less(ii2, (int)tr.geom, (int)tr.prim, best));
                     if (!accept) continue;
-                    if (alpha && (tr.flags & RPTR_BVH_TRI_ALPHA) && alpha->reject(*cur_inst, tr, t, u, v)) continue;
+                    if (alpha && (tr.flags & RPTR_BVH_TRI_ALPHA) && alpha->reject(tri_inst, tr, t, u, v)) continue;
                     best.t = t; best.u = u; best.v = v;
                     best.inst = ii2; best.geom = (int)tr.geom; best.prim = (int)tr.prim;
                     best.lo = o; best.ld = d;

@@ -434,10 +434,14 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                             const float t = rp_dot_fma(e2, q) * inv_det;
                             if (t > tmin) {
                                 const int prim = __float_as_int(q2.y), geom = __float_as_int(q2.z);
+                                // a triangle of a flattened scene names its own instance record (rptr_bvh.h), any other one
+                                // belongs to the instance being traversed
+                                const int tri_rec = (int)RPTR_BVH_TRI_INSTANCE(__float_as_uint(q2.w));
+                                const int hit_inst = tri_rec ? tri_rec : cur_inst, hit_inst_id = tri_rec ? tri_rec - 1 : cur_inst_id;
                                 bool accept = t < best.t;
                                 if (!accept && t == best.t && best.inst_idx >= 0) {
-                                    if (cur_inst_id != best_inst_id)
-                                        accept = cur_inst_id < best_inst_id;
+                                    if (hit_inst_id != best_inst_id)
+                                        accept = hit_inst_id < best_inst_id;
                                     else if (geom != best.geom)
                                         accept = geom < best.geom;
                                     else
@@ -445,7 +449,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                 }
                                 if (ALPHA) {
                                     if (accept && (__float_as_uint(q2.w) & RPTR_BVH_TRI_ALPHA) != 0u)
-                                        accept = !alpha(my_i, cur_inst, cur_inst_id, geom, prim, un * inv_det, vn * inv_det);
+                                        accept = !alpha(my_i, hit_inst, hit_inst_id, geom, prim, un * inv_det, vn * inv_det);
                                 }
                                 if (accept) {
                                     best.t = t;
@@ -453,8 +457,8 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                     best.v = vn * inv_det;
                                     best.prim = prim;
                                     best.geom = geom;
-                                    best.inst_idx = cur_inst;
-                                    best_inst_id = cur_inst_id;
+                                    best.inst_idx = hit_inst;
+                                    best_inst_id = hit_inst_id;
                                     any_hit = true;
                                 }
                             }

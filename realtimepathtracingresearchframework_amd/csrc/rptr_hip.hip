@@ -126,6 +126,7 @@ struct rptr_hip {
     int num_tlas_nodes = 0;
     std::vector<RptrBvhTri> h_tris;
     std::vector<RptrBvhInstance> h_insts;
+    int num_tlas_insts = 0;
     std::vector<MeshRt> meshes;
     std::vector<void *> scene_allocs;
     int num_lights = 0, num_materials = 0;
@@ -276,9 +277,29 @@ struct HostBvh {
     std::vector<MeshRt> meshes;
     std::vector<int> mesh_root;
     int num_tlas_nodes = 0;
+    int num_tlas_insts = 0; // instance records the top level refers to (a flattened scene keeps the scene's own records behind them)
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
     int stack_need = 0;
 };
+
+// RPTR_FLATTEN=1: a static scene with several instances is built as ONE bottom-level tree over all instanced triangles,
+// pre-transformed to world space (a 10 M-triangle forest is 0.6 GB of triangles and nodes: nothing on a 288 GB device). Rays then
+// meet one well-separated tree instead of a thousand overlapping instance boxes, each with its own ray transform. Hits are
+// found on the world-space triangles, so t / u / v may differ from the two-level walk by rounding; shading still reads the
+// mesh's own vertex streams through the instance record the triangle names (RptrBvhTri.flags bits 8..31).
+static bool want_flatten(const RptrSceneDesc *s) {
+    const char *e = getenv("RPTR_FLATTEN");
+    if (!e || atoi(e) == 0 || s->num_instances < 2) return false;
+    size_t limit = (size_t)1 << 26;
+    if (const char *m = getenv("RPTR_FLATTEN_MAX_TRIS")) limit = (size_t)atoll(m);
+    size_t total = 0;
+    for (uint32_t i = 0; i < s->num_instances; ++i) {
+        const RptrMeshDesc &mesh = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh].mesh];
+        if (mesh.dynamic) return false;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) total += s->geometries[mesh.first_geometry + j].num_tris;
+    }
+    return total <= limit && s->num_instances < (1u << 24) - 1;
+}
 
 static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
     // instanceCustomIndex of every parameterized mesh = number of geometries before it (render_vulkan.cpp:2748-2850)
@@ -337,7 +358,61 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
             off += nt;
         }
     }
-    for (uint32_t m = 0; m < s->num_meshes; ++m) {
+    const bool flatten = want_flatten(s);
+    if (flatten) {
+        std::vector<rptr::BuildPrim> prims;
+        std::vector<RptrBvhTri> mtris;
+        for (uint32_t i = 0; i < s->num_instances; ++i) {
+            const RptrInstanceDesc &in = s->instances[i];
+            const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
+            const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+            const float *M = in.transform;
+            size_t off = 0;
+            for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+                const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
+                for (uint32_t t = 0; t < gd.num_tris; ++t) {
+                    float v[3][3], w[3][3];
+                    for (int k = 0; k < 3; ++k) {
+                        dequantize_position(gd.qpos[3 * (size_t)t + k], gd.quantized_scaling, gd.quantized_offset, v[k]);
+                        for (int r = 0; r < 3; ++r) w[k][r] = ((M[4 * r] * v[k][0] + M[4 * r + 1] * v[k][1]) + M[4 * r + 2] * v[k][2]) + M[4 * r + 3];
+                    }
+                    RptrBvhTri tri;
+                    rptr::BuildPrim bp;
+                    for (int k = 0; k < 3; ++k) {
+                        tri.v0[k] = w[0][k];
+                        tri.e1[k] = w[1][k] - w[0][k];
+                        tri.e2[k] = w[2][k] - w[0][k];
+                        bp.lo[k] = std::fmin(w[0][k], std::fmin(w[1][k], w[2][k]));
+                        bp.hi[k] = std::fmax(w[0][k], std::fmax(w[1][k], w[2][k]));
+                    }
+                    const int64_t mid = (int64_t)pm.material_offsets[j] + (pm.tri_material_ids ? (int64_t)pm.tri_material_ids[off + t] : 0);
+                    const bool alpha = mid >= 0 && mid < (int64_t)s->num_materials && (s->materials[mid].flags & RPTR_BASE_MATERIAL_NOALPHA) == 0;
+                    tri.prim = t;
+                    tri.geom = j;
+                    tri.flags = (alpha ? RPTR_BVH_TRI_ALPHA : 0u) | ((i + 1u) << 8); // its instance: record i + 1 of the instance array
+                    mtris.push_back(tri);
+                    prims.push_back(bp);
+                }
+                off += gd.num_tris;
+            }
+        }
+        rptr::BuiltTree tree;
+        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
+        rptr::Wide4Tree wide;
+        rptr::collapse_bvh4(tree, wide);
+        for (MeshRt &mr : B.meshes) { // no mesh has a tree of its own: they all point at the one tree
+            mr.node_base = 0;
+            mr.node_count = 0;
+            mr.tri_base = 0;
+            mr.tri_count = 0;
+            memcpy(mr.lo, tree.lo, 12);
+            memcpy(mr.hi, tree.hi, 12);
+        }
+        B.tris.reserve(mtris.size());
+        for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
+        encode_tree(wide, 0, 0, blas_nodes, blas_boxes);
+    }
+    for (uint32_t m = 0; m < s->num_meshes && !flatten; ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
         std::vector<rptr::BuildPrim> prims;
         std::vector<RptrBvhTri> mtris;
@@ -384,6 +459,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
     // inner nodes), each with the world box of its own subtree.
     int braid = s->num_instances >= 16 ? 4 : 1;
     if (const char *e = getenv("RPTR_REBRAID")) braid = std::max(1, std::min(64, atoi(e)));
+    if (flatten) braid = 1;
     std::vector<rptr::BuildPrim> iprims;
     std::vector<RptrBvhInstance> insts;
     iprims.reserve((size_t)s->num_instances * braid);
@@ -421,7 +497,37 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         }
         mesh_cut[m] = cut;
     }
-    for (uint32_t i = 0; i < s->num_instances; ++i) {
+    std::vector<RptrBvhInstance> own_records; // flattened scene: the scene's instance records, behind the one the top level uses
+    if (flatten) {
+        RptrBvhInstance bi;
+        memset(&bi, 0, sizeof(bi));
+        const float identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        memcpy(bi.object_to_world, identity, 48);
+        memcpy(bi.world_to_object, identity, 48);
+        bi.blas_root = 0; // relocated below
+        bi.instance_id = -1;
+        bi.flags = RPTR_BVH_INSTANCE_FLAT;
+        insts.push_back(bi);
+        rptr::BuildPrim bp;
+        const std::array<float, 6> &mb = blas_boxes[0];
+        for (int k = 0; k < 3; ++k) {
+            bp.lo[k] = mb[k];
+            bp.hi[k] = mb[3 + k];
+        }
+        iprims.push_back(bp);
+        for (uint32_t i = 0; i < s->num_instances; ++i) {
+            const RptrInstanceDesc &in = s->instances[i];
+            RptrBvhInstance r;
+            memset(&r, 0, sizeof(r));
+            memcpy(r.object_to_world, in.transform, 48);
+            invert_affine(in.transform, r.world_to_object);
+            r.blas_root = -1;
+            r.geometry_base = pmesh_base[in.parameterized_mesh];
+            r.instance_id = (int)i;
+            own_records.push_back(r);
+        }
+    }
+    for (uint32_t i = 0; i < s->num_instances && !flatten; ++i) {
         const RptrInstanceDesc &in = s->instances[i];
         const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
         RptrBvhInstance bi;
@@ -481,6 +587,8 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         B.insts[k] = insts[tlas.order[k]];
         B.insts[k].blas_root += reloc;
     }
+    B.num_tlas_insts = (int)B.insts.size();
+    B.insts.insert(B.insts.end(), own_records.begin(), own_records.end());
     // ---- the traversal stack must hold the worst case of this tree: per node (children - 1) siblings plus whatever
     // its deepest child needs; + the exit marker, + the instance-exit sentinel between the two levels
     {
@@ -932,6 +1040,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->h_node_box = std::move(B.node_box);
     h->h_tris = std::move(B.tris);
     h->h_insts = std::move(B.insts);
+    h->num_tlas_insts = B.num_tlas_insts;
     h->meshes = std::move(B.meshes);
     h->mesh_root = std::move(B.mesh_root);
     h->num_tlas_nodes = B.num_tlas_nodes;
@@ -1021,7 +1130,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_lights = (int)s->num_lights;
     h->master.dscene.num_materials = (int)s->num_materials;
     h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
-    h->master.dscene.single_instance = (h->h_insts.size() == 1 && !getenv("RPTR_NO_SINGLE_INSTANCE")) ? 1 : 0;
+    h->master.dscene.single_instance = (h->num_tlas_insts == 1 && !getenv("RPTR_NO_SINGLE_INSTANCE")) ? 1 : 0;
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
     h->master.dscene.srgb_lut = d_srgb_lut;

@@ -162,3 +162,34 @@ def test_alpha_flags_of_the_host_built_tree():
     imp, _ = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED)
     rmse = float(np.sqrt(np.mean((own[..., :3] - imp[..., :3]).astype(np.float64) ** 2)))
     assert rmse < 0.05
+
+
+def test_flattened_tree_on_the_host(monkeypatch):
+    """RPTR_FLATTEN=1: one tree over all instanced triangles in world space; every triangle names its instance record, the first
+    record is the identity instance the top level refers to, the scene's own records follow"""
+    s = scenes.two_level_test()
+    monkeypatch.setenv("RPTR_FLATTEN", "1")
+    nodes, tris, insts, need = backend.build_bvh_host(s)
+    monkeypatch.delenv("RPTR_FLATTEN")
+    t = np.frombuffer(np.ascontiguousarray(tris).tobytes(), dtype=np.uint32).reshape(-1, 12)
+    recs = np.frombuffer(np.ascontiguousarray(insts).tobytes(), dtype=np.int32).reshape(-1, 32)
+    n_inst = len(s.instances)
+    instanced = sum(sum(g.num_tris for g in s.geometries[s.meshes[s.pmeshes[i.pmesh].mesh].first_geometry:][:s.meshes[s.pmeshes[i.pmesh].mesh].num_geometries])
+                    for i in s.instances)
+    assert len(t) == instanced and len(recs) == n_inst + 1
+    rec = t[:, 11] >> 8
+    assert rec.min() == 1 and rec.max() == n_inst and len(np.unique(rec)) == n_inst
+    assert recs[0, 15] & 1 and recs[0, 14] == -1                  # flags: RPTR_BVH_INSTANCE_FLAT; instance_id of the start record
+    assert recs[1:, 14].tolist() == list(range(n_inst))           # the scene's records in instance order
+    ident = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    assert np.array_equal(recs[0, :12].view(np.float32), ident)
+    # the oracle walks it: same image as its own two-level tree up to the rounding of the pre-transformed triangles
+    osc = O.OracleScene(s)
+    own, _ = osc.render(80, 60, 2)
+    osc.import_bvh(nodes, tris, insts)
+    flat, st = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED, count=True)
+    assert float(np.sqrt(np.nanmean((own[..., :3] - flat[..., :3]).astype(np.float64) ** 2))) < 5e-3
+    nodes2, tris2, insts2, _ = backend.build_bvh_host(s)
+    osc.import_bvh(nodes2, tris2, insts2)
+    _, st2 = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED, count=True)
+    assert st.nodes_closest < st2.nodes_closest                   # and with fewer node visits
