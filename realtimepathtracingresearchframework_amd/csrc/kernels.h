@@ -911,66 +911,86 @@ __global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *
 }
 // one height level of nodes: child boxes from the triangle / instance bounds (leaves) or from the exact float
 // bounds of the child nodes (node_box, written by the level below), then the shared encoder (bvh4.h)
-__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box,
-                                                        const uint32_t *list, uint32_t begin, uint32_t end) {
-    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) {
-        const uint32_t e = list[i];
-        const bool tlas = (e >> 31) != 0;
-        const uint32_t ni = e & 0x7FFFFFFFu;
-        int32_t child[4];
-        RpBox4 b;
-        for (int k = 0; k < 4; ++k) {
-            const int32_t c = nodes[ni].child[k];
-            child[k] = c;
+RP_DEV void rp_refit_node(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box, const uint32_t e) {
+    const bool tlas = (e >> 31) != 0;
+    const uint32_t ni = e & 0x7FFFFFFFu;
+    int32_t child[4];
+    RpBox4 b;
+    for (int k = 0; k < 4; ++k) {
+        const int32_t c = nodes[ni].child[k];
+        child[k] = c;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[k][a] = INFINITY;
+            b.hi[k][a] = -INFINITY;
+        }
+        if (c == RPTR_BVH4_EMPTY) continue;
+        if (c >= 0) {
+            const float *nb = node_box + 6ull * c;
             for (int a = 0; a < 3; ++a) {
-                b.lo[k][a] = INFINITY;
-                b.hi[k][a] = -INFINITY;
+                b.lo[k][a] = nb[a];
+                b.hi[k][a] = nb[3 + a];
             }
-            if (c == RPTR_BVH4_EMPTY) continue;
-            if (c >= 0) {
-                const float *nb = node_box + 6ull * c;
+        } else {
+            const int first = RPTR_BVH_LEAF_FIRST(c), count = RPTR_BVH_LEAF_COUNT(c);
+            for (int j = 0; j < count; ++j) {
+                const float *lb = (tlas ? inst_box : tri_box) + 6ull * (first + j);
                 for (int a = 0; a < 3; ++a) {
-                    b.lo[k][a] = nb[a];
-                    b.hi[k][a] = nb[3 + a];
-                }
-            } else {
-                const int first = RPTR_BVH_LEAF_FIRST(c), count = RPTR_BVH_LEAF_COUNT(c);
-                for (int j = 0; j < count; ++j) {
-                    const float *lb = (tlas ? inst_box : tri_box) + 6ull * (first + j);
-                    for (int a = 0; a < 3; ++a) {
-                        b.lo[k][a] = fminf(b.lo[k][a], lb[a]);
-                        b.hi[k][a] = fmaxf(b.hi[k][a], lb[3 + a]);
-                    }
+                    b.lo[k][a] = fminf(b.lo[k][a], lb[a]);
+                    b.hi[k][a] = fmaxf(b.hi[k][a], lb[3 + a]);
                 }
             }
         }
-        RptrBvh4Node n;
-        float *nb = node_box + 6ull * ni;
-        rp_bvh4_encode(b, child, &n, nb, nb + 3);
-        nodes[ni] = n;
+    }
+    RptrBvh4Node n;
+    float *nb = node_box + 6ull * ni;
+    rp_bvh4_encode(b, child, &n, nb, nb + 3);
+    nodes[ni] = n;
+}
+RP_DEV void rp_refit_instance(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t i) {
+    const RptrBvhInstance &in = insts[i];
+    const float *mb = node_box + 6ull * in.blas_root; // exact bounds of the mesh
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = INFINITY;
+        hi[k] = -INFINITY;
+    }
+    const float *M = in.object_to_world;
+    for (int c = 0; c < 8; ++c) {
+        const float p[3] = {c & 1 ? mb[3] : mb[0], c & 2 ? mb[4] : mb[1], c & 4 ? mb[5] : mb[2]};
+        for (int rr = 0; rr < 3; ++rr) {
+            const float w = ((M[4 * rr] * p[0] + M[4 * rr + 1] * p[1]) + M[4 * rr + 2] * p[2]) + M[4 * rr + 3];
+            lo[rr] = fminf(lo[rr], w);
+            hi[rr] = fmaxf(hi[rr], w);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        inst_box[6 * i + k] = lo[k];
+        inst_box[6 * i + 3 + k] = hi[k];
     }
 }
+__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box,
+                                                        const uint32_t *list, uint32_t begin, uint32_t end) {
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
+        rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
+}
 __global__ __launch_bounds__(256) void rp_k_refit_instances(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const RptrBvhInstance &in = insts[i];
-        const float *mb = node_box + 6ull * in.blas_root; // exact bounds of the mesh
-        float lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = INFINITY;
-            hi[k] = -INFINITY;
-        }
-        const float *M = in.object_to_world;
-        for (int c = 0; c < 8; ++c) {
-            const float p[3] = {c & 1 ? mb[3] : mb[0], c & 2 ? mb[4] : mb[1], c & 4 ? mb[5] : mb[2]};
-            for (int rr = 0; rr < 3; ++rr) {
-                const float w = ((M[4 * rr] * p[0] + M[4 * rr + 1] * p[1]) + M[4 * rr + 2] * p[2]) + M[4 * rr + 3];
-                lo[rr] = fminf(lo[rr], w);
-                hi[rr] = fmaxf(hi[rr], w);
-            }
-        }
-        for (int k = 0; k < 3; ++k) {
-            inst_box[6 * i + k] = lo[k];
-            inst_box[6 * i + 3 + k] = hi[k];
-        }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
+}
+// The small top of a refit in ONE launch of one block: the upper bottom-level levels (a level waits for the one below: a block
+// barrier instead of a launch), the instance bounds, the top-level levels. `levels` holds [begin, end) pairs into `list`:
+// n_blas bottom-level levels, then n_tlas top-level ones. Same per-node arithmetic as the stand-alone kernels.
+__global__ __launch_bounds__(1024) void rp_k_refit_top(RptrBvh4Node *nodes, float *node_box, const float *tri_box, float *inst_box, const uint32_t *list,
+                                                       const uint2 *levels, int n_blas, int n_tlas, const RptrBvhInstance *insts, uint32_t n_insts) {
+    for (int l = 0; l < n_blas; ++l) {
+        const uint2 lv = levels[l];
+        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n_insts; i += blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
+    __syncthreads();
+    for (int l = 0; l < n_tlas; ++l) {
+        const uint2 lv = levels[n_blas + l];
+        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
+        __syncthreads();
     }
 }

@@ -141,7 +141,12 @@ struct rptr_hip {
     std::vector<int> mesh_root;             // per mesh: absolute node index of the BLAS root
     uint32_t *d_refit_list = nullptr;       // node indices, bit 31 = TLAS node
     std::vector<std::array<uint32_t, 2>> refit_levels_blas, refit_levels_tlas; // [begin, end) per height
+    uint2 *d_refit_levels = nullptr;        // the same pairs on the device (bottom-level levels, then top-level ones)
+    size_t refit_top_split = 0;             // bottom-level levels [split, end) are small: they run inside rp_k_refit_top
+    bool refit_top_all = false;             // ... together with the instance bounds and the top-level levels
     bool host_bvh_stale = false;
+    uint64_t vertex_updates = 0, vertex_updates_refitted = 0;
+    bool master_refit_pending = false; // rptr_hip_refit with frame contexts that own their sets: the master tree is refitted on demand
 
     // device buffers (frame sized)
     // queue of the first bounce: the ids of the pixel samples that exist. It only depends on the frame size, the tiling and
@@ -1107,7 +1112,26 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.tri_box = nullptr;
     if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->master.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
     if (!refit_list.empty()) HIP_TRY(h, hipMemcpy(h->d_refit_list, refit_list.data(), refit_list.size() * 4, hipMemcpyHostToDevice));
+    {
+        // the small upper levels of a refit share one launch (kernels.h rp_k_refit_top): every level is one more dependent launch
+        // otherwise, and an animated frame pays for them whatever its size
+        const uint32_t small = 4096;
+        std::vector<uint2> lv;
+        for (auto &l : h->refit_levels_blas) lv.push_back(make_uint2(l[0], l[1]));
+        for (auto &l : h->refit_levels_tlas) lv.push_back(make_uint2(l[0], l[1]));
+        h->refit_top_split = h->refit_levels_blas.size();
+        while (h->refit_top_split > 0 && h->refit_levels_blas[h->refit_top_split - 1][1] - h->refit_levels_blas[h->refit_top_split - 1][0] <= small)
+            h->refit_top_split--;
+        h->refit_top_all = h->h_insts.size() <= 4 * small;
+        for (auto &l : h->refit_levels_tlas) h->refit_top_all = h->refit_top_all && l[1] - l[0] <= small;
+        h->d_refit_levels = nullptr;
+        if (!lv.empty()) {
+            if ((rc = dev_alloc(h, &h->d_refit_levels, lv.size(), &h->scene_allocs))) return rc;
+            HIP_TRY(h, hipMemcpy(h->d_refit_levels, lv.data(), lv.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        }
+    }
     h->host_bvh_stale = false;
+    h->master_refit_pending = false;
     if ((rc = dev_alloc(h, &h->master.node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
     HIP_TRY(h, hipMemcpy(h->master.node_box, h->h_node_box.data(), h->h_node_box.size() * 24, hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(d_nodes, h->h_nodes.data(), h->h_nodes.size() * sizeof(RptrBvh4Node), hipMemcpyHostToDevice));
@@ -1212,6 +1236,7 @@ static int update_vertices_common(rptr_hip_t *h, uint32_t geometry, const float 
                               h->stream));
     if (!device_src) HIP_TRY(h, hipStreamSynchronize(h->stream)); // the host array is only borrowed for the call
     h->master.mesh_dirty[h->geom_mesh[geometry]] = 1;
+    h->vertex_updates++;
     return RPTR_OK;
 }
 int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz, uint32_t num_vertices) {
@@ -1243,14 +1268,23 @@ static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipSt
     }
     // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
     RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
-    for (auto &lv : h->refit_levels_blas)
+    const size_t nb = h->refit_levels_blas.size(), nt = h->refit_levels_tlas.size();
+    for (size_t l = 0; l < h->refit_top_split; ++l) { // the large lower levels: one launch each
+        const auto &lv = h->refit_levels_blas[l];
         hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
                            h->d_refit_list, lv[0], lv[1]);
+    }
     const uint32_t ni = (uint32_t)h->h_insts.size();
-    if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
-    for (auto &lv : h->refit_levels_tlas)
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
-                           h->d_refit_list, lv[0], lv[1]);
+    if (h->refit_top_split < nb || h->refit_top_all) // the small upper levels (+ instance bounds + top level) in one block
+        hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, h->d_refit_list,
+                           h->d_refit_levels + h->refit_top_split, (int)(nb - h->refit_top_split), h->refit_top_all ? (int)nt : 0, insts,
+                           h->refit_top_all ? ni : 0u);
+    if (!h->refit_top_all) {
+        if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
+        for (auto &lv : h->refit_levels_tlas)
+            hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
+                               h->d_refit_list, lv[0], lv[1]);
+    }
     return true;
 }
 } // extern "C++"
@@ -1263,12 +1297,32 @@ int rptr_hip_refit(rptr_hip_t *h) {
         int rc0 = drain(h);
         if (rc0) return rc0;
     }
+    if (!h->ctx_scene.empty()) {
+        // frames render from the contexts' own sets, which follow from the master's VERTICES when their next frame is submitted:
+        // the master's tree is only needed by ray queries and the export, and is refitted when one of them asks for it
+        if (h->vertex_updates != h->vertex_updates_refitted) { // (the dirty marks stay for the deferred refit of the master tree)
+            h->vertex_updates_refitted = h->vertex_updates;
+            h->master_refit_pending = true;
+            h->host_bvh_stale = true;
+            h->refit_version++;
+        }
+        return RPTR_OK;
+    }
     if (refit_scene_copy(h, h->master, false, h->stream)) {
         HIP_TRY(h, hipGetLastError());
         h->host_bvh_stale = true;
         h->refit_version++; // the frame contexts' own sets follow when their next frame is submitted
         h->master.version = h->refit_version;
     }
+    return RPTR_OK;
+}
+
+// the master set's tree after a deferred refit (see rptr_hip_refit)
+static int ensure_master_tree(rptr_hip *h) {
+    if (!h->master_refit_pending) return RPTR_OK;
+    h->master_refit_pending = false;
+    if (refit_scene_copy(h, h->master, false, h->stream)) HIP_TRY(h, hipGetLastError());
+    h->master.version = h->refit_version;
     return RPTR_OK;
 }
 
@@ -1838,6 +1892,7 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
     {
         int rc0 = drain(h); // the query kernel borrows context 0's cursor and stack scratch
         if (rc0) return rc0;
+        if ((rc0 = ensure_master_tree(h))) return rc0;
     }
     if (n == 0) return RPTR_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1911,6 +1966,10 @@ int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_n
 int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances, size_t *n_instances) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "export before set_scene");
+    {
+        int rc0 = ensure_master_tree(h);
+        if (rc0) return rc0;
+    }
     if (h->host_bvh_stale) { // a refit happened on the device: refresh the host mirror first
         HIP_TRY(h, hipSetDevice(h->device));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
