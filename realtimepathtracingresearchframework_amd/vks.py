@@ -638,7 +638,7 @@ def _normal_uv_stream(g):
     return qn.astype(np.uint64) | (qu.astype(np.uint64) << np.uint64(32))
 
 
-def write_vks(path, scene: Scene, version=4, material_names=None):
+def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=None):
     """Writes `scene` as <path> (.vks, file version 3 or 4) plus <base>_textures/ with what `read_vks` / the reference's
     `load_vkrs` pick up again. Constraints of the format, checked here: every parameterized mesh becomes a .vks mesh (a mesh
     shared by several parameterized meshes is written once per use), its geometries share one quantisation grid, instance
@@ -648,8 +648,17 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
     BC1 RGB formats, scene.cpp:857-873 -- RGBA8 for alpha-tested ones), roughness / metallic / specular ->
     <name>_Specular.vkt (BC1: g, b, r), normal map -> <name>_Normal.vkt (BC5); a material without a normal map gets none and
     the reader substitutes the reference's flat default texel (127, 127). Emission and transmission go into the .txt files.
+    lod_groups (file version 4): [[(parameterized mesh, detail reduction), ...], ...] -- every list becomes a LoD group (vkr.h:261-270)
+    whose first entry is the base level; the reader instances base levels only (scene.cpp:722-736).
     Returns the material names."""
     names = material_names or ["mat%03d" % i for i in range(len(scene.materials))]
+    lod_groups = lod_groups or []
+    if lod_groups and version < 4:
+        raise VksError("LoD groups need file version 4")
+    mesh_lod = {}
+    for gi, group in enumerate(lod_groups):
+        for pmesh, _ in group:
+            mesh_lod[int(pmesh)] = gi + 1        # group 0 is the implicit "no levels of detail" group
     n_tris_total = 0
     mesh_blobs, mesh_headers = [], []
     for p, pm in enumerate(scene.pmeshes):
@@ -680,7 +689,7 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
         name = "mesh%04d" % p
         head = struct.pack("<3f3f", *[float(x) for x in g0.scaling], *[float(x) for x in g0.offset])
         tail = struct.pack("<QQiI", len(geoms), n, base, in_range)
-        tail += struct.pack("<q4Q", 0, 0, 0, 0, 0) if version >= 4 else struct.pack("<5Q", 0, 0, 0, 0, 0)
+        tail += struct.pack("<q4Q", mesh_lod.get(p, 0), 0, 0, 0, 0) if version >= 4 else struct.pack("<5Q", 0, 0, 0, 0, 0)
         tail += b"".join(struct.pack("<Q", g.num_tris) for g in geoms) + b"".join(struct.pack("<i", o) for o in seg_offsets) + _string(name)
         mesh_headers.append((head, tail))
         mesh_blobs.append(qpos.tobytes() + qnu.tobytes() + ids.tobytes())
@@ -701,7 +710,9 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
         at = end
     lod_offset = at
     if version >= 4:
-        at += 8                                      # one LoD group with zero levels
+        at += 8                                      # group 0: zero levels
+        for group in lod_groups:
+            at += 8 + 12 * len(group)                # count, mesh ids (i64), detail reductions (f32)
     data_offset = at
     at += sum(len(_string(nm)) for nm in names)
     mesh_data_offset = []
@@ -713,7 +724,7 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
         f.write(struct.pack("<ii3Q", VKR_MAGIC, version, 0, scene_header, data_offset))
         f.write(struct.pack("<5Q", len(scene.pmeshes), len(scene.instances), len(names), n_tris_total, len(scene.instances)))
         if version >= 4:
-            f.write(struct.pack("<QqQqffQQQq", 1, lod_offset, 0, 0, 0.0, 0.0, 1, len(transforms), 0, animation_offset))
+            f.write(struct.pack("<QqQqffQQQq", 1 + len(lod_groups), lod_offset, 0, 0, 0.0, 0.0, 1, len(transforms), 0, animation_offset))
         for (head, tail), end, off in zip(mesh_headers, mesh_header_end, mesh_data_offset):
             f.write(head + struct.pack("<3Q", 0, end, off) + tail)
         for k, (inst, (name, data_off, end)) in enumerate(zip(scene.instances, group_meta)):
@@ -721,6 +732,9 @@ def write_vks(path, scene: Scene, version=4, material_names=None):
             f.write(struct.pack("<I", k) if version >= 4 else np.asarray(transforms[k], f32).tobytes())
         if version >= 4:
             f.write(struct.pack("<Q", 0))
+            for group in lod_groups:
+                f.write(struct.pack("<Q", len(group)) + b"".join(struct.pack("<q", int(m)) for m, _ in group)
+                        + b"".join(struct.pack("<f", float(d)) for _, d in group))
         for nm in names:
             f.write(_string(nm))
         for blob in mesh_blobs:

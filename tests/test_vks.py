@@ -189,6 +189,30 @@ def test_write_then_read_keeps_the_scene(tmp_path, name, version):
     assert abs(float(fa.mean()) - float(fb.mean())) < 0.05 * float(fa.mean()) + 0.01
 
 
+def test_lod_groups_instance_the_base_level_only(tmp_path):
+    """file version 4 LoD groups (vkr.h:261-270): meshes of a group share their instances' placement, the loader keeps the
+    instances of a group's first (base) mesh only (scene.cpp:722-736) -- and the reference's reader sees the same groups"""
+    s = scenes.two_level_test()
+    n_pm = len(s.pmeshes)
+    assert n_pm >= 3
+    path = str(tmp_path / "lod.vks")
+    vks.write_vks(path, s, lod_groups=[[(0, 0.0), (1, 0.5)]])          # parameterized mesh 1 is a coarser level of mesh 0
+    v = vks.read_vks_header(path)
+    assert v["numLodGroups"] == 2 and v["lodGroups"][1]["meshIds"] == [0, 1] and v["lodGroups"][1]["detailReduction"] == [0.0, 0.5]
+    assert [m["lodGroup"] for m in v["meshes"]][:3] == [1, 1, 0]
+    r = vks.read_vks(path)
+    kept = [i for i in s.instances if i.pmesh != 1]
+    assert len(r.instances) == len(kept) and all(a.pmesh == b.pmesh for a, b in zip(r.instances, kept))
+    if os.path.isfile(REF_LIB):
+        out = str(tmp_path / "dump.json")
+        assert _ref().ref_vkr_dump(path.encode(), out.encode()) == 0
+        ref = json.load(open(out))
+        _compare_with_dump(path, ref)
+        assert [g["detailReduction"] for g in ref["lodGroups"]][1] == _bits([0.0, 0.5]).tolist()
+    with pytest.raises(vks.VksError):
+        vks.write_vks(str(tmp_path / "lod3.vks"), s, version=3, lod_groups=[[(0, 0.0), (1, 0.5)]])
+
+
 def test_unrepresentable_scenes_are_refused(tmp_path):
     s = scenes.cornell32()
     s.instances[0].transform = s.instances[0].transform.copy()
