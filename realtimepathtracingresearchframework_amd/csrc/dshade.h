@@ -114,13 +114,9 @@ RP_DEV int rp_local_row_to_global(const RpFrame &f, int ly) {
 
 // ------------------------------------------------------------------ AOV stores (vulkan/accumulate.glsl:76-103)
 RP_DEV uint2 rp_half4(float a, float b, float c, float d) { // RGBA16F texel, round to nearest even
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b, hc = (_Float16)c, hd = (_Float16)d;
-    uint16_t ua, ub, uc, ud;
-    __builtin_memcpy(&ua, &ha, 2);
-    __builtin_memcpy(&ub, &hb, 2);
-    __builtin_memcpy(&uc, &hc, 2);
-    __builtin_memcpy(&ud, &hd, 2);
-    return make_uint2(uint32_t(ua) | (uint32_t(ub) << 16), uint32_t(uc) | (uint32_t(ud) << 16));
+    const uint32_t ua = __builtin_bit_cast(uint16_t, (_Float16)a), ub = __builtin_bit_cast(uint16_t, (_Float16)b);
+    const uint32_t uc = __builtin_bit_cast(uint16_t, (_Float16)c), ud = __builtin_bit_cast(uint16_t, (_Float16)d);
+    return make_uint2(ua | (ub << 16), uc | (ud << 16));
 }
 RP_DEV void rp_project(const float *view, const float *proj, V3 p, float &x, float &y, float &w) {
     const float vx = ((view[0] * p.x + view[1] * p.y) + view[2] * p.z) + view[3];
