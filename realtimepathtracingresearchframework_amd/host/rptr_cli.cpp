@@ -16,10 +16,15 @@
 //  * --animate-wave a k (profiling mode, scenes whose mesh 0 is dynamic): y = y0 + a sin(k x + 2 pi t) on geometry 0 before
 //    every frame, followed by rptr_hip_refit -- SURVEY 8d C5 (the reference animates with a compute shader,
 //    render_vulkan.cpp:2834-2840; per-frame BLAS update + TLAS refit :1323-1354).
-// The scene comes from a dump file (scene_dump.hpp) instead of a .vks.
+//  * data-capture mode (--data-capture <prefix> [--data-capture-spp n]) stores the accumulation buffer and the three AOV images of
+//    keyframe 1 as EXR (libapp/app_state.cpp:499-531).
+// Images: --exr (default, as in the reference), --pfm, --png (write_image.hpp).
+// The scene comes from a dump file (scene_dump.hpp) instead of a .vks (python -m ...vks converts).
 #include "render_hip.hpp"
 #include "scene_dump.hpp"
+#include "write_image.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,30 +33,39 @@
 #include <string>
 #include <vector>
 
-static bool write_pfm(const std::string &prefix, unsigned width, unsigned height, unsigned channels, const float *pixels) {
-    if (width == 0 || height == 0 || channels < 3 || !pixels) return false;
-    const std::string path = prefix + ".pfm";
-    FILE *f = std::fopen(path.c_str(), "wb");
-    if (!f) return false;
-    std::fprintf(f, "PF\n%i %i\n-1.0\n", width, height);
-    std::vector<float> rgb((size_t)width * height * 3);
-    for (unsigned y = 0; y < height; ++y) // the file stores the bottom row first
-        for (unsigned x = 0; x < width; ++x)
-            for (unsigned j = 0; j < 3; ++j) rgb[((size_t)width * (height - y - 1) + x) * 3 + j] = pixels[((size_t)width * y + x) * channels + j];
-    const bool ok = std::fwrite(rgb.data(), sizeof(float), rgb.size(), f) == rgb.size();
-    std::fclose(f);
-    return ok;
-}
+enum OutputFormat { FORMAT_EXR, FORMAT_PFM, FORMAT_PNG }; // cmdline.cpp:450-460: EXR is the default
 
-static void save_pfm(rptr::RenderHip &backend, const std::string &prefix, int number, int width, int height, std::vector<float> &img) {
-    if (backend.readback_framebuffer(img.size(), img.data()) != img.size()) throw std::runtime_error("read-back failed");
+// BasicApplicationState::save_framebuffer (libapp/app_state.cpp:341-438): the float accumulation buffer as EXR / PFM, the 8-bit
+// frame buffer as PNG, under <prefix>_<number> (+ suffix)
+static void save_image(rptr::RenderHip &backend, OutputFormat format, const std::string &prefix, int number, const std::string &suffix, int width, int height,
+                       std::vector<float> &img) {
     char name[32];
     std::snprintf(name, sizeof(name), "_%04d", number);
-    if (!write_pfm(prefix + name, (unsigned)width, (unsigned)height, 4, img.data())) throw std::runtime_error("cannot write " + prefix + name + ".pfm");
+    const std::string base = prefix + name + suffix;
+    bool ok = false;
+    if (format == FORMAT_PNG) {
+        std::vector<unsigned char> rgba8((size_t)width * height * 4);
+        if (backend.readback_framebuffer(rgba8.size(), rgba8.data()) != rgba8.size()) throw std::runtime_error("read-back failed");
+        ok = rptr::write_png(base, (unsigned)width, (unsigned)height, 4, rgba8.data());
+    } else {
+        if (backend.readback_framebuffer(img.size(), img.data()) != img.size()) throw std::runtime_error("read-back failed");
+        ok = format == FORMAT_PFM ? rptr::write_pfm(base, (unsigned)width, (unsigned)height, 4, img.data())
+                                  : rptr::write_exr<float>(base, (unsigned)width, (unsigned)height, 4, img.data());
+    }
+    if (!ok) throw std::runtime_error("cannot write " + base);
+}
+// BasicApplicationState::save_aov_exr (libapp/app_state.cpp:441-462): an AOV image as a HALF EXR
+static void save_aov(rptr::RenderHip &backend, rptr::RenderHip::AOVBufferIndex aov, const std::string &base, int width, int height) {
+    std::vector<uint16_t> half((size_t)width * height * 4);
+    if (backend.readback_aov(aov, half.size(), half.data()) != half.size()) throw std::runtime_error("AOV read-back failed");
+    if (!rptr::write_exr<uint16_t>(base, (unsigned)width, (unsigned)height, 4, half.data())) throw std::runtime_error("cannot write " + base + ".exr");
 }
 
 int main(int argc, char **argv) {
-    std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix;
+    std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix, capture_prefix;
+    OutputFormat format = FORMAT_EXR;
+    bool data_capture = false;
+    int capture_spp = 1;
     int target_spp = 1, width = 256, height = 256, variant = RPTR_VARIANT_GLTF, batch_spp = 1, profiling_frames = 60;
     float profiling_fps = 60.f, wave_amp = 0.f, wave_k = 0.f;
     float eye[3], center[3], up[3] = {0, 1, 0}, fov = 0.f;
@@ -84,7 +98,13 @@ int main(int argc, char **argv) {
         else if (a == "--variant") { need(1); variant = std::strcmp(argv[++i], "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : RPTR_VARIANT_GLTF; }
         else if (a == "--every-frame") every_frame = true;
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
-        else if (a == "--pfm") {} // the only image format of this tool
+        else if (a == "--pfm") format = FORMAT_PFM;
+        else if (a == "--exr") format = FORMAT_EXR;
+        else if (a == "--png") format = FORMAT_PNG;
+        else if (a == "--data-capture") { need(1); capture_prefix = argv[++i]; data_capture = true; }
+        else if (a == "--data-capture-spp") { need(1); capture_spp = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--backend") { need(1); ++i; } // there is one backend here
+        else if (a == "--disable-ui" || a == "--freeze-frame") {}
         else if (a[0] != '-') scene_path = a;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -110,11 +130,12 @@ int main(int argc, char **argv) {
         every_frame = true;
         target_spp = 1;
     }
-    if (scene_path.empty() || validation == profiling || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
+    if (scene_path.empty() || (int)validation + (int)profiling + (int)data_capture != 1 || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
         std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
                              "[--profiling-img <prefix>] [--profiling-frames n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
-                             "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--pfm]\n"
-                             "validation mode and profiling mode are mutually exclusive (cmdline.cpp:479-486)\n");
+                             "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png]\n"
+                             "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n]   (rgba + AOV images as EXR)\n"
+                             "validation, profiling and data-capture mode are mutually exclusive (cmdline.cpp:479-486)\n");
         return 2;
     }
     try {
@@ -155,9 +176,27 @@ int main(int argc, char **argv) {
                 cfg.reset_accumulation = false;
                 accumulated = st.spp;
                 gpu_ms += st.render_time;
-                if (accumulated >= target_spp || every_frame) save_pfm(backend, validation_prefix, accumulated, width, height, img);
+                if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
             }
-            std::printf("%s: %d spp in %.3f ms GPU time -> %s_%04d.pfm\n", backend.name().c_str(), accumulated, gpu_ms, validation_prefix.c_str(), accumulated);
+            std::printf("%s: %d spp in %.3f ms GPU time -> %s_%04d.%s\n", backend.name().c_str(), accumulated, gpu_ms, validation_prefix.c_str(), accumulated,
+                        format == FORMAT_PFM ? "pfm" : format == FORMAT_PNG ? "png" : "exr");
+            return 0;
+        }
+        if (data_capture) {
+            // libapp/app_state.cpp:499-531: when a frame is ready (--data-capture-spp samples) the accumulation buffer and the three
+            // AOV images of keyframe 1 are stored as <prefix>_0001_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr
+            int accumulated = 0;
+            while (accumulated < capture_spp) {
+                const rptr::RenderStats st = backend.render(cfg);
+                cfg.reset_accumulation = false;
+                accumulated = st.spp;
+            }
+            save_image(backend, FORMAT_EXR, capture_prefix, 1, "_rgba", width, height, img);
+            const std::string pf = capture_prefix + "_0001";
+            save_aov(backend, rptr::RenderHip::AOVAlbedoRoughnessIndex, pf + "_albedo_roughness", width, height);
+            save_aov(backend, rptr::RenderHip::AOVNormalDepthIndex, pf + "_normal_depth", width, height);
+            save_aov(backend, rptr::RenderHip::AOVMotionJitterIndex, pf + "_motion_jitter", width, height);
+            std::printf("%s: %d spp -> %s_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr\n", backend.name().c_str(), accumulated, pf.c_str());
             return 0;
         }
 
@@ -203,7 +242,7 @@ int main(int argc, char **argv) {
             std::fprintf(csv, "%d,%d,%d,%g,%g\n", frame + 1, keyframe, frames_accumulated, st.render_time, app_ms);
             // once per second of animation time, at the end of the keyframe (libapp/app_state.cpp:484-493)
             if (!profiling_img_prefix.empty() && (current_time + dt) >= std::ceil(current_time))
-                save_pfm(backend, profiling_img_prefix, keyframe, width, height, img);
+                save_image(backend, format, profiling_img_prefix, keyframe, "", width, height, img);
             current_time += dt;
         }
         std::fclose(csv);

@@ -58,6 +58,97 @@ def test_scene_dump_round_trips_through_the_cpp_loader(tmp_path):
     assert subprocess.run([exe, path, "--describe"], capture_output=True).returncode == 3
 
 
+def read_exr(path):
+    """minimal reader of what write_image.hpp writes: single-part scan-line OpenEXR, no compression, channels A B G R of one
+    type -> (h, w, 4) RGBA array (float32, or uint16 holding halfs)"""
+    import struct
+    raw = open(path, "rb").read()
+    assert struct.unpack_from("<II", raw, 0) == (20000630, 2)
+    at, attrs = 8, {}
+    while raw[at] != 0:
+        name_end = raw.index(b"\0", at)
+        type_end = raw.index(b"\0", name_end + 1)
+        size = struct.unpack_from("<I", raw, type_end + 1)[0]
+        attrs[raw[at:name_end].decode()] = (raw[name_end + 1:type_end].decode(), raw[type_end + 5:type_end + 5 + size])
+        at = type_end + 5 + size
+    at += 1
+    assert attrs["compression"][1] == b"\0" and attrs["lineOrder"][1] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    ch, names, types = attrs["channels"][1], [], []
+    k = 0
+    while ch[k] != 0:
+        e = ch.index(b"\0", k)
+        names.append(ch[k:e].decode())
+        types.append(struct.unpack_from("<I", ch, e + 1)[0])
+        k = e + 1 + 16
+    assert names == ["A", "B", "G", "R"] and len(set(types)) == 1
+    dt = np.float32 if types[0] == 2 else np.uint16
+    offsets = struct.unpack_from("<%dQ" % h, raw, at)
+    img = np.zeros((h, w, 4), dt)
+    for y in range(h):
+        yy, size = struct.unpack_from("<iI", raw, offsets[y])
+        assert yy == y and size == w * 4 * np.dtype(dt).itemsize
+        rows = np.frombuffer(raw, dtype=dt, count=4 * w, offset=offsets[y] + 8).reshape(4, w)
+        img[y, :, 3], img[y, :, 2], img[y, :, 1], img[y, :, 0] = rows[0], rows[1], rows[2], rows[3]
+    return img
+
+
+def read_png(path):
+    """8-bit RGBA PNG with filter type 0 rows (what write_image.hpp writes) -> (h, w, 4) uint8; checks every chunk's CRC"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, w, h = 8, b"", 0, 0
+    while at < len(raw):
+        n, kind = struct.unpack_from(">I4s", raw, at)
+        data = raw[at + 8:at + 8 + n]
+        assert zlib.crc32(kind + data) == struct.unpack_from(">I", raw, at + 8 + n)[0]
+        if kind == b"IHDR":
+            w, h, depth, colour = struct.unpack_from(">IIBB", data, 0)
+            assert (depth, colour) == (8, 6)
+        elif kind == b"IDAT":
+            idat += data
+        at += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 4 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 4).copy()
+
+
+def test_image_writers(tmp_path):
+    """write_image.hpp on the host alone: PFM in the reference's layout, EXR (float and half) and PNG readable by the minimal
+    readers above (PNG through zlib: stored deflate blocks, Adler-32 and CRCs are checked by it)"""
+    src = tmp_path / "w.cpp"
+    src.write_text('''
+#include "write_image.hpp"
+#include <cmath>
+int main(int, char **argv) {
+    const unsigned w = 37, h = 301;   // more than 65535 bytes of PNG rows: several stored blocks
+    std::vector<float> f((size_t)w * h * 4);
+    std::vector<uint16_t> half(f.size());
+    std::vector<unsigned char> u8(f.size());
+    for (size_t i = 0; i < f.size(); ++i) { f[i] = std::sin(0.37f * i) * 100.0f; half[i] = (uint16_t)(i * 7919u); u8[i] = (unsigned char)(i * 31u + 5u); }
+    std::string p = argv[1];
+    return rptr::write_pfm(p + "/a", w, h, 4, f.data()) && rptr::write_exr<float>(p + "/a", w, h, 4, f.data()) &&
+           rptr::write_exr<uint16_t>(p + "/b", w, h, 4, half.data()) && rptr::write_png(p + "/a", w, h, 4, u8.data()) ? 0 : 1;
+}
+''')
+    exe = str(tmp_path / "w")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + HOST, str(src), "-o", exe])
+    assert subprocess.run([exe, str(tmp_path)]).returncode == 0
+    w, h = 37, 301
+    i = np.arange(w * h * 4, dtype=np.float32)
+    f = (np.sin(np.float32(0.37) * i).astype(np.float32) * np.float32(100.0)).reshape(h, w, 4)
+    exr = read_exr(str(tmp_path / "a.exr"))
+    assert exr.dtype == np.float32 and np.allclose(exr, f, rtol=1e-5, atol=1e-4)      # (libm's sinf vs numpy's: not bit-equal)
+    assert np.array_equal(read_pfm(str(tmp_path / "a.pfm")), exr[..., :3])            # the same floats in both files
+    half = read_exr(str(tmp_path / "b.exr"))
+    assert half.dtype == np.uint16 and np.array_equal(half.reshape(-1), (np.arange(w * h * 4, dtype=np.uint64) * 7919 % 65536).astype(np.uint16))
+    png = read_png(str(tmp_path / "a.png"))
+    assert np.array_equal(png.reshape(-1), ((np.arange(w * h * 4, dtype=np.uint64) * 31 + 5) % 256).astype(np.uint8))
+
+
 def test_vks_scene_reaches_the_cpp_host_tool(tmp_path):
     """.vks -> `python -m ...vks --dump` -> bin/rptr_hip: the reference's asset format in front of the C++ host"""
     from realtimepathtracingresearchframework_amd import vks
@@ -153,7 +244,7 @@ def test_profiling_mode_csv_images_and_camera_flags(tmp_path):
     W, H = 64, 48
     csv_prefix, img_prefix = str(tmp_path / "prof"), str(tmp_path / "pimg")
     p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "4", "--profiling-frames", "8", "--profiling-img", img_prefix,
-                        "--img", str(W), str(H), "--eye", "0.5", "0.2", "3.0", "--center", "0", "0", "0", "--fov", "50"],
+                        "--img", str(W), str(H), "--eye", "0.5", "0.2", "3.0", "--center", "0", "0", "0", "--fov", "50", "--pfm"],
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     rows = open(csv_prefix + ".csv").read().strip().split("\n")
@@ -193,7 +284,7 @@ def test_profiling_mode_animated_wave_refits_every_frame(tmp_path):
     s.dump(path)
     csv_prefix, img_prefix = str(tmp_path / "anim"), str(tmp_path / "aimg")
     p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "2", "--profiling-frames", "4", "--profiling-img", img_prefix,
-                        "--img", "96", "64", "--variant", "diffuse", "--animate-wave", "0.5", "0.4"], capture_output=True, text=True)
+                        "--img", "96", "64", "--variant", "diffuse", "--animate-wave", "0.5", "0.4", "--pfm"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     vals = [r.split(",") for r in open(csv_prefix + ".csv").read().strip().split("\n")[1:]]
     assert [int(v[2]) for v in vals] == [1, 1, 1, 1]                        # every frame starts a new accumulation
@@ -205,3 +296,50 @@ def test_profiling_mode_animated_wave_refits_every_frame(tmp_path):
     s2.dump(path2)
     p = subprocess.run([exe, path2, "--profiling", csv_prefix, "--animate-wave", "0.5", "0.4"], capture_output=True, text=True)
     assert p.returncode == 3 and "dynamic" in p.stderr
+
+
+@pytest.mark.gpu
+def test_exr_png_and_data_capture_outputs(tmp_path):
+    """--exr (the default, as in the reference) holds the floats of --pfm plus alpha; --png the 8-bit frame buffer; --data-capture
+    stores the accumulation buffer and the three AOV images as EXR (libapp/app_state.cpp:499-531) = what the Python mirror reads back"""
+    from common import gpu_render
+    from realtimepathtracingresearchframework_amd import backend
+    exe = _build_cli(tmp_path)
+    s = scenes.textured_test()
+    path = str(tmp_path / "t.rpsc")
+    s.dump(path)
+    W, H, spp = 80, 60, 2
+    common = ["--validation-spp", str(spp), "--img", str(W), str(H)]
+    for flags in ([], ["--pfm"], ["--png"]):
+        prefix = str(tmp_path / ("v" + "".join(flags).strip("-")))
+        p = subprocess.run([exe, path, "--validation", prefix] + common + flags, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+    exr = read_exr(str(tmp_path / "v_0002.exr"))
+    pfm = read_pfm(str(tmp_path / "vpfm_0002.pfm"))
+    png = read_png(str(tmp_path / "vpng_0002.png"))
+    assert exr.dtype == np.float32 and np.array_equal(exr[..., :3].view(np.uint32), pfm.view(np.uint32))
+    img, _, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
+    assert np.array_equal(exr.view(np.uint32), img.view(np.uint32))
+    u8 = np.zeros((H, W, 4), np.uint8)
+    r.readback_framebuffer(u8)
+    assert np.array_equal(png, u8)
+    # data capture: 1 spp, keyframe 1
+    prefix = str(tmp_path / "cap")
+    p = subprocess.run([exe, path, "--data-capture", prefix, "--data-capture-spp", "1", "--img", str(W), str(H)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    r2 = backend.RenderHip()
+    r2.initialize(W, H)
+    r2.set_scene(s)
+    r2.render(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1)
+    rgba = np.zeros((H, W, 4), np.float32)
+    r2.readback_framebuffer(rgba)
+    assert np.array_equal(read_exr(prefix + "_0001_rgba.exr").view(np.uint32), rgba.view(np.uint32))
+    for k, name in enumerate(("albedo_roughness", "normal_depth", "motion_jitter")):
+        half = np.zeros((H, W, 4), np.float16)
+        r2.readback_aov(k, half)
+        got = read_exr("%s_0001_%s.exr" % (prefix, name))
+        assert got.dtype == np.uint16 and np.array_equal(got, half.view(np.uint16)), name
+    r.close()
+    r2.close()
+    assert subprocess.run([exe, path, "--data-capture", prefix, "--validation", "x"], capture_output=True).returncode == 2
+
