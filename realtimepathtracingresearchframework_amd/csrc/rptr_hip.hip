@@ -104,7 +104,7 @@ struct rptr_hip {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 0;
-    size_t bytes_allocated = 0;
+    size_t bytes_allocated = 0, bytes_frame = 0, bytes_scene = 0; // what is allocated now (frame buffers + path state, scene)
     std::vector<void *> allocations;
 
     // frame
@@ -208,7 +208,8 @@ int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track) {
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    h->bytes_allocated += bytes;
+    (track == &h->scene_allocs ? h->bytes_scene : h->bytes_frame) += bytes;
+    h->bytes_allocated = h->bytes_scene + h->bytes_frame;
     (track ? track : &h->allocations)->push_back(p);
     *out = reinterpret_cast<T *>(p);
     return RPTR_OK;
@@ -780,6 +781,8 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     for (void *p : h->allocations) (void)hipFree(p);
     h->allocations.clear();
+    h->bytes_frame = 0;
+    h->bytes_allocated = h->bytes_scene;
     h->first_queue.clear();
     h->width = fb_width;
     h->height = fb_height;
@@ -891,6 +894,8 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         (void)hipFree(p);
     }
     h->scene_allocs.clear();
+    h->bytes_scene = 0;
+    h->bytes_allocated = h->bytes_frame;
     h->have_scene = false;
     // ---- validation (what the reference host rejects or this build does not cover yet)
     if (s->num_textures && !s->textures) return fail(h, RPTR_E_INVALID, "num_textures = %u but textures is NULL", s->num_textures);
