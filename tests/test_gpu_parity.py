@@ -697,3 +697,25 @@ def test_flattened_scene_matches_the_oracle_on_the_same_tree(scene_name):
         assert abs(float(np.nanmean(img[..., :3])) - float(np.nanmean(img2[..., :3]))) < 0.03 * float(np.nanmean(img2[..., :3]))
     else:
         assert image_error(img, img2)[0] < 5 * RMSE_TOL
+
+
+def test_reinitialize_and_new_scene_on_one_handle():
+    """initialize() and set_scene() may come again (resize, scene switch: app.cpp:445,150-175): old buffers are released, the
+    adaptive tail hand-over starts over, images stay right and the reported device memory is what is allocated now"""
+    r = backend.RenderHip(frames_in_flight=2)
+    s1, s2 = scenes.textured_test(), scenes.two_level_test()
+    reported = {}
+    for W, H, s in [(64, 48, s1), (128, 96, s2), (64, 48, s1)]:
+        r.initialize(W, H)
+        r.set_scene(s)
+        for k in range(3):
+            st = r.render(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=(k == 0)), spp=2)
+        img = np.zeros((H, W, 4), np.float32)
+        assert r.readback_framebuffer(img) == W * H * 4
+        ref, _ = O.OracleScene(s).render(W, H, 6)
+        rmse, same, _ = image_error(img, ref)
+        assert same and rmse < RMSE_TOL
+        reported.setdefault((W, H, s.name), []).append(int(st.raw.device_bytes_allocated))
+    first, again = reported[(64, 48, s1.name)]
+    assert first == again
+    r.close()
