@@ -719,3 +719,32 @@ def test_reinitialize_and_new_scene_on_one_handle():
     first, again = reported[(64, 48, s1.name)]
     assert first == again
     r.close()
+
+
+def test_full_size_forest_flattened_against_two_level():
+    """BASELINE configs[3] at full size (10 M instanced triangles, 1080p): the world-space tree and the two-level tree trace the same
+    frame -- same closest-hit queries up to silhouette flips, images equal up to those pixels -- the flattened one with fewer node
+    fetches; its stripe split is bit-identical to the whole frame; a band of rows agrees with the oracle's own two-level tree"""
+    import os
+    s = scenes.forest()
+    W, H = 1920, 1080
+    two, st2, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF, count=True)
+    os.environ["RPTR_FLATTEN"] = "1"
+    try:
+        flat, st1, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF, count=True)
+        half = np.zeros_like(flat)
+        for rank in range(2):
+            img, _, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF, rank=rank, world=2, stripe_rows=8)
+            rows = [y for y in range(H) if (y // 8) % 2 == rank]
+            half[rows] = img[rows]
+    finally:
+        del os.environ["RPTR_FLATTEN"]
+    assert np.array_equal(flat.view(np.uint32), half.view(np.uint32))
+    assert abs(int(st1.raw.rays_closest) - int(st2.raw.rays_closest)) <= 2e-3 * int(st2.raw.rays_closest)
+    assert st1.raw.nodes_closest < 0.8 * st2.raw.nodes_closest
+    differ = (np.abs(flat[..., :3] - two[..., :3]).max(axis=2) > 1e-4).mean()
+    assert differ < 0.02                                           # a path that flips at a silhouette changes its whole pixel
+    rows = (600, 604)
+    ref, _ = O.OracleScene(s).render(W, H, 1, variant=abi.VARIANT_GLTF, rows=rows)
+    band = np.abs(flat[rows[0]:rows[1], :, :3] - ref[rows[0]:rows[1], :, :3]).max(axis=2)
+    assert (band > 1e-4).mean() < 0.02
