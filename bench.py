@@ -24,8 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # One hardware queue per HIP stream: every frame context of the backend owns a stream, and two streams that share a hardware
 # queue serialise (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 queues by default; measured: 7 contexts on 4 queues
-# 0.34 ms per 1/8 frame, on 8 queues 0.29 ms). Read by the runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # 7 frame contexts + the caller's stream + RCCL's
+# 0.34 ms per 1/8 frame, on 8 queues 0.29 ms; 11 contexts on 16 queues 0.25 ms). Read by the runtime when it initialises, so it is set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 11 frame contexts + the caller's stream + RCCL's
 
 # record sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
@@ -58,8 +58,8 @@ def parse_args():
                          "(inside the timed region) and renders")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head. "
-                         "Default: 3 on one GPU, 7 for the small per-rank frames of a multi-GPU split (measured: a 1/8 frame takes 0.36 ms "
-                         "with 3 contexts, 0.29 ms with 7; a full frame 1.50 vs 1.47 ms)")
+                         "Default: 3 on one GPU, 11 for the small per-rank frames of a multi-GPU split (measured: a 1/8 frame takes 0.34 ms "
+                         "with 3 contexts, 0.28 ms with 7, 0.25 ms with 11; a full frame 1.49 vs 1.46 ms)")
     ap.add_argument("--stripe-rows", type=int, default=8,
                     help="rows per screen stripe of the tile split (multiple of 8); stripe s belongs to rank s %% N. 1080 rows in 8-row "
                          "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
@@ -126,7 +126,7 @@ def main():
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
     small_frames = world > 1 or args.emulate_world > 1
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if small_frames else 3)  # (dynamic scene: every context refits its own tree copy)
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (11 if small_frames else 3)  # (dynamic scene: every context refits its own tree copy)
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     else:

@@ -850,6 +850,10 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     int occ = 0;
     HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false, false>, RP_TRAVERSE_BLOCK, 0));
     occ = std::max(1, std::min(occ, 8));
+    // frames in flight share the CUs: with n contexts a traversal launch asks for about 12 / n blocks per CU instead of all that
+    // fit, so that the kernels of the other frames find room next to it (measured, profiles/r01_notes.md: 3 contexts 5 -> 4 blocks
+    // 1.50 -> 1.49 ms per full frame; 11 contexts 5 -> 1 blocks 0.30 -> 0.25 ms per 1/8 frame)
+    if (h->ctx.size() > 1) occ = std::max(1, std::min(occ, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
     h->persistent_blocks = h->num_cus * occ;
     h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
