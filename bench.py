@@ -126,7 +126,7 @@ def main():
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
     small_frames = world > 1 or args.emulate_world > 1
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else (11 if small_frames else 3)  # (dynamic scene: every context refits its own tree copy)
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else ((7 if args.animate else 11) if small_frames else 3)  # (dynamic scene: every context refits its own tree copy)
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     else:

@@ -1620,19 +1620,22 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
-    if (!h->ctx_scene.empty() && scn.version != h->refit_version) {
-        // this context's own tree / vertices follow the master set: copy the float positions, refit (on the backend's
-        // stream, behind the caller's updates; this context is idle, the others keep rendering from their own sets)
+    const bool follow = !h->ctx_scene.empty() && scn.version != h->refit_version;
+    if (follow) {
+        // this context's own vertices follow the master set: the copy of the float positions is queued on the backend's stream,
+        // behind the caller's updates (this context is idle, the others keep rendering from their own sets)
         for (size_t gi = 0; gi < scn.dynpos.size(); ++gi)
             if (scn.dynpos[gi])
                 HIP_TRY(h, hipMemcpyAsync(scn.dynpos[gi], h->master.dynpos[gi], (size_t)h->geom_tris[gi] * 9 * sizeof(float), hipMemcpyDeviceToDevice,
                                           h->stream));
-        (void)refit_scene_copy(h, scn, true, h->stream);
-        scn.version = h->refit_version;
     }
-    if (multi) { // whatever the caller queued on the backend's stream (vertex updates, refit) comes first
+    if (multi) { // whatever the caller queued on the backend's stream (vertex updates, the copy above) comes first
         HIP_TRY(h, hipEventRecord(c.ev_dep, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_dep, 0));
+    }
+    if (follow) { // ... and its tree is refitted on its OWN stream: the refits of different contexts run side by side
+        (void)refit_scene_copy(h, scn, true, c.stream);
+        scn.version = h->refit_version;
     }
     HIP_TRY(h, hipEventRecord(c.ev_begin, c.stream));
     c.launches_extend = c.launches_connect = 0;
