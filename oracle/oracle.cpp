@@ -864,19 +864,93 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
 }
 
 // process_samples.comp:143-190: exposure, sRGB, RGBA8 (alpha < 0 pixels skipped)
-int orc_resolve_u8(const float *accum, int n_pixels, float exposure, unsigned char *out) {
-    for (int i = 0; i < n_pixels; ++i) {
-        vec4 c(accum[4 * i], accum[4 * i + 1], accum[4 * i + 2], fminf(accum[4 * i + 3], 1.0f));
-        if (!(c.w >= 0.0f)) continue;
-        float e = exp2f(exposure);
-        float r = linear_to_srgb(c.x * e), g = linear_to_srgb(c.y * e), b = linear_to_srgb(c.z * e);
-        auto q = [](float v) { // imageStore to rgba8: unorm conversion, round to nearest
-            v = fminf(fmaxf(v, 0.0f), 1.0f);
-            return (unsigned char)(v * 255.0f + 0.5f);
-        };
-        out[4 * i] = q(r); out[4 * i + 1] = q(g); out[4 * i + 2] = q(b); out[4 * i + 3] = q(c.w);
+static inline float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { // subnormal half: value = m * 2^-24
+            float v = (float)m * 5.9604644775390625e-08f;
+            memcpy(&u, &v, 4);
+            u |= sign;
+        }
+    } else if (e == 31) u = sign | 0x7F800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// rendering/postprocess/tonemapping_utils.glsl:9-33 (NO / NEUTRAL / FAST = 0 / 1 / 2, postprocess/tonemapping.h)
+static inline vec3 tonemap(int mode, vec3 c) {
+    if (mode == 2) return c / (vec3(1.0f) + c);
+    if (mode == 1) {
+        const float luminance_level = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, 1.0f));
+        return c * (mix(0.1f * log2f(luminance_level), 1.0f, 0.8f) / luminance_level);
     }
+    return c;
+}
+// vulkan/process_samples.comp:134-198 for an already resolved accumulation buffer: alpha clamp, exposure (only for
+// OUTPUT_CHANNEL_COLOR, :143-144), early tone mapping (:148-149), the AOV views (:150-178, ENABLE_AOV_BUFFERS; aov* = RGBA16F images
+// of width*height texels or NULL = the build without AOV buffers :179-188), sRGB (:190), RGBA8 store, 2x2 replication when
+// render_upscale_factor == 2 (:192-197; `out` is then (2 width) x (2 height)). Pixels with alpha < 0 are left untouched (:139-140).
+int orc_process_samples_u8(const float *accum, int width, int height, const RptrRenderParams *rp, const float cam_pos[3], const uint16_t *aov_albedo_roughness,
+                           const uint16_t *aov_normal_depth, const uint16_t *aov_motion_jitter, unsigned char *out) {
+    auto q = [](float v) { // imageStore to rgba8: unorm conversion, round to nearest
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        return (unsigned char)(v * 255.0f + 0.5f);
+    };
+    auto ld = [](const uint16_t *img, size_t i) { return vec4(half_to_float(img[4 * i]), half_to_float(img[4 * i + 1]), half_to_float(img[4 * i + 2]), half_to_float(img[4 * i + 3])); };
+    const int up = rp->render_upscale_factor == 2 ? 2 : 1;
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            const size_t i = (size_t)y * width + x;
+            vec4 c(accum[4 * i], accum[4 * i + 1], accum[4 * i + 2], fminf(accum[4 * i + 3], 1.0f));
+            if (!(c.w >= 0.0f)) continue;
+            if (rp->output_channel == 0) {
+                const float e = exp2f(rp->exposure);
+                vec3 v(c.x * e, c.y * e, c.z * e);
+                if (rp->early_tone_mapping_mode >= 0) v = tonemap(rp->early_tone_mapping_mode, v);
+                c = vec4(v.x, v.y, v.z, c.w);
+            } else if (aov_albedo_roughness) {
+                if (rp->output_channel == 1) {
+                    c = ld(aov_albedo_roughness, i);
+                    if (rp->output_moment != 0) c = vec4(c.w, c.w, c.w, c.w);
+                } else if (rp->output_channel == 2) {
+                    c = ld(aov_normal_depth, i);
+                    if (rp->output_moment != 0) c = vec4(c.w * 0.05f, c.w * 0.05f, c.w * 0.05f, c.w);
+                    else c = vec4(c.x * 0.5f + 0.5f, c.y * 0.5f + 0.5f, c.z * 0.5f + 0.5f, c.w);
+                } else if (rp->output_channel == 3) {
+                    const vec4 mj = ld(aov_motion_jitter, i);
+                    if (rp->output_moment == 0) c = vec4(fabsf(10.0f * mj.x), fabsf(10.0f * mj.y), 0.0f, 1.0f);
+                    else {
+                        const float jx = (mj.z + 1.0f / float(width)) * (float(width) / 2.0f), jy = (mj.w + 1.0f / float(height)) * (float(height) / 2.0f);
+                        c = vec4(jx * 0.5f + 0.5f, jy * 0.5f + 0.5f, 0.0f, 1.0f);
+                    }
+                }
+            } else {
+                if (rp->output_channel == 2) {
+                    if (rp->output_moment != 0) {
+                        const float l = length(vec3(c.x, c.y, c.z));
+                        c = vec4(l, l, l, c.w);
+                    } else c = vec4(c.x * 0.5f + 0.5f, c.y * 0.5f + 0.5f, c.z * 0.5f + 0.5f, c.w);
+                } else if (rp->output_channel == 3)
+                    c = vec4((c.x - cam_pos[0]) * 0.1f + 0.5f, (c.y - cam_pos[1]) * 0.1f + 0.5f, (c.z - cam_pos[2]) * 0.1f + 0.5f, c.w);
+            }
+            const unsigned char px[4] = {q(linear_to_srgb(c.x)), q(linear_to_srgb(c.y)), q(linear_to_srgb(c.z)), q(c.w)};
+            for (int dy = 0; dy < up; ++dy)
+                for (int dx = 0; dx < up; ++dx) memcpy(out + 4 * ((size_t)(up * y + dy) * (up * width) + (up * x + dx)), px, 4);
+        }
     return 0;
+}
+// the default view (output_channel 0, no tone mapping, no upscale) of n_pixels resolved pixels
+int orc_resolve_u8(const float *accum, int n_pixels, float exposure, unsigned char *out) {
+    RptrRenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.exposure = exposure;
+    rp.early_tone_mapping_mode = -1;
+    rp.render_upscale_factor = 1;
+    const float cam[3] = {0, 0, 0};
+    return orc_process_samples_u8(accum, n_pixels, 1, &rp, cam, nullptr, nullptr, nullptr, out);
 }
 
 // ---- function-level probes (numpy drives these for unit/property tests) ----

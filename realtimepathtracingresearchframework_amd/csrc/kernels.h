@@ -1,6 +1,6 @@
 // kernels.h -- the wavefront stages that replace the reference's megakernel.
 //
-//   raygen   pt_megakernel.glsl:310-325   camera rays, RNG seeding, path state init
+//   raygen   pt_megakernel.glsl:310-325   camera rays, RNG seeding: computed by the first extend / shade (rp_primary_ray)
 //   extend   pt_megakernel.glsl:440-475   closest-hit queries      (persistent waves)
 //   sort     (new)                        regroup hit paths by material id
 //   shade    pt_megakernel.glsl:480-730   miss/sky, hit attributes, emitter MIS, NEE
@@ -104,32 +104,28 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir)
     return true;
 }
 
-// queue of the first bounce: the ids of the pixel samples that exist (tile padding and rows beyond the frame drop out)
-__global__ __launch_bounds__(256) void rp_k_raygen(RpFrame f, uint32_t *queue, RpCounters *ctr) {
-    __shared__ uint32_t s_ids[RP_CHUNK];
-    __shared__ uint32_t s_n, s_base;
-    const uint32_t total = uint32_t(f.batch_spp) * uint32_t(f.npix_padded);
-    const uint32_t nchunks = (total + RP_CHUNK - 1) / RP_CHUNK;
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-#pragma unroll 1
-        for (uint32_t k = 0; k < RP_CHUNK / 256; ++k) {
-            const uint32_t p = chunk * RP_CHUNK + k * 256 + threadIdx.x;
-            bool valid = p < total;
-            if (valid) {
-                const uint32_t sslot = p / uint32_t(f.npix_padded);
-                const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
-                int lx = 0, ly = 0;
-                valid = rp_slot_to_local(f, slot, lx, ly) && rp_local_row_to_global(f, ly) < f.height;
-            }
-            const uint32_t at = rp_wave_append(&s_n, valid);
-            if (valid) s_ids[at] = p;
-        }
-        __syncthreads();
-        rp_block_flush(s_ids, s_n, queue, &ctr->bounce[0].queue_count, &s_base);
-        __syncthreads();
-    }
+// The queue of the first bounce -- the ids of the pixel samples that exist (tile padding drops out) -- is never stored: its
+// entry i is a pure function of the frame's tiling. Sample slot after sample slot; inside a slot the 8x8 tiles row by row, the
+// pixels of a tile next to each other (64 consecutive entries = one full tile = one wave of camera rays). Every row a rank owns
+// exists in the frame (rptr_hip.hip local_row_count), so an entry is valid iff lx < width and ly < local_rows.
+RP_DEV uint32_t rp_first_path_id(const RpFrame &f, uint32_t i) {
+    const uint32_t per_slot = uint32_t(f.width) * uint32_t(f.local_rows);
+    const uint32_t sslot = i / per_slot;
+    uint32_t j = i - sslot * per_slot;
+    const uint32_t band = 8u * uint32_t(f.width); // pixels of a full row of tiles
+    const uint32_t ty = j / band;
+    j -= ty * band;
+    const uint32_t rh = min(8u, uint32_t(f.local_rows) - 8u * ty); // rows of this row of tiles
+    const uint32_t per_tile = rh * 8u;
+    const uint32_t tx = min(j / per_tile, uint32_t(f.tiles_x) - 1u);
+    j -= tx * per_tile;
+    const uint32_t cw = min(8u, uint32_t(f.width) - 8u * tx); // columns of this tile
+    const uint32_t r = j / cw, c = j - r * cw;
+    return sslot * uint32_t(f.npix_padded) + (ty * uint32_t(f.tiles_x) + tx) * 64u + r * 8u + c;
+}
+// the same list in memory, for the opt-in regrouping pass (its kernels read a queue array)
+__global__ __launch_bounds__(256) void rp_k_first_queue(RpFrame f, uint32_t *queue, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = rp_first_path_id(f, i);
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
@@ -143,8 +139,10 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
                            int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
+    uint32_t lane_p = 0; // the path whose ray this lane traces
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
-        const uint32_t p = queue[i];
+        const uint32_t p = (FIRST && !queue) ? rp_first_path_id(f, i) : queue[i]; // FIRST: the first queue is computed (NULL) unless the caller stored it
+        lane_p = p;
         if (FIRST) {
             uint32_t rng;
             (void)rp_primary_ray(f, p, rng, rd); // the queue holds existing pixel samples only
@@ -161,8 +159,8 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             if (ALPHA) lane_rng = lane_rng_in = __float_as_uint(ps.rng_tt[p].x);
         }
     };
-    auto done = [&](uint32_t i, const RpHitRec &h) {
-        const uint32_t p = queue[i];
+    auto done = [&](uint32_t, const RpHitRec &h) {
+        const uint32_t p = lane_p;
         ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
         if (ALPHA) {
@@ -428,7 +426,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             uint32_t pp = 0;
             bool is_hit = false;
             if (valid) {
-                pp = order[i];
+                pp = (FIRST && !order) ? rp_first_path_id(f, i) : order[i];
                 is_hit = ps.hit_ids[pp].x >= 0;
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
@@ -812,8 +810,61 @@ __global__ void rp_k_reset_u32(uint32_t *p) { *p = 0; }
 
 // ------------------------------------------------------------------ resolve
 // accumulate.glsl:68-73 (store this sample) + process_samples.comp:116-132 (running mean into the
-// history) + :143-190 (exposure, sRGB, RGBA8). One thread per local pixel, samples folded in order.
+// history) + :143-198 (exposure, early tone mapping, AOV views, sRGB, RGBA8). One thread per local pixel, samples folded in order.
 // out_accum / out_fb (frames in flight, else NULL): a second copy of what this frame leaves in accum / fb
+RP_DEV float4 rp_half4_to_float4(uint2 h) {
+    return make_float4((float)__builtin_bit_cast(_Float16, (uint16_t)(h.x & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(h.x >> 16)),
+                       (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y >> 16)));
+}
+// rendering/postprocess/tonemapping_utils.glsl:9-33 (modes: postprocess/tonemapping.h)
+RP_DEV V3 rp_tonemap(int mode, V3 c) {
+    if (mode == 2) // FAST_TONE_MAPPING
+        return c / (v3s(1.0f) + c);
+    if (mode == 1) { // NEUTRAL_TONE_MAPPING
+        const float luminance_level = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, 1.0f));
+        return c * (mixf(0.1f * log2f(luminance_level), 1.0f, 0.8f) / luminance_level);
+    }
+    return c; // NO_TONE_MAPPING
+}
+// process_samples.comp:143-190: what the RGBA8 frame buffer shows for the resolved pixel `acc` (alpha already clamped)
+RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
+    const int ch = f.rp.output_channel;
+    if (ch == 0) { // OUTPUT_CHANNEL_COLOR
+        const float e = exp2f(f.rp.exposure);
+        V3 c = v3(o.x * e, o.y * e, o.z * e);
+        if (f.rp.early_tone_mapping_mode >= 0) c = rp_tonemap(f.rp.early_tone_mapping_mode, c);
+        o = f4(c, o.w);
+    } else if (f.aov_albedo_roughness) { // ENABLE_AOV_BUFFERS: the views of the AOV images
+        if (ch == 1) {
+            o = rp_half4_to_float4(f.aov_albedo_roughness[pixel]);
+            if (f.rp.output_moment != 0) o = make_float4(o.w, o.w, o.w, o.w);
+        } else if (ch == 2) {
+            o = rp_half4_to_float4(f.aov_normal_depth[pixel]);
+            if (f.rp.output_moment != 0)
+                o = make_float4(o.w * 0.05f, o.w * 0.05f, o.w * 0.05f, o.w);
+            else
+                o = make_float4(o.x * 0.5f + 0.5f, o.y * 0.5f + 0.5f, o.z * 0.5f + 0.5f, o.w);
+        } else if (ch == 3) {
+            const float4 mj = rp_half4_to_float4(f.aov_motion_jitter[pixel]);
+            if (f.rp.output_moment == 0)
+                o = make_float4(fabsf(10.0f * mj.x), fabsf(10.0f * mj.y), 0.0f, 1.0f);
+            else { // jitter back to pixel units (process_samples.comp:171-176)
+                const float jx = (mj.z + 1.0f / float(f.width)) * (float(f.width) / 2.0f), jy = (mj.w + 1.0f / float(f.height)) * (float(f.height) / 2.0f);
+                o = make_float4(jx * 0.5f + 0.5f, jy * 0.5f + 0.5f, 0.0f, 1.0f);
+            }
+        }
+    } else { // without AOV images (RPTR_AOVS=0): the views of what the integrator accumulated (process_samples.comp:179-188)
+        if (ch == 2) {
+            if (f.rp.output_moment != 0) {
+                const float l = len3(v3(o.x, o.y, o.z));
+                o = make_float4(l, l, l, o.w);
+            } else
+                o = make_float4(o.x * 0.5f + 0.5f, o.y * 0.5f + 0.5f, o.z * 0.5f + 0.5f, o.w);
+        } else if (ch == 3)
+            o = make_float4((o.x - f.cam_pos[0]) * 0.1f + 0.5f, (o.y - f.cam_pos[1]) * 0.1f + 0.5f, (o.z - f.cam_pos[2]) * 0.1f + 0.5f, o.w);
+    }
+    return make_float4(rp_linear_to_srgb(o.x), rp_linear_to_srgb(o.y), rp_linear_to_srgb(o.z), o.w);
+}
 __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb, float4 *out_accum, uchar4 *out_fb) {
     const int npix = f.width * f.local_rows;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
@@ -840,10 +891,9 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
         float4 o = acc;
         o.w = fminf(o.w, 1.0f);
         if (o.w >= 0.0f) {
-            const float e = exp2f(f.rp.exposure);
-            const float r = rp_linear_to_srgb(o.x * e), g = rp_linear_to_srgb(o.y * e), b = rp_linear_to_srgb(o.z * e);
-            const uchar4 px = make_uchar4((unsigned char)(clamp1(r, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(g, 0.f, 1.f) * 255.0f + 0.5f),
-                                          (unsigned char)(clamp1(b, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
+            o = rp_display_color(f, o, i);
+            const uchar4 px = make_uchar4((unsigned char)(clamp1(o.x, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.y, 0.f, 1.f) * 255.0f + 0.5f),
+                                          (unsigned char)(clamp1(o.z, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
             fb[i] = px;
             if (out_fb) out_fb[i] = px;
         } else if (out_fb)

@@ -149,18 +149,13 @@ struct rptr_hip {
     bool master_refit_pending = false; // rptr_hip_refit with frame contexts that own their sets: the master tree is refitted on demand
 
     // device buffers (frame sized)
-    // queue of the first bounce: the ids of the pixel samples that exist. It only depends on the frame size, the tiling and
-    // the number of sample slots of the batch, so it is built once per batch size (rp_k_raygen) and shared, read-only
-    struct FirstQueue {
-        uint32_t *ids = nullptr;
-        uint32_t count = 0;
-    };
-    std::map<int, FirstQueue> first_queue;
     std::vector<FrameCtx> ctx;      // frames in flight (RptrCreateInfo.frames_in_flight, at least 1)
     uint64_t next_ticket = 1;
     int next_ctx = 0;
     int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
     int aov_ctx = 0;                // the context whose AOV images readback_aov returns (last finished frame)
+    bool output_overwritten = false; // a newer frame was submitted on output_ctx / aov_ctx: its resolve rewrites the images a read-back
+    bool aov_overwritten = false;    // would return, so read-backs fail until that frame has been waited for
     int tail_mode = -1;             // RPTR_TAIL_BOUNCE: -1 adaptive, 0 off, k > 0: the tail kernel takes over at bounce k
     int tail_adaptive = 1 << 30;    // adaptive choice for the next frame (from the queue lengths of the last finished frame)
     int tail_blocks = 0;
@@ -293,6 +288,48 @@ struct HostBvh {
 // meet one well-separated tree instead of a thousand overlapping instance boxes, each with its own ray transform. Hits are
 // found on the world-space triangles, so t / u / v may differ from the two-level walk by rounding; shading still reads the
 // mesh's own vertex streams through the instance record the triangle names (RptrBvhTri.flags bits 8..31).
+// What both set_scene and rptr_hip_build_bvh_host check before they touch the borrowed arrays: index ranges of the mesh /
+// geometry / material tables (a malformed .vks file must be rejected, not read out of bounds). Returns "" when fine.
+static std::string validate_scene_tables(const RptrSceneDesc *s) {
+    char buf[256];
+    auto err = [&](const char *fmt, auto... a) {
+        snprintf(buf, sizeof(buf), fmt, a...);
+        return std::string(buf);
+    };
+    if ((s->num_geometries && !s->geometries) || (s->num_meshes && !s->meshes) || (s->num_parameterized_meshes && !s->parameterized_meshes) ||
+        (s->num_instances && !s->instances) || (s->num_materials && !s->materials) || (s->num_lights && !s->lights))
+        return "a table of the scene is NULL but its count is not 0";
+    for (uint32_t g = 0; g < s->num_geometries; ++g)
+        if (s->geometries[g].num_tris && !s->geometries[g].qpos) return err("geometry %u: qpos is NULL", g);
+    for (uint32_t m = 0; m < s->num_meshes; ++m)
+        if ((uint64_t)s->meshes[m].first_geometry + s->meshes[m].num_geometries > s->num_geometries)
+            return err("mesh %u: geometries [%u, +%u) are outside the scene's %u geometries", m, s->meshes[m].first_geometry, s->meshes[m].num_geometries,
+                       s->num_geometries);
+    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p) {
+        const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[p];
+        if (pm.mesh >= s->num_meshes) return err("parameterized mesh %u: bad mesh index", p);
+        const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+        if (mesh.num_geometries && !pm.material_offsets) return err("parameterized mesh %u: material_offsets is NULL", p);
+        size_t off = 0;
+        for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+            const uint32_t nt = s->geometries[mesh.first_geometry + j].num_tris;
+            if (pm.material_offsets[j] < 0 || (uint32_t)pm.material_offsets[j] >= s->num_materials)
+                return err("parameterized mesh %u geometry %u: material offset %d out of range (%u materials)", p, j, pm.material_offsets[j], s->num_materials);
+            if (pm.tri_material_ids) {
+                uint32_t max_local = 0;
+                for (uint32_t t = 0; t < nt; ++t) max_local = std::max<uint32_t>(max_local, pm.tri_material_ids[off + t]);
+                if (nt && (uint64_t)pm.material_offsets[j] + max_local >= s->num_materials)
+                    return err("parameterized mesh %u geometry %u: per-triangle material id %u + offset %d is outside the scene's %u materials", p, j, max_local,
+                               pm.material_offsets[j], s->num_materials);
+            }
+            off += nt;
+        }
+    }
+    for (uint32_t i = 0; i < s->num_instances; ++i)
+        if (s->instances[i].parameterized_mesh >= s->num_parameterized_meshes) return err("instance %u: bad mesh", i);
+    return std::string();
+}
+
 static bool want_flatten(const RptrSceneDesc *s) {
     const char *e = getenv("RPTR_FLATTEN");
     if (!e || atoi(e) == 0 || s->num_instances < 2) return false;
@@ -783,7 +820,6 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->allocations.clear();
     h->bytes_frame = 0;
     h->bytes_allocated = h->bytes_scene;
-    h->first_queue.clear();
     h->width = fb_width;
     h->height = fb_height;
     h->local_rows = local_row_count(fb_height, h->stripe_rows, h->rank, h->world);
@@ -840,6 +876,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->output_ctx = -1;
     h->last_resolved = nullptr;
     h->aov_ctx = 0;
+    h->output_overwritten = h->aov_overwritten = false;
     if (h->aovs)
         for (FrameCtx &c : h->ctx)
             for (int k = 0; k < 3; ++k) {
@@ -902,6 +939,10 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->bytes_allocated = h->bytes_frame;
     h->have_scene = false;
     // ---- validation (what the reference host rejects or this build does not cover yet)
+    {
+        const std::string bad = validate_scene_tables(s);
+        if (!bad.empty()) return fail(h, RPTR_E_INVALID, "%s", bad.c_str());
+    }
     if (s->num_textures && !s->textures) return fail(h, RPTR_E_INVALID, "num_textures = %u but textures is NULL", s->num_textures);
     for (uint32_t t = 0; t < s->num_textures; ++t)
         if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].width > 16384 || s->textures[t].height > 16384)
@@ -924,11 +965,6 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
                 return fail(h, RPTR_E_INVALID, "material %u: textured parameter refers to texture %u of %u", m, RPTR_TEXTURE_ID(u), s->num_textures);
         }
     }
-    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p)
-        if (s->parameterized_meshes[p].mesh >= s->num_meshes) return fail(h, RPTR_E_INVALID, "parameterized mesh %u: bad mesh index", p);
-    for (uint32_t i = 0; i < s->num_instances; ++i)
-        if (s->instances[i].parameterized_mesh >= s->num_parameterized_meshes) return fail(h, RPTR_E_INVALID, "instance %u: bad mesh", i);
-
     int rc;
     // ---- textures (RGBA8) + the sRGB decode table
     RpTexture *d_textures = nullptr;
@@ -1032,11 +1068,6 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             r.material_id = d_ids ? -1 - pm.material_offsets[j] : pm.material_offsets[j];
             r.flags = (gd.has_normals && d_qnu[gi] ? RP_GEOM_HAS_NORMALS : 0u) | (gd.has_uvs && d_qnu[gi] ? RP_GEOM_HAS_UVS : 0u) |
                       (h->master.dynpos[gi] ? RP_GEOM_DYNAMIC : 0u);
-            // material index range check
-            const int max_local = d_ids ? 255 : 0;
-            if (pm.material_offsets[j] < 0 || (uint32_t)(pm.material_offsets[j]) >= s->num_materials)
-                return fail(h, RPTR_E_INVALID, "parameterized mesh %u geometry %u: material offset out of range", p, j);
-            (void)max_local;
             geoms.push_back(r);
             prim_offset += gd.num_tris;
         }
@@ -1488,8 +1519,12 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
     st.launches_extend = c.launches_extend;
     st.launches_connect = c.launches_connect;
     st.device_bytes_allocated = h->bytes_allocated;
-    if (h->ctx.size() > 1) h->output_ctx = (int)(&c - h->ctx.data());
+    if (h->ctx.size() > 1) {
+        h->output_ctx = (int)(&c - h->ctx.data());
+        h->output_overwritten = false;
+    }
     h->aov_ctx = (int)(&c - h->ctx.data());
+    h->aov_overwritten = false;
     if (h->local_rows > 0) {
         // where the next frame hands over to the tail kernel: the first bounce whose queue was short in this frame. Queue
         // lengths are known up to the bounce the tail took over at (it does not publish its block-local lists), so the
@@ -1534,6 +1569,11 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                     (unsigned long long)c.ticket);
     h->next_ctx = (h->next_ctx + 1) % (int)h->ctx.size();
     const bool multi = h->ctx.size() > 1;
+    if (multi) { // this context's images are about to be rewritten: what was queued on the backend's stream so far still sees the old
+                 // ones (ev_dep below), a read-back issued after this submission would not
+        if ((int)(&c - h->ctx.data()) == h->output_ctx) h->output_overwritten = true;
+        if ((int)(&c - h->ctx.data()) == h->aov_ctx) h->aov_overwritten = true;
+    }
     // begin_frame: render_vulkan.cpp:1937-1941
     if (reset_accumulation) {
         h->frame_offset += h->frame_id;
@@ -1652,22 +1692,15 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
         f.batch_spp = batch;
         if (local_work) {
             HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
-            auto fq = h->first_queue.find(batch);
-            if (fq == h->first_queue.end()) { // first frame with this batch size: build the list (synchronous, once)
-                rptr_hip::FirstQueue q;
-                const size_t total = (size_t)batch * h->npix_padded;
-                int rc2 = dev_alloc(h, &q.ids, total, nullptr);
-                if (rc2) return rc2;
-                RpCounters *tmp = nullptr;
-                if ((rc2 = dev_alloc(h, &tmp, 1, nullptr))) return rc2;
-                HIP_TRY(h, hipMemsetAsync(tmp, 0, sizeof(RpCounters), c.stream));
-                hipLaunchKernelGGL(rp_k_raygen, dim3(grid_for(h, total)), dim3(256), 0, c.stream, f, q.ids, tmp);
-                HIP_TRY(h, hipMemcpyAsync(&q.count, &tmp->bounce[0].queue_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-                HIP_TRY(h, hipStreamSynchronize(c.stream));
-                fq = h->first_queue.emplace(batch, q).first;
+            // the first bounce's queue is computed, not stored (kernels.h rp_first_path_id); only the opt-in regrouping pass, whose
+            // kernels read a queue array, gets it written out (into the queue buffer the first bounce leaves unused)
+            const uint32_t first_count = (uint32_t)((size_t)batch * h->width * h->local_rows);
+            const uint32_t *first_ids = nullptr;
+            if (do_sort) {
+                hipLaunchKernelGGL(rp_k_first_queue, dim3(grid_for(h, first_count)), dim3(256), 0, c.stream, f, c.queue[0], first_count);
+                first_ids = c.queue[0];
             }
-            const uint32_t *first_ids = fq->second.ids;
-            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)fq->second.count, 1, c.stream));
+            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
             // the late bounces in one launch (kernels.h rp_k_tail); counting and the regrouping pass keep the stand-alone kernels
             int tail_from = h->params.max_path_depth;
             if (h->tail_mode != 0 && !count_traversal && !do_sort)
@@ -1846,6 +1879,9 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
     if (!h || !device_dst) return fail(h, RPTR_E_INVALID, "NULL argument");
     const size_t need = (size_t)h->width * h->local_rows * sizeof(float4);
     if (n_bytes < need) return fail(h, RPTR_E_INVALID, "destination too small: %zu < %zu", n_bytes, need);
+    if (h->output_overwritten)
+        return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame in flight on the same frame context: "
+                                       "read back before submitting that frame, or rptr_hip_wait for it first");
     HIP_TRY(h, hipSetDevice(h->device));
     // frames in flight: the image of the frame that was waited for last (its context keeps a copy)
     const float4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum;
@@ -1876,18 +1912,44 @@ static int readback_rows(rptr_hip *h, const T *dev_local, T *host_full, size_t n
 
 int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (h->output_overwritten)
+        return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame in flight on the same frame context: "
+                                       "read back before submitting that frame, or rptr_hip_wait for it first");
     return readback_rows<float4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum, reinterpret_cast<float4 *>(rgba),
                                  n_floats / 4);
 }
 int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
-    return readback_rows<uchar4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb : h->fb, reinterpret_cast<uchar4 *>(rgba),
-                                 n_bytes / 4);
+    if (h->output_overwritten)
+        return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame in flight on the same frame context: "
+                                       "read back before submitting that frame, or rptr_hip_wait for it first");
+    const uchar4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb : h->fb;
+    if (h->params.render_upscale_factor != 2) return readback_rows<uchar4>(h, src, reinterpret_cast<uchar4 *>(rgba), n_bytes / 4);
+    // render_upscale_factor == 2 (process_samples.comp:192-197): the frame buffer has twice the render resolution, every rendered
+    // pixel fills a 2x2 block. Replicated here, on the way out (rows of other ranks stay untouched, as in the 1:1 read-back).
+    const size_t W = (size_t)h->width, H = (size_t)h->height;
+    if (n_bytes / 4 < 4 * W * H) return fail(h, RPTR_E_INVALID, "read-back buffer too small for the 2x upscaled frame buffer");
+    std::vector<uchar4> lo(W * H);
+    const uchar4 *big = reinterpret_cast<const uchar4 *>(rgba);
+    for (size_t y = 0; y < H; ++y) // keep what the caller's buffer holds for rows this rank does not own
+        for (size_t x = 0; x < W; ++x) lo[y * W + x] = big[(2 * y) * (2 * W) + 2 * x];
+    int rc = readback_rows<uchar4>(h, src, lo.data(), lo.size());
+    if (rc) return rc;
+    uchar4 *out = reinterpret_cast<uchar4 *>(rgba);
+    for (size_t y = 0; y < H; ++y)
+        for (size_t x = 0; x < W; ++x) {
+            const uchar4 px = lo[y * W + x];
+            out[(2 * y) * (2 * W) + 2 * x] = out[(2 * y) * (2 * W) + 2 * x + 1] = out[(2 * y + 1) * (2 * W) + 2 * x] = out[(2 * y + 1) * (2 * W) + 2 * x + 1] = px;
+        }
+    return RPTR_OK;
 }
 
 int rptr_hip_readback_aov(rptr_hip_t *h, int aov_index, uint16_t *rgba16f, size_t n_halfs) {
     if (!h || !rgba16f) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (aov_index < 0 || aov_index >= 3) return fail(h, RPTR_E_INVALID, "AOV index %d (0 albedo+roughness, 1 normal+depth, 2 motion+jitter)", aov_index);
+    if (h->aov_overwritten)
+        return fail(h, RPTR_E_INVALID, "the AOV images of the last finished frame are being overwritten by a newer frame in flight on the same frame "
+                                       "context: read back before submitting that frame, or rptr_hip_wait for it first");
     const FrameCtx &c = h->ctx[(size_t)h->aov_ctx];
     if (!c.aov[aov_index]) return fail(h, RPTR_E_INVALID, "AOV images are switched off (RPTR_AOVS=0) or initialize() has not run");
     return readback_rows<uint2>(h, c.aov[aov_index], reinterpret_cast<uint2 *>(rgba16f), n_halfs / 4);
@@ -1959,10 +2021,10 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
 int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances,
                             size_t *n_instances, int32_t *out_stack_need) {
     if (!scene) return fail(nullptr, RPTR_E_INVALID, "NULL scene");
-    for (uint32_t p = 0; p < scene->num_parameterized_meshes; ++p)
-        if (scene->parameterized_meshes[p].mesh >= scene->num_meshes) return fail(nullptr, RPTR_E_INVALID, "parameterized mesh %u: bad mesh index", p);
-    for (uint32_t i = 0; i < scene->num_instances; ++i)
-        if (scene->instances[i].parameterized_mesh >= scene->num_parameterized_meshes) return fail(nullptr, RPTR_E_INVALID, "instance %u: bad mesh", i);
+    {
+        const std::string bad = validate_scene_tables(scene);
+        if (!bad.empty()) return fail(nullptr, RPTR_E_INVALID, "%s", bad.c_str());
+    }
     HostBvh B;
     build_host_bvh(scene, B);
     if (nodes && n_nodes && *n_nodes >= B.nodes.size()) memcpy(nodes, B.nodes.data(), B.nodes.size() * sizeof(RptrBvh4Node));

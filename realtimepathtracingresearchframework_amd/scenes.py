@@ -283,10 +283,11 @@ class Scene:
     def scene_params(self) -> abi.SceneParams:
         """≙ update_config + update_sky_light (render_vulkan.cpp:2954-2959, render_sky.cpp:25-72).
 
-        The Hosek-Wilkie fit needs the reference's data tables; the fitted
-        SkyModelParams/sun radiance for the synthetic configs are golden vectors
-        generated from the reference's own sky_model.cpp (tests/golden/sky_params.json,
-        script tests/golden/gen_sky_fixture.py)."""
+        The Hosek-Wilkie fit needs the model's published data tables (66 KB RGB + 514 KB spectral coefficients,
+        rendering/lights/sky_model_arhosek/sky_model_data_*.h), which this package does not carry: in a drop-in the
+        adapter calls the reference's own sky_model.cpp (INTEGRATION.md "update_config"), and the built-in scenes
+        take their fitted SkyModelParams / sun radiance from package data generated with that very code
+        (data/sky_params.json, written by tools/gen_sky_params.py)."""
         sky = load_sky_fixture(self.sky_key, has_lights=len(self.lights) > 0)
         sp = abi.SceneParams()
         for i in range(9):
@@ -303,7 +304,7 @@ _SKY_CACHE = None
 
 
 def sky_fixture_path():
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sky_params.json")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sky_params.json")
 
 
 def load_sky_fixture(key, has_lights):

@@ -66,6 +66,7 @@ def lib():
         L.orc_render_aovs.argtypes = [C.c_void_p, C.POINTER(OrcRenderArgs), C.c_void_p, C.POINTER(OrcRenderStats), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]
         L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+        L.orc_process_samples_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
         L.orc_texture_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_hw_threads.restype = C.c_int
@@ -206,6 +207,22 @@ class OracleScene:
 def resolve_u8(accum, exposure=0.0):
     out = np.zeros(accum.shape[:2] + (4,), dtype=np.uint8)
     lib().orc_resolve_u8(_p(np.ascontiguousarray(accum)), accum.shape[0] * accum.shape[1], exposure, _p(out))
+    return out
+
+
+def process_samples_u8(accum, params=None, cam_pos=(0.0, 0.0, 0.0), aovs=None):
+    """vulkan/process_samples.comp:134-198 on a resolved RGBA32F image: the RGBA8 frame buffer the reference would show for it
+    (exposure, early tone mapping, AOV views of `aovs` = [albedo_roughness, normal_depth, motion_jitter] float16 images, sRGB,
+    2x2 replication for render_upscale_factor 2)"""
+    params = params or abi.RenderParams.default()
+    h, w = accum.shape[:2]
+    up = 2 if params.render_upscale_factor == 2 else 1
+    out = np.zeros((up * h, up * w, 4), dtype=np.uint8)
+    cam = np.asarray(cam_pos, dtype=np.float32)
+    a = [np.ascontiguousarray(x).view(np.uint16) for x in aovs] if aovs is not None else [None] * 3
+    rc = lib().orc_process_samples_u8(_p(np.ascontiguousarray(accum, dtype=np.float32)), w, h, C.byref(params), _p(cam),
+                                      *[(_p(x) if x is not None else None) for x in a], _p(out))
+    assert rc == 0
     return out
 
 

@@ -1,0 +1,216 @@
+"""BASELINE.json configs[2] (C3) and configs[4] (C5) at FULL size against the oracle, the RGBA8 half of process_samples, and the
+flattened C4 tree against the oracle walking the very same tree.
+
+Sizes: C3 = grid_1m_lights (1 000 512 triangles, 512 of them emissive), glTF BSDF + binned-RIS NEE, 1920x1080, 8 spp;
+C5 = the 1 M-triangle height field as a dynamic mesh, 3840x2160, 2 spp, device-side vertex updates + refit per frame.
+The oracle renders bands of rows of the same full-size frames (same pixels, same seeds): RMSE < 1e-3 (north_star).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from common import RMSE_TOL, assert_ray_visit_parity, gpu_render, image_error, random_queries
+from realtimepathtracingresearchframework_amd import abi, backend, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------- C3
+def test_c3_full_size_gltf_area_lights_8spp():
+    s = scenes.grid_1m_lights()
+    assert s.num_tris() == 1_000_512 and len(s.lights) >= 512
+    W, H, spp = 1920, 1080, 8
+    a, sa, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
+    assert np.isfinite(a).all() and sa.spp == spp
+    # ray-count sanity: one primary ray per pixel sample, at most max_path_depth closest-hit queries per path, at most one shadow
+    # query per closest hit; the emitters matter (shadow rays towards them: more than the sun-only frame would issue)
+    n = W * H * spp
+    assert n <= sa.raw.rays_closest <= 9 * n and sa.raw.hits_shaded < sa.raw.rays_closest
+    assert 0 < sa.raw.rays_shadow <= sa.raw.hits_shaded
+    # every ray of a (small) frame of this scene walks the exported tree like the oracle: results and visit counts, ray by ray
+    osc = O.OracleScene(s)
+    assert_ray_visit_parity(r, osc, 96, 54, 1, abi.VARIANT_GLTF)
+    r.close()
+    # determinism (same seed needs a fresh handle: a reset on the same handle advances frame_offset)
+    b, sb, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.raw.rays_closest == sb.raw.rays_closest and sa.raw.rays_shadow == sb.raw.rays_shadow
+    # bands of rows of the full-size frame against the oracle: sky/horizon rows, the far field, the near field
+    osc.build_bvh()
+    for rows in ((300, 304), (560, 564), (900, 904)):
+        ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, rows=rows)
+        rmse, same, maxabs = image_error(a[rows[0]:rows[1]], ref[rows[0]:rows[1]])
+        assert same and rmse < RMSE_TOL, (rows, rmse, maxabs)
+        assert np.array_equal(a[rows[0]:rows[1], :, 3], ref[rows[0]:rows[1], :, 3])
+
+
+# ---------------------------------------------------------------- C5
+def _device_buffer(xyz):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32)).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+def test_c5_full_size_animated_4k_refit_per_frame():
+    NX, NZ = 1000, 500
+    s = scenes.grid(NX, NZ, deform_t=0.0, name="grid-1M-dynamic")
+    assert s.num_tris() == 1_000_000
+    W, H, spp = 3840, 2160, 2
+    times = [1 / 60, 2 / 60, 3 / 60, 0.4]
+    bufs = [_device_buffer(scenes.grid_positions(NX, NZ, t)) for t in times]
+    cam = s.camera_params()
+
+    def run(fif):
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(s)
+        images, queue = [], []
+
+        def collect():
+            st = r.wait(queue.pop(0))
+            assert st.spp == spp
+            img = np.zeros((H, W, 4), np.float32)
+            assert r.readback_framebuffer(img) == W * H * 4
+            images.append(img)
+        for k, buf in enumerate(bufs):
+            r.update_vertices_device(0, buf.data_ptr(), buf.shape[0])
+            r.refit()
+            cfg = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
+            queue.append(r.render_async(cfg, spp=spp))
+            if len(queue) >= fif:
+                collect()
+        while queue:
+            collect()
+        return r, images
+
+    r1, one = run(1)
+    # refit-then-trace == oracle rebuild-then-trace, on the geometry of the last frame
+    osc = O.OracleScene(s)
+    osc.set_dynamic_vertices(0, scenes.grid_positions(NX, NZ, times[-1]))
+    osc.build_bvh()
+    q = random_queries(np.random.default_rng(21), 1 << 17, -60, 60)
+    q[:, 1] = np.abs(q[:, 1]) * 0.2 + 3.0
+    q[:, 5] = -np.abs(q[:, 5])
+    res = r1.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_OWN, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).mean() > 0.3
+    r1.close()
+    # band of the last full-size frame against the oracle: the 4th reset of this handle -> frame_offset = 3 frames x 2 samples
+    last = one[-1]
+    assert np.isfinite(last).all()
+    for rows in ((1100, 1104), (1800, 1804)):
+        ref_img, _ = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE, rows=rows, frame_offset=(len(times) - 1) * spp)
+        rmse, same, maxabs = image_error(last[rows[0]:rows[1]], ref_img[rows[0]:rows[1]])
+        assert same and rmse < RMSE_TOL, (rows, rmse, maxabs)
+    # frames in flight == one frame at a time, every frame, bit for bit
+    r3, three = run(3)
+    r3.close()
+    assert len(three) == len(one) == len(times)
+    for x, y in zip(three, one):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert not np.array_equal(one[-1], one[-2])    # the surface moved between the frames
+
+
+# ---------------------------------------------------------------- a18: the RGBA8 frame buffer against process_samples.comp
+def _u8_close(got, want):
+    """RGBA8 values agree up to one code in a few pixels: powf of the device vs libm at a rounding boundary"""
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    return int(d.max()) <= 1 and float((d > 0).mean()) < 2e-3
+
+
+@pytest.mark.parametrize("exposure,tonemap", [(0.0, -1), (1.5, -1), (-2.0, 0), (0.5, 1), (2.0, 2)])
+def test_rgba8_framebuffer_matches_process_samples(exposure, tonemap):
+    s = scenes.grid(120, 60, with_emitters=True)
+    W, H = 240, 136
+    params = abi.RenderParams.default()
+    params.exposure = exposure
+    params.early_tone_mapping_mode = tonemap
+    img, _, r = gpu_render(s, W, H, 3, abi.VARIANT_GLTF, params=params, keep=True)
+    u8 = np.zeros((H, W, 4), np.uint8)
+    assert r.readback_framebuffer(u8) == W * H * 4
+    r.close()
+    want = O.process_samples_u8(img, params)
+    assert _u8_close(u8, want)
+    assert u8[..., :3].std() > 5                      # an image, not a constant
+    if exposure == 0.0 and tonemap < 0:
+        assert np.array_equal(want, O.resolve_u8(img, 0.0))
+    # ... and against the oracle's own frame (float parity carries over to the 8-bit view up to one code at boundaries)
+    ref, _ = O.OracleScene(s).render(W, H, 3, variant=abi.VARIANT_GLTF)
+    ref_u8 = O.process_samples_u8(ref, params)
+    d = np.abs(u8.astype(np.int16) - ref_u8.astype(np.int16))
+    assert d.max() <= 2 and (d > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("channel,moment", [(1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (3, 1)])
+def test_rgba8_output_channel_views(channel, moment):
+    """OUTPUT_CHANNEL_ALBEDO_ROUGHNESS / NORMAL_DEPTH / MOTION_JITTER (process_samples.comp:150-178): the frame buffer shows the AOV
+    images; exposure does not apply to them (:143-144)"""
+    s = scenes.textured_test()
+    W, H = 160, 120
+    params = abi.RenderParams.default()
+    params.output_channel, params.output_moment, params.exposure = channel, moment, 1.0
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    r.params = params
+    cam0 = s.camera_params()
+    cam1 = s.camera_params()
+    cam1.pos[0] += 0.2                           # a moving camera: motion vectors are not all zero
+    for cam, reset in ((cam0, True), (cam1, True)):
+        r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=reset), spp=1)
+    img = np.zeros((H, W, 4), np.float32)
+    u8 = np.zeros((H, W, 4), np.uint8)
+    assert r.readback_framebuffer(img) and r.readback_framebuffer(u8)
+    aovs = [np.zeros((H, W, 4), np.float16) for _ in range(3)]
+    for k in range(3):
+        assert r.readback_aov(k, aovs[k]) == W * H * 4
+    r.close()
+    want = O.process_samples_u8(img, params, cam_pos=tuple(cam1.pos), aovs=aovs)
+    assert _u8_close(u8, want)
+    assert u8[..., :3].std() > 2
+
+
+def test_rgba8_upscale_factor_2_replicates_pixels():
+    s = scenes.cornell32()
+    W, H = 96, 64
+    params = abi.RenderParams.default()
+    params.render_upscale_factor = 2
+    img, _, r = gpu_render(s, W, H, 2, abi.VARIANT_GLTF, params=params, keep=True)
+    big = np.zeros((2 * H, 2 * W, 4), np.uint8)
+    assert r.readback_framebuffer(big) == W * H * 4          # element count of the RENDER resolution (get_framebuffer_size)
+    with pytest.raises(backend.BackendError):
+        r._check(r._L.rptr_hip_readback_u8(r._h, big.ctypes.data, W * H * 4))   # too small for the upscaled frame buffer
+    r.close()
+    assert _u8_close(big, O.process_samples_u8(img, params))
+    assert np.array_equal(big[0::2, 0::2], big[1::2, 1::2])
+
+
+# ---------------------------------------------------------------- read-backs and frames in flight
+def test_readback_after_resubmitting_on_the_same_context_is_an_error():
+    """wait(t0) -> render_async (reuses t0's context) -> read-back: the image of t0 is being overwritten; the call fails instead of
+    returning a torn image. Reading back BEFORE the submission, or after waiting for the newer frame, works."""
+    s = scenes.cornell32()
+    W = H = 64
+    r = backend.RenderHip(frames_in_flight=2)
+    r.initialize(W, H)
+    r.set_scene(s)
+    cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    t0 = r.render_async(cfg, spp=1)
+    t1 = r.render_async(cfg, spp=1)
+    r.wait(t0)
+    first = np.zeros((H, W, 4), np.float32)
+    assert r.readback_framebuffer(first) == W * H * 4           # fine: nothing newer on t0's context yet
+    t2 = r.render_async(cfg, spp=1)                              # lands on t0's context
+    buf = np.zeros((H, W, 4), np.float32)
+    with pytest.raises(backend.BackendError):
+        r.readback_framebuffer(buf)
+    with pytest.raises(backend.BackendError):
+        r.readback_aov(0, np.zeros((H, W, 4), np.float16))
+    r.wait(t1)
+    assert r.readback_framebuffer(buf) == W * H * 4             # t1's image: its context is untouched
+    r.wait(t2)
+    assert r.readback_framebuffer(buf) == W * H * 4
+    assert not np.array_equal(buf, first)                       # three resets, three seeds
+    r.close()

@@ -1,16 +1,16 @@
-"""Generates tests/golden/sky_params.json from the reference's own Hosek-Wilkie
+"""Generates realtimepathtracingresearchframework_amd/data/sky_params.json (package data: the fitted sky of the built-in scenes) from the reference's own Hosek-Wilkie
 fit (rendering/lights/sky_model_arhosek/sky_model.cpp compiled unmodified into
 oracle/_ref/libsky_ref.so; driver oracle/ref_sky_driver.cpp restates
 vulkan/render_sky.cpp:25-72). Run in the build container only:
 
-    make -C oracle ref && python tests/golden/gen_sky_fixture.py
+    make -C oracle ref && python tools/gen_sky_params.py
 """
 import ctypes as C
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from realtimepathtracingresearchframework_amd.scenes import SKY_CONFIGS  # noqa: E402
 
@@ -49,9 +49,9 @@ def main():
                          theta.ctypes.data, theta.ctypes.data, len(theta), out.ctypes.data)
     entries["default"]["eval_cos_theta"] = [float(x) for x in cos_t]
     entries["default"]["eval_rgb_times_100"] = [[float(v) for v in row] for row in out]
-    doc = {"generator": "tests/golden/gen_sky_fixture.py", "source": "oracle/_ref/libsky_ref.so <- reference sky_model.cpp + render_sky.cpp:25-72",
+    doc = {"generator": "tools/gen_sky_params.py", "source": "oracle/_ref/libsky_ref.so <- reference sky_model.cpp + render_sky.cpp:25-72",
            "entries": entries}
-    with open(os.path.join(ROOT, "tests", "golden", "sky_params.json"), "w") as f:
+    with open(os.path.join(ROOT, "realtimepathtracingresearchframework_amd", "data", "sky_params.json"), "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote", len(entries), "entries")
 
