@@ -350,6 +350,37 @@ int rptr_hip_tile_rows(const rptr_hip_t *h, int rank, int32_t *first_and_count, 
 int rptr_hip_local_pixel_count(const rptr_hip_t *h, uint64_t *out_pixels);
 int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes);
 
+/* ---- multi-GPU: the path's ONE collective, a gather of tile radiance to rank 0 over RCCL / xGMI (north_star; the
+ * reference itself is single-GPU: vulkan/render_vulkan_extensions.cpp:77-82 picks one physical device). One communicator rank per
+ * handle (RptrCreateInfo.rank / world_size). RCCL is loaded at run time (librccl.so.1, the copy already in the process if there is
+ * one), so the library has no link-time dependency on it and single-GPU hosts never touch it.
+ *
+ *   one process per GPU:   rank 0: rptr_hip_comm_get_unique_id -> hand the 128 bytes to every rank (file, pipe, MPI, torch.distributed)
+ *                          every rank: rptr_hip_comm_init_rank(h, id)            (collective: returns when all ranks have joined)
+ *                          per frame:  rptr_hip_wait(h, ticket, ..); rptr_hip_gather(h);
+ *   one process, n GPUs:   rptr_hip_comm_init_all(handles, n)                    (handles[i] must have rank i, world_size n)
+ *                          per frame:  wait every handle's frame; rptr_hip_gather_all(handles, n);
+ *
+ * rptr_hip_gather sends the packed rows of the frame that was waited for last (the context's image itself: no staging copy) and, on
+ * rank 0, receives every other rank's rows and assembles the full frame with one kernel. It is asynchronous: everything runs on
+ * a communication stream of its own, ordered behind the waited frame; the next frame that reuses the sending frame context waits
+ * for the send on the device, nothing else does -- with frames in flight the gather of frame i overlaps the rendering of frames
+ * i+1.. . The assembled frame (rank 0) is read with rptr_hip_readback_gathered_f32 (which waits for the last gather) or used in
+ * place through rptr_hip_gathered_frame (valid once the communication stream has been synchronised / an event recorded by the
+ * caller after rptr_hip_gather_done_event). Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
+ * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. */
+#define RPTR_COMM_ID_BYTES 128
+int rptr_hip_comm_get_unique_id(void *out_id128);
+int rptr_hip_comm_init_rank(rptr_hip_t *h, const void *id128);
+int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n);
+int rptr_hip_comm_destroy(rptr_hip_t *h);
+int rptr_hip_gather(rptr_hip_t *h);
+int rptr_hip_gather_all(rptr_hip_t *const *handles, int n);
+int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f);
+int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats);
+/* gathers issued so far, and the mean GPU time of the completed ones on this rank's communication stream (send / receive + assembly) */
+int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_gather_ms);
+
 /* ---- enable_ray_queries / render_ray_queries with the RQ_CLOSEST kernel
  * (render_backend.h:101-102, vulkan/rt_intersect.comp:31-68): n queries ->
  * n x float4 (bary.x, bary.y, bits(instance_custom_index + geometry_index),

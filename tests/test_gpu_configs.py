@@ -95,7 +95,7 @@ def test_c5_full_size_animated_4k_refit_per_frame():
     res = r1.render_ray_queries(q)
     ref = np.zeros_like(res)
     osc.trace(q, bvh_mode=O.BVH_OWN, out=ref)
-    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).mean() > 0.3
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).mean() > 0.2
     r1.close()
     # band of the last full-size frame against the oracle: the 4th reset of this handle -> frame_offset = 3 frames x 2 samples
     last = one[-1]
