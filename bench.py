@@ -4,19 +4,26 @@ tracer on BASELINE.json configs[1]: procedural 1M-triangle mesh, 1920x1080,
 4 spp, diffuse-only BSDF, sun + sky.
 
 One "step" = one frame = 4 samples per pixel through the whole hot path
-(raygen -> {extend, [sort], shade, connect} x max_path_depth -> resolve), with the
-scene resident in HBM. For --gpus N the frame is sharded by 32-row screen
-stripes (stripe s -> rank s % N, no data-path collective while rendering) and
-the tile radiance is gathered to rank 0 over RCCL at the end of every step
-(inside the timed region). Strong scaling: the frame is fixed, N GPUs share it.
+({extend, [sort], shade, connect} x bounces -> tail -> resolve), with the scene
+resident in HBM. For --gpus N the frame is sharded by screen stripes (stripe s ->
+rank s % N, no data-path collective while rendering) and the tile radiance is
+gathered to rank 0 over RCCL at the end of every step (inside the timed region;
+the library's own grouped ncclSend/ncclRecv on a communication stream, csrc/host_comm.h).
+Strong scaling: the frame is fixed, N GPUs share it.
+
+`python bench.py --gpus N` without a torch.distributed.run environment starts the
+N ranks itself (re-executes under `python -m torch.distributed.run`).
 
 Rank 0 prints ONE JSON line (contract in the task description) carrying
-`roofline` (dominant kernel = closest-hit traversal `rp_k_extend`) and, at N=1,
-`cpu_baseline` (the CPU oracle timed on the same frame on all host cores).
+`roofline` (dominant kernel = closest-hit traversal `rp_k_extend`; DESIGN.md section 6
+says what each figure is) and, at N=1, `cpu_baseline` (the CPU oracle timed on the
+same frame on the host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,16 +32,19 @@ sys.path.insert(0, ROOT)
 # One hardware queue per HIP stream: every frame context of the backend owns a stream, and two streams that share a hardware
 # queue serialise (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 queues by default; measured: 7 contexts on 4 queues
 # 0.34 ms per 1/8 frame, on 8 queues 0.29 ms; 11 contexts on 16 queues 0.25 ms). Read by the runtime when it initialises, so it is set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 11 frame contexts + the caller's stream + RCCL's
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 11 frame contexts + the caller's stream + the communication stream + RCCL's
 
 # record sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
 HIT_BYTES = 24      # hit_tuv (float4) + hit_ids (int2) written per closest query
-QUEUE_BYTES = 4     # path id read from the ray queue
+QUEUE_BYTES = 4     # path id read from the ray queue (not for the first bounce: its queue is computed)
 NODE_BYTES = 64     # RptrBvh4Node (an instance record, 128 B, counts as two)
 TRI_BYTES = 48      # RptrBvhTri
 SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-write for a visible shadow ray
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PATH_READ_BYTES, PATH_WRITE_BYTES = 72, 80    # shade: path state in (ray_o, ray_d, thr, illum, rng_tt; not on the first bounce) / out per vertex
+VERTEX_BYTES, MATERIAL_BYTES = 48, 80         # 3 x (qpos + qnrm_uv), RptrBaseMaterial
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md "HBM")
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2 (per XCD)"): the ceiling of bytes served by the cache hierarchy
 
 
 def parse_args():
@@ -65,11 +75,28 @@ def parse_args():
                          "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic (single GPU): render only rank 0's stripes of an N-rank tile split, no gather")
+    ap.add_argument("--gather", type=str, default="native", choices=["native", "torch"],
+                    help="native: the library's RCCL gather (csrc/host_comm.h; falls back to torch when the communicator cannot be made, "
+                         "noted in the JSON line); torch: tile copy + torch.distributed.gather + index_select")
     ap.add_argument("--dist-backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test rig for the N>1 control flow on a box with fewer GPUs than ranks (tiles are staged through the host)")
     ap.add_argument("--same-device", action="store_true", help="test rig: every rank renders on cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-pass", action="store_true",
+                    help="for rocprofv3 --pmc / --kernel-trace passes (tools/pmc.sh): warm-up + `steps` frames one at a time, nothing else, no JSON line")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a torch.distributed.run launch: start the N ranks (one process per GPU) and pass their
+    output through. The children see WORLD_SIZE and take the normal path."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
 def host_cpu_budget(hw_threads):
@@ -84,18 +111,36 @@ def host_cpu_budget(hw_threads):
     return max(1, hw_threads)
 
 
+def load_pmc_traffic():
+    """profiles/pmc_traffic.json: HBM-side bytes per launch of every kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of the default workload (tools/pmc.sh + tools/make_traffic.py). None when absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None
+
+
+def traffic_of(pmc, prefix):
+    """bytes per launch of the kernel whose (template) name starts with `prefix`, averaged over its launches"""
+    if not pmc:
+        return None
+    hit = [v for k, v in pmc.get("kernels", {}).items() if k.replace("void ", "").startswith(prefix)]
+    n = sum(v["launches"] for v in hit)
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n if n else None
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
     from realtimepathtracingresearchframework_amd import abi, backend, scenes
-    from realtimepathtracingresearchframework_amd.distributed import TileGather
+    from realtimepathtracingresearchframework_amd.distributed import NativeGather, TileGather
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -117,9 +162,8 @@ def main():
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
 
-    # one explicit stream for torch AND the backend: the tile copy, the gather and the animation kernel are ordered with the
-    # frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream":
-    # the tile copy would then run unordered with the gather.)
+    # one explicit stream for torch AND the backend: the animation kernel, the tile copy and torch's gather (--gather torch) are ordered
+    # with the frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream".)
     flatten = args.flatten if args.flatten >= 0 else (1 if args.scene == "forest" else 0)
     os.environ["RPTR_FLATTEN"] = str(flatten)
     torch_stream = torch.cuda.Stream()
@@ -136,10 +180,32 @@ def main():
     r.set_scene(scene)
     t_build = time.time() - t0
     cam = scene.camera_params()
+
+    # ---- the gather (N > 1): the library's own RCCL path, or torch.distributed as plumbing
     on_host = world > 1 and args.dist_backend == "gloo"
-    gather = TileGather(W, H, args.stripe_rows, rank, world, device="cpu" if on_host else "cuda")
-    stage = torch.zeros_like(gather.tile, device="cuda") if on_host else None  # gloo rig: device tile -> host tile
+    gather_mode, gather_note, native, tgather, stage = None, None, None, None, None
+    if world > 1:
+        gather_mode = "native" if (args.gather == "native" and not on_host and not args.same_device) else "torch"
+        if gather_mode == "native":
+            ok = 1
+            try:
+                native = NativeGather(r, rank, world)
+            except Exception as e:  # every rank must take the same path: agree on it
+                ok, gather_note = 0, "native RCCL communicator failed (%s): torch.distributed gather used instead" % (str(e)[:200],)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                gather_mode, native = "torch", None
+                gather_note = gather_note or "native RCCL communicator failed on another rank: torch.distributed gather used instead"
+                try:
+                    r.comm_destroy()
+                except Exception:
+                    pass
+        if gather_mode == "torch":
+            tgather = TileGather(W, H, args.stripe_rows, rank, world, device="cpu" if on_host else "cuda")
+            stage = torch.zeros_like(tgather.tile, device="cuda") if on_host else None  # gloo rig: device tile -> host tile
     my_bytes = r.local_pixel_count() * 16
+    host_gather_s = [0.0]
 
     anim = None
     if args.animate:
@@ -162,18 +228,24 @@ def main():
         anim["ev"].append((e0, e1))
 
     def finish(ticket):
-        """collect one queued frame; N > 1: the path's one collective, tile radiance -> rank 0"""
+        """collect one queued frame; N > 1: the path's one collective, tile radiance -> rank 0. Asynchronous on the device: it runs
+        behind the collected frame, beside the frames still in flight."""
         st = r.wait(ticket)
         if world > 1:
-            if my_bytes:
-                r.copy_tile_to_device((stage if on_host else gather.tile).data_ptr(), my_bytes)
-            if on_host:
-                gather.tile.copy_(stage)  # synchronising device-to-host copy on the current stream
-            gather.gather()
+            t_g = time.perf_counter()
+            if native is not None:
+                native.gather()
+            else:
+                if my_bytes:
+                    r.copy_tile_to_device((stage if on_host else tgather.tile).data_ptr(), my_bytes)
+                if on_host:
+                    tgather.tile.copy_(stage)  # synchronising device-to-host copy on the current stream
+                tgather.gather()
+            host_gather_s[0] += time.perf_counter() - t_g
         return st
 
     def step(count=False):
-        """one synchronous frame (warm-up and the instrumented pass)"""
+        """one synchronous frame (warm-up and the instrumented passes)"""
         if anim is not None:
             animate()
         cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
@@ -193,44 +265,56 @@ def main():
         while queue:
             on_stats(finish(queue.pop(0)))
 
+    if args.profile_pass:  # what a rocprofv3 pass should see: identical frames, one at a time, no instrumented variants
+        r.set_stage_timing(0)
+        for _ in range(max(1, args.warmup) + args.steps):
+            step()
+        torch.cuda.synchronize()
+        return
+
     r.set_stage_timing(int(os.environ.get("BENCH_STAGE_TIMING", "1")))  # timed region: HIP events around every closest-hit traversal launch (the roofline kernel) only
     for _ in range(args.warmup):
         step()
     if anim is not None:
         anim["ev"].clear()
+    host_gather_s[0] = 0.0
+    gathers_before = native.stats()[0] if native is not None else 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
-    acc = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0, rays=0, launches=0)
+    acc = dict(ext=0.0, rays=0, launches=0)
 
     def on_stats(st):
         acc["launches"] = int(st.raw.launches_extend)  # stand-alone closest-hit launches per frame (the rest runs in the tail kernel)
         acc["ext"] += st.raw.extend_time_ms
-        acc["con"] += st.raw.connect_time_ms
-        acc["other"] += st.raw.shade_time_ms
-        acc["gpu"] += st.raw.render_time_ms
         acc["rays"] += st.raw.rays_closest + st.raw.rays_shadow
 
     timed_steps(args.steps, on_stats)
-    ext_ms, con_ms, other_ms, gpu_ms, rays = acc["ext"], acc["con"], acc["other"], acc["gpu"], acc["rays"]
+    ext_ms, rays = acc["ext"], acc["rays"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_begin
     refit_ms = sum(a.elapsed_time(b) for a, b in anim["ev"]) / max(len(anim["ev"]), 1) if anim is not None else None
+    gather_host_ms = host_gather_s[0] * 1e3 / args.steps
+    gather_gpu_ms = native.stats()[1] if native is not None else None
 
-    # untimed, one frame at a time: (1) events around every stage -> the stage split without overlap between frames,
-    # (2) one instrumented step: node / triangle visits of this rank's queries (counted, not modelled)
+    # untimed, one frame at a time: (1) events around every stage -> EXCLUSIVE launch durations (no other frame on the GPU): what the
+    # roofline figures use; (2) instrumented frames: node / triangle visits of this rank's queries (counted, not modelled)
     r.set_stage_timing(2)
-    serial = dict(ext=0.0, con=0.0, other=0.0, gpu=0.0)
+    serial = dict(ext=0.0, con=0.0, shade=0.0, tail=0.0, resolve=0.0, other=0.0, gpu=0.0)
     n_serial = max(3, min(10, args.steps))
     for _ in range(n_serial):
         st = step().raw
         serial["ext"] += st.extend_time_ms / n_serial
         serial["con"] += st.connect_time_ms / n_serial
-        serial["other"] += st.shade_time_ms / n_serial
+        serial["shade"] += st.shade_only_time_ms / n_serial
+        serial["tail"] += st.tail_time_ms / n_serial
+        serial["resolve"] += st.resolve_time_ms / n_serial
+        serial["other"] += (st.shade_time_ms - st.shade_only_time_ms - st.tail_time_ms - st.resolve_time_ms) / n_serial
         serial["gpu"] += st.render_time_ms / n_serial
+
     def counted(depth=None):
         """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
         full = r.params.max_path_depth
@@ -258,9 +342,13 @@ def main():
 
     if world > 1:
         rdev = "cpu" if on_host else "cuda"
-        t = torch.tensor([elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"]], dtype=torch.float64, device=rdev)
+        t = torch.tensor([elapsed, ext_ms, gather_host_ms] + [serial[k] for k in ("ext", "con", "shade", "tail", "resolve", "other", "gpu")],
+                         dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ext_ms, serial["ext"], serial["con"], serial["other"], serial["gpu"] = (float(v) for v in t)
+        vals = [float(v) for v in t]
+        elapsed, ext_ms, gather_host_ms = vals[:3]
+        for k, v in zip(("ext", "con", "shade", "tail", "resolve", "other", "gpu"), vals[3:]):
+            serial[k] = v
         tr = torch.tensor([float(rays)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         rays = int(tr[0])
@@ -272,46 +360,80 @@ def main():
     K = args.steps
     ms_per_step = elapsed * 1e3 / K
     mrays = rays / elapsed / 1e6
-    # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share
-    primary = r.local_pixel_count() * spp  # the first launch computes its camera rays instead of reading them
-    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * RAY_BYTES + cnt_ext["nodes_closest"] * NODE_BYTES
+    # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share.
+    # All durations below are EXCLUSIVE: HIP events on the dispatch packets of frames rendered one at a time (nothing else on the GPU).
+    primary = r.local_pixel_count() * spp  # the first launch computes its camera rays and its queue instead of reading them
+    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * (RAY_BYTES + QUEUE_BYTES) + cnt_ext["nodes_closest"] * NODE_BYTES
                  + cnt_ext["tris_closest"] * TRI_BYTES)
     con_bytes = (cnt_con["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt_con["nodes_shadow"] * NODE_BYTES
                  + cnt_con["tris_shadow"] * TRI_BYTES)
-    ext_ms_step = ext_ms / K  # HIP events in the timed region; with frames in flight the launches of different frames overlap
-    achieved = ext_bytes / (ext_ms_step * 1e-3) / 1e9 if ext_ms_step > 0 else 0.0
-    achieved_serial = ext_bytes / (serial["ext"] * 1e-3) / 1e9 if serial["ext"] > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    # the committed PMC passes were taken on the default workload (configs[1], one GPU): no figure for anything else
+    shade_vertices = cnt_ext["rays_closest"]       # one shade invocation per closest-hit query of the stand-alone bounces
+    shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES)
+                   + cnt_ext["hits"] * (VERTEX_BYTES + MATERIAL_BYTES))
     default_workload = (args.scene == "grid" and args.grid == "1000x500" and args.variant == "diffuse" and not args.lights and not args.animate
                         and (W, H, spp) == (1920, 1080, 4) and world == 1 and args.emulate_world <= 1)
-    if default_workload and os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("rp_k_extend_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    pmc = load_pmc_traffic() if default_workload else None   # the committed PMC passes were taken on the default workload: no figure for anything else
+    n_launch = max(launches_extend, 1)
+
+    def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches):
+        """one kernel class: exclusive time, algorithmic bytes and their rate against the cache-hierarchy ceiling, counter traffic
+        and its rate against the HBM peak"""
+        tr = None
+        if pmc:
+            parts = [traffic_of(pmc, p) for p in prefix_list]
+            if all(v is not None for v in parts):
+                tr = sum(parts) / len(parts)       # mean bytes per launch over the listed instantiations (one launch each per frame)
+        launch_ms = ms_step / max(launches, 1)
+        e = {"kernel": name, "launches_per_step": launches, "launch_ms": round(launch_ms, 5), "exclusive_ms_per_step": round(ms_step, 4),
+             "algorithmic_bytes_per_launch": int(alg_bytes_step // max(launches, 1)),
+             "algorithmic_gbs": round(alg_bytes_step / (ms_step * 1e-3) / 1e9, 1) if ms_step > 0 else 0.0}
+        e["algorithmic_frac"] = round(e["algorithmic_gbs"] / L2_PEAK_GBS, 4)
+        e["hbm_bytes_per_launch"] = int(tr) if tr is not None else None
+        e["hbm_gbs"] = round(tr / (launch_ms * 1e-3) / 1e9, 1) if (tr is not None and launch_ms > 0) else None
+        e["hbm_frac"] = round(e["hbm_gbs"] / HBM_PEAK_GBS, 4) if e["hbm_gbs"] is not None else None
+        return e
+
+    single = len(scene.instances) == 1
+    sfx = ", false, %s>" % ("true" if single else "false")
+    var_id = "1" if variant == abi.VARIANT_SIMPLE else "0"
+    k_ext = kernel_entry("rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE=%s>: first bounce FIRST=true, later bounces FIRST=false" % str(single).lower(),
+                         ["rp_k_extend<false, true" + sfx, "rp_k_extend<false, false" + sfx][:n_launch], ext_bytes, serial["ext"], launches_extend)
+    k_con = kernel_entry("rp_k_connect<COUNT=false, ALPHA=false, SINGLE=%s>" % str(single).lower(), ["rp_k_connect<false" + sfx], con_bytes, serial["con"], launches_extend)
+    k_shade = kernel_entry("rp_k_shade<VARIANT=%s, FIRST, LIGHTS, TEX>" % var_id, ["rp_k_shade<%s, true" % var_id, "rp_k_shade<%s, false" % var_id][:n_launch],
+                           shade_bytes, serial["shade"], launches_extend)
+    hbm_known = k_ext["hbm_gbs"] is not None
+    fetches = cnt_ext["nodes_closest"] + cnt_ext["tris_closest"]
     roofline = {
-        "bound": "hbm", "kernel": "rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE> (first bounce: FIRST=true, later bounces: FIRST=false; SINGLE=true for scenes with one instance)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per "
-                          "launch averaged over the stand-alone closest-hit launches of a frame" if traffic is not None else None,
-        "algorithmic_bytes_per_launch": int(ext_bytes // max(launches_extend, 1)),
-        "launch_ms": round(ext_ms_step / max(launches_extend, 1), 5), "launches_per_step": launches_extend,
-        "note": "achieved/launch_ms: HIP events over the timed region (%d frames in flight: launches of neighbouring frames share the GPU); "
-                "one_frame_at_a_time: the same kernel with no other frame on the GPU" % fif,
-        "one_frame_at_a_time": {"achieved": round(achieved_serial, 2), "frac": round(achieved_serial / HBM_PEAK_GBS, 5),
-                                "launch_ms": round(serial["ext"] / max(launches_extend, 1), 5), "frames": n_serial,
-                                "stage_ms_per_step": {"extend": round(serial["ext"], 4), "connect": round(serial["con"], 4),
-                                                      "raygen_sort_shade_resolve": round(serial["other"], 4),
-                                                      "gpu_total": round(serial["gpu"], 4)},
-                                "connect": {"kernel": "rp_k_connect<COUNT=false, ALPHA=false, SINGLE>",
-                                            "achieved": round(con_bytes / (serial["con"] * 1e-3) / 1e9, 2) if serial["con"] > 0 else 0.0,
-                                            "algorithmic_bytes_per_step": int(con_bytes)}},
+        # contract fields. The kernel is a dependent-gather kernel whose working set (tree + triangles, tens of MB) is served by L2 /
+        # Infinity Cache: `achieved` / `frac` are what it really moves over the HBM-side fabric (PMC counters), `algorithmic_*` what its
+        # lanes consume, held against the cache hierarchy's bandwidth. Neither bounds it: latency x divergence and VALU issue do
+        # (DESIGN.md section 6, profiles/r02_notes.md).
+        "bound": "hbm", "kernel": k_ext["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "achieved": k_ext["hbm_gbs"] if hbm_known else None, "frac": k_ext["hbm_frac"] if hbm_known else None,
+        "traffic": k_ext["hbm_bytes_per_launch"],
+        "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per launch "
+                           "averaged over the stand-alone closest-hit launches of a frame; gfx950 correction 2 x FETCH_SIZE") if hbm_known else None,
+        "hbm_frac": k_ext["hbm_frac"], "algorithmic_frac": k_ext["algorithmic_frac"],
+        "algorithmic_bytes_per_launch": k_ext["algorithmic_bytes_per_launch"], "algorithmic_gbs": k_ext["algorithmic_gbs"],
+        "algorithmic_ceiling": {"gbs": L2_PEAK_GBS, "what": "aggregate L2 bandwidth, MI355X_MICROARCH.md 'L2 (per XCD)': the tree is cache resident, so the bytes the "
+                                                            "lanes consume are bounded by the cache hierarchy, not by HBM"},
+        "launch_ms": k_ext["launch_ms"], "launches_per_step": launches_extend, "exclusive_ms_per_step": k_ext["exclusive_ms_per_step"],
+        "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region (no other frame on the GPU); "
+                  "sum of all stages = stage_ms_per_step.gpu_total" % n_serial,
+        "node_and_triangle_fetches_per_s": round(fetches / (serial["ext"] * 1e-3)) if serial["ext"] > 0 else None,
+        "gather_reference": "tools/microbench/gather64.hip: fully divergent dependent 64-byte lane fetches run at 220 G/s (L1 resident), 120 G/s (32 MB), "
+                            "62 G/s (256 MB) chip-wide; traversal fetches of neighbouring rays partly coincide, so this is a reference point, not a ceiling",
+        "kernels": {"rp_k_extend": k_ext, "rp_k_connect": k_con, "rp_k_shade": k_shade},
+        "stage_ms_per_step": {"extend": round(serial["ext"], 4), "connect": round(serial["con"], 4), "shade": round(serial["shade"], 4),
+                              "tail": round(serial["tail"], 4), "resolve": round(serial["resolve"], 4), "other": round(serial["other"], 4),
+                              "gpu_total": round(serial["gpu"], 4)},
+        "pipelined": {"frames_in_flight": fif, "ms_per_step": round(ms_per_step, 4),
+                      "extend_launch_ms_overlapped": round(ext_ms / K / n_launch, 5),
+                      "note": "launches of neighbouring frames share the GPU in the timed region: their durations overlap and are NOT exclusive (their sum may "
+                              "exceed ms_per_step); they are reported for the rocprofv3 cross-check only (profiles/, same command)"},
         "counts_per_step": cnt,
         "tail": {"from_bounce": launches_extend, "max_path_depth": max_depth,
-                 "note": "bounces >= from_bounce run in one rp_k_tail launch per frame (its time is part of raygen_sort_shade_resolve); the "
-                         "roofline figures cover the stand-alone launches of bounces < from_bounce",
+                 "note": "bounces >= from_bounce run in one rp_k_tail launch per frame; the kernel figures cover the stand-alone launches of bounces < from_bounce",
                  "standalone_counts": {"rays_closest": cnt_ext["rays_closest"], "nodes_closest": cnt_ext["nodes_closest"],
                                        "tris_closest": cnt_ext["tris_closest"], "rays_shadow": cnt_con["rays_shadow"],
                                        "nodes_shadow": cnt_con["nodes_shadow"], "tris_shadow": cnt_con["tris_shadow"]}} if launches_extend < max_depth else None,
@@ -338,8 +460,16 @@ def main():
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,
     }
+    if world > 1:
+        out["gather"] = {"mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h)",
+                                  "torch": "tile copy + torch.distributed.gather + index_select"}[gather_mode],
+                         "gather_ms": round(gather_gpu_ms, 4) if gather_gpu_ms is not None else None,
+                         "gather_ms_note": "mean GPU time of one gather on rank 0's communication stream (receive of N-1 tiles + assembly); asynchronous: it runs "
+                                           "beside the frames in flight, inside the timed region",
+                         "host_ms_per_step": round(gather_host_ms, 4), "gathers": (native.stats()[0] - gathers_before) if native is not None else K,
+                         "bytes_per_step": W * H * 16 - my_bytes, "note": gather_note}
 
-    # ---- CPU baseline: the oracle on the same frame, all host cores (a rate; 1 warm-up band + the full frame)
+    # ---- CPU baseline: the oracle on the same frame, host cores (a rate): 1 warm-up band, then 3 timed passes, median
     if world == 1 and not args.no_cpu_baseline and args.emulate_world <= 1:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -347,14 +477,19 @@ def main():
         osc.build_bvh()
         osc.render(W, H, 1, variant=variant, rows=(H // 2, H // 2 + 8), threads=0)  # warm-up
         cores = host_cpu_budget(O.lib().orc_hw_threads())
-        # bounded sample: the whole frame when there are many cores, a centred band of rows otherwise (~10-30 core-seconds)
+        # bounded sample: the whole frame when there are many cores, a centred band of rows otherwise (~10-30 core-seconds per pass)
         rows = (0, H) if cores >= 16 else (H // 2 - H // 8, H // 2 + H // 8)
-        _, ost = osc.render(W, H, spp, variant=variant, rows=rows, threads=cores)
-        cpu_rays = ost.rays_closest + ost.rays_shadow
+        runs = []
+        for _ in range(3):
+            _, ost = osc.render(W, H, spp, variant=variant, rows=rows, threads=cores)
+            runs.append(((ost.rays_closest + ost.rays_shadow) / ost.seconds / 1e6, ost.rays_closest + ost.rays_shadow, ost.seconds, int(ost.threads)))
+        runs.sort()
+        rate, cpu_rays, secs, threads = runs[1]
         out["cpu_baseline"] = {
-            "value": round(cpu_rays / ost.seconds / 1e6, 3), "unit": "Mrays/s", "cores": int(ost.threads), "kind": "port",
-            "sample": "rows %d..%d of the same %dx%d frame at %d spp: %d rays in %.2f s; oracle/liboracle.so (scalar BVH2 traversal + "
-                      "shading, std::thread over rows)" % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, ost.seconds),
+            "value": round(rate, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "median of 3 timed passes over rows %d..%d of the same %dx%d frame at %d spp (%d rays in %.2f s; all three: %s Mrays/s); "
+                      "oracle/liboracle.so (scalar BVH2 traversal + shading, std::thread over rows)"
+                      % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, secs, ", ".join("%.1f" % x[0] for x in runs)),
         }
     print(json.dumps(out))
     if world > 1:

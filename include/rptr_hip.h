@@ -265,6 +265,12 @@ typedef struct RptrStats {
     int32_t launches_connect;
     int32_t _pad;
     uint64_t device_bytes_allocated;
+    /* the parts of shade_time_ms (stage timing level 2): the shade launches alone, the tail kernel (late bounces: extend + shade +
+     * connect of a few thousand paths in one launch), the resolve */
+    float shade_only_time_ms;
+    float tail_time_ms;
+    float resolve_time_ms;
+    float _pad2;
 } RptrStats;
 
 typedef struct rptr_hip rptr_hip_t;
@@ -366,8 +372,8 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
  * a communication stream of its own, ordered behind the waited frame; the next frame that reuses the sending frame context waits
  * for the send on the device, nothing else does -- with frames in flight the gather of frame i overlaps the rendering of frames
  * i+1.. . The assembled frame (rank 0) is read with rptr_hip_readback_gathered_f32 (which waits for the last gather) or used in
- * place through rptr_hip_gathered_frame (valid once the communication stream has been synchronised / an event recorded by the
- * caller after rptr_hip_gather_done_event). Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
+ * place through rptr_hip_gathered_frame (valid once rptr_hip_readback_gathered_f32 / rptr_hip_comm_stats have waited for it, or the device has been synchronised by the
+ * caller). Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
  * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. */
 #define RPTR_COMM_ID_BYTES 128
 int rptr_hip_comm_get_unique_id(void *out_id128);

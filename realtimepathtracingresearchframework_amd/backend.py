@@ -78,6 +78,15 @@ def load_library(path=None):
     L.rptr_hip_trace_counted.argtypes = [vp, vp, i32, vp, vp, vp, i32]
     L.rptr_hip_export_bvh.argtypes = [vp, vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t), vp, C.POINTER(C.c_size_t)]
     L.rptr_hip_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.rptr_hip_comm_get_unique_id.argtypes = [vp]
+    L.rptr_hip_comm_init_rank.argtypes = [vp, vp]
+    L.rptr_hip_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.rptr_hip_comm_destroy.argtypes = [vp]
+    L.rptr_hip_gather.argtypes = [vp]
+    L.rptr_hip_gather_all.argtypes = [C.POINTER(vp), i32]
+    L.rptr_hip_gathered_frame.argtypes = [vp, C.POINTER(vp)]
+    L.rptr_hip_readback_gathered_f32.argtypes = [vp, vp, C.c_size_t]
+    L.rptr_hip_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     for name in abi.EXPORTED_SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -338,6 +347,67 @@ class RenderHip:
 
     def refit(self):
         self._check(self._L.rptr_hip_refit(self._h))
+
+    # ---- the RCCL gather of tile radiance (include/rptr_hip.h "multi-GPU"; csrc/host_comm.h)
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128 bytes every rank of a one-process-per-GPU job hands to comm_init_rank (ncclGetUniqueId)"""
+        L = load_library()
+        buf = C.create_string_buffer(abi.COMM_ID_BYTES)
+        rc = L.rptr_hip_comm_get_unique_id(buf)
+        if rc != 0:
+            raise BackendError(rc, L.rptr_hip_last_error(None).decode())
+        return buf.raw
+
+    def comm_init_rank(self, unique_id: bytes):
+        """collective over all ranks of the job (one process per GPU): joins the communicator as RptrCreateInfo.rank"""
+        assert len(unique_id) == abi.COMM_ID_BYTES
+        self._check(self._L.rptr_hip_comm_init_rank(self._h, C.c_char_p(unique_id)))
+
+    @staticmethod
+    def _handle_array(renderers):
+        arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+        return arr
+
+    @staticmethod
+    def comm_init_all(renderers):
+        """one process, len(renderers) handles: renderers[i] is rank i of the frame"""
+        rc = renderers[0]._L.rptr_hip_comm_init_all(RenderHip._handle_array(renderers), len(renderers))
+        if rc != 0:
+            msgs = [r._L.rptr_hip_last_error(r._h).decode() for r in renderers]
+            raise BackendError(rc, "; ".join(m for m in msgs if m) or renderers[0]._L.rptr_hip_last_error(None).decode())
+
+    def gather(self):
+        """this rank's part of the per-frame gather (asynchronous; call right after wait())"""
+        self._check(self._L.rptr_hip_gather(self._h))
+
+    @staticmethod
+    def gather_all(renderers):
+        rc = renderers[0]._L.rptr_hip_gather_all(RenderHip._handle_array(renderers), len(renderers))
+        if rc != 0:
+            msgs = [r._L.rptr_hip_last_error(r._h).decode() for r in renderers]
+            raise BackendError(rc, "; ".join(m for m in msgs if m))
+
+    def gathered_frame_ptr(self):
+        p = C.c_void_p()
+        self._check(self._L.rptr_hip_gathered_frame(self._h, C.byref(p)))
+        return p.value
+
+    def readback_gathered(self, buffer: np.ndarray):
+        """rank 0: the assembled RGBA32F frame of the last gather (waits for it). Returns #elements or 0."""
+        w, hgt, c = self.get_framebuffer_size()
+        if buffer.size < w * hgt * c or buffer.dtype != np.float32:
+            return 0
+        self._check(self._L.rptr_hip_readback_gathered_f32(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
+        return w * hgt * c
+
+    def comm_stats(self):
+        n, ms = C.c_uint64(), C.c_float()
+        self._check(self._L.rptr_hip_comm_stats(self._h, C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def comm_destroy(self):
+        self._check(self._L.rptr_hip_comm_destroy(self._h))
 
     def copy_tile_to_device(self, device_ptr, n_bytes):
         self._check(self._L.rptr_hip_copy_tile_to_device(self._h, C.c_void_p(device_ptr), n_bytes))

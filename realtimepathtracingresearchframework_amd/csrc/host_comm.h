@@ -1,0 +1,408 @@
+// host_comm.h -- the path's one collective: a gather of tile radiance to rank 0 (include/rptr_hip.h "multi-GPU").
+//
+// Included once, at the end of rptr_hip.hip (it works on the handle's internals). No reference counterpart: the reference renders on
+// one physical device (vulkan/render_vulkan_extensions.cpp:77-82); the partitioning is SURVEY 8e's -- screen stripes, scene replicas,
+// resolved float4 radiance moves, nothing else.
+//
+// Transport. RCCL has no gather primitive; the idiom is grouped point-to-point: every rank r != 0 posts ONE ncclSend of its packed rows
+// (the frame context's own image: its rows top to bottom are exactly the tile, no staging copy), rank 0 posts N-1 ncclRecv into one
+// receive buffer, all inside ncclGroupStart/End. On xGMI every peer has its own link to rank 0, so the N-1 transfers run side by
+// side (1080p: 4.1 MB per link and frame) -- this is not a ring collective and not bound by a ring's per-link rate. One HIP kernel then
+// interleaves the stripes into the frame (HBM stream: 2 x 16 B per pixel). librccl is dlopen'ed (librccl.so.1: the copy already in the
+// process -- PyTorch ships one -- or the system's), so single-GPU hosts and the build container never need it.
+// One process with several handles can also move the rows with hipMemcpyPeerAsync (handles that share a device in test rigs, or
+// RPTR_COMM_TRANSPORT=copy); same stream / event structure, same assembly kernel.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: nothing links against librccl
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi &rccl() {
+    static RcclApi api;
+    if (api.lib || !api.error.empty()) return api;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) // a copy that is already loaded wins (two RCCL instances in one process would each own the devices)
+        if ((api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!api.lib)
+        for (const char *n : names)
+            if ((api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!api.lib) {
+        api.error = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "?");
+        return api;
+    }
+    auto sym = [&](const char *name) {
+        void *p = dlsym(api.lib, name);
+        if (!p && api.error.empty()) api.error = std::string("librccl lacks ") + name;
+        return p;
+    };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    return api;
+}
+
+enum { COMM_RCCL = 0, COMM_COPY = 1 };
+
+} // namespace
+
+struct RptrComm {
+    int transport = COMM_RCCL;
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr;     // everything of a gather runs here, behind the frame it sends
+    hipEvent_t ev_src = nullptr;      // "the waited frame is visible" (recorded on the backend's stream)
+    hipEvent_t ev_done = nullptr;     // the last gather of this rank has finished (send done / frame assembled)
+    // rank 0
+    float4 *recv = nullptr;           // packed rows of the ranks 1..N-1 (RPTR_COMM_SELF: and of rank 0), rank after rank
+    float4 *gathered = nullptr;       // the assembled frame, width * height
+    unsigned long long *d_offsets = nullptr; // per rank: first float4 of its rows in `recv`
+    std::vector<size_t> rank_pixels, rank_offset;
+    bool self = false;                // RPTR_COMM_SELF=1 (diagnostic): rank 0's own rows also travel through ncclSend / ncclRecv
+    // one process, several handles: the peers (rank order) and, for peer copies, the events that tell rank 0 a peer's rows have landed
+    std::vector<rptr_hip *> peers;
+    hipEvent_t ev_copied = nullptr;
+    // statistics
+    uint64_t gathers = 0, timed = 0;
+    double total_ms = 0.0;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    bool timing_pending = false;
+};
+
+// rows of rank r's tile, packed top to bottom, into the frame
+__global__ __launch_bounds__(256) void rp_k_assemble(float4 *frame, const float4 *own, const float4 *recv, const unsigned long long *offsets, int width,
+                                                     int height, int stripe_rows, int world, int self) {
+    const size_t n = (size_t)width * height;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+        const int s = y / stripe_rows, r = s % world;
+        const int local_row = (s / world) * stripe_rows + (y - s * stripe_rows);
+        const float4 *src = (r == 0 && !self) ? own : recv + offsets[r];
+        frame[i] = src[(size_t)local_row * width + x];
+    }
+}
+
+namespace {
+
+int comm_fail_nccl(rptr_hip *h, const char *what, ncclResult_t r) {
+    return fail(h, RPTR_E_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error");
+}
+
+#define NCCL_TRY(h, expr)                                          \
+    do {                                                           \
+        ncclResult_t _r = (expr);                                  \
+        if (_r != ncclSuccess) return comm_fail_nccl(h, #expr, _r); \
+    } while (0)
+
+// what every rank needs besides the communicator: stream, events and (rank 0) the receive buffer, the frame, the offsets
+int comm_setup_local(rptr_hip *h, int transport) {
+    if (h->width == 0) return fail(h, RPTR_E_INVALID, "communicator before initialize (the receive buffers depend on the frame size)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    RptrComm *c = new RptrComm();
+    c->transport = transport;
+    if (const char *e = getenv("RPTR_COMM_SELF")) c->self = atoi(e) != 0;
+    h->comm = c;
+    HIP_TRY(h, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreate(&c->ev_t0));
+    HIP_TRY(h, hipEventCreate(&c->ev_t1));
+    c->rank_pixels.assign((size_t)h->world, 0);
+    c->rank_offset.assign((size_t)h->world, 0);
+    size_t at = 0;
+    for (int r = 0; r < h->world; ++r) {
+        c->rank_pixels[(size_t)r] = (size_t)h->width * local_row_count(h->height, h->stripe_rows, r, h->world);
+        c->rank_offset[(size_t)r] = at;
+        if (r != 0 || c->self) at += c->rank_pixels[(size_t)r];
+    }
+    if (h->rank == 0) {
+        // (comm buffers are frame-sized: released with the frame buffers by the next initialize, which also drops the communicator)
+        int rc;
+        if ((rc = dev_alloc(h, &c->recv, at, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c->gathered, (size_t)h->width * h->height, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c->d_offsets, (size_t)h->world, nullptr))) return rc;
+        std::vector<unsigned long long> off(c->rank_offset.begin(), c->rank_offset.end());
+        HIP_TRY(h, hipMemcpy(c->d_offsets, off.data(), off.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemset(c->gathered, 0, (size_t)h->width * h->height * sizeof(float4)));
+    }
+    return RPTR_OK;
+}
+
+void comm_release(rptr_hip *h) {
+    RptrComm *c = h->comm;
+    if (!c) return;
+    (void)hipSetDevice(h->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
+    for (hipEvent_t e : {c->ev_src, c->ev_done, c->ev_copied, c->ev_t0, c->ev_t1})
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (FrameCtx &fc : h->ctx) fc.gather_pending = false;
+    delete c;
+    h->comm = nullptr;
+}
+
+// the image the gather sends: the rows of the frame that was waited for last
+const float4 *comm_source(rptr_hip *h, FrameCtx *&owner) {
+    if (h->output_ctx >= 0) {
+        owner = &h->ctx[(size_t)h->output_ctx];
+        return owner->out_accum;
+    }
+    owner = &h->ctx[0];
+    return h->accum;
+}
+
+void comm_collect_timing(RptrComm *c, bool wait) {
+    if (!c->timing_pending) return;
+    if (wait) (void)hipEventSynchronize(c->ev_t1);
+    else if (hipEventQuery(c->ev_t1) != hipSuccess) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) == hipSuccess) {
+        c->total_ms += ms;
+        c->timed++;
+    }
+    c->timing_pending = false;
+}
+
+// first half of a rank's gather: order the communication stream behind the waited frame
+int comm_begin(rptr_hip *h, const float4 *&src, FrameCtx *&owner) {
+    RptrComm *c = h->comm;
+    if (!c) return fail(h, RPTR_E_INVALID, "rptr_hip_gather without a communicator (rptr_hip_comm_init_rank / _init_all)");
+    if (h->output_overwritten)
+        return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame on the same frame context: gather right "
+                                       "after rptr_hip_wait");
+    HIP_TRY(h, hipSetDevice(h->device));
+    src = comm_source(h, owner);
+    HIP_TRY(h, hipEventRecord(c->ev_src, h->stream)); // finish_frame made the backend's stream wait for the frame
+    HIP_TRY(h, hipStreamWaitEvent(c->stream, c->ev_src, 0));
+    comm_collect_timing(c, false);
+    if (!c->timing_pending) HIP_TRY(h, hipEventRecord(c->ev_t0, c->stream));
+    return RPTR_OK;
+}
+
+// second half: rank 0 assembles; the sender's frame context learns when its image is free again
+int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner) {
+    RptrComm *c = h->comm;
+    if (h->rank == 0) {
+        const size_t npix = (size_t)h->width * h->height;
+        hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered, src, c->recv, c->d_offsets, h->width, h->height,
+                           h->stripe_rows, h->world, c->self ? 1 : 0);
+    }
+    if (!c->timing_pending) {
+        HIP_TRY(h, hipEventRecord(c->ev_t1, c->stream));
+        c->timing_pending = true;
+    }
+    HIP_TRY(h, hipEventRecord(c->ev_done, c->stream));
+    if (!owner->ev_gather) HIP_TRY(h, hipEventCreateWithFlags(&owner->ev_gather, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(owner->ev_gather, c->stream)); // the next frame on this context waits for it before it touches the image
+    owner->gather_pending = true;
+    c->gathers++;
+    HIP_TRY(h, hipGetLastError());
+    return RPTR_OK;
+}
+
+// this rank's sends / receives (inside the caller's ncclGroupStart / End)
+int comm_post_rccl(rptr_hip *h, const float4 *src) {
+    RptrComm *c = h->comm;
+    RcclApi &R = rccl();
+    const size_t mine = c->rank_pixels[(size_t)h->rank];
+    if ((h->rank != 0 || c->self) && mine) NCCL_TRY(h, R.Send(src, mine * 4, ncclFloat, 0, c->nccl, c->stream));
+    if (h->rank == 0)
+        for (int r = c->self ? 0 : 1; r < h->world; ++r)
+            if (c->rank_pixels[(size_t)r]) NCCL_TRY(h, R.Recv(c->recv + c->rank_offset[(size_t)r], c->rank_pixels[(size_t)r] * 4, ncclFloat, r, c->nccl, c->stream));
+    return RPTR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int rptr_hip_comm_get_unique_id(void *out_id128) {
+    if (!out_id128) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    RcclApi &R = rccl();
+    if (!R.error.empty()) return fail(nullptr, RPTR_E_UNSUPPORTED, "%s", R.error.c_str());
+    ncclUniqueId id;
+    static_assert(sizeof(id) == RPTR_COMM_ID_BYTES, "ncclUniqueId size");
+    NCCL_TRY(nullptr, R.GetUniqueId(&id));
+    memcpy(out_id128, &id, sizeof(id));
+    return RPTR_OK;
+}
+
+int rptr_hip_comm_init_rank(rptr_hip_t *h, const void *id128) {
+    if (!h || !id128) return fail(h, RPTR_E_INVALID, "NULL argument");
+    RcclApi &R = rccl();
+    if (!R.error.empty()) return fail(h, RPTR_E_UNSUPPORTED, "%s", R.error.c_str());
+    comm_release(h);
+    int rc = comm_setup_local(h, COMM_RCCL);
+    if (rc) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(h, R.CommInitRank(&h->comm->nccl, h->world, id, h->rank));
+    return RPTR_OK;
+}
+
+int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
+    if (!handles || n < 1) return fail(nullptr, RPTR_E_INVALID, "bad argument");
+    bool distinct = true;
+    for (int i = 0; i < n; ++i) {
+        rptr_hip *h = handles[i];
+        if (!h) return fail(nullptr, RPTR_E_INVALID, "handle %d is NULL", i);
+        if (h->rank != i || h->world != n) return fail(h, RPTR_E_INVALID, "handle %d has rank %d of %d: handles[i] must be rank i of n = %d", i, h->rank, h->world, n);
+        if (h->width != handles[0]->width || h->height != handles[0]->height || h->stripe_rows != handles[0]->stripe_rows)
+            return fail(h, RPTR_E_INVALID, "handle %d: frame size / stripe rows differ from handle 0", i);
+        for (int j = 0; j < i; ++j) distinct = distinct && handles[j]->device != h->device;
+    }
+    int transport = distinct ? COMM_RCCL : COMM_COPY; // RCCL refuses two ranks on one device: such rigs move the rows with copies
+    if (const char *e = getenv("RPTR_COMM_TRANSPORT")) {
+        if (!strcmp(e, "copy")) transport = COMM_COPY;
+        else if (!strcmp(e, "rccl")) transport = COMM_RCCL;
+    }
+    RcclApi &R = rccl();
+    if (transport == COMM_RCCL && !R.error.empty()) return fail(handles[0], RPTR_E_UNSUPPORTED, "%s", R.error.c_str());
+    for (int i = 0; i < n; ++i) {
+        comm_release(handles[i]);
+        int rc = comm_setup_local(handles[i], transport);
+        if (rc) return rc;
+        handles[i]->comm->peers.assign(handles, handles + n);
+    }
+    if (transport == COMM_RCCL) {
+        ncclUniqueId id;
+        NCCL_TRY(handles[0], R.GetUniqueId(&id));
+        // one thread, several devices: the rank initialisations must be fused into one group (rccl.h ncclCommInitRank)
+        NCCL_TRY(handles[0], R.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(handles[i], hipSetDevice(handles[i]->device));
+            NCCL_TRY(handles[i], R.CommInitRank(&handles[i]->comm->nccl, n, id, i));
+        }
+        NCCL_TRY(handles[0], R.GroupEnd());
+    } else {
+        for (int i = 1; i < n; ++i) // peer access for the copies (a no-op error when it is already on or the device is the same)
+            if (handles[i]->device != handles[0]->device) {
+                (void)hipSetDevice(handles[i]->device);
+                (void)hipDeviceEnablePeerAccess(handles[0]->device, 0);
+                (void)hipSetDevice(handles[0]->device);
+                (void)hipDeviceEnablePeerAccess(handles[i]->device, 0);
+                (void)hipGetLastError();
+            }
+    }
+    return RPTR_OK;
+}
+
+int rptr_hip_comm_destroy(rptr_hip_t *h) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    comm_release(h);
+    return RPTR_OK;
+}
+
+int rptr_hip_gather(rptr_hip_t *h) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (!h->comm) return fail(h, RPTR_E_INVALID, "rptr_hip_gather without a communicator (rptr_hip_comm_init_rank)");
+    if (h->comm->peers.size() > 1) return fail(h, RPTR_E_INVALID, "this handle belongs to a one-process group: use rptr_hip_gather_all");
+    const float4 *src = nullptr;
+    FrameCtx *owner = nullptr;
+    int rc = comm_begin(h, src, owner);
+    if (rc) return rc;
+    RcclApi &R = rccl();
+    NCCL_TRY(h, R.GroupStart());
+    rc = comm_post_rccl(h, src);
+    NCCL_TRY(h, R.GroupEnd());
+    if (rc) return rc;
+    return comm_end(h, src, owner);
+}
+
+int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
+    if (!handles || n < 1 || !handles[0]) return fail(nullptr, RPTR_E_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!handles[i] || !handles[i]->comm || (int)handles[i]->comm->peers.size() != n || handles[i]->comm->peers[(size_t)i] != handles[i])
+            return fail(handles[i], RPTR_E_INVALID, "handle %d is not rank %d of a group made by rptr_hip_comm_init_all", i, i);
+    std::vector<const float4 *> src((size_t)n, nullptr);
+    std::vector<FrameCtx *> owner((size_t)n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        int rc = comm_begin(handles[i], src[(size_t)i], owner[(size_t)i]);
+        if (rc) return rc;
+    }
+    rptr_hip *h0 = handles[0];
+    RptrComm *c0 = h0->comm;
+    if (c0->transport == COMM_RCCL) {
+        RcclApi &R = rccl();
+        NCCL_TRY(h0, R.GroupStart()); // one group over all devices: sends and receives progress together
+        int rc = RPTR_OK;
+        for (int i = 0; i < n && !rc; ++i) {
+            HIP_TRY(handles[i], hipSetDevice(handles[i]->device));
+            rc = comm_post_rccl(handles[i], src[(size_t)i]);
+        }
+        NCCL_TRY(h0, R.GroupEnd());
+        if (rc) return rc;
+    } else {
+        // peer copies: rank r writes its rows into rank 0's receive buffer on its OWN communication stream (behind its frame), rank 0's
+        // stream waits for every copy before it assembles
+        for (int i = c0->self ? 0 : 1; i < n; ++i) {
+            rptr_hip *h = handles[i];
+            RptrComm *c = h->comm;
+            const size_t bytes = c0->rank_pixels[(size_t)i] * sizeof(float4);
+            if (!bytes) continue;
+            HIP_TRY(h, hipSetDevice(h->device));
+            if (h->device == h0->device)
+                HIP_TRY(h, hipMemcpyAsync(c0->recv + c0->rank_offset[(size_t)i], src[(size_t)i], bytes, hipMemcpyDeviceToDevice, c->stream));
+            else
+                HIP_TRY(h, hipMemcpyPeerAsync(c0->recv + c0->rank_offset[(size_t)i], h0->device, src[(size_t)i], h->device, bytes, c->stream));
+            HIP_TRY(h, hipEventRecord(c->ev_copied, c->stream));
+            HIP_TRY(h0, hipSetDevice(h0->device));
+            HIP_TRY(h0, hipStreamWaitEvent(c0->stream, c->ev_copied, 0));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(handles[i], hipSetDevice(handles[i]->device));
+        int rc = comm_end(handles[i], src[(size_t)i], owner[(size_t)i]);
+        if (rc) return rc;
+    }
+    return RPTR_OK;
+}
+
+int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f) {
+    if (!h || !out_device_rgba32f) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
+    *out_device_rgba32f = h->comm->gathered;
+    return RPTR_OK;
+}
+
+int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
+    if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
+    const size_t need = (size_t)h->width * h->height * 4;
+    if (n_floats < need) return fail(h, RPTR_E_INVALID, "read-back buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered, need * sizeof(float), hipMemcpyDeviceToHost, h->comm->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
+    return RPTR_OK;
+}
+
+int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_gather_ms) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (!h->comm) return fail(h, RPTR_E_INVALID, "no communicator");
+    (void)hipSetDevice(h->device);
+    comm_collect_timing(h->comm, true);
+    if (out_gathers) *out_gathers = h->comm->gathers;
+    if (out_mean_gather_ms) *out_mean_gather_ms = h->comm->timed ? (float)(h->comm->total_ms / (double)h->comm->timed) : 0.0f;
+    return RPTR_OK;
+}
+
+} // extern "C"

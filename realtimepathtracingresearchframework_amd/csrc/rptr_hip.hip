@@ -58,7 +58,7 @@ struct SceneCopy {
 
 struct Span {
     hipEvent_t a, b;
-    int kind; // 0 extend, 1 connect, 2 other
+    int kind; // 0 extend, 1 connect, 2 shade, 3 tail, 4 resolve, 5 other (regrouping pass)
 };
 
 // Everything one frame in flight owns: its stream, path state, queues, counters, stack scratch, events.
@@ -93,11 +93,17 @@ struct FrameCtx {
     RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
     int launches_extend = 0, launches_connect = 0, spp_after = 0;
     int tail_from = 0; // the bounce at which this context's last frame handed over to the tail kernel (= max depth: no tail)
+    // multi-GPU gather (host_comm.h): the image this context produced is being sent; its next frame waits for that on the device
+    hipEvent_t ev_gather = nullptr;
+    bool gather_pending = false;
 };
 
 } // namespace
 
+struct RptrComm; // host_comm.h
+
 struct rptr_hip {
+    RptrComm *comm = nullptr; // communicator rank of this handle (rptr_hip_comm_init_rank / _init_all), NULL on a single GPU
     std::string last_error;
     int device = 0;
     int rank = 0, world = 1, stripe_rows = 32;
@@ -179,6 +185,8 @@ struct rptr_hip {
 };
 
 namespace {
+
+void comm_release(rptr_hip *h); // host_comm.h
 
 int fail(rptr_hip *h, int code, const char *fmt, ...) {
     char buf[1024];
@@ -773,6 +781,7 @@ void rptr_hip_destroy(rptr_hip_t *h) {
     (void)hipSetDevice(h->device);
     for (FrameCtx &c : h->ctx) (void)hipStreamSynchronize(c.stream);
     (void)hipStreamSynchronize(h->stream);
+    comm_release(h);
     free_list(h->allocations);
     free_list(h->scene_allocs);
     for (FrameCtx &c : h->ctx) {
@@ -781,7 +790,7 @@ void rptr_hip_destroy(rptr_hip_t *h) {
             (void)hipStreamSynchronize(c.side);
             (void)hipStreamDestroy(c.side);
         }
-        for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved, c.ev_fork, c.ev_side})
+        for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved, c.ev_fork, c.ev_side, c.ev_gather})
             if (e) (void)hipEventDestroy(e);
         if (c.host_counters) (void)hipHostFree(c.host_counters);
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
@@ -816,6 +825,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         if (rc0) return rc0;
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    comm_release(h); // its receive buffers and the assembled frame are frame-sized: a communicator is made again after a resize
     for (void *p : h->allocations) (void)hipFree(p);
     h->allocations.clear();
     h->bytes_frame = 0;
@@ -1504,7 +1514,12 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
         (void)hipEventElapsedTime(&t, sp.a, sp.b);
         if (sp.kind == 0) st.extend_time_ms += t;
         else if (sp.kind == 1) st.connect_time_ms += t;
-        else st.shade_time_ms += t;
+        else {
+            st.shade_time_ms += t;
+            if (sp.kind == 2) st.shade_only_time_ms += t;
+            else if (sp.kind == 3) st.tail_time_ms += t;
+            else if (sp.kind == 4) st.resolve_time_ms += t;
+        }
     }
     RpCounters tot = c.earlier_batches;
     if (h->local_rows > 0) add_counters(tot, *c.host_counters);
@@ -1677,6 +1692,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
         (void)refit_scene_copy(h, scn, true, c.stream);
         scn.version = h->refit_version;
     }
+    if (c.gather_pending) { // the image this context produced last is still being sent to rank 0 (host_comm.h)
+        HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_gather, 0));
+        c.gather_pending = false;
+    }
     HIP_TRY(h, hipEventRecord(c.ev_begin, c.stream));
     c.launches_extend = c.launches_connect = 0;
     memset(&c.earlier_batches, 0, sizeof(c.earlier_batches));
@@ -1714,7 +1733,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
                     auto go = [&](auto kernel) {
-                        timed_kernel(c.stream, 2, kernel, dim3(h->tail_blocks), dim3(256), scn.dscene, f, c.ps, c.sq, (const uint32_t *)c.queue[in], c.counters, b,
+                        timed_kernel(c.stream, 3, kernel, dim3(h->tail_blocks), dim3(256), scn.dscene, f, c.ps, c.sq, (const uint32_t *)c.queue[in], c.counters, b,
                                      c.gstack);
                     };
                     pick(variant == RPTR_VARIANT_SIMPLE, [&](auto V) {
@@ -1746,7 +1765,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
                 const uint32_t *order = in_queue;
                 if (do_sort) {
-                    timed(2, [&] {
+                    timed(5, [&] {
                         hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, scn.dscene, f, c.ps, in_queue,
                                            &bc->queue_count, c.keys, c.sort_hist);
                         hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
@@ -1788,7 +1807,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                timed_kernel(c.stream, 2, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
+                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
             }
             if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
@@ -2062,3 +2081,5 @@ int rptr_hip_export_bvh(rptr_hip_t *h, void *nodes, size_t *n_nodes, void *tris,
 }
 
 } // extern "C"
+
+#include "host_comm.h"

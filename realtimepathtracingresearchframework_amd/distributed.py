@@ -66,3 +66,36 @@ class TileGather:
         import torch.distributed as dist
         dist.gather(self.tile, self.recv, dst=0)
         return self.assemble() if self.rank == 0 else None
+
+
+def exchange_unique_id(make_id, rank, world):
+    """rank 0 calls make_id() (128 bytes, rptr_hip_comm_get_unique_id); every rank returns the same bytes. The bytes travel through
+    torch.distributed's own store-backed object broadcast -- plumbing only, any side channel would do (rptr_cli uses a file)."""
+    import torch.distributed as dist
+    box = [make_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+class NativeGather:
+    """The gather done by the library itself (include/rptr_hip.h "multi-GPU", csrc/host_comm.h): grouped ncclSend / ncclRecv on a
+    communication stream of the backend, rows sent straight from the frame context's image, stripes interleaved by one HIP kernel
+    on rank 0. Python only hands the RCCL unique id around once; per frame it makes ONE ctypes call (`gather()`), which returns as
+    soon as the work is queued -- with frames in flight the gather of frame i runs beside the rendering of frames i+1.. ."""
+
+    def __init__(self, renderer, rank, world):
+        from .backend import RenderHip
+        self.r, self.rank, self.world = renderer, rank, world
+        uid = exchange_unique_id(RenderHip.comm_unique_id, rank, world)
+        renderer.comm_init_rank(uid)
+
+    def gather(self):
+        self.r.gather()
+
+    def frame(self, out):
+        """rank 0: waits for the last gather and copies the assembled frame into `out` (float32, height x width x 4)"""
+        return self.r.readback_gathered(out)
+
+    def stats(self):
+        return self.r.comm_stats()

@@ -214,3 +214,101 @@ def test_readback_after_resubmitting_on_the_same_context_is_an_error():
     assert r.readback_framebuffer(buf) == W * H * 4
     assert not np.array_equal(buf, first)                       # three resets, three seeds
     r.close()
+
+
+# ---------------------------------------------------------------- the library's own gather (csrc/host_comm.h)
+@pytest.mark.parametrize("world,fif,stripe_rows", [(2, 1, 32), (3, 3, 8), (8, 2, 8)])
+def test_gather_all_of_n_handles_on_one_device_is_bit_identical_to_one_rank(world, fif, stripe_rows):
+    """one process, `world` handles (all on device 0: the rows travel by device copies, the transport of rigs whose ranks share a
+    device; stream / event structure and the assembly kernel are those of the RCCL transport): a sequence of frames, every rank
+    rendering its stripes with `fif` frames in flight, gathered by rptr_hip_gather_all -> the assembled frames equal the frames of
+    ONE rank rendering everything, bit for bit, frame by frame"""
+    s = scenes.grid(120, 60, with_emitters=True)
+    W, H, spp, n_frames = 200, 120, 2, 5
+    cam = s.camera_params()
+
+    def cfg(k):
+        return backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=(k % 2 == 0))
+
+    ref = backend.RenderHip()
+    ref.initialize(W, H)
+    ref.set_scene(s)
+    want = []
+    for k in range(n_frames):
+        ref.render(cfg(k), spp=spp)
+        img = np.zeros((H, W, 4), np.float32)
+        ref.readback_framebuffer(img)
+        want.append(img)
+    ref.close()
+
+    rs = [backend.RenderHip(rank=k, world_size=world, stripe_rows=stripe_rows, frames_in_flight=fif) for k in range(world)]
+    for r in rs:
+        r.initialize(W, H)
+        r.set_scene(s)
+    with pytest.raises(backend.BackendError):
+        rs[0].gather()                                   # no communicator yet
+    backend.RenderHip.comm_init_all(rs)
+    with pytest.raises(backend.BackendError):
+        rs[0].gather()                                   # member of a one-process group: gather_all
+    got, queue = [], []
+
+    def collect():
+        tickets = queue.pop(0)
+        for r, t in zip(rs, tickets):
+            r.wait(t)
+        backend.RenderHip.gather_all(rs)
+        img = np.zeros((H, W, 4), np.float32)
+        assert rs[0].readback_gathered(img) == W * H * 4
+        got.append(img)
+    for k in range(n_frames):
+        queue.append([r.render_async(cfg(k), spp=spp) for r in rs])
+        if len(queue) >= fif:
+            collect()
+    while queue:
+        collect()
+    n, ms = rs[0].comm_stats()
+    assert n == n_frames and ms > 0.0
+    with pytest.raises(backend.BackendError):
+        rs[1].gathered_frame_ptr()
+    for r in rs:
+        r.close()
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_rccl_gather_on_one_gpu_through_self_send(monkeypatch):
+    """The RCCL transport on the one GPU of this box: world 1, and RPTR_COMM_SELF=1 routes rank 0's own rows through
+    ncclSend / ncclRecv (peer 0) and the receive buffer -- librccl is loaded at run time, a communicator is made from a unique id,
+    grouped point-to-point runs on the communication stream, the assembly kernel reads the received rows. (Transfers between
+    different GPUs need the multi-GPU node: bench.py --gpus N.)"""
+    monkeypatch.setenv("RPTR_COMM_SELF", "1")
+    s = scenes.cornell32()
+    W, H = 160, 96
+    r = backend.RenderHip(frames_in_flight=2)
+    r.initialize(W, H)
+    r.set_scene(s)
+    uid = backend.RenderHip.comm_unique_id()
+    assert len(uid) == abi.COMM_ID_BYTES and any(uid)
+    r.comm_init_rank(uid)
+    cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    t0 = r.render_async(cfg, spp=2)
+    t1 = r.render_async(cfg, spp=2)
+    images = []
+    for t in (t0, t1):
+        r.wait(t)
+        own = np.zeros((H, W, 4), np.float32)
+        r.readback_framebuffer(own)
+        r.gather()
+        got = np.zeros((H, W, 4), np.float32)
+        assert r.readback_gathered(got) == W * H * 4
+        assert np.array_equal(got.view(np.uint32), own.view(np.uint32))
+        images.append(got)
+    assert not np.array_equal(images[0], images[1])
+    t2 = r.render_async(cfg, spp=1)          # reuses t0's context: waits for that context's send on the device
+    r.wait(t2)
+    r.gather()
+    assert r.comm_stats()[0] == 3
+    r.initialize(W, H)                       # a resize drops the communicator with its frame-sized buffers
+    with pytest.raises(backend.BackendError):
+        r.gather()
+    r.close()

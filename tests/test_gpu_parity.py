@@ -389,6 +389,28 @@ def test_bench_two_ranks_on_one_gpu_with_gloo(tmp_path):
     assert "cpu_baseline" not in d
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the way a driver may call it): bench.py re-executes itself under
+    torch.distributed.run, one JSON line comes back"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--grid", "100x50", "--width", "320",
+           "--height", "180", "--dist-backend", "gloo", "--same-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["gather"]["mode"].startswith("tile copy")
+    rf = d["roofline"]
+    assert rf["exclusive_ms_per_step"] <= rf["stage_ms_per_step"]["gpu_total"] + 1e-6
+    for k in rf["kernels"].values():
+        assert 0.0 <= k["algorithmic_frac"] <= 1.0 and (k["hbm_frac"] is None or 0.0 <= k["hbm_frac"] <= 1.0)
+
+
 # ---------------------------------------------------------------- fuzz
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_fuzz_soups_trace_and_image(seed):

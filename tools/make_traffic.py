@@ -23,7 +23,7 @@ def read(path, counter):
 def main():
     fetch = read(os.path.join(ROOT, "gpurun_out", "pmc_fetch", "summary_fetch.csv"), "FETCH_SIZE")
     write = read(os.path.join(ROOT, "gpurun_out", "pmc_write", "summary_write.csv"), "WRITE_SIZE")
-    doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
+    doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --profile-pass --steps 3 --warmup 1 (frames one at a time, RPTR_TAIL_BOUNCE=2)",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads 1/2, MI355X_MICROARCH.md)", "kernels": {}}
     for k in fetch:
         calls, f = fetch[k]
