@@ -58,6 +58,25 @@ struct RpScene {
     const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)
 };
 
+// Division of a 31-bit number by a frame constant (tiles per row, rows per stripe, padded pixels per sample slot) without the ~25
+// instructions of a 32-bit integer division: q = mulhi(n, mul) >> shift with mul = ceil(2^(32 + shift) / d), shift = ceil(log2 d) - 1,
+// exact for every n < 2^31 (n * (mul * d - 2^(32+shift)) < 2^(32+shift) because mul * d - 2^(32+shift) < d <= 2^(shift+1)). mul == 0: d == 1.
+struct RpDivU32 {
+    uint32_t mul, shift;
+};
+#ifdef __HIPCC__
+RP_DEV uint32_t rp_div(uint32_t n, RpDivU32 d) { return d.mul ? (__umulhi(n, d.mul) >> d.shift) : n; }
+#endif
+static inline RpDivU32 rp_make_div(uint32_t d) { // host side (rptr_hip.hip); d >= 1
+    RpDivU32 r{0u, 0u};
+    if (d <= 1u) return r;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l; // ceil(log2 d) >= 1
+    r.shift = l - 1u;
+    r.mul = (uint32_t)((((unsigned long long)1 << (32u + r.shift)) + d - 1u) / d);
+    return r;
+}
+
 // the per-frame constants: RenderParams + SceneParams + ViewParams subset
 // (vulkan/gpu_params.glsl:61-87,120-131) + this backend's tile mapping
 struct RpFrame {
@@ -93,12 +112,14 @@ struct RpFrame {
     int32_t sort_cells;          // cells per material group = 2^(sum of sort_bits)
     int32_t sort_bits[3];
     int32_t sort_num_keys;       // 1 + sort_groups * sort_cells
+    RpDivU32 div_npix_padded, div_tiles_x, div_stripe_rows, div_width; // rp_div by npix_padded / tiles_x / stripe_rows / width
 };
 
 // local tiled slot -> local pixel; false for padding lanes
 RP_DEV bool rp_slot_to_local(const RpFrame &f, uint32_t slot, int &lx, int &ly) {
     uint32_t tile = slot >> 6, in = slot & 63u;
-    int tx = int(tile % uint32_t(f.tiles_x)), ty = int(tile / uint32_t(f.tiles_x));
+    const uint32_t tyu = rp_div(tile, f.div_tiles_x);
+    int tx = int(tile - tyu * uint32_t(f.tiles_x)), ty = int(tyu);
     lx = tx * 8 + int(in & 7u);
     ly = ty * 8 + int(in >> 3);
     return lx < f.width && ly < f.local_rows;
@@ -108,7 +129,7 @@ RP_DEV uint32_t rp_local_to_slot(const RpFrame &f, int lx, int ly) {
 }
 // local row -> frame row (stripe s of `stripe_rows` rows belongs to rank s % world)
 RP_DEV int rp_local_row_to_global(const RpFrame &f, int ly) {
-    int stripe_local = ly / f.stripe_rows;
+    int stripe_local = int(rp_div(uint32_t(ly), f.div_stripe_rows));
     return (stripe_local * f.world + f.rank) * f.stripe_rows + (ly - stripe_local * f.stripe_rows);
 }
 

@@ -99,7 +99,7 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 // machine; when RP_REFILL_MIN or more lanes have finished their ray, the idle
 // lanes take the next pool entries (ballot + mbcnt rank, no atomics), so short
 // rays do not leave lanes idle while the longest ray of the wave finishes.
-//   Load(i, o, d, tmin, tmax)  fetches queue entry i
+//   Load(i, o, d, tmin, tmax)  fetches queue entry i; false = the entry names no ray, nothing is traced or consumed for it
 //   Done(i, hit)               consumes the result of entry i
 //   Alpha(i, inst_idx, inst_id, geom, prim, u, v) -> true = ignore this candidate (ALPHA only: the reference's
 //                              any-hit test of alpha-tested materials, pt_megakernel.glsl:153-212); called for the
@@ -234,7 +234,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 if (idle && rank < avail) {
                     my_i = pool_next + rank;
                     float tmax;
-                    load(my_i, ro, rd, tmin, tmax);
+                    if (load(my_i, ro, rd, tmin, tmax)) { // false: the entry names no ray (tile padding of the first queue): the lane stays idle
                     best.t = tmax;
                     best.u = best.v = 0.0f;
                     best.prim = best.geom = best.inst_idx = -1;
@@ -258,6 +258,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         cur = 0;
                     }
                     active = true;
+                    }
                 }
                 pool_next += min(nidle, avail);
             } else if (nidle == 64u)

@@ -88,10 +88,10 @@ RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *q
 // The camera ray of path p (pt_megakernel.glsl:314-325 + :330-352 pinhole branch): a pure function of the frame
 // constants and the path id, so nothing of it is stored -- the first extend and the first shade both call it
 // (saves writing and re-reading 72 bytes of path state per pixel sample). Returns false for padding slots.
-RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir) {
-    const uint32_t sslot = p / uint32_t(f.npix_padded);
+RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot) {
+    sslot = rp_div(p, f.div_npix_padded);
     const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
-    int lx = 0, ly = 0;
+    lx = ly = 0;
     if (!rp_slot_to_local(f, slot, lx, ly)) return false;
     const int gy = rp_local_row_to_global(f, ly);
     if (gy >= f.height) return false;
@@ -103,29 +103,19 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir)
     dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
     return true;
 }
-
-// The queue of the first bounce -- the ids of the pixel samples that exist (tile padding drops out) -- is never stored: its
-// entry i is a pure function of the frame's tiling. Sample slot after sample slot; inside a slot the 8x8 tiles row by row, the
-// pixels of a tile next to each other (64 consecutive entries = one full tile = one wave of camera rays). Every row a rank owns
-// exists in the frame (rptr_hip.hip local_row_count), so an entry is valid iff lx < width and ly < local_rows.
-RP_DEV uint32_t rp_first_path_id(const RpFrame &f, uint32_t i) {
-    const uint32_t per_slot = uint32_t(f.width) * uint32_t(f.local_rows);
-    const uint32_t sslot = i / per_slot;
-    uint32_t j = i - sslot * per_slot;
-    const uint32_t band = 8u * uint32_t(f.width); // pixels of a full row of tiles
-    const uint32_t ty = j / band;
-    j -= ty * band;
-    const uint32_t rh = min(8u, uint32_t(f.local_rows) - 8u * ty); // rows of this row of tiles
-    const uint32_t per_tile = rh * 8u;
-    const uint32_t tx = min(j / per_tile, uint32_t(f.tiles_x) - 1u);
-    j -= tx * per_tile;
-    const uint32_t cw = min(8u, uint32_t(f.width) - 8u * tx); // columns of this tile
-    const uint32_t r = j / cw, c = j - r * cw;
-    return sslot * uint32_t(f.npix_padded) + (ty * uint32_t(f.tiles_x) + tx) * 64u + r * 8u + c;
+RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir) {
+    int lx, ly;
+    uint32_t sslot;
+    return rp_primary_ray_ex(f, p, rng, dir, lx, ly, sslot);
 }
-// the same list in memory, for the opt-in regrouping pass (its kernels read a queue array)
-__global__ __launch_bounds__(256) void rp_k_first_queue(RpFrame f, uint32_t *queue, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = rp_first_path_id(f, i);
+
+// The queue of the first bounce is never stored: its entry i IS path id i (sample slot after sample slot, inside a slot the 8x8
+// tiles row by row: 64 consecutive entries = one tile = one wave of camera rays). Ids of the tile padding beyond the right / bottom
+// edge of a frame whose size is not a multiple of 8 name no pixel sample: rp_primary_ray returns false for them, the first extend
+// gives them an empty interval (nothing is traversed), the first shade skips them.
+// The same list in memory, for the opt-in regrouping pass (its kernels read a queue array):
+__global__ __launch_bounds__(256) void rp_k_first_queue(uint32_t *queue, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = i;
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
@@ -140,12 +130,16 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
     uint32_t lane_p = 0; // the path whose ray this lane traces
-    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
-        const uint32_t p = (FIRST && !queue) ? rp_first_path_id(f, i) : queue[i]; // FIRST: the first queue is computed (NULL) unless the caller stored it
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
+        const uint32_t p = (FIRST && !queue) ? i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
         lane_p = p;
         if (FIRST) {
-            uint32_t rng;
-            (void)rp_primary_ray(f, p, rng, rd); // the queue holds existing pixel samples only
+            uint32_t rng = 0;
+            rd = v3(0.0f, 0.0f, 1.0f);
+            if (!rp_primary_ray(f, p, rng, rd)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
+                ps.hit_ids[p] = make_int2(-1, -1);
+                return false;
+            }
             ro = ld3(f.cam_pos);
             tmin = 0.0f;
             tmax = 2.e32f;
@@ -158,6 +152,7 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             tmax = d.w;
             if (ALPHA) lane_rng = lane_rng_in = __float_as_uint(ps.rng_tt[p].x);
         }
+        return true;
     };
     auto done = [&](uint32_t, const RpHitRec &h) {
         const uint32_t p = lane_p;
@@ -200,7 +195,7 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
     uint32_t n_nodes = 0, n_tris = 0;
     auto alpha = [&](uint32_t i, int inst_idx, int inst_id, int geom, int prim, float u, float v) -> bool {
         const uint32_t p = ids[i];
-        const uint32_t sslot = p / uint32_t(f.npix_padded);
+        const uint32_t sslot = rp_div(p, f.div_npix_padded);
         const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
         int lx = 0, ly = 0;
         (void)rp_slot_to_local(f, slot, lx, ly);
@@ -208,13 +203,14 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
         uint32_t rng = rp_rng_seed(uint32_t(prim) ^ f.frame_id, uint32_t(inst_id) ^ f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, rng);
     };
-    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
         const uint32_t p = ids[i];
         const float4 o = sq.o[p], d = sq.d[p];
         ro = xyz(o);
         rd = xyz(d);
         tmin = o.w;
         tmax = d.w;
+        return true;
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
         if (h.inst_idx < 0) { // visible: NEE contribution arrives (nee.glsl:76-84)
@@ -426,7 +422,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             uint32_t pp = 0;
             bool is_hit = false;
             if (valid) {
-                pp = (FIRST && !order) ? rp_first_path_id(f, i) : order[i];
+                pp = (FIRST && !order) ? i : order[i];
                 is_hit = ps.hit_ids[pp].x >= 0;
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
@@ -463,20 +459,20 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             const int output_channel = f.rp.output_channel;
             const float sun_w = f.sp.sun_radiance[3];
             // ---------------- A
-            if (il < chunk_n) {
+            bool present = il < chunk_n; // this lane shades a path
+            int first_lx = 0, first_ly = 0;
+            uint32_t first_sslot = 0;
+            if (present) {
                 p = il < chunk_hits ? s_list[il] : s_list[RP_CHUNK - 1 - (il - chunk_hits)];
+                // bounce 0: the camera ray again; ids of tile padding name no pixel sample (the first queue is the identity)
+                if (FIRST) present = rp_primary_ray_ex(f, p, rng, ray_dir, first_lx, first_ly, first_sslot);
+            }
+            if (present) {
                 my_closest++;
-                if (FIRST) { // bounce 0: the camera ray again + init_shading_sample_state (shading_interface.glsl:20-22)
-                    (void)rp_primary_ray(f, p, rng, ray_dir);
+                if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
                     if (f.alpha_test) rng = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
-                    if (f.aov_albedo_roughness) { // the first sample of the frame writes the AOVs
-                        const uint32_t sslot = p / uint32_t(f.npix_padded);
-                        if (f.sample_base + sslot == f.frame_id) {
-                            int lx = 0, ly = 0;
-                            (void)rp_slot_to_local(f, p - sslot * uint32_t(f.npix_padded), lx, ly);
-                            aov_px = ly * f.width + lx;
-                        }
-                    }
+                    if (f.aov_albedo_roughness && f.sample_base + first_sslot == f.frame_id) // the first sample of the frame writes the AOVs
+                        aov_px = first_ly * f.width + first_lx;
                     ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
                     illum = v3s(0.0f);
@@ -868,7 +864,7 @@ RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
 __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb, float4 *out_accum, uchar4 *out_fb) {
     const int npix = f.width * f.local_rows;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        const int ly = i / f.width, lx = i - ly * f.width;
+        const int ly = int(rp_div(uint32_t(i), f.div_width)), lx = i - ly * f.width;
         if (rp_local_row_to_global(f, ly) >= f.height) continue;
         const uint32_t slot = rp_local_to_slot(f, lx, ly);
         float4 acc = accum[i];
@@ -908,13 +904,14 @@ template <bool COUNT, bool ANY, bool SINGLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, uint32_t n, float4 *results, uint32_t *cursor,
                                               int *gstack, uint2 *per_ray, const float *tmin_arr) {
     uint32_t nn = 0, nt = 0, nn_prev = 0, nt_prev = 0;
-    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) {
+    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
         const float4 *qp = reinterpret_cast<const float4 *>(queries + i);
         const float4 q0 = qp[0], q1 = qp[1];
         ro = v3(q0.x, q0.y, q0.z);
         rd = v3(q1.x, q1.y, q1.z);
         tmin = tmin_arr ? tmin_arr[i] : RPTR_RAY_EPSILON * len3(ro); // rt_intersect.comp:40
         tmax = __float_as_int(q0.w) < 0 ? -1.0f : q1.w;  // mode < 0: skipped query, empty interval
+        return true;
     };
     auto done = [&](uint32_t i, const RpHitRec &h) {
         if (COUNT && per_ray) { // the lane's counters run across its queries: report the difference

@@ -1618,6 +1618,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     f.rank = h->rank;
     f.world = h->world;
     f.stripe_rows = h->stripe_rows;
+    f.div_npix_padded = rp_make_div((uint32_t)h->npix_padded);
+    f.div_tiles_x = rp_make_div((uint32_t)h->tiles_x);
+    f.div_stripe_rows = rp_make_div((uint32_t)h->stripe_rows);
+    f.div_width = rp_make_div((uint32_t)h->width);
     f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
     // regrouping grid: material groups x hit cells, bits handed to the longest remaining axis
     {
@@ -1711,12 +1715,12 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
         f.batch_spp = batch;
         if (local_work) {
             HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
-            // the first bounce's queue is computed, not stored (kernels.h rp_first_path_id); only the opt-in regrouping pass, whose
-            // kernels read a queue array, gets it written out (into the queue buffer the first bounce leaves unused)
-            const uint32_t first_count = (uint32_t)((size_t)batch * h->width * h->local_rows);
+            // the first bounce's queue is the identity over the batch's path ids and is not stored (kernels.h); only the opt-in regrouping
+            // pass, whose kernels read a queue array, gets it written out (into the queue buffer the first bounce leaves unused)
+            const uint32_t first_count = (uint32_t)((size_t)batch * h->npix_padded);
             const uint32_t *first_ids = nullptr;
             if (do_sort) {
-                hipLaunchKernelGGL(rp_k_first_queue, dim3(grid_for(h, first_count)), dim3(256), 0, c.stream, f, c.queue[0], first_count);
+                hipLaunchKernelGGL(rp_k_first_queue, dim3(grid_for(h, first_count)), dim3(256), 0, c.stream, c.queue[0], first_count);
                 first_ids = c.queue[0];
             }
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
