@@ -67,6 +67,11 @@ extern "C" {
  *          "diffuse-only BSDF" of BASELINE.json configs[1].                     */
 #define RPTR_VARIANT_GLTF 0
 #define RPTR_VARIANT_SIMPLE 1
+/* GLTF_TRANSMISSION = the same BSDF built with GLTF_SUPPORT_TRANSMISSION + GLTF_SUPPORT_TRANSMISSION_ROUGHNESS (what the reference's
+ * MEGAKERNEL_MATERIALS / RT-pipeline hit groups compile, gltf_bsdf.glsl:10-13, vulkan/CMakeLists.txt:35-40): a third lobe for
+ * BaseMaterial.specular_transmission -- refraction through BASE_MATERIAL_ONESIDED surfaces, thin "double reflection" through
+ * two-sided ones; transmission roughness = roughness, reflection roughness = sqrt(clearcoat_gloss) (gltf_bsdf.glsl:38-62). */
+#define RPTR_VARIANT_GLTF_TRANSMISSION 2
 
 /* rendering/bsdfs/base_material.h.glsl:13-34 -- 80 bytes */
 typedef struct RptrBaseMaterial {

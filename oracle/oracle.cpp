@@ -825,8 +825,9 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
                 float *px = accum + 4 * ((size_t)y * a->width + x);
                 for (int si = 0; si < a->spp; ++si) {
                     uint32_t sample_index = uint32_t(a->sample_begin + si);
-                    vec4 c = (a->variant == RPTR_VARIANT_SIMPLE) ? main_spp<SimpleMaterial>(f, x, y, sample_index, pc)
-                                                                 : main_spp<GLTFMaterial>(f, x, y, sample_index, pc);
+                    vec4 c = (a->variant == RPTR_VARIANT_SIMPLE)              ? main_spp<SimpleMaterial>(f, x, y, sample_index, pc)
+                             : (a->variant == RPTR_VARIANT_GLTF_TRANSMISSION) ? main_spp<GLTFTransMaterial>(f, x, y, sample_index, pc)
+                                                                              : main_spp<GLTFMaterial>(f, x, y, sample_index, pc);
                     if (sample_index == 0) {
                         px[0] = c.x; px[1] = c.y; px[2] = c.z; px[3] = c.w;
                     } else {
@@ -985,9 +986,11 @@ void orc_dequantize_normal_uv(const uint64_t *q, int n, float *nrm, float *uv) {
     }
 }
 // sample_gltf_brdf / gltf_bsdf / gltf_wpdf for n (n, w_o, u_dir, u_lobe) tuples with one material
-void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *u4, int n, float *wi3, float *weight3,
-                     float *pdf, float *mis_pdf, float *f3, float *wpdf) {
-    GLTFMaterial mat;
+} // extern "C"
+template <class MAT>
+static void gltf_sample_probe(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *u4, int n, float *wi3, float *weight3, float *pdf,
+                              float *mis_pdf, float *f3, float *wpdf) {
+    MAT mat;
     vec3 emit;
     static const TextureTable no_textures; // probes take untextured materials
     unpack_material(no_textures, mat, emit, *m, vec2(0, 0));
@@ -1007,11 +1010,11 @@ void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo
         wpdf[i] = (p > 0) ? gltf_wpdf(mat, nn, wo, wi) : 0.0f;
     }
 }
-// evaluate gltf_bsdf and gltf_wpdf for explicit directions
-void orc_gltf_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
-    GLTFMaterial mat;
+template <class MAT>
+static void gltf_eval_probe(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
+    MAT mat;
     vec3 emit;
-    static const TextureTable no_textures; // probes take untextured materials
+    static const TextureTable no_textures;
     unpack_material(no_textures, mat, emit, *m, vec2(0, 0));
     for (int i = 0; i < n; ++i) {
         vec3 nn(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]), wo(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
@@ -1019,6 +1022,23 @@ void orc_gltf_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3,
         f3[3 * i] = fv.x; f3[3 * i + 1] = fv.y; f3[3 * i + 2] = fv.z;
         wpdf[i] = gltf_wpdf(mat, nn, wo, wi);
     }
+}
+extern "C" {
+void orc_gltf_sample(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *u4, int n, float *wi3, float *weight3,
+                     float *pdf, float *mis_pdf, float *f3, float *wpdf) {
+    gltf_sample_probe<GLTFMaterial>(m, n3, wo3, u4, n, wi3, weight3, pdf, mis_pdf, f3, wpdf);
+}
+// evaluate gltf_bsdf and gltf_wpdf for explicit directions
+void orc_gltf_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
+    gltf_eval_probe<GLTFMaterial>(m, n3, wo3, wi3, n, f3, wpdf);
+}
+// the same two probes for the build with the transmission lobe (RPTR_VARIANT_GLTF_TRANSMISSION)
+void orc_gltf_t_sample(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *u4, int n, float *wi3, float *weight3,
+                       float *pdf, float *mis_pdf, float *f3, float *wpdf) {
+    gltf_sample_probe<GLTFTransMaterial>(m, n3, wo3, u4, n, wi3, weight3, pdf, mis_pdf, f3, wpdf);
+}
+void orc_gltf_t_eval(const RptrBaseMaterial *m, const float *n3, const float *wo3, const float *wi3, int n, float *f3, float *wpdf) {
+    gltf_eval_probe<GLTFTransMaterial>(m, n3, wo3, wi3, n, f3, wpdf);
 }
 void orc_sky_radiance(const RptrSkyModelParams *sky, const float sun_dir[3], const float *dirs3, int n, float *out3) {
     for (int i = 0; i < n; ++i) {

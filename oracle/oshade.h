@@ -594,6 +594,298 @@ static inline vec3 sample_simple_brdf(const SimpleMaterial &mat, const vec3 n, c
     return mat.base_color;
 }
 
+// ---------------------------------------------------------------- glTF BSDF with the transmission lobe
+// rendering/bsdfs/gltf_bsdf.glsl compiled with GLTF_SUPPORT_TRANSMISSION + GLTF_SUPPORT_TRANSMISSION_ROUGHNESS (what
+// MEGAKERNEL_MATERIALS switches on, :10-13; the RT-pipeline hit groups of vulkan/CMakeLists.txt:35-40 build it). Three components:
+// diffuse, GGX reflection, GGX transmission -- through a ONESIDED surface a refraction (w_h = -ior w_i - w_o, angle compression),
+// through a two-sided one the "thin" double reflection w_i = reflect(reflect(-w_o, w_h), n).
+struct GLTFTransMaterial { // :15-35
+    vec3 base_color;
+    float metallic;
+    float specular;
+    float roughness;
+    float ior;
+    float transmission_roughness;
+    float specular_transmission;
+    vec3 transmission_color;
+    uint32_t flags;
+};
+// GLSL refract(I, N, eta)
+static inline vec3 refract(vec3 I, vec3 N, float eta) {
+    const float d = dot(N, I);
+    const float k = 1.0f - (eta * eta) * (1.0f - d * d);
+    if (k < 0.0f) return vec3(0.0f);
+    return eta * I - (eta * d + sqrtf(k)) * N;
+}
+// material_textures.glsl:95-135 + load_material gltf_bsdf.glsl:38-62
+static inline float unpack_material(const TextureTable &tt, GLTFTransMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+    GLTFMaterial base;
+    float alpha = unpack_material(tt, base, emitter_radiance, p, uv);
+    mat.base_color = base.base_color;
+    mat.metallic = base.metallic;
+    mat.specular = base.specular;
+    mat.roughness = base.roughness;
+    mat.ior = base.ior;
+    mat.flags = base.flags;
+    mat.transmission_roughness = 0.0f;
+    mat.transmission_color = vec3(0.0f);
+    mat.specular_transmission = textured_scalar_param(tt, p.specular_transmission, uv);
+    if (mat.specular_transmission > 0.0f) {
+        if (!(mat.ior > 1.0f)) {
+            alpha *= 1.0f - mat.specular_transmission;
+            mat.specular_transmission = 0.0f;
+        } else {
+            mat.transmission_color = mat.base_color;
+            mat.transmission_roughness = mat.roughness;
+            mat.roughness = sqrtf(textured_scalar_param(tt, p.clearcoat_gloss, uv));
+        }
+    } else
+        mat.transmission_color = vec3(0.0f);
+    return alpha;
+}
+static inline vec3 gltf_diffuse_basecolor(const GLTFTransMaterial &mat) { return (1.0f - mat.metallic) * mat.base_color; }
+static inline vec3 gltf_specular_basecolor(const GLTFTransMaterial &mat, float ior) {
+    vec3 dielectric_base = vec3(pow2((ior - 1.0f) / (ior + 1.0f)));
+    return mix(dielectric_base, mat.base_color, mat.metallic);
+}
+static inline float gltf_specular_alpha(const GLTFTransMaterial &mat) { return fmaxf(mat.roughness * mat.roughness, 0.002f); }
+static inline float gltf_transmission_alpha(const GLTFTransMaterial &mat) { return fmaxf(mat.transmission_roughness * mat.transmission_roughness, 0.002f); } // :278-282
+// :294-359
+static inline vec3 gltf_bsdf(const GLTFTransMaterial &mat, const vec3 n, const vec3 w_o, const vec3 w_i) {
+    float i_dot_n = dot(n, w_i);
+    float o_dot_n = dot(n, w_o);
+    float ior = o_dot_n < 0.0f ? 1.0f / mat.ior : mat.ior;
+    vec3 w_h;
+    if (i_dot_n * o_dot_n < 0.0f) {
+        if (!(mat.specular_transmission > 0.f))
+            return vec3(0.0f);
+        if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0)
+            w_h = -ior * w_i - w_o;
+        else
+            w_h = reflect(w_i, n) + w_o;
+        if (!(dot(w_h, n) > 0.0f))
+            return vec3(0.0f);
+    } else
+        w_h = w_i + w_o;
+    w_h = normalize(w_h);
+    float o_dot_h = dot(w_o, w_h), i_dot_h = dot(w_i, w_h);
+    vec3 diffuse = gltf_diffuse_basecolor(mat) * float(M_1_PIf);
+    vec3 specular = vec3(0.0f);
+    if (mat.ior > 1.0f) {
+        vec3 f0 = gltf_specular_basecolor(mat, mat.ior);
+        float specular_alpha = gltf_specular_alpha(mat);
+        if (i_dot_n * o_dot_n < 0.0f)
+            specular_alpha = gltf_transmission_alpha(mat);
+        float specular_refl = gtr_2(dot(n, w_h), specular_alpha);
+        specular_refl *= smith_visibility_ggx(o_dot_n, i_dot_n, specular_alpha);
+        float f_weight = gltf_schlick_weight(fabsf(o_dot_h), ior);
+        vec3 F = mix(f0, vec3(1.0f), f_weight);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            diffuse = vec3(0.0f);
+            specular = ((specular_refl * (1.f - mat.metallic)) * mat.specular_transmission) * mat.transmission_color * (vec3(1.0f) - F);
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0) { // transmission angle compression
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular *= angle_compression * angle_compression;
+            }
+        } else {
+            diffuse *= (1.0f - mat.specular_transmission);
+            diffuse *= (vec3(1.0f) - F);
+            specular = specular_refl * F;
+        }
+    }
+    return diffuse + specular;
+}
+// :366-394 (GLTF_COMPONENT_COUNT = 3)
+struct GLTFComponentSampler3 {
+    float weights[3];
+};
+static inline GLTFComponentSampler3 gltf_component_sampler(const GLTFTransMaterial &mat, float ior, vec4 o_dot_h, vec4 visibility) {
+    GLTFComponentSampler3 components;
+    float specular_base_lum = luminance(gltf_specular_basecolor(mat, mat.ior));
+    float F0 = mix(specular_base_lum, 1.0f, gltf_schlick_weight(o_dot_h.x, 1.0f));
+    float F1 = mix(specular_base_lum, 1.0f, gltf_schlick_weight(o_dot_h.y, 1.0f));
+    float F2 = mix(specular_base_lum, 1.0f, gltf_schlick_weight(o_dot_h.z, ior));
+    components.weights[0] = (1.0f - F0) * visibility.x * (1.0f - mat.metallic) * luminance(gltf_diffuse_basecolor(mat));
+    components.weights[1] = F1 * visibility.y;
+    components.weights[0] *= (1.0f - mat.specular_transmission);
+    components.weights[2] = (1.0f - F2) * visibility.z * (1.0f - mat.metallic) * mat.specular_transmission;
+    float weight_sum = 0.0f;
+    for (int i = 0; i < 3; ++i)
+        weight_sum += components.weights[i];
+    if (weight_sum > 0.0f) {
+        for (int i = 0; i < 3; ++i)
+            components.weights[i] /= weight_sum;
+    } else
+        components.weights[0] = 1.0f;
+    return components;
+}
+static inline int glft_sample_reuse_component(const GLTFComponentSampler3 &components, float &rnd, float &component_probability) { // :395-409
+    int component = 0;
+    float next_layer_p_base = 0.0f, layer_p_base = 0.0f;
+    for (int i = 0; i < 3; ++i) {
+        float layer_p = components.weights[i];
+        if (layer_p > 0.0f && rnd >= next_layer_p_base) {
+            component = i;
+            component_probability = layer_p;
+            layer_p_base = next_layer_p_base;
+        }
+        next_layer_p_base += layer_p;
+    }
+    rnd = fminf(1.0f, (rnd - layer_p_base) / component_probability);
+    return component;
+}
+// :414-494
+static inline float gltf_wpdf(const GLTFTransMaterial &mat, const vec3 n, const vec3 w_o, const vec3 w_i) {
+    float i_dot_n = dot(n, w_i);
+    float o_dot_n = dot(n, w_o);
+    float ior = o_dot_n < 0.0f ? 1.0f / mat.ior : mat.ior;
+    float pdf = M_1_PIf * fabsf(i_dot_n);
+    if (mat.ior > 1.0f) {
+        vec3 w_h;
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if (!(mat.specular_transmission > 0.f))
+                return 0.0f;
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0)
+                w_h = -ior * w_i - w_o;
+            else
+                w_h = reflect(w_i, n) + w_o;
+            if (!(dot(w_h, n) > 0.0f))
+                return 0.0f;
+        } else
+            w_h = w_i + w_o;
+        w_h = normalize(w_h);
+        float o_dot_h = dot(w_o, w_h), i_dot_h = dot(w_i, w_h);
+        float cos_theta_h = dot(w_h, n);
+        vec4 visibility = vec4(0.0f);
+        visibility.x = 1.0f;
+        float specular_alpha = gltf_specular_alpha(mat);
+        visibility.y = 2.0f * fabsf(i_dot_n) / smith_visibility_den1(i_dot_n, specular_alpha * specular_alpha);
+        visibility.z = visibility.y;
+        float transmission_alpha = specular_alpha;
+        if (mat.specular_transmission > 0.f) {
+            transmission_alpha = gltf_transmission_alpha(mat);
+            visibility.z = 2.0f * fabsf(i_dot_n) / smith_visibility_den1(i_dot_n, transmission_alpha * transmission_alpha);
+        }
+        GLTFComponentSampler3 components = gltf_component_sampler(mat, ior, vec4(fabsf(o_dot_h)), visibility);
+        if (i_dot_n * o_dot_n < 0.0f)
+            specular_alpha = transmission_alpha;
+        float specular = gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0) {
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular *= angle_compression * angle_compression;
+            }
+            pdf = specular * components.weights[2];
+        } else {
+            pdf *= components.weights[0];
+            pdf += specular * components.weights[1];
+        }
+    }
+    return pdf;
+}
+// :496-645
+static inline vec3 sample_gltf_brdf(const GLTFTransMaterial &mat, const vec3 n, const vec3 w_o, vec3 &w_i, float &pdf,
+                                    float &mis_wpdf, vec2 rng_sample, vec2 fresnel_sample, const vec3 v_x, const vec3 v_y) {
+    vec3 w_o_local = transpose(mat3(v_x, v_y, n)) * w_o;
+    float o_dot_n = w_o_local.z;
+    float ior = o_dot_n < 0.0f ? 1.0f / mat.ior : mat.ior;
+    if (o_dot_n < 0.0f)
+        w_o_local.z = -w_o_local.z;
+    vec3 UP = to_pipe_sample(rng_sample);
+    vec3 w_i_diffuse = normalize(n + sample_sphere(UP));
+    if (o_dot_n < 0.0f)
+        w_i_diffuse = -w_i_diffuse;
+    float specular_alpha = gltf_specular_alpha(mat);
+    int component = 0;
+    float component_selection_pdf = 0.0f;
+    GLTFComponentSampler3 components;
+    components.weights[0] = components.weights[1] = components.weights[2] = 0.0f;
+    vec3 w_h_specular_local;
+    vec3 w_h_transmission_local;
+    if (mat.ior > 1.0f) {
+        vec4 o_dot_h_all = vec4(0.0f);
+        vec4 visibility_all = vec4(0.0f);
+        o_dot_h_all.x = cos_half_angle(dot(w_o, w_i_diffuse));
+        visibility_all.x = 1.0f;
+        w_h_specular_local = sample_gtr_2_vndf(w_o_local, vec2(specular_alpha), UP);
+        o_dot_h_all.y = dot(w_o_local, w_h_specular_local);
+        float spec_i_dot_n_local = reflect(-w_o_local, w_h_specular_local).z;
+        visibility_all.y = spec_i_dot_n_local > 0.0f
+                               ? 2.0f * spec_i_dot_n_local / smith_visibility_den1(spec_i_dot_n_local, specular_alpha * specular_alpha)
+                               : 0.0f;
+        float transmission_alpha = specular_alpha;
+        w_h_transmission_local = w_h_specular_local;
+        o_dot_h_all.z = o_dot_h_all.y;
+        float trans_i_dot_n_local = spec_i_dot_n_local;
+        if (mat.specular_transmission > 0.f) {
+            transmission_alpha = gltf_transmission_alpha(mat);
+            w_h_transmission_local = sample_gtr_2_vndf(w_o_local, vec2(transmission_alpha), UP);
+            o_dot_h_all.z = dot(w_o_local, w_h_transmission_local);
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0)
+                trans_i_dot_n_local = -refract(-w_o_local, w_h_transmission_local, 1.0f / ior).z;
+            else
+                trans_i_dot_n_local = reflect(-w_o_local, w_h_transmission_local).z;
+            visibility_all.z = trans_i_dot_n_local > 0.0f
+                                   ? 2.0f * trans_i_dot_n_local / smith_visibility_den1(trans_i_dot_n_local, transmission_alpha * transmission_alpha)
+                                   : 0.0f;
+        }
+        components = gltf_component_sampler(mat, ior, o_dot_h_all, visibility_all);
+        component = glft_sample_reuse_component(components, fresnel_sample.x, component_selection_pdf);
+    }
+    float cos_theta_h;
+    float i_dot_h;
+    float o_dot_h;
+    if (component == 0) {
+        w_i = w_i_diffuse;
+        vec3 w_h = normalize(w_i + w_o);
+        cos_theta_h = dot(n, w_h);
+        i_dot_h = o_dot_h = dot(w_o, w_h);
+    } else {
+        if (component == 2) {
+            specular_alpha = gltf_transmission_alpha(mat);
+            w_h_specular_local = w_h_transmission_local;
+        }
+        vec3 w_h = w_h_specular_local;
+        if (o_dot_n < 0.0f)
+            w_h.z = -w_h.z;
+        cos_theta_h = w_h.z;
+        w_h = mat3(v_x, v_y, n) * w_h;
+        i_dot_h = o_dot_h = dot(w_o, w_h);
+        if (component != 1) {
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0) {
+                w_i = refract(-w_o, w_h, 1.0f / ior);
+                i_dot_h = dot(w_i, w_h);
+            } else
+                w_i = reflect(reflect(-w_o, w_h), n);
+        } else
+            w_i = reflect(-w_o, w_h);
+    }
+    float i_dot_n = dot(n, w_i);
+    if ((i_dot_n * o_dot_n > 0.0f) != (component != 2)) {
+        pdf = 0.0f;
+        return vec3(0.0f);
+    }
+    float diffuse = M_1_PIf * fabsf(i_dot_n);
+    pdf = diffuse;
+    if (mat.ior > 1.0f) {
+        pdf *= components.weights[0];
+        float specular = gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if ((mat.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0) {
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular *= angle_compression * angle_compression;
+            }
+            pdf = specular * components.weights[2];
+        } else
+            pdf += specular * components.weights[1];
+    }
+    if (!(pdf > 0.0f))
+        return vec3(0.0f);
+    vec3 result = gltf_bsdf(mat, n, w_o, w_i);
+    mis_wpdf = gltf_wpdf(mat, n, w_o, w_i);
+    return result * fabsf(i_dot_n) / pdf;
+}
+
 // material registration (gltf_bsdf.glsl:649-655, simple_bsdf.glsl:98-104)
 struct InteractionPoint { // rendering/bsdfs/hit_point.glsl:14-21
     vec3 p, gn, n, v_x, v_y;
@@ -602,6 +894,12 @@ struct InteractionPoint { // rendering/bsdfs/hit_point.glsl:14-21
 static inline vec3 eval_bsdf(const GLTFMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 w_i) { return gltf_bsdf(m, h.n, w_o, w_i); }
 static inline float eval_bsdf_wpdf(const GLTFMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 w_i) { return gltf_wpdf(m, h.n, w_o, w_i); }
 static inline vec3 sample_bsdf(const GLTFMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 &w_i, float &pdf, float &mis,
+                               vec2 rn_dir, vec2 rn_lobe) {
+    return sample_gltf_brdf(m, h.n, w_o, w_i, pdf, mis, rn_dir, rn_lobe, h.v_x, h.v_y);
+}
+static inline vec3 eval_bsdf(const GLTFTransMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 w_i) { return gltf_bsdf(m, h.n, w_o, w_i); }
+static inline float eval_bsdf_wpdf(const GLTFTransMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 w_i) { return gltf_wpdf(m, h.n, w_o, w_i); }
+static inline vec3 sample_bsdf(const GLTFTransMaterial &m, const InteractionPoint &h, vec3 w_o, vec3 &w_i, float &pdf, float &mis,
                                vec2 rn_dir, vec2 rn_lobe) {
     return sample_gltf_brdf(m, h.n, w_o, w_i, pdf, mis, rn_dir, rn_lobe, h.v_x, h.v_y);
 }

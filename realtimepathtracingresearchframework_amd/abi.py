@@ -14,7 +14,8 @@ RPTR_E_HIP = -5
 
 VARIANT_GLTF = 0
 VARIANT_SIMPLE = 1
-VARIANT_NAMES = ["wavefront-gltf", "wavefront-diffuse"]
+VARIANT_GLTF_TRANSMISSION = 2
+VARIANT_NAMES = ["wavefront-gltf", "wavefront-diffuse", "wavefront-gltf-transmission"]
 
 BASE_MATERIAL_NOALPHA = 0x01
 BASE_MATERIAL_ONESIDED = 0x02

@@ -203,7 +203,7 @@ class RenderHip:
         self.scene_params = sp
 
     def configure_for(self, options=None, variant_idx=0):
-        if variant_idx not in (abi.VARIANT_GLTF, abi.VARIANT_SIMPLE):
+        if variant_idx not in (abi.VARIANT_GLTF, abi.VARIANT_SIMPLE, abi.VARIANT_GLTF_TRANSMISSION):
             return False
         self._variant = variant_idx
         return True

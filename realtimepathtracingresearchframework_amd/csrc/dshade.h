@@ -328,6 +328,9 @@ struct RpMaterial { // GLTFMaterial (gltf_bsdf.glsl:15-35) / SimpleMaterial (sim
     V3 base_color;
     float metallic, specular, roughness, ior;
     uint32_t flags;
+    // RPTR_VARIANT_GLTF_TRANSMISSION only (GLTF_SUPPORT_TRANSMISSION[_ROUGHNESS])
+    float transmission_roughness, specular_transmission;
+    V3 transmission_color;
 };
 // ---- texture sampling: textureLod(sampler2D, uv, 0) of the reference's material sampler (linear filter, REPEAT,
 // render_vulkan.cpp:1657-1670), in software: texel centres at (i + 0.5) / size, bilinear weights in float,
@@ -409,6 +412,20 @@ RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_rad
     if (p.emission_intensity != 0.0f) {
         if (TEX && rp_is_textured(p.base_color[0])) emitter_radiance = m.base_color * p.emission_intensity;
         m.base_color = v3s(0.0f);
+    }
+    if (VARIANT == RPTR_VARIANT_GLTF_TRANSMISSION) { // load_material, gltf_bsdf.glsl:38-62
+        m.transmission_roughness = 0.0f;
+        m.transmission_color = v3s(0.0f);
+        m.specular_transmission = TEX ? rp_textured_scalar_param(sc, p.specular_transmission, uv) : p.specular_transmission;
+        if (m.specular_transmission > 0.0f) {
+            if (!(m.ior > 1.0f))
+                m.specular_transmission = 0.0f; // (the reference folds it into the alpha it returns, which nothing reads any more)
+            else {
+                m.transmission_color = m.base_color;
+                m.transmission_roughness = m.roughness;
+                m.roughness = sqrtf(TEX ? rp_textured_scalar_param(sc, p.clearcoat_gloss, uv) : p.clearcoat_gloss);
+            }
+        }
     }
     m.flags = p.flags;
 }
@@ -581,6 +598,223 @@ RP_DEV V3 rp_sample_gltf_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, float 
     return result * fabsf(i_dot_n) / pdf;
 }
 
+// ------------------------------------------------------------------ glTF BSDF with the transmission lobe
+// gltf_bsdf.glsl built with GLTF_SUPPORT_TRANSMISSION + GLTF_SUPPORT_TRANSMISSION_ROUGHNESS (RPTR_VARIANT_GLTF_TRANSMISSION): three
+// components -- diffuse, GGX reflection, GGX transmission (refraction through ONESIDED surfaces, thin double reflection otherwise)
+RP_DEV V3 rp_refract3(V3 I, V3 N, float eta) { // GLSL refract
+    const float d = dot3(N, I);
+    const float k = 1.0f - (eta * eta) * (1.0f - d * d);
+    if (k < 0.0f) return v3s(0.0f);
+    return eta * I - (eta * d + sqrtf(k)) * N;
+}
+RP_DEV float rp_gltf_transmission_alpha(const RpMaterial &m) { return fmaxf(m.transmission_roughness * m.transmission_roughness, 0.002f); } // :278-282
+RP_DEV V3 rp_gltf_t_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :294-359
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
+    V3 w_h;
+    if (i_dot_n * o_dot_n < 0.0f) {
+        if (!(m.specular_transmission > 0.f)) return v3s(0.0f);
+        if (onesided)
+            w_h = (-ior) * w_i - w_o;
+        else
+            w_h = reflect3(w_i, n) + w_o;
+        if (!(dot3(w_h, n) > 0.0f)) return v3s(0.0f);
+    } else
+        w_h = w_i + w_o;
+    w_h = norm3(w_h);
+    float o_dot_h = dot3(w_o, w_h), i_dot_h = dot3(w_i, w_h);
+    V3 diffuse = rp_gltf_diffuse_basecolor(m) * RP_1_PI;
+    V3 specular = v3s(0.0f);
+    if (m.ior > 1.0f) {
+        V3 f0 = rp_gltf_specular_basecolor(m, m.ior);
+        float specular_alpha = rp_gltf_specular_alpha(m);
+        if (i_dot_n * o_dot_n < 0.0f) specular_alpha = rp_gltf_transmission_alpha(m);
+        float specular_refl = rp_gtr_2(dot3(n, w_h), specular_alpha);
+        specular_refl *= rp_smith_ggx(o_dot_n, i_dot_n, specular_alpha);
+        float f_weight = rp_gltf_schlick_weight(fabsf(o_dot_h), ior);
+        V3 F = mix3(f0, v3s(1.0f), f_weight);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            diffuse = v3s(0.0f);
+            specular = ((specular_refl * (1.f - m.metallic)) * m.specular_transmission) * m.transmission_color * (v3s(1.0f) - F);
+            if (onesided) { // transmission angle compression
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular = specular * (angle_compression * angle_compression);
+            }
+        } else {
+            diffuse = diffuse * (1.0f - m.specular_transmission);
+            diffuse = diffuse * (v3s(1.0f) - F);
+            specular = specular_refl * F;
+        }
+    }
+    return diffuse + specular;
+}
+struct RpLobes3 {
+    float w0, w1, w2;
+};
+RP_DEV RpLobes3 rp_gltf_t_component_sampler(const RpMaterial &m, float ior, float odh_x, float odh_y, float odh_z, float vis_x, float vis_y, float vis_z) { // :366-394
+    RpLobes3 c;
+    float specular_base_lum = luminance3(rp_gltf_specular_basecolor(m, m.ior));
+    float F0 = mixf(specular_base_lum, 1.0f, rp_gltf_schlick_weight(odh_x, 1.0f));
+    float F1 = mixf(specular_base_lum, 1.0f, rp_gltf_schlick_weight(odh_y, 1.0f));
+    float F2 = mixf(specular_base_lum, 1.0f, rp_gltf_schlick_weight(odh_z, ior));
+    c.w0 = (1.0f - F0) * vis_x * (1.0f - m.metallic) * luminance3(rp_gltf_diffuse_basecolor(m));
+    c.w1 = F1 * vis_y;
+    c.w0 *= (1.0f - m.specular_transmission);
+    c.w2 = (1.0f - F2) * vis_z * (1.0f - m.metallic) * m.specular_transmission;
+    float weight_sum = 0.0f;
+    weight_sum += c.w0;
+    weight_sum += c.w1;
+    weight_sum += c.w2;
+    if (weight_sum > 0.0f) {
+        c.w0 /= weight_sum;
+        c.w1 /= weight_sum;
+        c.w2 /= weight_sum;
+    } else
+        c.w0 = 1.0f;
+    return c;
+}
+RP_DEV float rp_gltf_t_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :414-494
+    float i_dot_n = dot3(n, w_i);
+    float o_dot_n = dot3(n, w_o);
+    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
+    float pdf = RP_1_PI * fabsf(i_dot_n);
+    if (m.ior > 1.0f) {
+        V3 w_h;
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if (!(m.specular_transmission > 0.f)) return 0.0f;
+            if (onesided)
+                w_h = (-ior) * w_i - w_o;
+            else
+                w_h = reflect3(w_i, n) + w_o;
+            if (!(dot3(w_h, n) > 0.0f)) return 0.0f;
+        } else
+            w_h = w_i + w_o;
+        w_h = norm3(w_h);
+        float o_dot_h = dot3(w_o, w_h), i_dot_h = dot3(w_i, w_h);
+        float cos_theta_h = dot3(w_h, n);
+        float specular_alpha = rp_gltf_specular_alpha(m);
+        float vis_y = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, specular_alpha * specular_alpha);
+        float vis_z = vis_y;
+        float transmission_alpha = specular_alpha;
+        if (m.specular_transmission > 0.f) {
+            transmission_alpha = rp_gltf_transmission_alpha(m);
+            vis_z = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, transmission_alpha * transmission_alpha);
+        }
+        RpLobes3 c = rp_gltf_t_component_sampler(m, ior, fabsf(o_dot_h), fabsf(o_dot_h), fabsf(o_dot_h), 1.0f, vis_y, vis_z);
+        if (i_dot_n * o_dot_n < 0.0f) specular_alpha = transmission_alpha;
+        float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if (onesided) {
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular *= angle_compression * angle_compression;
+            }
+            pdf = specular * c.w2;
+        } else {
+            pdf *= c.w0;
+            pdf += specular * c.w1;
+        }
+    }
+    return pdf;
+}
+RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, float &pdf, float &mis_wpdf, V2 rng_sample, V2 fresnel_sample, V3 v_x,
+                                V3 v_y) { // :496-645
+    M3 frame{v_x, v_y, n};
+    V3 w_o_local = mul_t(frame, w_o);
+    float o_dot_n = w_o_local.z;
+    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
+    mis_wpdf = 0.0f;
+    if (o_dot_n < 0.0f) w_o_local.z = -w_o_local.z;
+    V3 UP = rp_to_pipe_sample(rng_sample);
+    V3 w_i_diffuse = norm3(n + rp_sample_sphere(UP));
+    if (o_dot_n < 0.0f) w_i_diffuse = -w_i_diffuse;
+    float specular_alpha = rp_gltf_specular_alpha(m);
+    int component = 0;
+    RpLobes3 lobes{0.0f, 0.0f, 0.0f};
+    V3 w_h_specular_local = v3s(0.0f), w_h_transmission_local = v3s(0.0f);
+    if (m.ior > 1.0f) {
+        float odh_x = rp_cos_half_angle(dot3(w_o, w_i_diffuse));
+        w_h_specular_local = rp_sample_gtr_2_vndf(w_o_local, specular_alpha, UP);
+        float odh_y = dot3(w_o_local, w_h_specular_local);
+        float spec_i_dot_n_local = reflect3(-w_o_local, w_h_specular_local).z;
+        float vis_y = spec_i_dot_n_local > 0.0f ? 2.0f * spec_i_dot_n_local / rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha) : 0.0f;
+        float transmission_alpha = specular_alpha;
+        w_h_transmission_local = w_h_specular_local;
+        float odh_z = odh_y;
+        float trans_i_dot_n_local = spec_i_dot_n_local;
+        float vis_z = 0.0f;
+        if (m.specular_transmission > 0.f) {
+            transmission_alpha = rp_gltf_transmission_alpha(m);
+            w_h_transmission_local = rp_sample_gtr_2_vndf(w_o_local, transmission_alpha, UP);
+            odh_z = dot3(w_o_local, w_h_transmission_local);
+            if (onesided)
+                trans_i_dot_n_local = -rp_refract3(-w_o_local, w_h_transmission_local, 1.0f / ior).z;
+            else
+                trans_i_dot_n_local = reflect3(-w_o_local, w_h_transmission_local).z;
+            vis_z = trans_i_dot_n_local > 0.0f ? 2.0f * trans_i_dot_n_local / rp_smith_den1(trans_i_dot_n_local, transmission_alpha * transmission_alpha) : 0.0f;
+        }
+        lobes = rp_gltf_t_component_sampler(m, ior, odh_x, odh_y, odh_z, 1.0f, vis_y, vis_z);
+        // glft_sample_reuse_component (:395-409), 3 components, only the index is used afterwards
+        float rnd = fresnel_sample.x;
+        float next_base = 0.0f;
+        if (lobes.w0 > 0.0f && rnd >= next_base) component = 0;
+        next_base += lobes.w0;
+        if (lobes.w1 > 0.0f && rnd >= next_base) component = 1;
+        next_base += lobes.w1;
+        if (lobes.w2 > 0.0f && rnd >= next_base) component = 2;
+    }
+    float cos_theta_h, i_dot_h, o_dot_h;
+    if (component == 0) {
+        w_i = w_i_diffuse;
+        V3 w_h = norm3(w_i + w_o);
+        cos_theta_h = dot3(n, w_h);
+        i_dot_h = o_dot_h = dot3(w_o, w_h);
+    } else {
+        if (component == 2) {
+            specular_alpha = rp_gltf_transmission_alpha(m);
+            w_h_specular_local = w_h_transmission_local;
+        }
+        V3 w_h = w_h_specular_local;
+        if (o_dot_n < 0.0f) w_h.z = -w_h.z; // flip into the original frame if necessary
+        cos_theta_h = w_h.z;
+        w_h = mul(frame, w_h);
+        i_dot_h = o_dot_h = dot3(w_o, w_h);
+        if (component != 1) {
+            if (onesided) {
+                w_i = rp_refract3(-w_o, w_h, 1.0f / ior);
+                i_dot_h = dot3(w_i, w_h);
+            } else
+                w_i = reflect3(reflect3(-w_o, w_h), n);
+        } else
+            w_i = reflect3(-w_o, w_h);
+    }
+    float i_dot_n = dot3(n, w_i);
+    if ((i_dot_n * o_dot_n > 0.0f) != (component != 2)) {
+        pdf = 0.0f;
+        return v3s(0.0f);
+    }
+    pdf = RP_1_PI * fabsf(i_dot_n);
+    if (m.ior > 1.0f) {
+        pdf *= lobes.w0;
+        float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
+        if (i_dot_n * o_dot_n < 0.0f) {
+            if (onesided) {
+                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                specular *= angle_compression * angle_compression;
+            }
+            pdf = specular * lobes.w2;
+        } else
+            pdf += specular * lobes.w1;
+    }
+    if (!(pdf > 0.0f)) return v3s(0.0f);
+    V3 result = rp_gltf_t_bsdf(m, n, w_o, w_i);
+    mis_wpdf = rp_gltf_t_wpdf(m, n, w_o, w_i);
+    return result * fabsf(i_dot_n) / pdf;
+}
+
 // ------------------------------------------------------------------ Lambert BSDF, rendering/bsdfs/simple_bsdf.glsl
 RP_DEV V3 rp_simple_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :44-59
     float i_dot_n = dot3(n, w_i);
@@ -610,10 +844,12 @@ RP_DEV V3 rp_sample_simple_brdf(const RpMaterial &m, V3 n, V3 &w_i, float &pdf, 
 // material registration (gltf_bsdf.glsl:649-655, simple_bsdf.glsl:98-104)
 template <int VARIANT>
 RP_DEV V3 rp_eval_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) {
+    if (VARIANT == RPTR_VARIANT_GLTF_TRANSMISSION) return rp_gltf_t_bsdf(m, n, w_o, w_i);
     return VARIANT == RPTR_VARIANT_SIMPLE ? rp_simple_bsdf(m, n, w_o, w_i) : rp_gltf_bsdf(m, n, w_o, w_i);
 }
 template <int VARIANT>
 RP_DEV float rp_eval_bsdf_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) {
+    if (VARIANT == RPTR_VARIANT_GLTF_TRANSMISSION) return rp_gltf_t_wpdf(m, n, w_o, w_i);
     return VARIANT == RPTR_VARIANT_SIMPLE ? rp_simple_pdf(n, w_o, w_i) : rp_gltf_wpdf(m, n, w_o, w_i);
 }
 

@@ -688,6 +688,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     V3 bsdf;
                     if (VARIANT == RPTR_VARIANT_SIMPLE)
                         bsdf = rp_sample_simple_brdf(mat, nn, w_i, sampling_pdf, mis_pdf, dir_sample2);
+                    else if (VARIANT == RPTR_VARIANT_GLTF_TRANSMISSION)
+                        bsdf = rp_sample_gltf_t_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample2, lobe_sample, v_x, v_y);
                     else
                         bsdf = rp_sample_gltf_brdf(mat, nn, w_o, w_i, sampling_pdf, mis_pdf, dir_sample2, lobe_sample, v_x, v_y);
                     ++bounce;

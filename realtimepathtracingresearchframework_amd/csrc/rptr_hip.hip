@@ -1575,7 +1575,8 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "render before set_scene");
     if (h->width == 0) return fail(h, RPTR_E_INVALID, "render before initialize");
-    if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE) return fail(h, RPTR_E_INVALID, "unknown variant %d", variant);
+    if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE && variant != RPTR_VARIANT_GLTF_TRANSMISSION)
+        return fail(h, RPTR_E_INVALID, "unknown variant %d", variant);
     if (spp < 1) return fail(h, RPTR_E_INVALID, "spp must be >= 1");
     HIP_TRY(h, hipSetDevice(h->device));
     FrameCtx &c = h->ctx[(size_t)h->next_ctx];
@@ -1740,16 +1741,19 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                         timed_kernel(c.stream, 3, kernel, dim3(h->tail_blocks), dim3(256), scn.dscene, f, c.ps, c.sq, (const uint32_t *)c.queue[in], c.counters, b,
                                      c.gstack);
                     };
-                    pick(variant == RPTR_VARIANT_SIMPLE, [&](auto V) {
+                    auto with_variant = [&](auto V) {
                         pick(lights, [&](auto L) {
                             pick(full, [&](auto F) {
-                                pick(single, [&](auto S) {
-                                    constexpr int VAR = decltype(V)::value ? RPTR_VARIANT_SIMPLE : RPTR_VARIANT_GLTF;
-                                    go(rp_k_tail<VAR, decltype(L)::value, decltype(F)::value, decltype(F)::value, decltype(S)::value>);
-                                });
+                                pick(single, [&](auto S) { go(rp_k_tail<decltype(V)::value, decltype(L)::value, decltype(F)::value, decltype(F)::value, decltype(S)::value>); });
                             });
                         });
-                    });
+                    };
+                    if (variant == RPTR_VARIANT_SIMPLE)
+                        with_variant(std::integral_constant<int, RPTR_VARIANT_SIMPLE>());
+                    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
+                        with_variant(std::integral_constant<int, RPTR_VARIANT_GLTF_TRANSMISSION>());
+                    else
+                        with_variant(std::integral_constant<int, RPTR_VARIANT_GLTF>());
                     break;
                 }
                 {
@@ -1782,6 +1786,8 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
                 timed(2, [&] {
                     if (variant == RPTR_VARIANT_SIMPLE)
                         launch_shade<RPTR_VARIANT_SIMPLE>(h, c, scn.dscene, f, order, b, out);
+                    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
+                        launch_shade<RPTR_VARIANT_GLTF_TRANSMISSION>(h, c, scn.dscene, f, order, b, out);
                     else
                         launch_shade<RPTR_VARIANT_GLTF>(h, c, scn.dscene, f, order, b, out);
                 });

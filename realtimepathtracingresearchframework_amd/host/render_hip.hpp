@@ -73,7 +73,7 @@ public:
     }
     void refit() { check(rptr_hip_refit(h_)); }
     bool configure_for(int variant_idx) {
-        if (variant_idx != RPTR_VARIANT_GLTF && variant_idx != RPTR_VARIANT_SIMPLE) return false;
+        if (variant_idx != RPTR_VARIANT_GLTF && variant_idx != RPTR_VARIANT_SIMPLE && variant_idx != RPTR_VARIANT_GLTF_TRANSMISSION) return false;
         variant_ = variant_idx;
         return true;
     }

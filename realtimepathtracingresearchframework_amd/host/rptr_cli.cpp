@@ -95,7 +95,7 @@ int main(int argc, char **argv) {
         else if (a == "--up") { vec3(up); got_up = true; }
         else if (a == "--fov") { need(1); fov = (float)std::atof(argv[++i]); }
         else if (a == "--batch-spp") { need(1); batch_spp = std::atoi(argv[++i]); }
-        else if (a == "--variant") { need(1); variant = std::strcmp(argv[++i], "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : RPTR_VARIANT_GLTF; }
+        else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; }
         else if (a == "--every-frame") every_frame = true;
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
         else if (a == "--pfm") format = FORMAT_PFM;

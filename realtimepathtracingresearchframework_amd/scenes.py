@@ -422,6 +422,43 @@ def cornell32() -> Scene:
     return s
 
 
+def glass_test() -> Scene:
+    """Cornell box whose tall box is solid glass (BASE_MATERIAL_ONESIDED: refraction, gltf_bsdf.glsl:308-309,591-593), whose short box
+    is frosted thin glass (two-sided: the "double reflection" transmission, :310-311,595-596), plus a thin clear pane across the front:
+    the scene of RPTR_VARIANT_GLTF_TRANSMISSION."""
+    s = cornell32()
+    s.name = "glass"
+    ids = s.pmeshes[0].tri_material_ids.copy()
+    G1, G2, G3 = len(s.materials), len(s.materials) + 1, len(s.materials) + 2
+    ids[10:20] = G2       # short box: thin frosted glass
+    ids[20:30] = G1       # tall box: solid glass
+    solid = abi.make_material((0.95, 0.98, 1.0), roughness=0.05, ior=1.5, flags=abi.BASE_MATERIAL_NOALPHA | abi.BASE_MATERIAL_ONESIDED)
+    solid.specular_transmission = 0.95
+    solid.clearcoat_gloss = 0.0025
+    frosted = abi.make_material((0.9, 0.7, 0.5), roughness=0.35, ior=1.45)
+    frosted.specular_transmission = 0.8
+    frosted.clearcoat_gloss = 0.09
+    pane = abi.make_material((1.0, 1.0, 1.0), roughness=0.02, ior=1.5)
+    pane.specular_transmission = 1.0
+    pane.clearcoat_gloss = 0.0004
+    s.materials += [solid, frosted, pane]
+    # rebuild the mesh with the pane (2 more triangles)
+    g = s.geometries[0]
+    P = dequantize_positions(g.qpos, g.scaling, g.offset).reshape(-1, 3, 3)
+    T = [tuple(map(tuple, t)) for t in P.tolist()] + _quad((-0.6, -0.5, 0.8), (0.2, -0.5, 0.8), (0.2, 0.4, 0.8), (-0.6, 0.4, 0.8))
+    ids = np.concatenate([ids, np.array([G3, G3], np.uint8)])
+    s2 = Scene(name="glass")
+    mesh = _add_mesh(s2, np.array(T, dtype=f32))
+    s2.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=ids))
+    s2.instances.append(Instance(transform=IDENTITY.copy(), pmesh=0))
+    s2.materials = s.materials
+    s2.camera = s.camera
+    s2.config = s.config
+    s2.sky_key = s.sky_key
+    s2.prepare_lights()
+    return s2
+
+
 # ------------------------------------------------------------------ value-noise fbm (scene definition, deterministic)
 def _hash2(ix, iz, seed):
     h = (ix.astype(np.uint32) * np.uint32(0x9E3779B1)) ^ (iz.astype(np.uint32) * np.uint32(0x85EBCA77)) ^ np.uint32(seed)

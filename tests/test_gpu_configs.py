@@ -312,3 +312,27 @@ def test_rccl_gather_on_one_gpu_through_self_send(monkeypatch):
     with pytest.raises(backend.BackendError):
         r.gather()
     r.close()
+
+
+# ---------------------------------------------------------------- the transmission lobe
+def test_transmission_variant_image_parity_on_a_glass_scene():
+    """RPTR_VARIANT_GLTF_TRANSMISSION (gltf_bsdf.glsl with GLTF_SUPPORT_TRANSMISSION[_ROUGHNESS]): solid glass (ONESIDED, refraction),
+    thin frosted glass and a clear pane; image within tolerance of the oracle, ray counts equal up to branch flips, the lobe matters, and
+    a scene without transmissive materials renders bit-identically in both builds of the BSDF"""
+    s = scenes.glass_test()
+    W, H, spp = 192, 192, 4
+    img, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF_TRANSMISSION, keep=True)
+    osc = O.OracleScene(s)
+    ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF_TRANSMISSION)
+    rmse, same, maxabs = image_error(img, ref)
+    assert same and rmse < RMSE_TOL, (rmse, maxabs)
+    assert abs(int(st.raw.rays_closest) - int(ost.rays_closest)) <= max(8, 2e-3 * ost.rays_closest)
+    assert abs(int(st.raw.rays_shadow) - int(ost.rays_shadow)) <= max(8, 2e-3 * ost.rays_shadow)
+    plain, _, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, renderer=r, reset=True)
+    r.close()
+    assert image_error(img, plain)[0] > 0.02           # light passes through the glass
+    assert st.raw.rays_closest > 1.05 * W * H * spp
+    opaque = scenes.cornell32()
+    a, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF_TRANSMISSION)
+    b, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

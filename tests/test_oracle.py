@@ -154,6 +154,82 @@ def test_gltf_wpdf_integrates_to_one_and_bsdf_conserves_energy(oracle):
         assert (f[~upper] == 0).all() and (wpdf[~upper] == 0).all()
 
 
+# ---------------------------------------------------------------- glTF BSDF with the transmission lobe (RPTR_VARIANT_GLTF_TRANSMISSION)
+def _gltf_t_sample(oracle, m, n, wo, u):
+    N = len(n)
+    wi, w, f = (np.zeros((N, 3), np.float32) for _ in range(3))
+    pdf, mis, wpdf = (np.zeros(N, np.float32) for _ in range(3))
+    oracle.lib().orc_gltf_t_sample(C.byref(m), _p(n), _p(wo), _p(u), N, _p(wi), _p(w), _p(pdf), _p(mis), _p(f), _p(wpdf))
+    return wi, w, pdf, mis, f, wpdf
+
+
+def _random_frames(rng, N, both_sides):
+    n = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    wo = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    if not both_sides:
+        flip = np.sum(n * wo, axis=1) < 0
+        wo[flip] *= -1
+    return n, wo, rng.uniform(0, 1, (N, 4)).astype(np.float32)
+
+
+def test_transmission_build_without_transmission_equals_the_shipped_bsdf(oracle):
+    """specular_transmission == 0: the build with GLTF_SUPPORT_TRANSMISSION gives the same samples, values and pdfs as the shipped
+    two-lobe build, bit for bit (w_o above the surface: the shipped build returns nothing from below, gltf_bsdf.glsl:507-512)"""
+    rng = np.random.default_rng(5)
+    N = 50000
+    n, wo, u = _random_frames(rng, N, both_sides=False)
+    for metallic, rough in ((0.0, 0.3), (1.0, 0.1), (0.4, 0.8)):
+        m = abi.make_material((0.6, 0.5, 0.4), roughness=rough, metallic=metallic, ior=1.5)
+        wi, w, pdf, mis, f, wpdf = _gltf_t_sample(oracle, m, n, wo, u)
+        wi0, w0, f0 = (np.zeros((N, 3), np.float32) for _ in range(3))
+        pdf0, mis0, wpdf0 = (np.zeros(N, np.float32) for _ in range(3))
+        oracle.lib().orc_gltf_sample(C.byref(m), _p(n), _p(wo), _p(u), N, _p(wi0), _p(w0), _p(pdf0), _p(mis0), _p(f0), _p(wpdf0))
+        for a, b in ((wi, wi0), (w, w0), (pdf, pdf0), (mis, mis0), (f, f0), (wpdf, wpdf0)):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("onesided", [False, True])
+def test_transmission_lobe_properties(oracle, onesided):
+    """glass (ior 1.5, specular_transmission 0.9): no NaN; weight * pdf == f * |cos| (the sampler and the evaluation agree); the
+    transmission component crosses the surface, the other two do not; refraction through a ONESIDED surface obeys Snell's law
+    about the sampled half vector; seen from inside (w_o below n) it works with 1/ior; weights stay bounded"""
+    rng = np.random.default_rng(9)
+    N = 200000
+    flags = abi.BASE_MATERIAL_NOALPHA | (abi.BASE_MATERIAL_ONESIDED if onesided else 0)
+    m = abi.make_material((0.9, 0.95, 1.0), roughness=0.25, metallic=0.0, ior=1.5, flags=flags)
+    m.specular_transmission = 0.9
+    m.clearcoat_gloss = 0.04            # reflection roughness = sqrt(clearcoat_gloss) = 0.2 (gltf_bsdf.glsl:54-55)
+    n, wo, u = _random_frames(rng, N, both_sides=onesided)
+    wi, w, pdf, mis, f, wpdf = _gltf_t_sample(oracle, m, n, wo, u)
+    ok = pdf > 0
+    assert ok.mean() > (0.6 if onesided else 0.85)       # (from inside, total internal reflection leaves no transmitted direction)
+    assert np.isfinite(w[ok]).all() and np.isfinite(pdf[ok]).all() and np.isfinite(mis[ok]).all() and np.isfinite(wi[ok]).all()
+    cos_i = np.sum(n * wi, axis=1)
+    cos_o = np.sum(n * wo, axis=1)
+    assert np.allclose(w[ok] * pdf[ok, None], f[ok] * np.abs(cos_i[ok, None]), rtol=5e-4, atol=1e-6)
+    assert np.allclose(np.linalg.norm(wi[ok], axis=1), 1.0, atol=2e-4)
+    through = ok & (cos_i * cos_o < 0)
+    assert 0.2 < through.sum() / ok.sum() < 0.95         # most of the energy of clear glass goes through
+    assert (w[ok] < 4.0).all(axis=1).mean() > 0.98
+    assert (mis[ok] > 0).mean() > 0.99
+    if onesided:
+        # Snell: the tangential parts of w_o and w_i about the half vector h ~ -(eta_i w_i + eta_o w_o) have the ratio of the indices
+        outside = cos_o > 0
+        ior = np.where(outside, 1.5, 1.0 / 1.5)[:, None]
+        h = -(ior * wi + wo)
+        h /= np.linalg.norm(h, axis=1, keepdims=True)
+        sin_o = np.linalg.norm(wo - h * np.sum(wo * h, axis=1, keepdims=True), axis=1)
+        sin_i = np.linalg.norm(wi - h * np.sum(wi * h, axis=1, keepdims=True), axis=1)
+        sel = through & (sin_o > 0.05)
+        assert np.allclose(sin_o[sel], ior[sel, 0] * sin_i[sel], rtol=2e-3, atol=2e-4)
+    else:
+        # thin surface: the transmitted direction is the mirror image (about the surface) of a reflection
+        refl = wi - 2 * cos_i[:, None] * n
+        assert (np.sum(refl * n, axis=1)[through] * cos_o[through] > 0).all()
+
+
 # ---------------------------------------------------------------- sun + triangle lights
 def test_sun_samples_lie_in_the_cone(oracle):
     rng = np.random.default_rng(3)
