@@ -422,25 +422,26 @@ def cornell32() -> Scene:
     return s
 
 
-def glass_test() -> Scene:
+def glass_test(clear=False) -> Scene:
     """Cornell box whose tall box is solid glass (BASE_MATERIAL_ONESIDED: refraction, gltf_bsdf.glsl:308-309,591-593), whose short box
     is frosted thin glass (two-sided: the "double reflection" transmission, :310-311,595-596), plus a thin clear pane across the front:
-    the scene of RPTR_VARIANT_GLTF_TRANSMISSION."""
+    the scene of RPTR_VARIANT_GLTF_TRANSMISSION. clear=True: near-specular glass (roughness 0.02 .. 0.05) -- paths through it amplify
+    a last-bit difference of sin / cos by 1 / alpha, so single pixels of two correct renderers differ visibly."""
     s = cornell32()
     s.name = "glass"
     ids = s.pmeshes[0].tri_material_ids.copy()
     G1, G2, G3 = len(s.materials), len(s.materials) + 1, len(s.materials) + 2
     ids[10:20] = G2       # short box: thin frosted glass
     ids[20:30] = G1       # tall box: solid glass
-    solid = abi.make_material((0.95, 0.98, 1.0), roughness=0.05, ior=1.5, flags=abi.BASE_MATERIAL_NOALPHA | abi.BASE_MATERIAL_ONESIDED)
+    solid = abi.make_material((0.95, 0.98, 1.0), roughness=0.05 if clear else 0.25, ior=1.5, flags=abi.BASE_MATERIAL_NOALPHA | abi.BASE_MATERIAL_ONESIDED)
     solid.specular_transmission = 0.95
-    solid.clearcoat_gloss = 0.0025
+    solid.clearcoat_gloss = 0.0025 if clear else 0.04
     frosted = abi.make_material((0.9, 0.7, 0.5), roughness=0.35, ior=1.45)
     frosted.specular_transmission = 0.8
     frosted.clearcoat_gloss = 0.09
-    pane = abi.make_material((1.0, 1.0, 1.0), roughness=0.02, ior=1.5)
+    pane = abi.make_material((1.0, 1.0, 1.0), roughness=0.02 if clear else 0.15, ior=1.5)
     pane.specular_transmission = 1.0
-    pane.clearcoat_gloss = 0.0004
+    pane.clearcoat_gloss = 0.0004 if clear else 0.0225
     s.materials += [solid, frosted, pane]
     # rebuild the mesh with the pane (2 more triangles)
     g = s.geometries[0]

@@ -332,6 +332,15 @@ def test_transmission_variant_image_parity_on_a_glass_scene():
     r.close()
     assert image_error(img, plain)[0] > 0.02           # light passes through the glass
     assert st.raw.rays_closest > 1.05 * W * H * spp
+    # near-specular glass: GGX lobes of alpha 0.002 .. 0.0025 amplify a last-bit difference of the device's sin / cos against libm's by
+    # 1 / alpha; most pixels are still bit-identical, a few paths flip -- the image is judged by how many pixels differ, not by RMSE
+    clear = scenes.glass_test(clear=True)
+    img, st, _ = gpu_render(clear, W, H, spp, abi.VARIANT_GLTF_TRANSMISSION)
+    ref, ost = O.OracleScene(clear).render(W, H, spp, variant=abi.VARIANT_GLTF_TRANSMISSION)
+    d = np.abs(img[..., :3] - ref[..., :3]).max(axis=2)
+    assert np.isfinite(img).all() and float(np.median(d)) == 0.0 and (d > 1e-3).mean() < 0.01
+    assert abs(int(st.raw.rays_closest) - int(ost.rays_closest)) <= 2e-3 * ost.rays_closest
+    assert abs(float(img[..., :3].mean()) - float(ref[..., :3].mean())) < 2e-3 * float(ref[..., :3].mean())
     opaque = scenes.cornell32()
     a, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF_TRANSMISSION)
     b, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF)
