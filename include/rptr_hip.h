@@ -329,6 +329,10 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
 int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation,
                           int count_traversal, uint64_t *out_ticket);
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats);
+/* RenderConfiguration::freeze_frame (librender/render_backend.h:39; vulkan/render_vulkan.cpp:1937-1941,2152-2154): while set, a reset
+ * does not advance frame_offset and a rendered frame does not advance frame_id -- every frame repeats the same samples (the
+ * reference's --freeze-frame, cmdline.cpp:359-360). */
+int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame);
 /* hipEvent pairs recorded per frame for RptrStats.*_time_ms: 0 none (render_time_ms only), 1 around the closest-hit
  * traversal launches (extend_time_ms), 2 every stage (default; ~0.1 ms per 1080p frame of launch gaps). */
 int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);

@@ -65,6 +65,7 @@ def load_library(path=None):
     L.rptr_hip_render_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_wait.argtypes = [vp, C.c_uint64, C.POINTER(abi.Stats)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
+    L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
@@ -209,6 +210,7 @@ class RenderHip:
         return True
 
     def _push_params(self):
+        self._check(self._L.rptr_hip_set_freeze_frame(self._h, 1 if self.freeze_frame else 0))
         self._check(self._L.rptr_hip_set_params(self._h, C.byref(self.params), C.byref(self.scene_params) if self.scene_params else None,
                                                 C.byref(self.lighting_params)))
 

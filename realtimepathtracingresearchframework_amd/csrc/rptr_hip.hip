@@ -180,6 +180,7 @@ struct rptr_hip {
     int side_connect = 0; // opt-in (RPTR_SIDE_CONNECT=1): connect(b) on a side stream next to extend(b+1)
     int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
+    bool freeze_frame = false; // RenderConfiguration::freeze_frame: frame_offset / frame_id stand still
 
     RptrStats stats;
 };
@@ -1592,9 +1593,10 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     }
     // begin_frame: render_vulkan.cpp:1937-1941
     if (reset_accumulation) {
-        h->frame_offset += h->frame_id;
+        if (!h->freeze_frame) h->frame_offset += h->frame_id;
         h->frame_id = 0;
     }
+    const uint32_t frame_id_before = h->frame_id;
     RpFrame f;
     memset(&f, 0, sizeof(f));
     f.rp = h->params;
@@ -1838,10 +1840,17 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     }
     HIP_TRY(h, hipEventRecord(c.ev_end, c.stream));
     HIP_TRY(h, hipGetLastError());
+    if (h->freeze_frame) h->frame_id = frame_id_before; // end_frame, render_vulkan.cpp:2152-2154: the next frame repeats these samples
     c.spp_after = h->accumulated_spp;
     c.pending = true;
     c.ticket = h->next_ticket++;
     if (out_ticket) *out_ticket = c.ticket;
+    return RPTR_OK;
+}
+
+int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    h->freeze_frame = freeze_frame != 0;
     return RPTR_OK;
 }
 

@@ -1,0 +1,112 @@
+// render_group.hpp -- one host process driving several GPUs: N `RenderHip` backends (one per device, rank i of N) that share a frame
+// by screen stripes, plus the library's gather of tile radiance to rank 0 (include/rptr_hip.h "multi-GPU": rptr_hip_comm_init_all /
+// rptr_hip_gather_all -- grouped ncclSend / ncclRecv over xGMI, or peer copies when handles share a device).
+// Shaped like one RenderBackend: the application calls set_scene / render / readback once, the group fans out. No reference
+// counterpart (the reference renders on one physical device, vulkan/render_vulkan_extensions.cpp:77-82); partitioning per SURVEY 8e.
+#pragma once
+#include "render_hip.hpp"
+
+#include <memory>
+#include <vector>
+
+namespace rptr {
+
+class RenderGroup {
+public:
+    // devices: HIP ordinals, one rank each (the same ordinal may appear several times: a test rig on one GPU)
+    RenderGroup(const std::vector<int> &devices, int stripe_rows = 8, int frames_in_flight = 1) {
+        const int n = (int)devices.size();
+        if (n < 1) throw std::runtime_error("RenderGroup: no devices");
+        for (int i = 0; i < n; ++i) ranks_.emplace_back(new RenderHip(devices[(size_t)i], i, n, stripe_rows, nullptr, frames_in_flight));
+    }
+    int size() const { return (int)ranks_.size(); }
+    RenderHip &rank(int i) { return *ranks_[(size_t)i]; }
+    std::string name() const { return ranks_[0]->name() + " x" + std::to_string(size()); }
+
+    void initialize(int fb_width, int fb_height) {
+        width_ = fb_width;
+        height_ = fb_height;
+        for (auto &r : ranks_) r->initialize(fb_width, fb_height);
+        if (size() > 1) { // (a communicator's buffers are frame-sized: it is made again after every initialize)
+            std::vector<rptr_hip_t *> hs;
+            for (auto &r : ranks_) hs.push_back(r->handle());
+            if (rptr_hip_comm_init_all(hs.data(), size()) != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_comm_init_all: ") + last_error());
+        }
+    }
+    void set_scene(const RptrSceneDesc &scene) { // every GPU holds a replica of the scene
+        for (auto &r : ranks_) r->set_scene(scene);
+    }
+    void update_config(const RptrSceneParams &sp) {
+        for (auto &r : ranks_) r->update_config(sp);
+    }
+    void set_params(const RptrRenderParams &p, const RptrLightSamplingConfig &l) {
+        for (auto &r : ranks_) {
+            r->params = p;
+            r->lighting_params = l;
+        }
+    }
+    void update_vertices(uint32_t geometry, const float *xyz, uint32_t num_vertices) {
+        for (auto &r : ranks_) r->update_vertices(geometry, xyz, num_vertices);
+    }
+    void refit() {
+        for (auto &r : ranks_) r->refit();
+    }
+    // one frame on all GPUs: every rank renders its stripes (asynchronously, side by side), then the tiles are gathered to rank 0
+    RenderStats render(const RenderConfiguration &config, int spp = 0) {
+        std::vector<uint64_t> tickets;
+        for (auto &r : ranks_) tickets.push_back(r->render_async(config, spp));
+        RenderStats total{};
+        for (size_t i = 0; i < ranks_.size(); ++i) {
+            const RenderStats s = ranks_[i]->wait(tickets[i]);
+            total.render_time = std::max(total.render_time, s.render_time);
+            rays_ += s.has_valid_frame_stats ? double(s.rays_per_second) * s.render_time * 1e-3 : 0.0;
+            total.spp = s.spp;
+            total.total_device_bytes_allocated += s.total_device_bytes_allocated;
+        }
+        if (size() > 1) {
+            std::vector<rptr_hip_t *> hs;
+            for (auto &r : ranks_) hs.push_back(r->handle());
+            if (rptr_hip_gather_all(hs.data(), size()) != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_gather_all: ") + last_error());
+        }
+        return total;
+    }
+    // the full frame (RGBA32F accumulation buffer) on the host: rank 0's assembled frame
+    size_t readback_framebuffer(size_t buffer_size, float *buffer) {
+        if (size() == 1) return ranks_[0]->readback_framebuffer(buffer_size, buffer);
+        const size_t need = (size_t)width_ * height_ * 4;
+        if (buffer_size < need) return 0;
+        if (rptr_hip_readback_gathered_f32(ranks_[0]->handle(), buffer, buffer_size) != RPTR_OK) throw std::runtime_error(std::string("readback: ") + last_error());
+        return need;
+    }
+    // 8-bit frame buffer / AOV images: every rank fills in its own rows (the read-backs leave the other rows untouched)
+    size_t readback_framebuffer(size_t buffer_size, unsigned char *buffer) {
+        size_t n = 0;
+        for (auto &r : ranks_) n = r->readback_framebuffer(buffer_size, buffer);
+        return n;
+    }
+    size_t readback_aov(RenderHip::AOVBufferIndex aov, size_t buffer_size, uint16_t *buffer) {
+        size_t n = 0;
+        for (auto &r : ranks_) n = r->readback_aov(aov, buffer_size, buffer);
+        return n;
+    }
+    float mean_gather_ms() {
+        uint64_t n = 0;
+        float ms = 0.f;
+        if (size() > 1) (void)rptr_hip_comm_stats(ranks_[0]->handle(), &n, &ms);
+        return ms;
+    }
+
+private:
+    std::string last_error() {
+        for (auto &r : ranks_) {
+            const char *e = rptr_hip_last_error(r->handle());
+            if (e && *e) return e;
+        }
+        return rptr_hip_last_error(nullptr);
+    }
+    std::vector<std::unique_ptr<RenderHip>> ranks_;
+    int width_ = 0, height_ = 0;
+    double rays_ = 0.0;
+};
+
+} // namespace rptr

@@ -59,7 +59,7 @@ public:
     RenderHip &operator=(const RenderHip &) = delete;
 
     std::string name() const { return rptr_hip_name(); }
-    std::vector<std::string> variant_names() const { return {"wavefront-gltf", "wavefront-diffuse"}; }
+    std::vector<std::string> variant_names() const { return {"wavefront-gltf", "wavefront-diffuse", "wavefront-gltf-transmission"}; }
 
     void initialize(const int fb_width, const int fb_height) { check(rptr_hip_initialize(h_, fb_width, fb_height)); }
     // set_scene(const Scene&): the adapter flattens Scene into RptrSceneDesc
@@ -86,6 +86,7 @@ public:
     }
     void draw_frame(int spp = 0) {
         check(rptr_hip_set_params(h_, &params, have_scene_params_ ? &scene_params_ : nullptr, &lighting_params));
+        check(rptr_hip_set_freeze_frame(h_, freeze_frame ? 1 : 0));
         RptrCamera cam;
         for (int k = 0; k < 3; ++k) {
             cam.pos[k] = camera.pos[k];
@@ -101,6 +102,7 @@ public:
     uint64_t render_async(const RenderConfiguration &config, int spp = 0) {
         begin_frame(config);
         check(rptr_hip_set_params(h_, &params, have_scene_params_ ? &scene_params_ : nullptr, &lighting_params));
+        check(rptr_hip_set_freeze_frame(h_, freeze_frame ? 1 : 0));
         RptrCamera cam;
         for (int k = 0; k < 3; ++k) {
             cam.pos[k] = camera.pos[k];

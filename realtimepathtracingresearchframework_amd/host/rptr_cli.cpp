@@ -3,7 +3,14 @@
 //   rptr_hip <scene.rpsc> --validation <prefix> [--validation-spp n] [--img w h] [--pfm]
 //   rptr_hip <scene.rpsc> --profiling <csv prefix> [--profiling-fps f] [--profiling-img <prefix>] [--profiling-frames n]
 //            [--animate-wave amplitude kx]
-//   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame]
+//   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
+//            [--config file.ini]... [--keyframe [<seconds>:]file.ini]... [--camera n] [--freeze-frame] [--upscale n] [--backend hip]
+//            [--devices n | --devices a,b,c] [--stripe-rows r]
+//
+// --config / --keyframe read the reference's .ini files (ini_config.hpp); in profiling mode every keyframe is held for its length
+// (default 1 s of animation time = --profiling-fps frames) and the accumulation restarts when the keyframe changes.
+// --devices: one process, several GPUs (render_group.hpp): the frame is cut into stripes of --stripe-rows rows, stripe s -> device
+// s % n, tile radiance gathered to the first device with the library's RCCL gather (peer copies when a device is listed twice).
 //
 // Flag names, file names and the CSV header are the reference's (cmdline.cpp:10-104,296-474; libapp/app_state.cpp:218-255,
 // 291-322,464-498; libapp/benchmark_info.cpp:69-124; util/write_image.cpp:34-64):
@@ -20,7 +27,8 @@
 //    keyframe 1 as EXR (libapp/app_state.cpp:499-531).
 // Images: --exr (default, as in the reference), --pfm, --png (write_image.hpp).
 // The scene comes from a dump file (scene_dump.hpp) instead of a .vks (python -m ...vks converts).
-#include "render_hip.hpp"
+#include "ini_config.hpp"
+#include "render_group.hpp"
 #include "scene_dump.hpp"
 #include "write_image.hpp"
 
@@ -37,7 +45,7 @@ enum OutputFormat { FORMAT_EXR, FORMAT_PFM, FORMAT_PNG }; // cmdline.cpp:450-460
 
 // BasicApplicationState::save_framebuffer (libapp/app_state.cpp:341-438): the float accumulation buffer as EXR / PFM, the 8-bit
 // frame buffer as PNG, under <prefix>_<number> (+ suffix)
-static void save_image(rptr::RenderHip &backend, OutputFormat format, const std::string &prefix, int number, const std::string &suffix, int width, int height,
+static void save_image(rptr::RenderGroup &backend, OutputFormat format, const std::string &prefix, int number, const std::string &suffix, int width, int height,
                        std::vector<float> &img) {
     char name[32];
     std::snprintf(name, sizeof(name), "_%04d", number);
@@ -55,7 +63,7 @@ static void save_image(rptr::RenderHip &backend, OutputFormat format, const std:
     if (!ok) throw std::runtime_error("cannot write " + base);
 }
 // BasicApplicationState::save_aov_exr (libapp/app_state.cpp:441-462): an AOV image as a HALF EXR
-static void save_aov(rptr::RenderHip &backend, rptr::RenderHip::AOVBufferIndex aov, const std::string &base, int width, int height) {
+static void save_aov(rptr::RenderGroup &backend, rptr::RenderHip::AOVBufferIndex aov, const std::string &base, int width, int height) {
     std::vector<uint16_t> half((size_t)width * height * 4);
     if (backend.readback_aov(aov, half.size(), half.data()) != half.size()) throw std::runtime_error("AOV read-back failed");
     if (!rptr::write_exr<uint16_t>(base, (unsigned)width, (unsigned)height, 4, half.data())) throw std::runtime_error("cannot write " + base + ".exr");
@@ -70,6 +78,15 @@ int main(int argc, char **argv) {
     float profiling_fps = 60.f, wave_amp = 0.f, wave_k = 0.f;
     float eye[3], center[3], up[3] = {0, 1, 0}, fov = 0.f;
     bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
+    bool freeze_frame = false, got_batch_spp = false, got_variant = false;
+    int upscale = 0, stripe_rows = 8;
+    std::vector<int> devices{0};
+    std::vector<std::string> config_inis;
+    struct Keyframe {
+        std::string ini;
+        double hold;
+    };
+    std::vector<Keyframe> keyframes;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](int k) {
@@ -94,8 +111,43 @@ int main(int argc, char **argv) {
         else if (a == "--center") { vec3(center); got_center = true; }
         else if (a == "--up") { vec3(up); got_up = true; }
         else if (a == "--fov") { need(1); fov = (float)std::atof(argv[++i]); }
-        else if (a == "--batch-spp") { need(1); batch_spp = std::atoi(argv[++i]); }
-        else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; }
+        else if (a == "--batch-spp") { need(1); batch_spp = std::atoi(argv[++i]); got_batch_spp = true; }
+        else if (a == "--config") { need(1); config_inis.push_back(argv[++i]); }
+        else if (a == "--keyframe") { // [<length>:]<file> (cmdline.cpp:334-348)
+            need(1);
+            std::string v = argv[++i];
+            double hold = 1.0;
+            const size_t colon = v.find(':');
+            if (colon != std::string::npos && colon > 0) {
+                char *end = nullptr;
+                const double len = std::strtod(v.c_str(), &end);
+                if (end == v.c_str() + colon) {
+                    hold = len;
+                    v.erase(0, colon + 1);
+                }
+            }
+            keyframes.push_back({v, hold});
+        }
+        else if (a == "--camera") { need(1); if (std::atoi(argv[++i]) != 0) { std::fprintf(stderr, "the scene file holds one camera (index 0)\n"); return 2; } }
+        else if (a == "--upscale") { need(1); upscale = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--stripe-rows") { need(1); stripe_rows = std::atoi(argv[++i]); }
+        else if (a == "--devices") { // a count (devices 0..n-1) or a comma-separated list of HIP ordinals
+            need(1);
+            const std::string v = argv[++i];
+            devices.clear();
+            if (v.find(',') == std::string::npos) {
+                for (int d = 0; d < std::max(1, std::atoi(v.c_str())); ++d) devices.push_back(d);
+            } else {
+                size_t at = 0;
+                while (at <= v.size()) {
+                    const size_t comma = v.find(',', at);
+                    devices.push_back(std::atoi(v.substr(at, comma == std::string::npos ? std::string::npos : comma - at).c_str()));
+                    if (comma == std::string::npos) break;
+                    at = comma + 1;
+                }
+            }
+        }
+        else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; got_variant = true; }
         else if (a == "--every-frame") every_frame = true;
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
         else if (a == "--pfm") format = FORMAT_PFM;
@@ -103,8 +155,13 @@ int main(int argc, char **argv) {
         else if (a == "--png") format = FORMAT_PNG;
         else if (a == "--data-capture") { need(1); capture_prefix = argv[++i]; data_capture = true; }
         else if (a == "--data-capture-spp") { need(1); capture_spp = std::max(1, std::atoi(argv[++i])); }
-        else if (a == "--backend") { need(1); ++i; } // there is one backend here
-        else if (a == "--disable-ui" || a == "--freeze-frame") {}
+        else if (a == "--backend") { // cmdline.cpp:363-376: the last one wins; this binary hosts one
+            need(1);
+            const std::string b = argv[++i];
+            if (b != "hip" && b != "rptr_hip") { std::fprintf(stderr, "unknown backend %s (available: hip)\n", b.c_str()); return 2; }
+        }
+        else if (a == "--freeze-frame") freeze_frame = true;
+        else if (a == "--disable-ui") {}
         else if (a[0] != '-') scene_path = a;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -120,6 +177,26 @@ int main(int argc, char **argv) {
                         "max_path_depth %d bin_size %d sun_w %.6f\n",
                         s.geometries.size(), s.meshes.size(), s.pmeshes.size(), s.instances.size(), s.materials.size(), s.lights.size(), tris, qsum,
                         s.camera.fovy, s.render_params.max_path_depth, s.lighting.bin_size, s.scene_params.sun_radiance[3]);
+            if (!config_inis.empty() || !keyframes.empty()) { // ... and what the configuration files make of it
+                rptr::HostConfig c;
+                c.params = s.render_params;
+                c.lighting = s.lighting;
+                c.camera = s.camera;
+                for (const std::string &ini : config_inis) rptr::load_config(ini, c);
+                std::printf("config target_spp %d batch_spp %d max_path_depth %d rr_path_depth %d glossy_only %d exposure %.6f tonemap %d output_channel %d "
+                            "output_moment %d bin_size %d variant %d force_bvh_rebuild %d rebuild_triangle_budget %d bump_scale %.6f sun_changed %d "
+                            "cam_pos %.6f %.6f %.6f cam_dir %.6f %.6f %.6f\n",
+                            c.target_spp, c.params.batch_spp, c.params.max_path_depth, c.params.rr_path_depth, c.params.glossy_only_mode, c.params.exposure,
+                            c.params.early_tone_mapping_mode, c.params.output_channel, c.params.output_moment, c.lighting.bin_size, c.variant, c.force_bvh_rebuild,
+                            c.rebuild_triangle_budget, c.bump_scale, c.sun_changed ? 1 : 0, c.camera.pos[0], c.camera.pos[1], c.camera.pos[2], c.camera.dir[0],
+                            c.camera.dir[1], c.camera.dir[2]);
+                for (const Keyframe &k : keyframes) {
+                    rptr::HostConfig kc = c;
+                    const int blocks = rptr::load_config(k.ini, kc);
+                    std::printf("keyframe hold %.6f blocks %d exposure %.6f cam_pos %.6f %.6f %.6f\n", k.hold, blocks, kc.params.exposure, kc.camera.pos[0],
+                                kc.camera.pos[1], kc.camera.pos[2]);
+                }
+            }
             return 0;
         } catch (const std::exception &e) {
             std::fprintf(stderr, "rptr_hip: %s\n", e.what());
@@ -140,13 +217,40 @@ int main(int argc, char **argv) {
     }
     try {
         rptr::SceneDump scene = rptr::SceneDump::load(scene_path);
-        rptr::RenderHip backend;
+        // ---- configuration: the scene file's state, then every --config in order, then the command line (main.cpp:121-149, app.cpp:204-213)
+        rptr::HostConfig base;
+        base.params = scene.render_params;
+        base.lighting = scene.lighting;
+        base.camera = scene.camera;
+        for (const std::string &ini : config_inis) {
+            std::printf("Loading config from %s\n", ini.c_str());
+            rptr::load_config(ini, base);
+        }
+        std::vector<rptr::HostConfig> frames; // one per keyframe (profiling mode); empty = the base configuration throughout
+        std::vector<double> holds;
+        for (const Keyframe &k : keyframes) {
+            std::printf("Loading config from %s\n", k.ini.c_str());
+            const std::vector<rptr::IniBlock> blocks = rptr::parse_ini(k.ini);
+            // every [Application] block of a keyframe file that changes the state is a keyframe; a static file is held for `hold` seconds
+            rptr::HostConfig state = frames.empty() ? base : frames.back();
+            for (const rptr::IniBlock &b : blocks) rptr::apply_ini_object(b.root, state);
+            frames.push_back(state);
+            holds.push_back(k.hold);
+        }
+        for (const rptr::HostConfig *c : {&base})
+            for (const std::string &n : c->notes) std::fprintf(stderr, "note: %s\n", n.c_str());
+        if (base.target_spp > 0 && !validation) target_spp = base.target_spp;
+        if (!got_batch_spp) batch_spp = std::max(1, base.params.batch_spp);
+        if (!got_variant && base.variant >= 0) variant = base.variant;
+        if (upscale >= 1) base.params.render_upscale_factor = upscale;
+        rptr::RenderGroup backend(devices, stripe_rows);
         backend.initialize(width, height);
         backend.set_scene(scene.desc());
-        backend.params = scene.render_params;
-        backend.params.batch_spp = batch_spp;
-        backend.lighting_params = scene.lighting;
+        base.params.batch_spp = batch_spp;
+        backend.set_params(base.params, base.lighting);
+        if (base.bump_scale > 0.f) scene.scene_params.normal_z_scale = 1.0f / base.bump_scale; // render_vulkan.cpp:2954-2959
         backend.update_config(scene.scene_params);
+        scene.camera = base.camera;
         rptr::RenderConfiguration cfg{};
         std::memcpy(cfg.camera.pos, scene.camera.pos, 12);
         std::memcpy(cfg.camera.dir, scene.camera.dir, 12);
@@ -165,6 +269,7 @@ int main(int argc, char **argv) {
         if (got_up) std::memcpy(cfg.camera.up, up, 12);
         if (fov > 0) cfg.camera.fovy = fov;
         cfg.active_variant = variant;
+        cfg.freeze_frame = freeze_frame;
         cfg.reset_accumulation = true; // frame 0 of the accumulation (app.cpp: reset on scene load)
         std::vector<float> img((size_t)width * height * 4);
 
@@ -174,7 +279,7 @@ int main(int argc, char **argv) {
             while (accumulated < target_spp) {
                 const rptr::RenderStats st = backend.render(cfg); // params.batch_spp samples
                 cfg.reset_accumulation = false;
-                accumulated = st.spp;
+                accumulated = freeze_frame ? accumulated + batch_spp : st.spp; // (a frozen frame repeats its samples: the application counts, app_state.cpp)
                 gpu_ms += st.render_time;
                 if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
             }
@@ -201,18 +306,18 @@ int main(int argc, char **argv) {
         }
 
         // ---- profiling mode
-        std::vector<float> base, cur; // --animate-wave: float positions of geometry 0 at rest
+        std::vector<float> rest, cur; // --animate-wave: float positions of geometry 0 at rest
         if (wave_amp != 0.f) {
             if (scene.meshes.empty() || !scene.meshes[0].dynamic) throw std::runtime_error("--animate-wave needs a scene whose mesh 0 is dynamic");
             const RptrGeometryDesc &g = scene.geometries[scene.meshes[0].first_geometry];
-            base.resize((size_t)g.num_tris * 9);
+            rest.resize((size_t)g.num_tris * 9);
             for (size_t v = 0; v < (size_t)g.num_tris * 3; ++v) { // librender/dequantize.glsl:8-21
                 const uint64_t w = g.qpos[v];
-                base[3 * v + 0] = float(uint32_t(w) & 0x1FFFFFu) * g.quantized_scaling[0] + g.quantized_offset[0];
-                base[3 * v + 1] = float(uint32_t(w >> 21) & 0x1FFFFFu) * g.quantized_scaling[1] + g.quantized_offset[1];
-                base[3 * v + 2] = float(uint32_t(w >> 42) & 0x1FFFFFu) * g.quantized_scaling[2] + g.quantized_offset[2];
+                rest[3 * v + 0] = float(uint32_t(w) & 0x1FFFFFu) * g.quantized_scaling[0] + g.quantized_offset[0];
+                rest[3 * v + 1] = float(uint32_t(w >> 21) & 0x1FFFFFu) * g.quantized_scaling[1] + g.quantized_offset[1];
+                rest[3 * v + 2] = float(uint32_t(w >> 42) & 0x1FFFFFu) * g.quantized_scaling[2] + g.quantized_offset[2];
             }
-            cur = base;
+            cur = rest;
         }
         const std::string csv_path = csv_prefix + ".csv";
         FILE *csv = std::fopen(csv_path.c_str(), "w");
@@ -221,11 +326,36 @@ int main(int argc, char **argv) {
         const float dt = 1.f / profiling_fps;
         double current_time = 0.0, gpu_ms = 0.0;
         int frames_accumulated = 0;
+        // keyframes: each is held for its length on the animation timeline (default one second = profiling_fps frames); without
+        // keyframes the run lasts --profiling-frames frames of the base configuration
+        std::vector<double> key_end;
+        if (!frames.empty()) {
+            double t = 0.0;
+            for (double hsec : holds) key_end.push_back(t += std::max(hsec, (double)dt));
+            profiling_frames = std::max(1, (int)std::floor(key_end.back() * profiling_fps + 0.5));
+        }
+        int active_key = -1;
         auto last = std::chrono::steady_clock::now();
         for (int frame = 0; frame < profiling_frames; ++frame) {
-            if (!base.empty()) { // the geometry moves: new vertices, refit, and the accumulation starts over
+            if (!frames.empty()) { // the keyframe this frame belongs to; a change applies its state and restarts the accumulation
+                int k = 0;
+                while (k + 1 < (int)key_end.size() && current_time >= key_end[(size_t)k] - 1e-9) ++k;
+                if (k != active_key) {
+                    active_key = k;
+                    rptr::HostConfig st = frames[(size_t)k];
+                    st.params.batch_spp = batch_spp;
+                    if (upscale >= 1) st.params.render_upscale_factor = upscale;
+                    backend.set_params(st.params, st.lighting);
+                    std::memcpy(cfg.camera.pos, st.camera.pos, 12);
+                    std::memcpy(cfg.camera.dir, st.camera.dir, 12);
+                    std::memcpy(cfg.camera.up, st.camera.up, 12);
+                    if (!got_variant && st.variant >= 0) cfg.active_variant = st.variant;
+                    cfg.reset_accumulation = true;
+                }
+            }
+            if (!rest.empty()) { // the geometry moves: new vertices, refit, and the accumulation starts over
                 const float phase = 6.283185307179586f * (float)current_time;
-                for (size_t v = 0; v < base.size() / 3; ++v) cur[3 * v + 1] = base[3 * v + 1] + wave_amp * std::sin(wave_k * base[3 * v] + phase);
+                for (size_t v = 0; v < rest.size() / 3; ++v) cur[3 * v + 1] = rest[3 * v + 1] + wave_amp * std::sin(wave_k * rest[3 * v] + phase);
                 backend.update_vertices(scene.meshes[0].first_geometry, cur.data(), (uint32_t)(cur.size() / 3));
                 backend.refit();
                 cfg.reset_accumulation = true;
@@ -238,12 +368,14 @@ int main(int argc, char **argv) {
             const auto now = std::chrono::steady_clock::now();
             const double app_ms = std::chrono::duration<double, std::milli>(now - last).count();
             last = now;
-            const int keyframe = (int)std::floor(current_time) + 1;
+            const int keyframe = frames.empty() ? (int)std::floor(current_time) + 1 : active_key + 1;
             std::fprintf(csv, "%d,%d,%d,%g,%g\n", frame + 1, keyframe, frames_accumulated, st.render_time, app_ms);
-            // once per second of animation time, at the end of the keyframe (libapp/app_state.cpp:484-493)
-            if (!profiling_img_prefix.empty() && (current_time + dt) >= std::ceil(current_time))
-                save_image(backend, format, profiling_img_prefix, keyframe, "", width, height, img);
-            current_time += dt;
+            // once per keyframe, at its end (libapp/app_state.cpp:484-493): without keyframe files a keyframe is one second
+            const bool key_ends = frames.empty() ? (current_time + dt) >= std::ceil(current_time + 1e-9)
+                                                 : (current_time + dt) >= key_end[(size_t)active_key] - 1e-9;
+            if (!profiling_img_prefix.empty() && key_ends) save_image(backend, format, profiling_img_prefix, keyframe, "", width, height, img);
+            if (!freeze_frame) current_time += dt; // --freeze-frame keeps repeating the same frame (app.cpp:339-345)
+            else if (!frames.empty() && frame + 1 >= (int)std::floor(key_end[(size_t)active_key] * profiling_fps + 0.5)) current_time = key_end[(size_t)active_key];
         }
         std::fclose(csv);
         std::printf("%s: %d frames at %.3g fps animation time, %.3f ms GPU time per frame -> %s\n", backend.name().c_str(), profiling_frames, profiling_fps,

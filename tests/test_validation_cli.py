@@ -343,3 +343,120 @@ def test_exr_png_and_data_capture_outputs(tmp_path):
     r2.close()
     assert subprocess.run([exe, path, "--data-capture", prefix, "--validation", "x"], capture_output=True).returncode == 2
 
+
+
+# ---------------------------------------------------------------- configuration / keyframe files, devices (SURVEY 8f rank 1)
+INI_BASE = """[Window][Debug##Default]
+Pos=60,60
+
+[Application][]
+target spp= 8
+batch spp= 2
+max path depth= 5
+rr path depth= 3
+glossy-only mode= 0
+force bvh rebuild= 1
+rebuild triangle budget= 250000
+pixel radius= 1.000000e+00
+[.][*output channel]
+OUTPUT_CHANNEL_COLOR= 1
+..
+[.][*variant]
+wavefront-gltf-transmission= 1
+..
+
+[Application][scene.vks]
+[.][Camera]
+speed= 1.000000e-01
+position= 1.500000e+00 2.500000e-01 3.000000e+00
+direction= -4.000000e-01 0.000000e+00 -9.165151e-01
+up= 0.000000e+00 1.000000e+00 0.000000e+00
+..
+[.][Sensor]
+light bin size= 8
+..
+[.][Tonemapping]
+[.][*operator]
+FAST_TONE_MAPPING= 1
+..
+exposure= 1.250000e+00
+..
+[.][Scene]
+bump scale= 2.000000e+00
+..
+"""
+
+INI_KEY = """[Application][scene.vks]
+[.][Camera]
+position= -1.000000e+00 0.000000e+00 3.200000e+00
+..
+[.][Tonemapping]
+exposure= -5.000000e-01
+..
+"""
+
+
+def test_cli_reads_the_reference_ini_configuration_files(tmp_path):
+    """--config / --keyframe: the ImGui-settings text the reference serialises its state to (imstate.cpp:226-330): objects, nested
+    headers, combo boxes, %e floats. --describe prints what the files make of the scene's defaults (no GPU needed)."""
+    exe = _build_cli(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    (tmp_path / "base.ini").write_text(INI_BASE)
+    (tmp_path / "key.ini").write_text(INI_KEY)
+    out = subprocess.run([exe, path, "--describe", "--config", str(tmp_path / "base.ini"), "--keyframe", "0.5:" + str(tmp_path / "key.ini"),
+                          "--keyframe", str(tmp_path / "base.ini")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    cfg = lines[1].split()
+    kv = dict(zip(cfg[1::2], cfg[2::2]))
+    assert (int(kv["target_spp"]), int(kv["batch_spp"]), int(kv["max_path_depth"]), int(kv["rr_path_depth"])) == (8, 2, 5, 3)
+    assert abs(float(kv["exposure"]) - 1.25) < 1e-6 and int(kv["tonemap"]) == 2 and int(kv["output_channel"]) == 0
+    assert int(kv["bin_size"]) == 8 and int(kv["variant"]) == abi.VARIANT_GLTF_TRANSMISSION
+    assert int(kv["force_bvh_rebuild"]) == 1 and int(kv["rebuild_triangle_budget"]) == 250000 and abs(float(kv["bump_scale"]) - 2.0) < 1e-6
+    at = cfg.index("cam_pos")
+    assert [float(v) for v in cfg[at + 1:at + 4]] == [1.5, 0.25, 3.0]
+    k0, k1 = lines[2].split(), lines[3].split()
+    assert float(k0[2]) == 0.5 and int(k0[4]) == 1 and abs(float(k0[6]) + 0.5) < 1e-6 and [float(v) for v in k0[8:11]] == [-1.0, 0.0, 3.2]
+    assert float(k1[2]) == 1.0 and int(k1[4]) == 2
+    # a missing file is the reference's error (main.cpp:131-133)
+    bad = subprocess.run([exe, path, "--describe", "--config", str(tmp_path / "nope.ini")], capture_output=True, text=True)
+    assert bad.returncode == 3 and "Cannot find config file" in bad.stderr
+    assert subprocess.run([exe, path, "--validation", "x", "--backend", "vulkan"], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_cli_keyframes_and_two_ranks_on_one_device(tmp_path):
+    """profiling mode over two keyframes (0.5 s + 1 s at 4 fps = 6 frames, the accumulation restarts with the second keyframe, one
+    image per keyframe), --freeze-frame repeats the frame, and --devices 0,0 (two ranks of the frame on one GPU, tiles gathered by the
+    library) writes the image of a single device, bit for bit"""
+    exe = _build_cli(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    (tmp_path / "base.ini").write_text(INI_BASE.replace("wavefront-gltf-transmission", "wavefront-gltf"))
+    (tmp_path / "key.ini").write_text(INI_KEY)
+    common = [exe, path, "--img", "96", "64", "--pfm"]
+    run = subprocess.run(common + ["--profiling", str(tmp_path / "prof"), "--profiling-fps", "4", "--profiling-img", str(tmp_path / "pimg"),
+                                   "--keyframe", "0.5:" + str(tmp_path / "base.ini"), "--keyframe", str(tmp_path / "key.ini")], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    rows = (tmp_path / "prof.csv").read_text().strip().splitlines()
+    assert rows[0] == "frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms" and len(rows) == 1 + 6
+    cols = [r.split(",") for r in rows[1:]]
+    assert [int(c[1]) for c in cols] == [1, 1, 2, 2, 2, 2] and [int(c[2]) for c in cols] == [1, 2, 1, 2, 3, 4]
+    k1, k2 = read_pfm(str(tmp_path / "pimg_0001.pfm")), read_pfm(str(tmp_path / "pimg_0002.pfm"))
+    assert k1.shape == (64, 96, 3) and not np.array_equal(k1, k2)          # another camera, another exposure-independent radiance
+    # one device against two ranks on that device, validation mode, same configuration
+    for tag, extra in (("one", []), ("two", ["--devices", "0,0", "--stripe-rows", "8"])):
+        r = subprocess.run(common + ["--validation", str(tmp_path / tag), "--validation-spp", "4", "--config", str(tmp_path / "base.ini")] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    a, b = read_pfm(str(tmp_path / "one_0004.pfm")), read_pfm(str(tmp_path / "two_0004.pfm"))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.std() > 0.01
+    # --freeze-frame: every frame repeats the same samples -> accumulating the same frame changes nothing
+    for tag, extra in (("f1", ["--validation-spp", "1"]), ("f3", ["--validation-spp", "3"])):
+        r = subprocess.run(common + ["--validation", str(tmp_path / tag), "--freeze-frame"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    f1, f3 = read_pfm(str(tmp_path / "f1_0001.pfm")), read_pfm(str(tmp_path / "f3_0003.pfm"))
+    assert np.array_equal(f1.view(np.uint32), f3.view(np.uint32))
