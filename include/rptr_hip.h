@@ -301,6 +301,16 @@ int rptr_hip_update_vertices(rptr_hip_t *h, uint32_t geometry, const float *xyz,
  * buffer, render_vulkan.cpp:2834-2840): a device-to-device copy ordered on the backend's stream */
 int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const float *device_xyz, uint32_t num_vertices);
 int rptr_hip_refit(rptr_hip_t *h);
+/* RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget (librender/render_params.glsl.h:61,90-93; the reference ships the
+ * options and their UI, libapp/app_state.cpp:65-66, but not the animation extension that consumed them): what rptr_hip_refit does with
+ * a dynamic mesh whose vertices changed. force_bvh_rebuild != 0: a new tree every time. Otherwise rebuild_triangle_budget triangles
+ * may be rebuilt per rptr_hip_refit call -- the budget is saved up until it covers the next dynamic mesh in turn, so a mesh of n
+ * triangles gets a new tree every ceil(n / budget) calls and is refitted in between; 0 (the default here) = refit only.
+ * A rebuild runs on the device, asynchronously, on the stream of the refit: Morton codes + radix sort + binary radix tree + 4-wide
+ * collapse + the encoder of the host builder (csrc/lbvh.h). Ray-query results are those of any tree (closest hit = smallest t, ties
+ * by ids); only the number of node visits differs. rptr_hip_bvh_rebuild_count: device-side rebuilds so far (all scene copies). */
+int rptr_hip_set_bvh_policy(rptr_hip_t *h, int force_bvh_rebuild, int rebuild_triangle_budget);
+int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds);
 
 /* ---- RenderBackend::params / lighting_params / update_config
  * (render_backend.h:69-76, render_vulkan.cpp:2943-2959) */

@@ -66,6 +66,8 @@ def load_library(path=None):
     L.rptr_hip_wait.argtypes = [vp, C.c_uint64, C.POINTER(abi.Stats)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
+    L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
+    L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
@@ -349,6 +351,16 @@ class RenderHip:
 
     def refit(self):
         self._check(self._L.rptr_hip_refit(self._h))
+
+    def set_bvh_policy(self, force_bvh_rebuild=False, rebuild_triangle_budget=0):
+        """RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget (render_params.glsl.h:61,90-93): device-side rebuilds of
+        dynamic meshes instead of refits (include/rptr_hip.h)"""
+        self._check(self._L.rptr_hip_set_bvh_policy(self._h, 1 if force_bvh_rebuild else 0, int(rebuild_triangle_budget)))
+
+    def bvh_rebuild_count(self):
+        n = C.c_uint64()
+        self._check(self._L.rptr_hip_bvh_rebuild_count(self._h, C.byref(n)))
+        return int(n.value)
 
     # ---- the RCCL gather of tile radiance (include/rptr_hip.h "multi-GPU"; csrc/host_comm.h)
     @staticmethod

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "librptr_hip.so")
 SOURCES = ["rptr_hip.hip", "bvh_build.cpp"]
-HEADERS = ["kernels.h", "host_comm.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h", "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
+HEADERS = ["kernels.h", "host_comm.h", "lbvh.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h", "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
 
 # -ffp-contract=off: fused multiply-adds only where the reference writes fma()
 # itself; keeps images bit-reproducible across launches/tilings and comparable

@@ -9,6 +9,7 @@
 
 #include "bvh_build.h"
 #include "kernels.h"
+#include "lbvh.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -35,6 +36,7 @@ struct DevBuf {
 struct MeshRt { // one bottom-level structure
     int node_base = 0;  // absolute index of the root in the shared node array
     int node_count = 0;
+    int node_capacity = 0; // dynamic meshes reserve one node per triangle: what a device-side rebuild (lbvh.h) can need
     int tri_base = 0;
     int tri_count = 0;
     float lo[3], hi[3];
@@ -54,6 +56,13 @@ struct SceneCopy {
     std::vector<const float **> mesh_dyn;   // per mesh: device table of its geometries' dynpos pointers
     std::vector<char> mesh_dirty;           // 0 clean, 1 new vertices, 2 dynamic but triangle bounds never written
     uint64_t version = 0;                   // rptr_hip.refit_version this copy reflects
+    // bottom-up refit (lbvh.h): per node its parent, the number of its inner children, an arrival counter; per mesh the node count
+    int *parent4 = nullptr;
+    uint32_t *ninner4 = nullptr, *visit4 = nullptr;
+    int *mesh_count = nullptr;
+    std::vector<char> device_built;         // per mesh: its tree was rebuilt on the device (node count lives in mesh_count)
+    std::vector<uint64_t> built_epoch;      // per mesh: rptr_hip.rebuild_epoch this copy's tree reflects
+    RpLbvhScratch scratch;                  // work space of device-side rebuilds (allocated at the first one)
 };
 
 struct Span {
@@ -145,11 +154,17 @@ struct rptr_hip {
     std::vector<uint32_t> geom_tris;        // per global geometry: triangle count
     std::vector<int> geom_mesh;             // per global geometry: owning mesh
     std::vector<int> mesh_root;             // per mesh: absolute node index of the BLAS root
-    uint32_t *d_refit_list = nullptr;       // node indices, bit 31 = TLAS node
-    std::vector<std::array<uint32_t, 2>> refit_levels_blas, refit_levels_tlas; // [begin, end) per height
-    uint2 *d_refit_levels = nullptr;        // the same pairs on the device (bottom-level levels, then top-level ones)
-    size_t refit_top_split = 0;             // bottom-level levels [split, end) are small: they run inside rp_k_refit_top
-    bool refit_top_all = false;             // ... together with the instance bounds and the top-level levels
+    uint32_t *d_refit_list = nullptr;       // top-level node indices (bit 31 set) by height
+    std::vector<std::array<uint32_t, 2>> refit_levels_tlas; // [begin, end) per height
+    uint2 *d_refit_levels = nullptr;        // the same pairs on the device
+    bool refit_top_all = false;             // instance bounds + top-level levels fit one single-block launch (rp_k_refit_top)
+    bool has_dynamic = false;               // some mesh is dynamic
+    // BVH policy (RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget, librender/render_params.glsl.h:61,90-93)
+    bool bvh_force_rebuild = false;
+    long long bvh_budget = 0, bvh_credit = 0; // triangles a refit call may rebuild; what has been saved up
+    std::vector<uint64_t> rebuild_epoch;    // per mesh: bumped when the policy asks for a rebuild of its tree
+    int rebuild_cursor = 0;                 // round robin over the dynamic meshes
+    uint64_t rebuilds_done = 0;
     bool host_bvh_stale = false;
     uint64_t vertex_updates = 0, vertex_updates_refitted = 0;
     bool master_refit_pending = false; // rptr_hip_refit with frame contexts that own their sets: the master tree is refitted on demand
@@ -497,12 +512,22 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         rptr::collapse_bvh4(tree, wide);
         mr.node_base = (int)blas_nodes.size();
         mr.node_count = (int)wide.nodes.size();
+        mr.node_capacity = mr.dynamic ? std::max(mr.node_count, (int)mtris.size()) : mr.node_count;
         mr.tri_base = (int)B.tris.size();
         mr.tri_count = (int)mtris.size();
         memcpy(mr.lo, tree.lo, 12);
         memcpy(mr.hi, tree.hi, 12);
         for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
         encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
+        if (mr.node_capacity > mr.node_count) { // room for a device-side rebuild of this dynamic mesh (lbvh.h): unreachable empty nodes
+            rptr::Wide4 pad_src;
+            (void)pad_src;
+            RptrBvh4Node empty;
+            memset(&empty, 0, sizeof(empty));
+            for (int k = 0; k < 4; ++k) empty.child[k] = RPTR_BVH4_EMPTY;
+            blas_nodes.resize((size_t)mr.node_base + mr.node_capacity, empty);
+            blas_boxes.resize((size_t)mr.node_base + mr.node_capacity, std::array<float, 6>{0, 0, 0, 0, 0, 0});
+        }
     }
     // ---- top level over instance bounds (1 instance record per leaf). Partial re-braiding: when many instances overlap
     // (a forest), one box per instance makes rays enter instance after instance just to leave them at the first nodes.
@@ -1102,47 +1127,56 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->num_tlas_nodes = B.num_tlas_nodes;
     memcpy(h->scene_lo, B.scene_lo, 12);
     memcpy(h->scene_hi, B.scene_hi, 12);
-    // ---- refit schedule: nodes of the dynamic meshes by height (children before parents), then the TLAS by height
+    // ---- refit: the top level by height (children before parents); the bottom-level trees of dynamic meshes are refitted bottom-up
+    // with arrival counters (lbvh.h rp_k_refit_up): per node its parent and the number of its inner children
     std::vector<uint32_t> refit_list;
-    h->refit_levels_blas.clear();
     h->refit_levels_tlas.clear();
+    h->has_dynamic = false;
+    for (const MeshRt &mr : h->meshes) h->has_dynamic = h->has_dynamic || mr.dynamic;
+    std::vector<int> h_parent4(h->h_nodes.size(), -1);
+    std::vector<uint32_t> h_ninner4(h->h_nodes.size(), 0u);
     {
         const size_t nn = h->h_nodes.size();
         std::vector<int> height(nn, -1);
-        auto collect = [&](int root, bool tlas_part, std::vector<std::vector<uint32_t>> &by_height) {
-            // iterative post-order: height = 1 + max(height of inner children), 0 for nodes with leaf children only
-            std::vector<std::pair<int, int>> st{{root, 0}};
-            while (!st.empty()) {
-                auto [n, phase] = st.back();
-                st.pop_back();
-                const RptrBvh4Node &nd = h->h_nodes[n];
-                if (phase == 0) {
-                    st.push_back({n, 1});
-                    for (int k = 0; k < 4; ++k)
-                        if (nd.child[k] >= 0) st.push_back({nd.child[k], 0});
-                } else {
-                    int hgt = 0;
-                    for (int k = 0; k < 4; ++k)
-                        if (nd.child[k] >= 0) hgt = std::max(hgt, height[nd.child[k]] + 1);
-                    height[n] = hgt;
-                    if ((size_t)hgt >= by_height.size()) by_height.resize(hgt + 1);
-                    by_height[hgt].push_back((uint32_t)n | (tlas_part ? 0x80000000u : 0u));
-                }
+        std::vector<std::vector<uint32_t>> tlas_levels;
+        // iterative post-order: height = 1 + max(height of inner children), 0 for nodes with leaf children only
+        std::vector<std::pair<int, int>> st{{0, 0}};
+        while (!st.empty()) {
+            auto [n, phase] = st.back();
+            st.pop_back();
+            const RptrBvh4Node &nd = h->h_nodes[n];
+            if (phase == 0) {
+                st.push_back({n, 1});
+                for (int k = 0; k < 4; ++k)
+                    if (nd.child[k] >= 0) st.push_back({nd.child[k], 0});
+            } else {
+                int hgt = 0;
+                for (int k = 0; k < 4; ++k)
+                    if (nd.child[k] >= 0) hgt = std::max(hgt, height[nd.child[k]] + 1);
+                height[n] = hgt;
+                if ((size_t)hgt >= tlas_levels.size()) tlas_levels.resize(hgt + 1);
+                tlas_levels[hgt].push_back((uint32_t)n | 0x80000000u);
             }
-        };
-        std::vector<std::vector<uint32_t>> blas_levels, tlas_levels;
-        for (size_t m = 0; m < h->meshes.size(); ++m)
-            if (h->meshes[m].dynamic) collect(h->mesh_root[m], false, blas_levels);
-        collect(0, true, tlas_levels);
-        for (auto &lv : blas_levels) {
-            h->refit_levels_blas.push_back({(uint32_t)refit_list.size(), (uint32_t)(refit_list.size() + lv.size())});
-            refit_list.insert(refit_list.end(), lv.begin(), lv.end());
         }
         for (auto &lv : tlas_levels) {
             h->refit_levels_tlas.push_back({(uint32_t)refit_list.size(), (uint32_t)(refit_list.size() + lv.size())});
             refit_list.insert(refit_list.end(), lv.begin(), lv.end());
         }
+        for (const MeshRt &mr : h->meshes) {
+            if (!mr.dynamic) continue;
+            for (int i = mr.node_base; i < mr.node_base + mr.node_count; ++i)
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t c = h->h_nodes[(size_t)i].child[k];
+                    if (c >= 0) {
+                        h_parent4[(size_t)c] = i;
+                        h_ninner4[(size_t)i]++;
+                    }
+                }
+        }
     }
+    h->rebuild_epoch.assign(h->meshes.size(), 0);
+    h->bvh_credit = 0;
+    h->rebuild_cursor = 0;
     // ---- upload
     RptrBvh4Node *d_nodes = nullptr;
     RptrBvhTri *d_tris = nullptr;
@@ -1161,18 +1195,14 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     if ((rc = dev_alloc(h, &h->d_refit_list, refit_list.size(), &h->scene_allocs))) return rc;
     if ((rc = dev_alloc(h, &h->master.inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
     h->master.tri_box = nullptr;
-    if (!h->refit_levels_blas.empty() && (rc = dev_alloc(h, &h->master.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
+    if (h->has_dynamic && (rc = dev_alloc(h, &h->master.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
     if (!refit_list.empty()) HIP_TRY(h, hipMemcpy(h->d_refit_list, refit_list.data(), refit_list.size() * 4, hipMemcpyHostToDevice));
     {
-        // the small upper levels of a refit share one launch (kernels.h rp_k_refit_top): every level is one more dependent launch
-        // otherwise, and an animated frame pays for them whatever its size
+        // the instance bounds and the (small) top-level levels of a refit share one launch (kernels.h rp_k_refit_top): every level is one
+        // more dependent launch otherwise, and an animated frame pays for them whatever its size
         const uint32_t small = 4096;
         std::vector<uint2> lv;
-        for (auto &l : h->refit_levels_blas) lv.push_back(make_uint2(l[0], l[1]));
         for (auto &l : h->refit_levels_tlas) lv.push_back(make_uint2(l[0], l[1]));
-        h->refit_top_split = h->refit_levels_blas.size();
-        while (h->refit_top_split > 0 && h->refit_levels_blas[h->refit_top_split - 1][1] - h->refit_levels_blas[h->refit_top_split - 1][0] <= small)
-            h->refit_top_split--;
         h->refit_top_all = h->h_insts.size() <= 4 * small;
         for (auto &l : h->refit_levels_tlas) h->refit_top_all = h->refit_top_all && l[1] - l[0] <= small;
         h->d_refit_levels = nullptr;
@@ -1181,6 +1211,29 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             HIP_TRY(h, hipMemcpy(h->d_refit_levels, lv.data(), lv.size() * sizeof(uint2), hipMemcpyHostToDevice));
         }
     }
+    // per-node topology of the bottom-up refit + per-mesh node counts (master copy)
+    auto make_refit_tables = [&](SceneCopy &sc) -> int {
+        int rc2;
+        sc.device_built.assign(h->meshes.size(), 0);
+        sc.built_epoch.assign(h->meshes.size(), 0);
+        sc.scratch = RpLbvhScratch();
+        sc.parent4 = nullptr;
+        sc.ninner4 = sc.visit4 = nullptr;
+        sc.mesh_count = nullptr;
+        if (!h->has_dynamic) return RPTR_OK;
+        if ((rc2 = dev_alloc(h, &sc.parent4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
+        if ((rc2 = dev_alloc(h, &sc.ninner4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
+        if ((rc2 = dev_alloc(h, &sc.visit4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
+        if ((rc2 = dev_alloc(h, &sc.mesh_count, h->meshes.size(), &h->scene_allocs))) return rc2;
+        HIP_TRY(h, hipMemcpy(sc.parent4, h_parent4.data(), h_parent4.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(sc.ninner4, h_ninner4.data(), h_ninner4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemset(sc.visit4, 0, h->h_nodes.size() * sizeof(uint32_t)));
+        std::vector<int> counts;
+        for (const MeshRt &mr : h->meshes) counts.push_back(mr.node_count);
+        HIP_TRY(h, hipMemcpy(sc.mesh_count, counts.data(), counts.size() * sizeof(int), hipMemcpyHostToDevice));
+        return RPTR_OK;
+    };
+    if ((rc = make_refit_tables(h->master))) return rc;
     h->host_bvh_stale = false;
     h->master_refit_pending = false;
     if ((rc = dev_alloc(h, &h->master.node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
@@ -1213,7 +1266,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->num_materials = (int)s->num_materials;
     // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites
     h->ctx_scene.clear();
-    if (!h->refit_levels_blas.empty() && h->ctx.size() > 1) {
+    if (h->has_dynamic && h->ctx.size() > 1) {
         h->ctx_scene.resize(h->ctx.size());
         for (SceneCopy &sc : h->ctx_scene) {
             sc.dscene = h->master.dscene;
@@ -1262,6 +1315,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             sc.dscene.tris = sc.tris;
             sc.dscene.geoms = cg;
             sc.version = h->refit_version;
+            if ((rc = make_refit_tables(sc))) return rc;
         }
     }
     h->have_scene = true;
@@ -1303,34 +1357,97 @@ int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const floa
 // (render_vulkan.cpp:1323-1354, executed at the top of draw_frame :2165): topology is kept, triangles and all
 // boxes are recomputed on the device, level by level from the leaves up.
 extern "C++" {
-// refits one copy of the mutable scene on stream `st`; all_dynamic: treat every dynamic mesh as changed
+// device-side rebuild of the bottom-level tree of dynamic mesh m of one scene copy (lbvh.h), on stream `st`. The triangles of the mesh
+// (current order) must hold the new vertices already (rp_k_refit_tris).
+static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st) {
+    const MeshRt &mr = h->meshes[m];
+    const uint32_t n = (uint32_t)mr.tri_count;
+    RpLbvhScratch &w = sc.scratch;
+    if (w.capacity < (size_t)std::max<uint32_t>(n, 2)) { // first rebuild (of a mesh this large): work space for the largest dynamic mesh
+        size_t cap = 2;
+        for (const MeshRt &x : h->meshes)
+            if (x.dynamic) cap = std::max<size_t>(cap, (size_t)x.tri_count);
+        int rc;
+        if ((rc = dev_alloc(h, &w.keys_a, cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.keys_b, cap, &h->scene_allocs))) return rc;
+        for (int **p : {&w.left, &w.right, &w.parent, &w.first, &w.last, &w.leaf_parent})
+            if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.bbox, 6 * cap, &h->scene_allocs))) return rc;
+        for (uint32_t **p : {&w.visit, &w.flag, &w.slot})
+            if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.tri_copy, cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.tribox_copy, 6 * cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.bounds, 8, &h->scene_allocs))) return rc;
+        size_t sort_bytes = 0, scan_bytes = 0;
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, w.keys_a, w.keys_b, (int)cap, 0, 62, st);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, w.flag, w.slot, (int)cap, st);
+        w.cub_bytes = std::max(sort_bytes, scan_bytes) + 256;
+        char *tmp = nullptr;
+        if ((rc = dev_alloc(h, &tmp, w.cub_bytes, &h->scene_allocs))) return rc;
+        w.cub_tmp = tmp;
+        w.capacity = cap;
+    }
+    RptrBvhTri *tris = sc.tris + mr.tri_base;
+    float *tri_box = sc.tri_box + 6ull * mr.tri_base;
+    const int g = grid_for(h, n);
+    if (n >= 2) {
+        hipLaunchKernelGGL(rp_k_lbvh_reset, dim3(1), dim3(64), 0, st, w.bounds);
+        hipLaunchKernelGGL(rp_k_lbvh_bounds, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds);
+        hipLaunchKernelGGL(rp_k_lbvh_keys, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds, w.keys_a);
+        size_t bytes = w.cub_bytes;
+        HIP_TRY(h, hipcub::DeviceRadixSort::SortKeys(w.cub_tmp, bytes, w.keys_a, w.keys_b, (int)n, 0, 62, st));
+        hipLaunchKernelGGL(rp_k_lbvh_hierarchy, dim3(g), dim3(256), 0, st, w.keys_b, (int)n, w.left, w.right, w.parent, w.leaf_parent, w.first, w.last);
+        HIP_TRY(h, hipMemcpyAsync(w.tri_copy, tris, (size_t)n * sizeof(RptrBvhTri), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(h, hipMemcpyAsync(w.tribox_copy, tri_box, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(rp_k_lbvh_gather, dim3(g), dim3(256), 0, st, w.keys_b, n, w.tri_copy, w.tribox_copy, tris, tri_box);
+        HIP_TRY(h, hipMemsetAsync(w.visit, 0, (size_t)n * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(rp_k_lbvh_boxes, dim3(g), dim3(256), 0, st, tri_box, (int)n, w.left, w.right, w.parent, w.leaf_parent, w.bbox, w.visit);
+        hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, w.parent, w.first, w.last, w.flag);
+        bytes = w.cub_bytes;
+        HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, bytes, w.flag, w.slot, (int)n - 1, st));
+    }
+    // (tri_box is indexed from the mesh's first triangle here, so leaf references get tri_base added)
+    hipLaunchKernelGGL(rp_k_lbvh_emit, dim3(g), dim3(256), 0, st, (int)n, w.left, w.right, w.first, w.last, w.flag, w.slot, w.bbox, tri_box, mr.node_base, mr.tri_base,
+                       sc.nodes, sc.node_box, sc.parent4, sc.ninner4, sc.visit4, sc.mesh_count + m);
+    HIP_TRY(h, hipGetLastError());
+    sc.device_built[m] = 1;
+    h->rebuilds_done++;
+    return RPTR_OK;
+}
+
+// refits one copy of the mutable scene on stream `st`; all_dynamic: treat every dynamic mesh as changed. A mesh whose tree is older
+// than the rebuild the policy asked for (rptr_hip_refit) is rebuilt instead of refitted.
 static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipStream_t st) {
-    bool any = all_dynamic && !h->refit_levels_blas.empty();
-    for (size_t m = 0; m < h->meshes.size(); ++m) any = any || sc.mesh_dirty[m] == 1;
+    bool any = all_dynamic && h->has_dynamic;
+    for (size_t m = 0; m < h->meshes.size(); ++m) any = any || sc.mesh_dirty[m] == 1 || (h->meshes[m].dynamic && sc.built_epoch[m] != h->rebuild_epoch[m]);
     if (!any) return false;
     for (size_t m = 0; m < h->meshes.size(); ++m) {
         const MeshRt &mr = h->meshes[m];
         if (!mr.dynamic) continue;
-        if (!all_dynamic && !sc.mesh_dirty[m]) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
+        const bool rebuild = sc.built_epoch[m] != h->rebuild_epoch[m];
+        if (!all_dynamic && !sc.mesh_dirty[m] && !rebuild) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
         if (mr.tri_count)
             hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.tris, sc.tri_box, (uint32_t)mr.tri_base,
                                (uint32_t)mr.tri_count, sc.mesh_dyn[m]);
         sc.mesh_dirty[m] = 0;
+        if (rebuild) {
+            if (lbvh_rebuild(h, sc, m, st) != RPTR_OK) return true; // (the error text is in the handle; the frame still has a valid, older tree)
+            sc.built_epoch[m] = h->rebuild_epoch[m];
+        } else {
+            // all nodes of the mesh bottom-up in one launch (a clean dynamic mesh refits to identical boxes)
+            RpRefitMesh rm{mr.node_base, sc.device_built[m] ? -1 : mr.node_count, sc.mesh_count + m};
+            const size_t work = sc.device_built[m] ? (size_t)mr.node_capacity : (size_t)mr.node_count;
+            hipLaunchKernelGGL(rp_k_refit_up, dim3(grid_for(h, work)), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.parent4, sc.ninner4, sc.visit4, rm);
+        }
     }
-    // all dynamic BLAS levels (a clean dynamic mesh refits to identical boxes), then instance bounds, then the TLAS
+    // instance bounds, then the top level
     RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
-    const size_t nb = h->refit_levels_blas.size(), nt = h->refit_levels_tlas.size();
-    for (size_t l = 0; l < h->refit_top_split; ++l) { // the large lower levels: one launch each
-        const auto &lv = h->refit_levels_blas[l];
-        hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
-                           h->d_refit_list, lv[0], lv[1]);
-    }
+    const size_t nt = h->refit_levels_tlas.size();
     const uint32_t ni = (uint32_t)h->h_insts.size();
-    if (h->refit_top_split < nb || h->refit_top_all) // the small upper levels (+ instance bounds + top level) in one block
-        hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, h->d_refit_list,
-                           h->d_refit_levels + h->refit_top_split, (int)(nb - h->refit_top_split), h->refit_top_all ? (int)nt : 0, insts,
-                           h->refit_top_all ? ni : 0u);
-    if (!h->refit_top_all) {
+    if (h->refit_top_all) // instance bounds + top-level levels in one block
+        hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, h->d_refit_list, h->d_refit_levels, 0, (int)nt,
+                           insts, ni);
+    else {
         if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
         for (auto &lv : h->refit_levels_tlas)
             hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
@@ -1347,6 +1464,33 @@ int rptr_hip_refit(rptr_hip_t *h) {
     if (h->ctx_scene.empty()) { // frames in flight read the master set
         int rc0 = drain(h);
         if (rc0) return rc0;
+    }
+    // ---- the BVH policy: which dynamic meshes get a new tree instead of a refit (librender/render_params.glsl.h:61,90-93)
+    {
+        bool changed = false;
+        for (size_t m = 0; m < h->meshes.size(); ++m) changed = changed || (h->meshes[m].dynamic && h->master.mesh_dirty[m] == 1);
+        if (changed && h->bvh_force_rebuild) {
+            for (size_t m = 0; m < h->meshes.size(); ++m)
+                if (h->meshes[m].dynamic && h->master.mesh_dirty[m] == 1) h->rebuild_epoch[m]++;
+        } else if (changed && h->bvh_budget > 0) {
+            // a budget of triangles per refit call: it is saved up until it covers the next mesh in turn (a mesh larger than the budget is
+            // rebuilt every ceil(triangles / budget) calls), dynamic meshes take turns
+            long long total = 0;
+            std::vector<size_t> dyn;
+            for (size_t m = 0; m < h->meshes.size(); ++m)
+                if (h->meshes[m].dynamic) {
+                    dyn.push_back(m);
+                    total += h->meshes[m].tri_count;
+                }
+            h->bvh_credit = std::min(h->bvh_credit + h->bvh_budget, std::max(total, h->bvh_budget));
+            for (size_t tries = 0; tries < dyn.size(); ++tries) {
+                const size_t m = dyn[(size_t)h->rebuild_cursor % dyn.size()];
+                if (h->bvh_credit < h->meshes[m].tri_count) break;
+                h->bvh_credit -= h->meshes[m].tri_count;
+                h->rebuild_epoch[m]++;
+                h->rebuild_cursor = (h->rebuild_cursor + 1) % (int)dyn.size();
+            }
+        }
     }
     if (!h->ctx_scene.empty()) {
         // frames render from the contexts' own sets, which follow from the master's VERTICES when their next frame is submitted:
@@ -1845,6 +1989,20 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     c.pending = true;
     c.ticket = h->next_ticket++;
     if (out_ticket) *out_ticket = c.ticket;
+    return RPTR_OK;
+}
+
+int rptr_hip_set_bvh_policy(rptr_hip_t *h, int force_bvh_rebuild, int rebuild_triangle_budget) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (rebuild_triangle_budget < 0) return fail(h, RPTR_E_INVALID, "rebuild_triangle_budget must be >= 0");
+    h->bvh_force_rebuild = force_bvh_rebuild != 0;
+    h->bvh_budget = rebuild_triangle_budget;
+    return RPTR_OK;
+}
+
+int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds) {
+    if (!h || !out_rebuilds) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
+    *out_rebuilds = h->rebuilds_done;
     return RPTR_OK;
 }
 

@@ -270,3 +270,136 @@ def test_animated_frames_in_flight_equal_one_at_a_time(dyn_grid):
     ref, _ = osc.render(W, H, 1, variant=abi.VARIANT_SIMPLE, frame_offset=4)
     rmse, same, _ = image_error(images[-1], ref)
     assert same and rmse < RMSE_TOL
+
+
+# ---------------------------------------------------------------- device-side rebuild + BVH policy (csrc/lbvh.h)
+def _rebuild_check(r, osc, s, seed, lo=-60, hi=60):
+    """ray queries through the device-built tree == the oracle's brute force / own tree, bit for bit; every ray of a frame walks the
+    exported tree exactly as the oracle does (same nodes, same triangles)"""
+    q = _grid_queries(20000, seed) if lo == -60 else random_queries(np.random.default_rng(seed), 20000, lo, hi)
+    res = r.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_OWN, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    assert_ray_visit_parity(r, osc, 64, 48, 1, abi.VARIANT_SIMPLE)
+
+
+@pytest.mark.parametrize("nx,nz", [(96, 48), (400, 200)])
+def test_forced_device_rebuild_equals_refit_and_oracle(nx, nz):
+    """force_bvh_rebuild: every refit of changed vertices builds a new tree on the device (Morton order, binary radix tree, 4-wide
+    collapse, shared encoder). Hits equal those of the refitted host tree and of the oracle's rebuild; the exported tree is walked
+    identically by the oracle; a later plain refit of the device-built tree (bottom-up, node count read on the device) is right too."""
+    s = scenes.grid(nx, nz, deform_t=0.0, name="dyn-grid-rebuild")
+    r = backend.RenderHip()
+    r.initialize(64, 48)
+    r.set_scene(s)
+    osc = O.OracleScene(s)
+    # 1. refit only (no policy): the reference result for the same vertices
+    P1 = scenes.grid_positions(nx, nz, 0.3)
+    r.update_vertices(0, P1)
+    r.refit()
+    q = _grid_queries(20000, 3)
+    refit_hits = r.render_ray_queries(q).copy()
+    assert r.bvh_rebuild_count() == 0
+    # 2. the same vertices again, now with a forced rebuild
+    r.set_bvh_policy(force_bvh_rebuild=True)
+    r.update_vertices(0, P1)
+    r.refit()
+    assert r.bvh_rebuild_count() == 1
+    assert np.array_equal(r.render_ray_queries(q).view(np.uint32), refit_hits.view(np.uint32))
+    osc.set_dynamic_vertices(0, P1)
+    _rebuild_check(r, osc, s, 5)
+    # 3. policy off again: new vertices, a bottom-up refit of the DEVICE-built tree
+    r.set_bvh_policy()
+    P2 = scenes.grid_positions(nx, nz, 0.8)
+    r.update_vertices(0, P2)
+    r.refit()
+    assert r.bvh_rebuild_count() == 1
+    osc.set_dynamic_vertices(0, P2)
+    _rebuild_check(r, osc, s, 6)
+    # 4. refitting unchanged vertices reproduces the device-built tree bit for bit
+    n0, t0, _ = (a.copy() for a in r.export_bvh())
+    r.update_vertices(0, P2)
+    r.refit()
+    n1, t1, _ = r.export_bvh()
+    assert np.array_equal(n0.view(np.uint32), n1.view(np.uint32)) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+    # image of the rebuilt scene against the oracle
+    img, _, _ = gpu_render(s, 64, 48, 2, abi.VARIANT_SIMPLE, renderer=r)
+    ref, _ = osc.render(64, 48, 2, variant=abi.VARIANT_SIMPLE, frame_offset=0)
+    assert image_error(img, ref)[0] < RMSE_TOL
+    r.close()
+
+
+def test_rebuild_triangle_budget_spreads_rebuilds_over_refits():
+    """rebuild_triangle_budget = half the mesh: a new tree every second refit call, refits in between; images of an animated
+    sequence equal those of the refit-only run within tolerance (same hits, different tree), also with frames in flight"""
+    s = scenes.grid(NX, NZ, deform_t=0.0, name="dyn-grid-budget")
+    ntri = s.num_tris()
+    W, H = 96, 64
+    times = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]
+
+    def run(budget, fif):
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(s)
+        r.set_bvh_policy(rebuild_triangle_budget=budget)
+        images, queue = [], []
+
+        def collect():
+            r.wait(queue.pop(0))
+            img = np.zeros((H, W, 4), np.float32)
+            r.readback_framebuffer(img)
+            images.append(img)
+        for t in times:
+            r.update_vertices(0, scenes.grid_positions(NX, NZ, t))
+            r.refit()
+            queue.append(r.render_async(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=1))
+            if len(queue) >= fif:
+                collect()
+        while queue:
+            collect()
+        n = r.bvh_rebuild_count()
+        r.close()
+        return images, n
+
+    ref_images, n0 = run(0, 1)
+    images, n1 = run(ntri // 2, 1)
+    assert n0 == 0 and n1 == len(times) // 2
+    for a, b in zip(images, ref_images):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))   # the closest hit does not depend on the tree: same paths, same image
+    images3, n3 = run(ntri // 2, 3)
+    assert n3 >= len(times) // 2                                       # (every frame context rebuilds its own copy)
+    for a, b in zip(images3, ref_images):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_device_rebuild_of_soups_and_tiny_meshes(seed):
+    """degenerate input for the builder: meshes of a few hundred triangles with collapsed / flat geometry, instanced with shears
+    and mirrors, every mesh dynamic and rebuilt on the device"""
+    s = scenes.soup(seed, tris_per_mesh=37)
+    for m in s.meshes:
+        m.dynamic = True
+    r = backend.RenderHip()
+    r.initialize(64, 64)
+    r.set_scene(s)
+    r.set_bvh_policy(force_bvh_rebuild=True)
+    osc = O.OracleScene(s)
+    rng = np.random.default_rng(seed)
+    for gi, g in enumerate(s.geometries):
+        P = scenes.dequantize_positions(g.qpos, g.scaling, g.offset)
+        P = (P + rng.normal(size=P.shape) * 0.2).astype(np.float32)
+        P[0:3] = P[0]
+        if gi == 1:
+            P[:] = P[0]                                                     # a whole geometry collapsed to a point: all centroids equal
+        r.update_vertices(gi, P)
+        osc.set_dynamic_vertices(gi, P)
+    r.refit()
+    assert r.bvh_rebuild_count() == len(s.meshes)
+    q = random_queries(np.random.default_rng(seed + 1), 20000, -6, 6)
+    res = r.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 200
+    assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
+    r.close()
