@@ -66,10 +66,13 @@ def parse_args():
     ap.add_argument("--animate", action="store_true",
                     help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
                          "(inside the timed region) and renders")
+    ap.add_argument("--rebuild-budget", type=int, default=0,
+                    help="--animate: rptr_hip_set_bvh_policy -- triangles a refit may rebuild on the device (a mesh of n triangles gets a new "
+                         "LBVH tree every ceil(n / budget) frames); -1: force_bvh_rebuild (a new tree every frame); 0: refit only (BASELINE configs[4])")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head. "
-                         "Default: 3 on one GPU, 11 for the small per-rank frames of a multi-GPU split (measured: a 1/8 frame takes 0.34 ms "
-                         "with 3 contexts, 0.28 ms with 7, 0.25 ms with 11; a full frame 1.49 vs 1.46 ms)")
+                         "Default: 11 (7 with --animate). Measured: a full frame 1.51 / 1.44 / 1.40 ms with 3 / 7 / 11 contexts, a 1/8 frame "
+                         "0.34 / 0.28 / 0.25 ms")
     ap.add_argument("--stripe-rows", type=int, default=8,
                     help="rows per screen stripe of the tile split (multiple of 8); stripe s belongs to rank s %% N. 1080 rows in 8-row "
                          "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
@@ -170,7 +173,9 @@ def main():
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
     small_frames = world > 1 or args.emulate_world > 1
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else ((7 if args.animate else 11) if small_frames else 3)  # (dynamic scene: every context refits its own tree copy)
+    # 11 frame contexts (7 for the animated scene: every context refits its own tree copy). One GPU, full frame: 3 / 7 / 11 contexts give
+    # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     else:
@@ -179,6 +184,8 @@ def main():
     t0 = time.time()
     r.set_scene(scene)
     t_build = time.time() - t0
+    if args.animate and args.rebuild_budget != 0:
+        r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
     cam = scene.camera_params()
 
     # ---- the gather (N > 1): the library's own RCCL path, or torch.distributed as plumbing
@@ -440,6 +447,7 @@ def main():
     }
     if refit_ms is not None:
         roofline["update_vertices_and_refit_ms"] = round(refit_ms, 4)
+        roofline["bvh_policy"] = {"rebuild_budget": args.rebuild_budget, "device_rebuilds": r.bvh_rebuild_count()}
     bsdf = "diffuse-only" if variant == abi.VARIANT_SIMPLE else "glTF"
     which = "configs[2]" if args.lights else "configs[1]"
     if args.scene == "forest":

@@ -1025,21 +1025,22 @@ __global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvh4Node *nodes, flo
 __global__ __launch_bounds__(256) void rp_k_refit_instances(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
 }
-// The small top of a refit in ONE launch of one block: the upper bottom-level levels (a level waits for the one below: a block
-// barrier instead of a launch), the instance bounds, the top-level levels. `levels` holds [begin, end) pairs into `list`:
-// n_blas bottom-level levels, then n_tlas top-level ones. Same per-node arithmetic as the stand-alone kernels.
-__global__ __launch_bounds__(1024) void rp_k_refit_top(RptrBvh4Node *nodes, float *node_box, const float *tri_box, float *inst_box, const uint32_t *list,
-                                                       const uint2 *levels, int n_blas, int n_tlas, const RptrBvhInstance *insts, uint32_t n_insts) {
+// The small top of a refit in ONE launch of one block: the shallow bottom-level levels of one dynamic mesh (a level waits for the one
+// below: a block barrier instead of a launch), the instance bounds, the top-level levels. `blas_levels` / `tlas_levels` hold [begin, end)
+// pairs into their lists, in processing order. Same per-node arithmetic as the stand-alone kernels.
+__global__ __launch_bounds__(1024) void rp_k_refit_top(RptrBvh4Node *nodes, float *node_box, const float *tri_box, float *inst_box, const uint32_t *blas_list,
+                                                       const uint2 *blas_levels, int n_blas, const uint32_t *tlas_list, const uint2 *tlas_levels, int n_tlas,
+                                                       const RptrBvhInstance *insts, uint32_t n_insts) {
     for (int l = 0; l < n_blas; ++l) {
-        const uint2 lv = levels[l];
-        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
+        const uint2 lv = blas_levels[l];
+        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, blas_list[i]);
         __syncthreads();
     }
     for (uint32_t i = threadIdx.x; i < n_insts; i += blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
     __syncthreads();
     for (int l = 0; l < n_tlas; ++l) {
-        const uint2 lv = levels[n_blas + l];
-        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
+        const uint2 lv = tlas_levels[l];
+        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, tlas_list[i]);
         __syncthreads();
     }
 }

@@ -11,20 +11,27 @@
 //   3. radix sort of the keys (hipCUB = rocPRIM: a plain library sort),
 //   4. binary radix tree over the sorted keys (Karras 2012: one thread per inner node, no atomics),
 //   5. triangles gathered into sorted order,
-//   6. float boxes of the binary nodes bottom-up (one thread per leaf, the second thread to arrive at a node merges its children),
-//   7. 4-wide collapse: a binary node whose range holds <= RPTR_BVH_MAX_LEAF_TRIS triangles becomes a leaf; of the remaining inner
-//      nodes those of even depth become 4-wide nodes that adopt their grandchildren (odd depths are absorbed) -- an exclusive scan
-//      over the flags gives every 4-wide node its slot (the root gets slot 0 = the mesh's root index, as the traversal expects),
-//   8. every 4-wide node is encoded with rp_bvh4_encode -- the very encoder of the host builder and the refit.
-// The tree is a linear BVH: about 1.2-1.5x more node visits per ray than the host's binned-SAH tree, built in well under a
-// millisecond per million triangles. Ray-query results do not depend on the tree (closest hit = smallest t, ties by ids).
+//   6. 4-wide collapse: a binary node whose range holds <= RP_LBVH_LEAF_TRIS triangles becomes a leaf; of the remaining inner nodes
+//      those of even depth become 4-wide nodes that adopt their grandchildren (odd depths are absorbed) -- an exclusive scan over the
+//      flags gives every 4-wide node its slot (the root gets slot 0 = the mesh's root index, as the traversal expects),
+//   7. the child references of every 4-wide node are written, and the nodes are listed by depth (every inner child of a 4-wide node
+//      lies exactly one 4-wide level below it: depth levels are a valid bottom-up order),
+//   8. boxes and encoding come from a REFIT of the new topology, deepest level first: rp_refit_node + rp_bvh4_encode -- the very
+//      code of every other refit and the encoder of the host builder.
+// No step synchronises threads through memory (per-XCD L2s are not coherent: agent-scope fences inside a kernel cost a write-back
+// each -- a bottom-up pass with arrival counters took 0.8 ms per refit of 300 k nodes against 0.1 ms for launches per level).
+// The tree is a linear BVH: more node visits per ray than the host's binned-SAH tree (measured in profiles/r02_notes.md), built
+// in about a millisecond per million triangles. Ray-query results do not depend on the tree (closest hit = smallest t, ties by ids).
 //
-// Refit (all dynamic meshes, one launch): a thread starts at every 4-wide node without inner children, re-encodes it from the
-// triangle bounds and walks up; at a parent it counts arrivals (agent-scope acq_rel atomic: releases its own stores, acquires the
-// siblings') and the last of the parent's inner children to arrive continues. Same per-node arithmetic as before (rp_refit_node),
-// so "refit of unchanged vertices reproduces the built tree bit for bit" still holds.
+// Refit: launches per depth level, deepest first; the level bounds are read from the device (a device-built tree's level sizes are
+// unknown to the host until an asynchronous copy has arrived; until then every possible level gets its launch).
 #pragma once
 #include <hipcub/hipcub.hpp>
+
+#define RP_REFIT_LEVELS 40 // 4-wide depth levels a tree can have (64-bit keys: binary depth <= 64, 4-wide depth <= 32)
+#ifndef RP_LBVH_LEAF_TRIS
+#define RP_LBVH_LEAF_TRIS 2 // triangles per leaf of a device-built tree (Morton-order leaves are looser than SAH leaves: fewer per leaf)
+#endif
 
 struct RpLbvhScratch { // per scene copy, sized for the largest dynamic mesh, allocated at the first rebuild
     size_t capacity = 0; // triangles
@@ -32,10 +39,8 @@ struct RpLbvhScratch { // per scene copy, sized for the largest dynamic mesh, al
     void *cub_tmp = nullptr;
     size_t cub_bytes = 0;
     int *left = nullptr, *right = nullptr, *parent = nullptr, *first = nullptr, *last = nullptr; // binary inner nodes 0..n-2
-    int *leaf_parent = nullptr; // the inner node above the leaf at sorted position k
-    float *bbox = nullptr;      // [n-1][6] boxes of the binary inner nodes
-    uint32_t *visit = nullptr;  // arrival counters of the binary inner nodes
-    uint32_t *flag = nullptr, *slot = nullptr; // 4-wide node? / its slot (exclusive scan)
+    uint32_t *flag = nullptr, *slot = nullptr, *depth4 = nullptr; // 4-wide node? / its slot (exclusive scan) / its 4-wide depth
+    uint32_t *level_hist = nullptr, *level_cursor = nullptr;      // RP_REFIT_LEVELS entries each
     RptrBvhTri *tri_copy = nullptr;
     float *tribox_copy = nullptr;
     uint32_t *bounds = nullptr; // 6 ordered-uint encoded floats: centroid lo, hi
@@ -110,8 +115,7 @@ RP_DEV int rp_lbvh_delta(const unsigned long long *keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
     return __clzll((long long)(keys[i] ^ keys[j])); // keys are unique: never 64
 }
-__global__ __launch_bounds__(256) void rp_k_lbvh_hierarchy(const unsigned long long *keys, int n, int *left, int *right, int *parent, int *leaf_parent, int *first,
-                                                           int *last) {
+__global__ __launch_bounds__(256) void rp_k_lbvh_hierarchy(const unsigned long long *keys, int n, int *left, int *right, int *parent, int *first, int *last) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
         const int d = rp_lbvh_delta(keys, n, i, i + 1) - rp_lbvh_delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
         const int dmin = rp_lbvh_delta(keys, n, i, i - d);
@@ -135,9 +139,7 @@ __global__ __launch_bounds__(256) void rp_k_lbvh_hierarchy(const unsigned long l
         first[i] = lo;
         last[i] = hi;
         if (lc >= 0) parent[lc] = i;
-        else leaf_parent[gamma] = i;
         if (rc >= 0) parent[rc] = i;
-        else leaf_parent[gamma + 1] = i;
         if (i == 0) parent[0] = -1;
     }
 }
@@ -156,155 +158,91 @@ __global__ __launch_bounds__(256) void rp_k_lbvh_gather(const unsigned long long
         for (int a = 0; a < 6; ++a) o[a] = b[a];
     }
 }
-// 6. boxes of the binary inner nodes, bottom-up
-__global__ __launch_bounds__(256) void rp_k_lbvh_boxes(const float *tri_box, int n, const int *left, const int *right, const int *parent, const int *leaf_parent,
-                                                       float *bbox, uint32_t *visit) {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        int p = n > 1 ? leaf_parent[k] : -1;
-        while (p >= 0) {
-            __threadfence();
-            const uint32_t old = __hip_atomic_fetch_add(&visit[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == 0u) break; // the first to arrive leaves the node to the second
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            const int ch[2] = {left[p], right[p]};
-            for (int c = 0; c < 2; ++c) {
-                const float *b = ch[c] >= 0 ? bbox + 6ull * ch[c] : tri_box + 6ull * (size_t)(~ch[c]);
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = fminf(lo[a], b[a]);
-                    hi[a] = fmaxf(hi[a], b[3 + a]);
-                }
-            }
-            float *o = bbox + 6ull * p;
-            for (int a = 0; a < 3; ++a) {
-                o[a] = lo[a];
-                o[3 + a] = hi[a];
-            }
-            p = parent[p];
-        }
-    }
-}
-// 7a. which binary inner nodes become 4-wide nodes: inner (range > leaf size) and of even depth
-__global__ __launch_bounds__(256) void rp_k_lbvh_flags(int n, const int *parent, const int *first, const int *last, uint32_t *flag) {
+// 6. which binary inner nodes become 4-wide nodes: inner (range > leaf size) and of even depth. depth4[i] = depth / 2 for those.
+__global__ __launch_bounds__(256) void rp_k_lbvh_flags(int n, const int *parent, const int *first, const int *last, uint32_t *flag, uint32_t *depth4) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
-        const bool inner = last[i] - first[i] + 1 > RPTR_BVH_MAX_LEAF_TRIS;
+        const bool inner = last[i] - first[i] + 1 > RP_LBVH_LEAF_TRIS;
         int depth = 0;
         for (int p = parent[i]; p >= 0; p = parent[p]) ++depth;
-        flag[i] = ((inner && (depth & 1) == 0) || i == 0) ? 1u : 0u; // (the root is always a node, also of a mesh of <= 4 triangles)
+        const bool node = (inner && (depth & 1) == 0) || i == 0; // (the root is always a node, also of a mesh of <= RP_LBVH_LEAF_TRIS triangles)
+        flag[i] = node ? 1u : 0u;
+        depth4[i] = (uint32_t)(depth >> 1);
     }
 }
-// 7b + 8. one 4-wide node per flagged binary node
-RP_DEV void rp_lbvh_child(int c, const int *first, const int *last, const uint32_t *slot, int node_base, int tri_base, const float *bbox, const float *tri_box,
-                          int32_t &ref, float lo[3], float hi[3], bool &inner) {
-    // c: a binary child. A leaf of the binary tree, or an inner node with a small range, is a leaf of the 4-wide tree.
-    int f, l;
-    const float *b;
-    if (c < 0) {
-        f = l = ~c;
-        b = tri_box + 6ull * (size_t)f;
-        inner = false;
-    } else {
-        f = first[c];
-        l = last[c];
-        b = bbox + 6ull * c;
-        inner = l - f + 1 > RPTR_BVH_MAX_LEAF_TRIS;
-    }
-    ref = inner ? node_base + (int)slot[c] : RPTR_BVH_LEAF(tri_base + f, l - f + 1);
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = b[a];
-        hi[a] = b[3 + a];
-    }
+// 7. topology of one 4-wide node per flagged binary node: child references only -- boxes and encoding come from the refit that
+// follows (rp_refit_node: leaf children from the triangle bounds, inner children from the exact float bounds of the level below).
+// A binary child that is a leaf of the binary tree, or an inner node with a small range, is a leaf of the 4-wide tree.
+RP_DEV int32_t rp_lbvh_child_ref(int c, const int *first, const int *last, const uint32_t *slot, int node_base, int tri_base) {
+    if (c < 0) return RPTR_BVH_LEAF(tri_base + ~c, 1);
+    const int f = first[c], l = last[c];
+    return l - f + 1 > RP_LBVH_LEAF_TRIS ? node_base + (int)slot[c] : RPTR_BVH_LEAF(tri_base + f, l - f + 1);
 }
+// levels: slot k of the level table holds the nodes of depth RP_REFIT_LEVELS - 1 - k, so that ascending k = deepest first
 __global__ __launch_bounds__(256) void rp_k_lbvh_emit(int n, const int *left, const int *right, const int *first, const int *last, const uint32_t *flag,
-                                                      const uint32_t *slot, const float *bbox, const float *tri_box, int node_base, int tri_base,
-                                                      RptrBvh4Node *nodes, float *node_box, int *parent4, uint32_t *ninner4, uint32_t *visit4, int *out_count) {
+                                                      const uint32_t *slot, const uint32_t *depth4, int node_base, int tri_base, RptrBvh4Node *nodes,
+                                                      uint32_t *level_hist, int *out_count) {
+    __shared__ uint32_t s_hist[RP_REFIT_LEVELS];
+    if (threadIdx.x < RP_REFIT_LEVELS) s_hist[threadIdx.x] = 0;
+    __syncthreads();
     const int n_inner = max(n - 1, 1);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_inner; i += gridDim.x * blockDim.x) {
-        if (n < 2) { // a mesh of one triangle (or none): a root with that leaf
-            int32_t child[4] = {n == 1 ? RPTR_BVH_LEAF(tri_base, 1) : RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY};
-            RpBox4 b;
-            for (int k = 0; k < 4; ++k)
-                for (int a = 0; a < 3; ++a) {
-                    b.lo[k][a] = (k == 0 && n == 1) ? tri_box[a] : INFINITY;
-                    b.hi[k][a] = (k == 0 && n == 1) ? tri_box[3 + a] : -INFINITY;
-                }
-            RptrBvh4Node nd;
-            float *nb = node_box + 6ull * node_base;
-            rp_bvh4_encode(b, child, &nd, nb, nb + 3);
-            nodes[node_base] = nd;
-            parent4[node_base] = -1;
-            ninner4[node_base] = 0;
-            visit4[node_base] = 0;
-            *out_count = 1;
-            return;
-        }
-        if (i == n - 2) *out_count = (int)(slot[i] + flag[i]); // (the scan is exclusive: the last element closes the count)
-        if (!flag[i]) continue;
-        const int me = node_base + (int)slot[i];
         int32_t child[4] = {RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY};
-        RpBox4 b;
-        for (int k = 0; k < 4; ++k)
-            for (int a = 0; a < 3; ++a) {
-                b.lo[k][a] = INFINITY;
-                b.hi[k][a] = -INFINITY;
-            }
-        int nc = 0;
-        uint32_t n_in = 0;
-        const bool me_inner = last[i] - first[i] + 1 > RPTR_BVH_MAX_LEAF_TRIS;
-        if (!me_inner) { // only the root of a tiny mesh: one leaf with everything
-            child[0] = RPTR_BVH_LEAF(tri_base + first[i], last[i] - first[i] + 1);
-            for (int a = 0; a < 3; ++a) {
-                b.lo[0][a] = bbox[6ull * i + a];
-                b.hi[0][a] = bbox[6ull * i + 3 + a];
-            }
-            nc = 1;
+        int me = node_base;
+        uint32_t depth = 0;
+        if (n < 2) { // a mesh of one triangle (or none): a root with that leaf
+            if (n == 1) child[0] = RPTR_BVH_LEAF(tri_base, 1);
+            *out_count = 1;
         } else {
-            const int two[2] = {left[i], right[i]};
-            for (int c = 0; c < 2; ++c) {
-                const int ch = two[c];
-                const bool absorb = ch >= 0 && last[ch] - first[ch] + 1 > RPTR_BVH_MAX_LEAF_TRIS; // an inner node of odd depth: its children move up
-                const int cand[2] = {absorb ? left[ch] : ch, absorb ? right[ch] : ch};
-                for (int g = 0; g < (absorb ? 2 : 1); ++g) {
-                    bool inner;
-                    rp_lbvh_child(cand[g], first, last, slot, node_base, tri_base, bbox, tri_box, child[nc], b.lo[nc], b.hi[nc], inner);
-                    if (inner) {
-                        parent4[child[nc]] = me;
-                        ++n_in;
-                    }
-                    ++nc;
+            if (i == n - 2) *out_count = (int)(slot[i] + flag[i]); // (the scan is exclusive: the last element closes the count)
+            if (!flag[i]) continue;
+            me = node_base + (int)slot[i];
+            depth = depth4[i];
+            if (last[i] - first[i] + 1 <= RP_LBVH_LEAF_TRIS) // only the root of a tiny mesh: one leaf with everything
+                child[0] = RPTR_BVH_LEAF(tri_base + first[i], last[i] - first[i] + 1);
+            else {
+                int nc = 0;
+                const int two[2] = {left[i], right[i]};
+                for (int c = 0; c < 2; ++c) {
+                    const int ch = two[c];
+                    if (ch >= 0 && last[ch] - first[ch] + 1 > RP_LBVH_LEAF_TRIS) { // an inner node of odd depth: its children move up
+                        child[nc++] = rp_lbvh_child_ref(left[ch], first, last, slot, node_base, tri_base);
+                        child[nc++] = rp_lbvh_child_ref(right[ch], first, last, slot, node_base, tri_base);
+                    } else
+                        child[nc++] = rp_lbvh_child_ref(ch, first, last, slot, node_base, tri_base);
                 }
             }
         }
         RptrBvh4Node nd;
-        float *nb = node_box + 6ull * me;
-        rp_bvh4_encode(b, child, &nd, nb, nb + 3);
+        __builtin_memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 4; ++k) nd.child[k] = child[k];
+        nd._pad1[0] = min(depth, (uint32_t)(RP_REFIT_LEVELS - 1)); // parked in the node's padding until rp_k_lbvh_level_scatter has read it
         nodes[me] = nd;
-        ninner4[me] = n_in;
-        visit4[me] = 0;
-        if (i == 0) parent4[me] = -1;
+        atomicAdd(&s_hist[RP_REFIT_LEVELS - 1 - min(depth, (uint32_t)(RP_REFIT_LEVELS - 1))], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < RP_REFIT_LEVELS && s_hist[threadIdx.x]) atomicAdd(&level_hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+// level table of one mesh from the histogram: [begin, end) into the mesh's slice of the node list; cursor[k] = begin (for the scatter)
+__global__ void rp_k_lbvh_level_scan(const uint32_t *level_hist, uint32_t list_base, uint2 *levels, uint32_t *cursor) {
+    if (threadIdx.x != 0) return;
+    uint32_t at = list_base;
+    for (int k = 0; k < RP_REFIT_LEVELS; ++k) {
+        levels[k] = make_uint2(at, at + level_hist[k]);
+        cursor[k] = at;
+        at += level_hist[k];
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_lbvh_level_scatter(const RptrBvh4Node *nodes, int node_base, const int *count_ptr, uint32_t *cursor, uint32_t *list) {
+    const int count = *count_ptr;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const uint32_t depth = nodes[node_base + k]._pad1[0];
+        list[atomicAdd(&cursor[RP_REFIT_LEVELS - 1 - depth], 1u)] = (uint32_t)(node_base + k);
     }
 }
 
-// ------------------------------------------------------------------ bottom-up refit of the dynamic bottom-level trees
-// meshes[]: (node_base, pointer to the node count) of every dynamic mesh that is refitted by this launch
-struct RpRefitMesh {
-    int node_base;
-    int node_count; // host-known count, or -1: read *count_ptr (a tree the device built)
-    const int *count_ptr;
-};
-__global__ __launch_bounds__(256) void rp_k_refit_up(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const int *parent4, const uint32_t *ninner4,
-                                                     uint32_t *visit4, RpRefitMesh mesh) {
-    const int count = mesh.node_count >= 0 ? mesh.node_count : *mesh.count_ptr;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        int j = mesh.node_base + k;
-        if (ninner4[j] != 0u) continue; // starts are the nodes whose children are all leaves
-        for (;;) {
-            rp_refit_node(nodes, node_box, tri_box, nullptr, (uint32_t)j);
-            const int p = parent4[j];
-            if (p < 0) break;
-            __threadfence();
-            const uint32_t old = __hip_atomic_fetch_add(&visit4[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if ((old + 1u) % ninner4[p] != 0u) break; // not the last inner child to arrive (the counter is never reset: it runs modulo)
-            j = p;
-        }
-    }
+// ------------------------------------------------------------------ refit by depth levels whose sizes live on the device
+// one level of a mesh: the nodes list[levels[k].x .. levels[k].y)
+__global__ __launch_bounds__(256) void rp_k_refit_level(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const uint32_t *list, const uint2 *level) {
+    const uint2 lv = *level;
+    for (uint32_t i = lv.x + blockIdx.x * blockDim.x + threadIdx.x; i < lv.y; i += gridDim.x * blockDim.x) rp_refit_node(nodes, node_box, tri_box, nullptr, list[i]);
 }

@@ -56,10 +56,15 @@ struct SceneCopy {
     std::vector<const float **> mesh_dyn;   // per mesh: device table of its geometries' dynpos pointers
     std::vector<char> mesh_dirty;           // 0 clean, 1 new vertices, 2 dynamic but triangle bounds never written
     uint64_t version = 0;                   // rptr_hip.refit_version this copy reflects
-    // bottom-up refit (lbvh.h): per node its parent, the number of its inner children, an arrival counter; per mesh the node count
-    int *parent4 = nullptr;
-    uint32_t *ninner4 = nullptr, *visit4 = nullptr;
+    // refit of the dynamic bottom-level trees by depth levels (lbvh.h): the node list (every mesh's nodes in its own slice, deepest
+    // level first), per mesh RP_REFIT_LEVELS [begin, end) pairs, per mesh the node count
+    uint32_t *blas_list = nullptr;
+    uint2 *blas_levels = nullptr;
     int *mesh_count = nullptr;
+    std::vector<std::array<uint2, RP_REFIT_LEVELS>> host_levels; // per mesh: the level table as the host knows it
+    std::vector<char> levels_known;         // per mesh: host_levels is current (a device-built tree: once its read-back has arrived)
+    std::vector<uint2 *> pinned_levels;     // per dynamic mesh: pinned staging of that read-back
+    std::vector<hipEvent_t> ev_levels;
     std::vector<char> device_built;         // per mesh: its tree was rebuilt on the device (node count lives in mesh_count)
     std::vector<uint64_t> built_epoch;      // per mesh: rptr_hip.rebuild_epoch this copy's tree reflects
     RpLbvhScratch scratch;                  // work space of device-side rebuilds (allocated at the first one)
@@ -232,6 +237,15 @@ int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track) {
     (track ? track : &h->allocations)->push_back(p);
     *out = reinterpret_cast<T *>(p);
     return RPTR_OK;
+}
+
+void release_scene_copy_host(SceneCopy &sc) { // pinned staging + events of the level read-backs
+    for (uint2 *p : sc.pinned_levels)
+        if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : sc.ev_levels)
+        if (e) (void)hipEventDestroy(e);
+    sc.pinned_levels.clear();
+    sc.ev_levels.clear();
 }
 
 void free_list(std::vector<void *> &v) {
@@ -808,6 +822,8 @@ void rptr_hip_destroy(rptr_hip_t *h) {
     for (FrameCtx &c : h->ctx) (void)hipStreamSynchronize(c.stream);
     (void)hipStreamSynchronize(h->stream);
     comm_release(h);
+    release_scene_copy_host(h->master);
+    for (SceneCopy &sc : h->ctx_scene) release_scene_copy_host(sc);
     free_list(h->allocations);
     free_list(h->scene_allocs);
     for (FrameCtx &c : h->ctx) {
@@ -1133,8 +1149,9 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->refit_levels_tlas.clear();
     h->has_dynamic = false;
     for (const MeshRt &mr : h->meshes) h->has_dynamic = h->has_dynamic || mr.dynamic;
-    std::vector<int> h_parent4(h->h_nodes.size(), -1);
-    std::vector<uint32_t> h_ninner4(h->h_nodes.size(), 0u);
+    // depth levels of every dynamic mesh's tree (slot RP_REFIT_LEVELS - 1 - depth: ascending slot = deepest first)
+    std::vector<uint32_t> h_blas_list(h->h_nodes.size(), 0u);
+    std::vector<std::array<uint2, RP_REFIT_LEVELS>> h_levels(h->meshes.size());
     {
         const size_t nn = h->h_nodes.size();
         std::vector<int> height(nn, -1);
@@ -1162,16 +1179,28 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             h->refit_levels_tlas.push_back({(uint32_t)refit_list.size(), (uint32_t)(refit_list.size() + lv.size())});
             refit_list.insert(refit_list.end(), lv.begin(), lv.end());
         }
-        for (const MeshRt &mr : h->meshes) {
+        for (size_t m = 0; m < h->meshes.size(); ++m) {
+            const MeshRt &mr = h->meshes[m];
+            for (auto &l : h_levels[m]) l = make_uint2((uint32_t)mr.node_base, (uint32_t)mr.node_base);
             if (!mr.dynamic) continue;
-            for (int i = mr.node_base; i < mr.node_base + mr.node_count; ++i)
-                for (int k = 0; k < 4; ++k) {
-                    const int32_t c = h->h_nodes[(size_t)i].child[k];
-                    if (c >= 0) {
-                        h_parent4[(size_t)c] = i;
-                        h_ninner4[(size_t)i]++;
-                    }
-                }
+            std::vector<std::vector<uint32_t>> by_depth;
+            std::vector<std::pair<int, int>> bfs{{h->mesh_root[m], 0}};
+            for (size_t at = 0; at < bfs.size(); ++at) {
+                const auto [n, d] = bfs[at];
+                if ((size_t)d >= by_depth.size()) by_depth.resize((size_t)d + 1);
+                by_depth[(size_t)d].push_back((uint32_t)n);
+                for (int k = 0; k < 4; ++k)
+                    if (h->h_nodes[(size_t)n].child[k] >= 0) bfs.push_back({h->h_nodes[(size_t)n].child[k], d + 1});
+            }
+            if (by_depth.size() > RP_REFIT_LEVELS) return fail(h, RPTR_E_UNSUPPORTED, "mesh %zu: a tree of %zu levels (limit %d)", m, by_depth.size(), RP_REFIT_LEVELS);
+            uint32_t at = (uint32_t)mr.node_base;
+            for (int slot = 0; slot < RP_REFIT_LEVELS; ++slot) {
+                const int d = RP_REFIT_LEVELS - 1 - slot;
+                const uint32_t cnt = (size_t)d < by_depth.size() ? (uint32_t)by_depth[(size_t)d].size() : 0u;
+                h_levels[m][(size_t)slot] = make_uint2(at, at + cnt);
+                for (uint32_t k = 0; k < cnt; ++k) h_blas_list[at + k] = by_depth[(size_t)d][k];
+                at += cnt;
+            }
         }
     }
     h->rebuild_epoch.assign(h->meshes.size(), 0);
@@ -1211,26 +1240,35 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             HIP_TRY(h, hipMemcpy(h->d_refit_levels, lv.data(), lv.size() * sizeof(uint2), hipMemcpyHostToDevice));
         }
     }
-    // per-node topology of the bottom-up refit + per-mesh node counts (master copy)
+    // level tables + node lists of the dynamic meshes + per-mesh node counts (one set per scene copy: copies are rebuilt independently)
     auto make_refit_tables = [&](SceneCopy &sc) -> int {
         int rc2;
         sc.device_built.assign(h->meshes.size(), 0);
         sc.built_epoch.assign(h->meshes.size(), 0);
         sc.scratch = RpLbvhScratch();
-        sc.parent4 = nullptr;
-        sc.ninner4 = sc.visit4 = nullptr;
+        sc.blas_list = nullptr;
+        sc.blas_levels = nullptr;
         sc.mesh_count = nullptr;
+        sc.host_levels = h_levels;
+        sc.levels_known.assign(h->meshes.size(), 1);
+        release_scene_copy_host(sc);
+        sc.pinned_levels.assign(h->meshes.size(), nullptr);
+        sc.ev_levels.assign(h->meshes.size(), nullptr);
         if (!h->has_dynamic) return RPTR_OK;
-        if ((rc2 = dev_alloc(h, &sc.parent4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
-        if ((rc2 = dev_alloc(h, &sc.ninner4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
-        if ((rc2 = dev_alloc(h, &sc.visit4, h->h_nodes.size(), &h->scene_allocs))) return rc2;
+        if ((rc2 = dev_alloc(h, &sc.blas_list, h->h_nodes.size(), &h->scene_allocs))) return rc2;
+        if ((rc2 = dev_alloc(h, &sc.blas_levels, h->meshes.size() * RP_REFIT_LEVELS, &h->scene_allocs))) return rc2;
         if ((rc2 = dev_alloc(h, &sc.mesh_count, h->meshes.size(), &h->scene_allocs))) return rc2;
-        HIP_TRY(h, hipMemcpy(sc.parent4, h_parent4.data(), h_parent4.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemcpy(sc.ninner4, h_ninner4.data(), h_ninner4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemset(sc.visit4, 0, h->h_nodes.size() * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemcpy(sc.blas_list, h_blas_list.data(), h_blas_list.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(sc.blas_levels, h_levels.data(), h_levels.size() * sizeof(h_levels[0]), hipMemcpyHostToDevice));
         std::vector<int> counts;
         for (const MeshRt &mr : h->meshes) counts.push_back(mr.node_count);
         HIP_TRY(h, hipMemcpy(sc.mesh_count, counts.data(), counts.size() * sizeof(int), hipMemcpyHostToDevice));
+        for (size_t m = 0; m < h->meshes.size(); ++m)
+            if (h->meshes[m].dynamic) {
+                if (hipHostMalloc((void **)&sc.pinned_levels[m], RP_REFIT_LEVELS * sizeof(uint2), hipHostMallocDefault) != hipSuccess)
+                    return fail(h, RPTR_E_NOMEM, "hipHostMalloc failed");
+                HIP_TRY(h, hipEventCreateWithFlags(&sc.ev_levels[m], hipEventDisableTiming));
+            }
         return RPTR_OK;
     };
     if ((rc = make_refit_tables(h->master))) return rc;
@@ -1265,6 +1303,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
     // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites
+    for (SceneCopy &sc : h->ctx_scene) release_scene_copy_host(sc);
     h->ctx_scene.clear();
     if (h->has_dynamic && h->ctx.size() > 1) {
         h->ctx_scene.resize(h->ctx.size());
@@ -1357,9 +1396,33 @@ int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const floa
 // (render_vulkan.cpp:1323-1354, executed at the top of draw_frame :2165): topology is kept, triangles and all
 // boxes are recomputed on the device, level by level from the leaves up.
 extern "C++" {
+// the depth levels of dynamic mesh m of one scene copy, deepest first: a launch per deep level, the shallow ones (at most 4^5 + ... + 1
+// nodes) in the single-block kernel, which also does the instance bounds and the top level when `with_top`
+static void refit_mesh_levels(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bool with_top) {
+    const MeshRt &mr = h->meshes[m];
+    if (!sc.levels_known[m] && sc.ev_levels[m] && hipEventQuery(sc.ev_levels[m]) == hipSuccess) { // the read-back of a device-built tree's table has arrived
+        memcpy(sc.host_levels[m].data(), sc.pinned_levels[m], RP_REFIT_LEVELS * sizeof(uint2));
+        sc.levels_known[m] = 1;
+    }
+    const uint2 *dev_levels = sc.blas_levels + m * RP_REFIT_LEVELS;
+    const int n_top = 6; // depths 0..5
+    for (int slot = 0; slot < RP_REFIT_LEVELS - n_top; ++slot) {
+        size_t work = (size_t)mr.node_capacity; // level size unknown to the host: any launch covers it (grid stride)
+        if (sc.levels_known[m]) {
+            work = sc.host_levels[m][(size_t)slot].y - sc.host_levels[m][(size_t)slot].x;
+            if (!work) continue;
+        }
+        hipLaunchKernelGGL(rp_k_refit_level, dim3(grid_for(h, work, 4)), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.blas_list, dev_levels + slot);
+    }
+    RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
+    hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, sc.blas_list,
+                       dev_levels + (RP_REFIT_LEVELS - n_top), n_top, h->d_refit_list, h->d_refit_levels, with_top ? (int)h->refit_levels_tlas.size() : 0, insts,
+                       with_top ? (uint32_t)h->h_insts.size() : 0u);
+}
+
 // device-side rebuild of the bottom-level tree of dynamic mesh m of one scene copy (lbvh.h), on stream `st`. The triangles of the mesh
-// (current order) must hold the new vertices already (rp_k_refit_tris).
-static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st) {
+// (current order) must hold the new vertices already (rp_k_refit_tris). Ends with the refit that gives the new topology its boxes.
+static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bool with_top) {
     const MeshRt &mr = h->meshes[m];
     const uint32_t n = (uint32_t)mr.tri_count;
     RpLbvhScratch &w = sc.scratch;
@@ -1370,11 +1433,12 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st) {
         int rc;
         if ((rc = dev_alloc(h, &w.keys_a, cap, &h->scene_allocs))) return rc;
         if ((rc = dev_alloc(h, &w.keys_b, cap, &h->scene_allocs))) return rc;
-        for (int **p : {&w.left, &w.right, &w.parent, &w.first, &w.last, &w.leaf_parent})
+        for (int **p : {&w.left, &w.right, &w.parent, &w.first, &w.last})
             if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.bbox, 6 * cap, &h->scene_allocs))) return rc;
-        for (uint32_t **p : {&w.visit, &w.flag, &w.slot})
+        for (uint32_t **p : {&w.flag, &w.slot, &w.depth4})
             if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.level_hist, RP_REFIT_LEVELS, &h->scene_allocs))) return rc;
+        if ((rc = dev_alloc(h, &w.level_cursor, RP_REFIT_LEVELS, &h->scene_allocs))) return rc;
         if ((rc = dev_alloc(h, &w.tri_copy, cap, &h->scene_allocs))) return rc;
         if ((rc = dev_alloc(h, &w.tribox_copy, 6 * cap, &h->scene_allocs))) return rc;
         if ((rc = dev_alloc(h, &w.bounds, 8, &h->scene_allocs))) return rc;
@@ -1396,19 +1460,26 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st) {
         hipLaunchKernelGGL(rp_k_lbvh_keys, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds, w.keys_a);
         size_t bytes = w.cub_bytes;
         HIP_TRY(h, hipcub::DeviceRadixSort::SortKeys(w.cub_tmp, bytes, w.keys_a, w.keys_b, (int)n, 0, 62, st));
-        hipLaunchKernelGGL(rp_k_lbvh_hierarchy, dim3(g), dim3(256), 0, st, w.keys_b, (int)n, w.left, w.right, w.parent, w.leaf_parent, w.first, w.last);
+        hipLaunchKernelGGL(rp_k_lbvh_hierarchy, dim3(g), dim3(256), 0, st, w.keys_b, (int)n, w.left, w.right, w.parent, w.first, w.last);
         HIP_TRY(h, hipMemcpyAsync(w.tri_copy, tris, (size_t)n * sizeof(RptrBvhTri), hipMemcpyDeviceToDevice, st));
         HIP_TRY(h, hipMemcpyAsync(w.tribox_copy, tri_box, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(rp_k_lbvh_gather, dim3(g), dim3(256), 0, st, w.keys_b, n, w.tri_copy, w.tribox_copy, tris, tri_box);
-        HIP_TRY(h, hipMemsetAsync(w.visit, 0, (size_t)n * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(rp_k_lbvh_boxes, dim3(g), dim3(256), 0, st, tri_box, (int)n, w.left, w.right, w.parent, w.leaf_parent, w.bbox, w.visit);
-        hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, w.parent, w.first, w.last, w.flag);
+        hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, w.parent, w.first, w.last, w.flag, w.depth4);
         bytes = w.cub_bytes;
         HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, bytes, w.flag, w.slot, (int)n - 1, st));
     }
-    // (tri_box is indexed from the mesh's first triangle here, so leaf references get tri_base added)
-    hipLaunchKernelGGL(rp_k_lbvh_emit, dim3(g), dim3(256), 0, st, (int)n, w.left, w.right, w.first, w.last, w.flag, w.slot, w.bbox, tri_box, mr.node_base, mr.tri_base,
-                       sc.nodes, sc.node_box, sc.parent4, sc.ninner4, sc.visit4, sc.mesh_count + m);
+    HIP_TRY(h, hipMemsetAsync(w.level_hist, 0, RP_REFIT_LEVELS * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(rp_k_lbvh_emit, dim3(g), dim3(256), 0, st, (int)n, w.left, w.right, w.first, w.last, w.flag, w.slot, w.depth4, mr.node_base, mr.tri_base, sc.nodes,
+                       w.level_hist, sc.mesh_count + m);
+    uint2 *dev_levels = sc.blas_levels + m * RP_REFIT_LEVELS;
+    hipLaunchKernelGGL(rp_k_lbvh_level_scan, dim3(1), dim3(64), 0, st, w.level_hist, (uint32_t)mr.node_base, dev_levels, w.level_cursor);
+    hipLaunchKernelGGL(rp_k_lbvh_level_scatter, dim3(grid_for(h, (size_t)mr.node_capacity)), dim3(256), 0, st, sc.nodes, mr.node_base, sc.mesh_count + m, w.level_cursor,
+                       sc.blas_list);
+    // the host learns the level sizes when this copy has arrived; until then a refit launches every possible level
+    sc.levels_known[m] = 0;
+    HIP_TRY(h, hipMemcpyAsync(sc.pinned_levels[m], dev_levels, RP_REFIT_LEVELS * sizeof(uint2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipEventRecord(sc.ev_levels[m], st));
+    refit_mesh_levels(h, sc, m, st, with_top);
     HIP_TRY(h, hipGetLastError());
     sc.device_built[m] = 1;
     h->rebuilds_done++;
@@ -1421,37 +1492,43 @@ static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipSt
     bool any = all_dynamic && h->has_dynamic;
     for (size_t m = 0; m < h->meshes.size(); ++m) any = any || sc.mesh_dirty[m] == 1 || (h->meshes[m].dynamic && sc.built_epoch[m] != h->rebuild_epoch[m]);
     if (!any) return false;
+    std::vector<size_t> todo;
     for (size_t m = 0; m < h->meshes.size(); ++m) {
         const MeshRt &mr = h->meshes[m];
         if (!mr.dynamic) continue;
         const bool rebuild = sc.built_epoch[m] != h->rebuild_epoch[m];
         if (!all_dynamic && !sc.mesh_dirty[m] && !rebuild) continue; // 1 = new vertices, 2 = dynamic but its triangle bounds were never written
+        todo.push_back(m);
+    }
+    // the instance bounds and the top level ride in the single-block launch of the last mesh when they are small
+    bool top_done = false;
+    for (size_t k = 0; k < todo.size(); ++k) {
+        const size_t m = todo[k];
+        const MeshRt &mr = h->meshes[m];
+        const bool with_top = h->refit_top_all && k + 1 == todo.size();
         if (mr.tri_count)
             hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.tris, sc.tri_box, (uint32_t)mr.tri_base,
                                (uint32_t)mr.tri_count, sc.mesh_dyn[m]);
         sc.mesh_dirty[m] = 0;
-        if (rebuild) {
-            if (lbvh_rebuild(h, sc, m, st) != RPTR_OK) return true; // (the error text is in the handle; the frame still has a valid, older tree)
+        if (sc.built_epoch[m] != h->rebuild_epoch[m]) {
+            if (lbvh_rebuild(h, sc, m, st, with_top) != RPTR_OK) return true; // (the error text is in the handle)
             sc.built_epoch[m] = h->rebuild_epoch[m];
-        } else {
-            // all nodes of the mesh bottom-up in one launch (a clean dynamic mesh refits to identical boxes)
-            RpRefitMesh rm{mr.node_base, sc.device_built[m] ? -1 : mr.node_count, sc.mesh_count + m};
-            const size_t work = sc.device_built[m] ? (size_t)mr.node_capacity : (size_t)mr.node_count;
-            hipLaunchKernelGGL(rp_k_refit_up, dim3(grid_for(h, work)), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.parent4, sc.ninner4, sc.visit4, rm);
-        }
+        } else
+            refit_mesh_levels(h, sc, m, st, with_top);
+        top_done = top_done || with_top;
     }
-    // instance bounds, then the top level
-    RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
-    const size_t nt = h->refit_levels_tlas.size();
-    const uint32_t ni = (uint32_t)h->h_insts.size();
-    if (h->refit_top_all) // instance bounds + top-level levels in one block
-        hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, h->d_refit_list, h->d_refit_levels, 0, (int)nt,
-                           insts, ni);
-    else {
-        if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
-        for (auto &lv : h->refit_levels_tlas)
-            hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
-                               h->d_refit_list, lv[0], lv[1]);
+    if (!top_done) { // instance bounds, then the top level
+        RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
+        const uint32_t ni = (uint32_t)h->h_insts.size();
+        if (h->refit_top_all)
+            hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, sc.blas_list, sc.blas_levels, 0,
+                               h->d_refit_list, h->d_refit_levels, (int)h->refit_levels_tlas.size(), insts, ni);
+        else {
+            if (ni) hipLaunchKernelGGL(rp_k_refit_instances, dim3(grid_for(h, ni)), dim3(256), 0, st, sc.node_box, insts, sc.inst_box, ni);
+            for (auto &lv : h->refit_levels_tlas)
+                hipLaunchKernelGGL(rp_k_refit_nodes, dim3(grid_for(h, lv[1] - lv[0])), dim3(256), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box,
+                                   h->d_refit_list, lv[0], lv[1]);
+        }
     }
     return true;
 }
