@@ -123,13 +123,28 @@ def load_pmc_traffic():
         return None
 
 
-def traffic_of(pmc, prefix):
-    """bytes per launch of the kernel whose (template) name starts with `prefix`, averaged over its launches"""
+def traffic_of(pmc, prefix, field="hbm_bytes_per_launch"):
+    """`field` per launch of the kernel whose (template) name starts with `prefix`, averaged over its launches"""
     if not pmc:
         return None
-    hit = [v for k, v in pmc.get("kernels", {}).items() if k.replace("void ", "").startswith(prefix)]
+    hit = [v for k, v in pmc.get("kernels", {}).items() if k.replace("void ", "").startswith(prefix) and field in v]
     n = sum(v["launches"] for v in hit)
-    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / n if n else None
+    return sum(v[field] * v["launches"] for v in hit) / n if n else None
+
+
+def valu_frame(pmc, ms_per_step, valu_peak, launches):
+    """all kernels of one frame (PMC instruction counts x launches per frame) against the VALU issue peak over the PIPELINED frame time:
+    how much of the machine's instruction issue the steady state uses"""
+    per_frame = {"rp_k_extend<false, true": 1, "rp_k_extend<false, false": max(launches - 1, 0), "rp_k_connect<false": launches,
+                 "rp_k_shade<1, true": 1, "rp_k_shade<1, false": max(launches - 1, 0), "rp_k_tail": 1, "rp_k_resolve": 1}
+    total = 0.0
+    for prefix, n in per_frame.items():
+        v = traffic_of(pmc, prefix, "valu_insts_per_launch")
+        if v is None:
+            return None
+        total += v * n
+    return {"valu_insts_per_step": int(total), "pipelined_ginst_s": round(total / (ms_per_step * 1e-3) / 1e9, 1),
+            "pipelined_frac": round(total / (ms_per_step * 1e-3) / 1e9 / valu_peak, 4)}
 
 
 def main():
@@ -307,13 +322,35 @@ def main():
     gather_host_ms = host_gather_s[0] * 1e3 / args.steps
     gather_gpu_ms = native.stats()[1] if native is not None else None
 
-    # untimed, one frame at a time: (1) events around every stage -> EXCLUSIVE launch durations (no other frame on the GPU): what the
-    # roofline figures use; (2) instrumented frames: node / triangle visits of this rank's queries (counted, not modelled)
-    r.set_stage_timing(2)
+    # untimed, one frame at a time, on a SECOND handle with one frame context (a traversal launch then asks for all the blocks a CU holds;
+    # with 11 contexts each launch is sized to share the GPU with ten others): (1) events around every stage -> EXCLUSIVE launch durations
+    # (nothing else on the GPU): what the roofline figures use; (2) instrumented frames: node / triangle visits of this rank's queries
+    # (counted, not modelled). The rocprofv3 passes under profiles/ run the same configuration (bench.py --profile-pass).
+    torch.cuda.synchronize()
+    rx = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=1)
+    rx.initialize(W, H)
+    rx.set_scene(scene)
+    if args.animate and args.rebuild_budget != 0:
+        rx.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
+
+    def step_x(count=False):
+        if anim is not None:
+            t = 0.02 * anim["frame"]
+            anim["frame"] += 1
+            cur, b = anim["cur"], anim["base"]
+            torch.add(b[:, 1], torch.sin(b[:, 0] * 0.4 + 6.283185307179586 * t), alpha=0.5, out=cur[:, 1])
+            rx.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
+            rx.refit()
+        cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
+        return rx.wait(rx.render_async(cfg, spp=spp, count_traversal=count))
+
+    rx.set_stage_timing(2)
+    for _ in range(3):
+        step_x()
     serial = dict(ext=0.0, con=0.0, shade=0.0, tail=0.0, resolve=0.0, other=0.0, gpu=0.0)
     n_serial = max(3, min(10, args.steps))
     for _ in range(n_serial):
-        st = step().raw
+        st = step_x().raw
         serial["ext"] += st.extend_time_ms / n_serial
         serial["con"] += st.connect_time_ms / n_serial
         serial["shade"] += st.shade_only_time_ms / n_serial
@@ -324,13 +361,13 @@ def main():
 
     def counted(depth=None):
         """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
-        full = r.params.max_path_depth
+        full = rx.params.max_path_depth
         if depth is not None:
-            r.params.max_path_depth = depth
+            rx.params.max_path_depth = depth
         try:
-            stc = step(count=True).raw
+            stc = step_x(count=True).raw
         finally:
-            r.params.max_path_depth = full
+            rx.params.max_path_depth = full
         return dict(rays_closest=int(stc.rays_closest), rays_shadow=int(stc.rays_shadow), hits=int(stc.hits_shaded),
                     nodes_closest=int(stc.nodes_closest), tris_closest=int(stc.tris_closest),
                     nodes_shadow=int(stc.nodes_visited - stc.nodes_closest), tris_shadow=int(stc.tris_tested - stc.tris_closest),
@@ -381,6 +418,9 @@ def main():
                         and (W, H, spp) == (1920, 1080, 4) and world == 1 and args.emulate_world <= 1)
     pmc = load_pmc_traffic() if default_workload else None   # the committed PMC passes were taken on the default workload: no figure for anything else
     n_launch = max(launches_extend, 1)
+    props = torch.cuda.get_device_properties(local_rank)
+    clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6
+    valu_peak = props.multi_processor_count * clock_ghz   # G wave-instructions / s: CUs x 4 SIMDs x 1 VALU instruction per 4 clocks
 
     def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches):
         """one kernel class: exclusive time, algorithmic bytes and their rate against the cache-hierarchy ceiling, counter traffic
@@ -398,6 +438,15 @@ def main():
         e["hbm_bytes_per_launch"] = int(tr) if tr is not None else None
         e["hbm_gbs"] = round(tr / (launch_ms * 1e-3) / 1e9, 1) if (tr is not None and launch_ms > 0) else None
         e["hbm_frac"] = round(e["hbm_gbs"] / HBM_PEAK_GBS, 4) if e["hbm_gbs"] is not None else None
+        # VALU issue: what binds these kernels (PMC: SQ_INSTS_VALU per launch) against CUs x 4 SIMDs x 1 wave instruction per 4 clocks
+        vi = None
+        if pmc:
+            parts = [traffic_of(pmc, p, "valu_insts_per_launch") for p in prefix_list]
+            if all(v is not None for v in parts):
+                vi = sum(parts) / len(parts)
+        e["valu_insts_per_launch"] = int(vi) if vi is not None else None
+        e["valu_ginst_s"] = round(vi / (launch_ms * 1e-3) / 1e9, 1) if (vi is not None and launch_ms > 0) else None
+        e["valu_frac"] = round(e["valu_ginst_s"] / valu_peak, 4) if e["valu_ginst_s"] is not None else None
         return e
 
     single = len(scene.instances) == 1
@@ -425,8 +474,13 @@ def main():
         "algorithmic_ceiling": {"gbs": L2_PEAK_GBS, "what": "aggregate L2 bandwidth, MI355X_MICROARCH.md 'L2 (per XCD)': the tree is cache resident, so the bytes the "
                                                             "lanes consume are bounded by the cache hierarchy, not by HBM"},
         "launch_ms": k_ext["launch_ms"], "launches_per_step": launches_extend, "exclusive_ms_per_step": k_ext["exclusive_ms_per_step"],
-        "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region (no other frame on the GPU); "
+        "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region, on a handle with one frame context (no other frame on the GPU, every launch at full size); "
                   "sum of all stages = stage_ms_per_step.gpu_total" % n_serial,
+        "valu": {"binding_unit": "VALU issue", "peak_ginst_s": round(valu_peak, 1),
+                 "peak_what": "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.2f GHz (hipDeviceProp clockRate)" % (props.multi_processor_count, clock_ghz),
+                 "frac": k_ext["valu_frac"], "ginst_s": k_ext["valu_ginst_s"], "insts_per_launch": k_ext["valu_insts_per_launch"],
+                 "frame": valu_frame(pmc, ms_per_step, valu_peak, launches_extend) if pmc else None,
+                 "source": "profiles/pmc_traffic.json: rocprofv3 --pmc SQ_INSTS_VALU pass of this workload (tools/pmc.sh insts)" if pmc else None},
         "node_and_triangle_fetches_per_s": round(fetches / (serial["ext"] * 1e-3)) if serial["ext"] > 0 else None,
         "gather_reference": "tools/microbench/gather64.hip: fully divergent dependent 64-byte lane fetches run at 220 G/s (L1 resident), 120 G/s (32 MB), "
                             "62 G/s (256 MB) chip-wide; traversal fetches of neighbouring rays partly coincide, so this is a reference point, not a ceiling",

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Turns the FETCH_SIZE / WRITE_SIZE PMC passes (tools/pmc.sh fetch|write) into profiles/pmc_traffic.json.
+"""Turns the rocprofv3 --pmc passes of `bench.py --profile-pass` (tools/pmc.sh fetch | write | insts | cycles) into
+profiles/pmc_traffic.json: per kernel, per launch -- HBM-side bytes and VALU instructions.
 
-HBM bytes per launch = (FETCH_SIZE * 2 + WRITE_SIZE) * 1024 / launches: FETCH_SIZE/WRITE_SIZE are reported
-in KiB, and on gfx950 FETCH_SIZE reads half of the fetched bytes (MI355X_MICROARCH.md, HBM section; the
-factor was calibrated on wide streaming reads -- for the divergent 16 B/lane gathers of the traversal
-kernels it is an upper-bound style correction, stated as such in DESIGN.md)."""
+HBM bytes per launch = (FETCH_SIZE * 2 + WRITE_SIZE) * 1024 / launches: FETCH_SIZE / WRITE_SIZE are reported in KiB, and on gfx950
+FETCH_SIZE reads half of the fetched bytes (MI355X_MICROARCH.md, HBM section; the factor was calibrated on wide streaming reads -- for
+the divergent 16 B/lane gathers of the traversal kernels it is an upper-bound style correction, stated as such in DESIGN.md).
+VALU instructions per launch = SQ_INSTS_VALU / launches (wave-level instructions: one per wave and instruction)."""
 import csv
 import json
 import os
@@ -13,29 +14,40 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def read(path, counter):
+def read(tag, counter):
+    path = os.path.join(ROOT, "gpurun_out", "pmc_" + tag, "summary_%s.csv" % tag)
     out = {}
+    if not os.path.exists(path):
+        return out
     for row in csv.DictReader(open(path)):
-        out[row["kernel"]] = (int(row["calls"]), float(row[counter]))
+        if counter in row:
+            out[row["kernel"]] = (int(row["calls"]), float(row[counter]))
     return out
 
 
 def main():
-    fetch = read(os.path.join(ROOT, "gpurun_out", "pmc_fetch", "summary_fetch.csv"), "FETCH_SIZE")
-    write = read(os.path.join(ROOT, "gpurun_out", "pmc_write", "summary_write.csv"), "WRITE_SIZE")
-    doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --profile-pass --steps 3 --warmup 1 (frames one at a time, RPTR_TAIL_BOUNCE=2)",
+    tag = sys.argv[1] if len(sys.argv) > 1 else ""
+    fetch, write = read("fetch", "FETCH_SIZE"), read("write", "WRITE_SIZE")
+    valu, salu, waves = read("insts", "SQ_INSTS_VALU"), read("insts", "SQ_INSTS_SALU"), read("insts", "SQ_WAVES")
+    busy, gui = read("cycles", "SQ_BUSY_CYCLES"), read("cycles", "GRBM_GUI_ACTIVE")
+    doc = {"source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_*_CYCLES) over "
+                     "bench.py --profile-pass --steps 3 --warmup 1 (frames one at a time, RPTR_TAIL_BOUNCE=2); tools/pmc.sh + tools/make_traffic.py",
+           "build": tag,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads 1/2, MI355X_MICROARCH.md)", "kernels": {}}
     for k in fetch:
         calls, f = fetch[k]
         w = write.get(k, (calls, 0.0))[1]
-        doc["kernels"][k] = {"launches": calls, "fetch_kib_raw": f, "write_kib_raw": w,
-                             "hbm_bytes_per_launch": (2 * f + w) * 1024 / max(calls, 1)}
-    ext = [v for k, v in doc["kernels"].items() if "rp_k_extend<false" in k]  # <false, true, ALPHA> (first bounce) + <false, false, ALPHA>
-    if ext:
-        doc["rp_k_extend_hbm_bytes_per_launch"] = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ext) /
-                                                   max(sum(v["launches"] for v in ext), 1))
+        e = {"launches": calls, "fetch_kib_raw": f, "write_kib_raw": w, "hbm_bytes_per_launch": (2 * f + w) * 1024 / max(calls, 1)}
+        if k in valu:
+            e["valu_insts_per_launch"] = valu[k][1] / max(valu[k][0], 1)
+            e["salu_insts_per_launch"] = salu[k][1] / max(salu[k][0], 1)
+            e["waves_per_launch"] = waves[k][1] / max(waves[k][0], 1)
+        if k in gui:
+            e["gui_active_cycles_per_launch"] = gui[k][1] / max(gui[k][0], 1)
+        doc["kernels"][k] = e
     json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in doc["kernels"].items()}, indent=1))
+    for k, v in doc["kernels"].items():
+        print("%-48s %8.1f MB HBM  %8.1f M VALU insts per launch" % (k[:48], v["hbm_bytes_per_launch"] / 1e6, v.get("valu_insts_per_launch", 0) / 1e6))
 
 
 if __name__ == "__main__":

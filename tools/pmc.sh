@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export RPTR_FRAMES_IN_FLIGHT=1
 export RPTR_TAIL_BOUNCE=${RPTR_TAIL_BOUNCE:-2}  # every frame of the pass hands over at the same bounce (adaptive would start the first frame without a tail)
 cd /tmp; rm -rf /tmp/pmc_$TAG
 timeout -k 5 240 rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc_$TAG -o $TAG --output-format csv -- python $R/bench.py --profile-pass --steps 3 --warmup 1 "$@" > $OUT/bench.log 2>&1
