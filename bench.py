@@ -191,6 +191,8 @@ def main():
     # 11 frame contexts (7 for the animated scene: every context refits its own tree copy). One GPU, full frame: 3 / 7 / 11 contexts give
     # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
+    if args.profile_pass:
+        fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
     else:
