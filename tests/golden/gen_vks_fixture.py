@@ -84,7 +84,39 @@ def main():
         mats.append(m.view(np.uint32).reshape(-1).tolist())
         packed.append(q.tolist())
         back.append(b.view(np.uint32).reshape(-1).tolist())
+    # degenerate / extreme transforms: identity, pure translations, half turns about every axis, mirrors, tiny and huge uniform scales,
+    # a zero matrix, translations at the limits of float
+    special = []
+    ident = np.zeros((4, 3), np.float32)
+    ident[:3] = np.eye(3, dtype=np.float32)
+    special.append(ident.copy())
+    for t in ([1e-20, 0, 0], [0, -3.5e7, 2.0], [1e30, -1e30, 1e-30]):
+        m = ident.copy()
+        m[3] = t
+        special.append(m)
+    for diag in ([1, -1, -1], [-1, 1, -1], [-1, -1, 1], [-1, 1, 1], [1, -1, 1], [-1, -1, -1]):
+        m = ident.copy()
+        m[:3] = np.diag(np.array(diag, np.float32))
+        special.append(m)
+    for sc in (1e-6, 1e-3, 1e3, 1e6):
+        m = ident.copy()
+        m[:3] *= np.float32(sc)
+        special.append(m)
+    special.append(np.zeros((4, 3), np.float32))
+    perm = ident.copy()
+    perm[:3] = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], np.float32) * np.float32(2.5)
+    special.append(perm)
+    smats, spacked, sback = [], [], []
+    for m in special:
+        q = np.zeros(24, np.uint8)
+        lib.vkr_quantize_transform(q.ctypes.data, np.ascontiguousarray(m).ctypes.data)
+        b = np.zeros((4, 3), np.float32)
+        lib.vkr_dequantize_transform(b.ctypes.data, q.ctypes.data)
+        smats.append(m.view(np.uint32).reshape(-1).tolist())
+        spacked.append(q.tolist())
+        sback.append(b.view(np.uint32).reshape(-1).tolist())
     json.dump({"note": "floats as uint32 bit patterns; outputs from the reference's libvkr (ext/libvkr/src/vkr.c:1223-1411)",
+               "special_transform_in": smats, "special_transform_packed": spacked, "special_transform_out": sback,
                "vertex_q": [int(x) for x in vq], "vertex_scale": scale.view(np.uint32).tolist(), "vertex_offset": offset.view(np.uint32).tolist(),
                "vertex_out": pos.view(np.uint32).reshape(-1).tolist(),
                "normal_uv_q": [int(x) for x in nq], "normal_out": nrm.view(np.uint32).reshape(-1).tolist(), "uv_out": uv.view(np.uint32).reshape(-1).tolist(),

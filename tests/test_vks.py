@@ -97,6 +97,18 @@ def test_quantization_matches_the_reference_vectors():
         m = np.array(m_in, np.uint32).view(np.float32).reshape(4, 3)
         assert list(vks.quantize_transform(m)) == packed
         assert _bits(vks.dequantize_transform(bytes(packed))).reshape(-1).tolist() == out
+    # identity, pure translations, half turns, mirrors, extreme scales, a zero matrix: the packed bytes and the round trip of the
+    # reference's vkr_quantize_transform / vkr_dequantize_transform
+    assert len(g["special_transform_in"]) >= 16
+    for m_in, packed, out in zip(g["special_transform_in"], g["special_transform_packed"], g["special_transform_out"]):
+        m = np.array(m_in, np.uint32).view(np.float32).reshape(4, 3)
+        with np.errstate(all="ignore"):
+            got = list(vks.quantize_transform(m))
+            back = _bits(vks.dequantize_transform(bytes(packed))).reshape(-1).tolist()
+        assert got == packed, (m.tolist(), got, packed)
+        want = np.array(out, np.uint32).view(np.float32)
+        have = np.array(back, np.uint32).view(np.float32)
+        assert np.array_equal(np.isnan(want), np.isnan(have)) and np.array_equal(np.nan_to_num(want).view(np.uint32), np.nan_to_num(have).view(np.uint32))
 
 
 def test_block_decoders_known_answers():

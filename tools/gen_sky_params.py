@@ -49,6 +49,27 @@ def main():
                          theta.ctypes.data, theta.ctypes.data, len(theta), out.ctypes.data)
     entries["default"]["eval_cos_theta"] = [float(x) for x in cos_t]
     entries["default"]["eval_rgb_times_100"] = [[float(v) for v in row] for row in out]
+    # ... and for EVERY configuration on the directions where the zenith angle equals the angle to the sun (the great circle through the
+    # bisector of up and sun, perpendicular to up - sun): there the shader's formula, which feeds the zenith angle into the term the C
+    # code feeds the sun angle into (sky_model.glsl:46-48), must agree with the reference's C evaluation
+    for key, cfg in SKY_CONFIGS.items():
+        sd = np.array(entries[key]["sun_dir"], np.float64)
+        up = np.array([0.0, 1.0, 0.0])
+        b = up + sd
+        nrm = np.cross(up, sd)
+        if np.linalg.norm(b) < 1e-6 or np.linalg.norm(nrm) < 1e-6:
+            continue  # sun at the zenith (covered above) or at the nadir
+        b /= np.linalg.norm(b)
+        nrm /= np.linalg.norm(nrm)
+        phi = np.linspace(-1.45, 1.45, 25)
+        dirs = np.cos(phi)[:, None] * b[None, :] + np.sin(phi)[:, None] * nrm[None, :]
+        dirs = dirs[dirs[:, 1] > 0.02]
+        theta = np.arccos(np.clip(dirs[:, 1], -1, 1))
+        out = np.zeros((len(theta), 3))
+        lib.ref_sky_radiance((C.c_float * 3)(*cfg["sun_dir"]), cfg["turbidity"], (C.c_float * 3)(*cfg["albedo"]), theta.ctypes.data, theta.ctypes.data,
+                             len(theta), out.ctypes.data)
+        entries[key]["eval_equal_angle_dirs"] = [[float(v) for v in row] for row in dirs]
+        entries[key]["eval_equal_angle_rgb_times_100"] = [[float(v) for v in row] for row in out]
     doc = {"generator": "tools/gen_sky_params.py", "source": "oracle/_ref/libsky_ref.so <- reference sky_model.cpp + render_sky.cpp:25-72",
            "entries": entries}
     with open(os.path.join(ROOT, "realtimepathtracingresearchframework_amd", "data", "sky_params.json"), "w") as f:
