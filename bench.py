@@ -73,6 +73,9 @@ def parse_args():
                     help="frames queued at once (rptr_hip_render_async): the latency-bound tail of a frame overlaps the next frame's head. "
                          "Default: 11 (7 with --animate). Measured: a full frame 1.51 / 1.44 / 1.40 ms with 3 / 7 / 11 contexts, a 1/8 frame "
                          "0.34 / 0.28 / 0.25 ms")
+    ap.add_argument("--batch-frames", type=int, default=0,
+                    help="frames per launch sequence (rptr_hip_render_batch_async: the samples of consecutive frames share the launches, every "
+                         "frame keeps its seeds, its image and its ticket). Default: min(4, 16 // spp); 1 with --animate (every frame has its own geometry)")
     ap.add_argument("--stripe-rows", type=int, default=8,
                     help="rows per screen stripe of the tile split (multiple of 8); stripe s belongs to rank s %% N. 1080 rows in 8-row "
                          "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
@@ -191,6 +194,7 @@ def main():
     # 11 frame contexts (7 for the animated scene: every context refits its own tree copy). One GPU, full frame: 3 / 7 / 11 contexts give
     # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
+    batch_frames = args.batch_frames if args.batch_frames > 0 else (1 if args.animate else max(1, min(4, 16 // max(spp, 1))))
     if args.profile_pass:
         fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
     if args.emulate_world > 1:
@@ -276,18 +280,22 @@ def main():
         return finish(r.render_async(cfg, spp=spp, count_traversal=count))
 
     def timed_steps(k, on_stats):
-        """k frames with up to `fif` of them in flight; every frame is submitted, rendered, collected (and gathered)
-        inside the caller's timed region"""
-        queue = []
-        for _ in range(k):
+        """k frames, `batch_frames` of them per launch sequence, up to `fif` launch sequences in flight; every frame is submitted,
+        rendered, collected (and gathered) inside the caller's timed region"""
+        queue, left = [], k
+        while left > 0:
             if anim is not None:
                 animate()
             cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
-            queue.append(r.render_async(cfg, spp=spp))
+            n = min(batch_frames, left)
+            queue.append(r.render_batch_async(cfg, spp=spp, n_frames=n, reset_rest=True) if n > 1 else [r.render_async(cfg, spp=spp)])
+            left -= n
             if len(queue) >= fif:
-                on_stats(finish(queue.pop(0)))
+                for t in queue.pop(0):
+                    on_stats(finish(t))
         while queue:
-            on_stats(finish(queue.pop(0)))
+            for t in queue.pop(0):
+                on_stats(finish(t))
 
     if args.profile_pass:  # what a rocprofv3 pass should see: identical frames, one at a time, no instrumented variants
         r.set_stage_timing(0)
@@ -490,8 +498,8 @@ def main():
         "stage_ms_per_step": {"extend": round(serial["ext"], 4), "connect": round(serial["con"], 4), "shade": round(serial["shade"], 4),
                               "tail": round(serial["tail"], 4), "resolve": round(serial["resolve"], 4), "other": round(serial["other"], 4),
                               "gpu_total": round(serial["gpu"], 4)},
-        "pipelined": {"frames_in_flight": fif, "ms_per_step": round(ms_per_step, 4),
-                      "extend_launch_ms_overlapped": round(ext_ms / K / n_launch, 5),
+        "pipelined": {"frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "ms_per_step": round(ms_per_step, 4),
+                      "extend_launch_ms_overlapped": round(ext_ms * batch_frames / K / n_launch, 5),
                       "note": "launches of neighbouring frames share the GPU in the timed region: their durations overlap and are NOT exclusive (their sum may "
                               "exceed ms_per_step); they are reported for the rocprofv3 cross-check only (profiles/, same command)"},
         "counts_per_step": cnt,
@@ -519,7 +527,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
-                   "frames_in_flight": fif, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
+                   "frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
         "roofline": roofline,

@@ -339,6 +339,19 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
 int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation,
                           int count_traversal, uint64_t *out_ticket);
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats);
+/* Several frames in ONE launch sequence. A wavefront frame is a chain of dependent launches that each last at least as long as their
+ * slowest ray; a small frame (the stripes of one rank of a multi-GPU split) cannot fill the GPU however many frames are in flight. Paths
+ * are independent, so the samples of `n_frames` consecutive frames with the same camera and parameters can share the launches: sample
+ * slots [k*spp, (k+1)*spp) belong to frame k, which keeps its own frame_offset / sample indices (reset_first: frame 0 restarts the
+ * accumulation, reset_rest: so does every further frame -- begin_frame's rule per frame, render_vulkan.cpp:1937-1941), its own image
+ * and its own ticket (out_tickets[0..n_frames)). Every frame is bit-identical to the same frame rendered on its own; the resolve folds
+ * the frames into the accumulation in order. n_frames * spp sample slots must fit (RptrCreateInfo / RPTR_PATH_BUDGET_MB: at most
+ * 16), n_frames <= RPTR_MAX_BATCH_FRAMES (4), frames_in_flight >= 2. rptr_hip_wait on any ticket of the batch waits for the batch;
+ * read-backs, AOV read-backs (AOV images: of the batch's last frame) and rptr_hip_gather return / send the image of the ticket waited
+ * for last; a frame context is free again when all of its batch's tickets have been waited for. RptrStats of a batched frame: an
+ * equal share of the batch's times and counts. No reference counterpart (the reference renders one frame per submission). */
+int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                                int count_traversal, uint64_t *out_tickets);
 /* RenderConfiguration::freeze_frame (librender/render_backend.h:39; vulkan/render_vulkan.cpp:1937-1941,2152-2154): while set, a reset
  * does not advance frame_offset and a rendered frame does not advance frame_id -- every frame repeats the same samples (the
  * reference's --freeze-frame, cmdline.cpp:359-360). */

@@ -64,6 +64,7 @@ def load_library(path=None):
     L.rptr_hip_render.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(abi.Stats)]
     L.rptr_hip_render_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_wait.argtypes = [vp, C.c_uint64, C.POINTER(abi.Stats)]
+    L.rptr_hip_render_batch_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
@@ -244,6 +245,17 @@ class RenderHip:
                                                   1 if count_traversal else 0, C.byref(ticket)))
         self.reset_accumulation = False
         return int(ticket.value)
+
+    def render_batch_async(self, config: RenderConfiguration, spp=1, n_frames=1, reset_rest=True, count_traversal=False):
+        """n_frames consecutive frames of the same view in one launch sequence (include/rptr_hip.h rptr_hip_render_batch_async): frame 0
+        resets iff config.reset_accumulation, the others iff reset_rest; returns their tickets"""
+        self.begin_frame(None, config)
+        self._push_params()
+        tickets = (C.c_uint64 * n_frames)()
+        self._check(self._L.rptr_hip_render_batch_async(self._h, C.byref(self.camera), self._variant, spp, n_frames, 1 if self.reset_accumulation else 0,
+                                                        1 if reset_rest else 0, 1 if count_traversal else 0, tickets))
+        self.reset_accumulation = False
+        return [int(t) for t in tickets]
 
     def wait(self, ticket):
         st = abi.Stats()

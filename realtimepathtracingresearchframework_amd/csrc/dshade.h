@@ -113,7 +113,40 @@ struct RpFrame {
     int32_t sort_bits[3];
     int32_t sort_num_keys;       // 1 + sort_groups * sort_cells
     RpDivU32 div_npix_padded, div_tiles_x, div_stripe_rows, div_width; // rp_div by npix_padded / tiles_x / stripe_rows / width
+    // A launch sequence may carry the samples of SEVERAL frames (rptr_hip_render_batch_async): sample slots [k * frame_spp, (k+1) *
+    // frame_spp) belong to frame k of the batch. Frame 0 has (frame_offset, sample_base, frame_id) above; the frames behind it all reset
+    // the accumulation (batch_reset != 0: begin_frame's frame_offset += frame_id, frame_id = 0 per frame) or all continue it.
+    int32_t batch_frames;        // frames in this launch sequence (1: the whole batch is one frame)
+    int32_t frame_spp;           // sample slots per frame
+    int32_t batch_reset;         // frames 1.. restart the accumulation
+    RpDivU32 div_frame_spp;
+    size_t out_stride;           // pixels between the per-frame output images of a batch (out_accum / out_fb of rp_k_resolve)
 };
+// the frame a sample slot belongs to and its frame constants: sample_index, frame_offset (lcg_rng.glsl:36-39) and view_params.frame_id
+// (samples accumulated before the frame: seeds the alpha test of shadow rays, pt_megakernel.glsl:251-262)
+struct RpSlotFrame {
+    uint32_t frame, sample_index, frame_offset, frame_id;
+};
+#ifdef __HIPCC__
+RP_DEV RpSlotFrame rp_slot_frame(const RpFrame &f, uint32_t sslot) {
+    RpSlotFrame r;
+    r.frame = f.batch_frames > 1 ? rp_div(sslot, f.div_frame_spp) : 0u;
+    if (r.frame == 0u) {
+        r.sample_index = f.sample_base + sslot;
+        r.frame_offset = f.frame_offset;
+        r.frame_id = f.frame_id;
+    } else if (f.batch_reset) { // begin_frame of every further frame: frame_offset += frame_id (= what was accumulated), frame_id = 0
+        r.sample_index = sslot - r.frame * uint32_t(f.frame_spp);
+        r.frame_offset = f.frame_offset + f.sample_base + r.frame * uint32_t(f.frame_spp);
+        r.frame_id = 0u;
+    } else {
+        r.sample_index = f.sample_base + sslot;
+        r.frame_offset = f.frame_offset;
+        r.frame_id = f.frame_id + r.frame * uint32_t(f.frame_spp);
+    }
+    return r;
+}
+#endif
 
 // local tiled slot -> local pixel; false for padding lanes
 RP_DEV bool rp_slot_to_local(const RpFrame &f, uint32_t slot, int &lx, int &ly) {

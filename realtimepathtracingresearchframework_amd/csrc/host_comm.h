@@ -164,7 +164,7 @@ void comm_release(rptr_hip *h) {
 const float4 *comm_source(rptr_hip *h, FrameCtx *&owner) {
     if (h->output_ctx >= 0) {
         owner = &h->ctx[(size_t)h->output_ctx];
-        return owner->out_accum;
+        return owner->out_accum + (size_t)h->output_index * ((size_t)h->width * (size_t)std::max(h->local_rows, 1));
     }
     owner = &h->ctx[0];
     return h->accum;

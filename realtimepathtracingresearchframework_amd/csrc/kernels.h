@@ -95,8 +95,8 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &d
     if (!rp_slot_to_local(f, slot, lx, ly)) return false;
     const int gy = rp_local_row_to_global(f, ly);
     if (gy >= f.height) return false;
-    const uint32_t sample_index = f.sample_base + sslot;
-    rng = rp_rng_seed(sample_index, f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+    const RpSlotFrame sf = rp_slot_frame(f, sslot);
+    rng = rp_rng_seed(sf.sample_index, sf.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
     V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
     if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
     point = v2(point.x / float(f.width), point.y / float(f.height));
@@ -200,7 +200,8 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
         int lx = 0, ly = 0;
         (void)rp_slot_to_local(f, slot, lx, ly);
         const int gy = rp_local_row_to_global(f, ly);
-        uint32_t rng = rp_rng_seed(uint32_t(prim) ^ f.frame_id, uint32_t(inst_id) ^ f.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+        const RpSlotFrame sf = rp_slot_frame(f, sslot);
+        uint32_t rng = rp_rng_seed(uint32_t(prim) ^ sf.frame_id, uint32_t(inst_id) ^ sf.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, rng);
     };
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
@@ -471,8 +472,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
                     if (f.alpha_test) rng = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
-                    if (f.aov_albedo_roughness && f.sample_base + first_sslot == f.frame_id) // the first sample of the frame writes the AOVs
-                        aov_px = first_ly * f.width + first_lx;
+                    if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
+                        const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
+                        if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) aov_px = first_ly * f.width + first_lx;
+                    }
                     ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
                     illum = v3s(0.0f);
@@ -863,6 +866,7 @@ RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
     }
     return make_float4(rp_linear_to_srgb(o.x), rp_linear_to_srgb(o.y), rp_linear_to_srgb(o.z), o.w);
 }
+// out_accum / out_fb (frames in flight, else NULL): what each frame of the batch leaves in accum / fb, frame k at k * f.out_stride
 __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb, float4 *out_accum, uchar4 *out_fb) {
     const int npix = f.width * f.local_rows;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
@@ -870,32 +874,38 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
         if (rp_local_row_to_global(f, ly) >= f.height) continue;
         const uint32_t slot = rp_local_to_slot(f, lx, ly);
         float4 acc = accum[i];
-        for (int s = 0; s < f.batch_spp; ++s) {
-            const float4 il = ps.illum[size_t(s) * size_t(f.npix_padded) + slot];
-            const float4 c = make_float4(il.x, il.y, il.z, __float_as_int(il.w) == 0 ? 0.0f : 1.0f); // pt_megakernel.glsl:736
-            const uint32_t sample_index = f.sample_base + uint32_t(s);
-            if (sample_index == 0)
-                acc = c;
-            else {
-                const float denom = float(int(sample_index) + 1);
-                acc.x += (c.x - acc.x) / denom;
-                acc.y += (c.y - acc.y) / denom;
-                acc.z += (c.z - acc.z) / denom;
-                acc.w += (c.w - acc.w) / denom;
+        uchar4 shown = fb[i];
+        const int per_frame = f.batch_frames > 1 ? f.frame_spp : f.batch_spp;
+        for (int k = 0; k < f.batch_frames; ++k) {
+            for (int j = 0; j < per_frame; ++j) {
+                const int s = k * per_frame + j;
+                const float4 il = ps.illum[size_t(s) * size_t(f.npix_padded) + slot];
+                const float4 c = make_float4(il.x, il.y, il.z, __float_as_int(il.w) == 0 ? 0.0f : 1.0f); // pt_megakernel.glsl:736
+                const uint32_t sample_index = rp_slot_frame(f, uint32_t(s)).sample_index;
+                if (sample_index == 0)
+                    acc = c;
+                else {
+                    const float denom = float(int(sample_index) + 1);
+                    acc.x += (c.x - acc.x) / denom;
+                    acc.y += (c.y - acc.y) / denom;
+                    acc.z += (c.z - acc.z) / denom;
+                    acc.w += (c.w - acc.w) / denom;
+                }
+            }
+            float4 o = acc;
+            o.w = fminf(o.w, 1.0f);
+            if (o.w >= 0.0f) {
+                o = rp_display_color(f, o, i);
+                shown = make_uchar4((unsigned char)(clamp1(o.x, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.y, 0.f, 1.f) * 255.0f + 0.5f),
+                                    (unsigned char)(clamp1(o.z, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
+            }
+            if (out_accum) {
+                out_accum[size_t(k) * f.out_stride + size_t(i)] = acc;
+                out_fb[size_t(k) * f.out_stride + size_t(i)] = shown;
             }
         }
         accum[i] = acc;
-        if (out_accum) out_accum[i] = acc;
-        float4 o = acc;
-        o.w = fminf(o.w, 1.0f);
-        if (o.w >= 0.0f) {
-            o = rp_display_color(f, o, i);
-            const uchar4 px = make_uchar4((unsigned char)(clamp1(o.x, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.y, 0.f, 1.f) * 255.0f + 0.5f),
-                                          (unsigned char)(clamp1(o.z, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
-            fb[i] = px;
-            if (out_fb) out_fb[i] = px;
-        } else if (out_fb)
-            out_fb[i] = fb[i];
+        fb[i] = shown;
     }
 }
 

@@ -95,14 +95,19 @@ struct FrameCtx {
     hipStream_t side = nullptr;
     int *gstack_side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr;
-    float4 *out_accum = nullptr; // frames_in_flight > 1: the image after this frame's resolve
+    float4 *out_accum = nullptr; // frames_in_flight > 1: the image after this frame's resolve (a batch: one image per frame, max_batch_frames of them)
     uchar4 *out_fb = nullptr;
     uint2 *aov[3] = {nullptr, nullptr, nullptr}; // RGBA16F albedo+roughness, normal+depth, motion+jitter of this context's last frame
     hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_dep = nullptr, ev_resolved = nullptr;
     std::vector<hipEvent_t> ev_pool;
     // the frame in flight on this context
-    bool pending = false;
-    uint64_t ticket = 0;
+    bool pending = false;        // a frame (or a batch of frames) was submitted here and not all of its tickets have been waited for
+    bool synced = false;         // ... and its end has been awaited: stats are in batch_stats
+    uint64_t ticket = 0;         // the first ticket of the batch; its frames hold ticket .. ticket + batch_n - 1
+    int batch_n = 1;
+    uint32_t collected = 0;      // bit k: frame k of the batch has been waited for
+    int batch_spp_after[16] = {0};
+    RptrStats batch_stats;       // what every frame of the batch reports (totals / batch_n)
     std::vector<Span> spans;
     RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
     int launches_extend = 0, launches_connect = 0, spp_after = 0;
@@ -179,6 +184,8 @@ struct rptr_hip {
     uint64_t next_ticket = 1;
     int next_ctx = 0;
     int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
+    int output_index = 0;           // ... and which frame of that context's batch
+    int max_batch_frames = 4;       // RPTR_MAX_BATCH_FRAMES: per-frame output images a context keeps (rptr_hip_render_batch_async)
     int aov_ctx = 0;                // the context whose AOV images readback_aov returns (last finished frame)
     bool output_overwritten = false; // a newer frame was submitted on output_ctx / aov_ctx: its resolve rewrites the images a read-back
     bool aov_overwritten = false;    // would return, so read-backs fail until that frame has been waited for
@@ -763,6 +770,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
         if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
         if (const char *s = getenv("RPTR_TAIL_THRESHOLD")) h->tail_threshold = std::max(0, atoi(s));
+        if (const char *s = getenv("RPTR_MAX_BATCH_FRAMES")) h->max_batch_frames = std::max(1, std::min(16, atoi(s)));
         for (FrameCtx &c : h->ctx) {
             memset(&c.ps, 0, sizeof(c.ps));
             memset(&c.sq, 0, sizeof(c.sq));
@@ -920,10 +928,11 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     HIP_TRY(h, hipMemsetAsync(h->fb, 0, npix_local * sizeof(uchar4), h->stream));
     if (h->ctx.size() > 1)
         for (FrameCtx &c : h->ctx) {
-            if ((rc = dev_alloc(h, &c.out_accum, npix_local, nullptr))) return rc;
-            if ((rc = dev_alloc(h, &c.out_fb, npix_local, nullptr))) return rc;
-            HIP_TRY(h, hipMemsetAsync(c.out_accum, 0, npix_local * sizeof(float4), h->stream));
-            HIP_TRY(h, hipMemsetAsync(c.out_fb, 0, npix_local * sizeof(uchar4), h->stream));
+            const size_t nout = npix_local * (size_t)h->max_batch_frames;
+            if ((rc = dev_alloc(h, &c.out_accum, nout, nullptr))) return rc;
+            if ((rc = dev_alloc(h, &c.out_fb, nout, nullptr))) return rc;
+            HIP_TRY(h, hipMemsetAsync(c.out_accum, 0, nout * sizeof(float4), h->stream));
+            HIP_TRY(h, hipMemsetAsync(c.out_fb, 0, nout * sizeof(uchar4), h->stream));
         }
     h->output_ctx = -1;
     h->last_resolved = nullptr;
@@ -1702,13 +1711,31 @@ static void add_counters(RpCounters &dst, const RpCounters &c) {
 }
 
 // waits for the frame in flight on `c` and turns its events / counters into RptrStats
-static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
+// `which`: the frame of the batch that is being collected (-1: all of them, stats dropped)
+static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int which = -1) {
     if (!c.pending) return fail(h, RPTR_E_INVALID, "no frame in flight on this context");
+    const uint32_t all = c.batch_n >= 32 ? ~0u : ((1u << c.batch_n) - 1u);
+    if (c.synced) { // a later frame of a batch whose end has been awaited already
+        RptrStats st = c.batch_stats;
+        st.spp = c.batch_spp_after[std::max(which, 0)];
+        h->stats = st;
+        if (out_stats) *out_stats = st;
+        c.collected |= which < 0 ? all : (1u << which);
+        if (c.collected == all) c.pending = false;
+        if (h->ctx.size() > 1) {
+            h->output_ctx = (int)(&c - h->ctx.data());
+            h->output_index = std::max(which, 0);
+            h->output_overwritten = false;
+        }
+        return RPTR_OK;
+    }
     // work queued on the backend's stream from here on (tile copies, read-backs) sees this frame; joining at collection
     // time, not at submission, is what lets the next frame's dependency event pass while this frame still runs
     if (h->ctx.size() > 1) HIP_TRY(h, hipStreamWaitEvent(h->stream, c.ev_end, 0));
     HIP_TRY(h, hipEventSynchronize(c.ev_end));
-    c.pending = false;
+    c.synced = true;
+    c.collected |= which < 0 ? all : (1u << which);
+    if (c.collected == all) c.pending = false;
 #ifdef RP_PROF
     {
         unsigned long long pr[16];
@@ -1752,12 +1779,26 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats) {
     st.nodes_closest = tot.nodes;
     st.tris_closest = tot.tris;
     st.hits_shaded = tot.hits_shaded;
-    st.spp = c.spp_after;
     st.launches_extend = c.launches_extend;
     st.launches_connect = c.launches_connect;
     st.device_bytes_allocated = h->bytes_allocated;
+    if (c.batch_n > 1) { // the frames of a batch share its launches: each reports an equal share
+        const float inv = 1.0f / float(c.batch_n);
+        st.render_time_ms *= inv;
+        st.extend_time_ms *= inv;
+        st.connect_time_ms *= inv;
+        st.shade_time_ms *= inv;
+        st.shade_only_time_ms *= inv;
+        st.tail_time_ms *= inv;
+        st.resolve_time_ms *= inv;
+        for (uint64_t *v : {&st.rays_closest, &st.rays_shadow, &st.nodes_visited, &st.tris_tested, &st.hits_shaded, &st.nodes_closest, &st.tris_closest})
+            *v /= (uint64_t)c.batch_n;
+    }
+    c.batch_stats = st;
+    st.spp = c.batch_spp_after[std::max(which, 0)];
     if (h->ctx.size() > 1) {
         h->output_ctx = (int)(&c - h->ctx.data());
+        h->output_index = std::max(which, 0);
         h->output_overwritten = false;
     }
     h->aov_ctx = (int)(&c - h->ctx.data());
@@ -1794,7 +1835,21 @@ static int drain(rptr_hip *h) {
 
 int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation, int count_traversal,
                           uint64_t *out_ticket) {
+    return rptr_hip_render_batch_async(h, camera, variant, spp, 1, reset_accumulation, 0, count_traversal, out_ticket);
+}
+
+int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                                int count_traversal, uint64_t *out_tickets) {
+    const int reset_accumulation = reset_first;
     if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (n_frames < 1) return fail(h, RPTR_E_INVALID, "n_frames must be >= 1");
+    if (n_frames > 1) {
+        if (h->ctx.size() < 2) return fail(h, RPTR_E_INVALID, "batches of frames need frames_in_flight >= 2 (every frame of a batch keeps its own image)");
+        if (n_frames > h->max_batch_frames) return fail(h, RPTR_E_INVALID, "a batch holds at most %d frames (RPTR_MAX_BATCH_FRAMES)", h->max_batch_frames);
+        if (n_frames * spp > h->max_batch_spp)
+            return fail(h, RPTR_E_INVALID, "%d frames of %d samples do not fit the %d sample slots in flight (RPTR_PATH_BUDGET_MB)", n_frames, spp, h->max_batch_spp);
+        if (h->freeze_frame) return fail(h, RPTR_E_INVALID, "a frozen frame cannot be batched with others");
+    }
     if (!h->have_scene) return fail(h, RPTR_E_INVALID, "render before set_scene");
     if (h->width == 0) return fail(h, RPTR_E_INVALID, "render before initialize");
     if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE && variant != RPTR_VARIANT_GLTF_TRANSMISSION)
@@ -1832,6 +1887,11 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     f.aov_normal_depth = c.aov[1];
     f.aov_motion_jitter = c.aov[2];
     f.frame_offset = h->frame_offset;
+    f.batch_frames = n_frames;
+    f.frame_spp = spp;
+    f.batch_reset = reset_rest ? 1 : 0;
+    f.div_frame_spp = rp_make_div((uint32_t)spp);
+    f.out_stride = (size_t)h->width * (size_t)std::max(h->local_rows, 1);
     f.variant = variant;
     f.width = h->width;
     f.height = h->height;
@@ -1928,7 +1988,7 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     c.launches_extend = c.launches_connect = 0;
     memset(&c.earlier_batches, 0, sizeof(c.earlier_batches));
     memset(c.host_counters, 0, sizeof(RpCounters));
-    int remaining = spp;
+    int remaining = spp * n_frames; // (n_frames > 1: one internal batch holds them all, checked above)
     const bool local_work = h->local_rows > 0;
     f.frame_id = h->frame_id; // the whole call is one frame of the reference (its batch_spp = spp), whatever the internal batches
     f.alpha_test = h->uses_alpha ? 1 : 0;
@@ -2055,17 +2115,36 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
             }
         }
         // end_frame: render_vulkan.cpp:2152-2154
-        h->accumulated_spp = int(h->frame_id) + batch;
-        h->frame_id += (uint32_t)batch;
+        if (n_frames == 1) {
+            h->accumulated_spp = int(h->frame_id) + batch;
+            h->frame_id += (uint32_t)batch;
+        }
         remaining -= batch;
+    }
+    c.batch_spp_after[0] = h->accumulated_spp;
+    if (n_frames > 1) { // begin_frame / end_frame of every frame of the batch (kernels: dshade.h rp_slot_frame)
+        for (int k = 0; k < n_frames; ++k) {
+            if (k > 0 && reset_rest) {
+                h->frame_offset += h->frame_id;
+                h->frame_id = 0;
+            }
+            h->frame_id += (uint32_t)spp;
+            h->accumulated_spp = (int)h->frame_id;
+            c.batch_spp_after[k] = h->accumulated_spp;
+        }
     }
     HIP_TRY(h, hipEventRecord(c.ev_end, c.stream));
     HIP_TRY(h, hipGetLastError());
     if (h->freeze_frame) h->frame_id = frame_id_before; // end_frame, render_vulkan.cpp:2152-2154: the next frame repeats these samples
     c.spp_after = h->accumulated_spp;
     c.pending = true;
-    c.ticket = h->next_ticket++;
-    if (out_ticket) *out_ticket = c.ticket;
+    c.synced = false;
+    c.collected = 0;
+    c.batch_n = n_frames;
+    c.ticket = h->next_ticket;
+    h->next_ticket += (uint64_t)n_frames;
+    if (out_tickets)
+        for (int k = 0; k < n_frames; ++k) out_tickets[k] = c.ticket + (uint64_t)k;
     return RPTR_OK;
 }
 
@@ -2100,7 +2179,11 @@ int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     HIP_TRY(h, hipSetDevice(h->device));
     for (FrameCtx &c : h->ctx)
-        if (c.pending && c.ticket == ticket) return finish_frame(h, c, out_stats);
+        if (c.pending && ticket >= c.ticket && ticket < c.ticket + (uint64_t)c.batch_n) {
+            const int which = (int)(ticket - c.ticket);
+            if (c.collected & (1u << which)) break; // waited for already
+            return finish_frame(h, c, out_stats, which);
+        }
     return fail(h, RPTR_E_INVALID, "ticket %llu is not in flight", (unsigned long long)ticket);
 }
 
@@ -2157,7 +2240,8 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
                                        "read back before submitting that frame, or rptr_hip_wait for it first");
     HIP_TRY(h, hipSetDevice(h->device));
     // frames in flight: the image of the frame that was waited for last (its context keeps a copy)
-    const float4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum;
+    const size_t out_stride = (size_t)h->width * (size_t)std::max(h->local_rows, 1);
+    const float4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum + (size_t)h->output_index * out_stride : h->accum;
     if (need) HIP_TRY(h, hipMemcpyAsync(device_dst, src, need, hipMemcpyDeviceToDevice, h->stream));
     return RPTR_OK;
 }
@@ -2188,15 +2272,17 @@ int rptr_hip_readback_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
     if (h->output_overwritten)
         return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame in flight on the same frame context: "
                                        "read back before submitting that frame, or rptr_hip_wait for it first");
-    return readback_rows<float4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum : h->accum, reinterpret_cast<float4 *>(rgba),
-                                 n_floats / 4);
+    const size_t out_stride = (size_t)h->width * (size_t)std::max(h->local_rows, 1);
+    return readback_rows<float4>(h, h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_accum + (size_t)h->output_index * out_stride : h->accum,
+                                 reinterpret_cast<float4 *>(rgba), n_floats / 4);
 }
 int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (h->output_overwritten)
         return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame in flight on the same frame context: "
                                        "read back before submitting that frame, or rptr_hip_wait for it first");
-    const uchar4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb : h->fb;
+    const size_t out_stride = (size_t)h->width * (size_t)std::max(h->local_rows, 1);
+    const uchar4 *src = h->output_ctx >= 0 ? h->ctx[(size_t)h->output_ctx].out_fb + (size_t)h->output_index * out_stride : h->fb;
     if (h->params.render_upscale_factor != 2) return readback_rows<uchar4>(h, src, reinterpret_cast<uchar4 *>(rgba), n_bytes / 4);
     // render_upscale_factor == 2 (process_samples.comp:192-197): the frame buffer has twice the render resolution, every rendered
     // pixel fills a 2x2 block. Replicated here, on the way out (rows of other ranks stay untouched, as in the 1:1 read-back).

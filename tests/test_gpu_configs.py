@@ -345,3 +345,95 @@ def test_transmission_variant_image_parity_on_a_glass_scene():
     a, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF_TRANSMISSION)
     b, _, _ = gpu_render(opaque, 96, 96, 2, abi.VARIANT_GLTF)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ---------------------------------------------------------------- several frames in one launch sequence
+@pytest.mark.parametrize("reset_rest", [True, False])
+def test_batched_frames_are_bit_identical_to_frames_rendered_one_by_one(reset_rest):
+    """rptr_hip_render_batch_async: 3 frames x 2 spp share their launches; every frame keeps its frame_offset / sample indices, its
+    image and its ticket. reset_rest: every frame restarts the accumulation (the benchmark's pattern) / the frames accumulate
+    progressively. Images, spp and ray totals equal those of the same frames submitted one by one, with a following unbatched frame too."""
+    s = scenes.grid(120, 60, with_emitters=True)
+    W, H, spp = 160, 96, 2
+    cam = s.camera_params()
+
+    def run(batched):
+        r = backend.RenderHip(frames_in_flight=2)
+        r.initialize(W, H)
+        r.set_scene(s)
+        images, spps, rays = [], [], 0
+
+        def collect(t):
+            nonlocal rays
+            st = r.wait(t)
+            img = np.zeros((H, W, 4), np.float32)
+            assert r.readback_framebuffer(img) == W * H * 4
+            u8 = np.zeros((H, W, 4), np.uint8)
+            assert r.readback_framebuffer(u8) == W * H * 4
+            images.append((img, u8))
+            spps.append(st.spp)
+            rays += st.raw.rays_closest + st.raw.rays_shadow
+        first = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+        collect(r.render_async(first, spp=1))                        # something accumulated before the batch: frame_id = 1
+        cfg0 = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=reset_rest)
+        if batched:
+            tickets = r.render_batch_async(cfg0, spp=spp, n_frames=3, reset_rest=reset_rest)
+            assert tickets == [tickets[0], tickets[0] + 1, tickets[0] + 2]
+            for t in (tickets[1], tickets[0], tickets[2]):           # any order; the middle frame first
+                collect(t)
+            images[1], images[2] = images[2], images[1]
+            spps[1], spps[2] = spps[2], spps[1]
+            with pytest.raises(backend.BackendError):
+                r.wait(tickets[1])                                   # waited for already
+        else:
+            for k in range(3):
+                collect(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=reset_rest), spp=spp))
+        collect(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=False), spp=1))
+        r.close()
+        return images, spps, rays
+
+    ref_images, ref_spps, ref_rays = run(False)
+    images, spps, rays = run(True)
+    assert spps == ref_spps and (ref_spps[1:4] == ([2, 2, 2] if reset_rest else [3, 5, 7]))
+    assert abs(rays - ref_rays) <= 3                                  # (a batched frame reports an equal share of the batch's counts)
+    for (a, au), (b, bu) in zip(images, ref_images):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(au, bu)
+    assert not np.array_equal(ref_images[1][0], ref_images[2][0])
+
+
+def test_batch_limits_and_gather_of_batched_frames():
+    s = scenes.cornell32()
+    W, H = 96, 64
+    cam = s.camera_params()
+    cfg = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    one = backend.RenderHip(frames_in_flight=1)
+    one.initialize(W, H)
+    one.set_scene(s)
+    with pytest.raises(backend.BackendError):
+        one.render_batch_async(cfg, spp=1, n_frames=2)               # a batch needs per-frame images: frames_in_flight >= 2
+    want = []
+    for k in range(4):
+        one.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=2)
+        img = np.zeros((H, W, 4), np.float32)
+        one.readback_framebuffer(img)
+        want.append(img)
+    one.close()
+    rs = [backend.RenderHip(rank=k, world_size=2, stripe_rows=8, frames_in_flight=2) for k in range(2)]
+    for r in rs:
+        r.initialize(W, H)
+        r.set_scene(s)
+    with pytest.raises(backend.BackendError):
+        rs[0].render_batch_async(cfg, spp=2, n_frames=5)             # more than RPTR_MAX_BATCH_FRAMES
+    with pytest.raises(backend.BackendError):
+        rs[0].render_batch_async(cfg, spp=8, n_frames=3)             # 24 sample slots do not fit
+    backend.RenderHip.comm_init_all(rs)
+    tickets = [r.render_batch_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=2, n_frames=4) for r in rs]
+    for k in range(4):                                               # frame by frame: wait on every rank, gather, compare with one rank
+        for r, t in zip(rs, tickets):
+            r.wait(t[k])
+        backend.RenderHip.gather_all(rs)
+        got = np.zeros((H, W, 4), np.float32)
+        assert rs[0].readback_gathered(got) == W * H * 4
+        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32))
+    for r in rs:
+        r.close()
