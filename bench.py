@@ -44,6 +44,7 @@ SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-writ
 PATH_READ_BYTES, PATH_WRITE_BYTES = 72, 80    # shade: path state in (ray_o, ray_d, thr, illum, rng_tt; not on the first bounce) / out per vertex
 VERTEX_BYTES, MATERIAL_BYTES = 48, 80         # 3 x (qpos + qnrm_uv), RptrBaseMaterial
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md "HBM")
+MAX_CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: max clock 2400 MHz
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2 (per XCD)"): the ceiling of bytes served by the cache hierarchy
 
 
@@ -429,7 +430,7 @@ def main():
     pmc = load_pmc_traffic() if default_workload else None   # the committed PMC passes were taken on the default workload: no figure for anything else
     n_launch = max(launches_extend, 1)
     props = torch.cuda.get_device_properties(local_rank)
-    clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6
+    clock_ghz = MAX_CLOCK_GHZ   # (hipDeviceProp's clockRate varies from box to box with the power state: the peak uses the chip's maximum)
     valu_peak = props.multi_processor_count * clock_ghz   # G wave-instructions / s: CUs x 4 SIMDs x 1 VALU instruction per 4 clocks
 
     def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches):
@@ -487,7 +488,8 @@ def main():
         "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region, on a handle with one frame context (no other frame on the GPU, every launch at full size); "
                   "sum of all stages = stage_ms_per_step.gpu_total" % n_serial,
         "valu": {"binding_unit": "VALU issue", "peak_ginst_s": round(valu_peak, 1),
-                 "peak_what": "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.2f GHz (hipDeviceProp clockRate)" % (props.multi_processor_count, clock_ghz),
+                 "peak_what": "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.1f GHz (max clock, MI355X_MICROARCH.md; this box reports %d MHz)"
+                              % (props.multi_processor_count, clock_ghz, int(getattr(props, "clock_rate", 0) / 1000)),
                  "frac": k_ext["valu_frac"], "ginst_s": k_ext["valu_ginst_s"], "insts_per_launch": k_ext["valu_insts_per_launch"],
                  "frame": valu_frame(pmc, ms_per_step, valu_peak, launches_extend) if pmc else None,
                  "source": "profiles/pmc_traffic.json: rocprofv3 --pmc SQ_INSTS_VALU pass of this workload (tools/pmc.sh insts)" if pmc else None},
