@@ -73,6 +73,21 @@ extern "C" {
  * two-sided ones; transmission roughness = roughness, reflection roughness = sqrt(clearcoat_gloss) (gltf_bsdf.glsl:38-62). */
 #define RPTR_VARIANT_GLTF_TRANSMISSION 2
 
+/* Point sets: the render backend option rng_variant (librender/render_params.glsl.h:34-37,56,76; rendering/pointsets/selected_rng.glsl).
+ * UNIFORM = a per-path LCG (lcg_rng.glsl), the default and what BASELINE.json's configurations use. BN = blue-noise dithered sampling
+ * (bn_rng.glsl, BN_OPTIMIZED_SPP 1), SOBOL = the Joe-Kuo Sobol' sequence with a fresh random digital shift per draw (sobol.glsl),
+ * Z_SBL = the same sequence with sample indices assigned along a shuffled Z-order curve inside 256 x 256 tiles (Z_ORDER_SHUFFLING). */
+#define RPTR_RNG_VARIANT_UNIFORM 0
+#define RPTR_RNG_VARIANT_BN 1
+#define RPTR_RNG_VARIANT_SOBOL 2
+#define RPTR_RNG_VARIANT_Z_SBL 3
+/* table sizes in bytes, laid out as the reference uploads them:
+ * SobolData (rendering/pointsets/sobol_data.h:13-17): uint32 matrix[1024 * 32], tile_invert_1_0[256 * 256];
+ * BNData (bn_data.h:12-27): uint32 sobol_spp_d[256 * 256], tile_scrambling_yx_d_1spp[128 * 128 * 8], then six tables that
+ * BN_OPTIMIZED_SPP 1 never reads (they may be left off). */
+#define RPTR_SOBOL_TABLE_BYTES ((1024u * 32u + 256u * 256u) * 4u)
+#define RPTR_BN_TABLE_MIN_BYTES ((256u * 256u + 128u * 128u * 8u) * 4u)
+
 /* rendering/bsdfs/base_material.h.glsl:13-34 -- 80 bytes */
 typedef struct RptrBaseMaterial {
     float base_color[3];
@@ -356,6 +371,11 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
  * does not advance frame_offset and a rendered frame does not advance frame_id -- every frame repeats the same samples (the
  * reference's --freeze-frame, cmdline.cpp:359-360). */
 int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame);
+/* set_backend_options(rng_variant) + the upload of the point set's table (vulkan/pointsets/render_sobol.cpp:84-104, render_bn.cpp:78-126:
+ * the buffer bound at RANDOM_NUMBERS_BIND_POINT). `table` = host pointer to SobolData / BNData bytes (sizes above; NULL and 0 for
+ * UNIFORM); the library keeps a device copy. Frames in flight are waited for; accumulation is not reset (the caller resets, as
+ * the reference does when backend options change). A table that is too short, or a variant outside 0..3, fails with RPTR_E_INVALID. */
+int rptr_hip_set_rng_variant(rptr_hip_t *h, int rng_variant, const void *table, size_t table_bytes);
 /* hipEvent pairs recorded per frame for RptrStats.*_time_ms: 0 none (render_time_ms only), 1 around the closest-hit
  * traversal launches (extend_time_ms), 2 every stage (default; ~0.1 ms per 1080p frame of launch gaps). */
 int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);

@@ -87,6 +87,7 @@ struct Scene {
     std::vector<RptrTriLightData> lights;        // padded by one zeroed bin (see sample_tri_lights)
     int num_lights = 0;
     bool alpha_test = false; // some material lacks BASE_MATERIAL_NOALPHA
+    PointSetTable pointset;  // orc_scene_set_rng_variant (the render backend option + the table its extension uploads)
 };
 
 // AOV images of a frame (vulkan/accumulate.glsl:76-103): RGBA16F, written by the first sample of the frame at bounce 0
@@ -408,7 +409,7 @@ struct ShadingSampleState { // rendering/mc/shading_interface.glsl:15-22
 template <class MAT>
 static int shade_base_material(const Frame &f, float geometry_scale, ShadingSampleState &state, vec3 &illum, vec3 &path_throughput,
                                const RptrBaseMaterial &params, vec2 hit_uv, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
-                               LCGRand &rng, vec3 &w_i, PathCounters &pc) {
+                               RandomState &rng, vec3 &w_i, PathCounters &pc) {
     MAT mat;
     vec3 emit_radiance;
     unpack_material(f.sc->textures, mat, emit_radiance, params, hit_uv);
@@ -432,15 +433,17 @@ static int shade_base_material(const Frame &f, float geometry_scale, ShadingSamp
     if (state.bounce + 1 >= f.rp.max_path_depth) return SHADING_RESULT_TERMINATE;
     if (state.output_channel == 0) {
         // GLSL evaluates constructor arguments left to right: position sample first, then selection
-        vec2 pos_sample = random_float2(rng);
-        vec2 sel_sample = random_float2(rng);
+        vec2 pos_sample = random_float2(rng, DIM_POSITION_X);
+        vec2 sel_sample = random_float2(rng, DIM_LIGHT_SEL_1);
         illum += scatter_throughput * sample_direct_light(f, geometry_scale, mat, interaction, w_o, pos_sample, sel_sample, pc);
     }
+    random_shift_dim(rng, DIM_LIGHT_END);
     if (f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) return SHADING_RESULT_TERMINATE;
-    vec2 bsdfLobeSample = random_float2(rng);
-    vec2 bsdfDirSample = random_float2(rng);
+    vec2 bsdfLobeSample = random_float2(rng, DIM_LOBE);
+    vec2 bsdfDirSample = random_float2(rng, DIM_DIRECTION_X);
     float sampling_pdf = 0.0f, mis_pdf = 0.0f;
     vec3 bsdf = sample_bsdf(mat, interaction, w_o, w_i, sampling_pdf, mis_pdf, bsdfDirSample, bsdfLobeSample);
+    random_shift_dim(rng, DIM_VERTEX_END);
     ++state.bounce;
     // note: when sample_bsdf bails out early the reference leaves mis_pdf
     // undefined, but bsdf == 0 then terminates regardless.
@@ -455,13 +458,15 @@ static int shade_base_material(const Frame &f, float geometry_scale, ShadingSamp
 template <class MAT>
 static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_index, PathCounters &pc) {
     const Scene &sc = *f.sc;
-    LCGRand rng = get_lcg_rng(sample_index, f.vp.frame_offset, px, py, f.vp.dims_x);
+    RandomState rng = get_rng(&sc.pointset, sample_index, f.vp.frame_offset, px, py, f.vp.dims_x, f.vp.frame_id, f.vp.frame_offset);
+    // :354-358: the alpha test of closest-hit queries draws from the path's generator for the uniform point set, from its own LCG otherwise
+    LCGRand alpha_rng_own = get_lcg_rng(sample_index, f.vp.frame_offset, px, py, f.vp.dims_x);
     pc.px = px;
     pc.py = py;
-    pc.path_rng = &rng;
+    pc.path_rng = rng.variant() == RPTR_RNG_VARIANT_UNIFORM ? &rng.lcg : &alpha_rng_own;
     pc.aov_pixel = (f.aov && sample_index == f.vp.frame_id) ? (long long)py * f.vp.dims_x + px : -1;
     vec2 point = vec2(px + 0.5f, py + 0.5f);
-    if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng) - vec2(0.5f));
+    if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng, DIM_PIXEL_X) - vec2(0.5f));
     point = point / vec2((float)f.vp.dims_x, (float)f.vp.dims_y);
     vec3 ray_origin = f.vp.cam_pos;
     vec3 ray_dir = normalize(point.x * f.vp.cam_du + point.y * f.vp.cam_dv + f.vp.cam_dir_top_left);
@@ -472,6 +477,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
     vec3 path_throughput = vec3(1.f);
     ShadingSampleState shading_state{0, f.rp.output_channel, 2.e16f};
     for (int b = 0; b < f.rp.max_path_depth; ++b) {
+        random_set_dim(rng, DIM_CAMERA_END + b * (DIM_VERTEX_END + DIM_LIGHT_END)); // :423
         Hit h;
         Ray r{ray_origin, ray_dir, t_min, t_max};
         bool found = trace_closest(f, r, h, pc);
@@ -578,7 +584,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
         if (shading_state.bounce >= f.rp.rr_path_depth) {
             float prefix_weight = fmaxf(path_throughput.x, fmaxf(path_throughput.y, path_throughput.z));
             float rr_prob = prefix_weight;
-            float rr_sample = lcg_randomf(rng);
+            float rr_sample = random_float1(rng, DIM_RR);
             if (shading_state.bounce > 6)
                 rr_prob = fminf(0.95f, rr_prob);
             else
@@ -638,6 +644,28 @@ void *orc_scene_create(const RptrSceneDesc *desc) {
     return s;
 }
 void orc_scene_destroy(void *p) { delete (Scene *)p; }
+// RBO rng_variant + the table its render extension uploads (vulkan/pointsets/render_sobol.cpp:84-104, render_bn.cpp:78-126)
+int orc_scene_set_rng_variant(void *p, int variant, const uint32_t *words, size_t n_words) {
+    Scene *s = (Scene *)p;
+    size_t need = 0;
+    if (variant == RPTR_RNG_VARIANT_BN) need = RPTR_BN_TABLE_MIN_BYTES / 4;
+    else if (variant == RPTR_RNG_VARIANT_SOBOL || variant == RPTR_RNG_VARIANT_Z_SBL) need = RPTR_SOBOL_TABLE_BYTES / 4;
+    else if (variant != RPTR_RNG_VARIANT_UNIFORM) return -1;
+    if (n_words < need) return -1;
+    s->pointset.variant = variant;
+    s->pointset.words.assign(words, words + need);
+    return 0;
+}
+// the draws of one pixel sample: get_rng, then n (dimension, value) draws at the dimensions `dims` after RANDOM_SET_DIM(set_dim)
+int orc_pointset_probe(void *p, uint32_t sample_index, uint32_t frame_offset, uint32_t frame_id, uint32_t px, uint32_t py, uint32_t dimx, int set_dim,
+                       const int32_t *dims, int n, float *out, uint32_t *out_index) {
+    Scene *s = (Scene *)p;
+    RandomState r = get_rng(&s->pointset, sample_index, frame_offset, px, py, dimx, frame_id, frame_offset);
+    if (out_index) *out_index = r.index;
+    random_set_dim(r, set_dim);
+    for (int i = 0; i < n; ++i) out[i] = random_float1(r, dims[i]);
+    return 0;
+}
 // Dynamic meshes: replace the positions of one geometry by floats (9 per triangle). The oracle's own BVH is
 // REBUILT from scratch on next use (the device refits; closest-hit results must not depend on the topology).
 int orc_scene_set_dynamic_vertices(void *p, uint32_t geometry, const float *xyz, uint32_t num_vertices) {

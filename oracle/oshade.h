@@ -10,6 +10,7 @@
 // unpinned" -- checked by domain properties in tests/ only.
 #pragma once
 #include "ovec.h"
+#include <vector>
 #include "../include/rptr_hip.h"
 
 namespace orc {
@@ -70,6 +71,158 @@ static inline vec2 random_float2(LCGRand &rng) {
     r.y = lcg_randomf(rng);
     return r;
 }
+
+// ------------------------------------------------------------------ point sets (RBO rng_variant, librender/render_params.glsl.h:34-37)
+// RANDOM_STATE / RANDOM_FLOAT1 / RANDOM_SET_DIM / RANDOM_SHIFT_DIM / GET_RNG of rendering/pointsets/{lcg_rng,sobol,bn_rng}.glsl
+// behind one type (rendering/pointsets/selected_rng.glsl picks one at shader compile time; here `variant` does at run time).
+struct PointSetTable { // the buffer at RANDOM_NUMBERS_BIND_POINT: SobolData (sobol_data.h:13-17) or BNData (bn_data.h:12-27)
+    int variant = 0;   // RPTR_RNG_VARIANT_*
+    std::vector<uint32_t> words;
+};
+enum { SobolData_Dimensions = 1024, SobolData_MatrixSize = 32, SobolData_TileSize = 256 };
+enum { BNData_SampleCount = 256, BNData_Dimensions = 256, BNData_ScramblingDimensions = 8, BNData_TileSize = 128 };
+struct RandomState {
+    const PointSetTable *table = nullptr; // nullptr: uniform
+    LCGRand lcg;          // uniform: the generator; Sobol: the scramble
+    uint32_t index = 0;   // Sobol: point index; blue noise: sampleID
+    uint32_t pixel = 0;   // blue noise: pixelID in the tile
+    int32_t dimension = 0;
+    int variant() const { return table ? table->variant : RPTR_RNG_VARIANT_UNIFORM; }
+};
+static inline uint32_t part1by1(uint32_t x) { // rendering/util.glsl:156-163
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+static inline int find_msb(uint32_t x) { return x ? 31 - __builtin_clz(x) : -1; }
+// rendering/pointsets/sample_order.glsl:22-73, all parameters kept
+static inline uint32_t morton_sample_id(uint32_t sample_id, uint32_t pixel_x, uint32_t pixel_y, uint32_t tile_x, uint32_t tile_y, bool hash_tile_id,
+                                        bool hash_sample_id) {
+    uint32_t padded_x = 1u << find_msb(tile_x), padded_y = 1u << find_msb(tile_y);
+    if (padded_x != tile_x) padded_x <<= 1;
+    if (padded_y != tile_y) padded_y <<= 1;
+    const uint32_t pcount = padded_x * padded_y;
+    const uint32_t ex = part1by1(pixel_x), ey = part1by1(pixel_y);
+    uint32_t linear = (ey << 1) + ex;
+    const uint32_t min_dim_mask = (padded_x - 1u) & (padded_y - 1u);
+    const uint32_t interleaved_mask = (min_dim_mask + 1u) * (min_dim_mask + 1u) - 1u;
+    linear &= interleaved_mask;
+    linear |= ((pixel_x | pixel_y) & ~min_dim_mask) * (min_dim_mask + 1u);
+    if (!hash_tile_id) linear &= pcount - 1u;
+    uint32_t scrambled = linear;
+    uint32_t swap_vec = ex ^ ey;
+    swap_vec |= swap_vec << 1;
+    const uint32_t scramble_mask = interleaved_mask;
+    const uint32_t sample_hash = hash_sample_id ? murmur_hash3_mix(0, sample_id) : 0u;
+    for (uint32_t ie = 2u * (uint32_t)find_msb(min_dim_mask + 1u); ie > 0u;) {
+        uint32_t perm = murmur_hash3_finalize(murmur_hash3_mix(sample_hash, linear >> ie));
+        const bool swap = (perm & 0x4u) != 0u;
+        perm &= 0x3u;
+        ie -= 2u;
+        scrambled ^= (perm << ie) & scramble_mask;
+        const uint32_t swap_mask = swap ? (0x3u << ie) : 0u;
+        if (swap_mask == (scramble_mask & swap_mask)) scrambled ^= swap_vec & swap_mask;
+    }
+    if (hash_tile_id) scrambled &= pcount - 1u;
+    return sample_id * pcount + scrambled;
+}
+// rendering/pointsets/sobol.glsl:74-108
+static inline float sobol_point(const PointSetTable &t, uint32_t index, uint32_t dimension, uint32_t scramble) {
+    dimension &= uint32_t(SobolData_Dimensions - 1);
+    uint32_t result = scramble;
+    for (uint32_t i = dimension * SobolData_MatrixSize; index != 0; index >>= 1, ++i)
+        if (index & 1u) result ^= t.words[i];
+    if (t.variant == RPTR_RNG_VARIANT_Z_SBL && dimension < 2) {
+        const uint32_t tile_bits = (uint32_t)__builtin_popcount(SobolData_TileSize - 1);
+        result ^= result << tile_bits;
+    }
+    return ldexpf((float)result, -32);
+}
+// sobol.glsl:112-130
+static inline uint32_t sobol_shift_invert(const PointSetTable &t, uint32_t index, uint32_t index_shift) {
+    index += index_shift;
+    uint32_t r0 = 0, r1 = 0;
+    for (uint32_t i = 0; index != 0; index >>= 1, ++i)
+        if (index & 1u) {
+            r0 ^= t.words[0 * SobolData_MatrixSize + i];
+            r1 ^= t.words[1 * SobolData_MatrixSize + i];
+        }
+    const uint32_t tile_bits = (uint32_t)__builtin_popcount(SobolData_TileSize - 1);
+    r0 >>= 32 - tile_bits;
+    r1 >>= 32 - tile_bits;
+    return index_shift + t.words[SobolData_Dimensions * SobolData_MatrixSize + r1 * SobolData_TileSize + r0];
+}
+// bn_rng.glsl:30-71 with BN_OPTIMIZED_DIMENSION_REPEAT and BN_OPTIMIZED_SPP 1
+static inline float sample_bnd(const PointSetTable &t, uint32_t pixelID, uint32_t sampleID, uint32_t d) {
+    const uint32_t T = BNData_TileSize, S = BNData_ScramblingDimensions;
+    const uint32_t x_doffset = d / S;
+    pixelID = ((pixelID + x_doffset) & (T - 1u)) + (pixelID & ~(T - 1u));
+    d = (d & (S - 1u)) + x_doffset / T * S;
+    d &= uint32_t(BNData_Dimensions - 1);
+    if (sampleID & 1u) pixelID ^= T - 1u;
+    if (sampleID & 2u) pixelID ^= (T - 1u) * T;
+    const uint32_t x_soffset = sampleID * 73u, y_soffset = sampleID * 97u;
+    pixelID = ((pixelID + x_soffset) & (T - 1u)) + (pixelID & ~(T - 1u));
+    pixelID = ((pixelID + y_soffset * T) & (T * (T - 1u))) + (pixelID & ~(T * (T - 1u)));
+    sampleID = 0;
+    const uint32_t rankingIndex = pixelID * S + (d & (S - 1u));
+    uint32_t value = t.words[d + sampleID * BNData_Dimensions];
+    value ^= t.words[BNData_SampleCount * BNData_Dimensions + rankingIndex]; // tile_scrambling_yx_d_1spp
+    return (0.5f + (float)value) / 256.0f;
+}
+// GET_RNG(index, frame, uvec4(pixel, dims)): lcg_rng.glsl:36-39 | sobol.glsl:165-195 | bn_rng.glsl:80-92,112 (which takes
+// view_params.frame_id / frame_offset instead of the arguments)
+static inline RandomState get_rng(const PointSetTable *table, uint32_t index, uint32_t frame, uint32_t px, uint32_t py, uint32_t dimx,
+                                  uint32_t view_frame_id, uint32_t view_frame_offset) {
+    RandomState r;
+    r.table = (table && table->variant != RPTR_RNG_VARIANT_UNIFORM) ? table : nullptr;
+    switch (r.variant()) {
+    case RPTR_RNG_VARIANT_UNIFORM:
+        r.lcg = get_lcg_rng(index, frame, px, py, dimx);
+        break;
+    case RPTR_RNG_VARIANT_BN:
+        r.lcg.state = 0;
+        r.pixel = (px & uint32_t(BNData_TileSize - 1)) + (py & uint32_t(BNData_TileSize - 1)) * BNData_TileSize;
+        r.index = view_frame_id + view_frame_offset * 13u;
+        break;
+    default: {
+        uint32_t linear = px + py * dimx;
+        uint32_t sample_id = index;
+        if (r.variant() == RPTR_RNG_VARIANT_Z_SBL) {
+            const uint32_t T = SobolData_TileSize;
+            const uint32_t sample_offset = morton_sample_id(0, px, py, T, T, true, false) & (T * T - 1u);
+            sample_id = sobol_shift_invert(*table, sample_offset, T * T * sample_id);
+            const uint32_t tile_bits = (uint32_t)__builtin_popcount(T - 1u);
+            linear = (px >> tile_bits) + (py >> tile_bits) * (dimx >> tile_bits);
+        }
+        r.index = sample_id;
+        r.lcg = get_lcg_rng(frame, 0, linear);
+    }
+    }
+    r.dimension = 0;
+    return r;
+}
+static inline float random_float1(RandomState &r, int dim) {
+    switch (r.variant()) {
+    case RPTR_RNG_VARIANT_UNIFORM: return lcg_randomf(r.lcg);
+    case RPTR_RNG_VARIANT_BN: return sample_bnd(*r.table, r.pixel, r.index, uint32_t(r.dimension + dim));
+    default: return sobol_point(*r.table, r.index, uint32_t(r.dimension) + uint32_t(dim), lcg_random(r.lcg));
+    }
+}
+static inline vec2 random_float2(RandomState &r, int dim) { // defaults.glsl:29-35
+    vec2 v;
+    v.x = random_float1(r, dim);
+    v.y = random_float1(r, dim + 1);
+    return v;
+}
+static inline void random_shift_dim(RandomState &r, int dim_offset) { r.dimension += dim_offset; }
+static inline void random_set_dim(RandomState &r, int dim) { r.dimension = dim; }
+// rendering/pathspace.h
+enum { DIM_PIXEL_X = 0, DIM_CAMERA_END = 6, DIM_DIRECTION_X = 0, DIM_LOBE = 2, DIM_FREE_PATH = 3, DIM_VERTEX_END = 4, DIM_RR = DIM_FREE_PATH - DIM_VERTEX_END,
+       DIM_LIGHT_SEL_1 = 0, DIM_POSITION_X = 2, DIM_LIGHT_END = 4 };
 
 // ---------------------------------------------------------------- util.glsl
 // rendering/util.glsl:73-87

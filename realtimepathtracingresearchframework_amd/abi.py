@@ -15,6 +15,11 @@ RPTR_E_HIP = -5
 VARIANT_GLTF = 0
 VARIANT_SIMPLE = 1
 VARIANT_GLTF_TRANSMISSION = 2
+# RBO rng_variant (librender/render_params.glsl.h:34-37)
+RNG_VARIANT_UNIFORM, RNG_VARIANT_BN, RNG_VARIANT_SOBOL, RNG_VARIANT_Z_SBL = 0, 1, 2, 3
+RNG_VARIANT_NAMES = ("UNIFORM", "BN", "SOBOL", "Z_SBL")
+SOBOL_TABLE_BYTES = (1024 * 32 + 256 * 256) * 4      # RPTR_SOBOL_TABLE_BYTES
+BN_TABLE_MIN_BYTES = (256 * 256 + 128 * 128 * 8) * 4  # RPTR_BN_TABLE_MIN_BYTES
 VARIANT_NAMES = ["wavefront-gltf", "wavefront-diffuse", "wavefront-gltf-transmission"]
 
 BASE_MATERIAL_NOALPHA = 0x01
@@ -235,7 +240,7 @@ COMM_ID_BYTES = 128  # RPTR_COMM_ID_BYTES
 EXPORTED_SYMBOLS = [
     "rptr_hip_create", "rptr_hip_destroy", "rptr_hip_last_error", "rptr_hip_name", "rptr_hip_set_stream",
     "rptr_hip_initialize", "rptr_hip_set_scene", "rptr_hip_update_vertices", "rptr_hip_update_vertices_device", "rptr_hip_refit", "rptr_hip_set_params",
-    "rptr_hip_render", "rptr_hip_render_async", "rptr_hip_render_batch_async", "rptr_hip_wait", "rptr_hip_set_stage_timing", "rptr_hip_set_freeze_frame", "rptr_hip_set_bvh_policy", "rptr_hip_bvh_rebuild_count", "rptr_hip_get_framebuffer_size", "rptr_hip_readback_f32", "rptr_hip_readback_u8", "rptr_hip_readback_aov",
+    "rptr_hip_render", "rptr_hip_render_async", "rptr_hip_render_batch_async", "rptr_hip_wait", "rptr_hip_set_stage_timing", "rptr_hip_set_freeze_frame", "rptr_hip_set_rng_variant", "rptr_hip_set_bvh_policy", "rptr_hip_bvh_rebuild_count", "rptr_hip_get_framebuffer_size", "rptr_hip_readback_f32", "rptr_hip_readback_u8", "rptr_hip_readback_aov",
     "rptr_hip_tile_rows", "rptr_hip_local_pixel_count", "rptr_hip_copy_tile_to_device", "rptr_hip_trace", "rptr_hip_trace_counted",
     "rptr_hip_export_bvh", "rptr_hip_build_bvh_host", "rptr_hip_stats",
     "rptr_hip_comm_get_unique_id", "rptr_hip_comm_init_rank", "rptr_hip_comm_init_all", "rptr_hip_comm_destroy", "rptr_hip_gather", "rptr_hip_gather_all",

@@ -67,6 +67,7 @@ def load_library(path=None):
     L.rptr_hip_render_batch_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
+    L.rptr_hip_set_rng_variant.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
     L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
@@ -363,6 +364,19 @@ class RenderHip:
 
     def refit(self):
         self._check(self._L.rptr_hip_refit(self._h))
+
+    def set_rng_variant(self, rng_variant, table=None):
+        """RenderBackendOptions::rng_variant (render_params.glsl.h:34-37,76) + the table upload of the point set's render extension
+        (vulkan/pointsets/render_{sobol,bn}.cpp). table: uint32 array laid out as SobolData / BNData; None = `pointsets.default_table`."""
+        from . import pointsets
+        if table is None:
+            table = pointsets.default_table(rng_variant)
+        if table is None:
+            self._check(self._L.rptr_hip_set_rng_variant(self._h, int(rng_variant), None, 0))
+        else:
+            t = np.ascontiguousarray(table, dtype=np.uint32)
+            self._check(self._L.rptr_hip_set_rng_variant(self._h, int(rng_variant), t.ctypes.data_as(C.c_void_p), t.nbytes))
+        self.rng_variant = int(rng_variant)
 
     def set_bvh_policy(self, force_bvh_rebuild=False, rebuild_triangle_budget=0):
         """RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget (render_params.glsl.h:61,90-93): device-side rebuilds of

@@ -10,13 +10,23 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "librptr_hip.so")
-SOURCES = ["rptr_hip.hip", "bvh_build.cpp"]
-HEADERS = ["kernels.h", "host_comm.h", "lbvh.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h", "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
+# Translation units: (object name, source, extra flags). The path stages are templates with a few hundred instantiations between them;
+# one family per unit (csrc/launch.h), the units compile side by side.
+UNITS = [
+    ("rptr_hip", "rptr_hip.hip", []),
+    ("bvh_build", "bvh_build.cpp", []),
+    ("k_extend", "k_extend.hip", []),
+] + [("k_shade_v%d" % v, "k_shade.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)] \
+  + [("k_tail_v%d" % v, "k_tail.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)]
+SOURCES = sorted({u[1] for u in UNITS})
+HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_comm.h", "lbvh.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
+           "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
+OBJ_DIR = os.path.join(CSRC, "obj")
 
 # -ffp-contract=off: fused multiply-adds only where the reference writes fma()
 # itself; keeps images bit-reproducible across launches/tilings and comparable
 # with the CPU oracle (DESIGN.md "Numerics").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():
@@ -26,24 +36,44 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP backend cannot be built (there is no CPU fallback)")
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+def _newest_input():
+    return max(os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
 
 
-def build_library(force=False, verbose=False, extra_flags=()):
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+def needs_build(lib_path=LIB_PATH):
+    return not os.path.exists(lib_path) or _newest_input() > os.path.getmtime(lib_path)
+
+
+def build_library(force=False, verbose=False, extra_flags=(), lib_path=LIB_PATH, obj_dir=None, jobs=None):
+    """hipcc -c per unit (in parallel), then one link. extra_flags / lib_path / obj_dir: measurement builds (tools/mkvariant.sh)."""
+    if not force and not needs_build(lib_path):
+        return lib_path
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = obj_dir or OBJ_DIR
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_unit(unit):
+        name, src, flags = unit
+        obj = os.path.join(obj_dir, name + ".o")
+        cmd = [hipcc] + FLAGS + list(extra_flags) + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        return obj, r.returncode, r.stdout
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(UNITS), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_unit, UNITS))
+    for obj, rc, out in results:
+        if out.strip():
+            print(out)
+        if rc != 0:
+            raise RuntimeError("hipcc failed for %s" % obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [r[0] for r in results] + ["-o", lib_path]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 HOST_TOOLS = {"rptr_hip": "rptr_cli.cpp", "demo_host": "demo_host.cpp"}

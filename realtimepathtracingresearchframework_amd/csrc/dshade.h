@@ -121,6 +121,11 @@ struct RpFrame {
     int32_t batch_reset;         // frames 1.. restart the accumulation
     RpDivU32 div_frame_spp;
     size_t out_stride;           // pixels between the per-frame output images of a batch (out_accum / out_fb of rp_k_resolve)
+    // point set (rptr_hip_set_rng_variant): RPTR_RNG_VARIANT_* and its table as the reference uploads it (SobolData: 1024 x 32 matrix
+    // words + the 256 x 256 tile inversion; BNData: 256 x 256 sequence values + the 128 x 128 x 8 scrambling tile)
+    int32_t rng_variant;
+    int32_t _pad_rng;
+    const uint32_t *rng_table;
 };
 // the frame a sample slot belongs to and its frame constants: sample_index, frame_offset (lcg_rng.glsl:36-39) and view_params.frame_id
 // (samples accumulated before the frame: seeds the alpha test of shadow rays, pt_megakernel.glsl:251-262)
@@ -227,6 +232,138 @@ RP_DEV V2 rp_rand2(uint32_t &state) { // rendering/defaults.glsl:29-35
     r.y = rp_randf(state);
     return r;
 }
+
+// ------------------------------------------------------------------ point sets (RBO rng_variant, render_params.glsl.h:34-37)
+// The generator of a path: RANDOM_STATE of rendering/pointsets/{lcg_rng,sobol,bn_rng}.glsl behind one type.
+//   uniform: `s` is the LCG state, dimensions are ignored (defaults.glsl:23-50).
+//   Sobol / Z-Sobol: `index` is the point of the sequence, every draw XORs a fresh LCG number (`s`: the scramble) into it (sobol.glsl:197-206).
+//   blue noise: `index` = sampleID, `pix` = pixelID inside the 128 x 128 tile (bn_rng.glsl:80-92); no state changes between draws.
+// Only `s` lives in the path state (rng_tt.x); index / pix are functions of the path id and are recomputed by rp_rng_open.
+struct RpRng {
+    uint32_t s, index, pix;
+};
+#define RP_SOBOL_DIMS 1024u   // sobol_data.h:7-11
+#define RP_SOBOL_BITS 32u
+#define RP_SOBOL_TILE 256u
+#define RP_BN_SAMPLES 256u    // bn_data.h:7-10
+#define RP_BN_DIMS 256u
+#define RP_BN_SCR_DIMS 8u
+#define RP_BN_TILE 128u
+RP_DEV uint32_t rp_part1by1(uint32_t x) { // rendering/util.glsl:156-163 (bits of x spread to the even positions)
+    x &= 0x0000ffffu;
+    x = (x ^ (x << 8)) & 0x00ff00ffu;
+    x = (x ^ (x << 4)) & 0x0f0f0f0fu;
+    x = (x ^ (x << 2)) & 0x33333333u;
+    x = (x ^ (x << 1)) & 0x55555555u;
+    return x;
+}
+// sample_order.glsl:22-73 morton_sample_id(0, pixel, uvec2(tile), hash_tile_id = true, hash_sample_id = false) for a square power-of-two tile:
+// the Z-order position of the pixel inside its tile, every bit pair permuted (and possibly swapped) by a hash of the bits above it.
+RP_DEV uint32_t rp_morton_shuffled(uint32_t px, uint32_t py, uint32_t tile) {
+    const uint32_t pcount = tile * tile, mask1 = tile - 1u, mask2 = pcount - 1u;
+    const uint32_t ex = rp_part1by1(px), ey = rp_part1by1(py);
+    uint32_t id = ((ey << 1) + ex) & mask2;
+    id |= ((px | py) & ~mask1) * tile; // bits present in one dimension only go on top (they take part in the hashes: hash_tile_id)
+    uint32_t swap_bits = ex ^ ey;
+    swap_bits |= swap_bits << 1;
+    uint32_t out = id;
+    for (uint32_t ie = 2u * uint32_t(31 - __clz(int(tile))); ie > 0u;) {
+        uint32_t perm = rp_murmur_finalize(rp_murmur_mix(0u, id >> ie));
+        const bool swap = (perm & 4u) != 0u;
+        perm &= 3u;
+        ie -= 2u;
+        out ^= (perm << ie) & mask2;
+        const uint32_t swap_mask = swap ? (3u << ie) : 0u;
+        if (swap_mask == (mask2 & swap_mask)) out ^= swap_bits & swap_mask;
+    }
+    return out & mask2;
+}
+// sobol.glsl:112-130: the next point after `index_shift` whose first two coordinates fall on the same pixel of the 256 x 256 tile as
+// point index_shift + index would without the shift (tile_invert_1_0: pixel -> point, rendering/tools/prepare_sobol.cpp:36-58)
+RP_DEV uint32_t rp_sobol_shift_invert(const uint32_t *table, uint32_t index, uint32_t index_shift) {
+    index += index_shift;
+    uint32_t r0 = 0u, r1 = 0u;
+    for (uint32_t i = 0u; index != 0u; index >>= 1, ++i)
+        if (index & 1u) {
+            r0 ^= table[i];
+            r1 ^= table[RP_SOBOL_BITS + i];
+        }
+    r0 >>= 24;
+    r1 >>= 24;
+    return index_shift + table[RP_SOBOL_DIMS * RP_SOBOL_BITS + r1 * RP_SOBOL_TILE + r0];
+}
+// GET_RNG(sample_index, view_params.frame_offset, uvec4(pixel, frame_dims)) of the selected point set (pt_megakernel.glsl:314;
+// lcg_rng.glsl:28-39, sobol.glsl:165-195, bn_rng.glsl:80-92 -- whose GET_RNG takes frame_id / frame_offset of the view instead)
+// TABLE = false: the uniform generator (RBO default), the table code is compiled out of the kernel
+template <bool TABLE>
+RP_DEV RpRng rp_rng_open(const RpFrame &f, const RpSlotFrame &sf, uint32_t px, uint32_t py) {
+    RpRng r;
+    r.index = r.pix = 0u;
+    if (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) {
+        r.s = rp_rng_seed(sf.sample_index, sf.frame_offset, px, py, uint32_t(f.width));
+    } else if (f.rng_variant == RPTR_RNG_VARIANT_BN) {
+        r.s = 0u;
+        r.pix = (px & (RP_BN_TILE - 1u)) + (py & (RP_BN_TILE - 1u)) * RP_BN_TILE;
+        r.index = sf.frame_id + sf.frame_offset * 13u;
+    } else {
+        uint32_t linear = px + py * uint32_t(f.width); // per-pixel scrambling
+        r.index = sf.sample_index;
+        if (f.rng_variant == RPTR_RNG_VARIANT_Z_SBL) {
+            const uint32_t sample_offset = rp_morton_shuffled(px, py, RP_SOBOL_TILE);
+            r.index = rp_sobol_shift_invert(f.rng_table, sample_offset, RP_SOBOL_TILE * RP_SOBOL_TILE * sf.sample_index);
+            linear = (px >> 8) + (py >> 8) * (uint32_t(f.width) >> 8); // per-tile scrambling
+        }
+        // get_lcg_rng(frame_id, 0, linear) with sobol.glsl's "frame_id" = the rnd_offset it is handed
+        r.s = rp_murmur_finalize(rp_murmur_mix(rp_murmur_mix(0u, linear), sf.frame_offset));
+    }
+    return r;
+}
+// sobol.glsl:74-108 (sobol_point) / bn_rng.glsl:30-71 (sample_bnd, BN_OPTIMIZED_SPP 1: no ranking) for absolute dimension `d`
+RP_DEV float rp_draw_table(const RpFrame &f, RpRng &r, uint32_t d) {
+    const uint32_t *table = f.rng_table;
+    if (f.rng_variant == RPTR_RNG_VARIANT_BN) {
+        uint32_t pixel = r.pix, sample = r.index;
+        const uint32_t x_doffset = d / RP_BN_SCR_DIMS;
+        pixel = ((pixel + x_doffset) & (RP_BN_TILE - 1u)) + (pixel & ~(RP_BN_TILE - 1u));
+        d = (d & (RP_BN_SCR_DIMS - 1u)) + x_doffset / RP_BN_TILE * RP_BN_SCR_DIMS;
+        d &= RP_BN_DIMS - 1u;
+        if (sample & 1u) pixel ^= RP_BN_TILE - 1u;
+        if (sample & 2u) pixel ^= (RP_BN_TILE - 1u) * RP_BN_TILE;
+        const uint32_t x_soffset = sample * 73u, y_soffset = sample * 97u;
+        pixel = ((pixel + x_soffset) & (RP_BN_TILE - 1u)) + (pixel & ~(RP_BN_TILE - 1u));
+        pixel = ((pixel + y_soffset * RP_BN_TILE) & (RP_BN_TILE * (RP_BN_TILE - 1u))) + (pixel & ~(RP_BN_TILE * (RP_BN_TILE - 1u)));
+        sample = 0u; // sampleID & (BN_OPTIMIZED_SPP - 1)
+        const uint32_t ranking_index = pixel * RP_BN_SCR_DIMS + (d & (RP_BN_SCR_DIMS - 1u));
+        uint32_t value = table[d + sample * RP_BN_DIMS];
+        value ^= table[RP_BN_SAMPLES * RP_BN_DIMS + ranking_index];
+        return (0.5f + float(value)) / 256.0f;
+    }
+    r.s = r.s * 1664525u + 1013904223u; // lcg_random(rng.scramble)
+    d &= RP_SOBOL_DIMS - 1u;
+    uint32_t result = r.s;
+    uint32_t index = r.index;
+    for (uint32_t i = d * RP_SOBOL_BITS; index != 0u; index >>= 1, ++i)
+        if (index & 1u) result ^= table[i];
+    if (f.rng_variant == RPTR_RNG_VARIANT_Z_SBL && d < 2u) result ^= result << 8; // sobol.glsl:88-102
+    return float(result) * 2.3283064365386962890625e-10f;
+}
+// RANDOM_FLOAT1 / RANDOM_FLOAT2(rng, dim) with the dimension already made absolute (RANDOM_SET_DIM / RANDOM_SHIFT_DIM are plain
+// additions: the callers pass DIM_CAMERA_END + bounce * (DIM_VERTEX_END + DIM_LIGHT_END) + ..., rendering/pathspace.h)
+template <bool TABLE>
+RP_DEV float rp_draw1(const RpFrame &f, RpRng &r, uint32_t d) {
+    if (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) return rp_randf(r.s);
+    return rp_draw_table(f, r, d);
+}
+template <bool TABLE>
+RP_DEV V2 rp_draw2(const RpFrame &f, RpRng &r, uint32_t d) { // defaults.glsl:29-35: x first
+    V2 v;
+    v.x = rp_draw1<TABLE>(f, r, d);
+    v.y = rp_draw1<TABLE>(f, r, d + 1u);
+    return v;
+}
+#define RP_DIM_CAMERA_END 6u   // pathspace.h:17 (the megakernel does not define USE_SIMPLIFIED_CAMERA)
+#define RP_DIM_BOUNCE 8u       // DIM_VERTEX_END + DIM_LIGHT_END
+RP_DEV uint32_t rp_bounce_dim(int bounce) { return RP_DIM_CAMERA_END + uint32_t(bounce) * RP_DIM_BOUNCE; }
 
 // ------------------------------------------------------------------ util.glsl
 RP_DEV void rp_ortho_basis(V3 &v_x, V3 &v_y, V3 n) { // rendering/util.glsl:73-87

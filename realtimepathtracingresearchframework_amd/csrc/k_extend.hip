@@ -1,0 +1,35 @@
+// k_extend.hip -- instantiations of the traversal stages (kernels.h rp_k_extend, rp_k_connect) and their launchers (launch.h)
+#include "launch.h"
+
+void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,
+                      const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+    // the point set only enters through the camera rays (FIRST) and the alpha test's generator (ALPHA)
+    const bool t = table && (first || alpha);
+    rp_pick(count, [&](auto C) {
+        rp_pick(first, [&](auto F) {
+            rp_pick(alpha, [&](auto A) {
+                rp_pick(single, [&](auto S) {
+                    rp_pick(t, [&](auto T) {
+                        rp_launch_kernel(l, rp_k_extend<decltype(C)::value, decltype(F)::value, decltype(A)::value, decltype(S)::value, decltype(T)::value>,
+                                         RP_TRAVERSE_BLOCK, sc, f, ps, queue, bc, ctr, gstack);
+                    });
+                });
+            });
+        });
+    });
+}
+
+void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
+                       RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+    rp_pick(count, [&](auto C) {
+        rp_pick(alpha, [&](auto A) {
+            rp_pick(single, [&](auto S) {
+                rp_launch_kernel(l, rp_k_connect<decltype(C)::value, decltype(A)::value, decltype(S)::value>, RP_TRAVERSE_BLOCK, sc, f, ps, sq, bc, ctr, gstack);
+            });
+        });
+    });
+}
+
+hipError_t rp_extend_blocks_per_cu(int *out) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_extend<false, false, false, false, false>, RP_TRAVERSE_BLOCK, 0);
+}

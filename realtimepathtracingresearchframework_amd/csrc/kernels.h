@@ -26,6 +26,7 @@ struct RpPathState {
     float4 *thr;     // throughput.xyz, prev_bounce_pdf
     float4 *illum;   // illum.xyz, bits(bounce)
     float2 *rng_tt;  // bits(rng state), total_t
+    uint32_t *alpha_rng; // the alpha-test generator of closest-hit queries when the point set is not the uniform one (else NULL)
     float4 *hit_tuv; // t, u, v, bits(prim)
     int2 *hit_ids;   // inst_idx, geom
 };
@@ -88,7 +89,8 @@ RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *q
 // The camera ray of path p (pt_megakernel.glsl:314-325 + :330-352 pinhole branch): a pure function of the frame
 // constants and the path id, so nothing of it is stored -- the first extend and the first shade both call it
 // (saves writing and re-reading 72 bytes of path state per pixel sample). Returns false for padding slots.
-RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot) {
+template <bool TABLE>
+RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot) {
     sslot = rp_div(p, f.div_npix_padded);
     const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
     lx = ly = 0;
@@ -96,26 +98,42 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &d
     const int gy = rp_local_row_to_global(f, ly);
     if (gy >= f.height) return false;
     const RpSlotFrame sf = rp_slot_frame(f, sslot);
-    rng = rp_rng_seed(sf.sample_index, sf.frame_offset, uint32_t(lx), uint32_t(gy), uint32_t(f.width));
+    rng = rp_rng_open<TABLE>(f, sf, uint32_t(lx), uint32_t(gy));
     V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
-    if (f.rp.enable_raster_taa == 0) point = point + (rp_rand2(rng) - v2(0.5f, 0.5f));
+    if (f.rp.enable_raster_taa == 0) point = point + (rp_draw2<TABLE>(f, rng, 0u /* DIM_PIXEL_X */) - v2(0.5f, 0.5f));
     point = v2(point.x / float(f.width), point.y / float(f.height));
     dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
     return true;
 }
-RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, uint32_t &rng, V3 &dir) {
+// the generator of path p at a later bounce: index / pixel recomputed, the state `s` from the path state
+template <bool TABLE>
+RP_DEV RpRng rp_rng_resume(const RpFrame &f, uint32_t p, uint32_t s) {
+    RpRng r;
+    r.s = s;
+    r.index = r.pix = 0u;
+    if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
+        const uint32_t sslot = rp_div(p, f.div_npix_padded);
+        int lx = 0, ly = 0;
+        (void)rp_slot_to_local(f, p - sslot * uint32_t(f.npix_padded), lx, ly);
+        r = rp_rng_open<TABLE>(f, rp_slot_frame(f, sslot), uint32_t(lx), uint32_t(rp_local_row_to_global(f, ly)));
+        r.s = s;
+    }
+    return r;
+}
+// the alpha-test generator of closest-hit queries: the path's own for the uniform point set (`#define alpha_rng rng`), a separate LCG
+// seeded like the uniform one otherwise (pt_megakernel.glsl:354-358)
+RP_DEV uint32_t rp_alpha_seed(const RpFrame &f, uint32_t p) {
+    const uint32_t sslot = rp_div(p, f.div_npix_padded);
+    int lx = 0, ly = 0;
+    (void)rp_slot_to_local(f, p - sslot * uint32_t(f.npix_padded), lx, ly);
+    const RpSlotFrame sf = rp_slot_frame(f, sslot);
+    return rp_rng_seed(sf.sample_index, sf.frame_offset, uint32_t(lx), uint32_t(rp_local_row_to_global(f, ly)), uint32_t(f.width));
+}
+template <bool TABLE>
+RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir) {
     int lx, ly;
     uint32_t sslot;
-    return rp_primary_ray_ex(f, p, rng, dir, lx, ly, sslot);
-}
-
-// The queue of the first bounce is never stored: its entry i IS path id i (sample slot after sample slot, inside a slot the 8x8
-// tiles row by row: 64 consecutive entries = one tile = one wave of camera rays). Ids of the tile padding beyond the right / bottom
-// edge of a frame whose size is not a multiple of 8 name no pixel sample: rp_primary_ray returns false for them, the first extend
-// gives them an empty interval (nothing is traversed), the first shade skips them.
-// The same list in memory, for the opt-in regrouping pass (its kernels read a queue array):
-__global__ __launch_bounds__(256) void rp_k_first_queue(uint32_t *queue, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = i;
+    return rp_primary_ray_ex<TABLE>(f, p, rng, dir, lx, ly, sslot);
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
@@ -124,7 +142,7 @@ __global__ __launch_bounds__(256) void rp_k_first_queue(uint32_t *queue, uint32_
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
 // SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
 // LOCAL: `queue` / `cursor` are a block-local list and its cursor in LDS (rp_k_tail).
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL>
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE>
 RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const uint32_t *queue, uint32_t n, uint32_t *cursor, RpCounters *ctr,
                            int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
@@ -134,23 +152,23 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         const uint32_t p = (FIRST && !queue) ? i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
         lane_p = p;
         if (FIRST) {
-            uint32_t rng = 0;
+            RpRng rng;
             rd = v3(0.0f, 0.0f, 1.0f);
-            if (!rp_primary_ray(f, p, rng, rd)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
+            if (!rp_primary_ray<TABLE>(f, p, rng, rd)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
                 ps.hit_ids[p] = make_int2(-1, -1);
                 return false;
             }
             ro = ld3(f.cam_pos);
             tmin = 0.0f;
             tmax = 2.e32f;
-            if (ALPHA) lane_rng = rng;
+            if (ALPHA) lane_rng = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? rng.s : rp_alpha_seed(f, p);
         } else {
             const float4 o = ps.ray_o[p], d = ps.ray_d[p];
             ro = xyz(o);
             rd = xyz(d);
             tmin = o.w;
             tmax = d.w;
-            if (ALPHA) lane_rng = lane_rng_in = __float_as_uint(ps.rng_tt[p].x);
+            if (ALPHA) lane_rng = lane_rng_in = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(ps.rng_tt[p].x) : ps.alpha_rng[p];
         }
         return true;
     };
@@ -159,7 +177,9 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
         if (ALPHA) {
-            if (FIRST)
+            if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
+                if (FIRST || lane_rng != lane_rng_in) ps.alpha_rng[p] = lane_rng;
+            } else if (FIRST)
                 ps.rng_tt[p] = make_float2(__uint_as_float(lane_rng), 0.0f); // the first shade takes it from here (f.alpha_test)
             else if (lane_rng != lane_rng_in)
                 reinterpret_cast<float *>(ps.rng_tt + p)[0] = __uint_as_float(lane_rng);
@@ -179,10 +199,10 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         }
     }
 }
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE>
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool TABLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
-    rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
+    rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false, TABLE>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
 }
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
@@ -239,142 +259,6 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathSta
     rp_connect_body<COUNT, ALPHA, SINGLE, false>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
 }
 
-// ------------------------------------------------------------------ sort by material and hit cell
-// Regroups the paths that were just extended so that a wave shades one material and
-// -- just as important on this machine -- neighbouring hit points: the shadow rays
-// and continuation rays it emits then start close together and share BVH nodes,
-// which is what the L1 path (64 B/clk/CU, one distinct line per clock) rewards.
-//   key 0                     = miss
-//   1 + group*cells + cell    = hit; group = material id % groups, cell = position
-//                               of the hit in a grid over the scene bounds
-// One counting-sort pass with up to RP_SORT_MAX_KEYS bins: block-local LDS
-// histograms (wave ballot aggregation for the dominant keys, ds_add for the rest),
-// one global add per non-empty (block, bin), single-block scan, and a scatter that
-// reserves a contiguous range per (block, bin).
-RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpFrame &f, const RpPathState &ps, uint32_t p) {
-    const int2 ids = ps.hit_ids[p];
-    if (ids.x < 0) return 0u;
-    const float4 hit = ps.hit_tuv[p];
-    const int prim = __float_as_int(hit.w);
-    const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[13]; // RptrBvhInstance::geometry_base
-    const RpGeomRecord &g = sc.geoms[geometry_base + ids.y];
-    const int mid = rp_hit_material_id(g, uint32_t(prim));
-    const float4 o = ps.ray_o[p], d = ps.ray_d[p];
-    const float px = o.x + hit.x * d.x, py = o.y + hit.x * d.y, pz = o.z + hit.x * d.z;
-    const int cx = min(max(int((px - f.sort_lo[0]) * f.sort_scale[0]), 0), (1 << f.sort_bits[0]) - 1);
-    const int cy = min(max(int((py - f.sort_lo[1]) * f.sort_scale[1]), 0), (1 << f.sort_bits[1]) - 1);
-    const int cz = min(max(int((pz - f.sort_lo[2]) * f.sort_scale[2]), 0), (1 << f.sort_bits[2]) - 1);
-    const uint32_t cell = (uint32_t(cx) << (f.sort_bits[1] + f.sort_bits[2])) | (uint32_t(cy) << f.sort_bits[2]) | uint32_t(cz);
-    const uint32_t group = uint32_t(mid) % uint32_t(f.sort_groups);
-    return 1u + group * uint32_t(f.sort_cells) + cell;
-}
-RP_DEV void rp_sort_slice(uint32_t n, uint32_t &begin, uint32_t &end) {
-    uint32_t per = (n + RP_SORT_BLOCKS - 1) / RP_SORT_BLOCKS;
-    per = (per + 255u) & ~255u;
-    begin = min(n, blockIdx.x * per);
-    end = min(n, begin + per);
-}
-// table[key] += 1 for every valid lane; returns the previous value seen by the lane (its slot).
-// The two most common keys of the wave are handled with ballot + one LDS add each.
-RP_DEV uint32_t rp_lds_take(uint32_t *table, uint32_t key, bool valid) {
-    const uint32_t lane = rp_lane_id();
-    uint32_t pos = 0;
-    unsigned long long todo = __ballot(valid);
-#pragma unroll 1
-    for (int it = 0; it < 2 && todo; ++it) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k = __shfl(key, leader);
-        const unsigned long long same = __ballot(valid && key == k);
-        uint32_t b = 0;
-        if (int(lane) == leader) b = atomicAdd(&table[k], (uint32_t)__popcll(same));
-        b = __shfl(b, leader);
-        if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) pos = atomicAdd(&table[key], 1u);
-    return pos;
-}
-__global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                                       uint32_t *keys, uint32_t *hist) {
-    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
-    const uint32_t n = *count_ptr;
-    if (n < RP_SORT_MIN_N) return;
-    const int num_keys = f.sort_num_keys;
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
-    __syncthreads();
-    uint32_t begin, end;
-    rp_sort_slice(n, begin, end);
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        uint32_t key = 0;
-        if (valid) {
-            key = rp_sort_key(sc, f, ps, queue[i]);
-            keys[i] = key;
-        }
-        (void)rp_lds_take(lh, key, valid);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
-        if (lh[k]) atomicAdd(&hist[k], lh[k]);
-}
-// single block: exclusive scan of hist -> base; clears hist and the scatter cursors for the next bounce
-__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *hist, uint32_t *base, uint32_t *cursor, int num_keys) {
-    __shared__ uint32_t partial[1024];
-    const uint32_t total = uint32_t(num_keys);
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = min(total, b + per);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += hist[i];
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = int(threadIdx.x) >= off ? partial[threadIdx.x - off] : 0u;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = partial[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t c = hist[i];
-        base[i] = run;
-        hist[i] = 0;
-        cursor[i] = 0;
-        run += c;
-    }
-}
-__global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
-                                                         const uint32_t *base, uint32_t *cursor, uint32_t *order) {
-    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
-    const uint32_t n = *count_ptr;
-    uint32_t begin, end;
-    rp_sort_slice(n, begin, end);
-    if (n < RP_SORT_MIN_N) { // too few paths for regrouping to pay: keep the queue order
-        for (uint32_t i = begin + threadIdx.x; i < end; i += 256) order[i] = queue[i];
-        return;
-    }
-    const int num_keys = f.sort_num_keys;
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
-    __syncthreads();
-    // pass A: this block's histogram of its slice
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        (void)rp_lds_take(lh, valid ? keys[i] : 0u, valid);
-    }
-    __syncthreads();
-    // reserve one contiguous output range per non-empty bin of this block
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) {
-        const uint32_t c = lh[k];
-        if (c) lh[k] = base[k] + atomicAdd(&cursor[k], c);
-    }
-    __syncthreads();
-    // pass B: scatter
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        const uint32_t pos = rp_lds_take(lh, valid ? keys[i] : 0u, valid);
-        if (valid) order[pos] = queue[i];
-    }
-}
-
 // ------------------------------------------------------------------ shade
 #ifndef RP_SHADE_WAVES
 #define RP_SHADE_WAVES 4 // minimum waves per SIMD the shade kernels are compiled for (bounds their VGPR budget)
@@ -384,7 +268,7 @@ __global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32
 // TEX = false: no material of the scene reads a texture (textured parameters, normal maps): sampling code compiled out
 // LOCAL (rp_k_tail): `order` is a block-local list of n <= RP_CHUNK path ids; the survivors and the shadow rays are not
 // published to the global queues but left in shared memory for the caller (local_next / local_shadow, counts in n_next / n_shadow)
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL>
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE>
 RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
                           uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
                           uint32_t *&local_shadow, uint32_t &n_shadow) {
@@ -446,7 +330,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             bool nee = false;       // ... and samples direct light
             bool nee_tri = false;   // ... from the triangle lights (needs the bin's contributions)
             bool terminate = false;
-            uint32_t rng = 0;
+            RpRng rng;
+            rng.s = rng.index = rng.pix = 0u;
             float total_t = 0.f, prev_bounce_pdf = 0.f, geometry_scale = 0.f;
             V3 ray_origin = v3s(0.f), ray_dir = v3s(0.f), throughput = v3s(0.f), illum = v3s(0.f), scatter_throughput = v3s(0.f);
             V3 ip_p = v3s(0.f), gn = v3s(0.f), nn = v3s(0.f), w_o = v3s(0.f), v_x = v3s(0.f), v_y = v3s(0.f);
@@ -466,12 +351,13 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             if (present) {
                 p = il < chunk_hits ? s_list[il] : s_list[RP_CHUNK - 1 - (il - chunk_hits)];
                 // bounce 0: the camera ray again; ids of tile padding name no pixel sample (the first queue is the identity)
-                if (FIRST) present = rp_primary_ray_ex(f, p, rng, ray_dir, first_lx, first_ly, first_sslot);
+                if (FIRST) present = rp_primary_ray_ex<TABLE>(f, p, rng, ray_dir, first_lx, first_ly, first_sslot);
             }
             if (present) {
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
-                    if (f.alpha_test) rng = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
+                    if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM))
+                        rng.s = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
                         if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) aov_px = first_ly * f.width + first_lx;
@@ -487,7 +373,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     const float4 thr4 = ps.thr[p];
                     const float4 il4 = ps.illum[p];
                     const float2 rt = ps.rng_tt[p];
-                    rng = __float_as_uint(rt.x);
+                    rng = rp_rng_resume<TABLE>(f, p, __float_as_uint(rt.x));
                     total_t = rt.y;
                     ray_origin = xyz(ro4);
                     ray_dir = xyz(rd4);
@@ -592,8 +478,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     if (!terminate && output_channel == 0) {
                         // ---- sample_direct_light, rendering/mc/nee.glsl:32-90: the random numbers and the kind of light
                         nee = true;
-                        dir_sample = rp_rand2(rng);
-                        sel_sample = rp_rand2(rng);
+                        dir_sample = rp_draw2<TABLE>(f, rng, rp_bounce_dim(bounce) + 2u); // DIM_POSITION_X
+                        sel_sample = rp_draw2<TABLE>(f, rng, rp_bounce_dim(bounce));      // DIM_LIGHT_SEL_1
                         if (LIGHTS && !(sel_sample.x <= sun_w)) {
                             nee_tri = true;
                             sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
@@ -684,8 +570,9 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             if (hit_lane) {
                 if (!terminate && f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
                 if (!terminate) {
-                    const V2 lobe_sample = rp_rand2(rng);
-                    const V2 dir_sample2 = rp_rand2(rng);
+                    const uint32_t vertex_dim = rp_bounce_dim(bounce) + 4u; // behind RANDOM_SHIFT_DIM(rng, DIM_LIGHT_END)
+                    const V2 lobe_sample = rp_draw2<TABLE>(f, rng, vertex_dim + 2u); // DIM_LOBE
+                    const V2 dir_sample2 = rp_draw2<TABLE>(f, rng, vertex_dim);      // DIM_DIRECTION_X
                     V3 w_i = v3s(0.0f);
                     float sampling_pdf = 0.0f, mis_pdf = 0.0f;
                     V3 bsdf;
@@ -710,7 +597,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         if (bounce >= f.rp.rr_path_depth) {
                             const float prefix_weight = fmaxf(throughput.x, fmaxf(throughput.y, throughput.z));
                             float rr_prob = prefix_weight;
-                            const float rr_sample = rp_randf(rng);
+                            const float rr_sample = rp_draw1<TABLE>(f, rng, vertex_dim + 3u); // DIM_RR: the unused free-path slot of this vertex
                             rr_prob = (bounce > 6) ? fminf(0.95f, rr_prob) : fminf(1.0f, rr_prob);
                             if (rr_sample < rr_prob)
                                 throughput = throughput / rr_prob;
@@ -722,7 +609,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                             ps.ray_o[p] = f4(ray_origin, t_min);
                             ps.ray_d[p] = f4(ray_dir, 1e20f);
                             ps.thr[p] = f4(throughput, prev_bounce_pdf);
-                            ps.rng_tt[p] = make_float2(__uint_as_float(rng), total_t);
+                            ps.rng_tt[p] = make_float2(__uint_as_float(rng.s), total_t);
                         }
                     }
                 }
@@ -762,13 +649,13 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
         n_shadow = s_ns;
     }
 }
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX>
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool TABLE>
 __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
     uint32_t *ln = nullptr, *ls = nullptr;
     uint32_t nn = 0, ns = 0;
-    rp_shade_body<VARIANT, FIRST, LIGHTS, TEX, false>(sc, f, ps, sq, order, *count_ptr, next_queue, next_count, shadow_count, ctr, ln, nn, ls, ns);
+    rp_shade_body<VARIANT, FIRST, LIGHTS, TEX, false, TABLE>(sc, f, ps, sq, order, *count_ptr, next_queue, next_count, shadow_count, ctr, ln, nn, ls, ns);
 }
 
 // ------------------------------------------------------------------ tail: the late bounces of a frame in ONE launch
@@ -778,7 +665,7 @@ __global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, Rp
 // them to the end -- extend, shade, connect per bounce on block-local lists in LDS, the same device code as the stand-alone
 // kernels (results are bit-identical, tests/test_gpu_parity.py) -- before it takes the next chunk.
 #define RP_TAIL_CHUNK 256
-template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE>
+template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
 __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
     __shared__ uint32_t s_cur[RP_TAIL_CHUNK];
@@ -792,265 +679,16 @@ __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPat
         for (int b = first_bounce; b < f.rp.max_path_depth && n > 0; ++b) {
             if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
             __syncthreads();
-            rp_extend_body<false, false, ALPHA, SINGLE, true>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack);
+            rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack);
             __syncthreads();
             uint32_t *next = nullptr, *shadow = nullptr;
             uint32_t n_next = 0, n_shadow = 0;
-            rp_shade_body<VARIANT, false, LIGHTS, TEX, true>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow);
+            rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow);
             __syncthreads();
             rp_connect_body<false, ALPHA, SINGLE, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack);
             __syncthreads();
             if (threadIdx.x < n_next) s_cur[threadIdx.x] = next[threadIdx.x]; // survivors: at most n <= RP_TAIL_CHUNK
             n = n_next;
         }
-    }
-}
-
-// the query kernel (rp_k_trace) borrows a pool cursor: reset it
-__global__ void rp_k_reset_u32(uint32_t *p) { *p = 0; }
-
-// ------------------------------------------------------------------ resolve
-// accumulate.glsl:68-73 (store this sample) + process_samples.comp:116-132 (running mean into the
-// history) + :143-198 (exposure, early tone mapping, AOV views, sRGB, RGBA8). One thread per local pixel, samples folded in order.
-// out_accum / out_fb (frames in flight, else NULL): a second copy of what this frame leaves in accum / fb
-RP_DEV float4 rp_half4_to_float4(uint2 h) {
-    return make_float4((float)__builtin_bit_cast(_Float16, (uint16_t)(h.x & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(h.x >> 16)),
-                       (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y & 0xFFFFu)), (float)__builtin_bit_cast(_Float16, (uint16_t)(h.y >> 16)));
-}
-// rendering/postprocess/tonemapping_utils.glsl:9-33 (modes: postprocess/tonemapping.h)
-RP_DEV V3 rp_tonemap(int mode, V3 c) {
-    if (mode == 2) // FAST_TONE_MAPPING
-        return c / (v3s(1.0f) + c);
-    if (mode == 1) { // NEUTRAL_TONE_MAPPING
-        const float luminance_level = fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, 1.0f));
-        return c * (mixf(0.1f * log2f(luminance_level), 1.0f, 0.8f) / luminance_level);
-    }
-    return c; // NO_TONE_MAPPING
-}
-// process_samples.comp:143-190: what the RGBA8 frame buffer shows for the resolved pixel `acc` (alpha already clamped)
-RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
-    const int ch = f.rp.output_channel;
-    if (ch == 0) { // OUTPUT_CHANNEL_COLOR
-        const float e = exp2f(f.rp.exposure);
-        V3 c = v3(o.x * e, o.y * e, o.z * e);
-        if (f.rp.early_tone_mapping_mode >= 0) c = rp_tonemap(f.rp.early_tone_mapping_mode, c);
-        o = f4(c, o.w);
-    } else if (f.aov_albedo_roughness) { // ENABLE_AOV_BUFFERS: the views of the AOV images
-        if (ch == 1) {
-            o = rp_half4_to_float4(f.aov_albedo_roughness[pixel]);
-            if (f.rp.output_moment != 0) o = make_float4(o.w, o.w, o.w, o.w);
-        } else if (ch == 2) {
-            o = rp_half4_to_float4(f.aov_normal_depth[pixel]);
-            if (f.rp.output_moment != 0)
-                o = make_float4(o.w * 0.05f, o.w * 0.05f, o.w * 0.05f, o.w);
-            else
-                o = make_float4(o.x * 0.5f + 0.5f, o.y * 0.5f + 0.5f, o.z * 0.5f + 0.5f, o.w);
-        } else if (ch == 3) {
-            const float4 mj = rp_half4_to_float4(f.aov_motion_jitter[pixel]);
-            if (f.rp.output_moment == 0)
-                o = make_float4(fabsf(10.0f * mj.x), fabsf(10.0f * mj.y), 0.0f, 1.0f);
-            else { // jitter back to pixel units (process_samples.comp:171-176)
-                const float jx = (mj.z + 1.0f / float(f.width)) * (float(f.width) / 2.0f), jy = (mj.w + 1.0f / float(f.height)) * (float(f.height) / 2.0f);
-                o = make_float4(jx * 0.5f + 0.5f, jy * 0.5f + 0.5f, 0.0f, 1.0f);
-            }
-        }
-    } else { // without AOV images (RPTR_AOVS=0): the views of what the integrator accumulated (process_samples.comp:179-188)
-        if (ch == 2) {
-            if (f.rp.output_moment != 0) {
-                const float l = len3(v3(o.x, o.y, o.z));
-                o = make_float4(l, l, l, o.w);
-            } else
-                o = make_float4(o.x * 0.5f + 0.5f, o.y * 0.5f + 0.5f, o.z * 0.5f + 0.5f, o.w);
-        } else if (ch == 3)
-            o = make_float4((o.x - f.cam_pos[0]) * 0.1f + 0.5f, (o.y - f.cam_pos[1]) * 0.1f + 0.5f, (o.z - f.cam_pos[2]) * 0.1f + 0.5f, o.w);
-    }
-    return make_float4(rp_linear_to_srgb(o.x), rp_linear_to_srgb(o.y), rp_linear_to_srgb(o.z), o.w);
-}
-// out_accum / out_fb (frames in flight, else NULL): what each frame of the batch leaves in accum / fb, frame k at k * f.out_stride
-__global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, float4 *accum, uchar4 *fb, float4 *out_accum, uchar4 *out_fb) {
-    const int npix = f.width * f.local_rows;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        const int ly = int(rp_div(uint32_t(i), f.div_width)), lx = i - ly * f.width;
-        if (rp_local_row_to_global(f, ly) >= f.height) continue;
-        const uint32_t slot = rp_local_to_slot(f, lx, ly);
-        float4 acc = accum[i];
-        uchar4 shown = fb[i];
-        const int per_frame = f.batch_frames > 1 ? f.frame_spp : f.batch_spp;
-        for (int k = 0; k < f.batch_frames; ++k) {
-            for (int j = 0; j < per_frame; ++j) {
-                const int s = k * per_frame + j;
-                const float4 il = ps.illum[size_t(s) * size_t(f.npix_padded) + slot];
-                const float4 c = make_float4(il.x, il.y, il.z, __float_as_int(il.w) == 0 ? 0.0f : 1.0f); // pt_megakernel.glsl:736
-                const uint32_t sample_index = rp_slot_frame(f, uint32_t(s)).sample_index;
-                if (sample_index == 0)
-                    acc = c;
-                else {
-                    const float denom = float(int(sample_index) + 1);
-                    acc.x += (c.x - acc.x) / denom;
-                    acc.y += (c.y - acc.y) / denom;
-                    acc.z += (c.z - acc.z) / denom;
-                    acc.w += (c.w - acc.w) / denom;
-                }
-            }
-            float4 o = acc;
-            o.w = fminf(o.w, 1.0f);
-            if (o.w >= 0.0f) {
-                o = rp_display_color(f, o, i);
-                shown = make_uchar4((unsigned char)(clamp1(o.x, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.y, 0.f, 1.f) * 255.0f + 0.5f),
-                                    (unsigned char)(clamp1(o.z, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
-            }
-            if (out_accum) {
-                out_accum[size_t(k) * f.out_stride + size_t(i)] = acc;
-                out_fb[size_t(k) * f.out_stride + size_t(i)] = shown;
-            }
-        }
-        accum[i] = acc;
-        fb[i] = shown;
-    }
-}
-
-// ------------------------------------------------------------------ RQ_CLOSEST, vulkan/rt_intersect.comp:31-68
-// COUNT: also writes per-query visit counts (nodes, triangles) -- the diagnostic behind rptr_hip_trace_counted
-// ANY (diagnostic only): occlusion query over (tmin_arr[i], t_max), result.x = 1 when anything is hit
-template <bool COUNT, bool ANY, bool SINGLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQuery *queries, uint32_t n, float4 *results, uint32_t *cursor,
-                                              int *gstack, uint2 *per_ray, const float *tmin_arr) {
-    uint32_t nn = 0, nt = 0, nn_prev = 0, nt_prev = 0;
-    auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
-        const float4 *qp = reinterpret_cast<const float4 *>(queries + i);
-        const float4 q0 = qp[0], q1 = qp[1];
-        ro = v3(q0.x, q0.y, q0.z);
-        rd = v3(q1.x, q1.y, q1.z);
-        tmin = tmin_arr ? tmin_arr[i] : RPTR_RAY_EPSILON * len3(ro); // rt_intersect.comp:40
-        tmax = __float_as_int(q0.w) < 0 ? -1.0f : q1.w;  // mode < 0: skipped query, empty interval
-        return true;
-    };
-    auto done = [&](uint32_t i, const RpHitRec &h) {
-        if (COUNT && per_ray) { // the lane's counters run across its queries: report the difference
-            per_ray[i] = make_uint2(nn - nn_prev, nt - nt_prev);
-            nn_prev = nn;
-            nt_prev = nt;
-        }
-        if (queries[i].mode_or_data < 0) return; // slot stays untouched (rt_intersect.comp:43-44)
-        float4 r;
-        if (ANY)
-            r = make_float4(h.inst_idx < 0 ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f);
-        else if (h.inst_idx < 0)
-            r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
-        else {
-            const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[13];
-            r = make_float4(h.u, h.v, __int_as_float(geometry_base + h.geom), __int_as_float(h.prim));
-        }
-        results[i] = r;
-    };
-    // ray queries see opaque geometry
-    rp_wave_trace<ANY, COUNT, (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN), false, SINGLE>(sc, n, cursor, gstack, load, done, RpNoAlpha(), nn, nt);
-}
-
-// ------------------------------------------------------------------ refit (dynamic meshes)
-// Stands in for the driver's acceleration-structure UPDATE builds (vulkan/vulkanrt_utils.h:83-105,
-// enqueue_refit): triangles are re-derived from the float vertex buffer, node boxes are recomputed
-// bottom-up one height level per launch, instance bounds from the BLAS roots, then the TLAS levels.
-// tri_box: bounds of the three VERTICES (what the builder bounds, bvh_build.cpp), kept for the node pass
-__global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *tri_box, uint32_t begin, uint32_t count,
-                                                       const float *const *geom_dyn) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        RptrBvhTri t = tris[begin + i];
-        const float *p = geom_dyn[t.geom] + 9ull * t.prim;
-        float *b = tri_box + 6ull * (begin + i);
-        for (int k = 0; k < 3; ++k) {
-            t.v0[k] = p[k];
-            t.e1[k] = p[3 + k] - p[k];
-            t.e2[k] = p[6 + k] - p[k];
-            b[k] = fminf(p[k], fminf(p[3 + k], p[6 + k]));
-            b[3 + k] = fmaxf(p[k], fmaxf(p[3 + k], p[6 + k]));
-        }
-        tris[begin + i] = t;
-    }
-}
-// one height level of nodes: child boxes from the triangle / instance bounds (leaves) or from the exact float
-// bounds of the child nodes (node_box, written by the level below), then the shared encoder (bvh4.h)
-RP_DEV void rp_refit_node(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box, const uint32_t e) {
-    const bool tlas = (e >> 31) != 0;
-    const uint32_t ni = e & 0x7FFFFFFFu;
-    int32_t child[4];
-    RpBox4 b;
-    for (int k = 0; k < 4; ++k) {
-        const int32_t c = nodes[ni].child[k];
-        child[k] = c;
-        for (int a = 0; a < 3; ++a) {
-            b.lo[k][a] = INFINITY;
-            b.hi[k][a] = -INFINITY;
-        }
-        if (c == RPTR_BVH4_EMPTY) continue;
-        if (c >= 0) {
-            const float *nb = node_box + 6ull * c;
-            for (int a = 0; a < 3; ++a) {
-                b.lo[k][a] = nb[a];
-                b.hi[k][a] = nb[3 + a];
-            }
-        } else {
-            const int first = RPTR_BVH_LEAF_FIRST(c), count = RPTR_BVH_LEAF_COUNT(c);
-            for (int j = 0; j < count; ++j) {
-                const float *lb = (tlas ? inst_box : tri_box) + 6ull * (first + j);
-                for (int a = 0; a < 3; ++a) {
-                    b.lo[k][a] = fminf(b.lo[k][a], lb[a]);
-                    b.hi[k][a] = fmaxf(b.hi[k][a], lb[3 + a]);
-                }
-            }
-        }
-    }
-    RptrBvh4Node n;
-    float *nb = node_box + 6ull * ni;
-    rp_bvh4_encode(b, child, &n, nb, nb + 3);
-    nodes[ni] = n;
-}
-RP_DEV void rp_refit_instance(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t i) {
-    const RptrBvhInstance &in = insts[i];
-    const float *mb = node_box + 6ull * in.blas_root; // exact bounds of the mesh
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = INFINITY;
-        hi[k] = -INFINITY;
-    }
-    const float *M = in.object_to_world;
-    for (int c = 0; c < 8; ++c) {
-        const float p[3] = {c & 1 ? mb[3] : mb[0], c & 2 ? mb[4] : mb[1], c & 4 ? mb[5] : mb[2]};
-        for (int rr = 0; rr < 3; ++rr) {
-            const float w = ((M[4 * rr] * p[0] + M[4 * rr + 1] * p[1]) + M[4 * rr + 2] * p[2]) + M[4 * rr + 3];
-            lo[rr] = fminf(lo[rr], w);
-            hi[rr] = fmaxf(hi[rr], w);
-        }
-    }
-    for (int k = 0; k < 3; ++k) {
-        inst_box[6 * i + k] = lo[k];
-        inst_box[6 * i + 3 + k] = hi[k];
-    }
-}
-__global__ __launch_bounds__(256) void rp_k_refit_nodes(RptrBvh4Node *nodes, float *node_box, const float *tri_box, const float *inst_box,
-                                                        const uint32_t *list, uint32_t begin, uint32_t end) {
-    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x)
-        rp_refit_node(nodes, node_box, tri_box, inst_box, list[i]);
-}
-__global__ __launch_bounds__(256) void rp_k_refit_instances(const float *node_box, const RptrBvhInstance *insts, float *inst_box, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
-}
-// The small top of a refit in ONE launch of one block: the shallow bottom-level levels of one dynamic mesh (a level waits for the one
-// below: a block barrier instead of a launch), the instance bounds, the top-level levels. `blas_levels` / `tlas_levels` hold [begin, end)
-// pairs into their lists, in processing order. Same per-node arithmetic as the stand-alone kernels.
-__global__ __launch_bounds__(1024) void rp_k_refit_top(RptrBvh4Node *nodes, float *node_box, const float *tri_box, float *inst_box, const uint32_t *blas_list,
-                                                       const uint2 *blas_levels, int n_blas, const uint32_t *tlas_list, const uint2 *tlas_levels, int n_tlas,
-                                                       const RptrBvhInstance *insts, uint32_t n_insts) {
-    for (int l = 0; l < n_blas; ++l) {
-        const uint2 lv = blas_levels[l];
-        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, blas_list[i]);
-        __syncthreads();
-    }
-    for (uint32_t i = threadIdx.x; i < n_insts; i += blockDim.x) rp_refit_instance(node_box, insts, inst_box, i);
-    __syncthreads();
-    for (int l = 0; l < n_tlas; ++l) {
-        const uint2 lv = tlas_levels[l];
-        for (uint32_t i = lv.x + threadIdx.x; i < lv.y; i += blockDim.x) rp_refit_node(nodes, node_box, tri_box, inst_box, tlas_list[i]);
-        __syncthreads();
     }
 }

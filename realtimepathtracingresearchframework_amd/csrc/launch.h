@@ -1,0 +1,68 @@
+// launch.h -- host-side launchers of the path stages. The stages are templates (kernels.h) with a few hundred instantiations between
+// them; each k_*.hip instantiates one family and exports a plain function that maps run-time flags to the instantiation, so that the
+// families compile side by side (build.py) and rptr_hip.hip never instantiates a path kernel itself.
+#pragma once
+#include <hip/hip_ext.h>
+#include <type_traits>
+
+#include "kernels.h"
+
+struct RpLaunch {
+    unsigned grid;
+    hipStream_t stream;
+    hipEvent_t start, stop; // non-NULL: start / stop events ride on the dispatch packet itself (hipExtLaunchKernelGGL)
+};
+template <class K, class... A>
+static inline void rp_launch_kernel(const RpLaunch &l, K kernel, unsigned block, A... args) {
+    if (l.start)
+        hipExtLaunchKernelGGL(kernel, dim3(l.grid), dim3(block), 0, l.stream, l.start, l.stop, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, dim3(l.grid), dim3(block), 0, l.stream, args...);
+}
+// run-time flag -> template argument: f(std::true_type) or f(std::false_type)
+template <class F>
+static inline void rp_pick(bool v, F &&f) {
+    if (v)
+        f(std::true_type());
+    else
+        f(std::false_type());
+}
+
+// k_extend.hip: closest-hit and shadow queries
+void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,
+                      const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr, int *gstack);
+void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
+                       RpBounceCounters *bc, RpCounters *ctr, int *gstack);
+hipError_t rp_extend_blocks_per_cu(int *out); // occupancy of the traversal kernels (they all fit the same budget)
+
+// k_shade.hip / k_tail.hip, built once per gpu-program variant (-DRP_INST_VARIANT=RPTR_VARIANT_*)
+#define RP_DECLARE_VARIANT(V)                                                                                                                          \
+    void rp_launch_shade_v##V(const RpLaunch &l, bool first, bool lights, bool tex, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,  \
+                              const RpShadowRays &sq, const uint32_t *order, const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count,     \
+                              uint32_t *shadow_count, RpCounters *ctr);                                                                                  \
+    void rp_launch_tail_v##V(const RpLaunch &l, bool lights, bool full, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,  \
+                             const RpShadowRays &sq, const uint32_t *queue, RpCounters *ctr, int first_bounce, int *gstack);
+RP_DECLARE_VARIANT(0)
+RP_DECLARE_VARIANT(1)
+RP_DECLARE_VARIANT(2)
+#undef RP_DECLARE_VARIANT
+
+template <class... A>
+static inline void rp_launch_shade(int variant, const RpLaunch &l, A... args) {
+    if (variant == RPTR_VARIANT_SIMPLE)
+        rp_launch_shade_v1(l, args...);
+    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
+        rp_launch_shade_v2(l, args...);
+    else
+        rp_launch_shade_v0(l, args...);
+}
+template <class... A>
+static inline void rp_launch_tail(int variant, const RpLaunch &l, A... args) {
+    if (variant == RPTR_VARIANT_SIMPLE)
+        rp_launch_tail_v1(l, args...);
+    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
+        rp_launch_tail_v2(l, args...);
+    else
+        rp_launch_tail_v0(l, args...);
+}
+static_assert(RPTR_VARIANT_GLTF == 0 && RPTR_VARIANT_SIMPLE == 1 && RPTR_VARIANT_GLTF_TRANSMISSION == 2, "k_shade.hip / k_tail.hip are built per variant number");

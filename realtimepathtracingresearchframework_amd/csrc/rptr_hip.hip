@@ -8,7 +8,8 @@
 #include "../../include/rptr_hip.h"
 
 #include "bvh_build.h"
-#include "kernels.h"
+#include "kernels_misc.h"
+#include "launch.h"
 #include "lbvh.h"
 #include <hip/hip_ext.h>
 
@@ -82,8 +83,8 @@ struct Span {
 struct FrameCtx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    RpPathState ps;
-    RpShadowRays sq;
+    RpPathState ps = {};
+    RpShadowRays sq = {};
     uint32_t *queue[2] = {nullptr, nullptr};
     uint32_t *order = nullptr, *keys = nullptr;
     uint32_t *sort_hist = nullptr, *sort_base = nullptr, *sort_cursor = nullptr;
@@ -208,6 +209,8 @@ struct rptr_hip {
     int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
     bool freeze_frame = false; // RenderConfiguration::freeze_frame: frame_offset / frame_id stand still
+    int rng_variant = RPTR_RNG_VARIANT_UNIFORM; // rptr_hip_set_rng_variant
+    uint32_t *rng_table = nullptr;              // device copy of SobolData / BNData (hipMalloc, freed on replace / destroy)
 
     RptrStats stats;
 };
@@ -846,6 +849,7 @@ void rptr_hip_destroy(rptr_hip_t *h) {
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    if (h->rng_table) (void)hipFree(h->rng_table);
     delete h;
 }
 
@@ -902,6 +906,8 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         if ((rc = dev_alloc(h, &c.ps.thr, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.illum, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.rng_tt, cap, nullptr))) return rc;
+        c.ps.alpha_rng = nullptr;
+        if (h->rng_variant != RPTR_RNG_VARIANT_UNIFORM && (rc = dev_alloc(h, &c.ps.alpha_rng, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_tuv, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_ids, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.sq.o, cap, nullptr))) return rc;
@@ -946,7 +952,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
             }
     // persistent traversal kernels: as many blocks as are co-resident
     int occ = 0;
-    HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, rp_k_extend<false, false, false, false>, RP_TRAVERSE_BLOCK, 0));
+    HIP_TRY(h, rp_extend_blocks_per_cu(&occ));
     occ = std::max(1, std::min(occ, 8));
     // frames in flight share the CUs: with n contexts a traversal launch asks for about 12 / n blocks per CU instead of all that
     // fit, so that the kernels of the other frames find room next to it (measured, profiles/r01_notes.md: 3 contexts 5 -> 4 blocks
@@ -1677,27 +1683,13 @@ static inline void pick(bool v, F &&f) {
         f(std::false_type());
 }
 
-template <int VARIANT>
-static void launch_shade(rptr_hip *h, FrameCtx &c, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
-    const int grid = grid_for(h, h->path_capacity);
-    auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, c.stream, scene, f, c.ps, c.sq, order, &c.counters->bounce[bounce].queue_count,
-                           c.queue[out], &c.counters->bounce[bounce + 1].queue_count, &c.counters->bounce[bounce].shadow_count, c.counters);
-    };
+static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
-    const bool tex = h->uses_textures;
-    if (bounce == 0) {
-        if (tex)
-            lights ? go(rp_k_shade<VARIANT, true, true, true>) : go(rp_k_shade<VARIANT, true, false, true>);
-        else
-            lights ? go(rp_k_shade<VARIANT, true, true, false>) : go(rp_k_shade<VARIANT, true, false, false>);
-    } else {
-        if (tex)
-            lights ? go(rp_k_shade<VARIANT, false, true, true>) : go(rp_k_shade<VARIANT, false, false, true>);
-        else
-            lights ? go(rp_k_shade<VARIANT, false, true, false>) : go(rp_k_shade<VARIANT, false, false, false>);
-    }
+    const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
+    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures, f.rng_variant != RPTR_RNG_VARIANT_UNIFORM, scene, f, c.ps, c.sq, order,
+                    (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
+                    &c.counters->bounce[bounce].shadow_count, c.counters);
 }
 
 static void add_counters(RpCounters &dst, const RpCounters &c) {
@@ -1960,6 +1952,17 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         } else
             hipLaunchKernelGGL(kernel, grid, block, 0, st, args...);
     };
+    // ... the same for the path stages, whose kernels are picked by the launchers of launch.h
+    auto timed_launch = [&](hipStream_t st, int kind, unsigned grid) -> RpLaunch {
+        RpLaunch l = {grid, st, nullptr, nullptr};
+        if (h->stage_timing >= 2 || (h->stage_timing == 1 && kind == 0)) {
+            l.start = next_event(c, ev_cursor);
+            l.stop = next_event(c, ev_cursor);
+            c.spans.push_back({l.start, l.stop, kind});
+        }
+        return l;
+    };
+    const bool table_rng = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM;
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
@@ -1992,6 +1995,8 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
     const bool local_work = h->local_rows > 0;
     f.frame_id = h->frame_id; // the whole call is one frame of the reference (its batch_spp = spp), whatever the internal batches
     f.alpha_test = h->uses_alpha ? 1 : 0;
+    f.rng_variant = h->rng_variant;
+    f.rng_table = h->rng_table;
     const bool single = h->master.dscene.single_instance != 0;
     while (remaining > 0) {
         const int batch = std::min(remaining, h->max_batch_spp);
@@ -2020,38 +2025,12 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
                     if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) on the side stream
                     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
-                    auto go = [&](auto kernel) {
-                        timed_kernel(c.stream, 3, kernel, dim3(h->tail_blocks), dim3(256), scn.dscene, f, c.ps, c.sq, (const uint32_t *)c.queue[in], c.counters, b,
-                                     c.gstack);
-                    };
-                    auto with_variant = [&](auto V) {
-                        pick(lights, [&](auto L) {
-                            pick(full, [&](auto F) {
-                                pick(single, [&](auto S) { go(rp_k_tail<decltype(V)::value, decltype(L)::value, decltype(F)::value, decltype(F)::value, decltype(S)::value>); });
-                            });
-                        });
-                    };
-                    if (variant == RPTR_VARIANT_SIMPLE)
-                        with_variant(std::integral_constant<int, RPTR_VARIANT_SIMPLE>());
-                    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
-                        with_variant(std::integral_constant<int, RPTR_VARIANT_GLTF_TRANSMISSION>());
-                    else
-                        with_variant(std::integral_constant<int, RPTR_VARIANT_GLTF>());
+                    rp_launch_tail(variant, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng, scn.dscene, f, c.ps, c.sq,
+                                   (const uint32_t *)c.queue[in], c.counters, b, c.gstack);
                     break;
                 }
-                {
-                    auto go = [&](auto kernel) {
-                        timed_kernel(c.stream, 0, kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), scn.dscene, f, c.ps,
-                                     b == 0 ? first_ids : (const uint32_t *)c.queue[in], bc, c.counters, c.gstack);
-                    };
-                    pick(count_traversal, [&](auto C) {
-                        pick(b == 0, [&](auto F) {
-                            pick(h->uses_alpha, [&](auto A) {
-                                pick(single, [&](auto S) { go(rp_k_extend<decltype(C)::value, decltype(F)::value, decltype(A)::value, decltype(S)::value>); });
-                            });
-                        });
-                    });
-                }
+                rp_launch_extend(timed_launch(c.stream, 0, (unsigned)h->persistent_blocks), count_traversal, b == 0, h->uses_alpha, single, table_rng, scn.dscene, f, c.ps,
+                                 b == 0 ? first_ids : (const uint32_t *)c.queue[in], bc, c.counters, c.gstack);
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
                 const uint32_t *order = in_queue;
@@ -2067,12 +2046,7 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
                 }
                 if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) wrote illum, frees the shadow queue
                 timed(2, [&] {
-                    if (variant == RPTR_VARIANT_SIMPLE)
-                        launch_shade<RPTR_VARIANT_SIMPLE>(h, c, scn.dscene, f, order, b, out);
-                    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
-                        launch_shade<RPTR_VARIANT_GLTF_TRANSMISSION>(h, c, scn.dscene, f, order, b, out);
-                    else
-                        launch_shade<RPTR_VARIANT_GLTF>(h, c, scn.dscene, f, order, b, out);
+                    launch_shade(h, c, variant, scn.dscene, f, order, b, out);
                 });
                 {
                     hipStream_t cs = side ? c.side : c.stream;
@@ -2081,16 +2055,8 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
                         HIP_TRY(h, hipEventRecord(c.ev_fork, c.stream));
                         HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
                     }
-                    {
-                        auto go = [&](auto kernel) {
-                            timed_kernel(cs, 1, kernel, dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), scn.dscene, f, c.ps, c.sq, bc, c.counters, stack);
-                        };
-                        pick(count_traversal, [&](auto C) {
-                            pick(h->uses_alpha, [&](auto A) {
-                                pick(single, [&](auto S) { go(rp_k_connect<decltype(C)::value, decltype(A)::value, decltype(S)::value>); });
-                            });
-                        });
-                    }
+                    rp_launch_connect(timed_launch(cs, 1, (unsigned)h->persistent_blocks), count_traversal, h->uses_alpha, single, scn.dscene, f, c.ps, c.sq, bc, c.counters,
+                                      stack);
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }
                 c.launches_connect++;
@@ -2165,6 +2131,33 @@ int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds) {
 int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     h->freeze_frame = freeze_frame != 0;
+    return RPTR_OK;
+}
+
+int rptr_hip_set_rng_variant(rptr_hip_t *h, int rng_variant, const void *table, size_t table_bytes) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (rng_variant < RPTR_RNG_VARIANT_UNIFORM || rng_variant > RPTR_RNG_VARIANT_Z_SBL)
+        return fail(h, RPTR_E_INVALID, "rng_variant %d (0 uniform, 1 blue noise, 2 Sobol, 3 Z-Sobol)", rng_variant);
+    size_t need = 0;
+    if (rng_variant == RPTR_RNG_VARIANT_BN) need = RPTR_BN_TABLE_MIN_BYTES;
+    if (rng_variant == RPTR_RNG_VARIANT_SOBOL || rng_variant == RPTR_RNG_VARIANT_Z_SBL) need = RPTR_SOBOL_TABLE_BYTES;
+    if (need && (!table || table_bytes < need))
+        return fail(h, RPTR_E_INVALID, "rng_variant %d needs a table of %zu bytes (got %zu)", rng_variant, need, table ? table_bytes : (size_t)0);
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = drain(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->rng_table) {
+        (void)hipFree(h->rng_table);
+        h->rng_table = nullptr;
+    }
+    if (need) {
+        HIP_TRY(h, hipMalloc((void **)&h->rng_table, need));
+        HIP_TRY(h, hipMemcpy(h->rng_table, table, need, hipMemcpyHostToDevice));
+        for (FrameCtx &c : h->ctx) // the alpha-test generator of closest-hit queries gets its own slot in the path state
+            if (!c.ps.alpha_rng && h->path_capacity && (rc = dev_alloc(h, &c.ps.alpha_rng, h->path_capacity, nullptr))) return rc;
+    }
+    h->rng_variant = rng_variant;
     return RPTR_OK;
 }
 

@@ -14,6 +14,7 @@
 // Every [Application] block of a file is one keyframe when the file is given with --keyframe.
 #pragma once
 #include "../../include/rptr_hip.h"
+#include "pointsets.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -115,7 +116,9 @@ struct HostConfig {
     RptrCamera camera;
     int target_spp = -1;
     int variant = -1; // -1: not set
+    int rng_variant = -1; // RNG_VARIANT_*, -1: not set
     int force_bvh_rebuild = 0, rebuild_triangle_budget = 500000; // RBO_rebuild_triangle_budget_DEFAULT
+    bool bvh_policy_set = false; // a file named one of the two
     float bump_scale = 0.f; // 0: not set
     bool sun_changed = false;
     std::vector<std::string> notes;
@@ -128,6 +131,7 @@ inline void apply_ini_object(const IniObject &o, HostConfig &c) {
     o.get("max path depth", &c.params.max_path_depth);
     o.get("rr path depth", &c.params.rr_path_depth);
     o.get("glossy-only mode", &c.params.glossy_only_mode);
+    if (o.attributes.count("force bvh rebuild") || o.attributes.count("rebuild triangle budget")) c.bvh_policy_set = true;
     o.get("force bvh rebuild", &c.force_bvh_rebuild);
     o.get("rebuild triangle budget", &c.rebuild_triangle_budget);
     o.get("pixel radius", &c.params.pixel_radius, 1);
@@ -147,7 +151,9 @@ inline void apply_ini_object(const IniObject &o, HostConfig &c) {
     }
     if (const IniObject *ch = o.child("pointset")) {
         const std::string s = ch->selected();
-        if (!s.empty() && s.find("UNIFORM") == std::string::npos) c.notes.push_back("pointset " + s + ": only RNG_VARIANT_UNIFORM is built (DESIGN.md section 9)");
+        const int v = rng_variant_from_name(s);
+        if (v >= 0) c.rng_variant = v;
+        else if (!s.empty()) c.notes.push_back("pointset " + s + ": not one of RNG_VARIANT_NAMES");
     }
     // scene state (libapp/camera_state.h:19-40, libapp/scene_state.h:45-101)
     if (const IniObject *cam = o.child("Camera")) {

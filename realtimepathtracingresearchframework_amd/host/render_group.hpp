@@ -51,6 +51,12 @@ public:
     void refit() {
         for (auto &r : ranks_) r->refit();
     }
+    void set_rng_variant(int rng_variant, const std::vector<uint32_t> &table = {}) {
+        for (auto &r : ranks_) r->set_rng_variant(rng_variant, table);
+    }
+    void set_bvh_policy(bool force_bvh_rebuild, int rebuild_triangle_budget) {
+        for (auto &r : ranks_) r->set_bvh_policy(force_bvh_rebuild, rebuild_triangle_budget);
+    }
     // one frame on all GPUs: every rank renders its stripes (asynchronously, side by side), then the tiles are gathered to rank 0
     RenderStats render(const RenderConfiguration &config, int spp = 0) {
         std::vector<uint64_t> tickets;

@@ -72,6 +72,13 @@ public:
         check(rptr_hip_update_vertices_device(h_, geometry, device_xyz, num_vertices));
     }
     void refit() { check(rptr_hip_refit(h_)); }
+    // RenderBackendOptions (render_params.glsl.h:56-93): the point set with the table its render extension uploads, and the BVH policy
+    void set_rng_variant(int rng_variant, const std::vector<uint32_t> &table = {}) {
+        check(rptr_hip_set_rng_variant(h_, rng_variant, table.empty() ? nullptr : table.data(), table.size() * sizeof(uint32_t)));
+    }
+    void set_bvh_policy(bool force_bvh_rebuild, int rebuild_triangle_budget) {
+        check(rptr_hip_set_bvh_policy(h_, force_bvh_rebuild ? 1 : 0, rebuild_triangle_budget));
+    }
     bool configure_for(int variant_idx) {
         if (variant_idx != RPTR_VARIANT_GLTF && variant_idx != RPTR_VARIANT_SIMPLE && variant_idx != RPTR_VARIANT_GLTF_TRANSMISSION) return false;
         variant_ = variant_idx;

@@ -5,6 +5,7 @@
 //            [--animate-wave amplitude kx]
 //   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
 //            [--config file.ini]... [--keyframe [<seconds>:]file.ini]... [--camera n] [--freeze-frame] [--upscale n] [--backend hip]
+//            [--rng-variant uniform|bn|sobol|z-sobol] [--bn-table BNData.u32] [--force-bvh-rebuild] [--rebuild-triangle-budget n]
 //            [--devices n | --devices a,b,c] [--stripe-rows r]
 //
 // --config / --keyframe read the reference's .ini files (ini_config.hpp); in profiling mode every keyframe is held for its length
@@ -36,6 +37,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -69,6 +71,18 @@ static void save_aov(rptr::RenderGroup &backend, rptr::RenderHip::AOVBufferIndex
     if (!rptr::write_exr<uint16_t>(base, (unsigned)width, (unsigned)height, 4, half.data())) throw std::runtime_error("cannot write " + base + ".exr");
 }
 
+// package data (data/) sits next to librptr_hip.so: the directory of the library this program is linked against
+static std::string data_dir() {
+    if (const char *e = std::getenv("RPTR_DATA_DIR")) return e;
+    Dl_info info;
+    if (dladdr((const void *)&rptr_hip_name, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/data";
+    }
+    return "data";
+}
+
 int main(int argc, char **argv) {
     std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix, capture_prefix;
     OutputFormat format = FORMAT_EXR;
@@ -79,6 +93,8 @@ int main(int argc, char **argv) {
     float eye[3], center[3], up[3] = {0, 1, 0}, fov = 0.f;
     bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
+    int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
+    std::string bn_table_path;
     int upscale = 0, stripe_rows = 8;
     std::vector<int> devices{0};
     std::vector<std::string> config_inis;
@@ -161,6 +177,14 @@ int main(int argc, char **argv) {
             if (b != "hip" && b != "rptr_hip") { std::fprintf(stderr, "unknown backend %s (available: hip)\n", b.c_str()); return 2; }
         }
         else if (a == "--freeze-frame") freeze_frame = true;
+        else if (a == "--rng-variant") { // RenderBackendOptions::rng_variant (render_params.glsl.h:34-43,76)
+            need(1);
+            rng_variant = rptr::rng_variant_from_name(argv[++i]);
+            if (rng_variant < 0) { std::fprintf(stderr, "unknown point set %s (uniform, bn, sobol, z-sobol)\n", argv[i]); return 2; }
+        }
+        else if (a == "--bn-table") { need(1); bn_table_path = argv[++i]; }
+        else if (a == "--force-bvh-rebuild") force_bvh_rebuild = 1;
+        else if (a == "--rebuild-triangle-budget") { need(1); rebuild_triangle_budget = std::atoi(argv[++i]); }
         else if (a == "--disable-ui") {}
         else if (a[0] != '-') scene_path = a;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -184,10 +208,10 @@ int main(int argc, char **argv) {
                 c.camera = s.camera;
                 for (const std::string &ini : config_inis) rptr::load_config(ini, c);
                 std::printf("config target_spp %d batch_spp %d max_path_depth %d rr_path_depth %d glossy_only %d exposure %.6f tonemap %d output_channel %d "
-                            "output_moment %d bin_size %d variant %d force_bvh_rebuild %d rebuild_triangle_budget %d bump_scale %.6f sun_changed %d "
+                            "output_moment %d bin_size %d variant %d rng_variant %d force_bvh_rebuild %d rebuild_triangle_budget %d bump_scale %.6f sun_changed %d "
                             "cam_pos %.6f %.6f %.6f cam_dir %.6f %.6f %.6f\n",
                             c.target_spp, c.params.batch_spp, c.params.max_path_depth, c.params.rr_path_depth, c.params.glossy_only_mode, c.params.exposure,
-                            c.params.early_tone_mapping_mode, c.params.output_channel, c.params.output_moment, c.lighting.bin_size, c.variant, c.force_bvh_rebuild,
+                            c.params.early_tone_mapping_mode, c.params.output_channel, c.params.output_moment, c.lighting.bin_size, c.variant, c.rng_variant, c.force_bvh_rebuild,
                             c.rebuild_triangle_budget, c.bump_scale, c.sun_changed ? 1 : 0, c.camera.pos[0], c.camera.pos[1], c.camera.pos[2], c.camera.dir[0],
                             c.camera.dir[1], c.camera.dir[2]);
                 for (const Keyframe &k : keyframes) {
@@ -250,6 +274,20 @@ int main(int argc, char **argv) {
         backend.set_params(base.params, base.lighting);
         if (base.bump_scale > 0.f) scene.scene_params.normal_z_scale = 1.0f / base.bump_scale; // render_vulkan.cpp:2954-2959
         backend.update_config(scene.scene_params);
+        // render backend options: the point set (with the table its render extension uploads) and the BVH policy of dynamic meshes
+        if (rng_variant < 0) rng_variant = base.rng_variant;
+        if (rng_variant > 0) {
+            const std::string matrices = data_dir() + "/sobol_matrices_1024x32.u32";
+            if (rng_variant == RPTR_RNG_VARIANT_BN)
+                backend.set_rng_variant(rng_variant, bn_table_path.empty() ? rptr::white_noise_bn_table(matrices) : rptr::read_u32_file(bn_table_path));
+            else
+                backend.set_rng_variant(rng_variant, rptr::sobol_table(matrices));
+        }
+        if (force_bvh_rebuild >= 0 || rebuild_triangle_budget >= 0 || base.bvh_policy_set) { // (otherwise the library's default: refit only)
+            if (force_bvh_rebuild < 0) force_bvh_rebuild = base.force_bvh_rebuild;
+            if (rebuild_triangle_budget < 0) rebuild_triangle_budget = base.rebuild_triangle_budget;
+            backend.set_bvh_policy(force_bvh_rebuild != 0, rebuild_triangle_budget);
+        }
         scene.camera = base.camera;
         rptr::RenderConfiguration cfg{};
         std::memcpy(cfg.camera.pos, scene.camera.pos, 12);

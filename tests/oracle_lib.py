@@ -67,6 +67,8 @@ def lib():
                                       C.c_void_p]
         L.orc_resolve_u8.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
         L.orc_process_samples_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scene_set_rng_variant.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_pointset_probe.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
         L.orc_texture_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_hw_threads.restype = C.c_int
@@ -96,6 +98,23 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_rng_variant(self, rng_variant, table=None):
+        """the render backend option rng_variant + its table (uint32 words laid out as SobolData / BNData)"""
+        if table is None:
+            rc = lib().orc_scene_set_rng_variant(self.h, int(rng_variant), None, 0)
+        else:
+            t = np.ascontiguousarray(table, dtype=np.uint32)
+            rc = lib().orc_scene_set_rng_variant(self.h, int(rng_variant), _p(t), t.size)
+        assert rc == 0, "orc_scene_set_rng_variant failed"
+
+    def pointset_probe(self, sample_index, frame_offset, frame_id, px, py, dimx, set_dim, dims):
+        """(values, index): the draws RANDOM_FLOAT1(rng, dims[i]) after GET_RNG + RANDOM_SET_DIM(set_dim) of one pixel sample"""
+        d = np.ascontiguousarray(dims, dtype=np.int32)
+        out = np.zeros(d.size, dtype=np.float32)
+        idx = C.c_uint32()
+        lib().orc_pointset_probe(self.h, sample_index, frame_offset, frame_id, px, py, dimx, set_dim, _p(d), d.size, _p(out), C.byref(idx))
+        return out, int(idx.value)
 
     def build_bvh(self):
         c = (C.c_uint64 * 3)()

@@ -364,6 +364,9 @@ OUTPUT_CHANNEL_COLOR= 1
 [.][*variant]
 wavefront-gltf-transmission= 1
 ..
+[.][*pointset]
+Z_SBL= 1
+..
 
 [Application][scene.vks]
 [.][Camera]
@@ -414,6 +417,7 @@ def test_cli_reads_the_reference_ini_configuration_files(tmp_path):
     assert (int(kv["target_spp"]), int(kv["batch_spp"]), int(kv["max_path_depth"]), int(kv["rr_path_depth"])) == (8, 2, 5, 3)
     assert abs(float(kv["exposure"]) - 1.25) < 1e-6 and int(kv["tonemap"]) == 2 and int(kv["output_channel"]) == 0
     assert int(kv["bin_size"]) == 8 and int(kv["variant"]) == abi.VARIANT_GLTF_TRANSMISSION
+    assert int(kv["rng_variant"]) == abi.RNG_VARIANT_Z_SBL
     assert int(kv["force_bvh_rebuild"]) == 1 and int(kv["rebuild_triangle_budget"]) == 250000 and abs(float(kv["bump_scale"]) - 2.0) < 1e-6
     at = cfg.index("cam_pos")
     assert [float(v) for v in cfg[at + 1:at + 4]] == [1.5, 0.25, 3.0]
@@ -460,3 +464,37 @@ def test_cli_keyframes_and_two_ranks_on_one_device(tmp_path):
         assert r.returncode == 0, r.stderr
     f1, f3 = read_pfm(str(tmp_path / "f1_0001.pfm")), read_pfm(str(tmp_path / "f3_0003.pfm"))
     assert np.array_equal(f1.view(np.uint32), f3.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rng_variant", [("sobol", abi.RNG_VARIANT_SOBOL), ("z-sobol", abi.RNG_VARIANT_Z_SBL)])
+def test_cli_point_sets_match_the_python_host(tmp_path, name, rng_variant):
+    """--rng-variant: the C++ host derives the same SobolData from the package's matrices as pointsets.py (tile inversion included)
+    -> the validation image of the CLI equals the Python host's, bit for bit; the blue-noise stand-in table renders too"""
+    from realtimepathtracingresearchframework_amd import backend
+    exe = _build_cli(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    W, H = 272, 64
+    r = subprocess.run([exe, path, "--img", str(W), str(H), "--pfm", "--validation", str(tmp_path / "v"), "--validation-spp", "2", "--rng-variant", name],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = read_pfm(str(tmp_path / "v_0002.pfm"))
+    rh = backend.RenderHip()
+    rh.initialize(W, H)
+    rh.set_scene(s)
+    rh.set_rng_variant(rng_variant)
+    for k in range(2):
+        rh.render(backend.RenderConfiguration(s.camera_params(), reset_accumulation=(k == 0)), spp=1)
+    img = np.zeros((H, W, 4), np.float32)
+    rh.readback_framebuffer(img)
+    rh.close()
+    assert np.array_equal(got.view(np.uint32), img[..., :3].view(np.uint32))
+    if rng_variant == abi.RNG_VARIANT_SOBOL:
+        b = subprocess.run([exe, path, "--img", str(W), str(H), "--pfm", "--validation", str(tmp_path / "b"), "--validation-spp", "2", "--rng-variant", "bn"],
+                           capture_output=True, text=True)
+        assert b.returncode == 0, b.stderr
+        bn = read_pfm(str(tmp_path / "b_0002.pfm"))
+        assert np.isfinite(bn).all() and bn.std() > 0.01 and not np.array_equal(bn, got)
+        assert subprocess.run([exe, path, "--validation", "x", "--rng-variant", "halton"], capture_output=True).returncode == 2

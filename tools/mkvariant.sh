@@ -3,5 +3,10 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 N=$1; shift
 mkdir -p $R/gpurun_variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wno-unused-function "$@" \
-  $R/realtimepathtracingresearchframework_amd/csrc/rptr_hip.hip $R/realtimepathtracingresearchframework_amd/csrc/bvh_build.cpp -o $R/gpurun_variants/lib_$N.so
+cd $R && python3 - "$N" "$@" <<'PY'
+import sys, tempfile
+from realtimepathtracingresearchframework_amd import build
+name, flags = sys.argv[1], sys.argv[2:]
+with tempfile.TemporaryDirectory() as d:
+    print(build.build_library(force=True, extra_flags=flags + ["-w"], lib_path="gpurun_variants/lib_%s.so" % name, obj_dir=d))
+PY
