@@ -550,8 +550,8 @@ static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
 
 // The device's tree (include/rptr_bvh.h RptrBvh4Node), walked in the device's canonical order
 // (csrc/dtraverse.h header): per node the four child boxes are tested on the node's 8-bit grid with
-// t = fma(q, A, B), A = step/d, B = (origin - o)/d; hit children are ordered by
-// key = (bits(t_near) & 0x7FFFFFFC) | slot ascending; the first is visited next, the others are pushed
+// t = fma(q, A, B), A = step/d, B = (origin - o)/d; hit children are taken in the node's looked-up front-to-back
+// order for the ray's direction signs (RptrBvh4Node::order); the first is visited next, the others are pushed
 // so that the nearest pops first. Leaves, instances and the triangle test are those of traverse2.
 template <bool ANY>
 static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha) {
@@ -589,7 +589,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 A[a] = bits_float(uint32_t(n.exp[a]) << 23) * ii[a];
                 B[a] = (n.origin[a] - oo[a]) * ii[a];
             }
-            uint32_t key[4];
+            bool hit[4];
             for (int k = 0; k < 4; ++k) {
                 float tl[3], th[3];
                 for (int a = 0; a < 3; ++a) {
@@ -598,15 +598,26 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 }
                 const float tn = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fmaxf(fminf(tl[2], th[2]), ray.tmin));
                 const float tf = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fminf(fmaxf(tl[2], th[2]), best.t));
-                const bool hit = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
-                key[k] = hit ? ((float_bits(tn) & 0x7FFFFFFCu) | uint32_t(k)) : 0xFFFFFFFFu;
+                hit[k] = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
             }
-            std::sort(key, key + 4);
-            if (g_dead_visits && key[0] == 0xFFFFFFFFu) __atomic_fetch_add(g_dead_visits, 1ull, __ATOMIC_RELAXED);
-            for (int k = 3; k >= 1; --k)
-                if (key[k] != 0xFFFFFFFFu) stack[sp++] = n.child[key[k] & 3u];
-            if (key[0] != 0xFFFFFFFFu)
-                cur = n.child[key[0] & 3u];
+            // front to back by the node's order word and the signs of the direction (include/rptr_bvh.h; csrc/dtraverse.h does the same
+            // with conditional swaps): bit a of a byte = swap for rays running in -axis a, bit 3 + a = for rays running in +axis a
+            const uint32_t s3 = (float_bits(id.x) >> 31) | ((float_bits(id.y) >> 31) << 1) | ((float_bits(id.z) >> 31) << 2);
+            const uint32_t ray6 = s3 | ((s3 ^ 7u) << 3);
+            int order[4] = {0, 1, 2, 3};
+            if ((n.order >> 8) & ray6) std::swap(order[0], order[1]);
+            if ((n.order >> 16) & ray6) std::swap(order[2], order[3]);
+            if (n.order & ray6) {
+                std::swap(order[0], order[2]);
+                std::swap(order[1], order[3]);
+            }
+            int visit[4], nv = 0;
+            for (int k = 0; k < 4; ++k)
+                if (hit[order[k]]) visit[nv++] = order[k];
+            if (g_dead_visits && nv == 0) __atomic_fetch_add(g_dead_visits, 1ull, __ATOMIC_RELAXED);
+            for (int k = nv - 1; k >= 1; --k) stack[sp++] = n.child[visit[k]];
+            if (nv)
+                cur = n.child[visit[0]];
             else
                 pop = true;
         } else if (cur == SENTINEL) {

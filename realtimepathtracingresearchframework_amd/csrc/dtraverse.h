@@ -13,7 +13,8 @@
 // inner nodes (>= 0), packed leaves (<= -2, include/rptr_bvh.h) and the
 // instance-exit sentinel. Inner node: slab-test the four child boxes against
 // [t_min, best_t] on the node's 8-bit grid (t = fma(q, step/d, (origin-o)/d));
-// the hit children are ordered by key = (bits(t_near) & ~3) | slot, ascending;
+// the hit children are taken in the node's looked-up front-to-back order for the
+// ray's direction signs (RptrBvh4Node::order, include/rptr_bvh.h; no sort):
 // continue with the first, push the others so that the nearest pops first.
 // BLAS leaf: test all its triangles; TLAS leaf: transform the ray, push the
 // sentinel, continue at the instance's root.
@@ -176,6 +177,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
     V3 inv = v3s(0.f); // 1/dir of the ray in the current space
     bool neg_x = false, neg_y = false, neg_z = false;
+    uint32_t dir_bits = 0u;
     float tmin = 0.f;
     RpHitRec best;
     best.t = 0.f;
@@ -205,6 +207,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         neg_x = __float_as_int(inv.x) < 0;
         neg_y = __float_as_int(inv.y) < 0;
         neg_z = __float_as_int(inv.z) < 0;
+        // the ray's side of RptrBvh4Node::order: bit a = runs in -axis a, bit 3 + a = runs in +axis a, in each of the three bytes
+        const uint32_t s3 = (uint32_t(__float_as_int(inv.x)) >> 31) | ((uint32_t(__float_as_int(inv.y)) >> 31) << 1) | ((uint32_t(__float_as_int(inv.z)) >> 31) << 2);
+        dir_bits = (s3 | ((s3 ^ 7u) << 3)) * 0x010101u;
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
@@ -293,7 +298,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const float4 n0 = *reinterpret_cast<const float4 *>(np);      // origin.xyz, exp bytes
             const uint4 n1 = *reinterpret_cast<const uint4 *>(np + 16);   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
             const uint4 n2 = *reinterpret_cast<const uint4 *>(np + 32);   // qhi.y qhi.z child0 child1
-            const uint2 n3 = *reinterpret_cast<const uint2 *>(np + 48);   // child2 child3
+            const uint4 n3 = *reinterpret_cast<const uint4 *>(np + 48);   // child2 child3 order -
             if (COUNT) n_nodes++;
             const uint32_t ex = __float_as_uint(n0.w);
             // plane distance t = q * A + B with A = step / d, B = (origin - o) / d
@@ -308,7 +313,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const rp_f2 ax2 = rp_mk2(ax, ax), ay2 = rp_mk2(ay, ay), az2 = rp_mk2(az, az);
             const rp_f2 bx2 = rp_mk2(bx, bx), by2 = rp_mk2(by, by), bz2 = rp_mk2(bz, bz);
             const float tfar_max = best.t;
-            uint32_t key[4];
+            // a missed child becomes an empty slot: from here on "hit" is "ref != EMPTY" (an empty slot stays one whatever its box says)
             int ref[4] = {(int)n2.z, (int)n2.w, (int)n3.x, (int)n3.y};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -318,39 +323,39 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
-                const bool hit = ref[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
-                key[k] = hit ? ((__float_as_uint(tn) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+                ref[k] = tn <= tf * 1.0000005f ? ref[k] : RPTR_BVH4_EMPTY;
             }
-            // sort (key, child) ascending by key with 5 compare-exchanges; misses (~0) end up last
-#define RP_CSWAP(i, j)                               \
-    {                                                \
-        const bool sw_ = key[j] < key[i];            \
-        const uint32_t ka_ = key[i], kb_ = key[j];   \
-        const int ra_ = ref[i], rb_ = ref[j];        \
-        key[i] = sw_ ? kb_ : ka_;                    \
-        key[j] = sw_ ? ka_ : kb_;                    \
-        ref[i] = sw_ ? rb_ : ra_;                    \
-        ref[j] = sw_ ? ra_ : rb_;                    \
+            // front-to-back order without a sort (include/rptr_bvh.h RptrBvh4Node::order): the node says along which axis the slots of
+            // a pair -- and the two pairs -- are separated and which lies lower, the ray in which direction it runs
+            const uint32_t sw = n3.z & dir_bits;
+            const bool sw_a = (sw & 0x0000FF00u) != 0u, sw_b = (sw & 0x00FF0000u) != 0u, sw_t = (sw & 0x000000FFu) != 0u;
+#define RP_SWAP_IF(c, i, j)                        \
+    {                                              \
+        const int ra_ = ref[i], rb_ = ref[j];      \
+        ref[i] = (c) ? rb_ : ra_;                  \
+        ref[j] = (c) ? ra_ : rb_;                  \
     }
-            RP_CSWAP(0, 1) RP_CSWAP(2, 3) RP_CSWAP(0, 2) RP_CSWAP(1, 3) RP_CSWAP(1, 2)
-#undef RP_CSWAP
-            const bool v0 = key[0] != 0xFFFFFFFFu, v1 = key[1] != 0xFFFFFFFFu, v2 = key[2] != 0xFFFFFFFFu, v3 = key[3] != 0xFFFFFFFFu;
+            RP_SWAP_IF(sw_a, 0, 1) RP_SWAP_IF(sw_b, 2, 3) RP_SWAP_IF(sw_t, 0, 2) RP_SWAP_IF(sw_t, 1, 3)
+#undef RP_SWAP_IF
+            const bool v0 = ref[0] != RPTR_BVH4_EMPTY, v1 = ref[1] != RPTR_BVH4_EMPTY, v2 = ref[2] != RPTR_BVH4_EMPTY, v3 = ref[3] != RPTR_BVH4_EMPTY;
+            // the first hit in that order is next; the later ones go on the stack, farthest first
+            const bool p3 = v3 && (v0 || v1 || v2), p2 = v2 && (v0 || v1), p1 = v1 && v0;
             int nxt;
             if (__builtin_expect(stack_slow, 0)) { // rare: some lane is about to leave the LDS part of its stack
-                if (v3) push(ref[3]);
-                if (v2) push(ref[2]);
-                if (v1) push(ref[1]);
-                nxt = v0 ? ref[0] : pop();
-            } else { // branch-free: write, then advance only for real entries (farthest first, so the nearest pops first);
-                     // no child hit = no push, and the entry read ahead from the top of the stack is the next item
+                if (p3) push(ref[3]);
+                if (p2) push(ref[2]);
+                if (p1) push(ref[1]);
+                nxt = v0 ? ref[0] : v1 ? ref[1] : v2 ? ref[2] : v3 ? ref[3] : pop();
+            } else { // branch-free: write, then advance only for real entries; no child hit = no push, and the entry read ahead
+                     // from the top of the stack is the next item
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[3];
-                sp += v3 ? 1 : 0;
+                sp += p3 ? 1 : 0;
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[2];
-                sp += v2 ? 1 : 0;
+                sp += p2 ? 1 : 0;
                 lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[1];
-                sp += v1 ? 1 : 0;
-                nxt = v0 ? ref[0] : top;
-                sp -= v0 ? 0 : 1;
+                sp += p1 ? 1 : 0;
+                nxt = v0 ? ref[0] : v1 ? ref[1] : v2 ? ref[2] : v3 ? ref[3] : top;
+                sp -= (v0 || v1 || v2 || v3) ? 0 : 1;
             }
             cur = nxt;
             }

@@ -155,13 +155,14 @@ def test_alpha_flags_of_the_host_built_tree():
     flags = t[:, 11]
     expect = 8 + 2 + int(np.isin(s.pmeshes[2].tri_material_ids, (0, 1)).sum()) + 2        # screens, mixed, literal quad
     assert int(flags.sum()) == expect and set(np.unique(flags)) <= {0, 1}
-    # the oracle walking this tree gives the oracle's own image (closest hits and the candidates met before them agree)
+    # the oracle walking this tree gives the oracle's own image up to noise: a fractional alpha draws from the path's generator per
+    # candidate met, and the two trees meet the candidates in different orders (the 4-wide tree's looked-up child order)
     osc = O.OracleScene(s)
-    own, _ = osc.render(80, 60, 2)
+    own, _ = osc.render(80, 60, 32)
     osc.import_bvh(nodes, tris, insts)
-    imp, _ = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED)
+    imp, _ = osc.render(80, 60, 32, bvh_mode=O.BVH_IMPORTED)
     rmse = float(np.sqrt(np.mean((own[..., :3] - imp[..., :3]).astype(np.float64) ** 2)))
-    assert rmse < 0.05
+    assert rmse < 0.08 and abs(float(own[..., :3].mean()) - float(imp[..., :3].mean())) < 0.02 * float(own[..., :3].mean())
 
 
 def test_flattened_tree_on_the_host(monkeypatch):
