@@ -16,11 +16,8 @@
  *                  In the TLAS a leaf lists `count` (1) RptrBvhInstance records, in a BLAS
  *                  `count` (1..RPTR_BVH_MAX_LEAF_TRIS) RptrBvhTri;
  *     child == RPTR_BVH4_EMPTY: unused slot (its box is inverted: qlo = 255, qhi = 0).
- *   - the children are visited front to back in an order that is looked up, not sorted: slots (0,1) and (2,3) are pairs
- *     (siblings in the binary tree the node was collapsed from, where the collapse was balanced); `order` says for each pair along
- *     which axis its two boxes are separated best and which one lies lower, and the same for the two pairs as wholes. A ray visits
- *     the lower one first iff it runs in + direction along that axis. Against an exact sort by entry distance this costs < 0.2 % more
- *     node visits for closest-hit rays (tools/order_probe.py) and saves a fifth of the instructions of a node step.
+ *   - slots (0,1) and (2,3) are PAIRS for the traversal's visit order (csrc/dtraverse.h): siblings of the binary tree the node was
+ *     collapsed from wherever the collapse was balanced.
  *
  * RptrBvhNode (2-wide, float boxes of both children) is the intermediate form of the host builder
  * (csrc/bvh_build.h) and of the test oracle's own tree; the device never sees it.
@@ -56,10 +53,7 @@ typedef struct RptrBvh4Node { /* 64 bytes, four 16-byte loads */
     uint8_t qlo[3][4]; /* [axis][child]: lower planes, rounded down                              */
     uint8_t qhi[3][4]; /* [axis][child]: upper planes, rounded up                                */
     int32_t child[4];
-    uint32_t order;    /* visit order of the children without a sort: bytes 0 / 1 / 2 = when to swap the pairs (0,1)|(2,3) as a whole /
-                          slot 0 with 1 / slot 2 with 3; in each byte bit a (0..2) = "swap if the ray runs in -axis a", bit 3 + a = "swap
-                          if it runs in +axis a" (at most one bit set). Derived from the child boxes by rp_bvh4_encode (csrc/bvh4.h). */
-    uint32_t _pad1;
+    uint32_t _pad1[2];
 } RptrBvh4Node;
 
 /* Moeller-Trumbore ready triangle, object space of its mesh: 48 bytes */

@@ -449,6 +449,7 @@ static inline void decode_leaf(int enc, int &first, int &count) {
     count = RPTR_BVH_LEAF_COUNT(enc);
 }
 static bool g_no_single_instance = getenv("RPTR_NO_SINGLE_INSTANCE") != nullptr; // same switch as the device library
+static const bool g_sort_by_distance = getenv("ORC_SORT_BY_DISTANCE") != nullptr; // diagnostic (tools/order_probe.py): a full sort by entry distance instead of the three comparisons
 static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
 // The reference's any-hit stage (vulkan/pt_megakernel.glsl:153-212, generate_candidate_hit): called for every hit of a
 // triangle flagged RPTR_BVH_TRI_ALPHA that the query would otherwise accept, in the canonical order of this traversal;
@@ -550,9 +551,9 @@ static bool traverse2(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
 
 // The device's tree (include/rptr_bvh.h RptrBvh4Node), walked in the device's canonical order
 // (csrc/dtraverse.h header): per node the four child boxes are tested on the node's 8-bit grid with
-// t = fma(q, A, B), A = step/d, B = (origin - o)/d; hit children are taken in the node's looked-up front-to-back
-// order for the ray's direction signs (RptrBvh4Node::order); the first is visited next, the others are pushed
-// so that the nearest pops first. Leaves, instances and the triangle test are those of traverse2.
+// t = fma(q, A, B), A = step/d, B = (origin - o)/d; hit children are ordered by three comparisons of their entry
+// distances (inside slot pairs (0,1) and (2,3), then pair against pair); the first is visited next, the others are
+// pushed so that the first of the rest pops next. Leaves, instances and the triangle test are those of traverse2.
 template <bool ANY>
 static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *cnt, AlphaTest *alpha) {
     best.t = ray.tmax;
@@ -590,6 +591,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 B[a] = (n.origin[a] - oo[a]) * ii[a];
             }
             bool hit[4];
+            float entry[4];
             for (int k = 0; k < 4; ++k) {
                 float tl[3], th[3];
                 for (int a = 0; a < 3; ++a) {
@@ -598,19 +600,23 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 }
                 const float tn = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fmaxf(fminf(tl[2], th[2]), ray.tmin));
                 const float tf = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fminf(fmaxf(tl[2], th[2]), best.t));
+                // (the device picks entry / exit planes by the sign of the direction instead of min / max: the inverted box of an empty
+                // slot never passes there, so it needs no test of its own; plane distances are finite, see DESIGN.md "Ray query semantics")
                 hit[k] = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
+                entry[k] = hit[k] ? tn : INFINITY;
             }
-            // front to back by the node's order word and the signs of the direction (include/rptr_bvh.h; csrc/dtraverse.h does the same
-            // with conditional swaps): bit a of a byte = swap for rays running in -axis a, bit 3 + a = for rays running in +axis a
-            const uint32_t s3 = (float_bits(id.x) >> 31) | ((float_bits(id.y) >> 31) << 1) | ((float_bits(id.z) >> 31) << 2);
-            const uint32_t ray6 = s3 | ((s3 ^ 7u) << 3);
+            // front to back with three comparisons of the entry distances (a miss counts as +inf, ties keep slot order): inside the pair of
+            // slots (0,1), inside the pair (2,3), and the pairs against each other by their nearer member (csrc/dtraverse.h does the same
+            // with conditional swaps)
+            const float *e = entry;
             int order[4] = {0, 1, 2, 3};
-            if ((n.order >> 8) & ray6) std::swap(order[0], order[1]);
-            if ((n.order >> 16) & ray6) std::swap(order[2], order[3]);
-            if (n.order & ray6) {
+            if (e[1] < e[0]) std::swap(order[0], order[1]);
+            if (e[3] < e[2]) std::swap(order[2], order[3]);
+            if (fminf(e[2], e[3]) < fminf(e[0], e[1])) {
                 std::swap(order[0], order[2]);
                 std::swap(order[1], order[3]);
             }
+            if (g_sort_by_distance) std::stable_sort(order, order + 4, [&](int a, int b) { return e[a] < e[b]; });
             int visit[4], nv = 0;
             for (int k = 0; k < 4; ++k)
                 if (hit[order[k]]) visit[nv++] = order[k];

@@ -39,25 +39,7 @@ struct RpBox4 { // float boxes of the (up to) four children of a node
     float lo[4][3], hi[4][3];
 };
 
-// One byte of RptrBvh4Node::order for two boxes (a "lower", b "upper" slot of a pair, or two pairs): the axis along which their centres
-// are farthest apart (ties: the lowest axis) and the direction in which a ray meets b first. 0 when either is missing.
-RP_HD uint32_t rp_bvh4_order_byte(const float alo[3], const float ahi[3], const float blo[3], const float bhi[3], bool a_valid, bool b_valid) {
-    if (!a_valid || !b_valid) return 0u;
-    int axis = 0;
-    float best = -1.0f, diff_at = 0.0f;
-    for (int a = 0; a < 3; ++a) {
-        const float diff = (blo[a] + bhi[a]) - (alo[a] + ahi[a]); // twice the distance of the centres
-        if (fabsf(diff) > best) {
-            best = fabsf(diff);
-            axis = a;
-            diff_at = diff;
-        }
-    }
-    // a is the lower one (or they coincide): b comes first for rays running in -axis; otherwise for rays running in +axis
-    return diff_at >= 0.0f ? (1u << axis) : (8u << axis);
-}
-
-// Writes origin / exp / qlo / qhi / child / order of `out`; slots with child == RPTR_BVH4_EMPTY get the inverted box.
+// Writes origin / exp / qlo / qhi / child of `out`; slots with child == RPTR_BVH4_EMPTY get the inverted box.
 // node_lo/node_hi (optional) receive the exact float bounds of the node = union of its children.
 RP_HD void rp_bvh4_encode(const RpBox4 &b, const int32_t child[4], RptrBvh4Node *out, float node_lo[3], float node_hi[3]) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -97,23 +79,5 @@ RP_HD void rp_bvh4_encode(const RpBox4 &b, const int32_t child[4], RptrBvh4Node 
         }
     }
     for (int k = 0; k < 4; ++k) n.child[k] = child[k];
-    {
-        bool valid[4];
-        for (int k = 0; k < 4; ++k) valid[k] = child[k] != RPTR_BVH4_EMPTY;
-        float plo[2][3], phi[2][3]; // the two pairs as wholes
-        for (int p = 0; p < 2; ++p)
-            for (int a = 0; a < 3; ++a) {
-                plo[p][a] = INFINITY;
-                phi[p][a] = -INFINITY;
-                for (int k = 2 * p; k < 2 * p + 2; ++k)
-                    if (valid[k]) {
-                        plo[p][a] = fminf(plo[p][a], b.lo[k][a]);
-                        phi[p][a] = fmaxf(phi[p][a], b.hi[k][a]);
-                    }
-            }
-        n.order = rp_bvh4_order_byte(plo[0], phi[0], plo[1], phi[1], valid[0] || valid[1], valid[2] || valid[3]) |
-                  (rp_bvh4_order_byte(b.lo[0], b.hi[0], b.lo[1], b.hi[1], valid[0], valid[1]) << 8) |
-                  (rp_bvh4_order_byte(b.lo[2], b.hi[2], b.lo[3], b.hi[3], valid[2], valid[3]) << 16);
-    }
     *out = n;
 }

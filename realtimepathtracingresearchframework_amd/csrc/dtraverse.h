@@ -13,9 +13,10 @@
 // inner nodes (>= 0), packed leaves (<= -2, include/rptr_bvh.h) and the
 // instance-exit sentinel. Inner node: slab-test the four child boxes against
 // [t_min, best_t] on the node's 8-bit grid (t = fma(q, step/d, (origin-o)/d));
-// the hit children are taken in the node's looked-up front-to-back order for the
-// ray's direction signs (RptrBvh4Node::order, include/rptr_bvh.h; no sort):
-// continue with the first, push the others so that the nearest pops first.
+// the hit children are ordered with three comparisons of their entry distances
+// (a miss counts as +inf; ties keep slot order): inside the pair of slots (0,1),
+// inside the pair (2,3), and the pairs against each other by their nearer member.
+// Continue with the first, push the others so that the first of the rest pops next.
 // BLAS leaf: test all its triangles; TLAS leaf: transform the ray, push the
 // sentinel, continue at the instance's root.
 //
@@ -177,7 +178,6 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
     V3 inv = v3s(0.f); // 1/dir of the ray in the current space
     bool neg_x = false, neg_y = false, neg_z = false;
-    uint32_t dir_bits = 0u;
     float tmin = 0.f;
     RpHitRec best;
     best.t = 0.f;
@@ -207,9 +207,6 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         neg_x = __float_as_int(inv.x) < 0;
         neg_y = __float_as_int(inv.y) < 0;
         neg_z = __float_as_int(inv.z) < 0;
-        // the ray's side of RptrBvh4Node::order: bit a = runs in -axis a, bit 3 + a = runs in +axis a, in each of the three bytes
-        const uint32_t s3 = (uint32_t(__float_as_int(inv.x)) >> 31) | ((uint32_t(__float_as_int(inv.y)) >> 31) << 1) | ((uint32_t(__float_as_int(inv.z)) >> 31) << 2);
-        dir_bits = (s3 | ((s3 ^ 7u) << 3)) * 0x010101u;
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
@@ -298,7 +295,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const float4 n0 = *reinterpret_cast<const float4 *>(np);      // origin.xyz, exp bytes
             const uint4 n1 = *reinterpret_cast<const uint4 *>(np + 16);   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
             const uint4 n2 = *reinterpret_cast<const uint4 *>(np + 32);   // qhi.y qhi.z child0 child1
-            const uint4 n3 = *reinterpret_cast<const uint4 *>(np + 48);   // child2 child3 order -
+            const uint2 n3 = *reinterpret_cast<const uint2 *>(np + 48);   // child2 child3
             if (COUNT) n_nodes++;
             const uint32_t ex = __float_as_uint(n0.w);
             // plane distance t = q * A + B with A = step / d, B = (origin - o) / d
@@ -313,8 +310,10 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const rp_f2 ax2 = rp_mk2(ax, ax), ay2 = rp_mk2(ay, ay), az2 = rp_mk2(az, az);
             const rp_f2 bx2 = rp_mk2(bx, bx), by2 = rp_mk2(by, by), bz2 = rp_mk2(bz, bz);
             const float tfar_max = best.t;
-            // a missed child becomes an empty slot: from here on "hit" is "ref != EMPTY" (an empty slot stays one whatever its box says)
+            // a missed child becomes an empty slot with entry distance +inf: from here on "hit" is "ref != EMPTY" (an empty slot stays
+            // one whatever its box says)
             int ref[4] = {(int)n2.z, (int)n2.w, (int)n3.x, (int)n3.y};
+            float ent[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // (near, far) pairs: one packed fma per axis
@@ -323,12 +322,14 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
                 const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
-                ref[k] = tn <= tf * 1.0000005f ? ref[k] : RPTR_BVH4_EMPTY;
+                const bool hit = tn <= tf * 1.0000005f;
+                ref[k] = hit ? ref[k] : RPTR_BVH4_EMPTY;
+                ent[k] = hit ? tn : INFINITY;
             }
-            // front-to-back order without a sort (include/rptr_bvh.h RptrBvh4Node::order): the node says along which axis the slots of
-            // a pair -- and the two pairs -- are separated and which lies lower, the ray in which direction it runs
-            const uint32_t sw = n3.z & dir_bits;
-            const bool sw_a = (sw & 0x0000FF00u) != 0u, sw_b = (sw & 0x00FF0000u) != 0u, sw_t = (sw & 0x000000FFu) != 0u;
+            // front-to-back order with three comparisons instead of a sorting network over (key, payload) pairs: nearer first inside
+            // each pair of slots, then the pair that holds the nearest child first. Against the full sort: +0.5 % node visits on the
+            // 10 M-triangle forest, none on the height field (tools/order_probe.py); 18 VALU instructions fewer per node.
+            const bool sw_a = ent[1] < ent[0], sw_b = ent[3] < ent[2], sw_t = fminf(ent[2], ent[3]) < fminf(ent[0], ent[1]);
 #define RP_SWAP_IF(c, i, j)                        \
     {                                              \
         const int ra_ = ref[i], rb_ = ref[j];      \

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void rp_k_lbvh_emit(int n, const int *left, co
         RptrBvh4Node nd;
         __builtin_memset(&nd, 0, sizeof(nd));
         for (int k = 0; k < 4; ++k) nd.child[k] = child[k];
-        nd.order = min(depth, (uint32_t)(RP_REFIT_LEVELS - 1)); // parked in the node's padding until rp_k_lbvh_level_scatter has read it
+        nd._pad1[0] = min(depth, (uint32_t)(RP_REFIT_LEVELS - 1)); // parked in the node's padding until rp_k_lbvh_level_scatter has read it
         nodes[me] = nd;
         atomicAdd(&s_hist[RP_REFIT_LEVELS - 1 - min(depth, (uint32_t)(RP_REFIT_LEVELS - 1))], 1u);
     }
@@ -235,7 +235,7 @@ __global__ void rp_k_lbvh_level_scan(const uint32_t *level_hist, uint32_t list_b
 __global__ __launch_bounds__(256) void rp_k_lbvh_level_scatter(const RptrBvh4Node *nodes, int node_base, const int *count_ptr, uint32_t *cursor, uint32_t *list) {
     const int count = *count_ptr;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
-        const uint32_t depth = nodes[node_base + k].order;
+        const uint32_t depth = nodes[node_base + k]._pad1[0];
         list[atomicAdd(&cursor[RP_REFIT_LEVELS - 1 - depth], 1u)] = (uint32_t)(node_base + k);
     }
 }
