@@ -137,16 +137,12 @@ def traffic_of(pmc, prefix, field="hbm_bytes_per_launch"):
 
 
 def valu_frame(pmc, ms_per_step, valu_peak, launches):
-    """all kernels of one frame (PMC instruction counts x launches per frame) against the VALU issue peak over the PIPELINED frame time:
-    how much of the machine's instruction issue the steady state uses"""
-    per_frame = {"rp_k_extend<false, true": 1, "rp_k_extend<false, false": max(launches - 1, 0), "rp_k_connect<false": launches,
-                 "rp_k_shade<1, true": 1, "rp_k_shade<1, false": max(launches - 1, 0), "rp_k_tail": 1, "rp_k_resolve": 1}
-    total = 0.0
-    for prefix, n in per_frame.items():
-        v = traffic_of(pmc, prefix, "valu_insts_per_launch")
-        if v is None:
-            return None
-        total += v * n
+    """all kernels of one frame (PMC instruction counts of the profile pass: every launch of every kernel / frames) against the VALU
+    issue peak over the PIPELINED frame time: how much of the machine's instruction issue the steady state uses. (The bounce at which
+    the tail kernel takes over may differ between the two runs; the work of a frame does not.)"""
+    total = pmc.get("valu_insts_per_frame")
+    if total is None:
+        return None
     return {"valu_insts_per_step": int(total), "pipelined_ginst_s": round(total / (ms_per_step * 1e-3) / 1e9, 1),
             "pipelined_frac": round(total / (ms_per_step * 1e-3) / 1e9 / valu_peak, 4)}
 
@@ -461,7 +457,7 @@ def main():
         return e
 
     single = len(scene.instances) == 1
-    sfx = ", false, %s>" % ("true" if single else "false")
+    sfx = ", false, %s" % ("true" if single else "false")   # (COUNT, FIRST,) ALPHA, SINGLE [, TABLE]
     var_id = "1" if variant == abi.VARIANT_SIMPLE else "0"
     k_ext = kernel_entry("rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE=%s>: first bounce FIRST=true, later bounces FIRST=false" % str(single).lower(),
                          ["rp_k_extend<false, true" + sfx, "rp_k_extend<false, false" + sfx][:n_launch], ext_bytes, serial["ext"], launches_extend)

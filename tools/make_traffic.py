@@ -45,7 +45,14 @@ def main():
         if k in gui:
             e["gui_active_cycles_per_launch"] = gui[k][1] / max(gui[k][0], 1)
         doc["kernels"][k] = e
+    # one frame = one rp_k_resolve launch: all VALU instructions of the pass / frames (where the tail kernel takes over does not change
+    # the work of a frame, so this holds for the pipelined run too, whatever bounce its tail starts at)
+    frames = max((v["launches"] for k, v in doc["kernels"].items() if "rp_k_resolve" in k), default=0)
+    if frames:
+        doc["frames"] = frames
+        doc["valu_insts_per_frame"] = sum(v.get("valu_insts_per_launch", 0.0) * v["launches"] for v in doc["kernels"].values()) / frames
     json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print("frames %d, VALU instructions per frame %.1f M" % (doc.get("frames", 0), doc.get("valu_insts_per_frame", 0) / 1e6))
     for k, v in doc["kernels"].items():
         print("%-48s %8.1f MB HBM  %8.1f M VALU insts per launch" % (k[:48], v["hbm_bytes_per_launch"] / 1e6, v.get("valu_insts_per_launch", 0) / 1e6))
 
