@@ -1,6 +1,7 @@
 // rptr_cli.cpp -- the reference's headless run modes through the C ABI (binary: bin/rptr_hip):
 //
-//   rptr_hip <scene.rpsc> --validation <prefix> [--validation-spp n] [--img w h] [--pfm]
+//   <scene> = the reference's .vks file (textures in <name>_textures/) or the flat dump scenes.py writes (.rpsc)
+//   rptr_hip <scene> --validation <prefix> [--validation-spp n] [--img w h] [--pfm]
 //   rptr_hip <scene.rpsc> --profiling <csv prefix> [--profiling-fps f] [--profiling-img <prefix>] [--profiling-frames n]
 //            [--animate-wave amplitude kx]
 //   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
@@ -31,6 +32,7 @@
 #include "ini_config.hpp"
 #include "render_group.hpp"
 #include "scene_dump.hpp"
+#include "vks_reader.hpp"
 #include "write_image.hpp"
 
 #include <algorithm>
@@ -83,6 +85,13 @@ static std::string data_dir() {
     return "data";
 }
 
+// a scene file: the reference's own .vks (with its _textures directory), or the flat dump of scenes.py
+static rptr::SceneDump load_scene(const std::string &path) {
+    const size_t n = path.size();
+    if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir());
+    return rptr::SceneDump::load(path);
+}
+
 int main(int argc, char **argv) {
     std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix, capture_prefix;
     OutputFormat format = FORMAT_EXR;
@@ -94,7 +103,7 @@ int main(int argc, char **argv) {
     bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
     int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
-    std::string bn_table_path;
+    std::string bn_table_path, dump_scene_path;
     int upscale = 0, stripe_rows = 8;
     std::vector<int> devices{0};
     std::vector<std::string> config_inis;
@@ -165,6 +174,7 @@ int main(int argc, char **argv) {
         }
         else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; got_variant = true; }
         else if (a == "--every-frame") every_frame = true;
+        else if (a == "--dump-scene") { need(1); dump_scene_path = argv[++i]; describe = true; } // --describe + the scene as read, in the flat layout
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
         else if (a == "--pfm") format = FORMAT_PFM;
         else if (a == "--exr") format = FORMAT_EXR;
@@ -191,7 +201,8 @@ int main(int argc, char **argv) {
     }
     if (describe && !scene_path.empty()) {
         try {
-            const rptr::SceneDump s = rptr::SceneDump::load(scene_path);
+            const rptr::SceneDump s = load_scene(scene_path);
+            if (!dump_scene_path.empty()) s.save(dump_scene_path);
             unsigned long long tris = 0, qsum = 0;
             for (size_t i = 0; i < s.geometries.size(); ++i) {
                 tris += s.geometries[i].num_tris;
@@ -240,7 +251,7 @@ int main(int argc, char **argv) {
         return 2;
     }
     try {
-        rptr::SceneDump scene = rptr::SceneDump::load(scene_path);
+        rptr::SceneDump scene = load_scene(scene_path);
         // ---- configuration: the scene file's state, then every --config in order, then the command line (main.cpp:121-149, app.cpp:204-213)
         rptr::HostConfig base;
         base.params = scene.render_params;

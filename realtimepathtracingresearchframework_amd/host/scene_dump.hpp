@@ -56,6 +56,60 @@ struct SceneDump {
         return d;
     }
 
+    // the same layout back to a file (rptr_cli --dump-scene: what a scene read from a .vks file looks like to the backend)
+    void save(const std::string &path) const {
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + path);
+        auto wr = [&](const void *src, size_t n) {
+            if (n && std::fwrite(src, 1, n, f) != n) {
+                std::fclose(f);
+                throw std::runtime_error("short write " + path);
+            }
+        };
+        wr("RPSC1\0\0\0", 8);
+        const uint32_t n[6] = {(uint32_t)geometries.size(), (uint32_t)meshes.size(), (uint32_t)pmeshes.size(), (uint32_t)instances.size(),
+                               (uint32_t)materials.size(), (uint32_t)lights.size()};
+        wr(n, sizeof(n));
+        for (const RptrGeometryDesc &g : geometries) {
+            const uint32_t h[3] = {g.num_tris, g.has_normals, g.has_uvs}, has_attr = g.qnrm_uv ? 1u : 0u;
+            wr(h, sizeof(h));
+            wr(g.quantized_scaling, 12);
+            wr(g.quantized_offset, 12);
+            wr(&has_attr, 4);
+            wr(g.qpos, (size_t)3 * g.num_tris * 8);
+            if (g.qnrm_uv) wr(g.qnrm_uv, (size_t)3 * g.num_tris * 8);
+        }
+        for (const RptrMeshDesc &m : meshes) {
+            const uint32_t h[3] = {m.first_geometry, m.num_geometries, m.dynamic};
+            wr(h, sizeof(h));
+        }
+        for (size_t i = 0; i < pmeshes.size(); ++i) {
+            const uint32_t h[2] = {pmeshes[i].mesh, (uint32_t)offsets[i].size()}, nid = pmeshes[i].tri_material_ids ? (uint32_t)tri_ids[i].size() : 0u;
+            wr(h, sizeof(h));
+            wr(offsets[i].data(), offsets[i].size() * 4);
+            wr(&nid, 4);
+            wr(tri_ids[i].data(), nid);
+        }
+        for (const RptrInstanceDesc &in : instances) {
+            wr(in.transform, 48);
+            wr(&in.parameterized_mesh, 4);
+        }
+        wr(materials.data(), materials.size() * sizeof(RptrBaseMaterial));
+        wr(lights.data(), lights.size() * sizeof(RptrTriLightData));
+        wr(&camera, sizeof(camera));
+        wr(&scene_params, sizeof(scene_params));
+        wr(&render_params, sizeof(render_params));
+        wr(&lighting, sizeof(lighting));
+        const uint32_t ntex = (uint32_t)textures.size();
+        wr(&ntex, 4);
+        for (size_t i = 0; i < textures.size(); ++i) {
+            const uint32_t h3[3] = {textures[i].width, textures[i].height, textures[i].srgb};
+            wr(h3, sizeof(h3));
+            wr(texels[i].data(), texels[i].size());
+        }
+        std::fclose(f);
+    }
+
     static SceneDump load(const std::string &path) {
         FILE *f = std::fopen(path.c_str(), "rb");
         if (!f) throw std::runtime_error("cannot open " + path);
