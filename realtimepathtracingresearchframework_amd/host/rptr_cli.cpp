@@ -86,9 +86,10 @@ static std::string data_dir() {
 }
 
 // a scene file: the reference's own .vks (with its _textures directory), or the flat dump of scenes.py
+static int g_remove_first_lods = 0; // --remove-first-lods (SceneLoaderParams::PerFile::remove_first_LODs)
 static rptr::SceneDump load_scene(const std::string &path) {
     const size_t n = path.size();
-    if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir());
+    if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir(), false, false, 0, g_remove_first_lods);
     return rptr::SceneDump::load(path);
 }
 
@@ -174,6 +175,7 @@ int main(int argc, char **argv) {
         }
         else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; got_variant = true; }
         else if (a == "--every-frame") every_frame = true;
+        else if (a == "--remove-first-lods") { need(1); g_remove_first_lods = std::max(0, std::atoi(argv[++i])); }
         else if (a == "--dump-scene") { need(1); dump_scene_path = argv[++i]; describe = true; } // --describe + the scene as read, in the flat layout
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
         else if (a == "--pfm") format = FORMAT_PFM;

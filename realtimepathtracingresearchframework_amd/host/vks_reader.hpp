@@ -4,8 +4,9 @@
 // transforms). The C++ twin of vks.py (reader half); tests compare the two on the same files, and vks.py itself is pinned against
 // libvkr compiled from the reference checkout (tests/test_vks.py).
 //
-// Not read (as in vks.py): versions 1-2 (legacy single-mesh files), 16-bit per-triangle material ids, index buffers, levels of
-// detail beyond the base level, animated transforms other than frame 0.
+// As in vks.py: versions 1-2 (legacy single-mesh files) are not read; 16-bit per-triangle material ids keep their low byte (what the
+// reference's backend uploads); index buffers are skipped (the vertex streams of a .vks file are unrolled); a level of detail other than the
+// base level is chosen at load time (remove_first_lods); animated transforms: one frame.
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -492,7 +493,7 @@ inline float textured_param(uint32_t texture_id, uint32_t channel) { // renderin
 // per-triangle material ids when a single segment spans several materials), base-LoD instances, per material the three standard
 // textures (1 x 1 defaults when a file is missing) wired in as texture handles; then emitters, default camera, default sky.
 inline SceneDump read_scene(const std::string &path, const std::string &data_dir, bool ignore_textures = false, bool load_specularity = false,
-                            uint64_t frame = 0) {
+                            uint64_t frame = 0, int remove_first_lods = 0) {
     const Header v = read_header(path);
     SceneDump s;
     size_t n_geom = 0;
@@ -535,8 +536,10 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
         pm.mesh = (uint32_t)i;
         pm.tri_material_ids = nullptr;
         if (vm.numSegments == 1 && vm.numMaterialsInRange > 1) { // scene.cpp:654-658
-            if (vm.materialIdSize != 1) throw Error("16-bit material ids are not supported (mesh " + std::to_string(i) + ")");
-            s.tri_ids[i].assign(v.raw.begin() + (long)vm.materialIdBufferOffset, v.raw.begin() + (long)(vm.materialIdBufferOffset + vm.numTriangles));
+            if (vm.materialIdBufferOffset + (uint64_t)vm.materialIdSize * vm.numTriangles > v.raw.size()) throw Error("material ids beyond the end of " + path);
+            s.tri_ids[i].resize((size_t)vm.numTriangles);
+            for (uint64_t t = 0; t < vm.numTriangles; ++t) // 16-bit ids: the backend keeps 8 bits per triangle (static_cast<uint8_t>, render_vulkan.cpp:1114-1126)
+                s.tri_ids[i][(size_t)t] = v.raw[(size_t)(vm.materialIdBufferOffset + (uint64_t)vm.materialIdSize * t)];
             s.offsets[i].assign(1, vm.materialIdBufferBase);
             pm.tri_material_ids = s.tri_ids[i].data();
         }
@@ -551,6 +554,8 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
         RptrInstanceDesc in;
         instance_transform(v.transforms.data() + at, in.transform);
         in.parameterized_mesh = (uint32_t)vi.meshId;
+        if (remove_first_lods > 0 && lod.meshIds.size() > 1) // SceneLoaderParams::PerFile::remove_first_LODs (scene.cpp:801-815, :229-246)
+            in.parameterized_mesh = (uint32_t)lod.meshIds[std::min((size_t)remove_first_lods, lod.meshIds.size() - 1)];
         s.instances.push_back(in);
     }
     const std::string tex_dir = texture_dir(path);

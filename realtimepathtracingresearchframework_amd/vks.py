@@ -508,7 +508,7 @@ def _load_material_files(tex_dir, name):
     return m
 
 
-def read_vks(path, ignore_textures=False, load_specularity=False, frame=0) -> Scene:
+def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remove_first_lods=0) -> Scene:
     """`Scene::load_vkrs` (librender/scene.cpp:544-977) for one file, without its override parameters: one mesh and one
     parameterized mesh per .vks mesh (a geometry per segment, per-triangle material ids when a single segment spans
     several materials), base-LoD instances with `vks_flip * dequantised transform`, and per material the three standard
@@ -533,9 +533,10 @@ def read_vks(path, ignore_textures=False, load_specularity=False, frame=0) -> Sc
             base += n
         s.meshes.append(Mesh(first_geometry=first, num_geometries=len(s.geometries) - first))
         if vm["numSegments"] == 1 and vm["numMaterialsInRange"] > 1:        # scene.cpp:654-658
-            if vm["materialIdSize"] != 1:
-                raise VksError("16-bit material ids are not supported (mesh %d)" % i)
-            ids = np.frombuffer(raw, dtype=np.uint8, count=vm["numTriangles"], offset=vm["materialIdBufferOffset"]).copy()
+            if vm["materialIdSize"] == 2:    # the backend keeps 8 bits per triangle: static_cast<uint8_t>(id), render_vulkan.cpp:1114-1126
+                ids = (np.frombuffer(raw, dtype=np.uint16, count=vm["numTriangles"], offset=vm["materialIdBufferOffset"]) & 0xFF).astype(np.uint8)
+            else:
+                ids = np.frombuffer(raw, dtype=np.uint8, count=vm["numTriangles"], offset=vm["materialIdBufferOffset"]).copy()
             s.pmeshes.append(ParameterizedMesh(mesh=i, material_offsets=np.array([vm["materialIdBufferBase"]], np.int32), tri_material_ids=ids))
         else:
             s.pmeshes.append(ParameterizedMesh(mesh=i, material_offsets=np.array(kept_offsets, np.int32)))
@@ -543,8 +544,13 @@ def read_vks(path, ignore_textures=False, load_specularity=False, frame=0) -> Sc
         lod = v["lodGroups"][v["meshes"][vi["meshId"]]["lodGroup"]]
         if lod["numLevelsOfDetail"] != 0 and lod["meshIds"][0] != vi["meshId"]:
             continue
+        pmesh = vi["meshId"]
+        if remove_first_lods > 0 and lod["numLevelsOfDetail"] > 1:
+            # SceneLoaderParams::PerFile::remove_first_LODs (scene.cpp:801-815): the first n levels are replaced by level n (or the
+            # coarsest), and unlink_pruned_lod_meshes (:229-246) re-aligns the instances of the group with its new first level
+            pmesh = int(lod["meshIds"][min(remove_first_lods, lod["numLevelsOfDetail"] - 1)])
         at = transform_offset(vi["transformIndex"], v["numStaticTransforms"], v["numAnimatedTransforms"], frame) * QUANTIZED_TRANSFORM_SIZE
-        s.instances.append(Instance(transform=instance_transform(v["transforms"][at:at + QUANTIZED_TRANSFORM_SIZE]), pmesh=vi["meshId"]))
+        s.instances.append(Instance(transform=instance_transform(v["transforms"][at:at + QUANTIZED_TRANSFORM_SIZE]), pmesh=pmesh))
     tex_dir = texture_dir(path)
     for i, name in enumerate(v["materialNames"]):   # scene.cpp:818-975
         vm = _load_material_files(tex_dir, name)
@@ -638,7 +644,7 @@ def _normal_uv_stream(g):
     return qn.astype(np.uint64) | (qu.astype(np.uint64) << np.uint64(32))
 
 
-def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=None):
+def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=None, wide_material_ids=None, index_buffers=False):
     """Writes `scene` as <path> (.vks, file version 3 or 4) plus <base>_textures/ with what `read_vks` / the reference's
     `load_vkrs` pick up again. Constraints of the format, checked here: every parameterized mesh becomes a .vks mesh (a mesh
     shared by several parameterized meshes is written once per use), its geometries share one quantisation grid, instance
@@ -650,7 +656,11 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
     the reader substitutes the reference's flat default texel (127, 127). Emission and transmission go into the .txt files.
     lod_groups (file version 4): [[(parameterized mesh, detail reduction), ...], ...] -- every list becomes a LoD group (vkr.h:261-270)
     whose first entry is the base level; the reader instances base levels only (scene.cpp:722-736).
+    wide_material_ids: {parameterized mesh: uint16 ids} -- that mesh is written with 16-bit per-triangle material ids and a material
+    range above 256 (vkr.c:1127-1130: two bytes per id when numMaterialsInRange > 0x100); index_buffers: every mesh also carries the
+    (redundant, identity) index buffer of VKR_MESH_FLAGS_INDICES files -- the vertex streams of a .vks file are unrolled either way.
     Returns the material names."""
+    wide_material_ids = wide_material_ids or {}
     names = material_names or ["mat%03d" % i for i in range(len(scene.materials))]
     lod_groups = lod_groups or []
     if lod_groups and version < 4:
@@ -684,7 +694,14 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
             seg_offsets = [int(x) for x in pm.material_offsets]
             if len(geoms) == 1:          # a single segment with one material: numMaterialsInRange = 1 keeps the per-segment path
                 base, in_range, seg_offsets = 0, 1, [int(pm.material_offsets[0])]
-        if in_range > 0x100 and len(geoms) == 1:
+        if p in wide_material_ids:
+            if len(geoms) != 1:
+                raise VksError("parameterized mesh %d: per-triangle materials need a single segment" % p)
+            ids = np.asarray(wide_material_ids[p], np.uint16)
+            if len(ids) != n:
+                raise VksError("parameterized mesh %d: one material id per triangle" % p)
+            base, in_range, seg_offsets = int(pm.material_offsets[0]), max(0x101, int(ids.max()) + 1), [0]
+        elif in_range > 0x100 and len(geoms) == 1:
             raise VksError("more than 256 materials in one segment")
         name = "mesh%04d" % p
         head = struct.pack("<3f3f", *[float(x) for x in g0.scaling], *[float(x) for x in g0.offset])
@@ -692,7 +709,10 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
         tail += struct.pack("<q4Q", mesh_lod.get(p, 0), 0, 0, 0, 0) if version >= 4 else struct.pack("<5Q", 0, 0, 0, 0, 0)
         tail += b"".join(struct.pack("<Q", g.num_tris) for g in geoms) + b"".join(struct.pack("<i", o) for o in seg_offsets) + _string(name)
         mesh_headers.append((head, tail))
-        mesh_blobs.append(qpos.tobytes() + qnu.tobytes() + ids.tobytes())
+        blob = qpos.tobytes() + qnu.tobytes() + ids.tobytes()
+        if index_buffers:
+            blob += np.arange(3 * n, dtype=np.uint32).tobytes()
+        mesh_blobs.append(blob)
     transforms = [storable_transform(inst.transform) for inst in scene.instances]
     # ---- sizes first: every header carries absolute offsets
     scene_header = 8 + 24 + 5 * 8 + (struct.calcsize("<QqQqffQQQq") if version >= 4 else 0)
@@ -726,7 +746,7 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
         if version >= 4:
             f.write(struct.pack("<QqQqffQQQq", 1 + len(lod_groups), lod_offset, 0, 0, 0.0, 0.0, 1, len(transforms), 0, animation_offset))
         for (head, tail), end, off in zip(mesh_headers, mesh_header_end, mesh_data_offset):
-            f.write(head + struct.pack("<3Q", 0, end, off) + tail)
+            f.write(head + struct.pack("<3Q", MESH_FLAGS_INDICES if index_buffers else 0, end, off) + tail)
         for k, (inst, (name, data_off, end)) in enumerate(zip(scene.instances, group_meta)):
             f.write(struct.pack("<Ii3Q", 0, inst.pmesh, end, data_off, 1) + name)
             f.write(struct.pack("<I", k) if version >= 4 else np.asarray(transforms[k], f32).tobytes())

@@ -571,3 +571,24 @@ def test_cli_renders_a_vks_file_like_the_python_host(tmp_path):
     rh.readback_framebuffer(img)
     rh.close()
     assert np.array_equal(got.view(np.uint32), img[..., :3].view(np.uint32)) and got.std() > 0.01
+
+
+def test_cpp_vks_reader_wide_ids_indices_and_lods(tmp_path):
+    """the C++ reader on a file with 16-bit material ids, index buffers and a LoD group: same flat scene as the Python reader, for the base
+    level and for --remove-first-lods 1"""
+    from realtimepathtracingresearchframework_amd import vks
+    exe = _build_cli(tmp_path)
+    s = scenes.alpha_test()
+    pm = next(i for i, p in enumerate(s.pmeshes) if p.tri_material_ids is not None)
+    n = len(s.pmeshes[pm].tri_material_ids)
+    wide = (np.asarray(s.pmeshes[pm].tri_material_ids, np.uint16) + np.uint16(512) * (np.arange(n) % 2).astype(np.uint16)).astype(np.uint16)
+    others = [i for i in range(len(s.pmeshes)) if i != pm]
+    path = str(tmp_path / "w.vks")
+    vks.write_vks(path, s, wide_material_ids={pm: wide}, index_buffers=True, lod_groups=[[(others[0], 0.0), (others[1], 0.5)]])
+    for lods in (0, 1):
+        py, cpp = str(tmp_path / ("py%d.rpsc" % lods)), str(tmp_path / ("cpp%d.rpsc" % lods))
+        vks.read_vks(path, remove_first_lods=lods).dump(py)
+        out = subprocess.run([exe, path, "--dump-scene", cpp, "--remove-first-lods", str(lods)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert open(py, "rb").read() == open(cpp, "rb").read()
+    assert open(str(tmp_path / "py0.rpsc"), "rb").read() != open(str(tmp_path / "py1.rpsc"), "rb").read()

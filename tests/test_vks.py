@@ -225,6 +225,47 @@ def test_lod_groups_instance_the_base_level_only(tmp_path):
         vks.write_vks(str(tmp_path / "lod3.vks"), s, version=3, lod_groups=[[(0, 0.0), (1, 0.5)]])
 
 
+def test_remove_first_lods_swaps_in_the_coarser_level(tmp_path):
+    """SceneLoaderParams::PerFile::remove_first_LODs (scene.cpp:801-815) + unlink_pruned_lod_meshes (:229-246): the instances of a LoD
+    group render level n instead of the base level (the coarsest one when the group has fewer levels)"""
+    s = scenes.two_level_test()
+    path = str(tmp_path / "lod.vks")
+    vks.write_vks(path, s, lod_groups=[[(0, 0.0), (1, 0.5)]])
+    base = vks.read_vks(path)
+    lvl1 = vks.read_vks(path, remove_first_lods=1)
+    lvl9 = vks.read_vks(path, remove_first_lods=9)
+    assert len(lvl1.instances) == len(base.instances)
+    assert [i.pmesh for i in lvl1.instances] == [1 if i.pmesh == 0 else i.pmesh for i in base.instances]
+    assert [i.pmesh for i in lvl9.instances] == [i.pmesh for i in lvl1.instances]
+    assert any(i.pmesh == 0 for i in base.instances) and all(np.array_equal(a.transform, b.transform) for a, b in zip(base.instances, lvl1.instances))
+
+
+def test_sixteen_bit_material_ids_and_index_buffers(tmp_path):
+    """a mesh whose material range exceeds 256 stores two bytes per triangle id (vkr.c:1127-1130); the reference's backend uploads
+    static_cast<uint8_t>(id) (render_vulkan.cpp:1114-1126), so does the reader. VKR_MESH_FLAGS_INDICES files carry a 12-byte-per-triangle
+    index buffer behind the ids (vkr.c:1131-1136): skipped, the vertex streams are unrolled. libvkr reads the same offsets."""
+    s = scenes.alpha_test()
+    pm = next(i for i, p in enumerate(s.pmeshes) if p.tri_material_ids is not None)
+    n = len(s.pmeshes[pm].tri_material_ids)
+    wide = (np.asarray(s.pmeshes[pm].tri_material_ids, np.uint16) + np.uint16(256) * (np.arange(n) % 3).astype(np.uint16)).astype(np.uint16)
+    path = str(tmp_path / "wide.vks")
+    vks.write_vks(path, s, wide_material_ids={pm: wide}, index_buffers=True)
+    v = vks.read_vks_header(path)
+    assert v["meshes"][pm]["materialIdSize"] == 2 and v["meshes"][pm]["numMaterialsInRange"] > 0x100
+    assert all(m["flags"] & vks.MESH_FLAGS_INDICES and m["indexBufferOffset"] > m["materialIdBufferOffset"] for m in v["meshes"])
+    r = vks.read_vks(path)
+    assert np.array_equal(r.pmeshes[pm].tri_material_ids, (wide & 0xFF).astype(np.uint8))
+    assert np.array_equal(r.pmeshes[pm].tri_material_ids, np.asarray(s.pmeshes[pm].tri_material_ids, np.uint8))
+    plain = str(tmp_path / "plain.vks")
+    vks.write_vks(plain, s)
+    q = vks.read_vks(plain)
+    assert all(np.array_equal(a.qpos, b.qpos) for a, b in zip(r.geometries, q.geometries)) and len(r.instances) == len(q.instances)
+    if os.path.isfile(REF_LIB):
+        out = str(tmp_path / "dump.json")
+        assert _ref().ref_vkr_dump(path.encode(), out.encode()) == 0
+        _compare_with_dump(path, json.load(open(out)))
+
+
 def test_unrepresentable_scenes_are_refused(tmp_path):
     s = scenes.cornell32()
     s.instances[0].transform = s.instances[0].transform.copy()
