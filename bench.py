@@ -356,6 +356,7 @@ def main():
         step_x()
     serial = dict(ext=0.0, con=0.0, shade=0.0, tail=0.0, resolve=0.0, other=0.0, gpu=0.0)
     n_serial = max(3, min(10, args.steps))
+    serial_launches = 0
     for _ in range(n_serial):
         st = step_x().raw
         serial["ext"] += st.extend_time_ms / n_serial
@@ -365,6 +366,7 @@ def main():
         serial["resolve"] += st.resolve_time_ms / n_serial
         serial["other"] += (st.shade_time_ms - st.shade_only_time_ms - st.tail_time_ms - st.resolve_time_ms) / n_serial
         serial["gpu"] += st.render_time_ms / n_serial
+        serial_launches = int(st.launches_extend)
 
     def counted(depth=None):
         """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
@@ -384,7 +386,9 @@ def main():
     # The timed frames hand the late bounces to the tail kernel: `launches_extend` stand-alone closest-hit launches (bounces
     # 0..k-1) and as many shadow-ray launches per frame. Their work, counted exactly: the closest-hit queries of a frame cut at k
     # bounces, the shadow queries of a frame cut at k+1 (the last bounce of a path issues no shadow ray).
-    launches_extend = acc["launches"] if acc["launches"] > 0 else max_depth
+    # (counted on the handle that renders one frame at a time, the one all per-kernel figures below come from: the pipelined run batches
+    # several frames per launch sequence and may hand over to the tail kernel one bounce later)
+    launches_extend = serial_launches if serial_launches > 0 else max_depth
     if launches_extend < max_depth:
         cnt_ext = counted(launches_extend)
         cnt_con = counted(launches_extend + 1)
