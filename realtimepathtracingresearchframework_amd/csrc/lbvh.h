@@ -7,7 +7,7 @@
 //
 // Build (one dynamic mesh, n triangles, everything on the caller's stream, no host round trip):
 //   1. centroid bounds of the mesh (block reduction + ordered-uint atomics),
-//   2. 30-bit Morton code of every centroid; key = code << 32 | triangle position  (unique keys),
+//   2. Morton code of every centroid (as many bits per axis as the key has room for); key = code << index bits | triangle position,
 //   3. radix sort of the keys (hipCUB = rocPRIM: a plain library sort),
 //   4. binary radix tree over the sorted keys (Karras 2012: one thread per inner node, no atomics),
 //   5. triangles gathered into sorted order,
@@ -20,8 +20,8 @@
 //      code of every other refit and the encoder of the host builder.
 // No step synchronises threads through memory (per-XCD L2s are not coherent: agent-scope fences inside a kernel cost a write-back
 // each -- a bottom-up pass with arrival counters took 0.8 ms per refit of 300 k nodes against 0.1 ms for launches per level).
-// The tree is a linear BVH: more node visits per ray than the host's binned-SAH tree (measured in profiles/r02_notes.md), built
-// in about a millisecond per million triangles. Ray-query results do not depend on the tree (closest hit = smallest t, ties by ids).
+// The tree is a linear BVH over cubic Morton cells: on the 1 M-triangle height field as good as the host's binned-SAH tree (9.5 against
+// 9.4 node visits per ray, profiles/r02_notes.md), in general looser; built in about three milliseconds per million triangles. Ray-query results do not depend on the tree (closest hit = smallest t, ties by ids).
 //
 // Refit: launches per depth level, deepest first; the level bounds are read from the device (a device-built tree's level sizes are
 // unknown to the host until an asynchronous copy has arrived; until then every possible level gets its launch).
@@ -83,30 +83,39 @@ __global__ __launch_bounds__(256) void rp_k_lbvh_bounds(const float *tri_box, ui
         }
     }
 }
-RP_DEV uint32_t rp_expand_bits10(uint32_t v) { // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+RP_DEV unsigned long long rp_expand_bits21(uint32_t v) { // 21 bits -> every third bit of 63
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
 }
 // 2. keys
-__global__ __launch_bounds__(256) void rp_k_lbvh_keys(const float *tri_box, uint32_t n, const uint32_t *bounds, unsigned long long *keys) {
-    float lo[3], inv[3];
+// key = Morton code of the centroid in the high bits | triangle position in the low `index_bits` bits (unique keys). The code gets
+// all the bits the index leaves: 14 per axis for a million triangles
+__global__ __launch_bounds__(256) void rp_k_lbvh_keys(const float *tri_box, uint32_t n, const uint32_t *bounds, unsigned long long *keys, int index_bits) {
+    const int axis_bits = min(21, (64 - index_bits) / 3);
+    const float cells = (float)((1u << axis_bits) - 1u);
+    // CUBIC cells: one scale for the three axes. Scaling every axis to the full range makes the curve split a flat mesh along its thin
+    // axis at every third level (a height field by height: children that overlap completely in plan).
+    float lo[3], max_ext = 0.0f;
     for (int a = 0; a < 3; ++a) {
         lo[a] = rp_ord_dec(bounds[a]);
-        const float ext = rp_ord_dec(bounds[3 + a]) - lo[a];
-        inv[a] = ext > 0.0f ? 1023.0f / ext : 0.0f;
+        max_ext = fmaxf(max_ext, rp_ord_dec(bounds[3 + a]) - lo[a]);
     }
+    const float inv = max_ext > 0.0f ? cells / max_ext : 0.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float *b = tri_box + 6ull * i;
         uint32_t q[3];
         for (int a = 0; a < 3; ++a) {
-            const float c = ((b[a] + b[3 + a]) - lo[a]) * inv[a];
-            q[a] = (uint32_t)fminf(fmaxf(c, 0.0f), 1023.0f); // (NaN vertices land in cell 0)
+            const float c = ((b[a] + b[3 + a]) - lo[a]) * inv;
+            q[a] = (uint32_t)fminf(fmaxf(c, 0.0f), cells); // (NaN vertices land in cell 0)
         }
-        const uint32_t code = (rp_expand_bits10(q[0]) << 2) | (rp_expand_bits10(q[1]) << 1) | rp_expand_bits10(q[2]);
-        keys[i] = ((unsigned long long)code << 32) | (unsigned long long)i;
+        // 21 bits per axis interleaved, then cut down to the 3 * axis_bits that are there (the low bits of the 21 are zero-filled cells)
+        const unsigned long long code = (rp_expand_bits21(q[0]) << 2) | (rp_expand_bits21(q[1]) << 1) | rp_expand_bits21(q[2]);
+        keys[i] = (code << index_bits) | (unsigned long long)i;
     }
 }
 // 4. binary radix tree (T. Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012).
@@ -145,9 +154,9 @@ __global__ __launch_bounds__(256) void rp_k_lbvh_hierarchy(const unsigned long l
 }
 // 5. triangles (and their vertex bounds) into sorted order
 __global__ __launch_bounds__(256) void rp_k_lbvh_gather(const unsigned long long *keys, uint32_t n, const RptrBvhTri *tri_in, const float *box_in, RptrBvhTri *tri_out,
-                                                        float *box_out) {
+                                                        float *box_out, unsigned long long index_mask) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t src = (uint32_t)(keys[i] & 0xFFFFFFFFull);
+        const uint32_t src = (uint32_t)(keys[i] & index_mask);
         const float4 *s = reinterpret_cast<const float4 *>(tri_in + src);
         float4 *d = reinterpret_cast<float4 *>(tri_out + i);
         d[0] = s[0];

@@ -1458,7 +1458,7 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bo
         if ((rc = dev_alloc(h, &w.tribox_copy, 6 * cap, &h->scene_allocs))) return rc;
         if ((rc = dev_alloc(h, &w.bounds, 8, &h->scene_allocs))) return rc;
         size_t sort_bytes = 0, scan_bytes = 0;
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, w.keys_a, w.keys_b, (int)cap, 0, 62, st);
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, w.keys_a, w.keys_b, (int)cap, 0, 64, st);
         (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, w.flag, w.slot, (int)cap, st);
         w.cub_bytes = std::max(sort_bytes, scan_bytes) + 256;
         char *tmp = nullptr;
@@ -1472,13 +1472,15 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bo
     if (n >= 2) {
         hipLaunchKernelGGL(rp_k_lbvh_reset, dim3(1), dim3(64), 0, st, w.bounds);
         hipLaunchKernelGGL(rp_k_lbvh_bounds, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds);
-        hipLaunchKernelGGL(rp_k_lbvh_keys, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds, w.keys_a);
+        int index_bits = 1;
+        while ((1ull << index_bits) < (unsigned long long)n) ++index_bits;
+        hipLaunchKernelGGL(rp_k_lbvh_keys, dim3(g), dim3(256), 0, st, tri_box, n, w.bounds, w.keys_a, index_bits);
         size_t bytes = w.cub_bytes;
-        HIP_TRY(h, hipcub::DeviceRadixSort::SortKeys(w.cub_tmp, bytes, w.keys_a, w.keys_b, (int)n, 0, 62, st));
+        HIP_TRY(h, hipcub::DeviceRadixSort::SortKeys(w.cub_tmp, bytes, w.keys_a, w.keys_b, (int)n, 0, 64, st));
         hipLaunchKernelGGL(rp_k_lbvh_hierarchy, dim3(g), dim3(256), 0, st, w.keys_b, (int)n, w.left, w.right, w.parent, w.first, w.last);
         HIP_TRY(h, hipMemcpyAsync(w.tri_copy, tris, (size_t)n * sizeof(RptrBvhTri), hipMemcpyDeviceToDevice, st));
         HIP_TRY(h, hipMemcpyAsync(w.tribox_copy, tri_box, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(rp_k_lbvh_gather, dim3(g), dim3(256), 0, st, w.keys_b, n, w.tri_copy, w.tribox_copy, tris, tri_box);
+        hipLaunchKernelGGL(rp_k_lbvh_gather, dim3(g), dim3(256), 0, st, w.keys_b, n, w.tri_copy, w.tribox_copy, tris, tri_box, (1ull << index_bits) - 1ull);
         hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, w.parent, w.first, w.last, w.flag, w.depth4);
         bytes = w.cub_bytes;
         HIP_TRY(h, hipcub::DeviceScan::ExclusiveSum(w.cub_tmp, bytes, w.flag, w.slot, (int)n - 1, st));
