@@ -1,0 +1,27 @@
+"""Tree quality of the device-side rebuild on thin instanced geometry: the forest of C4 with every tree mesh dynamic (two-level tree), host
+SAH trees (refit) against device LBVH trees (rebuild): node visits per ray and frame time."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import torch
+import numpy as np
+from realtimepathtracingresearchframework_amd import abi, backend, scenes
+s = scenes.forest()
+for m in s.meshes[:-1]:
+    m.dynamic = True
+r = backend.RenderHip()
+r.initialize(1920, 1080); r.set_scene(s)
+cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
+def run(label, force):
+    r.set_bvh_policy(force_bvh_rebuild=force)
+    for gi, g in enumerate(s.geometries[:-1]):
+        P = scenes.dequantize_positions(g.qpos, g.scaling, g.offset).astype(np.float32)
+        r.update_vertices(gi, P)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r.refit(); e1.record(); torch.cuda.synchronize()
+    st = r.render(cfg, spp=4, count_traversal=True).raw
+    t = min(r.render(cfg, spp=4).raw.render_time_ms for _ in range(3))
+    print("%-22s refit/rebuild %.2f ms | nodes/closest ray %.2f tris/ray %.2f | shadow nodes/ray %.2f | frame %.3f ms" % (label, e0.elapsed_time(e1),
+          st.nodes_closest / st.rays_closest, st.tris_closest / st.rays_closest, (st.nodes_visited - st.nodes_closest) / max(1, st.rays_shadow), t))
+run("host SAH (refit)", False)
+run("device LBVH (rebuild)", True)
