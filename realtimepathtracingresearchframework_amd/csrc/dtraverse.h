@@ -289,6 +289,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
 #endif
             // the whole wave takes the generic stack path when some lane is within 3 entries of the end of its LDS part
             const bool stack_slow = __any(sp > RP_LDS_STACK - 3);
+#ifdef RP_PROF
+            if (stack_slow && lane == 0) atomicAdd(&rp_prof[13], 1ull);
+#endif
             int top = 0;
             if (!stack_slow) top = lds_stack[(sp - 1) * RP_TRAVERSE_BLOCK + tid]; // read ahead: the item a miss would pop
             const char *np = node_base + (uint32_t(cur) << 6);

@@ -33,3 +33,12 @@ void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, c
 hipError_t rp_extend_blocks_per_cu(int *out) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_extend<false, false, false, false, false>, RP_TRAVERSE_BLOCK, 0);
 }
+
+#ifdef RP_PROF
+hipError_t rp_prof_exchange(unsigned long long out[16]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(rp_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), zero, sizeof(zero));
+}
+#endif

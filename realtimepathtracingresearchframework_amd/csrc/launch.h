@@ -33,7 +33,10 @@ void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, boo
                       const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr, int *gstack);
 void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
                        RpBounceCounters *bc, RpCounters *ctr, int *gstack);
-hipError_t rp_extend_blocks_per_cu(int *out); // occupancy of the traversal kernels (they all fit the same budget)
+hipError_t rp_extend_blocks_per_cu(int *out);
+#ifdef RP_PROF
+hipError_t rp_prof_exchange(unsigned long long out[16]); // reads and clears the -DRP_PROF counters of rp_k_extend / rp_k_connect
+#endif // occupancy of the traversal kernels (they all fit the same budget)
 
 // k_shade.hip / k_tail.hip, built once per gpu-program variant (-DRP_INST_VARIANT=RPTR_VARIANT_*)
 #define RP_DECLARE_VARIANT(V)                                                                                                                          \

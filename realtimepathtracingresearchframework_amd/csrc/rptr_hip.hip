@@ -1733,7 +1733,7 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
 #ifdef RP_PROF
     {
         unsigned long long pr[16];
-        HIP_TRY(h, hipMemcpyFromSymbol(pr, HIP_SYMBOL(rp_prof), sizeof(pr)));
+        HIP_TRY(h, rp_prof_exchange(pr)); // (the counters of the traversal kernels live in k_extend.hip's copy of rp_prof)
         fprintf(stderr, "[RP_PROF] node-phase cycles %llu wave-iters %llu lane-iters %llu phases %llu leaf-cycles %llu | cyc/wave-iter %.1f util %.3f iters/phase %.2f leafcyc/phase %.1f\n",
                 pr[0], pr[1], pr[2], pr[3], pr[4], double(pr[0]) / double(pr[1] ? pr[1] : 1), double(pr[2]) / (64.0 * double(pr[1] ? pr[1] : 1)),
                 double(pr[1]) / double(pr[3] ? pr[3] : 1), double(pr[4]) / double(pr[3] ? pr[3] : 1));
@@ -1743,8 +1743,8 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
         fprintf(stderr, "[RP_PROF] time: node %.3g leaf+done %.3g refill %.3g | per phase: tri lanes %.2f (in %.2f of phases) instance lanes %.2f (in %.2f of phases)\n",
                 double(pr[0]), double(pr[4]), double(pr[8]), double(pr[9]) / double(pr[3] ? pr[3] : 1), double(pr[11]) / double(pr[3] ? pr[3] : 1),
                 double(pr[10]) / double(pr[3] ? pr[3] : 1), double(pr[12]) / double(pr[3] ? pr[3] : 1));
-        memset(pr, 0, sizeof(pr));
-        HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(rp_prof), pr, sizeof(pr)));
+        fprintf(stderr, "[RP_PROF] node iterations on the generic stack path (some lane within 3 entries of the end of its LDS stack): %.4f\n",
+                double(pr[13]) / double(pr[1] ? pr[1] : 1));
     }
 #endif
     RptrStats &st = h->stats;

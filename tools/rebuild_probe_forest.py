@@ -23,5 +23,19 @@ def run(label, force):
     t = min(r.render(cfg, spp=4).raw.render_time_ms for _ in range(3))
     print("%-22s refit/rebuild %.2f ms | nodes/closest ray %.2f tris/ray %.2f | shadow nodes/ray %.2f | frame %.3f ms" % (label, e0.elapsed_time(e1),
           st.nodes_closest / st.rays_closest, st.tris_closest / st.rays_closest, (st.nodes_visited - st.nodes_closest) / max(1, st.rays_shadow), t))
+def tree_stats(label):
+    nodes, tris, insts = r.export_bvh()
+    n32 = np.ascontiguousarray(nodes).view(np.int32).reshape(-1, 16)
+    child = n32[:, 10:14]
+    EMPTY = -(2 ** 31) + 2
+    used = (child != EMPTY).any(axis=1)
+    inner = (child >= 0)
+    leaf = (child <= -2) & (child != EMPTY)
+    cnt = ((-2 - child) & 7)[leaf]
+    print("%-22s nodes in use %d | children per node %.2f | leaf slots %d with 1/2/3/4 triangles: %s | inner children per node %.2f" % (
+        label, int(used.sum()), float(((child != EMPTY).sum(axis=1)[used]).mean()), int(leaf.sum()), np.bincount(cnt, minlength=5)[1:5].tolist(),
+        float(inner.sum(axis=1)[used].mean())), flush=True)
 run("host SAH (refit)", False)
+tree_stats("host SAH")
 run("device LBVH (rebuild)", True)
+tree_stats("device LBVH")
