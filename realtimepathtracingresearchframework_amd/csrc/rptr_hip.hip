@@ -573,7 +573,9 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
             const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
             return dx * dy + dy * dz + dz * dx;
         };
-        while ((int)cut.size() < braid) {
+        // (a dynamic mesh keeps its one root: a device-side rebuild gives it a new topology, and sub-roots named by instance records
+        // would then point into the middle of another tree)
+        while ((int)cut.size() < braid && !B.meshes[m].dynamic) {
             int pick = -1;
             float best = -1.0f;
             for (size_t i = 0; i < cut.size(); ++i) {

@@ -426,3 +426,38 @@ def test_device_built_tree_is_as_good_as_the_host_tree_on_a_height_field():
     assert r.bvh_rebuild_count() == 1
     assert visits["device"] < 1.10 * visits["host"], visits
     r.close()
+
+
+def test_rebuild_of_dynamic_meshes_with_many_instances():
+    """scenes with 16 or more instances open the roots of their bottom-level trees in the top level (instance records name sub-roots):
+    not for dynamic meshes -- a device-side rebuild changes the topology under those records (geometry used to vanish). 40 rotated,
+    scaled instances of two dynamic tree meshes: refit and rebuild give the hits of the static scene, bit for bit"""
+    s = scenes.forest(n_meshes=2, tris_per_tree=600, n_instances=40, name="dyn-forest")
+    static_hits = None
+    q = random_queries(np.random.default_rng(9), 60000, -12, 12)
+    q[:, 1] = np.abs(q[:, 1]) * 0.2 + 0.1
+    r0 = backend.RenderHip()
+    r0.initialize(32, 32)
+    r0.set_scene(s)
+    static_hits = r0.render_ray_queries(q).copy()
+    r0.close()
+    assert (static_hits[:, 0] >= 0).sum() > 2000
+    for m in s.meshes[:-1]:
+        m.dynamic = True
+    r = backend.RenderHip()
+    r.initialize(32, 32)
+    r.set_scene(s)
+    P = [scenes.dequantize_positions(g.qpos, g.scaling, g.offset).astype(np.float32) for g in s.geometries[:-1]]
+    for force in (False, True):
+        r.set_bvh_policy(force_bvh_rebuild=force)
+        for gi, p in enumerate(P):
+            r.update_vertices(gi, p)
+        r.refit()
+        got = r.render_ray_queries(q)
+        assert np.array_equal(got.view(np.uint32), static_hits.view(np.uint32)), "rebuild" if force else "refit"
+    assert r.bvh_rebuild_count() == 2
+    osc = O.OracleScene(s)
+    for gi, p in enumerate(P):
+        osc.set_dynamic_vertices(gi, p)
+    assert_ray_visit_parity(r, osc, 48, 32, 1, abi.VARIANT_SIMPLE)
+    r.close()

@@ -20,7 +20,11 @@ def run(label, force):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r.refit(); e1.record(); torch.cuda.synchronize()
     st = r.render(cfg, spp=4, count_traversal=True).raw
-    t = min(r.render(cfg, spp=4).raw.render_time_ms for _ in range(3))
+    runs = [r.render(cfg, spp=4).raw for _ in range(3)]
+    t = min(x.render_time_ms for x in runs)
+    b = min(runs, key=lambda x: x.render_time_ms)
+    print('   rays closest %d shadow %d hits shaded %d' % (st.rays_closest, st.rays_shadow, st.hits_shaded), flush=True)
+    print('   stages: extend %.2f connect %.2f shade %.2f tail %.2f ms, %d stand-alone bounces' % (b.extend_time_ms, b.connect_time_ms, b.shade_only_time_ms, b.tail_time_ms, b.launches_extend), flush=True)
     print("%-22s refit/rebuild %.2f ms | nodes/closest ray %.2f tris/ray %.2f | shadow nodes/ray %.2f | frame %.3f ms" % (label, e0.elapsed_time(e1),
           st.nodes_closest / st.rays_closest, st.tris_closest / st.rays_closest, (st.nodes_visited - st.nodes_closest) / max(1, st.rays_shadow), t))
 def tree_stats(label):
