@@ -461,3 +461,36 @@ def test_rebuild_of_dynamic_meshes_with_many_instances():
         osc.set_dynamic_vertices(gi, p)
     assert_ray_visit_parity(r, osc, 48, 32, 1, abi.VARIANT_SIMPLE)
     r.close()
+
+
+@pytest.mark.parametrize("seed,n_instances", [(31, 9), (32, 24)])
+def test_fuzz_rebuild_of_soups(seed, n_instances):
+    """the device-side rebuild on what the fuzz scenes throw at it: every mesh dynamic, vertices far from where the host tree was built,
+    a triangle collapsed to a point, a mesh flattened to a plane (all Morton codes of one axis equal), sheared / mirrored instances, more
+    than 16 of them: brute-force answers, and the oracle walks the exported trees exactly like the device"""
+    s = scenes.soup(seed, n_instances=n_instances)
+    for m in s.meshes:
+        m.dynamic = True
+    r = backend.RenderHip()
+    r.initialize(64, 64)
+    r.set_scene(s)
+    r.set_bvh_policy(force_bvh_rebuild=True)
+    osc = O.OracleScene(s)
+    rng = np.random.default_rng(seed)
+    for gi, g in enumerate(s.geometries):
+        P = scenes.dequantize_positions(g.qpos, g.scaling, g.offset)
+        P = (P + rng.normal(size=P.shape) * 0.3).astype(np.float32)
+        P[0:3] = P[0]
+        if gi == 0:
+            P[:, 2] = 0.5
+        r.update_vertices(gi, P)
+        osc.set_dynamic_vertices(gi, P)
+    r.refit()
+    assert r.bvh_rebuild_count() == len(s.meshes)
+    q = random_queries(np.random.default_rng(seed + 1), 20000, -6, 6)
+    res = r.render_ray_queries(q)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
+    r.close()
