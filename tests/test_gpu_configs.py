@@ -437,3 +437,42 @@ def test_batch_limits_and_gather_of_batched_frames():
         assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32))
     for r in rs:
         r.close()
+
+
+def test_gather_all_when_some_ranks_own_no_rows():
+    """a frame of 20 rows in stripes of 8 has three stripes: of five ranks, two own nothing. They still take part in every gather (zero
+    rows), render (nothing) and report frames; the assembled frame is the one-rank frame"""
+    s = scenes.cornell32()
+    W, H, spp, world = 64, 20, 2, 5
+    cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    ref = backend.RenderHip()
+    ref.initialize(W, H)
+    ref.set_scene(s)
+    ref.render(cfg, spp=spp)
+    want = np.zeros((H, W, 4), np.float32)
+    ref.readback_framebuffer(want)
+    ref.close()
+    rs = [backend.RenderHip(rank=k, world_size=world, stripe_rows=8, frames_in_flight=2) for k in range(world)]
+    for r in rs:
+        r.initialize(W, H)
+        r.set_scene(s)
+    assert [r.local_pixel_count() for r in rs] == [8 * W, 8 * W, 4 * W, 0, 0]
+    backend.RenderHip.comm_init_all(rs)
+    for _ in range(2):
+        tickets = [r.render_async(cfg, spp=spp) for r in rs]
+        for r, t in zip(rs, tickets):
+            r.wait(t)
+        backend.RenderHip.gather_all(rs)
+    got = np.zeros((H, W, 4), np.float32)
+    assert rs[0].readback_gathered(got) == W * H * 4
+    # (the second frame: reset again -> frame_offset moved on by spp)
+    ref = backend.RenderHip()
+    ref.initialize(W, H)
+    ref.set_scene(s)
+    for _ in range(2):
+        ref.render(cfg, spp=spp)
+    ref.readback_framebuffer(want)
+    ref.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for r in rs:
+        r.close()
