@@ -194,10 +194,15 @@ typedef struct RptrGeometryDesc {
 } RptrGeometryDesc;
 
 /* a mesh = one bottom-level acceleration structure (librender/mesh.h:43-72) */
+#define RPTR_MESH_DYNAMIC 1u
+#define RPTR_MESH_SUBTLY_DYNAMIC 2u
 typedef struct RptrMeshDesc {
     uint32_t first_geometry;
     uint32_t num_geometries;
-    uint32_t dynamic; /* !=0: vertices may be updated + refit (Mesh::Dynamic)    */
+    uint32_t dynamic; /* Mesh::flags (librender/mesh.h:44-47): 0 static; bit 0 RPTR_MESH_DYNAMIC: vertices may be updated, the tree
+                       * is refitted -- or, under rptr_hip_set_bvh_policy, rebuilt on the device; bit 1 RPTR_MESH_SUBTLY_DYNAMIC (small
+                       * deformations: SceneLoaderParams::small_deformation): updated and refitted, never rebuilt -- the reference builds
+                       * such meshes PREFER_FAST_TRACE | ALLOW_UPDATE instead of PREFER_FAST_BUILD (render_vulkan.cpp:942-952)          */
 } RptrMeshDesc;
 
 /* a mesh with a material assignment (librender/mesh.h:78-108, ParameterizedMesh) */

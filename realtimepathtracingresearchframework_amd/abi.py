@@ -15,6 +15,7 @@ RPTR_E_HIP = -5
 VARIANT_GLTF = 0
 VARIANT_SIMPLE = 1
 VARIANT_GLTF_TRANSMISSION = 2
+MESH_DYNAMIC, MESH_SUBTLY_DYNAMIC = 1, 2  # RptrMeshDesc.dynamic = Mesh::flags (librender/mesh.h:44-47)
 # RBO rng_variant (librender/render_params.glsl.h:34-37)
 RNG_VARIANT_UNIFORM, RNG_VARIANT_BN, RNG_VARIANT_SOBOL, RNG_VARIANT_Z_SBL = 0, 1, 2, 3
 RNG_VARIANT_NAMES = ("UNIFORM", "BN", "SOBOL", "Z_SBL")

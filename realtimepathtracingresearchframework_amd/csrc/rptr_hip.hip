@@ -42,6 +42,7 @@ struct MeshRt { // one bottom-level structure
     int tri_count = 0;
     float lo[3], hi[3];
     bool dynamic = false;
+    bool rebuildable = false; // dynamic and not RPTR_MESH_SUBTLY_DYNAMIC: the BVH policy may give it a new tree
 };
 
 // The part of the device scene a refit rewrites. The master set belongs to the handle (vertex updates, refit, ray
@@ -530,6 +531,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         }
         MeshRt &mr = B.meshes[m];
         mr.dynamic = mesh.dynamic != 0;
+        mr.rebuildable = mr.dynamic && (mesh.dynamic & RPTR_MESH_SUBTLY_DYNAMIC) == 0;
         rptr::BuiltTree tree;
         rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
@@ -573,9 +575,9 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
             const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
             return dx * dy + dy * dz + dz * dx;
         };
-        // (a dynamic mesh keeps its one root: a device-side rebuild gives it a new topology, and sub-roots named by instance records
-        // would then point into the middle of another tree)
-        while ((int)cut.size() < braid && !B.meshes[m].dynamic) {
+        // (a mesh the BVH policy may rebuild keeps its one root: a device-side rebuild gives it a new topology, and sub-roots named by
+        // instance records would then point into the middle of another tree; refits keep the topology)
+        while ((int)cut.size() < braid && !B.meshes[m].rebuildable) {
             int pick = -1;
             float best = -1.0f;
             for (size_t i = 0; i < cut.size(); ++i) {
@@ -1567,19 +1569,19 @@ int rptr_hip_refit(rptr_hip_t *h) {
         for (size_t m = 0; m < h->meshes.size(); ++m) changed = changed || (h->meshes[m].dynamic && h->master.mesh_dirty[m] == 1);
         if (changed && h->bvh_force_rebuild) {
             for (size_t m = 0; m < h->meshes.size(); ++m)
-                if (h->meshes[m].dynamic && h->master.mesh_dirty[m] == 1) h->rebuild_epoch[m]++;
+                if (h->meshes[m].rebuildable && h->master.mesh_dirty[m] == 1) h->rebuild_epoch[m]++;
         } else if (changed && h->bvh_budget > 0) {
             // a budget of triangles per refit call: it is saved up until it covers the next mesh in turn (a mesh larger than the budget is
             // rebuilt every ceil(triangles / budget) calls), dynamic meshes take turns
             long long total = 0;
             std::vector<size_t> dyn;
             for (size_t m = 0; m < h->meshes.size(); ++m)
-                if (h->meshes[m].dynamic) {
+                if (h->meshes[m].rebuildable) {
                     dyn.push_back(m);
                     total += h->meshes[m].tri_count;
                 }
             h->bvh_credit = std::min(h->bvh_credit + h->bvh_budget, std::max(total, h->bvh_budget));
-            for (size_t tries = 0; tries < dyn.size(); ++tries) {
+            for (size_t tries = 0; tries < dyn.size() && !dyn.empty(); ++tries) {
                 const size_t m = dyn[(size_t)h->rebuild_cursor % dyn.size()];
                 if (h->bvh_credit < h->meshes[m].tri_count) break;
                 h->bvh_credit -= h->meshes[m].tri_count;

@@ -161,7 +161,7 @@ class Scene:
                 if g.qnrm_uv is not None:
                     f.write(np.ascontiguousarray(g.qnrm_uv, dtype=np.uint64).tobytes())
             for m in self.meshes:
-                f.write(struct.pack("<3I", m.first_geometry, m.num_geometries, 1 if m.dynamic else 0))
+                f.write(struct.pack("<3I", m.first_geometry, m.num_geometries, int(m.dynamic)))
             for pm in self.pmeshes:
                 mo = np.ascontiguousarray(pm.material_offsets, dtype=np.int32)
                 f.write(struct.pack("<2I", pm.mesh, len(mo)) + mo.tobytes())
@@ -224,7 +224,7 @@ class Scene:
             G[i].quantized_offset[:] = [float(x) for x in g.offset]
         M = (abi.MeshDesc * max(1, len(self.meshes)))()
         for i, m in enumerate(self.meshes):
-            M[i].first_geometry, M[i].num_geometries, M[i].dynamic = m.first_geometry, m.num_geometries, 1 if m.dynamic else 0
+            M[i].first_geometry, M[i].num_geometries, M[i].dynamic = m.first_geometry, m.num_geometries, int(m.dynamic)  # Mesh::flags: 1 Dynamic, 2 SubtlyDynamic
         P = (abi.ParameterizedMeshDesc * max(1, len(self.pmeshes)))()
         for i, p in enumerate(self.pmeshes):
             mo = np.ascontiguousarray(p.material_offsets, dtype=np.int32)

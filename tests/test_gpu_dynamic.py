@@ -494,3 +494,30 @@ def test_fuzz_rebuild_of_soups(seed, n_instances):
     assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
     assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
     r.close()
+
+
+def test_subtly_dynamic_meshes_are_refitted_never_rebuilt():
+    """Mesh::SubtlyDynamic (SceneLoaderParams::small_deformation; the reference builds such meshes for fast tracing + updates,
+    render_vulkan.cpp:942-952): vertex updates and refits as for Mesh::Dynamic, but the BVH policy leaves the tree alone"""
+    s = scenes.grid(60, 40, deform_t=0.0, name="subtle")
+    s.meshes[0].dynamic = abi.MESH_SUBTLY_DYNAMIC
+    r = backend.RenderHip()
+    r.initialize(64, 48)
+    r.set_scene(s)
+    r.set_bvh_policy(force_bvh_rebuild=True)
+    P = scenes.grid_positions(60, 40, 0.4)
+    r.update_vertices(0, P)
+    r.refit()
+    assert r.bvh_rebuild_count() == 0
+    q = _grid_queries(8000, 5)
+    res = r.render_ray_queries(q)
+    osc = O.OracleScene(s)
+    osc.set_dynamic_vertices(0, P)
+    ref = np.zeros_like(res)
+    osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    r.set_bvh_policy(rebuild_triangle_budget=10)
+    r.update_vertices(0, P)
+    r.refit()
+    assert r.bvh_rebuild_count() == 0
+    r.close()
