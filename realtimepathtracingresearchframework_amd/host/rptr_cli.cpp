@@ -86,10 +86,10 @@ static std::string data_dir() {
 }
 
 // a scene file: the reference's own .vks (with its _textures directory), or the flat dump of scenes.py
-static int g_remove_first_lods = 0; // --remove-first-lods (SceneLoaderParams::PerFile::remove_first_LODs)
+static rptr::vks::LoadParams g_load; // --remove-first-lods, --instance-pruning, --small-deformation, --ignore-animation, --ignore-textures, --load-specularity (SceneLoaderParams::PerFile)
 static rptr::SceneDump load_scene(const std::string &path) {
     const size_t n = path.size();
-    if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir(), false, false, 0, g_remove_first_lods);
+    if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir(), g_load);
     return rptr::SceneDump::load(path);
 }
 
@@ -175,7 +175,12 @@ int main(int argc, char **argv) {
         }
         else if (a == "--variant") { need(1); const char *v = argv[++i]; variant = std::strcmp(v, "diffuse") == 0 ? RPTR_VARIANT_SIMPLE : std::strcmp(v, "gltf-transmission") == 0 ? RPTR_VARIANT_GLTF_TRANSMISSION : RPTR_VARIANT_GLTF; got_variant = true; }
         else if (a == "--every-frame") every_frame = true;
-        else if (a == "--remove-first-lods") { need(1); g_remove_first_lods = std::max(0, std::atoi(argv[++i])); }
+        else if (a == "--remove-first-lods") { need(1); g_load.remove_first_lods = std::max(0, std::atoi(argv[++i])); }
+        else if (a == "--instance-pruning") { need(1); g_load.instance_pruning_probability = (float)std::atof(argv[++i]); }
+        else if (a == "--small-deformation") g_load.small_deformation = true;
+        else if (a == "--ignore-animation") g_load.ignore_animation = true;
+        else if (a == "--ignore-textures") g_load.ignore_textures = true;
+        else if (a == "--load-specularity") g_load.load_specularity = true;
         else if (a == "--dump-scene") { need(1); dump_scene_path = argv[++i]; describe = true; } // --describe + the scene as read, in the flat layout
         else if (a == "--describe") describe = true; // load the scene, print what was read, do not render
         else if (a == "--pfm") format = FORMAT_PFM;
@@ -249,6 +254,8 @@ int main(int argc, char **argv) {
                              "[--profiling-img <prefix>] [--profiling-frames n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
                              "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png]\n"
                              "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n]   (rgba + AOV images as EXR)\n"
+                             "       <scene.vks>: [--remove-first-lods n] [--instance-pruning p] [--small-deformation] [--ignore-animation] [--ignore-textures] "
+                             "[--load-specularity] [--dump-scene out.rpsc]\n"
                              "validation, profiling and data-capture mode are mutually exclusive (cmdline.cpp:479-486)\n");
         return 2;
     }

@@ -492,10 +492,40 @@ inline float textured_param(uint32_t texture_id, uint32_t channel) { // renderin
 // Scene::load_vkrs for one file (without its override parameters): one mesh + parameterized mesh per .vks mesh (a geometry per segment,
 // per-triangle material ids when a single segment spans several materials), base-LoD instances, per material the three standard
 // textures (1 x 1 defaults when a file is missing) wired in as texture handles; then emitters, default camera, default sky.
-inline SceneDump read_scene(const std::string &path, const std::string &data_dir, bool ignore_textures = false, bool load_specularity = false,
-                            uint64_t frame = 0, int remove_first_lods = 0) {
+// SceneLoaderParams::PerFile (librender/scene.h:33-45), the members that change what is rendered; `dynamic_meshes` = a reference build
+// with ENABLE_DYNAMIC_MESHES (scene.cpp:691-706)
+struct LoadParams {
+    bool ignore_textures = false, load_specularity = false;
+    uint64_t frame = 0;
+    int remove_first_lods = 0;
+    float instance_pruning_probability = 0.0f;
+    bool small_deformation = false, ignore_animation = false, dynamic_meshes = true;
+};
+
+inline float halton2(uint32_t index) { // util/compute_util.h:19-33: reversed bits as a float's mantissa
+    uint32_t r = 0;
+    for (int b = 0; b < 32; ++b) r |= ((index >> b) & 1u) << (31 - b);
+    const uint32_t bits = 0x3f800000u | (r >> 9);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f - 1.0f;
+}
+
+inline std::string extended_material_name(const std::string &tex_dir, const std::string &name) { // vkr.c:526-534
+    bool exists = false;
+    const std::vector<uint8_t> ex = read_file(tex_dir + name + "_Ex.txt", &exists);
+    return exists ? std::string(ex.begin(), ex.end()) : name;
+}
+
+inline SceneDump read_scene(const std::string &path, const std::string &data_dir, const LoadParams &lp) {
+    const bool ignore_textures = lp.ignore_textures, load_specularity = lp.load_specularity;
+    const uint64_t frame = lp.frame;
+    const int remove_first_lods = lp.remove_first_lods;
     const Header v = read_header(path);
     SceneDump s;
+    const std::string tex_dir = texture_dir(path);
+    std::vector<std::string> extended_names;
+    for (const std::string &name : v.materialNames) extended_names.push_back(extended_material_name(tex_dir, name));
     size_t n_geom = 0;
     for (const MeshHeader &m : v.meshes)
         for (uint64_t n : m.segmentNumTriangles) n_geom += n ? 1 : 0;
@@ -543,12 +573,25 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
             s.offsets[i].assign(1, vm.materialIdBufferBase);
             pm.tri_material_ids = s.tri_ids[i].data();
         }
+        else if (lp.dynamic_meshes && !lp.ignore_animation && md.num_geometries > 0) {
+            // scene.cpp:658-706: `_SHADERMESH_<name>` / `_SHADERSUBMESH_<name>` in a segment material's extended name makes the mesh
+            // dynamic (the named vertex program is the host application's: rptr_hip_update_vertices)
+            for (uint64_t j = 0; j < vm.numSegments; ++j) {
+                const int32_t off = vm.segmentMaterialBaseOffsets[j];
+                if (off < 0 || (size_t)off >= extended_names.size()) continue;
+                const std::string &ext = extended_names[(size_t)off];
+                if (ext.find("_SHADERMESH_") != std::string::npos || ext.find("_SHADERSUBMESH_") != std::string::npos)
+                    s.meshes.back().dynamic |= lp.small_deformation ? RPTR_MESH_SUBTLY_DYNAMIC : RPTR_MESH_DYNAMIC;
+            }
+        }
         pm.material_offsets = s.offsets[i].data();
         s.pmeshes.push_back(pm);
     }
-    for (const InstanceHeader &vi : v.instances) { // scene.cpp:722-745: only the base level of a LoD group is instanced
+    for (size_t idx = 0; idx < v.instances.size(); ++idx) { // scene.cpp:722-749: only the base level of a LoD group is instanced
+        const InstanceHeader &vi = v.instances[idx];
         const LodGroup &lod = v.lodGroups[(size_t)v.meshes[(size_t)vi.meshId].lodGroup];
         if (!lod.meshIds.empty() && lod.meshIds[0] != vi.meshId) continue;
+        if (lp.instance_pruning_probability != 0.0f && halton2((uint32_t)idx) < lp.instance_pruning_probability) continue;
         const uint64_t at = transform_offset(vi.transformIndex, v.numStaticTransforms, v.numAnimatedTransforms, frame) * QUANTIZED_TRANSFORM_SIZE;
         if (at + QUANTIZED_TRANSFORM_SIZE > v.transforms.size()) throw Error("transform index beyond the table of " + path);
         RptrInstanceDesc in;
@@ -558,7 +601,6 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
             in.parameterized_mesh = (uint32_t)lod.meshIds[std::min((size_t)remove_first_lods, lod.meshIds.size() - 1)];
         s.instances.push_back(in);
     }
-    const std::string tex_dir = texture_dir(path);
     auto add_texture = [&](std::vector<uint8_t> rgba, uint32_t w, uint32_t h, bool srgb) {
         s.texels.push_back(std::move(rgba));
         RptrTextureDesc t;
@@ -571,12 +613,7 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
     };
     for (size_t i = 0; i < v.materialNames.size(); ++i) {
         const std::string &name = v.materialNames[i];
-        std::string extended_name = name;
-        {
-            bool exists = false;
-            const std::vector<uint8_t> ex = read_file(tex_dir + name + "_Ex.txt", &exists);
-            if (exists) extended_name.assign(ex.begin(), ex.end());
-        }
+        const std::string &extended_name = extended_names[i];
         float emission = 0.0f, emitter_color[3] = {0, 0, 0}, transmission[4] = {0.0f, 1.5f, 0.0f, 0.0f};
         std::vector<float> em;
         if (read_params(tex_dir + name + "_EmissionIntensity.txt", 4, em)) {

@@ -98,7 +98,7 @@ class Geometry:
 class Mesh:
     first_geometry: int
     num_geometries: int
-    dynamic: bool = False
+    dynamic: int = 0   # Mesh::flags (librender/mesh.h:44-47): 1 Dynamic, 2 SubtlyDynamic; bools work as before
 
 
 @dataclass

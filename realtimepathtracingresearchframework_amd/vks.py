@@ -508,14 +508,30 @@ def _load_material_files(tex_dir, name):
     return m
 
 
-def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remove_first_lods=0) -> Scene:
-    """`Scene::load_vkrs` (librender/scene.cpp:544-977) for one file, without its override parameters: one mesh and one
+def halton2(index):
+    """util/compute_util.h:19-33: the bit-reversed index written into a float's mantissa"""
+    r = int("{:032b}".format(index & 0xFFFFFFFF)[::-1], 2)
+    return float(np.array([0x3F800000 | (r >> 9)], np.uint32).view(f32)[0] - f32(1.0))
+
+
+def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remove_first_lods=0, instance_pruning_probability=0.0,
+             small_deformation=False, ignore_animation=False, dynamic_meshes=True) -> Scene:
+    """`Scene::load_vkrs` (librender/scene.cpp:544-977) for one file with the per-file override parameters of `SceneLoaderParams`
+    (librender/scene.h:33-45) that change what is rendered: one mesh and one
     parameterized mesh per .vks mesh (a geometry per segment, per-triangle material ids when a single segment spans
     several materials), base-LoD instances with `vks_flip * dequantised transform`, and per material the three standard
-    textures (1x1 defaults when a file is missing) wired into the `BaseMaterial` as texture handles."""
+    textures (1x1 defaults when a file is missing) wired into the `BaseMaterial` as texture handles.
+    `dynamic_meshes` = a reference build with ENABLE_DYNAMIC_MESHES: a mesh with a segment whose material's extended name carries
+    `_SHADERMESH_<name>` or `_SHADERSUBMESH_<name>` is flagged Mesh::Dynamic (Mesh::SubtlyDynamic with `small_deformation`), unless
+    `ignore_animation` (scene.cpp:658-706; the named vertex shader itself is the host application's: `update_vertices`).
+    `instance_pruning_probability`: instance i of the file is dropped when halton2(i) < p (scene.cpp:734-749).
+    (`merge_partition_instances` only regroups geometries of equal-transform instances into one mesh: no effect on the image, not done.)"""
     v = read_vks_header(path)
     raw = v["_raw"]
     s = Scene(name=os.path.splitext(os.path.basename(path))[0])
+    tex_dir = texture_dir(path)
+    mat_files = [_load_material_files(tex_dir, name) for name in v["materialNames"]]
+    dynamic_flag = abi.MESH_SUBTLY_DYNAMIC if small_deformation else abi.MESH_DYNAMIC
     for i, vm in enumerate(v["meshes"]):
         first = len(s.geometries)
         base = 0
@@ -540,9 +556,16 @@ def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remov
             s.pmeshes.append(ParameterizedMesh(mesh=i, material_offsets=np.array([vm["materialIdBufferBase"]], np.int32), tri_material_ids=ids))
         else:
             s.pmeshes.append(ParameterizedMesh(mesh=i, material_offsets=np.array(kept_offsets, np.int32)))
-    for vi in v["instances"]:              # scene.cpp:722-745: only the base level of a LoD group is instanced
+            if dynamic_meshes and not ignore_animation and s.meshes[-1].num_geometries > 0:
+                for off in vm["segmentMaterialBaseOffsets"][:vm["numSegments"]]:
+                    ext = mat_files[off]["extended_name"] if 0 <= off < len(mat_files) else ""
+                    if "_SHADERMESH_" in ext or "_SHADERSUBMESH_" in ext:
+                        s.meshes[-1].dynamic = int(s.meshes[-1].dynamic) | dynamic_flag
+    for idx, vi in enumerate(v["instances"]):              # scene.cpp:722-745: only the base level of a LoD group is instanced
         lod = v["lodGroups"][v["meshes"][vi["meshId"]]["lodGroup"]]
         if lod["numLevelsOfDetail"] != 0 and lod["meshIds"][0] != vi["meshId"]:
+            continue
+        if instance_pruning_probability and halton2(idx) < instance_pruning_probability:
             continue
         pmesh = vi["meshId"]
         if remove_first_lods > 0 and lod["numLevelsOfDetail"] > 1:
@@ -551,9 +574,8 @@ def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remov
             pmesh = int(lod["meshIds"][min(remove_first_lods, lod["numLevelsOfDetail"] - 1)])
         at = transform_offset(vi["transformIndex"], v["numStaticTransforms"], v["numAnimatedTransforms"], frame) * QUANTIZED_TRANSFORM_SIZE
         s.instances.append(Instance(transform=instance_transform(v["transforms"][at:at + QUANTIZED_TRANSFORM_SIZE]), pmesh=pmesh))
-    tex_dir = texture_dir(path)
     for i, name in enumerate(v["materialNames"]):   # scene.cpp:818-975
-        vm = _load_material_files(tex_dir, name)
+        vm = mat_files[i]
         mat = abi.make_material(flags=0)
         tid = 3 * i
         col = None if ignore_textures else vm["texBaseColor"]

@@ -592,3 +592,36 @@ def test_cpp_vks_reader_wide_ids_indices_and_lods(tmp_path):
         assert out.returncode == 0, out.stderr
         assert open(py, "rb").read() == open(cpp, "rb").read()
     assert open(str(tmp_path / "py0.rpsc"), "rb").read() != open(str(tmp_path / "py1.rpsc"), "rb").read()
+
+
+def test_vks_loader_params_dynamic_keywords_and_instance_pruning(tmp_path):
+    """SceneLoaderParams::PerFile (librender/scene.h:33-45) in both readers: `_SHADERMESH_` in a material's extended name flags its meshes
+    dynamic (subtly dynamic with small_deformation, not at all with ignore_animation), instance_pruning_probability drops the instances
+    whose halton2(index) lies below it (scene.cpp:658-706,734-749); same flat scene from Python and C++"""
+    from realtimepathtracingresearchframework_amd import vks, abi
+    exe = _build_cli(tmp_path)
+    s = scenes.two_level_test()
+    path = str(tmp_path / "f.vks")
+    names = vks.write_vks(path, s)
+    tex_dir = vks.texture_dir(path)
+    os.makedirs(tex_dir, exist_ok=True)
+    mat = next(int(p.material_offsets[0]) for p in s.pmeshes if p.tri_material_ids is None)
+    with open(tex_dir + names[mat] + "_Ex.txt", "w") as f:
+        f.write(names[mat] + "_SHADERMESH_wind")
+    users = {i for i, p in enumerate(s.pmeshes) if p.tri_material_ids is None and mat in [int(x) for x in p.material_offsets]}
+    assert users
+    assert [vks.halton2(i) for i in range(4)] == [0.0, 0.5, 0.25, 0.75]
+    cases = [({}, []), ({"small_deformation": True}, ["--small-deformation"]), ({"ignore_animation": True}, ["--ignore-animation"]),
+             ({"instance_pruning_probability": 0.3}, ["--instance-pruning", "0.3"])]
+    for k, (kw, flags) in enumerate(cases):
+        r = vks.read_vks(path, **kw)
+        want = 0 if "ignore_animation" in kw else abi.MESH_SUBTLY_DYNAMIC if "small_deformation" in kw else abi.MESH_DYNAMIC
+        for i, p in enumerate(r.pmeshes):
+            assert int(r.meshes[p.mesh].dynamic) == (want if i in users else 0)
+        kept = [i for i in range(len(s.instances)) if not (kw.get("instance_pruning_probability") and vks.halton2(i) < 0.3)]
+        assert len(r.instances) == len(kept) and (len(kept) == 12 or len(kept) == 8)
+        py, cpp = str(tmp_path / ("py%d.rpsc" % k)), str(tmp_path / ("cpp%d.rpsc" % k))
+        r.dump(py)
+        out = subprocess.run([exe, path, "--dump-scene", cpp] + flags, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        assert open(py, "rb").read() == open(cpp, "rb").read()
