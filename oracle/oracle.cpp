@@ -133,7 +133,7 @@ struct Frame {
     bool count;
     const AovOut *aov = nullptr;
 };
-// vulkan/accumulate.glsl:76-87 store_motion_jitter_aovs (motion_vector = 0: no dynamic-mesh motion; screen_jitter = 0 without raster TAA)
+// vulkan/accumulate.glsl:76-87 store_motion_jitter_aovs (motion_vector = 0: no dynamic-mesh motion)
 static inline void project(const float view[12], const float proj[2], vec3 p, float &x, float &y, float &w) {
     const float vx = ((view[0] * p.x + view[1] * p.y) + view[2] * p.z) + view[3];
     const float vy = ((view[4] * p.x + view[5] * p.y) + view[6] * p.z) + view[7];
@@ -142,6 +142,31 @@ static inline void project(const float view[12], const float proj[2], vec3 p, fl
     y = -(proj[1] * vy);
     w = -vz;
 }
+// librender/halton.h: entry i of the (2, 3) Halton sequence as that header tabulates it -- decimal literals with six digits after the point
+static vec2 halton_23_entry(uint32_t i) {
+    auto radical_inverse = [](uint32_t n, uint32_t base) {
+        double f = 1.0, r = 0.0;
+        for (; n; n /= base) {
+            f /= base;
+            r += f * (n % base);
+        }
+        return r;
+    };
+    float out[2];
+    for (int c = 0; c < 2; ++c) {
+        char txt[32];
+        snprintf(txt, sizeof(txt), "%.6f", radical_inverse(i + 1u, c ? 3u : 2u));
+        out[c] = strtof(txt, nullptr);
+    }
+    return vec2(out[0], out[1]);
+}
+// view_params.screen_jitter, vulkan/render_vulkan.cpp:2917-2926 (RASTER_TAA_NUM_SAMPLES = 16, CMakeLists.txt:30)
+static vec2 screen_jitter(const Frame &f) {
+    if (f.rp.enable_raster_taa <= 0) return vec2(0.0f);
+    const vec2 h = halton_23_entry((f.vp.frame_offset + f.vp.frame_id) % 16u);
+    const vec2 dims((float)f.vp.dims_x, (float)f.vp.dims_y);
+    return h * 2.0f / dims - vec2(1.0f) / dims;
+}
 static void store_geometry_aovs(const Frame &f, size_t pixel, vec3 normal, vec3 hit_point) { // :89-96
     float depth = length(hit_point - f.vp.cam_pos);
     store_half4(f.aov->normal_depth, pixel, normal.x, normal.y, normal.z, depth);
@@ -149,7 +174,8 @@ static void store_geometry_aovs(const Frame &f, size_t pixel, vec3 normal, vec3 
     project(f.vp.view_ref, f.vp.proj_ref, hit_point, rx, ry, rw);
     project(f.vp.view, f.vp.proj, hit_point, cx, cy, cw);
     const float rd = fmaxf(rw, 0.0f), cd = fmaxf(cw, 0.0f);
-    store_half4(f.aov->motion_jitter, pixel, rx / rd - cx / cd, ry / rd - cy / cd, 0.0f, 0.0f);
+    const vec2 jitter = screen_jitter(f);
+    store_half4(f.aov->motion_jitter, pixel, rx / rd - cx / cd, ry / rd - cy / cd, jitter.x, jitter.y);
 }
 static void store_material_aovs(const Frame &f, size_t pixel, vec3 albedo, float roughness, float ior) { // :98-103
     store_half4(f.aov->albedo_roughness, pixel, albedo.x, albedo.y, albedo.z, ior != 1.0f ? roughness : 1.0f);
@@ -468,6 +494,7 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
     vec2 point = vec2(px + 0.5f, py + 0.5f);
     if (f.rp.enable_raster_taa == 0) point = point + (random_float2(rng, DIM_PIXEL_X) - vec2(0.5f));
     point = point / vec2((float)f.vp.dims_x, (float)f.vp.dims_y);
+    if (f.rp.enable_raster_taa != 0) point = point + 0.5f * screen_jitter(f); // :319-320
     vec3 ray_origin = f.vp.cam_pos;
     vec3 ray_dir = normalize(point.x * f.vp.cam_du + point.y * f.vp.cam_dv + f.vp.cam_dir_top_left);
     float t_min = 0;
@@ -655,6 +682,11 @@ int orc_scene_set_rng_variant(void *p, int variant, const uint32_t *words, size_
     s->pointset.variant = variant;
     s->pointset.words.assign(words, words + need);
     return 0;
+}
+void orc_halton23_probe(uint32_t i, float *out) {
+    const vec2 h = halton_23_entry(i);
+    out[0] = h.x;
+    out[1] = h.y;
 }
 // the draws of one pixel sample: get_rng, then n (dimension, value) draws at the dimensions `dims` after RANDOM_SET_DIM(set_dim)
 int orc_pointset_probe(void *p, uint32_t sample_index, uint32_t frame_offset, uint32_t frame_id, uint32_t px, uint32_t py, uint32_t dimx, int set_dim,

@@ -185,13 +185,23 @@ RP_DEV void rp_project(const float *view, const float *proj, V3 p, float &x, flo
     y = -(proj[1] * vy);
     w = -vz;
 }
-RP_DEV void rp_store_geometry_aovs(const RpFrame &f, int pixel, V3 normal, V3 hit_point) { // :76-96 (motion_vector = 0, screen_jitter = 0)
+// view_params.screen_jitter (render_vulkan.cpp:2917-2926): with render_params.enable_raster_taa > 0 all primary rays of a frame share one
+// sub-pixel offset, entry (frame_offset + frame_id) mod RASTER_TAA_NUM_SAMPLES (16, CMakeLists.txt:30) of the (2, 3) Halton sequence at the
+// six decimals librender/halton.h tabulates it with, in clip-space units: h * 2 / dims - 1 / dims. Zero otherwise.
+RP_DEV V2 rp_screen_jitter(const RpFrame &f, uint32_t frame_offset, uint32_t frame_id) {
+    static constexpr float halton_23[32] = {0.500000f, 0.333333f, 0.250000f, 0.666667f, 0.750000f, 0.111111f, 0.125000f, 0.444444f, 0.625000f, 0.777778f, 0.375000f, 0.222222f, 0.875000f, 0.555556f, 0.062500f, 0.888889f, 0.562500f, 0.037037f, 0.312500f, 0.370370f, 0.812500f, 0.703704f, 0.187500f, 0.148148f, 0.687500f, 0.481481f, 0.437500f, 0.814815f, 0.937500f, 0.259259f, 0.031250f, 0.592593f};
+    if (f.rp.enable_raster_taa <= 0) return v2(0.0f, 0.0f);
+    const uint32_t idx = (frame_offset + frame_id) & 15u;
+    const float w = float(f.width), h = float(f.height);
+    return v2(halton_23[2 * idx] * 2.0f / w - 1.0f / w, halton_23[2 * idx + 1] * 2.0f / h - 1.0f / h);
+}
+RP_DEV void rp_store_geometry_aovs(const RpFrame &f, int pixel, V3 normal, V3 hit_point, V2 screen_jitter) { // :76-96 (motion_vector = 0)
     f.aov_normal_depth[pixel] = rp_half4(normal.x, normal.y, normal.z, len3(hit_point - ld3(f.cam_pos)));
     float rx, ry, rw, cx, cy, cw;
     rp_project(f.view_ref, f.proj_ref, hit_point, rx, ry, rw);
     rp_project(f.view, f.proj, hit_point, cx, cy, cw);
     const float rd = fmaxf(rw, 0.0f), cd = fmaxf(cw, 0.0f);
-    f.aov_motion_jitter[pixel] = rp_half4(rx / rd - cx / cd, ry / rd - cy / cd, 0.0f, 0.0f);
+    f.aov_motion_jitter[pixel] = rp_half4(rx / rd - cx / cd, ry / rd - cy / cd, screen_jitter.x, screen_jitter.y);
 }
 RP_DEV void rp_store_material_aovs(const RpFrame &f, int pixel, V3 albedo, float roughness, float ior) { // :98-103
     f.aov_albedo_roughness[pixel] = rp_half4(albedo.x, albedo.y, albedo.z, ior != 1.0f ? roughness : 1.0f);

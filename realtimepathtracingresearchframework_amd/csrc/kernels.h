@@ -100,8 +100,10 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir,
     const RpSlotFrame sf = rp_slot_frame(f, sslot);
     rng = rp_rng_open<TABLE>(f, sf, uint32_t(lx), uint32_t(gy));
     V2 point = v2(float(lx) + 0.5f, float(gy) + 0.5f);
-    if (f.rp.enable_raster_taa == 0) point = point + (rp_draw2<TABLE>(f, rng, 0u /* DIM_PIXEL_X */) - v2(0.5f, 0.5f));
+    // (enable_raster_taa != 0 is rendered by the TABLE instantiation: the shipped path has no branch on it)
+    if (!TABLE || f.rp.enable_raster_taa == 0) point = point + (rp_draw2<TABLE>(f, rng, 0u /* DIM_PIXEL_X */) - v2(0.5f, 0.5f));
     point = v2(point.x / float(f.width), point.y / float(f.height));
+    if (TABLE && f.rp.enable_raster_taa != 0) point = point + rp_screen_jitter(f, sf.frame_offset, sf.frame_id) * 0.5f; // pt_megakernel.glsl:319-320
     dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
     return true;
 }
@@ -337,6 +339,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             V3 ip_p = v3s(0.f), gn = v3s(0.f), nn = v3s(0.f), w_o = v3s(0.f), v_x = v3s(0.f), v_y = v3s(0.f);
             int bounce = 0;
             int aov_px = -1; // FIRST: local pixel whose AOVs this path writes
+            V2 aov_jitter = v2(0.0f, 0.0f);
             RpMaterial mat;
             V2 dir_sample = v2(0.f, 0.f), sel_sample = v2(0.f, 0.f);
             RpLightBin bin;
@@ -360,7 +363,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         rng.s = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
-                        if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) aov_px = first_ly * f.width + first_lx;
+                        if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) {
+                            aov_px = first_ly * f.width + first_lx;
+                            if (TABLE) aov_jitter = rp_screen_jitter(f, sf.frame_offset, sf.frame_id);
+                        }
                     }
                     ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
@@ -389,7 +395,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
                     ps.illum[p] = f4(illum, __int_as_float(bounce));
                     if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:482-487
-                        rp_store_geometry_aovs(f, aov_px, v3s(0.0f), v3s(2.e32f));
+                        rp_store_geometry_aovs(f, aov_px, v3s(0.0f), v3s(2.e32f), aov_jitter);
                         rp_store_material_aovs(f, aov_px, v3s(0.0f), 1.0f, 1.0f);
                     }
                 } else {
@@ -456,7 +462,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     rp_unpack_material<VARIANT, TEX>(sc, mat, emit, mp, hit.uv);
                     scatter_throughput = throughput;
                     if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:670-673, shade_base_material.glsl:28-31
-                        rp_store_geometry_aovs(f, aov_px, nn, ip_p);
+                        rp_store_geometry_aovs(f, aov_px, nn, ip_p, aov_jitter);
                         rp_store_material_aovs(f, aov_px, throughput * mat.base_color, mat.roughness, mat.ior);
                     }
                     if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {

@@ -1693,7 +1693,7 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &s
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
-    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures, f.rng_variant != RPTR_RNG_VARIANT_UNIFORM, scene, f, c.ps, c.sq, order,
+    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures, f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0, scene, f, c.ps, c.sq, order,
                     (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
                     &c.counters->bounce[bounce].shadow_count, c.counters);
 }
@@ -1968,7 +1968,8 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         }
         return l;
     };
-    const bool table_rng = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM;
+    // the general instantiation of the path stages: a table point set, or a screen jitter (raster TAA) -- the shipped path carries neither
+    const bool table_rng = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];

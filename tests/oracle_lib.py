@@ -245,6 +245,13 @@ def process_samples_u8(accum, params=None, cam_pos=(0.0, 0.0, 0.0), aovs=None):
     return out
 
 
+def halton23(i):
+    """entry i of the (2, 3) Halton table behind view_params.screen_jitter, as the oracle regenerates it"""
+    out = np.zeros(2, np.float32)
+    lib().orc_halton23_probe(C.c_uint32(i), _p(out))
+    return out
+
+
 def rng_probe(index, frame, px, py, dimx, n=8):
     st = C.c_uint32()
     fl = np.zeros(n, dtype=np.float32)

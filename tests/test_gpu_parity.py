@@ -786,3 +786,39 @@ def test_full_size_forest_flattened_against_two_level():
         ref, _ = osc.render(W, H, 1, variant=abi.VARIANT_GLTF, rows=rows, bvh_mode=O.BVH_IMPORTED)
         rmse, same, maxabs = image_error(flat[rows[0]:rows[1]], ref[rows[0]:rows[1]])
         assert same and rmse < RMSE_TOL, (rows, rmse, maxabs)
+
+
+def test_raster_taa_screen_jitter_matches_the_oracle():
+    """render_params.enable_raster_taa: no pixel-filter draw, all primary rays of a frame share view_params.screen_jitter = entry
+    (frame_offset + frame_id) % 16 of the (2, 3) Halton table (pt_megakernel.glsl:316-320, render_vulkan.cpp:2917-2926), which the
+    motion / jitter AOV carries in zw (accumulate.glsl:85). Three frames: reset, accumulate, reset -> entries 0, 2 and 4."""
+    s = scenes.textured_test()
+    W, H, spp = 96, 80, 2
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    r.params.enable_raster_taa = 1
+    p = abi.RenderParams.default()
+    p.enable_raster_taa = 1
+    osc = O.OracleScene(s)
+    cam = s.camera_params()
+    plan = [(True, 0, 0), (False, 2, 0), (True, 0, 4)]   # (reset, samples accumulated before = frame_id, frame_offset)
+    ref = None
+    images = []
+    for reset, frame_id, frame_offset in plan:
+        st = r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=reset), spp=spp)
+        img = np.zeros((H, W, 4), np.float32)
+        r.readback_framebuffer(img)
+        ref, _, aovs = osc.render(W, H, spp, params=p, sample_begin=frame_id, frame_offset=frame_offset, aovs=True,
+                                  accum=None if reset else ref.copy())
+        rmse, same, _ = image_error(img, ref)
+        assert same and rmse < RMSE_TOL, (frame_id, frame_offset, rmse)
+        got = np.zeros((H, W, 4), np.float16)
+        r.readback_aov(r.AOVMotionJitterIndex, got)
+        h = O.halton23((frame_offset + frame_id) % 16)
+        want = np.array([h[0] * 2 / W - 1 / W, h[1] * 2 / H - 1 / H], np.float32).astype(np.float16)
+        assert np.array_equal(got[..., 2:].reshape(-1, 2), np.broadcast_to(want, (W * H, 2))) and np.array_equal(got[..., 2:], aovs[2][..., 2:])
+        images.append(img)
+    # the jitter moved the image: without TAA-off pixel filtering two 2-spp frames of a static view differ only through it and the seeds
+    assert not np.array_equal(images[0], images[2])
+    r.close()

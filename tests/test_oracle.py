@@ -577,3 +577,16 @@ def test_aov_motion_vectors_follow_the_previous_view():
     near, far = m[hit][depth_order[:200], 0].mean(), m[hit][depth_order[-200:], 0].mean()
     assert near > far > 0
     assert np.all(m[..., 2:] == 0)
+
+
+def test_halton_table_of_the_screen_jitter():
+    """the (2, 3) Halton table behind view_params.screen_jitter (render_vulkan.cpp:2917-2926): regenerated at six decimals; equals
+    librender/halton.h entry by entry where the reference tree is at hand"""
+    import os, re
+    assert O.halton23(0).tolist() == [0.5, np.float32(0.333333)] and O.halton23(7).tolist() == [0.0625, np.float32(0.888889)]
+    ref = "/root/reference/librender/halton.h"
+    if os.path.exists(ref):
+        rows = re.findall(r"\{\s*([0-9.]+)f,\s*([0-9.]+)f\s*\}", open(ref).read())
+        assert len(rows) == 64
+        for i, (a, b) in enumerate(rows):
+            assert O.halton23(i).tolist() == [np.float32(a), np.float32(b)], i

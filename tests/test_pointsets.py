@@ -82,6 +82,33 @@ def test_sobol_table_equals_the_references_table():
     assert np.array_equal(t[1024 * 32:], ref_inv)
 
 
+REF_TOOL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "prepare_sobol")
+
+
+def _run_ref_tool(bits, tile, dx, dy):
+    import subprocess
+    txt = subprocess.run([REF_TOOL, str(bits), str(tile), str(dx), str(dy)], capture_output=True, text=True, check=True).stdout
+    i1 = txt.index("SobolInversion_")
+    m = np.array([int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{8})U", txt[:i1])], dtype=np.uint32)
+    body = txt[txt.index("{", i1) + 1:txt.index("}", i1)]
+    return m, np.array([int(x) for x in re.findall(r"\d+", body)], dtype=np.uint32), txt
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TOOL), reason="oracle/_ref/prepare_sobol is built from the reference tree (oracle/Makefile)")
+def test_sobol_table_equals_the_output_of_the_references_generator():
+    """pinned by oracle/_ref: rendering/tools/prepare_sobol.cpp compiled unmodified prints the tables the shaders read; the package's
+    regenerated matrices and the derived tile inversion equal them word by word — for the shipped (32 bits, 256 tile, dims 0 / 1) table
+    and for other tile sizes and dimension pairs of the same tool"""
+    m, inv, txt = _run_ref_tool(32, 256, 0, 1)
+    t = pointsets.sobol_table()
+    assert m.size == 1024 * 32 and inv.size == 256 * 256 and "Zeros: 1" in txt
+    assert np.array_equal(t[:1024 * 32], m) and np.array_equal(t[1024 * 32:], inv)
+    mine = pointsets.sobol_matrices()
+    for tile, dx, dy in ((64, 0, 1), (16, 1, 0), (128, 0, 1)):
+        _, inv, txt = _run_ref_tool(32, tile, dx, dy)
+        assert "Zeros: 1" in txt and np.array_equal(pointsets.sobol_tile_inversion(mine, tile=tile, dim_x=dx, dim_y=dy), inv)
+
+
 def test_tile_inversion_is_the_inverse_of_the_first_two_dimensions():
     m = pointsets.sobol_matrices()
     inv = pointsets.sobol_tile_inversion(m)
