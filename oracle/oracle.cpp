@@ -888,6 +888,8 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
                     vec4 c = (a->variant == RPTR_VARIANT_SIMPLE)              ? main_spp<SimpleMaterial>(f, x, y, sample_index, pc)
                              : (a->variant == RPTR_VARIANT_GLTF_TRANSMISSION) ? main_spp<GLTFTransMaterial>(f, x, y, sample_index, pc)
                                                                               : main_spp<GLTFMaterial>(f, x, y, sample_index, pc);
+                    // process_samples.comp:116-131, REPROJECTION_MODE_DISCARD_HISTORY: the frame's own samples only
+                    if (f.rp.reprojection_mode == 1) sample_index = uint32_t(si);
                     if (sample_index == 0) {
                         px[0] = c.x; px[1] = c.y; px[2] = c.z; px[3] = c.w;
                     } else {

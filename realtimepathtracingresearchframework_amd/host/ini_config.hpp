@@ -177,6 +177,22 @@ inline void apply_ini_object(const IniObject &o, HostConfig &c) {
             else if (s.find("NO_TONE") != std::string::npos || s.find("LINEAR") != std::string::npos) c.params.early_tone_mapping_mode = 0;
         }
     }
+    if (const IniObject *fl = o.child("Filtering")) { // libapp/app_state.cpp:148-195
+        if (const IniObject *op = fl->child("reprojection")) { // REPROJECTION_MODE_NAMES (postprocess/reprojection.h)
+            const std::string s = op->selected();
+            if (s.find("DISCARD_HISTORY") != std::string::npos) c.params.reprojection_mode = 1;
+            else if (s.find("ACCUMULATE") != std::string::npos) {
+                c.params.reprojection_mode = 0;
+                c.notes.push_back("reprojection ACCUMULATE belongs to ENABLE_REALTIME_RESOLVE builds: NONE is used");
+            } else if (s.find("NONE") != std::string::npos) c.params.reprojection_mode = 0;
+        }
+        int upscale = c.params.render_upscale_factor == 2 ? 1 : 0, taa = c.params.enable_raster_taa != 0 ? 1 : 0, unjittered = c.params.enable_raster_taa < 0 ? 1 : 0;
+        fl->get("use 2x upscaling", &upscale);
+        fl->get("raster TAA pattern", &taa);
+        fl->get("unjittered raster pattern", &unjittered);
+        c.params.render_upscale_factor = upscale ? 2 : 1;
+        c.params.enable_raster_taa = unjittered ? -1 : (taa ? 1 : 0);
+    }
     if (const IniObject *s = o.child("Sun")) {
         if (!s->attributes.empty()) {
             c.sun_changed = true;

@@ -226,11 +226,11 @@ int main(int argc, char **argv) {
                 c.camera = s.camera;
                 for (const std::string &ini : config_inis) rptr::load_config(ini, c);
                 std::printf("config target_spp %d batch_spp %d max_path_depth %d rr_path_depth %d glossy_only %d exposure %.6f tonemap %d output_channel %d "
-                            "output_moment %d bin_size %d variant %d rng_variant %d force_bvh_rebuild %d rebuild_triangle_budget %d bump_scale %.6f sun_changed %d "
+                            "output_moment %d bin_size %d variant %d rng_variant %d force_bvh_rebuild %d rebuild_triangle_budget %d bump_scale %.6f sun_changed %d reprojection_mode %d raster_taa %d upscale %d "
                             "cam_pos %.6f %.6f %.6f cam_dir %.6f %.6f %.6f\n",
                             c.target_spp, c.params.batch_spp, c.params.max_path_depth, c.params.rr_path_depth, c.params.glossy_only_mode, c.params.exposure,
                             c.params.early_tone_mapping_mode, c.params.output_channel, c.params.output_moment, c.lighting.bin_size, c.variant, c.rng_variant, c.force_bvh_rebuild,
-                            c.rebuild_triangle_budget, c.bump_scale, c.sun_changed ? 1 : 0, c.camera.pos[0], c.camera.pos[1], c.camera.pos[2], c.camera.dir[0],
+                            c.rebuild_triangle_budget, c.bump_scale, c.sun_changed ? 1 : 0, c.params.reprojection_mode, c.params.enable_raster_taa, c.params.render_upscale_factor, c.camera.pos[0], c.camera.pos[1], c.camera.pos[2], c.camera.dir[0],
                             c.camera.dir[1], c.camera.dir[2]);
                 for (const Keyframe &k : keyframes) {
                     rptr::HostConfig kc = c;

@@ -822,3 +822,32 @@ def test_raster_taa_screen_jitter_matches_the_oracle():
     # the jitter moved the image: without TAA-off pixel filtering two 2-spp frames of a static view differ only through it and the seeds
     assert not np.array_equal(images[0], images[2])
     r.close()
+
+
+def test_reprojection_mode_discard_history():
+    """render_params.reprojection_mode = REPROJECTION_MODE_DISCARD_HISTORY (process_samples.comp:116-131): the accumulation buffer of a
+    frame that does not reset holds that frame's samples only (seeded as samples 2..3), not the running mean over the history"""
+    s = scenes.cornell32()
+    W, H, spp = 64, 64, 2
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    r.params.reprojection_mode = 1
+    p = abi.RenderParams.default()
+    p.reprojection_mode = 1
+    osc = O.OracleScene(s)
+    cam = s.camera_params()
+    first = np.zeros((H, W, 4), np.float32)
+    second = np.zeros((H, W, 4), np.float32)
+    r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=spp)
+    r.readback_framebuffer(first)
+    r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=False), spp=spp)
+    r.readback_framebuffer(second)
+    ref1, _ = osc.render(W, H, spp, params=p)
+    ref2, _ = osc.render(W, H, spp, params=p, sample_begin=spp, accum=ref1.copy())
+    keep, _ = osc.render(W, H, spp, sample_begin=spp, accum=ref1.copy())      # the default mode folds the history in
+    for got, ref in ((first, ref1), (second, ref2)):
+        rmse, same, _ = image_error(got, ref)
+        assert same and rmse < RMSE_TOL
+    assert image_error(second, keep)[0] > 10 * RMSE_TOL
+    r.close()

@@ -367,6 +367,14 @@ wavefront-gltf-transmission= 1
 [.][*pointset]
 Z_SBL= 1
 ..
+[.][Filtering]
+[.][*reprojection]
+DISCARD_HISTORY= 1
+..
+use 2x upscaling= 0
+raster TAA pattern= 1
+unjittered raster pattern= 0
+..
 
 [Application][scene.vks]
 [.][Camera]
@@ -418,6 +426,7 @@ def test_cli_reads_the_reference_ini_configuration_files(tmp_path):
     assert abs(float(kv["exposure"]) - 1.25) < 1e-6 and int(kv["tonemap"]) == 2 and int(kv["output_channel"]) == 0
     assert int(kv["bin_size"]) == 8 and int(kv["variant"]) == abi.VARIANT_GLTF_TRANSMISSION
     assert int(kv["rng_variant"]) == abi.RNG_VARIANT_Z_SBL
+    assert (int(kv["reprojection_mode"]), int(kv["raster_taa"]), int(kv["upscale"])) == (1, 1, 1)
     assert int(kv["force_bvh_rebuild"]) == 1 and int(kv["rebuild_triangle_budget"]) == 250000 and abs(float(kv["bump_scale"]) - 2.0) < 1e-6
     at = cfg.index("cam_pos")
     assert [float(v) for v in cfg[at + 1:at + 4]] == [1.5, 0.25, 3.0]
