@@ -20,13 +20,15 @@
 //    the float accumulation buffer as <prefix>_%04d.pfm (accumulated spp in the name); n < 1 = after every frame;
 //  * profiling mode advances time by 1/fps per frame (non-realtime), appends one CSV row per frame to <prefix>.csv with the
 //    header frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms, and writes <img prefix>_%04d.pfm once per
-//    second of animation time. The reference ends at its last keyframe; here a keyframe is one second and
-//    --profiling-frames (default 60) ends the run.
+//    second of animation time. The run ends at its last keyframe (--keyframe [len:]file.ini ...); without keyframes the reference
+//    stops after its first frame (imstate.cpp:890-898) and so does this host unless --profiling-count n (its own flag) asks for n
+//    frames, a keyframe then being one second. --profiling-frames is the reference's old spelling of --profiling-fps.
 //  * --animate-wave a k (profiling mode, scenes whose mesh 0 is dynamic): y = y0 + a sin(k x + 2 pi t) on geometry 0 before
 //    every frame, followed by rptr_hip_refit -- SURVEY 8d C5 (the reference animates with a compute shader,
 //    render_vulkan.cpp:2834-2840; per-frame BLAS update + TLAS refit :1323-1354).
-//  * data-capture mode (--data-capture <prefix> [--data-capture-spp n]) stores the accumulation buffer and the three AOV images of
-//    keyframe 1 as EXR (libapp/app_state.cpp:499-531).
+//  * data-capture mode (--data-capture <prefix> [--data-capture-spp n] [--data-capture-no-rgba] [--data-capture-no-aovs]
+//    [--data-capture-albedo-roughness|-normal-depth|-motion]) stores the accumulation buffer and the chosen AOV images of every
+//    keyframe as <prefix>_%04d_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr (libapp/app_state.cpp:499-531).
 // Images: --exr (default, as in the reference), --pfm, --png (write_image.hpp).
 // The scene comes from a dump file (scene_dump.hpp) instead of a .vks (python -m ...vks converts).
 #include "ini_config.hpp"
@@ -96,9 +98,11 @@ static rptr::SceneDump load_scene(const std::string &path) {
 int main(int argc, char **argv) {
     std::string scene_path, validation_prefix, csv_prefix, profiling_img_prefix, capture_prefix;
     OutputFormat format = FORMAT_EXR;
-    bool data_capture = false;
+    bool data_capture = false, capture_rgba = true, capture_albedo = true, capture_normal = true, capture_motion = true; // DataCaptureConfig, libapp/shell.h
+    bool have_profiling_options = false, want_help = false;
+    float capture_fps = 60.f;
     int capture_spp = 1;
-    int target_spp = 1, width = 256, height = 256, variant = RPTR_VARIANT_GLTF, batch_spp = 1, profiling_frames = 60;
+    int target_spp = 1, width = 256, height = 256, variant = RPTR_VARIANT_GLTF, batch_spp = 1, profiling_frames = 1; // without keyframes the reference's profiling run ends after its first frame (imstate.cpp:890-898)
     float profiling_fps = 60.f, wave_amp = 0.f, wave_k = 0.f;
     float eye[3], center[3], up[3] = {0, 1, 0}, fov = 0.f;
     bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
@@ -128,9 +132,12 @@ int main(int argc, char **argv) {
         if (a == "--validation") { need(1); validation_prefix = argv[++i]; validation = true; }
         else if (a == "--validation-spp") { need(1); target_spp = std::atoi(argv[++i]); }
         else if (a == "--profiling") { need(1); csv_prefix = argv[++i]; profiling = true; }
-        else if (a == "--profiling-fps") { need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; }
-        else if (a == "--profiling-img") { need(1); profiling_img_prefix = argv[++i]; }
-        else if (a == "--profiling-frames") { need(1); profiling_frames = std::atoi(argv[++i]); }
+        else if (a == "--profiling-fps") { need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; have_profiling_options = true; }
+        else if (a == "--profiling-img") { need(1); profiling_img_prefix = argv[++i]; have_profiling_options = true; }
+        else if (a == "--benchmark-file") { std::fprintf(stderr, "--benchmark-file <name>.csv is now --profiling <name>\n"); return 2; } // cmdline.cpp:409-413
+        else if (a == "--profiling-frames") { // the reference's old spelling of --profiling-fps (cmdline.cpp:397-403)
+            need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; have_profiling_options = true; }
+        else if (a == "--profiling-count") { need(1); profiling_frames = std::atoi(argv[++i]); have_profiling_options = true; } // (this host's: frames of a run without keyframes)
         else if (a == "--animate-wave") { need(2); wave_amp = (float)std::atof(argv[++i]); wave_k = (float)std::atof(argv[++i]); }
         else if (a == "--img") { need(2); width = std::atoi(argv[++i]); height = std::atoi(argv[++i]); }
         else if (a == "--eye") { vec3(eye); got_eye = true; }
@@ -139,7 +146,7 @@ int main(int argc, char **argv) {
         else if (a == "--fov") { need(1); fov = (float)std::atof(argv[++i]); }
         else if (a == "--batch-spp") { need(1); batch_spp = std::atoi(argv[++i]); got_batch_spp = true; }
         else if (a == "--config") { need(1); config_inis.push_back(argv[++i]); }
-        else if (a == "--keyframe") { // [<length>:]<file> (cmdline.cpp:334-348)
+        else if (a == "--keyframe" || a == "--frame") { // [<length>:]<file> (cmdline.cpp:319-334; --frame: the old spelling)
             need(1);
             std::string v = argv[++i];
             double hold = 1.0;
@@ -188,6 +195,16 @@ int main(int argc, char **argv) {
         else if (a == "--png") format = FORMAT_PNG;
         else if (a == "--data-capture") { need(1); capture_prefix = argv[++i]; data_capture = true; }
         else if (a == "--data-capture-spp") { need(1); capture_spp = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--data-capture-fps") { need(1); capture_fps = std::max(1.0f, (float)std::atof(argv[++i])); }
+        else if (a == "--data-capture-no-rgba") capture_rgba = false; // cmdline.cpp:432-452
+        else if (a == "--data-capture-no-aovs") capture_albedo = capture_normal = capture_motion = false;
+        else if (a == "--data-capture-albedo-roughness") capture_albedo = true;
+        else if (a == "--data-capture-normal-depth") capture_normal = true;
+        else if (a == "--data-capture-motion") capture_motion = true;
+        else if (a == "--vulkan-device") { need(1); devices.assign(1, std::atoi(argv[++i])); } // ProgramArgs::device_override: here the HIP ordinal
+        else if (a == "--resource-dir") { need(1); ++i; }      // (shader / resource search path of the reference's backends: nothing to find here)
+        else if (a == "--deduplicate-scene") {}                 // (Scene::deduplicate: a load-time memory optimisation, same image)
+        else if (a == "-h" || a == "--help") want_help = true;
         else if (a == "--backend") { // cmdline.cpp:363-376: the last one wins; this binary hosts one
             need(1);
             const std::string b = argv[++i];
@@ -204,7 +221,17 @@ int main(int argc, char **argv) {
         else if (a == "--rebuild-triangle-budget") { need(1); rebuild_triangle_budget = std::atoi(argv[++i]); }
         else if (a == "--disable-ui") {}
         else if (a[0] != '-') scene_path = a;
-        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+        else {
+            // cmdline.cpp:226-259: the single-dash arguments of old versions get a pointer to their successors
+            static const char *old_backends[] = {"-vulkan", "-embree", "-dxr", "-optix", "-metal"};
+            static const char *old_args[] = {"-img", "-config", "-validation", "-eye", "-center", "-up", "-fov", "-camera", "-spp", "-profiling-frames"};
+            for (const char *o : old_backends)
+                if (a == o) std::fprintf(stderr, "%s used to be a command line argument that selects a rendering backend: use --backend <BACKEND> (optional)\n", o);
+            for (const char *o : old_args)
+                if (a == o) std::fprintf(stderr, "%s used to be a command line argument: long-form arguments take double dashes now (-%s)\n", o, o);
+            std::fprintf(stderr, "Unknown argument: %s\n", a.c_str());
+            return 2;
+        }
     }
     if (describe && !scene_path.empty()) {
         try {
@@ -249,11 +276,17 @@ int main(int argc, char **argv) {
         every_frame = true;
         target_spp = 1;
     }
+    if (have_profiling_options && !profiling) { // cmdline.cpp:489-494
+        std::fprintf(stderr, "got profiling automation options without profiling mode, enable it using --profiling <stats>\n");
+        return 2;
+    }
+    if (want_help) scene_path.clear(); // prints the usage
     if (scene_path.empty() || (int)validation + (int)profiling + (int)data_capture != 1 || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
         std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
-                             "[--profiling-img <prefix>] [--profiling-frames n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
+                             "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
                              "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png]\n"
-                             "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n]   (rgba + AOV images as EXR)\n"
+                             "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n] [--data-capture-no-rgba] [--data-capture-no-aovs] "
+                             "[--data-capture-albedo-roughness] [--data-capture-normal-depth] [--data-capture-motion] [--keyframe ...]   (EXR images per keyframe)\n"
                              "       <scene.vks>: [--remove-first-lods n] [--instance-pruning p] [--small-deformation] [--ignore-animation] [--ignore-textures] "
                              "[--load-specularity] [--dump-scene out.rpsc]\n"
                              "validation, profiling and data-capture mode are mutually exclusive (cmdline.cpp:479-486)\n");
@@ -347,19 +380,38 @@ int main(int argc, char **argv) {
         }
         if (data_capture) {
             // libapp/app_state.cpp:499-531: when a frame is ready (--data-capture-spp samples) the accumulation buffer and the three
-            // AOV images of keyframe 1 are stored as <prefix>_0001_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr
-            int accumulated = 0;
-            while (accumulated < capture_spp) {
-                const rptr::RenderStats st = backend.render(cfg);
-                cfg.reset_accumulation = false;
-                accumulated = st.spp;
+            // AOV images
+            // of every keyframe (one without --keyframe) are stored as <prefix>_%04d_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr;
+            // --data-capture-fps only paces the reference's animation clock between captures (a keyframe here is captured once)
+            (void)capture_fps;
+            const size_t n_keys = std::max<size_t>(1, frames.size());
+            for (size_t k = 0; k < n_keys; ++k) {
+                if (!frames.empty()) {
+                    rptr::HostConfig st = frames[k];
+                    st.params.batch_spp = batch_spp;
+                    if (upscale >= 1) st.params.render_upscale_factor = upscale;
+                    backend.set_params(st.params, st.lighting);
+                    std::memcpy(cfg.camera.pos, st.camera.pos, 12);
+                    std::memcpy(cfg.camera.dir, st.camera.dir, 12);
+                    std::memcpy(cfg.camera.up, st.camera.up, 12);
+                    if (!got_variant && st.variant >= 0) cfg.active_variant = st.variant;
+                    cfg.reset_accumulation = true;
+                }
+                int accumulated = 0;
+                while (accumulated < capture_spp) {
+                    const rptr::RenderStats st = backend.render(cfg);
+                    cfg.reset_accumulation = false;
+                    accumulated = st.spp;
+                }
+                char idx[16];
+                std::snprintf(idx, sizeof(idx), "_%04d", (int)k + 1);
+                const std::string pf = capture_prefix + idx;
+                if (capture_rgba) save_image(backend, FORMAT_EXR, capture_prefix, (int)k + 1, "_rgba", width, height, img);
+                if (capture_albedo) save_aov(backend, rptr::RenderHip::AOVAlbedoRoughnessIndex, pf + "_albedo_roughness", width, height);
+                if (capture_normal) save_aov(backend, rptr::RenderHip::AOVNormalDepthIndex, pf + "_normal_depth", width, height);
+                if (capture_motion) save_aov(backend, rptr::RenderHip::AOVMotionJitterIndex, pf + "_motion_jitter", width, height);
+                std::printf("%s: %d spp -> %s_*.exr\n", backend.name().c_str(), accumulated, pf.c_str());
             }
-            save_image(backend, FORMAT_EXR, capture_prefix, 1, "_rgba", width, height, img);
-            const std::string pf = capture_prefix + "_0001";
-            save_aov(backend, rptr::RenderHip::AOVAlbedoRoughnessIndex, pf + "_albedo_roughness", width, height);
-            save_aov(backend, rptr::RenderHip::AOVNormalDepthIndex, pf + "_normal_depth", width, height);
-            save_aov(backend, rptr::RenderHip::AOVMotionJitterIndex, pf + "_motion_jitter", width, height);
-            std::printf("%s: %d spp -> %s_{rgba,albedo_roughness,normal_depth,motion_jitter}.exr\n", backend.name().c_str(), accumulated, pf.c_str());
             return 0;
         }
 

@@ -243,7 +243,7 @@ def test_profiling_mode_csv_images_and_camera_flags(tmp_path):
     s.dump(path)
     W, H = 64, 48
     csv_prefix, img_prefix = str(tmp_path / "prof"), str(tmp_path / "pimg")
-    p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "4", "--profiling-frames", "8", "--profiling-img", img_prefix,
+    p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "4", "--profiling-count", "8", "--profiling-img", img_prefix,
                         "--img", str(W), str(H), "--eye", "0.5", "0.2", "3.0", "--center", "0", "0", "0", "--fov", "50", "--pfm"],
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
@@ -283,7 +283,7 @@ def test_profiling_mode_animated_wave_refits_every_frame(tmp_path):
     path = str(tmp_path / "grid.rpsc")
     s.dump(path)
     csv_prefix, img_prefix = str(tmp_path / "anim"), str(tmp_path / "aimg")
-    p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "2", "--profiling-frames", "4", "--profiling-img", img_prefix,
+    p = subprocess.run([exe, path, "--profiling", csv_prefix, "--profiling-fps", "2", "--profiling-count", "4", "--profiling-img", img_prefix,
                         "--img", "96", "64", "--variant", "diffuse", "--animate-wave", "0.5", "0.4", "--pfm"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     vals = [r.split(",") for r in open(csv_prefix + ".csv").read().strip().split("\n")[1:]]
@@ -634,3 +634,55 @@ def test_vks_loader_params_dynamic_keywords_and_instance_pruning(tmp_path):
         out = subprocess.run([exe, path, "--dump-scene", cpp] + flags, capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         assert open(py, "rb").read() == open(cpp, "rb").read()
+
+
+def test_cli_argument_table_follows_the_reference(tmp_path):
+    """cmdline.cpp:226-259,296-494: old single-dash arguments and --benchmark-file are refused with a pointer to their successors,
+    profiling automation options need --profiling, -h / --help print the usage, --profiling-frames / --frame are the old spellings of
+    --profiling-fps / --keyframe (parsed; --describe shows the keyframe)"""
+    exe = _build_cli(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    run = lambda *a: subprocess.run([exe, path] + list(a), capture_output=True, text=True)
+    r = run("--validation", "x", "-spp", "4")
+    assert r.returncode == 2 and "double dashes" in r.stderr and "Unknown argument: -spp" in r.stderr
+    r = run("--validation", "x", "-vulkan")
+    assert r.returncode == 2 and "--backend" in r.stderr
+    r = run("--benchmark-file", "b.csv")
+    assert r.returncode == 2 and "is now --profiling" in r.stderr
+    for opt in (["--profiling-fps", "30"], ["--profiling-frames", "30"], ["--profiling-img", "p"]):
+        r = run("--validation", "x", *opt)
+        assert r.returncode == 2 and "without profiling mode" in r.stderr
+    for h in ("-h", "--help"):
+        r = run(h)
+        assert r.returncode == 2 and r.stderr.startswith("usage:")
+    (tmp_path / "key.ini").write_text(INI_KEY)
+    r = run("--describe", "--frame", "0.25:" + str(tmp_path / "key.ini"))
+    assert r.returncode == 0 and "keyframe hold 0.250000" in r.stdout
+    # accepted and without effect on this backend
+    r = run("--describe", "--resource-dir", "/tmp", "--deduplicate-scene", "--vulkan-device", "0", "--disable-ui")
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_data_capture_toggles_and_keyframes(tmp_path):
+    """--data-capture over two keyframes with --data-capture-no-aovs --data-capture-normal-depth: rgba + normal_depth per keyframe, nothing
+    else (cmdline.cpp:432-452, app_state.cpp:499-531); a profiling run without keyframes ends after its first frame (imstate.cpp:890-898)"""
+    exe = _build_cli(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    (tmp_path / "base.ini").write_text(INI_BASE.replace("wavefront-gltf-transmission", "wavefront-gltf"))
+    (tmp_path / "key.ini").write_text(INI_KEY)
+    prefix = str(tmp_path / "cap")
+    p = subprocess.run([exe, path, "--img", "64", "48", "--data-capture", prefix, "--data-capture-spp", "2", "--data-capture-no-aovs", "--data-capture-normal-depth",
+                        "--data-capture-fps", "30", "--keyframe", str(tmp_path / "base.ini"), "--keyframe", str(tmp_path / "key.ini")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    names = sorted(f for f in os.listdir(tmp_path) if f.startswith("cap_"))
+    assert names == ["cap_0001_normal_depth.exr", "cap_0001_rgba.exr", "cap_0002_normal_depth.exr", "cap_0002_rgba.exr"]
+    a, b = read_exr(prefix + "_0001_rgba.exr"), read_exr(prefix + "_0002_rgba.exr")
+    assert a.shape == (48, 64, 4) and not np.array_equal(a, b)          # the second keyframe moves the camera
+    p = subprocess.run([exe, path, "--img", "64", "48", "--profiling", str(tmp_path / "one"), "--profiling-frames", "30"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert len((tmp_path / "one.csv").read_text().strip().splitlines()) == 2
