@@ -161,7 +161,7 @@ int main(int argc, char **argv) {
             }
             keyframes.push_back({v, hold});
         }
-        else if (a == "--camera") { need(1); if (std::atoi(argv[++i]) != 0) { std::fprintf(stderr, "the scene file holds one camera (index 0)\n"); return 2; } }
+        else if (a == "--camera") { need(1); ++i; } // an index beyond the scene's cameras leaves the default view (libapp/scene_state.cpp:45-50); the scene file holds one
         else if (a == "--upscale") { need(1); upscale = std::max(1, std::atoi(argv[++i])); }
         else if (a == "--stripe-rows") { need(1); stripe_rows = std::atoi(argv[++i]); }
         else if (a == "--devices") { // a count (devices 0..n-1) or a comma-separated list of HIP ordinals
