@@ -77,18 +77,26 @@ def build_library(force=False, verbose=False, extra_flags=(), lib_path=LIB_PATH,
 
 
 HOST_TOOLS = {"rptr_hip": "rptr_cli.cpp", "demo_host": "demo_host.cpp"}
+PLAIN_TOOLS = {"rptr_compare": ("rptr_compare.cpp", ["-lz"])}  # no backend behind them
 BIN_DIR = os.path.join(HERE, "bin")
 
 
 def build_host_tools(verbose=False):
     """The C++ host programs over the C ABI (g++, no HIP headers): bin/rptr_hip (the reference's headless --validation / --profiling runs:
-    .pfm images, profiling CSV), bin/demo_host."""
+    .pfm images, profiling CSV), bin/demo_host, bin/rptr_compare (the reference's compare_exr)."""
     os.makedirs(BIN_DIR, exist_ok=True)
     out = []
     for name, src in HOST_TOOLS.items():
         exe = os.path.join(BIN_DIR, name)
         cmd = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HERE, "host", src), "-o", exe, "-L" + HERE, "-lrptr_hip",
                "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        out.append(exe)
+    for name, (src, libs) in PLAIN_TOOLS.items():
+        exe = os.path.join(BIN_DIR, name)
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HERE, "host", src), "-o", exe] + libs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

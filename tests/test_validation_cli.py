@@ -686,3 +686,113 @@ def test_cli_data_capture_toggles_and_keyframes(tmp_path):
     p = subprocess.run([exe, path, "--img", "64", "48", "--profiling", str(tmp_path / "one"), "--profiling-frames", "30"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert len((tmp_path / "one.csv").read_text().strip().splitlines()) == 2
+
+
+# ---------------------------------------------------------------- rptr_compare (util/compare_exr.cpp)
+def _build_compare(tmp_path):
+    exe = str(tmp_path / "rptr_compare")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(HOST, "rptr_compare.cpp"), "-o", exe, "-lz"])
+    return exe
+
+
+def write_exr_py(path, planes, half=False, compression=0):
+    """a scan-line OpenEXR file written independently of host/write_image.hpp: `planes` = {channel name: (h, w) array}, channels stored in
+    alphabetical order as FLOAT or HALF, compression NONE (0), ZIPS (2) or ZIP (3) with OpenEXR's byte shuffle + delta predictor"""
+    import struct
+    import zlib
+    names = sorted(planes)
+    h, w = planes[names[0]].shape
+    dt = np.float16 if half else np.float32
+
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(value)) + value
+    ch = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if half else 2, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", ch) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + \
+        attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + \
+        attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lines):
+        raw = b"".join(np.ascontiguousarray(planes[n][y], dtype=dt).tobytes() for y in range(y0, min(h, y0 + lines)) for n in names)
+        data = raw
+        if compression:
+            b = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)
+            d = t.copy()
+            d[1:] = (t[1:] - t[:-1] + 128 + 256) & 0xFF
+            z = zlib.compress(d.astype(np.uint8).tobytes())
+            data = z if len(z) < len(raw) else raw
+        blocks.append(struct.pack("<iI", y0, len(data)) + data)
+    table_at = len(head)
+    offs, at = [], table_at + 8 * len(blocks)
+    for b in blocks:
+        offs.append(at)
+        at += len(b)
+    with open(path, "wb") as f:
+        f.write(head + struct.pack("<%dQ" % len(offs), *offs) + b"".join(blocks))
+
+
+def test_compare_tool_follows_compare_exr(tmp_path):
+    """util/compare_exr.cpp:51-97: per value |ref - cmp| / ref (|cmp| where ref is 0), above 1e-6 anywhere = not the same, exit code -1,
+    the error of every value in <CMP>_err.exr; EXR files with NONE / ZIPS / ZIP compression, FLOAT and HALF channels; PFM; PIZ refused"""
+    exe = _build_compare(tmp_path)
+    rng = np.random.default_rng(3)
+    H, W = 37, 29
+    base = {n: rng.random((H, W)).astype(np.float32) + 0.25 for n in "RGBA"}
+    base["R"][0, 0] = 0.0
+    same = {n: v.copy() for n, v in base.items()}
+    close = {n: v * np.float32(1.0 + 4e-7) for n, v in base.items()}
+    off = {n: v.copy() for n, v in base.items()}
+    off["G"][5, 7] *= np.float32(1.0 + 1e-5)
+    off["R"][0, 0] = 3e-6
+    for name, planes, comp in (("ref", base, 0), ("same", same, 3), ("close", close, 2), ("off", off, 3)):
+        write_exr_py(str(tmp_path / (name + ".exr")), planes, compression=comp)
+    run = lambda *a: subprocess.run([exe] + [str(tmp_path / x) for x in a], capture_output=True, text=True)
+    r = run("ref.exr", "same.exr", "close.exr")
+    assert r.returncode == 0 and "Comparing" in r.stdout, r.stderr
+    r = run("ref.exr", "same.exr", "off.exr")
+    assert r.returncode == 255 and "off.exr isn't the same as" in r.stderr and "same.exr isn't" not in r.stderr
+    err = read_exr(str(tmp_path / "off.exr_err.exr"))
+    want = np.zeros((H, W, 4), np.float32)
+    want[5, 7, 1] = abs(base["G"][5, 7] - off["G"][5, 7]) / base["G"][5, 7]
+    want[0, 0, 0] = np.float32(3e-6)
+    assert np.array_equal(err, want)
+    # half channels (what the AOV captures hold), a PFM pair, a size mismatch, an unsupported compression, the usage
+    hb = {n: v.astype(np.float16) for n, v in base.items()}
+    write_exr_py(str(tmp_path / "h1.exr"), hb, half=True, compression=0)
+    write_exr_py(str(tmp_path / "h2.exr"), hb, half=True, compression=3)
+    assert run("h1.exr", "h2.exr").returncode == 0
+    from realtimepathtracingresearchframework_amd.scenes import f32
+    for name, scale in (("p1", 1.0), ("p2", 1.0), ("p3", 1.001)):
+        with open(tmp_path / (name + ".pfm"), "wb") as f:
+            f.write(b"PF\n%d %d\n-1.0\n" % (W, H))
+            f.write(np.ascontiguousarray(np.stack([base[c] * f32(scale) for c in "RGB"], axis=-1)[::-1]).tobytes())
+    assert run("p1.pfm", "p2.pfm").returncode == 0 and run("p1.pfm", "p3.pfm").returncode == 255
+    write_exr_py(str(tmp_path / "small.exr"), {n: v[:10] for n, v in base.items()})
+    r = run("ref.exr", "small.exr")
+    assert r.returncode == 255 and "same size" in r.stderr
+    raw = bytearray(open(tmp_path / "ref.exr", "rb").read())
+    k = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    raw[k] = 4
+    open(tmp_path / "piz.exr", "wb").write(raw)
+    r = run("ref.exr", "piz.exr")
+    assert r.returncode == 255 and "PIZ" in r.stderr
+    assert subprocess.run([exe, str(tmp_path / "ref.exr")], capture_output=True).returncode == 255
+
+
+@pytest.mark.gpu
+def test_validation_images_through_the_compare_tool(tmp_path):
+    """the reference's regression workflow end to end: two --validation runs of the same configuration compare equal (exit 0), a run with
+    another sample count does not"""
+    exe, cmp = _build_cli(tmp_path), _build_compare(tmp_path)
+    s = scenes.cornell32()
+    path = str(tmp_path / "c.rpsc")
+    s.dump(path)
+    for tag, spp in (("a", 4), ("b", 4), ("c", 5)):
+        r = subprocess.run([exe, path, "--img", "96", "64", "--validation", str(tmp_path / tag), "--validation-spp", str(spp)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert subprocess.run([cmp, str(tmp_path / "a_0004.exr"), str(tmp_path / "b_0004.exr")], capture_output=True).returncode == 0
+    r = subprocess.run([cmp, str(tmp_path / "a_0004.exr"), str(tmp_path / "c_0005.exr")], capture_output=True, text=True)
+    assert r.returncode == 255 and "isn't the same" in r.stderr and os.path.exists(str(tmp_path / "c_0005.exr_err.exr"))
