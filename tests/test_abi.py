@@ -55,3 +55,67 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in src and "oracle_lib" not in src and "orc_" not in src, os.path.join(dirpath, f)
+
+
+ABI_REF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "libabi_ref.so")
+
+
+@pytest.mark.skipif(not os.path.exists(ABI_REF), reason="oracle/_ref/libabi_ref.so is built from the reference tree (oracle/Makefile)")
+def test_boundary_structs_and_constants_against_the_references_headers():
+    """pinned by oracle/_ref: the reference's dual-language headers (render_params.glsl.h, base_material.h.glsl, tri.h.glsl,
+    sky_model.h.glsl, pathspace.h, sobol_data.h, bn_data.h, texture_channel_mask.h) compiled where they lie report sizes, member
+    offsets, default values and constants; the ctypes mirrors of include/rptr_hip.h, their defaults and the header's constants agree"""
+    import json
+    import struct
+    L = C.CDLL(ABI_REF)
+    L.ref_abi_json.restype = C.c_char_p
+    ref = json.loads(L.ref_abi_json())
+    for cls, name in ((abi.RenderParams, "RenderParams"), (abi.LightSamplingConfig, "LightSamplingConfig"), (abi.BaseMaterial, "BaseMaterial"),
+                      (abi.RenderRayQuery, "RenderRayQuery"), (abi.TriLightData, "TriLightData"), (abi.SkyModelParams, "SkyModelParams")):
+        assert C.sizeof(cls) == ref["sizeof_" + name], name
+        alias = {"v0_x": "v0", "v1_x": "v1", "v2_x": "v2", "radiance_x": "radiance"}
+        seen = 0
+        for key, off in ref.items():
+            if key.startswith("offsetof_%s_" % name):
+                field = key[len("offsetof_%s_" % name):]
+                assert getattr(cls, alias.get(field, field)).offset == off, key
+                seen += 1
+        assert seen >= 2, name
+    for obj, name in ((abi.RenderParams.default(), "RenderParams"), (abi.LightSamplingConfig.default(), "LightSamplingConfig"),
+                      (abi.make_material(flags=0), "BaseMaterial")):
+        n = 0
+        for key, val in ref.items():
+            if key.startswith("default_%s_" % name) and not key.endswith(("_x", "_y")):
+                assert np.float32(getattr(obj, key[len("default_%s_" % name):])) == np.float32(val), key
+                n += 1
+        assert n >= 4, name
+    m = abi.make_material(flags=0)
+    assert np.float32(m.base_color[0]) == np.float32(ref["default_BaseMaterial_base_color_x"]) and m.transmission_color[0] == ref["default_BaseMaterial_transmission_color_x"]
+    # constants of the header (through abi.py, which test_struct_sizes / the symbol tests hold against include/rptr_hip.h)
+    hdr = open(os.path.join(os.path.dirname(ABI_REF), "..", "..", "include", "rptr_hip.h")).read()
+    def define(name):
+        return eval(re.search(r"#define %s\s+(.+?)\s*(/\*|$)" % name, hdr, re.M).group(1).replace("u", "").replace("f", ""))
+    assert define("RPTR_MAX_PATH_DEPTH") == abi.MAX_PATH_DEPTH == ref["MAX_PATH_DEPTH"]
+    assert define("RPTR_DEFAULT_RR_PATH_DEPTH") == abi.DEFAULT_RR_PATH_DEPTH == ref["DEFAULT_RR_PATH_DEPTH"]
+    assert define("RPTR_BINNED_LIGHTS_BIN_MAX_SIZE") == abi.BINNED_LIGHTS_BIN_MAX_SIZE == ref["BINNED_LIGHTS_BIN_MAX_SIZE"]
+    for k in ("UNIFORM", "BN", "SOBOL", "Z_SBL"):
+        assert define("RPTR_RNG_VARIANT_" + k) == getattr(abi, "RNG_VARIANT_" + k) == ref["RNG_VARIANT_" + k]
+    for k in ("NOALPHA", "ONESIDED", "VOLUME", "EXTENDED"):
+        assert define("RPTR_BASE_MATERIAL_" + k) == ref["BASE_MATERIAL_" + k]
+    assert define("RPTR_SOBOL_TABLE_BYTES") == abi.SOBOL_TABLE_BYTES == ref["sizeof_SobolData"]
+    assert ref["offsetof_SobolData_tile_invert_1_0"] == 1024 * 32 * 4
+    assert define("RPTR_BN_TABLE_MIN_BYTES") == abi.BN_TABLE_MIN_BYTES == ref["offsetof_BNData_tile_scrambling_yx_d_4spp"]     # the 1 spp prefix of BNData
+    assert [define("RPTR_AOV_" + k) for k in ("ALBEDO_ROUGHNESS", "NORMAL_DEPTH", "MOTION_JITTER")] == \
+        [ref["OUTPUT_CHANNEL_" + k] - 1 for k in ("ALBEDO_ROUGHNESS", "NORMAL_DEPTH", "MOTION_JITTER")]
+    assert (ref["REPROJECTION_MODE_NONE"], ref["REPROJECTION_MODE_DISCARD_HISTORY"]) == (0, 1)            # kernels_misc.h rp_k_resolve, oracle.cpp
+    assert ref["default_RenderBackendOptions_rebuild_triangle_budget"] == 500000 and ref["default_RenderBackendOptions_force_bvh_rebuild"] == 0
+    assert ref["DEFAULT_RAY_QUERY_BUDGET"] == 512 * 512
+    # the dimension map of the table point sets (csrc/dshade.h RP_DIM_*, kernels.h draw sites; oracle/oshade.h DIM_*)
+    dsh = open(os.path.join(os.path.dirname(build.LIB_PATH), "csrc", "dshade.h")).read()
+    assert int(re.search(r"#define RP_DIM_CAMERA_END (\d+)u", dsh).group(1)) == ref["DIM_CAMERA_END"]
+    assert int(re.search(r"#define RP_DIM_BOUNCE (\d+)u", dsh).group(1)) == ref["DIM_VERTEX_END"] + ref["DIM_LIGHT_END"]
+    assert (ref["DIM_PIXEL_X"], ref["DIM_DIRECTION_X"], ref["DIM_LOBE"], ref["DIM_RR"], ref["DIM_LIGHT_SEL_1"], ref["DIM_POSITION_X"]) == (0, 0, 2, -1, 0, 2)
+    # texture handles (rendering/bsdfs/texture_channel_mask.h)
+    bits = struct.unpack("<I", struct.pack("<f", abi.textured_param(1234, 2)))[0]
+    assert bits == ref["texture_handle_1234_2"] and (bits & 0x1FFFFFFF, (bits >> 29) & 3) == (ref["texture_handle_id"], ref["texture_handle_channel"])
+    assert (ref["STANDARD_TEXTURE_NORMAL_SLOT"], ref["STANDARD_TEXTURE_BASECOLOR_SLOT"], ref["STANDARD_TEXTURE_SPECULAR_SLOT"]) == (0, 1, 2)
