@@ -476,3 +476,66 @@ def test_gather_all_when_some_ranks_own_no_rows():
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     for r in rs:
         r.close()
+
+
+# ---------------------------------------------------------------- C2 as bench.py runs it
+@pytest.mark.parametrize("rng_variant", [abi.RNG_VARIANT_UNIFORM, abi.RNG_VARIANT_Z_SBL])
+def test_c2_full_size_on_the_benchmarked_schedule(rng_variant):
+    """BASELINE.json configs[1] exactly as the bench line times it: 1 M triangles, 1920x1080, 4 spp, Lambert, 11 frame contexts, four frames
+    per launch sequence, every frame restarting the accumulation (frame k is seeded with frame_offset = 4 k). Frames 0, 5 and 11 of a
+    12-frame run against the oracle on bands of rows (RMSE < 1e-3, coverage identical), the ray counts of every frame against each other,
+    and the whole run against the same frames rendered one at a time on a fresh handle, bit for bit. Also with the Z-Sobol point set."""
+    from realtimepathtracingresearchframework_amd import pointsets
+    s = scenes.grid_1m()
+    W, H, spp, frames = 1920, 1080, 4, 12
+    cam = s.camera_params()
+    table = pointsets.default_table(rng_variant) if rng_variant != abi.RNG_VARIANT_UNIFORM else None
+
+    def run(fif, batch):
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(s)
+        if rng_variant != abi.RNG_VARIANT_UNIFORM:
+            r.set_rng_variant(rng_variant, table)
+        images, stats, queue, left = [], [], [], frames
+
+        def collect(tickets):
+            for t in tickets:
+                stats.append(r.wait(t))
+                img = np.zeros((H, W, 4), np.float32)
+                r.readback_framebuffer(img)
+                images.append(img)
+        while left > 0:
+            cfg = backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
+            n = min(batch, left)
+            queue.append(r.render_batch_async(cfg, spp=spp, n_frames=n, reset_rest=True) if n > 1 else [r.render_async(cfg, spp=spp)])
+            left -= n
+            if len(queue) >= fif:
+                collect(queue.pop(0))
+        while queue:
+            collect(queue.pop(0))
+        r.close()
+        return images, stats
+    fast, fast_stats = run(11, 4)
+    slow, slow_stats = run(1, 1)
+    for k in range(frames):
+        assert np.array_equal(fast[k].view(np.uint32), slow[k].view(np.uint32)), k
+        assert fast_stats[k].spp == spp and W * H * spp <= fast_stats[k].raw.rays_closest <= 9 * W * H * spp
+    # the frames of a launch sequence share its counters (every frame reports a quarter of the sequence's rays): sums per sequence
+    for g in range(0, frames, 4):
+        for field in ("rays_closest", "rays_shadow", "hits_shaded"):
+            together = sum(getattr(fast_stats[k].raw, field) for k in range(g, g + 4))
+            apart = sum(getattr(slow_stats[k].raw, field) for k in range(g, g + 4))
+            assert abs(together - apart) < 4, (g, field, together, apart)
+    assert not np.array_equal(fast[0], fast[1])                      # another frame_offset, other samples
+    osc = O.OracleScene(s)
+    if rng_variant != abi.RNG_VARIANT_UNIFORM:
+        osc.set_rng_variant(rng_variant, table)
+    osc.build_bvh()
+    # the ray counts of a frame rendered on its own are the oracle's, to the ray (SURVEY 8d counting rule)
+    _, ost = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE, frame_offset=0)
+    assert (ost.rays_closest, ost.rays_shadow, ost.hits_shaded) == (slow_stats[0].raw.rays_closest, slow_stats[0].raw.rays_shadow, slow_stats[0].raw.hits_shaded)
+    for k, rows in ((0, (556, 560)), (5, (700, 704)), (11, (1000, 1004))):
+        ref, _ = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE, rows=rows, frame_offset=spp * k)
+        rmse, same, maxabs = image_error(fast[k][rows[0]:rows[1]], ref[rows[0]:rows[1]])
+        assert same and rmse < RMSE_TOL, (k, rows, rmse, maxabs)
