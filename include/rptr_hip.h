@@ -220,8 +220,12 @@ typedef struct RptrInstanceDesc {
     uint32_t parameterized_mesh;
 } RptrInstanceDesc;
 
-/* A texture: RGBA8, row 0 first, sampled like the reference's material sampler (render_vulkan.cpp:1657-1670: linear filter,
- * REPEAT addressing) at mip level 0 (textureLod(..., 0), rendering/rt/material_textures.glsl:37-60 with NO_TEXTURE_GRAD);
+/* A texture: RGBA8, row 0 first, sampled like the reference's material sampler (render_vulkan.cpp:1657-1670: linear filter, linear
+ * mip filter, REPEAT addressing, anisotropy 12) over the footprint the path carries to the hit: textureGrad(uv, duvdxy) for material
+ * parameters (rendering/rt/material_textures.glsl:37-75 with USE_MIPMAPPING, librender/render_params.glsl.h:8), textureLod(uv, bounce)
+ * for normal maps (pt_megakernel.glsl:642-648), level 0 for the any-hit alpha test (:205).
+ * mip_levels: 0 or 1 = level 0 only; n = rgba8 holds levels 0..n-1 back to back, level l being max(1, width >> l) x max(1, height >> l)
+ * texels (what a .vkt file holds; none is generated: vulkan/resource_utils.cpp:34-100 uploads the levels of the file).
  * srgb != 0: the colour channels are sRGB-encoded (VK_FORMAT_R8G8B8A8_SRGB), alpha is linear. A float material parameter
  * with its sign bit set is a texture handle (rendering/bsdfs/texture_channel_mask.h): bits 0..28 = index into
  * RptrSceneDesc.textures, bits 29..30 = channel for scalar parameters. */
@@ -232,7 +236,7 @@ typedef struct RptrTextureDesc {
     const uint8_t *rgba8;
     uint32_t width, height;
     uint32_t srgb;
-    uint32_t _pad;
+    uint32_t mip_levels;
 } RptrTextureDesc;
 
 typedef struct RptrSceneDesc {

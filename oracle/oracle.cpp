@@ -434,7 +434,7 @@ struct ShadingSampleState { // rendering/mc/shading_interface.glsl:15-22
 // rendering/mc/shade_base_material.glsl:14-96
 template <class MAT>
 static int shade_base_material(const Frame &f, float geometry_scale, ShadingSampleState &state, vec3 &illum, vec3 &path_throughput,
-                               const RptrBaseMaterial &params, vec2 hit_uv, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
+                               const RptrBaseMaterial &params, const TexCoord &hit_uv, float approx_solid_angle, vec3 w_o, const InteractionPoint &interaction,
                                RandomState &rng, vec3 &w_i, PathCounters &pc) {
     MAT mat;
     vec3 emit_radiance;
@@ -500,6 +500,15 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
     float t_min = 0;
     float t_max = 2.e32f;
     float total_t = 0.0f;
+    // :336-352 (USE_MIPMAPPING, librender/render_params.glsl.h:8): the pixel's footprint, carried along the path for the texture lookups
+    mat2 texture_footprint(0.0f);
+    {
+        vec3 dpdx = f.vp.cam_du / (float)f.vp.dims_x;
+        vec3 dpdy = f.vp.cam_dv / (float)f.vp.dims_y;
+        dpdx = dpdx * f.rp.pixel_radius;
+        dpdy = dpdy * f.rp.pixel_radius;
+        texture_footprint = dpdxy_to_footprint(ray_dir, dpdx, dpdy);
+    }
     vec3 illum = vec3(0.f);
     vec3 path_throughput = vec3(1.f);
     ShadingSampleState shading_state{0, f.rp.output_channel, 2.e16f};
@@ -545,8 +554,21 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
         float approx_tri_solid_angle = length(hit.geo_normal);
         hit.geo_normal /= approx_tri_solid_angle;
         approx_tri_solid_angle *= fabsf(dot(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
-        // :585,605 (texture footprint itself is dead without textured parameters)
+        // :582-606: the footprint on the surface as uv derivatives
         total_t += hit.dist;
+        TexCoord hit_tc(hit.uv);
+        {
+            vec3 dpdx, dpdy;
+            footprint_to_dpdxy(dpdx, dpdy, ray_dir, texture_footprint);
+            const vec3 dir_tangent_un = ray_dir - hit.geo_normal * dot(ray_dir, hit.geo_normal);
+            const float cosTheta2 = fmaxf(1.0f - dot(dir_tangent_un, dir_tangent_un), 0.0f);
+            const vec3 dir_tangent_elong = dir_tangent_un / (sqrtf(cosTheta2) + cosTheta2);
+            const vec3 dpdx_ = dpdx + dir_tangent_elong * dot(dpdx, dir_tangent_un);
+            const vec3 dpdy_ = dpdy + dir_tangent_elong * dot(dpdy, dir_tangent_un);
+            const vec3 bitangent = hit.bitangent_l * cross(hit.geo_normal, normalize(hit.tangent));
+            hit_tc.ddx = vec2(dot(hit.tangent, dpdx_), dot(bitangent, dpdx_)) * total_t; // duvdxy[0]
+            hit_tc.ddy = vec2(dot(hit.tangent, dpdy_), dot(bitangent, dpdy_)) * total_t; // duvdxy[1]
+        }
         float geometry_scale = total_t;
         const vec3 w_o = -ray_dir;
         InteractionPoint interaction;
@@ -573,7 +595,8 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
             vec3 t_x = cross(t_y, hit.normal);
             t_x = t_x * length(hit.tangent);
             t_y = t_y * hit.bitangent_l;
-            const vec4 tx = texture_lod0(sc.textures, mparams.normal_map, hit.uv);
+            // :642-648: "for now, reduce normal resolution with bounces"
+            const vec4 tx = texture_lod(sc.textures, mparams.normal_map, hit.uv, float(shading_state.bounce));
             vec3 map_nrm(2.0f * tx.x - 1.0f, 2.0f * tx.y - 1.0f, 1.0f * tx.z - 0.0f);
             // Z encoding might be unclear, just reconstruct
             map_nrm.z = sqrtf(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
@@ -599,10 +622,11 @@ static vec4 main_spp(const Frame &f, uint32_t px, uint32_t py, uint32_t sample_i
             fprintf(stderr, "[b%d] t=%g uv=(%g,%g) inst=%d geom=%d prim=%d mat=%d p=(%g,%g,%g) n=(%g,%g,%g) gn=(%g,%g,%g) tan=(%g,%g,%g) thr=(%g,%g,%g) illum=(%g,%g,%g) sa=%g\n", b, h.t, h.u, h.v,
                     h.inst, h.geom, h.prim, hit.material_id, interaction.p.x, interaction.p.y, interaction.p.z, interaction.n.x, interaction.n.y,
                     interaction.n.z, interaction.gn.x, interaction.gn.y, interaction.gn.z, hit.tangent.x, hit.tangent.y, hit.tangent.z, path_throughput.x, path_throughput.y, path_throughput.z, illum.x, illum.y, illum.z, approx_tri_solid_angle);
-        int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams, hit.uv,
+        int shading_result = shade_base_material<MAT>(f, geometry_scale, shading_state, illum, path_throughput, mparams, hit_tc,
                                                       approx_tri_solid_angle, w_o, interaction, rng, w_i, pc);
         if (shading_result == SHADING_RESULT_TERMINATE) break;
-        // :703-709
+        // :698-709
+        if (dot(w_i, interaction.n) * dot(w_o, interaction.n) > -0.999f) texture_footprint = reflect_footprint(w_i, ray_dir, texture_footprint);
         ray_dir = w_i;
         ray_origin = interaction.p;
         t_min = geometry_scale_to_tmin(ray_origin, total_t);
@@ -1145,6 +1169,28 @@ void orc_texture_probe(void *p, int tex_id, const float *uv, int n, float *out4)
         const vec4 c = texture_lod0(s->textures, tex_id, vec2(uv[2 * i], uv[2 * i + 1]));
         out4[4 * i] = c.x; out4[4 * i + 1] = c.y; out4[4 * i + 2] = c.z; out4[4 * i + 3] = c.w;
     }
+}
+// ... textureGrad(uv, ddx, ddy) (mode 0; 6 floats per sample) / textureLod(uv, lod) (mode 1; uv + lod in ddx[0], same stride)
+void orc_texture_probe_ex(void *p, int tex_id, int mode, const float *uv_ddx_ddy, int n, float *out4) {
+    Scene *s = (Scene *)p;
+    for (int i = 0; i < n; ++i) {
+        const float *q = uv_ddx_ddy + 6 * i;
+        const vec4 c = mode == 0 ? texture_grad(s->textures, tex_id, TexCoord(vec2(q[0], q[1]), vec2(q[2], q[3]), vec2(q[4], q[5])))
+                                 : texture_lod(s->textures, tex_id, vec2(q[0], q[1]), q[2]);
+        out4[4 * i] = c.x; out4[4 * i + 1] = c.y; out4[4 * i + 2] = c.z; out4[4 * i + 3] = c.w;
+    }
+}
+// rendering/rt/footprint.glsl on one input: F = dpdxy_to_footprint(dir, dpdx, dpdy) -> out[0..3] (column major), footprint_to_dpdxy(dir, F)
+// -> out[4..9], reflect_footprint(dst_dir, dir, F) -> out[10..13]
+void orc_footprint_probe(const float *dir, const float *dpdx, const float *dpdy, const float *dst_dir, float *out) {
+    const vec3 d(dir[0], dir[1], dir[2]);
+    const mat2 F = dpdxy_to_footprint(d, vec3(dpdx[0], dpdx[1], dpdx[2]), vec3(dpdy[0], dpdy[1], dpdy[2]));
+    out[0] = F[0][0]; out[1] = F[0][1]; out[2] = F[1][0]; out[3] = F[1][1];
+    vec3 a, b;
+    footprint_to_dpdxy(a, b, d, F);
+    out[4] = a.x; out[5] = a.y; out[6] = a.z; out[7] = b.x; out[8] = b.y; out[9] = b.z;
+    const mat2 R = reflect_footprint(vec3(dst_dir[0], dst_dir[1], dst_dir[2]), d, F);
+    out[10] = R[0][0]; out[11] = R[0][1]; out[12] = R[1][0]; out[13] = R[1][1];
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }

@@ -403,10 +403,16 @@ struct SimpleMaterial {
     float ior;
     uint32_t flags;
 };
-// ---- textures: textureLod(sampler2D, uv, 0) with the reference's material sampler (render_vulkan.cpp:1657-1670: linear
-// filter, REPEAT addressing), restated in software. Texel centres at (i + 0.5) / size, bilinear weights in float, unorm
-// byte / 255, sRGB decode (IEC 61966-2-1) per texel before filtering. The reference runs this on the GPU's texture unit,
-// whose fixed-point weights are not specified bit for bit: "parity unpinned", tolerance-level agreement only.
+// ---- textures: the reference's material sampler (render_vulkan.cpp:1657-1670: linear filter, linear mip filter, REPEAT addressing,
+// LOD range 0..16, anisotropy 12) restated in software after the Vulkan specification's "Texel filtering" equations -- what the texture
+// unit of the reference's GPU implements up to its fixed-point weights: "parity unpinned", tolerance-level agreement only.
+// Texel centres at (i + 0.5) / size, bilinear weights in float, unorm byte / 255, sRGB decode (IEC 61966-2-1) per texel before filtering.
+//   textureLod(uv, lod): lod clamped to the texture's levels, the two nearest levels blended by the fraction.
+//   textureGrad(uv, ddx, ddy): rho_x = |ddx * size|, rho_y = |ddy * size|; eta = min(rho_max / rho_min, 12); N = ceil(eta) taps at
+//   uv + major * (i / (N + 1) - 1/2), i = 1..N, along the larger derivative, each a textureLod at log2(rho_max / eta), averaged.
+//   Zero derivatives (the any-hit alpha test, pt_megakernel.glsl:205) = one bilinear tap of level 0.
+// Mip levels: RptrTextureDesc.mip_levels levels stored back to back, level l = max(1, w >> l) x max(1, h >> l)
+// (vulkan/resource_utils.cpp:86-100); the reference uploads the levels its .vkt files hold and generates none.
 struct TextureTable {
     const RptrTextureDesc *textures = nullptr;
     uint32_t num_textures = 0;
@@ -418,8 +424,28 @@ struct TextureTable {
         }
     }
 };
-static inline vec4 fetch_texel(const TextureTable &tt, const RptrTextureDesc &t, int ix, int iy) {
-    const uint8_t *c = t.rgba8 + 4 * ((size_t)iy * t.width + (size_t)ix);
+// HitPoint::uv + HitPoint::duvdxy (rendering/rt/hit.glsl): where and over which footprint a material reads its textures
+struct TexCoord {
+    vec2 uv, ddx, ddy;
+    TexCoord(vec2 uv_) : uv(uv_), ddx(0, 0), ddy(0, 0) {}
+    TexCoord(vec2 uv_, vec2 ddx_, vec2 ddy_) : uv(uv_), ddx(ddx_), ddy(ddy_) {}
+};
+struct MipView {
+    const uint8_t *texels;
+    int w, h;
+};
+static inline int texture_levels(const RptrTextureDesc &t) { return t.mip_levels > 1u ? (int)t.mip_levels : 1; }
+static inline MipView mip_view(const RptrTextureDesc &t, int level) {
+    MipView v{t.rgba8, (int)t.width, (int)t.height};
+    for (int l = 0; l < level; ++l) {
+        v.texels += 4 * (size_t)v.w * (size_t)v.h;
+        if (v.w > 1) v.w /= 2;
+        if (v.h > 1) v.h /= 2;
+    }
+    return v;
+}
+static inline vec4 fetch_texel(const TextureTable &tt, const RptrTextureDesc &t, const MipView &v, int ix, int iy) {
+    const uint8_t *c = v.texels + 4 * ((size_t)iy * v.w + (size_t)ix);
     if (t.srgb) return vec4(tt.srgb_lut[c[0]], tt.srgb_lut[c[1]], tt.srgb_lut[c[2]], float(c[3]) / 255.0f);
     return vec4(float(c[0]) / 255.0f, float(c[1]) / 255.0f, float(c[2]) / 255.0f, float(c[3]) / 255.0f);
 }
@@ -427,32 +453,66 @@ static inline int wrap_repeat(int i, int n) {
     i %= n;
     return i < 0 ? i + n : i;
 }
-static inline vec4 texture_lod0(const TextureTable &tt, int tex_id, vec2 uv) {
-    const RptrTextureDesc &t = tt.textures[tex_id];
-    const int w = (int)t.width, h = (int)t.height;
+static inline vec4 texture_bilinear(const TextureTable &tt, const RptrTextureDesc &t, int level, vec2 uv) {
+    const MipView v = mip_view(t, level);
+    const int w = v.w, h = v.h;
     const float x = uv.x * float(w) - 0.5f, y = uv.y * float(h) - 0.5f;
     const float x0 = floorf(x), y0 = floorf(y);
     const float fx = x - x0, fy = y - y0;
     const int ix0 = wrap_repeat(int(x0), w), ix1 = wrap_repeat(int(x0) + 1, w);
     const int iy0 = wrap_repeat(int(y0), h), iy1 = wrap_repeat(int(y0) + 1, h);
-    const vec4 c00 = fetch_texel(tt, t, ix0, iy0), c10 = fetch_texel(tt, t, ix1, iy0), c01 = fetch_texel(tt, t, ix0, iy1),
-               c11 = fetch_texel(tt, t, ix1, iy1);
+    const vec4 c00 = fetch_texel(tt, t, v, ix0, iy0), c10 = fetch_texel(tt, t, v, ix1, iy0), c01 = fetch_texel(tt, t, v, ix0, iy1),
+               c11 = fetch_texel(tt, t, v, ix1, iy1);
     const float gx = 1.0f - fx, gy = 1.0f - fy;
     const vec4 top(c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx);
     const vec4 bot(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
     return vec4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
 }
-// rendering/rt/material_textures.glsl:37-60 (NO_TEXTURE_GRAD: textureLod with bias 0)
+static inline vec4 texture_lod(const TextureTable &tt, int tex_id, vec2 uv, float lod) {
+    const RptrTextureDesc &t = tt.textures[tex_id];
+    const float last = float(texture_levels(t) - 1);
+    lod = fminf(fmaxf(lod, 0.0f), fminf(last, 16.0f)); // (a NaN lod ends up at level 0)
+    if (!(lod > 0.0f)) return texture_bilinear(tt, t, 0, uv);
+    const float hi = floorf(lod), delta = lod - hi;
+    const vec4 a = texture_bilinear(tt, t, int(hi), uv);
+    if (delta == 0.0f) return a;
+    const vec4 b = texture_bilinear(tt, t, int(hi) + 1, uv);
+    const float g = 1.0f - delta;
+    return vec4(a.x * g + b.x * delta, a.y * g + b.y * delta, a.z * g + b.z * delta, a.w * g + b.w * delta);
+}
+static inline vec4 texture_lod0(const TextureTable &tt, int tex_id, vec2 uv) { return texture_bilinear(tt, tt.textures[tex_id], 0, uv); }
+#define ORC_MAX_ANISOTROPY 12.0f
+static inline vec4 texture_grad(const TextureTable &tt, int tex_id, const TexCoord &tc) {
+    const RptrTextureDesc &t = tt.textures[tex_id];
+    const float w = float(t.width), h = float(t.height);
+    const float mxx = tc.ddx.x * w, mxy = tc.ddx.y * h, myx = tc.ddy.x * w, myy = tc.ddy.y * h;
+    const float rx = sqrtf(mxx * mxx + mxy * mxy), ry = sqrtf(myx * myx + myy * myy);
+    const float rmax = fmaxf(rx, ry), rmin = fminf(rx, ry);
+    if (!(rmax > 0.0f)) return texture_bilinear(tt, t, 0, tc.uv);
+    const float eta = rmin > 0.0f ? fminf(rmax / rmin, ORC_MAX_ANISOTROPY) : ORC_MAX_ANISOTROPY;
+    const int n = (int)ceilf(eta);
+    const float lod = log2f(rmax / eta);
+    const vec2 major = rx > ry ? tc.ddx : tc.ddy;
+    vec4 sum(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = 1; i <= n; ++i) {
+        const float at = float(i) / float(n + 1) - 0.5f;
+        const vec4 c = texture_lod(tt, tex_id, vec2(tc.uv.x + major.x * at, tc.uv.y + major.y * at), lod);
+        sum = vec4(sum.x + c.x, sum.y + c.y, sum.z + c.z, sum.w + c.w);
+    }
+    const float inv = 1.0f / float(n);
+    return vec4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+}
+// rendering/rt/material_textures.glsl:37-60 (textureGrad: USE_MIPMAPPING is defined, librender/render_params.glsl.h:8)
 static inline bool is_textured_param(float x) { return (float_bits(x) & RPTR_TEXTURED_PARAM_MASK) != 0u; }
-static inline vec4 textured_color_param(const TextureTable &tt, vec4 x, vec2 uv) {
+static inline vec4 textured_color_param(const TextureTable &tt, vec4 x, const TexCoord &uv) {
     const uint32_t mask = float_bits(x.x);
-    if (mask & RPTR_TEXTURED_PARAM_MASK) return texture_lod0(tt, int(RPTR_TEXTURE_ID(mask)), uv);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) return texture_grad(tt, int(RPTR_TEXTURE_ID(mask)), uv);
     return x;
 }
-static inline float textured_scalar_param(const TextureTable &tt, float x, vec2 uv) {
+static inline float textured_scalar_param(const TextureTable &tt, float x, const TexCoord &uv) {
     const uint32_t mask = float_bits(x);
     if (mask & RPTR_TEXTURED_PARAM_MASK) {
-        const vec4 t = texture_lod0(tt, int(RPTR_TEXTURE_ID(mask)), uv);
+        const vec4 t = texture_grad(tt, int(RPTR_TEXTURE_ID(mask)), uv);
         const uint32_t ch = RPTR_TEXTURE_CHANNEL(mask);
         return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
     }
@@ -460,7 +520,7 @@ static inline float textured_scalar_param(const TextureTable &tt, float x, vec2 
 }
 // rendering/rt/material_textures.glsl:95-135, non-unrolled standard textures (a parameter is a literal or a texture handle);
 // PREMULTIPLIED_BASE_COLOR_ALPHA is defined (vulkan/gpu_params.glsl:12)
-static inline float unpack_material(const TextureTable &tt, GLTFMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+static inline float unpack_material(const TextureTable &tt, GLTFMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, const TexCoord &uv) {
     const vec4 texel = textured_color_param(tt, vec4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f), uv);
     float alpha = texel.w;
     mat.base_color = vec3(texel.x, texel.y, texel.z);
@@ -479,7 +539,7 @@ static inline float unpack_material(const TextureTable &tt, GLTFMaterial &mat, v
     return alpha;
 }
 // same with SIMPLIFIED_MATERIAL (simple_bsdf.glsl:14-16,31-39)
-static inline float unpack_material(const TextureTable &tt, SimpleMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+static inline float unpack_material(const TextureTable &tt, SimpleMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, const TexCoord &uv) {
     const vec4 texel = textured_color_param(tt, vec4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f), uv);
     float alpha = texel.w;
     mat.base_color = vec3(texel.x, texel.y, texel.z);
@@ -771,7 +831,7 @@ static inline vec3 refract(vec3 I, vec3 N, float eta) {
     return eta * I - (eta * d + sqrtf(k)) * N;
 }
 // material_textures.glsl:95-135 + load_material gltf_bsdf.glsl:38-62
-static inline float unpack_material(const TextureTable &tt, GLTFTransMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, vec2 uv) {
+static inline float unpack_material(const TextureTable &tt, GLTFTransMaterial &mat, vec3 &emitter_radiance, const RptrBaseMaterial &p, const TexCoord &uv) {
     GLTFMaterial base;
     float alpha = unpack_material(tt, base, emitter_radiance, p, uv);
     mat.base_color = base.base_color;
@@ -1182,7 +1242,6 @@ static inline float nee_mis_heuristic(float n_f, float pdf_f, float n_g, float p
 }
 
 // ---------------------------------------------------------------- footprint (USE_MIPMAPPING helpers)
-// Only needed once textured parameters exist; kept as stand-alone functions.
 // rendering/rt/footprint.glsl:10-15
 static inline mat2 dpdxy_to_footprint(vec3 ray_dir, vec3 dpdx, vec3 dpdy) {
     vec3 t, b;
@@ -1190,6 +1249,42 @@ static inline mat2 dpdxy_to_footprint(vec3 ray_dir, vec3 dpdx, vec3 dpdy) {
     // F = transpose(mat2x3(t,b)) * mat2x3(dpdx,dpdy)
     mat2 F(vec2(dot(t, dpdx), dot(b, dpdx)), vec2(dot(t, dpdy), dot(b, dpdy)));
     return F * transpose(F);
+}
+
+// rendering/rt/footprint.glsl:28-43
+static inline mat2 transform_footprint(vec3 dst_ray_dir, const mat3 &T, vec3 src_ray_dir, const mat2 &F) {
+    vec3 t, b;
+    ortho_basis(t, b, src_ray_dir);
+    const vec3 Tt = T * t, Tb = T * b; // mat2x3 T2 = T * mat2x3(t, b)
+    ortho_basis(t, b, dst_ray_dir);
+    const mat2 T3(vec2(dot(t, Tt), dot(b, Tt)), vec2(dot(t, Tb), dot(b, Tb))); // transpose(mat2x3(t, b)) * T2
+    return T3 * F * transpose(T3);
+}
+static inline mat2 reflect_footprint(vec3 dst_ray_dir, vec3 src_ray_dir, const mat2 &F) {
+    const vec3 n = normalize(dst_ray_dir - src_ray_dir);
+    // mat3(1) - 2 outerProduct(n, n), column by column
+    const mat3 R(vec3(1.0f - 2.0f * (n.x * n.x), 0.0f - 2.0f * (n.y * n.x), 0.0f - 2.0f * (n.z * n.x)),
+                 vec3(0.0f - 2.0f * (n.x * n.y), 1.0f - 2.0f * (n.y * n.y), 0.0f - 2.0f * (n.z * n.y)),
+                 vec3(0.0f - 2.0f * (n.x * n.z), 0.0f - 2.0f * (n.y * n.z), 1.0f - 2.0f * (n.z * n.z)));
+    return transform_footprint(dst_ray_dir, R, src_ray_dir, F);
+}
+// rendering/rt/footprint.glsl:45-63
+static inline void footprint_to_dpdxy(vec3 &dpdx, vec3 &dpdy, vec3 ray_dir, const mat2 &F) {
+    const float B = F[0][0] + F[1][1];
+    const float C = F[0][0] * F[1][1] - F[0][1] * F[1][0];
+    const float D = sqrtf(B * B * 0.25f - C);
+    const vec2 ev(0.5f * B - D, 0.5f * B + D);
+    mat2 X;
+    if (fabsf(F[0][1]) > 3.0e-39f) {
+        X[0] = vec2(F[1][0], ev.x - F[0][0]);
+        X[1] = vec2(ev.y - F[1][1], F[0][1]);
+    } else
+        X = mat2(1.0f);
+    vec3 t, b;
+    ortho_basis(t, b, ray_dir);
+    const vec2 x0 = normalize(X[0]) * sqrtf(ev.x), x1 = normalize(X[1]) * sqrtf(ev.y);
+    dpdx = t * x0.x + b * x0.y; // mat2x3(t, b) * v
+    dpdy = t * x1.x + b * x1.y;
 }
 
 } // namespace orc

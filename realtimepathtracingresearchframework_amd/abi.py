@@ -158,7 +158,7 @@ class InstanceDesc(C.Structure):
 
 
 class TextureDesc(C.Structure):  # include/rptr_hip.h RptrTextureDesc
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("srgb", C.c_uint32), ("_pad", C.c_uint32)]
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("srgb", C.c_uint32), ("mip_levels", C.c_uint32)]
 
 
 def textured_param(texture_id, channel=0):

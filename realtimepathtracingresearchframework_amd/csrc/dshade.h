@@ -39,7 +39,7 @@ struct RpTexture { // RptrTextureDesc on the device
     const uchar4 *texels;
     int width, height;
     int srgb;
-    int _pad;
+    int levels; // mip levels stored back to back behind level 0 (>= 1)
 };
 
 struct RpScene {
@@ -512,11 +512,31 @@ struct RpMaterial { // GLTFMaterial (gltf_bsdf.glsl:15-35) / SimpleMaterial (sim
     float transmission_roughness, specular_transmission;
     V3 transmission_color;
 };
-// ---- texture sampling: textureLod(sampler2D, uv, 0) of the reference's material sampler (linear filter, REPEAT,
-// render_vulkan.cpp:1657-1670), in software: texel centres at (i + 0.5) / size, bilinear weights in float,
-// unorm byte / 255, sRGB decode per texel through the host-computed table before filtering (as the hardware does)
-RP_DEV float4 rp_texel(const RpScene &sc, const RpTexture &t, int ix, int iy) {
-    const uchar4 c = t.texels[(size_t)iy * (size_t)t.width + (size_t)ix];
+// ---- texture sampling: the reference's material sampler (render_vulkan.cpp:1657-1670: linear filter, linear mip filter, REPEAT, LOD 0..16,
+// anisotropy 12) in software after the Vulkan specification's texel-filtering equations (oracle/oshade.h states them): texel centres at
+// (i + 0.5) / size, bilinear weights in float, unorm byte / 255, sRGB decode per texel through the host-computed table before filtering.
+//   rp_texture_lod(uv, lod): the two nearest levels blended by the fraction of the clamped lod
+//   rp_texture_grad(uv, ddx, ddy): eta = min(rho_max / rho_min, 12), N = ceil(eta) taps along the larger derivative at log2(rho_max / eta)
+// Levels are stored back to back, level l = max(1, w >> l) x max(1, h >> l) (RptrTextureDesc.mip_levels).
+struct RpTexCoord { // HitPoint::uv + HitPoint::duvdxy
+    V2 uv, ddx, ddy;
+};
+RP_DEV RpTexCoord rp_texcoord(V2 uv) { return RpTexCoord{uv, v2(0.0f, 0.0f), v2(0.0f, 0.0f)}; }
+struct RpMipView {
+    const uchar4 *texels;
+    int w, h;
+};
+RP_DEV RpMipView rp_mip_view(const RpTexture &t, int level) {
+    RpMipView v{t.texels, t.width, t.height};
+    for (int l = 0; l < level; ++l) {
+        v.texels += (size_t)v.w * (size_t)v.h;
+        if (v.w > 1) v.w /= 2;
+        if (v.h > 1) v.h /= 2;
+    }
+    return v;
+}
+RP_DEV float4 rp_texel(const RpScene &sc, const RpTexture &t, const RpMipView &v, int ix, int iy) {
+    const uchar4 c = v.texels[(size_t)iy * (size_t)v.w + (size_t)ix];
     if (t.srgb) return make_float4(sc.srgb_lut[c.x], sc.srgb_lut[c.y], sc.srgb_lut[c.z], float(c.w) / 255.0f);
     return make_float4(float(c.x) / 255.0f, float(c.y) / 255.0f, float(c.z) / 255.0f, float(c.w) / 255.0f);
 }
@@ -524,30 +544,126 @@ RP_DEV int rp_wrap_repeat(int i, int n) {
     i %= n;
     return i < 0 ? i + n : i;
 }
-RP_DEV float4 rp_texture_lod0(const RpScene &sc, int tex_id, V2 uv) {
-    const RpTexture t = sc.textures[tex_id];
-    const float x = uv.x * float(t.width) - 0.5f, y = uv.y * float(t.height) - 0.5f;
+RP_DEV float4 rp_texture_bilinear(const RpScene &sc, const RpTexture &t, int level, V2 uv) {
+    const RpMipView mv = rp_mip_view(t, level);
+    const float x = uv.x * float(mv.w) - 0.5f, y = uv.y * float(mv.h) - 0.5f;
     const float x0 = floorf(x), y0 = floorf(y);
     const float fx = x - x0, fy = y - y0;
-    const int ix0 = rp_wrap_repeat(int(x0), t.width), ix1 = rp_wrap_repeat(int(x0) + 1, t.width);
-    const int iy0 = rp_wrap_repeat(int(y0), t.height), iy1 = rp_wrap_repeat(int(y0) + 1, t.height);
-    const float4 c00 = rp_texel(sc, t, ix0, iy0), c10 = rp_texel(sc, t, ix1, iy0), c01 = rp_texel(sc, t, ix0, iy1), c11 = rp_texel(sc, t, ix1, iy1);
+    const int ix0 = rp_wrap_repeat(int(x0), mv.w), ix1 = rp_wrap_repeat(int(x0) + 1, mv.w);
+    const int iy0 = rp_wrap_repeat(int(y0), mv.h), iy1 = rp_wrap_repeat(int(y0) + 1, mv.h);
+    const float4 c00 = rp_texel(sc, t, mv, ix0, iy0), c10 = rp_texel(sc, t, mv, ix1, iy0), c01 = rp_texel(sc, t, mv, ix0, iy1), c11 = rp_texel(sc, t, mv, ix1, iy1);
     const float gx = 1.0f - fx, gy = 1.0f - fy;
     const float4 top = make_float4(c00.x * gx + c10.x * fx, c00.y * gx + c10.y * fx, c00.z * gx + c10.z * fx, c00.w * gx + c10.w * fx);
     const float4 bot = make_float4(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
     return make_float4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
 }
-// rendering/rt/material_textures.glsl:37-60
+RP_DEV float4 rp_texture_lod0(const RpScene &sc, int tex_id, V2 uv) { return rp_texture_bilinear(sc, sc.textures[tex_id], 0, uv); }
+RP_DEV float4 rp_texture_lod(const RpScene &sc, int tex_id, V2 uv, float lod) {
+    const RpTexture t = sc.textures[tex_id];
+    lod = fminf(fmaxf(lod, 0.0f), fminf(float(t.levels - 1), 16.0f));
+    if (!(lod > 0.0f)) return rp_texture_bilinear(sc, t, 0, uv);
+    const float hi = floorf(lod), delta = lod - hi;
+    const float4 a = rp_texture_bilinear(sc, t, int(hi), uv);
+    if (delta == 0.0f) return a;
+    const float4 b = rp_texture_bilinear(sc, t, int(hi) + 1, uv);
+    const float g = 1.0f - delta;
+    return make_float4(a.x * g + b.x * delta, a.y * g + b.y * delta, a.z * g + b.z * delta, a.w * g + b.w * delta);
+}
+#define RP_MAX_ANISOTROPY 12.0f
+RP_DEV float4 rp_texture_grad(const RpScene &sc, int tex_id, const RpTexCoord &tc) {
+    const RpTexture t = sc.textures[tex_id];
+    const float w = float(t.width), h = float(t.height);
+    const float mxx = tc.ddx.x * w, mxy = tc.ddx.y * h, myx = tc.ddy.x * w, myy = tc.ddy.y * h;
+    const float rx = sqrtf(mxx * mxx + mxy * mxy), ry = sqrtf(myx * myx + myy * myy);
+    const float rmax = fmaxf(rx, ry), rmin = fminf(rx, ry);
+    if (!(rmax > 0.0f)) return rp_texture_bilinear(sc, t, 0, tc.uv);
+    const float eta = rmin > 0.0f ? fminf(rmax / rmin, RP_MAX_ANISOTROPY) : RP_MAX_ANISOTROPY;
+    const int n = int(ceilf(eta));
+    const float lod = log2f(rmax / eta);
+    const V2 major = rx > ry ? tc.ddx : tc.ddy;
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = 1; i <= n; ++i) {
+        const float at = float(i) / float(n + 1) - 0.5f;
+        const float4 c = rp_texture_lod(sc, tex_id, v2(tc.uv.x + major.x * at, tc.uv.y + major.y * at), lod);
+        sum = make_float4(sum.x + c.x, sum.y + c.y, sum.z + c.z, sum.w + c.w);
+    }
+    const float inv = 1.0f / float(n);
+    return make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+}
+// ---- the pixel footprint a path carries for its texture lookups (rendering/rt/footprint.glsl; column-major 2 x 2, same operation order
+// as oracle/oshade.h)
+struct M2 {
+    V2 c0, c1;
+};
+RP_DEV V2 mul2(const M2 &m, V2 v) { return v2(m.c0.x * v.x + m.c1.x * v.y, m.c0.y * v.x + m.c1.y * v.y); }
+RP_DEV M2 mul2(const M2 &a, const M2 &b) { return M2{mul2(a, b.c0), mul2(a, b.c1)}; }
+RP_DEV M2 transpose2(const M2 &m) { return M2{v2(m.c0.x, m.c1.x), v2(m.c0.y, m.c1.y)}; }
+RP_DEV V2 norm2(V2 v) { return v * (1.0f / sqrtf(v.x * v.x + v.y * v.y)); }
+RP_DEV M2 rp_dpdxy_to_footprint(V3 ray_dir, V3 dpdx, V3 dpdy) { // :10-15
+    V3 t, b;
+    rp_ortho_basis(t, b, ray_dir);
+    const M2 F{v2(dot3(t, dpdx), dot3(b, dpdx)), v2(dot3(t, dpdy), dot3(b, dpdy))};
+    return mul2(F, transpose2(F));
+}
+RP_DEV M2 rp_transform_footprint(V3 dst_ray_dir, const M3 &T, V3 src_ray_dir, const M2 &F) { // :28-35
+    V3 t, b;
+    rp_ortho_basis(t, b, src_ray_dir);
+    const V3 Tt = mul(T, t), Tb = mul(T, b);
+    rp_ortho_basis(t, b, dst_ray_dir);
+    const M2 T3{v2(dot3(t, Tt), dot3(b, Tt)), v2(dot3(t, Tb), dot3(b, Tb))};
+    return mul2(mul2(T3, F), transpose2(T3));
+}
+RP_DEV M2 rp_reflect_footprint(V3 dst_ray_dir, V3 src_ray_dir, const M2 &F) { // :38-43
+    const V3 n = norm3(dst_ray_dir - src_ray_dir);
+    const M3 R{v3(1.0f - 2.0f * (n.x * n.x), 0.0f - 2.0f * (n.y * n.x), 0.0f - 2.0f * (n.z * n.x)),
+               v3(0.0f - 2.0f * (n.x * n.y), 1.0f - 2.0f * (n.y * n.y), 0.0f - 2.0f * (n.z * n.y)),
+               v3(0.0f - 2.0f * (n.x * n.z), 0.0f - 2.0f * (n.y * n.z), 1.0f - 2.0f * (n.z * n.z))};
+    return rp_transform_footprint(dst_ray_dir, R, src_ray_dir, F);
+}
+RP_DEV void rp_footprint_to_dpdxy(V3 &dpdx, V3 &dpdy, V3 ray_dir, const M2 &F) { // :45-63
+    const float B = F.c0.x + F.c1.y;
+    const float C = F.c0.x * F.c1.y - F.c0.y * F.c1.x;
+    const float D = sqrtf(B * B * 0.25f - C);
+    const V2 ev = v2(0.5f * B - D, 0.5f * B + D);
+    M2 X;
+    if (fabsf(F.c0.y) > 3.0e-39f) {
+        X.c0 = v2(F.c1.x, ev.x - F.c0.x);
+        X.c1 = v2(ev.y - F.c1.y, F.c0.y);
+    } else
+        X = M2{v2(1.0f, 0.0f), v2(0.0f, 1.0f)};
+    V3 t, b;
+    rp_ortho_basis(t, b, ray_dir);
+    const V2 x0 = norm2(X.c0) * sqrtf(ev.x), x1 = norm2(X.c1) * sqrtf(ev.y);
+    dpdx = t * x0.x + b * x0.y;
+    dpdy = t * x1.x + b * x1.y;
+}
+// the footprint on the surface as uv derivatives (pt_megakernel.glsl:582-606)
+RP_DEV RpTexCoord rp_hit_texcoord(V2 uv, const M2 &footprint, V3 ray_dir, V3 geo_normal, V3 tangent, float bitangent_l, float total_t) {
+    V3 dpdx, dpdy;
+    rp_footprint_to_dpdxy(dpdx, dpdy, ray_dir, footprint);
+    const V3 dir_tangent_un = ray_dir - geo_normal * dot3(ray_dir, geo_normal);
+    const float cosTheta2 = fmaxf(1.0f - dot3(dir_tangent_un, dir_tangent_un), 0.0f);
+    const V3 dir_tangent_elong = dir_tangent_un / (sqrtf(cosTheta2) + cosTheta2);
+    const V3 dpdx_ = dpdx + dir_tangent_elong * dot3(dpdx, dir_tangent_un);
+    const V3 dpdy_ = dpdy + dir_tangent_elong * dot3(dpdy, dir_tangent_un);
+    const V3 bitangent = bitangent_l * cross3(geo_normal, norm3(tangent));
+    RpTexCoord tc;
+    tc.uv = uv;
+    tc.ddx = v2(dot3(tangent, dpdx_), dot3(bitangent, dpdx_)) * total_t;
+    tc.ddy = v2(dot3(tangent, dpdy_), dot3(bitangent, dpdy_)) * total_t;
+    return tc;
+}
+// rendering/rt/material_textures.glsl:37-60 (textureGrad: USE_MIPMAPPING, librender/render_params.glsl.h:8)
 RP_DEV bool rp_is_textured(float x) { return (__float_as_uint(x) & RPTR_TEXTURED_PARAM_MASK) != 0u; }
-RP_DEV float4 rp_textured_color_param(const RpScene &sc, float4 x, V2 uv) {
+RP_DEV float4 rp_textured_color_param(const RpScene &sc, float4 x, const RpTexCoord &uv) {
     const uint32_t mask = __float_as_uint(x.x);
-    if (mask & RPTR_TEXTURED_PARAM_MASK) return rp_texture_lod0(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) return rp_texture_grad(sc, int(RPTR_TEXTURE_ID(mask)), uv);
     return x;
 }
-RP_DEV float rp_textured_scalar_param(const RpScene &sc, float x, V2 uv) {
+RP_DEV float rp_textured_scalar_param(const RpScene &sc, float x, const RpTexCoord &uv) {
     const uint32_t mask = __float_as_uint(x);
     if (mask & RPTR_TEXTURED_PARAM_MASK) {
-        const float4 t = rp_texture_lod0(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+        const float4 t = rp_texture_grad(sc, int(RPTR_TEXTURE_ID(mask)), uv);
         const uint32_t ch = RPTR_TEXTURE_CHANNEL(mask);
         return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
     }
@@ -571,7 +687,7 @@ RP_DEV bool rp_alpha_rejects(const RpScene &sc, int inst_idx, int geom, int prim
 // rendering/rt/material_textures.glsl:95-135 (non-unrolled standard textures: a parameter is a literal or a texture handle;
 // PREMULTIPLIED_BASE_COLOR_ALPHA is defined, vulkan/gpu_params.glsl:12)
 template <int VARIANT, bool TEX>
-RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p, V2 uv) {
+RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p, const RpTexCoord &uv) {
     const float4 literal = make_float4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f);
     const float4 texel = TEX ? rp_textured_color_param(sc, literal, uv) : literal;
     const float alpha = texel.w;

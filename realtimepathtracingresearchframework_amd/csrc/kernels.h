@@ -26,6 +26,7 @@ struct RpPathState {
     float4 *thr;     // throughput.xyz, prev_bounce_pdf
     float4 *illum;   // illum.xyz, bits(bounce)
     float2 *rng_tt;  // bits(rng state), total_t
+    float4 *footprint; // the texture footprint (2 x 2, column major) of paths through scenes with textures (else NULL)
     uint32_t *alpha_rng; // the alpha-test generator of closest-hit queries when the point set is not the uniform one (else NULL)
     float4 *hit_tuv; // t, u, v, bits(prim)
     int2 *hit_ids;   // inst_idx, geom
@@ -341,6 +342,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             int aov_px = -1; // FIRST: local pixel whose AOVs this path writes
             V2 aov_jitter = v2(0.0f, 0.0f);
             RpMaterial mat;
+            M2 tex_fp{v2(0.f, 0.f), v2(0.f, 0.f)}; // TEX: texture_footprint (pt_megakernel.glsl:336-352)
             V2 dir_sample = v2(0.f, 0.f), sel_sample = v2(0.f, 0.f);
             RpLightBin bin;
             bin.bin_begin = bin.bin_end = 0;
@@ -374,6 +376,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     prev_bounce_pdf = 2.e16f;
                     total_t = 0.0f;
                     bounce = 0;
+                    if (TEX) { // :341-351
+                        const V3 dpdx = (ld3(f.cam_du) / float(f.width)) * f.rp.pixel_radius, dpdy = (ld3(f.cam_dv) / float(f.height)) * f.rp.pixel_radius;
+                        tex_fp = rp_dpdxy_to_footprint(ray_dir, dpdx, dpdy);
+                    }
                 } else {
                     const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
                     const float4 thr4 = ps.thr[p];
@@ -387,6 +393,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     illum = xyz(il4);
                     prev_bounce_pdf = thr4.w;
                     bounce = __float_as_int(il4.w);
+                    if (TEX) {
+                        const float4 fp = ps.footprint[p];
+                        tex_fp = M2{v2(fp.x, fp.y), v2(fp.z, fp.w)};
+                    }
                 }
                 const float4 hit4 = ps.hit_tuv[p];
                 const int2 ids = ps.hit_ids[p];
@@ -414,8 +424,9 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     float approx_tri_solid_angle = len3(hit.geo_normal);
                     hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
                     approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
-                    // :585,605
+                    // :582-606
                     total_t += hit.dist;
+                    const RpTexCoord tc = TEX ? rp_hit_texcoord(hit.uv, tex_fp, ray_dir, hit.geo_normal, hit.tangent, hit.bitangent_l, total_t) : rp_texcoord(hit.uv);
                     geometry_scale = total_t;
                     w_o = -ray_dir;
                     ip_p = ray_origin + hit.dist * ray_dir;
@@ -438,7 +449,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         V3 t_x = cross3(t_y, hit.normal);
                         t_x = t_x * len3(hit.tangent);
                         t_y = t_y * hit.bitangent_l;
-                        const float4 tx = rp_texture_lod0(sc, mp.normal_map, hit.uv);
+                        const float4 tx = rp_texture_lod(sc, mp.normal_map, hit.uv, float(bounce)); // :642-648
                         V3 map_nrm = v3(2.0f * tx.x - 1.0f, 2.0f * tx.y - 1.0f, 1.0f * tx.z - 0.0f);
                         map_nrm.z = sqrtf(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
                         const V3 t_z = f.sp.normal_z_scale * nn;
@@ -459,7 +470,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
 
                     // ---- shade_base_material, rendering/mc/shade_base_material.glsl:14-96
                     V3 emit;
-                    rp_unpack_material<VARIANT, TEX>(sc, mat, emit, mp, hit.uv);
+                    rp_unpack_material<VARIANT, TEX>(sc, mat, emit, mp, tc);
                     scatter_throughput = throughput;
                     if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:670-673, shade_base_material.glsl:28-31
                         rp_store_geometry_aovs(f, aov_px, nn, ip_p, aov_jitter);
@@ -594,7 +605,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     else {
                         throughput = throughput * bsdf;
                         prev_bounce_pdf = mis_pdf;
-                        // pt_megakernel.glsl:703-709
+                        // pt_megakernel.glsl:698-709
+                        if (TEX && dot3(w_i, nn) * dot3(w_o, nn) > -0.999f) tex_fp = rp_reflect_footprint(w_i, ray_dir, tex_fp);
                         ray_dir = w_i;
                         ray_origin = ip_p;
                         const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
@@ -616,6 +628,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                             ps.ray_d[p] = f4(ray_dir, 1e20f);
                             ps.thr[p] = f4(throughput, prev_bounce_pdf);
                             ps.rng_tt[p] = make_float2(__uint_as_float(rng.s), total_t);
+                            if (TEX) ps.footprint[p] = make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y);
                         }
                     }
                 }

@@ -912,6 +912,8 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         if ((rc = dev_alloc(h, &c.ps.rng_tt, cap, nullptr))) return rc;
         c.ps.alpha_rng = nullptr;
         if (h->rng_variant != RPTR_RNG_VARIANT_UNIFORM && (rc = dev_alloc(h, &c.ps.alpha_rng, cap, nullptr))) return rc;
+        c.ps.footprint = nullptr; // scenes with textures: set_scene allocates it; a scene set before this call keeps its flags
+        if ((h->uses_textures || h->uses_alpha) && (rc = dev_alloc(h, &c.ps.footprint, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_tuv, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_ids, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.sq.o, cap, nullptr))) return rc;
@@ -1015,9 +1017,17 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         if (!bad.empty()) return fail(h, RPTR_E_INVALID, "%s", bad.c_str());
     }
     if (s->num_textures && !s->textures) return fail(h, RPTR_E_INVALID, "num_textures = %u but textures is NULL", s->num_textures);
-    for (uint32_t t = 0; t < s->num_textures; ++t)
+    for (uint32_t t = 0; t < s->num_textures; ++t) {
         if (!s->textures[t].rgba8 || s->textures[t].width == 0 || s->textures[t].height == 0 || s->textures[t].width > 16384 || s->textures[t].height > 16384)
             return fail(h, RPTR_E_INVALID, "texture %u: bad size or NULL data", t);
+        if (s->textures[t].mip_levels > 1u) { // at most the full chain down to 1 x 1
+            uint32_t full = 1;
+            for (uint32_t w = s->textures[t].width, hh = s->textures[t].height; w > 1 || hh > 1; w = std::max(1u, w / 2), hh = std::max(1u, hh / 2)) ++full;
+            if (s->textures[t].mip_levels > full)
+                return fail(h, RPTR_E_INVALID, "texture %u: %u mip levels, a %u x %u texture has at most %u", t, s->textures[t].mip_levels, s->textures[t].width,
+                            s->textures[t].height, full);
+        }
+    }
     h->uses_textures = false;
     h->uses_alpha = false;
     h->tail_adaptive = 1 << 30; // the first frame of a scene shows the queue lengths of every bounce
@@ -1038,6 +1048,11 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     }
     int rc;
     // ---- textures (RGBA8) + the sRGB decode table
+    // paths through a scene with textures carry their texture footprint (kernels.h TEX; the tail kernel's textured instantiation also serves
+    // alpha-tested scenes)
+    if ((h->uses_textures || h->uses_alpha) && h->path_capacity)
+        for (FrameCtx &c : h->ctx)
+            if (!c.ps.footprint && (rc = dev_alloc(h, &c.ps.footprint, h->path_capacity, nullptr))) return rc;
     RpTexture *d_textures = nullptr;
     float *d_srgb_lut = nullptr;
     {
@@ -1045,14 +1060,16 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         for (uint32_t t = 0; t < s->num_textures; ++t) {
             const RptrTextureDesc &td = s->textures[t];
             uchar4 *dt = nullptr;
-            const size_t n = (size_t)td.width * td.height;
+            const uint32_t levels = td.mip_levels > 1u ? td.mip_levels : 1u;
+            size_t n = 0; // the levels back to back, level l = max(1, w >> l) x max(1, h >> l) (vulkan/resource_utils.cpp:86-100)
+            for (uint32_t l = 0, w = td.width, hh = td.height; l < levels; ++l, w = std::max(1u, w / 2), hh = std::max(1u, hh / 2)) n += (size_t)w * hh;
             if ((rc = dev_alloc(h, &dt, n, &h->scene_allocs))) return rc;
             HIP_TRY(h, hipMemcpy(dt, td.rgba8, n * 4, hipMemcpyHostToDevice));
             tex[t].texels = dt;
             tex[t].width = (int)td.width;
             tex[t].height = (int)td.height;
             tex[t].srgb = td.srgb ? 1 : 0;
-            tex[t]._pad = 0;
+            tex[t].levels = (int)levels;
         }
         if ((rc = dev_alloc(h, &d_textures, std::max<size_t>(1, tex.size()), &h->scene_allocs))) return rc;
         if (!tex.empty()) HIP_TRY(h, hipMemcpy(d_textures, tex.data(), tex.size() * sizeof(RpTexture), hipMemcpyHostToDevice));

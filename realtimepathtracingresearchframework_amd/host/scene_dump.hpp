@@ -103,7 +103,7 @@ struct SceneDump {
         const uint32_t ntex = (uint32_t)textures.size();
         wr(&ntex, 4);
         for (size_t i = 0; i < textures.size(); ++i) {
-            const uint32_t h3[3] = {textures[i].width, textures[i].height, textures[i].srgb};
+            const uint32_t h3[3] = {textures[i].width, textures[i].height, (textures[i].srgb ? 1u : 0u) | ((textures[i].mip_levels > 1u ? textures[i].mip_levels : 0u) << 8)};
             wr(h3, sizeof(h3));
             wr(texels[i].data(), texels[i].size());
         }
@@ -194,13 +194,16 @@ struct SceneDump {
             for (uint32_t i = 0; i < ntex; ++i) {
                 uint32_t h3[3];
                 rd(h3, sizeof(h3));
-                s.texels[i].resize((size_t)h3[0] * h3[1] * 4);
+                const uint32_t levels = h3[2] >> 8; // srgb flag in the low byte, number of mip levels above it (0 = level 0 only)
+                size_t texels = 0;
+                for (uint32_t l = 0, w = h3[0], hh = h3[1]; l < std::max(1u, levels); ++l, w = std::max(1u, w / 2), hh = std::max(1u, hh / 2)) texels += (size_t)w * hh;
+                s.texels[i].resize(texels * 4);
                 rd(s.texels[i].data(), s.texels[i].size());
                 s.textures[i].rgba8 = s.texels[i].data();
                 s.textures[i].width = h3[0];
                 s.textures[i].height = h3[1];
-                s.textures[i].srgb = h3[2];
-                s.textures[i]._pad = 0;
+                s.textures[i].srgb = h3[2] & 0xFFu;
+                s.textures[i].mip_levels = levels;
             }
         }
         std::fclose(f);

@@ -608,7 +608,7 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
         t.width = w;
         t.height = h;
         t.srgb = srgb ? 1u : 0u;
-        t._pad = 0;
+        t.mip_levels = 0;
         s.textures.push_back(t);
     };
     for (size_t i = 0; i < v.materialNames.size(); ++i) {

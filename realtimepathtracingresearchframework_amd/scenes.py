@@ -126,6 +126,17 @@ class SceneConfig:  # librender/render_params.glsl.h:157-162
 class Texture:
     rgba: np.ndarray  # (height, width, 4) uint8, row 0 first
     srgb: bool = False
+    mips: Optional[list] = None  # levels 1..n-1, level l being (max(1, height >> l), max(1, width >> l), 4) uint8; None: level 0 only
+
+    def levels(self):
+        """all levels, level 0 first, shapes checked"""
+        out = [np.ascontiguousarray(self.rgba, dtype=np.uint8)]
+        for m in self.mips or []:
+            h, w = out[-1].shape[:2]
+            m = np.ascontiguousarray(m, dtype=np.uint8)
+            assert m.shape == (max(1, h // 2), max(1, w // 2), 4), "mip level %d has shape %s" % (len(out), m.shape)
+            out.append(m)
+        return out
 
 
 @dataclass
@@ -180,10 +191,11 @@ class Scene:
             f.write(bytes(rp))
             f.write(bytes(lc))
             f.write(struct.pack("<I", len(self.textures)))  # optional trailing section (absent in files without textures)
-            for t in self.textures:
-                px = np.ascontiguousarray(t.rgba, dtype=np.uint8)
-                f.write(struct.pack("<3I", px.shape[1], px.shape[0], 1 if t.srgb else 0))
-                f.write(px.tobytes())
+            for t in self.textures:   # third word: srgb flag in the low byte, number of mip levels above it (0 = level 0 only)
+                lv = t.levels()
+                f.write(struct.pack("<3I", lv[0].shape[1], lv[0].shape[0], (1 if t.srgb else 0) | ((len(lv) if len(lv) > 1 else 0) << 8)))
+                for px in lv:
+                    f.write(px.tobytes())
 
     def num_tris(self):
         return sum(g.num_tris for g in self.geometries)
@@ -255,12 +267,14 @@ class Scene:
         d.lights, d.num_lights = LT, nl
         TX = (abi.TextureDesc * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
-            px = np.ascontiguousarray(t.rgba, dtype=np.uint8)
-            assert px.ndim == 3 and px.shape[2] == 4
+            lv = t.levels()
+            assert lv[0].ndim == 3 and lv[0].shape[2] == 4
+            px = np.concatenate([l.reshape(-1) for l in lv])   # the levels back to back
             keep.append(px)
             TX[i].rgba8 = px.ctypes.data
-            TX[i].height, TX[i].width = px.shape[0], px.shape[1]
+            TX[i].height, TX[i].width = lv[0].shape[0], lv[0].shape[1]
             TX[i].srgb = 1 if t.srgb else 0
+            TX[i].mip_levels = len(lv) if len(lv) > 1 else 0
         d.textures, d.num_textures = TX, len(self.textures)
         keep += [G, M, P, I, MAT, LT, TX]
         self._keep = keep

@@ -71,6 +71,8 @@ def lib():
         L.orc_pointset_probe.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_rng_probe.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32), C.c_void_p, C.c_int]
         L.orc_texture_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_texture_probe_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_footprint_probe.argtypes = [C.c_void_p] * 5
         L.orc_hw_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -125,6 +127,21 @@ class OracleScene:
         uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
         out = np.zeros((len(uv), 4), dtype=np.float32)
         lib().orc_texture_probe(self.h, int(tex_id), _p(uv), len(uv), _p(out))
+        return out
+
+    def texture_grad(self, tex_id, uv, ddx, ddy):
+        """textureGrad of the reference's material sampler (anisotropic, trilinear) as the oracle restates it"""
+        q = np.ascontiguousarray(np.concatenate([np.reshape(uv, (-1, 2)), np.reshape(ddx, (-1, 2)), np.reshape(ddy, (-1, 2))], axis=1), dtype=np.float32)
+        out = np.zeros((len(q), 4), dtype=np.float32)
+        lib().orc_texture_probe_ex(self.h, int(tex_id), 0, _p(q), len(q), _p(out))
+        return out
+
+    def texture_lod(self, tex_id, uv, lod):
+        uv = np.reshape(uv, (-1, 2))
+        q = np.zeros((len(uv), 6), np.float32)
+        q[:, :2], q[:, 2] = uv, lod
+        out = np.zeros((len(q), 4), dtype=np.float32)
+        lib().orc_texture_probe_ex(self.h, int(tex_id), 1, _p(q), len(q), _p(out))
         return out
 
     def set_dynamic_vertices(self, geometry, xyz):
@@ -250,6 +267,14 @@ def halton23(i):
     out = np.zeros(2, np.float32)
     lib().orc_halton23_probe(C.c_uint32(i), _p(out))
     return out
+
+
+def footprint_probe(ray_dir, dpdx, dpdy, dst_dir):
+    """-> (F 2x2 column major, dpdx', dpdy' recovered from F, reflected F)"""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (ray_dir, dpdx, dpdy, dst_dir)]
+    out = np.zeros(14, np.float32)
+    lib().orc_footprint_probe(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out))
+    return out[0:4].reshape(2, 2).T.copy(), out[4:7].copy(), out[7:10].copy(), out[10:14].reshape(2, 2).T.copy()
 
 
 def rng_probe(index, frame, px, py, dimx, n=8):

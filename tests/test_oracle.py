@@ -590,3 +590,79 @@ def test_halton_table_of_the_screen_jitter():
         assert len(rows) == 64
         for i, (a, b) in enumerate(rows):
             assert O.halton23(i).tolist() == [np.float32(a), np.float32(b)], i
+
+
+def _mip_chain(level0):
+    """box-filtered levels 1.. down to 1 x 1 (test data: the product generates none)"""
+    out, cur = [], level0.astype(np.float64)
+    while cur.shape[0] > 1 or cur.shape[1] > 1:
+        h, w = max(1, cur.shape[0] // 2), max(1, cur.shape[1] // 2)
+        cur = cur[:2 * h if cur.shape[0] > 1 else 1, :2 * w if cur.shape[1] > 1 else 1]
+        cur = cur.reshape(h, cur.shape[0] // h, w, cur.shape[1] // w, 4).mean(axis=(1, 3))
+        out.append(np.clip(np.round(cur), 0, 255).astype(np.uint8))
+    return out
+
+
+def test_texture_sampler_lod_and_anisotropy():
+    """the material sampler as restated after the Vulkan specification (oshade.h texture_grad / texture_lod): zero derivatives = bilinear
+    level 0; an isotropic footprint of 4 texels = level 2; fractional levels blend; an 8 : 1 footprint = 8 taps of level 0 along the major
+    axis at uv + ddx (i / 9 - 1/2); levels beyond the chain and single-level textures clamp"""
+    rng = np.random.default_rng(5)
+    s = scenes.textured_test()
+    base = rng.integers(0, 256, (16, 16, 4)).astype(np.uint8)
+    s.textures.append(scenes.Texture(rgba=base, srgb=False, mips=_mip_chain(base)))
+    s.textures.append(scenes.Texture(rgba=base, srgb=False))
+    full, single = len(s.textures) - 2, len(s.textures) - 1
+    osc = O.OracleScene(s)
+    uv = rng.random((64, 2)).astype(np.float32) * 3 - 1
+    zero = np.zeros_like(uv)
+    assert np.array_equal(osc.texture_grad(full, uv, zero, zero), osc.texture_probe(full, uv))
+    assert np.array_equal(osc.texture_lod(full, uv, 0.0), osc.texture_probe(full, uv))
+    # level 2 of the chain is a 4 x 4 texture: sample it through a scene texture of its own
+    lv = s.textures[full].levels()
+    s2 = scenes.textured_test()
+    s2.textures.append(scenes.Texture(rgba=lv[2], srgb=False))
+    s2.textures.append(scenes.Texture(rgba=lv[1], srgb=False))
+    o2 = O.OracleScene(s2)
+    l2, l1 = o2.texture_probe(len(s2.textures) - 2, uv), o2.texture_probe(len(s2.textures) - 1, uv)
+    iso = np.tile(np.array([[4 / 16, 0.0]], np.float32), (len(uv), 1))
+    assert np.array_equal(osc.texture_grad(full, uv, iso, iso[:, ::-1].copy()), l2)
+    assert np.array_equal(osc.texture_lod(full, uv, 2.0), l2)
+    assert np.allclose(osc.texture_lod(full, uv, 1.25), 0.75 * l1 + 0.25 * l2, atol=2e-7)
+    assert np.array_equal(osc.texture_lod(full, uv, 40.0), osc.texture_lod(full, uv, 4.0))         # the 1 x 1 level
+    assert np.allclose(osc.texture_lod(full, uv, 4.0), lv[4].reshape(1, 4) / 255.0, atol=1e-7)
+    # anisotropy 8: rho = (8, 1) texels -> eta = 8, N = 8, lod = log2(8 / 8) = 0
+    ddx = np.tile(np.array([[8 / 16, 0.0]], np.float32), (len(uv), 1))
+    ddy = np.tile(np.array([[0.0, 1 / 16]], np.float32), (len(uv), 1))
+    taps = [osc.texture_probe(full, uv + ddx * np.float32(np.float32(i) / np.float32(9) - np.float32(0.5))) for i in range(1, 9)]
+    assert np.allclose(osc.texture_grad(full, uv, ddx, ddy), np.mean(taps, axis=0), atol=3e-7)
+    # beyond anisotropy 12 the level rises: rho = (48, 1) -> eta = 12, lod = log2(4) = 2, 12 taps of level 2
+    ddx48 = ddx * np.float32(6)
+    taps = [o2.texture_probe(len(s2.textures) - 2, uv + ddx48 * np.float32(np.float32(i) / np.float32(13) - np.float32(0.5))) for i in range(1, 13)]
+    assert np.allclose(osc.texture_grad(full, uv, ddx48, ddy), np.mean(taps, axis=0), atol=3e-7)
+    # one level: every lod is level 0, the taps stay
+    assert np.array_equal(osc.texture_lod(single, uv, 3.0), osc.texture_probe(single, uv))
+    assert np.array_equal(osc.texture_grad(single, uv, iso, iso[:, ::-1].copy()), osc.texture_probe(single, uv))
+
+
+def test_footprint_functions():
+    """rendering/rt/footprint.glsl: F = J J^T of the pixel's differentials in the ray's tangent frame; footprint_to_dpdxy returns its
+    principal axes (minor first); a mirror reflection keeps the eigenvalues"""
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        a = np.cross(d, rng.normal(size=3))
+        a /= np.linalg.norm(a)
+        b = np.cross(d, a)
+        la, lb = rng.uniform(0.01, 0.2), rng.uniform(0.3, 0.9)
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        dst = d - 2 * np.dot(d, n) * n
+        F, px, py, R = O.footprint_probe(d, a * la, b * lb, dst)
+        ev = np.sort(np.linalg.eigvalsh(F.astype(np.float64)))
+        assert np.allclose(ev, [la * la, lb * lb], rtol=2e-4) and abs(F[0, 1] - F[1, 0]) < 1e-7
+        assert np.isclose(np.linalg.norm(px), la, rtol=2e-3) and np.isclose(np.linalg.norm(py), lb, rtol=2e-3)
+        assert abs(np.dot(px, d)) < 1e-5 and abs(np.dot(py, d)) < 1e-5 and abs(np.dot(px, py)) < 1e-4
+        assert np.isclose(abs(np.dot(px / np.linalg.norm(px), a)), 1.0, atol=2e-3)
+        assert np.allclose(np.sort(np.linalg.eigvalsh(R.astype(np.float64))), ev, rtol=2e-3)
