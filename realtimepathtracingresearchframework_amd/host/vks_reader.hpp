@@ -220,9 +220,11 @@ inline std::vector<uint8_t> decode_texture(const uint8_t *data, size_t size, int
 struct Texture {
     bool present = false;
     int width = 0, height = 0, format = 0;
-    std::vector<uint8_t> rgba;
+    uint32_t levels = 0;       // mip levels in `rgba` (RptrTextureDesc.mip_levels: 0 = level 0 only)
+    std::vector<uint8_t> rgba; // the levels back to back as RGBA8
 };
-// -> level 0 as RGBA8; present = false when the file does not exist (textures are optional, vkr.c:475-489)
+// -> every level of the file as RGBA8 (the reference maps dataSize bytes from dataOffset and uploads every level: scene.cpp:866,
+// vulkan/resource_utils.cpp:86-100); present = false when the file does not exist (textures are optional, vkr.c:475-489)
 inline Texture read_vkt(const std::string &path) {
     Texture t;
     bool exists = false;
@@ -237,18 +239,26 @@ inline Texture read_vkt(const std::string &path) {
     if (h6[1] != 1) throw Error("Unsupported file version " + std::to_string(h6[1]) + " in " + path);
     const int nmips = h6[2];
     if (nmips < 1 || raw.size() < 32 + (size_t)24 * nmips) throw Error("Failed to read mip level header.");
-    int32_t mw, mh;
-    uint64_t msize;
-    std::memcpy(&mw, raw.data() + 32, 4);
-    std::memcpy(&mh, raw.data() + 36, 4);
-    std::memcpy(&msize, raw.data() + 40, 8);
-    const size_t data_offset = 32 + (size_t)24 * nmips; // dataOffset = ftell(f) after the mip headers
-    if (data_offset + msize > raw.size()) throw Error("texture payload too short");
-    t.present = true;
-    t.width = mw;
-    t.height = mh;
+    size_t at = 32 + (size_t)24 * nmips; // dataOffset = ftell(f) after the mip headers
     t.format = h6[5];
-    t.rgba = decode_texture(raw.data() + data_offset, (size_t)msize, mw, mh, t.format);
+    int pw = 0, ph = 0;
+    for (int l = 0; l < nmips; ++l) {
+        int32_t mw, mh;
+        uint64_t msize;
+        std::memcpy(&mw, raw.data() + 32 + (size_t)24 * l, 4);
+        std::memcpy(&mh, raw.data() + 36 + (size_t)24 * l, 4);
+        std::memcpy(&msize, raw.data() + 40 + (size_t)24 * l, 8);
+        if (l && (mw != std::max(1, pw / 2) || mh != std::max(1, ph / 2)))
+            throw Error("mip level " + std::to_string(l) + " of " + path + " is " + std::to_string(mw) + " x " + std::to_string(mh));
+        if (at + msize > raw.size()) throw Error("texture payload too short");
+        const std::vector<uint8_t> level = decode_texture(raw.data() + at, (size_t)msize, mw, mh, t.format);
+        t.rgba.insert(t.rgba.end(), level.begin(), level.end());
+        at += (size_t)msize;
+        if (l == 0) t.width = mw, t.height = mh;
+        pw = mw, ph = mh;
+    }
+    t.present = true;
+    t.levels = nmips > 1 ? (uint32_t)nmips : 0u;
     return t;
 }
 
@@ -601,14 +611,14 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
             in.parameterized_mesh = (uint32_t)lod.meshIds[std::min((size_t)remove_first_lods, lod.meshIds.size() - 1)];
         s.instances.push_back(in);
     }
-    auto add_texture = [&](std::vector<uint8_t> rgba, uint32_t w, uint32_t h, bool srgb) {
+    auto add_texture = [&](std::vector<uint8_t> rgba, uint32_t w, uint32_t h, bool srgb, uint32_t levels = 0) {
         s.texels.push_back(std::move(rgba));
         RptrTextureDesc t;
         t.rgba8 = nullptr; // (set below: the vector of vectors may still move)
         t.width = w;
         t.height = h;
         t.srgb = srgb ? 1u : 0u;
-        t.mip_levels = 0;
+        t.mip_levels = levels;
         s.textures.push_back(t);
     };
     for (size_t i = 0; i < v.materialNames.size(); ++i) {
@@ -640,7 +650,7 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
         if (col.present) {
             has_alpha = col.format == FMT_BC1_RGBA_UNORM || col.format == FMT_BC1_RGBA_SRGB || col.format == FMT_BC3_UNORM || col.format == FMT_BC3_SRGB ||
                         col.format == FMT_RGBA8_UNORM || col.format == FMT_RGBA8_SRGB;
-            add_texture(std::move(col.rgba), (uint32_t)col.width, (uint32_t)col.height, true);
+            add_texture(std::move(col.rgba), (uint32_t)col.width, (uint32_t)col.height, true, col.levels);
         } else
             add_texture({255, 255, 255, 255}, 1, 1, true);
         if (!has_alpha) mat.flags |= RPTR_BASE_MATERIAL_NOALPHA;
@@ -650,13 +660,13 @@ inline SceneDump read_scene(const std::string &path, const std::string &data_dir
         }
         Texture nrm = ignore_textures ? Texture{} : read_vkt(tex_dir + name + "_Normal.vkt");
         if (nrm.present)
-            add_texture(std::move(nrm.rgba), (uint32_t)nrm.width, (uint32_t)nrm.height, false);
+            add_texture(std::move(nrm.rgba), (uint32_t)nrm.width, (uint32_t)nrm.height, false, nrm.levels);
         else
             add_texture({127, 127, 127, 255}, 1, 1, false);
         mat.normal_map = (int32_t)tid + 1;
         Texture spec = ignore_textures ? Texture{} : read_vkt(tex_dir + name + "_Specular.vkt");
         if (spec.present)
-            add_texture(std::move(spec.rgba), (uint32_t)spec.width, (uint32_t)spec.height, false);
+            add_texture(std::move(spec.rgba), (uint32_t)spec.width, (uint32_t)spec.height, false, spec.levels);
         else
             add_texture({255, 127, 0, 255}, 1, 1, false);
         mat.roughness = textured_param(tid + 2, 1);

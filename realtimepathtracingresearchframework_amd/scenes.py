@@ -138,6 +138,17 @@ class Texture:
             out.append(m)
         return out
 
+    def packed(self):
+        """the levels back to back in one buffer (RptrTextureDesc.rgba8); the same buffer for every caller while the texture does not
+        change, so that descriptors made earlier (the oracle keeps its scene's) stay valid when another one is made"""
+        key = (id(self.rgba),) + tuple(id(m) for m in (self.mips or []))
+        cache = getattr(self, "_packed", None)
+        if cache is None or cache[0] != key:
+            lv = self.levels()
+            cache = (key, lv[0] if len(lv) == 1 else np.concatenate([l.reshape(-1) for l in lv]), len(lv), lv[0].shape)
+            object.__setattr__(self, "_packed", cache)
+        return cache[1], cache[2], cache[3]
+
 
 @dataclass
 class Scene:
@@ -267,14 +278,13 @@ class Scene:
         d.lights, d.num_lights = LT, nl
         TX = (abi.TextureDesc * max(1, len(self.textures)))()
         for i, t in enumerate(self.textures):
-            lv = t.levels()
-            assert lv[0].ndim == 3 and lv[0].shape[2] == 4
-            px = np.concatenate([l.reshape(-1) for l in lv])   # the levels back to back
+            px, n_levels, shape0 = t.packed()   # the levels back to back
+            assert len(shape0) == 3 and shape0[2] == 4
             keep.append(px)
             TX[i].rgba8 = px.ctypes.data
-            TX[i].height, TX[i].width = lv[0].shape[0], lv[0].shape[1]
+            TX[i].height, TX[i].width = shape0[0], shape0[1]
             TX[i].srgb = 1 if t.srgb else 0
-            TX[i].mip_levels = len(lv) if len(lv) > 1 else 0
+            TX[i].mip_levels = n_levels if n_levels > 1 else 0
         d.textures, d.num_textures = TX, len(self.textures)
         keep += [G, M, P, I, MAT, LT, TX]
         self._keep = keep

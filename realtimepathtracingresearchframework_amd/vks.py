@@ -279,28 +279,37 @@ def encode_bc3(rgba):
 
 
 # ------------------------------------------------------------------ .vkt (vkr.c:216-306, header structs :1511-1531)
-def write_vkt(path, rgba, fmt):
-    """one mip level. `fmt` picks the encoding: RGBA8 (37 / 43) raw, BC1 (131 / 132), BC3 (137 / 138), BC5 (141)."""
-    rgba = np.asarray(rgba, dtype=np.uint8)
-    h, w = rgba.shape[:2]
-    if fmt in (FMT_RGBA8_UNORM, FMT_RGBA8_SRGB):
-        data = np.ascontiguousarray(rgba).tobytes()
-    elif fmt in (FMT_BC1_RGB_UNORM, FMT_BC1_RGB_SRGB):
-        data = encode_bc1(rgba)
-    elif fmt in (FMT_BC3_UNORM, FMT_BC3_SRGB):
-        data = encode_bc3(rgba)
-    elif fmt == FMT_BC5_UNORM:
-        data = encode_bc5(rgba)
-    else:
+def write_vkt(path, rgba, fmt, mips=None):
+    """level 0 and (`mips`) the levels behind it, back to back (vkr.c:1546-1558, 1997-2014). `fmt` picks the encoding: RGBA8 (37 / 43) raw,
+    BC1 (131 / 132), BC3 (137 / 138), BC5 (141)."""
+    def encode(px):
+        px = np.asarray(px, dtype=np.uint8)
+        if fmt in (FMT_RGBA8_UNORM, FMT_RGBA8_SRGB):
+            return np.ascontiguousarray(px).tobytes()
+        if fmt in (FMT_BC1_RGB_UNORM, FMT_BC1_RGB_SRGB):
+            return encode_bc1(px)
+        if fmt in (FMT_BC3_UNORM, FMT_BC3_SRGB):
+            return encode_bc3(px)
+        if fmt == FMT_BC5_UNORM:
+            return encode_bc5(px)
         raise VksError("write_vkt: unsupported format %d" % fmt)
+    levels = [np.asarray(rgba, dtype=np.uint8)] + [np.asarray(m, dtype=np.uint8) for m in (mips or [])]
+    data = [encode(px) for px in levels]
+    h, w = levels[0].shape[:2]
     with open(path, "wb") as f:
-        f.write(struct.pack("<6iQ", VKT_MAGIC, 1, 1, w, h, fmt, len(data)))
-        f.write(struct.pack("<iiQq", w, h, len(data), 32 + 24))
-        f.write(data)
+        f.write(struct.pack("<6iQ", VKT_MAGIC, 1, len(levels), w, h, fmt, sum(len(d) for d in data)))
+        at = 32 + 24 * len(levels)
+        for px, d in zip(levels, data):
+            f.write(struct.pack("<iiQq", px.shape[1], px.shape[0], len(d), at))
+            at += len(d)
+        for d in data:
+            f.write(d)
 
 
 def read_vkt(path):
-    """-> (rgba8 level 0, VkFormat) or None when the file does not exist (textures are optional, vkr.c:475-489)"""
+    """-> (rgba8 level 0, VkFormat, [rgba8 of the levels behind it]) or None when the file does not exist (textures are optional,
+    vkr.c:475-489). The levels lie back to back behind the mip headers (the reference maps dataSize bytes from dataOffset and uploads
+    every level: scene.cpp:866, vulkan/resource_utils.cpp:86-100)."""
     if not os.path.isfile(path):
         return None
     with open(path, "rb") as f:
@@ -314,9 +323,17 @@ def read_vkt(path):
         raise VksError("Unsupported file version %d in %s" % (version, path))
     if nmips < 1 or len(raw) < 32 + 24 * nmips:
         raise VksError("Failed to read mip level header.")
-    mw, mh, msize, _moff = struct.unpack_from("<iiQq", raw, 32)
-    data_offset = 32 + 24 * nmips                             # t->dataOffset = ftell(f) after the mip headers
-    return decode_texture(raw[data_offset:data_offset + msize], mw, mh, fmt), fmt
+    at = 32 + 24 * nmips                                      # t->dataOffset = ftell(f) after the mip headers
+    levels = []
+    for l in range(nmips):
+        mw, mh, msize, _moff = struct.unpack_from("<iiQq", raw, 32 + 24 * l)
+        if l and (mw, mh) != (max(1, levels[-1].shape[1] // 2), max(1, levels[-1].shape[0] // 2)):
+            raise VksError("mip level %d of %s is %d x %d" % (l, path, mw, mh))
+        if at + msize > len(raw):
+            raise VksError("texture payload too short")
+        levels.append(decode_texture(raw[at:at + msize], mw, mh, fmt))
+        at += msize
+    return levels[0], fmt, levels[1:]
 
 
 # ------------------------------------------------------------------ material parameter files (vkr.c:412-452)
@@ -582,17 +599,19 @@ def read_vks(path, ignore_textures=False, load_specularity=False, frame=0, remov
         has_alpha = False
         if col is not None:
             has_alpha = col[1] in (FMT_BC1_RGBA_UNORM, FMT_BC1_RGBA_SRGB, FMT_BC3_UNORM, FMT_BC3_SRGB, FMT_RGBA8_UNORM, FMT_RGBA8_SRGB)
-            s.textures.append(Texture(rgba=col[0], srgb=True))
+            s.textures.append(Texture(rgba=col[0], srgb=True, mips=col[2] or None))
         else:
             s.textures.append(Texture(rgba=np.full((1, 1, 4), 255, np.uint8), srgb=True))
         if not has_alpha:
             mat.flags |= abi.BASE_MATERIAL_NOALPHA
         abi.set_float_bits(mat.base_color, 0, 0x80000000 | tid)
         nrm = None if ignore_textures else vm["texNormal"]
-        s.textures.append(Texture(rgba=nrm[0] if nrm is not None else np.array([[[127, 127, 127, 255]]], np.uint8), srgb=False))
+        s.textures.append(Texture(rgba=nrm[0] if nrm is not None else np.array([[[127, 127, 127, 255]]], np.uint8), srgb=False,
+                                  mips=(nrm[2] or None) if nrm is not None else None))
         mat.normal_map = tid + 1
         spec = None if ignore_textures else vm["texSpecular"]
-        s.textures.append(Texture(rgba=spec[0] if spec is not None else np.array([[[255, 127, 0, 255]]], np.uint8), srgb=False))
+        s.textures.append(Texture(rgba=spec[0] if spec is not None else np.array([[[255, 127, 0, 255]]], np.uint8), srgb=False,
+                                  mips=(spec[2] or None) if spec is not None else None))
         mat.roughness = abi.textured_param(tid + 2, 1)
         mat.metallic = abi.textured_param(tid + 2, 2)
         if load_specularity:
@@ -800,7 +819,9 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
             rgb = _linear_to_srgb8([mat.base_color[0], mat.base_color[1], mat.base_color[2]])
             base_tex = _solid([rgb[0], rgb[1], rgb[2], 255])
         if base_tex is not None:
-            write_vkt(tdir + nm + "_BaseColor.vkt", base_tex, FMT_BC1_RGB_SRGB if (mat.flags & abi.BASE_MATERIAL_NOALPHA) else FMT_RGBA8_UNORM)
+            bits = abi.float_bits(mat.base_color[0])
+            base_mips = scene.textures[bits & 0x1FFFFFFF].mips if (bits & 0x80000000) else None   # a texture's mip levels go along
+            write_vkt(tdir + nm + "_BaseColor.vkt", base_tex, FMT_BC1_RGB_SRGB if (mat.flags & abi.BASE_MATERIAL_NOALPHA) else FMT_RGBA8_UNORM, mips=base_mips)
         chans = []
         for value in (mat.specular, mat.roughness, mat.metallic):
             tex, _ = literal_or_texture(value, channel_of=True)
@@ -812,7 +833,7 @@ def write_vks(path, scene: Scene, version=4, material_names=None, lod_groups=Non
         spec = np.stack([np.broadcast_to(c, (h, w)) for c in chans] + [np.full((h, w), 255, np.uint8)], axis=2)
         write_vkt(tdir + nm + "_Specular.vkt", spec if (h, w) != (1, 1) else _solid(spec[0, 0]), FMT_BC1_RGB_UNORM)
         if mat.normal_map != -1:
-            write_vkt(tdir + nm + "_Normal.vkt", scene.textures[mat.normal_map].rgba, FMT_BC5_UNORM)
+            write_vkt(tdir + nm + "_Normal.vkt", scene.textures[mat.normal_map].rgba, FMT_BC5_UNORM, mips=scene.textures[mat.normal_map].mips)
         if emissive:
             lit = [0.0, 0.0, 0.0] if base_tex is not None else [float(mat.base_color[k]) for k in range(3)]
             with open(tdir + nm + "_EmissionIntensity.txt", "w") as f:

@@ -851,3 +851,49 @@ def test_reprojection_mode_discard_history():
         assert same and rmse < RMSE_TOL
     assert image_error(second, keep)[0] > 10 * RMSE_TOL
     r.close()
+
+
+def _with_mip_chains(s):
+    """box-filtered mip chains for every texture of the scene (test data: the product generates none)"""
+    for t in s.textures:
+        lv, cur = [], np.asarray(t.rgba).astype(np.float64)
+        while cur.shape[0] > 1 or cur.shape[1] > 1:
+            h, w = max(1, cur.shape[0] // 2), max(1, cur.shape[1] // 2)
+            cur = cur[:2 * h if cur.shape[0] > 1 else 1, :2 * w if cur.shape[1] > 1 else 1]
+            cur = cur.reshape(h, cur.shape[0] // h, w, cur.shape[1] // w, 4).mean(axis=(1, 3))
+            lv.append(np.clip(np.round(cur), 0, 255).astype(np.uint8))
+        t.mips = lv or None
+    return s
+
+
+@pytest.mark.parametrize("variant", [abi.VARIANT_GLTF, abi.VARIANT_SIMPLE])
+def test_mip_mapped_textures_and_path_footprints(variant):
+    """textures with mip levels, seen small and at a grazing angle: the footprint a path carries (pt_megakernel.glsl:336-352, 582-606,
+    698-702) picks level and anisotropy of every material lookup (textureGrad) and the normal map drops a level per bounce; image within
+    tolerance of the oracle at two resolutions, and the levels do matter (the same scene without them renders another image)"""
+    s = _with_mip_chains(scenes.textured_test())
+    cam = s.camera_params()
+    for k in range(3):                                   # step back and down: minification, anisotropy
+        cam.pos[k] = cam.pos[k] - 2.5 * cam.dir[k]
+    cam.pos[1] -= 0.6
+    osc = O.OracleScene(s)
+    for W, H, spp in ((96, 72, 3), (240, 180, 1)):
+        r = backend.RenderHip()
+        r.initialize(W, H)
+        r.set_scene(s)
+        r.render(backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True), spp=spp)
+        img = np.zeros((H, W, 4), np.float32)
+        r.readback_framebuffer(img)
+        r.close()
+        ref, _ = osc.render(W, H, spp, variant=variant, camera=cam)
+        rmse, same, maxabs = image_error(img, ref)
+        assert same and rmse < RMSE_TOL, (W, H, rmse, maxabs)
+    flat = scenes.textured_test()
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(flat)
+    r.render(backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True), spp=spp)
+    img2 = np.zeros((H, W, 4), np.float32)
+    r.readback_framebuffer(img2)
+    r.close()
+    assert image_error(img, img2)[0] > 10 * RMSE_TOL

@@ -796,3 +796,30 @@ def test_validation_images_through_the_compare_tool(tmp_path):
     assert subprocess.run([cmp, str(tmp_path / "a_0004.exr"), str(tmp_path / "b_0004.exr")], capture_output=True).returncode == 0
     r = subprocess.run([cmp, str(tmp_path / "a_0004.exr"), str(tmp_path / "c_0005.exr")], capture_output=True, text=True)
     assert r.returncode == 255 and "isn't the same" in r.stderr and os.path.exists(str(tmp_path / "c_0005.exr_err.exr"))
+
+
+def test_cpp_vks_reader_keeps_mip_levels(tmp_path):
+    """a .vks scene whose textures carry mip levels: the C++ reader's flat scene (levels back to back, RptrTextureDesc.mip_levels) equals the
+    Python reader's byte for byte, and the dump reads back with the levels in place"""
+    from realtimepathtracingresearchframework_amd import vks
+    exe = _build_cli(tmp_path)
+    s = scenes.textured_test()
+    for t in s.textures:
+        lv, cur = [], np.asarray(t.rgba)
+        while cur.shape[0] > 1 or cur.shape[1] > 1:
+            cur = np.ascontiguousarray(cur[::2, ::2][:max(1, cur.shape[0] // 2), :max(1, cur.shape[1] // 2)])
+            lv.append(cur)
+        t.mips = lv or None
+    path = str(tmp_path / "t.vks")
+    vks.write_vks(path, s)
+    py, cpp = str(tmp_path / "py.rpsc"), str(tmp_path / "cpp.rpsc")
+    r = vks.read_vks(path)
+    assert any(t.mips for t in r.textures)
+    r.dump(py)
+    out = subprocess.run([exe, path, "--dump-scene", cpp], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert open(py, "rb").read() == open(cpp, "rb").read()
+    again = str(tmp_path / "again.rpsc")
+    out = subprocess.run([exe, cpp, "--dump-scene", again], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert open(again, "rb").read() == open(cpp, "rb").read()

@@ -333,3 +333,41 @@ def test_reference_and_reader_reject_the_same_files(tmp_path):
         except vks.VksError:
             mine_ok = False
         assert mine_ok == (rc == 0), tag
+
+
+def test_vkt_mip_levels_round_trip(tmp_path):
+    """.vkt files hold their mip levels back to back behind the level headers (vkr.c:1546-1558): written, read back level by level (RGBA8
+    bit for bit, BC1 within the block quantisation, levels below 4 x 4 as one padded block) and carried into the scene's textures"""
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, (32, 16, 4)).astype(np.uint8)
+    base[..., 3] = 255
+    mips, cur = [], base
+    while cur.shape[0] > 1 or cur.shape[1] > 1:
+        h, w = max(1, cur.shape[0] // 2), max(1, cur.shape[1] // 2)
+        cur = cur[:2 * h if cur.shape[0] > 1 else 1, :2 * w if cur.shape[1] > 1 else 1].astype(np.float64)
+        cur = np.clip(np.round(cur.reshape(h, cur.shape[0] // h, w, cur.shape[1] // w, 4).mean(axis=(1, 3))), 0, 255).astype(np.uint8)
+        mips.append(cur)
+    assert [m.shape[:2] for m in mips] == [(16, 8), (8, 4), (4, 2), (2, 1), (1, 1)]
+    p = str(tmp_path / "m.vkt")
+    vks.write_vkt(p, base, vks.FMT_RGBA8_UNORM, mips=mips)
+    l0, fmt, rest = vks.read_vkt(p)
+    assert fmt == vks.FMT_RGBA8_UNORM and np.array_equal(l0, base) and len(rest) == 5 and all(np.array_equal(a, b) for a, b in zip(rest, mips))
+    flat = np.tile(np.array([[[200, 40, 90, 255]]], np.uint8), (32, 16, 1))
+    fm = [np.tile(flat[:1, :1], (max(1, 32 >> l), max(1, 16 >> l), 1)) for l in range(1, 6)]
+    vks.write_vkt(p, flat, vks.FMT_BC1_RGB_UNORM, mips=fm)
+    l0, fmt, rest = vks.read_vkt(p)
+    assert [m.shape for m in rest] == [m.shape for m in fm] and all(np.abs(m.astype(int) - f.astype(int)).max() <= 8 for m, f in zip([l0] + rest, [flat] + fm))
+    # through a scene file: the base colour texture of a material keeps its levels
+    s = scenes.textured_test()
+    tid = next(abi.float_bits(m.base_color[0]) & 0x1FFFFFFF for m in s.materials if abi.float_bits(m.base_color[0]) & 0x80000000)
+    t = s.textures[tid]
+    tm, cur = [], np.asarray(t.rgba)
+    while cur.shape[0] > 1 or cur.shape[1] > 1:
+        cur = cur[::2, ::2][:max(1, cur.shape[0] // 2), :max(1, cur.shape[1] // 2)]
+        tm.append(np.ascontiguousarray(cur))
+    t.mips = tm
+    path = str(tmp_path / "t.vks")
+    vks.write_vks(path, s)
+    r = vks.read_vks(path)
+    with_mips = [x for x in r.textures if x.mips]
+    assert len(with_mips) >= 1 and len(with_mips[0].levels()) == len(tm) + 1
