@@ -655,15 +655,28 @@ RP_DEV RpTexCoord rp_hit_texcoord(V2 uv, const M2 &footprint, V3 ray_dir, V3 geo
 }
 // rendering/rt/material_textures.glsl:37-60 (textureGrad: USE_MIPMAPPING, librender/render_params.glsl.h:8)
 RP_DEV bool rp_is_textured(float x) { return (__float_as_uint(x) & RPTR_TEXTURED_PARAM_MASK) != 0u; }
-RP_DEV float4 rp_textured_color_param(const RpScene &sc, float4 x, const RpTexCoord &uv) {
+// the parameters of a material often read channels of ONE texture at one place (.vks: specular / roughness / metallic): the filtered
+// texel of the last lookup is kept, a repeated lookup of the same texture costs nothing (same value: same arithmetic)
+struct RpTexelCache {
+    int id;
+    float4 texel;
+};
+RP_DEV float4 rp_texture_grad_cached(const RpScene &sc, RpTexelCache &cache, int tex_id, const RpTexCoord &uv) {
+    if (cache.id != tex_id) {
+        cache.texel = rp_texture_grad(sc, tex_id, uv);
+        cache.id = tex_id;
+    }
+    return cache.texel;
+}
+RP_DEV float4 rp_textured_color_param(const RpScene &sc, RpTexelCache &cache, float4 x, const RpTexCoord &uv) {
     const uint32_t mask = __float_as_uint(x.x);
-    if (mask & RPTR_TEXTURED_PARAM_MASK) return rp_texture_grad(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+    if (mask & RPTR_TEXTURED_PARAM_MASK) return rp_texture_grad_cached(sc, cache, int(RPTR_TEXTURE_ID(mask)), uv);
     return x;
 }
-RP_DEV float rp_textured_scalar_param(const RpScene &sc, float x, const RpTexCoord &uv) {
+RP_DEV float rp_textured_scalar_param(const RpScene &sc, RpTexelCache &cache, float x, const RpTexCoord &uv) {
     const uint32_t mask = __float_as_uint(x);
     if (mask & RPTR_TEXTURED_PARAM_MASK) {
-        const float4 t = rp_texture_grad(sc, int(RPTR_TEXTURE_ID(mask)), uv);
+        const float4 t = rp_texture_grad_cached(sc, cache, int(RPTR_TEXTURE_ID(mask)), uv);
         const uint32_t ch = RPTR_TEXTURE_CHANNEL(mask);
         return ch == 0 ? t.x : ch == 1 ? t.y : ch == 2 ? t.z : t.w;
     }
@@ -688,8 +701,9 @@ RP_DEV bool rp_alpha_rejects(const RpScene &sc, int inst_idx, int geom, int prim
 // PREMULTIPLIED_BASE_COLOR_ALPHA is defined, vulkan/gpu_params.glsl:12)
 template <int VARIANT, bool TEX>
 RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_radiance, const RptrBaseMaterial &p, const RpTexCoord &uv) {
+    RpTexelCache cache{-1, make_float4(0.0f, 0.0f, 0.0f, 0.0f)};
     const float4 literal = make_float4(p.base_color[0], p.base_color[1], p.base_color[2], 1.0f);
-    const float4 texel = TEX ? rp_textured_color_param(sc, literal, uv) : literal;
+    const float4 texel = TEX ? rp_textured_color_param(sc, cache, literal, uv) : literal;
     const float alpha = texel.w;
     m.base_color = v3(texel.x, texel.y, texel.z);
     if (alpha > 0.001f) m.base_color = m.base_color / alpha;
@@ -699,10 +713,10 @@ RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_rad
         m.metallic = 0.0f;
         m.specular = 0.0f;
     } else {
-        m.specular = TEX ? rp_textured_scalar_param(sc, p.specular, uv) : p.specular;
-        m.roughness = TEX ? rp_textured_scalar_param(sc, p.roughness, uv) : p.roughness;
-        m.metallic = TEX ? rp_textured_scalar_param(sc, p.metallic, uv) : p.metallic;
-        m.ior = TEX ? rp_textured_scalar_param(sc, p.ior, uv) : p.ior;
+        m.specular = TEX ? rp_textured_scalar_param(sc, cache, p.specular, uv) : p.specular;
+        m.roughness = TEX ? rp_textured_scalar_param(sc, cache, p.roughness, uv) : p.roughness;
+        m.metallic = TEX ? rp_textured_scalar_param(sc, cache, p.metallic, uv) : p.metallic;
+        m.ior = TEX ? rp_textured_scalar_param(sc, cache, p.ior, uv) : p.ior;
     }
     emitter_radiance = v3(p.base_color[0], p.base_color[1], p.base_color[2]) * p.emission_intensity;
     if (p.emission_intensity != 0.0f) {
@@ -712,14 +726,14 @@ RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_rad
     if (VARIANT == RPTR_VARIANT_GLTF_TRANSMISSION) { // load_material, gltf_bsdf.glsl:38-62
         m.transmission_roughness = 0.0f;
         m.transmission_color = v3s(0.0f);
-        m.specular_transmission = TEX ? rp_textured_scalar_param(sc, p.specular_transmission, uv) : p.specular_transmission;
+        m.specular_transmission = TEX ? rp_textured_scalar_param(sc, cache, p.specular_transmission, uv) : p.specular_transmission;
         if (m.specular_transmission > 0.0f) {
             if (!(m.ior > 1.0f))
                 m.specular_transmission = 0.0f; // (the reference folds it into the alpha it returns, which nothing reads any more)
             else {
                 m.transmission_color = m.base_color;
                 m.transmission_roughness = m.roughness;
-                m.roughness = sqrtf(TEX ? rp_textured_scalar_param(sc, p.clearcoat_gloss, uv) : p.clearcoat_gloss);
+                m.roughness = sqrtf(TEX ? rp_textured_scalar_param(sc, cache, p.clearcoat_gloss, uv) : p.clearcoat_gloss);
             }
         }
     }
