@@ -1,0 +1,23 @@
+"""tools/soak_dynamic.py [first_seed] [count]: the refit / device-rebuild fuzz tests of tests/test_gpu_dynamic.py over more seeds (GPU).
+(40 seeds, round 2: the only assertion that ever fired is the sanity bound "more than 500 of the 20 000 random queries hit something" on a
+three-instance scene -- results and visit counts never differ.)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_dynamic as T  # noqa: E402
+
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+bad = []
+for seed in range(first, first + count):
+    for name, call in (("refit", lambda: T.test_fuzz_refit_of_soups(seed)), ("rebuild-small", lambda: T.test_device_rebuild_of_soups_and_tiny_meshes(seed)),
+                       ("rebuild-3", lambda: T.test_fuzz_rebuild_of_soups(seed, 3)), ("rebuild-20", lambda: T.test_fuzz_rebuild_of_soups(seed, 20))):
+        try:
+            call()
+        except Exception as e:  # noqa: BLE001
+            bad.append((seed, name))
+            print("seed", seed, name, "FAILED:", str(e)[:300], flush=True)
+print("%d seeds, failures: %s" % (count, bad))
+sys.exit(len(bad))
