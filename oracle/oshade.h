@@ -410,7 +410,8 @@ struct SimpleMaterial {
 //   textureLod(uv, lod): lod clamped to the texture's levels, the two nearest levels blended by the fraction.
 //   textureGrad(uv, ddx, ddy): rho_x = |ddx * size|, rho_y = |ddy * size|; eta = min(rho_max / rho_min, 12); N = ceil(eta) taps at
 //   uv + major * (i / (N + 1) - 1/2), i = 1..N, along the larger derivative, each a textureLod at log2(rho_max / eta), averaged.
-//   Zero derivatives (the any-hit alpha test, pt_megakernel.glsl:205) = one bilinear tap of level 0.
+//   A footprint inside one texel (rho_max <= 1: magnification; zero derivatives: the any-hit alpha test, pt_megakernel.glsl:205) and
+//   1 x 1 textures = one bilinear tap of level 0.
 // Mip levels: RptrTextureDesc.mip_levels levels stored back to back, level l = max(1, w >> l) x max(1, h >> l)
 // (vulkan/resource_utils.cpp:86-100); the reference uploads the levels its .vkt files hold and generates none.
 struct TextureTable {
@@ -488,7 +489,8 @@ static inline vec4 texture_grad(const TextureTable &tt, int tex_id, const TexCoo
     const float mxx = tc.ddx.x * w, mxy = tc.ddx.y * h, myx = tc.ddy.x * w, myy = tc.ddy.y * h;
     const float rx = sqrtf(mxx * mxx + mxy * mxy), ry = sqrtf(myx * myx + myy * myy);
     const float rmax = fmaxf(rx, ry), rmin = fminf(rx, ry);
-    if (!(rmax > 0.0f)) return texture_bilinear(tt, t, 0, tc.uv);
+    // magnification (the footprint lies inside one texel), or nothing to filter (a 1 x 1 texture): one bilinear tap of level 0
+    if (!(rmax > 1.0f) || (t.width == 1u && t.height == 1u)) return texture_bilinear(tt, t, 0, tc.uv);
     const float eta = rmin > 0.0f ? fminf(rmax / rmin, ORC_MAX_ANISOTROPY) : ORC_MAX_ANISOTROPY;
     const int n = (int)ceilf(eta);
     const float lod = log2f(rmax / eta);

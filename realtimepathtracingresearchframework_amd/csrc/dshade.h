@@ -576,7 +576,8 @@ RP_DEV float4 rp_texture_grad(const RpScene &sc, int tex_id, const RpTexCoord &t
     const float mxx = tc.ddx.x * w, mxy = tc.ddx.y * h, myx = tc.ddy.x * w, myy = tc.ddy.y * h;
     const float rx = sqrtf(mxx * mxx + mxy * mxy), ry = sqrtf(myx * myx + myy * myy);
     const float rmax = fmaxf(rx, ry), rmin = fminf(rx, ry);
-    if (!(rmax > 0.0f)) return rp_texture_bilinear(sc, t, 0, tc.uv);
+    // magnification (the footprint lies inside one texel), or nothing to filter (a 1 x 1 texture): one bilinear tap of level 0
+    if (!(rmax > 1.0f) || (t.width == 1 && t.height == 1)) return rp_texture_bilinear(sc, t, 0, tc.uv);
     const float eta = rmin > 0.0f ? fminf(rmax / rmin, RP_MAX_ANISOTROPY) : RP_MAX_ANISOTROPY;
     const int n = int(ceilf(eta));
     const float lod = log2f(rmax / eta);
