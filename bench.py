@@ -480,6 +480,8 @@ def main():
         "traffic": k_ext["hbm_bytes_per_launch"],
         "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per launch "
                            "averaged over the stand-alone closest-hit launches of a frame; gfx950 correction 2 x FETCH_SIZE") if hbm_known else None,
+        # what the measurements say binds the frame (neither of the contract's two): the whole pipeline's VALU instruction issue, see "valu"
+        "binding": "valu_issue", "binding_frac": (valu_frame(pmc, ms_per_step, valu_peak, launches_extend) or {}).get("pipelined_frac") if pmc else None,
         "hbm_frac": k_ext["hbm_frac"], "algorithmic_frac": k_ext["algorithmic_frac"],
         "algorithmic_bytes_per_launch": k_ext["algorithmic_bytes_per_launch"], "algorithmic_gbs": k_ext["algorithmic_gbs"],
         "algorithmic_ceiling": {"gbs": L2_PEAK_GBS, "what": "aggregate L2 bandwidth, MI355X_MICROARCH.md 'L2 (per XCD)': the tree is cache resident, so the bytes the "
