@@ -544,8 +544,7 @@ RP_DEV int rp_wrap_repeat(int i, int n) {
     i %= n;
     return i < 0 ? i + n : i;
 }
-RP_DEV float4 rp_texture_bilinear(const RpScene &sc, const RpTexture &t, int level, V2 uv) {
-    const RpMipView mv = rp_mip_view(t, level);
+RP_DEV float4 rp_texture_bilinear(const RpScene &sc, const RpTexture &t, const RpMipView &mv, V2 uv) {
     const float x = uv.x * float(mv.w) - 0.5f, y = uv.y * float(mv.h) - 0.5f;
     const float x0 = floorf(x), y0 = floorf(y);
     const float fx = x - x0, fy = y - y0;
@@ -557,17 +556,42 @@ RP_DEV float4 rp_texture_bilinear(const RpScene &sc, const RpTexture &t, int lev
     const float4 bot = make_float4(c01.x * gx + c11.x * fx, c01.y * gx + c11.y * fx, c01.z * gx + c11.z * fx, c01.w * gx + c11.w * fx);
     return make_float4(top.x * gy + bot.x * fy, top.y * gy + bot.y * fy, top.z * gy + bot.z * fy, top.w * gy + bot.w * fy);
 }
+RP_DEV float4 rp_texture_bilinear(const RpScene &sc, const RpTexture &t, int level, V2 uv) { return rp_texture_bilinear(sc, t, rp_mip_view(t, level), uv); }
 RP_DEV float4 rp_texture_lod0(const RpScene &sc, int tex_id, V2 uv) { return rp_texture_bilinear(sc, sc.textures[tex_id], 0, uv); }
+// the two levels a clamped lod blends and the weight of the coarser one (0: the finer level alone), chosen once for all taps of a lookup
+struct RpLodPick {
+    RpMipView fine, coarse;
+    float delta;
+};
+RP_DEV RpLodPick rp_pick_levels(const RpTexture &t, float lod) {
+    lod = fminf(fmaxf(lod, 0.0f), fminf(float(t.levels - 1), 16.0f)); // (a NaN lod ends up at level 0)
+    RpLodPick k;
+    k.delta = 0.0f;
+    if (!(lod > 0.0f)) {
+        k.fine = k.coarse = rp_mip_view(t, 0);
+        return k;
+    }
+    const float hi = floorf(lod);
+    k.delta = lod - hi;
+    k.fine = rp_mip_view(t, int(hi));
+    k.coarse = k.fine;
+    if (k.delta != 0.0f) { // one level further
+        k.coarse.texels += (size_t)k.fine.w * (size_t)k.fine.h;
+        if (k.coarse.w > 1) k.coarse.w /= 2;
+        if (k.coarse.h > 1) k.coarse.h /= 2;
+    }
+    return k;
+}
+RP_DEV float4 rp_texture_tap(const RpScene &sc, const RpTexture &t, const RpLodPick &k, V2 uv) {
+    const float4 a = rp_texture_bilinear(sc, t, k.fine, uv);
+    if (k.delta == 0.0f) return a;
+    const float4 b = rp_texture_bilinear(sc, t, k.coarse, uv);
+    const float g = 1.0f - k.delta;
+    return make_float4(a.x * g + b.x * k.delta, a.y * g + b.y * k.delta, a.z * g + b.z * k.delta, a.w * g + b.w * k.delta);
+}
 RP_DEV float4 rp_texture_lod(const RpScene &sc, int tex_id, V2 uv, float lod) {
     const RpTexture t = sc.textures[tex_id];
-    lod = fminf(fmaxf(lod, 0.0f), fminf(float(t.levels - 1), 16.0f));
-    if (!(lod > 0.0f)) return rp_texture_bilinear(sc, t, 0, uv);
-    const float hi = floorf(lod), delta = lod - hi;
-    const float4 a = rp_texture_bilinear(sc, t, int(hi), uv);
-    if (delta == 0.0f) return a;
-    const float4 b = rp_texture_bilinear(sc, t, int(hi) + 1, uv);
-    const float g = 1.0f - delta;
-    return make_float4(a.x * g + b.x * delta, a.y * g + b.y * delta, a.z * g + b.z * delta, a.w * g + b.w * delta);
+    return rp_texture_tap(sc, t, rp_pick_levels(t, lod), uv);
 }
 #define RP_MAX_ANISOTROPY 12.0f
 RP_DEV float4 rp_texture_grad(const RpScene &sc, int tex_id, const RpTexCoord &tc) {
@@ -580,12 +604,12 @@ RP_DEV float4 rp_texture_grad(const RpScene &sc, int tex_id, const RpTexCoord &t
     if (!(rmax > 1.0f) || (t.width == 1 && t.height == 1)) return rp_texture_bilinear(sc, t, 0, tc.uv);
     const float eta = rmin > 0.0f ? fminf(rmax / rmin, RP_MAX_ANISOTROPY) : RP_MAX_ANISOTROPY;
     const int n = int(ceilf(eta));
-    const float lod = log2f(rmax / eta);
+    const RpLodPick pick = rp_pick_levels(t, log2f(rmax / eta));
     const V2 major = rx > ry ? tc.ddx : tc.ddy;
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = 1; i <= n; ++i) {
         const float at = float(i) / float(n + 1) - 0.5f;
-        const float4 c = rp_texture_lod(sc, tex_id, v2(tc.uv.x + major.x * at, tc.uv.y + major.y * at), lod);
+        const float4 c = rp_texture_tap(sc, t, pick, v2(tc.uv.x + major.x * at, tc.uv.y + major.y * at));
         sum = make_float4(sum.x + c.x, sum.y + c.y, sum.z + c.z, sum.w + c.w);
     }
     const float inv = 1.0f / float(n);
