@@ -50,6 +50,7 @@ def _compare_with_dump(path, ref):
             assert (m[mine] is None) == (r[theirs] is None), (name, mine)
             if m[mine] is not None:
                 assert m[mine][0].shape[:2] == (r[theirs]["height"], r[theirs]["width"]) and m[mine][1] == r[theirs]["format"]
+                assert 1 + len(m[mine][2]) == r[theirs]["numMipLevels"] and r[theirs]["dataOffset"] == 32 + 24 * r[theirs]["numMipLevels"], (name, mine)
     # the transform table as the reference dequantises it
     assert len(ref["transforms"]) == v["numStaticTransforms"]
     for k, r in enumerate(ref["transforms"]):
@@ -371,3 +372,29 @@ def test_vkt_mip_levels_round_trip(tmp_path):
     r = vks.read_vks(path)
     with_mips = [x for x in r.textures if x.mips]
     assert len(with_mips) >= 1 and len(with_mips[0].levels()) == len(tm) + 1
+
+
+@needs_ref
+def test_mip_mapped_vkt_files_are_read_by_the_reference(tmp_path):
+    """pinned by oracle/_ref: .vkt files written with several mip levels are accepted by the reference's own reader, which reports the
+    level count, the payload size and the payload offset the writer meant (vkr.c:248-300)"""
+    s = scenes.textured_test()
+    for t in s.textures:
+        lv, cur = [], np.asarray(t.rgba)
+        while cur.shape[0] > 1 or cur.shape[1] > 1:
+            cur = np.ascontiguousarray(cur[::2, ::2][:max(1, cur.shape[0] // 2), :max(1, cur.shape[1] // 2)])
+            lv.append(cur)
+        t.mips = lv or None
+    path = str(tmp_path / "m.vks")
+    vks.write_vks(path, s)
+    out = str(tmp_path / "dump.json")
+    assert _ref().ref_vkr_dump(path.encode(), out.encode()) == 0
+    ref = json.load(open(out))
+    _compare_with_dump(path, ref)
+    levels = [m["texBaseColor"]["numMipLevels"] for m in ref["materials"] if m["texBaseColor"]]
+    assert max(levels) >= 4
+    tdir = vks.texture_dir(path)
+    for m in ref["materials"]:
+        for key, suffix in (("texBaseColor", "_BaseColor.vkt"), ("texNormal", "_Normal.vkt"), ("texSpecular", "_Specular.vkt")):
+            if m[key]:
+                assert m[key]["dataOffset"] + m[key]["dataSize"] == os.path.getsize(tdir + m["name"] + suffix)
