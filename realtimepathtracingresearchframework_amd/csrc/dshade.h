@@ -541,6 +541,7 @@ RP_DEV float4 rp_texel(const RpScene &sc, const RpTexture &t, const RpMipView &v
     return make_float4(float(c.x) / 255.0f, float(c.y) / 255.0f, float(c.z) / 255.0f, float(c.w) / 255.0f);
 }
 RP_DEV int rp_wrap_repeat(int i, int n) {
+    if ((n & (n - 1)) == 0) return i & (n - 1); // power-of-two sizes (the usual case): no integer division (~30 instructions each, 4 per tap)
     i %= n;
     return i < 0 ? i + n : i;
 }
