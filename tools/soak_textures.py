@@ -1,0 +1,64 @@
+"""tools/soak_textures.py [count]: the textured test scene with random mip-mapped textures from random view points (near, far, grazing),
+both variants with textures, against the oracle (GPU): footprint propagation and the software sampler beyond the suite's two views."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from common import RMSE_TOL, image_error  # noqa: E402
+from realtimepathtracingresearchframework_amd import abi, backend, scenes  # noqa: E402
+
+
+def chain(level0):
+    out, cur = [], level0.astype(np.float64)
+    while cur.shape[0] > 1 or cur.shape[1] > 1:
+        h, w = max(1, cur.shape[0] // 2), max(1, cur.shape[1] // 2)
+        cur = cur[:2 * h if cur.shape[0] > 1 else 1, :2 * w if cur.shape[1] > 1 else 1]
+        cur = cur.reshape(h, cur.shape[0] // h, w, cur.shape[1] // w, 4).mean(axis=(1, 3))
+        out.append(np.clip(np.round(cur), 0, 255).astype(np.uint8))
+    return out
+
+
+count = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+bad, worst = [], 0.0
+for seed in range(count):
+    rng = np.random.default_rng(1000 + seed)
+    s = scenes.textured_test()
+    for t in s.textures:
+        if rng.random() < 0.8:   # another size (also non-power-of-two), fresh texels, a full or a cut-off chain
+            h, w = int(rng.choice([3, 8, 20, 64, 128])), int(rng.choice([5, 16, 48, 64, 256]))
+            px = rng.integers(0, 256, (h, w, 4)).astype(np.uint8)
+            px[..., 3] = 255 if rng.random() < 0.7 else px[..., 3] | 128
+            if t.rgba.shape[:2] == (2, 2) or rng.random() < 0.5:
+                px[..., :3] = (px[..., :3].astype(np.int32) // 2 + 64).astype(np.uint8)
+            t.rgba = px
+            full = chain(px)
+            t.mips = full[:int(rng.integers(0, len(full) + 1))] or None
+    cam = s.camera_params()
+    back = float(rng.uniform(-0.5, 6.0))
+    for k in range(3):
+        cam.pos[k] = cam.pos[k] - back * cam.dir[k]
+    cam.pos[1] += float(rng.uniform(-0.9, 1.5))
+    cam.pos[0] += float(rng.uniform(-1.0, 1.0))
+    W, H, spp = int(rng.choice([64, 120, 200])), int(rng.choice([48, 90, 150])), int(rng.integers(1, 4))
+    variant = abi.VARIANT_GLTF if seed % 3 else abi.VARIANT_GLTF_TRANSMISSION
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    r.render(backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True), spp=spp)
+    img = np.zeros((H, W, 4), np.float32)
+    r.readback_framebuffer(img)
+    r.close()
+    ref, _ = O.OracleScene(s).render(W, H, spp, variant=variant, camera=cam)
+    rmse, same, maxabs = image_error(img, ref)
+    worst = max(worst, rmse)
+    if not (same and rmse < RMSE_TOL):
+        d = np.abs(img[..., :3] - ref[..., :3]).max(axis=2)
+        bad.append(seed)
+        print("seed", seed, "%dx%d spp %d variant %d: rmse %g, %d pixels differ by more than 1e-3 (max %g)" % (W, H, spp, variant, rmse, int((d > 1e-3).sum()), maxabs), flush=True)
+print("%d views, %d beyond 1e-3 RMSE: %s; largest RMSE %.3g" % (count, len(bad), bad, worst))
+sys.exit(len(bad))
