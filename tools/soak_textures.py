@@ -56,8 +56,10 @@ for seed in range(count):
     ref, _ = O.OracleScene(s).render(W, H, spp, variant=variant, camera=cam)
     rmse, same, maxabs = image_error(img, ref)
     worst = max(worst, rmse)
+    d = np.abs(img[..., :3] - ref[..., :3]).max(axis=2)
+    if rmse > 1e-4 and os.environ.get("SOAK_VERBOSE"):
+        print("seed", seed, "%dx%d spp %d: rmse %.3g, pixels off by > 1e-3: %d, > 1e-5: %d, max %.3g" % (W, H, spp, rmse, int((d > 1e-3).sum()), int((d > 1e-5).sum()), d.max()), flush=True)
     if not (same and rmse < RMSE_TOL):
-        d = np.abs(img[..., :3] - ref[..., :3]).max(axis=2)
         bad.append(seed)
         print("seed", seed, "%dx%d spp %d variant %d: rmse %g, %d pixels differ by more than 1e-3 (max %g)" % (W, H, spp, variant, rmse, int((d > 1e-3).sum()), maxabs), flush=True)
 print("%d views, %d beyond 1e-3 RMSE: %s; largest RMSE %.3g" % (count, len(bad), bad, worst))
