@@ -1,5 +1,5 @@
 // read_image.hpp -- reads back what the validation / profiling / data-capture modes write (and what a build of the reference writes where
-// no wavelet decoder is needed): single-part scan-line OpenEXR files with compression NONE, ZIPS or ZIP (zlib), channels of type HALF,
+// no wavelet decoder is needed): single-part scan-line OpenEXR files with compression NONE, RLE, ZIPS or ZIP (zlib), channels of type HALF,
 // FLOAT or UINT, every channel decoded to a float plane; and PFM. No tinyexr (the reference's util/compare_exr.cpp:16-49 loads through
 // it with requested_pixel_types = FLOAT: the same result for these files). PIZ / PXR24 / B44 / DWA and tiled files are refused by name.
 #pragma once
@@ -49,11 +49,28 @@ inline float half_bits_to_float(uint16_t h) {
     std::memcpy(&f, &u, 4);
     return f;
 }
-// the byte shuffle + delta predictor OpenEXR's ZIP / ZIPS compression applies before deflate, undone
-inline void exr_unzip(const uint8_t *src, size_t src_size, uint8_t *dst, size_t dst_size) {
+// the byte shuffle + delta predictor OpenEXR's ZIP / ZIPS / RLE compression applies before the entropy coder, undone; rle: run-length
+// coded (count >= 0: count + 1 copies of the next byte, count < 0: -count literal bytes) instead of deflated
+inline void exr_unzip(const uint8_t *src, size_t src_size, uint8_t *dst, size_t dst_size, bool rle = false) {
     std::vector<uint8_t> t(dst_size);
-    uLongf got = (uLongf)dst_size;
-    if (uncompress(t.data(), &got, src, (uLong)src_size) != Z_OK || got != dst_size) throw std::runtime_error("corrupt ZIP block in EXR file");
+    if (rle) {
+        size_t in = 0, out = 0;
+        while (in < src_size) {
+            const int count = (int8_t)src[in++];
+            const size_t n = count < 0 ? (size_t)(-count) : (size_t)count + 1;
+            if (out + n > dst_size || in + (count < 0 ? n : 1) > src_size) throw std::runtime_error("corrupt RLE block in EXR file");
+            if (count < 0) {
+                std::memcpy(t.data() + out, src + in, n);
+                in += n;
+            } else
+                std::memset(t.data() + out, src[in++], n);
+            out += n;
+        }
+        if (out != dst_size) throw std::runtime_error("corrupt RLE block in EXR file");
+    } else {
+        uLongf got = (uLongf)dst_size;
+        if (uncompress(t.data(), &got, src, (uLong)src_size) != Z_OK || got != dst_size) throw std::runtime_error("corrupt ZIP block in EXR file");
+    }
     for (size_t i = 1; i < dst_size; ++i) t[i] = (uint8_t)(t[i - 1] + t[i] - 128);
     const size_t half = (dst_size + 1) / 2;
     for (size_t i = 0; i < dst_size; ++i) dst[i] = (i & 1) ? t[half + i / 2] : t[i / 2];
@@ -87,8 +104,8 @@ inline PlanarImage read_exr(const std::string &path) {
         if (!attrs.count(need)) throw std::runtime_error(std::string("EXR header without ") + need + " in " + path);
     const int compression = attrs["compression"][0];
     static const char *comp_names[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
-    if (!(compression == 0 || compression == 2 || compression == 3))
-        throw std::runtime_error(path + ": compression " + (compression < 10 ? comp_names[compression] : "?") + " is not supported (NONE, ZIPS, ZIP are)");
+    if (!(compression >= 0 && compression <= 3))
+        throw std::runtime_error(path + ": compression " + (compression < 10 ? comp_names[compression] : "?") + " is not supported (NONE, RLE, ZIPS, ZIP are)");
     int32_t box[4];
     std::memcpy(box, attrs["dataWindow"].data(), 16);
     PlanarImage img;
@@ -133,7 +150,7 @@ inline PlanarImage read_exr(const std::string &path) {
             if (size != want) throw std::runtime_error("scan-line block of the wrong size in " + path);
             std::memcpy(block.data(), raw.data() + off + 8, want);
         } else
-            exr_unzip(raw.data() + off + 8, size, block.data(), want);
+            exr_unzip(raw.data() + off + 8, size, block.data(), want, compression == 1);
         const uint8_t *p = block.data();
         for (int l = 0; l < lines; ++l)
             for (size_t c = 0; c < nch; ++c) {

@@ -2,7 +2,7 @@
 // `--validation <prefix>`): every CMP image is compared with REF channel by channel, the relative error of a value is |ref - cmp| / ref
 // (|cmp| where ref is 0, :71-76), an image with an error above 1e-6 anywhere "isn't the same" (:80-81), the error of every value is
 // written to <CMP>_err.exr (32-bit float channels, :86-92), the exit code is -1 when any image differs or cannot be read (:99-130).
-// Files: what host/read_image.hpp reads (scan-line EXR with NONE / ZIP / ZIPS compression, PFM).
+// Files: what host/read_image.hpp reads (scan-line EXR with NONE / RLE / ZIP / ZIPS compression, PFM).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -697,7 +697,7 @@ def _build_compare(tmp_path):
 
 def write_exr_py(path, planes, half=False, compression=0):
     """a scan-line OpenEXR file written independently of host/write_image.hpp: `planes` = {channel name: (h, w) array}, channels stored in
-    alphabetical order as FLOAT or HALF, compression NONE (0), ZIPS (2) or ZIP (3) with OpenEXR's byte shuffle + delta predictor"""
+    alphabetical order as FLOAT or HALF, compression NONE (0), RLE (1), ZIPS (2) or ZIP (3) with OpenEXR's byte shuffle + delta predictor"""
     import struct
     import zlib
     names = sorted(planes)
@@ -722,7 +722,25 @@ def write_exr_py(path, planes, half=False, compression=0):
             t = np.concatenate([b[0::2], b[1::2]]).astype(np.int32)
             d = t.copy()
             d[1:] = (t[1:] - t[:-1] + 128 + 256) & 0xFF
-            z = zlib.compress(d.astype(np.uint8).tobytes())
+            d = d.astype(np.uint8).tobytes()
+            if compression == 1:      # RLE: runs of 3..128 equal bytes as (n - 1, byte), everything else as (-n, n literal bytes)
+                z, i = bytearray(), 0
+                while i < len(d):
+                    run = 1
+                    while i + run < len(d) and run < 128 and d[i + run] == d[i]:
+                        run += 1
+                    if run >= 3:
+                        z += bytes([run - 1, d[i]])
+                        i += run
+                    else:
+                        j = i
+                        while j < len(d) and j - i < 127 and not (j + 2 < len(d) and d[j] == d[j + 1] == d[j + 2]):
+                            j += 1
+                        z += bytes([(256 - (j - i)) & 0xFF]) + d[i:j]
+                        i = j
+                z = bytes(z)
+            else:
+                z = zlib.compress(d)
             data = z if len(z) < len(raw) else raw
         blocks.append(struct.pack("<iI", y0, len(data)) + data)
     table_at = len(head)
@@ -760,6 +778,10 @@ def test_compare_tool_follows_compare_exr(tmp_path):
     want[0, 0, 0] = np.float32(3e-6)
     assert np.array_equal(err, want)
     # half channels (what the AOV captures hold), a PFM pair, a size mismatch, an unsupported compression, the usage
+    smooth = {n: np.round(v * 4).astype(np.float32) / 4 for n, v in base.items()}          # long runs after the predictor: RLE pays
+    write_exr_py(str(tmp_path / "r0.exr"), smooth, compression=0)
+    write_exr_py(str(tmp_path / "r1.exr"), smooth, compression=1)
+    assert os.path.getsize(tmp_path / "r1.exr") < os.path.getsize(tmp_path / "r0.exr") and run("r0.exr", "r1.exr").returncode == 0
     hb = {n: v.astype(np.float16) for n, v in base.items()}
     write_exr_py(str(tmp_path / "h1.exr"), hb, half=True, compression=0)
     write_exr_py(str(tmp_path / "h2.exr"), hb, half=True, compression=3)
