@@ -140,7 +140,8 @@ class Texture:
 
     def packed(self):
         """the levels back to back in one buffer (RptrTextureDesc.rgba8); the same buffer for every caller while the texture does not
-        change, so that descriptors made earlier (the oracle keeps its scene's) stay valid when another one is made"""
+        change, so that descriptors made earlier (the oracle keeps its scene's) stay valid when another one is made. A texture with mip
+        levels is copied into that buffer once: assign new arrays to `rgba` / `mips` instead of writing into the old ones."""
         key = (id(self.rgba),) + tuple(id(m) for m in (self.mips or []))
         cache = getattr(self, "_packed", None)
         if cache is None or cache[0] != key:
