@@ -264,6 +264,10 @@ typedef struct RptrSceneDesc {
  * s % world_size.  A rank only allocates and renders its own rows. */
 /* Threading: a handle is not thread-safe; calls on ONE handle must come from one thread at a time (different handles are
  * independent). Everything is asynchronous to the host only where said so (rptr_hip_render_async, *_device copies). */
+/* Version of this header's struct layouts and field meanings. History: 1 = round 1; 2 = RptrTextureDesc._pad became mip_levels, RptrStats grew
+ * the stage split; 3 = RptrCreateInfo._pad became abi_version (checked), rank 0 keeps two assembled frames. rptr_hip_abi_version()
+ * returns the library's value. Fields named _pad must be zero. */
+#define RPTR_HIP_ABI_VERSION 3
 typedef struct RptrCreateInfo {
     int32_t device_ordinal; /* hipSetDevice                                      */
     int32_t rank;
@@ -274,7 +278,9 @@ typedef struct RptrCreateInfo {
                                * their own streams, see rptr_hip_render_async. Every context's stream wants a hardware
                                * queue of its own: start the process with GPU_MAX_HW_QUEUES >= frames_in_flight + 1
                                * (HIP runtime variable, default 4; streams that share a queue serialise).          */
-    int32_t _pad;
+    int32_t abi_version;      /* RPTR_HIP_ABI_VERSION of the header the caller was compiled against: rptr_hip_create refuses any other
+                               * value (a caller built against an older header would hand over structs whose former padding
+                               * fields have since been given a meaning, e.g. RptrTextureDesc.mip_levels) */
 } RptrCreateInfo;
 
 typedef struct RptrStats {
@@ -306,6 +312,7 @@ typedef struct rptr_hip rptr_hip_t;
 
 /* ---- lifetime (≙ create_backend_function, render_backend.h:118-119) */
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out);
+int rptr_hip_abi_version(void);
 void rptr_hip_destroy(rptr_hip_t *h);
 const char *rptr_hip_last_error(const rptr_hip_t *h);
 const char *rptr_hip_name(void); /* RenderBackend::name() */
@@ -434,7 +441,9 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
  * for the send on the device, nothing else does -- with frames in flight the gather of frame i overlaps the rendering of frames
  * i+1.. . The assembled frame (rank 0) is read with rptr_hip_readback_gathered_f32 (which waits for the last gather) or used in
  * place through rptr_hip_gathered_frame (valid once rptr_hip_readback_gathered_f32 / rptr_hip_comm_stats have waited for it, or the device has been synchronised by the
- * caller). Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
+ * caller). Rank 0 keeps TWO receive buffers and TWO assembled frames and uses them in turn: the frame of gather g stays intact while
+ * gather g + 1 arrives and is assembled (a reader can hold frame i while i + 1 is in flight), and is rewritten by gather g + 2.
+ * Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
  * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. */
 #define RPTR_COMM_ID_BYTES 128
 int rptr_hip_comm_get_unique_id(void *out_id128);

@@ -146,7 +146,7 @@ class RenderHip:
         work on it), or None / 0 for a stream the backend owns. torch's *default* stream has handle 0: to share ordering
         with torch, make a torch.cuda.Stream() current and pass its .cuda_stream (bench.py does)."""
         self._L = load_library()
-        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream, frames_in_flight, 0)
+        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream, frames_in_flight, abi.ABI_VERSION)
         self.frames_in_flight = max(1, frames_in_flight)
         h = C.c_void_p()
         rc = self._L.rptr_hip_create(C.byref(info), C.byref(h))

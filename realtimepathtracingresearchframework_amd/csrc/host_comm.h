@@ -70,9 +70,14 @@ struct RptrComm {
     hipStream_t stream = nullptr;     // everything of a gather runs here, behind the frame it sends
     hipEvent_t ev_src = nullptr;      // "the waited frame is visible" (recorded on the backend's stream)
     hipEvent_t ev_done = nullptr;     // the last gather of this rank has finished (send done / frame assembled)
-    // rank 0
-    float4 *recv = nullptr;           // packed rows of the ranks 1..N-1 (RPTR_COMM_SELF: and of rank 0), rank after rank
-    float4 *gathered = nullptr;       // the assembled frame, width * height
+    // rank 0: two slots, used in turn (gather g works on slot g % 2), so that a reader can hold frame i while frame i + 1 arrives and is
+    // assembled, and so that a peer's copy for gather g + 1 never lands in the rows gather g is still assembling from
+    float4 *recv[2] = {nullptr, nullptr};      // packed rows of the ranks 1..N-1 (RPTR_COMM_SELF: and of rank 0), rank after rank
+    float4 *gathered[2] = {nullptr, nullptr};  // the assembled frame, width * height
+    hipEvent_t ev_slot[2] = {nullptr, nullptr}; // "the assembly that used this slot has finished" (recorded on rank 0's stream)
+    bool slot_used[2] = {false, false};
+    int last_slot = 0;                // the slot of the last gather: what rptr_hip_gathered_frame / _readback_gathered_f32 show
+    size_t bytes_owned = 0;           // device bytes of the buffers above (counted in the handle's bytes_frame)
     unsigned long long *d_offsets = nullptr; // per rank: first float4 of its rows in `recv`
     std::vector<size_t> rank_pixels, rank_offset;
     bool self = false;                // RPTR_COMM_SELF=1 (diagnostic): rank 0's own rows also travel through ncclSend / ncclRecv
@@ -134,14 +139,27 @@ int comm_setup_local(rptr_hip *h, int transport) {
         if (r != 0 || c->self) at += c->rank_pixels[(size_t)r];
     }
     if (h->rank == 0) {
-        // (comm buffers are frame-sized: released with the frame buffers by the next initialize, which also drops the communicator)
+        // the communicator owns its buffers (frame-sized: comm_release frees them, and the next initialize drops the communicator)
+        const size_t npix = (size_t)h->width * h->height;
+        auto own = [&](void **out, size_t bytes) -> int {
+            bytes = std::max<size_t>(bytes, 16);
+            hipError_t e = hipMalloc(out, bytes);
+            if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            c->bytes_owned += bytes;
+            h->bytes_frame += bytes;
+            h->bytes_allocated = h->bytes_scene + h->bytes_frame;
+            return RPTR_OK;
+        };
         int rc;
-        if ((rc = dev_alloc(h, &c->recv, at, nullptr))) return rc;
-        if ((rc = dev_alloc(h, &c->gathered, (size_t)h->width * h->height, nullptr))) return rc;
-        if ((rc = dev_alloc(h, &c->d_offsets, (size_t)h->world, nullptr))) return rc;
+        for (int s = 0; s < 2; ++s) {
+            if ((rc = own((void **)&c->recv[s], at * sizeof(float4)))) return rc;
+            if ((rc = own((void **)&c->gathered[s], npix * sizeof(float4)))) return rc;
+            HIP_TRY(h, hipMemset(c->gathered[s], 0, npix * sizeof(float4)));
+            HIP_TRY(h, hipEventCreateWithFlags(&c->ev_slot[s], hipEventDisableTiming));
+        }
+        if ((rc = own((void **)&c->d_offsets, (size_t)h->world * sizeof(unsigned long long)))) return rc;
         std::vector<unsigned long long> off(c->rank_offset.begin(), c->rank_offset.end());
         HIP_TRY(h, hipMemcpy(c->d_offsets, off.data(), off.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-        HIP_TRY(h, hipMemset(c->gathered, 0, (size_t)h->width * h->height * sizeof(float4)));
     }
     return RPTR_OK;
 }
@@ -152,13 +170,20 @@ void comm_release(rptr_hip *h) {
     (void)hipSetDevice(h->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
-    for (hipEvent_t e : {c->ev_src, c->ev_done, c->ev_copied, c->ev_t0, c->ev_t1})
+    for (hipEvent_t e : {c->ev_src, c->ev_done, c->ev_copied, c->ev_t0, c->ev_t1, c->ev_slot[0], c->ev_slot[1]})
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (void *p : {(void *)c->recv[0], (void *)c->recv[1], (void *)c->gathered[0], (void *)c->gathered[1], (void *)c->d_offsets})
+        if (p) (void)hipFree(p);
+    h->bytes_frame -= std::min(h->bytes_frame, c->bytes_owned);
+    h->bytes_allocated = h->bytes_scene + h->bytes_frame;
     for (FrameCtx &fc : h->ctx) fc.gather_pending = false;
     delete c;
     h->comm = nullptr;
 }
+
+// the slot (rank 0's receive buffer + assembled frame) the gather that is being issued works on
+inline int comm_slot(const RptrComm *c) { return (int)(c->gathers & 1u); }
 
 // the image the gather sends: the rows of the frame that was waited for last
 const float4 *comm_source(rptr_hip *h, FrameCtx *&owner) {
@@ -203,8 +228,12 @@ int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner) {
     RptrComm *c = h->comm;
     if (h->rank == 0) {
         const size_t npix = (size_t)h->width * h->height;
-        hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered, src, c->recv, c->d_offsets, h->width, h->height,
-                           h->stripe_rows, h->world, c->self ? 1 : 0);
+        const int slot = comm_slot(c);
+        hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered[slot], src, c->recv[slot], c->d_offsets, h->width,
+                           h->height, h->stripe_rows, h->world, c->self ? 1 : 0);
+        HIP_TRY(h, hipEventRecord(c->ev_slot[slot], c->stream));
+        c->slot_used[slot] = true;
+        c->last_slot = slot;
     }
     if (!c->timing_pending) {
         HIP_TRY(h, hipEventRecord(c->ev_t1, c->stream));
@@ -227,7 +256,7 @@ int comm_post_rccl(rptr_hip *h, const float4 *src) {
     if ((h->rank != 0 || c->self) && mine) NCCL_TRY(h, R.Send(src, mine * 4, ncclFloat, 0, c->nccl, c->stream));
     if (h->rank == 0)
         for (int r = c->self ? 0 : 1; r < h->world; ++r)
-            if (c->rank_pixels[(size_t)r]) NCCL_TRY(h, R.Recv(c->recv + c->rank_offset[(size_t)r], c->rank_pixels[(size_t)r] * 4, ncclFloat, r, c->nccl, c->stream));
+            if (c->rank_pixels[(size_t)r]) NCCL_TRY(h, R.Recv(c->recv[comm_slot(c)] + c->rank_offset[(size_t)r], c->rank_pixels[(size_t)r] * 4, ncclFloat, r, c->nccl, c->stream));
     return RPTR_OK;
 }
 
@@ -352,18 +381,21 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
         NCCL_TRY(h0, R.GroupEnd());
         if (rc) return rc;
     } else {
-        // peer copies: rank r writes its rows into rank 0's receive buffer on its OWN communication stream (behind its frame), rank 0's
-        // stream waits for every copy before it assembles
+        // peer copies: rank r writes its rows into rank 0's receive buffer on its OWN communication stream (behind its frame, and behind
+        // the assembly that last read this slot of the receive buffer), rank 0's stream waits for every copy before it assembles
+        const int slot = comm_slot(c0);
+        float4 *recv = c0->recv[slot];
         for (int i = c0->self ? 0 : 1; i < n; ++i) {
             rptr_hip *h = handles[i];
             RptrComm *c = h->comm;
             const size_t bytes = c0->rank_pixels[(size_t)i] * sizeof(float4);
             if (!bytes) continue;
             HIP_TRY(h, hipSetDevice(h->device));
+            if (c0->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(c->stream, c0->ev_slot[slot], 0));
             if (h->device == h0->device)
-                HIP_TRY(h, hipMemcpyAsync(c0->recv + c0->rank_offset[(size_t)i], src[(size_t)i], bytes, hipMemcpyDeviceToDevice, c->stream));
+                HIP_TRY(h, hipMemcpyAsync(recv + c0->rank_offset[(size_t)i], src[(size_t)i], bytes, hipMemcpyDeviceToDevice, c->stream));
             else
-                HIP_TRY(h, hipMemcpyPeerAsync(c0->recv + c0->rank_offset[(size_t)i], h0->device, src[(size_t)i], h->device, bytes, c->stream));
+                HIP_TRY(h, hipMemcpyPeerAsync(recv + c0->rank_offset[(size_t)i], h0->device, src[(size_t)i], h->device, bytes, c->stream));
             HIP_TRY(h, hipEventRecord(c->ev_copied, c->stream));
             HIP_TRY(h0, hipSetDevice(h0->device));
             HIP_TRY(h0, hipStreamWaitEvent(c0->stream, c->ev_copied, 0));
@@ -380,7 +412,7 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
 int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f) {
     if (!h || !out_device_rgba32f) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
-    *out_device_rgba32f = h->comm->gathered;
+    *out_device_rgba32f = h->comm->gathered[h->comm->last_slot]; // stays intact during the NEXT gather (two slots), is rewritten by the one after
     return RPTR_OK;
 }
 
@@ -390,7 +422,7 @@ int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats) 
     const size_t need = (size_t)h->width * h->height * 4;
     if (n_floats < need) return fail(h, RPTR_E_INVALID, "read-back buffer too small");
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered, need * sizeof(float), hipMemcpyDeviceToHost, h->comm->stream));
+    HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered[h->comm->last_slot], need * sizeof(float), hipMemcpyDeviceToHost, h->comm->stream));
     HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
     return RPTR_OK;
 }

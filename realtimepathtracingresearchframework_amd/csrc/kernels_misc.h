@@ -224,8 +224,11 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
                 const int s = k * per_frame + j;
                 const float4 il = ps.illum[size_t(s) * size_t(f.npix_padded) + slot];
                 const float4 c = make_float4(il.x, il.y, il.z, __float_as_int(il.w) == 0 ? 0.0f : 1.0f); // pt_megakernel.glsl:736
-                // REPROJECTION_MODE_DISCARD_HISTORY (process_samples.comp:116-131): the history is not folded in, a frame shows its own samples
-                const uint32_t sample_index = f.rp.reprojection_mode == 1 ? uint32_t(j) : rp_slot_frame(f, uint32_t(s)).sample_index;
+                // REPROJECTION_MODE_DISCARD_HISTORY (process_samples.comp:116-131): the history of EARLIER frames is not folded in, a frame shows
+                // all of its own samples -- the index inside the frame, which for a frame the backend splits into several internal launches
+                // (spp > max_batch_spp) continues where the previous launch stopped (sample_base - frame_id samples of this frame came before)
+                const uint32_t in_frame = (f.batch_frames > 1 ? 0u : f.sample_base - f.frame_id) + uint32_t(j);
+                const uint32_t sample_index = f.rp.reprojection_mode == 1 ? in_frame : rp_slot_frame(f, uint32_t(s)).sample_index;
                 if (sample_index == 0)
                     acc = c;
                 else {

@@ -231,6 +231,44 @@ int fail(rptr_hip *h, int code, const char *fmt, ...) {
     return code;
 }
 
+// Hardware queues. Every frame context renders on a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+// queues (default 4): streams that share a queue serialise, and the schedule bench.py measures (11 contexts) needs one queue per
+// context + the caller's stream + the communication stream. The runtime reads the variable ONCE, when the process makes its first HIP
+// call -- so the library sets it (a) when it is loaded (constructor below: 16, only if the variable is unset) and (b) raises it in the
+// first rptr_hip_create when more contexts are asked for, which still works when that create is the process's first HIP call (the C++
+// hosts: bin/rptr_hip, host/render_group.hpp). When the host initialised HIP before loading the library with fewer queues than the
+// contexts need, the create says so once on stderr (RPTR_QUIET=1 silences it); nothing else can be done from here.
+static bool g_hw_queues_set_by_library = false;
+__attribute__((constructor)) static void rptr_hip_set_default_hw_queues() {
+    if (!getenv("GPU_MAX_HW_QUEUES")) {
+        setenv("GPU_MAX_HW_QUEUES", "16", 0);
+        g_hw_queues_set_by_library = true;
+    }
+}
+
+static void ensure_hw_queues(int frames_in_flight) {
+    static bool first_create = true;
+    if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) frames_in_flight = atoi(s);
+    const int want = std::max(1, std::min(frames_in_flight, 16)) + 2; // + the caller's stream + the communication stream
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    const int have = e ? atoi(e) : 4;
+    if (have < want) {
+        if (first_create && (g_hw_queues_set_by_library || !e)) { // ours to raise; effective when no HIP call has been made yet
+            char buf[16];
+            snprintf(buf, sizeof buf, "%d", want);
+            setenv("GPU_MAX_HW_QUEUES", buf, 1);
+            g_hw_queues_set_by_library = true;
+        } else if (!getenv("RPTR_QUIET") || atoi(getenv("RPTR_QUIET")) == 0) {
+            static bool warned = false;
+            if (!warned)
+                fprintf(stderr, "rptr_hip: GPU_MAX_HW_QUEUES=%d but %d frame contexts want %d hardware queues (streams that share a queue serialise); "
+                                "set GPU_MAX_HW_QUEUES>=%d before the process's first HIP call\n", have, want - 2, want, want);
+            warned = true;
+        }
+    }
+    first_create = false;
+}
+
 #define HIP_TRY(h, expr)                                                                                   \
     do {                                                                                                   \
         hipError_t _e = (expr);                                                                            \
@@ -725,9 +763,16 @@ const char *rptr_hip_name(void) { return "HIP wavefront path tracer (gfx950)"; }
 
 const char *rptr_hip_last_error(const rptr_hip_t *h) { return h ? h->last_error.c_str() : g_last_error.c_str(); }
 
+int rptr_hip_abi_version(void) { return RPTR_HIP_ABI_VERSION; }
+
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     if (!out) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: out is NULL");
     *out = nullptr;
+    if (info && info->abi_version != RPTR_HIP_ABI_VERSION)
+        return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: RptrCreateInfo.abi_version is %d, this library implements version %d of include/rptr_hip.h "
+                                             "(set abi_version = RPTR_HIP_ABI_VERSION; struct fields that used to be padding carry meaning now)",
+                    info->abi_version, RPTR_HIP_ABI_VERSION);
+    ensure_hw_queues(info ? info->frames_in_flight : 1);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -1525,8 +1570,10 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bo
 }
 
 // refits one copy of the mutable scene on stream `st`; all_dynamic: treat every dynamic mesh as changed. A mesh whose tree is older
-// than the rebuild the policy asked for (rptr_hip_refit) is rebuilt instead of refitted.
-static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipStream_t st) {
+// than the rebuild the policy asked for (rptr_hip_refit) is rebuilt instead of refitted. A rebuild that cannot start (no memory for its
+// work space) is reported through *err -- the error text is in the handle -- and the mesh is refitted on its old topology instead, so
+// that its boxes always match the new vertices; the rebuild is tried again with the next refit.
+static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipStream_t st, int *err) {
     bool any = all_dynamic && h->has_dynamic;
     for (size_t m = 0; m < h->meshes.size(); ++m) any = any || sc.mesh_dirty[m] == 1 || (h->meshes[m].dynamic && sc.built_epoch[m] != h->rebuild_epoch[m]);
     if (!any) return false;
@@ -1549,8 +1596,13 @@ static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipSt
                                (uint32_t)mr.tri_count, sc.mesh_dyn[m]);
         sc.mesh_dirty[m] = 0;
         if (sc.built_epoch[m] != h->rebuild_epoch[m]) {
-            if (lbvh_rebuild(h, sc, m, st, with_top) != RPTR_OK) return true; // (the error text is in the handle)
-            sc.built_epoch[m] = h->rebuild_epoch[m];
+            const int rc = lbvh_rebuild(h, sc, m, st, with_top);
+            if (rc == RPTR_OK)
+                sc.built_epoch[m] = h->rebuild_epoch[m];
+            else {
+                if (err && *err == RPTR_OK) *err = rc;
+                refit_mesh_levels(h, sc, m, st, with_top);
+            }
         } else
             refit_mesh_levels(h, sc, m, st, with_top);
         top_done = top_done || with_top;
@@ -1618,22 +1670,24 @@ int rptr_hip_refit(rptr_hip_t *h) {
         }
         return RPTR_OK;
     }
-    if (refit_scene_copy(h, h->master, false, h->stream)) {
+    int err = RPTR_OK;
+    if (refit_scene_copy(h, h->master, false, h->stream, &err)) {
         HIP_TRY(h, hipGetLastError());
         h->host_bvh_stale = true;
         h->refit_version++; // the frame contexts' own sets follow when their next frame is submitted
         h->master.version = h->refit_version;
     }
-    return RPTR_OK;
+    return err;
 }
 
 // the master set's tree after a deferred refit (see rptr_hip_refit)
 static int ensure_master_tree(rptr_hip *h) {
     if (!h->master_refit_pending) return RPTR_OK;
     h->master_refit_pending = false;
-    if (refit_scene_copy(h, h->master, false, h->stream)) HIP_TRY(h, hipGetLastError());
+    int err = RPTR_OK;
+    if (refit_scene_copy(h, h->master, false, h->stream, &err)) HIP_TRY(h, hipGetLastError());
     h->master.version = h->refit_version;
-    return RPTR_OK;
+    return err;
 }
 
 // host part of a3: vulkan/render_vulkan.cpp:2880-2896
@@ -2004,8 +2058,10 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_dep, 0));
     }
     if (follow) { // ... and its tree is refitted on its OWN stream: the refits of different contexts run side by side
-        (void)refit_scene_copy(h, scn, true, c.stream);
+        int err = RPTR_OK;
+        (void)refit_scene_copy(h, scn, true, c.stream, &err);
         scn.version = h->refit_version;
+        if (err != RPTR_OK) return err; // (the tree was refitted on its old topology: the context is consistent, the caller learns why no rebuild happened)
     }
     if (c.gather_pending) { // the image this context produced last is still being sent to rank 0 (host_comm.h)
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_gather, 0));

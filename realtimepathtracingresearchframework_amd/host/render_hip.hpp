@@ -48,7 +48,7 @@ public:
 
     explicit RenderHip(int device_ordinal = 0, int rank = 0, int world_size = 1, int stripe_rows = 32, void *hip_stream = nullptr,
                        int frames_in_flight = 1) {
-        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream, frames_in_flight, 0};
+        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream, frames_in_flight, RPTR_HIP_ABI_VERSION};
         int rc = rptr_hip_create(&info, &h_);
         if (rc != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_create: ") + rptr_hip_last_error(nullptr));
         params = RptrRenderParams{1, RPTR_MAX_PATH_DEPTH, RPTR_DEFAULT_RR_PATH_DEPTH, 0, 0.f, 2.5f, 1.f, 4.f, 0, 0, 0.f, -1, 0, 8, 0, 1, 35.f, 0, 0, 0};

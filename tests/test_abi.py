@@ -38,6 +38,39 @@ def test_library_loads_and_exports_every_symbol():
     assert b"HIP" in L.rptr_hip_name()
 
 
+def test_abi_version_is_checked_before_anything_else():
+    """RptrCreateInfo.abi_version (struct padding was given a meaning without a guard): the header's number = the library's =
+    abi.py's, and a caller compiled against another layout -- or one that left the former padding word at 0 -- is refused by
+    rptr_hip_create before any device work, GPU or not"""
+    hdr = open(os.path.join(ROOT, "include", "rptr_hip.h")).read()
+    version = int(re.search(r"#define RPTR_HIP_ABI_VERSION\s+(\d+)", hdr).group(1))
+    L = backend.load_library()
+    L.rptr_hip_abi_version.restype = C.c_int
+    assert L.rptr_hip_abi_version() == version == abi.ABI_VERSION
+    assert abi.CreateInfo.abi_version.offset == 28 and C.sizeof(abi.CreateInfo) == 32
+    for bad in (0, version - 1, version + 1):
+        info = abi.CreateInfo(0, 0, 1, 32, None, 1, bad)
+        h = C.c_void_p()
+        assert L.rptr_hip_create(C.byref(info), C.byref(h)) == abi.RPTR_E_INVALID and not h.value
+        assert b"abi_version" in L.rptr_hip_last_error(None)
+    # RptrTextureDesc.mip_levels used to be padding: the field is where the header says, and the mirror names it
+    assert abi.TextureDesc.mip_levels.offset == 20 and C.sizeof(abi.TextureDesc) == 24
+
+
+def test_library_asks_for_enough_hardware_queues_when_nobody_did():
+    """GPU_MAX_HW_QUEUES (one hardware queue per frame context's stream: DESIGN.md section 3): loading the library in a process that has
+    not set the variable sets it, so the C++ hosts get the schedule the benchmark measures; a value the host chose is left alone"""
+    import subprocess
+    import sys
+    # (os.environ is a snapshot: ask the C library)
+    probe = ("import os, ctypes\n%s\nL = ctypes.CDLL(%r)\ng = ctypes.CDLL(None).getenv\ng.restype = ctypes.c_char_p\nprint((g(b'GPU_MAX_HW_QUEUES') or b'unset').decode())")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", probe % ("", build.LIB_PATH)], env=env, capture_output=True, text=True, check=True).stdout.strip()
+    assert int(out) >= 13
+    out = subprocess.run([sys.executable, "-c", probe % ("", build.LIB_PATH)], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "6"
+
+
 def test_no_cpu_fallback_create_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

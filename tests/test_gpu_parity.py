@@ -853,6 +853,39 @@ def test_reprojection_mode_discard_history():
     r.close()
 
 
+def test_discard_history_keeps_all_samples_of_a_frame_the_backend_splits(monkeypatch):
+    """a frame of more samples than fit in flight is rendered in several internal launches (RPTR_MAX_BATCH_SPP): with
+    REPROJECTION_MODE_DISCARD_HISTORY the displayed frame still holds ALL of its samples (only earlier frames are dropped), bit for bit the
+    image of the same frame rendered in one launch"""
+    s = scenes.cornell32()
+    W, H, spp = 48, 48, 4
+    cam = s.camera_params()
+    images = []
+    for split in (None, "1", "3"):
+        if split:
+            monkeypatch.setenv("RPTR_MAX_BATCH_SPP", split)
+        r = backend.RenderHip()
+        r.initialize(W, H)
+        r.set_scene(s)
+        r.params.reprojection_mode = 1
+        img = np.zeros((H, W, 4), np.float32)
+        r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=2)   # history to discard
+        r.render(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=False), spp=spp)
+        r.readback_framebuffer(img)
+        images.append(img)
+        r.close()
+        if split:
+            monkeypatch.delenv("RPTR_MAX_BATCH_SPP")
+    assert np.array_equal(images[0], images[1]) and np.array_equal(images[0], images[2])
+    p = abi.RenderParams.default()
+    p.reprojection_mode = 1
+    osc = O.OracleScene(s)
+    ref1, _ = osc.render(W, H, 2, params=p)
+    ref2, _ = osc.render(W, H, spp, params=p, sample_begin=2, accum=ref1.copy())
+    rmse, same, _ = image_error(images[0], ref2)
+    assert same and rmse < RMSE_TOL
+
+
 def _with_mip_chains(s):
     """box-filtered mip chains for every texture of the scene (test data: the product generates none)"""
     for t in s.textures:

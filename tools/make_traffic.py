@@ -14,7 +14,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+PREFIX = ""
+
+
 def read(tag, counter):
+    tag = PREFIX + tag
     path = os.path.join(ROOT, "gpurun_out", "pmc_" + tag, "summary_%s.csv" % tag)
     out = {}
     if not os.path.exists(path):
@@ -26,12 +30,21 @@ def read(tag, counter):
 
 
 def main():
+    """make_traffic.py <build tag> [<workload key> [<bench args>]]: the passes gpurun_out/pmc_<key>_{fetch,write,insts,cycles,tcc} -> the
+    entry `workloads[<key>]` of profiles/pmc_traffic.json (the other workloads' entries are kept)"""
+    global PREFIX
     tag = sys.argv[1] if len(sys.argv) > 1 else ""
+    key = sys.argv[2] if len(sys.argv) > 2 else "c2"
+    bench_args = sys.argv[3] if len(sys.argv) > 3 else ""
+    PREFIX = key + "_"
     fetch, write = read("fetch", "FETCH_SIZE"), read("write", "WRITE_SIZE")
     valu, salu, waves = read("insts", "SQ_INSTS_VALU"), read("insts", "SQ_INSTS_SALU"), read("insts", "SQ_WAVES")
     busy, gui = read("cycles", "SQ_BUSY_CYCLES"), read("cycles", "GRBM_GUI_ACTIVE")
-    doc = {"source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_*_CYCLES) over "
-                     "bench.py --profile-pass --steps 3 --warmup 1 (frames one at a time, RPTR_TAIL_BOUNCE=2); tools/pmc.sh + tools/make_traffic.py",
+    cyc = {c: read("cycles", c) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")}
+    tcc_hit, tcc_miss = read("tcc", "TCC_HIT_sum"), read("tcc", "TCC_MISS_sum")
+    doc = {"bench_args": bench_args,
+           "source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_*_CYCLES) over "
+                     "bench.py --profile-pass --steps 3 --warmup 1 <bench_args> (frames one at a time, RPTR_TAIL_BOUNCE=2); tools/pmc.sh + tools/make_traffic.py",
            "build": tag,
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads 1/2, MI355X_MICROARCH.md)", "kernels": {}}
     for k in fetch:
@@ -44,6 +57,18 @@ def main():
             e["waves_per_launch"] = waves[k][1] / max(waves[k][0], 1)
         if k in gui:
             e["gui_active_cycles_per_launch"] = gui[k][1] / max(gui[k][0], 1)
+        if k in cyc["SQ_WAVE_CYCLES"] and cyc["SQ_WAVE_CYCLES"][k][1] > 0:
+            wc = cyc["SQ_WAVE_CYCLES"][k][1]
+            # fractions of the wave-cycles (quad-cycles summed over resident waves): parked on s_waitcnt / barrier, issue-stalled, issuing
+            for name, c in (("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_any_frac", "SQ_WAIT_INST_ANY"), ("active_inst_any_frac", "SQ_ACTIVE_INST_ANY"),
+                            ("active_inst_valu_frac", "SQ_ACTIVE_INST_VALU")):
+                if k in cyc[c]:
+                    e[name] = round(cyc[c][k][1] / wc, 4)
+            e["wave_quad_cycles_per_launch"] = wc / max(cyc["SQ_WAVE_CYCLES"][k][0], 1)
+            if k in busy:
+                e["sq_busy_cycles_per_launch"] = busy[k][1] / max(busy[k][0], 1)
+        if k in tcc_hit and k in tcc_miss and tcc_hit[k][1] + tcc_miss[k][1] > 0:
+            e["tcc_hit_rate"] = round(tcc_hit[k][1] / (tcc_hit[k][1] + tcc_miss[k][1]), 4)
         doc["kernels"][k] = e
     # one frame = one rp_k_resolve launch: all VALU instructions of the pass / frames (where the tail kernel takes over does not change
     # the work of a frame, so this holds for the pipelined run too, whatever bounce its tail starts at)
@@ -51,7 +76,15 @@ def main():
     if frames:
         doc["frames"] = frames
         doc["valu_insts_per_frame"] = sum(v.get("valu_insts_per_launch", 0.0) * v["launches"] for v in doc["kernels"].values()) / frames
-    json.dump(doc, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        full = json.load(open(path))
+    except Exception:
+        full = {}
+    if "workloads" not in full:   # round 2's file held the default workload only
+        full = {"workloads": {}}
+    full["workloads"][key] = doc
+    json.dump(full, open(path, "w"), indent=1)
     print("frames %d, VALU instructions per frame %.1f M" % (doc.get("frames", 0), doc.get("valu_insts_per_frame", 0) / 1e6))
     for k, v in doc["kernels"].items():
         print("%-48s %8.1f MB HBM  %8.1f M VALU insts per launch" % (k[:48], v["hbm_bytes_per_launch"] / 1e6, v.get("valu_insts_per_launch", 0) / 1e6))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/pmc.sh <tag> "<counters...>" [bench args]: one --pmc pass over bench.py --profile-pass (identical frames, one at a time), prints per-kernel sums
+# tools/pmc.sh <tag> "<counters...>" [bench args]: one --pmc pass over bench.py --profile-pass <bench args> (identical frames, one at a time), prints per-kernel sums
 set -u
 TAG=$1; CNT=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 export RPTR_FRAMES_IN_FLIGHT=1
 export RPTR_TAIL_BOUNCE=${RPTR_TAIL_BOUNCE:-2}  # every frame of the pass hands over at the same bounce (adaptive would start the first frame without a tail)
 cd /tmp; rm -rf /tmp/pmc_$TAG
-timeout -k 5 240 rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc_$TAG -o $TAG --output-format csv -- python $R/bench.py --profile-pass --steps 3 --warmup 1 "$@" > $OUT/bench.log 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $CNT -d /tmp/pmc_$TAG -o $TAG --output-format csv -- python $R/bench.py --profile-pass --steps 3 --warmup 1 "$@" > $OUT/bench.log 2>&1
 F=$(find /tmp/pmc_$TAG -name "*counter_collection.csv" | head -1)
 [ -z "$F" ] && { echo "no counter file"; tail -5 $OUT/bench.log; exit 1; }
 python3 - "$F" "$OUT/summary_$TAG.csv" <<'PY'
