@@ -313,6 +313,13 @@ typedef struct rptr_hip rptr_hip_t;
 /* ---- lifetime (≙ create_backend_function, render_backend.h:118-119) */
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out);
 int rptr_hip_abi_version(void);
+/* the acceleration-structure step of the last rptr_hip_set_scene (the reference builds and compacts its BLAS / TLAS on the GPU inside
+ * set_scene: vulkan/render_vulkan.cpp:476-543, vulkan/vulkanrt_utils.h:83-105). Large static triangle sets -- a flattened instanced scene,
+ * static meshes of millions of triangles -- are built on the device (csrc/ploc.h: Morton sort, PLOC clustering, a binned-SAH top over the
+ * remaining clusters, 4-wide collapse, encoding), everything else by the host's binned-SAH builder. RPTR_BVH_BUILDER=host|device|auto
+ * (default auto: the device from RPTR_DEVICE_BUILD_MIN_TRIS = 2 Mi triangles). out_build_ms: wall time of the whole step;
+ * out_device_ms: GPU time of the device builds in it (0 when the host built everything). */
+int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out_build_ms, float *out_device_ms);
 void rptr_hip_destroy(rptr_hip_t *h);
 const char *rptr_hip_last_error(const rptr_hip_t *h);
 const char *rptr_hip_name(void); /* RenderBackend::name() */

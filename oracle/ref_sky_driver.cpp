@@ -56,8 +56,8 @@ int ref_update_sky_light(const float sun_dir_in[3], float turbidity, const float
     for (int i = 0; i < CM_CIE_SAMPLES; ++i) {
         float wavelength = float(i) * float(CM_CIE_MAX - CM_CIE_MIN) / float(CM_CIE_SAMPLES - 1) + float(CM_CIE_MIN);
         if (wavelength > 720.0f) break;
-        float radiance = (float)arhosekskymodel_solar_radiance(&sunState, sun_dir[1], 0.0, wavelength);
-        radiance -= (float)arhosekskymodel_radiance(&sunState, sun_dir[1], 0.0, wavelength);
+        float radiance = arhosekskymodel_solar_radiance(&sunState, sun_dir[1], 0.0, wavelength);
+        radiance -= arhosekskymodel_radiance(&sunState, sun_dir[1], 0.0, wavelength); // float -= double, as render_sky.cpp:52 writes it
         xyz[0] += TX[i] * radiance;
         xyz[1] += TY[i] * radiance;
         xyz[2] += TZ[i] * radiance;

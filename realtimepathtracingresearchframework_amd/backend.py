@@ -70,6 +70,7 @@ def load_library(path=None):
     L.rptr_hip_set_rng_variant.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
     L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rptr_hip_bvh_build_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
@@ -382,6 +383,12 @@ class RenderHip:
         """RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget (render_params.glsl.h:61,90-93): device-side rebuilds of
         dynamic meshes instead of refits (include/rptr_hip.h)"""
         self._check(self._L.rptr_hip_set_bvh_policy(self._h, 1 if force_bvh_rebuild else 0, int(rebuild_triangle_budget)))
+
+    def bvh_build_info(self):
+        """(built on the device?, milliseconds of set_scene's acceleration-structure step, GPU milliseconds of its device builds)"""
+        dev, ms, dms = C.c_int32(), C.c_float(), C.c_float()
+        self._check(self._L.rptr_hip_bvh_build_info(self._h, C.byref(dev), C.byref(ms), C.byref(dms)))
+        return bool(dev.value), float(ms.value), float(dms.value)
 
     def bvh_rebuild_count(self):
         n = C.c_uint64()

@@ -28,6 +28,12 @@ struct BuiltTree {
 // (median splits below it). threads <= 0 -> hardware_concurrency.
 void build_bvh2(const BuildPrim *prims, uint32_t n, uint32_t max_leaf, int max_depth, int threads, BuiltTree &out);
 
+// The same output from PLOC (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", TVCG
+// 2018): clusters in Morton order, every cluster finds the neighbour within `radius` positions whose union with it has the smallest
+// area, mutual nearest neighbours merge, repeat; leaves by SAH over the finished tree. The host statement of what the device builder
+// (csrc/ploc.h) computes -- same order of operations, so both give the same tree.
+void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t max_leaf, int threads, BuiltTree &out);
+
 // bottom-up refit of node boxes from new primitive bounds given in LEAF order
 // (prims[i] corresponds to order[i]); host fallback used by tests.
 void refit_bvh2(BuiltTree &tree, const BuildPrim *prims_leaf_order);
@@ -44,5 +50,26 @@ struct Wide4Tree {
 // Collapses the binary tree: a node adopts its grandchildren, largest box first, until it has four
 // children (Wald et al. style). Leaves and the primitive order are kept.
 void collapse_bvh4(const BuiltTree &tree, Wide4Tree &out);
+
+} // namespace rptr
+
+namespace rptr {
+
+// ---- triangle pre-splitting (spatial splits before the build; static geometry only)
+// A long thin diagonal triangle has a box that is almost entirely empty; a tree over such boxes overlaps everywhere (the forest of
+// config C4: 7.5 triangle tests and 26 node visits per closest-hit ray). The triangle is therefore REFERENCED several times, each
+// reference with the box of the part of the triangle inside one cell of a hierarchical grid (Karras & Aila 2013, section 4: split
+// planes are the most important median planes of the scene's cubic grid that cross the box, the number of splits of a triangle is
+// floor(density * cbrt(2^-level * (box area - ideal area) / scene extent^2)) -- an absolute rule, so that a mesh of well-shaped
+// triangles is left alone -- scaled down when more than `budget` * n extra references would come out).
+// References of one triangle all name the same triangle record: a hit has the same t / u / v / ids whichever reference finds it, so the
+// closest-hit answer (smallest t, ties by (instance, geometry, primitive)) does not depend on the splitting. Boxes are computed in
+// double precision and rounded outwards, so the references of a triangle cover it completely.
+struct TriVerts {
+    float v[3][3];
+};
+// out_box[r] / out_tri[r]: reference r and the triangle it belongs to (every triangle gets at least one reference; order: by triangle)
+void presplit_triangles(const TriVerts *tris, uint32_t n, float density, float budget, int max_refs_per_tri, int threads, std::vector<BuildPrim> &out_box,
+                        std::vector<uint32_t> &out_tri);
 
 } // namespace rptr

@@ -1,0 +1,227 @@
+// ploc.h -- device-side BUILD of the acceleration structure of static geometry (set_scene), SAH-like quality at sort speed.
+//
+// Stands in for what the reference gets from the Vulkan driver inside set_scene: BLAS builds on the GPU with PREFER_FAST_TRACE for
+// static meshes + compaction (vulkan/vulkanrt_utils.h:83-105 enqueue_build / compact, vulkan/render_vulkan.cpp:476-543,942-952). The
+// host builder (bvh_build.cpp: binned SAH) needs 5.5 s for the 10 M world-space triangles of a flattened forest; the linear BVH of
+// lbvh.h is built in milliseconds but costs 38 % more node visits per ray there. This builder gets within 5 % of the host tree:
+//
+//   1. world-space (flattened scene) or object-space (one mesh) triangles + vertex bounds, straight from the quantised vertex streams
+//      that shading reads (rp_k_build_tris: the host loop of build_host_bvh, one thread per triangle, same float operations),
+//   2. Morton keys on a cubic grid, radix sort, gather (lbvh.h steps 1-3, 5),
+//   3. PLOC (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", TVCG 2018): the
+//      clusters -- first the triangles in Morton order -- each look RP_PLOC_RADIUS positions to both sides for the neighbour whose
+//      union with them has the smallest surface area; mutual nearest neighbours merge into a new node (the lower position keeps the
+//      slot, an exclusive scan compacts the rest and numbers the new nodes: no atomics, the tree does not depend on scheduling);
+//      repeated until RP_PLOC_TOP clusters are left,
+//   4. the TOP of the tree -- where local clustering is weakest (+9 % node visits on the forest, +20 % on the height field when PLOC
+//      runs to the root) -- is a binned-SAH tree over the remaining <= 65 536 cluster boxes, built by the host builder in
+//      milliseconds and stitched on,
+//   5. depth-first positions of all triangles (every subtree a contiguous range: what the leaf encoding needs), second gather,
+//   6. the 4-wide collapse, child references, depth levels and the refit + encoding of lbvh.h steps 6-8, unchanged.
+// bvh_build.cpp: build_bvh2_ploc is the same algorithm stated on the host (same keys, same float operations, same tie rules): both
+// give the same tree, which is how the device path is tested (tests/test_gpu_device_build.py) and how its quality was measured before
+// it was written (profiles/r03_notes.md: forest 27.2 node visits per closest-hit ray against 26.0 for the host SAH tree and 35.8 for
+// the linear BVH; height field 9.12 / 8.91 / 9.5).
+#pragma once
+#include "lbvh.h"
+
+#ifndef RP_PLOC_RADIUS
+#define RP_PLOC_RADIUS 25
+#endif
+#ifndef RP_PLOC_TOP
+#define RP_PLOC_TOP 65536
+#endif
+
+// one source of triangles of a build: `count` triangles of one geometry (optionally under an instance transform), output positions
+// [begin, begin + count)
+struct RpBuildSegment {
+    const uint64_t *qpos;
+    const uint8_t *mat_ids;  // per-triangle material ids of the geometry under this parameterized mesh, or NULL
+    float scaling[3];
+    int32_t material_offset;
+    float offset[3];
+    uint32_t begin;
+    float transform[12];     // row-major 3x4 (world-space builds), unused otherwise
+    uint32_t count, geom, flags_hi /* (instance record index) << 8, or 0 */, has_transform;
+};
+
+// 1. triangles of a build from the vertex streams (what build_host_bvh does on the host: dequantise, transform, edges, bounds)
+__global__ __launch_bounds__(256) void rp_k_build_tris(const RpBuildSegment *segs, int n_segs, uint32_t n, const uint8_t *mat_alpha, uint32_t n_mats, RptrBvhTri *tris,
+                                                       float *tri_box) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_segs - 1; // the segment that holds output triangle i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].begin <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const RpBuildSegment &sg = segs[lo];
+        const uint32_t t = i - sg.begin;
+        float w[3][3];
+        for (int k = 0; k < 3; ++k) {
+            const uint64_t q = sg.qpos[3ull * t + k];
+            const float v[3] = {float(uint32_t(q) & 0x1FFFFFu) * sg.scaling[0] + sg.offset[0], float(uint32_t(q >> 21) & 0x1FFFFFu) * sg.scaling[1] + sg.offset[1],
+                                float(uint32_t(q >> 42) & 0x1FFFFFu) * sg.scaling[2] + sg.offset[2]};
+            if (sg.has_transform) {
+                const float *M = sg.transform;
+                for (int r = 0; r < 3; ++r) w[k][r] = ((M[4 * r] * v[0] + M[4 * r + 1] * v[1]) + M[4 * r + 2] * v[2]) + M[4 * r + 3];
+            } else
+                for (int r = 0; r < 3; ++r) w[k][r] = v[r];
+        }
+        RptrBvhTri tri;
+        float *b = tri_box + 6ull * i;
+        for (int k = 0; k < 3; ++k) {
+            tri.v0[k] = w[0][k];
+            tri.e1[k] = w[1][k] - w[0][k];
+            tri.e2[k] = w[2][k] - w[0][k];
+            b[k] = fminf(w[0][k], fminf(w[1][k], w[2][k]));
+            b[3 + k] = fmaxf(w[0][k], fmaxf(w[1][k], w[2][k]));
+        }
+        const int64_t mid = (int64_t)sg.material_offset + (sg.mat_ids ? (int64_t)sg.mat_ids[t] : 0);
+        const bool alpha = mid >= 0 && mid < (int64_t)n_mats && mat_alpha[mid] != 0;
+        tri.prim = t;
+        tri.geom = sg.geom;
+        tri.flags = (alpha ? RPTR_BVH_TRI_ALPHA : 0u) | sg.flags_hi;
+        float4 *d = reinterpret_cast<float4 *>(tris + i);
+        const float4 *s = reinterpret_cast<const float4 *>(&tri);
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+    }
+}
+
+// ---- 3. PLOC. Node ids: 0..n-1 the triangles in Morton order, n.. the merges in creation order. left / right are indexed by id - n.
+__global__ __launch_bounds__(256) void rp_k_ploc_init(uint32_t n, const float *tri_box, uint32_t *cid, float *cbox, int *parent, uint32_t *count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        cid[i] = i;
+        for (int a = 0; a < 6; ++a) cbox[6ull * i + a] = tri_box[6ull * i + a];
+        parent[i] = -1;
+        count[i] = 1u;
+    }
+}
+// nearest neighbour of every cluster within RADIUS positions: smallest half area of the union, ties to the lower position
+template <int RADIUS>
+__global__ __launch_bounds__(256) void rp_k_ploc_nn(uint32_t m, const float *cbox, uint32_t *nn) {
+    __shared__ float s_box[6][256 + 2 * RADIUS];
+    const int64_t base = (int64_t)blockIdx.x * 256 - RADIUS;
+    for (int k = threadIdx.x; k < 256 + 2 * RADIUS; k += 256) {
+        const int64_t j = base + k;
+        const bool in = j >= 0 && j < (int64_t)m;
+        for (int a = 0; a < 6; ++a) s_box[a][k] = in ? cbox[6ull * (uint64_t)j + a] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const int me = threadIdx.x + RADIUS;
+    const float lo0 = s_box[0][me], lo1 = s_box[1][me], lo2 = s_box[2][me], hi0 = s_box[3][me], hi1 = s_box[4][me], hi2 = s_box[5][me];
+    float best = INFINITY;
+    uint32_t arg = i == 0 ? min(m - 1, (uint32_t)RADIUS) : (i > (uint32_t)RADIUS ? i - RADIUS : 0u); // (no candidate beats +inf: NaN boxes)
+    for (int k = -RADIUS; k <= RADIUS; ++k) {
+        if (k == 0) continue;
+        const int64_t j = (int64_t)i + k;
+        if (j < 0 || j >= (int64_t)m) continue;
+        const int at = me + k;
+        const float dx = fmaxf(hi0, s_box[3][at]) - fminf(lo0, s_box[0][at]), dy = fmaxf(hi1, s_box[4][at]) - fminf(lo1, s_box[1][at]),
+                    dz = fmaxf(hi2, s_box[5][at]) - fminf(lo2, s_box[2][at]);
+        const float a = dx * dy + dy * dz + dz * dx;
+        if (a < best) {
+            best = a;
+            arg = (uint32_t)j;
+        }
+    }
+    nn[i] = arg;
+}
+// keep (low word): the cluster stays in the list (it is not the upper partner of a merge); merge (high word): it is the lower partner
+__global__ __launch_bounds__(256) void rp_k_ploc_flags(uint32_t m, const uint32_t *nn, unsigned long long *packed) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t j = nn[i];
+        const bool mutual = nn[j] == i;
+        packed[i] = (unsigned long long)((mutual && i > j) ? 0u : 1u) | ((unsigned long long)((mutual && i < j) ? 1u : 0u) << 32);
+    }
+}
+// totals[0] = clusters after this iteration, totals[1] = nodes made so far (in / out)
+__global__ __launch_bounds__(256) void rp_k_ploc_apply(uint32_t m, uint32_t n, const uint32_t *nn, const unsigned long long *packed, const unsigned long long *scan,
+                                                       const uint32_t *cid_in, const float *cbox_in, uint32_t *cid_out, float *cbox_out, int *left, int *right,
+                                                       int *parent, uint32_t *count, const uint32_t *totals_in, uint32_t *totals_out) {
+    const uint32_t made = totals_in[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const unsigned long long p = packed[i], s = scan[i];
+        if (i == m - 1) {
+            totals_out[0] = (uint32_t)(s & 0xFFFFFFFFull) + (uint32_t)(p & 0xFFFFFFFFull);
+            totals_out[1] = made + (uint32_t)(s >> 32) + (uint32_t)(p >> 32);
+        }
+        if ((p & 0xFFFFFFFFull) == 0) continue;
+        const uint32_t slot = (uint32_t)(s & 0xFFFFFFFFull);
+        float b[6];
+        for (int a = 0; a < 6; ++a) b[a] = cbox_in[6ull * i + a];
+        uint32_t id = cid_in[i];
+        if (p >> 32) {
+            const uint32_t j = nn[i], a_id = id, b_id = cid_in[j];
+            for (int a = 0; a < 3; ++a) {
+                b[a] = fminf(b[a], cbox_in[6ull * j + a]);
+                b[3 + a] = fmaxf(b[3 + a], cbox_in[6ull * j + 3 + a]);
+            }
+            id = made + (uint32_t)(s >> 32);
+            left[id - n] = (int)a_id;
+            right[id - n] = (int)b_id;
+            parent[a_id] = (int)id;
+            parent[b_id] = (int)id;
+            parent[id] = -1;
+            count[id] = count[a_id] + count[b_id];
+        }
+        cid_out[slot] = id;
+        for (int a = 0; a < 6; ++a) cbox_out[6ull * slot + a] = b[a];
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_ploc_gather_counts(uint32_t m, const uint32_t *cid, const uint32_t *count, uint32_t *out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = count[cid[i]];
+}
+// 4. the stitched-on top: nodes first_id.. (left, right, count given per node), parents of everything they refer to
+__global__ __launch_bounds__(256) void rp_k_ploc_stitch(uint32_t k, uint32_t n, uint32_t first_id, const int *top_left, const int *top_right, const uint32_t *top_count,
+                                                        int *left, int *right, int *parent, uint32_t *count) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < k; i += gridDim.x * blockDim.x) {
+        const uint32_t id = first_id + i;
+        left[id - n] = top_left[i];
+        right[id - n] = top_right[i];
+        count[id] = top_count[i];
+        parent[top_left[i]] = (int)id;
+        parent[top_right[i]] = (int)id;
+        if (i == k - 1) parent[id] = -1; // the root is made last
+    }
+}
+// 5. depth-first position of the first triangle below a node: the triangles of the left siblings on the way up
+RP_DEV uint32_t rp_ploc_first(uint32_t id, uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count) {
+    uint32_t off = 0, c = id;
+    for (int p = parent[c]; p >= 0; p = parent[p]) {
+        if ((uint32_t)right[(uint32_t)p - n] == c) off += count[left[(uint32_t)p - n]];
+        c = (uint32_t)p;
+    }
+    return off;
+}
+// the binary tree in the form lbvh.h steps 6-8 take: inner node idx = 2n - 2 - id (the root, made last, is 0), leaves as ~position
+__global__ __launch_bounds__(256) void rp_k_ploc_finalize(uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count, int *o_left, int *o_right,
+                                                          int *o_parent, int *o_first, int *o_last) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k + 1 < n; k += gridDim.x * blockDim.x) {
+        const uint32_t id = n + k, idx = 2u * n - 2u - id;
+        const uint32_t first = rp_ploc_first(id, n, left, right, parent, count);
+        const int l = left[k], r = right[k];
+        const uint32_t cl = count[l];
+        o_left[idx] = (uint32_t)l < n ? ~(int)first : (int)(2u * n - 2u - (uint32_t)l);
+        o_right[idx] = (uint32_t)r < n ? ~(int)(first + cl) : (int)(2u * n - 2u - (uint32_t)r);
+        o_parent[idx] = parent[id] < 0 ? -1 : (int)(2u * n - 2u - (uint32_t)parent[id]);
+        o_first[idx] = (int)first;
+        o_last[idx] = (int)(first + count[id] - 1u);
+    }
+}
+__global__ __launch_bounds__(256) void rp_k_ploc_scatter(uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count, const RptrBvhTri *tri_in,
+                                                         const float *box_in, RptrBvhTri *tri_out, float *box_out) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t pos = rp_ploc_first(k, n, left, right, parent, count);
+        const float4 *s = reinterpret_cast<const float4 *>(tri_in + k);
+        float4 *d = reinterpret_cast<float4 *>(tri_out + pos);
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+        for (int a = 0; a < 6; ++a) box_out[6ull * pos + a] = box_in[6ull * k + a];
+    }
+}

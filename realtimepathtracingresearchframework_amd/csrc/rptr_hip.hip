@@ -11,16 +11,19 @@
 #include "kernels_misc.h"
 #include "launch.h"
 #include "lbvh.h"
+#include "ploc.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -132,6 +135,8 @@ struct rptr_hip {
     bool own_stream = false;
     int num_cus = 0;
     size_t bytes_allocated = 0, bytes_frame = 0, bytes_scene = 0; // what is allocated now (frame buffers + path state, scene)
+    double bvh_build_ms = 0.0, bvh_device_ms = 0.0; // the last set_scene: its acceleration-structure step, the device part of it
+    bool bvh_device_built = false;
     std::vector<void *> allocations;
 
     // frame
@@ -368,6 +373,9 @@ struct HostBvh {
     int num_tlas_insts = 0; // instance records the top level refers to (a flattened scene keeps the scene's own records behind them)
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
     int stack_need = 0;
+    bool device_built = false; // some bottom-level tree came from the device builder (ploc.h)
+    double device_ms = 0.0;
+    int device_iterations = 0;
 };
 
 // RPTR_FLATTEN=1: a static scene with several instances is built as ONE bottom-level tree over all instanced triangles,
@@ -431,7 +439,263 @@ static bool want_flatten(const RptrSceneDesc *s) {
     return total <= limit && s->num_instances < (1u << 24) - 1;
 }
 
-static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
+// ------------------------------------------------------------------ device-side build of one bottom-level tree (ploc.h)
+// What a build hands back to build_host_bvh: the tree in the form the host builder's encode_tree produces (local node indices from 0,
+// leaf ranges from triangle 0 of `tris`), so that everything behind it -- top level, relocation, stack need, upload -- is shared.
+struct DeviceTree {
+    std::vector<RptrBvh4Node> nodes;
+    std::vector<std::array<float, 6>> boxes;
+    std::vector<RptrBvhTri> tris;
+    double ms_device = 0.0, ms_top = 0.0;
+    int iterations = 0;
+    uint32_t top_clusters = 0;
+};
+// segments: the triangles' sources (device pointers of the vertex streams the scene upload made); mat_alpha: per material, 1 = alpha-tested
+using DeviceTreeBuilder = std::function<bool(const std::vector<RpBuildSegment> &, uint32_t, DeviceTree &)>;
+struct DeviceBuildCtx {
+    DeviceTreeBuilder build;                         // empty: no device (rptr_hip_build_bvh_host on a CPU box)
+    const std::vector<const uint64_t *> *d_qpos = nullptr; // per global geometry
+    const std::vector<RpGeomRecord> *geoms = nullptr; // per (parameterized mesh, geometry): mat_ids
+    size_t min_tris = (size_t)2 << 20;               // RPTR_BVH_BUILDER=auto: prim sets of at least this size are built on the device
+};
+
+namespace {
+struct DevScratch { // frees what it allocated when the build is over
+    std::vector<void *> ptrs;
+    template <class T>
+    T *get(size_t count) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+    ~DevScratch() {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+};
+} // namespace
+
+static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &segs, uint32_t n, const std::vector<uint8_t> &mat_alpha, DeviceTree &out) {
+    if (n < 2 || segs.empty()) return false;
+    hipStream_t st = h->stream;
+    DevScratch S;
+#define DB_TRY(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            fail(h, RPTR_E_HIP, "device BVH build: %s failed: %s", #expr, hipGetErrorString(_e));    \
+            (void)hipGetLastError();                                                                  \
+            return false;                                                                             \
+        }                                                                                             \
+    } while (0)
+#define DB_ALLOC(var, T, count)                                                          \
+    T *var = S.get<T>(count);                                                            \
+    if (!var) {                                                                          \
+        fail(h, RPTR_E_NOMEM, "device BVH build: out of device memory (%s)", #var);     \
+        (void)hipGetLastError();                                                         \
+        return false;                                                                    \
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    struct EvGuard {
+        hipEvent_t &a, &b;
+        ~EvGuard() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev_guard{e0, e1};
+    (void)hipEventRecord(e0, st);
+    const int g = grid_for(h, n);
+    // 1. triangles + bounds
+    DB_ALLOC(d_segs, RpBuildSegment, segs.size());
+    DB_ALLOC(d_alpha, uint8_t, mat_alpha.size());
+    DB_ALLOC(tris_a, RptrBvhTri, (size_t)n + 2);
+    DB_ALLOC(tris_b, RptrBvhTri, (size_t)n + 2);
+    DB_ALLOC(box_a, float, 6 * (size_t)n);
+    DB_ALLOC(box_b, float, 6 * (size_t)n);
+    DB_TRY(hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(RpBuildSegment), hipMemcpyHostToDevice, st));
+    if (!mat_alpha.empty()) DB_TRY(hipMemcpyAsync(d_alpha, mat_alpha.data(), mat_alpha.size(), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(rp_k_build_tris, dim3(g), dim3(256), 0, st, d_segs, (int)segs.size(), n, d_alpha, (uint32_t)mat_alpha.size(), tris_a, box_a);
+    // 2. Morton order
+    DB_ALLOC(keys_a, unsigned long long, n);
+    DB_ALLOC(keys_b, unsigned long long, n);
+    DB_ALLOC(bounds, uint32_t, 8);
+    size_t sort_bytes = 0, scan_bytes = 0, scan64_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_a, keys_b, (int)n, 0, 64, st);
+    DB_ALLOC(flag, uint32_t, n);
+    DB_ALLOC(slot, uint32_t, n);
+    DB_ALLOC(packed, unsigned long long, n);
+    DB_ALLOC(pscan, unsigned long long, n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flag, slot, (int)n, st);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan64_bytes, packed, pscan, (int)n, st);
+    const size_t cub_bytes = std::max(sort_bytes, std::max(scan_bytes, scan64_bytes)) + 256;
+    DB_ALLOC(cub_tmp, char, cub_bytes);
+    hipLaunchKernelGGL(rp_k_lbvh_reset, dim3(1), dim3(64), 0, st, bounds);
+    hipLaunchKernelGGL(rp_k_lbvh_bounds, dim3(g), dim3(256), 0, st, box_a, n, bounds);
+    int index_bits = 1;
+    while ((1ull << index_bits) < (unsigned long long)n) ++index_bits;
+    hipLaunchKernelGGL(rp_k_lbvh_keys, dim3(g), dim3(256), 0, st, box_a, n, bounds, keys_a, index_bits);
+    size_t bytes = cub_bytes;
+    DB_TRY(hipcub::DeviceRadixSort::SortKeys(cub_tmp, bytes, keys_a, keys_b, (int)n, 0, 64, st));
+    hipLaunchKernelGGL(rp_k_lbvh_gather, dim3(g), dim3(256), 0, st, keys_b, n, tris_a, box_a, tris_b, box_b, (1ull << index_bits) - 1ull);
+    // 3. PLOC
+    DB_ALLOC(cid_a, uint32_t, n);
+    DB_ALLOC(cid_b, uint32_t, n);
+    DB_ALLOC(nn, uint32_t, n);
+    DB_ALLOC(left, int, n);
+    DB_ALLOC(right, int, n);
+    DB_ALLOC(parent, int, 2 * (size_t)n);
+    DB_ALLOC(count, uint32_t, 2 * (size_t)n);
+    DB_ALLOC(totals, uint32_t, 4);
+    float *cbox_a = box_a, *cbox_b = nullptr; // (box_a is free again after the gather; the second cluster box list is its own)
+    DB_ALLOC(cbox_second, float, 6 * (size_t)n);
+    cbox_b = cbox_second;
+    hipLaunchKernelGGL(rp_k_ploc_init, dim3(g), dim3(256), 0, st, n, box_b, cid_a, cbox_a, parent, count);
+    uint32_t host_totals[2] = {n, n}; // clusters, nodes made so far (ids below n are the triangles)
+    DB_TRY(hipMemcpyAsync(totals, host_totals, sizeof(host_totals), hipMemcpyHostToDevice, st));
+    size_t top_k = RP_PLOC_TOP;
+    if (const char *e = getenv("RPTR_PLOC_TOP")) top_k = std::max<size_t>(1, (size_t)atoll(e));
+    uint32_t m = n;
+    int iterations = 0;
+    while (m > top_k && m > 1) {
+        hipLaunchKernelGGL(rp_k_ploc_nn<RP_PLOC_RADIUS>, dim3((m + 255) / 256), dim3(256), 0, st, m, cbox_a, nn);
+        hipLaunchKernelGGL(rp_k_ploc_flags, dim3(grid_for(h, m)), dim3(256), 0, st, m, nn, packed);
+        bytes = cub_bytes;
+        DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, packed, pscan, (int)m, st));
+        hipLaunchKernelGGL(rp_k_ploc_apply, dim3(grid_for(h, m)), dim3(256), 0, st, m, n, nn, packed, pscan, cid_a, cbox_a, cid_b, cbox_b, left, right, parent, count, totals,
+                           totals + 2);
+        DB_TRY(hipMemcpyAsync(totals, totals + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        DB_TRY(hipMemcpyAsync(host_totals, totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
+        DB_TRY(hipStreamSynchronize(st));
+        if (host_totals[0] >= m) { // (cannot happen: the globally closest pair is always mutual)
+            fail(h, RPTR_E_HIP, "device BVH build: clustering made no progress at %u clusters", m);
+            return false;
+        }
+        m = host_totals[0];
+        std::swap(cid_a, cid_b);
+        std::swap(cbox_a, cbox_b);
+        ++iterations;
+    }
+    out.iterations = iterations;
+    out.top_clusters = m;
+    // 4. the top: binned SAH over the remaining clusters (host, milliseconds), stitched on
+    const auto t_top0 = std::chrono::steady_clock::now();
+    if (m > 1) {
+        std::vector<rptr::BuildPrim> cp(m);
+        std::vector<uint32_t> ids(m), cnt(m);
+        static_assert(sizeof(rptr::BuildPrim) == 24, "cluster boxes are copied as build primitives");
+        DB_ALLOC(d_cnt, uint32_t, m);
+        hipLaunchKernelGGL(rp_k_ploc_gather_counts, dim3(grid_for(h, m)), dim3(256), 0, st, m, cid_a, count, d_cnt);
+        DB_TRY(hipMemcpyAsync(cp.data(), cbox_a, (size_t)m * 24, hipMemcpyDeviceToHost, st));
+        DB_TRY(hipMemcpyAsync(ids.data(), cid_a, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        DB_TRY(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+        DB_TRY(hipStreamSynchronize(st));
+        rptr::BuiltTree top;
+        rptr::build_bvh2(cp.data(), m, 1, 56, 0, top);
+        const size_t T = top.nodes.size();
+        if (T != (size_t)m - 1) {
+            fail(h, RPTR_E_HIP, "device BVH build: the top tree over %u clusters has %zu nodes", m, T);
+            return false;
+        }
+        std::vector<int> tl(T), tr(T);
+        std::vector<uint32_t> tc(T);
+        std::vector<uint32_t> id_of(T), cnt_of(T);
+        const uint32_t first_id = host_totals[1];
+        for (int64_t i = (int64_t)T - 1; i >= 0; --i) { // children lie behind their parents: backwards = bottom-up, the root is made last
+            const RptrBvhNode &t = top.nodes[(size_t)i];
+            const size_t k = T - 1 - (size_t)i;
+            uint32_t c_id[2], c_cnt[2];
+            const int32_t two[2] = {t.child0, t.child1};
+            for (int w = 0; w < 2; ++w) {
+                if (two[w] >= 0) {
+                    c_id[w] = id_of[(size_t)two[w]];
+                    c_cnt[w] = cnt_of[(size_t)two[w]];
+                } else {
+                    const uint32_t ci = top.order[(size_t)RPTR_BVH_LEAF_FIRST(two[w])];
+                    c_id[w] = ids[ci];
+                    c_cnt[w] = cnt[ci];
+                }
+            }
+            tl[k] = (int)c_id[0];
+            tr[k] = (int)c_id[1];
+            tc[k] = c_cnt[0] + c_cnt[1];
+            id_of[(size_t)i] = first_id + (uint32_t)k;
+            cnt_of[(size_t)i] = tc[k];
+        }
+        DB_ALLOC(d_tl, int, T);
+        DB_ALLOC(d_tr, int, T);
+        DB_ALLOC(d_tc, uint32_t, T);
+        DB_TRY(hipMemcpyAsync(d_tl, tl.data(), T * 4, hipMemcpyHostToDevice, st));
+        DB_TRY(hipMemcpyAsync(d_tr, tr.data(), T * 4, hipMemcpyHostToDevice, st));
+        DB_TRY(hipMemcpyAsync(d_tc, tc.data(), T * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(rp_k_ploc_stitch, dim3(grid_for(h, T)), dim3(256), 0, st, (uint32_t)T, n, first_id, d_tl, d_tr, d_tc, left, right, parent, count);
+        DB_TRY(hipStreamSynchronize(st)); // (the host arrays are read by the copies above)
+        if (first_id + (uint32_t)T != 2u * n - 1u) {
+            fail(h, RPTR_E_HIP, "device BVH build: %u + %zu nodes for %u triangles", first_id, T, n);
+            return false;
+        }
+    } else if (host_totals[1] != 2u * n - 1u) {
+        fail(h, RPTR_E_HIP, "device BVH build: %u nodes for %u triangles", host_totals[1], n);
+        return false;
+    }
+    out.ms_top = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_top0).count();
+    // 5. depth-first order, the binary tree in lbvh.h's form
+    DB_ALLOC(o_left, int, n);
+    DB_ALLOC(o_right, int, n);
+    DB_ALLOC(o_parent, int, n);
+    DB_ALLOC(o_first, int, n);
+    DB_ALLOC(o_last, int, n);
+    hipLaunchKernelGGL(rp_k_ploc_finalize, dim3(g), dim3(256), 0, st, n, left, right, parent, count, o_left, o_right, o_parent, o_first, o_last);
+    float *tri_box = cbox_b; // (the cluster box lists are dead after the stitch: one of them takes the triangle bounds in their final order)
+    hipLaunchKernelGGL(rp_k_ploc_scatter, dim3(g), dim3(256), 0, st, n, left, right, parent, count, tris_b, box_b, tris_a, tri_box);
+    // 6. collapse, child references, levels, refit + encoding (lbvh.h steps 6-8)
+    DB_ALLOC(depth4, uint32_t, n);
+    DB_ALLOC(level_hist, uint32_t, RP_REFIT_LEVELS);
+    DB_ALLOC(level_cursor, uint32_t, RP_REFIT_LEVELS);
+    DB_ALLOC(levels, uint2, RP_REFIT_LEVELS);
+    DB_ALLOC(d_count, int, 1);
+    DB_ALLOC(nodes, RptrBvh4Node, n);
+    DB_ALLOC(node_box, float, 6 * (size_t)n);
+    DB_ALLOC(list, uint32_t, n);
+    hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, o_parent, o_first, o_last, flag, depth4);
+    bytes = cub_bytes;
+    DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, flag, slot, (int)n - 1, st));
+    DB_TRY(hipMemsetAsync(level_hist, 0, RP_REFIT_LEVELS * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(rp_k_lbvh_emit, dim3(g), dim3(256), 0, st, (int)n, o_left, o_right, o_first, o_last, flag, slot, depth4, 0, 0, nodes, level_hist, d_count);
+    hipLaunchKernelGGL(rp_k_lbvh_level_scan, dim3(1), dim3(64), 0, st, level_hist, 0u, levels, level_cursor);
+    hipLaunchKernelGGL(rp_k_lbvh_level_scatter, dim3(g), dim3(256), 0, st, nodes, 0, d_count, level_cursor, list);
+    uint2 h_levels[RP_REFIT_LEVELS];
+    int h_count = 0;
+    DB_TRY(hipMemcpyAsync(h_levels, levels, sizeof(h_levels), hipMemcpyDeviceToHost, st));
+    DB_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    DB_TRY(hipStreamSynchronize(st));
+    if (h_levels[0].y > h_levels[0].x || h_count < 1 || (uint32_t)h_count > n) { // slot 0 = the clamped deepest level: a tree deeper than the level table
+        fail(h, RPTR_E_UNSUPPORTED, "device BVH build: the tree has %d nodes / more than %d levels", h_count, RP_REFIT_LEVELS - 1);
+        return false;
+    }
+    for (int k = 0; k < RP_REFIT_LEVELS; ++k)
+        if (h_levels[k].y > h_levels[k].x)
+            hipLaunchKernelGGL(rp_k_refit_level, dim3(grid_for(h, h_levels[k].y - h_levels[k].x)), dim3(256), 0, st, nodes, node_box, tri_box, list, levels + k);
+    (void)hipEventRecord(e1, st);
+    // back to the host, in the host builder's form
+    out.nodes.resize((size_t)h_count);
+    out.boxes.resize((size_t)h_count);
+    out.tris.resize(n);
+    DB_TRY(hipMemcpyAsync(out.nodes.data(), nodes, (size_t)h_count * sizeof(RptrBvh4Node), hipMemcpyDeviceToHost, st));
+    DB_TRY(hipMemcpyAsync(out.boxes.data(), node_box, (size_t)h_count * 24, hipMemcpyDeviceToHost, st));
+    DB_TRY(hipMemcpyAsync(out.tris.data(), tris_a, (size_t)n * sizeof(RptrBvhTri), hipMemcpyDeviceToHost, st));
+    DB_TRY(hipStreamSynchronize(st));
+    DB_TRY(hipGetLastError());
+    float ms = 0.f;
+    if (e0 && e1 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) out.ms_device = ms;
+    for (RptrBvh4Node &nd : out.nodes) nd._pad1[0] = 0; // (the depth parked there by the emit kernel is not part of the tree)
+    return true;
+#undef DB_TRY
+#undef DB_ALLOC
+}
+
+static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuildCtx *dev = nullptr) {
     // instanceCustomIndex of every parameterized mesh = number of geometries before it (render_vulkan.cpp:2748-2850)
     std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
     {
@@ -489,9 +753,74 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
         }
     }
     const bool flatten = want_flatten(s);
-    if (flatten) {
+    // spatial splits for static geometry (bvh_build.h presplit_triangles): RPTR_PRESPLIT="density[,budget]". Off unless asked for:
+    // on the 10 M-triangle forest they buy 16 % fewer triangle tests for 7 % more node visits and twice the references
+    // (profiles/r03_notes.md), on height fields nothing
+    float split_density = 0.0f, split_budget = 1.0f;
+    if (const char *e = getenv("RPTR_PRESPLIT")) {
+        split_density = (float)atof(e);
+        if (const char *c = strchr(e, ',')) split_budget = (float)atof(c + 1);
+    }
+    // who builds a bottom-level tree: RPTR_BVH_BUILDER = auto (the device for large static triangle sets, the host otherwise), host, device
+    int builder_mode = 0;
+    if (const char *e = getenv("RPTR_BVH_BUILDER")) builder_mode = !strcmp(e, "host") ? 1 : (!strcmp(e, "device") ? 2 : 0);
+    auto on_device = [&](size_t n_tris) {
+        return dev && dev->build && builder_mode != 1 && n_tris >= 2 && n_tris < ((size_t)1 << 28) && (builder_mode == 2 || n_tris >= dev->min_tris) &&
+               !(split_density > 0.0f && split_budget > 0.0f);
+    };
+    bool flat_done = false;
+    if (flatten) { // the one world-space tree on the device: triangles from the vertex streams, sort, clustering, collapse, encoding (ploc.h)
+        size_t total = 0;
+        std::vector<RpBuildSegment> segs;
+        for (uint32_t i = 0; i < s->num_instances; ++i) {
+            const RptrInstanceDesc &in = s->instances[i];
+            const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
+            const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+            for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+                const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
+                if (!gd.num_tris) continue;
+                RpBuildSegment sg;
+                memset(&sg, 0, sizeof(sg));
+                if (dev && dev->d_qpos) {
+                    sg.qpos = (*dev->d_qpos)[mesh.first_geometry + j];
+                    sg.mat_ids = (*dev->geoms)[(size_t)pmesh_base[in.parameterized_mesh] + j].mat_ids;
+                }
+                memcpy(sg.scaling, gd.quantized_scaling, 12);
+                memcpy(sg.offset, gd.quantized_offset, 12);
+                sg.material_offset = pm.material_offsets[j];
+                sg.begin = (uint32_t)total;
+                memcpy(sg.transform, in.transform, 48);
+                sg.count = gd.num_tris;
+                sg.geom = j;
+                sg.flags_hi = (i + 1u) << 8;
+                sg.has_transform = 1;
+                segs.push_back(sg);
+                total += gd.num_tris;
+            }
+        }
+        DeviceTree dt;
+        if (on_device(total) && dev->build(segs, (uint32_t)total, dt)) {
+            for (MeshRt &mr : B.meshes) {
+                mr.node_base = 0;
+                mr.node_count = 0;
+                mr.tri_base = 0;
+                mr.tri_count = 0;
+                memcpy(mr.lo, dt.boxes[0].data(), 12);
+                memcpy(mr.hi, dt.boxes[0].data() + 3, 12);
+            }
+            B.tris = std::move(dt.tris);
+            blas_nodes = std::move(dt.nodes);
+            blas_boxes = std::move(dt.boxes);
+            B.device_built = true;
+            B.device_ms = dt.ms_device;
+            B.device_iterations = dt.iterations;
+            flat_done = true;
+        }
+    }
+    if (flatten && !flat_done) {
         std::vector<rptr::BuildPrim> prims;
         std::vector<RptrBvhTri> mtris;
+        std::vector<rptr::TriVerts> verts;
         for (uint32_t i = 0; i < s->num_instances; ++i) {
             const RptrInstanceDesc &in = s->instances[i];
             const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
@@ -522,12 +851,21 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
                     tri.flags = (alpha ? RPTR_BVH_TRI_ALPHA : 0u) | ((i + 1u) << 8); // its instance: record i + 1 of the instance array
                     mtris.push_back(tri);
                     prims.push_back(bp);
+                    rptr::TriVerts tv;
+                    memcpy(tv.v, w, sizeof(tv.v));
+                    verts.push_back(tv);
                 }
                 off += gd.num_tris;
             }
         }
+        std::vector<uint32_t> ref_tri; // reference -> triangle (empty: one reference per triangle)
+        if (split_density > 0.0f && split_budget > 0.0f) rptr::presplit_triangles(verts.data(), (uint32_t)verts.size(), split_density, split_budget, 256, 0, prims, ref_tri);
+        std::vector<rptr::TriVerts>().swap(verts);
         rptr::BuiltTree tree;
-        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
+        if (const char *e = getenv("RPTR_HOST_PLOC")) // experiment: the clustering of the device builder, stated on the host
+            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), std::max(1, atoi(e)), RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
+        else
+            rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
         rptr::collapse_bvh4(tree, wide);
         for (MeshRt &mr : B.meshes) { // no mesh has a tree of its own: they all point at the one tree
@@ -538,14 +876,71 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
             memcpy(mr.lo, tree.lo, 12);
             memcpy(mr.hi, tree.hi, 12);
         }
-        B.tris.reserve(mtris.size());
-        for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
+        B.tris.reserve(tree.order.size());
+        for (uint32_t id : tree.order) B.tris.push_back(mtris[ref_tri.empty() ? id : ref_tri[id]]);
         encode_tree(wide, 0, 0, blas_nodes, blas_boxes);
     }
     for (uint32_t m = 0; m < s->num_meshes && !flatten; ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
+        {
+            size_t total = 0;
+            for (uint32_t j = 0; j < mesh.num_geometries; ++j) total += s->geometries[mesh.first_geometry + j].num_tris;
+            if (mesh.dynamic == 0 && on_device(total) && dev->d_qpos) {
+                std::vector<RpBuildSegment> segs;
+                std::vector<size_t> geom_first(mesh.num_geometries, 0);
+                size_t at = 0;
+                for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
+                    const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
+                    geom_first[j] = at;
+                    if (gd.num_tris) {
+                        RpBuildSegment sg;
+                        memset(&sg, 0, sizeof(sg));
+                        sg.qpos = (*dev->d_qpos)[mesh.first_geometry + j];
+                        memcpy(sg.scaling, gd.quantized_scaling, 12);
+                        memcpy(sg.offset, gd.quantized_offset, 12);
+                        sg.material_offset = -1; // (the alpha flag of a mesh's triangle is the OR over its parameterized meshes: set below)
+                        sg.begin = (uint32_t)at;
+                        sg.count = gd.num_tris;
+                        sg.geom = j;
+                        segs.push_back(sg);
+                    }
+                    at += gd.num_tris;
+                }
+                DeviceTree dt;
+                if (dev->build(segs, (uint32_t)total, dt)) {
+                    MeshRt &mr = B.meshes[m];
+                    mr.dynamic = false;
+                    mr.rebuildable = false;
+                    mr.node_base = (int)blas_nodes.size();
+                    mr.node_count = mr.node_capacity = (int)dt.nodes.size();
+                    mr.tri_base = (int)B.tris.size();
+                    mr.tri_count = (int)dt.tris.size();
+                    memcpy(mr.lo, dt.boxes[0].data(), 12);
+                    memcpy(mr.hi, dt.boxes[0].data() + 3, 12);
+                    for (RptrBvhTri &t : dt.tris) {
+                        const size_t lin = geom_first[t.geom] + t.prim;
+                        if (lin < tri_alpha[m].size() && tri_alpha[m][lin]) t.flags |= RPTR_BVH_TRI_ALPHA;
+                    }
+                    for (RptrBvh4Node &nd : dt.nodes) // local -> absolute references (what encode_tree's shifts do for a host tree)
+                        for (int k = 0; k < 4; ++k) {
+                            const int32_t c = nd.child[k];
+                            if (c == RPTR_BVH4_EMPTY) continue;
+                            nd.child[k] = c >= 0 ? c + mr.node_base : RPTR_BVH_LEAF(RPTR_BVH_LEAF_FIRST(c) + mr.tri_base, RPTR_BVH_LEAF_COUNT(c));
+                        }
+                    B.tris.insert(B.tris.end(), dt.tris.begin(), dt.tris.end());
+                    blas_nodes.insert(blas_nodes.end(), dt.nodes.begin(), dt.nodes.end());
+                    blas_boxes.insert(blas_boxes.end(), dt.boxes.begin(), dt.boxes.end());
+                    B.device_built = true;
+                    B.device_ms += dt.ms_device;
+                    B.device_iterations = std::max(B.device_iterations, dt.iterations);
+                    continue;
+                }
+            }
+        }
         std::vector<rptr::BuildPrim> prims;
         std::vector<RptrBvhTri> mtris;
+        std::vector<rptr::TriVerts> verts;
+        const bool split_mesh = mesh.dynamic == 0 && split_density > 0.0f && split_budget > 0.0f; // (a refit recomputes boxes from whole triangles)
         for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
             const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
             for (uint32_t t = 0; t < gd.num_tris; ++t) {
@@ -565,23 +960,33 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B) {
                 tri.flags = (mtris.size() < tri_alpha[m].size() && tri_alpha[m][mtris.size()]) ? RPTR_BVH_TRI_ALPHA : 0u;
                 mtris.push_back(tri);
                 prims.push_back(bp);
+                if (split_mesh) {
+                    rptr::TriVerts tv;
+                    memcpy(tv.v, v, sizeof(tv.v));
+                    verts.push_back(tv);
+                }
             }
         }
         MeshRt &mr = B.meshes[m];
         mr.dynamic = mesh.dynamic != 0;
         mr.rebuildable = mr.dynamic && (mesh.dynamic & RPTR_MESH_SUBTLY_DYNAMIC) == 0;
+        std::vector<uint32_t> ref_tri;
+        if (split_mesh) rptr::presplit_triangles(verts.data(), (uint32_t)verts.size(), split_density, split_budget, 256, 0, prims, ref_tri);
         rptr::BuiltTree tree;
-        rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
+        if (const char *e = getenv("RPTR_HOST_PLOC")) // experiment: the clustering of the device builder, stated on the host
+            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), std::max(1, atoi(e)), RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
+        else
+            rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
         rptr::collapse_bvh4(tree, wide);
         mr.node_base = (int)blas_nodes.size();
         mr.node_count = (int)wide.nodes.size();
         mr.node_capacity = mr.dynamic ? std::max(mr.node_count, (int)mtris.size()) : mr.node_count;
         mr.tri_base = (int)B.tris.size();
-        mr.tri_count = (int)mtris.size();
+        mr.tri_count = (int)tree.order.size(); // references (= triangles unless the mesh was pre-split)
         memcpy(mr.lo, tree.lo, 12);
         memcpy(mr.hi, tree.hi, 12);
-        for (uint32_t id : tree.order) B.tris.push_back(mtris[id]);
+        for (uint32_t id : tree.order) B.tris.push_back(mtris[ref_tri.empty() ? id : ref_tri[id]]);
         encode_tree(wide, mr.node_base, mr.tri_base, blas_nodes, blas_boxes);
         if (mr.node_capacity > mr.node_count) { // room for a device-side rebuild of this dynamic mesh (lbvh.h): unreachable empty nodes
             rptr::Wide4 pad_src;
@@ -764,6 +1169,14 @@ const char *rptr_hip_name(void) { return "HIP wavefront path tracer (gfx950)"; }
 const char *rptr_hip_last_error(const rptr_hip_t *h) { return h ? h->last_error.c_str() : g_last_error.c_str(); }
 
 int rptr_hip_abi_version(void) { return RPTR_HIP_ABI_VERSION; }
+
+int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out_build_ms, float *out_device_ms) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (out_device_built) *out_device_built = h->bvh_device_built ? 1 : 0;
+    if (out_build_ms) *out_build_ms = (float)h->bvh_build_ms;
+    if (out_device_ms) *out_device_ms = (float)h->bvh_device_ms;
+    return RPTR_OK;
+}
 
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     if (!out) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: out is NULL");
@@ -1207,7 +1620,21 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     }
     // ---- acceleration structure (host part, no device involved)
     HostBvh B;
-    build_host_bvh(s, B);
+    {
+        // large static triangle sets are built on the device (csrc/ploc.h) from the vertex streams uploaded above
+        std::vector<uint8_t> mat_alpha(s->num_materials, 0);
+        for (uint32_t i = 0; i < s->num_materials; ++i) mat_alpha[i] = (s->materials[i].flags & RPTR_BASE_MATERIAL_NOALPHA) == 0 ? 1 : 0;
+        DeviceBuildCtx ctx;
+        ctx.d_qpos = &d_qpos;
+        ctx.geoms = &geoms;
+        if (const char *e = getenv("RPTR_DEVICE_BUILD_MIN_TRIS")) ctx.min_tris = (size_t)atoll(e);
+        ctx.build = [&](const std::vector<RpBuildSegment> &segs, uint32_t n, DeviceTree &out) { return device_build_tree(h, segs, n, mat_alpha, out); };
+        const auto t_build = std::chrono::steady_clock::now();
+        build_host_bvh(s, B, &ctx);
+        h->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
+        h->bvh_device_built = B.device_built;
+        h->bvh_device_ms = B.device_ms;
+    }
     {
         const int capacity = RP_LDS_STACK + RPTR_BVH_STACK_DEPTH;
         if (B.stack_need > capacity)

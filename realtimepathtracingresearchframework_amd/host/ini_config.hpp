@@ -9,13 +9,15 @@
 // This reader keeps what a headless run of the path-traced hot path consumes: camera (position / direction / up), the RenderParams
 // sliders (batch spp, max path depth, rr path depth, glossy-only mode, pixel radius, output channel / moment, exposure, tone mapping
 // operator, variance radius), LightSamplingConfig (light bin size, light mis angle), target spp, the BVH policy (force bvh rebuild,
-// rebuild triangle budget), the integrator variant and bump scale. Sun / sky sliders (height, angle, turbidity, Color) are
-// recognised and reported: refitting the sky needs the Hosek-Wilkie tables, which live on the reference side.
+// rebuild triangle budget), the integrator variant and bump scale, and the Sun sliders (height, angle, turbidity, Color:
+// libapp/scene_state.h:79-96) -- the host refits the sky for them (host/sky_fit.hpp) when it was told where the Hosek-Wilkie data
+// headers are (--sky-data / RPTR_SKY_DATA); without the data the scene file's sky is kept and a note says so.
 // Every [Application] block of a file is one keyframe when the file is given with --keyframe.
 #pragma once
 #include "../../include/rptr_hip.h"
 #include "pointsets.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,6 +123,8 @@ struct HostConfig {
     bool bvh_policy_set = false; // a file named one of the two
     float bump_scale = 0.f; // 0: not set
     bool sun_changed = false;
+    // the Sun header of the scene state (libapp/scene_state.h:79-96); NAN = not named by any file so far
+    float sun_height = NAN, sun_angle = NAN, turbidity = NAN, albedo[3] = {NAN, NAN, NAN};
     std::vector<std::string> notes;
 };
 
@@ -194,10 +198,11 @@ inline void apply_ini_object(const IniObject &o, HostConfig &c) {
         c.params.enable_raster_taa = unjittered ? -1 : (taa ? 1 : 0);
     }
     if (const IniObject *s = o.child("Sun")) {
-        if (!s->attributes.empty()) {
-            c.sun_changed = true;
-            c.notes.push_back("Sun settings (height / angle / turbidity / Color) need the Hosek-Wilkie fit on the reference side: the scene file's sky is kept");
-        }
+        if (!s->attributes.empty()) c.sun_changed = true;
+        s->get("height", &c.sun_height, 1);
+        s->get("angle", &c.sun_angle, 1);
+        s->get("turbidity", &c.turbidity, 1);
+        s->get("Color", c.albedo, 3);
     }
     if (const IniObject *s = o.child("Scene")) s->get("bump scale", &c.bump_scale, 1);
 }

@@ -6,6 +6,7 @@
 //            [--animate-wave amplitude kx]
 //   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
 //            [--config file.ini]... [--keyframe [<seconds>:]file.ini]... [--camera n] [--freeze-frame] [--upscale n] [--backend hip]
+//            [--sky-data <dir with the Hosek-Wilkie data headers>]   (Sun settings of the .ini files refit the sky: host/sky_fit.hpp; also RPTR_SKY_DATA)
 //            [--rng-variant uniform|bn|sobol|z-sobol] [--bn-table BNData.u32] [--force-bvh-rebuild] [--rebuild-triangle-budget n]
 //            [--devices n | --devices a,b,c] [--stripe-rows r]
 //
@@ -34,6 +35,7 @@
 #include "ini_config.hpp"
 #include "render_group.hpp"
 #include "scene_dump.hpp"
+#include "sky_fit.hpp"
 #include "vks_reader.hpp"
 #include "write_image.hpp"
 
@@ -108,7 +110,7 @@ int main(int argc, char **argv) {
     bool every_frame = false, describe = false, validation = false, profiling = false, got_eye = false, got_center = false, got_up = false;
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
     int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
-    std::string bn_table_path, dump_scene_path;
+    std::string bn_table_path, dump_scene_path, sky_data;
     int upscale = 0, stripe_rows = 8;
     std::vector<int> devices{0};
     std::vector<std::string> config_inis;
@@ -163,6 +165,7 @@ int main(int argc, char **argv) {
         }
         else if (a == "--camera") { need(1); ++i; } // an index beyond the scene's cameras leaves the default view (libapp/scene_state.cpp:45-50); the scene file holds one
         else if (a == "--upscale") { need(1); upscale = std::max(1, std::atoi(argv[++i])); }
+        else if (a == "--sky-data") { need(1); sky_data = argv[++i]; }
         else if (a == "--stripe-rows") { need(1); stripe_rows = std::atoi(argv[++i]); }
         else if (a == "--devices") { // a count (devices 0..n-1) or a comma-separated list of HIP ordinals
             need(1);
@@ -284,7 +287,7 @@ int main(int argc, char **argv) {
     if (scene_path.empty() || (int)validation + (int)profiling + (int)data_capture != 1 || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
         std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
                              "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
-                             "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png]\n"
+                             "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png] [--config file.ini ...] [--sky-data <dir of the Hosek-Wilkie data headers>]\n"
                              "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n] [--data-capture-no-rgba] [--data-capture-no-aovs] "
                              "[--data-capture-albedo-roughness] [--data-capture-normal-depth] [--data-capture-motion] [--keyframe ...]   (EXR images per keyframe)\n"
                              "       <scene.vks>: [--remove-first-lods n] [--instance-pruning p] [--small-deformation] [--ignore-animation] [--ignore-textures] "
@@ -314,6 +317,38 @@ int main(int argc, char **argv) {
             frames.push_back(state);
             holds.push_back(k.hold);
         }
+        // the sky of a scene state (update_config -> update_sky_light, vulkan/render_sky.cpp:25-72): fitted here when a configuration names
+        // Sun settings and the Hosek-Wilkie data headers are at hand (--sky-data / RPTR_SKY_DATA; host/sky_fit.hpp)
+        rptr::SkyTables sky_tables;
+        bool have_sky = false;
+        if (sky_data.empty() && std::getenv("RPTR_SKY_DATA")) sky_data = std::getenv("RPTR_SKY_DATA");
+        if (!sky_data.empty()) {
+            std::string err;
+            have_sky = rptr::load_sky_tables(sky_data, sky_tables, err);
+            if (!have_sky) throw std::runtime_error("--sky-data: " + err);
+            if (!err.empty()) std::fprintf(stderr, "note: %s\n", err.c_str());
+        }
+        const RptrSceneParams file_sky = scene.scene_params;
+        auto sky_of = [&](rptr::HostConfig &c) { // the scene parameters of one state; reference defaults where no file named a value
+            RptrSceneParams sp = file_sky;
+            if (c.bump_scale > 0.f) sp.normal_z_scale = 1.0f / c.bump_scale; // render_vulkan.cpp:2954-2959
+            if (!c.sun_changed) return sp;
+            if (!have_sky) {
+                const char *note = "Sun settings (height / angle / turbidity / Color) need the Hosek-Wilkie data headers (--sky-data <dir> / RPTR_SKY_DATA): the scene file's sky is kept";
+                if (std::find(c.notes.begin(), c.notes.end(), note) == c.notes.end()) c.notes.push_back(note);
+                return sp;
+            }
+            float height, angle;
+            rptr::sun_height_angle_from_dir(file_sky.sun_dir, height, angle);
+            float dir[3] = {file_sky.sun_dir[0], file_sky.sun_dir[1], file_sky.sun_dir[2]};
+            if (!std::isnan(c.sun_height) || !std::isnan(c.sun_angle)) // scene_state.h:85-90
+                rptr::sun_dir_from_height_angle(std::isnan(c.sun_height) ? height : c.sun_height, std::isnan(c.sun_angle) ? angle : c.sun_angle, dir);
+            const float turbidity = std::isnan(c.turbidity) ? 3.0f : std::min(10.0f, std::max(1.0f, c.turbidity)); // SceneConfig defaults, render_params.glsl.h:157-162
+            const float albedo[3] = {std::isnan(c.albedo[0]) ? 0.2f : c.albedo[0], std::isnan(c.albedo[1]) ? 0.2f : c.albedo[1], std::isnan(c.albedo[2]) ? 0.2f : c.albedo[2]};
+            rptr::fit_sky(sky_tables, dir, turbidity, albedo, (int)scene.lights.size(), sp);
+            return sp;
+        };
+        scene.scene_params = sky_of(base);
         for (const rptr::HostConfig *c : {&base})
             for (const std::string &n : c->notes) std::fprintf(stderr, "note: %s\n", n.c_str());
         if (base.target_spp > 0 && !validation) target_spp = base.target_spp;
@@ -325,7 +360,6 @@ int main(int argc, char **argv) {
         backend.set_scene(scene.desc());
         base.params.batch_spp = batch_spp;
         backend.set_params(base.params, base.lighting);
-        if (base.bump_scale > 0.f) scene.scene_params.normal_z_scale = 1.0f / base.bump_scale; // render_vulkan.cpp:2954-2959
         backend.update_config(scene.scene_params);
         // render backend options: the point set (with the table its render extension uploads) and the BVH policy of dynamic meshes
         if (rng_variant < 0) rng_variant = base.rng_variant;
@@ -391,6 +425,7 @@ int main(int argc, char **argv) {
                     st.params.batch_spp = batch_spp;
                     if (upscale >= 1) st.params.render_upscale_factor = upscale;
                     backend.set_params(st.params, st.lighting);
+                    if (st.sun_changed || st.bump_scale > 0.f) backend.update_config(sky_of(st));
                     std::memcpy(cfg.camera.pos, st.camera.pos, 12);
                     std::memcpy(cfg.camera.dir, st.camera.dir, 12);
                     std::memcpy(cfg.camera.up, st.camera.up, 12);
@@ -456,6 +491,7 @@ int main(int argc, char **argv) {
                     st.params.batch_spp = batch_spp;
                     if (upscale >= 1) st.params.render_upscale_factor = upscale;
                     backend.set_params(st.params, st.lighting);
+                    if (st.sun_changed || st.bump_scale > 0.f) backend.update_config(sky_of(st));
                     std::memcpy(cfg.camera.pos, st.camera.pos, 12);
                     std::memcpy(cfg.camera.dir, st.camera.dir, 12);
                     std::memcpy(cfg.camera.up, st.camera.up, 12);

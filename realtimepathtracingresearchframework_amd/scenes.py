@@ -309,10 +309,14 @@ class Scene:
         """≙ update_config + update_sky_light (render_vulkan.cpp:2954-2959, render_sky.cpp:25-72).
 
         The Hosek-Wilkie fit needs the model's published data tables (66 KB RGB + 514 KB spectral coefficients,
-        rendering/lights/sky_model_arhosek/sky_model_data_*.h), which this package does not carry: in a drop-in the
-        adapter calls the reference's own sky_model.cpp (INTEGRATION.md "update_config"), and the built-in scenes
-        take their fitted SkyModelParams / sun radiance from package data generated with that very code
-        (data/sky_params.json, written by tools/gen_sky_params.py)."""
+        rendering/lights/sky_model_arhosek/sky_model_data_*.h), which this package does not carry: with RPTR_SKY_DATA pointing at
+        them the fit runs here (sky_fit.py = host/sky_fit.hpp, bit-equal to the reference's code: tests/test_sky_fit.py); without,
+        the built-in scenes take the fitted SkyModelParams / sun radiance of their five configurations from package data generated
+        with the reference's own code (data/sky_params.json, written by tools/gen_sky_params.py)."""
+        if os.environ.get("RPTR_SKY_DATA"):   # the data headers are at hand: fit this scene's own state (any sun / turbidity / albedo)
+            from . import sky_fit
+            return sky_fit.fit_sky(_sky_tables(os.environ["RPTR_SKY_DATA"]), self.config.sun_dir, self.config.turbidity, self.config.albedo,
+                                   len(self.lights), normal_z_scale=1.0 / self.config.bump_scale)
         sky = load_sky_fixture(self.sky_key, has_lights=len(self.lights) > 0)
         sp = abi.SceneParams()
         for i in range(9):
@@ -326,6 +330,14 @@ class Scene:
 
 
 _SKY_CACHE = None
+_SKY_TABLES = {}
+
+
+def _sky_tables(where):
+    if where not in _SKY_TABLES:
+        from . import sky_fit
+        _SKY_TABLES[where] = sky_fit.SkyTables(where)
+    return _SKY_TABLES[where]
 
 
 def sky_fixture_path():

@@ -45,6 +45,45 @@ def test_host_built_tree_walked_by_the_oracle_equals_brute_force(scene_fn, lo, h
     assert np.array_equal(any_b, any_t)
 
 
+@pytest.mark.parametrize("scene_fn,lo,hi", [(scenes.cornell32, -5, 5), (lambda: scenes.soup(3, n_meshes=2, tris_per_mesh=150, n_instances=4), -4, 4),
+                                            (lambda: scenes.forest(n_meshes=3, tris_per_tree=300, n_instances=25, name="f"), -6, 6)])
+@pytest.mark.parametrize("flatten", ["0", "1"])
+def test_trees_with_split_references_still_equal_brute_force(scene_fn, lo, hi, flatten, monkeypatch):
+    """RPTR_PRESPLIT (csrc/bvh_build.h presplit_triangles): a triangle is referenced by several leaves, each with the box of a part of it.
+    The parts cover the triangle (boxes rounded outwards), every reference names the same triangle record, so the closest hit -- smallest t,
+    ties by (instance, geometry, primitive) -- and every occlusion answer stay those of brute force, bit for bit; slivers, points,
+    duplicates and flat meshes (the soup) included."""
+    s = scene_fn()
+    monkeypatch.setenv("RPTR_FLATTEN", flatten)
+    monkeypatch.setenv("RPTR_PRESPLIT", "0")
+    nodes0, tris0, insts0, _ = backend.build_bvh_host(s)
+    monkeypatch.setenv("RPTR_PRESPLIT", "3000,2.0")
+    nodes, tris, insts, need = backend.build_bvh_host(s)
+    assert len(tris) > 1.2 * len(tris0)       # references were added ...
+    t0, t1 = tris0.view(TRI_DT), tris.view(TRI_DT)
+    rec0 = {bytes(r) for r in t0}
+    assert {bytes(r) for r in t1} == rec0     # ... and every reference is one of the scene's triangle records, none is lost
+    osc = O.OracleScene(s)
+    osc.import_bvh(nodes, tris, insts)
+    o, d = _rays(6000, 7, lo, hi)
+    if flatten == "1" and len(s.instances) > 1:
+        # a flattened scene intersects world-space triangles (t / u / v differ from the object-space brute force by rounding): the
+        # yardstick is the flattened tree WITHOUT split references, which holds the very same triangle records
+        base = O.OracleScene(s)
+        base.import_bvh(nodes0, tris0, insts0)
+        truth = lambda *a, **k: base.trace_ex(*a, bvh_mode=O.BVH_IMPORTED, **k)  # noqa: E731
+    else:
+        truth = lambda *a, **k: osc.trace_ex(*a, bvh_mode=O.BVH_BRUTE, **k)  # noqa: E731
+    tuv_b, ids_b = truth(o, d, 1e-4, 1e20)
+    tuv_t, ids_t = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+    assert (ids_b[:, 0] >= 0).sum() > 100
+    assert np.array_equal(tuv_b.view(np.uint32), tuv_t.view(np.uint32)) and np.array_equal(ids_b, ids_t)
+    tmax = np.where(tuv_b[:, 0] > 0, tuv_b[:, 0] * np.random.default_rng(2).choice([0.5, 1.5], len(o)), 5.0).astype(np.float32)
+    any_b = truth(o, d, 1e-4, tmax, any_hit=True)[1][:, 0]
+    any_t = osc.trace_ex(o, d, 1e-4, tmax, any_hit=True, bvh_mode=O.BVH_IMPORTED)[1][:, 0]
+    assert np.array_equal(any_b, any_t)
+
+
 def test_encoded_boxes_contain_their_subtrees_and_the_tree_is_sound():
     s = scenes.grid(40, 20)
     nodes_f, tris_f, insts_f, _ = backend.build_bvh_host(s)

@@ -845,3 +845,117 @@ def test_cpp_vks_reader_keeps_mip_levels(tmp_path):
     out = subprocess.run([exe, cpp, "--dump-scene", again], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert open(again, "rb").read() == open(cpp, "rb").read()
+
+
+# ---------------------------------------------------------------- a15 host half: Sun settings of an .ini refit the sky
+def write_synthetic_sky_data(dirpath, seed=11):
+    """data headers in the layout of the Hosek-Wilkie distribution (`double name[] = { ... };`) filled with made-up but well-behaved
+    coefficients: what the parser and the fit need on a box without the published tables. The Bezier / bilinear blends are convex
+    combinations, so every fitted coefficient stays in the range given per index here (finite skies, a positive sun)."""
+    rng = np.random.default_rng(seed)
+    rng_of = [(-1.2, -1.0), (-0.5, -0.1), (0.0, 1.0), (0.0, 1.0), (-3.0, -1.0), (0.0, 0.5), (0.0, 0.2), (0.0, 1.0), (0.3, 0.7)]
+
+    def arr(name, values, ctype="double"):
+        return "%s %s[] =\n{\n%s\n};\n\n" % (ctype, name, ",\n".join("\t%.9e" % v for v in values))
+
+    def dataset():   # [albedo 2][turbidity 10][control point 6][coefficient 9]
+        return np.concatenate([rng.uniform(lo, hi, 120)[:, None] for lo, hi in rng_of], axis=1).reshape(-1)
+    rgb = "// synthetic stand-in (tests): layout of ArHosekSkyModelData_RGB.h\n"
+    for c in range(3):
+        rgb += arr("datasetRGB%d" % (c + 1), dataset()) + arr("datasetRGBRad%d" % (c + 1), rng.uniform(5, 20, 120))
+    rgb += "double* datasetsRGB[] =\n{\n\tdatasetRGB1,\n\tdatasetRGB2,\n\tdatasetRGB3\n};\n"
+    spec = "/* synthetic stand-in (tests): layout of ArHosekSkyModelData_Spectral.h */\n"
+    for w in range(320, 721, 40):
+        spec += arr("dataset%d" % w, dataset()) + arr("datasetRad%d" % w, rng.uniform(5, 20, 120))
+    for w in range(320, 721, 40):
+        coef = np.zeros((10 * 45, 4))
+        coef[:, 3] = rng.uniform(1e3, 2e4, 450)      # piecewise cubics: constant term last (the loop reads backwards)
+        coef[:, 2] = rng.uniform(0, 1e3, 450)
+        spec += arr("solarDataset%d" % w, coef.reshape(-1))
+    for w in range(320, 721, 40):
+        spec += "double limbDarkeningDataset%d[] =\n{ %s };\n" % (w, ", ".join("%.6f" % v for v in [0.3, 0.9, -0.4, 0.3, -0.15, 0.05]))
+    cie = "#define CM_CIE_SAMPLES 95\ntypedef float Float;\nstatic const Float cie1931_tbl[CM_CIE_SAMPLES * 3] = {\n"
+    lam = np.linspace(360, 830, 95)
+    tbl = np.concatenate([np.exp(-0.5 * ((lam - mu) / sg) ** 2) for mu, sg in ((600, 40), (555, 45), (450, 25))])
+    cie += ", ".join("Float(%.12f)" % v for v in tbl) + "\n};\n"
+    (dirpath / "sky_model_data_rgb.h").write_text(rgb)
+    (dirpath / "sky_model_data_spectral.h").write_text(spec)
+    (dirpath / "color_matching.h").write_text(cie)
+
+
+INI_SUN = """[Application][scene.vks]
+[.][Sun]
+height= 2.500000e+01
+angle= -6.000000e+01
+turbidity= 6.500000e+00
+Color= 4.000000e-01 3.000000e-01 1.000000e-01
+..
+"""
+
+
+@pytest.mark.gpu
+def test_cli_refits_the_sky_for_the_sun_settings_of_an_ini(tmp_path):
+    """row a15, host half: `[.][Sun]` of a configuration file (height / angle / turbidity / Color, libapp/scene_state.h:79-96) moves the
+    sun -- the host runs the Hosek-Wilkie fit (host/sky_fit.hpp) on the data headers --sky-data points at. Synthetic tables of the
+    published layout here (the box has no copy of the real ones; the real ones are held against the reference's own code in
+    tests/test_sky_fit.py): the CLI's image = the Python mirror's image with sky_fit.py's parameters, bit for bit; and without the data
+    the scene file's sky is kept and a note says why."""
+    from common import gpu_render
+    from realtimepathtracingresearchframework_amd import backend, sky_fit
+    exe = _build_cli(tmp_path)
+    s = scenes.grid(40, 20, with_emitters=True)
+    path = str(tmp_path / "g.rpsc")
+    s.dump(path)
+    data = tmp_path / "skydata"
+    data.mkdir()
+    write_synthetic_sky_data(data)
+    (tmp_path / "sun.ini").write_text(INI_SUN)
+    W, H, spp = 96, 64, 2
+    p = subprocess.run([exe, path, "--validation", str(tmp_path / "sun"), "--validation-spp", str(spp), "--img", str(W), str(H), "--pfm", "--variant", "gltf",
+                        "--config", str(tmp_path / "sun.ini"), "--sky-data", str(data)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    moved = read_pfm("%s_%04d.pfm" % (tmp_path / "sun", spp))
+    tables = sky_fit.SkyTables(str(data))
+    assert tables.has_sun
+    sp = sky_fit.fit_sky(tables, sky_fit.sun_dir_from_height_angle(25.0, -60.0), 6.5, (0.4, 0.3, 0.1), len(s.lights))
+    assert sp.sun_radiance[0] > 0 and sp.sun_radiance[3] == 0.5 and np.isfinite(np.array([list(r) for r in sp.sky_params.configs])).all()
+    r = backend.RenderHip()
+    r.initialize(W, H)
+    r.set_scene(s)
+    r.update_config(sp)
+    r.render(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=spp)
+    ref = np.zeros((H, W, 4), np.float32)
+    r.readback_framebuffer(ref)
+    r.close()
+    assert np.isfinite(moved).all() and np.array_equal(moved.view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32))
+    # the environment variable does what the flag does; without the data the file's sky stays and the host says so
+    p = subprocess.run([exe, path, "--validation", str(tmp_path / "env"), "--validation-spp", str(spp), "--img", str(W), str(H), "--pfm", "--variant", "gltf",
+                        "--config", str(tmp_path / "sun.ini")], capture_output=True, text=True, env=dict(os.environ, RPTR_SKY_DATA=str(data)))
+    assert p.returncode == 0, p.stderr
+    assert np.array_equal(read_pfm("%s_%04d.pfm" % (tmp_path / "env", spp)).view(np.uint32), moved.view(np.uint32))
+    env = {k: v for k, v in os.environ.items() if k != "RPTR_SKY_DATA"}
+    p = subprocess.run([exe, path, "--validation", str(tmp_path / "kept"), "--validation-spp", str(spp), "--img", str(W), str(H), "--pfm", "--variant", "gltf",
+                        "--config", str(tmp_path / "sun.ini")], capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and "--sky-data" in p.stderr
+    kept = read_pfm("%s_%04d.pfm" % (tmp_path / "kept", spp))
+    plain, _, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+    assert np.array_equal(kept.view(np.uint32), np.ascontiguousarray(plain[..., :3]).view(np.uint32)) and not np.array_equal(kept, moved)
+    # a directory without the headers is an error, not a silent fallback
+    p = subprocess.run([exe, path, "--validation", str(tmp_path / "bad"), "--img", "8", "8", "--sky-data", str(tmp_path)], capture_output=True, text=True)
+    assert p.returncode == 3 and "sky_model_data_rgb.h" in p.stderr
+
+
+def test_synthetic_sky_tables_parse_like_the_real_layout(tmp_path):
+    """(CPU) the stand-in headers go through the same parsers (C++ and Python) and give the same fit in both"""
+    import ctypes as C
+    from test_sky_fit import as_words, build_shim
+    from realtimepathtracingresearchframework_amd import sky_fit
+    write_synthetic_sky_data(tmp_path)
+    t = sky_fit.SkyTables(str(tmp_path))
+    assert t.has_sun and [len(v) for v in t.rgb] == [1080] * 3 and [len(v) for v in t.solar] == [1800] * 11 and len(t.cie) == 285
+    L = build_shim(tmp_path)
+    err = C.create_string_buffer(512)
+    for d, turb, al, lights in (((0.3, 0.8, 0.5), 3.0, (0.2, 0.2, 0.2), 0), ((0.8, 0.25, 0.3), 6.5, (0.4, 0.3, 0.1), 4), ((0.0, -1.0, 0.0), 10.0, (1.0, 0.0, 0.5), 0)):
+        got = abi.SceneParams()
+        assert L.shim_fit(str(tmp_path).encode(), (C.c_float * 3)(*d), C.c_float(turb), (C.c_float * 3)(*al), lights, C.byref(got), err, 512) == 0, err.value
+        assert np.array_equal(as_words(got), as_words(sky_fit.fit_sky(t, d, turb, al, lights)))
