@@ -88,6 +88,11 @@ def parse_args():
     ap.add_argument("--dist-backend", type=str, default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test rig for the N>1 control flow on a box with fewer GPUs than ranks (tiles are staged through the host)")
     ap.add_argument("--same-device", action="store_true", help="test rig: every rank renders on cuda:0")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="N > 1: skip the RCCL probe (a child process per rank that tries torch's nccl group and the library's communicator + one "
+                         "gather under a time-out before the real run commits to them)")
+    ap.add_argument("--probe-timeout", type=float, default=150.0)
+    ap.add_argument("--rccl-probe", action="store_true", help="(internal) run as the probe child of a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-pass", action="store_true",
                     help="for rocprofv3 --pmc / --kernel-trace passes (tools/pmc.sh): warm-up + `steps` frames one at a time, nothing else, no JSON line")
@@ -106,6 +111,75 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
+def rccl_probe_child(args):
+    """One rank of the probe job (started by every rank of the real job, rendezvous on MASTER_PORT + 1): (1) torch's nccl process group +
+    an all-reduce, (2) the library's own communicator from a broadcast unique id + one gather of a tiny frame. Prints a line per stage that
+    worked; a hang is the parent's time-out. Nothing of the real run depends on this process."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from realtimepathtracingresearchframework_amd import abi, backend, scenes
+    from realtimepathtracingresearchframework_amd.distributed import NativeGather
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)
+    torch.cuda.synchronize()
+    if float(t[0]) != float(world):
+        raise SystemExit("all_reduce gave %r" % (t.tolist(),))
+    print("PROBE torch_nccl 1", flush=True)
+    s = scenes.cornell32()
+    r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=8)
+    r.initialize(64, 64)
+    r.set_scene(s)
+    g = NativeGather(r, rank, world)
+    for _ in range(2):
+        r.wait(r.render_async(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1))
+        g.gather()
+    if rank == 0:
+        img = np.zeros((64, 64, 4), np.float32)
+        g.frame(img)
+        if not (np.isfinite(img).all() and img[..., :3].max() > 0 and (img[..., 3] > 0).mean() > 0.5):
+            raise SystemExit("the gathered frame is empty")
+    else:
+        r.comm_stats()   # waits for this rank's send
+    dist.barrier()
+    print("PROBE native 1", flush=True)
+    r.close()
+    dist.destroy_process_group()
+
+
+def run_rccl_probe(args, timeout_s):
+    """starts this rank's probe child and reports which stages it got through: {"torch_nccl": 0|1, "native": 0|1, "note": str}"""
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    env["MASTER_ADDR"] = "127.0.0.1" if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("localhost", "127.0.0.1") else os.environ["MASTER_ADDR"]
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)   # the child makes its own TCP store on MASTER_PORT + 1, it does not join the agent's
+    cmd = [sys.executable, os.path.abspath(__file__), "--rccl-probe"] + (["--same-device"] if args.same_device else [])
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    note = ""
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, 9)   # the exact process group this call started
+        except Exception:
+            p.kill()
+        out, err = p.communicate()
+        note = "probe timed out after %.0f s" % timeout_s
+    got = {"torch_nccl": int("PROBE torch_nccl 1" in out), "native": int("PROBE native 1" in out)}
+    if not note and p.returncode != 0:
+        tail = [l for l in err.strip().splitlines() if l.strip()]
+        note = "probe exited with %s: %s" % (p.returncode, tail[-1][:200] if tail else "")
+    got["note"] = note
+    got["seconds"] = round(time.time() - t0, 1)
+    return got
+
+
 def host_cpu_budget(hw_threads):
     """Threads for the CPU baseline: the container's CPU quota (cgroup cpu.max) x2 for SMT, capped by the hardware threads.
     (The GPU box shows 256 hardware threads but grants 16 CPUs; 256 threads run 2x slower than 32 there.)"""
@@ -118,11 +192,45 @@ def host_cpu_budget(hw_threads):
     return max(1, hw_threads)
 
 
-def load_pmc_traffic():
-    """profiles/pmc_traffic.json: HBM-side bytes per launch of every kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    passes of the default workload (tools/pmc.sh + tools/make_traffic.py). None when absent."""
+def workload_key(args, world=1):
+    """the BASELINE workload a command line names, as tools/pmc_workloads.sh keys its counter passes (None: not one of them)"""
+    if world != 1 or args.emulate_world > 1 or args.grid != "1000x500" or args.rebuild_budget != 0:
+        return None
+    size = (args.width, args.height, args.spp)
+    flat = args.flatten if args.flatten >= 0 else (1 if args.scene == "forest" else 0)
+    if args.scene == "forest":
+        return ("c4_flat" if flat else "c4_two_level") if (size == (1920, 1080, 4) and args.variant == "diffuse" and not args.lights and not args.animate) else None
+    if args.animate:
+        return "c5" if (size == (3840, 2160, 2) and args.variant == "diffuse" and not args.lights) else None
+    if args.lights:
+        return "c3" if (size == (1920, 1080, 8) and args.variant == "gltf") else None
+    return "c2" if (size == (1920, 1080, 4) and args.variant == "diffuse") else None
+
+
+def load_pmc_traffic(key):
+    """profiles/pmc_traffic.json: per workload, HBM-side bytes / VALU instructions / wave-cycle split per launch of every kernel, from
+    the committed rocprofv3 --pmc passes of that workload (tools/pmc_workloads.sh: tools/pmc.sh + tools/make_traffic.py). None when absent."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        return doc["workloads"].get(key) if key else None
+    except Exception:
+        return None
+
+
+def load_valu_peak():
+    """the VALU issue ceiling, MEASURED (tools/microbench/valu_issue.hip -> profiles/r03a_valu_issue.json, chip-wide G wave64
+    instructions / s at 8 waves per SIMD): of plain full-rate instructions (v_fma_f32 / v_mul_f32 / v_add_u32: one per 2 clocks per
+    SIMD, MI355X_MICROARCH.md) and of the instruction mix of the BVH4 node step (v_cvt_f32_ubyte, v_pk_fma_f32, min / max issue at half
+    that rate). None when the file is absent."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "r03a_valu_issue.json")))
+        best = {}
+        for r in doc["results"]:
+            best[r["op"]] = max(best.get(r["op"], 0.0), r["ginst_s_wall"])
+        mix = max(v for k, v in best.items() if k.startswith("node_step_mix"))
+        full = max(best.get("v_fma_f32", 0.0), best.get("v_mul_f32", 0.0), best.get("v_add_u32", 0.0))
+        return {"node_step_mix_ginst_s": mix, "full_rate_ginst_s": full, "half_rate_ginst_s": best.get("v_pk_fma_f32"),
+                "source": "profiles/r03a_valu_issue.json (tools/microbench/valu_issue.hip on an MI355X of the pool)"}
     except Exception:
         return None
 
@@ -140,7 +248,7 @@ def valu_frame(pmc, ms_per_step, valu_peak, launches):
     """all kernels of one frame (PMC instruction counts of the profile pass: every launch of every kernel / frames) against the VALU
     issue peak over the PIPELINED frame time: how much of the machine's instruction issue the steady state uses. (The bounce at which
     the tail kernel takes over may differ between the two runs; the work of a frame does not.)"""
-    total = pmc.get("valu_insts_per_frame")
+    total = pmc.get("valu_insts_per_frame") if pmc else None
     if total is None:
         return None
     return {"valu_insts_per_step": int(total), "pipelined_ginst_s": round(total / (ms_per_step * 1e-3) / 1e9, 1),
@@ -149,6 +257,8 @@ def valu_frame(pmc, ms_per_step, valu_peak, launches):
 
 def main():
     args = parse_args()
+    if args.rccl_probe:
+        return rccl_probe_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     import torch
@@ -162,12 +272,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    probe = None
     if world > 1:
+        # Control plane (barriers, the max / sum over ranks of a few host numbers, the unique-id broadcast): a gloo group -- it cannot hang
+        # on a GPU. Data plane (the path's ONE collective, the gather of tile radiance): RCCL, through the library's own communicator or,
+        # failing that, torch's nccl group; which of them this node can do is found out by a probe child per rank under a time-out
+        # BEFORE the run commits to it (a wedged ncclCommInitRank would otherwise eat the whole job).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            probe = {"torch_nccl": 1, "native": 1, "note": "not probed (--no-probe)", "seconds": 0.0} if args.no_probe else run_rccl_probe(args, args.probe_timeout)
+            flags = torch.tensor([probe["torch_nccl"], probe["native"]], dtype=torch.int32)
+            dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # every rank takes the same path
+            mine = (probe["torch_nccl"], probe["native"])
+            probe["torch_nccl"], probe["native"] = int(flags[0]), int(flags[1])
+            if mine != (probe["torch_nccl"], probe["native"]) and not probe["note"]:
+                probe["note"] = "the probe failed on another rank"
 
     nx, nz = (int(v) for v in args.grid.split("x"))
     t0 = time.time()
@@ -192,6 +312,9 @@ def main():
     # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
     batch_frames = args.batch_frames if args.batch_frames > 0 else (1 if args.animate else max(1, min(4, 16 // max(spp, 1))))
+    # no more contexts than the timed region has launch sequences for: the line names the schedule that ran (20 steps in sequences of 4
+    # frames are 5 sequences, not 11)
+    fif = max(2 if batch_frames > 1 else 1, min(fif, -(-args.steps // batch_frames)))   # (a batch of frames needs two contexts: every frame keeps its image)
     if args.profile_pass:
         fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
     if args.emulate_world > 1:
@@ -202,22 +325,27 @@ def main():
     t0 = time.time()
     r.set_scene(scene)
     t_build = time.time() - t0
+    bvh_on_device, bvh_step_ms, bvh_device_ms = r.bvh_build_info()
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
     cam = scene.camera_params()
 
     # ---- the gather (N > 1): the library's own RCCL path, or torch.distributed as plumbing
-    on_host = world > 1 and args.dist_backend == "gloo"
-    gather_mode, gather_note, native, tgather, stage = None, None, None, None, None
+    # the gather: "native" = the library's RCCL gather; "torch" = tile copy + torch.distributed.gather over an nccl group; "host" = the same over
+    # gloo with the tiles staged through the host (the last resort, and the CPU test rig --dist-backend gloo)
+    on_host = world > 1 and (args.dist_backend == "gloo" or not probe["torch_nccl"])
+    gather_mode, gather_note, native, tgather, stage, nccl_group = None, None, None, None, None, None
     if world > 1:
-        gather_mode = "native" if (args.gather == "native" and not on_host and not args.same_device) else "torch"
+        gather_mode = "native" if (args.gather == "native" and not on_host and probe["native"]) else ("host" if on_host else "torch")
+        if probe is not None and probe["note"] and gather_mode != "native":
+            gather_note = "RCCL probe: %s -> %s" % (probe["note"], {"torch": "torch.distributed gather over nccl", "host": "gather over gloo, tiles staged through the host"}[gather_mode])
         if gather_mode == "native":
             ok = 1
             try:
                 native = NativeGather(r, rank, world)
             except Exception as e:  # every rank must take the same path: agree on it
                 ok, gather_note = 0, "native RCCL communicator failed (%s): torch.distributed gather used instead" % (str(e)[:200],)
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 0:
                 gather_mode, native = "torch", None
@@ -227,8 +355,10 @@ def main():
                 except Exception:
                     pass
         if gather_mode == "torch":
-            tgather = TileGather(W, H, args.stripe_rows, rank, world, device="cpu" if on_host else "cuda")
-            stage = torch.zeros_like(tgather.tile, device="cuda") if on_host else None  # gloo rig: device tile -> host tile
+            nccl_group = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if gather_mode in ("torch", "host"):
+            tgather = TileGather(W, H, args.stripe_rows, rank, world, device="cpu" if on_host else "cuda", group=nccl_group)
+            stage = torch.zeros_like(tgather.tile, device="cuda") if on_host else None  # device tile -> host tile
     my_bytes = r.local_pixel_count() * 16
     host_gather_s = [0.0]
 
@@ -302,8 +432,10 @@ def main():
         return
 
     r.set_stage_timing(int(os.environ.get("BENCH_STAGE_TIMING", "1")))  # timed region: HIP events around every closest-hit traversal launch (the roofline kernel) only
-    for _ in range(args.warmup):
-        step()
+    # warm-up: W steps through the very path the timed region takes (launch sequences of `batch_frames` frames, `fif` of them in flight:
+    # every frame context renders before the clock starts); the first frame of a handle runs without the tail kernel, so at least two
+    step()
+    timed_steps(max(args.warmup, 1), lambda st: None)
     if anim is not None:
         anim["ev"].clear()
     host_gather_s[0] = 0.0
@@ -334,22 +466,33 @@ def main():
     # (nothing else on the GPU): what the roofline figures use; (2) instrumented frames: node / triangle visits of this rank's queries
     # (counted, not modelled). The rocprofv3 passes under profiles/ run the same configuration (bench.py --profile-pass).
     torch.cuda.synchronize()
+    # (a handle with ONE frame context runs the shadow rays of bounce b on a side stream beside the closest-hit rays of bounce b + 1 unless
+    # told otherwise: the exclusive figures need every launch alone on the GPU)
+    side_env = os.environ.get("RPTR_SIDE_CONNECT")
+    os.environ["RPTR_SIDE_CONNECT"] = "0"
     rx = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=1)
+    if side_env is None:
+        del os.environ["RPTR_SIDE_CONNECT"]
+    else:
+        os.environ["RPTR_SIDE_CONNECT"] = side_env
     rx.initialize(W, H)
     rx.set_scene(scene)
     if args.animate and args.rebuild_budget != 0:
         rx.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
 
-    def step_x(count=False):
+    def submit_on(handle, count=False):
         if anim is not None:
             t = 0.02 * anim["frame"]
             anim["frame"] += 1
             cur, b = anim["cur"], anim["base"]
             torch.add(b[:, 1], torch.sin(b[:, 0] * 0.4 + 6.283185307179586 * t), alpha=0.5, out=cur[:, 1])
-            rx.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
-            rx.refit()
+            handle.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
+            handle.refit()
         cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
-        return rx.wait(rx.render_async(cfg, spp=spp, count_traversal=count))
+        return handle.render_async(cfg, spp=spp, count_traversal=count)
+
+    def step_x(count=False):
+        return rx.wait(submit_on(rx, count))
 
     rx.set_stage_timing(2)
     for _ in range(3):
@@ -367,6 +510,41 @@ def main():
         serial["other"] += (st.shade_time_ms - st.shade_only_time_ms - st.tail_time_ms - st.resolve_time_ms) / n_serial
         serial["gpu"] += st.render_time_ms / n_serial
         serial_launches = int(st.launches_extend)
+
+    # ---- latency (ms/frame = GPU time from the first stage launch to the resolve): frames ONE at a time, and TWO in flight
+    # -- what the reference's swap chain holds (RenderGraphic::MAX_SWAP_BUFFERS = 2, util/display/render_graphic.h:19). `value` above is
+    # the throughput of the pipelined schedule (config.frames_in_flight x frames_per_launch_sequence); these are the figures of an
+    # interactive host that cannot queue frames ahead.
+    def latency_of(handle, depth, n_frames):
+        handle.set_stage_timing(0)
+        for _ in range(2):
+            handle.wait(submit_on(handle))
+        torch.cuda.synchronize()
+        t_l, q, rays_l, gpu_l = time.perf_counter(), [], 0, 0.0
+        for k in range(n_frames + depth):
+            if k < n_frames:
+                q.append(submit_on(handle))
+            if len(q) >= depth or k >= n_frames:
+                if not q:
+                    break
+                stl = handle.wait(q.pop(0)).raw
+                rays_l += int(stl.rays_closest + stl.rays_shadow)
+                gpu_l += stl.render_time_ms
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t_l) * 1e3 / n_frames
+        return {"frames_in_flight": depth, "ms_per_frame": round(wall, 4), "mrays_s": round(rays_l / n_frames / wall / 1e3, 1),
+                "gpu_ms_first_launch_to_resolve": round(gpu_l / n_frames, 4), "frames": n_frames}
+
+    n_lat = max(10, min(40, args.steps))
+    latency = {}
+    for depth in ((1, 2) if (world == 1 and args.emulate_world <= 1) else (1,)):
+        rl = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=depth)
+        rl.initialize(W, H)
+        rl.set_scene(scene)
+        if args.animate and args.rebuild_budget != 0:
+            rl.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
+        latency[str(depth)] = latency_of(rl, depth, n_lat)
+        rl.close()
 
     def counted(depth=None):
         """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
@@ -396,7 +574,7 @@ def main():
         cnt_ext = cnt_con = cnt
 
     if world > 1:
-        rdev = "cpu" if on_host else "cuda"
+        rdev = "cpu"   # (the control plane is a gloo group)
         t = torch.tensor([elapsed, ext_ms, gather_host_ms] + [serial[k] for k in ("ext", "con", "shade", "tail", "resolve", "other", "gpu")],
                          dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -425,13 +603,16 @@ def main():
     shade_vertices = cnt_ext["rays_closest"]       # one shade invocation per closest-hit query of the stand-alone bounces
     shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES)
                    + cnt_ext["hits"] * (VERTEX_BYTES + MATERIAL_BYTES))
-    default_workload = (args.scene == "grid" and args.grid == "1000x500" and args.variant == "diffuse" and not args.lights and not args.animate
-                        and (W, H, spp) == (1920, 1080, 4) and world == 1 and args.emulate_world <= 1)
-    pmc = load_pmc_traffic() if default_workload else None   # the committed PMC passes were taken on the default workload: no figure for anything else
+    wkey = workload_key(args, world)
+    pmc = load_pmc_traffic(wkey)   # the committed counter passes of THIS workload (profiles/pmc_traffic.json), None for anything else
     n_launch = max(launches_extend, 1)
     props = torch.cuda.get_device_properties(local_rank)
-    clock_ghz = MAX_CLOCK_GHZ   # (hipDeviceProp's clockRate varies from box to box with the power state: the peak uses the chip's maximum)
-    valu_peak = props.multi_processor_count * clock_ghz   # G wave-instructions / s: CUs x 4 SIMDs x 1 VALU instruction per 4 clocks
+    # VALU issue ceiling: MEASURED (tools/microbench/valu_issue.hip). Plain v_fma / v_mul / v_add issue at one wave64 instruction per
+    # 2 clocks per SIMD (912-964 G/s chip-wide, as MI355X_MICROARCH.md says), but v_cvt_f32_ubyte, v_pk_fma_f32, v_min3 / v_max -- most
+    # of the BVH4 node step -- at half of that: the instruction mix of the node step tops out at 588 G/s. (Round 2 assumed 4 clocks for
+    # everything = 614 G/s at 2.4 GHz: wrong reasoning, nearly the right number for this mix.)
+    vp = load_valu_peak()
+    valu_peak = vp["node_step_mix_ginst_s"] if vp else props.multi_processor_count * MAX_CLOCK_GHZ
 
     def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches):
         """one kernel class: exclusive time, algorithmic bytes and their rate against the cache-hierarchy ceiling, counter traffic
@@ -449,7 +630,8 @@ def main():
         e["hbm_bytes_per_launch"] = int(tr) if tr is not None else None
         e["hbm_gbs"] = round(tr / (launch_ms * 1e-3) / 1e9, 1) if (tr is not None and launch_ms > 0) else None
         e["hbm_frac"] = round(e["hbm_gbs"] / HBM_PEAK_GBS, 4) if e["hbm_gbs"] is not None else None
-        # VALU issue: what binds these kernels (PMC: SQ_INSTS_VALU per launch) against CUs x 4 SIMDs x 1 wave instruction per 4 clocks
+        # VALU issue (PMC: SQ_INSTS_VALU per launch) against the measured issue ceiling of the node step's instruction mix; and where the
+        # resident waves' cycles go (SQ_WAIT_ANY: parked on s_waitcnt = memory latency; SQ_WAIT_INST_ANY: issue stalls; SQ_ACTIVE_INST_*)
         vi = None
         if pmc:
             parts = [traffic_of(pmc, p, "valu_insts_per_launch") for p in prefix_list]
@@ -458,6 +640,10 @@ def main():
         e["valu_insts_per_launch"] = int(vi) if vi is not None else None
         e["valu_ginst_s"] = round(vi / (launch_ms * 1e-3) / 1e9, 1) if (vi is not None and launch_ms > 0) else None
         e["valu_frac"] = round(e["valu_ginst_s"] / valu_peak, 4) if e["valu_ginst_s"] is not None else None
+        if pmc:
+            for fld in ("wait_any_frac", "wait_inst_any_frac", "active_inst_valu_frac", "tcc_hit_rate"):
+                parts = [traffic_of(pmc, p, fld) for p in prefix_list]
+                e[fld] = round(sum(parts) / len(parts), 4) if all(v is not None for v in parts) else None
         return e
 
     single = len(scene.instances) == 1
@@ -475,13 +661,22 @@ def main():
         # Infinity Cache: `achieved` / `frac` are what it really moves over the HBM-side fabric (PMC counters), `algorithmic_*` what its
         # lanes consume, held against the cache hierarchy's bandwidth. Neither bounds it: latency x divergence and VALU issue do
         # (profiles/r02_notes.md).
+        # the contract's fields, by the contract's recipe: ALGORITHMIC bytes of the dominant kernel per launch / its exclusive
+        # launch duration, against the HBM peak. The tree is cache resident (L2 + 256 MiB Infinity Cache), so this figure can exceed what
+        # HBM could deliver -- `traffic` (counters) says how little of it reaches HBM; it is a statement about work per second, not a bound.
         "bound": "hbm", "kernel": k_ext["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
-        "achieved": k_ext["hbm_gbs"] if hbm_known else None, "frac": k_ext["hbm_frac"] if hbm_known else None,
+        "achieved": k_ext["algorithmic_gbs"], "frac": round(k_ext["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
         "traffic": k_ext["hbm_bytes_per_launch"],
-        "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc.sh) of this workload, bytes per launch "
-                           "averaged over the stand-alone closest-hit launches of a frame; gfx950 correction 2 x FETCH_SIZE") if hbm_known else None,
-        # what the measurements say binds the frame (neither of the contract's two): the whole pipeline's VALU instruction issue, see "valu"
+        "traffic_source": ("profiles/pmc_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_workloads.sh) of this workload, bytes per launch "
+                           "averaged over the stand-alone closest-hit launches of a frame; gfx950 correction 2 x FETCH_SIZE" % wkey) if hbm_known else None,
+        "hbm_counter": {"gbs": k_ext["hbm_gbs"], "frac_of_hbm_peak": k_ext["hbm_frac"],
+                        "traffic_over_algorithmic": round(k_ext["hbm_bytes_per_launch"] / max(k_ext["algorithmic_bytes_per_launch"], 1), 4) if hbm_known else None,
+                        "what": "bytes that really cross the HBM-side fabric (counters) / exclusive launch time / 8 TB/s: HBM is nearly idle, the kernel does not wait for it"},
+        # what the measurements say binds the frame (neither of the contract's two): VALU instruction issue of the whole pipeline against the
+        # MEASURED issue ceiling of the traversal's instruction mix, see "valu"; one kernel alone additionally waits on memory LATENCY
+        # (wait_any_frac of its wave-cycles), which the frames in flight hide
         "binding": "valu_issue", "binding_frac": (valu_frame(pmc, ms_per_step, valu_peak, launches_extend) or {}).get("pipelined_frac") if pmc else None,
+        "workload_key": wkey,
         "hbm_frac": k_ext["hbm_frac"], "algorithmic_frac": k_ext["algorithmic_frac"],
         "algorithmic_bytes_per_launch": k_ext["algorithmic_bytes_per_launch"], "algorithmic_gbs": k_ext["algorithmic_gbs"],
         "algorithmic_ceiling": {"gbs": L2_PEAK_GBS, "what": "aggregate L2 bandwidth, MI355X_MICROARCH.md 'L2 (per XCD)': the tree is cache resident, so the bytes the "
@@ -490,8 +685,12 @@ def main():
         "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region, on a handle with one frame context (no other frame on the GPU, every launch at full size); "
                   "sum of all stages = stage_ms_per_step.gpu_total" % n_serial,
         "valu": {"binding_unit": "VALU issue", "peak_ginst_s": round(valu_peak, 1),
-                 "peak_what": "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.1f GHz (max clock, MI355X_MICROARCH.md; this box reports %d MHz)"
-                              % (props.multi_processor_count, clock_ghz, int(getattr(props, "clock_rate", 0) / 1000)),
+                 "peak_what": ("MEASURED: wave64 instructions / s of the BVH4 node step's instruction mix (24 v_cvt_f32_ubyte, 12 v_pk_fma_f32, 18 min / max, 14 v_cndmask, "
+                               "12 integer per 80) at 8 waves per SIMD, tools/microbench/valu_issue.hip; plain v_fma / v_mul / v_add_u32 reach %.0f G/s (1 per 2 clocks per SIMD), "
+                               "v_pk_fma_f32 / v_cvt_f32_ubyte / v_min3 / v_max %.0f G/s" % (vp["full_rate_ginst_s"], vp["half_rate_ginst_s"])) if vp else
+                              "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.1f GHz (profiles/r03a_valu_issue.json absent)" % (props.multi_processor_count, MAX_CLOCK_GHZ),
+                 "peak_source": vp["source"] if vp else None,
+                 "wait_any_frac": k_ext.get("wait_any_frac"), "wait_inst_any_frac": k_ext.get("wait_inst_any_frac"),
                  "frac": k_ext["valu_frac"], "ginst_s": k_ext["valu_ginst_s"], "insts_per_launch": k_ext["valu_insts_per_launch"],
                  "frame": valu_frame(pmc, ms_per_step, valu_peak, launches_extend) if pmc else None,
                  "source": "profiles/pmc_traffic.json: rocprofv3 --pmc SQ_INSTS_VALU pass of this workload (tools/pmc.sh insts)" if pmc else None},
@@ -506,6 +705,7 @@ def main():
                       "extend_launch_ms_overlapped": round(ext_ms * batch_frames / K / n_launch, 5),
                       "note": "launches of neighbouring frames share the GPU in the timed region: their durations overlap and are NOT exclusive (their sum may "
                               "exceed ms_per_step); they are reported for the rocprofv3 cross-check only (profiles/, same command)"},
+        "latency": latency,
         "counts_per_step": cnt,
         "tail": {"from_bounce": launches_extend, "max_path_depth": max_depth,
                  "note": "bounces >= from_bounce run in one rp_k_tail launch per frame; the kernel figures cover the stand-alone launches of bounces < from_bounce",
@@ -533,12 +733,16 @@ def main():
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
                    "frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
-                   "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2)},
+                   "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2),
+                   "bvh": {"built_on": "device (csrc/ploc.h)" if bvh_on_device else "host (csrc/bvh_build.cpp)", "acceleration_structure_step_ms": round(bvh_step_ms, 1),
+                           "device_ms": round(bvh_device_ms, 2)}},
         "roofline": roofline,
     }
     if world > 1:
         out["gather"] = {"mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h)",
-                                  "torch": "tile copy + torch.distributed.gather + index_select"}[gather_mode],
+                                  "torch": "tile copy + torch.distributed.gather (nccl group) + index_select",
+                                  "host": "tile copy + torch.distributed.gather (gloo, tiles staged through the host) + index_select"}[gather_mode],
+                         "probe": probe,
                          "gather_ms": round(gather_gpu_ms, 4) if gather_gpu_ms is not None else None,
                          "gather_ms_note": "mean GPU time of one gather on rank 0's communication stream (receive of N-1 tiles + assembly); asynchronous: it runs "
                                            "beside the frames in flight, inside the timed region",

@@ -320,7 +320,7 @@ void collapse_bvh4(const BuiltTree &t, Wide4Tree &out) {
             ++pos;
         }
     };
-    static const bool even_rule = getenv("RPTR_COLLAPSE") && !strcmp(getenv("RPTR_COLLAPSE"), "even"); // experiment: the device's rule
+    const bool even_rule = getenv("RPTR_COLLAPSE") && !strcmp(getenv("RPTR_COLLAPSE"), "even"); // the device's rule (lbvh.h rp_k_lbvh_emit)
     std::vector<int32_t> queue{0}; // binary node behind every wide node, breadth first
     for (size_t qi = 0; qi < queue.size(); ++qi) {
         std::vector<Slot> slots;
@@ -527,6 +527,7 @@ void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t ma
     }
     const uint32_t root = cur[0];
     // leaf collapse by SAH: cost of a subtree = min(triangles as one leaf, 1 + area-weighted cost of the children)
+    const int force_leaf = getenv("RPTR_PLOC_LEAF") ? atoi(getenv("RPTR_PLOC_LEAF")) : 0; // the device's rule instead: a range of <= k triangles is a leaf
     std::vector<float> cost(nodes.size());
     std::vector<uint8_t> is_leaf(nodes.size(), 0);
     for (size_t i = 0; i < nodes.size(); ++i) { // children are created before their parents: ascending order is bottom-up
@@ -539,7 +540,6 @@ void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t ma
         const float a = p.box.half_area();
         const float split = 1.0f + (a > 0 ? (nodes[p.left].box.half_area() * cost[p.left] + nodes[p.right].box.half_area() * cost[p.right]) / a
                                           : cost[p.left] + cost[p.right]);
-        static const int force_leaf = getenv("RPTR_PLOC_LEAF") ? atoi(getenv("RPTR_PLOC_LEAF")) : 0; // experiment: the device rule (range <= k)
         if (force_leaf > 0 ? p.count <= (uint32_t)force_leaf : (p.count <= max_leaf && (float)p.count <= split)) {
             cost[i] = (float)p.count;
             is_leaf[i] = 1;

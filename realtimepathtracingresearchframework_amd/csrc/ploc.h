@@ -17,7 +17,8 @@
 //      runs to the root) -- is a binned-SAH tree over the remaining <= 65 536 cluster boxes, built by the host builder in
 //      milliseconds and stitched on,
 //   5. depth-first positions of all triangles (every subtree a contiguous range: what the leaf encoding needs), second gather,
-//   6. the 4-wide collapse, child references, depth levels and the refit + encoding of lbvh.h steps 6-8, unchanged.
+//   6. the 4-wide collapse by the host builder's rule (largest child first), breadth first: one launch pair per depth level, node
+//      indices from exclusive scans; then boxes + encoding level by level, deepest first, with the refit code of every other tree.
 // bvh_build.cpp: build_bvh2_ploc is the same algorithm stated on the host (same keys, same float operations, same tie rules): both
 // give the same tree, which is how the device path is tested (tests/test_gpu_device_build.py) and how its quality was measured before
 // it was written (profiles/r03_notes.md: forest 27.2 node visits per closest-hit ray against 26.0 for the host SAH tree and 35.8 for
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void rp_k_ploc_flags(uint32_t m, const uint32_
 // totals[0] = clusters after this iteration, totals[1] = nodes made so far (in / out)
 __global__ __launch_bounds__(256) void rp_k_ploc_apply(uint32_t m, uint32_t n, const uint32_t *nn, const unsigned long long *packed, const unsigned long long *scan,
                                                        const uint32_t *cid_in, const float *cbox_in, uint32_t *cid_out, float *cbox_out, int *left, int *right,
-                                                       int *parent, uint32_t *count, const uint32_t *totals_in, uint32_t *totals_out) {
+                                                       int *parent, uint32_t *count, float *area, const uint32_t *totals_in, uint32_t *totals_out) {
     const uint32_t made = totals_in[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const unsigned long long p = packed[i], s = scan[i];
@@ -168,6 +169,8 @@ __global__ __launch_bounds__(256) void rp_k_ploc_apply(uint32_t m, uint32_t n, c
             parent[b_id] = (int)id;
             parent[id] = -1;
             count[id] = count[a_id] + count[b_id];
+            const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            area[id - n] = (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f; // (what the collapse weighs slots by)
         }
         cid_out[slot] = id;
         for (int a = 0; a < 6; ++a) cbox_out[6ull * slot + a] = b[a];
@@ -178,12 +181,13 @@ __global__ __launch_bounds__(256) void rp_k_ploc_gather_counts(uint32_t m, const
 }
 // 4. the stitched-on top: nodes first_id.. (left, right, count given per node), parents of everything they refer to
 __global__ __launch_bounds__(256) void rp_k_ploc_stitch(uint32_t k, uint32_t n, uint32_t first_id, const int *top_left, const int *top_right, const uint32_t *top_count,
-                                                        int *left, int *right, int *parent, uint32_t *count) {
+                                                        const float *top_area, int *left, int *right, int *parent, uint32_t *count, float *area) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < k; i += gridDim.x * blockDim.x) {
         const uint32_t id = first_id + i;
         left[id - n] = top_left[i];
         right[id - n] = top_right[i];
         count[id] = top_count[i];
+        area[id - n] = top_area[i];
         parent[top_left[i]] = (int)id;
         parent[top_right[i]] = (int)id;
         if (i == k - 1) parent[id] = -1; // the root is made last
@@ -198,20 +202,88 @@ RP_DEV uint32_t rp_ploc_first(uint32_t id, uint32_t n, const int *left, const in
     }
     return off;
 }
-// the binary tree in the form lbvh.h steps 6-8 take: inner node idx = 2n - 2 - id (the root, made last, is 0), leaves as ~position
-__global__ __launch_bounds__(256) void rp_k_ploc_finalize(uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count, int *o_left, int *o_right,
-                                                          int *o_parent, int *o_first, int *o_last) {
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k + 1 < n; k += gridDim.x * blockDim.x) {
-        const uint32_t id = n + k, idx = 2u * n - 2u - id;
-        const uint32_t first = rp_ploc_first(id, n, left, right, parent, count);
-        const int l = left[k], r = right[k];
-        const uint32_t cl = count[l];
-        o_left[idx] = (uint32_t)l < n ? ~(int)first : (int)(2u * n - 2u - (uint32_t)l);
-        o_right[idx] = (uint32_t)r < n ? ~(int)(first + cl) : (int)(2u * n - 2u - (uint32_t)r);
-        o_parent[idx] = parent[id] < 0 ? -1 : (int)(2u * n - 2u - (uint32_t)parent[id]);
-        o_first[idx] = (int)first;
-        o_last[idx] = (int)(first + count[id] - 1u);
+// depth-first position of the first triangle below every inner node (index id - n)
+__global__ __launch_bounds__(256) void rp_k_ploc_firsts(uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count, uint32_t *nfirst) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k + 1 < n; k += gridDim.x * blockDim.x) nfirst[k] = rp_ploc_first(n + k, n, left, right, parent, count);
+}
+
+// ---- 6. the 4-wide collapse, breadth first (the host builder's rule, bvh_build.cpp collapse_bvh4: a node takes the two children of its
+// binary node and then, until it has four, replaces the inner child of the largest surface area by that child's two children -- in
+// place, so that slots (0,1) and (2,3) stay pairs of siblings wherever the collapse was balanced). A subtree of <= RP_LBVH_LEAF_TRIS
+// triangles is a leaf. One launch pair per 4-wide depth level: levels are what the refit needs anyway, and a node's index -- its level's
+// base + its position in the level's queue, given by an exclusive scan -- does not depend on scheduling.
+RP_DEV bool rp_ploc_expandable(int id, uint32_t n, const uint32_t *count) { return (uint32_t)id >= n && count[id] > (uint32_t)RP_LBVH_LEAF_TRIS; }
+RP_DEV int rp_ploc_expand(int b, uint32_t n, const int *left, const int *right, const uint32_t *count, const float *area, int slots[4]) {
+    int ns = 2;
+    slots[0] = left[(uint32_t)b - n];
+    slots[1] = right[(uint32_t)b - n];
+    while (ns < 4) {
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < ns; ++k)
+            if (rp_ploc_expandable(slots[k], n, count)) {
+                const float a = area[(uint32_t)slots[k] - n];
+                if (a > best) {
+                    best = a;
+                    pick = k;
+                }
+            }
+        if (pick < 0) break;
+        const int x = slots[pick];
+        for (int k = ns; k > pick + 1; --k) slots[k] = slots[k - 1]; // make room behind the picked slot
+        slots[pick] = left[(uint32_t)x - n];
+        slots[pick + 1] = right[(uint32_t)x - n];
+        ++ns;
     }
+    return ns;
+}
+// pass 1 of a level: how many inner children each of its nodes has
+__global__ __launch_bounds__(256) void rp_k_ploc_collapse_count(const int *queue, uint32_t size, uint32_t n, const int *left, const int *right, const uint32_t *count,
+                                                                const float *area, uint32_t *inner) {
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < size; w += gridDim.x * blockDim.x) {
+        int slots[4];
+        const int ns = rp_ploc_expand(queue[w], n, left, right, count, area, slots);
+        uint32_t c = 0;
+        for (int k = 0; k < ns; ++k) c += rp_ploc_expandable(slots[k], n, count) ? 1u : 0u;
+        inner[w] = c;
+    }
+}
+// pass 2: child references (inner: next level's base + scan position; leaf: its triangle range in depth-first order) and the next queue.
+// The root of a tree whose triangles all fit one leaf is a node with that one leaf (queue[0] = the root, flagged by `tiny`).
+__global__ __launch_bounds__(256) void rp_k_ploc_collapse_emit(const int *queue, uint32_t size, uint32_t n, const int *left, const int *right, const int *parent,
+                                                               const uint32_t *count, const float *area, const uint32_t *nfirst, const uint32_t *inner_scan,
+                                                               uint32_t level_base, uint32_t next_base, RptrBvh4Node *nodes, int *next_queue, uint32_t *next_size) {
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < size; w += gridDim.x * blockDim.x) {
+        int slots[4];
+        const int b = queue[w];
+        int32_t child[4] = {RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY, RPTR_BVH4_EMPTY};
+        uint32_t at = inner_scan[w];
+        if (!rp_ploc_expandable(b, n, count)) // (only the root of a tiny tree gets here)
+            child[0] = RPTR_BVH_LEAF(0, (int)count[b]);
+        else {
+            const int ns = rp_ploc_expand(b, n, left, right, count, area, slots);
+            for (int k = 0; k < ns; ++k) {
+                const int x = slots[k];
+                if (rp_ploc_expandable(x, n, count)) {
+                    next_queue[at] = x;
+                    child[k] = (int32_t)(next_base + at);
+                    ++at;
+                } else {
+                    const uint32_t first = (uint32_t)x < n ? rp_ploc_first((uint32_t)x, n, left, right, parent, count) : nfirst[(uint32_t)x - n];
+                    child[k] = RPTR_BVH_LEAF((int)first, (int)count[x]);
+                }
+            }
+        }
+        if (w == size - 1) *next_size = at;
+        RptrBvh4Node nd;
+        __builtin_memset(&nd, 0, sizeof(nd));
+        for (int k = 0; k < 4; ++k) nd.child[k] = child[k];
+        nodes[level_base + w] = nd;
+    }
+}
+// boxes + encoding of one level (children of deeper levels are done): the refit of every other tree (kernels_misc.h rp_refit_node)
+__global__ __launch_bounds__(256) void rp_k_ploc_refit_range(RptrBvh4Node *nodes, float *node_box, const float *tri_box, uint32_t begin, uint32_t end) {
+    for (uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x; i < end; i += gridDim.x * blockDim.x) rp_refit_node(nodes, node_box, tri_box, nullptr, i);
 }
 __global__ __launch_bounds__(256) void rp_k_ploc_scatter(uint32_t n, const int *left, const int *right, const int *parent, const uint32_t *count, const RptrBvhTri *tri_in,
                                                          const float *box_in, RptrBvhTri *tri_out, float *box_out) {

@@ -547,6 +547,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
     DB_ALLOC(right, int, n);
     DB_ALLOC(parent, int, 2 * (size_t)n);
     DB_ALLOC(count, uint32_t, 2 * (size_t)n);
+    DB_ALLOC(area, float, n);
     DB_ALLOC(totals, uint32_t, 4);
     float *cbox_a = box_a, *cbox_b = nullptr; // (box_a is free again after the gather; the second cluster box list is its own)
     DB_ALLOC(cbox_second, float, 6 * (size_t)n);
@@ -563,7 +564,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
         hipLaunchKernelGGL(rp_k_ploc_flags, dim3(grid_for(h, m)), dim3(256), 0, st, m, nn, packed);
         bytes = cub_bytes;
         DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, packed, pscan, (int)m, st));
-        hipLaunchKernelGGL(rp_k_ploc_apply, dim3(grid_for(h, m)), dim3(256), 0, st, m, n, nn, packed, pscan, cid_a, cbox_a, cid_b, cbox_b, left, right, parent, count, totals,
+        hipLaunchKernelGGL(rp_k_ploc_apply, dim3(grid_for(h, m)), dim3(256), 0, st, m, n, nn, packed, pscan, cid_a, cbox_a, cid_b, cbox_b, left, right, parent, count, area, totals,
                            totals + 2);
         DB_TRY(hipMemcpyAsync(totals, totals + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         DB_TRY(hipMemcpyAsync(host_totals, totals, sizeof(host_totals), hipMemcpyDeviceToHost, st));
@@ -600,6 +601,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
         }
         std::vector<int> tl(T), tr(T);
         std::vector<uint32_t> tc(T);
+        std::vector<float> ta(T);
         std::vector<uint32_t> id_of(T), cnt_of(T);
         const uint32_t first_id = host_totals[1];
         for (int64_t i = (int64_t)T - 1; i >= 0; --i) { // children lie behind their parents: backwards = bottom-up, the root is made last
@@ -620,16 +622,27 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
             tl[k] = (int)c_id[0];
             tr[k] = (int)c_id[1];
             tc[k] = c_cnt[0] + c_cnt[1];
+            {   // surface (half) area of the node's box = union of its children's boxes, as the clustering computes it for its own nodes
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::fmin(t.lo0[a], t.lo1[a]);
+                    hi[a] = std::fmax(t.hi0[a], t.hi1[a]);
+                }
+                const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                ta[k] = (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f;
+            }
             id_of[(size_t)i] = first_id + (uint32_t)k;
             cnt_of[(size_t)i] = tc[k];
         }
         DB_ALLOC(d_tl, int, T);
         DB_ALLOC(d_tr, int, T);
         DB_ALLOC(d_tc, uint32_t, T);
+        DB_ALLOC(d_ta, float, T);
+        DB_TRY(hipMemcpyAsync(d_ta, ta.data(), T * 4, hipMemcpyHostToDevice, st));
         DB_TRY(hipMemcpyAsync(d_tl, tl.data(), T * 4, hipMemcpyHostToDevice, st));
         DB_TRY(hipMemcpyAsync(d_tr, tr.data(), T * 4, hipMemcpyHostToDevice, st));
         DB_TRY(hipMemcpyAsync(d_tc, tc.data(), T * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(rp_k_ploc_stitch, dim3(grid_for(h, T)), dim3(256), 0, st, (uint32_t)T, n, first_id, d_tl, d_tr, d_tc, left, right, parent, count);
+        hipLaunchKernelGGL(rp_k_ploc_stitch, dim3(grid_for(h, T)), dim3(256), 0, st, (uint32_t)T, n, first_id, d_tl, d_tr, d_tc, d_ta, left, right, parent, count, area);
         DB_TRY(hipStreamSynchronize(st)); // (the host arrays are read by the copies above)
         if (first_id + (uint32_t)T != 2u * n - 1u) {
             fail(h, RPTR_E_HIP, "device BVH build: %u + %zu nodes for %u triangles", first_id, T, n);
@@ -640,43 +653,47 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
         return false;
     }
     out.ms_top = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_top0).count();
-    // 5. depth-first order, the binary tree in lbvh.h's form
-    DB_ALLOC(o_left, int, n);
-    DB_ALLOC(o_right, int, n);
-    DB_ALLOC(o_parent, int, n);
-    DB_ALLOC(o_first, int, n);
-    DB_ALLOC(o_last, int, n);
-    hipLaunchKernelGGL(rp_k_ploc_finalize, dim3(g), dim3(256), 0, st, n, left, right, parent, count, o_left, o_right, o_parent, o_first, o_last);
+    // 5. depth-first order of the triangles (every subtree a contiguous range)
+    const uint32_t root_id = 2u * n - 2u;
+    DB_ALLOC(nfirst, uint32_t, n);
+    hipLaunchKernelGGL(rp_k_ploc_firsts, dim3(g), dim3(256), 0, st, n, left, right, parent, count, nfirst);
     float *tri_box = cbox_b; // (the cluster box lists are dead after the stitch: one of them takes the triangle bounds in their final order)
     hipLaunchKernelGGL(rp_k_ploc_scatter, dim3(g), dim3(256), 0, st, n, left, right, parent, count, tris_b, box_b, tris_a, tri_box);
-    // 6. collapse, child references, levels, refit + encoding (lbvh.h steps 6-8)
-    DB_ALLOC(depth4, uint32_t, n);
-    DB_ALLOC(level_hist, uint32_t, RP_REFIT_LEVELS);
-    DB_ALLOC(level_cursor, uint32_t, RP_REFIT_LEVELS);
-    DB_ALLOC(levels, uint2, RP_REFIT_LEVELS);
-    DB_ALLOC(d_count, int, 1);
+    // 6. 4-wide collapse, breadth first: a launch pair + one scan per depth level; then boxes + encoding, deepest level first
     DB_ALLOC(nodes, RptrBvh4Node, n);
     DB_ALLOC(node_box, float, 6 * (size_t)n);
-    DB_ALLOC(list, uint32_t, n);
-    hipLaunchKernelGGL(rp_k_lbvh_flags, dim3(g), dim3(256), 0, st, (int)n, o_parent, o_first, o_last, flag, depth4);
-    bytes = cub_bytes;
-    DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, flag, slot, (int)n - 1, st));
-    DB_TRY(hipMemsetAsync(level_hist, 0, RP_REFIT_LEVELS * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(rp_k_lbvh_emit, dim3(g), dim3(256), 0, st, (int)n, o_left, o_right, o_first, o_last, flag, slot, depth4, 0, 0, nodes, level_hist, d_count);
-    hipLaunchKernelGGL(rp_k_lbvh_level_scan, dim3(1), dim3(64), 0, st, level_hist, 0u, levels, level_cursor);
-    hipLaunchKernelGGL(rp_k_lbvh_level_scatter, dim3(g), dim3(256), 0, st, nodes, 0, d_count, level_cursor, list);
-    uint2 h_levels[RP_REFIT_LEVELS];
-    int h_count = 0;
-    DB_TRY(hipMemcpyAsync(h_levels, levels, sizeof(h_levels), hipMemcpyDeviceToHost, st));
-    DB_TRY(hipMemcpyAsync(&h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st));
-    DB_TRY(hipStreamSynchronize(st));
-    if (h_levels[0].y > h_levels[0].x || h_count < 1 || (uint32_t)h_count > n) { // slot 0 = the clamped deepest level: a tree deeper than the level table
-        fail(h, RPTR_E_UNSUPPORTED, "device BVH build: the tree has %d nodes / more than %d levels", h_count, RP_REFIT_LEVELS - 1);
-        return false;
+    DB_ALLOC(queue_a, int, n);
+    DB_ALLOC(queue_b, int, n);
+    DB_ALLOC(d_next, uint32_t, 1);
+    std::vector<uint32_t> level_base;
+    {
+        const int h_root = (int)root_id;
+        DB_TRY(hipMemcpyAsync(queue_a, &h_root, sizeof(int), hipMemcpyHostToDevice, st));
+        uint32_t size = 1, base = 0;
+        while (size > 0) {
+            if (level_base.size() >= 2 * RP_REFIT_LEVELS || (size_t)base + size > (size_t)n) {
+                fail(h, RPTR_E_UNSUPPORTED, "device BVH build: a tree of more than %d levels / %u nodes", 2 * RP_REFIT_LEVELS, base + size);
+                return false;
+            }
+            level_base.push_back(base);
+            const int gl = grid_for(h, size);
+            hipLaunchKernelGGL(rp_k_ploc_collapse_count, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, count, area, flag);
+            bytes = cub_bytes;
+            DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, flag, slot, (int)size, st));
+            hipLaunchKernelGGL(rp_k_ploc_collapse_emit, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, parent, count, area, nfirst, slot, base, base + size, nodes,
+                               queue_b, d_next);
+            uint32_t next = 0;
+            DB_TRY(hipMemcpyAsync(&next, d_next, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            DB_TRY(hipStreamSynchronize(st));
+            base += size;
+            size = next;
+            std::swap(queue_a, queue_b);
+        }
+        level_base.push_back(base); // = the number of nodes
     }
-    for (int k = 0; k < RP_REFIT_LEVELS; ++k)
-        if (h_levels[k].y > h_levels[k].x)
-            hipLaunchKernelGGL(rp_k_refit_level, dim3(grid_for(h, h_levels[k].y - h_levels[k].x)), dim3(256), 0, st, nodes, node_box, tri_box, list, levels + k);
+    const int h_count = (int)level_base.back();
+    for (size_t l = level_base.size() - 1; l-- > 0;)
+        hipLaunchKernelGGL(rp_k_ploc_refit_range, dim3(grid_for(h, level_base[l + 1] - level_base[l])), dim3(256), 0, st, nodes, node_box, tri_box, level_base[l], level_base[l + 1]);
     (void)hipEventRecord(e1, st);
     // back to the host, in the host builder's form
     out.nodes.resize((size_t)h_count);
@@ -1225,11 +1242,16 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         }
         h->own_stream = true;
     }
-    if (const char *s = getenv("RPTR_SIDE_CONNECT")) h->side_connect = atoi(s) != 0 ? 1 : 0;
     {
         int fif = info ? info->frames_in_flight : 1;
         if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) fif = atoi(s);
         fif = std::max(1, std::min(fif, 16));
+        // connect(b) -- the shadow rays of bounce b -- on a side stream beside extend(b + 1): both only depend on shade(b). With ONE frame
+        // context nothing else fills the ramp-down of a launch: a single frame gets 2-4 % shorter (C2 2.07 -> 2.04 ms, C3 6.52 -> 6.31, a 1/8
+        // frame 0.83 -> 0.80, profiles/r03_notes.md). With frames in flight the extra stream only gets in the way of the other frames' launches
+        // (+5 % pipelined): off there. RPTR_SIDE_CONNECT=0|1 overrides.
+        h->side_connect = fif == 1 ? 1 : 0;
+        if (const char *s = getenv("RPTR_SIDE_CONNECT")) h->side_connect = atoi(s) != 0 ? 1 : 0;
         if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
         h->ctx.resize((size_t)fif);
         if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;

@@ -25,9 +25,10 @@ class TileGather:
     to the largest tile: one `gather` per frame (RCCL has no native gather; torch
     lowers it to grouped send/recv, each peer using its own xGMI link to rank 0)."""
 
-    def __init__(self, width, height, stripe_rows, rank, world, device):
+    def __init__(self, width, height, stripe_rows, rank, world, device, group=None):
         import torch
         self.torch = torch
+        self.group = group   # the process group the tiles travel through (None: the default group)
         self.width, self.height, self.rank, self.world = width, height, rank, world
         self.layout = [tile_rows(height, stripe_rows, k, world) for k in range(world)]
         self.tile_rows = [sum(c for _, c in rows) for rows in self.layout]
@@ -64,7 +65,7 @@ class TileGather:
             self.recv_all[0].copy_(self.tile)
             return self.assemble()
         import torch.distributed as dist
-        dist.gather(self.tile, self.recv, dst=0)
+        dist.gather(self.tile, self.recv, dst=0, group=self.group)
         return self.assemble() if self.rank == 0 else None
 
 

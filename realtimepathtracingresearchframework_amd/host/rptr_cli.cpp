@@ -91,10 +91,28 @@ static std::string data_dir() {
 
 // a scene file: the reference's own .vks (with its _textures directory), or the flat dump of scenes.py
 static rptr::vks::LoadParams g_load; // --remove-first-lods, --instance-pruning, --small-deformation, --ignore-animation, --ignore-textures, --load-specularity (SceneLoaderParams::PerFile)
-static rptr::SceneDump load_scene(const std::string &path) {
+static rptr::SceneDump load_one_scene(const std::string &path) {
     const size_t n = path.size();
     if (n >= 4 && path.compare(n - 4, 4, ".vks") == 0) return rptr::vks::read_scene(path, data_dir(), g_load);
     return rptr::SceneDump::load(path);
+}
+// `<scene_file> [<scene_file>...]` (Scene::Scene(fnames, ...), librender/scene.cpp:50-69): every further file is appended to the first --
+// meshes, parameterized meshes, instances, materials, textures, indices shifted; camera and parameters are the first file's -- then
+// `--deduplicate-scene` merges equal meshes / materials / textures and drops what nothing refers to (Scene::deduplicate + garbage_collect),
+// and the emitters are collected and binned again over the whole scene (librender/lights.cpp through host/lights.hpp).
+static std::vector<std::string> g_more_scenes;
+static bool g_deduplicate = false;
+static rptr::SceneDump load_scene(const std::string &path) {
+    rptr::SceneDump s = load_one_scene(path);
+    for (const std::string &more : g_more_scenes) s.append(load_one_scene(more));
+    if (g_deduplicate) {
+        const rptr::SceneDump::DedupStats st = s.deduplicate();
+        if (st.meshes) std::printf("Duplicate geometry detected! Removed %zu meshes\n", st.meshes);
+        if (st.materials) std::printf("Removed %zu unused materials\n", st.materials);
+        if (st.textures) std::printf("Removed %zu unused textures\n", st.textures);
+    }
+    if (!g_more_scenes.empty() || g_deduplicate) rptr::lights::prepare_lights(s);
+    return s;
 }
 
 int main(int argc, char **argv) {
@@ -206,7 +224,7 @@ int main(int argc, char **argv) {
         else if (a == "--data-capture-motion") capture_motion = true;
         else if (a == "--vulkan-device") { need(1); devices.assign(1, std::atoi(argv[++i])); } // ProgramArgs::device_override: here the HIP ordinal
         else if (a == "--resource-dir") { need(1); ++i; }      // (shader / resource search path of the reference's backends: nothing to find here)
-        else if (a == "--deduplicate-scene") {}                 // (Scene::deduplicate: a load-time memory optimisation, same image)
+        else if (a == "--deduplicate-scene") g_deduplicate = true; // Scene::deduplicate + garbage_collect: less memory, same image
         else if (a == "-h" || a == "--help") want_help = true;
         else if (a == "--backend") { // cmdline.cpp:363-376: the last one wins; this binary hosts one
             need(1);
@@ -223,7 +241,10 @@ int main(int argc, char **argv) {
         else if (a == "--force-bvh-rebuild") force_bvh_rebuild = 1;
         else if (a == "--rebuild-triangle-budget") { need(1); rebuild_triangle_budget = std::atoi(argv[++i]); }
         else if (a == "--disable-ui") {}
-        else if (a[0] != '-') scene_path = a;
+        else if (a[0] != '-') {
+            if (scene_path.empty()) scene_path = a;
+            else g_more_scenes.push_back(a);
+        }
         else {
             // cmdline.cpp:226-259: the single-dash arguments of old versions get a pointer to their successors
             static const char *old_backends[] = {"-vulkan", "-embree", "-dxr", "-optix", "-metal"};

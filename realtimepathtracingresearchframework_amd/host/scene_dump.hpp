@@ -12,6 +12,7 @@
 #pragma once
 #include "../../include/rptr_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -54,6 +55,230 @@ struct SceneDump {
         d.textures = textures.empty() ? nullptr : textures.data();
         d.num_textures = (uint32_t)textures.size();
         return d;
+    }
+
+    // the descriptors point into the owned storage (call after anything that moved or re-indexed it)
+    void fix_pointers() {
+        for (size_t i = 0; i < geometries.size(); ++i) {
+            geometries[i].qpos = qpos[i].data();
+            geometries[i].qnrm_uv = qnu[i].empty() ? nullptr : qnu[i].data();
+        }
+        for (size_t i = 0; i < pmeshes.size(); ++i) {
+            pmeshes[i].material_offsets = offsets[i].data();
+            pmeshes[i].tri_material_ids = tri_ids[i].empty() ? nullptr : tri_ids[i].data();
+        }
+        for (size_t i = 0; i < textures.size(); ++i) textures[i].rgba8 = texels[i].data();
+    }
+
+    // A parameter of a material is a literal or a texture handle (rendering/bsdfs/texture_channel_mask.h: sign bit, channel in bits
+    // 29..30, texture index in bits 0..28); normal_map is a plain index (< 0: none).
+    template <class F>
+    static void for_each_texture_ref(RptrBaseMaterial &m, F &&f) {
+        float *fields[] = {&m.base_color[0], &m.roughness, &m.specular, &m.metallic, &m.sheen, &m.sheen_tint, &m.clearcoat, &m.clearcoat_gloss, &m.ior,
+                           &m.specular_transmission, &m.anisotropy, &m.specular_tint, &m.transmission_color[0], &m.emission_intensity};
+        for (float *p : fields) {
+            uint32_t bits;
+            std::memcpy(&bits, p, 4);
+            if (bits & 0x80000000u) {
+                uint32_t id = bits & 0x1FFFFFFFu;
+                f(id);
+                bits = (bits & 0xE0000000u) | (id & 0x1FFFFFFFu);
+                std::memcpy(p, &bits, 4);
+            }
+        }
+        if (m.normal_map >= 0) {
+            uint32_t id = (uint32_t)m.normal_map;
+            f(id);
+            m.normal_map = (int32_t)id;
+        }
+    }
+
+    // Scene::Scene(fnames, ...) (librender/scene.cpp:50-69): every further scene file appends its meshes, parameterized meshes,
+    // instances, materials and textures behind what is there, indices shifted. Camera and parameters stay those of the first file;
+    // the lights are collected again by the caller (they are binned over the whole scene).
+    void append(const SceneDump &o) {
+        const uint32_t g0 = (uint32_t)geometries.size(), m0 = (uint32_t)meshes.size(), p0 = (uint32_t)pmeshes.size(), mat0 = (uint32_t)materials.size(),
+                       t0 = (uint32_t)textures.size();
+        qpos.insert(qpos.end(), o.qpos.begin(), o.qpos.end());
+        qnu.insert(qnu.end(), o.qnu.begin(), o.qnu.end());
+        geometries.insert(geometries.end(), o.geometries.begin(), o.geometries.end());
+        for (RptrMeshDesc m : o.meshes) {
+            m.first_geometry += g0;
+            meshes.push_back(m);
+        }
+        for (size_t i = 0; i < o.pmeshes.size(); ++i) {
+            RptrParameterizedMeshDesc pm = o.pmeshes[i];
+            pm.mesh += m0;
+            std::vector<int32_t> off = o.offsets[i];
+            for (int32_t &v : off) v += (int32_t)mat0;
+            offsets.push_back(std::move(off));
+            tri_ids.push_back(o.tri_ids[i]);
+            pmeshes.push_back(pm);
+        }
+        for (RptrInstanceDesc in : o.instances) {
+            in.parameterized_mesh += p0;
+            instances.push_back(in);
+        }
+        for (RptrBaseMaterial m : o.materials) {
+            for_each_texture_ref(m, [&](uint32_t &id) { id += t0; });
+            materials.push_back(m);
+        }
+        texels.insert(texels.end(), o.texels.begin(), o.texels.end());
+        textures.insert(textures.end(), o.textures.begin(), o.textures.end());
+        fix_pointers();
+    }
+
+    // Scene::deduplicate + garbage_collect (librender/scene.cpp:142-148 and below; `--deduplicate-scene`): meshes with the same content
+    // become one mesh, equal materials one material, equal textures one texture; what nothing refers to any more is dropped. Instances keep
+    // their order and their parameterized meshes (ray-query ids and the order of the emitters do not change): the image is the same.
+    struct DedupStats {
+        size_t meshes = 0, materials = 0, textures = 0;
+    };
+    DedupStats deduplicate() {
+        DedupStats st;
+        // textures by content
+        std::vector<uint32_t> tex_map(textures.size());
+        for (size_t i = 0; i < textures.size(); ++i) {
+            tex_map[i] = (uint32_t)i;
+            for (size_t j = 0; j < i; ++j)
+                if (tex_map[j] == j && textures[j].width == textures[i].width && textures[j].height == textures[i].height && textures[j].srgb == textures[i].srgb &&
+                    textures[j].mip_levels == textures[i].mip_levels && texels[j] == texels[i]) {
+                    tex_map[i] = (uint32_t)j;
+                    break;
+                }
+        }
+        for (RptrBaseMaterial &m : materials) for_each_texture_ref(m, [&](uint32_t &id) { if (id < tex_map.size()) id = tex_map[id]; });
+        // materials by content
+        std::vector<uint32_t> mat_map(materials.size());
+        for (size_t i = 0; i < materials.size(); ++i) {
+            mat_map[i] = (uint32_t)i;
+            for (size_t j = 0; j < i; ++j)
+                if (mat_map[j] == j && std::memcmp(&materials[j], &materials[i], sizeof(RptrBaseMaterial)) == 0) {
+                    mat_map[i] = (uint32_t)j;
+                    break;
+                }
+        }
+        // a parameterized mesh addresses materials as offset + per-triangle id: the offset can only move when the whole range it can reach
+        // maps by the same shift, which is the case for ranges without duplicates; otherwise the per-triangle ids are rewritten
+        for (size_t p = 0; p < pmeshes.size(); ++p) {
+            const RptrMeshDesc &mesh = meshes[pmeshes[p].mesh];
+            size_t at = 0;
+            for (uint32_t j = 0; j < mesh.num_geometries && j < offsets[p].size(); ++j) {
+                const uint32_t nt = geometries[mesh.first_geometry + j].num_tris;
+                const int32_t off = offsets[p][j];
+                if (tri_ids[p].empty()) {
+                    if (off >= 0 && (size_t)off < mat_map.size()) offsets[p][j] = (int32_t)mat_map[(size_t)off];
+                } else {
+                    // new offset: the smallest mapped id of the range; ids become distances to it (they stay bytes: checked)
+                    uint32_t lo = 0xFFFFFFFFu, hi = 0;
+                    for (uint32_t t = 0; t < nt; ++t) {
+                        const uint32_t m = mat_map[(size_t)off + tri_ids[p][at + t]];
+                        lo = std::min(lo, m);
+                        hi = std::max(hi, m);
+                    }
+                    if (nt && hi - lo < 256u) {
+                        for (uint32_t t = 0; t < nt; ++t) tri_ids[p][at + t] = (uint8_t)(mat_map[(size_t)off + tri_ids[p][at + t]] - lo);
+                        offsets[p][j] = (int32_t)lo;
+                    }
+                }
+                at += nt;
+            }
+        }
+        // meshes by content (geometry streams, quantisation, flags)
+        auto same_mesh = [&](const RptrMeshDesc &a, const RptrMeshDesc &b) {
+            if (a.num_geometries != b.num_geometries || a.dynamic != b.dynamic) return false;
+            for (uint32_t j = 0; j < a.num_geometries; ++j) {
+                const size_t ga = a.first_geometry + j, gb = b.first_geometry + j;
+                const RptrGeometryDesc &x = geometries[ga], &y = geometries[gb];
+                if (x.num_tris != y.num_tris || x.has_normals != y.has_normals || x.has_uvs != y.has_uvs || std::memcmp(x.quantized_scaling, y.quantized_scaling, 12) ||
+                    std::memcmp(x.quantized_offset, y.quantized_offset, 12) || qpos[ga] != qpos[gb] || qnu[ga] != qnu[gb])
+                    return false;
+            }
+            return true;
+        };
+        std::vector<uint32_t> mesh_map(meshes.size());
+        for (size_t i = 0; i < meshes.size(); ++i) {
+            mesh_map[i] = (uint32_t)i;
+            for (size_t j = 0; j < i; ++j)
+                if (mesh_map[j] == j && same_mesh(meshes[j], meshes[i])) {
+                    mesh_map[i] = (uint32_t)j;
+                    break;
+                }
+        }
+        for (RptrParameterizedMeshDesc &pm : pmeshes) pm.mesh = mesh_map[pm.mesh];
+        // ---- garbage collection: meshes (with their geometries), materials, textures nothing refers to
+        std::vector<char> mesh_used(meshes.size(), 0), mat_used(materials.size(), 0), tex_used(textures.size(), 0);
+        for (const RptrParameterizedMeshDesc &pm : pmeshes) mesh_used[pm.mesh] = 1;
+        for (size_t p = 0; p < pmeshes.size(); ++p) {
+            const RptrMeshDesc &mesh = meshes[pmeshes[p].mesh];
+            size_t at = 0;
+            for (uint32_t j = 0; j < mesh.num_geometries && j < offsets[p].size(); ++j) {
+                const uint32_t nt = geometries[mesh.first_geometry + j].num_tris;
+                if (tri_ids[p].empty()) {
+                    if ((size_t)offsets[p][j] < mat_used.size()) mat_used[(size_t)offsets[p][j]] = 1;
+                } else
+                    for (uint32_t t = 0; t < nt; ++t) {
+                        const size_t m = (size_t)offsets[p][j] + tri_ids[p][at + t];
+                        if (m < mat_used.size()) mat_used[m] = 1;
+                    }
+                at += nt;
+            }
+        }
+        // (materials are addressed as offset + id: holes inside a used range must survive, so only a used / unused PREFIX structure is
+        // compacted: a material is dropped when it is unused AND every range that spans it is rewritten -- kept simple: unused materials
+        // at the tail are dropped)
+        size_t keep_mats = materials.size();
+        while (keep_mats > 0 && !mat_used[keep_mats - 1]) --keep_mats;
+        st.materials = materials.size() - keep_mats;
+        materials.resize(keep_mats);
+        for (const RptrBaseMaterial &m : materials) {
+            RptrBaseMaterial c = m;
+            for_each_texture_ref(c, [&](uint32_t &id) { if (id < tex_used.size()) tex_used[id] = 1; });
+        }
+        std::vector<uint32_t> tex_new(textures.size(), 0);
+        {
+            std::vector<std::vector<uint8_t>> nt;
+            std::vector<RptrTextureDesc> nd;
+            for (size_t i = 0; i < textures.size(); ++i)
+                if (tex_used[i]) {
+                    tex_new[i] = (uint32_t)nd.size();
+                    nt.push_back(std::move(texels[i]));
+                    nd.push_back(textures[i]);
+                } else
+                    ++st.textures;
+            texels.swap(nt);
+            textures.swap(nd);
+        }
+        for (RptrBaseMaterial &m : materials) for_each_texture_ref(m, [&](uint32_t &id) { if (id < tex_new.size()) id = tex_new[id]; });
+        std::vector<uint32_t> mesh_new(meshes.size(), 0);
+        {
+            std::vector<RptrMeshDesc> nm;
+            std::vector<RptrGeometryDesc> ng;
+            std::vector<std::vector<uint64_t>> np, nn;
+            for (size_t i = 0; i < meshes.size(); ++i) {
+                if (!mesh_used[i]) {
+                    ++st.meshes;
+                    continue;
+                }
+                RptrMeshDesc m = meshes[i];
+                mesh_new[i] = (uint32_t)nm.size();
+                const uint32_t first = (uint32_t)ng.size();
+                for (uint32_t j = 0; j < m.num_geometries; ++j) {
+                    ng.push_back(geometries[m.first_geometry + j]);
+                    np.push_back(std::move(qpos[m.first_geometry + j]));
+                    nn.push_back(std::move(qnu[m.first_geometry + j]));
+                }
+                m.first_geometry = first;
+                nm.push_back(m);
+            }
+            meshes.swap(nm);
+            geometries.swap(ng);
+            qpos.swap(np);
+            qnu.swap(nn);
+        }
+        for (RptrParameterizedMeshDesc &pm : pmeshes) pm.mesh = mesh_new[pm.mesh];
+        fix_pointers();
+        return st;
     }
 
     // the same layout back to a file (rptr_cli --dump-scene: what a scene read from a .vks file looks like to the backend)

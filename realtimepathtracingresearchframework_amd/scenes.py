@@ -209,6 +209,31 @@ class Scene:
                 for px in lv:
                     f.write(px.tobytes())
 
+    def append(self, other: "Scene"):
+        """Scene::Scene(fnames, ...) (librender/scene.cpp:50-69): a further scene file is appended -- meshes, parameterized meshes,
+        instances, materials, textures behind what is there, indices shifted (texture handles inside the materials too); camera and
+        configuration stay this scene's; the emitters are collected and binned again over the whole scene. Twin of host/scene_dump.hpp
+        SceneDump::append."""
+        import copy
+        import ctypes
+        g0, m0, p0, mat0, t0 = len(self.geometries), len(self.meshes), len(self.pmeshes), len(self.materials), len(self.textures)
+        self.geometries += list(other.geometries)
+        self.meshes += [Mesh(m.first_geometry + g0, m.num_geometries, m.dynamic) for m in other.meshes]
+        self.pmeshes += [ParameterizedMesh(pm.mesh + m0, np.asarray(pm.material_offsets, np.int32) + np.int32(mat0), pm.tri_material_ids) for pm in other.pmeshes]
+        self.instances += [Instance(inst.transform, inst.pmesh + p0) for inst in other.instances]
+        for m in other.materials:
+            c = copy.deepcopy(m)
+            words = ctypes.cast(ctypes.pointer(c), ctypes.POINTER(ctypes.c_uint32))
+            for w in (0, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 19):   # float fields that may hold a texture handle (sign bit set)
+                if words[w] & 0x80000000:
+                    words[w] = (words[w] & 0xE0000000) | (((words[w] & 0x1FFFFFFF) + t0) & 0x1FFFFFFF)
+            if c.normal_map >= 0:
+                c.normal_map += t0
+            self.materials.append(c)
+        self.textures += list(other.textures)
+        self.prepare_lights()
+        return self
+
     def num_tris(self):
         return sum(g.num_tris for g in self.geometries)
 

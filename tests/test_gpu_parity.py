@@ -411,6 +411,32 @@ def test_bench_gpus_n_starts_its_own_ranks():
         assert 0.0 <= k["algorithmic_frac"] <= 1.0 and (k["hbm_frac"] is None or 0.0 <= k["hbm_frac"] <= 1.0)
 
 
+def test_bench_n_ranks_dry_run_probes_rccl_and_falls_back_without_hanging():
+    """The exact N > 1 path the driver launches (`bench.py --gpus N`, default --dist-backend nccl), on the one GPU of this box with both
+    ranks on cuda:0: the gloo control plane comes up, every rank's probe child tries torch's nccl group and the library's communicator
+    under a time-out, RCCL refuses two ranks on one device ("Duplicate GPU"), all ranks agree on the fall-back (tiles over gloo, staged
+    through the host), the run completes and the line says what happened. On a real node the same code takes the native path
+    (gather.mode "library: grouped ncclSend/ncclRecv ...")."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--grid", "100x50", "--width", "320",
+           "--height", "180", "--same-device", "--probe-timeout", "120"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    g = d["gather"]
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong"
+    assert g["probe"]["native"] == 0 and g["mode"].startswith("tile copy") and "gloo" in g["mode"] and g["note"] and "probe" in g["note"].lower()
+    assert g["probe"]["seconds"] < 120 and g["gathers"] == 6 and g["bytes_per_step"] > 0
+    assert d["config"]["rays_per_step"] > 320 * 180 * 4          # both ranks' rays are summed
+    assert d["roofline"]["latency"]["1"]["ms_per_frame"] > 0
+
+
 # ---------------------------------------------------------------- fuzz
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_fuzz_soups_trace_and_image(seed):
@@ -851,6 +877,25 @@ def test_reprojection_mode_discard_history():
         assert same and rmse < RMSE_TOL
     assert image_error(second, keep)[0] > 10 * RMSE_TOL
     r.close()
+
+
+def test_shadow_rays_on_the_side_stream_change_no_bit(monkeypatch):
+    """a handle with ONE frame context runs connect(b) on a side stream beside extend(b + 1) (csrc/rptr_hip.hip: side_connect, the default for
+    frames_in_flight = 1): the order of float additions into a path's radiance is kept by the joins, so the image, the ray counts and the
+    counted traversal work equal those of the single-stream schedule bit for bit"""
+    s = scenes.grid(120, 60, with_emitters=True)
+    W, H, spp = 160, 96, 3
+    out = []
+    for side in ("0", "1", None):
+        if side is None:
+            monkeypatch.delenv("RPTR_SIDE_CONNECT", raising=False)
+        else:
+            monkeypatch.setenv("RPTR_SIDE_CONNECT", side)
+        img, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, count=True)
+        out.append((img, int(st.raw.rays_closest), int(st.raw.rays_shadow), int(st.raw.nodes_visited), int(st.raw.tris_tested)))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0].view(np.uint32), other[0].view(np.uint32)) and out[0][1:] == other[1:]
+    assert out[0][2] > 0
 
 
 def test_discard_history_keeps_all_samples_of_a_frame_the_backend_splits(monkeypatch):

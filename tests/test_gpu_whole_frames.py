@@ -134,6 +134,8 @@ def test_c5_whole_frame_animated_4k_2spp_after_the_last_refit():
         r.refit()
         queue.append(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=spp))
         torch.cuda.synchronize()   # (the buffer is borrowed until the copy has run)
+        if len(queue) >= 3:
+            st = r.wait(queue.pop(0))
     for ticket in queue:
         st = r.wait(ticket)
     assert r.readback_framebuffer(last) == W * H * 4

@@ -6,8 +6,11 @@
 // 160 KiB / W, so "W waves per SIMD" is exact when the dispatcher spreads the blocks (checked through the per-block cycle counts:
 // a CU that got more than its share shows a longer s_memtime span). A wave runs ITER iterations of an unrolled block of UNROLL
 // independent instructions over 8 accumulators (dependency distance 8 instructions >= the 4-cycle dependent latency at 2 cycles each).
-// Reported: wave-instructions / clock / SIMD from (a) s_memtime (shader clock ticks, per wave, min / median / max over waves) and
-// (b) the wall clock of the launch (hipEvents) at the measured effective clock = median cycles / wall time.
+// Reported: (a) chip-wide G wave-instructions / s from the wall clock of the launch (hipEvents) -- the figure bench.py's roofline uses:
+// it needs no clock assumption -- and (b) wave-instructions per s_memtime tick per SIMD (per wave: median / fastest / slowest).
+// s_memtime counters are per XCD and not synchronised with each other (the "eff. GHz" column, ticks over the whole launch / wall time, is
+// meaningless across XCDs and only printed for completeness), and the dispatcher does not spread W blocks per CU evenly, so (b) is a
+// cross-check of (a) at W = 1 and W = 2 only.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_issue.hip -o tools/microbench/valu_issue
 // Run:   tools/microbench/valu_issue [out.json]
@@ -123,6 +126,7 @@ int main(int argc, char **argv) {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     const int iters = argc > 2 ? atoi(argv[2]) : 4000;
+    const bool quick = argc > 3;
     const size_t lds_total = 160 * 1024;
     uint64_t *cyc;
     float *sink;
@@ -137,7 +141,9 @@ int main(int argc, char **argv) {
     printf("%s (%s), %d CUs, hipDeviceProp clockRate %d kHz\n", prop.name, prop.gcnArchName, cus, prop.clockRate);
     printf("%-60s %5s %12s %12s %12s %10s %10s\n", "instruction stream", "W/SIMD", "inst/clk/SIMD", "(min wave)", "(max wave)", "eff. GHz", "G inst/s");
     for (int op = 0; op < N_OPS; ++op) {
+        if (op == FMA_SALU && !getenv("VALU_ISSUE_SALU")) continue; // (the per-lane scalar accumulators of this stream compile to readfirstlane loops: off by default)
         for (int w : {1, 2, 3, 4, 6, 8}) {
+            if (quick && w != 1 && w != 8) continue; // (under a counter pass every dispatch is slow: two occupancies are enough there)
             const int grid = cus * w;
             const size_t lds = (lds_total / w) & ~(size_t)1023; // W blocks of 256 threads fit one CU, W + 1 do not
             const size_t lds_use = lds > 64 * 1024 ? lds : lds;  // (gfx950 lets one block take all 160 KiB)

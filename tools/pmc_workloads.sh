@@ -20,8 +20,19 @@ args_of() {
     *) echo "" ;;
   esac
 }
+# the bounce at which the tail kernel takes over in the workload's benchmarked schedule (bench.py chooses it adaptively from the previous
+# frame's queue lengths; a counter pass renders a handful of frames, so the value is pinned: every frame of the pass then has the same launches)
+tail_of() {
+  case $1 in
+    c2) echo 2 ;;
+    c3|c5) echo 3 ;;
+    c4_flat|c4_two_level) echo 5 ;;
+    *) echo 2 ;;
+  esac
+}
 for K in $KEYS; do
   A=$(args_of $K)
+  export RPTR_TAIL_BOUNCE=$(tail_of $K)
   bash tools/pmc.sh ${K}_insts "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $A > $O/pmc_${K}_insts.txt 2>&1
   bash tools/pmc.sh ${K}_cycles "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" $A > $O/pmc_${K}_cycles.txt 2>&1
   bash tools/pmc.sh ${K}_fetch "FETCH_SIZE" $A > $O/pmc_${K}_fetch.txt 2>&1

@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/profile_round.sh <tag>: everything profiles/ keeps for one build, into gpurun_out/<tag>/ (run through gpurun from the repository root):
-#   pmc passes (instructions, cycles, fetch, write, cache) of bench.py --profile-pass -> pmc_*.csv + pmc_traffic.json (also written to profiles/),
+#   the VALU issue-rate microbenchmark, the pmc passes (instructions, cycles, fetch, write, cache) of bench.py --profile-pass for EVERY BASELINE
+#   workload -> pmc_<key>_*.csv + pmc_traffic.json (keyed by workload; copy it to profiles/),
 #   rocprofv3 --kernel-trace --stats of bench.py --profile-pass (exclusive launches) and of the default bench.py (pipelined),
 #   the bench lines of configs[1..4] (C2 default, C3, C4 flattened + two-level, C5), the emulated N-way shares.
 set -u
@@ -9,14 +10,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-bash tools/pmc.sh insts "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" > $O/pmc_insts.txt 2>&1
-bash tools/pmc.sh cycles "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" > $O/pmc_cycles.txt 2>&1
-bash tools/pmc.sh fetch "FETCH_SIZE" > $O/pmc_fetch.txt 2>&1
-bash tools/pmc.sh write "WRITE_SIZE" > $O/pmc_write.txt 2>&1
-bash tools/pmc.sh tcc "TCC_HIT_sum TCC_MISS_sum TA_TA_BUSY_sum" > $O/pmc_tcc.txt 2>&1
-for t in insts cycles fetch write tcc; do cp gpurun_out/pmc_$t/summary_$t.csv $O/pmc_$t.csv 2>/dev/null; done
-python3 tools/make_traffic.py $TAG > $O/pmc_traffic.txt 2>&1
-cp profiles/pmc_traffic.json $O/pmc_traffic.json
+bash tools/valu_issue.sh $TAG > $O/valu_issue_run.txt 2>&1
+bash tools/pmc_workloads.sh $TAG c2 c3 c4_flat c4_two_level c5 > $O/pmc_workloads.txt 2>&1
 bash tools/prof.sh ${TAG}_exclusive --profile-pass --steps 20 --warmup 2 > $O/prof_exclusive.txt 2>&1
 cp gpurun_out/prof_${TAG}_exclusive/*kernel_stats.csv $O/kernel_stats_exclusive_profile_pass.csv 2>/dev/null
 bash tools/prof.sh ${TAG}_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1

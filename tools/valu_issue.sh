@@ -11,7 +11,7 @@ cd $R
 tools/microbench/valu_issue $O/valu_issue.json > $O/valu_issue.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/pmc_valu
-timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_valu -o valu --output-format csv -- $R/tools/microbench/valu_issue /tmp/valu_pmc.json 2000 > $O/valu_issue_under_pmc.txt 2>&1
+timeout -k 5 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d /tmp/pmc_valu -o valu --output-format csv -- $R/tools/microbench/valu_issue /tmp/valu_pmc.json 400 quick > $O/valu_issue_under_pmc.txt 2>&1
 F=$(find /tmp/pmc_valu -name "*counter_collection.csv" | head -1)
 python3 - "$F" > $O/valu_issue_pmc.csv <<'PY'
 import csv,sys,collections
