@@ -105,13 +105,8 @@ struct RpFrame {
     // x / y / w rows of VP and VP_reference (render_vulkan.cpp:2926-2931): world -> view (3x4 row-major) and the two scale
     // factors of the infinite perspective, clip = (P00 v.x, -P11 v.y, ., -v.z)
     float view[12], view_ref[12], proj[2], proj_ref[2];
-    // regrouping pass (kernels.h "sort"): hit-cell grid over the scene bounds
-    float sort_lo[3];
-    int32_t sort_groups;         // material groups
-    float sort_scale[3];         // cells per world unit and axis
-    int32_t sort_cells;          // cells per material group = 2^(sum of sort_bits)
-    int32_t sort_bits[3];
-    int32_t sort_num_keys;       // 1 + sort_groups * sort_cells
+    int32_t regroup_materials;   // RPTR_REGROUP=1: shade orders the hits of a chunk by material inside its LDS compaction (kernels.h)
+    int32_t _pad_regroup;
     RpDivU32 div_npix_padded, div_tiles_x, div_stripe_rows, div_width; // rp_div by npix_padded / tiles_x / stripe_rows / width
     // A launch sequence may carry the samples of SEVERAL frames (rptr_hip_render_batch_async): sample slots [k * frame_spp, (k+1) *
     // frame_spp) belong to frame k of the batch. Frame 0 has (frame_offset, sample_base, frame_id) above; the frames behind it all reset

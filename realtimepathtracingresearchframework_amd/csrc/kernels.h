@@ -56,9 +56,6 @@ struct RpCounters {
     uint32_t _pad2;
 };
 
-#define RP_SORT_MAX_KEYS 16384 // bins of the regrouping pass (64 KiB of LDS per block)
-#define RP_SORT_BLOCKS 512
-#define RP_SORT_MIN_N 32768u   // below this many paths the regrouping pass is skipped
 #define RP_CHUNK 1024     // entries a producer block publishes per global atomic
 
 // ---- wave64 helpers
@@ -320,6 +317,40 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
         }
         __syncthreads();
         const uint32_t chunk_hits = s_nhit, chunk_n = s_nhit + s_nmiss;
+        // north_star's "regroup rays by material before the BSDF stages", fused into this compaction (no launch, no extra pass over the
+        // queue): the hits of the chunk are ordered by material id -- a counting sort through 64 LDS bins, s_next as the second buffer (it is
+        // empty here). The order inside a bin depends on the LDS atomics, a path's result does not depend on its position. Measured
+        // (profiles/r03_notes.md): it does not pay -- every material runs the same BSDF code, only its parameters differ -- so it stays an
+        // experiment behind RPTR_REGROUP=1.
+        if (f.regroup_materials && chunk_hits > 64u) {
+            __shared__ uint32_t s_bin[64];
+            __shared__ unsigned char s_key[RP_CHUNK];
+            if (threadIdx.x < 64) s_bin[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t il = threadIdx.x; il < chunk_hits; il += 256) {
+                const uint32_t pp = s_list[il];
+                const int2 ids = ps.hit_ids[pp];
+                const int prim = __float_as_int(ps.hit_tuv[pp].w);
+                const RpGeomRecord &g = sc.geoms[sc.insts[ids.x].geometry_base + ids.y];
+                const uint32_t key = (uint32_t)rp_hit_material_id(g, (uint32_t)prim) & 63u;
+                s_key[il] = (unsigned char)key;
+                atomicAdd(&s_bin[key], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) { // exclusive prefix over the 64 bins (one wave)
+                uint32_t v = s_bin[threadIdx.x], incl = v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(incl, off);
+                    if ((int)threadIdx.x >= off) incl += o;
+                }
+                s_bin[threadIdx.x] = incl - v;
+            }
+            __syncthreads();
+            for (uint32_t il = threadIdx.x; il < chunk_hits; il += 256) s_next[atomicAdd(&s_bin[s_key[il]], 1u)] = s_list[il];
+            __syncthreads();
+            for (uint32_t il = threadIdx.x; il < chunk_hits; il += 256) s_list[il] = s_next[il];
+            __syncthreads();
+        }
 #pragma unroll 1
         for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
             const uint32_t il = kk * 256 + threadIdx.x; // position in the regrouped chunk

@@ -1,4 +1,4 @@
-// kernels_misc.h -- the kernels around the path stages: the stored first queue, the regrouping pass, resolve (accumulate.glsl +
+// kernels_misc.h -- the kernels around the path stages: resolve (accumulate.glsl +
 // process_samples.comp), the ray-query kernel (rt_intersect.comp) and the refit of dynamic meshes. Included by rptr_hip.hip only
 // (non-template kernels: one definition); the path stages themselves are templates in kernels.h, instantiated in k_*.hip.
 #pragma once
@@ -8,146 +8,10 @@
 // tiles row by row: 64 consecutive entries = one tile = one wave of camera rays). Ids of the tile padding beyond the right / bottom
 // edge of a frame whose size is not a multiple of 8 name no pixel sample: rp_primary_ray returns false for them, the first extend
 // gives them an empty interval (nothing is traversed), the first shade skips them.
-// The same list in memory, for the opt-in regrouping pass (its kernels read a queue array):
-__global__ __launch_bounds__(256) void rp_k_first_queue(uint32_t *queue, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = i;
-}
-
-// ------------------------------------------------------------------ sort by material and hit cell
-// Regroups the paths that were just extended so that a wave shades one material and
-// -- just as important on this machine -- neighbouring hit points: the shadow rays
-// and continuation rays it emits then start close together and share BVH nodes,
-// which is what the L1 path (64 B/clk/CU, one distinct line per clock) rewards.
-//   key 0                     = miss
-//   1 + group*cells + cell    = hit; group = material id % groups, cell = position
-//                               of the hit in a grid over the scene bounds
-// One counting-sort pass with up to RP_SORT_MAX_KEYS bins: block-local LDS
-// histograms (wave ballot aggregation for the dominant keys, ds_add for the rest),
-// one global add per non-empty (block, bin), single-block scan, and a scatter that
-// reserves a contiguous range per (block, bin).
-RP_DEV uint32_t rp_sort_key(const RpScene &sc, const RpFrame &f, const RpPathState &ps, uint32_t p) {
-    const int2 ids = ps.hit_ids[p];
-    if (ids.x < 0) return 0u;
-    const float4 hit = ps.hit_tuv[p];
-    const int prim = __float_as_int(hit.w);
-    const int geometry_base = reinterpret_cast<const int *>(sc.insts + ids.x)[13]; // RptrBvhInstance::geometry_base
-    const RpGeomRecord &g = sc.geoms[geometry_base + ids.y];
-    const int mid = rp_hit_material_id(g, uint32_t(prim));
-    const float4 o = ps.ray_o[p], d = ps.ray_d[p];
-    const float px = o.x + hit.x * d.x, py = o.y + hit.x * d.y, pz = o.z + hit.x * d.z;
-    const int cx = min(max(int((px - f.sort_lo[0]) * f.sort_scale[0]), 0), (1 << f.sort_bits[0]) - 1);
-    const int cy = min(max(int((py - f.sort_lo[1]) * f.sort_scale[1]), 0), (1 << f.sort_bits[1]) - 1);
-    const int cz = min(max(int((pz - f.sort_lo[2]) * f.sort_scale[2]), 0), (1 << f.sort_bits[2]) - 1);
-    const uint32_t cell = (uint32_t(cx) << (f.sort_bits[1] + f.sort_bits[2])) | (uint32_t(cy) << f.sort_bits[2]) | uint32_t(cz);
-    const uint32_t group = uint32_t(mid) % uint32_t(f.sort_groups);
-    return 1u + group * uint32_t(f.sort_cells) + cell;
-}
-RP_DEV void rp_sort_slice(uint32_t n, uint32_t &begin, uint32_t &end) {
-    uint32_t per = (n + RP_SORT_BLOCKS - 1) / RP_SORT_BLOCKS;
-    per = (per + 255u) & ~255u;
-    begin = min(n, blockIdx.x * per);
-    end = min(n, begin + per);
-}
-// table[key] += 1 for every valid lane; returns the previous value seen by the lane (its slot).
-// The two most common keys of the wave are handled with ballot + one LDS add each.
-RP_DEV uint32_t rp_lds_take(uint32_t *table, uint32_t key, bool valid) {
-    const uint32_t lane = rp_lane_id();
-    uint32_t pos = 0;
-    unsigned long long todo = __ballot(valid);
-#pragma unroll 1
-    for (int it = 0; it < 2 && todo; ++it) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k = __shfl(key, leader);
-        const unsigned long long same = __ballot(valid && key == k);
-        uint32_t b = 0;
-        if (int(lane) == leader) b = atomicAdd(&table[k], (uint32_t)__popcll(same));
-        b = __shfl(b, leader);
-        if (valid && key == k) pos = b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) pos = atomicAdd(&table[key], 1u);
-    return pos;
-}
-__global__ __launch_bounds__(256) void rp_k_sort_count(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, const uint32_t *count_ptr,
-                                                       uint32_t *keys, uint32_t *hist) {
-    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
-    const uint32_t n = *count_ptr;
-    if (n < RP_SORT_MIN_N) return;
-    const int num_keys = f.sort_num_keys;
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
-    __syncthreads();
-    uint32_t begin, end;
-    rp_sort_slice(n, begin, end);
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        uint32_t key = 0;
-        if (valid) {
-            key = rp_sort_key(sc, f, ps, queue[i]);
-            keys[i] = key;
-        }
-        (void)rp_lds_take(lh, key, valid);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
-        if (lh[k]) atomicAdd(&hist[k], lh[k]);
-}
-// single block: exclusive scan of hist -> base; clears hist and the scatter cursors for the next bounce
-__global__ __launch_bounds__(1024) void rp_k_sort_scan(uint32_t *hist, uint32_t *base, uint32_t *cursor, int num_keys) {
-    __shared__ uint32_t partial[1024];
-    const uint32_t total = uint32_t(num_keys);
-    const uint32_t per = (total + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = min(total, b + per);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += hist[i];
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t v = int(threadIdx.x) >= off ? partial[threadIdx.x - off] : 0u;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = partial[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t c = hist[i];
-        base[i] = run;
-        hist[i] = 0;
-        cursor[i] = 0;
-        run += c;
-    }
-}
-__global__ __launch_bounds__(256) void rp_k_sort_scatter(RpFrame f, const uint32_t *queue, const uint32_t *count_ptr, const uint32_t *keys,
-                                                         const uint32_t *base, uint32_t *cursor, uint32_t *order) {
-    __shared__ uint32_t lh[RP_SORT_MAX_KEYS];
-    const uint32_t n = *count_ptr;
-    uint32_t begin, end;
-    rp_sort_slice(n, begin, end);
-    if (n < RP_SORT_MIN_N) { // too few paths for regrouping to pay: keep the queue order
-        for (uint32_t i = begin + threadIdx.x; i < end; i += 256) order[i] = queue[i];
-        return;
-    }
-    const int num_keys = f.sort_num_keys;
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) lh[k] = 0;
-    __syncthreads();
-    // pass A: this block's histogram of its slice
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        (void)rp_lds_take(lh, valid ? keys[i] : 0u, valid);
-    }
-    __syncthreads();
-    // reserve one contiguous output range per non-empty bin of this block
-    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) {
-        const uint32_t c = lh[k];
-        if (c) lh[k] = base[k] + atomicAdd(&cursor[k], c);
-    }
-    __syncthreads();
-    // pass B: scatter
-    for (uint32_t i = begin + threadIdx.x; i < ((end + 255u) & ~255u) && begin < end; i += 256) {
-        const bool valid = i < end;
-        const uint32_t pos = rp_lds_take(lh, valid ? keys[i] : 0u, valid);
-        if (valid) order[pos] = queue[i];
-    }
-}
+// (Rounds 1-2 had a separate regrouping pass here -- rp_k_sort_count / _scan / _scatter: a counting sort of the extended paths by
+// (material group, hit cell), three launches per bounce. It made the following shade launch up to 1.8x faster and cost more than it saved
+// on every configuration; what north_star asks of it now lives inside the shade kernel's own LDS compaction, kernels.h rp_shade_body,
+// RPTR_REGROUP.)
 
 // the query kernel (rp_k_trace) borrows a pool cursor: reset it
 __global__ void rp_k_reset_u32(uint32_t *p) { *p = 0; }

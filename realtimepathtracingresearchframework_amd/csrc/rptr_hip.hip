@@ -90,8 +90,6 @@ struct FrameCtx {
     RpPathState ps = {};
     RpShadowRays sq = {};
     uint32_t *queue[2] = {nullptr, nullptr};
-    uint32_t *order = nullptr, *keys = nullptr;
-    uint32_t *sort_hist = nullptr, *sort_base = nullptr, *sort_cursor = nullptr;
     RpCounters *counters = nullptr;
     RpCounters *host_counters = nullptr; // pinned
     int *gstack = nullptr;
@@ -212,7 +210,6 @@ struct rptr_hip {
 
     // options (environment, read once)
     int side_connect = 0; // opt-in (RPTR_SIDE_CONNECT=1): connect(b) on a side stream next to extend(b+1)
-    int use_sort = 0; // regrouping pass by (material, hit cell): opt-in with RPTR_SORT=1
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
     bool freeze_frame = false; // RenderConfiguration::freeze_frame: frame_offset / frame_id stand still
     int rng_variant = RPTR_RNG_VARIANT_UNIFORM; // rptr_hip_set_rng_variant
@@ -1252,7 +1249,6 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         // (+5 % pipelined): off there. RPTR_SIDE_CONNECT=0|1 overrides.
         h->side_connect = fif == 1 ? 1 : 0;
         if (const char *s = getenv("RPTR_SIDE_CONNECT")) h->side_connect = atoi(s) != 0 ? 1 : 0;
-        if (getenv("RPTR_SORT") && atoi(getenv("RPTR_SORT")) != 0) fif = 1; // the opt-in regrouping pass keeps one context
         h->ctx.resize((size_t)fif);
         if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
         if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
@@ -1305,7 +1301,6 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     h->scene_params.sun_cos_angle = 0.99998933f;
     h->scene_params.sun_radiance[3] = 1.0f;
     h->scene_params.normal_z_scale = 1.0f;
-    if (const char *s = getenv("RPTR_SORT")) h->use_sort = atoi(s) != 0 ? 1 : 0;
     if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = std::max(0, std::min(2, atoi(s)));
     *out = h;
     return RPTR_OK;
@@ -1402,15 +1397,6 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         if ((rc = dev_alloc(h, &c.sq.ids, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.queue[0], cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.queue[1], cap, nullptr))) return rc;
-        if (h->use_sort) {
-            if ((rc = dev_alloc(h, &c.order, cap, nullptr))) return rc;
-            if ((rc = dev_alloc(h, &c.keys, cap, nullptr))) return rc;
-            if ((rc = dev_alloc(h, &c.sort_hist, RP_SORT_MAX_KEYS, nullptr))) return rc;
-            if ((rc = dev_alloc(h, &c.sort_base, RP_SORT_MAX_KEYS, nullptr))) return rc;
-            if ((rc = dev_alloc(h, &c.sort_cursor, RP_SORT_MAX_KEYS, nullptr))) return rc;
-            HIP_TRY(h, hipMemsetAsync(c.sort_hist, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
-            HIP_TRY(h, hipMemsetAsync(c.sort_cursor, 0, RP_SORT_MAX_KEYS * sizeof(uint32_t), h->stream));
-        }
         if ((rc = dev_alloc(h, &c.counters, 1, nullptr))) return rc;
     }
     const size_t npix_local = (size_t)h->width * std::max(h->local_rows, 1);
@@ -2425,36 +2411,11 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
     f.div_stripe_rows = rp_make_div((uint32_t)h->stripe_rows);
     f.div_width = rp_make_div((uint32_t)h->width);
     f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
-    // regrouping grid: material groups x hit cells, bits handed to the longest remaining axis
-    {
-        const int groups = std::max(1, std::min(h->num_materials, 15));
-        int cell_bits = 0;
-        while ((1 + groups * (2 << cell_bits)) <= RP_SORT_MAX_KEYS) ++cell_bits;
-        if (const char *s = getenv("RPTR_SORT_CELL_BITS")) cell_bits = std::max(0, std::min(cell_bits, atoi(s)));
-        float ext[3];
-        for (int k = 0; k < 3; ++k) ext[k] = std::max(h->scene_hi[k] - h->scene_lo[k], 1e-20f);
-        int bits[3] = {0, 0, 0};
-        for (int b = 0; b < cell_bits; ++b) {
-            int ax = 0;
-            for (int k = 1; k < 3; ++k)
-                if (ext[k] / float(1 << bits[k]) > ext[ax] / float(1 << bits[ax])) ax = k;
-            bits[ax]++;
-        }
-        f.sort_groups = groups;
-        f.sort_cells = 1 << cell_bits;
-        f.sort_num_keys = 1 + groups * f.sort_cells;
-        for (int k = 0; k < 3; ++k) {
-            f.sort_lo[k] = h->scene_lo[k];
-            f.sort_bits[k] = bits[k];
-            f.sort_scale[k] = float(1 << bits[k]) / ext[k];
-        }
-    }
-
-
-    // the regrouping pass costs ~0.4 ms per 1080p x 4 spp frame and makes shade up to 1.8x faster per bounce,
-    // but neither on configs[1] (Lambert) nor on configs[2] (glTF + area lights) does that pay for the pass
-    // (profiles/r01_notes.md): it is opt-in (RPTR_SORT=1)
-    const bool do_sort = h->use_sort > 0;
+    // north_star's regrouping of rays by material lives INSIDE the shade kernel's LDS compaction (kernels.h rp_shade_body, RPTR_REGROUP=1):
+    // measured on C3 with 48 textured materials it costs 6 % of the shade time and gains nothing (every material runs the same BSDF code),
+    // so it is off unless asked for. The separate counting-sort pass of rounds 1-2 (rp_k_sort_*: three launches per bounce, one frame
+    // context only, 0.4 ms per frame) lost on every configuration and is gone (profiles/r03_notes.md section 6).
+    f.regroup_materials = (getenv("RPTR_REGROUP") && atoi(getenv("RPTR_REGROUP")) != 0) ? 1 : 0;
     size_t ev_cursor = 0;
     c.spans.clear();
     auto timed_on = [&](hipStream_t st, int kind, auto &&launch) {
@@ -2533,18 +2494,13 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         f.batch_spp = batch;
         if (local_work) {
             HIP_TRY(h, hipMemsetAsync(c.counters, 0, sizeof(RpCounters), c.stream));
-            // the first bounce's queue is the identity over the batch's path ids and is not stored (kernels.h); only the opt-in regrouping
-            // pass, whose kernels read a queue array, gets it written out (into the queue buffer the first bounce leaves unused)
+            // the first bounce's queue is the identity over the batch's path ids and is not stored (kernels.h)
             const uint32_t first_count = (uint32_t)((size_t)batch * h->npix_padded);
             const uint32_t *first_ids = nullptr;
-            if (do_sort) {
-                hipLaunchKernelGGL(rp_k_first_queue, dim3(grid_for(h, first_count)), dim3(256), 0, c.stream, c.queue[0], first_count);
-                first_ids = c.queue[0];
-            }
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
-            // the late bounces in one launch (kernels.h rp_k_tail); counting and the regrouping pass keep the stand-alone kernels
+            // the late bounces in one launch (kernels.h rp_k_tail); counting keeps the stand-alone kernels
             int tail_from = h->params.max_path_depth;
-            if (h->tail_mode != 0 && !count_traversal && !do_sort)
+            if (h->tail_mode != 0 && !count_traversal)
                 tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
             c.tail_from = tail_from;
             for (int b = 0; b < h->params.max_path_depth; ++b) {
@@ -2563,16 +2519,6 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
                 const uint32_t *order = in_queue;
-                if (do_sort) {
-                    timed(5, [&] {
-                        hipLaunchKernelGGL(rp_k_sort_count, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, scn.dscene, f, c.ps, in_queue,
-                                           &bc->queue_count, c.keys, c.sort_hist);
-                        hipLaunchKernelGGL(rp_k_sort_scan, dim3(1), dim3(1024), 0, c.stream, c.sort_hist, c.sort_base, c.sort_cursor, f.sort_num_keys);
-                        hipLaunchKernelGGL(rp_k_sort_scatter, dim3(RP_SORT_BLOCKS), dim3(256), 0, c.stream, f, in_queue,
-                                           &bc->queue_count, c.keys, c.sort_base, c.sort_cursor, c.order);
-                    });
-                    order = c.order;
-                }
                 if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) wrote illum, frees the shadow queue
                 timed(2, [&] {
                     launch_shade(h, c, variant, scn.dscene, f, order, b, out);

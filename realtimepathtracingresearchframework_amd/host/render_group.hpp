@@ -76,6 +76,41 @@ public:
         }
         return total;
     }
+    // The pipelined schedule (what bench.py measures): a launch sequence of `n_frames` frames is queued on every GPU and collected later,
+    // while others are in flight (the group's frames_in_flight contexts). collect() waits for the sequence's frames in order, gathers each
+    // to rank 0 and returns one RenderStats per frame (render_time: the slowest rank's share of the sequence).
+    struct Sequence {
+        std::vector<std::vector<uint64_t>> tickets; // [rank][frame]
+        int frames = 0;
+    };
+    Sequence submit(const RenderConfiguration &config, int spp, int n_frames, bool reset_rest = true) {
+        Sequence q;
+        q.frames = n_frames;
+        for (auto &r : ranks_) q.tickets.push_back(n_frames > 1 ? r->render_batch_async(config, spp, n_frames, reset_rest) : std::vector<uint64_t>{r->render_async(config, spp)});
+        return q;
+    }
+    std::vector<RenderStats> collect(const Sequence &q) {
+        std::vector<RenderStats> out;
+        for (int k = 0; k < q.frames; ++k) {
+            RenderStats total{};
+            for (size_t i = 0; i < ranks_.size(); ++i) {
+                const RenderStats s = ranks_[i]->wait(q.tickets[i][(size_t)k]);
+                total.render_time = std::max(total.render_time, s.render_time);
+                total.has_valid_frame_stats = total.has_valid_frame_stats || s.has_valid_frame_stats;
+                rays_ += s.has_valid_frame_stats ? double(s.rays_per_second) * s.render_time * 1e-3 : 0.0;
+                total.spp = s.spp;
+                total.total_device_bytes_allocated += s.total_device_bytes_allocated;
+            }
+            if (size() > 1) {
+                std::vector<rptr_hip_t *> hs;
+                for (auto &r : ranks_) hs.push_back(r->handle());
+                if (rptr_hip_gather_all(hs.data(), size()) != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_gather_all: ") + last_error());
+            }
+            out.push_back(total);
+        }
+        return out;
+    }
+    double rays_traced() const { return rays_; }
     // the full frame (RGBA32F accumulation buffer) on the host: rank 0's assembled frame
     size_t readback_framebuffer(size_t buffer_size, float *buffer) {
         if (size() == 1) return ranks_[0]->readback_framebuffer(buffer_size, buffer);

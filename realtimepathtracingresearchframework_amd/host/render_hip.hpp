@@ -123,6 +123,24 @@ public:
         reset_accumulation = false;
         return ticket;
     }
+    // several frames of the same view in ONE launch sequence (rptr_hip_render_batch_async): tickets[k] is frame k's
+    std::vector<uint64_t> render_batch_async(const RenderConfiguration &config, int spp, int n_frames, bool reset_rest = true) {
+        begin_frame(config);
+        check(rptr_hip_set_params(h_, &params, have_scene_params_ ? &scene_params_ : nullptr, &lighting_params));
+        check(rptr_hip_set_freeze_frame(h_, freeze_frame ? 1 : 0));
+        RptrCamera cam;
+        for (int k = 0; k < 3; ++k) {
+            cam.pos[k] = camera.pos[k];
+            cam.dir[k] = camera.dir[k];
+            cam.up[k] = camera.up[k];
+        }
+        cam.fovy = camera.fovy;
+        std::vector<uint64_t> tickets((size_t)n_frames, 0);
+        check(rptr_hip_render_batch_async(h_, &cam, variant_, spp > 0 ? spp : (params.batch_spp > 0 ? params.batch_spp : 1), n_frames, reset_accumulation ? 1 : 0,
+                                          reset_rest ? 1 : 0, 0, tickets.data()));
+        reset_accumulation = false;
+        return tickets;
+    }
     RenderStats wait(uint64_t ticket) {
         check(rptr_hip_wait(h_, ticket, &last_));
         return stats();

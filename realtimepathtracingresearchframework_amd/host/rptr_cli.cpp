@@ -129,7 +129,7 @@ int main(int argc, char **argv) {
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
     int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
     std::string bn_table_path, dump_scene_path, sky_data;
-    int upscale = 0, stripe_rows = 8;
+    int upscale = 0, stripe_rows = 8, frames_in_flight = 1, frames_per_launch = 1;
     std::vector<int> devices{0};
     std::vector<std::string> config_inis;
     struct Keyframe {
@@ -157,6 +157,8 @@ int main(int argc, char **argv) {
         else if (a == "--benchmark-file") { std::fprintf(stderr, "--benchmark-file <name>.csv is now --profiling <name>\n"); return 2; } // cmdline.cpp:409-413
         else if (a == "--profiling-frames") { // the reference's old spelling of --profiling-fps (cmdline.cpp:397-403)
             need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; have_profiling_options = true; }
+        else if (a == "--frames-in-flight") { need(1); frames_in_flight = std::max(1, std::min(16, std::atoi(argv[++i]))); }   // (this host's: the pipelined schedule of bench.py)
+        else if (a == "--frames-per-launch") { need(1); frames_per_launch = std::max(1, std::min(4, std::atoi(argv[++i]))); }
         else if (a == "--profiling-count") { need(1); profiling_frames = std::atoi(argv[++i]); have_profiling_options = true; } // (this host's: frames of a run without keyframes)
         else if (a == "--animate-wave") { need(2); wave_amp = (float)std::atof(argv[++i]); wave_k = (float)std::atof(argv[++i]); }
         else if (a == "--img") { need(2); width = std::atoi(argv[++i]); height = std::atoi(argv[++i]); }
@@ -307,7 +309,7 @@ int main(int argc, char **argv) {
     if (want_help) scene_path.clear(); // prints the usage
     if (scene_path.empty() || (int)validation + (int)profiling + (int)data_capture != 1 || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
         std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
-                             "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
+                             "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--frames-in-flight n [--frames-per-launch b]] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
                              "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png] [--config file.ini ...] [--sky-data <dir of the Hosek-Wilkie data headers>]\n"
                              "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n] [--data-capture-no-rgba] [--data-capture-no-aovs] "
                              "[--data-capture-albedo-roughness] [--data-capture-normal-depth] [--data-capture-motion] [--keyframe ...]   (EXR images per keyframe)\n"
@@ -376,7 +378,7 @@ int main(int argc, char **argv) {
         if (!got_batch_spp) batch_spp = std::max(1, base.params.batch_spp);
         if (!got_variant && base.variant >= 0) variant = base.variant;
         if (upscale >= 1) base.params.render_upscale_factor = upscale;
-        rptr::RenderGroup backend(devices, stripe_rows);
+        rptr::RenderGroup backend(devices, stripe_rows, frames_in_flight);
         backend.initialize(width, height);
         backend.set_scene(scene.desc());
         base.params.batch_spp = batch_spp;
@@ -502,6 +504,49 @@ int main(int argc, char **argv) {
         }
         int active_key = -1;
         auto last = std::chrono::steady_clock::now();
+        // ---- the pipelined schedule (--frames-in-flight n [--frames-per-launch b]; a static view, no keyframes): launch sequences of b frames,
+        // n of them in flight, every frame restarts the accumulation -- exactly what bench.py times (the library asks the HIP runtime for a
+        // hardware queue per frame context itself: csrc/rptr_hip.hip ensure_hw_queues). One CSV line per frame as it is collected.
+        if (frames_in_flight > 1 && frames.empty() && rest.empty()) {
+            frames_per_launch = std::min(frames_per_launch, std::max(1, 16 / std::max(1, batch_spp)));
+            std::vector<rptr::RenderGroup::Sequence> queue;
+            for (int w = 0; w < 2; ++w) { // warm-up: every context renders once, the adaptive tail hand-over settles
+                for (int k = 0; k < frames_in_flight; ++k) {
+                    cfg.reset_accumulation = true;
+                    queue.push_back(backend.submit(cfg, batch_spp, frames_per_launch));
+                }
+                for (const auto &q : queue) backend.collect(q);
+                queue.clear();
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const double rays0 = backend.rays_traced();
+            last = t0;
+            int submitted = 0, collected = 0;
+            auto drain_one = [&] {
+                const std::vector<rptr::RenderStats> sts = backend.collect(queue.front());
+                queue.erase(queue.begin());
+                for (const rptr::RenderStats &st : sts) {
+                    gpu_ms += st.render_time;
+                    const auto now = std::chrono::steady_clock::now();
+                    std::fprintf(csv, "%d,%d,%d,%g,%g\n", ++collected, 1, 1, st.render_time, std::chrono::duration<double, std::milli>(now - last).count());
+                    last = now;
+                }
+            };
+            while (submitted < profiling_frames) {
+                const int n = std::min(frames_per_launch, profiling_frames - submitted);
+                cfg.reset_accumulation = true;
+                queue.push_back(backend.submit(cfg, batch_spp, n));
+                submitted += n;
+                if ((int)queue.size() >= frames_in_flight) drain_one();
+            }
+            while (!queue.empty()) drain_one();
+            const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fclose(csv);
+            if (!profiling_img_prefix.empty()) save_image(backend, format, profiling_img_prefix, 1, "", width, height, img);
+            std::printf("%s: %d frames, %d in flight x %d per launch sequence: %.4f ms per frame (wall), %.1f Mrays/s -> %s\n", backend.name().c_str(), profiling_frames,
+                        frames_in_flight, frames_per_launch, wall_ms / profiling_frames, (backend.rays_traced() - rays0) / wall_ms * 1e-3, csv_path.c_str());
+            return 0;
+        }
         for (int frame = 0; frame < profiling_frames; ++frame) {
             if (!frames.empty()) { // the keyframe this frame belongs to; a change applies its state and restarts the accumulation
                 int k = 0;

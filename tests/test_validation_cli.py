@@ -1023,5 +1023,42 @@ def test_cli_renders_several_scene_files_like_the_merged_scene(tmp_path):
     got = cli("ab", pa, pb)
     assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32))
     assert not np.array_equal(got, cli("a", pa))                       # the second file is in the picture
-    twice = cli("aa", pa, pa)
-    assert np.array_equal(twice.view(np.uint32), cli("aad", pa, pa, "--deduplicate-scene").view(np.uint32))
+    # de-duplication: same image. (With a literal emission colour: collect_emitters multiplies the raw base-colour words, librender/lights.cpp:14-73,
+    # so for an emitter whose colour is a texture HANDLE the light's radiance changes with the texture's index -- in the reference as here.)
+    c = scenes.textured_test()
+    for m in c.materials:
+        if m.emission_intensity > 0:
+            m.base_color[:] = [1.0, 0.8, 0.6]
+    c.prepare_lights()
+    pc = str(tmp_path / "c.rpsc")
+    c.dump(pc)
+    twice = cli("cc", pc, pc)
+    assert np.array_equal(twice.view(np.uint32), cli("ccd", pc, pc, "--deduplicate-scene").view(np.uint32))
+    assert not np.array_equal(twice, cli("c", pc))
+
+
+@pytest.mark.gpu
+def test_cli_profiling_reproduces_the_benchmarks_schedule(tmp_path):
+    """the C++ host gets the schedule bench.py measures -- 11 frame contexts x 4 frames per launch sequence, a hardware queue
+    per context (the library sets GPU_MAX_HW_QUEUES itself when nobody did: csrc/rptr_hip.hip ensure_hw_queues) -- and with it bench.py's
+    ms per frame on C2 (1 M triangles, 1080p, 4 spp, diffuse), within a few percent."""
+    import json
+    import re
+    import sys
+    exe = _build_cli(tmp_path)
+    s = scenes.grid_1m()
+    path = str(tmp_path / "grid1m.rpsc")
+    s.dump(path)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}      # nobody sets it for the host: the library must
+    p = subprocess.run([exe, path, "--profiling", str(tmp_path / "prof"), "--profiling-count", "200", "--frames-in-flight", "11", "--frames-per-launch", "4",
+                        "--img", "1920", "1080", "--batch-spp", "4", "--variant", "diffuse"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    assert "hardware queues" not in p.stderr                                     # (the warning of a host that initialised HIP with too few)
+    cli_ms = float(re.search(r"([0-9.]+) ms per frame \(wall\)", p.stdout).group(1))
+    rows = open(str(tmp_path / "prof.csv")).read().strip().splitlines()
+    assert rows[0] == "frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms" and len(rows) == 201
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", "200"], capture_output=True, text=True, cwd=ROOT)
+    assert b.returncode == 0, b.stderr[-2000:]
+    bench_ms = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"]
+    print("C2 ms per frame: bin/rptr_hip --profiling %.4f, bench.py %.4f (ratio %.3f)" % (cli_ms, bench_ms, cli_ms / bench_ms))
+    assert abs(cli_ms / bench_ms - 1.0) < 0.05
