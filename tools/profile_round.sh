@@ -20,15 +20,23 @@ grep '^{' gpurun_out/prof_${TAG}_pipelined/bench.log | tail -1 > $O/bench_under_
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 > $O/bench_c3.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4.json 2>/dev/null
+RPTR_BVH_BUILDER=host python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4_host_built_tree.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_level.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --animate --width 3840 --height 2160 --spp 2 > $O/bench_c5.json 2>/dev/null
 for n in 2 4 8; do python3 bench.py --no-cpu-baseline --emulate-world $n > $O/bench_emulated_world$n.json 2>/dev/null; done
+# the N > 1 path end to end on this box's one GPU (both ranks on cuda:0: the RCCL probe refuses, the run falls back and says so) with every rank
+# under rocprofv3: what tools/prof_ranks.sh <tag> 8 gives on a real node
+bash tools/prof_ranks.sh ${TAG}_ranks 2 --same-device > $O/prof_ranks_same_device.txt 2>&1
+cp gpurun_out/${TAG}_ranks/bench_gpus2.json $O/bench_gpus2_same_device.json 2>/dev/null
+cp gpurun_out/${TAG}_ranks/hbm_gbs_per_rank.txt $O/hbm_gbs_per_rank_same_device.txt 2>/dev/null
 python3 - $O <<'PY'
 import json,sys,glob,os
 for f in sorted(glob.glob(sys.argv[1]+"/bench_*.json")):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1]); rf=d["roofline"]
-        print("%-36s ms/step %.3f Mrays/s %7.0f | excl extend %.3f ms valu_frac %s hbm_frac %s alg_frac %s | frame valu %s" % (os.path.basename(f), d["ms_per_step"], d["value"], rf["exclusive_ms_per_step"], rf["valu"]["frac"], rf["hbm_frac"], rf["algorithmic_frac"], (rf["valu"]["frame"] or {}).get("pipelined_frac")))
+        print("%-36s ms/step %.3f Mrays/s %7.0f | excl extend %.3f ms valu_frac %s hbm_counter_frac %s contract frac %s | frame valu %s | latency 1/2 in flight %s / %s ms | bvh %s" % (
+            os.path.basename(f), d["ms_per_step"], d["value"], rf["exclusive_ms_per_step"], rf["valu"]["frac"], rf["hbm_frac"], rf["frac"], (rf["valu"]["frame"] or {}).get("pipelined_frac"),
+            rf["latency"]["1"]["ms_per_frame"], (rf["latency"].get("2") or {}).get("ms_per_frame"), d["config"].get("bvh", {}).get("built_on")))
     except Exception as e:
         print(f, "unreadable", e)
 PY

