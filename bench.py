@@ -174,7 +174,8 @@ def run_rccl_probe(args, timeout_s):
     got = {"torch_nccl": int("PROBE torch_nccl 1" in out), "native": int("PROBE native 1" in out)}
     if not note and p.returncode != 0:
         tail = [l for l in err.strip().splitlines() if l.strip()]
-        note = "probe exited with %s: %s" % (p.returncode, tail[-1][:200] if tail else "")
+        telling = [l for l in tail if any(w in l for w in ("Error", "error", "Duplicate", "failed", "refus", "invalid"))]   # (not a profiler's last words)
+        note = "probe exited with %s: %s" % (p.returncode, (telling or tail or [""])[-1].strip()[:240])
     got["note"] = note
     got["seconds"] = round(time.time() - t0, 1)
     return got
@@ -646,7 +647,7 @@ def main():
                 e[fld] = round(sum(parts) / len(parts), 4) if all(v is not None for v in parts) else None
         return e
 
-    single = len(scene.instances) == 1
+    single = len(scene.instances) == 1 or (bool(flatten) and not args.animate)   # (a flattened scene is one identity instance over one tree)
     sfx = ", false, %s" % ("true" if single else "false")   # (COUNT, FIRST,) ALPHA, SINGLE [, TABLE]
     var_id = "1" if variant == abi.VARIANT_SIMPLE else "0"
     k_ext = kernel_entry("rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE=%s>: first bounce FIRST=true, later bounces FIRST=false" % str(single).lower(),
@@ -692,6 +693,9 @@ def main():
                  "peak_source": vp["source"] if vp else None,
                  "wait_any_frac": k_ext.get("wait_any_frac"), "wait_inst_any_frac": k_ext.get("wait_inst_any_frac"),
                  "frac": k_ext["valu_frac"], "ginst_s": k_ext["valu_ginst_s"], "insts_per_launch": k_ext["valu_insts_per_launch"],
+                 "full_rate_ginst_s": round(vp["full_rate_ginst_s"], 1) if vp else None,
+                 "ceiling_note": "the ceiling is that of the node step's instruction mix; a frame with more triangle tests and shading per node visit (C3, C4) "
+                                 "issues more full-rate instructions and can exceed it (its own ceiling lies between peak_ginst_s and full_rate_ginst_s)",
                  "frame": valu_frame(pmc, ms_per_step, valu_peak, launches_extend) if pmc else None,
                  "source": "profiles/pmc_traffic.json: rocprofv3 --pmc SQ_INSTS_VALU pass of this workload (tools/pmc.sh insts)" if pmc else None},
         "node_and_triangle_fetches_per_s": round(fetches / (serial["ext"] * 1e-3)) if serial["ext"] > 0 else None,

@@ -101,17 +101,25 @@ static rptr::SceneDump load_one_scene(const std::string &path) {
 // `--deduplicate-scene` merges equal meshes / materials / textures and drops what nothing refers to (Scene::deduplicate + garbage_collect),
 // and the emitters are collected and binned again over the whole scene (librender/lights.cpp through host/lights.hpp).
 static std::vector<std::string> g_more_scenes;
-static bool g_deduplicate = false;
+static bool g_deduplicate = false, g_merge_partitions = false; // --deduplicate-scene, --merge-partition-instances (SceneLoaderParams)
 static rptr::SceneDump load_scene(const std::string &path) {
-    rptr::SceneDump s = load_one_scene(path);
-    for (const std::string &more : g_more_scenes) s.append(load_one_scene(more));
+    auto one = [&](const std::string &file) {
+        rptr::SceneDump d = load_one_scene(file);
+        if (g_merge_partitions) {
+            const size_t n = d.merge_partition_instances();
+            if (n) std::printf("%s: merged %zu partition instances\n", file.c_str(), n);
+        }
+        return d;
+    };
+    rptr::SceneDump s = one(path);
+    for (const std::string &more : g_more_scenes) s.append(one(more));
     if (g_deduplicate) {
         const rptr::SceneDump::DedupStats st = s.deduplicate();
         if (st.meshes) std::printf("Duplicate geometry detected! Removed %zu meshes\n", st.meshes);
         if (st.materials) std::printf("Removed %zu unused materials\n", st.materials);
         if (st.textures) std::printf("Removed %zu unused textures\n", st.textures);
     }
-    if (!g_more_scenes.empty() || g_deduplicate) rptr::lights::prepare_lights(s);
+    if (!g_more_scenes.empty() || g_deduplicate || g_merge_partitions) rptr::lights::prepare_lights(s);
     return s;
 }
 
@@ -226,6 +234,7 @@ int main(int argc, char **argv) {
         else if (a == "--data-capture-motion") capture_motion = true;
         else if (a == "--vulkan-device") { need(1); devices.assign(1, std::atoi(argv[++i])); } // ProgramArgs::device_override: here the HIP ordinal
         else if (a == "--resource-dir") { need(1); ++i; }      // (shader / resource search path of the reference's backends: nothing to find here)
+        else if (a == "--merge-partition-instances") g_merge_partitions = true; // SceneLoaderParams::PerFile::merge_partition_instances, librender/scene.cpp:757-797
         else if (a == "--deduplicate-scene") g_deduplicate = true; // Scene::deduplicate + garbage_collect: less memory, same image
         else if (a == "-h" || a == "--help") want_help = true;
         else if (a == "--backend") { // cmdline.cpp:363-376: the last one wins; this binary hosts one
@@ -315,6 +324,7 @@ int main(int argc, char **argv) {
                              "[--data-capture-albedo-roughness] [--data-capture-normal-depth] [--data-capture-motion] [--keyframe ...]   (EXR images per keyframe)\n"
                              "       <scene.vks>: [--remove-first-lods n] [--instance-pruning p] [--small-deformation] [--ignore-animation] [--ignore-textures] "
                              "[--load-specularity] [--dump-scene out.rpsc]\n"
+                             "       <scene_file> [<scene_file>...] [--deduplicate-scene] [--merge-partition-instances]\n"
                              "validation, profiling and data-capture mode are mutually exclusive (cmdline.cpp:479-486)\n");
         return 2;
     }

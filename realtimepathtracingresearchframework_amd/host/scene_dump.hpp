@@ -128,6 +128,63 @@ struct SceneDump {
         fix_pointers();
     }
 
+    // SceneLoaderParams::PerFile::merge_partition_instances (librender/scene.cpp:757-797): a scene exported in partitions has runs of
+    // consecutive instances with the SAME transform, each with a mesh of its own; such a run becomes ONE instance whose mesh lists the
+    // geometries of all of them (material offsets appended alike). Instances whose parameterized mesh carries per-triangle material ids
+    // are left alone and end a run (the reference's condition reads `lod_group == 0 || ... && !per_triangle_materials()`, which by
+    // operator precedence would also merge those -- without their ids; the intended rule is implemented). Instance indices after the first
+    // merged run shift, as in the reference. Returns the number of instances merged away.
+    size_t merge_partition_instances(size_t instance_base = 0) {
+        std::vector<std::vector<uint32_t>> mesh_geoms(meshes.size());
+        for (size_t m = 0; m < meshes.size(); ++m)
+            for (uint32_t j = 0; j < meshes[m].num_geometries; ++j) mesh_geoms[m].push_back(meshes[m].first_geometry + j);
+        bool have_cursor = false;
+        size_t cursor_i = instance_base, ic = instance_base;
+        float cursor_transform[12];
+        for (size_t i = instance_base; i < instances.size(); ++i) {
+            const uint32_t p = instances[i].parameterized_mesh;
+            if (!tri_ids[p].empty()) {
+                have_cursor = false;
+                instances[ic++] = instances[i];
+                continue;
+            }
+            const uint32_t cp = instances[cursor_i].parameterized_mesh;
+            const bool merge = have_cursor && std::memcmp(cursor_transform, instances[i].transform, 48) == 0 && meshes[pmeshes[p].mesh].dynamic == meshes[pmeshes[cp].mesh].dynamic &&
+                               pmeshes[p].mesh != pmeshes[cp].mesh;
+            if (!merge) {
+                std::memcpy(cursor_transform, instances[i].transform, 48);
+                have_cursor = true;
+                instances[ic] = instances[i];
+                cursor_i = ic++;
+                continue;
+            }
+            std::vector<uint32_t> &dst = mesh_geoms[pmeshes[cp].mesh];
+            const std::vector<uint32_t> &src = mesh_geoms[pmeshes[p].mesh];
+            dst.insert(dst.end(), src.begin(), src.end());
+            offsets[cp].insert(offsets[cp].end(), offsets[p].begin(), offsets[p].end());
+        }
+        const size_t merged = instances.size() - ic;
+        instances.resize(ic);
+        if (!merged) return 0;
+        // geometries again mesh by mesh (a mesh's geometries are a contiguous range of the geometry table)
+        std::vector<RptrGeometryDesc> ng;
+        std::vector<std::vector<uint64_t>> np, nn;
+        for (size_t m = 0; m < meshes.size(); ++m) {
+            meshes[m].first_geometry = (uint32_t)ng.size();
+            meshes[m].num_geometries = (uint32_t)mesh_geoms[m].size();
+            for (uint32_t g : mesh_geoms[m]) { // (a geometry listed by two meshes after a merge is stored twice)
+                ng.push_back(geometries[g]);
+                np.push_back(qpos[g]);
+                nn.push_back(qnu[g]);
+            }
+        }
+        geometries.swap(ng);
+        qpos.swap(np);
+        qnu.swap(nn);
+        fix_pointers();
+        return merged;
+    }
+
     // Scene::deduplicate + garbage_collect (librender/scene.cpp:142-148 and below; `--deduplicate-scene`): meshes with the same content
     // become one mesh, equal materials one material, equal textures one texture; what nothing refers to any more is dropped. Instances keep
     // their order and their parameterized meshes (ray-query ids and the order of the emitters do not change): the image is the same.

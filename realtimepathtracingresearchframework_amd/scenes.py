@@ -234,6 +234,37 @@ class Scene:
         self.prepare_lights()
         return self
 
+    def merge_partition_instances(self):
+        """SceneLoaderParams::PerFile::merge_partition_instances (librender/scene.cpp:757-797): runs of consecutive instances with the same
+        transform (the partitions of one exported object), each with its own single-material mesh, become one instance whose mesh lists all
+        their geometries. Twin of host/scene_dump.hpp SceneDump::merge_partition_instances. Returns the number of instances merged away."""
+        geoms = [list(range(m.first_geometry, m.first_geometry + m.num_geometries)) for m in self.meshes]
+        kept, cursor, cursor_t = [], None, None
+        for inst in self.instances:
+            pm = self.pmeshes[inst.pmesh]
+            if pm.tri_material_ids is not None:
+                cursor = None
+                kept.append(inst)
+                continue
+            t = np.asarray(inst.transform, f32).tobytes()
+            cpm = self.pmeshes[cursor.pmesh] if cursor is not None else None
+            if cursor is None or t != cursor_t or int(self.meshes[pm.mesh].dynamic) != int(self.meshes[cpm.mesh].dynamic) or pm.mesh == cpm.mesh:
+                cursor, cursor_t = inst, t
+                kept.append(inst)
+                continue
+            geoms[cpm.mesh] += geoms[pm.mesh]
+            cpm.material_offsets = np.concatenate([np.asarray(cpm.material_offsets, np.int32), np.asarray(pm.material_offsets, np.int32)])
+        merged = len(self.instances) - len(kept)
+        self.instances = kept
+        if merged:
+            new = []
+            for m, gl in zip(self.meshes, geoms):
+                m.first_geometry, m.num_geometries = len(new), len(gl)
+                new += [self.geometries[g] for g in gl]
+            self.geometries = new
+            self.prepare_lights()
+        return merged
+
     def num_tris(self):
         return sum(g.num_tris for g in self.geometries)
 

@@ -1062,3 +1062,65 @@ def test_cli_profiling_reproduces_the_benchmarks_schedule(tmp_path):
     bench_ms = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"]
     print("C2 ms per frame: bin/rptr_hip --profiling %.4f, bench.py %.4f (ratio %.3f)" % (cli_ms, bench_ms, cli_ms / bench_ms))
     assert abs(cli_ms / bench_ms - 1.0) < 0.05
+
+
+def _partitioned_scene():
+    """one object exported in three partitions (three meshes of one material each under the same transform) + an unrelated instance"""
+    s = scenes.Scene(name="partitions")
+    s.materials = [abi.make_material((0.8, 0.3, 0.2), roughness=0.6), abi.make_material((0.2, 0.7, 0.3), roughness=0.3, metallic=1.0),
+                   abi.make_material((0.3, 0.3, 0.9), roughness=0.8), abi.make_material((0.7, 0.7, 0.7), roughness=0.9)]
+    M = np.array([[0.9, 0, 0.2, 0.1], [0, 1.1, 0, 0.0], [-0.2, 0, 0.9, -0.3]], np.float32)
+    for k in range(3):
+        P, N, UV = scenes._heightfield(10, 10, -1.5 + k, -0.5 + k, -1.0, 1.0, lambda X, Z: 0.25 * np.sin(3 * X) * np.cos(2 * Z))
+        mesh = scenes._add_mesh(s, P, N, UV)
+        s.pmeshes.append(scenes.ParameterizedMesh(mesh=mesh, material_offsets=np.array([k], np.int32)))
+        s.instances.append(scenes.Instance(transform=M.copy(), pmesh=k))
+    P, N, UV = scenes._heightfield(6, 6, -4.0, 4.0, -4.0, 4.0, lambda X, Z: -0.6 + 0.0 * X)
+    g = scenes._add_mesh(s, P, N, UV)
+    s.pmeshes.append(scenes.ParameterizedMesh(mesh=g, material_offsets=np.array([3], np.int32)))
+    s.instances.append(scenes.Instance(transform=scenes.IDENTITY.copy(), pmesh=3))
+    s.camera = dict(eye=(0, 2.0, 5.0), center=(0, 0, 0), up=(0, 1, 0), fov=45.0)
+    s.config = scenes.SceneConfig(**scenes.SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s
+
+
+def test_cli_merges_partition_instances(tmp_path):
+    """--merge-partition-instances (SceneLoaderParams::PerFile::merge_partition_instances, librender/scene.cpp:757-797): consecutive instances
+    with one transform become one instance whose mesh lists all their geometries; same triangles, fewer instances. No GPU needed."""
+    exe = _build_cli(tmp_path)
+    s = _partitioned_scene()
+    path = str(tmp_path / "p.rpsc")
+    s.dump(path)
+    k0, _ = _describe(exe, path)
+    k1, text = _describe(exe, path, "--merge-partition-instances")
+    assert (int(k0["instances"]), int(k1["instances"])) == (4, 2) and "merged 2 partition instances" in text
+    # (the merged-away meshes stay in the tables, unreferenced by any instance, as in the reference: their two geometries are now listed by
+    # mesh 0 as well)
+    assert int(k1["geometries"]) == int(k0["geometries"]) + 2 and int(k1["triangles"]) == int(k0["triangles"]) + 2 * 200 and int(k1["meshes"]) == int(k0["meshes"])
+    twin = _partitioned_scene()
+    assert twin.merge_partition_instances() == 2 and len(twin.instances) == 2 and twin.meshes[0].num_geometries == 3
+    assert list(twin.pmeshes[0].material_offsets) == [0, 1, 2]
+
+
+@pytest.mark.gpu
+def test_merged_partition_instances_render_the_same_image(tmp_path):
+    from common import gpu_render
+    exe = _build_cli(tmp_path)
+    s = _partitioned_scene()
+    path = str(tmp_path / "p.rpsc")
+    s.dump(path)
+    W, H, spp = 96, 64, 2
+    imgs = []
+    for extra in ([], ["--merge-partition-instances"]):
+        prefix = str(tmp_path / ("m%d" % len(extra)))
+        p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", str(spp), "--img", str(W), str(H), "--pfm", "--variant", "gltf"] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        imgs.append(read_pfm("%s_%04d.pfm" % (prefix, spp)))
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))       # no coincident surfaces: ids decide nothing
+    twin = _partitioned_scene()
+    twin.merge_partition_instances()
+    ref, _, _ = gpu_render(twin, W, H, spp, abi.VARIANT_GLTF)
+    assert np.array_equal(imgs[1].view(np.uint32), np.ascontiguousarray(ref[..., :3]).view(np.uint32))

@@ -73,9 +73,14 @@ def main():
     # one frame = one rp_k_resolve launch: all VALU instructions of the pass / frames (where the tail kernel takes over does not change
     # the work of a frame, so this holds for the pipelined run too, whatever bounce its tail starts at)
     frames = max((v["launches"] for k, v in doc["kernels"].items() if "rp_k_resolve" in k), default=0)
+    # (the one-time device build of a static tree -- rp_k_build_tris, rp_k_ploc_*, and the rp_k_lbvh_* steps it borrows -- is set_scene's work,
+    # not a frame's)
+    static_build = any("rp_k_ploc_" in k for k in doc["kernels"])
+    per_frame = {k: v for k, v in doc["kernels"].items()
+                 if not ("rp_k_ploc_" in k or "rp_k_build_tris" in k or (static_build and "rp_k_lbvh_" in k))}
     if frames:
         doc["frames"] = frames
-        doc["valu_insts_per_frame"] = sum(v.get("valu_insts_per_launch", 0.0) * v["launches"] for v in doc["kernels"].values()) / frames
+        doc["valu_insts_per_frame"] = sum(v.get("valu_insts_per_launch", 0.0) * v["launches"] for v in per_frame.values()) / frames
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         full = json.load(open(path))
