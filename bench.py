@@ -151,10 +151,10 @@ def rccl_probe_child(args):
     dist.destroy_process_group()
 
 
-def run_rccl_probe(args, timeout_s):
+def run_rccl_probe(args, timeout_s, port_offset=1):
     """starts this rank's probe child and reports which stages it got through: {"torch_nccl": 0|1, "native": 0|1, "note": str}"""
     env = dict(os.environ)
-    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
     env["MASTER_ADDR"] = "127.0.0.1" if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("localhost", "127.0.0.1") else os.environ["MASTER_ADDR"]
     for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
         env.pop(k, None)   # the child makes its own TCP store on MASTER_PORT + 1, it does not join the agent's
@@ -282,13 +282,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         if args.dist_backend == "nccl":
-            probe = {"torch_nccl": 1, "native": 1, "note": "not probed (--no-probe)", "seconds": 0.0} if args.no_probe else run_rccl_probe(args, args.probe_timeout)
-            flags = torch.tensor([probe["torch_nccl"], probe["native"]], dtype=torch.int32)
-            dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # every rank takes the same path
-            mine = (probe["torch_nccl"], probe["native"])
-            probe["torch_nccl"], probe["native"] = int(flags[0]), int(flags[1])
-            if mine != (probe["torch_nccl"], probe["native"]) and not probe["note"]:
-                probe["note"] = "the probe failed on another rank"
+            # (a second attempt on another rendezvous port when the first fails fast everywhere: MASTER_PORT + 1 may be taken)
+            for attempt, offset in enumerate((1, 101)):
+                probe = ({"torch_nccl": 1, "native": 1, "note": "not probed (--no-probe)", "seconds": 0.0} if args.no_probe
+                         else run_rccl_probe(args, args.probe_timeout, offset))
+                flags = torch.tensor([probe["torch_nccl"], probe["native"], int(probe["seconds"] < 30.0)], dtype=torch.int32)
+                dist.all_reduce(flags, op=dist.ReduceOp.MIN)   # every rank takes the same path
+                mine = (probe["torch_nccl"], probe["native"])
+                probe["torch_nccl"], probe["native"] = int(flags[0]), int(flags[1])
+                probe["attempts"] = attempt + 1
+                if mine != (probe["torch_nccl"], probe["native"]) and not probe["note"]:
+                    probe["note"] = "the probe failed on another rank"
+                if probe["native"] or args.no_probe or not int(flags[2]) or args.same_device:
+                    break   # fine, or a slow failure (a time-out is not a port problem), or the rig where RCCL cannot work
 
     nx, nz = (int(v) for v in args.grid.split("x"))
     t0 = time.time()
@@ -327,6 +333,7 @@ def main():
     r.set_scene(scene)
     t_build = time.time() - t0
     bvh_on_device, bvh_step_ms, bvh_device_ms = r.bvh_build_info()
+    bvh_area_cost, trav_node_min, trav_refill_min = r.traversal_preset()
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
     cam = scene.camera_params()
@@ -739,7 +746,9 @@ def main():
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2),
                    "bvh": {"built_on": "device (csrc/ploc.h)" if bvh_on_device else "host (csrc/bvh_build.cpp)", "acceleration_structure_step_ms": round(bvh_step_ms, 1),
-                           "device_ms": round(bvh_device_ms, 2)}},
+                           "device_ms": round(bvh_device_ms, 2), "area_cost": round(bvh_area_cost, 1),
+                           "traversal_thresholds": {"node_min": trav_node_min or 10, "refill_min": trav_refill_min or 48,
+                                                    "preset": "dense (area cost >= 30)" if trav_node_min else "default"}}},
         "roofline": roofline,
     }
     if world > 1:

@@ -320,6 +320,12 @@ int rptr_hip_abi_version(void);
  * (default auto: the device from RPTR_DEVICE_BUILD_MIN_TRIS = 2 Mi triangles). out_build_ms: wall time of the whole step;
  * out_device_ms: GPU time of the device builds in it (0 when the host built everything). */
 int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out_build_ms, float *out_device_ms);
+/* the scheduling thresholds the traversal kernels use for the current scene (csrc/dtraverse.h: a wave refills its idle lanes once
+ * `refill_min` have finished and leaves a node phase once fewer than `node_min` lanes are at inner nodes; 0 = the compile-time defaults
+ * 10 / 48) and the measure they were chosen by at set_scene: the surface-area cost of the largest bottom-level tree times that of the top
+ * level (>= 30: the dense preset 16 / 32). They change when lanes take their steps, never what a ray finds. RPTR_TRAVERSE_PRESET="n,r"
+ * overrides. No reference counterpart (the reference's traversal is the driver's). */
+int rptr_hip_traversal_preset(rptr_hip_t *h, float *out_area_cost, int32_t *out_node_min, int32_t *out_refill_min);
 void rptr_hip_destroy(rptr_hip_t *h);
 const char *rptr_hip_last_error(const rptr_hip_t *h);
 const char *rptr_hip_name(void); /* RenderBackend::name() */

@@ -71,6 +71,7 @@ def load_library(path=None):
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
     L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rptr_hip_bvh_build_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rptr_hip_traversal_preset.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rptr_hip_get_framebuffer_size.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rptr_hip_readback_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_readback_u8.argtypes = [vp, vp, C.c_size_t]
@@ -389,6 +390,12 @@ class RenderHip:
         dev, ms, dms = C.c_int32(), C.c_float(), C.c_float()
         self._check(self._L.rptr_hip_bvh_build_info(self._h, C.byref(dev), C.byref(ms), C.byref(dms)))
         return bool(dev.value), float(ms.value), float(dms.value)
+
+    def traversal_preset(self):
+        """(surface-area cost of the scene's tree, node_min, refill_min): the traversal's scheduling thresholds for this scene (0 = defaults)"""
+        cost, nm, rm = C.c_float(), C.c_int32(), C.c_int32()
+        self._check(self._L.rptr_hip_traversal_preset(self._h, C.byref(cost), C.byref(nm), C.byref(rm)))
+        return float(cost.value), int(nm.value), int(rm.value)
 
     def bvh_rebuild_count(self):
         n = C.c_uint64()

@@ -56,6 +56,7 @@ struct RpScene {
     int32_t num_textures;
     const RpTexture *textures;
     const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)
+    int32_t node_min, refill_min; // scheduling thresholds of the traversal for this scene (dtraverse.h), 0 = the compile-time defaults
 };
 
 // Division of a 31-bit number by a frame constant (tiles per row, rows per stripe, padded pixels per sample slot) without the ~25

@@ -154,6 +154,11 @@ template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
                           uint32_t &n_nodes, uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+    // The two scheduling thresholds are the scene's (RpScene.node_min / refill_min, chosen at set_scene from the tree: rptr_hip.hip
+    // traversal_preset; 0 = this instantiation's compile-time default). They decide WHEN a lane makes its next step, never the sequence of
+    // steps of a ray: results and visit counts do not depend on them. Wave-uniform values: the compares below are scalar.
+    const uint32_t node_min = sc.node_min > 0 ? (uint32_t)sc.node_min : (uint32_t)NODE_MIN;
+    const uint32_t refill_min = sc.refill_min > 0 ? (uint32_t)sc.refill_min : (uint32_t)REFILL_MIN;
     const uint32_t tid = threadIdx.x;
     const uint32_t gstride = gridDim.x * blockDim.x;
     int *const glob = gstack + (blockIdx.x * blockDim.x + tid);
@@ -219,7 +224,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         const bool idle = cur == RP_EXIT;
         const unsigned long long idle_mask = __ballot(idle);
         const uint32_t nidle = (uint32_t)__popcll(idle_mask);
-        if (nidle >= (uint32_t)REFILL_MIN) {
+        if (nidle >= refill_min) {
             if (pool_next >= pool_end && more) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, fetch); // the cursor counts entries handed out behind the static pools
@@ -279,7 +284,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             const unsigned long long want_node = __ballot(cur >= 0);
             if (want_node == 0ull) break;
 #if RP_NODE_MIN > 1
-            if ((uint32_t)__popcll(want_node) < (uint32_t)NODE_MIN &&
+            if ((uint32_t)__popcll(want_node) < node_min &&
                 (uint32_t)__popcll(__ballot(cur < 0 && cur != RP_EXIT)) >= (uint32_t)RP_LEAF_MIN)
                 break;
 #endif

@@ -134,6 +134,7 @@ struct rptr_hip {
     int num_cus = 0;
     size_t bytes_allocated = 0, bytes_frame = 0, bytes_scene = 0; // what is allocated now (frame buffers + path state, scene)
     double bvh_build_ms = 0.0, bvh_device_ms = 0.0; // the last set_scene: its acceleration-structure step, the device part of it
+    double bvh_area_cost = 0.0;                     // surface-area cost of the largest bottom-level tree (picks the traversal's scheduling thresholds)
     bool bvh_device_built = false;
     std::vector<void *> allocations;
 
@@ -1192,6 +1193,14 @@ int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out
     return RPTR_OK;
 }
 
+int rptr_hip_traversal_preset(rptr_hip_t *h, float *out_area_cost, int32_t *out_node_min, int32_t *out_refill_min) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (out_area_cost) *out_area_cost = (float)h->bvh_area_cost;
+    if (out_node_min) *out_node_min = h->master.dscene.node_min;
+    if (out_refill_min) *out_refill_min = h->master.dscene.refill_min;
+    return RPTR_OK;
+}
+
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     if (!out) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: out is NULL");
     *out = nullptr;
@@ -1816,6 +1825,66 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
     h->master.dscene.srgb_lut = d_srgb_lut;
+    // Scheduling thresholds of the traversal (dtraverse.h): a wave refills its idle lanes together once `refill_min` of them have finished,
+    // and leaves a node phase for a leaf phase once fewer than `node_min` lanes are at inner nodes. The defaults (48 / 10) were tuned on the
+    // height field; in a dense soup of overlapping primitive boxes -- the forest: 26 node visits per ray, node-phase lane utilisation 0.55
+    // instead of 0.67, a quarter of the lane slots waiting for a refill -- 32 / 16 are 5 % faster (C4 5.89 -> 5.61 ms) and 1.4 % slower on the
+    // height field (profiles/r03_notes.md section 7). The choice follows the tree: the surface-area cost of its largest bottom-level tree
+    // (sum of the inner children's box areas over the root's: 11 for the height field, 92 for the flattened forest). RPTR_TRAVERSE_PRESET=
+    // "node_min,refill_min" overrides (0,0 = the compile-time defaults).
+    {
+        double best_cost = 0.0;
+        size_t best_tris = 0;
+        auto half_area = [&](size_t n) {
+            const std::array<float, 6> &b = h->h_node_box[n];
+            const double dx = std::max(0.0f, b[3] - b[0]), dy = std::max(0.0f, b[4] - b[1]), dz = std::max(0.0f, b[5] - b[2]);
+            return dx * dy + dy * dz + dz * dx;
+        };
+        for (size_t m = 0; m < h->meshes.size(); ++m) {
+            const MeshRt &mr = h->meshes[m];
+            const size_t root = (size_t)h->mesh_root[m], count = (size_t)(mr.node_count > 0 ? mr.node_count : (m == 0 ? (int)h->h_nodes.size() - h->num_tlas_nodes : 0));
+            const size_t tris_m = mr.tri_count > 0 ? (size_t)mr.tri_count : (m == 0 ? h->h_tris.size() : 0);
+            if (!count || tris_m < best_tris || root >= h->h_nodes.size()) continue;
+            const double a0 = half_area(root);
+            if (!(a0 > 0.0)) continue;
+            double sum = 0.0;
+            for (size_t n = root; n < std::min(root + count, h->h_nodes.size()); ++n)
+                for (int k = 0; k < 4; ++k)
+                    if (h->h_nodes[n].child[k] >= 0) sum += half_area((size_t)h->h_nodes[n].child[k]);
+            best_cost = sum / a0;
+            best_tris = tris_m;
+        }
+        // ... times the same measure of the top level (all child boxes of its nodes, instance boxes included, over the scene's box: 1 for a
+        // single instance, ~ 6 for the forest's 1001 overlapping instances: the two-level forest gains the same 5 %, 8.38 -> 7.95 ms)
+        double tlas_cost = 1.0;
+        if (h->num_tlas_nodes > 0 && h->num_tlas_insts > 1) {
+            const double a0 = half_area(0);
+            double sum = 0.0;
+            for (int n = 0; n < h->num_tlas_nodes; ++n) {
+                const RptrBvh4Node &nd = h->h_nodes[(size_t)n];
+                for (int k = 0; k < 4; ++k) {
+                    if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
+                    double d[3];
+                    for (int a = 0; a < 3; ++a) d[a] = std::max(0.0, (double)((int)nd.qhi[a][k] - (int)nd.qlo[a][k])) * std::ldexp(1.0, (int)nd.exp[a] - 127);
+                    sum += d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+                }
+            }
+            if (a0 > 0.0) tlas_cost = std::max(1.0, sum / a0);
+        }
+        best_cost *= tlas_cost;
+        h->bvh_area_cost = best_cost;
+        int node_min = 0, refill_min = 0;
+        if (best_cost >= 30.0) {
+            node_min = 16;
+            refill_min = 32;
+        }
+        if (const char *e = getenv("RPTR_TRAVERSE_PRESET")) {
+            node_min = atoi(e);
+            if (const char *c = strchr(e, ',')) refill_min = atoi(c + 1);
+        }
+        h->master.dscene.node_min = std::max(0, std::min(64, node_min));
+        h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
+    }
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
     // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites

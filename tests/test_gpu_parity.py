@@ -137,6 +137,40 @@ def test_small_batches_equal_large_batches(small_scenes, monkeypatch):
     assert np.array_equal(a, b)
 
 
+def test_traversal_thresholds_follow_the_tree_and_change_no_bit(monkeypatch):
+    """the scheduling thresholds of the traversal (when a wave refills its idle lanes, when it leaves a node phase) are chosen per scene from
+    the surface-area cost of its tree (rptr_hip_traversal_preset): the dense forest gets 16 / 32, the height field the defaults -- and whatever
+    they are, image, ray counts and counted node / triangle visits stay the same bit for bit (they decide when a lane steps, not what it finds)"""
+    forest = scenes.forest(n_meshes=4, tris_per_tree=3000, n_instances=120, name="small-forest")
+    field = scenes.grid(160, 80)
+    for flatten in ("1", "0"):
+        monkeypatch.setenv("RPTR_FLATTEN", flatten)
+        r = backend.RenderHip()
+        r.initialize(64, 48)
+        r.set_scene(forest)
+        cost, nm, rm = r.traversal_preset()
+        r.close()
+        assert cost >= 30.0 and (nm, rm) == (16, 32), (flatten, cost, nm, rm)
+    monkeypatch.setenv("RPTR_FLATTEN", "0")
+    r = backend.RenderHip()
+    r.initialize(64, 48)
+    r.set_scene(field)
+    cost, nm, rm = r.traversal_preset()
+    r.close()
+    assert cost < 30.0 and (nm, rm) == (0, 0), (cost, nm, rm)
+    monkeypatch.setenv("RPTR_FLATTEN", "1")
+    out = []
+    for preset in (None, "0,0", "40,8", "1,64"):
+        if preset is None:
+            monkeypatch.delenv("RPTR_TRAVERSE_PRESET", raising=False)
+        else:
+            monkeypatch.setenv("RPTR_TRAVERSE_PRESET", preset)
+        img, st, _ = gpu_render(forest, 200, 120, 2, abi.VARIANT_GLTF, count=True)
+        out.append((img, int(st.raw.rays_closest), int(st.raw.rays_shadow), int(st.raw.nodes_visited), int(st.raw.tris_tested)))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0].view(np.uint32), other[0].view(np.uint32)) and out[0][1:] == other[1:]
+
+
 def test_regrouping_by_material_does_not_change_the_image(small_scenes, monkeypatch):
     """north_star's regrouping of rays by material, fused into the shade kernel's LDS compaction (RPTR_REGROUP=1; off by default: it costs
     6 % of the shade time on C3 with 48 textured materials and gains nothing, profiles/r03_notes.md): a path's result does not depend on
