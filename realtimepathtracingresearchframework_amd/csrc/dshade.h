@@ -57,6 +57,7 @@ struct RpScene {
     const RpTexture *textures;
     const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)
     int32_t node_min, refill_min; // scheduling thresholds of the traversal for this scene (dtraverse.h), 0 = the compile-time defaults
+    int32_t lds_top, _pad_lds;    // RPTR_LDS_TOP=1: launch the traversal instantiations that stage the top of the tree in LDS (k_extend.hip)
 };
 
 // Division of a 31-bit number by a frame constant (tiles per row, rows per stripe, padded pixels per sample slot) without the ~25

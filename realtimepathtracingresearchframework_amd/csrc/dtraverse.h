@@ -149,8 +149,16 @@ __device__ unsigned long long rp_prof[16];
 struct RpNoAlpha {
     RP_DEV bool operator()(uint32_t, int, int, int, int, float, float) const { return false; }
 };
+// LDSTOP (north_star: "LDS-staged node tiles"; RPTR_LDS_TOP=1, off by default): the first LDSTOP nodes of the node array -- trees are laid
+// out breadth first, so these are the top levels, a third of all node visits on the height field for 64 nodes -- are copied into LDS when
+// the block starts, and a node step reads nodes below that index from there (ds_read_b128) instead of through the vector cache. Measured
+// (profiles/r03_notes.md section 8): no gain -- the top of the tree is what the L1 serves best (many lanes of a wave read the same line)
+// -- which is why it is a separate instantiation that the default launches never touch.
+#ifndef RP_LDS_TOP_NODES
+#define RP_LDS_TOP_NODES 64
+#endif
 template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN),
-          bool ALPHA = false, bool SINGLE = false, bool LOCAL = false, class Load, class Done, class Alpha>
+          bool ALPHA = false, bool SINGLE = false, bool LOCAL = false, int LDSTOP = 0, class Load, class Done, class Alpha>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
                           uint32_t &n_nodes, uint32_t &n_tris) {
     __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
@@ -160,6 +168,13 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     const uint32_t node_min = sc.node_min > 0 ? (uint32_t)sc.node_min : (uint32_t)NODE_MIN;
     const uint32_t refill_min = sc.refill_min > 0 ? (uint32_t)sc.refill_min : (uint32_t)REFILL_MIN;
     const uint32_t tid = threadIdx.x;
+    __shared__ float4 lds_top[LDSTOP > 0 ? LDSTOP * 4 : 1];
+    if (LDSTOP > 0) { // stage the top of the tree (whole block; the caller's threads all get here)
+        const uint32_t n_top = min((uint32_t)LDSTOP, sc.num_nodes);
+        const float4 *src = reinterpret_cast<const float4 *>(sc.nodes);
+        for (uint32_t k = threadIdx.x; k < n_top * 4u; k += blockDim.x) lds_top[k] = src[k];
+        __syncthreads();
+    }
     const uint32_t gstride = gridDim.x * blockDim.x;
     int *const glob = gstack + (blockIdx.x * blockDim.x + tid);
     const uint32_t lane = rp_lane_id();
@@ -300,10 +315,23 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             int top = 0;
             if (!stack_slow) top = lds_stack[(sp - 1) * RP_TRAVERSE_BLOCK + tid]; // read ahead: the item a miss would pop
             const char *np = node_base + (uint32_t(cur) << 6);
-            const float4 n0 = *reinterpret_cast<const float4 *>(np);      // origin.xyz, exp bytes
-            const uint4 n1 = *reinterpret_cast<const uint4 *>(np + 16);   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
-            const uint4 n2 = *reinterpret_cast<const uint4 *>(np + 32);   // qhi.y qhi.z child0 child1
-            const uint2 n3 = *reinterpret_cast<const uint2 *>(np + 48);   // child2 child3
+            float4 n0;  // origin.xyz, exp bytes
+            uint4 n1;   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
+            uint4 n2;   // qhi.y qhi.z child0 child1
+            uint2 n3;   // child2 child3
+            if (LDSTOP > 0 && uint32_t(cur) < (uint32_t)LDSTOP) {
+                const float4 *lp = lds_top + (uint32_t(cur) << 2);
+                n0 = lp[0];
+                const float4 a1 = lp[1], a2 = lp[2], a3 = lp[3];
+                n1 = make_uint4(__float_as_uint(a1.x), __float_as_uint(a1.y), __float_as_uint(a1.z), __float_as_uint(a1.w));
+                n2 = make_uint4(__float_as_uint(a2.x), __float_as_uint(a2.y), __float_as_uint(a2.z), __float_as_uint(a2.w));
+                n3 = make_uint2(__float_as_uint(a3.x), __float_as_uint(a3.y));
+            } else {
+                n0 = *reinterpret_cast<const float4 *>(np);
+                n1 = *reinterpret_cast<const uint4 *>(np + 16);
+                n2 = *reinterpret_cast<const uint4 *>(np + 32);
+                n3 = *reinterpret_cast<const uint2 *>(np + 48);
+            }
             if (COUNT) n_nodes++;
             const uint32_t ex = __float_as_uint(n0.w);
             // plane distance t = q * A + B with A = step / d, B = (origin - o) / d

@@ -5,6 +5,13 @@ void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, boo
                       const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     // the point set only enters through the camera rays (FIRST) and the alpha test's generator (ALPHA)
     const bool t = table && (first || alpha);
+    if (sc.lds_top && !count && !alpha && single && !t) { // RPTR_LDS_TOP=1: the instantiation with the top of the tree staged in LDS
+        if (first)
+            rp_launch_kernel(l, rp_k_extend_ldstop<true>, RP_TRAVERSE_BLOCK, sc, f, ps, queue, bc, ctr, gstack);
+        else
+            rp_launch_kernel(l, rp_k_extend_ldstop<false>, RP_TRAVERSE_BLOCK, sc, f, ps, queue, bc, ctr, gstack);
+        return;
+    }
     rp_pick(count, [&](auto C) {
         rp_pick(first, [&](auto F) {
             rp_pick(alpha, [&](auto A) {
@@ -21,6 +28,10 @@ void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, boo
 
 void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
                        RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+    if (sc.lds_top && !count && !alpha && single) {
+        rp_launch_kernel(l, rp_k_connect_ldstop<RP_LDS_TOP_NODES>, RP_TRAVERSE_BLOCK, sc, f, ps, sq, bc, ctr, gstack);
+        return;
+    }
     rp_pick(count, [&](auto C) {
         rp_pick(alpha, [&](auto A) {
             rp_pick(single, [&](auto S) {

@@ -142,7 +142,7 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir) {
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
 // SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
 // LOCAL: `queue` / `cursor` are a block-local list and its cursor in LDS (rp_k_tail).
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE>
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE, int LDSTOP = 0>
 RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const uint32_t *queue, uint32_t n, uint32_t *cursor, RpCounters *ctr,
                            int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
@@ -188,7 +188,7 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, lane_rng);
     };
-    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE, LOCAL>(
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE, LOCAL, LDSTOP>(
         sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
@@ -204,12 +204,19 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathStat
                                                int *gstack) {
     rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false, TABLE>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
 }
+// the same with the top of the tree staged in LDS (dtraverse.h LDSTOP; RPTR_LDS_TOP=1): plain scenes only (one instance record, no alpha
+// test, the LCG point set)
+template <bool FIRST>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_extend_ldstop(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+                                                      int *gstack) {
+    rp_extend_body<false, FIRST, false, true, false, false, RP_LDS_TOP_NODES>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
+}
 
 // ------------------------------------------------------------------ connect (shadow rays), persistent waves
 // ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
 // instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
 // ids: the compacted path ids of the shadow rays (sq.ids, or the tail kernel's block-local list: LOCAL)
-template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL>
+template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL, int LDSTOP = 0>
 RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *ids, uint32_t n, uint32_t *cursor,
                             RpCounters *ctr, int *gstack) {
     uint32_t n_nodes = 0, n_tris = 0;
@@ -244,7 +251,7 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
             ps.illum[p] = il;
         }
     };
-    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
+    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL, LDSTOP>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -257,6 +264,10 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
 template <bool COUNT, bool ALPHA, bool SINGLE>
 __global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     rp_connect_body<COUNT, ALPHA, SINGLE, false>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
+}
+template <int LDSTOP>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_connect_ldstop(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+    rp_connect_body<false, false, true, false, LDSTOP>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
 }
 
 // ------------------------------------------------------------------ shade

@@ -1884,6 +1884,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         }
         h->master.dscene.node_min = std::max(0, std::min(64, node_min));
         h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
+        h->master.dscene.lds_top = (getenv("RPTR_LDS_TOP") && atoi(getenv("RPTR_LDS_TOP")) != 0) ? 1 : 0;
     }
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;

@@ -171,6 +171,32 @@ def test_traversal_thresholds_follow_the_tree_and_change_no_bit(monkeypatch):
         assert np.array_equal(out[0][0].view(np.uint32), other[0].view(np.uint32)) and out[0][1:] == other[1:]
 
 
+def test_lds_staged_top_of_the_tree_changes_no_bit(monkeypatch):
+    """north_star's "LDS-staged node tiles" (RPTR_LDS_TOP=1: the first 64 nodes of the breadth-first node array are copied into LDS when a
+    traversal block starts and read from there; a separate instantiation of the closest-hit / shadow kernels for plain single-instance
+    scenes; off by default -- it does not pay, profiles/r03_notes.md section 8): same image and ray counts bit for bit, one frame at a time
+    and with frames in flight"""
+    s = scenes.grid(200, 100, with_emitters=True)
+    W, H, spp = 256, 144, 3
+    out = []
+    for top in ("0", "1"):
+        monkeypatch.setenv("RPTR_LDS_TOP", top)
+        img, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+        r = backend.RenderHip(frames_in_flight=3)
+        r.initialize(W, H)
+        r.set_scene(s)
+        cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
+        tickets = [r.render_async(cfg, spp=spp) for _ in range(3)]
+        for t in tickets:
+            r.wait(t)
+        img2 = np.zeros((H, W, 4), np.float32)
+        r.readback_framebuffer(img2)
+        r.close()
+        out.append((img, img2, int(st.raw.rays_closest), int(st.raw.rays_shadow)))
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert out[0][2:] == out[1][2:] and out[0][3] > 0
+
+
 def test_regrouping_by_material_does_not_change_the_image(small_scenes, monkeypatch):
     """north_star's regrouping of rays by material, fused into the shade kernel's LDS compaction (RPTR_REGROUP=1; off by default: it costs
     6 % of the shade time on C3 with 48 textured materials and gains nothing, profiles/r03_notes.md): a path's result does not depend on
