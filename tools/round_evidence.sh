@@ -1,5 +1,5 @@
-# final evidence of the round: the GPU suite, then the bench lines of every config on the final build (profiles/r03g_*)
-O=gpurun_out/r03g; mkdir -p $O
+# tools/round_evidence.sh [tag]: the GPU suite, then the bench lines of every config on the current build -> gpurun_out/<tag>/ (profiles/r03g_* came from it)
+TAG=${1:-r03g}; O=gpurun_out/$TAG; mkdir -p $O
 timeout 2700 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1; tail -4 $O/gpu_suite.log
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_default_steps20.json 2>/dev/null
@@ -10,8 +10,8 @@ python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_
 python3 bench.py --no-cpu-baseline --animate --width 3840 --height 2160 --spp 2 > $O/bench_c5.json 2>/dev/null
 for n in 2 4 8; do python3 bench.py --no-cpu-baseline --emulate-world $n > $O/bench_emulated_world$n.json 2>/dev/null; done
 python3 bench.py --gpus 2 --same-device --steps 40 --no-cpu-baseline > $O/bench_gpus2_same_device.json 2> $O/bench_gpus2_same_device.err
-bash tools/prof.sh r03g_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1
-cp gpurun_out/prof_r03g_pipelined/*kernel_stats.csv $O/kernel_stats_pipelined_steps200.csv 2>/dev/null
+bash tools/prof.sh ${TAG}_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1
+cp gpurun_out/prof_${TAG}_pipelined/*kernel_stats.csv $O/kernel_stats_pipelined_steps200.csv 2>/dev/null
 python3 - $O <<'PY'
 import json,sys,glob,os
 for f in sorted(glob.glob(sys.argv[1]+"/bench_*.json")):
