@@ -63,7 +63,8 @@ def parse_args():
                     help="forest = SURVEY 8d C4: 10 tree meshes x 10k triangles, 1000 instances (10M instanced triangles)")
     ap.add_argument("--flatten", type=int, default=-1,
                     help="RPTR_FLATTEN: build a static multi-instance scene as one world-space tree (memory for speed). Default: on "
-                         "for --scene forest (10 M instanced triangles = 0.6 GB), off otherwise")
+                         "for a static scene (the forest's 10 M instanced triangles = 0.6 GB; the grid + its emitter mesh of --lights), "
+                         "off with --animate (a dynamic mesh keeps its own tree for the refit)")
     ap.add_argument("--animate", action="store_true",
                     help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
                          "(inside the timed region) and renders")
@@ -198,13 +199,13 @@ def workload_key(args, world=1):
     if world != 1 or args.emulate_world > 1 or args.grid != "1000x500" or args.rebuild_budget != 0:
         return None
     size = (args.width, args.height, args.spp)
-    flat = args.flatten if args.flatten >= 0 else (1 if args.scene == "forest" else 0)
+    flat = args.flatten if args.flatten >= 0 else (0 if args.animate else 1)
     if args.scene == "forest":
         return ("c4_flat" if flat else "c4_two_level") if (size == (1920, 1080, 4) and args.variant == "diffuse" and not args.lights and not args.animate) else None
     if args.animate:
         return "c5" if (size == (3840, 2160, 2) and args.variant == "diffuse" and not args.lights) else None
     if args.lights:
-        return "c3" if (size == (1920, 1080, 8) and args.variant == "gltf") else None
+        return ("c3" if flat else "c3_two_level") if (size == (1920, 1080, 8) and args.variant == "gltf") else None
     return "c2" if (size == (1920, 1080, 4) and args.variant == "diffuse") else None
 
 
@@ -309,7 +310,7 @@ def main():
 
     # one explicit stream for torch AND the backend: the animation kernel, the tile copy and torch's gather (--gather torch) are ordered
     # with the frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream".)
-    flatten = args.flatten if args.flatten >= 0 else (1 if args.scene == "forest" else 0)
+    flatten = args.flatten if args.flatten >= 0 else (0 if args.animate else 1)
     os.environ["RPTR_FLATTEN"] = str(flatten)
     torch_stream = torch.cuda.Stream()
     torch.cuda.set_stream(torch_stream)

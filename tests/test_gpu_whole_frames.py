@@ -4,7 +4,8 @@ tests of rounds 1-2 compared bands of 12-16 rows of 1080; the oracle renders a w
   C1  Cornell box (32 triangles), 256x256, 1 spp, through `bin/rptr_hip --validation <prefix> --validation-spp 1 --pfm`
       (libapp/app_state.cpp:464-481: <prefix>_%04d.pfm of the float accumulation buffer)
   C2  procedural 1 M-triangle mesh, 1920x1080, 4 spp, diffuse-only BSDF
-  C3  the same scene + 512 emissive triangles, glTF BSDF + binned-RIS NEE, 1920x1080, 8 spp
+  C3  the same scene + 512 emissive triangles, glTF BSDF + binned-RIS NEE, 1920x1080, 8 spp: two-level AND as one flattened tree
+      (what bench.py times)
   C4  10 M-triangle instanced forest, 1920x1080, 4 spp: the two-level tree against the oracle's own tree AND the flattened
       world-space tree against the oracle walking the exported tree
   C5  animated 1 M-triangle scene, 3840x2160, 2 spp, after the last of several per-frame refits
@@ -82,15 +83,22 @@ def test_c2_whole_frame_1m_triangles_1080p_4spp_diffuse():
 
 
 # ---------------------------------------------------------------- C3
-def test_c3_whole_frame_gltf_area_lights_1080p_8spp():
+@pytest.mark.parametrize("flatten", [0, 1])
+def test_c3_whole_frame_gltf_area_lights_1080p_8spp(flatten, monkeypatch):
+    """flatten=1 is what bench.py times: the height field and the emitter mesh (two identity instances) in ONE tree instead of a top level
+    over two bottom-level trees. An identity transform moves no vertex, so the oracle's own tree finds the same hits either way."""
+    monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
     s = scenes.grid_1m_lights()
-    assert s.num_tris() == 1_000_512 and len(s.lights) >= 512
+    assert s.num_tris() == 1_000_512 and len(s.lights) >= 512 and len(s.instances) == 2
     W, H, spp = 1920, 1080, 8
-    got, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+    got, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
+    info = r.bvh_build_info()
+    r.close()
+    print("C3 flatten=%d: %s" % (flatten, info))
     osc = O.OracleScene(s)
     osc.build_bvh()
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF)
-    compare_whole_frame("C3 grid-1M glTF + 512 emitters", got, ref, st, ost)
+    compare_whole_frame("C3 grid-1M glTF + 512 emitters (%s)" % ("one flattened tree" if flatten else "two-level"), got, ref, st, ost)
 
 
 # ---------------------------------------------------------------- C4

@@ -9,11 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-KEYS=${@:-c2 c3 c4_flat c4_two_level c5}
+KEYS=${@:-c2 c3 c3_two_level c4_flat c4_two_level c5}
 args_of() {
   case $1 in
     c2) echo "" ;;
     c3) echo "--lights --variant gltf --spp 8" ;;
+    c3_two_level) echo "--lights --variant gltf --spp 8 --flatten 0" ;;
     c4_flat) echo "--scene forest" ;;
     c4_two_level) echo "--scene forest --flatten 0" ;;
     c5) echo "--animate --width 3840 --height 2160 --spp 2" ;;
@@ -25,7 +26,7 @@ args_of() {
 tail_of() {
   case $1 in
     c2) echo 2 ;;
-    c3|c5) echo 3 ;;
+    c3|c3_two_level|c5) echo 3 ;;
     c4_flat|c4_two_level) echo 5 ;;
     *) echo 2 ;;
   esac

@@ -19,6 +19,7 @@ cp gpurun_out/prof_${TAG}_pipelined/*kernel_stats.csv $O/kernel_stats_pipelined_
 grep '^{' gpurun_out/prof_${TAG}_pipelined/bench.log | tail -1 > $O/bench_under_rocprof_steps200.json
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 > $O/bench_c3.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 --flatten 0 > $O/bench_c3_two_level.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4.json 2>/dev/null
 RPTR_BVH_BUILDER=host python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4_host_built_tree.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_level.json 2>/dev/null

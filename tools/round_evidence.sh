@@ -4,6 +4,7 @@ timeout 2700 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1; tail -4 $
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_default_steps20.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 > $O/bench_c3.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 --flatten 0 > $O/bench_c3_two_level.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4.json 2>/dev/null
 RPTR_BVH_BUILDER=host python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4_host_built_tree.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_level.json 2>/dev/null
