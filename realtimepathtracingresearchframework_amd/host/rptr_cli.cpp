@@ -7,7 +7,7 @@
 //   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
 //            [--config file.ini]... [--keyframe [<seconds>:]file.ini]... [--camera n] [--freeze-frame] [--upscale n] [--backend hip]
 //            [--sky-data <dir with the Hosek-Wilkie data headers>]   (Sun settings of the .ini files refit the sky: host/sky_fit.hpp; also RPTR_SKY_DATA)
-//            [--rng-variant uniform|bn|sobol|z-sobol] [--bn-table BNData.u32] [--force-bvh-rebuild] [--rebuild-triangle-budget n]
+//            [--rng-variant uniform|bn|sobol|z-sobol] [--bn-table bn_tables.h|BNData.u32] [--force-bvh-rebuild] [--rebuild-triangle-budget n]
 //            [--devices n | --devices a,b,c] [--stripe-rows r]
 //
 // --config / --keyframe read the reference's .ini files (ini_config.hpp); in profiling mode every keyframe is held for its length
@@ -399,7 +399,7 @@ int main(int argc, char **argv) {
         if (rng_variant > 0) {
             const std::string matrices = data_dir() + "/sobol_matrices_1024x32.u32";
             if (rng_variant == RPTR_RNG_VARIANT_BN)
-                backend.set_rng_variant(rng_variant, bn_table_path.empty() ? rptr::white_noise_bn_table(matrices) : rptr::read_u32_file(bn_table_path));
+                backend.set_rng_variant(rng_variant, bn_table_path.empty() ? rptr::white_noise_bn_table(matrices) : rptr::read_bn_table(bn_table_path));
             else
                 backend.set_rng_variant(rng_variant, rptr::sobol_table(matrices));
         }

@@ -7,7 +7,9 @@
   an Owen-scrambled 256-sample sequence, and per-pixel scrambling keys optimised for a blue-noise error distribution); they are data
   an integration hands to `rptr_hip_set_rng_variant` as they are. `white_noise_bn_table` builds a table of the same layout without the
   optimisation (a digitally shifted Sobol' sequence and random keys): every pixel still gets a well-distributed sequence, the error is
-  white instead of blue in screen space. Tests use it for parity of the lookup arithmetic.
+  white instead of blue in screen space. Tests use it for parity of the lookup arithmetic. The optimised tables themselves stay where
+  they are: `bn_table_from_header` reads the C arrays of the reference's `rendering/pointsets/bn_tables.h` at run time (`RPTR_BN_DATA=<that
+  file>`, CLI `--bn-table <that file>`), the way `sky_fit.py` reads the Hosek-Wilkie coefficient headers.
 
 Host-side only: nothing here touches the GPU.
 """
@@ -79,10 +81,51 @@ def white_noise_bn_table(seed=1):
     return t
 
 
+# the arrays of bn_tables.h in the order BNData lays them out (bn_data.h:12-27; the 1 spp ranking keys are all zero and have no member)
+BN_HEADER_ARRAYS = ("sobol_256spp_256d", "scramblingTile_yx_d_1spp", "scramblingTile_yx_d_4spp", "rankingTile_yx_d_4spp",
+                    "scramblingTile_yx_d_16spp", "rankingTile_yx_d_16spp", "scramblingTile_yx_d_256spp", "rankingTile_yx_d_256spp")
+
+
+def read_bn_tables_header(path):
+    """{array name: uint32 words} of every `static const int name[...] = {...};` in a C header of blue-noise tables
+    (the reference's rendering/pointsets/bn_tables.h, or Heitz et al.'s published samplerBlueNoiseErrorDistribution_*.cpp)"""
+    import re
+    with open(path, "r") as f:
+        txt = f.read()
+    out = {}
+    for m in re.finditer(r"static\s+const\s+int\s+(\w+)\s*\[[^\]]*\]\s*=\s*\{([^}]*)\}", txt):
+        out[m.group(1)] = np.array(re.findall(r"\d+", m.group(2)), dtype=np.uint32)
+    return out
+
+
+def bn_table_from_header(path):
+    """BNData (bn_data.h:12-27) as uint32 words from the arrays of `path`: what render_vulkan.cpp uploads for RNG_VARIANT_BN"""
+    arrs = read_bn_tables_header(path)
+    sizes = {"sobol_256spp_256d": BN_SAMPLES * BN_DIMS}
+    parts = []
+    for name in BN_HEADER_ARRAYS:
+        if name not in arrs:
+            raise RuntimeError("%s: no array `%s`" % (path, name))
+        want = sizes.get(name, BN_TILE * BN_TILE * BN_SCR_DIMS)
+        if arrs[name].size != want:
+            raise RuntimeError("%s: `%s` has %d values, expected %d" % (path, name, arrs[name].size, want))
+        if int(arrs[name].max()) > 255:
+            raise RuntimeError("%s: `%s` holds values above 255" % (path, name))
+        parts.append(arrs[name])
+    rank1 = arrs.get("rankingTile_yx_d_1spp")
+    if rank1 is not None and np.any(rank1 != 0):   # bn_data.h:17: BNData has no such member because the keys are { 0 }
+        raise RuntimeError("%s: the 1 spp ranking keys are not all zero: not the table set BNData expects" % path)
+    t = np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+    assert t.nbytes >= abi.BN_TABLE_MIN_BYTES
+    return t
+
+
 def default_table(rng_variant, seed=1):
     """the table `HipBackend.set_rng_variant` uploads when the caller passes none"""
     if rng_variant in (abi.RNG_VARIANT_SOBOL, abi.RNG_VARIANT_Z_SBL):
         return sobol_table()
     if rng_variant == abi.RNG_VARIANT_BN:
+        if os.environ.get("RPTR_BN_DATA"):   # the optimised tables, read from the header an installation of the reference holds
+            return bn_table_from_header(os.environ["RPTR_BN_DATA"])
         return white_noise_bn_table(seed)
     return None

@@ -229,3 +229,86 @@ def test_low_discrepancy_points_beat_the_uniform_generator_on_a_smooth_image():
         err[name] = float(np.sqrt(np.mean((img[..., :3] - ref) ** 2)))
     osc.close()
     assert err["sobol"] < err["uniform"] and err["z_sobol"] < err["uniform"], err
+
+
+# ------------------------------------------------------------------ the optimised blue-noise tables (reference data, read where they lie)
+REF_BN = "/root/reference/rendering/pointsets/bn_tables.h"
+needs_ref_bn = pytest.mark.skipif(not os.path.exists(REF_BN), reason="the reference's bn_tables.h is not on this machine")
+
+
+def _low_frequency_share(img, radius=10):
+    """share of the spectrum's energy (mean removed) below `radius` cycles per tile: ~ pi r^2 / n^2 for white noise"""
+    n = img.shape[0]
+    f = np.fft.fftshift(np.abs(np.fft.fft2(img - img.mean())) ** 2)
+    yy, xx = np.mgrid[-n // 2:n // 2, -n // 2:n // 2]
+    return float(f[np.sqrt(xx * xx + yy * yy) < radius].sum() / f.sum())
+
+
+@needs_ref_bn
+def test_the_references_blue_noise_header_parses_into_bndata():
+    """bn_data.h:12-27 / vulkan/pointsets/render_bn.cpp:84-104: sobol_spp_d, then scrambling (+ ranking above 1 spp) keys per optimised spp"""
+    arrs = pointsets.read_bn_tables_header(REF_BN)
+    assert set(pointsets.BN_HEADER_ARRAYS) <= set(arrs) and "rankingTile_yx_d_1spp" in arrs
+    t = pointsets.bn_table_from_header(REF_BN)
+    assert t.dtype == np.uint32 and t.size == 256 * 256 + 7 * 128 * 128 * 8 and t.nbytes >= abi.BN_TABLE_MIN_BYTES and int(t.max()) == 255
+    at = 0
+    for name in pointsets.BN_HEADER_ARRAYS:
+        assert np.array_equal(t[at:at + arrs[name].size], arrs[name]), name
+        at += arrs[name].size
+    assert not arrs["rankingTile_yx_d_1spp"].any() and int(arrs["rankingTile_yx_d_4spp"].max()) == 3 and int(arrs["rankingTile_yx_d_16spp"].max()) == 15
+    # every dimension of the 256-sample sequence is a permutation of the 256 byte values (an Owen-scrambled (0, 8, 1)-net in base 2)
+    seq = t[:65536].reshape(256, 256)
+    assert all(np.array_equal(np.sort(seq[:, d]), np.arange(256)) for d in range(256))
+
+
+@needs_ref_bn
+def test_cpp_reader_of_the_blue_noise_header_equals_the_python_reader(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "bn.cpp"
+    src.write_text('#include "realtimepathtracingresearchframework_amd/host/pointsets.hpp"\n'
+                   'int main(int argc, char **argv) { try { const std::vector<uint32_t> t = rptr::read_bn_table(argv[1]);\n'
+                   '  std::FILE *f = std::fopen(argv[2], "wb"); std::fwrite(t.data(), 4, t.size(), f); std::fclose(f); return 0; }\n'
+                   '  catch (const std::exception &e) { std::fprintf(stderr, "%s\\n", e.what()); return 1; } }\n')
+    exe = str(tmp_path / "bn")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + root, str(src), "-o", exe])
+    out = str(tmp_path / "BNData.u32")
+    subprocess.check_call([exe, REF_BN, out])
+    t = pointsets.bn_table_from_header(REF_BN)
+    assert np.array_equal(np.fromfile(out, dtype="<u4"), t)
+    out2 = str(tmp_path / "again.u32")   # ... and the raw words are accepted as they are
+    subprocess.check_call([exe, out, out2])
+    assert np.array_equal(np.fromfile(out2, dtype="<u4"), t)
+    bad = tmp_path / "short.h"
+    bad.write_text("static const int sobol_256spp_256d[4] = {1,2,3,4};\n")
+    p = subprocess.run([exe, str(bad), out2], capture_output=True, text=True)
+    assert p.returncode == 1 and "expected 65536" in p.stderr
+
+
+@needs_ref_bn
+def test_oracle_draws_from_the_real_tables_are_blue_noise_in_screen_space(osc):
+    """The lookup (oracle/oshade.h = bn_rng.glsl:31-75) fed with the REAL tables: the 1 spp draws of a dimension over a 128 x 128 tile are a
+    blue-noise mask -- almost no energy at low frequencies (5e-5 of the spectrum below 10 cycles per tile; white noise: 2e-2). Any mistake
+    in the layout (pixel = x + 128 y, 8 keys per pixel, BNData's member order) or in the mask shifts of later dimensions / frames turns
+    the mask white. The stand-in table, read by the same code, is white by construction."""
+    real, stand_in = pointsets.bn_table_from_header(REF_BN), pointsets.white_noise_bn_table(2)
+    W = 640
+
+    def mask(frame_id, set_dim, dim, x0=0, y0=0):
+        img = np.zeros((128, 128), np.float32)
+        for y in range(128):
+            for x in range(128):
+                img[y, x] = osc.pointset_probe(0, 0, frame_id, x0 + x, y0 + y, W, set_dim, [dim])[0][0]
+        return img
+    osc.set_rng_variant(abi.RNG_VARIANT_BN, real)
+    shares = {}
+    for (frame_id, set_dim, dim, x0, y0) in ((0, 0, 0, 0, 0), (0, 0, 7, 128, 0), (0, 8, 3, 0, 128), (1, 0, 2, 256, 128), (3, 6, 5, 0, 0)):
+        m = mask(frame_id, set_dim, dim, x0, y0)
+        assert m.min() > 0.0 and m.max() < 1.0
+        assert abs(float(m.mean()) - 0.5) < 0.01 and abs(float(m.std()) - 12 ** -0.5) < 0.01   # uniform over the tile
+        shares[(frame_id, set_dim, dim)] = _low_frequency_share(m)
+    osc.set_rng_variant(abi.RNG_VARIANT_BN, stand_in)
+    white = _low_frequency_share(mask(0, 0, 0))
+    osc.set_rng_variant(abi.RNG_VARIANT_UNIFORM)
+    print("low-frequency share of the draws' spectrum: real tables", {k: round(v, 6) for k, v in shares.items()}, " stand-in %.4f" % white)
+    assert max(shares.values()) < 1e-3 and white > 5e-3, (shares, white)
