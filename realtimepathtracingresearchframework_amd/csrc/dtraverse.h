@@ -130,6 +130,9 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_SPEC
 #define RP_SPEC 0
 #endif
+#ifndef RP_SENTINEL_INLINE
+#define RP_SENTINEL_INLINE 1
+#endif
 #ifndef RP_FETCH_DIV
 #define RP_FETCH_DIV 1u // a wave is dealt about 1/RP_FETCH_DIV of its fair share at a time
 #endif
@@ -236,6 +239,12 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         neg_x = __float_as_int(inv.x) < 0;
         neg_y = __float_as_int(inv.y) < 0;
         neg_z = __float_as_int(inv.z) < 0;
+    };
+    auto leave_instance = [&]() { // the sentinel under an instance's entries: the query goes on in world space
+        cur_inst = -1;
+        cur_inst_id = -1;
+        set_ray(ro, rd);
+        cur = pop();
     };
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
@@ -410,6 +419,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 sp -= (v0 || v1 || v2 || v3) ? 0 : 1;
             }
             cur = nxt;
+            // the bottom-level tree is done: back to the top level right here (a few instructions for the lanes concerned) instead of
+            // parking the lane until the wave's next leaf phase
+            if (!SINGLE && RP_SENTINEL_INLINE && cur == RP_SENTINEL) leave_instance();
             }
         }
 #ifdef RP_PROF
@@ -444,10 +456,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         // ---- one leaf / sentinel item. A BLAS leaf (two triangles = 96 bytes) and a TLAS leaf (the first 64 bytes of
         // an instance record) are fetched by the same six loads, so that a phase with both kinds costs one round trip.
         if (!SINGLE && cur == RP_SENTINEL) {
-            cur_inst = -1;
-            cur_inst_id = -1;
-            set_ray(ro, rd);
-            cur = pop();
+            leave_instance();
         } else if (SPEC ? pend != 0 : (cur < 0 && cur != RP_EXIT)) {
             const int leaf_ref = SPEC ? pend : cur;
             const int first = RPTR_BVH_LEAF_FIRST(leaf_ref);
@@ -536,8 +545,10 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 if (SPEC) { // the item the lane went on with stays; an occluded ray drops it
                     pend = 0;
                     if (ANY && any_hit) cur = RP_EXIT;
-                } else
+                } else {
                     cur = (ANY && any_hit) ? RP_EXIT : pop();
+                    if (!SINGLE && RP_SENTINEL_INLINE && cur == RP_SENTINEL) leave_instance();
+                }
             }
         }
         if (active && cur == RP_EXIT && (!SPEC || pend == 0)) {
