@@ -24,9 +24,11 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Op { FMA, PK_FMA, CVT_UBYTE, MIN3, MAX_F, CNDMASK, MUL, ADD_U32, RCP, SQRT, NODE_MIX, FMA_SALU, N_OPS };
+enum Op { FMA, PK_FMA, CVT_UBYTE, MIN3, MAX_F, CNDMASK, MUL, ADD_U32, RCP, SQRT, NODE_MIX, FMA_SALU, FMA_MIX, CVT_F16, CVT_U32, BFE_U32, NODE_MIX_F16, N_OPS };
 static const char *op_names[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_min3_f32", "v_max_f32", "v_cndmask_b32", "v_mul_f32",
-                                      "v_add_u32", "v_rcp_f32", "v_sqrt_f32", "node_step_mix(24 cvt,12 pk_fma,18 minmax,14 cndmask,12 add/and)", "v_fma_f32 + s_add_u32 (1:1)"};
+                                      "v_add_u32", "v_rcp_f32", "v_sqrt_f32", "node_step_mix(24 cvt,12 pk_fma,18 minmax,14 cndmask,12 add/and)", "v_fma_f32 + s_add_u32 (1:1)",
+                                      "v_fma_mix_f32 (f16 x f32 + f32)", "v_cvt_f32_f16", "v_cvt_f32_u32", "v_bfe_u32",
+                                      "node_step_mix with f16 planes(24 fma_mix,18 minmax,14 cndmask,12 add/and)"};
 
 // one instruction on accumulator `a` (and, where it needs them, constants b, c). All streams are independent across the 8 accumulators.
 #define I_FMA(a)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
@@ -39,6 +41,10 @@ static const char *op_names[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ub
 #define I_ADDU(a)     asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
 #define I_RCP(a)      asm volatile("v_rcp_f32 %0, %0" : "+v"(a));
 #define I_SQRT(a)     asm volatile("v_sqrt_f32 %0, %0" : "+v"(a));
+#define I_FMAMIX(a)   asm volatile("v_fma_mix_f32 %0, %0, %1, %2 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(b), "v"(c));
+#define I_CVTH(a)     asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a));
+#define I_CVTU(a)     asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a));
+#define I_BFE(a)      asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a));
 #define I_SALU(s)     asm volatile("s_add_u32 %0, %0, 1" : "+s"(s));
 
 #define R8(M) M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
@@ -74,6 +80,16 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
             R8(I_CND) I_CND(a0) I_CND(a1) I_CND(a2) I_CND(a3) I_CND(a4) I_CND(a5)   // 14 v_cndmask
             R8(I_ADDU) I_ADDU(a0) I_ADDU(a1) I_ADDU(a2) I_ADDU(a3)    // 12 integer
         }
+        if (OP == FMA_MIX) { R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX) }
+        if (OP == CVT_F16) { R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) R8(I_CVTH) }
+        if (OP == CVT_U32) { R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) R8(I_CVTU) }
+        if (OP == BFE_U32) { R8(I_BFE) R8(I_BFE) R8(I_BFE) R8(I_BFE) R8(I_BFE) R8(I_BFE) R8(I_BFE) R8(I_BFE) }
+        if (OP == NODE_MIX_F16) { // the node step if the planes were stored as halves: the conversion rides in the fma (68 instructions)
+            R8(I_FMAMIX) R8(I_FMAMIX) R8(I_FMAMIX)
+            R8(I_MIN3) R8(I_MAX) I_MIN3(a0) I_MAX(a1)
+            R8(I_CND) I_CND(a0) I_CND(a1) I_CND(a2) I_CND(a3) I_CND(a4) I_CND(a5)
+            R8(I_ADDU) I_ADDU(a0) I_ADDU(a1) I_ADDU(a2) I_ADDU(a3)
+        }
         if (OP == FMA_SALU) { // 64 VALU + 64 SALU interleaved: does scalar issue take VALU slots of the same wave / SIMD?
 #define FS(a, s) I_FMA(a) I_SALU(s)
             FS(a0, s0) FS(a1, s1) FS(a2, s2) FS(a3, s3) FS(a4, s0) FS(a5, s1) FS(a6, s2) FS(a7, s3)
@@ -96,7 +112,7 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
     }
 }
 
-static int insts_per_iter(int op) { return op == NODE_MIX ? 80 : 64; } // VALU instructions (FMA_SALU: 64 VALU + 64 SALU)
+static int insts_per_iter(int op) { return op == NODE_MIX ? 80 : op == NODE_MIX_F16 ? 68 : 64; } // VALU instructions (FMA_SALU: 64 VALU + 64 SALU)
 
 template <int OP>
 static void launch(int grid, size_t lds, int iters, uint64_t *cyc, float *sink) {
@@ -118,6 +134,11 @@ static void launch_op(int op, int grid, size_t lds, int iters, uint64_t *cyc, fl
     case SQRT: launch<SQRT>(grid, lds, iters, cyc, sink); break;
     case NODE_MIX: launch<NODE_MIX>(grid, lds, iters, cyc, sink); break;
     case FMA_SALU: launch<FMA_SALU>(grid, lds, iters, cyc, sink); break;
+    case FMA_MIX: launch<FMA_MIX>(grid, lds, iters, cyc, sink); break;
+    case CVT_F16: launch<CVT_F16>(grid, lds, iters, cyc, sink); break;
+    case CVT_U32: launch<CVT_U32>(grid, lds, iters, cyc, sink); break;
+    case BFE_U32: launch<BFE_U32>(grid, lds, iters, cyc, sink); break;
+    case NODE_MIX_F16: launch<NODE_MIX_F16>(grid, lds, iters, cyc, sink); break;
     }
 }
 
