@@ -1,5 +1,5 @@
-# tools/round_evidence.sh [tag]: the GPU suite, then the bench lines of every config on the current build -> gpurun_out/<tag>/ (profiles/r03g_* came from it)
-TAG=${1:-r03g}; O=gpurun_out/$TAG; mkdir -p $O
+# tools/round_evidence.sh [tag]: the GPU suite, then the bench lines of every config on the current build -> gpurun_out/<tag>/ (profiles/r03m_* came from it)
+TAG=${1:-r03m}; O=gpurun_out/$TAG; mkdir -p $O
 timeout 2700 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1; tail -4 $O/gpu_suite.log
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_default_steps20.json 2>/dev/null
