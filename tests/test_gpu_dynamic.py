@@ -491,7 +491,9 @@ def test_fuzz_rebuild_of_soups(seed, n_instances):
     res = r.render_ray_queries(q)
     ref = np.zeros_like(res)
     osc.trace(q, bvh_mode=O.BVH_BRUTE, out=ref)
-    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)) and (res[:, 0] >= 0).sum() > 500
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32)), "queries differ from brute force"
+    # (sanity: the random queries do meet the scene; the suite's seeds give > 500 hits, a sparse three-instance soup of the soak a few hundred)
+    assert (res[:, 0] >= 0).sum() > 100, "only %d of the random queries hit anything" % int((res[:, 0] >= 0).sum())
     assert_ray_visit_parity(r, osc, 64, 64, 1, abi.VARIANT_GLTF)
     r.close()
 

@@ -1,6 +1,7 @@
 """tools/soak_dynamic.py [first_seed] [count]: the refit / device-rebuild fuzz tests of tests/test_gpu_dynamic.py over more seeds (GPU).
 (40 seeds, round 2: the only assertion that ever fired is the sanity bound "more than 500 of the 20 000 random queries hit something" on a
-three-instance scene -- results and visit counts never differ.)"""
+three-instance scene -- results and visit counts never differ. Round 3, seeds 300..359: the same, seed 348 with 387 hits; the bound of that
+test is 100 now and says what it is.)"""
 import os
 import sys
 
