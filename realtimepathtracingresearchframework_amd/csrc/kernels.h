@@ -279,6 +279,33 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_connect_ldstop(RpScene sc, RpFrame f, Rp
 // TEX = false: no material of the scene reads a texture (textured parameters, normal maps): sampling code compiled out
 // LOCAL (rp_k_tail): `order` is a block-local list of n <= RP_CHUNK path ids; the survivors and the shadow rays are not
 // published to the global queues but left in shared memory for the caller (local_next / local_shadow, counts in n_next / n_shadow)
+// RP_KERNARG_RELOAD: left alone, the shade kernels keep ~300 scalar values of their by-value arguments (RpFrame, RpScene) alive across the
+// whole loop and spill 200-330 of them into VGPR lanes (v_writelane / v_readlane: VALU instructions, a tenth of the loop's). The loop body
+// therefore reads the two structs from the kernel-argument segment again at three points -- scalar loads from constant memory behind an asm
+// barrier that keeps them from being hoisted -- so that nothing of them has to stay in registers from one stretch to the next: 25 spilled
+// SGPRs instead of 199-330, VGPR spills 44 -> 5 (glTF + lights) and 114 -> 33 (textured), the Lambert kernel 110 -> 97 VGPRs; shade launches
+// -6 % on C3 and on textured scenes, frames -1 % (C2) ... -3 % (C3) (profiles/r03_notes.md section 9). -DRP_KERNARG_RELOAD=0: the old code.
+#ifndef RP_KERNARG_RELOAD
+#define RP_KERNARG_RELOAD 1
+#endif
+template <class T>
+RP_DEV const T &rp_kernarg(uint32_t offset) {
+    typedef const T __attribute__((address_space(4))) *KP;
+    uint64_t a = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr() + offset;
+    asm volatile("" : "+s"(a));
+    return *(const T *)(KP)a;
+}
+// both callers (rp_k_shade, rp_k_tail) start their argument lists with (RpScene sc, RpFrame f, ...): explicit kernel arguments lie in the
+// kernel-argument segment from offset 0 at their natural alignment (the whole-frame parity tests would not survive a wrong offset)
+#define RP_KERNARG_OFF_SC 0u
+#define RP_KERNARG_OFF_F ((uint32_t)((sizeof(RpScene) + alignof(RpFrame) - 1) / alignof(RpFrame) * alignof(RpFrame)))
+#if RP_KERNARG_RELOAD
+#define RP_RELOAD_ARGS                                               \
+    const RpFrame &f = rp_kernarg<RpFrame>(RP_KERNARG_OFF_F);        \
+    const RpScene &sc = rp_kernarg<RpScene>(RP_KERNARG_OFF_SC);
+#else
+#define RP_RELOAD_ARGS
+#endif
 template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE>
 RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
                           uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
@@ -364,6 +391,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
         }
 #pragma unroll 1
         for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
+            RP_RELOAD_ARGS
             const uint32_t il = kk * 256 + threadIdx.x; // position in the regrouped chunk
             bool alive = false;      // path continues with a new ray
             bool has_shadow = false; // a shadow query is issued
@@ -585,6 +613,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             }
             // ---------------- B: next-event estimation
             if (nee) {
+                RP_RELOAD_ARGS
                 V3 nee_l = v3s(0.0f);
                 V3 light_dir = v3s(0.0f);
                 float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
@@ -627,6 +656,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             }
             // ---------------- C: continuation
             if (hit_lane) {
+                RP_RELOAD_ARGS
                 if (!terminate && f.rp.glossy_only_mode != 0 && !(mat.roughness < 0.1f && mat.ior != 1.0f)) terminate = true;
                 if (!terminate) {
                     const uint32_t vertex_dim = rp_bounce_dim(bounce) + 4u; // behind RANDOM_SHIFT_DIM(rng, DIM_LIGHT_END)
