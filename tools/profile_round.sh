@@ -11,7 +11,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 bash tools/valu_issue.sh $TAG > $O/valu_issue_run.txt 2>&1
-bash tools/pmc_workloads.sh $TAG c2 c3 c4_flat c4_two_level c5 > $O/pmc_workloads.txt 2>&1
+bash tools/pmc_workloads.sh $TAG c2 c3 c3_two_level c4_flat c4_two_level c5 > $O/pmc_workloads.txt 2>&1
 bash tools/prof.sh ${TAG}_exclusive --profile-pass --steps 20 --warmup 2 > $O/prof_exclusive.txt 2>&1
 cp gpurun_out/prof_${TAG}_exclusive/*kernel_stats.csv $O/kernel_stats_exclusive_profile_pass.csv 2>/dev/null
 bash tools/prof.sh ${TAG}_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1
