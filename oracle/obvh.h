@@ -450,6 +450,7 @@ static inline void decode_leaf(int enc, int &first, int &count) {
 }
 static bool g_no_single_instance = getenv("RPTR_NO_SINGLE_INSTANCE") != nullptr; // same switch as the device library
 static const bool g_sort_by_distance = getenv("ORC_SORT_BY_DISTANCE") != nullptr; // diagnostic (tools/order_probe.py): a full sort by entry distance instead of the three comparisons
+static const int g_order_key = getenv("ORC_ORDER_KEY") ? atoi(getenv("ORC_ORDER_KEY")) : 0; // diagnostic: 1 = box midpoint along the ray, 2 = unclamped entry (all queries), 3 = exit, 4 = entry then exit, 5 / 6 = ties to the smaller / larger box, 7 = clamped entry (the order of rounds 1-3a)
 static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
 // The reference's any-hit stage (vulkan/pt_megakernel.glsl:153-212, generate_candidate_hit): called for every hit of a
 // triangle flagged RPTR_BVH_TRI_ALPHA that the query would otherwise accept, in the canonical order of this traversal;
@@ -603,18 +604,42 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 // (the device picks entry / exit planes by the sign of the direction instead of min / max: the inverted box of an empty
                 // slot never passes there, so it needs no test of its own; plane distances are finite, see DESIGN.md "Ray query semantics")
                 hit[k] = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
-                entry[k] = hit[k] ? tn : INFINITY;
+                // the order key of a closest-hit query is the entry distance before it is clamped to t_min (csrc/dtraverse.h: boxes the ray
+                // starts inside are still told apart); an occlusion query orders by the clamped one
+                const float tn_unclamped = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fminf(tl[2], th[2]));
+                entry[k] = hit[k] ? (ANY ? tn : tn_unclamped) : INFINITY;
+                if (g_order_key && hit[k]) { // diagnostic (tools/order_probe.py): other visit-order keys than the clamped entry distance
+                    const float tn_raw = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fminf(tl[2], th[2]));
+                    const float tf_raw = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fmaxf(tl[2], th[2]));
+                    entry[k] = g_order_key == 1 ? tn_raw + tf_raw : g_order_key == 2 ? tn_raw : g_order_key == 3 ? tf_raw : g_order_key == 7 ? tn : tn + 1e-3f * tf_raw;
+                }
             }
             // front to back with three comparisons of the entry distances (a miss counts as +inf, ties keep slot order): inside the pair of
             // slots (0,1), inside the pair (2,3), and the pairs against each other by their nearer member (csrc/dtraverse.h does the same
             // with conditional swaps)
             const float *e = entry;
             int order[4] = {0, 1, 2, 3};
+            if (g_order_key == 5 || g_order_key == 6) { // diagnostic: ties of the entry distance (ray origin inside both boxes) go to the smaller (5) / larger (6) box
+                float area[4];
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = float(n.qhi[0][k] - n.qlo[0][k]) * bits_float(uint32_t(n.exp[0]) << 23), dy = float(n.qhi[1][k] - n.qlo[1][k]) * bits_float(uint32_t(n.exp[1]) << 23),
+                                dz = float(n.qhi[2][k] - n.qlo[2][k]) * bits_float(uint32_t(n.exp[2]) << 23);
+                    area[k] = (dx * dy + dy * dz + dz * dx) * (g_order_key == 5 ? 1.0f : -1.0f);
+                }
+                auto less = [&](int a, int b) { return e[a] < e[b] || (e[a] == e[b] && area[a] < area[b]); };
+                if (less(1, 0)) std::swap(order[0], order[1]);
+                if (less(3, 2)) std::swap(order[2], order[3]);
+                if (less(order[2], order[0])) {
+                    std::swap(order[0], order[2]);
+                    std::swap(order[1], order[3]);
+                }
+            } else {
             if (e[1] < e[0]) std::swap(order[0], order[1]);
             if (e[3] < e[2]) std::swap(order[2], order[3]);
             if (fminf(e[2], e[3]) < fminf(e[0], e[1])) {
                 std::swap(order[0], order[2]);
                 std::swap(order[1], order[3]);
+            }
             }
             if (g_sort_by_distance) std::stable_sort(order, order + 4, [&](int a, int b) { return e[a] < e[b]; });
             int visit[4], nv = 0;

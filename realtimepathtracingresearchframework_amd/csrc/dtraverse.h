@@ -13,7 +13,7 @@
 // inner nodes (>= 0), packed leaves (<= -2, include/rptr_bvh.h) and the
 // instance-exit sentinel. Inner node: slab-test the four child boxes against
 // [t_min, best_t] on the node's 8-bit grid (t = fma(q, step/d, (origin-o)/d));
-// the hit children are ordered with three comparisons of their entry distances
+// the hit children are ordered with three comparisons of their entry distances (closest-hit queries: before the clamp to t_min)
 // (a miss counts as +inf; ties keep slot order): inside the pair of slots (0,1),
 // inside the pair (2,3), and the pairs against each other by their nearer member.
 // Continue with the first, push the others so that the first of the rest pops next.
@@ -380,11 +380,17 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 const rp_f2 tx = __builtin_elementwise_fma(rp_mk2((float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu)), ax2, bx2);
                 const rp_f2 ty = __builtin_elementwise_fma(rp_mk2((float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu)), ay2, by2);
                 const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
-                const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+                // closest-hit queries order the children by the entry distance BEFORE it is clamped to t_min: a ray that starts inside several
+                // overlapping boxes (instance boxes of a forest, secondary rays) has the same clamped entry distance for all of them and the
+                // visit order would fall back to slot order -- which is right or wrong by the luck of the builder's left / right (37 or 46
+                // node visits per ray on the instanced forest, depending on nothing but that). The unclamped value -- how far behind the
+                // origin the box begins -- still tells them apart. Occlusion queries keep the clamped key (any hit ends them; measured better).
+                const float tn_raw = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+                const float tn = fmaxf(tn_raw, tmin);
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
                 const bool hit = tn <= tf * 1.0000005f;
                 ref[k] = hit ? ref[k] : RPTR_BVH4_EMPTY;
-                ent[k] = hit ? tn : INFINITY;
+                ent[k] = hit ? (ANY ? tn : tn_raw) : INFINITY;
             }
             // front-to-back order with three comparisons instead of a sorting network over (key, payload) pairs: nearer first inside
             // each pair of slots, then the pair that holds the nearest child first. Against the full sort: +0.5 % node visits on the

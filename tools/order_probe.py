@@ -20,12 +20,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     osc.import_bvh(nodes, tris, insts)
     _, st = osc.render(480, 270, 1, variant=abi.VARIANT_SIMPLE, bvh_mode=O.BVH_IMPORTED, count=True)
     print("%-16s %-8s %8d nodes | closest-hit rays: %.2f nodes %.2f triangles per ray | shadow rays: %.2f nodes %.2f triangles per ray" % (
-        name, "sorted" if os.environ.get("ORC_SORT_BY_DISTANCE") else "pairs", len(nodes) // 16, st.nodes_closest / st.rays_closest,
+        name, ("sorted" if os.environ.get("ORC_SORT_BY_DISTANCE") else "pairs") + (" key " + os.environ["ORC_ORDER_KEY"] if os.environ.get("ORC_ORDER_KEY") else ""), len(nodes) // 16, st.nodes_closest / st.rays_closest,
         st.tris_closest / st.rays_closest, st.nodes_shadow / max(1, st.rays_shadow), st.tris_shadow / max(1, st.rays_shadow)))
     sys.exit(0)
 
 for scene in (sys.argv[1:] or ["grid_1m"]):
-    for sort in (False, True):
+    for sort in ((False,) if os.environ.get("ORC_ORDER_KEY") else (False, True)):
         env = dict(os.environ)
         env.pop("ORC_SORT_BY_DISTANCE", None)
         if sort:
