@@ -450,7 +450,7 @@ static inline void decode_leaf(int enc, int &first, int &count) {
 }
 static bool g_no_single_instance = getenv("RPTR_NO_SINGLE_INSTANCE") != nullptr; // same switch as the device library
 static const bool g_sort_by_distance = getenv("ORC_SORT_BY_DISTANCE") != nullptr; // diagnostic (tools/order_probe.py): a full sort by entry distance instead of the three comparisons
-static const int g_order_key = getenv("ORC_ORDER_KEY") ? atoi(getenv("ORC_ORDER_KEY")) : 0; // diagnostic: 1 = box midpoint along the ray, 2 = unclamped entry (all queries), 3 = exit, 4 = entry then exit, 5 / 6 = ties to the smaller / larger box, 7 = clamped entry (the order of rounds 1-3a)
+static const int g_order_key = getenv("ORC_ORDER_KEY") ? atoi(getenv("ORC_ORDER_KEY")) : 0; // diagnostic: 1 = box midpoint along the ray, 2 = unclamped entry (all queries), 3 = exit, 4 = entry then exit, 5 / 6 = ties to the smaller / larger box, 7 = clamped entry for every query (the order of rounds 1-3a)
 static unsigned long long *g_dead_visits = nullptr; // diagnostic: node visits in which no child box was hit
 // The reference's any-hit stage (vulkan/pt_megakernel.glsl:153-212, generate_candidate_hit): called for every hit of a
 // triangle flagged RPTR_BVH_TRI_ALPHA that the query would otherwise accept, in the canonical order of this traversal;
@@ -603,11 +603,14 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 const float tf = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fminf(fmaxf(tl[2], th[2]), best.t));
                 // (the device picks entry / exit planes by the sign of the direction instead of min / max: the inverted box of an empty
                 // slot never passes there, so it needs no test of its own; plane distances are finite, see DESIGN.md "Ray query semantics")
-                hit[k] = n.child[k] != RPTR_BVH4_EMPTY && tn <= tf * 1.0000005f;
-                // the order key of a closest-hit query is the entry distance before it is clamped to t_min (csrc/dtraverse.h: boxes the ray
-                // starts inside are still told apart); an occlusion query orders by the clamped one
+                // entry <= exit with a 1 + 2^-21 slack on the exit, as ONE fused operation: gap = entry - 1.0000005 exit <= 0 (csrc/dtraverse.h)
+                const float gap = fmaf(-1.0000005f, tf, tn);
+                hit[k] = n.child[k] != RPTR_BVH4_EMPTY && gap <= 0.0f;
+                // order keys (csrc/dtraverse.h): a closest-hit query takes the entry distance before it is clamped to t_min (boxes the ray
+                // starts inside are still told apart); an occlusion query takes `gap` -- the child the ray spends the longest stretch in comes
+                // first (16.3 instead of 18.2 node visits and 3.8 instead of 5.7 triangle tests per shadow ray on the flattened forest)
                 const float tn_unclamped = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fminf(tl[2], th[2]));
-                entry[k] = hit[k] ? (ANY ? tn : tn_unclamped) : INFINITY;
+                entry[k] = hit[k] ? (ANY ? gap : tn_unclamped) : INFINITY;
                 if (g_order_key && hit[k]) { // diagnostic (tools/order_probe.py): other visit-order keys than the clamped entry distance
                     const float tn_raw = fmaxf(fmaxf(fminf(tl[0], th[0]), fminf(tl[1], th[1])), fminf(tl[2], th[2]));
                     const float tf_raw = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fmaxf(tl[2], th[2]));

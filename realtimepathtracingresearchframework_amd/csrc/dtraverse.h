@@ -384,13 +384,17 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 // overlapping boxes (instance boxes of a forest, secondary rays) has the same clamped entry distance for all of them and the
                 // visit order would fall back to slot order -- which is right or wrong by the luck of the builder's left / right (37 or 46
                 // node visits per ray on the instanced forest, depending on nothing but that). The unclamped value -- how far behind the
-                // origin the box begins -- still tells them apart. Occlusion queries keep the clamped key (any hit ends them; measured better).
+                // origin the box begins -- still tells them apart.
                 const float tn_raw = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                 const float tn = fmaxf(tn_raw, tmin);
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
-                const bool hit = tn <= tf * 1.0000005f;
+                // entry <= exit with a 1 + 2^-21 slack on the exit, as one fma: gap = entry - 1.0000005 exit <= 0. For an occlusion query the gap
+                // is the order key as well: most negative first = the child the ray spends the longest stretch in, where an occluder is most
+                // likely (flattened forest: 16.3 instead of 18.2 node visits, 3.8 instead of 5.7 triangle tests per shadow ray) -- for free.
+                const float gap = fmaf(-1.0000005f, tf, tn);
+                const bool hit = gap <= 0.0f;
                 ref[k] = hit ? ref[k] : RPTR_BVH4_EMPTY;
-                ent[k] = hit ? (ANY ? tn : tn_raw) : INFINITY;
+                ent[k] = hit ? (ANY ? gap : tn_raw) : INFINITY;
             }
             // front-to-back order with three comparisons instead of a sorting network over (key, payload) pairs: nearer first inside
             // each pair of slots, then the pair that holds the nearest child first. Against the full sort: +0.5 % node visits on the
