@@ -563,6 +563,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
     best.geom = best.prim = -1;
     const RptrBvh4Node *nodes = bvh.nodes4.data();
     int stack[4 * RPTR_BVH_STACK_DEPTH];
+    float stack_tn[4 * RPTR_BVH_STACK_DEPTH];
     int sp = 0;
     const int SENTINEL = INT32_MIN;
     vec3 o = ray.o, d = ray.d;
@@ -592,7 +593,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 B[a] = (n.origin[a] - oo[a]) * ii[a];
             }
             bool hit[4];
-            float entry[4];
+            float entry[4], tnc[4];
             for (int k = 0; k < 4; ++k) {
                 float tl[3], th[3];
                 for (int a = 0; a < 3; ++a) {
@@ -604,6 +605,7 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 // (the device picks entry / exit planes by the sign of the direction instead of min / max: the inverted box of an empty
                 // slot never passes there, so it needs no test of its own; plane distances are finite, see DESIGN.md "Ray query semantics")
                 // entry <= exit with a 1 + 2^-21 slack on the exit, as ONE fused operation: gap = entry - 1.0000005 exit <= 0 (csrc/dtraverse.h)
+                tnc[k] = tn;
                 const float gap = fmaf(-1.0000005f, tf, tn);
                 hit[k] = n.child[k] != RPTR_BVH4_EMPTY && gap <= 0.0f;
                 // order keys (csrc/dtraverse.h): a closest-hit query takes the entry distance before it is clamped to t_min (boxes the ray
@@ -649,7 +651,10 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
             for (int k = 0; k < 4; ++k)
                 if (hit[order[k]]) visit[nv++] = order[k];
             if (g_dead_visits && nv == 0) __atomic_fetch_add(g_dead_visits, 1ull, __ATOMIC_RELAXED);
-            for (int k = nv - 1; k >= 1; --k) stack[sp++] = n.child[visit[k]];
+            for (int k = nv - 1; k >= 1; --k) {
+                stack_tn[sp] = tnc[visit[k]];
+                stack[sp++] = n.child[visit[k]];
+            }
             if (nv)
                 cur = n.child[visit[0]];
             else
@@ -701,6 +706,9 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
         if (pop) {
             if (sp == 0) return best.inst >= 0;
             cur = stack[--sp];
+            // diagnostic ([1], [2] of the dead-visit counters): entries that were pushed with an entry distance the hit found since lies in
+            // front of -- what an entry distance kept on the stack could drop without a node step / a leaf test
+            if (g_dead_visits && cur != SENTINEL && stack_tn[sp] > best.t) __atomic_fetch_add(g_dead_visits + (cur >= 0 ? 1 : 2), 1ull, __ATOMIC_RELAXED);
         }
     }
 }

@@ -1194,7 +1194,7 @@ void orc_footprint_probe(const float *dir, const float *dpdx, const float *dpdy,
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }
-void orc_set_dead_visit_counter(unsigned long long *c) { g_dead_visits = c; }
+void orc_set_dead_visit_counter(unsigned long long *c) { g_dead_visits = c; } // c[3]: dead visits, stale node pops, stale leaf pops
 // every ray of the following single-threaded orc_render calls is appended to buf (9 floats each); returns the count so far
 size_t orc_set_ray_log(float *buf, size_t cap_rays) {
     const size_t n = g_ray_log_n;

@@ -1,4 +1,5 @@
-"""How many node visits of the device tree end with no child box hit (what a t_near on the stack could skip)?"""
+"""How many node visits of the device tree end with no child box hit, and how many popped entries (nodes, leaves) were pushed with an entry
+distance that lies behind the hit found since (what a t_near kept on the stack could skip)?"""
 import sys, os, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
@@ -9,8 +10,9 @@ s = scenes.grid_1m()
 W, H = 480, 270
 r = backend.RenderHip(); r.initialize(W, H); r.set_scene(s)
 osc = O.OracleScene(s); osc.import_bvh(*r.export_bvh())
-c = C.c_ulonglong(0)
-O.lib().orc_set_dead_visit_counter(C.byref(c))
+c = (C.c_ulonglong * 3)()   # [0] dead visits, [1] / [2] stale pops of nodes / leaves (oracle/obvh.h traverse4)
+O.lib().orc_set_dead_visit_counter(c)
 _, st = osc.render(W, H, 1, variant=abi.VARIANT_SIMPLE, bvh_mode=O.BVH_IMPORTED, count=True, threads=1)
-print("rays", st.rays_closest, st.rays_shadow, "nodes closest", st.nodes_closest, "shadow", st.nodes_shadow, "dead visits (both kinds)", c.value,
-      "= %.1f%% of node visits" % (100.0 * c.value / (st.nodes_closest + st.nodes_shadow)))
+print("rays", st.rays_closest, st.rays_shadow, "nodes closest", st.nodes_closest, "shadow", st.nodes_shadow, "dead visits (both kinds)", c[0],
+      "= %.1f%% of node visits; popped with an entry distance behind the hit found since: %d nodes (%.1f%% of node visits), %d leaves" % (
+          100.0 * c[0] / (st.nodes_closest + st.nodes_shadow), c[1], 100.0 * c[1] / (st.nodes_closest + st.nodes_shadow), c[2]))
