@@ -2,6 +2,7 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <functional>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -287,7 +288,7 @@ void refit_bvh2(BuiltTree &tree, const BuildPrim *p) {
 }
 
 // ------------------------------------------------------------------ BVH2 -> BVH4
-void collapse_bvh4(const BuiltTree &t, Wide4Tree &out) {
+void collapse_bvh4(const BuiltTree &t, Wide4Tree &out, int rule, int fallback) {
     out.nodes.clear();
     memcpy(out.lo, t.lo, 12);
     memcpy(out.hi, t.hi, 12);
@@ -320,10 +321,96 @@ void collapse_bvh4(const BuiltTree &t, Wide4Tree &out) {
             ++pos;
         }
     };
-    const bool even_rule = getenv("RPTR_COLLAPSE") && !strcmp(getenv("RPTR_COLLAPSE"), "even"); // the device's rule (lbvh.h rp_k_lbvh_emit)
+    if (rule < 0) { // (read per call: tests switch it)
+        rule = fallback;
+        if (const char *e = getenv("RPTR_COLLAPSE")) {
+            if (!strcmp(e, "even")) rule = COLLAPSE_EVEN;
+            else if (!strcmp(e, "greedy")) rule = COLLAPSE_GREEDY;
+            else if (!strcmp(e, "dp") || !strcmp(e, "optimal")) rule = COLLAPSE_OPTIMAL;
+        }
+    }
+    const bool even_rule = rule == COLLAPSE_EVEN; // the device's rebuild rule (lbvh.h rp_k_lbvh_emit)
+    const bool dp_rule = rule == COLLAPSE_OPTIMAL; // bvh_build.h
+    const size_t nb = t.nodes.size();
+    std::vector<float> cost1, F; // cost1[n]: subtree n as ONE wide node; F[4 n + i - 1]: the children of n spread over at most i slots
+    std::vector<float> node_area;
+    if (dp_rule) {
+        cost1.assign(nb, 0.0f);
+        F.assign(4 * nb, 0.0f);
+        node_area.assign(nb, 0.0f);
+        auto half_area = [](const float *lo, const float *hi) {
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        // children are allocated behind their parents (Builder::alloc, build_bvh2_ploc's relabelling): last to first is bottom-up
+        auto G = [&](int32_t c, int i) -> float { // subtree c through at most i slots
+            if (c < 0) return 0.0f;
+            return i == 1 ? cost1[c] : std::min(cost1[c], F[4 * (size_t)c + i - 1]);
+        };
+        for (size_t k = nb; k-- > 0;) {
+            const RptrBvhNode &nd = t.nodes[k];
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::fmin(nd.lo0[a], nd.lo1[a]);
+                hi[a] = std::fmax(nd.hi0[a], nd.hi1[a]);
+            }
+            node_area[k] = half_area(lo, hi);
+            if ((nd.child0 >= 0 && (size_t)nd.child0 <= k) || (nd.child1 >= 0 && (size_t)nd.child1 <= k)) { // not in that order: fall back
+                cost1.clear();
+                break;
+            }
+            F[4 * k + 0] = INFINITY; // two children never fit one slot
+            for (int i = 2; i <= 4; ++i) {
+                float best = INFINITY;
+                for (int l = 1; l < i; ++l) best = std::min(best, G(nd.child0, l) + G(nd.child1, i - l));
+                F[4 * k + i - 1] = best;
+            }
+            cost1[k] = node_area[k] + F[4 * k + 3];
+        }
+    }
+    std::function<void(int32_t, const float *, const float *, int, std::vector<Slot> &)> emit_dp = [&](int32_t c, const float *lo, const float *hi, int i,
+                                                                                                         std::vector<Slot> &dst) {
+        if (c < 0 && RPTR_BVH_LEAF_COUNT(c) == 0) return;
+        if (c < 0 || i == 1 || cost1[c] <= F[4 * (size_t)c + i - 1]) {
+            Slot sl;
+            sl.ref = c;
+            memcpy(sl.lo, lo, 12);
+            memcpy(sl.hi, hi, 12);
+            dst.push_back(sl);
+            return;
+        }
+        const RptrBvhNode &nd = t.nodes[c];
+        int best_l = 1;
+        float best = INFINITY;
+        auto G = [&](int32_t x, int j) -> float { return x < 0 ? 0.0f : (j == 1 ? cost1[x] : std::min(cost1[x], F[4 * (size_t)x + j - 1])); };
+        for (int l = 1; l < i; ++l) {
+            const float v = G(nd.child0, l) + G(nd.child1, i - l);
+            if (v < best) {
+                best = v;
+                best_l = l;
+            }
+        }
+        emit_dp(nd.child0, nd.lo0, nd.hi0, best_l, dst);
+        emit_dp(nd.child1, nd.lo1, nd.hi1, i - best_l, dst);
+    };
     std::vector<int32_t> queue{0}; // binary node behind every wide node, breadth first
     for (size_t qi = 0; qi < queue.size(); ++qi) {
         std::vector<Slot> slots;
+        if (dp_rule && !cost1.empty()) {
+            const RptrBvhNode &nd = t.nodes[queue[qi]];
+            int best_l = 1;
+            float best = INFINITY;
+            auto G = [&](int32_t x, int j) -> float { return x < 0 ? 0.0f : (j == 1 ? cost1[x] : std::min(cost1[x], F[4 * (size_t)x + j - 1])); };
+            for (int l = 1; l < 4; ++l) {
+                const float v = G(nd.child0, l) + G(nd.child1, 4 - l);
+                if (v < best) {
+                    best = v;
+                    best_l = l;
+                }
+            }
+            emit_dp(nd.child0, nd.lo0, nd.hi0, best_l, slots);
+            emit_dp(nd.child1, nd.lo1, nd.hi1, 4 - best_l, slots);
+        } else
         children_of(queue[qi], slots, 0);
         if (even_rule) { // every inner child hands its two children up, whatever their size (csrc/lbvh.h rp_k_lbvh_emit)
             std::vector<Slot> up;
@@ -335,7 +422,7 @@ void collapse_bvh4(const BuiltTree &t, Wide4Tree &out) {
             }
             slots.swap(up);
         }
-        while (!even_rule && slots.size() < 4) {
+        while (!even_rule && !(dp_rule && !cost1.empty()) && slots.size() < 4) {
             int pick = -1;
             float best = -1.0f;
             for (size_t i = 0; i < slots.size(); ++i)

@@ -302,7 +302,9 @@ RP_DEV const T &rp_kernarg(uint32_t offset) {
 #if RP_KERNARG_RELOAD
 #define RP_RELOAD_ARGS                                               \
     const RpFrame &f = rp_kernarg<RpFrame>(RP_KERNARG_OFF_F);        \
-    const RpScene &sc = rp_kernarg<RpScene>(RP_KERNARG_OFF_SC);
+    const RpScene &sc = rp_kernarg<RpScene>(RP_KERNARG_OFF_SC);      \
+    (void)f;                                                         \
+    (void)sc;
 #else
 #define RP_RELOAD_ARGS
 #endif

@@ -207,42 +207,75 @@ __global__ __launch_bounds__(256) void rp_k_ploc_firsts(uint32_t n, const int *l
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k + 1 < n; k += gridDim.x * blockDim.x) nfirst[k] = rp_ploc_first(n + k, n, left, right, parent, count);
 }
 
-// ---- 6. the 4-wide collapse, breadth first (the host builder's rule, bvh_build.cpp collapse_bvh4: a node takes the two children of its
-// binary node and then, until it has four, replaces the inner child of the largest surface area by that child's two children -- in
-// place, so that slots (0,1) and (2,3) stay pairs of siblings wherever the collapse was balanced). A subtree of <= RP_LBVH_LEAF_TRIS
-// triangles is a leaf. One launch pair per 4-wide depth level: levels are what the refit needs anyway, and a node's index -- its level's
+// ---- 6. the 4-wide collapse, breadth first (the host builder's rule, bvh_build.cpp collapse_bvh4 COLLAPSE_OPTIMAL, below). A subtree of
+// <= RP_LBVH_LEAF_TRIS triangles is a leaf. One launch pair per 4-wide depth level: levels are what the refit needs anyway, and a node's index -- its level's
 // base + its position in the level's queue, given by an exclusive scan -- does not depend on scheduling.
 RP_DEV bool rp_ploc_expandable(int id, uint32_t n, const uint32_t *count) { return (uint32_t)id >= n && count[id] > (uint32_t)RP_LBVH_LEAF_TRIS; }
-RP_DEV int rp_ploc_expand(int b, uint32_t n, const int *left, const int *right, const uint32_t *count, const float *area, int slots[4]) {
-    int ns = 2;
-    slots[0] = left[(uint32_t)b - n];
-    slots[1] = right[(uint32_t)b - n];
-    while (ns < 4) {
-        int pick = -1;
-        float best = -1.0f;
-        for (int k = 0; k < ns; ++k)
-            if (rp_ploc_expandable(slots[k], n, count)) {
-                const float a = area[(uint32_t)slots[k] - n];
-                if (a > best) {
-                    best = a;
-                    pick = k;
-                }
+// The collapse is the host builder's (bvh_build.h COLLAPSE_OPTIMAL): the one that minimises the summed surface area of the binary nodes that
+// survive as wide nodes. dpc[id - n] = (cost of subtree id as ONE wide node, cost of its children spread over at most 2 / 3 / 4 slots of a
+// parent), computed bottom-up: rp_k_ploc_dp_range once per clustering iteration (a merge's children are older than the merge), the stitched
+// top on the host (rptr_hip.hip). Same float operations in the same order as bvh_build.cpp collapse_bvh4: both give the same tree.
+RP_DEV float rp_ploc_dp_g(int x, int i, uint32_t n, const uint32_t *count, const float4 *dpc) { // subtree x through at most i slots
+    if (!rp_ploc_expandable(x, n, count)) return 0.0f;
+    const float4 c = dpc[(uint32_t)x - n];
+    return i == 1 ? c.x : fminf(c.x, i == 2 ? c.y : i == 3 ? c.z : c.w);
+}
+RP_DEV float4 rp_ploc_dp_node(int l, int r, float a, uint32_t n, const uint32_t *count, const float4 *dpc) {
+    const float l1 = rp_ploc_dp_g(l, 1, n, count, dpc), l2 = rp_ploc_dp_g(l, 2, n, count, dpc), l3 = rp_ploc_dp_g(l, 3, n, count, dpc);
+    const float r1 = rp_ploc_dp_g(r, 1, n, count, dpc), r2 = rp_ploc_dp_g(r, 2, n, count, dpc), r3 = rp_ploc_dp_g(r, 3, n, count, dpc);
+    const float f2 = l1 + r1, f3 = fminf(l1 + r2, l2 + r1), f4 = fminf(fminf(l1 + r3, l2 + r2), l3 + r1);
+    return make_float4(a + f4, f2, f3, f4);
+}
+__global__ __launch_bounds__(256) void rp_k_ploc_dp_range(uint32_t begin, uint32_t end, uint32_t n, const int *left, const int *right, const uint32_t *count,
+                                                          const float *area, float4 *dpc) {
+    for (uint32_t id = begin + blockIdx.x * blockDim.x + threadIdx.x; id < end; id += gridDim.x * blockDim.x)
+        if (rp_ploc_expandable((int)id, n, count)) dpc[id - n] = rp_ploc_dp_node(left[id - n], right[id - n], area[id - n], n, count, dpc);
+}
+__global__ __launch_bounds__(256) void rp_k_ploc_gather_costs(uint32_t m, uint32_t n, const uint32_t *cid, const float4 *dpc, float4 *out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = cid[i] >= n ? dpc[cid[i] - n] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// the children of wide node b: its binary node is dissolved over four slots; a subtree below keeps its root (one slot) or is dissolved in turn,
+// whichever the costs say (ties: keep the root; the split of a quota: the first of the cheapest). Slots come out left to right.
+RP_DEV int rp_ploc_expand(int b, uint32_t n, const int *left, const int *right, const uint32_t *count, const float4 *dpc, int slots[4]) {
+    int ns = 0, sp = 0;
+    int wn[4], wq[4];
+    auto split = [&](int c, int q) {
+        const int l = left[(uint32_t)c - n], r = right[(uint32_t)c - n];
+        int best_l = 1;
+        float best = INFINITY;
+        for (int k = 1; k < q; ++k) {
+            const float v = rp_ploc_dp_g(l, k, n, count, dpc) + rp_ploc_dp_g(r, q - k, n, count, dpc);
+            if (v < best) {
+                best = v;
+                best_l = k;
             }
-        if (pick < 0) break;
-        const int x = slots[pick];
-        for (int k = ns; k > pick + 1; --k) slots[k] = slots[k - 1]; // make room behind the picked slot
-        slots[pick] = left[(uint32_t)x - n];
-        slots[pick + 1] = right[(uint32_t)x - n];
-        ++ns;
+        }
+        wn[sp] = r;
+        wq[sp++] = q - best_l;
+        wn[sp] = l;
+        wq[sp++] = best_l;
+    };
+    split(b, 4);
+    while (sp > 0) {
+        const int c = wn[--sp], q = wq[sp];
+        bool keep = !rp_ploc_expandable(c, n, count) || q == 1;
+        if (!keep) {
+            const float4 d = dpc[(uint32_t)c - n];
+            keep = d.x <= (q == 2 ? d.y : q == 3 ? d.z : d.w);
+        }
+        if (keep)
+            slots[ns++] = c;
+        else
+            split(c, q);
     }
     return ns;
 }
 // pass 1 of a level: how many inner children each of its nodes has
 __global__ __launch_bounds__(256) void rp_k_ploc_collapse_count(const int *queue, uint32_t size, uint32_t n, const int *left, const int *right, const uint32_t *count,
-                                                                const float *area, uint32_t *inner) {
+                                                                const float4 *dpc, uint32_t *inner) {
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < size; w += gridDim.x * blockDim.x) {
         int slots[4];
-        const int ns = rp_ploc_expand(queue[w], n, left, right, count, area, slots);
+        const int ns = rp_ploc_expand(queue[w], n, left, right, count, dpc, slots);
         uint32_t c = 0;
         for (int k = 0; k < ns; ++k) c += rp_ploc_expandable(slots[k], n, count) ? 1u : 0u;
         inner[w] = c;
@@ -251,7 +284,7 @@ __global__ __launch_bounds__(256) void rp_k_ploc_collapse_count(const int *queue
 // pass 2: child references (inner: next level's base + scan position; leaf: its triangle range in depth-first order) and the next queue.
 // The root of a tree whose triangles all fit one leaf is a node with that one leaf (queue[0] = the root, flagged by `tiny`).
 __global__ __launch_bounds__(256) void rp_k_ploc_collapse_emit(const int *queue, uint32_t size, uint32_t n, const int *left, const int *right, const int *parent,
-                                                               const uint32_t *count, const float *area, const uint32_t *nfirst, const uint32_t *inner_scan,
+                                                               const uint32_t *count, const float4 *dpc, const uint32_t *nfirst, const uint32_t *inner_scan,
                                                                uint32_t level_base, uint32_t next_base, RptrBvh4Node *nodes, int *next_queue, uint32_t *next_size) {
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < size; w += gridDim.x * blockDim.x) {
         int slots[4];
@@ -261,7 +294,7 @@ __global__ __launch_bounds__(256) void rp_k_ploc_collapse_emit(const int *queue,
         if (!rp_ploc_expandable(b, n, count)) // (only the root of a tiny tree gets here)
             child[0] = RPTR_BVH_LEAF(0, (int)count[b]);
         else {
-            const int ns = rp_ploc_expand(b, n, left, right, count, area, slots);
+            const int ns = rp_ploc_expand(b, n, left, right, count, dpc, slots);
             for (int k = 0; k < ns; ++k) {
                 const int x = slots[k];
                 if (rp_ploc_expandable(x, n, count)) {

@@ -547,6 +547,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
     DB_ALLOC(count, uint32_t, 2 * (size_t)n);
     DB_ALLOC(area, float, n);
     DB_ALLOC(totals, uint32_t, 4);
+    DB_ALLOC(dpc, float4, n); // per inner node: the costs the collapse decides by (ploc.h rp_ploc_dp_node)
     float *cbox_a = box_a, *cbox_b = nullptr; // (box_a is free again after the gather; the second cluster box list is its own)
     DB_ALLOC(cbox_second, float, 6 * (size_t)n);
     cbox_b = cbox_second;
@@ -555,7 +556,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
     DB_TRY(hipMemcpyAsync(totals, host_totals, sizeof(host_totals), hipMemcpyHostToDevice, st));
     size_t top_k = RP_PLOC_TOP;
     if (const char *e = getenv("RPTR_PLOC_TOP")) top_k = std::max<size_t>(1, (size_t)atoll(e));
-    uint32_t m = n;
+    uint32_t m = n, nodes_before = n;
     int iterations = 0;
     while (m > top_k && m > 1) {
         hipLaunchKernelGGL(rp_k_ploc_nn<RP_PLOC_RADIUS>, dim3((m + 255) / 256), dim3(256), 0, st, m, cbox_a, nn);
@@ -571,6 +572,9 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
             fail(h, RPTR_E_HIP, "device BVH build: clustering made no progress at %u clusters", m);
             return false;
         }
+        if (host_totals[1] > nodes_before) // the merges of this iteration: their children are older, their costs known
+            hipLaunchKernelGGL(rp_k_ploc_dp_range, dim3(grid_for(h, host_totals[1] - nodes_before)), dim3(256), 0, st, nodes_before, host_totals[1], n, left, right, count, area, dpc);
+        nodes_before = host_totals[1];
         m = host_totals[0];
         std::swap(cid_a, cid_b);
         std::swap(cbox_a, cbox_b);
@@ -597,9 +601,17 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
             fail(h, RPTR_E_HIP, "device BVH build: the top tree over %u clusters has %zu nodes", m, T);
             return false;
         }
+        std::vector<float4> ccost(m), tcost(T); // collapse costs of the cluster roots (from the device) and of the top nodes (made here)
+        {
+            DB_ALLOC(d_ccost, float4, m);
+            hipLaunchKernelGGL(rp_k_ploc_gather_costs, dim3(grid_for(h, m)), dim3(256), 0, st, m, n, cid_a, dpc, d_ccost);
+            DB_TRY(hipMemcpyAsync(ccost.data(), d_ccost, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, st));
+            DB_TRY(hipStreamSynchronize(st));
+        }
         std::vector<int> tl(T), tr(T);
         std::vector<uint32_t> tc(T);
         std::vector<float> ta(T);
+        std::vector<float4> cost_of(T); // by top-tree node index
         std::vector<uint32_t> id_of(T), cnt_of(T);
         const uint32_t first_id = host_totals[1];
         for (int64_t i = (int64_t)T - 1; i >= 0; --i) { // children lie behind their parents: backwards = bottom-up, the root is made last
@@ -629,6 +641,18 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
                 const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
                 ta[k] = (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f;
             }
+            {   // ploc.h rp_ploc_dp_node, for a node of the top (same operations in the same order)
+                float4 cc[2];
+                bool exp[2];
+                for (int w = 0; w < 2; ++w) {
+                    cc[w] = two[w] >= 0 ? cost_of[(size_t)two[w]] : ccost[top.order[(size_t)RPTR_BVH_LEAF_FIRST(two[w])]];
+                    exp[w] = c_id[w] >= n && c_cnt[w] > (uint32_t)RP_LBVH_LEAF_TRIS;
+                }
+                auto G = [&](int w, int q) { return !exp[w] ? 0.0f : q == 1 ? cc[w].x : std::fmin(cc[w].x, q == 2 ? cc[w].y : q == 3 ? cc[w].z : cc[w].w); };
+                const float f2 = G(0, 1) + G(1, 1), f3 = std::fmin(G(0, 1) + G(1, 2), G(0, 2) + G(1, 1)),
+                            f4 = std::fmin(std::fmin(G(0, 1) + G(1, 3), G(0, 2) + G(1, 2)), G(0, 3) + G(1, 1));
+                tcost[k] = cost_of[(size_t)i] = make_float4(ta[k] + f4, f2, f3, f4);
+            }
             id_of[(size_t)i] = first_id + (uint32_t)k;
             cnt_of[(size_t)i] = tc[k];
         }
@@ -640,6 +664,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
         DB_TRY(hipMemcpyAsync(d_tl, tl.data(), T * 4, hipMemcpyHostToDevice, st));
         DB_TRY(hipMemcpyAsync(d_tr, tr.data(), T * 4, hipMemcpyHostToDevice, st));
         DB_TRY(hipMemcpyAsync(d_tc, tc.data(), T * 4, hipMemcpyHostToDevice, st));
+        DB_TRY(hipMemcpyAsync(dpc + (first_id - n), tcost.data(), T * sizeof(float4), hipMemcpyHostToDevice, st)); // (top node k has id first_id + k)
         hipLaunchKernelGGL(rp_k_ploc_stitch, dim3(grid_for(h, T)), dim3(256), 0, st, (uint32_t)T, n, first_id, d_tl, d_tr, d_tc, d_ta, left, right, parent, count, area);
         DB_TRY(hipStreamSynchronize(st)); // (the host arrays are read by the copies above)
         if (first_id + (uint32_t)T != 2u * n - 1u) {
@@ -675,10 +700,10 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
             }
             level_base.push_back(base);
             const int gl = grid_for(h, size);
-            hipLaunchKernelGGL(rp_k_ploc_collapse_count, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, count, area, flag);
+            hipLaunchKernelGGL(rp_k_ploc_collapse_count, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, count, dpc, flag);
             bytes = cub_bytes;
             DB_TRY(hipcub::DeviceScan::ExclusiveSum(cub_tmp, bytes, flag, slot, (int)size, st));
-            hipLaunchKernelGGL(rp_k_ploc_collapse_emit, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, parent, count, area, nfirst, slot, base, base + size, nodes,
+            hipLaunchKernelGGL(rp_k_ploc_collapse_emit, dim3(gl), dim3(256), 0, st, queue_a, size, n, left, right, parent, count, dpc, nfirst, slot, base, base + size, nodes,
                                queue_b, d_next);
             uint32_t next = 0;
             DB_TRY(hipMemcpyAsync(&next, d_next, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -993,7 +1018,10 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
         else
             rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
-        rptr::collapse_bvh4(tree, wide);
+        // (the meshes of a scene whose instances get several sub-roots each -- partial re-braiding below -- keep the greedy collapse: the cut
+        // through the top of the tree wants the balanced nodes it makes; with the area-optimal collapse the instanced forest needs 38.5
+        // instead of 36.8 node visits per ray)
+        rptr::collapse_bvh4(tree, wide, -1, (s->num_instances >= 16 && !getenv("RPTR_HOST_PLOC")) ? rptr::COLLAPSE_GREEDY : rptr::COLLAPSE_OPTIMAL); // (the device builder and its host statement: always the optimal one)
         mr.node_base = (int)blas_nodes.size();
         mr.node_count = (int)wide.nodes.size();
         mr.node_capacity = mr.dynamic ? std::max(mr.node_count, (int)mtris.size()) : mr.node_count;
@@ -1123,7 +1151,12 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
     rptr::BuiltTree tlas;
     rptr::build_bvh2(iprims.data(), (uint32_t)iprims.size(), 1, 24, 1, tlas);
     rptr::Wide4Tree tlas_wide;
-    rptr::collapse_bvh4(tlas, tlas_wide);
+    // (the top level keeps the greedy rule: over the heavily overlapping instance boxes of a forest the area-optimal collapse needs 38.5 node
+    // visits per ray where the greedy one needs 36.8 -- there the area of a box says little about what a ray does inside it;
+    // RPTR_TLAS_COLLAPSE=optimal to try)
+    int tlas_rule = rptr::COLLAPSE_GREEDY;
+    if (const char *e = getenv("RPTR_TLAS_COLLAPSE")) tlas_rule = !strcmp(e, "optimal") || !strcmp(e, "dp") ? rptr::COLLAPSE_OPTIMAL : !strcmp(e, "even") ? rptr::COLLAPSE_EVEN : rptr::COLLAPSE_GREEDY;
+    rptr::collapse_bvh4(tlas, tlas_wide, tlas_rule);
     for (int k = 0; k < 3; ++k) {
         B.scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
         B.scene_hi[k] = std::isfinite(tlas.hi[k]) ? tlas.hi[k] : 1.0f;
@@ -1874,7 +1907,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         best_cost *= tlas_cost;
         h->bvh_area_cost = best_cost;
         int node_min = 0, refill_min = 0;
-        if (best_cost >= 30.0) {
+        if (best_cost >= 24.0) { // (height fields: 10-12; the small forests of the tests: 29-35; C4: 90 flattened, 250-280 two-level)
             node_min = 16;
             refill_min = 32;
         }
