@@ -127,9 +127,6 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_REFILL_MIN_FIRST
 #define RP_REFILL_MIN_FIRST RP_REFILL_MIN
 #endif
-#ifndef RP_SPEC
-#define RP_SPEC 0
-#endif
 #ifndef RP_SENTINEL_INLINE
 #define RP_SENTINEL_INLINE 1
 #endif
@@ -173,12 +170,6 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     // steps of a ray: results and visit counts do not depend on them. Wave-uniform values: the compares below are scalar.
     const uint32_t node_min = sc.node_min > 0 ? (uint32_t)sc.node_min : (uint32_t)NODE_MIN;
     const uint32_t refill_min = sc.refill_min > 0 ? (uint32_t)sc.refill_min : (uint32_t)REFILL_MIN;
-    // SPEC (-DRP_SPEC=1; flattened scenes, no alpha test, timed instantiations): speculative traversal. A lane that reaches a leaf parks
-    // it in `pend` and goes on with the next item of its stack while the wave is still in its node phase; the leaf phase tests the
-    // parked leaves. Hits do not depend on the order leaves are tested in (closest t, ties by ids; any hit for occlusion) -- the
-    // price is node steps under a t_max the parked leaf would have shortened.
-    constexpr bool SPEC = (RP_SPEC != 0) && SINGLE && !ALPHA && !COUNT;
-    int pend = 0; // a leaf reference is negative; 0 = nothing parked
     const uint32_t tid = threadIdx.x;
     __shared__ float4 lds_top[LDSTOP > 0 ? LDSTOP * 4 : 1];
     if (LDSTOP > 0) { // stage the top of the tree (whole block; the caller's threads all get here)
@@ -254,7 +245,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         const long long prof_tr = wall_clock64();
 #endif
         // ---- refill idle lanes
-        const bool idle = cur == RP_EXIT && (!SPEC || pend == 0);
+        const bool idle = cur == RP_EXIT;
         const unsigned long long idle_mask = __ballot(idle);
         const uint32_t nidle = (uint32_t)__popcll(idle_mask);
         if (nidle >= refill_min) {
@@ -309,22 +300,16 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         const long long prof_t0 = wall_clock64();
         if (lane == 0) atomicAdd(&rp_prof[8], (unsigned long long)(prof_t0 - prof_tr)); // refill section
         uint32_t prof_it = 0;
-        const uint32_t prof_idle0 = (uint32_t)__popcll(__ballot(cur == RP_EXIT && (!SPEC || pend == 0)));
+        const uint32_t prof_idle0 = (uint32_t)__popcll(__ballot(cur == RP_EXIT));
         const uint32_t prof_node0 = (uint32_t)__popcll(__ballot(cur >= 0));
 #endif
         // node phase: keeps stepping while at least RP_NODE_MIN lanes are at an inner node (or nobody waits with a leaf)
         for (;;) {
-            if (SPEC) {
-                if (cur < 0 && cur != RP_EXIT && pend == 0) { // park the leaf, go on with the stack
-                    pend = cur;
-                    cur = pop();
-                }
-            }
             const unsigned long long want_node = __ballot(cur >= 0);
             if (want_node == 0ull) break;
 #if RP_NODE_MIN > 1
             if ((uint32_t)__popcll(want_node) < node_min &&
-                (uint32_t)__popcll(__ballot(SPEC ? pend != 0 : (cur < 0 && cur != RP_EXIT))) >= (uint32_t)RP_LEAF_MIN)
+                (uint32_t)__popcll(__ballot(cur < 0 && cur != RP_EXIT)) >= (uint32_t)RP_LEAF_MIN)
                 break;
 #endif
             if (cur >= 0) {
@@ -453,7 +438,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         }
         const long long prof_t2 = wall_clock64();
         {
-            const bool isleaf = SPEC ? pend != 0 : (cur < 0 && cur != RP_EXIT);
+            const bool isleaf = cur < 0 && cur != RP_EXIT;
             const uint32_t n_tri = (uint32_t)__popcll(__ballot(isleaf && cur_inst >= 0)), n_inst = (uint32_t)__popcll(__ballot(isleaf && cur_inst < 0));
             if (lane == 0) {
                 atomicAdd(&rp_prof[9], (unsigned long long)n_tri);
@@ -467,10 +452,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
         // an instance record) are fetched by the same six loads, so that a phase with both kinds costs one round trip.
         if (!SINGLE && cur == RP_SENTINEL) {
             leave_instance();
-        } else if (SPEC ? pend != 0 : (cur < 0 && cur != RP_EXIT)) {
-            const int leaf_ref = SPEC ? pend : cur;
-            const int first = RPTR_BVH_LEAF_FIRST(leaf_ref);
-            int count = RPTR_BVH_LEAF_COUNT(leaf_ref);
+        } else if (cur < 0 && cur != RP_EXIT) {
+            const int first = RPTR_BVH_LEAF_FIRST(cur);
+            int count = RPTR_BVH_LEAF_COUNT(cur);
             const bool is_inst = !SINGLE && cur_inst < 0;
             const char *lp = is_inst ? inst_base + (size_t)(uint32_t)first * sizeof(RptrBvhInstance) : tri_base + (size_t)(uint32_t)first * 48u;
             float4 qa0 = *reinterpret_cast<const float4 *>(lp), qa1 = *reinterpret_cast<const float4 *>(lp + 16),
@@ -552,16 +536,11 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     qb1 = *reinterpret_cast<const float4 *>(lp + 64);
                     qb2 = *reinterpret_cast<const float4 *>(lp + 80);
                 }
-                if (SPEC) { // the item the lane went on with stays; an occluded ray drops it
-                    pend = 0;
-                    if (ANY && any_hit) cur = RP_EXIT;
-                } else {
-                    cur = (ANY && any_hit) ? RP_EXIT : pop();
-                    if (!SINGLE && RP_SENTINEL_INLINE && cur == RP_SENTINEL) leave_instance();
-                }
+                cur = (ANY && any_hit) ? RP_EXIT : pop();
+                if (!SINGLE && RP_SENTINEL_INLINE && cur == RP_SENTINEL) leave_instance();
             }
         }
-        if (active && cur == RP_EXIT && (!SPEC || pend == 0)) {
+        if (active && cur == RP_EXIT) {
             done(my_i, best);
             active = false;
         }
