@@ -233,3 +233,47 @@ def test_flattened_tree_on_the_host(monkeypatch):
     osc.import_bvh(nodes2, tris2, insts2)
     _, st2 = osc.render(80, 60, 2, bvh_mode=O.BVH_IMPORTED, count=True)
     assert st.nodes_closest < st2.nodes_closest                   # and with fewer node visits
+
+
+def _surviving_area(nodes_f, first, count):
+    """sum of the (dequantised) child boxes' half areas over all inner children of the node range: what the area-optimal collapse minimises
+    (every binary node that survives as a wide node is a visit with probability ~ its area), up to the rounding of the 8-bit planes"""
+    nd = nodes_f.view(NODE_DT)[first:first + count]
+    step = np.ldexp(1.0, nd["exp"].astype(np.int32) - 127)[:, :, None]
+    ext = (nd["qhi"].astype(np.float64) - nd["qlo"].astype(np.float64)) * step           # (n, 3, 4)
+    area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]          # (n, 4)
+    return float(area[nd["child"] >= 0].sum())
+
+
+@pytest.mark.parametrize("scene_fn,lo,hi", [(lambda: scenes.grid(64, 32), -30, 30), (lambda: scenes.soup(11, n_meshes=1, tris_per_mesh=900, n_instances=1), -4, 4),
+                                            (lambda: scenes.forest(n_meshes=1, tris_per_tree=2000, n_instances=1, name="one-tree"), -6, 6)])
+def test_collapse_rules_area_optimal_against_greedy(scene_fn, lo, hi, monkeypatch):
+    """bvh_build.h collapse_bvh4: the default (COLLAPSE_OPTIMAL, dynamic programming over slot quotas) never keeps more box area in inner nodes than
+    the greedy rule, makes fewer nodes, visits fewer on average -- and every rule gives brute force's answers with the same leaves"""
+    s = scene_fn()
+    o, d = _rays(5000, 9, lo, hi)
+    out = {}
+    for rule in ("greedy", "optimal", "even"):
+        monkeypatch.setenv("RPTR_COLLAPSE", rule)
+        nodes, tris, insts, _ = backend.build_bvh_host(s)
+        osc = O.OracleScene(s)
+        osc.import_bvh(nodes, tris, insts)
+        tuv_b, ids_b = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_BRUTE)
+        tuv_t, ids_t, visits = osc.trace_ex_counts(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+        assert np.array_equal(tuv_b.view(np.uint32), tuv_t.view(np.uint32)) and np.array_equal(ids_b, ids_t), rule
+        n_nodes = len(nodes) // 16
+        out[rule] = (n_nodes, _surviving_area(nodes, 1, n_nodes - 1), float(visits[:, 0].mean()), np.sort(tris.view(np.uint32).reshape(-1, 12), axis=0))
+        osc.close()
+    monkeypatch.delenv("RPTR_COLLAPSE")
+    assert backend.build_bvh_host(s)[0].tobytes() == _rebuild(s, monkeypatch, "optimal")   # the default IS the optimal rule
+    (ng, ag, vg, tg), (no, ao, vo, to) = out["greedy"], out["optimal"]
+    print("nodes greedy %d optimal %d even %d | inner box area %.4g / %.4g | node visits per ray %.2f / %.2f / %.2f" % (ng, no, out["even"][0], ag, ao, vg, vo, out["even"][2]))
+    assert np.array_equal(tg, to)                       # the same triangles (the collapse does not touch the leaves)
+    assert no <= ng and ao <= ag * 1.02 and vo <= vg * 1.02   # (1.02: the areas are those of the 8-bit boxes, the rule minimises the float boxes')
+
+
+def _rebuild(s, monkeypatch, rule):
+    monkeypatch.setenv("RPTR_COLLAPSE", rule)
+    b = backend.build_bvh_host(s)[0].tobytes()
+    monkeypatch.delenv("RPTR_COLLAPSE")
+    return b
