@@ -86,14 +86,14 @@ static inline bool mt_intersect(const vec3 o, const vec3 d, const vec3 v0, const
 static inline float safe_rcp(float x) { return fabsf(x) >= 1e-30f ? 1.0f / x : copysignf(1e30f, x); }
 
 // slab test shared by every traversal (and restated by the HIP kernels):
-// returns entry distance in tnear; hit iff tnear <= tfar * (1 + 2^-21).
+// returns entry distance in tnear; hit iff tnear <= tfar * (1 + 2^-19).
 static inline bool slab(const float lo[3], const float hi[3], const vec3 o, const vec3 id, float tmin, float tmax, float &tnear) {
     float t0x = (lo[0] - o.x) * id.x, t1x = (hi[0] - o.x) * id.x;
     float t0y = (lo[1] - o.y) * id.y, t1y = (hi[1] - o.y) * id.y;
     float t0z = (lo[2] - o.z) * id.z, t1z = (hi[2] - o.z) * id.z;
     tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    return tnear <= tfar * 1.0000005f;
+    return tnear <= tfar * 1.0000019f;
 }
 
 static inline vec3 xform_point(const float m[12], vec3 p) {
@@ -604,9 +604,9 @@ static bool traverse4(const Bvh &bvh, const Ray &ray, Hit &best, TraceCounters *
                 const float tf = fminf(fminf(fmaxf(tl[0], th[0]), fmaxf(tl[1], th[1])), fminf(fmaxf(tl[2], th[2]), best.t));
                 // (the device picks entry / exit planes by the sign of the direction instead of min / max: the inverted box of an empty
                 // slot never passes there, so it needs no test of its own; plane distances are finite, see DESIGN.md "Ray query semantics")
-                // entry <= exit with a 1 + 2^-21 slack on the exit, as ONE fused operation: gap = entry - 1.0000005 exit <= 0 (csrc/dtraverse.h)
+                // entry <= exit with a 1 + 2^-19 slack on the exit, as ONE fused operation: gap = entry - 1.0000019 exit <= 0 (csrc/dtraverse.h)
                 tnc[k] = tn;
-                const float gap = fmaf(-1.0000005f, tf, tn);
+                const float gap = fmaf(-1.0000019f, tf, tn);
                 hit[k] = n.child[k] != RPTR_BVH4_EMPTY && gap <= 0.0f;
                 // order keys (csrc/dtraverse.h): a closest-hit query takes the entry distance before it is clamped to t_min (boxes the ray
                 // starts inside are still told apart); an occlusion query takes `gap` -- the child the ray spends the longest stretch in comes

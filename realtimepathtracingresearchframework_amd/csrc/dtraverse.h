@@ -83,7 +83,7 @@ RP_DEV bool rp_slab(V3 lo, V3 hi, V3 o, V3 id, float tmin, float tmax, float &tn
     float t0z = (lo.z - o.z) * id.z, t1z = (hi.z - o.z) * id.z;
     tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    return tnear <= tfar * 1.0000005f;
+    return tnear <= tfar * 1.0000019f;
 }
 
 RP_DEV V3 rp_xform_point(const float4 r0, const float4 r1, const float4 r2, V3 p) {
@@ -373,10 +373,10 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 const float tn_raw = fmaxf(fmaxf(tx.x, ty.x), tz.x);
                 const float tn = fmaxf(tn_raw, tmin);
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
-                // entry <= exit with a 1 + 2^-21 slack on the exit, as one fma: gap = entry - 1.0000005 exit <= 0. For an occlusion query the gap
+                // entry <= exit with a 1 + 2^-19 slack on the exit, as one fma: gap = entry - 1.0000019 exit <= 0. For an occlusion query the gap
                 // is the order key as well: most negative first = the child the ray spends the longest stretch in, where an occluder is most
                 // likely (flattened forest: 16.3 instead of 18.2 node visits, 3.8 instead of 5.7 triangle tests per shadow ray) -- for free.
-                const float gap = fmaf(-1.0000005f, tf, tn);
+                const float gap = fmaf(-1.0000019f, tf, tn);
                 const bool hit = gap <= 0.0f;
                 ref[k] = hit ? ref[k] : RPTR_BVH4_EMPTY;
                 ent[k] = hit ? (ANY ? gap : tn_raw) : INFINITY;
