@@ -19,6 +19,7 @@
 // with ONE global atomic; persistent consumers pull 256 entries per atomic.
 #pragma once
 #include "dtraverse.h"
+#include <type_traits>
 
 struct RpPathState {
     float4 *ray_o;   // origin.xyz, t_min
@@ -785,3 +786,13 @@ __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPat
         }
     }
 }
+
+// rp_kernarg (above) reads RpScene / RpFrame at the offsets they have as the FIRST TWO by-value arguments of a kernel: both kernels that run
+// rp_shade_body must start their argument lists that way.
+template <class F>
+struct rp_args_start_with_scene_and_frame : std::false_type {};
+template <class... Rest>
+struct rp_args_start_with_scene_and_frame<void (*)(RpScene, RpFrame, Rest...)> : std::true_type {};
+static_assert(rp_args_start_with_scene_and_frame<decltype(&rp_k_shade<RPTR_VARIANT_SIMPLE, true, false, false, false>)>::value &&
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value,
+              "rp_k_shade / rp_k_tail: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");
