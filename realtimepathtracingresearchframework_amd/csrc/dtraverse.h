@@ -379,7 +379,8 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 const float gap = fmaf(-1.0000019f, tf, tn);
                 const bool hit = gap <= 0.0f;
                 ref[k] = hit ? ref[k] : RPTR_BVH4_EMPTY;
-                ent[k] = hit ? (ANY ? gap : tn_raw) : INFINITY;
+                // (a missed child needs no +inf key in an occlusion query: its gap is positive, behind every hit child's)
+                ent[k] = ANY ? gap : (hit ? tn_raw : INFINITY);
             }
             // front-to-back order with three comparisons instead of a sorting network over (key, payload) pairs: nearer first inside
             // each pair of slots, then the pair that holds the nearest child first. Against the full sort: +0.5 % node visits on the
