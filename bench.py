@@ -170,7 +170,10 @@ def run_rccl_probe(args, timeout_s, port_offset=1):
             os.killpg(p.pid, 9)   # the exact process group this call started
         except Exception:
             p.kill()
-        out, err = p.communicate()
+        try:
+            out, err = p.communicate(timeout=15)
+        except subprocess.TimeoutExpired:   # (a child stuck in the driver does not even die: leave it behind, its pipes unread)
+            out, err = "", ""
         note = "probe timed out after %.0f s" % timeout_s
     got = {"torch_nccl": int("PROBE torch_nccl 1" in out), "native": int("PROBE native 1" in out)}
     if not note and p.returncode != 0:
