@@ -42,6 +42,7 @@ def main():
     busy, gui = read("cycles", "SQ_BUSY_CYCLES"), read("cycles", "GRBM_GUI_ACTIVE")
     cyc = {c: read("cycles", c) for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")}
     tcc_hit, tcc_miss = read("tcc", "TCC_HIT_sum"), read("tcc", "TCC_MISS_sum")
+    ta_busy = read("tcc", "TA_TA_BUSY_sum")
     doc = {"bench_args": bench_args,
            "source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_*_CYCLES) over "
                      "bench.py --profile-pass --steps 3 --warmup 1 <bench_args> (frames one at a time, RPTR_TAIL_BOUNCE=2); tools/pmc.sh + tools/make_traffic.py",
@@ -69,6 +70,10 @@ def main():
                 e["sq_busy_cycles_per_launch"] = busy[k][1] / max(busy[k][0], 1)
         if k in tcc_hit and k in tcc_miss and tcc_hit[k][1] + tcc_miss[k][1] > 0:
             e["tcc_hit_rate"] = round(tcc_hit[k][1] / (tcc_hit[k][1] + tcc_miss[k][1]), 4)
+        if k in ta_busy and k in gui and gui[k][1] > 0 and ta_busy[k][0] == gui[k][0]:
+            # busy share of a CU's texture-address unit (the vector-memory path) while the kernel runs ALONE: TA_TA_BUSY_sum is the sum over
+            # the chip's 256 units, GRBM_GUI_ACTIVE (as rocprofv3 reports it on this part) the sum over its 8 XCDs
+            e["ta_busy_frac"] = round((ta_busy[k][1] / 256.0) / (gui[k][1] / 8.0), 4)
         doc["kernels"][k] = e
     # one frame = one rp_k_resolve launch: all VALU instructions of the pass / frames (where the tail kernel takes over does not change
     # the work of a frame, so this holds for the pipelined run too, whatever bounce its tail starts at)
