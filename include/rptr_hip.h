@@ -383,6 +383,15 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
 int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation,
                           int count_traversal, uint64_t *out_ticket);
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats);
+/* How a frame is issued. 0: a sequence of stage launches (extend / shade / connect per bounce, then the tail kernel). 1: ONE launch whose
+ * blocks pull extend -> shade -> connect work of the frame from device-side queues (csrc/kernels.h rp_k_frame) -- the reference's
+ * megakernel is one dispatch per frame (vulkan/render_pipeline_vulkan.cpp:253-261) --: chunk-level dependencies instead of grid-wide
+ * ones, which is what a frame rendered ALONE wants (a launch lasts as long as its slowest ray; a chunk only holds back its own block).
+ * Same device code per path, bit-identical images. RPTR_FRAME_KERNEL=0|1 sets the default of new handles. count_traversal frames always
+ * run as stage launches. rptr_hip_get_frame_schedule: the mode, the number of bounces that had global queues in the last finished frame,
+ * their lengths (out_queue_lengths[0 .. cap), zero beyond). */
+int rptr_hip_set_frame_schedule(rptr_hip_t *h, int one_launch_per_frame);
+int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, int32_t *out_published_bounces, uint32_t *out_queue_lengths, int cap);
 /* Several frames in ONE launch sequence. A wavefront frame is a chain of dependent launches that each last at least as long as their
  * slowest ray; a small frame (the stripes of one rank of a multi-GPU split) cannot fill the GPU however many frames are in flight. Paths
  * are independent, so the samples of `n_frames` consecutive frames with the same camera and parameters can share the launches: sample

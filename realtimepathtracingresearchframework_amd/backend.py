@@ -67,6 +67,8 @@ def load_library(path=None):
     L.rptr_hip_render_batch_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
+    L.rptr_hip_set_frame_schedule.argtypes = [vp, i32]
+    L.rptr_hip_get_frame_schedule.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), i32]
     L.rptr_hip_set_rng_variant.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
     L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -269,6 +271,18 @@ class RenderHip:
     def set_stage_timing(self, level):
         """0: no per-stage events, 1: around the closest-hit traversal launches, 2: every stage (default)."""
         self._check(self._L.rptr_hip_set_stage_timing(self._h, int(level)))
+
+    def set_frame_schedule(self, one_launch_per_frame):
+        """False: a frame is a sequence of stage launches; True: ONE launch driven from device-side queues (csrc/kernels.h rp_k_frame).
+        Bit-identical images either way (include/rptr_hip.h)."""
+        self._check(self._L.rptr_hip_set_frame_schedule(self._h, 1 if one_launch_per_frame else 0))
+
+    def frame_schedule(self):
+        """(one launch per frame?, bounces that had global queues in the last finished frame, their lengths, (claim attempts, idle attempts))"""
+        one, pub = C.c_int32(), C.c_int32()
+        q = (C.c_uint32 * 16)()
+        self._check(self._L.rptr_hip_get_frame_schedule(self._h, C.byref(one), C.byref(pub), q, 16))
+        return bool(one.value), int(pub.value), [int(v) for v in q[:max(0, pub.value)]], (int(q[8]), int(q[9]))
 
     def end_frame(self, cmd_stream=None, variant_idx=0):
         pass  # resolve (process_samples) is sequenced inside draw_frame on the same stream

@@ -161,10 +161,13 @@ struct RpNoAlpha {
 #define RP_LDS_TOP_NODES 64
 #endif
 template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_MIN), int REFILL_MIN = (ANY ? RP_REFILL_MIN_ANY : RP_REFILL_MIN),
-          bool ALPHA = false, bool SINGLE = false, bool LOCAL = false, int LDSTOP = 0, class Load, class Done, class Alpha>
+          bool ALPHA = false, bool SINGLE = false, bool LOCAL = false, int LDSTOP = 0, bool EXTLDS = false, class Load, class Done, class Alpha>
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
-                          uint32_t &n_nodes, uint32_t &n_tris) {
-    __shared__ int lds_stack[RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+                          uint32_t &n_nodes, uint32_t &n_tris, int *ext_stack = nullptr) {
+    // EXTLDS: the caller owns the LDS part of the stacks (RP_LDS_STACK * RP_TRAVERSE_BLOCK ints) and shares it with its other phases
+    // (kernels.h rp_k_frame: the closest-hit traversal, the shade scratch and the shadow-ray traversal of a block take turns on one arena)
+    __shared__ int lds_stack_own[EXTLDS ? 1 : RP_LDS_STACK * RP_TRAVERSE_BLOCK];
+    int *const lds_stack = EXTLDS ? ext_stack : lds_stack_own;
     // The two scheduling thresholds are the scene's (RpScene.node_min / refill_min, chosen at set_scene from the tree: rptr_hip.hip
     // traversal_preset; 0 = this instantiation's compile-time default). They decide WHEN a lane makes its next step, never the sequence of
     // steps of a ray: results and visit counts do not depend on them. Wave-uniform values: the compares below are scalar.

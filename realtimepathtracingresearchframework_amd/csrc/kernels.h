@@ -59,6 +59,63 @@ struct RpCounters {
 
 #define RP_CHUNK 1024     // entries a producer block publishes per global atomic
 
+// ---- path state that crosses workgroups INSIDE a launch (rp_k_frame below; SH = true)
+// Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores (MI355X_MICROARCH.md
+// "inter-workgroup visibility"): what one block writes and another block of the same launch reads goes through device-coherent accesses on
+// both sides -- `sc0 sc1` buffer loads / stores (loads bypass the L1, stores write through the L2; a 16-byte sc1 access costs what a plain
+// one does, and path state is read once per bounce, so nothing is lost in the L1) -- plus a drained store queue before the entry that
+// names the path is published. SH = false (the stand-alone stages: a kernel boundary lies between producer and consumer) compiles to the
+// plain accesses it always was.
+typedef uint32_t rp_u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t rp_u2v __attribute__((ext_vector_type(2)));
+#ifndef RP_AUX_COHERENT
+#define RP_AUX_COHERENT 17 // sc0 | sc1
+#endif
+RP_DEV __amdgpu_buffer_rsrc_t rp_rsrc(const void *base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7FFFFFFF, 0x00020000); }
+template <bool SH>
+RP_DEV float4 rp_ld4(const float4 *a, uint32_t i) {
+    if (!SH) return a[i];
+    const rp_u4v v = __builtin_amdgcn_raw_buffer_load_b128(rp_rsrc(a), int(i * 16u), 0, RP_AUX_COHERENT);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <bool SH>
+RP_DEV void rp_st4(float4 *a, uint32_t i, float4 x) {
+    if (!SH) {
+        a[i] = x;
+        return;
+    }
+    const rp_u4v v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rp_rsrc(a), int(i * 16u), 0, RP_AUX_COHERENT);
+}
+template <bool SH>
+RP_DEV float2 rp_ld2(const float2 *a, uint32_t i) {
+    if (!SH) return a[i];
+    const rp_u2v v = __builtin_amdgcn_raw_buffer_load_b64(rp_rsrc(a), int(i * 8u), 0, RP_AUX_COHERENT);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <bool SH>
+RP_DEV void rp_st2(float2 *a, uint32_t i, float2 x) {
+    if (!SH) {
+        a[i] = x;
+        return;
+    }
+    const rp_u2v v = {__float_as_uint(x.x), __float_as_uint(x.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, rp_rsrc(a), int(i * 8u), 0, RP_AUX_COHERENT);
+}
+template <bool SH>
+RP_DEV uint32_t rp_ld1(const uint32_t *a, uint32_t i) { // i: element index
+    if (!SH) return a[i];
+    return __builtin_amdgcn_raw_buffer_load_b32(rp_rsrc(a), int(i * 4u), 0, RP_AUX_COHERENT);
+}
+template <bool SH>
+RP_DEV void rp_st1(uint32_t *a, uint32_t i, uint32_t x) {
+    if (!SH) {
+        a[i] = x;
+        return;
+    }
+    __builtin_amdgcn_raw_buffer_store_b32(x, rp_rsrc(a), int(i * 4u), 0, RP_AUX_COHERENT);
+}
+
 // ---- wave64 helpers
 // reserves one slot per flagged lane with one atomic per wave (counter may live in LDS or global memory)
 RP_DEV uint32_t rp_wave_append(uint32_t *counter, bool flag) {
@@ -143,14 +200,16 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir) {
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
 // SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
 // LOCAL: `queue` / `cursor` are a block-local list and its cursor in LDS (rp_k_tail).
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE, int LDSTOP = 0>
+// SH / EXTLDS (rp_k_frame): path state through device-coherent accesses; the stacks' LDS belongs to the caller. base: the path id of entry 0
+// when the queue is the identity (FIRST, queue == NULL)
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE, int LDSTOP = 0, bool SH = false, bool EXTLDS = false>
 RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const uint32_t *queue, uint32_t n, uint32_t *cursor, RpCounters *ctr,
-                           int *gstack) {
+                           int *gstack, uint32_t base = 0u, int *ext_stack = nullptr) {
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
     uint32_t lane_p = 0; // the path whose ray this lane traces
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
-        const uint32_t p = (FIRST && !queue) ? i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
+        const uint32_t p = (FIRST && !queue) ? base + i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
         lane_p = p;
         if (FIRST) {
             RpRng rng;
@@ -164,12 +223,14 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             tmax = 2.e32f;
             if (ALPHA) lane_rng = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? rng.s : rp_alpha_seed(f, p);
         } else {
-            const float4 o = ps.ray_o[p], d = ps.ray_d[p];
+            const float4 o = rp_ld4<SH>(ps.ray_o, p), d = rp_ld4<SH>(ps.ray_d, p);
             ro = xyz(o);
             rd = xyz(d);
             tmin = o.w;
             tmax = d.w;
-            if (ALPHA) lane_rng = lane_rng_in = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(ps.rng_tt[p].x) : ps.alpha_rng[p];
+            if (ALPHA)
+                lane_rng = lane_rng_in =
+                    (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(rp_ld2<SH>(ps.rng_tt, p).x) : rp_ld1<SH>(ps.alpha_rng, p);
         }
         return true;
     };
@@ -179,18 +240,18 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
         if (ALPHA) {
             if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
-                if (FIRST || lane_rng != lane_rng_in) ps.alpha_rng[p] = lane_rng;
+                if (FIRST || lane_rng != lane_rng_in) rp_st1<SH>(ps.alpha_rng, p, lane_rng);
             } else if (FIRST)
-                ps.rng_tt[p] = make_float2(__uint_as_float(lane_rng), 0.0f); // the first shade takes it from here (f.alpha_test)
+                rp_st2<SH>(ps.rng_tt, p, make_float2(__uint_as_float(lane_rng), 0.0f)); // the first shade takes it from here (f.alpha_test)
             else if (lane_rng != lane_rng_in)
-                reinterpret_cast<float *>(ps.rng_tt + p)[0] = __uint_as_float(lane_rng);
+                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.rng_tt), 2u * p, lane_rng);
         }
     };
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
         return rp_alpha_rejects(sc, inst_idx, geom, prim, u, v, lane_rng);
     };
-    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE, LOCAL, LDSTOP>(
-        sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
+    rp_wave_trace<false, COUNT, (FIRST ? RP_NODE_MIN_FIRST : RP_NODE_MIN), (FIRST ? RP_REFILL_MIN_FIRST : RP_REFILL_MIN), ALPHA, SINGLE, LOCAL, LDSTOP, EXTLDS>(
+        sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris, ext_stack);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -217,9 +278,9 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend_ldstop(RpScene sc, RpFrame f, RpP
 // ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
 // instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
 // ids: the compacted path ids of the shadow rays (sq.ids, or the tail kernel's block-local list: LOCAL)
-template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL, int LDSTOP = 0>
+template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL, int LDSTOP = 0, bool SH = false, bool EXTLDS = false>
 RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *ids, uint32_t n, uint32_t *cursor,
-                            RpCounters *ctr, int *gstack) {
+                            RpCounters *ctr, int *gstack, int *ext_stack = nullptr) {
     uint32_t n_nodes = 0, n_tris = 0;
     auto alpha = [&](uint32_t i, int inst_idx, int inst_id, int geom, int prim, float u, float v) -> bool {
         const uint32_t p = ids[i];
@@ -245,14 +306,15 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
         if (h.inst_idx < 0) { // visible: NEE contribution arrives (nee.glsl:76-84)
             const uint32_t p = ids[i];
             const float4 c = sq.contrib[p];
-            float4 il = ps.illum[p];
+            float4 il = rp_ld4<SH>(ps.illum, p);
             il.x += c.x;
             il.y += c.y;
             il.z += c.z;
-            ps.illum[p] = il;
+            rp_st4<SH>(ps.illum, p, il);
         }
     };
-    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL, LDSTOP>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris);
+    rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL, LDSTOP, EXTLDS>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris,
+                                                                                                        ext_stack);
     if (COUNT) {
         n_nodes = rp_wave_sum_u32(n_nodes);
         n_tris = rp_wave_sum_u32(n_tris);
@@ -309,18 +371,31 @@ RP_DEV const T &rp_kernarg(uint32_t offset) {
 #else
 #define RP_RELOAD_ARGS
 #endif
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE>
+// the LDS buffers of rp_shade_body when the caller owns them (EXTLDS; rp_k_frame): `next` and `shadow` (RP_CHUNK words each) outlive the call
+// (the survivors and the shadow rays of the chunk), `list` (RP_CHUNK words), `ris_req` (2048 floats) and `ris_contrib` (4096 floats; LIGHTS
+// only) are scratch the caller may reuse between calls
+struct RpShadeLds {
+    uint32_t *next, *shadow, *list;
+    float *ris_req, *ris_contrib;
+};
+#define RP_SHADE_RIS_REQ_FLOATS ((256 / 64) * 64 * 8)
+#define RP_SHADE_RIS_CONTRIB_FLOATS ((256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE)
+// SH / EXTLDS / base: as for rp_extend_body
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE, bool SH = false, bool EXTLDS = false>
 RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
                           uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
-                          uint32_t *&local_shadow, uint32_t &n_shadow) {
-    __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
+                          uint32_t *&local_shadow, uint32_t &n_shadow, uint32_t base = 0u, const RpShadeLds *ext = nullptr) {
+    __shared__ uint32_t s_next_own[EXTLDS ? 1 : RP_CHUNK], s_shadow_own[EXTLDS ? 1 : RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
-    __shared__ uint32_t s_list[RP_CHUNK]; // path ids of the chunk, hits first
+    __shared__ uint32_t s_list_own[EXTLDS ? 1 : RP_CHUNK]; // path ids of the chunk, hits first
     __shared__ uint32_t s_nhit, s_nmiss;
     // per wave: the tri-light requests of its lanes (hit point, normal, bin) and the contributions of their bins
-    __shared__ float s_ris_req[LIGHTS ? (256 / 64) * 64 * 8 : 1];
-    __shared__ float s_ris_contrib[LIGHTS ? (256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE : 1];
+    __shared__ float s_ris_req_own[LIGHTS && !EXTLDS ? RP_SHADE_RIS_REQ_FLOATS : 1];
+    __shared__ float s_ris_contrib_own[LIGHTS && !EXTLDS ? RP_SHADE_RIS_CONTRIB_FLOATS : 1];
+    uint32_t *const s_next = EXTLDS ? ext->next : s_next_own, *const s_shadow = EXTLDS ? ext->shadow : s_shadow_own;
+    uint32_t *const s_list = EXTLDS ? ext->list : s_list_own;
+    float *const s_ris_req = EXTLDS ? ext->ris_req : s_ris_req_own, *const s_ris_contrib = EXTLDS ? ext->ris_contrib : s_ris_contrib_own;
     if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
     if (LOCAL) {
         if (threadIdx.x == 0) {
@@ -348,7 +423,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             uint32_t pp = 0;
             bool is_hit = false;
             if (valid) {
-                pp = (FIRST && !order) ? i : order[i];
+                pp = (FIRST && !order) ? base + i : order[i];
                 is_hit = ps.hit_ids[pp].x >= 0;
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
@@ -435,7 +510,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
                     if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM))
-                        rng.s = __float_as_uint(ps.rng_tt[p].x); // alpha tests of the first extend may have drawn from it
+                        rng.s = __float_as_uint(rp_ld2<SH>(ps.rng_tt, p).x); // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
                         if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) {
@@ -454,10 +529,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         tex_fp = rp_dpdxy_to_footprint(ray_dir, dpdx, dpdy);
                     }
                 } else {
-                    const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
-                    const float4 thr4 = ps.thr[p];
-                    const float4 il4 = ps.illum[p];
-                    const float2 rt = ps.rng_tt[p];
+                    const float4 ro4 = rp_ld4<SH>(ps.ray_o, p), rd4 = rp_ld4<SH>(ps.ray_d, p);
+                    const float4 thr4 = rp_ld4<SH>(ps.thr, p);
+                    const float4 il4 = rp_ld4<SH>(ps.illum, p);
+                    const float2 rt = rp_ld2<SH>(ps.rng_tt, p);
                     rng = rp_rng_resume<TABLE>(f, p, __float_as_uint(rt.x));
                     total_t = rt.y;
                     ray_origin = xyz(ro4);
@@ -467,7 +542,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     prev_bounce_pdf = thr4.w;
                     bounce = __float_as_int(il4.w);
                     if (TEX) {
-                        const float4 fp = ps.footprint[p];
+                        const float4 fp = rp_ld4<SH>(ps.footprint, p);
                         tex_fp = M2{v2(fp.x, fp.y), v2(fp.z, fp.w)};
                     }
                 }
@@ -476,7 +551,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 if (ids.x < 0) {
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
-                    ps.illum[p] = f4(illum, __int_as_float(bounce));
+                    rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
                     if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:482-487
                         rp_store_geometry_aovs(f, aov_px, v3s(0.0f), v3s(2.e32f), aov_jitter);
                         rp_store_material_aovs(f, aov_px, v3s(0.0f), 1.0f, 1.0f);
@@ -699,15 +774,15 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         }
                         if (survive) {
                             alive = true;
-                            ps.ray_o[p] = f4(ray_origin, t_min);
-                            ps.ray_d[p] = f4(ray_dir, 1e20f);
-                            ps.thr[p] = f4(throughput, prev_bounce_pdf);
-                            ps.rng_tt[p] = make_float2(__uint_as_float(rng.s), total_t);
-                            if (TEX) ps.footprint[p] = make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y);
+                            rp_st4<SH>(ps.ray_o, p, f4(ray_origin, t_min));
+                            rp_st4<SH>(ps.ray_d, p, f4(ray_dir, 1e20f));
+                            rp_st4<SH>(ps.thr, p, f4(throughput, prev_bounce_pdf));
+                            rp_st2<SH>(ps.rng_tt, p, make_float2(__uint_as_float(rng.s), total_t));
+                            if (TEX) rp_st4<SH>(ps.footprint, p, make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y));
                         }
                     }
                 }
-                ps.illum[p] = f4(illum, __int_as_float(bounce));
+                rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
             }
             const uint32_t at = rp_wave_append(&s_nn, alive);
             if (alive) s_next[at] = p;
@@ -787,6 +862,311 @@ __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPat
     }
 }
 
+// ------------------------------------------------------------------ frame: the whole frame in ONE launch, driven from device-side queues
+// (the reference's megakernel is one dispatch per frame: vulkan/render_pipeline_vulkan.cpp:253-261, render_vulkan.cpp:2961-3059)
+//
+// The stand-alone stages make a frame a chain of ~10 dependent launches, and every launch lasts as long as its slowest ray: ONE frame
+// rendered alone takes 2.06 ms where frames in flight reach 1.3 ms (C2), and a 1/8 frame (one rank of an 8-GPU split) 0.79 ms instead of
+// 0.18 (profiles/r03_notes.md section 4). Paths are independent, so nothing in a frame needs a grid-wide step: rp_k_frame replaces the
+// launch boundaries by CHUNK-level dependencies. A block
+//   1. takes a work item: a SLOT of RP_CHUNK consecutive entries of some bounce's queue -- a slot of a bounce >= 1 from the ring of
+//      ready slots if there is one (deeper bounces first: paths end sooner, queues stay short), else up to k0 slots of bounce 0 (the
+//      identity over the path ids; several at a time so that the block-local traversal has rays to refill its lanes with),
+//   2. runs the slot's paths through extend -> shade -> connect with the device code of the stand-alone kernels (rp_*_body, LOCAL lists in
+//      LDS: what rp_k_tail does), so the image is bit-identical to theirs,
+//   3. appends the survivors to the NEXT bounce's global queue -- whichever block gets the slot they land in continues them, which is what
+//      keeps 64 lanes per wave busy on the second and third bounce where rp_k_tail's block-local lists would thin out -- or, from bounce
+//      n_pub - 1 on (queues of a few thousand paths), keeps them and runs them to their end like rp_k_tail.
+// A straggler -- a ray that grazes the height field through hundreds of nodes -- now holds back its own block, not the frame.
+//
+// Queue protocol. Nobody polls a slot: the events that make work say so. (A first version had every idle block walk tail / head / done
+// words and compare-and-swap a shared head: 5 M claim attempts for 11 thousand slots, 400 ms per frame -- one device word sustains ~88
+// atomics per microsecond, MI355X_MICROARCH.md "dequeue".)
+//   tail[b]       entries reserved in bounce b's queue: one atomicAdd per chunk of survivors (bounce 0: preset to the number of paths)
+//   commit[b][s]  entries of slot s whose ids are in memory. The producer whose add makes it RP_CHUNK pushes the slot into the ring.
+//   done[b]       slots of bounce b whose paths have been traced, shaded and whose survivors have been published
+//   final[b]      bounce b's tail will not grow: bounce b - 1 is final and done[b - 1] covers all of its slots (bounce 0: preset). Whoever
+//                 observes that first (after its own add to done[b - 1], or after setting final[b - 1]) sets the flag -- a compare-and-swap
+//                 elects one -- and pushes the bounce's last, partly filled slot. The frame is complete when the last published bounce is
+//                 final and done.
+//   ring          64-bit entries (frame epoch | bounce | slot | entries; no memset of the ring), written at a position reserved with an
+//                 atomicAdd on ring_tail, read by the block that holds the position's TICKET (an atomicAdd on ring_head: rp_fq_claim)
+//   head0         tickets of bounce 0 (atomicAdd: never fails)
+// Visibility (MI355X_MICROARCH.md "inter-workgroup visibility"): per-XCD L2s are not coherent and a CU's L1 is never refreshed by other
+// CUs' stores. Consumers read path state and ids around the L1 (SH accessors above); a producer drains its stores in every wave, joins at
+// a barrier, and ONE lane issues an agent-scope release (buffer_wbl2 sc1 + s_waitcnt) before the commit -- measured: sc1 "write-through"
+// stores drained with s_waitcnt vmcnt(0) alone were NOT enough (stale ids on the second frame of a handle, faults at 4 blocks per CU;
+// with the release: bit-identical on every size tried) --; the control words are agent-scope atomics.
+#define RP_FQ_MAX 8 // bounces whose queues can be global; later bounces always run block-local
+#ifndef RP_FRAME_WAVES
+#define RP_FRAME_WAVES 4 // blocks per CU the frame kernel is compiled for (VGPR budget: its shade phase)
+#endif
+struct RpFqState {
+    uint32_t tail[RP_FQ_MAX], done[RP_FQ_MAX], final[RP_FQ_MAX];
+    uint32_t head0;                 // slots of bounce 0 handed out
+    uint32_t ring_tail, ring_head;  // the ring of ready slots
+    uint32_t complete;              // the frame is done: idle blocks leave
+    uint32_t polls, idle_polls;     // diagnostics: claim attempts, attempts that found nothing to do (added once per block)
+    uint32_t timeout;               // a block gave up waiting for work that never came (a protocol error: the host reports it)
+    uint32_t bad_ids;               // queue entries that named no path (>= capacity): never on a correct run, reported by the host
+    unsigned long long t_claim, t_extend, t_shade, t_connect, t_publish, t_fence, t_total; // -DRP_FRAME_PROF: 100 MHz ticks summed over the blocks (lane 0)
+};
+struct RpFrameQueues {
+    RpFqState *st;
+    uint32_t *ids;               // path ids of bounce b >= 1 at ids + (b - 1) * capacity
+    uint32_t *commit;            // one word per slot, bounce b >= 1 at commit + (b - 1) * slots
+    unsigned long long *ring;    // ready slots (RP_FQ_MAX * slots entries: every slot is pushed once per frame at most)
+    uint32_t slots;
+    uint32_t epoch;              // this frame's tag in ring entries (1 .. 65535; the ring is zeroed when it is allocated)
+    int32_t n_pub;               // bounces 0 .. n_pub - 1 have global queues (1 <= n_pub <= RP_FQ_MAX)
+    int32_t k0;                  // slots of bounce 0 a block takes at a time (1 when n_pub == 1)
+    uint32_t capacity;           // path ids are below this
+    uint32_t dbg;                // RPTR_FRAME_DBG (experiments): bit 0 no release fence before a commit
+};
+struct RpFqWork {
+    uint32_t b, slot, m, n; // bounce (~0u: the frame is complete), first slot, slots, entries
+};
+RP_DEV uint32_t rp_fq_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV uint32_t rp_fq_add(uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RP_DEV uint32_t *rp_fq_ids(const RpFrameQueues &fq, uint32_t b) { return fq.ids + size_t(b - 1u) * fq.capacity; }
+RP_DEV uint32_t *rp_fq_commit(const RpFrameQueues &fq, uint32_t b) { return fq.commit + size_t(b - 1u) * fq.slots; }
+// every wave, before a block barrier behind which ANOTHER wave reads what this one stored device-coherently: a barrier orders the waves,
+// not their stores (sc1 accesses go around the L1 that orders the plain ones of a workgroup)
+RP_DEV void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// (one lane) a slot of bounce b with n entries is ready
+RP_DEV void rp_fq_push(const RpFrameQueues &fq, uint32_t b, uint32_t slot, uint32_t n) {
+    const uint32_t i = rp_fq_add(&fq.st->ring_tail, 1u);
+    const unsigned long long e = ((unsigned long long)fq.epoch << 48) | ((unsigned long long)b << 44) | ((unsigned long long)slot << 12) | n;
+    __hip_atomic_store(fq.ring + i, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (one lane) after an add to done[b1 - 1] or after final[b1 - 1] was set: bounce b1 may have become final (b1 == n_pub: the frame complete)
+RP_DEV void rp_fq_try_finalize(const RpFrameQueues &fq, uint32_t b1) {
+    RpFqState *const st = fq.st;
+    for (;; ++b1) {
+        const uint32_t b = b1 - 1u;
+        if (rp_fq_ld(&st->final[b]) == 0u) return;
+        rp_drain_stores(); // (a final bounce's tail stands still: read it after the flag)
+        const uint32_t t = rp_fq_ld(&st->tail[b]), dn = rp_fq_ld(&st->done[b]);
+        if (dn != (t + RP_CHUNK - 1u) / RP_CHUNK) return;
+        if (b1 == (uint32_t)fq.n_pub) {
+            __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        uint32_t expect = 0u;
+        if (!__hip_atomic_compare_exchange_strong(&st->final[b1], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        // this lane made bounce b1 final: its last slot, if partly filled, will never be completed by a producer
+        const uint32_t t1 = rp_fq_ld(&st->tail[b1]);
+        if (t1 % RP_CHUNK != 0u) rp_fq_push(fq, b1, t1 / RP_CHUNK, t1 % RP_CHUNK);
+    }
+}
+// (one lane) the block's next work item. Every block holds a TICKET of the ring -- position `ticket` belongs to it and to nobody else, so
+// taking a ready slot is a load of the block's own entry, no compare-and-swap race of a thousand blocks for one head word (which is what
+// a shared head cost: two thirds of every block's time went into claiming) -- and takes a new one when it has used it. A ready slot waits
+// for the holder of its ticket to finish the chunk it is working on; in the meantime the holder works on bounce 0.
+struct RpFqClaimState {
+    uint32_t ticket;
+    bool have_ticket, b0_exhausted;
+    uint32_t polls, idle_polls;
+};
+RP_DEV RpFqWork rp_fq_claim(const RpFrameQueues &fq, RpFqClaimState &cs) {
+    RpFqState *const st = fq.st;
+    const uint32_t n0 = rp_fq_ld(&st->tail[0]);
+    const uint32_t nsl0 = (n0 + RP_CHUNK - 1u) / RP_CHUNK;
+    RpFqWork w;
+    w.b = ~0u;
+    w.slot = w.m = w.n = 0u;
+    for (uint32_t idle = 0;;) {
+        ++cs.polls;
+        // 1. the ready slot of a later bounce that this block's ticket names
+        if (fq.n_pub > 1) {
+            if (!cs.have_ticket) {
+                cs.ticket = rp_fq_add(&st->ring_head, 1u);
+                cs.have_ticket = true;
+            }
+            const unsigned long long e = __hip_atomic_load(fq.ring + cs.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(e >> 48) == fq.epoch) {
+                cs.have_ticket = false;
+                w.b = (uint32_t)(e >> 44) & 15u;
+                w.slot = (uint32_t)(e >> 12);
+                w.m = 1u;
+                w.n = (uint32_t)e & 4095u;
+                return w;
+            }
+        }
+        // 2. the next slots of bounce 0
+        if (!cs.b0_exhausted) {
+            const uint32_t s = rp_fq_add(&st->head0, (uint32_t)fq.k0);
+            if (s < nsl0) {
+                w.b = 0u;
+                w.slot = s;
+                w.m = min((uint32_t)fq.k0, nsl0 - s);
+                w.n = min(w.m * RP_CHUNK, n0 - s * RP_CHUNK);
+                return w;
+            }
+            cs.b0_exhausted = true;
+        }
+        // 3. nothing to do right now: the ticket's entry is this block's own word to watch
+        if ((idle & 3u) == 0u && rp_fq_ld(&st->complete) != 0u) return w;
+        ++cs.idle_polls;
+        if (++idle > (1u << 21) || ((idle & 255u) == 0u && rp_fq_ld(&st->timeout) != 0u)) { // seconds without work while the frame is not complete: never on a correct run
+            rp_fq_add(&st->timeout, 1u);
+            return w;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+// all threads of the block: appends n ids (LDS) to bounce b's queue. The caller's waves have drained their path-state stores and a barrier
+// lies behind them.
+RP_DEV void rp_fq_publish(const RpFrameQueues &fq, uint32_t b, const uint32_t *ids, uint32_t n, uint32_t *s_base) {
+    if (n == 0u) return; // (block-uniform)
+    if (threadIdx.x == 0) *s_base = rp_fq_add(&fq.st->tail[b], n);
+    __syncthreads();
+    const uint32_t base = *s_base;
+    uint32_t *const q = rp_fq_ids(fq, b);
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rp_st1<true>(q, base + j, ids[j]);
+    rp_drain_stores(); // every writing wave: the ids have left it before the slot says so
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#ifdef RP_FRAME_PROF
+        const long long tf0 = wall_clock64();
+#endif
+        if (!(fq.dbg & 1u)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // path state + ids of the whole block are in memory ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... (the compiler may drop the wait behind buffer_wbl2: restated)
+        }
+#ifdef RP_FRAME_PROF
+        atomicAdd(&fq.st->t_fence, (unsigned long long)(wall_clock64() - tf0));
+#endif
+        const uint32_t s0 = base / RP_CHUNK, n0 = min(n, (s0 + 1u) * RP_CHUNK - base);
+        // the producer that completes a slot hands it on (every other producer's entries were released before its own add)
+        if (rp_fq_add(rp_fq_commit(fq, b) + s0, n0) + n0 == RP_CHUNK) rp_fq_push(fq, b, s0, RP_CHUNK);
+        if (n > n0 && rp_fq_add(rp_fq_commit(fq, b) + s0 + 1u, n - n0) + (n - n0) == RP_CHUNK) rp_fq_push(fq, b, s0 + 1u, RP_CHUNK);
+    }
+}
+template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
+__global__ __launch_bounds__(256, RP_FRAME_WAVES) void rp_k_frame(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpFrameQueues fq, RpCounters *ctr,
+                                                                 int *gstack) {
+    // one arena for the phases that take turns: the traversal stacks of extend / connect, the shade phase's scratch
+    constexpr uint32_t STACK_WORDS = RP_LDS_STACK * RP_TRAVERSE_BLOCK;
+    constexpr uint32_t SCRATCH_WORDS = RP_CHUNK + (LIGHTS ? RP_SHADE_RIS_REQ_FLOATS + RP_SHADE_RIS_CONTRIB_FLOATS : 0);
+    __shared__ __attribute__((aligned(16))) uint32_t s_arena[STACK_WORDS > SCRATCH_WORDS ? STACK_WORDS : SCRATCH_WORDS];
+    __shared__ uint32_t s_ids[RP_CHUNK];    // the list being processed; the shade phase leaves its survivors here (it has read the list by then)
+    __shared__ uint32_t s_shadow[RP_CHUNK]; // the shadow rays of the chunk
+    __shared__ uint32_t s_cursor[2];
+    __shared__ RpFqWork s_work;
+    __shared__ uint32_t s_base;
+    int *const stack = reinterpret_cast<int *>(s_arena);
+    RpShadeLds lds;
+    lds.next = s_ids;
+    lds.shadow = s_shadow;
+    lds.list = s_arena;
+    lds.ris_req = reinterpret_cast<float *>(s_arena + RP_CHUNK);
+    lds.ris_contrib = reinterpret_cast<float *>(s_arena + RP_CHUNK + RP_SHADE_RIS_REQ_FLOATS);
+    RpFqClaimState cs; // (lane 0)
+    cs.ticket = cs.polls = cs.idle_polls = 0u;
+    cs.have_ticket = cs.b0_exhausted = false;
+#ifdef RP_FRAME_PROF
+    long long pt[6] = {0, 0, 0, 0, 0, 0};
+    const long long pt_begin = wall_clock64();
+#define RP_FP_T0 const long long pt0_ = wall_clock64();
+#define RP_FP_T1(k) pt[k] += wall_clock64() - pt0_;
+#else
+#define RP_FP_T0
+#define RP_FP_T1(k)
+#endif
+    for (;;) {
+        __syncthreads(); // the previous slot's readers of s_work / s_ids are done
+        {
+            RP_FP_T0
+            if (threadIdx.x == 0) s_work = rp_fq_claim(fq, cs);
+            __syncthreads();
+            RP_FP_T1(0)
+        }
+        const RpFqWork w = s_work;
+        if (w.b == ~0u) break;
+        uint32_t b = w.b, n = w.n;
+        const uint32_t base = w.slot * RP_CHUNK; // bounce 0: the path id of the first entry
+        if (b > 0u)
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+                uint32_t id = rp_ld1<true>(rp_fq_ids(fq, b), base + j);
+                if (id >= fq.capacity) { // (a protocol error would otherwise show up as a wild store)
+                    rp_fq_add(&fq.st->bad_ids, 1u);
+                    id = 0u;
+                }
+                s_ids[j] = id;
+            }
+        for (;;) { // the slot's paths, bounce by bounce while they stay with this block
+            if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
+            __syncthreads();
+            {
+                RP_FP_T0
+                if (b == 0u)
+                    rp_extend_body<false, true, ALPHA, SINGLE, true, TABLE, 0, true, true>(sc, f, ps, nullptr, n, &s_cursor[0], ctr, gstack, base, stack);
+                else
+                    rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE, 0, true, true>(sc, f, ps, s_ids, n, &s_cursor[0], ctr, gstack, 0u, stack);
+                rp_drain_stores(); // (the alpha test's generator goes to the shade phase through the path state)
+                __syncthreads();
+                RP_FP_T1(1)
+            }
+            const bool publish = int(b) + 1 < fq.n_pub;
+            uint32_t n_next = 0;
+            for (uint32_t sub = 0; sub * RP_CHUNK < n; ++sub) { // (more than one pass only for k0 > 1 slots of bounce 0, which are always published)
+                const uint32_t cnt = min((uint32_t)RP_CHUNK, n - sub * RP_CHUNK);
+                uint32_t *next = nullptr, *shadow = nullptr;
+                uint32_t n_shadow = 0;
+                RP_FP_T0
+                if (b == 0u)
+                    rp_shade_body<VARIANT, true, LIGHTS, TEX, true, TABLE, true, true>(sc, f, ps, sq, nullptr, cnt, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
+                                                                                       n_shadow, base + sub * RP_CHUNK, &lds);
+                else
+                    rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, true, true>(sc, f, ps, sq, s_ids, cnt, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
+                                                                                        n_shadow, 0u, &lds);
+                rp_drain_stores(); // the shadow rays' contributions are added to the radiance this phase stored
+                __syncthreads();
+                RP_FP_T1(2)
+                {
+                    RP_FP_T0
+                    if (threadIdx.x == 0) s_cursor[1] = 0;
+                    __syncthreads();
+                    rp_connect_body<false, ALPHA, SINGLE, true, 0, true, true>(sc, f, ps, sq, s_shadow, n_shadow, &s_cursor[1], ctr, gstack, stack);
+                    rp_drain_stores(); // every wave: its path-state stores are in memory before the survivors are handed on
+                    __syncthreads();
+                    RP_FP_T1(3)
+                }
+                if (publish) {
+                    RP_FP_T0
+                    rp_fq_publish(fq, b + 1u, s_ids, n_next, &s_base);
+                    __syncthreads();
+                    RP_FP_T1(4)
+                }
+            }
+            if (publish || n_next == 0u || int(b) + 1 >= f.rp.max_path_depth) break;
+            ++b; // the survivors stay with this block (s_ids holds them)
+            n = n_next;
+        }
+        if (threadIdx.x == 0) {
+            rp_drain_stores(); // the commits (and pushes) of this slot's survivors first
+            rp_fq_add(&fq.st->done[w.b], w.m);
+            rp_drain_stores();
+            rp_fq_try_finalize(fq, w.b + 1u);
+        }
+    }
+    if (threadIdx.x == 0) {
+        rp_fq_add(&fq.st->polls, cs.polls);
+        rp_fq_add(&fq.st->idle_polls, cs.idle_polls);
+#ifdef RP_FRAME_PROF
+        atomicAdd(&fq.st->t_claim, (unsigned long long)pt[0]);
+        atomicAdd(&fq.st->t_extend, (unsigned long long)pt[1]);
+        atomicAdd(&fq.st->t_shade, (unsigned long long)pt[2]);
+        atomicAdd(&fq.st->t_connect, (unsigned long long)pt[3]);
+        atomicAdd(&fq.st->t_publish, (unsigned long long)pt[4]);
+        atomicAdd(&fq.st->t_total, (unsigned long long)(wall_clock64() - pt_begin));
+#endif
+    }
+#undef RP_FP_T0
+#undef RP_FP_T1
+}
+
 // rp_kernarg (above) reads RpScene / RpFrame at the offsets they have as the FIRST TWO by-value arguments of a kernel: both kernels that run
 // rp_shade_body must start their argument lists that way.
 template <class F>
@@ -794,5 +1174,6 @@ struct rp_args_start_with_scene_and_frame : std::false_type {};
 template <class... Rest>
 struct rp_args_start_with_scene_and_frame<void (*)(RpScene, RpFrame, Rest...)> : std::true_type {};
 static_assert(rp_args_start_with_scene_and_frame<decltype(&rp_k_shade<RPTR_VARIANT_SIMPLE, true, false, false, false>)>::value &&
-                  rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value,
-              "rp_k_shade / rp_k_tail: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value &&
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_frame<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value,
+              "rp_k_shade / rp_k_tail / rp_k_frame: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");

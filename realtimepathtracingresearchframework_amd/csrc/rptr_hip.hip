@@ -115,6 +115,13 @@ struct FrameCtx {
     RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
     int launches_extend = 0, launches_connect = 0, spp_after = 0;
     int tail_from = 0; // the bounce at which this context's last frame handed over to the tail kernel (= max depth: no tail)
+    // the one-launch frame (kernels.h rp_k_frame): global queues per published bounce, their control words, a pinned copy of those
+    RpFrameQueues fq = {};
+    RpPathState ps_fk = {};       // the frame kernel's path state: what crosses workgroups lives in fine-grained memory, the rest is c.ps's
+    size_t fq_words = 0;          // control words + per-slot commit counters: zeroed before every frame
+    RpFqState *host_fq = nullptr; // pinned
+    int fq_pub_used = 0;          // bounces with global queues in the frame in flight (0: it ran as stage launches)
+    size_t gstack_threads = 0;    // threads the stack scratch is sized for
     // multi-GPU gather (host_comm.h): the image this context produced is being sent; its next frame waits for that on the device
     hipEvent_t ev_gather = nullptr;
     bool gather_pending = false;
@@ -199,6 +206,15 @@ struct rptr_hip {
     int tail_adaptive = 1 << 30;    // adaptive choice for the next frame (from the queue lengths of the last finished frame)
     int tail_blocks = 0;
     int tail_threshold = 65536;     // RPTR_TAIL_THRESHOLD: queue length below which a bounce goes to the tail kernel
+    // the frame as ONE launch driven from device-side queues (kernels.h rp_k_frame; rptr_hip_set_frame_schedule, RPTR_FRAME_KERNEL)
+    int frame_kernel = 0;           // 0: stage launches, 1: one launch per frame
+    int frame_pub_mode = -1;        // RPTR_FRAME_PUB: -1 adaptive, k >= 1: bounces 0 .. k-1 have global queues
+    int frame_pub_max = 4;          // RPTR_FRAME_PUB_MAX: global queues a frame context may hold (path_capacity entries each)
+    int frame_pub_adaptive = 2;     // the next frame's choice (from the queue lengths of the last finished frame)
+    int frame_local_threshold = 262144; // RPTR_FRAME_LOCAL_THRESHOLD: a bounce whose PARENT queue is shorter stays with its blocks
+    int frame_k0 = 0;               // RPTR_FRAME_K0: slots of bounce 0 a block takes at a time (0: from the frame size)
+    int frame_blocks_per_cu = 0;    // RPTR_FRAME_BLOCKS_PER_CU (0: what the occupancy query says)
+    int frame_fine_grained = 1;     // RPTR_FRAME_FINE_GRAINED: path state + queue ids of the frame kernel in fine-grained device memory
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
     RptrCamera prev_camera;         // the previous frame's view (VP_reference)
     bool have_prev_camera = false;
@@ -278,11 +294,13 @@ static void ensure_hw_queues(int frames_in_flight) {
         if (_e != hipSuccess) return fail(h, RPTR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// fine: device memory that is coherent INSIDE a launch (hipDeviceMallocFinegrained: not held in the per-XCD L2s) -- what one workgroup of the
+// frame kernel writes for another to read (kernels.h rp_k_frame)
 template <class T>
-int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track) {
+int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track, bool fine = false) {
     void *p = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = fine ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     (track == &h->scene_allocs ? h->bytes_scene : h->bytes_frame) += bytes;
     h->bytes_allocated = h->bytes_scene + h->bytes_frame;
@@ -1296,6 +1314,13 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
         if (const char *s = getenv("RPTR_TAIL_THRESHOLD")) h->tail_threshold = std::max(0, atoi(s));
         if (const char *s = getenv("RPTR_MAX_BATCH_FRAMES")) h->max_batch_frames = std::max(1, std::min(16, atoi(s)));
+        if (const char *s = getenv("RPTR_FRAME_KERNEL")) h->frame_kernel = atoi(s) != 0 ? 1 : 0;
+        if (const char *s = getenv("RPTR_FRAME_PUB")) h->frame_pub_mode = atoi(s);
+        if (const char *s = getenv("RPTR_FRAME_PUB_MAX")) h->frame_pub_max = std::max(1, std::min(RP_FQ_MAX, atoi(s)));
+        if (const char *s = getenv("RPTR_FRAME_LOCAL_THRESHOLD")) h->frame_local_threshold = std::max(0, atoi(s));
+        if (const char *s = getenv("RPTR_FRAME_K0")) h->frame_k0 = std::max(0, std::min(16, atoi(s)));
+        if (const char *s = getenv("RPTR_FRAME_BLOCKS_PER_CU")) h->frame_blocks_per_cu = std::max(0, std::min(8, atoi(s)));
+        if (const char *s = getenv("RPTR_FRAME_FINE_GRAINED")) h->frame_fine_grained = atoi(s) != 0 ? 1 : 0;
         for (FrameCtx &c : h->ctx) {
             memset(&c.ps, 0, sizeof(c.ps));
             memset(&c.sq, 0, sizeof(c.sq));
@@ -1319,10 +1344,12 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
                 delete h;
                 return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
             }
-            if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess) {
+            if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&c.host_fq, sizeof(RpFqState), hipHostMallocDefault) != hipSuccess) {
                 delete h;
                 return fail(nullptr, RPTR_E_NOMEM, "hipHostMalloc failed");
             }
+            memset(c.host_fq, 0, sizeof(RpFqState));
         }
     }
     // defaults of RenderParams / LightSamplingConfig (librender/render_params.glsl.h:123-155)
@@ -1367,6 +1394,7 @@ void rptr_hip_destroy(rptr_hip_t *h) {
         for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved, c.ev_fork, c.ev_side, c.ev_gather})
             if (e) (void)hipEventDestroy(e);
         if (c.host_counters) (void)hipHostFree(c.host_counters);
+        if (c.host_fq) (void)hipHostFree(c.host_fq);
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1422,6 +1450,9 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->path_capacity = cap;
     int rc;
     for (FrameCtx &c : h->ctx) {
+        memset(&c.fq, 0, sizeof(c.fq)); // (freed with the other frame-sized allocations above; made again by the first frame that wants them)
+        memset(&c.ps_fk, 0, sizeof(c.ps_fk));
+        c.fq_words = 0;
         if ((rc = dev_alloc(h, &c.ps.ray_o, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.ray_d, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.thr, cap, nullptr))) return rc;
@@ -1477,6 +1508,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
     const size_t stack_threads = (size_t)h->persistent_blocks * RP_TRAVERSE_BLOCK;
     for (FrameCtx &c : h->ctx) {
+        c.gstack_threads = stack_threads;
         if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
         if (c.side && (rc = dev_alloc(h, &c.gstack_side, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
     }
@@ -2298,6 +2330,58 @@ static inline void pick(bool v, F &&f) {
         f(std::false_type());
 }
 
+// the one-launch frame's buffers, made by the first frame that wants them (frame-sized: initialize frees them with the rest): the control
+// words + one commit counter per slot of every published bounce (one allocation, one memset per frame), an id array per published bounce
+// >= 1, and stack scratch for the frame kernel's grid
+static int ensure_frame_queues(rptr_hip *h, FrameCtx &c, int grid_blocks) {
+    int rc;
+    const size_t slots = h->path_capacity / RP_CHUNK + 2;
+    if (!c.fq.st) {
+        const size_t words = sizeof(RpFqState) / sizeof(uint32_t) + (size_t)(RP_FQ_MAX - 1) * slots;
+        uint32_t *base = nullptr;
+        if ((rc = dev_alloc(h, &base, words, nullptr))) return rc;
+        c.fq.st = reinterpret_cast<RpFqState *>(base);
+        c.fq.commit = base + sizeof(RpFqState) / sizeof(uint32_t);
+        c.fq.slots = (uint32_t)slots;
+        c.fq.capacity = (uint32_t)h->path_capacity;
+        c.fq_words = words;
+        const bool fine = h->frame_fine_grained != 0;
+        if ((rc = dev_alloc(h, &c.fq.ids, (size_t)std::max(1, h->frame_pub_max - 1) * h->path_capacity, nullptr, fine))) return rc;
+        c.ps_fk = c.ps;
+        if (fine) {
+            const size_t cap = h->path_capacity;
+            if ((rc = dev_alloc(h, &c.ps_fk.ray_o, cap, nullptr, true))) return rc;
+            if ((rc = dev_alloc(h, &c.ps_fk.ray_d, cap, nullptr, true))) return rc;
+            if ((rc = dev_alloc(h, &c.ps_fk.thr, cap, nullptr, true))) return rc;
+            if ((rc = dev_alloc(h, &c.ps_fk.illum, cap, nullptr, true))) return rc;
+            if ((rc = dev_alloc(h, &c.ps_fk.rng_tt, cap, nullptr, true))) return rc;
+            c.ps_fk.alpha_rng = nullptr; // (made below when the handle has them: set_scene / set_rng_variant may add them later)
+            c.ps_fk.footprint = nullptr;
+        }
+        const size_t ring_entries = (size_t)RP_FQ_MAX * slots + 8192; // (every block of the grid holds a ticket beyond the last entry)
+        if ((rc = dev_alloc(h, &c.fq.ring, ring_entries, nullptr))) return rc;
+        HIP_TRY(h, hipMemsetAsync(c.fq.ring, 0, ring_entries * sizeof(unsigned long long), c.stream)); // epoch 0: no frame's
+        c.fq.epoch = 0;
+    }
+    {
+        const bool fine = h->frame_fine_grained != 0;
+        if (c.ps.alpha_rng && !c.ps_fk.alpha_rng) {
+            if (!fine) c.ps_fk.alpha_rng = c.ps.alpha_rng;
+            else if ((rc = dev_alloc(h, &c.ps_fk.alpha_rng, h->path_capacity, nullptr, true))) return rc;
+        }
+        if (c.ps.footprint && !c.ps_fk.footprint) {
+            if (!fine) c.ps_fk.footprint = c.ps.footprint;
+            else if ((rc = dev_alloc(h, &c.ps_fk.footprint, h->path_capacity, nullptr, true))) return rc;
+        }
+    }
+    const size_t threads = (size_t)grid_blocks * RP_TRAVERSE_BLOCK;
+    if (threads > c.gstack_threads) { // (the old scratch stays allocated until the next initialize: frames in flight may still use it)
+        if ((rc = dev_alloc(h, &c.gstack, threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+        c.gstack_threads = threads;
+    }
+    return RPTR_OK;
+}
+
 static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
@@ -2410,7 +2494,34 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
     }
     h->aov_ctx = (int)(&c - h->ctx.data());
     h->aov_overwritten = false;
-    if (h->local_rows > 0) {
+#ifdef RP_FRAME_PROF
+    if (c.fq_pub_used > 0) {
+        const RpFqState &q = *c.host_fq;
+        const double tot = std::max(1.0, (double)q.t_total);
+        fprintf(stderr, "[RP_FRAME_PROF] block time %.3f ms x blocks: claim %.3f extend %.3f shade %.3f connect %.3f publish %.3f (fence %.4f) | polls %u idle %u\n",
+                tot * 1e-5, q.t_claim / tot, q.t_extend / tot, q.t_shade / tot, q.t_connect / tot, q.t_publish / tot, q.t_fence / tot, q.polls, q.idle_polls);
+    }
+#endif
+    if (h->local_rows > 0 && c.fq_pub_used > 0 && c.host_fq->bad_ids != 0u)
+        return fail(h, RPTR_E_HIP, "the frame kernel read %u queue entries that name no path", c.host_fq->bad_ids);
+    if (h->local_rows > 0 && c.fq_pub_used > 0 && c.host_fq->timeout != 0u)
+        return fail(h, RPTR_E_HIP, "the frame kernel's queue protocol stalled (%u blocks gave up waiting; tail %u %u %u %u done %u %u %u %u final %u %u %u %u ring %u/%u)",
+                    c.host_fq->timeout, c.host_fq->tail[0], c.host_fq->tail[1], c.host_fq->tail[2], c.host_fq->tail[3], c.host_fq->done[0], c.host_fq->done[1],
+                    c.host_fq->done[2], c.host_fq->done[3], c.host_fq->final[0], c.host_fq->final[1], c.host_fq->final[2], c.host_fq->final[3],
+                    c.host_fq->ring_head, c.host_fq->ring_tail);
+    if (h->local_rows > 0 && c.fq_pub_used > 0) {
+        // how many bounces of the next one-launch frame get global queues: bounce b does when its PARENT queue was long (its survivors are
+        // then worth redistributing over all blocks); lengths are known for the bounces that were published, so the number grows by one per
+        // frame at most
+        const RpFqState &q = *c.host_fq;
+        int next = c.fq_pub_used + 1;
+        for (int b = 1; b <= c.fq_pub_used; ++b)
+            if (q.tail[b - 1] <= (uint32_t)h->frame_local_threshold) {
+                next = b;
+                break;
+            }
+        h->frame_pub_adaptive = std::max(1, std::min(next, h->frame_pub_max));
+    } else if (h->local_rows > 0) {
         // where the next frame hands over to the tail kernel: the first bounce whose queue was short in this frame. Queue
         // lengths are known up to the bounce the tail took over at (it does not publish its block-local lists), so the
         // hand-over moves later by one bounce per frame at most
@@ -2601,12 +2712,49 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
             const uint32_t first_count = (uint32_t)((size_t)batch * h->npix_padded);
             const uint32_t *first_ids = nullptr;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
+            // the whole frame in ONE launch (kernels.h rp_k_frame); counting keeps the stand-alone kernels
+            c.fq_pub_used = 0;
+            if (h->frame_kernel && !count_traversal) {
+                const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
+                const bool full = h->uses_textures || h->uses_alpha;
+                int per_cu = h->frame_blocks_per_cu;
+                if (per_cu <= 0) {
+                    HIP_TRY(h, rp_frame_blocks_per_cu(variant, lights, full, &per_cu));
+                    per_cu = std::max(1, std::min(per_cu, 8)); // (the ring holds 8192 tickets beyond its entries: 8 blocks per CU at most)
+                    // frames in flight share the CUs (as the traversal launches of the staged schedule do)
+                    if (h->ctx.size() > 1) per_cu = std::max(1, std::min(per_cu, (int)((8 + h->ctx.size() / 2) / h->ctx.size())));
+                }
+                const int blocks = h->num_cus * per_cu;
+                int n_pub = h->frame_pub_mode > 0 ? h->frame_pub_mode : h->frame_pub_adaptive;
+                n_pub = std::max(1, std::min(std::min(n_pub, h->frame_pub_max), std::min(h->params.max_path_depth, (int)RP_FQ_MAX)));
+                int rcq = ensure_frame_queues(h, c, blocks);
+                if (rcq) return rcq;
+                const uint32_t slots0 = (first_count + RP_CHUNK - 1) / RP_CHUNK;
+                // slots of bounce 0 a block takes at a time: enough rays to keep refilling its lanes, few enough that every block gets several turns
+                int k0 = h->frame_k0 > 0 ? h->frame_k0 : (int)std::max<uint32_t>(1u, std::min<uint32_t>(4u, slots0 / (4u * (uint32_t)blocks)));
+                if (n_pub == 1) k0 = 1; // the survivors stay with the block: one chunk at a time (kernels.h)
+                HIP_TRY(h, hipMemsetAsync(c.fq.st, 0, c.fq_words * sizeof(uint32_t), c.stream));
+                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.fq.st->tail[0], (int)first_count, 1, c.stream));
+                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.fq.st->final[0], 1, 1, c.stream));
+                c.fq.epoch = c.fq.epoch >= 65535u ? 1u : c.fq.epoch + 1u;
+                if (c.fq.epoch == 1u && h->next_ticket > 1) // the tags wrap: forget the old ones
+                    HIP_TRY(h, hipMemsetAsync(c.fq.ring, 0, ((size_t)RP_FQ_MAX * c.fq.slots + 8192) * sizeof(unsigned long long), c.stream));
+                RpFrameQueues fq = c.fq;
+                fq.n_pub = n_pub;
+                fq.k0 = k0;
+                fq.dbg = getenv("RPTR_FRAME_DBG") ? (uint32_t)atoi(getenv("RPTR_FRAME_DBG")) : 0u;
+                rp_launch_frame(variant, timed_launch(c.stream, 3, (unsigned)blocks), lights, full, single, table_rng, scn.dscene, f, c.ps_fk, c.sq, fq, c.counters,
+                                c.gstack);
+                HIP_TRY(h, hipMemcpyAsync(c.host_fq, c.fq.st, sizeof(RpFqState), hipMemcpyDeviceToHost, c.stream));
+                c.fq_pub_used = n_pub;
+                c.tail_from = 0;
+            }
             // the late bounces in one launch (kernels.h rp_k_tail); counting keeps the stand-alone kernels
             int tail_from = h->params.max_path_depth;
             if (h->tail_mode != 0 && !count_traversal)
                 tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
-            c.tail_from = tail_from;
-            for (int b = 0; b < h->params.max_path_depth; ++b) {
+            if (!c.fq_pub_used) c.tail_from = tail_from;
+            for (int b = 0; b < h->params.max_path_depth && !c.fq_pub_used; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 if (b == tail_from) {
@@ -2644,7 +2792,7 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
+                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.fq_pub_used ? c.ps_fk : c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
             }
             if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
@@ -2703,6 +2851,24 @@ int rptr_hip_set_bvh_policy(rptr_hip_t *h, int force_bvh_rebuild, int rebuild_tr
 int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds) {
     if (!h || !out_rebuilds) return fail(nullptr, RPTR_E_INVALID, "NULL argument");
     *out_rebuilds = h->rebuilds_done;
+    return RPTR_OK;
+}
+
+int rptr_hip_set_frame_schedule(rptr_hip_t *h, int one_launch_per_frame) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    h->frame_kernel = one_launch_per_frame != 0 ? 1 : 0;
+    return RPTR_OK;
+}
+int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, int32_t *out_published_bounces, uint32_t *out_queue_lengths, int cap) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (out_one_launch) *out_one_launch = h->frame_kernel;
+    const FrameCtx &c = h->ctx[(size_t)std::max(0, h->aov_ctx)];
+    if (out_published_bounces) *out_published_bounces = c.fq_pub_used;
+    for (int b = 0; out_queue_lengths && b < cap; ++b) out_queue_lengths[b] = (b < RP_FQ_MAX && b < c.fq_pub_used) ? c.host_fq->tail[b] : 0u;
+    if (out_queue_lengths && cap > RP_FQ_MAX + 1) { // diagnostics behind the lengths: claim attempts, attempts that found nothing
+        out_queue_lengths[RP_FQ_MAX] = c.host_fq->polls;
+        out_queue_lengths[RP_FQ_MAX + 1] = c.host_fq->idle_polls;
+    }
     return RPTR_OK;
 }
 
