@@ -405,6 +405,13 @@ int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, in
  * equal share of the batch's times and counts. No reference counterpart (the reference renders one frame per submission). */
 int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int n_frames, int reset_first, int reset_rest,
                                 int count_traversal, uint64_t *out_tickets);
+/* The same with a camera PER FRAME: cameras[0 .. n_frames) (n_frames <= 8). The reference's loop may move the camera every frame
+ * (app.cpp:350-469, vulkan/render_vulkan.cpp:2880-2941: the view parameters are written per frame); primary rays, the texture footprint
+ * and the position view of frame k use cameras[k], the AOV images (those of the last frame of the sequence) its view with the view of
+ * frame n_frames - 2 as VP_reference. Every frame is bit-identical to the same frame submitted alone with its camera. (Camera rays of
+ * such a sequence are made by the kernels' general instantiation -- the one that also serves table-driven point sets.) */
+int rptr_hip_render_batch_cameras_async(rptr_hip_t *h, const RptrCamera *cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                                        int count_traversal, uint64_t *out_tickets);
 /* RenderConfiguration::freeze_frame (librender/render_backend.h:39; vulkan/render_vulkan.cpp:1937-1941,2152-2154): while set, a reset
  * does not advance frame_offset and a rendered frame does not advance frame_id -- every frame repeats the same samples (the
  * reference's --freeze-frame, cmdline.cpp:359-360). */

@@ -65,6 +65,7 @@ def load_library(path=None):
     L.rptr_hip_render_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_wait.argtypes = [vp, C.c_uint64, C.POINTER(abi.Stats)]
     L.rptr_hip_render_batch_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
+    L.rptr_hip_render_batch_cameras_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
     L.rptr_hip_set_frame_schedule.argtypes = [vp, i32]
@@ -259,6 +260,20 @@ class RenderHip:
         tickets = (C.c_uint64 * n_frames)()
         self._check(self._L.rptr_hip_render_batch_async(self._h, C.byref(self.camera), self._variant, spp, n_frames, 1 if self.reset_accumulation else 0,
                                                         1 if reset_rest else 0, 1 if count_traversal else 0, tickets))
+        self.reset_accumulation = False
+        return [int(t) for t in tickets]
+
+    def render_batch_cameras_async(self, config: RenderConfiguration, cameras, spp=1, reset_rest=True, count_traversal=False):
+        """len(cameras) consecutive frames in one launch sequence, frame k through cameras[k] (include/rptr_hip.h
+        rptr_hip_render_batch_cameras_async; ≙ a host that moves the camera every frame, app.cpp:350-469); returns their tickets"""
+        self.begin_frame(None, config)
+        self._push_params()
+        n = len(cameras)
+        arr = (abi.Camera * n)(*cameras)
+        tickets = (C.c_uint64 * n)()
+        self._check(self._L.rptr_hip_render_batch_cameras_async(self._h, arr, self._variant, spp, n, 1 if self.reset_accumulation else 0,
+                                                                1 if reset_rest else 0, 1 if count_traversal else 0, tickets))
+        self.camera = cameras[-1]
         self.reset_accumulation = False
         return [int(t) for t in tickets]
 

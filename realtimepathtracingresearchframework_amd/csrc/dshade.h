@@ -79,6 +79,12 @@ static inline RpDivU32 rp_make_div(uint32_t d) { // host side (rptr_hip.hip); d 
     return r;
 }
 
+// the view of ONE frame of a launch sequence whose frames have cameras of their own (rptr_hip_render_batch_cameras_async; the reference's
+// loop may move the camera every frame: app.cpp:350-469, vulkan/render_vulkan.cpp:2880-2941)
+struct RpCam {
+    float pos[3], du[3], dv[3], dir_top_left[3];
+};
+#define RP_BATCH_CAMS 8 // frames of a launch sequence that can have a camera of their own
 // the per-frame constants: RenderParams + SceneParams + ViewParams subset
 // (vulkan/gpu_params.glsl:61-87,120-131) + this backend's tile mapping
 struct RpFrame {
@@ -121,8 +127,13 @@ struct RpFrame {
     // point set (rptr_hip_set_rng_variant): RPTR_RNG_VARIANT_* and its table as the reference uploads it (SobolData: 1024 x 32 matrix
     // words + the 256 x 256 tile inversion; BNData: 256 x 256 sequence values + the 128 x 128 x 8 scrambling tile)
     int32_t rng_variant;
-    int32_t _pad_rng;
+    int32_t per_frame_cams;      // the frames of this launch sequence have their own cameras (cams[frame]); 0: cam_* above serves them all
     const uint32_t *rng_table;
+    // cam_* above is frame 0's camera; view / proj / view_ref / proj_ref and aov_cam_pos belong to the LAST frame of the sequence (the one
+    // whose first sample writes the AOV images)
+    float aov_cam_pos[3];
+    float _pad_cam;
+    RpCam cams[RP_BATCH_CAMS];
 };
 // the frame a sample slot belongs to and its frame constants: sample_index, frame_offset (lcg_rng.glsl:36-39) and view_params.frame_id
 // (samples accumulated before the frame: seeds the alpha test of shadow rays, pt_megakernel.glsl:251-262)
@@ -193,7 +204,7 @@ RP_DEV V2 rp_screen_jitter(const RpFrame &f, uint32_t frame_offset, uint32_t fra
     return v2(halton_23[2 * idx] * 2.0f / w - 1.0f / w, halton_23[2 * idx + 1] * 2.0f / h - 1.0f / h);
 }
 RP_DEV void rp_store_geometry_aovs(const RpFrame &f, int pixel, V3 normal, V3 hit_point, V2 screen_jitter) { // :76-96 (motion_vector = 0)
-    f.aov_normal_depth[pixel] = rp_half4(normal.x, normal.y, normal.z, len3(hit_point - ld3(f.cam_pos)));
+    f.aov_normal_depth[pixel] = rp_half4(normal.x, normal.y, normal.z, len3(hit_point - ld3(f.aov_cam_pos)));
     float rx, ry, rw, cx, cy, cw;
     rp_project(f.view_ref, f.proj_ref, hit_point, rx, ry, rw);
     rp_project(f.view, f.proj, hit_point, cx, cy, cw);

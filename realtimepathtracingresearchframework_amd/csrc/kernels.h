@@ -145,8 +145,10 @@ RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *q
 // The camera ray of path p (pt_megakernel.glsl:314-325 + :330-352 pinhole branch): a pure function of the frame
 // constants and the path id, so nothing of it is stored -- the first extend and the first shade both call it
 // (saves writing and re-reading 72 bytes of path state per pixel sample). Returns false for padding slots.
+// origin: the camera position of the path's frame; du_dv (may be NULL): its image-plane axes. Frames with cameras of their own
+// (f.per_frame_cams) are rendered by the general (TABLE) instantiation: the shipped path reads the one camera of RpFrame as it always did.
 template <bool TABLE>
-RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot) {
+RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot, V3 &origin, V3 *du_dv = nullptr) {
     sslot = rp_div(p, f.div_npix_padded);
     const uint32_t slot = p - sslot * uint32_t(f.npix_padded);
     lx = ly = 0;
@@ -160,7 +162,20 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir,
     if (!TABLE || f.rp.enable_raster_taa == 0) point = point + (rp_draw2<TABLE>(f, rng, 0u /* DIM_PIXEL_X */) - v2(0.5f, 0.5f));
     point = v2(point.x / float(f.width), point.y / float(f.height));
     if (TABLE && f.rp.enable_raster_taa != 0) point = point + rp_screen_jitter(f, sf.frame_offset, sf.frame_id) * 0.5f; // pt_megakernel.glsl:319-320
-    dir = norm3(point.x * ld3(f.cam_du) + point.y * ld3(f.cam_dv) + ld3(f.cam_dir_top_left));
+    V3 du = ld3(f.cam_du), dv = ld3(f.cam_dv), tl = ld3(f.cam_dir_top_left);
+    origin = ld3(f.cam_pos);
+    if (TABLE && f.per_frame_cams != 0) {
+        const RpCam &c = f.cams[min(sf.frame, (uint32_t)(RP_BATCH_CAMS - 1))];
+        du = ld3(c.du);
+        dv = ld3(c.dv);
+        tl = ld3(c.dir_top_left);
+        origin = ld3(c.pos);
+    }
+    if (du_dv) {
+        du_dv[0] = du;
+        du_dv[1] = dv;
+    }
+    dir = norm3(point.x * du + point.y * dv + tl);
     return true;
 }
 // the generator of path p at a later bounce: index / pixel recomputed, the state `s` from the path state
@@ -188,10 +203,10 @@ RP_DEV uint32_t rp_alpha_seed(const RpFrame &f, uint32_t p) {
     return rp_rng_seed(sf.sample_index, sf.frame_offset, uint32_t(lx), uint32_t(rp_local_row_to_global(f, ly)), uint32_t(f.width));
 }
 template <bool TABLE>
-RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir) {
+RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, V3 &origin) {
     int lx, ly;
     uint32_t sslot;
-    return rp_primary_ray_ex<TABLE>(f, p, rng, dir, lx, ly, sslot);
+    return rp_primary_ray_ex<TABLE>(f, p, rng, dir, lx, ly, sslot, origin);
 }
 
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
@@ -214,11 +229,10 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         if (FIRST) {
             RpRng rng;
             rd = v3(0.0f, 0.0f, 1.0f);
-            if (!rp_primary_ray<TABLE>(f, p, rng, rd)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
+            if (!rp_primary_ray<TABLE>(f, p, rng, rd, ro)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
                 ps.hit_ids[p] = make_int2(-1, -1);
                 return false;
             }
-            ro = ld3(f.cam_pos);
             tmin = 0.0f;
             tmax = 2.e32f;
             if (ALPHA) lane_rng = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? rng.s : rp_alpha_seed(f, p);
@@ -501,10 +515,11 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             bool present = il < chunk_n; // this lane shades a path
             int first_lx = 0, first_ly = 0;
             uint32_t first_sslot = 0;
+            V3 first_du_dv[2] = {v3s(0.f), v3s(0.f)}; // FIRST && TEX: the image-plane axes of the path's camera
             if (present) {
                 p = il < chunk_hits ? s_list[il] : s_list[RP_CHUNK - 1 - (il - chunk_hits)];
                 // bounce 0: the camera ray again; ids of tile padding name no pixel sample (the first queue is the identity)
-                if (FIRST) present = rp_primary_ray_ex<TABLE>(f, p, rng, ray_dir, first_lx, first_ly, first_sslot);
+                if (FIRST) present = rp_primary_ray_ex<TABLE>(f, p, rng, ray_dir, first_lx, first_ly, first_sslot, ray_origin, TEX ? first_du_dv : nullptr);
             }
             if (present) {
                 my_closest++;
@@ -518,14 +533,13 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                             if (TABLE) aov_jitter = rp_screen_jitter(f, sf.frame_offset, sf.frame_id);
                         }
                     }
-                    ray_origin = ld3(f.cam_pos);
                     throughput = v3s(1.0f);
                     illum = v3s(0.0f);
                     prev_bounce_pdf = 2.e16f;
                     total_t = 0.0f;
                     bounce = 0;
                     if (TEX) { // :341-351
-                        const V3 dpdx = (ld3(f.cam_du) / float(f.width)) * f.rp.pixel_radius, dpdy = (ld3(f.cam_dv) / float(f.height)) * f.rp.pixel_radius;
+                        const V3 dpdx = (first_du_dv[0] / float(f.width)) * f.rp.pixel_radius, dpdy = (first_du_dv[1] / float(f.height)) * f.rp.pixel_radius;
                         tex_fp = rp_dpdxy_to_footprint(ray_dir, dpdx, dpdy);
                     }
                 } else {

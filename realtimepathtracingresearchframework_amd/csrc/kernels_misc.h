@@ -35,7 +35,7 @@ RP_DEV V3 rp_tonemap(int mode, V3 c) {
     return c; // NO_TONE_MAPPING
 }
 // process_samples.comp:143-190: what the RGBA8 frame buffer shows for the resolved pixel `acc` (alpha already clamped)
-RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
+RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel, int frame = 0) {
     const int ch = f.rp.output_channel;
     if (ch == 0) { // OUTPUT_CHANNEL_COLOR
         const float e = exp2f(f.rp.exposure);
@@ -69,7 +69,10 @@ RP_DEV float4 rp_display_color(const RpFrame &f, float4 o, int pixel) {
             } else
                 o = make_float4(o.x * 0.5f + 0.5f, o.y * 0.5f + 0.5f, o.z * 0.5f + 0.5f, o.w);
         } else if (ch == 3)
-            o = make_float4((o.x - f.cam_pos[0]) * 0.1f + 0.5f, (o.y - f.cam_pos[1]) * 0.1f + 0.5f, (o.z - f.cam_pos[2]) * 0.1f + 0.5f, o.w);
+        {
+            const float *cp = f.per_frame_cams != 0 ? f.cams[min(frame, RP_BATCH_CAMS - 1)].pos : f.cam_pos;
+            o = make_float4((o.x - cp[0]) * 0.1f + 0.5f, (o.y - cp[1]) * 0.1f + 0.5f, (o.z - cp[2]) * 0.1f + 0.5f, o.w);
+        }
     }
     return make_float4(rp_linear_to_srgb(o.x), rp_linear_to_srgb(o.y), rp_linear_to_srgb(o.z), o.w);
 }
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void rp_k_resolve(RpFrame f, RpPathState ps, f
             float4 o = acc;
             o.w = fminf(o.w, 1.0f);
             if (o.w >= 0.0f) {
-                o = rp_display_color(f, o, i);
+                o = rp_display_color(f, o, i, k);
                 shown = make_uchar4((unsigned char)(clamp1(o.x, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.y, 0.f, 1.f) * 255.0f + 0.5f),
                                     (unsigned char)(clamp1(o.z, 0.f, 1.f) * 255.0f + 0.5f), (unsigned char)(clamp1(o.w, 0.f, 1.f) * 255.0f + 0.5f));
             }

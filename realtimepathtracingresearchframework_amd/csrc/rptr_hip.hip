@@ -2386,7 +2386,8 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &s
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
-    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures, f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0, scene, f, c.ps, c.sq, order,
+    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures,
+                    f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0 || (bounce == 0 && f.per_frame_cams != 0), scene, f, c.ps, c.sq, order,
                     (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
                     &c.counters->bounce[bounce].shadow_count, c.counters);
 }
@@ -2556,11 +2557,28 @@ int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, 
     return rptr_hip_render_batch_async(h, camera, variant, spp, 1, reset_accumulation, 0, count_traversal, out_ticket);
 }
 
+extern "C++" {
+static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                             int count_traversal, uint64_t *out_tickets);
+}
 int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int n_frames, int reset_first, int reset_rest,
                                 int count_traversal, uint64_t *out_tickets) {
+    return render_batch_impl(h, camera, false, variant, spp, n_frames, reset_first, reset_rest, count_traversal, out_tickets);
+}
+int rptr_hip_render_batch_cameras_async(rptr_hip_t *h, const RptrCamera *cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                                        int count_traversal, uint64_t *out_tickets) {
+    return render_batch_impl(h, cameras, n_frames > 1, variant, spp, n_frames, reset_first, reset_rest, count_traversal, out_tickets);
+}
+
+extern "C++" {
+// camera: ONE camera for all frames of the sequence, or (per_frame_cameras) n_frames of them
+static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                             int count_traversal, uint64_t *out_tickets) {
     const int reset_accumulation = reset_first;
     if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (n_frames < 1) return fail(h, RPTR_E_INVALID, "n_frames must be >= 1");
+    if (per_frame_cameras && n_frames > RP_BATCH_CAMS)
+        return fail(h, RPTR_E_INVALID, "a launch sequence holds at most %d frames with cameras of their own", RP_BATCH_CAMS);
     if (n_frames > 1) {
         if (h->ctx.size() < 2) return fail(h, RPTR_E_INVALID, "batches of frames need frames_in_flight >= 2 (every frame of a batch keeps its own image)");
         if (n_frames > h->max_batch_frames) return fail(h, RPTR_E_INVALID, "a batch holds at most %d frames (RPTR_MAX_BATCH_FRAMES)", h->max_batch_frames);
@@ -2596,11 +2614,29 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
     f.rp = h->params;
     f.sp = h->scene_params;
     f.lc = h->lighting;
-    compute_view(*camera, h->width, h->height, f);
-    compute_view_projection(*camera, h->width, h->height, f.view, f.proj);
-    compute_view_projection(h->have_prev_camera ? h->prev_camera : *camera, h->width, h->height, f.view_ref, f.proj_ref);
-    h->prev_camera = *camera;
-    h->have_prev_camera = true;
+    compute_view(camera[0], h->width, h->height, f);
+    if (per_frame_cameras) { // every frame of the sequence looks through its own camera (kernels.h rp_primary_ray_ex: the general instantiation)
+        f.per_frame_cams = 1;
+        for (int k = 0; k < n_frames; ++k) {
+            RpFrame t;
+            compute_view(camera[k], h->width, h->height, t);
+            memcpy(f.cams[k].pos, t.cam_pos, sizeof(t.cam_pos));
+            memcpy(f.cams[k].du, t.cam_du, sizeof(t.cam_du));
+            memcpy(f.cams[k].dv, t.cam_dv, sizeof(t.cam_dv));
+            memcpy(f.cams[k].dir_top_left, t.cam_dir_top_left, sizeof(t.cam_dir_top_left));
+        }
+    }
+    {
+        // the AOV images are those of the LAST frame of the sequence: its view, and as VP_reference the view of the frame before it (the
+        // previous submission's last camera when the sequence is one frame)
+        const RptrCamera &last = camera[per_frame_cameras ? n_frames - 1 : 0];
+        const RptrCamera &before = n_frames > 1 ? camera[per_frame_cameras ? n_frames - 2 : 0] : (h->have_prev_camera ? h->prev_camera : last);
+        compute_view_projection(last, h->width, h->height, f.view, f.proj);
+        compute_view_projection(before, h->width, h->height, f.view_ref, f.proj_ref);
+        memcpy(f.aov_cam_pos, last.pos, sizeof(f.aov_cam_pos));
+        h->prev_camera = last;
+        h->have_prev_camera = true;
+    }
     f.aov_albedo_roughness = c.aov[0];
     f.aov_normal_depth = c.aov[1];
     f.aov_motion_jitter = c.aov[2];
@@ -2664,7 +2700,8 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         return l;
     };
     // the general instantiation of the path stages: a table point set, or a screen jitter (raster TAA) -- the shipped path carries neither
-    const bool table_rng = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
+    const bool table_rng_later = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
+    const bool table_rng = table_rng_later || per_frame_cameras; // (the launches that make camera rays: the first bounce, the one-launch frame)
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
@@ -2761,11 +2798,11 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
                     if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) on the side stream
                     const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
-                    rp_launch_tail(variant, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng, scn.dscene, f, c.ps, c.sq,
+                    rp_launch_tail(variant, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng_later, scn.dscene, f, c.ps, c.sq,
                                    (const uint32_t *)c.queue[in], c.counters, b, c.gstack);
                     break;
                 }
-                rp_launch_extend(timed_launch(c.stream, 0, (unsigned)h->persistent_blocks), count_traversal, b == 0, h->uses_alpha, single, table_rng, scn.dscene, f, c.ps,
+                rp_launch_extend(timed_launch(c.stream, 0, (unsigned)h->persistent_blocks), count_traversal, b == 0, h->uses_alpha, single, b == 0 ? table_rng : table_rng_later, scn.dscene, f, c.ps,
                                  b == 0 ? first_ids : (const uint32_t *)c.queue[in], bc, c.counters, c.gstack);
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
@@ -2839,6 +2876,7 @@ int rptr_hip_render_batch_async(rptr_hip_t *h, const RptrCamera *camera, int var
         for (int k = 0; k < n_frames; ++k) out_tickets[k] = c.ticket + (uint64_t)k;
     return RPTR_OK;
 }
+} // extern "C++"
 
 int rptr_hip_set_bvh_policy(rptr_hip_t *h, int force_bvh_rebuild, int rebuild_triangle_budget) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");

@@ -401,6 +401,73 @@ def test_batched_frames_are_bit_identical_to_frames_rendered_one_by_one(reset_re
     assert not np.array_equal(ref_images[1][0], ref_images[2][0])
 
 
+def _moved(cam, k):
+    """the camera of frame k: a small orbit step around the view (what a host's fly-through does every frame)"""
+    c = abi.Camera()
+    a = 0.03 * k
+    d = np.asarray(cam.dir[:], np.float32)
+    up = np.asarray(cam.up[:], np.float32)
+    right = np.cross(d, up).astype(np.float32)
+    nd = (np.cos(a) * d + np.sin(a) * right).astype(np.float32)
+    nd /= np.float32(np.sqrt(np.dot(nd, nd)))
+    c.pos[:] = [float(cam.pos[0] + 0.05 * k), float(cam.pos[1] + 0.02 * k), float(cam.pos[2] - 0.04 * k)]
+    c.dir[:] = [float(x) for x in nd]
+    c.up[:] = [float(x) for x in up]
+    c.fovy = float(cam.fovy + 0.5 * k)
+    return c
+
+
+@pytest.mark.parametrize("scene_name,reset_rest,one_launch", [("grid", True, False), ("grid", False, False), ("textured_test", True, False), ("grid", True, True)])
+def test_batched_frames_with_a_camera_per_frame_equal_frames_rendered_one_by_one(scene_name, reset_rest, one_launch):
+    """rptr_hip_render_batch_cameras_async: the reference's loop may move the camera every frame (app.cpp:350-469); a launch sequence
+    of 4 frames x 2 spp with four different views gives, frame by frame, the image -- and for the last frame the AOV images, whose
+    motion vectors are against the third frame's view -- of the same frames submitted alone. Textured scene: the footprint of the
+    camera rays follows the frame's camera too. one_launch: through the frame kernel."""
+    s = scenes.grid(120, 60, with_emitters=True) if scene_name == "grid" else scenes.textured_test()
+    W, H, spp, n = 168, 96, 2, 4
+    cams = [_moved(s.camera_params(), k) for k in range(n + 1)]
+
+    def run(batched):
+        r = backend.RenderHip(frames_in_flight=2)
+        r.initialize(W, H)
+        r.set_scene(s)
+        r.set_frame_schedule(one_launch)
+        out = []
+
+        def collect(t):
+            st = r.wait(t)
+            img = np.zeros((H, W, 4), np.float32)
+            assert r.readback_framebuffer(img) == W * H * 4
+            out.append((img, st.spp))
+        collect(r.render_async(backend.RenderConfiguration(cams[n], active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1))
+        if batched:
+            cfg0 = backend.RenderConfiguration(cams[0], active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+            for t in r.render_batch_cameras_async(cfg0, cams[:n], spp=spp, reset_rest=reset_rest):
+                collect(t)
+        else:
+            for k in range(n):
+                collect(r.render_async(backend.RenderConfiguration(cams[k], active_variant=abi.VARIANT_GLTF, reset_accumulation=(k == 0 or reset_rest)), spp=spp))
+        aovs = []
+        for i in range(3):
+            buf = np.zeros((H, W, 4), np.uint16)
+            assert r.readback_aov(i, buf) == W * H * 4
+            aovs.append(buf)
+        collect(r.render_async(backend.RenderConfiguration(cams[n - 1], active_variant=abi.VARIANT_GLTF, reset_accumulation=False), spp=1))
+        r.close()
+        return out, aovs
+
+    ref, ref_aovs = run(False)
+    got, aovs = run(True)
+    assert [g[1] for g in got] == [x[1] for x in ref]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)), k
+    for a, b in zip(aovs, ref_aovs):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(ref[1][0], ref[2][0])
+    if reset_rest:                                                    # different views, not the same image four times
+        assert np.abs(ref[1][0][..., :3] - ref[4][0][..., :3]).mean() > 1e-3
+
+
 def test_batch_limits_and_gather_of_batched_frames():
     s = scenes.cornell32()
     W, H = 96, 64
