@@ -95,6 +95,12 @@ def parse_args():
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--rccl-probe", action="store_true", help="(internal) run as the probe child of a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--static-camera", action="store_true",
+                    help="every frame through the same camera (rounds 1-3). Default: the camera MOVES every frame, as the reference's loop lets it "
+                         "(app.cpp:350-469) -- launch sequences of several frames then carry a camera per frame (rptr_hip_render_batch_cameras_async)")
+    ap.add_argument("--sustained-seconds", type=float, default=1.0,
+                    help="after the timed region the same schedule runs on for at least this long (untimed by --steps): roofline.sustained")
+    ap.add_argument("--one-launch", action="store_true", help="frames as ONE launch driven from device-side queues (rptr_hip_set_frame_schedule)")
     ap.add_argument("--profile-pass", action="store_true",
                     help="for rocprofv3 --pmc / --kernel-trace passes (tools/pmc.sh): warm-up + `steps` frames one at a time, nothing else, no JSON line")
     return ap.parse_args()
@@ -227,17 +233,21 @@ def load_valu_peak():
     instructions / s at 8 waves per SIMD): of plain full-rate instructions (v_fma_f32 / v_mul_f32 / v_add_u32: one per 2 clocks per
     SIMD, MI355X_MICROARCH.md) and of the instruction mix of the BVH4 node step (v_cvt_f32_ubyte, v_pk_fma_f32, min / max issue at half
     that rate). None when the file is absent."""
-    try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r03a_valu_issue.json")))
-        best = {}
-        for r in doc["results"]:
-            best[r["op"]] = max(best.get(r["op"], 0.0), r["ginst_s_wall"])
-        mix = max(v for k, v in best.items() if k.startswith("node_step_mix"))
-        full = max(best.get("v_fma_f32", 0.0), best.get("v_mul_f32", 0.0), best.get("v_add_u32", 0.0))
-        return {"node_step_mix_ginst_s": mix, "full_rate_ginst_s": full, "half_rate_ginst_s": best.get("v_pk_fma_f32"),
-                "source": "profiles/r03a_valu_issue.json (tools/microbench/valu_issue.hip on an MI355X of the pool)"}
-    except Exception:
-        return None
+    for name in ("r04_valu_issue.json", "r03a_valu_issue.json"):
+        try:
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            best = {}
+            for r in doc["results"]:
+                best[r["op"]] = max(best.get(r["op"], 0.0), r["ginst_s_wall"])
+            mix = max(v for k, v in best.items() if k.startswith("node_step_mix("))
+            full = max(best.get("v_fma_f32", 0.0), best.get("v_mul_f32", 0.0), best.get("v_add_u32", 0.0))
+            # the issue ceiling of each path kernel's OWN static instruction mix (tools/kernel_mix.py -> kmix_gen.h -> the microbenchmark)
+            kmix = {k[5:]: v for k, v in best.items() if k.startswith("kmix:")}
+            return {"node_step_mix_ginst_s": mix, "full_rate_ginst_s": full, "half_rate_ginst_s": best.get("v_pk_fma_f32"), "kmix": kmix,
+                    "source": "profiles/%s (tools/microbench/valu_issue.hip on an MI355X of the pool)" % name}
+        except Exception:
+            continue
+    return None
 
 
 def traffic_of(pmc, prefix, field="hbm_bytes_per_launch"):
@@ -341,6 +351,28 @@ def main():
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
     cam = scene.camera_params()
+    if args.one_launch:
+        r.set_frame_schedule(True)
+
+    def camera_of(k):
+        """the view of frame k: a fly-through step per frame (yaw 0.002 rad, 2 cm sideways), so that consecutive frames differ the way an
+        interactive host's do while the workload stays the one the configuration names"""
+        if args.static_camera:
+            return cam
+        import numpy as np
+        c = abi.Camera()
+        a = 0.002 * (k % 64)
+        d, up = np.asarray(cam.dir[:], np.float64), np.asarray(cam.up[:], np.float64)
+        right = np.cross(d, up)
+        right /= np.linalg.norm(right)
+        nd = np.cos(a) * d + np.sin(a) * right
+        nd /= np.linalg.norm(nd)
+        c.pos[:] = [float(np.float32(cam.pos[i] + 0.02 * (k % 64) * right[i])) for i in range(3)]
+        c.dir[:] = [float(np.float32(x)) for x in nd]
+        c.up[:] = list(cam.up[:])
+        c.fovy = cam.fovy
+        return c
+    frame_no = [0]
 
     # ---- the gather (N > 1): the library's own RCCL path, or torch.distributed as plumbing
     # the gather: "native" = the library's RCCL gather; "torch" = tile copy + torch.distributed.gather over an nccl group; "host" = the same over
@@ -425,9 +457,16 @@ def main():
         while left > 0:
             if anim is not None:
                 animate()
-            cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
             n = min(batch_frames, left)
-            queue.append(r.render_batch_async(cfg, spp=spp, n_frames=n, reset_rest=True) if n > 1 else [r.render_async(cfg, spp=spp)])
+            cams = [camera_of(frame_no[0] + j) for j in range(n)]
+            frame_no[0] += n
+            cfg = backend.RenderConfiguration(cams[0], active_variant=variant, reset_accumulation=True)
+            if n == 1:
+                queue.append([r.render_async(cfg, spp=spp)])
+            elif args.static_camera:
+                queue.append(r.render_batch_async(cfg, spp=spp, n_frames=n, reset_rest=True))
+            else:
+                queue.append(r.render_batch_cameras_async(cfg, cams, spp=spp, reset_rest=True))
             left -= n
             if len(queue) >= fif:
                 for t in queue.pop(0):
@@ -558,6 +597,30 @@ def main():
         latency[str(depth)] = latency_of(rl, depth, n_lat)
         rl.close()
 
+    # ---- sustained: the same schedule for at least --sustained-seconds more (the timed region of a 20-step run lasts 26 ms: no sampler
+    # sees it and it says nothing about clocks under load); and, for comparison, the same with a camera that stands still
+    sustained, static_leg = None, None   # (after the latency legs: they are taken on a GPU that has just finished the timed region, as in rounds 1-3)
+    if args.sustained_seconds > 0 and world == 1:
+        chunk = max(batch_frames * fif, 8)
+        n_s, t_s = 0, time.perf_counter()
+        while time.perf_counter() - t_s < args.sustained_seconds:
+            timed_steps(chunk, lambda st: None)
+            n_s += chunk
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_s
+        sustained = {"ms_per_step": round(dt * 1e3 / n_s, 4), "steps": n_s, "seconds": round(dt, 3)}
+        if not args.static_camera and anim is None:
+            args.static_camera = True
+            timed_steps(chunk, lambda st: None)
+            torch.cuda.synchronize()
+            n_c, t_c = 0, time.perf_counter()
+            while time.perf_counter() - t_c < min(0.5, args.sustained_seconds):
+                timed_steps(chunk, lambda st: None)
+                n_c += chunk
+            torch.cuda.synchronize()
+            static_leg = {"ms_per_step": round((time.perf_counter() - t_c) * 1e3 / n_c, 4), "steps": n_c,
+                          "what": "the same schedule with ONE camera for all frames (what rounds 1-3 timed)"}
+            args.static_camera = False
     def counted(depth=None):
         """one instrumented frame (COUNT kernels, every bounce a stand-alone launch), optionally cut at `depth` bounces"""
         full = rx.params.max_path_depth
@@ -615,6 +678,11 @@ def main():
     shade_vertices = cnt_ext["rays_closest"]       # one shade invocation per closest-hit query of the stand-alone bounces
     shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES)
                    + cnt_ext["hits"] * (VERTEX_BYTES + MATERIAL_BYTES))
+    # all bounces of a frame (the tail kernel's included), counted on the instrumented frame
+    total_alg_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * (RAY_BYTES + QUEUE_BYTES) + cnt["nodes_closest"] * NODE_BYTES
+                       + cnt["tris_closest"] * TRI_BYTES + cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
+                       + cnt["tris_shadow"] * TRI_BYTES + cnt["rays_closest"] * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES)
+                       - primary * (QUEUE_BYTES + PATH_READ_BYTES) + cnt["hits"] * (VERTEX_BYTES + MATERIAL_BYTES) + r.local_pixel_count() * (16 * spp + 36))
     wkey = workload_key(args, world)
     pmc = load_pmc_traffic(wkey)   # the committed counter passes of THIS workload (profiles/pmc_traffic.json), None for anything else
     n_launch = max(launches_extend, 1)
@@ -626,7 +694,13 @@ def main():
     vp = load_valu_peak()
     valu_peak = vp["node_step_mix_ginst_s"] if vp else props.multi_processor_count * MAX_CLOCK_GHZ
 
-    def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches):
+    def own_peak(labels):
+        """issue ceiling of a kernel class: the mean over its instantiations' static mixes; None when the mixes were not measured"""
+        k = (vp or {}).get("kmix") or {}
+        v = [k[l] for l in labels if l in k]
+        return sum(v) / len(v) if v else None
+
+    def kernel_entry(name, prefix_list, alg_bytes_step, ms_step, launches, mix_labels=(), node_step=False):
         """one kernel class: exclusive time, algorithmic bytes and their rate against the cache-hierarchy ceiling, counter traffic
         and its rate against the HBM peak"""
         tr = None
@@ -651,7 +725,13 @@ def main():
                 vi = sum(parts) / len(parts)
         e["valu_insts_per_launch"] = int(vi) if vi is not None else None
         e["valu_ginst_s"] = round(vi / (launch_ms * 1e-3) / 1e9, 1) if (vi is not None and launch_ms > 0) else None
-        e["valu_frac"] = round(e["valu_ginst_s"] / valu_peak, 4) if e["valu_ginst_s"] is not None else None
+        # the ceiling of THIS kernel's instruction mix: its static VALU histogram run through the issue microbenchmark (profiles/r04_kernel_mix.json);
+        # the traversal kernels spend their time in the node step, whose hand-counted mix has its own measurement (the lower of the two is used)
+        op = own_peak(mix_labels)
+        peak = min(op, valu_peak) if (op is not None and node_step) else (op if op is not None else valu_peak)
+        e["valu_peak_ginst_s"] = round(peak, 1)
+        e["valu_peak_what"] = ("static mix of the kernel (%s)%s" % (", ".join(mix_labels), "; node-step mix %.0f" % valu_peak if node_step else "")) if op is not None else "node-step mix (no per-kernel measurement)"
+        e["valu_frac"] = round(e["valu_ginst_s"] / peak, 4) if e["valu_ginst_s"] is not None else None
         if pmc:
             for fld in ("wait_any_frac", "wait_inst_any_frac", "active_inst_valu_frac", "tcc_hit_rate"):
                 parts = [traffic_of(pmc, p, fld) for p in prefix_list]
@@ -662,10 +742,12 @@ def main():
     sfx = ", false, %s" % ("true" if single else "false")   # (COUNT, FIRST,) ALPHA, SINGLE [, TABLE]
     var_id = "1" if variant == abi.VARIANT_SIMPLE else "0"
     k_ext = kernel_entry("rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE=%s>: first bounce FIRST=true, later bounces FIRST=false" % str(single).lower(),
-                         ["rp_k_extend<false, true" + sfx, "rp_k_extend<false, false" + sfx][:n_launch], ext_bytes, serial["ext"], launches_extend)
-    k_con = kernel_entry("rp_k_connect<COUNT=false, ALPHA=false, SINGLE=%s>" % str(single).lower(), ["rp_k_connect<false" + sfx], con_bytes, serial["con"], launches_extend)
+                         ["rp_k_extend<false, true" + sfx, "rp_k_extend<false, false" + sfx][:n_launch], ext_bytes, serial["ext"], launches_extend,
+                         ["extend_first", "extend"][:n_launch], True)
+    k_con = kernel_entry("rp_k_connect<COUNT=false, ALPHA=false, SINGLE=%s>" % str(single).lower(), ["rp_k_connect<false" + sfx], con_bytes, serial["con"], launches_extend, ["connect"], True)
     k_shade = kernel_entry("rp_k_shade<VARIANT=%s, FIRST, LIGHTS, TEX>" % var_id, ["rp_k_shade<%s, true" % var_id, "rp_k_shade<%s, false" % var_id][:n_launch],
-                           shade_bytes, serial["shade"], launches_extend)
+                           shade_bytes, serial["shade"], launches_extend,
+                           (["shade_first_lambert", "shade_lambert"] if variant == abi.VARIANT_SIMPLE else ["shade_first_gltf_lights", "shade_gltf_lights"])[:n_launch])
     hbm_known = k_ext["hbm_gbs"] is not None
     fetches = cnt_ext["nodes_closest"] + cnt_ext["tris_closest"]
     roofline = {
@@ -720,6 +802,13 @@ def main():
                       "extend_launch_ms_overlapped": round(ext_ms * batch_frames / K / n_launch, 5),
                       "note": "launches of neighbouring frames share the GPU in the timed region: their durations overlap and are NOT exclusive (their sum may "
                               "exceed ms_per_step); they are reported for the rocprofv3 cross-check only (profiles/, same command)"},
+        "sustained": sustained,
+        "static_camera": static_leg,
+        # every stage's algorithmic bytes of a frame over the pipelined frame time: more than HBM could deliver -- the tree (tens of MB) is
+        # served by the L2s and the Infinity Cache; a statement about work per second, not about a bound
+        "all_stages_algorithmic": {"bytes_per_step": int(total_alg_bytes), "gbs": round(total_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                   "over_hbm_peak": round(total_alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                   "what": "extend + connect + shade (all bounces, counted) + resolve bytes per frame / pipelined ms per frame: cache-served"},
         "latency": latency,
         "counts_per_step": cnt,
         "tail": {"from_bounce": launches_extend, "max_path_depth": max_depth,
@@ -746,6 +835,8 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
+                   "camera": "one view for all frames" if args.static_camera else "moves every frame (a camera per frame inside a launch sequence)",
+                   "frame_schedule": "one launch per frame (rp_k_frame)" if args.one_launch else "stage launches",
                    "frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2),
@@ -772,6 +863,10 @@ def main():
         import oracle_lib as O
         osc = O.OracleScene(scene)
         osc.build_bvh()
+        # the heavy configurations (C3 - C5) at 480 x 270 with the same spp, as BASELINE.md section 2 prescribes: Mrays/s is a rate
+        cw, chh = (W, H) if (args.scene == "grid" and not args.lights and not args.animate and W * H * spp <= 1920 * 1080 * 4) else (480, 270)
+        W_gpu, H_gpu = W, H
+        W, H = cw, chh
         osc.render(W, H, 1, variant=variant, rows=(H // 2, H // 2 + 8), threads=0)  # warm-up
         cores = host_cpu_budget(O.lib().orc_hw_threads())
         # bounded sample: the whole frame when there are many cores, a centred band of rows otherwise (~10-30 core-seconds per pass)
@@ -785,8 +880,9 @@ def main():
         out["cpu_baseline"] = {
             "value": round(rate, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "median of 3 timed passes over rows %d..%d of the same %dx%d frame at %d spp (%d rays in %.2f s; all three: %s Mrays/s); "
-                      "oracle/liboracle.so (scalar BVH2 traversal + shading, std::thread over rows)"
-                      % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, secs, ", ".join("%.1f" % x[0] for x in runs)),
+                      "oracle/liboracle.so (scalar BVH2 traversal + shading, std::thread over rows)%s"
+                      % (rows[0], rows[1] - 1, W, H, spp, cpu_rays, secs, ", ".join("%.1f" % x[0] for x in runs),
+                         "" if (W, H) == (W_gpu, H_gpu) else "; reduced resolution (the GPU frame is %dx%d): BASELINE.md section 2" % (W_gpu, H_gpu)),
         }
     print(json.dumps(out))
     if world > 1:

@@ -24,11 +24,18 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Op { FMA, PK_FMA, CVT_UBYTE, MIN3, MAX_F, CNDMASK, MUL, ADD_U32, RCP, SQRT, NODE_MIX, FMA_SALU, FMA_MIX, CVT_F16, CVT_U32, BFE_U32, NODE_MIX_F16, N_OPS };
-static const char *op_names[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_min3_f32", "v_max_f32", "v_cndmask_b32", "v_mul_f32",
+#if __has_include("kmix_gen.h")
+#include "kmix_gen.h" // the static VALU mix of each path kernel (tools/kernel_mix.py): KMIX_N loop bodies of 96 instructions
+#else
+#define KMIX_N 0
+#endif
+enum Op { FMA, PK_FMA, CVT_UBYTE, MIN3, MAX_F, CNDMASK, MUL, ADD_U32, RCP, SQRT, NODE_MIX, FMA_SALU, FMA_MIX, CVT_F16, CVT_U32, BFE_U32, NODE_MIX_F16,
+          AND_B32, LSHL_B32, MOV_B32, CMP_F32, ADD_F32, MUL_LO_U32, READLANE, N_BASE_OPS, KMIX0 = N_BASE_OPS, N_OPS = N_BASE_OPS + 16 };
+static const char *op_names[N_BASE_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_min3_f32", "v_max_f32", "v_cndmask_b32", "v_mul_f32",
                                       "v_add_u32", "v_rcp_f32", "v_sqrt_f32", "node_step_mix(24 cvt,12 pk_fma,18 minmax,14 cndmask,12 add/and)", "v_fma_f32 + s_add_u32 (1:1)",
                                       "v_fma_mix_f32 (f16 x f32 + f32)", "v_cvt_f32_f16", "v_cvt_f32_u32", "v_bfe_u32",
-                                      "node_step_mix with f16 planes(24 fma_mix,18 minmax,14 cndmask,12 add/and)"};
+                                      "node_step_mix with f16 planes(24 fma_mix,18 minmax,14 cndmask,12 add/and)",
+                                      "v_and_b32", "v_lshlrev_b32", "v_mov_b32", "v_cmp_lt_f32", "v_add_f32", "v_mul_lo_u32", "v_readfirstlane_b32"};
 
 // one instruction on accumulator `a` (and, where it needs them, constants b, c). All streams are independent across the 8 accumulators.
 #define I_FMA(a)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
@@ -46,6 +53,13 @@ static const char *op_names[N_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ub
 #define I_CVTU(a)     asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a));
 #define I_BFE(a)      asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(a));
 #define I_SALU(s)     asm volatile("s_add_u32 %0, %0, 1" : "+s"(s));
+#define I_AND(a)      asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define I_LSHL(a)     asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
+#define I_MOV(a)      asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b));
+#define I_CMP(a)      asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
+#define I_ADDF(a)     asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define I_MULLO(a)    asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+#define I_LANE(a)     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s0) : "v"(a));
 
 #define R8(M) M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
 #define R8P(M) M(p0) M(p1) M(p2) M(p3) M(p4) M(p5) M(p6) M(p7)
@@ -90,6 +104,43 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
             R8(I_CND) I_CND(a0) I_CND(a1) I_CND(a2) I_CND(a3) I_CND(a4) I_CND(a5)
             R8(I_ADDU) I_ADDU(a0) I_ADDU(a1) I_ADDU(a2) I_ADDU(a3)
         }
+        if (OP == AND_B32) { R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) }
+        if (OP == LSHL_B32) { R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) }
+        if (OP == MOV_B32) { R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) }
+        if (OP == CMP_F32) { R8(I_CMP) R8(I_CMP) R8(I_CMP) R8(I_CMP) R8(I_CMP) R8(I_CMP) R8(I_CMP) R8(I_CMP) }
+        if (OP == ADD_F32) { R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) R8(I_ADDF) }
+        if (OP == MUL_LO_U32) { R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) R8(I_MULLO) }
+        if (OP == READLANE) { R8(I_LANE) R8(I_LANE) R8(I_LANE) R8(I_LANE) R8(I_LANE) R8(I_LANE) R8(I_LANE) R8(I_LANE) }
+#if KMIX_N > 0
+        if (OP == KMIX0 + 0) { KMIX_BODY_0 }
+#endif
+#if KMIX_N > 1
+        if (OP == KMIX0 + 1) { KMIX_BODY_1 }
+#endif
+#if KMIX_N > 2
+        if (OP == KMIX0 + 2) { KMIX_BODY_2 }
+#endif
+#if KMIX_N > 3
+        if (OP == KMIX0 + 3) { KMIX_BODY_3 }
+#endif
+#if KMIX_N > 4
+        if (OP == KMIX0 + 4) { KMIX_BODY_4 }
+#endif
+#if KMIX_N > 5
+        if (OP == KMIX0 + 5) { KMIX_BODY_5 }
+#endif
+#if KMIX_N > 6
+        if (OP == KMIX0 + 6) { KMIX_BODY_6 }
+#endif
+#if KMIX_N > 7
+        if (OP == KMIX0 + 7) { KMIX_BODY_7 }
+#endif
+#if KMIX_N > 8
+        if (OP == KMIX0 + 8) { KMIX_BODY_8 }
+#endif
+#if KMIX_N > 9
+        if (OP == KMIX0 + 9) { KMIX_BODY_9 }
+#endif
         if (OP == FMA_SALU) { // 64 VALU + 64 SALU interleaved: does scalar issue take VALU slots of the same wave / SIMD?
 #define FS(a, s) I_FMA(a) I_SALU(s)
             FS(a0, s0) FS(a1, s1) FS(a2, s2) FS(a3, s3) FS(a4, s0) FS(a5, s1) FS(a6, s2) FS(a7, s3)
@@ -112,7 +163,13 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
     }
 }
 
-static int insts_per_iter(int op) { return op == NODE_MIX ? 80 : op == NODE_MIX_F16 ? 68 : 64; } // VALU instructions (FMA_SALU: 64 VALU + 64 SALU)
+static int insts_per_iter(int op) { return op >= KMIX0 ? 96 : op == NODE_MIX ? 80 : op == NODE_MIX_F16 ? 68 : 64; }
+static const char *name_of(int op) {
+#if KMIX_N > 0
+    if (op >= KMIX0) return kmix_names[op - KMIX0];
+#endif
+    return op_names[op];
+} // VALU instructions (FMA_SALU: 64 VALU + 64 SALU)
 
 template <int OP>
 static void launch(int grid, size_t lds, int iters, uint64_t *cyc, float *sink) {
@@ -139,6 +196,23 @@ static void launch_op(int op, int grid, size_t lds, int iters, uint64_t *cyc, fl
     case CVT_U32: launch<CVT_U32>(grid, lds, iters, cyc, sink); break;
     case BFE_U32: launch<BFE_U32>(grid, lds, iters, cyc, sink); break;
     case NODE_MIX_F16: launch<NODE_MIX_F16>(grid, lds, iters, cyc, sink); break;
+    case AND_B32: launch<AND_B32>(grid, lds, iters, cyc, sink); break;
+    case LSHL_B32: launch<LSHL_B32>(grid, lds, iters, cyc, sink); break;
+    case MOV_B32: launch<MOV_B32>(grid, lds, iters, cyc, sink); break;
+    case CMP_F32: launch<CMP_F32>(grid, lds, iters, cyc, sink); break;
+    case ADD_F32: launch<ADD_F32>(grid, lds, iters, cyc, sink); break;
+    case MUL_LO_U32: launch<MUL_LO_U32>(grid, lds, iters, cyc, sink); break;
+    case READLANE: launch<READLANE>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 0: launch<KMIX0 + 0>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 1: launch<KMIX0 + 1>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 2: launch<KMIX0 + 2>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 3: launch<KMIX0 + 3>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 4: launch<KMIX0 + 4>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 5: launch<KMIX0 + 5>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 6: launch<KMIX0 + 6>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 7: launch<KMIX0 + 7>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 8: launch<KMIX0 + 8>(grid, lds, iters, cyc, sink); break;
+    case KMIX0 + 9: launch<KMIX0 + 9>(grid, lds, iters, cyc, sink); break;
     }
 }
 
@@ -161,7 +235,7 @@ int main(int argc, char **argv) {
     bool first = true;
     printf("%s (%s), %d CUs, hipDeviceProp clockRate %d kHz\n", prop.name, prop.gcnArchName, cus, prop.clockRate);
     printf("%-60s %5s %12s %12s %12s %10s %10s\n", "instruction stream", "W/SIMD", "inst/clk/SIMD", "(min wave)", "(max wave)", "eff. GHz", "G inst/s");
-    for (int op = 0; op < N_OPS; ++op) {
+    for (int op = 0; op < KMIX0 + KMIX_N; ++op) {
         if (op == FMA_SALU && !getenv("VALU_ISSUE_SALU")) continue; // (the per-lane scalar accumulators of this stream compile to readfirstlane loops: off by default)
         for (int w : {1, 2, 3, 4, 6, 8}) {
             if (quick && w != 1 && w != 8) continue; // (under a counter pass every dispatch is slow: two occupancies are enough there)
@@ -192,10 +266,10 @@ int main(int argc, char **argv) {
             const double ipc_med = w * n_inst / med, ipc_fast = w * n_inst / mn, ipc_slow = w * n_inst / mx;
             const double eff_ghz = (double)(hi - lo) / (ms * 1e-3) / 1e9; // s_memtime ticks per wall second over the launch
             const double ginst = (double)grid * 4 * n_inst / (ms * 1e-3) / 1e9;
-            printf("%-60s %5d %12.4f %12.4f %12.4f %10.3f %10.1f\n", op_names[op], w, ipc_med, ipc_fast, ipc_slow, eff_ghz, ginst);
+            printf("%-60s %5d %12.4f %12.4f %12.4f %10.3f %10.1f\n", name_of(op), w, ipc_med, ipc_fast, ipc_slow, eff_ghz, ginst);
             char buf[512];
             snprintf(buf, sizeof buf, "%s{\"op\": \"%s\", \"waves_per_simd\": %d, \"inst_per_clk_per_simd\": %.5f, \"fastest_wave\": %.5f, \"slowest_wave\": %.5f, "
-                     "\"memtime_ghz\": %.4f, \"ginst_s_wall\": %.2f, \"launch_ms\": %.5f}", first ? "" : ", ", op_names[op], w, ipc_med, ipc_fast, ipc_slow, eff_ghz, ginst, ms);
+                     "\"memtime_ghz\": %.4f, \"ginst_s_wall\": %.2f, \"launch_ms\": %.5f}", first ? "" : ", ", name_of(op), w, ipc_med, ipc_fast, ipc_slow, eff_ghz, ginst, ms);
             json += buf;
             first = false;
         }
