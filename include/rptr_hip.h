@@ -323,7 +323,7 @@ int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out
 /* the scheduling thresholds the traversal kernels use for the current scene (csrc/dtraverse.h: a wave refills its idle lanes once
  * `refill_min` have finished and leaves a node phase once fewer than `node_min` lanes are at inner nodes; 0 = the compile-time defaults
  * 10 / 48) and the measure they were chosen by at set_scene: the surface-area cost of the largest bottom-level tree times that of the top
- * level (>= 30: the dense preset 16 / 32). They change when lanes take their steps, never what a ray finds. RPTR_TRAVERSE_PRESET="n,r"
+ * level (>= 24: the dense preset 16 / 32). They change when lanes take their steps, never what a ray finds. RPTR_TRAVERSE_PRESET="n,r"
  * overrides. No reference counterpart (the reference's traversal is the driver's). */
 int rptr_hip_traversal_preset(rptr_hip_t *h, float *out_area_cost, int32_t *out_node_min, int32_t *out_refill_min);
 void rptr_hip_destroy(rptr_hip_t *h);
@@ -492,6 +492,24 @@ int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_ga
  * bits(primitive_index)); miss = (-1,-1,bits(-1),bits(-1)); mode_or_data < 0
  * leaves the result slot untouched. Host pointers. */
 int rptr_hip_trace(rptr_hip_t *h, const RptrRenderRayQuery *queries, int n, float *out4);
+/* The same over DEVICE buffers, asynchronously on `hip_stream` (NULL: the backend's stream) -- what RenderBackend::render_ray_queries works
+ * on (vulkan/render_vulkan.cpp:1867-1876: the queries are in ray_query_buffer, written by other device code, the results go to
+ * ray_result_buffer). A caller's stream is ordered behind the scene uploads queued on the backend's stream and the backend's later work
+ * behind the queries. */
+int rptr_hip_trace_device(rptr_hip_t *h, const RptrRenderRayQuery *device_queries, int n, float *device_out4, void *hip_stream);
+/* RenderBackend::enable_ray_queries(max_queries, max_queries_per_pixel) (render_backend.h:101, render_vulkan.cpp:430-455): the library
+ * owns a device buffer of max(max_queries, width x height x max_queries_per_pixel) RptrRenderRayQuery records and one of as many float4
+ * results and returns their device addresses (≙ ray_query_buffer / ray_result_buffer; they stay valid until the next call that asks for
+ * more, or rptr_hip_destroy). RenderBackend::render_ray_queries(num_queries, ...) = rptr_hip_render_ray_queries: traces the first
+ * num_queries records of that buffer on the backend's stream. */
+int rptr_hip_enable_ray_queries(rptr_hip_t *h, int max_queries, int max_queries_per_pixel, void **out_device_queries, void **out_device_results);
+int rptr_hip_render_ray_queries(rptr_hip_t *h, int num_queries);
+/* RenderBackendOptions::light_sampling_variant (rendering/mc/light_sampling.h:11-20, rendering/mc/nee.glsl:12-14): 0 =
+ * LIGHT_SAMPLING_VARIANT_NONE disables next-event estimation towards the emissive triangles (every NEE sample goes to the sun; emitters
+ * that a path HITS still contribute, at full weight), 1 = LIGHT_SAMPLING_VARIANT_RIS (the default: binned RIS). The image is that of
+ * the scene handed over without its light array and with sun_radiance.w = 1 (tested bit for bit); the lights stay uploaded and come back
+ * with variant 1. */
+int rptr_hip_set_light_sampling_variant(rptr_hip_t *h, int variant);
 /* diagnostic twin: also returns, per query, the node and triangle visits of the traversal
  * (visits2[2*i], visits2[2*i+1]; may be NULL) -- the counts behind the roofline's algorithmic bytes,
  * checked ray by ray against the oracle walking the exported tree. tmin (NULL = the RQ_CLOSEST rule

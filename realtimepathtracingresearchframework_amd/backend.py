@@ -67,6 +67,10 @@ def load_library(path=None):
     L.rptr_hip_render_batch_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_render_batch_cameras_async.argtypes = [vp, C.POINTER(abi.Camera), i32, i32, i32, i32, i32, i32, C.POINTER(C.c_uint64)]
     L.rptr_hip_set_stage_timing.argtypes = [vp, i32]
+    L.rptr_hip_trace_device.argtypes = [vp, vp, i32, vp, vp]
+    L.rptr_hip_enable_ray_queries.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.rptr_hip_render_ray_queries.argtypes = [vp, i32]
+    L.rptr_hip_set_light_sampling_variant.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
     L.rptr_hip_set_frame_schedule.argtypes = [vp, i32]
     L.rptr_hip_get_frame_schedule.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), i32]
@@ -357,6 +361,23 @@ class RenderHip:
             results = np.zeros((len(q), 4), dtype=np.float32)
         self._check(self._L.rptr_hip_trace(self._h, q.ctypes.data_as(C.c_void_p), len(q), results.ctypes.data_as(C.c_void_p)))
         return results
+
+    def enable_ray_queries_device(self, max_queries, max_queries_per_pixel=0):
+        """RenderBackend::enable_ray_queries: the backend's device buffers (≙ ray_query_buffer / ray_result_buffer), as addresses"""
+        q, r = C.c_void_p(), C.c_void_p()
+        self._check(self._L.rptr_hip_enable_ray_queries(self._h, int(max_queries), int(max_queries_per_pixel), C.byref(q), C.byref(r)))
+        return q.value, r.value
+
+    def render_ray_queries_device(self, num_queries):
+        """RenderBackend::render_ray_queries over the backend's device buffers (asynchronous on the backend's stream)"""
+        self._check(self._L.rptr_hip_render_ray_queries(self._h, int(num_queries)))
+
+    def trace_device(self, device_queries, n, device_results, stream=None):
+        self._check(self._L.rptr_hip_trace_device(self._h, C.c_void_p(device_queries), int(n), C.c_void_p(device_results), C.c_void_p(stream or 0)))
+
+    def set_light_sampling_variant(self, variant):
+        """RenderBackendOptions::light_sampling_variant: 0 = NONE (no NEE towards emissive triangles), 1 = RIS (default)"""
+        self._check(self._L.rptr_hip_set_light_sampling_variant(self._h, int(variant)))
 
     def trace_counted(self, queries: np.ndarray, tmin: np.ndarray = None, any_hit=False):
         """diagnostic: (results (n,4) float32, visits (n,2) uint32 = nodes, triangles per query); tmin: explicit interval

@@ -539,7 +539,7 @@ void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t ma
     size_t made = n;
     std::vector<uint32_t> nn;
     std::vector<uint32_t> slot;
-    size_t top_k = 1; // experiment (RPTR_PLOC_TOP): stop clustering at this many clusters and put a binned-SAH tree over them
+    size_t top_k = RP_PLOC_TOP_DEFAULT; // stop clustering at this many clusters and put a binned-SAH tree over them: the device builder's default (csrc/ploc.h)
     if (const char *e = getenv("RPTR_PLOC_TOP")) top_k = std::max<size_t>(1, (size_t)atoll(e));
     while (cur.size() > top_k) {
         const size_t m = cur.size();

@@ -53,11 +53,15 @@ struct Wide4Tree {
 //     programming over "subtree c shown through at most i slots of its parent" (Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on
 //     GPUs Through Compressed Wide BVHs", HPG 2017, section 3.1, here for four slots). Against the greedy rule: a third fewer nodes on the
 //     height field (299 k -> 192 k), 1-4 % fewer node visits per ray on every scene;
-//   COLLAPSE_GREEDY: a node adopts its grandchildren, largest box first, until it has four children (Wald et al. style): what the device
-//     builder does (csrc/ploc.h), so its host statement uses it;
+//   COLLAPSE_GREEDY: a node adopts its grandchildren, largest box first, until it has four children (Wald et al. style): rounds 1-3; kept
+//     for the top level over instance boxes and for the meshes of re-braided scenes (the device builder, csrc/ploc.h, implements
+//     COLLAPSE_OPTIMAL, and so does its host statement build_bvh2_ploc + collapse_bvh4);
 //   COLLAPSE_EVEN: every inner child hands its two children up (the device's rebuild, csrc/lbvh.h).
 // rule < 0: RPTR_COLLAPSE = optimal | dp | greedy | even, default `fallback`.
 enum { COLLAPSE_GREEDY = 0, COLLAPSE_EVEN = 1, COLLAPSE_OPTIMAL = 2 };
+// clusters at which PLOC stops and a binned-SAH tree takes over: ONE default for the device builder (csrc/ploc.h RP_PLOC_TOP) and its host
+// statement (build_bvh2_ploc), so that "the same tree" does not depend on a test setting RPTR_PLOC_TOP
+#define RP_PLOC_TOP_DEFAULT 65536
 void collapse_bvh4(const BuiltTree &tree, Wide4Tree &out, int rule = -1, int fallback = COLLAPSE_OPTIMAL);
 
 } // namespace rptr

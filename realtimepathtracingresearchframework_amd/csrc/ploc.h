@@ -17,20 +17,23 @@
 //      runs to the root) -- is a binned-SAH tree over the remaining <= 65 536 cluster boxes, built by the host builder in
 //      milliseconds and stitched on,
 //   5. depth-first positions of all triangles (every subtree a contiguous range: what the leaf encoding needs), second gather,
-//   6. the 4-wide collapse by the host builder's rule (largest child first), breadth first: one launch pair per depth level, node
-//      indices from exclusive scans; then boxes + encoding level by level, deepest first, with the refit code of every other tree.
+//   6. the 4-wide collapse by the host builder's rule -- the AREA-OPTIMAL collapse (bvh_build.h COLLAPSE_OPTIMAL: dynamic programming over
+//      "subtree shown through at most i slots"; the costs come bottom-up with the clustering iterations, rp_ploc_dp_node / rp_ploc_expand) --
+//      breadth first: one launch pair per depth level, node indices from exclusive scans; then boxes + encoding level by level, deepest
+//      first, with the refit code of every other tree.
 // bvh_build.cpp: build_bvh2_ploc is the same algorithm stated on the host (same keys, same float operations, same tie rules): both
 // give the same tree, which is how the device path is tested (tests/test_gpu_device_build.py) and how its quality was measured before
 // it was written (profiles/r03_notes.md: forest 27.2 node visits per closest-hit ray against 26.0 for the host SAH tree and 35.8 for
 // the linear BVH; height field 9.12 / 8.91 / 9.5).
 #pragma once
+#include "bvh_build.h"
 #include "lbvh.h"
 
 #ifndef RP_PLOC_RADIUS
 #define RP_PLOC_RADIUS 25
 #endif
 #ifndef RP_PLOC_TOP
-#define RP_PLOC_TOP 65536
+#define RP_PLOC_TOP RP_PLOC_TOP_DEFAULT // (bvh_build.h)
 #endif
 
 // one source of triangles of a build: `count` triangles of one geometry (optionally under an instance transform), output positions

@@ -214,6 +214,11 @@ struct rptr_hip {
     int frame_local_threshold = 262144; // RPTR_FRAME_LOCAL_THRESHOLD: a bounce whose PARENT queue is shorter stays with its blocks
     int frame_k0 = 0;               // RPTR_FRAME_K0: slots of bounce 0 a block takes at a time (0: from the frame size)
     int frame_blocks_per_cu = 0;    // RPTR_FRAME_BLOCKS_PER_CU (0: what the occupancy query says)
+    // ray queries on device buffers (enable_ray_queries / render_ray_queries: the reference's ray_query_buffer / ray_result_buffer)
+    RptrRenderRayQuery *rq_queries = nullptr;
+    float4 *rq_results = nullptr;
+    size_t rq_capacity = 0;
+    bool lights_disabled = false;   // light_sampling_variant == LIGHT_SAMPLING_VARIANT_NONE: no area-light NEE (rptr_hip_set_light_sampling_variant)
     int frame_fine_grained = 1;     // RPTR_FRAME_FINE_GRAINED: path state + queue ids of the frame kernel in fine-grained device memory
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
     RptrCamera prev_camera;         // the previous frame's view (VP_reference)
@@ -226,7 +231,7 @@ struct rptr_hip {
     int persistent_blocks = 0;
 
     // options (environment, read once)
-    int side_connect = 0; // opt-in (RPTR_SIDE_CONNECT=1): connect(b) on a side stream next to extend(b+1)
+    int side_connect = 0; // connect(b) on a side stream next to extend(b+1): the default for handles with ONE frame context (RPTR_SIDE_CONNECT=0|1 overrides)
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
     bool freeze_frame = false; // RenderConfiguration::freeze_frame: frame_offset / frame_id stand still
     int rng_variant = RPTR_RNG_VARIANT_UNIFORM; // rptr_hip_set_rng_variant
@@ -258,11 +263,23 @@ int fail(rptr_hip *h, int code, const char *fmt, ...) {
 // hosts: bin/rptr_hip, host/render_group.hpp). When the host initialised HIP before loading the library with fewer queues than the
 // contexts need, the create says so once on stderr (RPTR_QUIET=1 silences it); nothing else can be done from here.
 static bool g_hw_queues_set_by_library = false;
+static int g_hw_queues_at_load = -1; // what the variable held before this library touched it (-1: unset = the runtime's default of 4)
 __attribute__((constructor)) static void rptr_hip_set_default_hw_queues() {
-    if (!getenv("GPU_MAX_HW_QUEUES")) {
+    // NOTE: a process-global side effect of loading this library (INTEGRATION.md "Hardware queues"): the variable is set for the whole host
+    // process, and only takes effect when the process has not made a HIP call yet
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    g_hw_queues_at_load = e ? atoi(e) : -1;
+    if (!e) {
         setenv("GPU_MAX_HW_QUEUES", "16", 0);
         g_hw_queues_set_by_library = true;
     }
+}
+// did the host initialise HIP before this library could set the variable? hipGetDeviceCount-style calls do not tell; what does: whether a
+// primary context is already active on device 0 when the first handle is created
+static bool hip_was_initialised_before_us() {
+    unsigned int flags = 0;
+    int active = 0;
+    return hipDevicePrimaryCtxGetState(0, &flags, &active) == hipSuccess && active != 0;
 }
 
 static void ensure_hw_queues(int frames_in_flight) {
@@ -270,7 +287,13 @@ static void ensure_hw_queues(int frames_in_flight) {
     if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) frames_in_flight = atoi(s);
     const int want = std::max(1, std::min(frames_in_flight, 16)) + 2; // + the caller's stream + the communication stream
     const char *e = getenv("GPU_MAX_HW_QUEUES");
-    const int have = e ? atoi(e) : 4;
+    int have = e ? atoi(e) : 4;
+    // the library's own setenv only counts when the runtime had not read the variable yet: a host that initialised HIP first (torch,
+    // bench.py) runs with what the variable held BEFORE this library was loaded
+    if (first_create && g_hw_queues_set_by_library && hip_was_initialised_before_us()) {
+        have = g_hw_queues_at_load > 0 ? g_hw_queues_at_load : 4;
+        g_hw_queues_set_by_library = false; // (nothing of ours to raise any more)
+    }
     if (have < want) {
         if (first_create && (g_hw_queues_set_by_library || !e)) { // ours to raise; effective when no HIP call has been made yet
             char buf[16];
@@ -1399,6 +1422,8 @@ void rptr_hip_destroy(rptr_hip_t *h) {
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     if (h->rng_table) (void)hipFree(h->rng_table);
+    if (h->rq_queries) (void)hipFree(h->rq_queries);
+    if (h->rq_results) (void)hipFree(h->rq_results);
     delete h;
 }
 
@@ -1710,9 +1735,23 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         ctx.d_qpos = &d_qpos;
         ctx.geoms = &geoms;
         if (const char *e = getenv("RPTR_DEVICE_BUILD_MIN_TRIS")) ctx.min_tris = (size_t)atoll(e);
-        ctx.build = [&](const std::vector<RpBuildSegment> &segs, uint32_t n, DeviceTree &out) { return device_build_tree(h, segs, n, mat_alpha, out); };
+        int device_failures = 0;
+        std::string device_failure;
+        ctx.build = [&](const std::vector<RpBuildSegment> &segs, uint32_t n, DeviceTree &out) {
+            const bool ok = device_build_tree(h, segs, n, mat_alpha, out);
+            if (!ok) { // the host builder takes over (same scene, seconds instead of a fraction of one): say so, and do not leave the
+                       // message behind as the "last error" of a call that succeeds
+                ++device_failures;
+                device_failure = h->last_error;
+                h->last_error.clear();
+            }
+            return ok;
+        };
         const auto t_build = std::chrono::steady_clock::now();
         build_host_bvh(s, B, &ctx);
+        if (device_failures && (!getenv("RPTR_QUIET") || atoi(getenv("RPTR_QUIET")) == 0))
+            fprintf(stderr, "rptr_hip: note: %d device-side BVH build(s) failed (%s); the host builder built those trees instead\n", device_failures,
+                    device_failure.c_str());
         h->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
         h->bvh_device_built = B.device_built;
         h->bvh_device_ms = B.device_ms;
@@ -2081,26 +2120,44 @@ static int lbvh_rebuild(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bo
         size_t cap = 2;
         for (const MeshRt &x : h->meshes)
             if (x.dynamic) cap = std::max<size_t>(cap, (size_t)x.tri_count);
+        // the work space is allocated into a local record and committed as a whole: a failure half way frees what it got (the rebuild is
+        // retried with every refit, and a retry must not leak the earlier attempt's buffers while the device is short of memory)
+        RpLbvhScratch t = w;
+        std::vector<void *> got;
+        auto fail_alloc = [&](int code) {
+            for (void *p : got) (void)hipFree(p);
+            return code;
+        };
+        auto alloc = [&](auto **out, size_t count) -> int {
+            void *p = nullptr;
+            const size_t bytes = std::max<size_t>(count, 1) * sizeof(**out);
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s (work space of a device-side BVH rebuild)", bytes, hipGetErrorString(e));
+            got.push_back(p);
+            *out = reinterpret_cast<std::remove_reference_t<decltype(**out)> *>(p);
+            return RPTR_OK;
+        };
         int rc;
-        if ((rc = dev_alloc(h, &w.keys_a, cap, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.keys_b, cap, &h->scene_allocs))) return rc;
-        for (int **p : {&w.left, &w.right, &w.parent, &w.first, &w.last})
-            if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
-        for (uint32_t **p : {&w.flag, &w.slot, &w.depth4})
-            if ((rc = dev_alloc(h, p, cap, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.level_hist, RP_REFIT_LEVELS, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.level_cursor, RP_REFIT_LEVELS, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.tri_copy, cap, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.tribox_copy, 6 * cap, &h->scene_allocs))) return rc;
-        if ((rc = dev_alloc(h, &w.bounds, 8, &h->scene_allocs))) return rc;
+        if ((rc = alloc(&t.keys_a, cap)) || (rc = alloc(&t.keys_b, cap))) return fail_alloc(rc);
+        for (int **p : {&t.left, &t.right, &t.parent, &t.first, &t.last})
+            if ((rc = alloc(p, cap))) return fail_alloc(rc);
+        for (uint32_t **p : {&t.flag, &t.slot, &t.depth4})
+            if ((rc = alloc(p, cap))) return fail_alloc(rc);
+        if ((rc = alloc(&t.level_hist, RP_REFIT_LEVELS)) || (rc = alloc(&t.level_cursor, RP_REFIT_LEVELS)) || (rc = alloc(&t.tri_copy, cap)) ||
+            (rc = alloc(&t.tribox_copy, 6 * cap)) || (rc = alloc(&t.bounds, 8)))
+            return fail_alloc(rc);
         size_t sort_bytes = 0, scan_bytes = 0;
-        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, w.keys_a, w.keys_b, (int)cap, 0, 64, st);
-        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, w.flag, w.slot, (int)cap, st);
-        w.cub_bytes = std::max(sort_bytes, scan_bytes) + 256;
+        (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, t.keys_a, t.keys_b, (int)cap, 0, 64, st);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, t.flag, t.slot, (int)cap, st);
+        t.cub_bytes = std::max(sort_bytes, scan_bytes) + 256;
         char *tmp = nullptr;
-        if ((rc = dev_alloc(h, &tmp, w.cub_bytes, &h->scene_allocs))) return rc;
-        w.cub_tmp = tmp;
-        w.capacity = cap;
+        if ((rc = alloc(&tmp, t.cub_bytes))) return fail_alloc(rc);
+        t.cub_tmp = tmp;
+        t.capacity = cap;
+        for (void *p : got) { // committed: the scene owns the buffers now (an earlier, smaller work space stays until the next set_scene)
+            h->scene_allocs.push_back(p);
+        }
+        w = t;
     }
     RptrBvhTri *tris = sc.tris + mr.tri_base;
     float *tri_box = sc.tri_box + 6ull * mr.tri_base;
@@ -2384,7 +2441,7 @@ static int ensure_frame_queues(rptr_hip *h, FrameCtx &c, int grid_blocks) {
 
 static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
-    const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
+    const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
     rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures,
                     f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0 || (bounce == 0 && f.per_frame_cams != 0), scene, f, c.ps, c.sq, order,
@@ -2661,6 +2718,13 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     f.div_stripe_rows = rp_make_div((uint32_t)h->stripe_rows);
     f.div_width = rp_make_div((uint32_t)h->width);
     f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
+    if (h->lights_disabled) { // LIGHT_SAMPLING_VARIANT_NONE (rendering/mc/nee.glsl:12-14): every NEE sample goes to the sun
+        // the adapter hands sun_radiance.w = 1 with this variant (vulkan/render_sky.cpp:67-70: light_count is 0 without the binned-lights
+        // extension); emitters that are HIT keep their full weight: pdf of picking them = (1 - 1) / (bins x solid angle) with a bin count
+        // that must not be zero for that product to be 0 rather than NaN
+        f.num_bins = std::max(f.num_bins, 1);
+        f.sp.sun_radiance[3] = 1.0f;
+    }
     // north_star's regrouping of rays by material lives INSIDE the shade kernel's LDS compaction (kernels.h rp_shade_body, RPTR_REGROUP=1):
     // measured on C3 with 48 textured materials it costs 6 % of the shade time and gains nothing (every material runs the same BSDF code),
     // so it is off unless asked for. The separate counting-sort pass of rounds 1-2 (rp_k_sort_*: three launches per bounce, one frame
@@ -2722,7 +2786,9 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
         int err = RPTR_OK;
         (void)refit_scene_copy(h, scn, true, c.stream, &err);
         scn.version = h->refit_version;
-        if (err != RPTR_OK) return err; // (the tree was refitted on its old topology: the context is consistent, the caller learns why no rebuild happened)
+        // a rebuild that could not start (no memory for its work space): the tree was refitted on its old topology, so this context is
+        // consistent and the frame is rendered on it; the handle's last error says why no rebuild happened, and the next refit tries again
+        (void)err;
     }
     if (c.gather_pending) { // the image this context produced last is still being sent to rank 0 (host_comm.h)
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_gather, 0));
@@ -2752,7 +2818,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             // the whole frame in ONE launch (kernels.h rp_k_frame); counting keeps the stand-alone kernels
             c.fq_pub_used = 0;
             if (h->frame_kernel && !count_traversal) {
-                const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
+                const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
                 const bool full = h->uses_textures || h->uses_alpha;
                 int per_cu = h->frame_blocks_per_cu;
                 if (per_cu <= 0) {
@@ -2796,7 +2862,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 if (b == tail_from) {
                     if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) on the side stream
-                    const bool lights = h->num_lights > 0 || f.sp.sun_radiance[3] < 1.0f;
+                    const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
                     rp_launch_tail(variant, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng_later, scn.dscene, f, c.ps, c.sq,
                                    (const uint32_t *)c.queue[in], c.counters, b, c.gstack);
@@ -3150,6 +3216,79 @@ int rptr_hip_trace_counted(rptr_hip_t *h, const RptrRenderRayQuery *queries, int
     (void)hipFree(dv);
     (void)hipFree(dt);
     return rc;
+}
+
+extern "C++" {
+// the RQ_CLOSEST kernel over DEVICE buffers, asynchronously on `st`
+static int trace_device_on(rptr_hip *h, const RptrRenderRayQuery *dq, int n, float4 *dr, hipStream_t st) {
+    if (n == 0) return RPTR_OK;
+    hipLaunchKernelGGL(rp_k_reset_u32, dim3(1), dim3(1), 0, st, &h->ctx[0].counters->bounce[0].cursor_extend);
+    pick(h->master.dscene.single_instance != 0, [&](auto S) {
+        hipLaunchKernelGGL((rp_k_trace<false, false, decltype(S)::value>), dim3(h->persistent_blocks), dim3(RP_TRAVERSE_BLOCK), 0, st, h->master.dscene, dq, (uint32_t)n, dr,
+                           &h->ctx[0].counters->bounce[0].cursor_extend, h->ctx[0].gstack, (uint2 *)nullptr, (const float *)nullptr);
+    });
+    HIP_TRY(h, hipGetLastError());
+    return RPTR_OK;
+}
+}
+
+int rptr_hip_trace_device(rptr_hip_t *h, const RptrRenderRayQuery *device_queries, int n, float *device_out4, void *hip_stream) {
+    if (!h || !device_queries || !device_out4 || n < 0) return fail(h, RPTR_E_INVALID, "bad argument");
+    if (!h->have_scene) return fail(h, RPTR_E_INVALID, "trace before set_scene");
+    if (!h->ctx[0].gstack) return fail(h, RPTR_E_INVALID, "trace before initialize");
+    int rc = drain(h); // the query kernel borrows context 0's cursor and stack scratch
+    if (rc || (rc = ensure_master_tree(h))) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+    if (st != h->stream) { // the caller's stream sees the scene uploads / refits queued on the backend's, and later frames see the queries
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        (void)hipEventRecord(e, h->stream);
+        (void)hipStreamWaitEvent(st, e, 0);
+        rc = trace_device_on(h, device_queries, n, reinterpret_cast<float4 *>(device_out4), st);
+        (void)hipEventRecord(e, st);
+        (void)hipStreamWaitEvent(h->stream, e, 0);
+        (void)hipEventDestroy(e);
+        return rc;
+    }
+    return trace_device_on(h, device_queries, n, reinterpret_cast<float4 *>(device_out4), st);
+}
+
+int rptr_hip_enable_ray_queries(rptr_hip_t *h, int max_queries, int max_queries_per_pixel, void **out_device_queries, void **out_device_results) {
+    if (!h || max_queries < 0 || max_queries_per_pixel < 0) return fail(h, RPTR_E_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // vulkan/render_vulkan.cpp:430-455: max(fixed budget, per-pixel budget x frame size) queries of 32 bytes, as many float4 results
+    const size_t want = std::max<size_t>((size_t)max_queries, (size_t)h->width * (size_t)h->height * (size_t)max_queries_per_pixel);
+    if (want > h->rq_capacity) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->rq_queries) (void)hipFree(h->rq_queries);
+        if (h->rq_results) (void)hipFree(h->rq_results);
+        h->rq_queries = nullptr;
+        h->rq_results = nullptr;
+        h->rq_capacity = 0;
+        if (hipMalloc((void **)&h->rq_queries, want * sizeof(RptrRenderRayQuery)) != hipSuccess || hipMalloc((void **)&h->rq_results, want * sizeof(float4)) != hipSuccess) {
+            if (h->rq_queries) (void)hipFree(h->rq_queries);
+            h->rq_queries = nullptr;
+            return fail(h, RPTR_E_NOMEM, "hipMalloc of the ray query buffers (%zu queries) failed", want);
+        }
+        h->rq_capacity = want;
+    }
+    if (out_device_queries) *out_device_queries = h->rq_queries;
+    if (out_device_results) *out_device_results = h->rq_results;
+    return RPTR_OK;
+}
+
+int rptr_hip_render_ray_queries(rptr_hip_t *h, int num_queries) {
+    if (!h || num_queries < 0) return fail(h, RPTR_E_INVALID, "bad argument");
+    if ((size_t)num_queries > h->rq_capacity) return fail(h, RPTR_E_INVALID, "%d ray queries exceed the budget of %zu (rptr_hip_enable_ray_queries)", num_queries, h->rq_capacity);
+    return rptr_hip_trace_device(h, h->rq_queries, num_queries, reinterpret_cast<float *>(h->rq_results), nullptr);
+}
+
+int rptr_hip_set_light_sampling_variant(rptr_hip_t *h, int variant) {
+    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
+    if (variant != 0 && variant != 1) return fail(h, RPTR_E_INVALID, "unknown light sampling variant %d (0 = NONE, 1 = RIS)", variant);
+    h->lights_disabled = variant == 0;
+    return RPTR_OK;
 }
 
 int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_nodes, void *tris, size_t *n_tris, void *instances,

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 
 static uint64_t qpos(float x, float y, float z, const float lo[3], const float ext[3]) { // librender/quantize.h:7-11
     const float p[3] = {(x - lo[0]) * 2097152.0f / ext[0], (y - lo[1]) * 2097152.0f / ext[1], (z - lo[2]) * 2097152.0f / ext[2]};
@@ -65,7 +66,58 @@ int main() {
             alpha += img[i + 3];
         }
         std::printf("spp %d  %.3f ms  mean radiance %.4f  coverage %.3f\n", st.spp, st.render_time, sum / (3 * 64 * 64), alpha / (64 * 64));
-        return (sum > 0 && alpha > 0) ? 0 : 4;
+        if (!(sum > 0 && alpha > 0)) return 4;
+        // ---- ray queries as RenderBackend::enable_ray_queries / render_ray_queries run them: queries in a DEVICE buffer the backend owns
+        // (some other device pass writes them in the reference; this demo copies three in), results in its result buffer. The HIP runtime
+        // is in the process already (the backend links it): hipMemcpy by name, so that this file needs no HIP headers.
+        typedef int (*memcpy_fn)(void *, const void *, size_t, int);
+        memcpy_fn hip_memcpy = (memcpy_fn)dlsym(RTLD_DEFAULT, "hipMemcpy");
+        RptrRenderRayQuery rq[3] = {};
+        const float ro[3][3] = {{0, 0.3f, 4}, {0, 5, 0.5f}, {0, 0.5f, 4}}, rd[3][3] = {{0, 0, -1}, {0, -1, 0}, {0, 1, 0}}; // the triangle, the ground, the sky
+        for (int i = 0; i < 3; ++i) {
+            std::memcpy(rq[i].origin, ro[i], 12);
+            std::memcpy(rq[i].dir, rd[i], 12);
+            rq[i].t_max = 1e20f;
+        }
+        float host_res[12], dev_res[12], rt_res[12];
+        if (!backend.render_ray_queries(rq, 3, host_res)) return 5;
+        backend.enable_ray_queries(16);
+        if (!hip_memcpy || hip_memcpy(backend.ray_query_buffer(), rq, sizeof rq, 1 /* hipMemcpyHostToDevice */) != 0) return 6;
+        if (!backend.render_ray_queries(3)) return 7;
+        if (hip_memcpy(dev_res, backend.ray_result_buffer(), sizeof dev_res, 2 /* hipMemcpyDeviceToHost: after the backend's stream work */) != 0) return 8;
+        // (hipMemcpy on the NULL stream does not wait for a non-blocking stream: the backend's next synchronous call does)
+        float again[12];
+        backend.render_ray_queries(rq, 3, again);
+        if (hip_memcpy(dev_res, backend.ray_result_buffer(), sizeof dev_res, 2) != 0) return 8;
+        const bool same = std::memcmp(host_res, dev_res, sizeof host_res) == 0;
+        int32_t prim0, prim1, prim2;
+        std::memcpy(&prim0, &host_res[3], 4);
+        std::memcpy(&prim1, &host_res[7], 4);
+        std::memcpy(&prim2, &host_res[11], 4);
+        std::printf("ray queries: device buffers %s host arrays; primitives %d %d %d\n", same ? "=" : "!=", prim0, prim1, prim2);
+        if (!same || prim0 != 2 || prim1 < 0 || prim1 > 1 || prim2 != -1) return 9;
+        // ---- the ray-query-only surface (struct RaytraceBackend, librender/raytrace_backend.h:13-19)
+        {
+            rptr::RaytraceHip rt;
+            rt.set_scene(scene);
+            const bool ok = rt.trace_ray(rq, 3, rt_res) == 3 && std::memcmp(rt_res, host_res, sizeof host_res) == 0;
+            std::printf("%s: %s\n", rt.name().c_str(), ok ? "same hits" : "DIFFERENT hits");
+            if (!ok) return 10;
+        }
+        // ---- light_sampling_variant NONE (rendering/mc/nee.glsl:12-14): every NEE sample goes to the sun; this scene has no emitters, so
+        // the image must not change
+        std::vector<float> img2(img.size());
+        {
+            rptr::RenderHip b2; // (a fresh handle: the seeds of a frame depend on how many frames its handle has reset before)
+            b2.initialize(64, 64);
+            b2.set_scene(scene);
+            b2.update_config(sp);
+            b2.set_light_sampling_variant(0);
+            b2.render(cfg, 2);
+            b2.readback_framebuffer(img2.size(), img2.data());
+        }
+        std::printf("light sampling NONE: image %s\n", std::memcmp(img.data(), img2.data(), img.size() * 4) == 0 ? "unchanged" : "CHANGED");
+        return std::memcmp(img.data(), img2.data(), img.size() * 4) == 0 ? 0 : 11;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 3;

@@ -191,13 +191,29 @@ public:
         return need;
     }
 
-    // enable_ray_queries / render_ray_queries with RQ_CLOSEST (render_backend.h:101-102)
-    void enable_ray_queries(const int max_queries, const int = 0) { max_queries_ = max_queries; }
+    // enable_ray_queries / render_ray_queries with RQ_CLOSEST (render_backend.h:101-102; vulkan/render_vulkan.cpp:430-455,1867-1876): the
+    // queries live in a DEVICE buffer the backend owns (ray_query_buffer), other device code fills it, the results land in
+    // ray_result_buffer. ray_query_buffer() / ray_result_buffer() are the device addresses.
+    void enable_ray_queries(const int max_queries, const int max_queries_per_pixel = 0) {
+        check(rptr_hip_enable_ray_queries(h_, max_queries, max_queries_per_pixel, &ray_query_buffer_, &ray_result_buffer_));
+        max_queries_ = max_queries;
+    }
+    void *ray_query_buffer() const { return ray_query_buffer_; }
+    void *ray_result_buffer() const { return ray_result_buffer_; }
+    bool render_ray_queries(int num_queries) { // (RenderParams / variant / command stream of the reference's signature select nothing here)
+        if (!ray_query_buffer_) return false;
+        check(rptr_hip_render_ray_queries(h_, num_queries));
+        return true;
+    }
+    // convenience over HOST arrays (tests, tools): rptr_hip_trace uploads, traces, reads back
     bool render_ray_queries(const RptrRenderRayQuery *queries, int num_queries, float *results4) {
         if (num_queries > max_queries_) return false;
         check(rptr_hip_trace(h_, queries, num_queries, results4));
         return true;
     }
+    // RenderBackendOptions::light_sampling_variant (rendering/mc/light_sampling.h:11-20): 0 NONE, 1 RIS; light_sampling_bucket_count is
+    // LightSamplingConfig::bin_size, at most RPTR_BINNED_LIGHTS_BIN_MAX_SIZE (set_params refuses more)
+    void set_light_sampling_variant(int variant) { check(rptr_hip_set_light_sampling_variant(h_, variant)); }
     rptr_hip_t *handle() { return h_; }
 
 private:
@@ -209,7 +225,26 @@ private:
     bool have_scene_params_ = false;
     int variant_ = RPTR_VARIANT_GLTF;
     int max_queries_ = 512 * 512;
+    void *ray_query_buffer_ = nullptr, *ray_result_buffer_ = nullptr;
     RptrStats last_{};
+};
+
+// ≙ struct RaytraceBackend (librender/raytrace_backend.h:13-19; libdatacapture's trace_ray over host arrays): closest-hit queries through
+// rptr_hip_trace. The adapter on the reference's side converts rt_datacapture::RayQuery {origin, dir, t_max} to RptrRenderRayQuery
+// (mode_or_data = 0) and RaytraceResults from the float4 rows (barycentrics, instance + geometry index, primitive index).
+class RaytraceHip {
+public:
+    explicit RaytraceHip(int device_ordinal = 0) : backend_(device_ordinal) { backend_.initialize(8, 8); } // (queries need no frame, the stack scratch does)
+    std::string name() const { return std::string(rptr_hip_name()) + " (ray queries)"; }
+    void set_scene(const RptrSceneDesc &scene) { backend_.set_scene(scene); }
+    // returns the number of queries traced; results4: 4 floats per query in rt_intersect.comp's layout, miss = (-1, -1, bits(-1), bits(-1))
+    int trace_ray(const RptrRenderRayQuery *queries, int num_queries, float *results4) {
+        return backend_.render_ray_queries(queries, num_queries, results4) ? num_queries : 0;
+    }
+    RenderHip &backend() { return backend_; }
+
+private:
+    RenderHip backend_;
 };
 
 } // namespace rptr

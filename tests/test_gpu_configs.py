@@ -606,3 +606,71 @@ def test_c2_full_size_on_the_benchmarked_schedule(rng_variant):
         ref, _ = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE, rows=rows, frame_offset=spp * k)
         rmse, same, maxabs = image_error(fast[k][rows[0]:rows[1]], ref[rows[0]:rows[1]])
         assert same and rmse < RMSE_TOL, (k, rows, rmse, maxabs)
+
+
+# ---------------------------------------------------------------- the rest of the adapter surface
+def test_ray_queries_on_device_buffers_equal_the_host_array_queries():
+    """RenderBackend::enable_ray_queries / render_ray_queries (vulkan/render_vulkan.cpp:430-455,1867-1876): queries and results in device
+    buffers the backend owns, traced asynchronously; and rptr_hip_trace_device over a caller's buffers on a caller's stream"""
+    import torch
+    from common import random_queries
+    s = scenes.two_level_test()
+    r = backend.RenderHip()
+    r.initialize(64, 64)
+    r.set_scene(s)
+    rng = np.random.default_rng(7)
+    n = 20000
+    q = random_queries(rng, n, -6, 6)
+    q[::7, 3] = np.int32(-1).view(np.float32)                       # mode_or_data < 0: the result slot is left alone
+    ref = r.render_ray_queries(q, np.full((n, 4), 7.0, np.float32))
+    dq, dr = r.enable_ray_queries_device(n)
+    tq = torch.from_numpy(q).cuda()
+    tr = torch.full((n, 4), 7.0, dtype=torch.float32, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(ctypes.c_void_p(dq), ctypes.c_void_p(tq.data_ptr()), ctypes.c_size_t(n * 32), 3) == 0      # device to device
+    assert hip.hipMemcpy(ctypes.c_void_p(dr), ctypes.c_void_p(tr.data_ptr()), ctypes.c_size_t(n * 16), 3) == 0
+    r.render_ray_queries_device(n)
+    r.render_ray_queries(q[:1])                                      # (a synchronous call on the backend's stream: the queries above are done)
+    out = torch.empty_like(tr)
+    assert hip.hipMemcpy(ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(dr), ctypes.c_size_t(n * 16), 3) == 0
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(backend.BackendError):
+        r.render_ray_queries_device(n + 1)                           # beyond the budget
+    # a caller's buffers on a caller's stream
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        r.trace_device(tq.data_ptr(), n, tr.data_ptr(), stream=st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(tr.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    r.close()
+
+
+def test_light_sampling_variant_none_equals_a_scene_without_a_light_array():
+    """RenderBackendOptions::light_sampling_variant = NONE (rendering/mc/nee.glsl:12-14): no next-event estimation towards the emissive
+    triangles; emitters a path hits still shine (at full weight). Bit-identical to the same scene handed over without its light array
+    (sun_radiance.w = 1) wherever that image is defined, different from binned RIS, and RIS comes back unchanged"""
+    import copy
+    s = scenes.grid(120, 60, with_emitters=True)
+    W, H, spp = 160, 96, 4
+    bare = copy.copy(s)
+    bare.lights = np.zeros((0, 4, 3), dtype=np.float32)
+    def fresh(variant):                                              # (a fresh handle each: frame_offset advances with every reset)
+        r = backend.RenderHip()
+        r.initialize(W, H)
+        r.set_scene(s)
+        r.set_light_sampling_variant(0)                              # toggled: RIS must come back unchanged
+        r.set_light_sampling_variant(variant)
+        img, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, renderer=r)
+        r.close()
+        return img, st
+    ris, _ = fresh(1)
+    none, st = fresh(0)
+    ris2, _, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+    ref, st_ref, _ = gpu_render(bare, W, H, spp, abi.VARIANT_GLTF)
+    assert np.isfinite(none).all()
+    # (paths that HIT an emitter: without a light array the MIS weight of that hit is 0 / 0; with the variant switched off it is 1)
+    ok = np.isfinite(ref).all(axis=2)
+    assert ok.mean() > 0.9 and np.array_equal(none[ok].view(np.uint32), ref[ok].view(np.uint32)) and int(st.raw.rays_shadow) == int(st_ref.raw.rays_shadow)
+    assert np.array_equal(ris.view(np.uint32), ris2.view(np.uint32)) and not np.array_equal(ris, none)

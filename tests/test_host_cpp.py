@@ -45,3 +45,6 @@ def test_cpp_host_renders_on_gpu(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert "mean radiance" in p.stdout
+    # the adapter surface beyond frames: device-resident ray queries (enable_ray_queries / render_ray_queries), the RaytraceBackend-shaped
+    # class, light_sampling_variant NONE
+    assert "ray queries: device buffers = host arrays" in p.stdout and "same hits" in p.stdout and "light sampling NONE: image unchanged" in p.stdout, p.stdout
