@@ -754,7 +754,8 @@ def write_exr_py(path, planes, half=False, compression=0):
 
 def test_compare_tool_follows_compare_exr(tmp_path):
     """util/compare_exr.cpp:51-97: per value |ref - cmp| / ref (|cmp| where ref is 0), above 1e-6 anywhere = not the same, exit code -1,
-    the error of every value in <CMP>_err.exr; EXR files with NONE / ZIPS / ZIP compression, FLOAT and HALF channels; PFM; PIZ refused"""
+    the error of every value in <CMP>_err.exr; EXR files with NONE / RLE / ZIPS / ZIP compression, FLOAT and HALF channels; PFM; compressions without
+    a decoder here (PXR24 ...) refused by name"""
     exe = _build_compare(tmp_path)
     rng = np.random.default_rng(3)
     H, W = 37, 29
@@ -797,11 +798,51 @@ def test_compare_tool_follows_compare_exr(tmp_path):
     assert r.returncode == 255 and "same size" in r.stderr
     raw = bytearray(open(tmp_path / "ref.exr", "rb").read())
     k = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    raw[k] = 4
-    open(tmp_path / "piz.exr", "wb").write(raw)
-    r = run("ref.exr", "piz.exr")
-    assert r.returncode == 255 and "PIZ" in r.stderr
+    raw[k] = 5
+    open(tmp_path / "pxr.exr", "wb").write(raw)
+    r = run("ref.exr", "pxr.exr")
+    assert r.returncode == 255 and "PXR24" in r.stderr
     assert subprocess.run([exe, str(tmp_path / "ref.exr")], capture_output=True).returncode == 255
+
+
+def test_compare_tool_reads_piz_compressed_validation_images(tmp_path):
+    """the reference's --validation run writes PIZ-compressed OpenEXR by default (libapp/app_state.cpp:476, util/write_image.cpp:150-151),
+    and its regression workflow (util/compare_exr.cpp:51-97) takes such a file as REF: bin/rptr_compare decodes them (host/read_image.hpp:
+    bitmap + LUT, wavelet, Huffman with run lengths). Fixtures: tests/golden/piz/ (generator and its limits: gen_piz_fixture.py) -- FLOAT
+    channels with two blocks (32 + 5 lines, odd width: the 16-bit wavelet), HALF channels in three blocks (the 14-bit wavelet), a constant
+    image (runs); any further <name>.exr + <name>.f32 pair dropped there (e.g. written by a build of the reference) is checked too."""
+    import glob
+    exe = _build_compare(tmp_path)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "piz")
+    names = sorted(glob.glob(os.path.join(gold, "*.exr")))
+    assert len(names) >= 3
+    for path in names:
+        raw = open(path, "rb").read()
+        k = raw.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+        assert raw[k] == 4                                                       # PIZ
+        want = np.fromfile(path[:-4] + ".f32", dtype="<f4")
+        # the same pixels as an uncompressed file: the tool must call them equal, and a changed value different
+        chans = []
+        at = raw.index(b"channels\0chlist\0") + len(b"channels\0chlist\0") + 4
+        while raw[at] != 0:
+            e = raw.index(b"\0", at)
+            chans.append((raw[at:e].decode(), int.from_bytes(raw[e + 1:e + 5], "little")))
+            at = e + 17
+        box = np.frombuffer(raw, "<i4", 4, raw.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4)
+        W, H = int(box[2] - box[0] + 1), int(box[3] - box[1] + 1)
+        planes = want.reshape(len(chans), H, W)
+        half = chans[0][1] == 1
+        ref = {n: (planes[i].astype(np.float16) if half else planes[i]) for i, (n, _) in enumerate(chans)}
+        write_exr_py(str(tmp_path / "plain.exr"), ref, half=half, compression=0)
+        r = subprocess.run([exe, path, str(tmp_path / "plain.exr")], capture_output=True, text=True)
+        assert r.returncode == 0, (path, r.stderr)
+        ref2 = {n: v.copy() for n, v in ref.items()}
+        n0 = chans[-1][0]
+        ref2[n0] = ref2[n0].copy()
+        ref2[n0][H - 1, W - 1] = ref2[n0][H - 1, W - 1] * 1.01 + 0.01
+        write_exr_py(str(tmp_path / "changed.exr"), ref2, half=half, compression=3)
+        r = subprocess.run([exe, path, str(tmp_path / "changed.exr")], capture_output=True, text=True)
+        assert r.returncode == 255 and "isn't the same" in r.stderr
 
 
 @pytest.mark.gpu
