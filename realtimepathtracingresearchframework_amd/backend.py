@@ -294,14 +294,14 @@ class RenderHip:
     def set_frame_schedule(self, one_launch_per_frame):
         """False: a frame is a sequence of stage launches; True: ONE launch driven from device-side queues (csrc/kernels.h rp_k_frame).
         Bit-identical images either way (include/rptr_hip.h)."""
-        self._check(self._L.rptr_hip_set_frame_schedule(self._h, 1 if one_launch_per_frame else 0))
+        self._check(self._L.rptr_hip_set_frame_schedule(self._h, int(one_launch_per_frame)))  # False / 0 stages, True / 1 one launch, 2 streaming pair
 
     def frame_schedule(self):
         """(one launch per frame?, bounces that had global queues in the last finished frame, their lengths, (claim attempts, idle attempts))"""
         one, pub = C.c_int32(), C.c_int32()
         q = (C.c_uint32 * 16)()
         self._check(self._L.rptr_hip_get_frame_schedule(self._h, C.byref(one), C.byref(pub), q, 16))
-        return bool(one.value), int(pub.value), [int(v) for v in q[:max(0, pub.value)]], (int(q[8]), int(q[9]))
+        return int(one.value), int(pub.value), [int(v) for v in (q[:4] if pub.value < 0 else q[:max(0, pub.value)])], (int(q[8]), int(q[9]))
 
     def end_frame(self, cmd_stream=None, variant_idx=0):
         pass  # resolve (process_samples) is sequenced inside draw_frame on the same stream

@@ -33,3 +33,15 @@ hipError_t RP_CAT(rp_frame_blocks_per_cu_v, RP_INST_VARIANT)(bool lights, bool f
     });
     return e;
 }
+
+// the shader of the streaming frame (kernels.h rp_k_stream_shade)
+void RP_CAT(rp_launch_stream_shade_v, RP_INST_VARIANT)(const RpLaunch &l, bool lights, bool tex, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,
+                                                       const RpShadowRays &sq, const RpStream &sx, RpCounters *ctr) {
+    rp_pick(lights, [&](auto L) {
+        rp_pick(tex, [&](auto X) {
+            rp_pick(table, [&](auto T) {
+                rp_launch_kernel(l, rp_k_stream_shade<RP_INST_VARIANT, decltype(L)::value, decltype(X)::value, decltype(T)::value>, 256u, sc, f, ps, sq, sx, ctr);
+            });
+        });
+    });
+}

@@ -19,6 +19,7 @@
 // with ONE global atomic; persistent consumers pull 256 entries per atomic.
 #pragma once
 #include "dtraverse.h"
+#include "dstream.h"
 #include <type_traits>
 
 struct RpPathState {
@@ -395,7 +396,13 @@ struct RpShadeLds {
 #define RP_SHADE_RIS_REQ_FLOATS ((256 / 64) * 64 * 8)
 #define RP_SHADE_RIS_CONTRIB_FLOATS ((256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE)
 // SH / EXTLDS / base: as for rp_extend_body
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE, bool SH = false, bool EXTLDS = false>
+// STREAM (rp_k_stream_shade): the hit records were written by ANOTHER workgroup (read around the L1), and the chunk leaves ONE list of
+// items -- path id | RP_ITEM_CONT (the path goes on) | RP_ITEM_SHADOW (a shadow ray is pending) -- in `next` instead of two lists
+#define RP_ITEM_CONT 0x40000000u
+#define RP_ITEM_SHADOW 0x80000000u
+#define RP_ITEM_PATH 0x3FFFFFFFu
+#define RP_ITEM_NONE 0xFFFFFFFFu // padding of a sealed chunk: no item
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE, bool SH = false, bool EXTLDS = false, bool STREAM = false>
 RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
                           uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
                           uint32_t *&local_shadow, uint32_t &n_shadow, uint32_t base = 0u, const RpShadeLds *ext = nullptr) {
@@ -438,7 +445,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             bool is_hit = false;
             if (valid) {
                 pp = (FIRST && !order) ? base + i : order[i];
-                is_hit = ps.hit_ids[pp].x >= 0;
+                is_hit = (STREAM ? __float_as_int(rp_ld2<true>(reinterpret_cast<const float2 *>(ps.hit_ids), pp).x) : ps.hit_ids[pp].x) >= 0;
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
             if (valid && is_hit) s_list[ah] = pp;
@@ -560,8 +567,13 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         tex_fp = M2{v2(fp.x, fp.y), v2(fp.z, fp.w)};
                     }
                 }
-                const float4 hit4 = ps.hit_tuv[p];
-                const int2 ids = ps.hit_ids[p];
+                const float4 hit4 = rp_ld4<STREAM>(ps.hit_tuv, p);
+                int2 ids;
+                if (STREAM) {
+                    const float2 idf = rp_ld2<true>(reinterpret_cast<const float2 *>(ps.hit_ids), p);
+                    ids = make_int2(__float_as_int(idf.x), __float_as_int(idf.y));
+                } else
+                    ids = ps.hit_ids[p];
                 if (ids.x < 0) {
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
@@ -798,10 +810,16 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 }
                 rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
             }
-            const uint32_t at = rp_wave_append(&s_nn, alive);
-            if (alive) s_next[at] = p;
-            const uint32_t sat = rp_wave_append(&s_ns, has_shadow);
-            if (has_shadow) s_shadow[sat] = p;
+            if (STREAM) {
+                const bool any = alive || has_shadow;
+                const uint32_t at = rp_wave_append(&s_nn, any);
+                if (any) s_next[at] = p | (alive ? RP_ITEM_CONT : 0u) | (has_shadow ? RP_ITEM_SHADOW : 0u);
+            } else {
+                const uint32_t at = rp_wave_append(&s_nn, alive);
+                if (alive) s_next[at] = p;
+                const uint32_t sat = rp_wave_append(&s_ns, has_shadow);
+                if (has_shadow) s_shadow[sat] = p;
+            }
         }
         __syncthreads();
         if (!LOCAL) {
@@ -1181,6 +1199,408 @@ __global__ __launch_bounds__(256, RP_FRAME_WAVES) void rp_k_frame(RpScene sc, Rp
 #undef RP_FP_T1
 }
 
+// ------------------------------------------------------------------ stream: the frame as TWO co-resident persistent kernels
+// rp_k_frame (above) shows what one kernel cannot do: its blocks carry the registers of the shade phase through their traversal phases (4
+// waves per SIMD at most) and refill their lanes from block-local pools -- a frame alone takes 2.6 ms where the stage launches take 2.0.
+// What frames in flight have -- traversal waves that refill from long queues at five per SIMD, with shade work of other frames in the
+// issue slots they leave -- needs kernels with their own register budgets side by side. So: a TRACER kernel (persistent waves, <= 96
+// VGPRs, four blocks per CU) and a SHADER kernel (one block per CU) run for the whole frame and hand each other work through memory.
+//   items     an item is a path that left a shade (or a camera path): an optional shadow ray, then an optional continuation ray, traced one
+//             after the other by ONE lane (dstream.h), so that the shadow ray's contribution is added to the path's radiance before the
+//             next shade adds anything -- the megakernel's order of additions with no dependency between lanes.
+//   S0        the camera paths: the identity over the path ids, dealt to tracer waves in pools of RP_ST_POOL entries (head: s0_head)
+//   R         the items the shader kernel emits (u32: path id | flags), appended with one atomicAdd per chunk of survivors (r_tail)
+//   chunks    RP_CHUNK consecutive entries of S0 or R are the unit of shading: traced[chunk] counts the entries whose rays are done (the
+//             tracer wave whose add completes a chunk hands it to the shader ring), commit[chunk] the entries of an R chunk that have
+//             been written (the shader block whose add completes it hands its four pools to the tracer ring)
+//   rings     64-bit entries tagged with the frame's epoch; a consumer (tracer wave / shader block) holds a TICKET -- position in the ring
+//             that is its own to watch -- so nobody races for a head word (as in rp_k_frame)
+//   the end   only shader blocks append. When a shader block finishes a chunk and finds every chunk that was ever handed out shaded
+//             (shaded == S0 chunks + R chunks handed to the tracers), nothing is in flight and R's tail stands still: it SEALS the last,
+//             partly filled chunk (pads it with RP_ITEM_NONE, which completes it) -- or, if there is none, sets `complete`.
+// Visibility: as rp_k_frame -- consumers read around the L1 (sc1), a producer drains its stores and issues ONE agent-scope release before
+// the atomic that publishes (a shader block per chunk; a tracer wave per report of finished items).
+#define RP_ST_POOL 256u // entries a tracer wave takes at a time
+#ifndef RP_ST_REPORT
+#define RP_ST_REPORT 192u     // ended items of one chunk a tracer wave collects before it reports them
+#endif
+#ifndef RP_ST_REPORT_AGE
+#define RP_ST_REPORT_AGE 24u  // ... or this many refill rounds, whichever comes first
+#endif
+struct RpStState {
+    uint32_t r_tail, s0_head, tr_tail, tr_head, sr_tail, sr_head;
+    uint32_t tr_chunks; // R chunks handed to the tracer ring so far
+    uint32_t shaded;    // chunks shaded
+    uint32_t complete;
+    uint32_t timeout, overflow, seals;
+    uint32_t n0;        // camera paths (preset by the host)
+    uint32_t trace_polls, shade_polls, _pad;
+    unsigned long long t_wait, t_load, t_shade, t_append, t_fence, t_total, t_trace_idle, t_trace_total, t_trace_report; // -DRP_FRAME_PROF: 100 MHz ticks (lane 0 of a block / wave)
+};
+struct RpStream {
+    RpStState *st;
+    uint32_t *r;                 // the items of later bounces
+    uint32_t *commit;            // per R chunk
+    uint32_t *traced;            // per chunk: S0 chunks first, R chunks behind them
+    unsigned long long *tr_ring; // pools of R for tracer waves: epoch << 48 | first entry
+    unsigned long long *sr_ring; // chunks for shader blocks: epoch << 48 | chunk id (S0 chunks first)
+    uint32_t r_capacity;         // entries R holds (a multiple of RP_CHUNK)
+    uint32_t n_s0_chunks;
+    uint32_t epoch;
+    uint32_t capacity;           // path ids are below this
+};
+RP_DEV void rp_st_push(unsigned long long *ring, uint32_t *tail, uint32_t epoch, uint32_t value, uint32_t n = 1u, uint32_t step = 0u) {
+    const uint32_t i = rp_fq_add(tail, n);
+    for (uint32_t k = 0; k < n; ++k)
+        __hip_atomic_store(ring + i + k, ((unsigned long long)epoch << 48) | (unsigned long long)(value + k * step), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+RP_DEV uint32_t rp_st_chunk_size(const RpStream &sx, uint32_t chunk, uint32_t n0) {
+    return chunk < sx.n_s0_chunks ? min((uint32_t)RP_CHUNK, n0 - chunk * RP_CHUNK) : (uint32_t)RP_CHUNK;
+}
+
+// ---- the tracer: persistent waves over items
+template <bool SINGLE, bool TABLE>
+__global__ RP_TRAVERSE_BOUNDS void rp_k_stream_trace(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpStream sx, int *gstack) {
+    RpStState *const st = sx.st;
+    const uint32_t lane = rp_lane_id();
+    const uint32_t n0 = rp_fq_ld(&st->n0);
+    // wave-uniform consumer state
+    uint32_t ticket = 0;
+    bool have_ticket = false, s0_done = false;
+    uint32_t idle_polls = 0;
+    // the lane's item
+    uint32_t my_p = 0, my_flags = 0, my_chunk = 0, fin_chunk = RP_ITEM_NONE;
+    auto pool = [&](uint32_t &first, uint32_t &end) -> int {
+        int r = 0;
+        uint32_t a = 0, b = 0;
+        if (lane == 0) {
+            if (!have_ticket) {
+                ticket = rp_fq_add(&st->tr_head, 1u);
+                have_ticket = true;
+            }
+            const unsigned long long e = __hip_atomic_load(sx.tr_ring + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(e >> 48) == sx.epoch) {
+                have_ticket = false;
+                a = 0x80000000u | (uint32_t)e;
+                b = a + RP_ST_POOL;
+                r = 1;
+            } else if (!s0_done) {
+                const uint32_t s = rp_fq_add(&st->s0_head, RP_ST_POOL);
+                if (s < n0) {
+                    a = s;
+                    b = min(n0, s + RP_ST_POOL);
+                    r = 1;
+                } else
+                    s0_done = true;
+            }
+            if (r == 0) {
+                if (rp_fq_ld(&st->complete) != 0u) r = -1;
+                else if (++idle_polls > (1u << 22) || ((idle_polls & 1023u) == 0u && rp_fq_ld(&st->timeout) != 0u)) {
+                    rp_fq_add(&st->timeout, 1u);
+                    r = -1;
+                }
+            } else
+                idle_polls = 0;
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+        end = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        return r;
+    };
+    auto cont_ray = [&](bool first, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool { // the closest-hit ray of the lane's item
+        if (first) {
+            RpRng rng;
+            rd = v3(0.0f, 0.0f, 1.0f);
+            if (!rp_primary_ray<TABLE>(f, my_p, rng, rd, ro)) return false; // tile padding: no such pixel sample
+            tmin = 0.0f;
+            tmax = 2.e32f;
+        } else {
+            const float4 o4 = rp_ld4<true>(ps.ray_o, my_p), d4 = rp_ld4<true>(ps.ray_d, my_p);
+            ro = xyz(o4);
+            rd = xyz(d4);
+            tmin = o4.w;
+            tmax = d4.w;
+        }
+        return true;
+    };
+    auto begin = [&](uint32_t idx, V3 &ro, V3 &rd, float &tmin, float &tmax, bool &anyq) -> bool {
+        if (idx & 0x80000000u) {
+            const uint32_t ri = idx & 0x7FFFFFFFu;
+            const uint32_t e = rp_ld1<true>(sx.r, ri);
+            my_chunk = sx.n_s0_chunks + ri / RP_CHUNK;
+            if (e == RP_ITEM_NONE || (e & RP_ITEM_PATH) >= sx.capacity) { // padding of a sealed chunk (or, never on a correct run, no path id)
+                if (e != RP_ITEM_NONE) rp_fq_add(&st->overflow, 1u);
+                fin_chunk = my_chunk;
+                return false;
+            }
+            my_p = e & RP_ITEM_PATH;
+            my_flags = e & (RP_ITEM_CONT | RP_ITEM_SHADOW);
+            if (my_flags & RP_ITEM_SHADOW) {
+                const float4 o4 = rp_ld4<true>(sq.o, my_p), d4 = rp_ld4<true>(sq.d, my_p);
+                ro = xyz(o4);
+                rd = xyz(d4);
+                tmin = o4.w;
+                tmax = d4.w;
+                anyq = true;
+                return true;
+            }
+            anyq = false;
+            return cont_ray(false, ro, rd, tmin, tmax); // (always true)
+        }
+        my_p = idx;
+        my_chunk = idx / RP_CHUNK;
+        my_flags = RP_ITEM_CONT;
+        anyq = false;
+        if (!cont_ray(true, ro, rd, tmin, tmax)) {
+            rp_st2<true>(reinterpret_cast<float2 *>(ps.hit_ids), my_p, make_float2(__int_as_float(-1), __int_as_float(-1))); // a miss is recorded
+            fin_chunk = my_chunk;
+            return false;
+        }
+        return true;
+    };
+    auto next = [&](const RpHitRec &h, V3 &ro, V3 &rd, float &tmin, float &tmax, bool &anyq) -> bool {
+        if (anyq) { // the shadow ray: its contribution arrives when nothing is hit (nee.glsl:76-84)
+            if (h.inst_idx < 0) {
+                const float4 c = rp_ld4<true>(sq.contrib, my_p);
+                float4 il = rp_ld4<true>(ps.illum, my_p);
+                il.x += c.x;
+                il.y += c.y;
+                il.z += c.z;
+                rp_st4<true>(ps.illum, my_p, il);
+            }
+            if (my_flags & RP_ITEM_CONT) {
+                anyq = false;
+                return cont_ray(false, ro, rd, tmin, tmax);
+            }
+            fin_chunk = my_chunk;
+            return false;
+        }
+        rp_st4<true>(ps.hit_tuv, my_p, make_float4(h.t, h.u, h.v, __int_as_float(h.prim)));
+        rp_st2<true>(reinterpret_cast<float2 *>(ps.hit_ids), my_p, make_float2(__int_as_float(h.inst_idx), __int_as_float(h.geom)));
+        fin_chunk = my_chunk;
+        return false;
+    };
+    // Ended items are counted per wave in a few (chunk, count) slots and handed over -- a release fence + one atomicAdd per slot -- when a slot
+    // holds RP_ST_REPORT items, when the wave runs out of slots, when it has nothing in flight, or after RP_ST_REPORT_AGE steps: a report per
+    // refill (every ~48 items) was half a million L2 write-backs per frame and made the frame six times slower
+    uint32_t slot_chunk[4] = {RP_ITEM_NONE, RP_ITEM_NONE, RP_ITEM_NONE, RP_ITEM_NONE}, slot_count[4] = {0u, 0u, 0u, 0u}, slot_age = 0u; // wave-uniform
+    auto flush = [&](uint32_t which_mask) { // wave-uniform
+        rp_drain_stores(); // this wave's hit records and radiance updates have left it ...
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // ... and are in memory before a chunk is called done
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((which_mask >> k) & 1u) {
+                if (lane == 0 && slot_count[k] > 0u &&
+                    rp_fq_add(sx.traced + slot_chunk[k], slot_count[k]) + slot_count[k] == rp_st_chunk_size(sx, slot_chunk[k], n0))
+                    rp_st_push(sx.sr_ring, &st->sr_tail, sx.epoch, slot_chunk[k]);
+                slot_chunk[k] = RP_ITEM_NONE;
+                slot_count[k] = 0u;
+            }
+    };
+    auto report = [&](bool now, bool idle_wave) {
+        unsigned long long mask = __ballot(fin_chunk != RP_ITEM_NONE);
+        while (mask != 0ull) { // (one or two distinct chunks)
+            const int leader = __ffsll((long long)mask) - 1;
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)fin_chunk, leader);
+            const unsigned long long same = __ballot(fin_chunk == c);
+            const uint32_t cnt = (uint32_t)__popcll(same);
+            int k = slot_chunk[0] == c ? 0 : slot_chunk[1] == c ? 1 : slot_chunk[2] == c ? 2 : slot_chunk[3] == c ? 3 : -1;
+            if (k < 0) {
+                k = slot_chunk[0] == RP_ITEM_NONE ? 0 : slot_chunk[1] == RP_ITEM_NONE ? 1 : slot_chunk[2] == RP_ITEM_NONE ? 2 : slot_chunk[3] == RP_ITEM_NONE ? 3 : -1;
+                if (k < 0) { // no slot left: hand everything over
+                    flush(15u);
+                    k = 0;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == k) {
+                    slot_chunk[j] = c;
+                    slot_count[j] += cnt;
+                }
+            if (fin_chunk == c) fin_chunk = RP_ITEM_NONE;
+            mask &= ~same;
+        }
+        uint32_t due = 0u;
+        bool pending = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (slot_count[j] >= RP_ST_REPORT) due |= 1u << j;
+            pending = pending || slot_count[j] > 0u;
+        }
+        if (!pending) {
+            slot_age = 0u;
+            return;
+        }
+        if (now && ++slot_age >= RP_ST_REPORT_AGE) due = 15u;
+        if (idle_wave) due = 15u; // nothing in flight: whoever waits for these chunks should not wait for this wave's next refill
+        if (due != 0u) {
+            flush(due);
+            slot_age = 0u;
+        }
+    };
+    rp_wave_trace_items<false, SINGLE>(sc, gstack, pool, begin, next, report, RpNoAlpha());
+}
+
+// ---- the shader: persistent blocks over chunks
+template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
+__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_stream_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpStream sx, RpCounters *ctr) {
+    __shared__ uint32_t s_ids[RP_CHUNK], s_shadow_unused[1];
+    __shared__ uint32_t s_list[RP_CHUNK];
+    __shared__ float s_ris_req[LIGHTS ? RP_SHADE_RIS_REQ_FLOATS : 1], s_ris_contrib[LIGHTS ? RP_SHADE_RIS_CONTRIB_FLOATS : 1];
+    __shared__ uint32_t s_chunk, s_n, s_base, s_seal;
+    RpStState *const st = sx.st;
+    RpShadeLds lds;
+    lds.next = s_ids;
+    lds.shadow = s_shadow_unused;
+    lds.list = s_list;
+    lds.ris_req = s_ris_req;
+    lds.ris_contrib = s_ris_contrib;
+#ifdef RP_STREAM_DEBUG
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("[dev shade] st %p r %p commit %p traced %p tr %p sr %p cap %u chunks0 %u epoch %u pathcap %u\n", (void *)sx.st, (void *)sx.r, (void *)sx.commit, (void *)sx.traced,
+               (void *)sx.tr_ring, (void *)sx.sr_ring, sx.r_capacity, sx.n_s0_chunks, sx.epoch, sx.capacity);
+#endif
+    const uint32_t n0 = rp_fq_ld(&st->n0);
+    uint32_t ticket = 0, idle = 0; // (thread 0)
+    bool have_ticket = false;
+    // all threads: appends n entries (LDS) to R; the chunks it completes go to the tracers
+    auto append = [&](const uint32_t *entries, uint32_t n, bool none) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the path state and shadow rays of this chunk are in memory before its items are
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_base = rp_fq_add(&st->r_tail, n);
+        }
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (base + n > sx.r_capacity) { // (never with the capacity the host allocates: total items of a frame; reported, the frame is cut short)
+            if (threadIdx.x == 0) {
+                rp_fq_add(&st->overflow, 1u);
+                __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rp_st1<true>(sx.r, base + j, none ? RP_ITEM_NONE : entries[j]);
+        rp_drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t c = base / RP_CHUNK; c * RP_CHUNK < base + n; ++c) {
+                const uint32_t lo = max(base, c * RP_CHUNK), hi = min(base + n, (c + 1u) * RP_CHUNK);
+                if (rp_fq_add(sx.commit + c, hi - lo) + (hi - lo) == RP_CHUNK) {
+                    rp_fq_add(&st->tr_chunks, 1u);
+                    rp_drain_stores();
+                    rp_st_push(sx.tr_ring, &st->tr_tail, sx.epoch, c * RP_CHUNK, RP_CHUNK / RP_ST_POOL, RP_ST_POOL);
+                }
+            }
+        }
+    };
+#ifdef RP_FRAME_PROF
+    long long pt[5] = {0, 0, 0, 0, 0};
+    const long long pt_begin = wall_clock64();
+    long long pt0 = pt_begin;
+#define RP_SP(k) { const long long t_ = wall_clock64(); pt[k] += t_ - pt0; pt0 = t_; }
+#else
+#define RP_SP(k)
+#endif
+    for (;;) {
+        __syncthreads();
+        RP_SP(3)
+        if (threadIdx.x == 0) { // the next chunk: this block's ticket of the shader ring
+            uint32_t chunk = RP_ITEM_NONE;
+            for (;;) {
+                if (!have_ticket) {
+                    ticket = rp_fq_add(&st->sr_head, 1u);
+                    have_ticket = true;
+                }
+                const unsigned long long e = __hip_atomic_load(sx.sr_ring + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(e >> 48) == sx.epoch) {
+                    have_ticket = false;
+                    chunk = (uint32_t)e;
+                    idle = 0;
+                    break;
+                }
+                if (rp_fq_ld(&st->complete) != 0u) break;
+                if (++idle > (1u << 21) || ((idle & 255u) == 0u && rp_fq_ld(&st->timeout) != 0u)) {
+                    rp_fq_add(&st->timeout, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            s_chunk = chunk;
+            s_n = 0;
+        }
+        __syncthreads();
+        const uint32_t chunk = s_chunk;
+        RP_SP(0)
+        if (chunk == RP_ITEM_NONE) break;
+        const bool first = chunk < sx.n_s0_chunks;
+        uint32_t n = 0, base = 0;
+        if (first) {
+            base = chunk * RP_CHUNK;
+            n = min((uint32_t)RP_CHUNK, n0 - base);
+        } else { // the paths of the chunk that go on: their continuation rays have been traced
+            const uint32_t r0 = (chunk - sx.n_s0_chunks) * RP_CHUNK;
+            for (uint32_t j = threadIdx.x; j < RP_CHUNK; j += blockDim.x) {
+                const uint32_t e = rp_ld1<true>(sx.r, r0 + j);
+                const bool go = e != RP_ITEM_NONE && (e & RP_ITEM_CONT) != 0u;
+                const uint32_t at = rp_wave_append(&s_n, go);
+                if (go) s_ids[at] = e & RP_ITEM_PATH;
+            }
+            __syncthreads();
+            n = s_n;
+        }
+        uint32_t *next = nullptr, *shadow = nullptr;
+        uint32_t n_next = 0, n_shadow = 0;
+        RP_SP(1)
+        if (n > 0u) {
+            if (first)
+                rp_shade_body<VARIANT, true, LIGHTS, TEX, true, TABLE, true, true, true>(sc, f, ps, sq, nullptr, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow,
+                                                                                         base, &lds);
+            else
+                rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, true, true, true>(sc, f, ps, sq, s_ids, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
+                                                                                          n_shadow, 0u, &lds);
+        }
+        rp_drain_stores();
+        __syncthreads();
+        RP_SP(2)
+        if (n_next > 0u) append(s_ids, n_next, false);
+        __syncthreads();
+        // this chunk is shaded. Is it the last one that was in flight?
+        if (threadIdx.x == 0) {
+            rp_drain_stores();
+            const uint32_t sh = rp_fq_add(&st->shaded, 1u) + 1u;
+            rp_drain_stores();
+            uint32_t seal = 0u;
+            if (sh == sx.n_s0_chunks + rp_fq_ld(&st->tr_chunks)) { // every chunk ever handed out is shaded: nobody appends any more
+                const uint32_t t = rp_fq_ld(&st->r_tail);
+                if (t % RP_CHUNK != 0u) {
+                    seal = RP_CHUNK - t % RP_CHUNK;
+                    rp_fq_add(&st->seals, 1u);
+                } else
+                    __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_seal = seal;
+        }
+        __syncthreads();
+        if (s_seal > 0u) append(nullptr, s_seal, true); // pads the last chunk: that completes it and sends it to the tracers
+    }
+#ifdef RP_FRAME_PROF
+    if (threadIdx.x == 0) {
+        atomicAdd(&st->t_wait, (unsigned long long)pt[0]);
+        atomicAdd(&st->t_load, (unsigned long long)pt[1]);
+        atomicAdd(&st->t_shade, (unsigned long long)pt[2]);
+        atomicAdd(&st->t_append, (unsigned long long)pt[3]);
+        atomicAdd(&st->t_total, (unsigned long long)(wall_clock64() - pt_begin));
+    }
+#endif
+#undef RP_SP
+}
+
 // rp_kernarg (above) reads RpScene / RpFrame at the offsets they have as the FIRST TWO by-value arguments of a kernel: both kernels that run
 // rp_shade_body must start their argument lists that way.
 template <class F>
@@ -1189,5 +1609,6 @@ template <class... Rest>
 struct rp_args_start_with_scene_and_frame<void (*)(RpScene, RpFrame, Rest...)> : std::true_type {};
 static_assert(rp_args_start_with_scene_and_frame<decltype(&rp_k_shade<RPTR_VARIANT_SIMPLE, true, false, false, false>)>::value &&
                   rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value &&
-                  rp_args_start_with_scene_and_frame<decltype(&rp_k_frame<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value,
-              "rp_k_shade / rp_k_tail / rp_k_frame: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_frame<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value &&
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_stream_shade<RPTR_VARIANT_SIMPLE, false, false, false>)>::value,
+              "rp_k_shade / rp_k_tail / rp_k_frame / rp_k_stream_shade: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");

@@ -121,6 +121,14 @@ struct FrameCtx {
     size_t fq_words = 0;          // control words + per-slot commit counters: zeroed before every frame
     RpFqState *host_fq = nullptr; // pinned
     int fq_pub_used = 0;          // bounces with global queues in the frame in flight (0: it ran as stage launches)
+    // the streaming frame (kernels.h rp_k_stream_trace + rp_k_stream_shade): item stream, chunk counters, the two rings, a second stream
+    RpStream sx = {};
+    size_t sx_words = 0;          // state + chunk counters: zeroed before every frame
+    size_t sx_tr_entries = 0, sx_sr_entries = 0;
+    RpStState *host_sx = nullptr; // pinned
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    bool streamed = false;        // the frame in flight ran as the streaming pair
     size_t gstack_threads = 0;    // threads the stack scratch is sized for
     // multi-GPU gather (host_comm.h): the image this context produced is being sent; its next frame waits for that on the device
     hipEvent_t ev_gather = nullptr;
@@ -207,7 +215,8 @@ struct rptr_hip {
     int tail_blocks = 0;
     int tail_threshold = 65536;     // RPTR_TAIL_THRESHOLD: queue length below which a bounce goes to the tail kernel
     // the frame as ONE launch driven from device-side queues (kernels.h rp_k_frame; rptr_hip_set_frame_schedule, RPTR_FRAME_KERNEL)
-    int frame_kernel = 0;           // 0: stage launches, 1: one launch per frame
+    int frame_kernel = 0;           // 0: stage launches, 1: one launch per frame (rp_k_frame), 2: a tracer and a shader kernel side by side (streaming)
+    int stream_trace_per_cu = 0, stream_shade_per_cu = 0; // RPTR_STREAM_TRACE_BLOCKS / RPTR_STREAM_SHADE_BLOCKS per CU (0: 4 and 1)
     int frame_pub_mode = -1;        // RPTR_FRAME_PUB: -1 adaptive, k >= 1: bounces 0 .. k-1 have global queues
     int frame_pub_max = 4;          // RPTR_FRAME_PUB_MAX: global queues a frame context may hold (path_capacity entries each)
     int frame_pub_adaptive = 2;     // the next frame's choice (from the queue lengths of the last finished frame)
@@ -219,7 +228,7 @@ struct rptr_hip {
     float4 *rq_results = nullptr;
     size_t rq_capacity = 0;
     bool lights_disabled = false;   // light_sampling_variant == LIGHT_SAMPLING_VARIANT_NONE: no area-light NEE (rptr_hip_set_light_sampling_variant)
-    int frame_fine_grained = 1;     // RPTR_FRAME_FINE_GRAINED: path state + queue ids of the frame kernel in fine-grained device memory
+    int frame_fine_grained = 0;     // RPTR_FRAME_FINE_GRAINED (measured: no effect; the release fences do the work): path state + queue ids of the frame kernel in fine-grained device memory
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
     RptrCamera prev_camera;         // the previous frame's view (VP_reference)
     bool have_prev_camera = false;
@@ -1337,7 +1346,9 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
         if (const char *s = getenv("RPTR_TAIL_THRESHOLD")) h->tail_threshold = std::max(0, atoi(s));
         if (const char *s = getenv("RPTR_MAX_BATCH_FRAMES")) h->max_batch_frames = std::max(1, std::min(16, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_KERNEL")) h->frame_kernel = atoi(s) != 0 ? 1 : 0;
+        if (const char *s = getenv("RPTR_FRAME_KERNEL")) h->frame_kernel = std::max(0, std::min(2, atoi(s)));
+        if (const char *s = getenv("RPTR_STREAM_TRACE_BLOCKS")) h->stream_trace_per_cu = std::max(0, std::min(8, atoi(s)));
+        if (const char *s = getenv("RPTR_STREAM_SHADE_BLOCKS")) h->stream_shade_per_cu = std::max(0, std::min(8, atoi(s)));
         if (const char *s = getenv("RPTR_FRAME_PUB")) h->frame_pub_mode = atoi(s);
         if (const char *s = getenv("RPTR_FRAME_PUB_MAX")) h->frame_pub_max = std::max(1, std::min(RP_FQ_MAX, atoi(s)));
         if (const char *s = getenv("RPTR_FRAME_LOCAL_THRESHOLD")) h->frame_local_threshold = std::max(0, atoi(s));
@@ -1368,11 +1379,13 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
                 return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
             }
             if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void **)&c.host_fq, sizeof(RpFqState), hipHostMallocDefault) != hipSuccess) {
+                hipHostMalloc((void **)&c.host_fq, sizeof(RpFqState), hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&c.host_sx, sizeof(RpStState), hipHostMallocDefault) != hipSuccess) {
                 delete h;
                 return fail(nullptr, RPTR_E_NOMEM, "hipHostMalloc failed");
             }
             memset(c.host_fq, 0, sizeof(RpFqState));
+            memset(c.host_sx, 0, sizeof(RpStState));
         }
     }
     // defaults of RenderParams / LightSamplingConfig (librender/render_params.glsl.h:123-155)
@@ -1418,6 +1431,13 @@ void rptr_hip_destroy(rptr_hip_t *h) {
             if (e) (void)hipEventDestroy(e);
         if (c.host_counters) (void)hipHostFree(c.host_counters);
         if (c.host_fq) (void)hipHostFree(c.host_fq);
+        if (c.host_sx) (void)hipHostFree(c.host_sx);
+        if (c.stream2) {
+            (void)hipStreamSynchronize(c.stream2);
+            (void)hipStreamDestroy(c.stream2);
+        }
+        for (hipEvent_t e : {c.ev_fork2, c.ev_join2})
+            if (e) (void)hipEventDestroy(e);
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1477,6 +1497,8 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     for (FrameCtx &c : h->ctx) {
         memset(&c.fq, 0, sizeof(c.fq)); // (freed with the other frame-sized allocations above; made again by the first frame that wants them)
         memset(&c.ps_fk, 0, sizeof(c.ps_fk));
+        memset(&c.sx, 0, sizeof(c.sx));
+        c.sx_words = 0;
         c.fq_words = 0;
         if ((rc = dev_alloc(h, &c.ps.ray_o, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.ray_d, cap, nullptr))) return rc;
@@ -2439,6 +2461,44 @@ static int ensure_frame_queues(rptr_hip *h, FrameCtx &c, int grid_blocks) {
     return RPTR_OK;
 }
 
+// the streaming frame's buffers (frame-sized, made by the first frame that wants them)
+static int ensure_stream(rptr_hip *h, FrameCtx &c, int trace_blocks) {
+    int rc;
+    if (!c.sx.st) {
+        const size_t cap = h->path_capacity;
+        const size_t r_capacity = ((std::min<size_t>(3 * cap, (size_t)0x7FFF0000u) + RP_CHUNK - 1) / RP_CHUNK) * RP_CHUNK; // items of all later bounces of a frame
+        const size_t r_chunks = r_capacity / RP_CHUNK, s0_chunks = cap / RP_CHUNK + 2;
+        const size_t words = sizeof(RpStState) / sizeof(uint32_t) + r_chunks + (s0_chunks + r_chunks);
+        uint32_t *base = nullptr;
+        if ((rc = dev_alloc(h, &base, words, nullptr))) return rc;
+        c.sx.st = reinterpret_cast<RpStState *>(base);
+        c.sx.commit = base + sizeof(RpStState) / sizeof(uint32_t);
+        c.sx.traced = c.sx.commit + r_chunks;
+        c.sx_words = words;
+        c.sx.r_capacity = (uint32_t)r_capacity;
+        c.sx.capacity = (uint32_t)cap;
+        if ((rc = dev_alloc(h, &c.sx.r, r_capacity, nullptr))) return rc;
+        c.sx_tr_entries = r_chunks * (RP_CHUNK / RP_ST_POOL) + 65536; // (+ a ticket per tracer wave beyond the last entry)
+        c.sx_sr_entries = s0_chunks + r_chunks + 8192;
+        if ((rc = dev_alloc(h, &c.sx.tr_ring, c.sx_tr_entries, nullptr))) return rc;
+        if ((rc = dev_alloc(h, &c.sx.sr_ring, c.sx_sr_entries, nullptr))) return rc;
+        HIP_TRY(h, hipMemsetAsync(c.sx.tr_ring, 0, c.sx_tr_entries * sizeof(unsigned long long), c.stream));
+        HIP_TRY(h, hipMemsetAsync(c.sx.sr_ring, 0, c.sx_sr_entries * sizeof(unsigned long long), c.stream));
+        c.sx.epoch = 0;
+    }
+    if (!c.stream2) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&c.ev_fork2, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
+    }
+    const size_t threads = (size_t)trace_blocks * RP_TRAVERSE_BLOCK;
+    if (threads > c.gstack_threads) {
+        if ((rc = dev_alloc(h, &c.gstack, threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
+        c.gstack_threads = threads;
+    }
+    return RPTR_OK;
+}
+
 static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
@@ -2552,7 +2612,17 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
     }
     h->aov_ctx = (int)(&c - h->ctx.data());
     h->aov_overwritten = false;
+    if (h->local_rows > 0 && c.streamed && (c.host_sx->timeout != 0u || c.host_sx->overflow != 0u))
+        return fail(h, RPTR_E_HIP, "the streaming frame stalled or overflowed (timeouts %u, overflow %u; S0 %u of %u, R tail %u, tracer ring %u/%u, shader ring %u/%u, R chunks out %u, "
+                                   "shaded %u, seals %u)", c.host_sx->timeout, c.host_sx->overflow, c.host_sx->s0_head, c.host_sx->n0, c.host_sx->r_tail, c.host_sx->tr_head,
+                    c.host_sx->tr_tail, c.host_sx->sr_head, c.host_sx->sr_tail, c.host_sx->tr_chunks, c.host_sx->shaded, c.host_sx->seals);
 #ifdef RP_FRAME_PROF
+    if (c.streamed) {
+        const RpStState &q = *c.host_sx;
+        const double tot = std::max(1.0, (double)q.t_total);
+        fprintf(stderr, "[RP_FRAME_PROF] shader blocks: %.3f ms x blocks: wait for a chunk %.3f, load entries %.3f, shade %.3f, append + bookkeeping %.3f | chunks %u seals %u\n", tot * 1e-5,
+                q.t_wait / tot, q.t_load / tot, q.t_shade / tot, q.t_append / tot, q.shaded, q.seals);
+    }
     if (c.fq_pub_used > 0) {
         const RpFqState &q = *c.host_fq;
         const double tot = std::max(1.0, (double)q.t_total);
@@ -2815,9 +2885,49 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             const uint32_t first_count = (uint32_t)((size_t)batch * h->npix_padded);
             const uint32_t *first_ids = nullptr;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
-            // the whole frame in ONE launch (kernels.h rp_k_frame); counting keeps the stand-alone kernels
+            // the frame as a tracer and a shader kernel that run side by side for its whole length (kernels.h rp_k_stream_*); counting and
+            // alpha-tested scenes keep the stage launches
             c.fq_pub_used = 0;
-            if (h->frame_kernel && !count_traversal) {
+            c.streamed = false;
+            if (h->frame_kernel == 2 && !count_traversal && !h->uses_alpha) {
+                const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
+                int tpc = h->stream_trace_per_cu, spc = h->stream_shade_per_cu > 0 ? h->stream_shade_per_cu : 1;
+                if (tpc <= 0) {
+                    HIP_TRY(h, rp_stream_trace_blocks_per_cu(&tpc));
+                    tpc = std::max(1, std::min(tpc, 4)); // (four tracer blocks leave a CU's fifth wave slot per SIMD -- and its last 128 registers -- to the shader)
+                }
+                const int tblocks = h->num_cus * tpc, sblocks = h->num_cus * spc;
+                int rcs = ensure_stream(h, c, tblocks);
+                if (rcs) return rcs;
+                HIP_TRY(h, hipMemsetAsync(c.sx.st, 0, c.sx_words * sizeof(uint32_t), c.stream));
+                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.sx.st->n0, (int)first_count, 1, c.stream));
+                c.sx.epoch = c.sx.epoch >= 65535u ? 1u : c.sx.epoch + 1u;
+                if (c.sx.epoch == 1u && h->next_ticket > 1) {
+                    HIP_TRY(h, hipMemsetAsync(c.sx.tr_ring, 0, c.sx_tr_entries * sizeof(unsigned long long), c.stream));
+                    HIP_TRY(h, hipMemsetAsync(c.sx.sr_ring, 0, c.sx_sr_entries * sizeof(unsigned long long), c.stream));
+                }
+                RpStream sx = c.sx;
+                sx.n_s0_chunks = (first_count + RP_CHUNK - 1) / RP_CHUNK;
+                HIP_TRY(h, hipEventRecord(c.ev_fork2, c.stream));
+                HIP_TRY(h, hipStreamWaitEvent(c.stream2, c.ev_fork2, 0));
+                if (getenv("RPTR_STREAM_DBG"))
+                    fprintf(stderr, "[stream] st %p r %p commit %p traced %p tr %p sr %p cap %u chunks0 %u epoch %u words %zu sizeof(RpStream) %zu RpFrame %zu RpScene %zu\n", (void *)sx.st,
+                            (void *)sx.r, (void *)sx.commit, (void *)sx.traced, (void *)sx.tr_ring, (void *)sx.sr_ring, sx.r_capacity, sx.n_s0_chunks, sx.epoch, c.sx_words,
+                            sizeof(RpStream), sizeof(RpFrame), sizeof(RpScene));
+                const int sdbg = getenv("RPTR_STREAM_DBG") ? atoi(getenv("RPTR_STREAM_DBG")) : 0; // experiments: 1 tracer only, 2 shader only (both end in the watchdog)
+                if (sdbg != 2) rp_launch_stream_trace(timed_launch(c.stream, 3, (unsigned)tblocks), single, table_rng, scn.dscene, f, c.ps, c.sq, sx, c.gstack);
+                if (sdbg != 1)
+                    rp_launch_stream_shade(variant, RpLaunch{(unsigned)sblocks, c.stream2, nullptr, nullptr}, lights, h->uses_textures, table_rng, scn.dscene, f, c.ps, c.sq, sx,
+                                           c.counters);
+                HIP_TRY(h, hipEventRecord(c.ev_join2, c.stream2));
+                HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_join2, 0));
+                HIP_TRY(h, hipMemcpyAsync(c.host_sx, c.sx.st, sizeof(RpStState), hipMemcpyDeviceToHost, c.stream));
+                c.streamed = true;
+                c.fq_pub_used = -1;
+                c.tail_from = 0;
+            }
+            // the whole frame in ONE launch (kernels.h rp_k_frame); counting keeps the stand-alone kernels
+            if (h->frame_kernel == 1 && !count_traversal) {
                 const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
                 const bool full = h->uses_textures || h->uses_alpha;
                 int per_cu = h->frame_blocks_per_cu;
@@ -2857,7 +2967,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             if (h->tail_mode != 0 && !count_traversal)
                 tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
             if (!c.fq_pub_used) c.tail_from = tail_from;
-            for (int b = 0; b < h->params.max_path_depth && !c.fq_pub_used; ++b) {
+            for (int b = 0; b < h->params.max_path_depth && c.fq_pub_used == 0; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 if (b == tail_from) {
@@ -2895,7 +3005,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.fq_pub_used ? c.ps_fk : c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
+                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.fq_pub_used > 0 ? c.ps_fk : c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
             }
             if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
@@ -2960,7 +3070,7 @@ int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds) {
 
 int rptr_hip_set_frame_schedule(rptr_hip_t *h, int one_launch_per_frame) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
-    h->frame_kernel = one_launch_per_frame != 0 ? 1 : 0;
+    h->frame_kernel = std::max(0, std::min(2, one_launch_per_frame)); // 2: the streaming pair (rp_k_stream_trace + rp_k_stream_shade)
     return RPTR_OK;
 }
 int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, int32_t *out_published_bounces, uint32_t *out_queue_lengths, int cap) {
@@ -2969,6 +3079,12 @@ int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, in
     const FrameCtx &c = h->ctx[(size_t)std::max(0, h->aov_ctx)];
     if (out_published_bounces) *out_published_bounces = c.fq_pub_used;
     for (int b = 0; out_queue_lengths && b < cap; ++b) out_queue_lengths[b] = (b < RP_FQ_MAX && b < c.fq_pub_used) ? c.host_fq->tail[b] : 0u;
+    if (c.streamed && out_queue_lengths && cap >= 4) { // the streaming frame: camera paths, later items, chunks sealed at the end, chunks shaded
+        out_queue_lengths[0] = c.host_sx->n0;
+        out_queue_lengths[1] = c.host_sx->r_tail;
+        out_queue_lengths[2] = c.host_sx->seals;
+        out_queue_lengths[3] = c.host_sx->shaded;
+    }
     if (out_queue_lengths && cap > RP_FQ_MAX + 1) { // diagnostics behind the lengths: claim attempts, attempts that found nothing
         out_queue_lengths[RP_FQ_MAX] = c.host_fq->polls;
         out_queue_lengths[RP_FQ_MAX + 1] = c.host_fq->idle_polls;

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _frames(scene, W, H, spp, variant, n_frames, one_launch, env=None, frames_in_flight=1, params=None):
+    """one_launch: False / 0 stage launches, True / 1 rp_k_frame, 2 the streaming pair (rp_k_stream_trace + rp_k_stream_shade)"""
     env = dict(env or {})
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -102,3 +103,35 @@ def test_one_launch_frames_in_flight_and_a_stripe_of_a_split():
         imgs.append((img.copy(), int(st.raw.rays_closest)))
         r.close()
     assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32)) and imgs[0][1] == imgs[1][1]
+
+
+@pytest.mark.parametrize("scene_name,variant", [("cornell32", abi.VARIANT_SIMPLE), ("cornell32", abi.VARIANT_GLTF), ("two_level_test", abi.VARIANT_GLTF),
+                                                ("glass_test", abi.VARIANT_GLTF_TRANSMISSION)])
+def test_streaming_frames_are_bit_identical_to_stage_launches(scene_name, variant):
+    """schedule 2: a tracer kernel (persistent waves over ITEMS: a path's shadow ray, then its continuation ray, in one lane) and a shader
+    kernel run side by side for the whole frame and hand each other chunks through memory (kernels.h "stream"); same device code per path,
+    same order of additions into a path's radiance: the same bits, frame after frame (the epoch tags of the rings, the seal at the end)"""
+    s = getattr(scenes, scene_name)()
+    W, H, spp = 200, 120, 3
+    ref, _ = _frames(s, W, H, spp, variant, 4, 0)
+    got, sched = _frames(s, W, H, spp, variant, 4, 2)
+    assert sched[0] == 2 and sched[1] == -1 and sched[2][0] >= W * H * spp and sched[2][3] >= (W * H * spp) // 1024
+    _assert_same(ref, got, scene_name)
+    got, _ = _frames(s, W, H, spp, variant, 2, 2, {"RPTR_STREAM_TRACE_BLOCKS": "2", "RPTR_STREAM_SHADE_BLOCKS": "2"})
+    _assert_same(ref[:2], got, scene_name + " 2+2 blocks")
+
+
+def test_streaming_frame_of_the_benchmark_scene_with_lights_at_full_size():
+    """C3's kernels (glTF + binned-RIS lights) at 1080p, 2 spp: ~6000 chunks through both rings; and a scene with alpha-tested materials,
+    which the streaming schedule hands back to the stage launches"""
+    s = scenes.grid_1m_lights()
+    W, H, spp = 1920, 1080, 2
+    ref, _ = _frames(s, W, H, spp, abi.VARIANT_GLTF, 3, 0)
+    got, sched = _frames(s, W, H, spp, abi.VARIANT_GLTF, 3, 2)
+    _assert_same(ref, got, "C3 kernels")
+    assert sched[1] == -1
+    a = scenes.alpha_test()
+    ref, _ = _frames(a, 160, 120, 2, abi.VARIANT_GLTF, 2, 0)
+    got, sched = _frames(a, 160, 120, 2, abi.VARIANT_GLTF, 2, 2)
+    _assert_same(ref, got, "alpha")
+    assert sched[1] == 0                                               # (ran as stage launches)

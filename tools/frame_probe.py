@@ -17,19 +17,23 @@ elif which == "forest":
     scene, W, H, spp, variant = scenes.forest(), 1920, 1080, 4, abi.VARIANT_GLTF
 else:
     raise SystemExit("unknown workload")
-settings = [("stages", None)] + [("one launch " + " ".join("%s=%s" % (k[11:], v) for k, v in e.items()), e) for e in (
+settings = [("stages", None)] + [("stream " + " ".join("%s=%s" % (k[12:], v) for k, v in e.items()), dict(e, MODE="2")) for e in (
+    {}, {"RPTR_STREAM_TRACE_BLOCKS": "3"}, {"RPTR_STREAM_SHADE_BLOCKS": "2", "RPTR_STREAM_TRACE_BLOCKS": "3"}, {"RPTR_STREAM_SHADE_BLOCKS": "2"},
+    {"RPTR_STREAM_TRACE_BLOCKS": "2", "RPTR_STREAM_SHADE_BLOCKS": "2"})] + [("one launch " + " ".join("%s=%s" % (k[11:], v) for k, v in e.items()), e) for e in (
     {}, {"RPTR_FRAME_K0": "1"}, {"RPTR_FRAME_K0": "2"}, {"RPTR_FRAME_K0": "4"}, {"RPTR_FRAME_K0": "8"}, {"RPTR_FRAME_PUB": "2"}, {"RPTR_FRAME_PUB": "4"},
     {"RPTR_FRAME_BLOCKS_PER_CU": "3"}, {"RPTR_FRAME_BLOCKS_PER_CU": "2"}, {"RPTR_FRAME_LOCAL_THRESHOLD": "65536"}, {"RPTR_FRAME_LOCAL_THRESHOLD": "1048576"})]
 if len(sys.argv) > 3:
-    settings = [s for s in settings if s[1] is None or sys.argv[3] in s[0]]
+    settings = [s for s in settings if s[1] is None or any(a in s[0] for a in sys.argv[3].split(","))]
 ref = None
 for name, env in settings:
+    mode = 0 if env is None else int(env.get("MODE", "1"))
     for k, v in (env or {}).items():
-        os.environ[k] = v
+        if k != "MODE":
+            os.environ[k] = v
     r = backend.RenderHip(rank=0, world_size=world, stripe_rows=8)
     r.initialize(W, H)
     r.set_scene(scene)
-    r.set_frame_schedule(env is not None)
+    r.set_frame_schedule(mode)
     r.set_stage_timing(0)
     cfg = backend.RenderConfiguration(scene.camera_params(), active_variant=variant, reset_accumulation=True)
     for _ in range(6):
@@ -50,4 +54,5 @@ for name, env in settings:
     print("%-44s wall %.3f ms  gpu %.3f ms  rays %d  queues %s polls %s%s" % (name, wall, gpu / n, st.raw.rays_closest + st.raw.rays_shadow, sched[2], sched[3], same), flush=True)
     r.close()
     for k in (env or {}):
-        del os.environ[k]
+        if k != "MODE":
+            del os.environ[k]
