@@ -41,7 +41,7 @@ QUEUE_BYTES = 4     # path id read from the ray queue (not for the first bounce:
 NODE_BYTES = 64     # RptrBvh4Node (an instance record, 128 B, counts as two)
 TRI_BYTES = 48      # RptrBvhTri
 SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-write for a visible shadow ray
-PATH_READ_BYTES, PATH_WRITE_BYTES = 72, 80    # shade: path state in (ray_o, ray_d, thr, illum, rng_tt; not on the first bounce) / out per vertex
+PATH_READ_BYTES, PATH_WRITE_BYTES = 64, 72    # shade: path state in (ray_o, ray_d, thr, illum; not on the first bounce) / out per vertex (the same + two queue words; rounds 1-3: 72 / 80 with the separate generator / path-length array)
 VERTEX_BYTES, MATERIAL_BYTES = 48, 80         # 3 x (qpos + qnrm_uv), RptrBaseMaterial
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md "HBM")
 MAX_CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: max clock 2400 MHz
@@ -335,7 +335,18 @@ def main():
     batch_frames = args.batch_frames if args.batch_frames > 0 else (1 if args.animate else max(1, min(4, 16 // max(spp, 1))))
     # no more contexts than the timed region has launch sequences for: the line names the schedule that ran (20 steps in sequences of 4
     # frames are 5 sequences, not 11)
-    fif = max(2 if batch_frames > 1 else 1, min(fif, -(-args.steps // batch_frames)))   # (a batch of frames needs two contexts: every frame keeps its image)
+    # BENCH_BATCH_PATTERN=a,b,c,... (experiment): the lengths of the timed region's first launch sequences (then `batch_frames` each)
+    batch_pattern = [max(1, min(batch_frames, int(x))) for x in os.environ.get("BENCH_BATCH_PATTERN", "").split(",") if x.strip()]
+
+    def sequence_lengths(k):
+        out, i = [], 0
+        while k > 0:
+            n = min(batch_pattern[i] if i < len(batch_pattern) else batch_frames, k)
+            out.append(n)
+            k -= n
+            i += 1
+        return out
+    fif = max(2 if batch_frames > 1 else 1, min(fif, len(sequence_lengths(args.steps))))   # (a batch of frames needs two contexts: every frame keeps its image)
     if args.profile_pass:
         fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
     if args.emulate_world > 1:
@@ -359,20 +370,28 @@ def main():
         interactive host's do while the workload stays the one the configuration names"""
         if args.static_camera:
             return cam
+        k %= 64
+        if k in cam_cache:  # (the 64 views are made once: nothing of this is host work inside the timed region)
+            return cam_cache[k]
         import numpy as np
         c = abi.Camera()
-        a = 0.002 * (k % 64)
+        amp = float(os.environ.get("BENCH_CAMERA_SCALE", "1"))  # diagnostics: 0 = per-frame cameras that all equal the configuration's view
+        a = 0.002 * (k % 64) * amp
         d, up = np.asarray(cam.dir[:], np.float64), np.asarray(cam.up[:], np.float64)
         right = np.cross(d, up)
         right /= np.linalg.norm(right)
         nd = np.cos(a) * d + np.sin(a) * right
         nd /= np.linalg.norm(nd)
-        c.pos[:] = [float(np.float32(cam.pos[i] + 0.02 * (k % 64) * right[i])) for i in range(3)]
+        c.pos[:] = [float(np.float32(cam.pos[i] + 0.02 * (k % 64) * amp * right[i])) for i in range(3)]
         c.dir[:] = [float(np.float32(x)) for x in nd]
         c.up[:] = list(cam.up[:])
         c.fovy = cam.fovy
+        cam_cache[k] = c
         return c
+    cam_cache = {}
     frame_no = [0]
+    for k_ in range(64):
+        camera_of(k_)
 
     # ---- the gather (N > 1): the library's own RCCL path, or torch.distributed as plumbing
     # the gather: "native" = the library's RCCL gather; "torch" = tile copy + torch.distributed.gather over an nccl group; "host" = the same over
@@ -426,14 +445,19 @@ def main():
         e1.record()
         anim["ev"].append((e0, e1))
 
-    def finish(ticket):
+    def finish(ticket, last_of=1):
         """collect one queued frame; N > 1: the path's one collective, tile radiance -> rank 0. Asynchronous on the device: it runs
-        behind the collected frame, beside the frames still in flight."""
+        behind the collected frame, beside the frames still in flight. The library's gather moves the frames of a launch sequence in ONE
+        collective (rptr_hip_gather_batch): issued with the sequence's last frame (last_of = its length; 0 = not the last, nothing to do yet);
+        the torch / host fall-backs gather frame by frame."""
         st = r.wait(ticket)
         if world > 1:
             t_g = time.perf_counter()
             if native is not None:
-                native.gather()
+                if last_of > 0:
+                    native.gather(last_of if batched_gather else 1)
+                elif not batched_gather:
+                    native.gather()
             else:
                 if my_bytes:
                     r.copy_tile_to_device((stage if on_host else tgather.tile).data_ptr(), my_bytes)
@@ -450,14 +474,21 @@ def main():
         cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
         return finish(r.render_async(cfg, spp=spp, count_traversal=count))
 
+    batched_gather = os.environ.get("BENCH_GATHER_PER_FRAME", "0") == "0"   # (1: one collective per frame, as rounds 2-3 did)
+
+    def collect(tickets, on_stats):
+        for j, t in enumerate(tickets):
+            on_stats(finish(t, len(tickets) if j == len(tickets) - 1 else 0))
+
     def timed_steps(k, on_stats):
         """k frames, `batch_frames` of them per launch sequence, up to `fif` launch sequences in flight; every frame is submitted,
         rendered, collected (and gathered) inside the caller's timed region"""
         queue, left = [], k
+        lengths = sequence_lengths(k)
         while left > 0:
             if anim is not None:
                 animate()
-            n = min(batch_frames, left)
+            n = lengths.pop(0)
             cams = [camera_of(frame_no[0] + j) for j in range(n)]
             frame_no[0] += n
             cfg = backend.RenderConfiguration(cams[0], active_variant=variant, reset_accumulation=True)
@@ -469,11 +500,9 @@ def main():
                 queue.append(r.render_batch_cameras_async(cfg, cams, spp=spp, reset_rest=True))
             left -= n
             if len(queue) >= fif:
-                for t in queue.pop(0):
-                    on_stats(finish(t))
+                collect(queue.pop(0), on_stats)
         while queue:
-            for t in queue.pop(0):
-                on_stats(finish(t))
+            collect(queue.pop(0), on_stats)
 
     if args.profile_pass:  # what a rocprofv3 pass should see: identical frames, one at a time, no instrumented variants
         r.set_stage_timing(0)
@@ -851,6 +880,8 @@ def main():
                                   "torch": "tile copy + torch.distributed.gather (nccl group) + index_select",
                                   "host": "tile copy + torch.distributed.gather (gloo, tiles staged through the host) + index_select"}[gather_mode],
                          "probe": probe,
+                         "frames_per_gather": (batch_frames if (batched_gather and native is not None) else 1),
+                         "frames_per_gather_note": "the library's gather moves the frames of a launch sequence in ONE collective (rptr_hip_gather_batch); BENCH_GATHER_PER_FRAME=1: one per frame",
                          "gather_ms": round(gather_gpu_ms, 4) if gather_gpu_ms is not None else None,
                          "gather_ms_note": "mean GPU time of one gather on rank 0's communication stream (receive of N-1 tiles + assembly); asynchronous: it runs "
                                            "beside the frames in flight, inside the timed region",

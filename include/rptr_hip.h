@@ -473,7 +473,10 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
  * caller). Rank 0 keeps TWO receive buffers and TWO assembled frames and uses them in turn: the frame of gather g stays intact while
  * gather g + 1 arrives and is assembled (a reader can hold frame i while i + 1 is in flight), and is rewritten by gather g + 2.
  * Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
- * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. */
+ * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. RPTR_COMM_TRANSPORT=peer (one-process mode, devices with peer
+ * access): every rank writes its rows straight into their places in rank 0's frame from a kernel on its own communication stream --
+ * rank 0 runs no receive kernels and no assembly pass (csrc/host_comm.h "Peer writes"). rptr_hip_comm_transport names what a handle's
+ * communicator uses: "rccl", "copy" or "peer" (NULL without a communicator). */
 #define RPTR_COMM_ID_BYTES 128
 int rptr_hip_comm_get_unique_id(void *out_id128);
 int rptr_hip_comm_init_rank(rptr_hip_t *h, const void *id128);
@@ -481,10 +484,20 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n);
 int rptr_hip_comm_destroy(rptr_hip_t *h);
 int rptr_hip_gather(rptr_hip_t *h);
 int rptr_hip_gather_all(rptr_hip_t *const *handles, int n);
+/* ONE collective for the frames of a launch sequence (rptr_hip_render_batch_async / _batch_cameras_async: they finish together and lie
+ * behind each other in the frame context's images): call after waiting for the LAST ticket of the sequence; the last n_frames frames of
+ * it (1 <= n_frames <= frames per launch sequence; every rank passes the same number) travel in one transfer per rank and are assembled
+ * in one pass -- a quarter of the per-frame cost for sequences of four (csrc/host_comm.h "Batched gathers"). n_frames = 1 is
+ * rptr_hip_gather. Rank 0 then holds n_frames assembled images: rptr_hip_gathered_frame / rptr_hip_readback_gathered_f32 show the last
+ * one, rptr_hip_readback_gathered_frame_f32(h, k, ..) image k (0 = the oldest) of the last gather. */
+int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames);
+int rptr_hip_gather_all_batch(rptr_hip_t *const *handles, int n, int n_frames);
 int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f);
 int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats);
+int rptr_hip_readback_gathered_frame_f32(rptr_hip_t *h, int index, float *rgba, size_t n_floats);
 /* gathers issued so far, and the mean GPU time of the completed ones on this rank's communication stream (send / receive + assembly) */
 int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_gather_ms);
+const char *rptr_hip_comm_transport(rptr_hip_t *h);
 
 /* ---- enable_ray_queries / render_ray_queries with the RQ_CLOSEST kernel
  * (render_backend.h:101-102, vulkan/rt_intersect.comp:31-68): n queries ->

@@ -98,9 +98,14 @@ def load_library(path=None):
     L.rptr_hip_comm_destroy.argtypes = [vp]
     L.rptr_hip_gather.argtypes = [vp]
     L.rptr_hip_gather_all.argtypes = [C.POINTER(vp), i32]
+    L.rptr_hip_gather_batch.argtypes = [vp, i32]
+    L.rptr_hip_gather_all_batch.argtypes = [C.POINTER(vp), i32, i32]
+    L.rptr_hip_readback_gathered_frame_f32.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_gathered_frame.argtypes = [vp, C.POINTER(vp)]
     L.rptr_hip_readback_gathered_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    L.rptr_hip_comm_transport.argtypes = [vp]
+    L.rptr_hip_comm_transport.restype = C.c_char_p
     for name in abi.EXPORTED_SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
     _lib = L
@@ -481,28 +486,38 @@ class RenderHip:
             msgs = [r._L.rptr_hip_last_error(r._h).decode() for r in renderers]
             raise BackendError(rc, "; ".join(m for m in msgs if m) or renderers[0]._L.rptr_hip_last_error(None).decode())
 
-    def gather(self):
-        """this rank's part of the per-frame gather (asynchronous; call right after wait())"""
-        self._check(self._L.rptr_hip_gather(self._h))
+    def gather(self, n_frames=1):
+        """this rank's part of the gather (asynchronous; call right after wait()). n_frames > 1: ONE collective for the last n_frames
+        frames of the launch sequence whose last ticket was just waited for"""
+        self._check(self._L.rptr_hip_gather_batch(self._h, int(n_frames)))
 
     @staticmethod
-    def gather_all(renderers):
-        rc = renderers[0]._L.rptr_hip_gather_all(RenderHip._handle_array(renderers), len(renderers))
+    def gather_all(renderers, n_frames=1):
+        rc = renderers[0]._L.rptr_hip_gather_all_batch(RenderHip._handle_array(renderers), len(renderers), int(n_frames))
         if rc != 0:
             msgs = [r._L.rptr_hip_last_error(r._h).decode() for r in renderers]
             raise BackendError(rc, "; ".join(m for m in msgs if m))
+
+    def comm_transport(self):
+        """what this handle's communicator moves rows with: "rccl", "copy" or "peer" (None without a communicator)"""
+        t = self._L.rptr_hip_comm_transport(self._h)
+        return t.decode() if t else None
 
     def gathered_frame_ptr(self):
         p = C.c_void_p()
         self._check(self._L.rptr_hip_gathered_frame(self._h, C.byref(p)))
         return p.value
 
-    def readback_gathered(self, buffer: np.ndarray):
-        """rank 0: the assembled RGBA32F frame of the last gather (waits for it). Returns #elements or 0."""
+    def readback_gathered(self, buffer: np.ndarray, index=None):
+        """rank 0: the assembled RGBA32F frame of the last gather (waits for it); index: frame k of a batched gather (default: its
+        last). Returns #elements or 0."""
         w, hgt, c = self.get_framebuffer_size()
         if buffer.size < w * hgt * c or buffer.dtype != np.float32:
             return 0
-        self._check(self._L.rptr_hip_readback_gathered_f32(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
+        if index is None:
+            self._check(self._L.rptr_hip_readback_gathered_f32(self._h, buffer.ctypes.data_as(C.c_void_p), buffer.size))
+        else:
+            self._check(self._L.rptr_hip_readback_gathered_frame_f32(self._h, int(index), buffer.ctypes.data_as(C.c_void_p), buffer.size))
         return w * hgt * c
 
     def comm_stats(self):

@@ -256,7 +256,7 @@ RP_DEV V2 rp_rand2(uint32_t &state) { // rendering/defaults.glsl:29-35
 //   uniform: `s` is the LCG state, dimensions are ignored (defaults.glsl:23-50).
 //   Sobol / Z-Sobol: `index` is the point of the sequence, every draw XORs a fresh LCG number (`s`: the scramble) into it (sobol.glsl:197-206).
 //   blue noise: `index` = sampleID, `pix` = pixelID inside the 128 x 128 tile (bn_rng.glsl:80-92); no state changes between draws.
-// Only `s` lives in the path state (rng_tt.x); index / pix are functions of the path id and are recomputed by rp_rng_open.
+// Only `s` lives in the path state (ray_d.w); index / pix are functions of the path id and are recomputed by rp_rng_open.
 struct RpRng {
     uint32_t s, index, pix;
 };

@@ -12,6 +12,15 @@
 // process -- PyTorch ships one -- or the system's), so single-GPU hosts and the build container never need it.
 // One process with several handles can also move the rows with hipMemcpyPeerAsync (handles that share a device in test rigs, or
 // RPTR_COMM_TRANSPORT=copy); same stream / event structure, same assembly kernel.
+// Peer writes (round 4; RPTR_COMM_TRANSPORT=peer, one-process groups): RCCL's receive side costs rank 0 -- its proxy kernels hold CUs of
+// an issue-bound renderer (+18 % on rank 0's frames, tools/gather_cost.py) and rank 0 then still runs the assembly pass over the whole
+// frame. With peer access on (hipDeviceEnablePeerAccess) every rank instead SCATTERS its rows itself, straight into their places in rank
+// 0's frame (rp_k_scatter_rows on the rank's own communication stream: 30 KB contiguous per row, full lines over the rank's own xGMI
+// link): rank 0 runs no receive kernels and no assembly, only the scatter of its own rows; its stream waits for one event per peer.
+// Batched gathers (round 4; rptr_hip_gather_batch / _gather_all_batch): "fewer, larger collectives" -- the frames of one launch sequence
+// finish together and lie behind each other in the frame context's image array, so ONE transfer per rank (n x its rows) and ONE assembly
+// pass move all n of them: measured beside a renderer whose frames take 0.2 ms (what a rank of an 8-way split renders), a gather per
+// frame costs +44 % (RCCL) / +16 % (peer writes) of the frame rate, a gather per sequence of four a quarter of that (tools/gather_cost.py).
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and prototypes only: nothing links against librccl
@@ -60,7 +69,7 @@ RcclApi &rccl() {
     return api;
 }
 
-enum { COMM_RCCL = 0, COMM_COPY = 1 };
+enum { COMM_RCCL = 0, COMM_COPY = 1, COMM_PEER = 2 };
 
 } // namespace
 
@@ -72,18 +81,22 @@ struct RptrComm {
     hipEvent_t ev_done = nullptr;     // the last gather of this rank has finished (send done / frame assembled)
     // rank 0: two slots, used in turn (gather g works on slot g % 2), so that a reader can hold frame i while frame i + 1 arrives and is
     // assembled, and so that a peer's copy for gather g + 1 never lands in the rows gather g is still assembling from
-    float4 *recv[2] = {nullptr, nullptr};      // packed rows of the ranks 1..N-1 (RPTR_COMM_SELF: and of rank 0), rank after rank
-    float4 *gathered[2] = {nullptr, nullptr};  // the assembled frame, width * height
+    float4 *recv[2] = {nullptr, nullptr};      // packed rows of the ranks 1..N-1 (RPTR_COMM_SELF: and of rank 0), rank after rank; a rank's block
+                                               // holds `max_batch` images of its rows (a batched gather fills the first n)
+    float4 *gathered[2] = {nullptr, nullptr};  // the assembled frame(s): max_batch images of width * height
+    int max_batch = 1;                // frames one gather can move (the handle's max_batch_frames; 1 without frames in flight)
+    int last_batch = 1;               // frames the last gather moved: rptr_hip_gathered_frame / _readback_gathered_f32 show the LAST of them
     hipEvent_t ev_slot[2] = {nullptr, nullptr}; // "the assembly that used this slot has finished" (recorded on rank 0's stream)
     bool slot_used[2] = {false, false};
     int last_slot = 0;                // the slot of the last gather: what rptr_hip_gathered_frame / _readback_gathered_f32 show
     size_t bytes_owned = 0;           // device bytes of the buffers above (counted in the handle's bytes_frame)
-    unsigned long long *d_offsets = nullptr; // per rank: first float4 of its rows in `recv`
+    unsigned long long *d_offsets = nullptr; // per rank: first float4 of its block in `recv`, then (world more entries) the pixels of one image of its rows
     std::vector<size_t> rank_pixels, rank_offset;
     bool self = false;                // RPTR_COMM_SELF=1 (diagnostic): rank 0's own rows also travel through ncclSend / ncclRecv
     // one process, several handles: the peers (rank order) and, for peer copies, the events that tell rank 0 a peer's rows have landed
     std::vector<rptr_hip *> peers;
     hipEvent_t ev_copied = nullptr;
+    hipEvent_t ev_gate = nullptr;     // (rank 0, peer writes) what rank 0's communication stream held when a gather began: the peers' writes into the slot wait for it
     // statistics
     uint64_t gathers = 0, timed = 0;
     double total_ms = 0.0;
@@ -92,15 +105,30 @@ struct RptrComm {
 };
 
 // rows of rank r's tile, packed top to bottom, into the frame
+// nb images: image k of rank r's rows lies at its block + k * (pixels of one image of its rows) (own: rank 0's images, same stride)
 __global__ __launch_bounds__(256) void rp_k_assemble(float4 *frame, const float4 *own, const float4 *recv, const unsigned long long *offsets, int width,
-                                                     int height, int stripe_rows, int world, int self) {
-    const size_t n = (size_t)width * height;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+                                                     int height, int stripe_rows, int world, int self, int nb) {
+    const size_t npix = (size_t)width * height, n = npix * (size_t)nb;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = j / npix, i = j - k * npix;
         const int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
         const int s = y / stripe_rows, r = s % world;
         const int local_row = (s / world) * stripe_rows + (y - s * stripe_rows);
-        const float4 *src = (r == 0 && !self) ? own : recv + offsets[r];
-        frame[i] = src[(size_t)local_row * width + x];
+        const float4 *src = ((r == 0 && !self) ? own : recv + offsets[r]) + k * offsets[world + r];
+        frame[j] = src[(size_t)local_row * width + x];
+    }
+}
+
+// the peer-write transport: the rows of rank `rank` (packed top to bottom) go to their places in the frame, which may live on another device
+__global__ __launch_bounds__(256) void rp_k_scatter_rows(float4 *frame, const float4 *rows, int width, int height, int local_rows, int stripe_rows, int world,
+                                                         int rank, int nb) {
+    const size_t per = (size_t)width * local_rows, n = per * (size_t)nb;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = j / per, i = j - k * per;
+        const int lr = (int)(i / (size_t)width), x = (int)(i - (size_t)lr * width);
+        const int s = lr / stripe_rows;
+        const int y = (s * world + rank) * stripe_rows + (lr - s * stripe_rows);
+        frame[k * ((size_t)width * height) + (size_t)y * width + x] = rows[j];
     }
 }
 
@@ -124,19 +152,30 @@ int comm_setup_local(rptr_hip *h, int transport) {
     c->transport = transport;
     if (const char *e = getenv("RPTR_COMM_SELF")) c->self = atoi(e) != 0;
     h->comm = c;
-    HIP_TRY(h, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // the gather's kernels are tiny next to the persistent traversal launches they run beside: a high-priority queue gets them their CU
+    // slots first (RPTR_COMM_PRIORITY=0: a plain stream)
+    {
+        int least = 0, greatest = 0;
+        const char *e = getenv("RPTR_COMM_PRIORITY");
+        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            HIP_TRY(h, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+        else
+            HIP_TRY(h, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     HIP_TRY(h, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming));
     HIP_TRY(h, hipEventCreate(&c->ev_t0));
     HIP_TRY(h, hipEventCreate(&c->ev_t1));
+    c->max_batch = h->ctx.size() > 1 ? std::max(1, h->max_batch_frames) : 1;
     c->rank_pixels.assign((size_t)h->world, 0);
     c->rank_offset.assign((size_t)h->world, 0);
     size_t at = 0;
     for (int r = 0; r < h->world; ++r) {
         c->rank_pixels[(size_t)r] = (size_t)h->width * local_row_count(h->height, h->stripe_rows, r, h->world);
         c->rank_offset[(size_t)r] = at;
-        if (r != 0 || c->self) at += c->rank_pixels[(size_t)r];
+        if (r != 0 || c->self) at += c->rank_pixels[(size_t)r] * (size_t)c->max_batch;
     }
     if (h->rank == 0) {
         // the communicator owns its buffers (frame-sized: comm_release frees them, and the next initialize drops the communicator)
@@ -152,13 +191,14 @@ int comm_setup_local(rptr_hip *h, int transport) {
         };
         int rc;
         for (int s = 0; s < 2; ++s) {
-            if ((rc = own((void **)&c->recv[s], at * sizeof(float4)))) return rc;
-            if ((rc = own((void **)&c->gathered[s], npix * sizeof(float4)))) return rc;
-            HIP_TRY(h, hipMemset(c->gathered[s], 0, npix * sizeof(float4)));
+            if ((rc = own((void **)&c->recv[s], (transport == COMM_PEER ? 0 : at) * sizeof(float4)))) return rc; // (peer writes land in the frame itself)
+            if ((rc = own((void **)&c->gathered[s], npix * (size_t)c->max_batch * sizeof(float4)))) return rc;
+            HIP_TRY(h, hipMemset(c->gathered[s], 0, npix * (size_t)c->max_batch * sizeof(float4)));
             HIP_TRY(h, hipEventCreateWithFlags(&c->ev_slot[s], hipEventDisableTiming));
         }
-        if ((rc = own((void **)&c->d_offsets, (size_t)h->world * sizeof(unsigned long long)))) return rc;
+        if ((rc = own((void **)&c->d_offsets, 2 * (size_t)h->world * sizeof(unsigned long long)))) return rc;
         std::vector<unsigned long long> off(c->rank_offset.begin(), c->rank_offset.end());
+        off.insert(off.end(), c->rank_pixels.begin(), c->rank_pixels.end());
         HIP_TRY(h, hipMemcpy(c->d_offsets, off.data(), off.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
     }
     return RPTR_OK;
@@ -170,7 +210,7 @@ void comm_release(rptr_hip *h) {
     (void)hipSetDevice(h->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && rccl().CommDestroy) (void)rccl().CommDestroy(c->nccl);
-    for (hipEvent_t e : {c->ev_src, c->ev_done, c->ev_copied, c->ev_t0, c->ev_t1, c->ev_slot[0], c->ev_slot[1]})
+    for (hipEvent_t e : {c->ev_src, c->ev_done, c->ev_copied, c->ev_gate, c->ev_t0, c->ev_t1, c->ev_slot[0], c->ev_slot[1]})
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (void *p : {(void *)c->recv[0], (void *)c->recv[1], (void *)c->gathered[0], (void *)c->gathered[1], (void *)c->d_offsets})
@@ -186,10 +226,11 @@ void comm_release(rptr_hip *h) {
 inline int comm_slot(const RptrComm *c) { return (int)(c->gathers & 1u); }
 
 // the image the gather sends: the rows of the frame that was waited for last
-const float4 *comm_source(rptr_hip *h, FrameCtx *&owner) {
+// nb > 1: the last nb frames of the waited launch sequence (images output_index - nb + 1 .. output_index of its context)
+const float4 *comm_source(rptr_hip *h, FrameCtx *&owner, int nb) {
     if (h->output_ctx >= 0) {
         owner = &h->ctx[(size_t)h->output_ctx];
-        return owner->out_accum + (size_t)h->output_index * ((size_t)h->width * (size_t)std::max(h->local_rows, 1));
+        return owner->out_accum + (size_t)(h->output_index - (nb - 1)) * ((size_t)h->width * (size_t)std::max(h->local_rows, 1));
     }
     owner = &h->ctx[0];
     return h->accum;
@@ -208,14 +249,18 @@ void comm_collect_timing(RptrComm *c, bool wait) {
 }
 
 // first half of a rank's gather: order the communication stream behind the waited frame
-int comm_begin(rptr_hip *h, const float4 *&src, FrameCtx *&owner) {
+int comm_begin(rptr_hip *h, const float4 *&src, FrameCtx *&owner, int nb) {
     RptrComm *c = h->comm;
     if (!c) return fail(h, RPTR_E_INVALID, "rptr_hip_gather without a communicator (rptr_hip_comm_init_rank / _init_all)");
+    if (nb < 1 || nb > c->max_batch)
+        return fail(h, RPTR_E_INVALID, "a gather moves 1..%d frames (the handle's frames per launch sequence), not %d", c->max_batch, nb);
+    if (nb > 1 && (h->output_ctx < 0 || h->output_index + 1 < nb))
+        return fail(h, RPTR_E_INVALID, "a gather of %d frames wants the LAST frame of a launch sequence of at least %d frames to have been waited for (waited: frame %d of its sequence)", nb, nb, h->output_index);
     if (h->output_overwritten)
         return fail(h, RPTR_E_INVALID, "the image of the last waited frame is being overwritten by a newer frame on the same frame context: gather right "
                                        "after rptr_hip_wait");
     HIP_TRY(h, hipSetDevice(h->device));
-    src = comm_source(h, owner);
+    src = comm_source(h, owner, nb);
     HIP_TRY(h, hipEventRecord(c->ev_src, h->stream)); // finish_frame made the backend's stream wait for the frame
     HIP_TRY(h, hipStreamWaitEvent(c->stream, c->ev_src, 0));
     comm_collect_timing(c, false);
@@ -224,13 +269,15 @@ int comm_begin(rptr_hip *h, const float4 *&src, FrameCtx *&owner) {
 }
 
 // second half: rank 0 assembles; the sender's frame context learns when its image is free again
-int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner) {
+int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner, int nb) {
     RptrComm *c = h->comm;
+    c->last_batch = nb;
     if (h->rank == 0) {
-        const size_t npix = (size_t)h->width * h->height;
+        const size_t npix = (size_t)h->width * h->height * (size_t)nb;
         const int slot = comm_slot(c);
-        hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered[slot], src, c->recv[slot], c->d_offsets, h->width,
-                           h->height, h->stripe_rows, h->world, c->self ? 1 : 0);
+        if (c->transport != COMM_PEER) // (peer writes: every rank, this one included, has put its rows into the frame already)
+            hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered[slot], src, c->recv[slot], c->d_offsets, h->width,
+                               h->height, h->stripe_rows, h->world, c->self ? 1 : 0, nb);
         HIP_TRY(h, hipEventRecord(c->ev_slot[slot], c->stream));
         c->slot_used[slot] = true;
         c->last_slot = slot;
@@ -249,14 +296,14 @@ int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner) {
 }
 
 // this rank's sends / receives (inside the caller's ncclGroupStart / End)
-int comm_post_rccl(rptr_hip *h, const float4 *src) {
+int comm_post_rccl(rptr_hip *h, const float4 *src, int nb) {
     RptrComm *c = h->comm;
     RcclApi &R = rccl();
-    const size_t mine = c->rank_pixels[(size_t)h->rank];
+    const size_t mine = c->rank_pixels[(size_t)h->rank] * (size_t)nb; // (the nb images of a rank's rows lie behind each other on both sides)
     if ((h->rank != 0 || c->self) && mine) NCCL_TRY(h, R.Send(src, mine * 4, ncclFloat, 0, c->nccl, c->stream));
     if (h->rank == 0)
         for (int r = c->self ? 0 : 1; r < h->world; ++r)
-            if (c->rank_pixels[(size_t)r]) NCCL_TRY(h, R.Recv(c->recv[comm_slot(c)] + c->rank_offset[(size_t)r], c->rank_pixels[(size_t)r] * 4, ncclFloat, r, c->nccl, c->stream));
+            if (c->rank_pixels[(size_t)r]) NCCL_TRY(h, R.Recv(c->recv[comm_slot(c)] + c->rank_offset[(size_t)r], c->rank_pixels[(size_t)r] * (size_t)nb * 4, ncclFloat, r, c->nccl, c->stream));
     return RPTR_OK;
 }
 
@@ -303,9 +350,18 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
     if (const char *e = getenv("RPTR_COMM_TRANSPORT")) {
         if (!strcmp(e, "copy")) transport = COMM_COPY;
         else if (!strcmp(e, "rccl")) transport = COMM_RCCL;
+        else if (!strcmp(e, "peer")) transport = COMM_PEER;
     }
     RcclApi &R = rccl();
     if (transport == COMM_RCCL && !R.error.empty()) return fail(handles[0], RPTR_E_UNSUPPORTED, "%s", R.error.c_str());
+    if (transport == COMM_PEER)
+        for (int i = 1; i < n; ++i)
+            if (handles[i]->device != handles[0]->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, handles[i]->device, handles[0]->device) != hipSuccess || !can)
+                    return fail(handles[i], RPTR_E_UNSUPPORTED, "RPTR_COMM_TRANSPORT=peer: device %d cannot access device %d's memory", handles[i]->device,
+                                handles[0]->device);
+            }
     for (int i = 0; i < n; ++i) {
         comm_release(handles[i]);
         int rc = comm_setup_local(handles[i], transport);
@@ -323,7 +379,7 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
         }
         NCCL_TRY(handles[0], R.GroupEnd());
     } else {
-        for (int i = 1; i < n; ++i) // peer access for the copies (a no-op error when it is already on or the device is the same)
+        for (int i = 1; i < n; ++i) // peer access for the copies / the peer writes (a no-op error when it is already on or the device is the same)
             if (handles[i]->device != handles[0]->device) {
                 (void)hipSetDevice(handles[i]->device);
                 (void)hipDeviceEnablePeerAccess(handles[0]->device, 0);
@@ -341,23 +397,29 @@ int rptr_hip_comm_destroy(rptr_hip_t *h) {
     return RPTR_OK;
 }
 
-int rptr_hip_gather(rptr_hip_t *h) {
+int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (!h->comm) return fail(h, RPTR_E_INVALID, "rptr_hip_gather without a communicator (rptr_hip_comm_init_rank)");
     if (h->comm->peers.size() > 1) return fail(h, RPTR_E_INVALID, "this handle belongs to a one-process group: use rptr_hip_gather_all");
+    const int nb = n_frames;
     const float4 *src = nullptr;
     FrameCtx *owner = nullptr;
-    int rc = comm_begin(h, src, owner);
+    int rc = comm_begin(h, src, owner, nb);
     if (rc) return rc;
     RcclApi &R = rccl();
     NCCL_TRY(h, R.GroupStart());
-    rc = comm_post_rccl(h, src);
+    rc = comm_post_rccl(h, src, nb);
     NCCL_TRY(h, R.GroupEnd());
     if (rc) return rc;
-    return comm_end(h, src, owner);
+    return comm_end(h, src, owner, nb);
 }
 
-int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
+int rptr_hip_gather(rptr_hip_t *h) { return rptr_hip_gather_batch(h, 1); }
+
+int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) { return rptr_hip_gather_all_batch(handles, n, 1); }
+
+int rptr_hip_gather_all_batch(rptr_hip_t *const *handles, int n, int n_frames) {
+    const int nb = n_frames;
     if (!handles || n < 1 || !handles[0]) return fail(nullptr, RPTR_E_INVALID, "bad argument");
     for (int i = 0; i < n; ++i)
         if (!handles[i] || !handles[i]->comm || (int)handles[i]->comm->peers.size() != n || handles[i]->comm->peers[(size_t)i] != handles[i])
@@ -365,7 +427,7 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
     std::vector<const float4 *> src((size_t)n, nullptr);
     std::vector<FrameCtx *> owner((size_t)n, nullptr);
     for (int i = 0; i < n; ++i) {
-        int rc = comm_begin(handles[i], src[(size_t)i], owner[(size_t)i]);
+        int rc = comm_begin(handles[i], src[(size_t)i], owner[(size_t)i], nb);
         if (rc) return rc;
     }
     rptr_hip *h0 = handles[0];
@@ -376,10 +438,34 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
         int rc = RPTR_OK;
         for (int i = 0; i < n && !rc; ++i) {
             HIP_TRY(handles[i], hipSetDevice(handles[i]->device));
-            rc = comm_post_rccl(handles[i], src[(size_t)i]);
+            rc = comm_post_rccl(handles[i], src[(size_t)i], nb);
         }
         NCCL_TRY(h0, R.GroupEnd());
         if (rc) return rc;
+    } else if (c0->transport == COMM_PEER) {
+        // peer writes: every rank scatters its rows into rank 0's frame on its OWN communication stream -- behind its frame (comm_begin)
+        // and behind whatever rank 0's communication stream held when this gather began (the gather that last used this slot, a read-back
+        // of it) --; rank 0's stream waits for every peer's event, then the frame is complete (comm_end records it)
+        const int slot = comm_slot(c0);
+        float4 *frame = c0->gathered[slot];
+        HIP_TRY(h0, hipSetDevice(h0->device));
+        HIP_TRY(h0, hipEventRecord(c0->ev_gate, c0->stream));
+        for (int i = 0; i < n; ++i) {
+            rptr_hip *h = handles[i];
+            RptrComm *c = h->comm;
+            const int rows = local_row_count(h0->height, h0->stripe_rows, i, n);
+            if (rows <= 0) continue;
+            HIP_TRY(h, hipSetDevice(h->device));
+            if (i != 0) HIP_TRY(h, hipStreamWaitEvent(c->stream, c0->ev_gate, 0));
+            hipLaunchKernelGGL(rp_k_scatter_rows, dim3(grid_for(h, (size_t)h0->width * rows * nb)), dim3(256), 0, c->stream, frame, src[(size_t)i], h0->width,
+                               h0->height, rows, h0->stripe_rows, n, i, nb);
+            HIP_TRY(h, hipGetLastError());
+            if (i != 0) {
+                HIP_TRY(h, hipEventRecord(c->ev_copied, c->stream));
+                HIP_TRY(h0, hipSetDevice(h0->device));
+                HIP_TRY(h0, hipStreamWaitEvent(c0->stream, c->ev_copied, 0));
+            }
+        }
     } else {
         // peer copies: rank r writes its rows into rank 0's receive buffer on its OWN communication stream (behind its frame, and behind
         // the assembly that last read this slot of the receive buffer), rank 0's stream waits for every copy before it assembles
@@ -388,7 +474,7 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
         for (int i = c0->self ? 0 : 1; i < n; ++i) {
             rptr_hip *h = handles[i];
             RptrComm *c = h->comm;
-            const size_t bytes = c0->rank_pixels[(size_t)i] * sizeof(float4);
+            const size_t bytes = c0->rank_pixels[(size_t)i] * (size_t)nb * sizeof(float4);
             if (!bytes) continue;
             HIP_TRY(h, hipSetDevice(h->device));
             if (c0->slot_used[slot]) HIP_TRY(h, hipStreamWaitEvent(c->stream, c0->ev_slot[slot], 0));
@@ -403,7 +489,7 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
     }
     for (int i = 0; i < n; ++i) {
         HIP_TRY(handles[i], hipSetDevice(handles[i]->device));
-        int rc = comm_end(handles[i], src[(size_t)i], owner[(size_t)i]);
+        int rc = comm_end(handles[i], src[(size_t)i], owner[(size_t)i], nb);
         if (rc) return rc;
     }
     return RPTR_OK;
@@ -412,19 +498,27 @@ int rptr_hip_gather_all(rptr_hip_t *const *handles, int n) {
 int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f) {
     if (!h || !out_device_rgba32f) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
-    *out_device_rgba32f = h->comm->gathered[h->comm->last_slot]; // stays intact during the NEXT gather (two slots), is rewritten by the one after
+    // the LAST image of the last gather; stays intact during the NEXT gather (two slots), is rewritten by the one after
+    *out_device_rgba32f = h->comm->gathered[h->comm->last_slot] + (size_t)(h->comm->last_batch - 1) * ((size_t)h->width * h->height);
+    return RPTR_OK;
+}
+
+int rptr_hip_readback_gathered_frame_f32(rptr_hip_t *h, int index, float *rgba, size_t n_floats) {
+    if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
+    if (index < 0 || index >= h->comm->last_batch) return fail(h, RPTR_E_INVALID, "the last gather moved %d frame(s): no frame %d", h->comm->last_batch, index);
+    const size_t need = (size_t)h->width * h->height * 4;
+    if (n_floats < need) return fail(h, RPTR_E_INVALID, "read-back buffer too small");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered[h->comm->last_slot] + (size_t)index * ((size_t)h->width * h->height), need * sizeof(float), hipMemcpyDeviceToHost,
+                              h->comm->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
     return RPTR_OK;
 }
 
 int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
-    if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
-    if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
-    const size_t need = (size_t)h->width * h->height * 4;
-    if (n_floats < need) return fail(h, RPTR_E_INVALID, "read-back buffer too small");
-    HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered[h->comm->last_slot], need * sizeof(float), hipMemcpyDeviceToHost, h->comm->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
-    return RPTR_OK;
+    if (!h || !h->comm) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
+    return rptr_hip_readback_gathered_frame_f32(h, h->comm->last_batch - 1, rgba, n_floats);
 }
 
 int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_gather_ms) {
@@ -435,6 +529,11 @@ int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_ga
     if (out_gathers) *out_gathers = h->comm->gathers;
     if (out_mean_gather_ms) *out_mean_gather_ms = h->comm->timed ? (float)(h->comm->total_ms / (double)h->comm->timed) : 0.0f;
     return RPTR_OK;
+}
+
+const char *rptr_hip_comm_transport(rptr_hip_t *h) {
+    if (!h || !h->comm) return nullptr;
+    return h->comm->transport == COMM_RCCL ? "rccl" : h->comm->transport == COMM_COPY ? "copy" : "peer";
 }
 
 } // extern "C"

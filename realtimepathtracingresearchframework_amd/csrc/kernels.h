@@ -22,12 +22,16 @@
 #include "dstream.h"
 #include <type_traits>
 
+// Round 4 (less path-state traffic, every value exact): the continuation ray's t_min is a function of its origin and the path length
+// (rp_geometry_scale_to_tmin: the extend recomputes it) and its t_max is a constant, so the two .w words carry the path length and the
+// generator instead and the separate 8-byte (generator, path length) array is gone; the shadow ray of a vertex starts where the
+// continuation ray does, with the same offset, so ray_o serves both (RpShadowRays has no origin array): a first-bounce path writes 96
+// bytes where it wrote 120, a later shade reads 88 instead of 96.
 struct RpPathState {
-    float4 *ray_o;   // origin.xyz, t_min
-    float4 *ray_d;   // dir.xyz, t_max
+    float4 *ray_o;   // origin.xyz, total_t (the path length up to the origin): origin of the continuation ray AND of the vertex's shadow ray
+    float4 *ray_d;   // dir.xyz, bits(rng state)
     float4 *thr;     // throughput.xyz, prev_bounce_pdf
     float4 *illum;   // illum.xyz, bits(bounce)
-    float2 *rng_tt;  // bits(rng state), total_t
     float4 *footprint; // the texture footprint (2 x 2, column major) of paths through scenes with textures (else NULL)
     uint32_t *alpha_rng; // the alpha-test generator of closest-hit queries when the point set is not the uniform one (else NULL)
     float4 *hit_tuv; // t, u, v, bits(prim)
@@ -36,8 +40,7 @@ struct RpPathState {
 // shadow rays live at the slot of their path (at most one per path and bounce);
 // the shadow queue itself only carries path ids
 struct RpShadowRays {
-    float4 *o;       // origin.xyz, t_min
-    float4 *d;       // dir.xyz, t_max
+    float4 *d;       // dir.xyz, t_max (the origin and t_min: RpPathState.ray_o)
     float4 *contrib; // radiance to add if visible .xyz
     uint32_t *ids;   // compacted path ids
 };
@@ -147,7 +150,9 @@ RP_DEV void rp_block_flush(const uint32_t *staged, uint32_t n_local, uint32_t *q
 // constants and the path id, so nothing of it is stored -- the first extend and the first shade both call it
 // (saves writing and re-reading 72 bytes of path state per pixel sample). Returns false for padding slots.
 // origin: the camera position of the path's frame; du_dv (may be NULL): its image-plane axes. Frames with cameras of their own
-// (f.per_frame_cams) are rendered by the general (TABLE) instantiation: the shipped path reads the one camera of RpFrame as it always did.
+// (f.per_frame_cams; wave-uniform, so the branch is a scalar one) read cams[frame] per lane -- a launch sequence's frames differ by sample
+// slot, and a wave's pool may straddle two of them -- in every instantiation (round 4: routing them through the general TABLE kernels
+// cost 3-5 % of a C2 frame for what is three cached 16-byte loads per camera ray).
 template <bool TABLE>
 RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, int &lx, int &ly, uint32_t &sslot, V3 &origin, V3 *du_dv = nullptr) {
     sslot = rp_div(p, f.div_npix_padded);
@@ -165,7 +170,7 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir,
     if (TABLE && f.rp.enable_raster_taa != 0) point = point + rp_screen_jitter(f, sf.frame_offset, sf.frame_id) * 0.5f; // pt_megakernel.glsl:319-320
     V3 du = ld3(f.cam_du), dv = ld3(f.cam_dv), tl = ld3(f.cam_dir_top_left);
     origin = ld3(f.cam_pos);
-    if (TABLE && f.per_frame_cams != 0) {
+    if (f.per_frame_cams != 0) {
         const RpCam &c = f.cams[min(sf.frame, (uint32_t)(RP_BATCH_CAMS - 1))];
         du = ld3(c.du);
         dv = ld3(c.dv);
@@ -241,11 +246,10 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             const float4 o = rp_ld4<SH>(ps.ray_o, p), d = rp_ld4<SH>(ps.ray_d, p);
             ro = xyz(o);
             rd = xyz(d);
-            tmin = o.w;
-            tmax = d.w;
+            tmin = rp_geometry_scale_to_tmin(ro, o.w); // (what the shade computed for its shadow ray: same operands, same bits)
+            tmax = 1e20f;
             if (ALPHA)
-                lane_rng = lane_rng_in =
-                    (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(rp_ld2<SH>(ps.rng_tt, p).x) : rp_ld1<SH>(ps.alpha_rng, p);
+                lane_rng = lane_rng_in = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(d.w) : rp_ld1<SH>(ps.alpha_rng, p);
         }
         return true;
     };
@@ -257,9 +261,9 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
                 if (FIRST || lane_rng != lane_rng_in) rp_st1<SH>(ps.alpha_rng, p, lane_rng);
             } else if (FIRST)
-                rp_st2<SH>(ps.rng_tt, p, make_float2(__uint_as_float(lane_rng), 0.0f)); // the first shade takes it from here (f.alpha_test)
+                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.ray_d), 4u * p + 3u, lane_rng); // the first shade takes it from here (f.alpha_test)
             else if (lane_rng != lane_rng_in)
-                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.rng_tt), 2u * p, lane_rng);
+                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.ray_d), 4u * p + 3u, lane_rng);
         }
     };
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
@@ -310,10 +314,10 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
     };
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
         const uint32_t p = ids[i];
-        const float4 o = sq.o[p], d = sq.d[p];
+        const float4 o = rp_ld4<SH>(ps.ray_o, p), d = sq.d[p]; // the vertex: origin of the shadow ray and of the continuation ray
         ro = xyz(o);
         rd = xyz(d);
-        tmin = o.w;
+        tmin = rp_geometry_scale_to_tmin(ro, o.w);
         tmax = d.w;
         return true;
     };
@@ -532,7 +536,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
                     if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM))
-                        rng.s = __float_as_uint(rp_ld2<SH>(ps.rng_tt, p).x); // alpha tests of the first extend may have drawn from it
+                        rng.s = rp_ld1<SH>(reinterpret_cast<const uint32_t *>(ps.ray_d), 4u * p + 3u); // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
                         if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) {
@@ -553,9 +557,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     const float4 ro4 = rp_ld4<SH>(ps.ray_o, p), rd4 = rp_ld4<SH>(ps.ray_d, p);
                     const float4 thr4 = rp_ld4<SH>(ps.thr, p);
                     const float4 il4 = rp_ld4<SH>(ps.illum, p);
-                    const float2 rt = rp_ld2<SH>(ps.rng_tt, p);
-                    rng = rp_rng_resume<TABLE>(f, p, __float_as_uint(rt.x));
-                    total_t = rt.y;
+                    rng = rp_rng_resume<TABLE>(f, p, __float_as_uint(rd4.w));
+                    total_t = ro4.w;
                     ray_origin = xyz(ro4);
                     ray_dir = xyz(rd4);
                     throughput = xyz(thr4);
@@ -749,8 +752,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         nee_l = nee_l * ((w * fabsf(dot3(light_dir, nn))) * bsdf);
                         const V3 c = scatter_throughput * nee_l;
                         if (needs_ray) {
-                            has_shadow = true;
-                            sq.o[p] = f4(ip_p, epsilon);
+                            has_shadow = true; // (its origin and offset: ray_o below -- ip_p and the path length the offset was computed from)
                             sq.d[p] = f4(light_dir, light_dist - epsilon);
                             sq.contrib[p] = f4(c, 0.0f);
                         } else
@@ -785,7 +787,6 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         if (TEX && dot3(w_i, nn) * dot3(w_o, nn) > -0.999f) tex_fp = rp_reflect_footprint(w_i, ray_dir, tex_fp);
                         ray_dir = w_i;
                         ray_origin = ip_p;
-                        const float t_min = rp_geometry_scale_to_tmin(ray_origin, total_t);
                         // :713-730 Russian roulette
                         bool survive = true;
                         if (bounce >= f.rp.rr_path_depth) {
@@ -800,14 +801,15 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         }
                         if (survive) {
                             alive = true;
-                            rp_st4<SH>(ps.ray_o, p, f4(ray_origin, t_min));
-                            rp_st4<SH>(ps.ray_d, p, f4(ray_dir, 1e20f));
+                            rp_st4<SH>(ps.ray_d, p, f4(ray_dir, __uint_as_float(rng.s)));
                             rp_st4<SH>(ps.thr, p, f4(throughput, prev_bounce_pdf));
-                            rp_st2<SH>(ps.rng_tt, p, make_float2(__uint_as_float(rng.s), total_t));
                             if (TEX) rp_st4<SH>(ps.footprint, p, make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y));
                         }
                     }
                 }
+                // the vertex (ip_p: a surviving path's ray_origin is ip_p) and the path length up to it: what the shadow ray and the continuation
+                // ray start from (their offset = rp_geometry_scale_to_tmin of the two, recomputed by connect / extend)
+                if (alive || has_shadow) rp_st4<SH>(ps.ray_o, p, f4(ip_p, total_t));
                 rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
             }
             if (STREAM) {
@@ -1318,8 +1320,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_stream_trace(RpScene sc, RpFrame f, RpPa
             const float4 o4 = rp_ld4<true>(ps.ray_o, my_p), d4 = rp_ld4<true>(ps.ray_d, my_p);
             ro = xyz(o4);
             rd = xyz(d4);
-            tmin = o4.w;
-            tmax = d4.w;
+            tmin = rp_geometry_scale_to_tmin(ro, o4.w);
+            tmax = 1e20f;
         }
         return true;
     };
@@ -1336,10 +1338,10 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_stream_trace(RpScene sc, RpFrame f, RpPa
             my_p = e & RP_ITEM_PATH;
             my_flags = e & (RP_ITEM_CONT | RP_ITEM_SHADOW);
             if (my_flags & RP_ITEM_SHADOW) {
-                const float4 o4 = rp_ld4<true>(sq.o, my_p), d4 = rp_ld4<true>(sq.d, my_p);
+                const float4 o4 = rp_ld4<true>(ps.ray_o, my_p), d4 = rp_ld4<true>(sq.d, my_p);
                 ro = xyz(o4);
                 rd = xyz(d4);
-                tmin = o4.w;
+                tmin = rp_geometry_scale_to_tmin(ro, o4.w);
                 tmax = d4.w;
                 anyq = true;
                 return true;

@@ -227,6 +227,7 @@ struct rptr_hip {
     RptrRenderRayQuery *rq_queries = nullptr;
     float4 *rq_results = nullptr;
     size_t rq_capacity = 0;
+    bool cams_general = getenv("RPTR_CAMS_GENERAL") && atoi(getenv("RPTR_CAMS_GENERAL")) != 0; // A/B knob, see render: per-frame cameras through the general kernels
     bool lights_disabled = false;   // light_sampling_variant == LIGHT_SAMPLING_VARIANT_NONE: no area-light NEE (rptr_hip_set_light_sampling_variant)
     int frame_fine_grained = 0;     // RPTR_FRAME_FINE_GRAINED (measured: no effect; the release fences do the work): path state + queue ids of the frame kernel in fine-grained device memory
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
@@ -1485,7 +1486,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->tiles_y = (std::max(h->local_rows, 1) + 7) / 8;
     h->npix_padded = h->tiles_x * h->tiles_y * 64;
     // sample slots in flight: as many as fit a ~6 GiB path-state budget per frame context (288 GB of HBM), at most 16
-    const size_t bytes_per_path = 16 * 5 + 8 + 8 + 3 * 16 + 5 * 4;
+    const size_t bytes_per_path = 16 * 5 + 8 + 2 * 16 + 5 * 4;
     size_t budget = (size_t)6 << 30;
     if (const char *s = getenv("RPTR_PATH_BUDGET_MB")) budget = (size_t)atoll(s) << 20;
     int mb = (int)std::min<size_t>(16, std::max<size_t>(1, budget / (bytes_per_path * (size_t)h->npix_padded)));
@@ -1504,14 +1505,12 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         if ((rc = dev_alloc(h, &c.ps.ray_d, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.thr, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.illum, cap, nullptr))) return rc;
-        if ((rc = dev_alloc(h, &c.ps.rng_tt, cap, nullptr))) return rc;
         c.ps.alpha_rng = nullptr;
         if (h->rng_variant != RPTR_RNG_VARIANT_UNIFORM && (rc = dev_alloc(h, &c.ps.alpha_rng, cap, nullptr))) return rc;
         c.ps.footprint = nullptr; // scenes with textures: set_scene allocates it; a scene set before this call keeps its flags
         if ((h->uses_textures || h->uses_alpha) && (rc = dev_alloc(h, &c.ps.footprint, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_tuv, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.hit_ids, cap, nullptr))) return rc;
-        if ((rc = dev_alloc(h, &c.sq.o, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.sq.d, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.sq.contrib, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.sq.ids, cap, nullptr))) return rc;
@@ -2433,7 +2432,6 @@ static int ensure_frame_queues(rptr_hip *h, FrameCtx &c, int grid_blocks) {
             if ((rc = dev_alloc(h, &c.ps_fk.ray_d, cap, nullptr, true))) return rc;
             if ((rc = dev_alloc(h, &c.ps_fk.thr, cap, nullptr, true))) return rc;
             if ((rc = dev_alloc(h, &c.ps_fk.illum, cap, nullptr, true))) return rc;
-            if ((rc = dev_alloc(h, &c.ps_fk.rng_tt, cap, nullptr, true))) return rc;
             c.ps_fk.alpha_rng = nullptr; // (made below when the handle has them: set_scene / set_rng_variant may add them later)
             c.ps_fk.footprint = nullptr;
         }
@@ -2504,7 +2502,7 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &s
     const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
     rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures,
-                    f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0 || (bounce == 0 && f.per_frame_cams != 0), scene, f, c.ps, c.sq, order,
+                    f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0 || (bounce == 0 && f.per_frame_cams != 0 && h->cams_general), scene, f, c.ps, c.sq, order,
                     (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
                     &c.counters->bounce[bounce].shadow_count, c.counters);
 }
@@ -2835,7 +2833,9 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     };
     // the general instantiation of the path stages: a table point set, or a screen jitter (raster TAA) -- the shipped path carries neither
     const bool table_rng_later = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
-    const bool table_rng = table_rng_later || per_frame_cameras; // (the launches that make camera rays: the first bounce, the one-launch frame)
+    // (RPTR_CAMS_GENERAL=1, an A/B knob: frames with cameras of their own go through the general instantiation of the launches that make
+    // camera rays, as they did when the feature went in)
+    const bool table_rng = table_rng_later || (per_frame_cameras && h->cams_general);
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];

@@ -91,12 +91,14 @@ class NativeGather:
         uid = exchange_unique_id(RenderHip.comm_unique_id, rank, world)
         renderer.comm_init_rank(uid)
 
-    def gather(self):
-        self.r.gather()
+    def gather(self, n_frames=1):
+        """n_frames > 1: one collective for the frames of the launch sequence whose last ticket was just waited for"""
+        self.r.gather(n_frames)
 
-    def frame(self, out):
-        """rank 0: waits for the last gather and copies the assembled frame into `out` (float32, height x width x 4)"""
-        return self.r.readback_gathered(out)
+    def frame(self, out, index=None):
+        """rank 0: waits for the last gather and copies the assembled frame (frame `index` of a batched gather; default its last)
+        into `out` (float32, height x width x 4)"""
+        return self.r.readback_gathered(out, index)
 
     def stats(self):
         return self.r.comm_stats()

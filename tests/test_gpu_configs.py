@@ -217,12 +217,15 @@ def test_readback_after_resubmitting_on_the_same_context_is_an_error():
 
 
 # ---------------------------------------------------------------- the library's own gather (csrc/host_comm.h)
+@pytest.mark.parametrize("transport", ["copy", "peer"])
 @pytest.mark.parametrize("world,fif,stripe_rows", [(2, 1, 32), (3, 3, 8), (8, 2, 8)])
-def test_gather_all_of_n_handles_on_one_device_is_bit_identical_to_one_rank(world, fif, stripe_rows):
+def test_gather_all_of_n_handles_on_one_device_is_bit_identical_to_one_rank(world, fif, stripe_rows, transport, monkeypatch):
     """one process, `world` handles (all on device 0: the rows travel by device copies, the transport of rigs whose ranks share a
-    device; stream / event structure and the assembly kernel are those of the RCCL transport): a sequence of frames, every rank
-    rendering its stripes with `fif` frames in flight, gathered by rptr_hip_gather_all -> the assembled frames equal the frames of
-    ONE rank rendering everything, bit for bit, frame by frame"""
+    device; stream / event structure and the assembly kernel are those of the RCCL transport -- or, transport "peer", every rank
+    writes its rows straight into rank 0's frame from a kernel of its own, no receive buffer and no assembly pass): a sequence of
+    frames, every rank rendering its stripes with `fif` frames in flight, gathered by rptr_hip_gather_all -> the assembled frames
+    equal the frames of ONE rank rendering everything, bit for bit, frame by frame"""
+    monkeypatch.setenv("RPTR_COMM_TRANSPORT", transport)
     s = scenes.grid(120, 60, with_emitters=True)
     W, H, spp, n_frames = 200, 120, 2, 5
     cam = s.camera_params()
@@ -247,7 +250,9 @@ def test_gather_all_of_n_handles_on_one_device_is_bit_identical_to_one_rank(worl
         r.set_scene(s)
     with pytest.raises(backend.BackendError):
         rs[0].gather()                                   # no communicator yet
+    assert rs[0].comm_transport() is None
     backend.RenderHip.comm_init_all(rs)
+    assert all(r.comm_transport() == transport for r in rs)
     with pytest.raises(backend.BackendError):
         rs[0].gather()                                   # member of a one-process group: gather_all
     got, queue = [], []
@@ -506,9 +511,87 @@ def test_batch_limits_and_gather_of_batched_frames():
         r.close()
 
 
-def test_gather_all_when_some_ranks_own_no_rows():
+@pytest.mark.parametrize("transport", ["copy", "peer", "rccl-self"])
+def test_one_gather_for_the_frames_of_a_launch_sequence(transport, monkeypatch):
+    """rptr_hip_gather_batch / _gather_all_batch: the frames of a launch sequence travel in ONE collective (one transfer per rank, one
+    assembly pass) after the sequence's last ticket was waited for -- image k of the gather equals frame k rendered by one rank, bit
+    for bit; a gather of the last two frames only; the limits (more frames than the sequence has, than a sequence can have, a batch
+    before the last frame was waited for). Transports: the one-process group's device copies and peer writes (three ranks on this
+    device), and RCCL through the self-send of world 1."""
+    s = scenes.grid(80, 40, with_emitters=True)
+    W, H, spp = 96, 64, 2
+    cam = s.camera_params()
+
+    def cfg():
+        return backend.RenderConfiguration(cam, active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+    one = backend.RenderHip(frames_in_flight=1)
+    one.initialize(W, H)
+    one.set_scene(s)
+    want = []
+    for k in range(8):
+        one.render(cfg(), spp=spp)
+        img = np.zeros((H, W, 4), np.float32)
+        one.readback_framebuffer(img)
+        want.append(img)
+    one.close()
+    if transport == "rccl-self":
+        monkeypatch.setenv("RPTR_COMM_SELF", "1")
+        rs = [backend.RenderHip(frames_in_flight=2)]
+    else:
+        monkeypatch.setenv("RPTR_COMM_TRANSPORT", transport)
+        rs = [backend.RenderHip(rank=k, world_size=3, stripe_rows=8, frames_in_flight=2) for k in range(3)]
+    for r in rs:
+        r.initialize(W, H)
+        r.set_scene(s)
+    if transport == "rccl-self":
+        rs[0].comm_init_rank(backend.RenderHip.comm_unique_id())
+
+        def gather(n):
+            rs[0].gather(n)
+    else:
+        backend.RenderHip.comm_init_all(rs)
+
+        def gather(n):
+            backend.RenderHip.gather_all(rs, n)
+    got = np.zeros((H, W, 4), np.float32)
+    # sequence 1: four frames, one gather
+    tickets = [r.render_batch_async(cfg(), spp=spp, n_frames=4) for r in rs]
+    for r, t in zip(rs, tickets):
+        r.wait(t[1])
+    with pytest.raises(backend.BackendError):
+        gather(4)                                  # frame 1 of the sequence was waited for last: frames 0..1 are all a gather can take
+    for r, t in zip(rs, tickets):
+        r.wait(t[3])
+    with pytest.raises(backend.BackendError):
+        gather(5)                                  # more than a launch sequence holds
+    gather(4)
+    for k in range(4):
+        assert rs[0].readback_gathered(got, k) == W * H * 4
+        assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), k
+    rs[0].readback_gathered(got)                   # the default: the last frame of the gather
+    assert np.array_equal(got.view(np.uint32), want[3].view(np.uint32))
+    with pytest.raises(backend.BackendError):
+        rs[0].readback_gathered(got, 4)
+    # sequence 2 (the other frame context, the other slot on rank 0): the last two of its four frames only
+    tickets = [r.render_batch_async(cfg(), spp=spp, n_frames=4) for r in rs]
+    for r, t in zip(rs, tickets):
+        r.wait(t[3])
+    gather(2)
+    for k in range(2):
+        rs[0].readback_gathered(got, k)
+        assert np.array_equal(got.view(np.uint32), want[6 + k].view(np.uint32)), k
+    with pytest.raises(backend.BackendError):
+        rs[0].readback_gathered(got, 2)
+    assert rs[0].comm_stats()[0] == 2
+    for r in rs:
+        r.close()
+
+
+@pytest.mark.parametrize("transport", ["copy", "peer"])
+def test_gather_all_when_some_ranks_own_no_rows(transport, monkeypatch):
     """a frame of 20 rows in stripes of 8 has three stripes: of five ranks, two own nothing. They still take part in every gather (zero
     rows), render (nothing) and report frames; the assembled frame is the one-rank frame"""
+    monkeypatch.setenv("RPTR_COMM_TRANSPORT", transport)
     s = scenes.cornell32()
     W, H, spp, world = 64, 20, 2, 5
     cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
