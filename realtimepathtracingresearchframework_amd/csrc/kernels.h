@@ -852,8 +852,18 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
         n_shadow = s_ns;
     }
 }
+// The Lambert instantiation without lights, textures or tables (C2, C4, C5) needs 97-105 VGPRs: just above the 96 that let a SIMD hold
+// five waves instead of four. Its later-bounce launches wait on dependent loads 70-80 % of their wave-cycles (hit -> instance -> geometry
+// -> vertices -> material; profiles/pmc_traffic.json wait_any_frac), so the fifth wave pays: compiled for five the two kernels fit 96
+// VGPRs without scratch; A/B on one box (tools/ab.sh, build variants): shade launches 0.439 -> 0.425 ms per C2 frame, the pipelined
+// frame 1.32 -> 1.30 ms, C5 3.20 -> 3.15, C4 unchanged. -DRP_SHADE_WAVES_LEAN=4: the old bound.
+#ifndef RP_SHADE_WAVES_LEAN
+#define RP_SHADE_WAVES_LEAN 5
+#endif
+template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
+constexpr int rp_shade_waves() { return (VARIANT == RPTR_VARIANT_SIMPLE && !LIGHTS && !TEX && !TABLE) ? RP_SHADE_WAVES_LEAN : RP_SHADE_WAVES; }
 template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool TABLE>
-__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
+__global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>())) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
     uint32_t *ln = nullptr, *ls = nullptr;

@@ -77,8 +77,10 @@ public:
         return total;
     }
     // The pipelined schedule (what bench.py measures): a launch sequence of `n_frames` frames is queued on every GPU and collected later,
-    // while others are in flight (the group's frames_in_flight contexts). collect() waits for the sequence's frames in order, gathers each
-    // to rank 0 and returns one RenderStats per frame (render_time: the slowest rank's share of the sequence).
+    // while others are in flight (the group's frames_in_flight contexts). collect() waits for the sequence's frames in order, gathers them
+    // to rank 0 in ONE collective (rptr_hip_gather_all_batch: the frames of a sequence finish together and lie behind each other in every
+    // rank's images; per_frame_gather = true: one collective per frame, as rounds 2-3 did) and returns one RenderStats per frame
+    // (render_time: the slowest rank's share of the sequence). readback_framebuffer(.., frame) then reads frame k of that sequence.
     struct Sequence {
         std::vector<std::vector<uint64_t>> tickets; // [rank][frame]
         int frames = 0;
@@ -89,7 +91,7 @@ public:
         for (auto &r : ranks_) q.tickets.push_back(n_frames > 1 ? r->render_batch_async(config, spp, n_frames, reset_rest) : std::vector<uint64_t>{r->render_async(config, spp)});
         return q;
     }
-    std::vector<RenderStats> collect(const Sequence &q) {
+    std::vector<RenderStats> collect(const Sequence &q, bool per_frame_gather = false) {
         std::vector<RenderStats> out;
         for (int k = 0; k < q.frames; ++k) {
             RenderStats total{};
@@ -101,14 +103,23 @@ public:
                 total.spp = s.spp;
                 total.total_device_bytes_allocated += s.total_device_bytes_allocated;
             }
-            if (size() > 1) {
+            if (size() > 1 && (per_frame_gather || k == q.frames - 1)) {
                 std::vector<rptr_hip_t *> hs;
                 for (auto &r : ranks_) hs.push_back(r->handle());
-                if (rptr_hip_gather_all(hs.data(), size()) != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_gather_all: ") + last_error());
+                if (rptr_hip_gather_all_batch(hs.data(), size(), per_frame_gather ? 1 : q.frames) != RPTR_OK)
+                    throw std::runtime_error(std::string("rptr_hip_gather_all_batch: ") + last_error());
             }
             out.push_back(total);
         }
         return out;
+    }
+    // frame k (0 = the oldest) of the sequence collected last, assembled on rank 0
+    size_t readback_framebuffer(size_t buffer_size, float *buffer, int frame) {
+        if (size() == 1) return 0; // (one rank: the frames of a sequence are read through the rank's own tickets)
+        const size_t need = (size_t)width_ * height_ * 4;
+        if (buffer_size < need) return 0;
+        if (rptr_hip_readback_gathered_frame_f32(ranks_[0]->handle(), frame, buffer, buffer_size) != RPTR_OK) throw std::runtime_error(std::string("readback: ") + last_error());
+        return need;
     }
     double rays_traced() const { return rays_; }
     // the full frame (RGBA32F accumulation buffer) on the host: rank 0's assembled frame
