@@ -333,6 +333,14 @@ def main():
     # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
     batch_frames = args.batch_frames if args.batch_frames > 0 else (1 if args.animate else max(1, min(4, 16 // max(spp, 1))))
+    # small frames (a rank of a >= 4-way split): launch sequences of EIGHT frames (32 sample slots in flight instead of 16; RPTR_MAX_BATCH_SPP /
+    # RPTR_MAX_BATCH_FRAMES are read when the handle is created) -- measured on rank 0's share of an 8-way / 4-way split: 0.193 -> 0.173 /
+    # 0.343 -> 0.330 ms per frame (profiles/r04_notes.md section 6); a full frame gains nothing from it
+    ranks_of_split = world if world > 1 else args.emulate_world
+    if args.batch_frames <= 0 and not args.animate and ranks_of_split >= 4 and "RPTR_MAX_BATCH_FRAMES" not in os.environ and "RPTR_MAX_BATCH_SPP" not in os.environ:
+        batch_frames = max(1, min(8, 32 // max(spp, 1)))
+        os.environ["RPTR_MAX_BATCH_FRAMES"] = str(batch_frames)
+        os.environ["RPTR_MAX_BATCH_SPP"] = str(batch_frames * spp)
     # no more contexts than the timed region has launch sequences for: the line names the schedule that ran (20 steps in sequences of 4
     # frames are 5 sequences, not 11)
     # BENCH_BATCH_PATTERN=a,b,c,... (experiment): the lengths of the timed region's first launch sequences (then `batch_frames` each)

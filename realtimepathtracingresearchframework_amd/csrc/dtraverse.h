@@ -39,6 +39,17 @@
 #define RP_TRAVERSE_WAVES 5
 #endif
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
+// the shadow-ray kernels carry less per lane (no hit record to keep): compiled for six waves per SIMD they fit 80 VGPRs with 12 bytes of
+// scratch and a launch that has the GPU to itself runs six blocks per CU (6 x 24 KB of LDS stacks). Measured (tools/ab.sh, build variants,
+// one box; profiles/r04_notes.md section 8): connect launches -4 % on C2, -5 % on C4; the closest-hit kernels at six waves lose 1.5 % on C2.
+#ifndef RP_CONNECT_WAVES
+#define RP_CONNECT_WAVES 6
+#endif
+// ... and the closest-hit launches of the later bounces (no camera-ray set-up in the refill): an experiment knob (default: as the first bounce)
+#ifndef RP_EXTEND_LATER_WAVES
+#define RP_EXTEND_LATER_WAVES RP_TRAVERSE_WAVES
+#endif
+#define RP_CONNECT_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_CONNECT_WAVES)
 // the node phase ends early when fewer than RP_NODE_MIN lanes are still at inner nodes and some lane waits with a leaf
 #ifndef RP_NODE_MIN
 #define RP_NODE_MIN 10

@@ -281,7 +281,7 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     }
 }
 template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool TABLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK, (FIRST ? RP_TRAVERSE_WAVES : RP_EXTEND_LATER_WAVES)) void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
     rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false, TABLE>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
 }
@@ -344,7 +344,7 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
     }
 }
 template <bool COUNT, bool ALPHA, bool SINGLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+__global__ RP_CONNECT_BOUNDS void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     rp_connect_body<COUNT, ALPHA, SINGLE, false>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
 }
 template <int LDSTOP>

@@ -3,12 +3,12 @@ TAG=${1:-r03m}; O=gpurun_out/$TAG; mkdir -p $O
 timeout 2700 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1; tail -4 $O/gpu_suite.log
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_default_steps20.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 > $O/bench_c3.json 2>/dev/null
+python3 bench.py --lights --variant gltf --spp 8 > $O/bench_c3.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --lights --variant gltf --spp 8 --flatten 0 > $O/bench_c3_two_level.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4.json 2>/dev/null
+python3 bench.py --scene forest > $O/bench_c4.json 2>/dev/null
 RPTR_BVH_BUILDER=host python3 bench.py --no-cpu-baseline --scene forest > $O/bench_c4_host_built_tree.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_level.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --animate --width 3840 --height 2160 --spp 2 > $O/bench_c5.json 2>/dev/null
+python3 bench.py --animate --width 3840 --height 2160 --spp 2 > $O/bench_c5.json 2>/dev/null
 for n in 2 4 8; do python3 bench.py --no-cpu-baseline --emulate-world $n > $O/bench_emulated_world$n.json 2>/dev/null; done
 python3 bench.py --gpus 2 --same-device --steps 40 --no-cpu-baseline > $O/bench_gpus2_same_device.json 2> $O/bench_gpus2_same_device.err
 bash tools/prof.sh ${TAG}_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1
