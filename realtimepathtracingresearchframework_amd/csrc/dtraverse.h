@@ -41,7 +41,8 @@
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
 // the shadow-ray kernels carry less per lane (no hit record to keep): compiled for six waves per SIMD they fit 80 VGPRs with 12 bytes of
 // scratch and a launch that has the GPU to itself runs six blocks per CU (6 x 24 KB of LDS stacks). Measured (tools/ab.sh, build variants,
-// one box; profiles/r04_notes.md section 8): connect launches -4 % on C2, -5 % on C4; the closest-hit kernels at six waves lose 1.5 % on C2.
+// one box; profiles/r04_notes.md section 5): connect launches -4 % on C2, -6 % on C4; the closest-hit kernels at six waves lose 1.5 % on C2.
+// Only the instantiations for scenes with one instance record get it (kernels.h rp_k_connect): the two-level walk spills 72-80 bytes at 80 VGPRs.
 #ifndef RP_CONNECT_WAVES
 #define RP_CONNECT_WAVES 6
 #endif

@@ -54,8 +54,9 @@ hipError_t rp_stream_trace_blocks_per_cu(int *out) {
 hipError_t rp_extend_blocks_per_cu(int *out) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_extend<false, true, false, false, false>, RP_TRAVERSE_BLOCK, 0);
 }
-hipError_t rp_connect_blocks_per_cu(int *out) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_connect<false, false, false>, RP_TRAVERSE_BLOCK, 0);
+hipError_t rp_connect_blocks_per_cu(int single, int *out) {
+    return single ? hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_connect<false, false, true>, RP_TRAVERSE_BLOCK, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_connect<false, false, false>, RP_TRAVERSE_BLOCK, 0);
 }
 hipError_t rp_extend_later_blocks_per_cu(int *out) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_extend<false, false, false, false, false>, RP_TRAVERSE_BLOCK, 0);

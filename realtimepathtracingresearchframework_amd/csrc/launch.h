@@ -34,7 +34,7 @@ void rp_launch_extend(const RpLaunch &l, bool count, bool first, bool alpha, boo
 void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
                        RpBounceCounters *bc, RpCounters *ctr, int *gstack);
 hipError_t rp_extend_blocks_per_cu(int *out);
-hipError_t rp_connect_blocks_per_cu(int *out);
+hipError_t rp_connect_blocks_per_cu(int single, int *out);
 hipError_t rp_extend_later_blocks_per_cu(int *out);
 // the tracer of the streaming frame (kernels.h rp_k_stream_trace)
 void rp_launch_stream_trace(const RpLaunch &l, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,

@@ -240,7 +240,7 @@ struct rptr_hip {
     size_t path_capacity = 0;
     int persistent_blocks = 0;
     int extend_later_blocks = 0;     // grid of a closest-hit launch of bounce >= 1 (RP_EXTEND_LATER_WAVES)
-    int connect_blocks = 0;          // grid of a stand-alone shadow-ray launch (>= persistent_blocks: RP_CONNECT_WAVES)
+    int connect_blocks[2] = {0, 0};  // grid of a stand-alone shadow-ray launch, [single instance record ? 1 : 0] (RP_CONNECT_WAVES)
 
     // options (environment, read once)
     int side_connect = 0; // connect(b) on a side stream next to extend(b+1): the default for handles with ONE frame context (RPTR_SIDE_CONNECT=0|1 overrides)
@@ -1555,12 +1555,14 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->persistent_blocks = h->num_cus * occ;
     // the shadow-ray kernels may be compiled for more waves per SIMD than the closest-hit kernels (RP_CONNECT_WAVES): their launches get the
     // blocks THEY can have resident (the same cap with frames in flight)
-    int occ_c = 0;
-    HIP_TRY(h, rp_connect_blocks_per_cu(&occ_c));
-    occ_c = std::max(1, std::min(occ_c, 8));
-    if (h->ctx.size() > 1) occ_c = std::max(1, std::min(occ_c, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
-    if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ_c = std::max(1, atoi(s));
-    h->connect_blocks = h->num_cus * std::max(occ, occ_c);
+    for (int sg = 0; sg < 2; ++sg) { // [0]: two-level scenes, [1]: scenes with one instance record (the instantiation compiled for six waves)
+        int occ_c = 0;
+        HIP_TRY(h, rp_connect_blocks_per_cu(sg, &occ_c));
+        occ_c = std::max(1, std::min(occ_c, 8));
+        if (h->ctx.size() > 1) occ_c = std::max(1, std::min(occ_c, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
+        if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ_c = std::max(1, atoi(s));
+        h->connect_blocks[sg] = h->num_cus * occ_c;
+    }
     int occ_l = 0;
     HIP_TRY(h, rp_extend_later_blocks_per_cu(&occ_l));
     occ_l = std::max(1, std::min(occ_l, 8));
@@ -1568,7 +1570,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ_l = std::max(1, atoi(s));
     h->extend_later_blocks = h->num_cus * occ_l;
     h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
-    const size_t stack_threads = (size_t)std::max(std::max(h->persistent_blocks, h->extend_later_blocks), h->connect_blocks) * RP_TRAVERSE_BLOCK;
+    const size_t stack_threads = (size_t)std::max(std::max(h->persistent_blocks, h->extend_later_blocks), std::max(h->connect_blocks[0], h->connect_blocks[1])) * RP_TRAVERSE_BLOCK;
     for (FrameCtx &c : h->ctx) {
         c.gstack_threads = stack_threads;
         if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
@@ -3010,7 +3012,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
                         HIP_TRY(h, hipEventRecord(c.ev_fork, c.stream));
                         HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
                     }
-                    rp_launch_connect(timed_launch(cs, 1, (unsigned)h->connect_blocks), count_traversal, h->uses_alpha, single, scn.dscene, f, c.ps, c.sq, bc, c.counters,
+                    rp_launch_connect(timed_launch(cs, 1, (unsigned)h->connect_blocks[single ? 1 : 0]), count_traversal, h->uses_alpha, single, scn.dscene, f, c.ps, c.sq, bc, c.counters,
                                       stack);
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }
