@@ -83,7 +83,7 @@ def parse_args():
                          "stripes split 17/16 over 8 ranks, 32-row stripes 5/4")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="diagnostic (single GPU): render only rank 0's stripes of an N-rank tile split, no gather")
-    ap.add_argument("--gather", type=str, default="native", choices=["native", "torch"],
+    ap.add_argument("--gather", type=str, default="native", choices=["native", "torch", "ipc"],
                     help="native: the library's RCCL gather (csrc/host_comm.h; falls back to torch when the communicator cannot be made, "
                          "noted in the JSON line); torch: tile copy + torch.distributed.gather + index_select")
     ap.add_argument("--dist-backend", type=str, default="nccl", choices=["nccl", "gloo"],
@@ -408,18 +408,20 @@ def main():
     gather_mode, gather_note, native, tgather, stage, nccl_group = None, None, None, None, None, None
     if world > 1:
         gather_mode = "native" if (args.gather == "native" and not on_host and probe["native"]) else ("host" if on_host else "torch")
+        if args.gather == "ipc":   # opt-in: peer writes through hipIpc-mapped frame buffers (no RCCL involved: works with ranks that share a device)
+            gather_mode = "native"
         if probe is not None and probe["note"] and gather_mode != "native":
             gather_note = "RCCL probe: %s -> %s" % (probe["note"], {"torch": "torch.distributed gather over nccl", "host": "gather over gloo, tiles staged through the host"}[gather_mode])
         if gather_mode == "native":
             ok = 1
             try:
-                native = NativeGather(r, rank, world)
+                native = NativeGather(r, rank, world, transport="ipc" if args.gather == "ipc" else "rccl")
             except Exception as e:  # every rank must take the same path: agree on it
                 ok, gather_note = 0, "native RCCL communicator failed (%s): torch.distributed gather used instead" % (str(e)[:200],)
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag[0]) == 0:
-                gather_mode, native = "torch", None
+                gather_mode, native = ("host" if on_host else "torch"), None
                 gather_note = gather_note or "native RCCL communicator failed on another rank: torch.distributed gather used instead"
                 try:
                     r.comm_destroy()
@@ -884,7 +886,8 @@ def main():
         "roofline": roofline,
     }
     if world > 1:
-        out["gather"] = {"mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h)",
+        out["gather"] = {"transport": (r.comm_transport() if native is not None else None),
+                         "mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h); --gather ipc: every rank writes its rows into rank 0's frame through hipIpc-mapped memory",
                                   "torch": "tile copy + torch.distributed.gather (nccl group) + index_select",
                                   "host": "tile copy + torch.distributed.gather (gloo, tiles staged through the host) + index_select"}[gather_mode],
                          "probe": probe,

@@ -498,6 +498,15 @@ int rptr_hip_readback_gathered_frame_f32(rptr_hip_t *h, int index, float *rgba, 
 /* gathers issued so far, and the mean GPU time of the completed ones on this rank's communication stream (send / receive + assembly) */
 int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_gather_ms);
 const char *rptr_hip_comm_transport(rptr_hip_t *h);
+/* Peer writes for ONE PROCESS PER GPU (opt-in; csrc/host_comm.h COMM_IPC): rank 0 calls rptr_hip_comm_ipc_export (which makes its
+ * communicator and writes RPTR_COMM_IPC_BYTES describing its frame buffers: hipIpcGetMemHandle), the bytes reach every rank through any side
+ * channel, every rank calls rptr_hip_comm_ipc_init(h, bytes) (rank 0 too: a check). rptr_hip_gather / _gather_batch then scatter every
+ * rank's rows straight into rank 0's frame from a kernel on the rank's own communication stream -- no RCCL, no receive buffer, no
+ * assembly pass; the ordering between the processes is carried by counters in a flag block of rank 0 (events do not cross processes).
+ * Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only supports dmabuf IPC. rptr_hip_comm_transport says "ipc". */
+#define RPTR_COMM_IPC_BYTES 256
+int rptr_hip_comm_ipc_export(rptr_hip_t *h, void *out_bytes);
+int rptr_hip_comm_ipc_init(rptr_hip_t *h, const void *bytes);
 
 /* ---- enable_ray_queries / render_ray_queries with the RQ_CLOSEST kernel
  * (render_backend.h:101-102, vulkan/rt_intersect.comp:31-68): n queries ->

@@ -105,6 +105,8 @@ def load_library(path=None):
     L.rptr_hip_readback_gathered_f32.argtypes = [vp, vp, C.c_size_t]
     L.rptr_hip_comm_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     L.rptr_hip_comm_transport.argtypes = [vp]
+    L.rptr_hip_comm_ipc_export.argtypes = [vp, vp]
+    L.rptr_hip_comm_ipc_init.argtypes = [vp, vp]
     L.rptr_hip_comm_transport.restype = C.c_char_p
     for name in abi.EXPORTED_SYMBOLS:
         getattr(L, name)  # AttributeError if the library lacks a declared symbol
@@ -472,6 +474,17 @@ class RenderHip:
         """collective over all ranks of the job (one process per GPU): joins the communicator as RptrCreateInfo.rank"""
         assert len(unique_id) == abi.COMM_ID_BYTES
         self._check(self._L.rptr_hip_comm_init_rank(self._h, C.c_char_p(unique_id)))
+
+    def comm_ipc_export(self):
+        """rank 0 of a one-process-per-GPU job: makes the peer-write (IPC) communicator and returns the bytes every rank hands to
+        comm_ipc_init (hipIpcGetMemHandle of rank 0's frame buffers and flag block)"""
+        buf = C.create_string_buffer(abi.COMM_IPC_BYTES)
+        self._check(self._L.rptr_hip_comm_ipc_export(self._h, buf))
+        return buf.raw
+
+    def comm_ipc_init(self, blob: bytes):
+        assert len(blob) == abi.COMM_IPC_BYTES
+        self._check(self._L.rptr_hip_comm_ipc_init(self._h, C.c_char_p(blob)))
 
     @staticmethod
     def _handle_array(renderers):

@@ -69,7 +69,28 @@ RcclApi &rccl() {
     return api;
 }
 
-enum { COMM_RCCL = 0, COMM_COPY = 1, COMM_PEER = 2 };
+enum { COMM_RCCL = 0, COMM_COPY = 1, COMM_PEER = 2, COMM_IPC = 3 };
+
+// COMM_IPC: the peer-write transport for ONE PROCESS PER GPU (round 4, opt-in: rptr_hip_comm_ipc_export / _ipc_init). Rank 0 exports its two
+// assembled-frame buffers and a small flag block through hipIpcGetMemHandle; every other rank maps them (hipIpcOpenMemHandle) and, per gather,
+// scatters its rows straight into rank 0's frame from a kernel on its own communication stream -- no RCCL kernels on either side, no receive
+// buffer, no assembly pass. Events do not cross processes reliably (a wait issued before the other side's record sees an unrecorded
+// event), so the ordering is carried by monotone counters in the flag block (uncached device memory of rank 0):
+//   gate      written by rank 0's communication stream when it reaches gather g: everything rank 0 queued before (the gather that last
+//             used this slot, a read-back of it) is done -- the peers' writes of gather g wait for gate >= g (a one-lane kernel that polls);
+//   done[r]   written by rank r's communication stream behind its scatter kernel: rank 0's stream waits for done[r] >= g of every peer.
+// Every rank counts its gathers itself (a gather is a collective: the same sequence of calls on every rank).
+struct RptrIpcFlags {
+    uint32_t gate;
+    uint32_t _pad[15];
+    uint32_t done[240]; // one word per rank (world <= 240)
+};
+struct RptrIpcBlob { // what rptr_hip_comm_ipc_export hands to the other ranks (RPTR_COMM_IPC_BYTES)
+    hipIpcMemHandle_t frame[2], flags;
+    uint64_t npix;
+    int32_t max_batch, world;
+    uint32_t magic;
+};
 
 } // namespace
 
@@ -96,6 +117,10 @@ struct RptrComm {
     // one process, several handles: the peers (rank order) and, for peer copies, the events that tell rank 0 a peer's rows have landed
     std::vector<rptr_hip *> peers;
     hipEvent_t ev_copied = nullptr;
+    // COMM_IPC: rank 0 owns `ipc_flags`; the other ranks hold rank 0's buffers mapped into their address space
+    RptrIpcFlags *ipc_flags = nullptr;
+    float4 *ipc_frame[2] = {nullptr, nullptr};
+    bool ipc_mapped = false;          // (this rank opened the handles: close them on release)
     hipEvent_t ev_gate = nullptr;     // (rank 0, peer writes) what rank 0's communication stream held when a gather began: the peers' writes into the slot wait for it
     // statistics
     uint64_t gathers = 0, timed = 0;
@@ -129,6 +154,26 @@ __global__ __launch_bounds__(256) void rp_k_scatter_rows(float4 *frame, const fl
         const int s = lr / stripe_rows;
         const int y = (s * world + rank) * stripe_rows + (lr - s * stripe_rows);
         frame[k * ((size_t)width * height) + (size_t)y * width + x] = rows[j];
+    }
+}
+
+// COMM_IPC flag kernels (one lane each). The flag block is uncached device memory of rank 0; a peer reaches it through its IPC mapping.
+__global__ void rp_k_flag_set(uint32_t *flag, uint32_t value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (behind the kernels queued before it: stream order)
+}
+// waits until flags[i * stride] >= value for i = 0..n-1; gives up after ~10 s (a rank that died must not wedge the others' GPUs) and says so
+__global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_t value, uint32_t *timed_out) {
+    for (int i = 0; i < n; ++i) {
+        const uint32_t *f = flags + (size_t)i * stride;
+        const long long t0 = wall_clock64();
+        // (counters only grow; a signed difference keeps the compare right across a wrap after 2^31 gathers)
+        while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > 1000000000ll) { // 10 s of the 100 MHz counter
+                if (timed_out) atomicAdd(timed_out, 1u);
+                return;
+            }
+        }
     }
 }
 
@@ -191,7 +236,7 @@ int comm_setup_local(rptr_hip *h, int transport) {
         };
         int rc;
         for (int s = 0; s < 2; ++s) {
-            if ((rc = own((void **)&c->recv[s], (transport == COMM_PEER ? 0 : at) * sizeof(float4)))) return rc; // (peer writes land in the frame itself)
+            if ((rc = own((void **)&c->recv[s], ((transport == COMM_PEER || transport == COMM_IPC) ? 0 : at) * sizeof(float4)))) return rc; // (peer writes land in the frame itself)
             if ((rc = own((void **)&c->gathered[s], npix * (size_t)c->max_batch * sizeof(float4)))) return rc;
             HIP_TRY(h, hipMemset(c->gathered[s], 0, npix * (size_t)c->max_batch * sizeof(float4)));
             HIP_TRY(h, hipEventCreateWithFlags(&c->ev_slot[s], hipEventDisableTiming));
@@ -215,6 +260,11 @@ void comm_release(rptr_hip *h) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (void *p : {(void *)c->recv[0], (void *)c->recv[1], (void *)c->gathered[0], (void *)c->gathered[1], (void *)c->d_offsets})
         if (p) (void)hipFree(p);
+    if (c->ipc_mapped) {
+        for (void *p : {(void *)c->ipc_frame[0], (void *)c->ipc_frame[1], (void *)c->ipc_flags})
+            if (p) (void)hipIpcCloseMemHandle(p);
+    } else if (c->ipc_flags)
+        (void)hipFree(c->ipc_flags);
     h->bytes_frame -= std::min(h->bytes_frame, c->bytes_owned);
     h->bytes_allocated = h->bytes_scene + h->bytes_frame;
     for (FrameCtx &fc : h->ctx) fc.gather_pending = false;
@@ -275,7 +325,7 @@ int comm_end(rptr_hip *h, const float4 *src, FrameCtx *owner, int nb) {
     if (h->rank == 0) {
         const size_t npix = (size_t)h->width * h->height * (size_t)nb;
         const int slot = comm_slot(c);
-        if (c->transport != COMM_PEER) // (peer writes: every rank, this one included, has put its rows into the frame already)
+        if (c->transport != COMM_PEER && c->transport != COMM_IPC) // (peer writes: every rank, this one included, has put its rows into the frame already)
             hipLaunchKernelGGL(rp_k_assemble, dim3(grid_for(h, npix)), dim3(256), 0, c->stream, c->gathered[slot], src, c->recv[slot], c->d_offsets, h->width,
                                h->height, h->stripe_rows, h->world, c->self ? 1 : 0, nb);
         HIP_TRY(h, hipEventRecord(c->ev_slot[slot], c->stream));
@@ -391,6 +441,64 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
     return RPTR_OK;
 }
 
+int rptr_hip_comm_ipc_export(rptr_hip_t *h, void *out_bytes) {
+    static_assert(sizeof(RptrIpcBlob) <= RPTR_COMM_IPC_BYTES, "RPTR_COMM_IPC_BYTES");
+    if (!h || !out_bytes) return fail(h, RPTR_E_INVALID, "NULL argument");
+    if (h->rank != 0) return fail(h, RPTR_E_INVALID, "rank 0 exports its frame (this handle is rank %d)", h->rank);
+    if (h->world > 240) return fail(h, RPTR_E_UNSUPPORTED, "the IPC transport holds 240 ranks");
+    comm_release(h);
+    int rc = comm_setup_local(h, COMM_IPC);
+    if (rc) return rc;
+    RptrComm *c = h->comm;
+    // the flag block: uncached, so that rank 0's polls see what the peers store over the fabric (and the peers' polls what rank 0 stores)
+    hipError_t e = hipExtMallocWithFlags((void **)&c->ipc_flags, sizeof(RptrIpcFlags), hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags((void **)&c->ipc_flags, sizeof(RptrIpcFlags), hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipExtMallocWithFlags(flag block) failed: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemset(c->ipc_flags, 0, sizeof(RptrIpcFlags)));
+    HIP_TRY(h, hipDeviceSynchronize());
+    c->ipc_frame[0] = c->gathered[0];
+    c->ipc_frame[1] = c->gathered[1];
+    RptrIpcBlob blob;
+    memset(&blob, 0, sizeof(blob));
+    HIP_TRY(h, hipIpcGetMemHandle(&blob.frame[0], c->gathered[0]));
+    HIP_TRY(h, hipIpcGetMemHandle(&blob.frame[1], c->gathered[1]));
+    HIP_TRY(h, hipIpcGetMemHandle(&blob.flags, c->ipc_flags));
+    blob.npix = (uint64_t)h->width * h->height;
+    blob.max_batch = c->max_batch;
+    blob.world = h->world;
+    blob.magic = 0x52495043u; // "RIPC"
+    memset(out_bytes, 0, RPTR_COMM_IPC_BYTES);
+    memcpy(out_bytes, &blob, sizeof(blob));
+    return RPTR_OK;
+}
+
+int rptr_hip_comm_ipc_init(rptr_hip_t *h, const void *bytes) {
+    if (!h || !bytes) return fail(h, RPTR_E_INVALID, "NULL argument");
+    RptrIpcBlob blob;
+    memcpy(&blob, bytes, sizeof(blob));
+    if (blob.magic != 0x52495043u) return fail(h, RPTR_E_INVALID, "not a blob of rptr_hip_comm_ipc_export");
+    if (blob.world != h->world || blob.npix != (uint64_t)h->width * h->height)
+        return fail(h, RPTR_E_INVALID, "the exported frame (%llu pixels, %d ranks) does not match this handle (%d x %d, %d ranks)", (unsigned long long)blob.npix, blob.world,
+                    h->width, h->height, h->world);
+    if (h->rank == 0) { // rank 0 made everything in rptr_hip_comm_ipc_export
+        if (!h->comm || h->comm->transport != COMM_IPC) return fail(h, RPTR_E_INVALID, "rank 0: call rptr_hip_comm_ipc_export first");
+        return RPTR_OK;
+    }
+    comm_release(h);
+    int rc = comm_setup_local(h, COMM_IPC);
+    if (rc) return rc;
+    RptrComm *c = h->comm;
+    if (c->max_batch > blob.max_batch) c->max_batch = blob.max_batch; // (rank 0's frames hold that many images)
+    c->ipc_mapped = true;
+    HIP_TRY(h, hipIpcOpenMemHandle((void **)&c->ipc_frame[0], blob.frame[0], hipIpcMemLazyEnablePeerAccess));
+    HIP_TRY(h, hipIpcOpenMemHandle((void **)&c->ipc_frame[1], blob.frame[1], hipIpcMemLazyEnablePeerAccess));
+    HIP_TRY(h, hipIpcOpenMemHandle((void **)&c->ipc_flags, blob.flags, hipIpcMemLazyEnablePeerAccess));
+    return RPTR_OK;
+}
+
 int rptr_hip_comm_destroy(rptr_hip_t *h) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     comm_release(h);
@@ -406,6 +514,26 @@ int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames) {
     FrameCtx *owner = nullptr;
     int rc = comm_begin(h, src, owner, nb);
     if (rc) return rc;
+    if (h->comm->transport == COMM_IPC) {
+        RptrComm *c = h->comm;
+        if (!c->ipc_flags || !c->ipc_frame[0]) return fail(h, RPTR_E_INVALID, "rptr_hip_comm_ipc_init has not been called on this handle");
+        const uint32_t g = (uint32_t)(c->gathers + 1); // the same number on every rank: a gather is a collective
+        const int slot = comm_slot(c);
+        const int rows = local_row_count(h->height, h->stripe_rows, h->rank, h->world);
+        uint32_t *timed_out = &c->ipc_flags->_pad[0]; // (rank 0's block: a diagnostic counter shared by all ranks)
+        if (h->rank == 0) hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->gate, g);
+        else hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->gate, 1, 1, g, timed_out);
+        if (rows > 0)
+            hipLaunchKernelGGL(rp_k_scatter_rows, dim3(grid_for(h, (size_t)h->width * rows * nb)), dim3(256), 0, c->stream, c->ipc_frame[slot], src, h->width, h->height,
+                               rows, h->stripe_rows, h->world, h->rank, nb);
+        if (h->rank == 0) {
+            if (h->world > 1)
+                hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->done[1], h->world - 1, 1, g, timed_out);
+        } else
+            hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->done[h->rank], g);
+        HIP_TRY(h, hipGetLastError());
+        return comm_end(h, src, owner, nb);
+    }
     RcclApi &R = rccl();
     NCCL_TRY(h, R.GroupStart());
     rc = comm_post_rccl(h, src, nb);
@@ -533,7 +661,7 @@ int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_ga
 
 const char *rptr_hip_comm_transport(rptr_hip_t *h) {
     if (!h || !h->comm) return nullptr;
-    return h->comm->transport == COMM_RCCL ? "rccl" : h->comm->transport == COMM_COPY ? "copy" : "peer";
+    return h->comm->transport == COMM_RCCL ? "rccl" : h->comm->transport == COMM_COPY ? "copy" : h->comm->transport == COMM_PEER ? "peer" : "ipc";
 }
 
 } // extern "C"

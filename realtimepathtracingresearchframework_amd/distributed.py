@@ -85,11 +85,17 @@ class NativeGather:
     on rank 0. Python only hands the RCCL unique id around once; per frame it makes ONE ctypes call (`gather()`), which returns as
     soon as the work is queued -- with frames in flight the gather of frame i runs beside the rendering of frames i+1.. ."""
 
-    def __init__(self, renderer, rank, world):
+    def __init__(self, renderer, rank, world, transport="rccl"):
+        """transport "ipc": peer writes instead of RCCL -- rank 0 exports its frame buffers (hipIpcGetMemHandle), every rank maps them and
+        scatters its rows into rank 0's frame itself (csrc/host_comm.h COMM_IPC)"""
         from .backend import RenderHip
         self.r, self.rank, self.world = renderer, rank, world
-        uid = exchange_unique_id(RenderHip.comm_unique_id, rank, world)
-        renderer.comm_init_rank(uid)
+        if transport == "ipc":
+            blob = exchange_unique_id(renderer.comm_ipc_export, rank, world)
+            renderer.comm_ipc_init(blob)
+        else:
+            uid = exchange_unique_id(RenderHip.comm_unique_id, rank, world)
+            renderer.comm_init_rank(uid)
 
     def gather(self, n_frames=1):
         """n_frames > 1: one collective for the frames of the launch sequence whose last ticket was just waited for"""

@@ -503,6 +503,42 @@ def test_bench_n_ranks_dry_run_probes_rccl_and_falls_back_without_hanging():
     assert d["roofline"]["latency"]["1"]["ms_per_frame"] > 0
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_ipc_peer_write_gather_between_processes_is_bit_identical_to_one_rank(ranks):
+    """One process per rank (torch.distributed.run, both / all three on cuda:0 of this box), the library's peer-write transport for that
+    launch mode: rank 0 exports its frame buffers (hipIpcGetMemHandle), the other processes map them and scatter their rows into rank 0's
+    frame themselves, ordered by counters in rank 0's flag block -- single frames and launch sequences of four gathered in ONE
+    collective; every assembled frame equals the one-rank frame bit for bit (tools/ipc_gather_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port",
+           str(29720 + ranks), os.path.join(root, "tools", "ipc_gather_check.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "IPC_GATHER_OK 10 frames, gathers 4" in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
+def test_bench_n_ranks_with_the_ipc_gather_on_one_device():
+    """`bench.py --gpus 2 --gather ipc` with both ranks on cuda:0: the data plane stays on the device (RCCL cannot run there and the default
+    run falls back to tiles over gloo), one gather per launch sequence, the line names the transport"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--grid", "100x50", "--width", "320",
+           "--height", "180", "--same-device", "--probe-timeout", "120", "--gather", "ipc", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    g = d["gather"]
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0
+    assert g["transport"] == "ipc" and g["frames_per_gather"] == 4 and g["gathers"] == 2 and g["mode"].startswith("library")
+
+
 # ---------------------------------------------------------------- fuzz
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_fuzz_soups_trace_and_image(seed):

@@ -11,6 +11,7 @@ python3 bench.py --no-cpu-baseline --scene forest --flatten 0 > $O/bench_c4_two_
 python3 bench.py --animate --width 3840 --height 2160 --spp 2 > $O/bench_c5.json 2>/dev/null
 for n in 2 4 8; do python3 bench.py --no-cpu-baseline --emulate-world $n > $O/bench_emulated_world$n.json 2>/dev/null; done
 python3 bench.py --gpus 2 --same-device --steps 40 --no-cpu-baseline > $O/bench_gpus2_same_device.json 2> $O/bench_gpus2_same_device.err
+python3 bench.py --gpus 2 --same-device --steps 40 --no-cpu-baseline --gather ipc > $O/bench_gpus2_same_device_ipc_gather.json 2> $O/bench_gpus2_same_device_ipc_gather.err
 bash tools/prof.sh ${TAG}_pipelined --steps 200 > $O/prof_pipelined.txt 2>&1
 cp gpurun_out/prof_${TAG}_pipelined/*kernel_stats.csv $O/kernel_stats_pipelined_steps200.csv 2>/dev/null
 python3 - $O <<'PY'
