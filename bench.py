@@ -154,6 +154,26 @@ def rccl_probe_child(args):
         r.comm_stats()   # waits for this rank's send
     dist.barrier()
     print("PROBE native 1", flush=True)
+    # Stage 3, informational (nothing of the run depends on it): the peer-write transport for one process per GPU (--gather ipc) on THIS
+    # node's devices -- the same two frames on a fresh handle, gathered through hipIpc-mapped stores into rank 0's frame, must equal the frame
+    # RCCL just delivered, bit for bit. The line's gather.probe.ipc says whether remote stores over the node's fabric did that.
+    try:
+        r2 = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=8)
+        r2.initialize(64, 64)
+        r2.set_scene(s)
+        g2 = NativeGather(r2, rank, world, transport="ipc")
+        for _ in range(2):
+            r2.wait(r2.render_async(backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True), spp=1))
+            g2.gather()
+        if rank == 0:
+            img2 = np.zeros((64, 64, 4), np.float32)
+            g2.frame(img2)   # (waits for every peer's counter, or for the polls' own 10 s time-out)
+            print("PROBE ipc %d" % int(np.array_equal(img.view(np.uint32), img2.view(np.uint32))), flush=True)
+        else:
+            r2.comm_stats()  # this rank's stores have left
+        r2.close()
+    except Exception as e:  # noqa: BLE001 -- informational stage
+        print("PROBE ipc 0 (%s)" % (str(e)[:160],), flush=True)
     r.close()
     dist.destroy_process_group()
 
@@ -181,7 +201,8 @@ def run_rccl_probe(args, timeout_s, port_offset=1):
         except subprocess.TimeoutExpired:   # (a child stuck in the driver does not even die: leave it behind, its pipes unread)
             out, err = "", ""
         note = "probe timed out after %.0f s" % timeout_s
-    got = {"torch_nccl": int("PROBE torch_nccl 1" in out), "native": int("PROBE native 1" in out)}
+    got = {"torch_nccl": int("PROBE torch_nccl 1" in out), "native": int("PROBE native 1" in out),
+           "ipc": (1 if "PROBE ipc 1" in out else (0 if "PROBE ipc 0" in out else None))}   # (None: the stage was not reached; rank 0's finding)
     if not note and p.returncode != 0:
         tail = [l for l in err.strip().splitlines() if l.strip()]
         telling = [l for l in tail if any(w in l for w in ("Error", "error", "Duplicate", "failed", "refus", "invalid"))]   # (not a profiler's last words)
