@@ -167,7 +167,7 @@ def rccl_probe_child(args):
             g2.gather()
         if rank == 0:
             img2 = np.zeros((64, 64, 4), np.float32)
-            g2.frame(img2)   # (waits for every peer's counter, or for the polls' own 10 s time-out)
+            g2.frame(img2)   # (waits for every peer's counter, or for the polls' own 30 s time-out)
             print("PROBE ipc %d" % int(np.array_equal(img.view(np.uint32), img2.view(np.uint32))), flush=True)
         else:
             r2.comm_stats()  # this rank's stores have left

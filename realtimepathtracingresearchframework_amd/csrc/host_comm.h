@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void rp_k_scatter_rows(float4 *frame, const fl
 __global__ void rp_k_flag_set(uint32_t *flag, uint32_t value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (behind the kernels queued before it: stream order)
 }
-// waits until flags[i * stride] >= value for i = 0..n-1; gives up after ~10 s (a rank that died must not wedge the others' GPUs) and says so
+// waits until flags[i * stride] >= value for i = 0..n-1; gives up after ~30 s (a rank that died must not wedge the others' GPUs) and says so
 __global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_t value, uint32_t *timed_out) {
     for (int i = 0; i < n; ++i) {
         const uint32_t *f = flags + (size_t)i * stride;
@@ -169,7 +169,7 @@ __global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_
         // (counters only grow; a signed difference keeps the compare right across a wrap after 2^31 gathers)
         while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - value) < 0) {
             __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > 1000000000ll) { // 10 s of the 100 MHz counter
+            if (wall_clock64() - t0 > 3000000000ll) { // 30 s of the 100 MHz counter
                 if (timed_out) atomicAdd(timed_out, 1u);
                 return;
             }
