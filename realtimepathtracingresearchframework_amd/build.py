@@ -27,7 +27,13 @@ OBJ_DIR = os.path.join(CSRC, "obj")
 # -ffp-contract=off: fused multiply-adds only where the reference writes fma()
 # itself; keeps images bit-reproducible across launches/tilings and comparable
 # with the CPU oracle (DESIGN.md "Numerics").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize (round 4): left alone, the SLP vectoriser pairs the shading code's scalar float operations into v_pk_mul_f32 /
+# v_pk_add_f32 -- which issue at HALF rate on gfx950 (tools/microbench/valu_issue.hip: two flops per slot either way) -- and pays for
+# it with v_mov_b32 to pack and unpack their operands and with register pairs: glTF shade kernel 552 -> 326 moves, 438 -> 0 packed
+# operations, no scratch; closest-hit kernels 95 / 90 -> 77 / 76 VGPRs. Same IEEE operations on the same values (the explicitly packed
+# slab test of dtraverse.h is untouched: it uses vector types): images bit-identical. Pipelined frames -4...-6 % on every configuration
+# (profiles/r04_notes.md section 9).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc():

@@ -174,10 +174,10 @@ RP_DEV void rp_wave_trace_items(const RpScene &sc, int *gstack, Pool pool, Begin
             float ent[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                // (near, far) pairs: one packed fma per axis
-                const rp_f2 tx = __builtin_elementwise_fma(rp_mk2((float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu)), ax2, bx2);
-                const rp_f2 ty = __builtin_elementwise_fma(rp_mk2((float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu)), ay2, by2);
-                const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
+                // the same six fmas as scalars (identical values): v_pk_fma_f32 issues at half rate on gfx950, and its register pairs cost moves
+                const rp_f2 tx = rp_mk2(fmaf((float)((qnx >> (8 * k)) & 0xFFu), ax, bx), fmaf((float)((qfx >> (8 * k)) & 0xFFu), ax, bx));
+                const rp_f2 ty = rp_mk2(fmaf((float)((qny >> (8 * k)) & 0xFFu), ay, by), fmaf((float)((qfy >> (8 * k)) & 0xFFu), ay, by));
+                const rp_f2 tz = rp_mk2(fmaf((float)((qnz >> (8 * k)) & 0xFFu), az, bz), fmaf((float)((qfz >> (8 * k)) & 0xFFu), az, bz));
                 // closest-hit queries order the children by the entry distance BEFORE it is clamped to t_min: a ray that starts inside several
                 // overlapping boxes (instance boxes of a forest, secondary rays) has the same clamped entry distance for all of them and the
                 // visit order would fall back to slot order -- which is right or wrong by the luck of the builder's left / right (37 or 46

@@ -124,6 +124,13 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 // (operands pre-rotated into the (x,y) (z,x) (y,z) pairs in which the 12 floats of
 // a node arrive), 32-bit node offsets (saddr loads), select instead of branch for
 // the child choice, and leaf triangles fetched two at a time before testing.
+// The node step's 24 plane distances: scalar fmas (default since round 4) or 12 v_pk_fma_f32 (rounds 1-3: -DRP_SLAB_PACKED=1). Same values
+// either way. The packed form halves the instruction count, but v_pk_fma_f32 issues at half rate on gfx950 (tools/microbench/valu_issue.hip:
+// two flops per issue slot both ways) and its register pairs cost VGPRs: scalar, the closest-hit kernels need 77 / 71 VGPRs instead of 77 / 76
+// and the shadow-ray kernel 67 instead of 70, C2 1.228-1.242 -> 1.211-1.217 ms per frame, C4 4.79 -> 4.76 (profiles/r04_notes.md section 9).
+#ifndef RP_SLAB_PACKED
+#define RP_SLAB_PACKED 0
+#endif
 #ifndef RP_REFILL_MIN
 #define RP_REFILL_MIN 48
 #endif
@@ -376,10 +383,17 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             float ent[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+#if RP_SLAB_PACKED
                 // (near, far) pairs: one packed fma per axis
                 const rp_f2 tx = __builtin_elementwise_fma(rp_mk2((float)((qnx >> (8 * k)) & 0xFFu), (float)((qfx >> (8 * k)) & 0xFFu)), ax2, bx2);
                 const rp_f2 ty = __builtin_elementwise_fma(rp_mk2((float)((qny >> (8 * k)) & 0xFFu), (float)((qfy >> (8 * k)) & 0xFFu)), ay2, by2);
                 const rp_f2 tz = __builtin_elementwise_fma(rp_mk2((float)((qnz >> (8 * k)) & 0xFFu), (float)((qfz >> (8 * k)) & 0xFFu)), az2, bz2);
+#else
+                // the same six fmas as scalars (identical values): v_pk_fma_f32 issues at half rate on gfx950, and its register pairs cost moves
+                const rp_f2 tx = rp_mk2(fmaf((float)((qnx >> (8 * k)) & 0xFFu), ax, bx), fmaf((float)((qfx >> (8 * k)) & 0xFFu), ax, bx));
+                const rp_f2 ty = rp_mk2(fmaf((float)((qny >> (8 * k)) & 0xFFu), ay, by), fmaf((float)((qfy >> (8 * k)) & 0xFFu), ay, by));
+                const rp_f2 tz = rp_mk2(fmaf((float)((qnz >> (8 * k)) & 0xFFu), az, bz), fmaf((float)((qfz >> (8 * k)) & 0xFFu), az, bz));
+#endif
                 // closest-hit queries order the children by the entry distance BEFORE it is clamped to t_min: a ray that starts inside several
                 // overlapping boxes (instance boxes of a forest, secondary rays) has the same clamped entry distance for all of them and the
                 // visit order would fall back to slot order -- which is right or wrong by the luck of the builder's left / right (37 or 46
