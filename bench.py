@@ -260,11 +260,15 @@ def load_valu_peak():
             best = {}
             for r in doc["results"]:
                 best[r["op"]] = max(best.get(r["op"], 0.0), r["ginst_s_wall"])
-            mix = max(v for k, v in best.items() if k.startswith("node_step_mix("))
+            # the node step's own mix: round 4's (24 scalar fmas for the plane distances) when the file holds it, else rounds 1-3's (12 v_pk_fma_f32)
+            r4 = [v for k, v in best.items() if k.startswith("node_step_mix_r4(")]
+            mix = max(r4) if r4 else max(v for k, v in best.items() if k.startswith("node_step_mix("))
             full = max(best.get("v_fma_f32", 0.0), best.get("v_mul_f32", 0.0), best.get("v_add_u32", 0.0))
             # the issue ceiling of each path kernel's OWN static instruction mix (tools/kernel_mix.py -> kmix_gen.h -> the microbenchmark)
             kmix = {k[5:]: v for k, v in best.items() if k.startswith("kmix:")}
-            return {"node_step_mix_ginst_s": mix, "full_rate_ginst_s": full, "half_rate_ginst_s": best.get("v_pk_fma_f32"), "kmix": kmix,
+            return {"node_step_mix_ginst_s": mix, "node_step_mix_what": ("24 v_cvt_f32_ubyte, 24 v_fma_f32, 18 min / max, 14 v_cndmask, 12 integer per 92: round 4's scalar plane distances" if r4 else
+                                                                       "24 v_cvt_f32_ubyte, 12 v_pk_fma_f32, 18 min / max, 14 v_cndmask, 12 integer per 80"),
+                    "full_rate_ginst_s": full, "half_rate_ginst_s": best.get("v_pk_fma_f32"), "kmix": kmix,
                     "source": "profiles/%s (tools/microbench/valu_issue.hip on an MI355X of the pool)" % name}
         except Exception:
             continue
@@ -839,9 +843,9 @@ def main():
         "timing": "exclusive: HIP events on the dispatch packets of %d frames rendered ONE AT A TIME after the timed region, on a handle with one frame context (no other frame on the GPU, every launch at full size); "
                   "sum of all stages = stage_ms_per_step.gpu_total" % n_serial,
         "valu": {"binding_unit": "VALU issue", "peak_ginst_s": round(valu_peak, 1),
-                 "peak_what": ("MEASURED: wave64 instructions / s of the BVH4 node step's instruction mix (24 v_cvt_f32_ubyte, 12 v_pk_fma_f32, 18 min / max, 14 v_cndmask, "
-                               "12 integer per 80) at 8 waves per SIMD, tools/microbench/valu_issue.hip; plain v_fma / v_mul / v_add_u32 reach %.0f G/s (1 per 2 clocks per SIMD), "
-                               "v_pk_fma_f32 / v_cvt_f32_ubyte / v_min3 / v_max %.0f G/s" % (vp["full_rate_ginst_s"], vp["half_rate_ginst_s"])) if vp else
+                 "peak_what": ("MEASURED: wave64 instructions / s of the BVH4 node step's instruction mix (%s) at 8 waves per SIMD, tools/microbench/valu_issue.hip; "
+                               "plain v_fma / v_mul / v_add_u32 reach %.0f G/s (1 per 2 clocks per SIMD), "
+                               "v_pk_fma_f32 / v_cvt_f32_ubyte / v_min3 / v_max %.0f G/s" % (vp["node_step_mix_what"], vp["full_rate_ginst_s"], vp["half_rate_ginst_s"])) if vp else
                               "%d CUs x 4 SIMDs x 1 wave64 VALU instruction per 4 clocks x %.1f GHz (profiles/r03a_valu_issue.json absent)" % (props.multi_processor_count, MAX_CLOCK_GHZ),
                  "peak_source": vp["source"] if vp else None,
                  "wait_any_frac": k_ext.get("wait_any_frac"), "wait_inst_any_frac": k_ext.get("wait_inst_any_frac"),

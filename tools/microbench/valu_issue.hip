@@ -30,12 +30,13 @@
 #define KMIX_N 0
 #endif
 enum Op { FMA, PK_FMA, CVT_UBYTE, MIN3, MAX_F, CNDMASK, MUL, ADD_U32, RCP, SQRT, NODE_MIX, FMA_SALU, FMA_MIX, CVT_F16, CVT_U32, BFE_U32, NODE_MIX_F16,
-          AND_B32, LSHL_B32, MOV_B32, CMP_F32, ADD_F32, MUL_LO_U32, READLANE, N_BASE_OPS, KMIX0 = N_BASE_OPS, N_OPS = N_BASE_OPS + 16 };
+          AND_B32, LSHL_B32, MOV_B32, CMP_F32, ADD_F32, MUL_LO_U32, READLANE, NODE_MIX_SCALAR, N_BASE_OPS, KMIX0 = N_BASE_OPS, N_OPS = N_BASE_OPS + 16 };
 static const char *op_names[N_BASE_OPS] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_min3_f32", "v_max_f32", "v_cndmask_b32", "v_mul_f32",
                                       "v_add_u32", "v_rcp_f32", "v_sqrt_f32", "node_step_mix(24 cvt,12 pk_fma,18 minmax,14 cndmask,12 add/and)", "v_fma_f32 + s_add_u32 (1:1)",
                                       "v_fma_mix_f32 (f16 x f32 + f32)", "v_cvt_f32_f16", "v_cvt_f32_u32", "v_bfe_u32",
                                       "node_step_mix with f16 planes(24 fma_mix,18 minmax,14 cndmask,12 add/and)",
-                                      "v_and_b32", "v_lshlrev_b32", "v_mov_b32", "v_cmp_lt_f32", "v_add_f32", "v_mul_lo_u32", "v_readfirstlane_b32"};
+                                      "v_and_b32", "v_lshlrev_b32", "v_mov_b32", "v_cmp_lt_f32", "v_add_f32", "v_mul_lo_u32", "v_readfirstlane_b32",
+                                      "node_step_mix_r4(24 cvt,24 fma,18 minmax,14 cndmask,12 add/and)"};
 
 // one instruction on accumulator `a` (and, where it needs them, constants b, c). All streams are independent across the 8 accumulators.
 #define I_FMA(a)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
@@ -104,6 +105,13 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
             R8(I_CND) I_CND(a0) I_CND(a1) I_CND(a2) I_CND(a3) I_CND(a4) I_CND(a5)
             R8(I_ADDU) I_ADDU(a0) I_ADDU(a1) I_ADDU(a2) I_ADDU(a3)
         }
+        if (OP == NODE_MIX_SCALAR) { // round 4's node step: the 24 plane distances as scalar fmas instead of 12 v_pk_fma_f32 (92 instructions)
+            R8(I_CVT) R8(I_CVT) R8(I_CVT)
+            R8(I_FMA) R8(I_FMA) R8(I_FMA)
+            R8(I_MIN3) R8(I_MAX) I_MIN3(a0) I_MAX(a1)
+            R8(I_CND) I_CND(a0) I_CND(a1) I_CND(a2) I_CND(a3) I_CND(a4) I_CND(a5)
+            R8(I_ADDU) I_ADDU(a0) I_ADDU(a1) I_ADDU(a2) I_ADDU(a3)
+        }
         if (OP == AND_B32) { R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) R8(I_AND) }
         if (OP == LSHL_B32) { R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) R8(I_LSHL) }
         if (OP == MOV_B32) { R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) R8(I_MOV) }
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void k_issue(int iters, uint64_t *cycles, floa
     }
 }
 
-static int insts_per_iter(int op) { return op >= KMIX0 ? 96 : op == NODE_MIX ? 80 : op == NODE_MIX_F16 ? 68 : 64; }
+static int insts_per_iter(int op) { return op >= KMIX0 ? 96 : op == NODE_MIX ? 80 : op == NODE_MIX_F16 ? 68 : op == NODE_MIX_SCALAR ? 92 : 64; }
 static const char *name_of(int op) {
 #if KMIX_N > 0
     if (op >= KMIX0) return kmix_names[op - KMIX0];
@@ -203,6 +211,7 @@ static void launch_op(int op, int grid, size_t lds, int iters, uint64_t *cyc, fl
     case ADD_F32: launch<ADD_F32>(grid, lds, iters, cyc, sink); break;
     case MUL_LO_U32: launch<MUL_LO_U32>(grid, lds, iters, cyc, sink); break;
     case READLANE: launch<READLANE>(grid, lds, iters, cyc, sink); break;
+    case NODE_MIX_SCALAR: launch<NODE_MIX_SCALAR>(grid, lds, iters, cyc, sink); break;
     case KMIX0 + 0: launch<KMIX0 + 0>(grid, lds, iters, cyc, sink); break;
     case KMIX0 + 1: launch<KMIX0 + 1>(grid, lds, iters, cyc, sink); break;
     case KMIX0 + 2: launch<KMIX0 + 2>(grid, lds, iters, cyc, sink); break;
