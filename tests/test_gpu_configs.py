@@ -714,6 +714,9 @@ def test_ray_queries_on_device_buffers_equal_the_host_array_queries():
     torch.cuda.synchronize()
     assert hip.hipMemcpy(ctypes.c_void_p(dq), ctypes.c_void_p(tq.data_ptr()), ctypes.c_size_t(n * 32), 3) == 0      # device to device
     assert hip.hipMemcpy(ctypes.c_void_p(dr), ctypes.c_void_p(tr.data_ptr()), ctypes.c_size_t(n * 16), 3) == 0
+    # (a device-to-device hipMemcpy may return before the copy has run, and the backend's stream does not synchronise with the null stream:
+    # without this the 7.0 fill raced the query kernel -- seen once, on the build whose kernels got faster)
+    assert hip.hipDeviceSynchronize() == 0
     r.render_ray_queries_device(n)
     r.render_ray_queries(q[:1])                                      # (a synchronous call on the backend's stream: the queries above are done)
     out = torch.empty_like(tr)
