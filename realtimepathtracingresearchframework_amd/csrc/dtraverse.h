@@ -44,7 +44,15 @@
 // one box; profiles/r04_notes.md section 5): connect launches -4 % on C2, -6 % on C4; the closest-hit kernels at six waves lose 1.5 % on C2.
 // Only the instantiations for scenes with one instance record get it (kernels.h rp_k_connect): the two-level walk spills 72-80 bytes at 80 VGPRs.
 #ifndef RP_CONNECT_WAVES
-#define RP_CONNECT_WAVES 6
+#define RP_CONNECT_WAVES 8
+#endif
+// After the build lost the SLP vectoriser and the packed slab test, the kernels for scenes with one instance record (no alpha test) need 77 /
+// 71 / 67 VGPRs (first / later closest-hit, shadow rays). They are compiled for a register budget of SEVEN / EIGHT waves per SIMD (72 / 64
+// VGPRs asked for, 79 / 71 / 67 used: the bound steers the scheduler's register / latency trade, the LDS stacks still limit a CU to six
+// blocks): C2 1.196 / 1.196 / 1.190 -> 1.161 / 1.176 / 1.167 ms pipelined (-2.3 %), C4 4.66 -> 4.63, C3 3.95 -> 3.91 (tools/ab.sh, one box).
+// The two-level and alpha-tested instantiations keep RP_TRAVERSE_WAVES (they need 96 VGPRs and would spill).
+#ifndef RP_SINGLE_EXTEND_WAVES
+#define RP_SINGLE_EXTEND_WAVES 7
 #endif
 // ... and the closest-hit launches of the later bounces (no camera-ray set-up in the refill): an experiment knob (default: as the first bounce)
 #ifndef RP_EXTEND_LATER_WAVES

@@ -281,7 +281,7 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     }
 }
 template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool TABLE>
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK, (FIRST ? RP_TRAVERSE_WAVES : RP_EXTEND_LATER_WAVES)) void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK, ((SINGLE && !ALPHA) ? RP_SINGLE_EXTEND_WAVES : (FIRST ? RP_TRAVERSE_WAVES : RP_EXTEND_LATER_WAVES))) void rp_k_extend(RpScene sc, RpFrame f, RpPathState ps, const uint32_t *queue, RpBounceCounters *bc, RpCounters *ctr,
                                                int *gstack) {
     rp_extend_body<COUNT, FIRST, ALPHA, SINGLE, false, TABLE>(sc, f, ps, queue, bc->queue_count, &bc->cursor_extend, ctr, gstack);
 }
@@ -346,7 +346,7 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
 // (six waves per SIMD only for scenes with one instance record: the two-level walk keeps the instance's state alive -- 72-80 bytes of scratch
 // at 80 VGPRs, two-level C4 connect 2.5 -> 3.2 ms: measured, so those instantiations keep the closest-hit kernels' bound)
 template <bool COUNT, bool ALPHA, bool SINGLE>
-__global__ __launch_bounds__(RP_TRAVERSE_BLOCK, (SINGLE ? RP_CONNECT_WAVES : RP_TRAVERSE_WAVES)) void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
+__global__ __launch_bounds__(RP_TRAVERSE_BLOCK, ((SINGLE && !ALPHA) ? RP_CONNECT_WAVES : RP_TRAVERSE_WAVES)) void rp_k_connect(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpBounceCounters *bc, RpCounters *ctr, int *gstack) {
     rp_connect_body<COUNT, ALPHA, SINGLE, false>(sc, f, ps, sq, sq.ids, bc->shadow_count, &bc->cursor_connect, ctr, gstack);
 }
 template <int LDSTOP>
@@ -859,8 +859,11 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
 // -> vertices -> material; profiles/pmc_traffic.json wait_any_frac), so the fifth wave pays: compiled for five the two kernels fit 96
 // VGPRs without scratch; A/B on one box (tools/ab.sh, build variants): shade launches 0.439 -> 0.425 ms per C2 frame, the pipelined
 // frame 1.32 -> 1.30 ms, C5 3.20 -> 3.15, C4 unchanged. -DRP_SHADE_WAVES_LEAN=4: the old bound.
+// (After the build lost the SLP vectoriser the two kernels need 87 / 96 VGPRs; compiled for SIX waves they fit 80 with 0 / 8 bytes of scratch.
+// Their exclusive times do not move, the pipelined frames do -- fewer registers per block leave room for the other frames' waves: C2 1.216 ->
+// 1.179 ms (three pairs of runs), C4 4.74 -> 4.65, C5 2.96 -> 2.91.)
 #ifndef RP_SHADE_WAVES_LEAN
-#define RP_SHADE_WAVES_LEAN 5
+#define RP_SHADE_WAVES_LEAN 6
 #endif
 template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
 constexpr int rp_shade_waves() { return (VARIANT == RPTR_VARIANT_SIMPLE && !LIGHTS && !TEX && !TABLE) ? RP_SHADE_WAVES_LEAN : RP_SHADE_WAVES; }
