@@ -165,8 +165,6 @@ RP_DEV void rp_wave_trace_items(const RpScene &sc, int *gstack, Pool pool, Begin
             const uint32_t qnx = neg_x ? n1.w : n1.x, qfx = neg_x ? n1.x : n1.w;
             const uint32_t qny = neg_y ? n2.x : n1.y, qfy = neg_y ? n1.y : n2.x;
             const uint32_t qnz = neg_z ? n2.y : n1.z, qfz = neg_z ? n1.z : n2.y;
-            const rp_f2 ax2 = rp_mk2(ax, ax), ay2 = rp_mk2(ay, ay), az2 = rp_mk2(az, az);
-            const rp_f2 bx2 = rp_mk2(bx, bx), by2 = rp_mk2(by, by), bz2 = rp_mk2(bz, bz);
             const float tfar_max = best.t;
             // a missed child becomes an empty slot with entry distance +inf: from here on "hit" is "ref != EMPTY" (an empty slot stays
             // one whatever its box says)

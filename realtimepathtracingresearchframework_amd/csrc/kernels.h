@@ -886,8 +886,23 @@ __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>()
 template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
 __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
+    // One arena for the phases that take turns (round 4, as in rp_k_frame): the LDS stacks of the closest-hit traversal, the shade phase's
+    // scratch (regrouped list, light-candidate exchange) and the LDS stacks of the shadow-ray traversal -- 33 KB per block instead of 64 (37
+    // instead of 88 with triangle lights). A tail block issues next to nothing for 0.16 ms of every frame; with eleven frames in flight one
+    // or two of them sit on every CU at any time, and what they hold is LDS the traversal blocks of the other frames want.
+    constexpr uint32_t STACK_WORDS = RP_LDS_STACK * RP_TRAVERSE_BLOCK;
+    constexpr uint32_t SCRATCH_WORDS = RP_CHUNK + (LIGHTS ? RP_SHADE_RIS_REQ_FLOATS + RP_SHADE_RIS_CONTRIB_FLOATS : 0);
+    __shared__ __attribute__((aligned(16))) uint32_t s_arena[STACK_WORDS > SCRATCH_WORDS ? STACK_WORDS : SCRATCH_WORDS];
+    __shared__ uint32_t s_next[RP_CHUNK], s_shadow[RP_CHUNK];
     __shared__ uint32_t s_cur[RP_TAIL_CHUNK];
     __shared__ uint32_t s_cursor[2];
+    int *const stack = reinterpret_cast<int *>(s_arena);
+    RpShadeLds lds;
+    lds.next = s_next;
+    lds.shadow = s_shadow;
+    lds.list = s_arena;
+    lds.ris_req = reinterpret_cast<float *>(s_arena + RP_CHUNK);
+    lds.ris_contrib = reinterpret_cast<float *>(s_arena + RP_CHUNK + RP_SHADE_RIS_REQ_FLOATS);
     const uint32_t n_total = ctr->bounce[first_bounce].queue_count;
     const uint32_t nchunks = (n_total + RP_TAIL_CHUNK - 1) / RP_TAIL_CHUNK;
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -897,13 +912,14 @@ __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPat
         for (int b = first_bounce; b < f.rp.max_path_depth && n > 0; ++b) {
             if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
             __syncthreads();
-            rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack);
+            rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE, 0, false, true>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack, 0u, stack);
             __syncthreads();
             uint32_t *next = nullptr, *shadow = nullptr;
             uint32_t n_next = 0, n_shadow = 0;
-            rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow);
+            rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, false, true>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow, 0u,
+                                                                                  &lds);
             __syncthreads();
-            rp_connect_body<false, ALPHA, SINGLE, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack);
+            rp_connect_body<false, ALPHA, SINGLE, true, 0, false, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack, stack);
             __syncthreads();
             if (threadIdx.x < n_next) s_cur[threadIdx.x] = next[threadIdx.x]; // survivors: at most n <= RP_TAIL_CHUNK
             n = n_next;

@@ -33,6 +33,7 @@ assert not re.search(r'\bCOUNT\b', core), [l for l in core.splitlines() if re.se
 core = core.replace('ent[k] = ANY ? gap : (hit ? tn_raw : INFINITY);', 'ent[k] = anyq ? gap : (hit ? tn_raw : INFINITY);')
 core = core.replace('(ANY && any_hit)', '(anyq && any_hit)')
 assert not re.search(r'\bANY\b', core), [l for l in core.splitlines() if re.search(r'\bANY\b', l)]
+core = re.sub(r'#if RP_SLAB_PACKED\n((?:(?!#else|#endif).)*?)#endif\n', '', core, flags=re.S)  # (the packed form's operand pairs)
 core = re.sub(r'#if RP_SLAB_PACKED\n.*?#else\n(.*?)#endif\n', r'\1', core, flags=re.S)  # the default (scalar fmas) branch of the plane distances
 core = core.replace('#if RP_NODE_MIN > 1\n', '').replace('#endif\n            if (cur >= 0) {', '            if (cur >= 0) {')
 assert '#endif' not in core and '#if' not in core, [l for l in core.splitlines() if l.startswith('#')]
