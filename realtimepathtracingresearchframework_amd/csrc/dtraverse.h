@@ -31,8 +31,12 @@
 #include "dshade.h"
 
 #define RP_TRAVERSE_BLOCK 256
+// 20 entries per lane in LDS (round 4; 24 until then): 20 KB per block let seven traversal blocks share a CU's 160 KB where 24 KB stopped at
+// six -- which only matters since the kernels need 67-79 VGPRs. Deeper entries spill to the global scratch as before (the whole wave takes the
+// generic path when a lane comes within three entries of the end). Measured (tools/ab.sh, one box): C2 1.143 / 1.150 -> 1.127 / 1.141 ms,
+// C3 3.83 -> 3.71, C4 4.54 -> 4.48, two-level C4 6.54 -> 6.50; 16 entries: C3 3.67 but the two-level forest 6.68 (its stacks are deeper).
 #ifndef RP_LDS_STACK
-#define RP_LDS_STACK 24
+#define RP_LDS_STACK 20
 #endif
 // waves per SIMD the traversal kernels are compiled for (bounds the VGPR budget)
 #ifndef RP_TRAVERSE_WAVES
