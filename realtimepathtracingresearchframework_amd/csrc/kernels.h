@@ -862,8 +862,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
 // (After the build lost the SLP vectoriser the two kernels need 87 / 96 VGPRs; compiled for SIX waves they fit 80 with 0 / 8 bytes of scratch.
 // Their exclusive times do not move, the pipelined frames do -- fewer registers per block leave room for the other frames' waves: C2 1.216 ->
 // 1.179 ms (three pairs of runs), C4 4.74 -> 4.65, C5 2.96 -> 2.91.)
+// (Seven: 72 VGPRs, 12 / 8 bytes of scratch -- and now the exclusive launches gain too, shade 0.421 -> 0.397 ms per C2 frame: the later bounces
+// wait on dependent loads and a seventh wave hides more of them; pipelined C2 1.150 / 1.136 / 1.164 -> 1.114 / 1.131 / 1.129, C4 4.47 -> 4.42.)
 #ifndef RP_SHADE_WAVES_LEAN
-#define RP_SHADE_WAVES_LEAN 6
+#define RP_SHADE_WAVES_LEAN 7
 #endif
 template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
 constexpr int rp_shade_waves() { return (VARIANT == RPTR_VARIANT_SIMPLE && !LIGHTS && !TEX && !TABLE) ? RP_SHADE_WAVES_LEAN : RP_SHADE_WAVES; }
@@ -883,8 +885,13 @@ __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>()
 // them to the end -- extend, shade, connect per bounce on block-local lists in LDS, the same device code as the stand-alone
 // kernels (results are bit-identical, tests/test_gpu_parity.py) -- before it takes the next chunk.
 #define RP_TAIL_CHUNK 256
+// register budget of the tail kernel in waves per SIMD (one block per CU runs whatever the budget: what the budget buys is registers that
+// the block does NOT hold while it idles beside the other frames' kernels)
+#ifndef RP_TAIL_WAVES
+#define RP_TAIL_WAVES 1
+#endif
 template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
-__global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
+__global__ __launch_bounds__(256, RP_TAIL_WAVES) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
     // One arena for the phases that take turns (round 4, as in rp_k_frame): the LDS stacks of the closest-hit traversal, the shade phase's
     // scratch (regrouped list, light-candidate exchange) and the LDS stacks of the shadow-ray traversal -- 33 KB per block instead of 64 (37
