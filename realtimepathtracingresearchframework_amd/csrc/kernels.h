@@ -885,13 +885,8 @@ __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>()
 // them to the end -- extend, shade, connect per bounce on block-local lists in LDS, the same device code as the stand-alone
 // kernels (results are bit-identical, tests/test_gpu_parity.py) -- before it takes the next chunk.
 #define RP_TAIL_CHUNK 256
-// register budget of the tail kernel in waves per SIMD (one block per CU runs whatever the budget: what the budget buys is registers that
-// the block does NOT hold while it idles beside the other frames' kernels)
-#ifndef RP_TAIL_WAVES
-#define RP_TAIL_WAVES 1
-#endif
 template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
-__global__ __launch_bounds__(256, RP_TAIL_WAVES) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
+__global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
     // One arena for the phases that take turns (round 4, as in rp_k_frame): the LDS stacks of the closest-hit traversal, the shade phase's
     // scratch (regrouped list, light-candidate exchange) and the LDS stacks of the shadow-ray traversal -- 33 KB per block instead of 64 (37
