@@ -39,8 +39,10 @@
 #define RP_LDS_STACK 20
 #endif
 // waves per SIMD the traversal kernels are compiled for (bounds the VGPR budget)
+// (six since the end of round 4: without packed math the two-level instantiations need 76-80 VGPRs; two-level C4 6.70 / 6.68 -> 6.62 / 6.61 ms,
+// two-level C3 4.38 -> 4.32. Rounds 1-3: five, 95-96 VGPRs.)
 #ifndef RP_TRAVERSE_WAVES
-#define RP_TRAVERSE_WAVES 5
+#define RP_TRAVERSE_WAVES 6
 #endif
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
 // the shadow-ray kernels carry less per lane (no hit record to keep): compiled for six waves per SIMD they fit 80 VGPRs with 12 bytes of
