@@ -62,9 +62,9 @@ def parse_args():
     ap.add_argument("--scene", type=str, default="grid", choices=["grid", "forest"],
                     help="forest = SURVEY 8d C4: 10 tree meshes x 10k triangles, 1000 instances (10M instanced triangles)")
     ap.add_argument("--flatten", type=int, default=-1,
-                    help="RPTR_FLATTEN: build a static multi-instance scene as one world-space tree (memory for speed). Default: on "
-                         "for a static scene (the forest's 10 M instanced triangles = 0.6 GB; the grid + its emitter mesh of --lights), "
-                         "off with --animate (a dynamic mesh keeps its own tree for the refit)")
+                    help="library option \"flatten\" (0: keep instances two-level). Default: not set -- the library flattens a static "
+                         "multi-instance scene itself (the forest's 10 M instanced triangles = 0.6 GB; the grid + its emitter mesh of --lights) "
+                         "and keeps a scene with a dynamic mesh (--animate) two-level")
     ap.add_argument("--animate", action="store_true",
                     help="SURVEY 8d C5: the grid is a dynamic mesh; every step animates its vertices on the device, refits the BVH "
                          "(inside the timed region) and renders")
@@ -100,7 +100,6 @@ def parse_args():
                          "(app.cpp:350-469) -- launch sequences of several frames then carry a camera per frame (rptr_hip_render_batch_cameras_async)")
     ap.add_argument("--sustained-seconds", type=float, default=1.0,
                     help="after the timed region the same schedule runs on for at least this long (untimed by --steps): roofline.sustained")
-    ap.add_argument("--one-launch", action="store_true", help="frames as ONE launch driven from device-side queues (rptr_hip_set_frame_schedule)")
     ap.add_argument("--profile-pass", action="store_true",
                     help="for rocprofv3 --pmc / --kernel-trace passes (tools/pmc.sh): warm-up + `steps` frames one at a time, nothing else, no JSON line")
     return ap.parse_args()
@@ -348,8 +347,12 @@ def main():
 
     # one explicit stream for torch AND the backend: the animation kernel, the tile copy and torch's gather (--gather torch) are ordered
     # with the frames by stream order. (torch's default stream has handle 0, which the C ABI reads as "create your own stream".)
+    # options of the handles (rptr_hip_set_option, include/rptr_hip.h "Options"): nothing is set unless a flag asks for it -- the library's
+    # defaults ARE the measured configuration (static multi-instance scenes are flattened by the library itself: option "flatten" = auto)
+    lib_options = {}
+    if args.flatten >= 0:
+        lib_options["flatten"] = args.flatten
     flatten = args.flatten if args.flatten >= 0 else (0 if args.animate else 1)
-    os.environ["RPTR_FLATTEN"] = str(flatten)
     torch_stream = torch.cuda.Stream()
     torch.cuda.set_stream(torch_stream)
     stream = torch_stream.cuda_stream
@@ -358,14 +361,13 @@ def main():
     # 1.51 / 1.44 / 1.40 ms per frame (profiles/r02_notes.md); the roofline figures come from frames rendered one at a time either way.
     fif = args.frames_in_flight if args.frames_in_flight > 0 else (7 if args.animate else 11)
     batch_frames = args.batch_frames if args.batch_frames > 0 else (1 if args.animate else max(1, min(4, 16 // max(spp, 1))))
-    # small frames (a rank of a >= 4-way split): launch sequences of EIGHT frames (32 sample slots in flight instead of 16; RPTR_MAX_BATCH_SPP /
-    # RPTR_MAX_BATCH_FRAMES are read when the handle is created) -- measured on rank 0's share of an 8-way / 4-way split: 0.193 -> 0.173 /
+    # small frames (a rank of a >= 4-way split): launch sequences of EIGHT frames (32 sample slots in flight instead of 16: option
+    # "max_batch_spp", read by initialize) -- measured on rank 0's share of an 8-way / 4-way split: 0.193 -> 0.173 /
     # 0.343 -> 0.330 ms per frame (profiles/r04_notes.md section 6); a full frame gains nothing from it
     ranks_of_split = world if world > 1 else args.emulate_world
     if args.batch_frames <= 0 and not args.animate and ranks_of_split >= 4 and "RPTR_MAX_BATCH_FRAMES" not in os.environ and "RPTR_MAX_BATCH_SPP" not in os.environ:
         batch_frames = max(1, min(8, 32 // max(spp, 1)))
-        os.environ["RPTR_MAX_BATCH_FRAMES"] = str(batch_frames)
-        os.environ["RPTR_MAX_BATCH_SPP"] = str(batch_frames * spp)
+        lib_options["max_batch_spp"] = batch_frames * spp
     # no more contexts than the timed region has launch sequences for: the line names the schedule that ran (20 steps in sequences of 4
     # frames are 5 sequences, not 11)
     # BENCH_BATCH_PATTERN=a,b,c,... (experiment): the lengths of the timed region's first launch sequences (then `batch_frames` each)
@@ -383,9 +385,9 @@ def main():
     if args.profile_pass:
         fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
     if args.emulate_world > 1:
-        r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
+        r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif, options=lib_options)
     else:
-        r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif)
+        r = backend.RenderHip(device_ordinal=local_rank, rank=rank, world_size=world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif, options=lib_options)
     r.initialize(W, H)
     t0 = time.time()
     r.set_scene(scene)
@@ -395,8 +397,6 @@ def main():
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
     cam = scene.camera_params()
-    if args.one_launch:
-        r.set_frame_schedule(True)
 
     def camera_of(k):
         """the view of frame k: a fly-through step per frame (yaw 0.002 rad, 2 cm sideways), so that consecutive frames differ the way an
@@ -583,13 +583,8 @@ def main():
     torch.cuda.synchronize()
     # (a handle with ONE frame context runs the shadow rays of bounce b on a side stream beside the closest-hit rays of bounce b + 1 unless
     # told otherwise: the exclusive figures need every launch alone on the GPU)
-    side_env = os.environ.get("RPTR_SIDE_CONNECT")
-    os.environ["RPTR_SIDE_CONNECT"] = "0"
-    rx = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=1)
-    if side_env is None:
-        del os.environ["RPTR_SIDE_CONNECT"]
-    else:
-        os.environ["RPTR_SIDE_CONNECT"] = side_env
+    rx = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=1,
+                           options=dict(lib_options, side_connect=0))
     rx.initialize(W, H)
     rx.set_scene(scene)
     if args.animate and args.rebuild_budget != 0:
@@ -653,7 +648,7 @@ def main():
     n_lat = max(10, min(40, args.steps))
     latency = {}
     for depth in ((1, 2) if (world == 1 and args.emulate_world <= 1) else (1,)):
-        rl = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=depth)
+        rl = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=depth, options=lib_options)
         rl.initialize(W, H)
         rl.set_scene(scene)
         if args.animate and args.rebuild_budget != 0:
@@ -900,7 +895,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
                    "camera": "one view for all frames" if args.static_camera else "moves every frame (a camera per frame inside a launch sequence)",
-                   "frame_schedule": "one launch per frame (rp_k_frame)" if args.one_launch else "stage launches",
+                   "frame_schedule": "stage launches",
                    "frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2),

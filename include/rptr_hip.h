@@ -266,8 +266,9 @@ typedef struct RptrSceneDesc {
  * independent). Everything is asynchronous to the host only where said so (rptr_hip_render_async, *_device copies). */
 /* Version of this header's struct layouts and field meanings. History: 1 = round 1; 2 = RptrTextureDesc._pad became mip_levels, RptrStats grew
  * the stage split; 3 = RptrCreateInfo._pad became abi_version (checked), rank 0 keeps two assembled frames. rptr_hip_abi_version()
- * returns the library's value. Fields named _pad must be zero. */
-#define RPTR_HIP_ABI_VERSION 3
+ * returns the library's value. Fields named _pad must be zero. 4 = round 5: rptr_hip_set_option / _get_option; rptr_hip_set_frame_schedule /
+ * _get_frame_schedule are gone (the device-driven frame schedules they selected lost to the stage launches and left the product). */
+#define RPTR_HIP_ABI_VERSION 4
 typedef struct RptrCreateInfo {
     int32_t device_ordinal; /* hipSetDevice                                      */
     int32_t rank;
@@ -316,15 +317,15 @@ int rptr_hip_abi_version(void);
 /* the acceleration-structure step of the last rptr_hip_set_scene (the reference builds and compacts its BLAS / TLAS on the GPU inside
  * set_scene: vulkan/render_vulkan.cpp:476-543, vulkan/vulkanrt_utils.h:83-105). Large static triangle sets -- a flattened instanced scene,
  * static meshes of millions of triangles -- are built on the device (csrc/ploc.h: Morton sort, PLOC clustering, a binned-SAH top over the
- * remaining clusters, 4-wide collapse, encoding), everything else by the host's binned-SAH builder. RPTR_BVH_BUILDER=host|device|auto
- * (default auto: the device from RPTR_DEVICE_BUILD_MIN_TRIS = 2 Mi triangles). out_build_ms: wall time of the whole step;
+ * remaining clusters, 4-wide collapse, encoding), everything else by the host's binned-SAH builder (options "bvh_builder",
+ * "device_build_min_tris"). out_build_ms: wall time of the whole step;
  * out_device_ms: GPU time of the device builds in it (0 when the host built everything). */
 int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out_build_ms, float *out_device_ms);
 /* the scheduling thresholds the traversal kernels use for the current scene (csrc/dtraverse.h: a wave refills its idle lanes once
  * `refill_min` have finished and leaves a node phase once fewer than `node_min` lanes are at inner nodes; 0 = the compile-time defaults
  * 10 / 48) and the measure they were chosen by at set_scene: the surface-area cost of the largest bottom-level tree times that of the top
- * level (>= 24: the dense preset 16 / 32). They change when lanes take their steps, never what a ray finds. RPTR_TRAVERSE_PRESET="n,r"
- * overrides. No reference counterpart (the reference's traversal is the driver's). */
+ * level (>= 24: the dense preset 16 / 32). They change when lanes take their steps, never what a ray finds. Options "traverse_node_min" /
+ * "traverse_refill_min" override. No reference counterpart (the reference's traversal is the driver's). */
 int rptr_hip_traversal_preset(rptr_hip_t *h, float *out_area_cost, int32_t *out_node_min, int32_t *out_refill_min);
 void rptr_hip_destroy(rptr_hip_t *h);
 const char *rptr_hip_last_error(const rptr_hip_t *h);
@@ -383,23 +384,14 @@ int rptr_hip_render(rptr_hip_t *h, const RptrCamera *camera, int variant, int sp
 int rptr_hip_render_async(rptr_hip_t *h, const RptrCamera *camera, int variant, int spp, int reset_accumulation,
                           int count_traversal, uint64_t *out_ticket);
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats);
-/* How a frame is issued. 0: a sequence of stage launches (extend / shade / connect per bounce, then the tail kernel). 1: ONE launch whose
- * blocks pull extend -> shade -> connect work of the frame from device-side queues (csrc/kernels.h rp_k_frame) -- the reference's
- * megakernel is one dispatch per frame (vulkan/render_pipeline_vulkan.cpp:253-261) --: chunk-level dependencies instead of grid-wide
- * ones, which is what a frame rendered ALONE wants (a launch lasts as long as its slowest ray; a chunk only holds back its own block).
- * Same device code per path, bit-identical images. RPTR_FRAME_KERNEL=0|1 sets the default of new handles. count_traversal frames always
- * run as stage launches. rptr_hip_get_frame_schedule: the mode, the number of bounces that had global queues in the last finished frame,
- * their lengths (out_queue_lengths[0 .. cap), zero beyond). */
-int rptr_hip_set_frame_schedule(rptr_hip_t *h, int one_launch_per_frame);
-int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, int32_t *out_published_bounces, uint32_t *out_queue_lengths, int cap);
 /* Several frames in ONE launch sequence. A wavefront frame is a chain of dependent launches that each last at least as long as their
  * slowest ray; a small frame (the stripes of one rank of a multi-GPU split) cannot fill the GPU however many frames are in flight. Paths
  * are independent, so the samples of `n_frames` consecutive frames with the same camera and parameters can share the launches: sample
  * slots [k*spp, (k+1)*spp) belong to frame k, which keeps its own frame_offset / sample indices (reset_first: frame 0 restarts the
  * accumulation, reset_rest: so does every further frame -- begin_frame's rule per frame, render_vulkan.cpp:1937-1941), its own image
  * and its own ticket (out_tickets[0..n_frames)). Every frame is bit-identical to the same frame rendered on its own; the resolve folds
- * the frames into the accumulation in order. n_frames * spp sample slots must fit (RptrCreateInfo / RPTR_PATH_BUDGET_MB: at most
- * 16), n_frames <= RPTR_MAX_BATCH_FRAMES (4), frames_in_flight >= 2. rptr_hip_wait on any ticket of the batch waits for the batch;
+ * the frames into the accumulation in order. n_frames * spp sample slots must fit (options "max_batch_spp" /
+ * "path_budget_mb": 16 by default), n_frames <= option "max_batch_frames" (8), frames_in_flight >= 2. rptr_hip_wait on any ticket of the batch waits for the batch;
  * read-backs, AOV read-backs (AOV images: of the batch's last frame) and rptr_hip_gather return / send the image of the ticket waited
  * for last; a frame context is free again when all of its batch's tickets have been waited for. RptrStats of a batched frame: an
  * equal share of the batch's times and counts. No reference counterpart (the reference renders one frame per submission). */
@@ -425,6 +417,54 @@ int rptr_hip_set_rng_variant(rptr_hip_t *h, int rng_variant, const void *table, 
  * traversal launches (extend_time_ms), 2 every stage (default; ~0.1 ms per 1080p frame of launch gaps). */
 int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
 
+/* ---- Options: how the library builds and schedules, beyond RptrCreateInfo. The reference expresses such intent per mesh and per backend
+ * option (Mesh::Dynamic / SubtlyDynamic -> build flags, vulkan/render_vulkan.cpp:942-952; RenderBackendOptions, librender/render_params.glsl.h:
+ * 56-93); here every such switch is a named integer. rptr_hip_set_option(h, key, value) changes one for a handle -- it takes effect at the
+ * call named below -- and rptr_hip_set_option(NULL, key, value) changes the process default that new handles (and the handle-less
+ * rptr_hip_build_bvh_host) start from. Unknown key or value out of range: RPTR_E_INVALID. rptr_hip_get_option reads the value in force.
+ * Every option also has an environment variable (right column): the experimenter's override for A/B runs of an unmodified host. When it is set
+ * (read once per handle, in rptr_hip_create) its value is in force and rptr_hip_set_option on that key is accepted and ignored. No other
+ * environment variable is read by the library (besides RPTR_FRAMES_IN_FLIGHT, which overrides RptrCreateInfo.frames_in_flight, and the HIP
+ * runtime's own GPU_MAX_HW_QUEUES). A host that sets NOTHING gets the configuration bench.py measures.
+ *
+ *   key                      default   takes effect      meaning                                                                   environment
+ *   flatten                  -1        set_scene         -1 / 1: a static scene with >= 2 instances (no RPTR_MESH_DYNAMIC mesh) is   RPTR_FLATTEN
+ *                                                        built as ONE world-space tree (~150 bytes per instanced triangle; 1.5 x
+ *                                                        faster to trace than instance records); 0: always two-level
+ *   flatten_max_tris         1 << 26   set_scene         ... up to this many instanced triangles                                   RPTR_FLATTEN_MAX_TRIS
+ *   bvh_builder              0         set_scene         0 auto, 1 host (binned SAH), 2 device (PLOC) for static trees             RPTR_BVH_BUILDER=auto|host|device
+ *   device_build_min_tris    2 << 20   set_scene         auto: triangle sets of at least this size are built on the device        RPTR_DEVICE_BUILD_MIN_TRIS
+ *   rebraid                  0         set_scene         instance records per instance (sub-roots of its tree); 0: 4 from 16       RPTR_REBRAID
+ *                                                        instances on, else 1
+ *   traverse_node_min /      -1        set_scene         scheduling thresholds of the traversal (rptr_hip_traversal_preset);       RPTR_TRAVERSE_PRESET=n,r
+ *   traverse_refill_min                                  -1: chosen from the tree
+ *   lds_top                  0         set_scene         1: traversal instantiations with the top 64 nodes staged in LDS           RPTR_LDS_TOP
+ *   single_instance          1         set_scene         queries of scenes with one instance record start inside it               RPTR_NO_SINGLE_INSTANCE (set = 0)
+ *   max_batch_frames         8         initialize        frames a launch sequence may hold (rptr_hip_render_batch_async)           RPTR_MAX_BATCH_FRAMES
+ *   max_batch_spp            0         initialize        sample slots in flight per frame context; 0: min(16, what the budget      RPTR_MAX_BATCH_SPP
+ *                                                        holds)
+ *   path_budget_mb           6144      initialize        path state per frame context                                              RPTR_PATH_BUDGET_MB
+ *   blocks_per_cu            0         initialize        persistent traversal blocks per CU; 0: occupancy, shared between the      RPTR_BLOCKS_PER_CU
+ *                                                        frame contexts
+ *   side_connect             -1        initialize        shadow rays of bounce b on a side stream beside the closest-hit rays of   RPTR_SIDE_CONNECT
+ *                                                        b + 1; -1: on with ONE frame context, off with several
+ *   aovs                     1         initialize        AOV images (rptr_hip_readback_aov)                                        RPTR_AOVS
+ *   tail_bounce              -1        next frame        bounce from which ONE launch finishes the frame; -1 adaptive, 0 never     RPTR_TAIL_BOUNCE
+ *   tail_threshold           65536     next frame        adaptive: queue length below which a bounce goes to that launch           RPTR_TAIL_THRESHOLD
+ *   stage_timing             2         next frame        = rptr_hip_set_stage_timing                                               RPTR_STAGE_TIMING
+ *   regroup_materials        0         next frame        shade orders the hits of a chunk by material id (measured: no gain)       RPTR_REGROUP
+ *   comm_transport           0         comm init         0 auto (RCCL between devices), 1 rccl, 2 copy, 3 peer writes              RPTR_COMM_TRANSPORT=rccl|copy|peer
+ *   comm_priority            1         comm init         the communication stream has the highest stream priority                 RPTR_COMM_PRIORITY
+ *   comm_self                0         comm init         diagnostic: rank 0's own rows travel through the transport too            RPTR_COMM_SELF
+ *   quiet                    0         -                 no notes on stderr                                                        RPTR_QUIET
+ *   builder experiments (measured, not adopted; profiles/r03_notes.md): tlas_collapse, collapse (0 greedy, 1 even, 2 optimal; -1 per tree),
+ *   presplit_density, presplit_budget_pct, host_ploc, ploc_top, ploc_leaf -- RPTR_TLAS_COLLAPSE, RPTR_COLLAPSE, RPTR_PRESPLIT=d[,b],
+ *   RPTR_HOST_PLOC, RPTR_PLOC_TOP, RPTR_PLOC_LEAF. rptr_hip_option_count / rptr_hip_option_name enumerate the keys. */
+int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value);
+int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value);
+int rptr_hip_option_count(void);
+const char *rptr_hip_option_name(int index);
+
 /* ---- RenderGraphic::get_framebuffer_size / readback_framebuffer
  * (util/display/render_graphic.h:26-37, render_vulkan.cpp:2256-2287).
  * The float read-back returns the RGBA32F accumulation buffer (what
@@ -437,8 +477,8 @@ int rptr_hip_readback_u8(rptr_hip_t *h, unsigned char *rgba, size_t n_bytes);
  * `aov_index` of the last finished frame, width*height*4 halfs (rows of other ranks stay untouched): 0 albedo.rgb + roughness
  * (1 when ior == 1), 1 shading normal + distance to the camera, 2 screen-space motion.xy + jitter.xy (motion of the hit point
  * between the previous frame's view and this one; no per-vertex motion, jitter 0). Written at bounce 0 by the first sample of a
- * frame (the reference lets every sample of the batch store to the pixel, vulkan/accumulate.glsl:76-103). RPTR_AOVS=0 in the
- * environment at create time switches them off. */
+ * frame (the reference lets every sample of the batch store to the pixel, vulkan/accumulate.glsl:76-103). Option "aovs" = 0 (before
+ * rptr_hip_initialize) switches them off. */
 #define RPTR_AOV_ALBEDO_ROUGHNESS 0
 #define RPTR_AOV_NORMAL_DEPTH 1
 #define RPTR_AOV_MOTION_JITTER 2
@@ -472,8 +512,8 @@ int rptr_hip_copy_tile_to_device(rptr_hip_t *h, void *device_dst, size_t n_bytes
  * place through rptr_hip_gathered_frame (valid once rptr_hip_readback_gathered_f32 / rptr_hip_comm_stats have waited for it, or the device has been synchronised by the
  * caller). Rank 0 keeps TWO receive buffers and TWO assembled frames and uses them in turn: the frame of gather g stays intact while
  * gather g + 1 arrives and is assembled (a reader can hold frame i while i + 1 is in flight), and is rewritten by gather g + 2.
- * Handles that share a device (test rigs) and RPTR_COMM_TRANSPORT=copy use peer-to-peer
- * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. RPTR_COMM_TRANSPORT=peer (one-process mode, devices with peer
+ * Handles that share a device (test rigs) and option "comm_transport" = 2 (copy) use peer-to-peer
+ * copies (hipMemcpyPeerAsync) instead of RCCL in the one-process mode. "comm_transport" = 3 (peer; one-process mode, devices with peer
  * access): every rank writes its rows straight into their places in rank 0's frame from a kernel on its own communication stream --
  * rank 0 runs no receive kernels and no assembly pass (csrc/host_comm.h "Peer writes"). rptr_hip_comm_transport names what a handle's
  * communicator uses: "rccl", "copy" or "peer" (NULL without a communicator). */

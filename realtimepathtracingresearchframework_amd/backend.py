@@ -72,8 +72,10 @@ def load_library(path=None):
     L.rptr_hip_render_ray_queries.argtypes = [vp, i32]
     L.rptr_hip_set_light_sampling_variant.argtypes = [vp, i32]
     L.rptr_hip_set_freeze_frame.argtypes = [vp, i32]
-    L.rptr_hip_set_frame_schedule.argtypes = [vp, i32]
-    L.rptr_hip_get_frame_schedule.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), i32]
+    L.rptr_hip_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.rptr_hip_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.rptr_hip_option_name.argtypes = [i32]
+    L.rptr_hip_option_name.restype = C.c_char_p
     L.rptr_hip_set_rng_variant.argtypes = [vp, i32, vp, C.c_size_t]
     L.rptr_hip_set_bvh_policy.argtypes = [vp, i32, i32]
     L.rptr_hip_bvh_rebuild_count.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -157,7 +159,7 @@ class RenderConfiguration:  # librender/render_backend.h:33-40
 class RenderHip:
     """Drop-in shaped like `struct RenderBackend` (render_backend.h:68-116)."""
 
-    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None, frames_in_flight=1):
+    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None, frames_in_flight=1, options=None):
         """stream: a hipStream_t handle shared with the caller (everything the backend queues is ordered with the caller's
         work on it), or None / 0 for a stream the backend owns. torch's *default* stream has handle 0: to share ordering
         with torch, make a torch.cuda.Stream() current and pass its .cuda_stream (bench.py does)."""
@@ -169,6 +171,8 @@ class RenderHip:
         if rc != 0:
             raise BackendError(rc, self._L.rptr_hip_last_error(None).decode())
         self._h = h
+        for k, v in (options or {}).items():  # rptr_hip_set_option right after the create: in force for initialize / set_scene
+            self.set_option(k, v)
         # public data members the app mutates directly (render_backend.h:69-76)
         self.params = abi.RenderParams.default()
         self.lighting_params = abi.LightSamplingConfig.default()
@@ -298,17 +302,15 @@ class RenderHip:
         """0: no per-stage events, 1: around the closest-hit traversal launches, 2: every stage (default)."""
         self._check(self._L.rptr_hip_set_stage_timing(self._h, int(level)))
 
-    def set_frame_schedule(self, one_launch_per_frame):
-        """False: a frame is a sequence of stage launches; True: ONE launch driven from device-side queues (csrc/kernels.h rp_k_frame).
-        Bit-identical images either way (include/rptr_hip.h)."""
-        self._check(self._L.rptr_hip_set_frame_schedule(self._h, int(one_launch_per_frame)))  # False / 0 stages, True / 1 one launch, 2 streaming pair
+    def set_option(self, key, value):
+        """rptr_hip_set_option (include/rptr_hip.h "Options"): takes effect at the call the header names for the key
+        (initialize / set_scene / the next frame / communicator set-up)."""
+        self._check(self._L.rptr_hip_set_option(self._h, key.encode(), int(value)))
 
-    def frame_schedule(self):
-        """(one launch per frame?, bounces that had global queues in the last finished frame, their lengths, (claim attempts, idle attempts))"""
-        one, pub = C.c_int32(), C.c_int32()
-        q = (C.c_uint32 * 16)()
-        self._check(self._L.rptr_hip_get_frame_schedule(self._h, C.byref(one), C.byref(pub), q, 16))
-        return int(one.value), int(pub.value), [int(v) for v in (q[:4] if pub.value < 0 else q[:max(0, pub.value)])], (int(q[8]), int(q[9]))
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._check(self._L.rptr_hip_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
 
     def end_frame(self, cmd_stream=None, variant_idx=0):
         pass  # resolve (process_samples) is sequenced inside draw_frame on the same stream

@@ -17,10 +17,9 @@ UNITS = [
     ("bvh_build", "bvh_build.cpp", []),
     ("k_extend", "k_extend.hip", []),
 ] + [("k_shade_v%d" % v, "k_shade.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)] \
-  + [("k_tail_v%d" % v, "k_tail.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)] \
-  + [("k_frame_v%d" % v, "k_frame.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)]
+  + [("k_tail_v%d" % v, "k_tail.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)]
 SOURCES = sorted({u[1] for u in UNITS})
-HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_comm.h", "lbvh.h", "ploc.h", "dtraverse.h", "dstream.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
+HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_comm.h", "lbvh.h", "ploc.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
            "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
 OBJ_DIR = os.path.join(CSRC, "obj")
 

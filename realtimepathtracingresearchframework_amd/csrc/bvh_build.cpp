@@ -9,6 +9,11 @@
 #include <thread>
 
 namespace rptr {
+
+BuildTuning &build_tuning() {
+    static BuildTuning t;
+    return t;
+}
 namespace {
 
 struct Box {
@@ -321,14 +326,7 @@ void collapse_bvh4(const BuiltTree &t, Wide4Tree &out, int rule, int fallback) {
             ++pos;
         }
     };
-    if (rule < 0) { // (read per call: tests switch it)
-        rule = fallback;
-        if (const char *e = getenv("RPTR_COLLAPSE")) {
-            if (!strcmp(e, "even")) rule = COLLAPSE_EVEN;
-            else if (!strcmp(e, "greedy")) rule = COLLAPSE_GREEDY;
-            else if (!strcmp(e, "dp") || !strcmp(e, "optimal")) rule = COLLAPSE_OPTIMAL;
-        }
-    }
+    if (rule < 0) rule = build_tuning().collapse_rule >= 0 ? build_tuning().collapse_rule : fallback;
     const bool even_rule = rule == COLLAPSE_EVEN; // the device's rebuild rule (lbvh.h rp_k_lbvh_emit)
     const bool dp_rule = rule == COLLAPSE_OPTIMAL; // bvh_build.h
     const size_t nb = t.nodes.size();
@@ -540,7 +538,7 @@ void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t ma
     std::vector<uint32_t> nn;
     std::vector<uint32_t> slot;
     size_t top_k = RP_PLOC_TOP_DEFAULT; // stop clustering at this many clusters and put a binned-SAH tree over them: the device builder's default (csrc/ploc.h)
-    if (const char *e = getenv("RPTR_PLOC_TOP")) top_k = std::max<size_t>(1, (size_t)atoll(e));
+    if (build_tuning().ploc_top > 0) top_k = build_tuning().ploc_top;
     while (cur.size() > top_k) {
         const size_t m = cur.size();
         nn.resize(m);
@@ -614,7 +612,7 @@ void build_bvh2_ploc(const BuildPrim *prims, uint32_t n, int radius, uint32_t ma
     }
     const uint32_t root = cur[0];
     // leaf collapse by SAH: cost of a subtree = min(triangles as one leaf, 1 + area-weighted cost of the children)
-    const int force_leaf = getenv("RPTR_PLOC_LEAF") ? atoi(getenv("RPTR_PLOC_LEAF")) : 0; // the device's rule instead: a range of <= k triangles is a leaf
+    const int force_leaf = build_tuning().ploc_leaf; // the device's rule instead: a range of <= k triangles is a leaf
     std::vector<float> cost(nodes.size());
     std::vector<uint8_t> is_leaf(nodes.size(), 0);
     for (size_t i = 0; i < nodes.size(); ++i) { // children are created before their parents: ascending order is bottom-up

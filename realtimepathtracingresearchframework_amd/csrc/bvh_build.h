@@ -59,6 +59,15 @@ struct Wide4Tree {
 //   COLLAPSE_EVEN: every inner child hands its two children up (the device's rebuild, csrc/lbvh.h).
 // rule < 0: RPTR_COLLAPSE = optimal | dp | greedy | even, default `fallback`.
 enum { COLLAPSE_GREEDY = 0, COLLAPSE_EVEN = 1, COLLAPSE_OPTIMAL = 2 };
+// Builder experiments (library options "collapse", "ploc_top", "ploc_leaf", include/rptr_hip.h; the caller -- build_host_bvh in rptr_hip.hip --
+// sets them from the handle's options before it builds; nothing here reads the environment). collapse_rule < 0: the caller's fallback rule;
+// ploc_top 0: RP_PLOC_TOP_DEFAULT; ploc_leaf 0: leaves by SAH.
+struct BuildTuning {
+    int collapse_rule = -1;
+    size_t ploc_top = 0;
+    int ploc_leaf = 0;
+};
+BuildTuning &build_tuning();
 // clusters at which PLOC stops and a binned-SAH tree takes over: ONE default for the device builder (csrc/ploc.h RP_PLOC_TOP) and its host
 // statement (build_bvh2_ploc), so that "the same tree" does not depend on a test setting RPTR_PLOC_TOP
 #define RP_PLOC_TOP_DEFAULT 65536

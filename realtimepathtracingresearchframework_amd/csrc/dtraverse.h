@@ -198,7 +198,7 @@ template <bool ANY, bool COUNT, int NODE_MIN = (ANY ? RP_NODE_MIN_ANY : RP_NODE_
 RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor, int *gstack, Load load, Done done, Alpha alpha,
                           uint32_t &n_nodes, uint32_t &n_tris, int *ext_stack = nullptr) {
     // EXTLDS: the caller owns the LDS part of the stacks (RP_LDS_STACK * RP_TRAVERSE_BLOCK ints) and shares it with its other phases
-    // (kernels.h rp_k_frame: the closest-hit traversal, the shade scratch and the shadow-ray traversal of a block take turns on one arena)
+    // (kernels.h rp_k_tail: the closest-hit traversal, the shade scratch and the shadow-ray traversal of a block take turns on one arena)
     __shared__ int lds_stack_own[EXTLDS ? 1 : RP_LDS_STACK * RP_TRAVERSE_BLOCK];
     int *const lds_stack = EXTLDS ? ext_stack : lds_stack_own;
     // The two scheduling thresholds are the scene's (RpScene.node_min / refill_min, chosen at set_scene from the tree: rptr_hip.hip

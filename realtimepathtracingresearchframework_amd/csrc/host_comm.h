@@ -195,14 +195,13 @@ int comm_setup_local(rptr_hip *h, int transport) {
     HIP_TRY(h, hipSetDevice(h->device));
     RptrComm *c = new RptrComm();
     c->transport = transport;
-    if (const char *e = getenv("RPTR_COMM_SELF")) c->self = atoi(e) != 0;
+    c->self = h->opt.v[OPT_COMM_SELF] != 0;
     h->comm = c;
     // the gather's kernels are tiny next to the persistent traversal launches they run beside: a high-priority queue gets them their CU
-    // slots first (RPTR_COMM_PRIORITY=0: a plain stream)
+    // slots first (option "comm_priority" = 0: a plain stream)
     {
         int least = 0, greatest = 0;
-        const char *e = getenv("RPTR_COMM_PRIORITY");
-        if ((!e || atoi(e) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        if (h->opt.v[OPT_COMM_PRIORITY] != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
             HIP_TRY(h, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
         else
             HIP_TRY(h, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -397,10 +396,11 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
         for (int j = 0; j < i; ++j) distinct = distinct && handles[j]->device != h->device;
     }
     int transport = distinct ? COMM_RCCL : COMM_COPY; // RCCL refuses two ranks on one device: such rigs move the rows with copies
-    if (const char *e = getenv("RPTR_COMM_TRANSPORT")) {
-        if (!strcmp(e, "copy")) transport = COMM_COPY;
-        else if (!strcmp(e, "rccl")) transport = COMM_RCCL;
-        else if (!strcmp(e, "peer")) transport = COMM_PEER;
+    switch (handles[0]->opt.v[OPT_COMM_TRANSPORT]) { // option "comm_transport" of handle 0 (0: the choice above)
+    case 1: transport = COMM_RCCL; break;
+    case 2: transport = COMM_COPY; break;
+    case 3: transport = COMM_PEER; break;
+    default: break;
     }
     RcclApi &R = rccl();
     if (transport == COMM_RCCL && !R.error.empty()) return fail(handles[0], RPTR_E_UNSUPPORTED, "%s", R.error.c_str());
@@ -409,7 +409,7 @@ int rptr_hip_comm_init_all(rptr_hip_t *const *handles, int n) {
             if (handles[i]->device != handles[0]->device) {
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, handles[i]->device, handles[0]->device) != hipSuccess || !can)
-                    return fail(handles[i], RPTR_E_UNSUPPORTED, "RPTR_COMM_TRANSPORT=peer: device %d cannot access device %d's memory", handles[i]->device,
+                    return fail(handles[i], RPTR_E_UNSUPPORTED, "comm_transport = peer: device %d cannot access device %d's memory", handles[i]->device,
                                 handles[0]->device);
             }
     for (int i = 0; i < n; ++i) {

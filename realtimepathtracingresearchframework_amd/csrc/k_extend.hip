@@ -41,16 +41,6 @@ void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, c
     });
 }
 
-void rp_launch_stream_trace(const RpLaunch &l, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
-                            const RpStream &sx, int *gstack) {
-    rp_pick(single, [&](auto S) {
-        rp_pick(table, [&](auto T) { rp_launch_kernel(l, rp_k_stream_trace<decltype(S)::value, decltype(T)::value>, RP_TRAVERSE_BLOCK, sc, f, ps, sq, sx, gstack); });
-    });
-}
-hipError_t rp_stream_trace_blocks_per_cu(int *out) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_stream_trace<true, false>, RP_TRAVERSE_BLOCK, 0);
-}
-
 hipError_t rp_extend_blocks_per_cu(int *out) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, rp_k_extend<false, true, false, false, false>, RP_TRAVERSE_BLOCK, 0);
 }

@@ -19,7 +19,6 @@
 // with ONE global atomic; persistent consumers pull 256 entries per atomic.
 #pragma once
 #include "dtraverse.h"
-#include "dstream.h"
 #include <type_traits>
 
 // Round 4 (less path-state traffic, every value exact): the continuation ray's t_min is a function of its origin and the path length
@@ -62,63 +61,6 @@ struct RpCounters {
 };
 
 #define RP_CHUNK 1024     // entries a producer block publishes per global atomic
-
-// ---- path state that crosses workgroups INSIDE a launch (rp_k_frame below; SH = true)
-// Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores (MI355X_MICROARCH.md
-// "inter-workgroup visibility"): what one block writes and another block of the same launch reads goes through device-coherent accesses on
-// both sides -- `sc0 sc1` buffer loads / stores (loads bypass the L1, stores write through the L2; a 16-byte sc1 access costs what a plain
-// one does, and path state is read once per bounce, so nothing is lost in the L1) -- plus a drained store queue before the entry that
-// names the path is published. SH = false (the stand-alone stages: a kernel boundary lies between producer and consumer) compiles to the
-// plain accesses it always was.
-typedef uint32_t rp_u4v __attribute__((ext_vector_type(4)));
-typedef uint32_t rp_u2v __attribute__((ext_vector_type(2)));
-#ifndef RP_AUX_COHERENT
-#define RP_AUX_COHERENT 17 // sc0 | sc1
-#endif
-RP_DEV __amdgpu_buffer_rsrc_t rp_rsrc(const void *base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7FFFFFFF, 0x00020000); }
-template <bool SH>
-RP_DEV float4 rp_ld4(const float4 *a, uint32_t i) {
-    if (!SH) return a[i];
-    const rp_u4v v = __builtin_amdgcn_raw_buffer_load_b128(rp_rsrc(a), int(i * 16u), 0, RP_AUX_COHERENT);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-template <bool SH>
-RP_DEV void rp_st4(float4 *a, uint32_t i, float4 x) {
-    if (!SH) {
-        a[i] = x;
-        return;
-    }
-    const rp_u4v v = {__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, rp_rsrc(a), int(i * 16u), 0, RP_AUX_COHERENT);
-}
-template <bool SH>
-RP_DEV float2 rp_ld2(const float2 *a, uint32_t i) {
-    if (!SH) return a[i];
-    const rp_u2v v = __builtin_amdgcn_raw_buffer_load_b64(rp_rsrc(a), int(i * 8u), 0, RP_AUX_COHERENT);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-template <bool SH>
-RP_DEV void rp_st2(float2 *a, uint32_t i, float2 x) {
-    if (!SH) {
-        a[i] = x;
-        return;
-    }
-    const rp_u2v v = {__float_as_uint(x.x), __float_as_uint(x.y)};
-    __builtin_amdgcn_raw_buffer_store_b64(v, rp_rsrc(a), int(i * 8u), 0, RP_AUX_COHERENT);
-}
-template <bool SH>
-RP_DEV uint32_t rp_ld1(const uint32_t *a, uint32_t i) { // i: element index
-    if (!SH) return a[i];
-    return __builtin_amdgcn_raw_buffer_load_b32(rp_rsrc(a), int(i * 4u), 0, RP_AUX_COHERENT);
-}
-template <bool SH>
-RP_DEV void rp_st1(uint32_t *a, uint32_t i, uint32_t x) {
-    if (!SH) {
-        a[i] = x;
-        return;
-    }
-    __builtin_amdgcn_raw_buffer_store_b32(x, rp_rsrc(a), int(i * 4u), 0, RP_AUX_COHERENT);
-}
 
 // ---- wave64 helpers
 // reserves one slot per flagged lane with one atomic per wave (counter may live in LDS or global memory)
@@ -221,16 +163,15 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, V3
 // (pt_megakernel.glsl:354-358), so the lane carries it through the traversal and hands it back in the path state.
 // SINGLE: the scene has one instance record; queries start inside it (dtraverse.h).
 // LOCAL: `queue` / `cursor` are a block-local list and its cursor in LDS (rp_k_tail).
-// SH / EXTLDS (rp_k_frame): path state through device-coherent accesses; the stacks' LDS belongs to the caller. base: the path id of entry 0
-// when the queue is the identity (FIRST, queue == NULL)
-template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE, int LDSTOP = 0, bool SH = false, bool EXTLDS = false>
+// EXTLDS (rp_k_tail): the stacks' LDS belongs to the caller.
+template <bool COUNT, bool FIRST, bool ALPHA, bool SINGLE, bool LOCAL, bool TABLE, int LDSTOP = 0, bool EXTLDS = false>
 RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const uint32_t *queue, uint32_t n, uint32_t *cursor, RpCounters *ctr,
-                           int *gstack, uint32_t base = 0u, int *ext_stack = nullptr) {
+                           int *gstack, int *ext_stack = nullptr) {
     uint32_t n_nodes = 0, n_tris = 0;
     uint32_t lane_rng = 0, lane_rng_in = 0; // ALPHA only
     uint32_t lane_p = 0; // the path whose ray this lane traces
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
-        const uint32_t p = (FIRST && !queue) ? base + i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
+        const uint32_t p = (FIRST && !queue) ? i : queue[i]; // FIRST: the first queue is the identity (NULL) unless the caller stored it
         lane_p = p;
         if (FIRST) {
             RpRng rng;
@@ -243,13 +184,13 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
             tmax = 2.e32f;
             if (ALPHA) lane_rng = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? rng.s : rp_alpha_seed(f, p);
         } else {
-            const float4 o = rp_ld4<SH>(ps.ray_o, p), d = rp_ld4<SH>(ps.ray_d, p);
+            const float4 o = ps.ray_o[p], d = ps.ray_d[p];
             ro = xyz(o);
             rd = xyz(d);
             tmin = rp_geometry_scale_to_tmin(ro, o.w); // (what the shade computed for its shadow ray: same operands, same bits)
             tmax = 1e20f;
             if (ALPHA)
-                lane_rng = lane_rng_in = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(d.w) : rp_ld1<SH>(ps.alpha_rng, p);
+                lane_rng = lane_rng_in = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? __float_as_uint(d.w) : ps.alpha_rng[p];
         }
         return true;
     };
@@ -259,11 +200,11 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
         if (ALPHA) {
             if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
-                if (FIRST || lane_rng != lane_rng_in) rp_st1<SH>(ps.alpha_rng, p, lane_rng);
+                if (FIRST || lane_rng != lane_rng_in) ps.alpha_rng[p] = lane_rng;
             } else if (FIRST)
-                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.ray_d), 4u * p + 3u, lane_rng); // the first shade takes it from here (f.alpha_test)
+                (reinterpret_cast<uint32_t *>(ps.ray_d))[4u * p + 3u] = lane_rng; // the first shade takes it from here (f.alpha_test)
             else if (lane_rng != lane_rng_in)
-                rp_st1<SH>(reinterpret_cast<uint32_t *>(ps.ray_d), 4u * p + 3u, lane_rng);
+                (reinterpret_cast<uint32_t *>(ps.ray_d))[4u * p + 3u] = lane_rng;
         }
     };
     auto alpha = [&](uint32_t, int inst_idx, int, int geom, int prim, float u, float v) -> bool {
@@ -297,7 +238,7 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_extend_ldstop(RpScene sc, RpFrame f, RpP
 // ALPHA: shadow rays test alpha-tested candidates with a generator seeded per candidate from (primitive ^ frame_id,
 // instance ^ frame_offset, pixel), pt_megakernel.glsl:251-262 -- independent of the order in which candidates turn up.
 // ids: the compacted path ids of the shadow rays (sq.ids, or the tail kernel's block-local list: LOCAL)
-template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL, int LDSTOP = 0, bool SH = false, bool EXTLDS = false>
+template <bool COUNT, bool ALPHA, bool SINGLE, bool LOCAL, int LDSTOP = 0, bool EXTLDS = false>
 RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *ids, uint32_t n, uint32_t *cursor,
                             RpCounters *ctr, int *gstack, int *ext_stack = nullptr) {
     uint32_t n_nodes = 0, n_tris = 0;
@@ -314,7 +255,7 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
     };
     auto load = [&](uint32_t i, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool {
         const uint32_t p = ids[i];
-        const float4 o = rp_ld4<SH>(ps.ray_o, p), d = sq.d[p]; // the vertex: origin of the shadow ray and of the continuation ray
+        const float4 o = ps.ray_o[p], d = sq.d[p]; // the vertex: origin of the shadow ray and of the continuation ray
         ro = xyz(o);
         rd = xyz(d);
         tmin = rp_geometry_scale_to_tmin(ro, o.w);
@@ -325,11 +266,11 @@ RP_DEV void rp_connect_body(const RpScene &sc, const RpFrame &f, const RpPathSta
         if (h.inst_idx < 0) { // visible: NEE contribution arrives (nee.glsl:76-84)
             const uint32_t p = ids[i];
             const float4 c = sq.contrib[p];
-            float4 il = rp_ld4<SH>(ps.illum, p);
+            float4 il = ps.illum[p];
             il.x += c.x;
             il.y += c.y;
             il.z += c.z;
-            rp_st4<SH>(ps.illum, p, il);
+            ps.illum[p] = il;
         }
     };
     rp_wave_trace<true, COUNT, RP_NODE_MIN_ANY, RP_REFILL_MIN_ANY, ALPHA, SINGLE, LOCAL, LDSTOP, EXTLDS>(sc, n, cursor, gstack, load, done, alpha, n_nodes, n_tris,
@@ -392,7 +333,7 @@ RP_DEV const T &rp_kernarg(uint32_t offset) {
 #else
 #define RP_RELOAD_ARGS
 #endif
-// the LDS buffers of rp_shade_body when the caller owns them (EXTLDS; rp_k_frame): `next` and `shadow` (RP_CHUNK words each) outlive the call
+// the LDS buffers of rp_shade_body when the caller owns them (EXTLDS; rp_k_tail): `next` and `shadow` (RP_CHUNK words each) outlive the call
 // (the survivors and the shadow rays of the chunk), `list` (RP_CHUNK words), `ris_req` (2048 floats) and `ris_contrib` (4096 floats; LIGHTS
 // only) are scratch the caller may reuse between calls
 struct RpShadeLds {
@@ -401,17 +342,11 @@ struct RpShadeLds {
 };
 #define RP_SHADE_RIS_REQ_FLOATS ((256 / 64) * 64 * 8)
 #define RP_SHADE_RIS_CONTRIB_FLOATS ((256 / 64) * 64 * RPTR_BINNED_LIGHTS_BIN_MAX_SIZE)
-// SH / EXTLDS / base: as for rp_extend_body
-// STREAM (rp_k_stream_shade): the hit records were written by ANOTHER workgroup (read around the L1), and the chunk leaves ONE list of
-// items -- path id | RP_ITEM_CONT (the path goes on) | RP_ITEM_SHADOW (a shadow ray is pending) -- in `next` instead of two lists
-#define RP_ITEM_CONT 0x40000000u
-#define RP_ITEM_SHADOW 0x80000000u
-#define RP_ITEM_PATH 0x3FFFFFFFu
-#define RP_ITEM_NONE 0xFFFFFFFFu // padding of a sealed chunk: no item
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE, bool SH = false, bool EXTLDS = false, bool STREAM = false>
+// EXTLDS: as for rp_extend_body
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool LOCAL, bool TABLE, bool EXTLDS = false>
 RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq, const uint32_t *order, const uint32_t n,
                           uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count, RpCounters *ctr, uint32_t *&local_next, uint32_t &n_next,
-                          uint32_t *&local_shadow, uint32_t &n_shadow, uint32_t base = 0u, const RpShadeLds *ext = nullptr) {
+                          uint32_t *&local_shadow, uint32_t &n_shadow, const RpShadeLds *ext = nullptr) {
     __shared__ uint32_t s_next_own[EXTLDS ? 1 : RP_CHUNK], s_shadow_own[EXTLDS ? 1 : RP_CHUNK];
     __shared__ uint32_t s_nn, s_ns, s_base;
     __shared__ uint32_t s_stat[3];
@@ -450,8 +385,8 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             uint32_t pp = 0;
             bool is_hit = false;
             if (valid) {
-                pp = (FIRST && !order) ? base + i : order[i];
-                is_hit = (STREAM ? __float_as_int(rp_ld2<true>(reinterpret_cast<const float2 *>(ps.hit_ids), pp).x) : ps.hit_ids[pp].x) >= 0;
+                pp = (FIRST && !order) ? i : order[i];
+                is_hit = ps.hit_ids[pp].x >= 0;
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
             if (valid && is_hit) s_list[ah] = pp;
@@ -538,7 +473,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
                     if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM))
-                        rng.s = rp_ld1<SH>(reinterpret_cast<const uint32_t *>(ps.ray_d), 4u * p + 3u); // alpha tests of the first extend may have drawn from it
+                        rng.s = (reinterpret_cast<const uint32_t *>(ps.ray_d))[4u * p + 3u]; // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
                         if (sf.sample_index == sf.frame_id && int(sf.frame) == f.batch_frames - 1) {
@@ -556,9 +491,9 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         tex_fp = rp_dpdxy_to_footprint(ray_dir, dpdx, dpdy);
                     }
                 } else {
-                    const float4 ro4 = rp_ld4<SH>(ps.ray_o, p), rd4 = rp_ld4<SH>(ps.ray_d, p);
-                    const float4 thr4 = rp_ld4<SH>(ps.thr, p);
-                    const float4 il4 = rp_ld4<SH>(ps.illum, p);
+                    const float4 ro4 = ps.ray_o[p], rd4 = ps.ray_d[p];
+                    const float4 thr4 = ps.thr[p];
+                    const float4 il4 = ps.illum[p];
                     rng = rp_rng_resume<TABLE>(f, p, __float_as_uint(rd4.w));
                     total_t = ro4.w;
                     ray_origin = xyz(ro4);
@@ -568,21 +503,16 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     prev_bounce_pdf = thr4.w;
                     bounce = __float_as_int(il4.w);
                     if (TEX) {
-                        const float4 fp = rp_ld4<SH>(ps.footprint, p);
+                        const float4 fp = ps.footprint[p];
                         tex_fp = M2{v2(fp.x, fp.y), v2(fp.z, fp.w)};
                     }
                 }
-                const float4 hit4 = rp_ld4<STREAM>(ps.hit_tuv, p);
-                int2 ids;
-                if (STREAM) {
-                    const float2 idf = rp_ld2<true>(reinterpret_cast<const float2 *>(ps.hit_ids), p);
-                    ids = make_int2(__float_as_int(idf.x), __float_as_int(idf.y));
-                } else
-                    ids = ps.hit_ids[p];
+                const float4 hit4 = ps.hit_tuv[p];
+                const int2 ids = ps.hit_ids[p];
                 if (ids.x < 0) {
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
-                    rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
+                    ps.illum[p] = f4(illum, __int_as_float(bounce));
                     if (FIRST && aov_px >= 0) { // pt_megakernel.glsl:482-487
                         rp_store_geometry_aovs(f, aov_px, v3s(0.0f), v3s(2.e32f), aov_jitter);
                         rp_store_material_aovs(f, aov_px, v3s(0.0f), 1.0f, 1.0f);
@@ -803,22 +733,18 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         }
                         if (survive) {
                             alive = true;
-                            rp_st4<SH>(ps.ray_d, p, f4(ray_dir, __uint_as_float(rng.s)));
-                            rp_st4<SH>(ps.thr, p, f4(throughput, prev_bounce_pdf));
-                            if (TEX) rp_st4<SH>(ps.footprint, p, make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y));
+                            ps.ray_d[p] = f4(ray_dir, __uint_as_float(rng.s));
+                            ps.thr[p] = f4(throughput, prev_bounce_pdf);
+                            if (TEX) ps.footprint[p] = make_float4(tex_fp.c0.x, tex_fp.c0.y, tex_fp.c1.x, tex_fp.c1.y);
                         }
                     }
                 }
                 // the vertex (ip_p: a surviving path's ray_origin is ip_p) and the path length up to it: what the shadow ray and the continuation
                 // ray start from (their offset = rp_geometry_scale_to_tmin of the two, recomputed by connect / extend)
-                if (alive || has_shadow) rp_st4<SH>(ps.ray_o, p, f4(ip_p, total_t));
-                rp_st4<SH>(ps.illum, p, f4(illum, __int_as_float(bounce)));
+                if (alive || has_shadow) ps.ray_o[p] = f4(ip_p, total_t);
+                ps.illum[p] = f4(illum, __int_as_float(bounce));
             }
-            if (STREAM) {
-                const bool any = alive || has_shadow;
-                const uint32_t at = rp_wave_append(&s_nn, any);
-                if (any) s_next[at] = p | (alive ? RP_ITEM_CONT : 0u) | (has_shadow ? RP_ITEM_SHADOW : 0u);
-            } else {
+            {
                 const uint32_t at = rp_wave_append(&s_nn, alive);
                 if (alive) s_next[at] = p;
                 const uint32_t sat = rp_wave_append(&s_ns, has_shadow);
@@ -888,7 +814,7 @@ __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>()
 template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
 __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
-    // One arena for the phases that take turns (round 4, as in rp_k_frame): the LDS stacks of the closest-hit traversal, the shade phase's
+    // One arena for the phases that take turns (round 4): the LDS stacks of the closest-hit traversal, the shade phase's
     // scratch (regrouped list, light-candidate exchange) and the LDS stacks of the shadow-ray traversal -- 33 KB per block instead of 64 (37
     // instead of 88 with triangle lights). A tail block issues next to nothing for 0.16 ms of every frame; with eleven frames in flight one
     // or two of them sit on every CU at any time, and what they hold is LDS the traversal blocks of the other frames want.
@@ -914,726 +840,19 @@ __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPat
         for (int b = first_bounce; b < f.rp.max_path_depth && n > 0; ++b) {
             if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
             __syncthreads();
-            rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE, 0, false, true>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack, 0u, stack);
+            rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE, 0, true>(sc, f, ps, s_cur, n, &s_cursor[0], ctr, gstack, stack);
             __syncthreads();
             uint32_t *next = nullptr, *shadow = nullptr;
             uint32_t n_next = 0, n_shadow = 0;
-            rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, false, true>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow, 0u,
+            rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, true>(sc, f, ps, sq, s_cur, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow,
                                                                                   &lds);
             __syncthreads();
-            rp_connect_body<false, ALPHA, SINGLE, true, 0, false, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack, stack);
+            rp_connect_body<false, ALPHA, SINGLE, true, 0, true>(sc, f, ps, sq, shadow, n_shadow, &s_cursor[1], ctr, gstack, stack);
             __syncthreads();
             if (threadIdx.x < n_next) s_cur[threadIdx.x] = next[threadIdx.x]; // survivors: at most n <= RP_TAIL_CHUNK
             n = n_next;
         }
     }
-}
-
-// ------------------------------------------------------------------ frame: the whole frame in ONE launch, driven from device-side queues
-// (the reference's megakernel is one dispatch per frame: vulkan/render_pipeline_vulkan.cpp:253-261, render_vulkan.cpp:2961-3059)
-//
-// The stand-alone stages make a frame a chain of ~10 dependent launches, and every launch lasts as long as its slowest ray: ONE frame
-// rendered alone takes 2.06 ms where frames in flight reach 1.3 ms (C2), and a 1/8 frame (one rank of an 8-GPU split) 0.79 ms instead of
-// 0.18 (profiles/r03_notes.md section 4). Paths are independent, so nothing in a frame needs a grid-wide step: rp_k_frame replaces the
-// launch boundaries by CHUNK-level dependencies. A block
-//   1. takes a work item: a SLOT of RP_CHUNK consecutive entries of some bounce's queue -- a slot of a bounce >= 1 from the ring of
-//      ready slots if there is one (deeper bounces first: paths end sooner, queues stay short), else up to k0 slots of bounce 0 (the
-//      identity over the path ids; several at a time so that the block-local traversal has rays to refill its lanes with),
-//   2. runs the slot's paths through extend -> shade -> connect with the device code of the stand-alone kernels (rp_*_body, LOCAL lists in
-//      LDS: what rp_k_tail does), so the image is bit-identical to theirs,
-//   3. appends the survivors to the NEXT bounce's global queue -- whichever block gets the slot they land in continues them, which is what
-//      keeps 64 lanes per wave busy on the second and third bounce where rp_k_tail's block-local lists would thin out -- or, from bounce
-//      n_pub - 1 on (queues of a few thousand paths), keeps them and runs them to their end like rp_k_tail.
-// A straggler -- a ray that grazes the height field through hundreds of nodes -- now holds back its own block, not the frame.
-//
-// Queue protocol. Nobody polls a slot: the events that make work say so. (A first version had every idle block walk tail / head / done
-// words and compare-and-swap a shared head: 5 M claim attempts for 11 thousand slots, 400 ms per frame -- one device word sustains ~88
-// atomics per microsecond, MI355X_MICROARCH.md "dequeue".)
-//   tail[b]       entries reserved in bounce b's queue: one atomicAdd per chunk of survivors (bounce 0: preset to the number of paths)
-//   commit[b][s]  entries of slot s whose ids are in memory. The producer whose add makes it RP_CHUNK pushes the slot into the ring.
-//   done[b]       slots of bounce b whose paths have been traced, shaded and whose survivors have been published
-//   final[b]      bounce b's tail will not grow: bounce b - 1 is final and done[b - 1] covers all of its slots (bounce 0: preset). Whoever
-//                 observes that first (after its own add to done[b - 1], or after setting final[b - 1]) sets the flag -- a compare-and-swap
-//                 elects one -- and pushes the bounce's last, partly filled slot. The frame is complete when the last published bounce is
-//                 final and done.
-//   ring          64-bit entries (frame epoch | bounce | slot | entries; no memset of the ring), written at a position reserved with an
-//                 atomicAdd on ring_tail, read by the block that holds the position's TICKET (an atomicAdd on ring_head: rp_fq_claim)
-//   head0         tickets of bounce 0 (atomicAdd: never fails)
-// Visibility (MI355X_MICROARCH.md "inter-workgroup visibility"): per-XCD L2s are not coherent and a CU's L1 is never refreshed by other
-// CUs' stores. Consumers read path state and ids around the L1 (SH accessors above); a producer drains its stores in every wave, joins at
-// a barrier, and ONE lane issues an agent-scope release (buffer_wbl2 sc1 + s_waitcnt) before the commit -- measured: sc1 "write-through"
-// stores drained with s_waitcnt vmcnt(0) alone were NOT enough (stale ids on the second frame of a handle, faults at 4 blocks per CU;
-// with the release: bit-identical on every size tried) --; the control words are agent-scope atomics.
-#define RP_FQ_MAX 8 // bounces whose queues can be global; later bounces always run block-local
-#ifndef RP_FRAME_WAVES
-#define RP_FRAME_WAVES 4 // blocks per CU the frame kernel is compiled for (VGPR budget: its shade phase)
-#endif
-struct RpFqState {
-    uint32_t tail[RP_FQ_MAX], done[RP_FQ_MAX], final[RP_FQ_MAX];
-    uint32_t head0;                 // slots of bounce 0 handed out
-    uint32_t ring_tail, ring_head;  // the ring of ready slots
-    uint32_t complete;              // the frame is done: idle blocks leave
-    uint32_t polls, idle_polls;     // diagnostics: claim attempts, attempts that found nothing to do (added once per block)
-    uint32_t timeout;               // a block gave up waiting for work that never came (a protocol error: the host reports it)
-    uint32_t bad_ids;               // queue entries that named no path (>= capacity): never on a correct run, reported by the host
-    unsigned long long t_claim, t_extend, t_shade, t_connect, t_publish, t_fence, t_total; // -DRP_FRAME_PROF: 100 MHz ticks summed over the blocks (lane 0)
-};
-struct RpFrameQueues {
-    RpFqState *st;
-    uint32_t *ids;               // path ids of bounce b >= 1 at ids + (b - 1) * capacity
-    uint32_t *commit;            // one word per slot, bounce b >= 1 at commit + (b - 1) * slots
-    unsigned long long *ring;    // ready slots (RP_FQ_MAX * slots entries: every slot is pushed once per frame at most)
-    uint32_t slots;
-    uint32_t epoch;              // this frame's tag in ring entries (1 .. 65535; the ring is zeroed when it is allocated)
-    int32_t n_pub;               // bounces 0 .. n_pub - 1 have global queues (1 <= n_pub <= RP_FQ_MAX)
-    int32_t k0;                  // slots of bounce 0 a block takes at a time (1 when n_pub == 1)
-    uint32_t capacity;           // path ids are below this
-    uint32_t dbg;                // RPTR_FRAME_DBG (experiments): bit 0 no release fence before a commit
-};
-struct RpFqWork {
-    uint32_t b, slot, m, n; // bounce (~0u: the frame is complete), first slot, slots, entries
-};
-RP_DEV uint32_t rp_fq_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RP_DEV uint32_t rp_fq_add(uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-RP_DEV uint32_t *rp_fq_ids(const RpFrameQueues &fq, uint32_t b) { return fq.ids + size_t(b - 1u) * fq.capacity; }
-RP_DEV uint32_t *rp_fq_commit(const RpFrameQueues &fq, uint32_t b) { return fq.commit + size_t(b - 1u) * fq.slots; }
-// every wave, before a block barrier behind which ANOTHER wave reads what this one stored device-coherently: a barrier orders the waves,
-// not their stores (sc1 accesses go around the L1 that orders the plain ones of a workgroup)
-RP_DEV void rp_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// (one lane) a slot of bounce b with n entries is ready
-RP_DEV void rp_fq_push(const RpFrameQueues &fq, uint32_t b, uint32_t slot, uint32_t n) {
-    const uint32_t i = rp_fq_add(&fq.st->ring_tail, 1u);
-    const unsigned long long e = ((unsigned long long)fq.epoch << 48) | ((unsigned long long)b << 44) | ((unsigned long long)slot << 12) | n;
-    __hip_atomic_store(fq.ring + i, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// (one lane) after an add to done[b1 - 1] or after final[b1 - 1] was set: bounce b1 may have become final (b1 == n_pub: the frame complete)
-RP_DEV void rp_fq_try_finalize(const RpFrameQueues &fq, uint32_t b1) {
-    RpFqState *const st = fq.st;
-    for (;; ++b1) {
-        const uint32_t b = b1 - 1u;
-        if (rp_fq_ld(&st->final[b]) == 0u) return;
-        rp_drain_stores(); // (a final bounce's tail stands still: read it after the flag)
-        const uint32_t t = rp_fq_ld(&st->tail[b]), dn = rp_fq_ld(&st->done[b]);
-        if (dn != (t + RP_CHUNK - 1u) / RP_CHUNK) return;
-        if (b1 == (uint32_t)fq.n_pub) {
-            __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        uint32_t expect = 0u;
-        if (!__hip_atomic_compare_exchange_strong(&st->final[b1], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        // this lane made bounce b1 final: its last slot, if partly filled, will never be completed by a producer
-        const uint32_t t1 = rp_fq_ld(&st->tail[b1]);
-        if (t1 % RP_CHUNK != 0u) rp_fq_push(fq, b1, t1 / RP_CHUNK, t1 % RP_CHUNK);
-    }
-}
-// (one lane) the block's next work item. Every block holds a TICKET of the ring -- position `ticket` belongs to it and to nobody else, so
-// taking a ready slot is a load of the block's own entry, no compare-and-swap race of a thousand blocks for one head word (which is what
-// a shared head cost: two thirds of every block's time went into claiming) -- and takes a new one when it has used it. A ready slot waits
-// for the holder of its ticket to finish the chunk it is working on; in the meantime the holder works on bounce 0.
-struct RpFqClaimState {
-    uint32_t ticket;
-    bool have_ticket, b0_exhausted;
-    uint32_t polls, idle_polls;
-};
-RP_DEV RpFqWork rp_fq_claim(const RpFrameQueues &fq, RpFqClaimState &cs) {
-    RpFqState *const st = fq.st;
-    const uint32_t n0 = rp_fq_ld(&st->tail[0]);
-    const uint32_t nsl0 = (n0 + RP_CHUNK - 1u) / RP_CHUNK;
-    RpFqWork w;
-    w.b = ~0u;
-    w.slot = w.m = w.n = 0u;
-    for (uint32_t idle = 0;;) {
-        ++cs.polls;
-        // 1. the ready slot of a later bounce that this block's ticket names
-        if (fq.n_pub > 1) {
-            if (!cs.have_ticket) {
-                cs.ticket = rp_fq_add(&st->ring_head, 1u);
-                cs.have_ticket = true;
-            }
-            const unsigned long long e = __hip_atomic_load(fq.ring + cs.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(e >> 48) == fq.epoch) {
-                cs.have_ticket = false;
-                w.b = (uint32_t)(e >> 44) & 15u;
-                w.slot = (uint32_t)(e >> 12);
-                w.m = 1u;
-                w.n = (uint32_t)e & 4095u;
-                return w;
-            }
-        }
-        // 2. the next slots of bounce 0
-        if (!cs.b0_exhausted) {
-            const uint32_t s = rp_fq_add(&st->head0, (uint32_t)fq.k0);
-            if (s < nsl0) {
-                w.b = 0u;
-                w.slot = s;
-                w.m = min((uint32_t)fq.k0, nsl0 - s);
-                w.n = min(w.m * RP_CHUNK, n0 - s * RP_CHUNK);
-                return w;
-            }
-            cs.b0_exhausted = true;
-        }
-        // 3. nothing to do right now: the ticket's entry is this block's own word to watch
-        if ((idle & 3u) == 0u && rp_fq_ld(&st->complete) != 0u) return w;
-        ++cs.idle_polls;
-        if (++idle > (1u << 21) || ((idle & 255u) == 0u && rp_fq_ld(&st->timeout) != 0u)) { // seconds without work while the frame is not complete: never on a correct run
-            rp_fq_add(&st->timeout, 1u);
-            return w;
-        }
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-// all threads of the block: appends n ids (LDS) to bounce b's queue. The caller's waves have drained their path-state stores and a barrier
-// lies behind them.
-RP_DEV void rp_fq_publish(const RpFrameQueues &fq, uint32_t b, const uint32_t *ids, uint32_t n, uint32_t *s_base) {
-    if (n == 0u) return; // (block-uniform)
-    if (threadIdx.x == 0) *s_base = rp_fq_add(&fq.st->tail[b], n);
-    __syncthreads();
-    const uint32_t base = *s_base;
-    uint32_t *const q = rp_fq_ids(fq, b);
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rp_st1<true>(q, base + j, ids[j]);
-    rp_drain_stores(); // every writing wave: the ids have left it before the slot says so
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#ifdef RP_FRAME_PROF
-        const long long tf0 = wall_clock64();
-#endif
-        if (!(fq.dbg & 1u)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // path state + ids of the whole block are in memory ...
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... (the compiler may drop the wait behind buffer_wbl2: restated)
-        }
-#ifdef RP_FRAME_PROF
-        atomicAdd(&fq.st->t_fence, (unsigned long long)(wall_clock64() - tf0));
-#endif
-        const uint32_t s0 = base / RP_CHUNK, n0 = min(n, (s0 + 1u) * RP_CHUNK - base);
-        // the producer that completes a slot hands it on (every other producer's entries were released before its own add)
-        if (rp_fq_add(rp_fq_commit(fq, b) + s0, n0) + n0 == RP_CHUNK) rp_fq_push(fq, b, s0, RP_CHUNK);
-        if (n > n0 && rp_fq_add(rp_fq_commit(fq, b) + s0 + 1u, n - n0) + (n - n0) == RP_CHUNK) rp_fq_push(fq, b, s0 + 1u, RP_CHUNK);
-    }
-}
-template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
-__global__ __launch_bounds__(256, RP_FRAME_WAVES) void rp_k_frame(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpFrameQueues fq, RpCounters *ctr,
-                                                                 int *gstack) {
-    // one arena for the phases that take turns: the traversal stacks of extend / connect, the shade phase's scratch
-    constexpr uint32_t STACK_WORDS = RP_LDS_STACK * RP_TRAVERSE_BLOCK;
-    constexpr uint32_t SCRATCH_WORDS = RP_CHUNK + (LIGHTS ? RP_SHADE_RIS_REQ_FLOATS + RP_SHADE_RIS_CONTRIB_FLOATS : 0);
-    __shared__ __attribute__((aligned(16))) uint32_t s_arena[STACK_WORDS > SCRATCH_WORDS ? STACK_WORDS : SCRATCH_WORDS];
-    __shared__ uint32_t s_ids[RP_CHUNK];    // the list being processed; the shade phase leaves its survivors here (it has read the list by then)
-    __shared__ uint32_t s_shadow[RP_CHUNK]; // the shadow rays of the chunk
-    __shared__ uint32_t s_cursor[2];
-    __shared__ RpFqWork s_work;
-    __shared__ uint32_t s_base;
-    int *const stack = reinterpret_cast<int *>(s_arena);
-    RpShadeLds lds;
-    lds.next = s_ids;
-    lds.shadow = s_shadow;
-    lds.list = s_arena;
-    lds.ris_req = reinterpret_cast<float *>(s_arena + RP_CHUNK);
-    lds.ris_contrib = reinterpret_cast<float *>(s_arena + RP_CHUNK + RP_SHADE_RIS_REQ_FLOATS);
-    RpFqClaimState cs; // (lane 0)
-    cs.ticket = cs.polls = cs.idle_polls = 0u;
-    cs.have_ticket = cs.b0_exhausted = false;
-#ifdef RP_FRAME_PROF
-    long long pt[6] = {0, 0, 0, 0, 0, 0};
-    const long long pt_begin = wall_clock64();
-#define RP_FP_T0 const long long pt0_ = wall_clock64();
-#define RP_FP_T1(k) pt[k] += wall_clock64() - pt0_;
-#else
-#define RP_FP_T0
-#define RP_FP_T1(k)
-#endif
-    for (;;) {
-        __syncthreads(); // the previous slot's readers of s_work / s_ids are done
-        {
-            RP_FP_T0
-            if (threadIdx.x == 0) s_work = rp_fq_claim(fq, cs);
-            __syncthreads();
-            RP_FP_T1(0)
-        }
-        const RpFqWork w = s_work;
-        if (w.b == ~0u) break;
-        uint32_t b = w.b, n = w.n;
-        const uint32_t base = w.slot * RP_CHUNK; // bounce 0: the path id of the first entry
-        if (b > 0u)
-            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-                uint32_t id = rp_ld1<true>(rp_fq_ids(fq, b), base + j);
-                if (id >= fq.capacity) { // (a protocol error would otherwise show up as a wild store)
-                    rp_fq_add(&fq.st->bad_ids, 1u);
-                    id = 0u;
-                }
-                s_ids[j] = id;
-            }
-        for (;;) { // the slot's paths, bounce by bounce while they stay with this block
-            if (threadIdx.x < 2) s_cursor[threadIdx.x] = 0;
-            __syncthreads();
-            {
-                RP_FP_T0
-                if (b == 0u)
-                    rp_extend_body<false, true, ALPHA, SINGLE, true, TABLE, 0, true, true>(sc, f, ps, nullptr, n, &s_cursor[0], ctr, gstack, base, stack);
-                else
-                    rp_extend_body<false, false, ALPHA, SINGLE, true, TABLE, 0, true, true>(sc, f, ps, s_ids, n, &s_cursor[0], ctr, gstack, 0u, stack);
-                rp_drain_stores(); // (the alpha test's generator goes to the shade phase through the path state)
-                __syncthreads();
-                RP_FP_T1(1)
-            }
-            const bool publish = int(b) + 1 < fq.n_pub;
-            uint32_t n_next = 0;
-            for (uint32_t sub = 0; sub * RP_CHUNK < n; ++sub) { // (more than one pass only for k0 > 1 slots of bounce 0, which are always published)
-                const uint32_t cnt = min((uint32_t)RP_CHUNK, n - sub * RP_CHUNK);
-                uint32_t *next = nullptr, *shadow = nullptr;
-                uint32_t n_shadow = 0;
-                RP_FP_T0
-                if (b == 0u)
-                    rp_shade_body<VARIANT, true, LIGHTS, TEX, true, TABLE, true, true>(sc, f, ps, sq, nullptr, cnt, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
-                                                                                       n_shadow, base + sub * RP_CHUNK, &lds);
-                else
-                    rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, true, true>(sc, f, ps, sq, s_ids, cnt, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
-                                                                                        n_shadow, 0u, &lds);
-                rp_drain_stores(); // the shadow rays' contributions are added to the radiance this phase stored
-                __syncthreads();
-                RP_FP_T1(2)
-                {
-                    RP_FP_T0
-                    if (threadIdx.x == 0) s_cursor[1] = 0;
-                    __syncthreads();
-                    rp_connect_body<false, ALPHA, SINGLE, true, 0, true, true>(sc, f, ps, sq, s_shadow, n_shadow, &s_cursor[1], ctr, gstack, stack);
-                    rp_drain_stores(); // every wave: its path-state stores are in memory before the survivors are handed on
-                    __syncthreads();
-                    RP_FP_T1(3)
-                }
-                if (publish) {
-                    RP_FP_T0
-                    rp_fq_publish(fq, b + 1u, s_ids, n_next, &s_base);
-                    __syncthreads();
-                    RP_FP_T1(4)
-                }
-            }
-            if (publish || n_next == 0u || int(b) + 1 >= f.rp.max_path_depth) break;
-            ++b; // the survivors stay with this block (s_ids holds them)
-            n = n_next;
-        }
-        if (threadIdx.x == 0) {
-            rp_drain_stores(); // the commits (and pushes) of this slot's survivors first
-            rp_fq_add(&fq.st->done[w.b], w.m);
-            rp_drain_stores();
-            rp_fq_try_finalize(fq, w.b + 1u);
-        }
-    }
-    if (threadIdx.x == 0) {
-        rp_fq_add(&fq.st->polls, cs.polls);
-        rp_fq_add(&fq.st->idle_polls, cs.idle_polls);
-#ifdef RP_FRAME_PROF
-        atomicAdd(&fq.st->t_claim, (unsigned long long)pt[0]);
-        atomicAdd(&fq.st->t_extend, (unsigned long long)pt[1]);
-        atomicAdd(&fq.st->t_shade, (unsigned long long)pt[2]);
-        atomicAdd(&fq.st->t_connect, (unsigned long long)pt[3]);
-        atomicAdd(&fq.st->t_publish, (unsigned long long)pt[4]);
-        atomicAdd(&fq.st->t_total, (unsigned long long)(wall_clock64() - pt_begin));
-#endif
-    }
-#undef RP_FP_T0
-#undef RP_FP_T1
-}
-
-// ------------------------------------------------------------------ stream: the frame as TWO co-resident persistent kernels
-// rp_k_frame (above) shows what one kernel cannot do: its blocks carry the registers of the shade phase through their traversal phases (4
-// waves per SIMD at most) and refill their lanes from block-local pools -- a frame alone takes 2.6 ms where the stage launches take 2.0.
-// What frames in flight have -- traversal waves that refill from long queues at five per SIMD, with shade work of other frames in the
-// issue slots they leave -- needs kernels with their own register budgets side by side. So: a TRACER kernel (persistent waves, <= 96
-// VGPRs, four blocks per CU) and a SHADER kernel (one block per CU) run for the whole frame and hand each other work through memory.
-//   items     an item is a path that left a shade (or a camera path): an optional shadow ray, then an optional continuation ray, traced one
-//             after the other by ONE lane (dstream.h), so that the shadow ray's contribution is added to the path's radiance before the
-//             next shade adds anything -- the megakernel's order of additions with no dependency between lanes.
-//   S0        the camera paths: the identity over the path ids, dealt to tracer waves in pools of RP_ST_POOL entries (head: s0_head)
-//   R         the items the shader kernel emits (u32: path id | flags), appended with one atomicAdd per chunk of survivors (r_tail)
-//   chunks    RP_CHUNK consecutive entries of S0 or R are the unit of shading: traced[chunk] counts the entries whose rays are done (the
-//             tracer wave whose add completes a chunk hands it to the shader ring), commit[chunk] the entries of an R chunk that have
-//             been written (the shader block whose add completes it hands its four pools to the tracer ring)
-//   rings     64-bit entries tagged with the frame's epoch; a consumer (tracer wave / shader block) holds a TICKET -- position in the ring
-//             that is its own to watch -- so nobody races for a head word (as in rp_k_frame)
-//   the end   only shader blocks append. When a shader block finishes a chunk and finds every chunk that was ever handed out shaded
-//             (shaded == S0 chunks + R chunks handed to the tracers), nothing is in flight and R's tail stands still: it SEALS the last,
-//             partly filled chunk (pads it with RP_ITEM_NONE, which completes it) -- or, if there is none, sets `complete`.
-// Visibility: as rp_k_frame -- consumers read around the L1 (sc1), a producer drains its stores and issues ONE agent-scope release before
-// the atomic that publishes (a shader block per chunk; a tracer wave per report of finished items).
-#define RP_ST_POOL 256u // entries a tracer wave takes at a time
-#ifndef RP_ST_REPORT
-#define RP_ST_REPORT 192u     // ended items of one chunk a tracer wave collects before it reports them
-#endif
-#ifndef RP_ST_REPORT_AGE
-#define RP_ST_REPORT_AGE 24u  // ... or this many refill rounds, whichever comes first
-#endif
-struct RpStState {
-    uint32_t r_tail, s0_head, tr_tail, tr_head, sr_tail, sr_head;
-    uint32_t tr_chunks; // R chunks handed to the tracer ring so far
-    uint32_t shaded;    // chunks shaded
-    uint32_t complete;
-    uint32_t timeout, overflow, seals;
-    uint32_t n0;        // camera paths (preset by the host)
-    uint32_t trace_polls, shade_polls, _pad;
-    unsigned long long t_wait, t_load, t_shade, t_append, t_fence, t_total, t_trace_idle, t_trace_total, t_trace_report; // -DRP_FRAME_PROF: 100 MHz ticks (lane 0 of a block / wave)
-};
-struct RpStream {
-    RpStState *st;
-    uint32_t *r;                 // the items of later bounces
-    uint32_t *commit;            // per R chunk
-    uint32_t *traced;            // per chunk: S0 chunks first, R chunks behind them
-    unsigned long long *tr_ring; // pools of R for tracer waves: epoch << 48 | first entry
-    unsigned long long *sr_ring; // chunks for shader blocks: epoch << 48 | chunk id (S0 chunks first)
-    uint32_t r_capacity;         // entries R holds (a multiple of RP_CHUNK)
-    uint32_t n_s0_chunks;
-    uint32_t epoch;
-    uint32_t capacity;           // path ids are below this
-};
-RP_DEV void rp_st_push(unsigned long long *ring, uint32_t *tail, uint32_t epoch, uint32_t value, uint32_t n = 1u, uint32_t step = 0u) {
-    const uint32_t i = rp_fq_add(tail, n);
-    for (uint32_t k = 0; k < n; ++k)
-        __hip_atomic_store(ring + i + k, ((unsigned long long)epoch << 48) | (unsigned long long)(value + k * step), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-RP_DEV uint32_t rp_st_chunk_size(const RpStream &sx, uint32_t chunk, uint32_t n0) {
-    return chunk < sx.n_s0_chunks ? min((uint32_t)RP_CHUNK, n0 - chunk * RP_CHUNK) : (uint32_t)RP_CHUNK;
-}
-
-// ---- the tracer: persistent waves over items
-template <bool SINGLE, bool TABLE>
-__global__ RP_TRAVERSE_BOUNDS void rp_k_stream_trace(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpStream sx, int *gstack) {
-    RpStState *const st = sx.st;
-    const uint32_t lane = rp_lane_id();
-    const uint32_t n0 = rp_fq_ld(&st->n0);
-    // wave-uniform consumer state
-    uint32_t ticket = 0;
-    bool have_ticket = false, s0_done = false;
-    uint32_t idle_polls = 0;
-    // the lane's item
-    uint32_t my_p = 0, my_flags = 0, my_chunk = 0, fin_chunk = RP_ITEM_NONE;
-    auto pool = [&](uint32_t &first, uint32_t &end) -> int {
-        int r = 0;
-        uint32_t a = 0, b = 0;
-        if (lane == 0) {
-            if (!have_ticket) {
-                ticket = rp_fq_add(&st->tr_head, 1u);
-                have_ticket = true;
-            }
-            const unsigned long long e = __hip_atomic_load(sx.tr_ring + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(e >> 48) == sx.epoch) {
-                have_ticket = false;
-                a = 0x80000000u | (uint32_t)e;
-                b = a + RP_ST_POOL;
-                r = 1;
-            } else if (!s0_done) {
-                const uint32_t s = rp_fq_add(&st->s0_head, RP_ST_POOL);
-                if (s < n0) {
-                    a = s;
-                    b = min(n0, s + RP_ST_POOL);
-                    r = 1;
-                } else
-                    s0_done = true;
-            }
-            if (r == 0) {
-                if (rp_fq_ld(&st->complete) != 0u) r = -1;
-                else if (++idle_polls > (1u << 22) || ((idle_polls & 1023u) == 0u && rp_fq_ld(&st->timeout) != 0u)) {
-                    rp_fq_add(&st->timeout, 1u);
-                    r = -1;
-                }
-            } else
-                idle_polls = 0;
-        }
-        r = __builtin_amdgcn_readfirstlane(r);
-        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-        end = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-        return r;
-    };
-    auto cont_ray = [&](bool first, V3 &ro, V3 &rd, float &tmin, float &tmax) -> bool { // the closest-hit ray of the lane's item
-        if (first) {
-            RpRng rng;
-            rd = v3(0.0f, 0.0f, 1.0f);
-            if (!rp_primary_ray<TABLE>(f, my_p, rng, rd, ro)) return false; // tile padding: no such pixel sample
-            tmin = 0.0f;
-            tmax = 2.e32f;
-        } else {
-            const float4 o4 = rp_ld4<true>(ps.ray_o, my_p), d4 = rp_ld4<true>(ps.ray_d, my_p);
-            ro = xyz(o4);
-            rd = xyz(d4);
-            tmin = rp_geometry_scale_to_tmin(ro, o4.w);
-            tmax = 1e20f;
-        }
-        return true;
-    };
-    auto begin = [&](uint32_t idx, V3 &ro, V3 &rd, float &tmin, float &tmax, bool &anyq) -> bool {
-        if (idx & 0x80000000u) {
-            const uint32_t ri = idx & 0x7FFFFFFFu;
-            const uint32_t e = rp_ld1<true>(sx.r, ri);
-            my_chunk = sx.n_s0_chunks + ri / RP_CHUNK;
-            if (e == RP_ITEM_NONE || (e & RP_ITEM_PATH) >= sx.capacity) { // padding of a sealed chunk (or, never on a correct run, no path id)
-                if (e != RP_ITEM_NONE) rp_fq_add(&st->overflow, 1u);
-                fin_chunk = my_chunk;
-                return false;
-            }
-            my_p = e & RP_ITEM_PATH;
-            my_flags = e & (RP_ITEM_CONT | RP_ITEM_SHADOW);
-            if (my_flags & RP_ITEM_SHADOW) {
-                const float4 o4 = rp_ld4<true>(ps.ray_o, my_p), d4 = rp_ld4<true>(sq.d, my_p);
-                ro = xyz(o4);
-                rd = xyz(d4);
-                tmin = rp_geometry_scale_to_tmin(ro, o4.w);
-                tmax = d4.w;
-                anyq = true;
-                return true;
-            }
-            anyq = false;
-            return cont_ray(false, ro, rd, tmin, tmax); // (always true)
-        }
-        my_p = idx;
-        my_chunk = idx / RP_CHUNK;
-        my_flags = RP_ITEM_CONT;
-        anyq = false;
-        if (!cont_ray(true, ro, rd, tmin, tmax)) {
-            rp_st2<true>(reinterpret_cast<float2 *>(ps.hit_ids), my_p, make_float2(__int_as_float(-1), __int_as_float(-1))); // a miss is recorded
-            fin_chunk = my_chunk;
-            return false;
-        }
-        return true;
-    };
-    auto next = [&](const RpHitRec &h, V3 &ro, V3 &rd, float &tmin, float &tmax, bool &anyq) -> bool {
-        if (anyq) { // the shadow ray: its contribution arrives when nothing is hit (nee.glsl:76-84)
-            if (h.inst_idx < 0) {
-                const float4 c = rp_ld4<true>(sq.contrib, my_p);
-                float4 il = rp_ld4<true>(ps.illum, my_p);
-                il.x += c.x;
-                il.y += c.y;
-                il.z += c.z;
-                rp_st4<true>(ps.illum, my_p, il);
-            }
-            if (my_flags & RP_ITEM_CONT) {
-                anyq = false;
-                return cont_ray(false, ro, rd, tmin, tmax);
-            }
-            fin_chunk = my_chunk;
-            return false;
-        }
-        rp_st4<true>(ps.hit_tuv, my_p, make_float4(h.t, h.u, h.v, __int_as_float(h.prim)));
-        rp_st2<true>(reinterpret_cast<float2 *>(ps.hit_ids), my_p, make_float2(__int_as_float(h.inst_idx), __int_as_float(h.geom)));
-        fin_chunk = my_chunk;
-        return false;
-    };
-    // Ended items are counted per wave in a few (chunk, count) slots and handed over -- a release fence + one atomicAdd per slot -- when a slot
-    // holds RP_ST_REPORT items, when the wave runs out of slots, when it has nothing in flight, or after RP_ST_REPORT_AGE steps: a report per
-    // refill (every ~48 items) was half a million L2 write-backs per frame and made the frame six times slower
-    uint32_t slot_chunk[4] = {RP_ITEM_NONE, RP_ITEM_NONE, RP_ITEM_NONE, RP_ITEM_NONE}, slot_count[4] = {0u, 0u, 0u, 0u}, slot_age = 0u; // wave-uniform
-    auto flush = [&](uint32_t which_mask) { // wave-uniform
-        rp_drain_stores(); // this wave's hit records and radiance updates have left it ...
-        if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // ... and are in memory before a chunk is called done
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((which_mask >> k) & 1u) {
-                if (lane == 0 && slot_count[k] > 0u &&
-                    rp_fq_add(sx.traced + slot_chunk[k], slot_count[k]) + slot_count[k] == rp_st_chunk_size(sx, slot_chunk[k], n0))
-                    rp_st_push(sx.sr_ring, &st->sr_tail, sx.epoch, slot_chunk[k]);
-                slot_chunk[k] = RP_ITEM_NONE;
-                slot_count[k] = 0u;
-            }
-    };
-    auto report = [&](bool now, bool idle_wave) {
-        unsigned long long mask = __ballot(fin_chunk != RP_ITEM_NONE);
-        while (mask != 0ull) { // (one or two distinct chunks)
-            const int leader = __ffsll((long long)mask) - 1;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)fin_chunk, leader);
-            const unsigned long long same = __ballot(fin_chunk == c);
-            const uint32_t cnt = (uint32_t)__popcll(same);
-            int k = slot_chunk[0] == c ? 0 : slot_chunk[1] == c ? 1 : slot_chunk[2] == c ? 2 : slot_chunk[3] == c ? 3 : -1;
-            if (k < 0) {
-                k = slot_chunk[0] == RP_ITEM_NONE ? 0 : slot_chunk[1] == RP_ITEM_NONE ? 1 : slot_chunk[2] == RP_ITEM_NONE ? 2 : slot_chunk[3] == RP_ITEM_NONE ? 3 : -1;
-                if (k < 0) { // no slot left: hand everything over
-                    flush(15u);
-                    k = 0;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j == k) {
-                    slot_chunk[j] = c;
-                    slot_count[j] += cnt;
-                }
-            if (fin_chunk == c) fin_chunk = RP_ITEM_NONE;
-            mask &= ~same;
-        }
-        uint32_t due = 0u;
-        bool pending = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (slot_count[j] >= RP_ST_REPORT) due |= 1u << j;
-            pending = pending || slot_count[j] > 0u;
-        }
-        if (!pending) {
-            slot_age = 0u;
-            return;
-        }
-        if (now && ++slot_age >= RP_ST_REPORT_AGE) due = 15u;
-        if (idle_wave) due = 15u; // nothing in flight: whoever waits for these chunks should not wait for this wave's next refill
-        if (due != 0u) {
-            flush(due);
-            slot_age = 0u;
-        }
-    };
-    rp_wave_trace_items<false, SINGLE>(sc, gstack, pool, begin, next, report, RpNoAlpha());
-}
-
-// ---- the shader: persistent blocks over chunks
-template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
-__global__ __launch_bounds__(256, RP_SHADE_WAVES) void rp_k_stream_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, RpStream sx, RpCounters *ctr) {
-    __shared__ uint32_t s_ids[RP_CHUNK], s_shadow_unused[1];
-    __shared__ uint32_t s_list[RP_CHUNK];
-    __shared__ float s_ris_req[LIGHTS ? RP_SHADE_RIS_REQ_FLOATS : 1], s_ris_contrib[LIGHTS ? RP_SHADE_RIS_CONTRIB_FLOATS : 1];
-    __shared__ uint32_t s_chunk, s_n, s_base, s_seal;
-    RpStState *const st = sx.st;
-    RpShadeLds lds;
-    lds.next = s_ids;
-    lds.shadow = s_shadow_unused;
-    lds.list = s_list;
-    lds.ris_req = s_ris_req;
-    lds.ris_contrib = s_ris_contrib;
-#ifdef RP_STREAM_DEBUG
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        printf("[dev shade] st %p r %p commit %p traced %p tr %p sr %p cap %u chunks0 %u epoch %u pathcap %u\n", (void *)sx.st, (void *)sx.r, (void *)sx.commit, (void *)sx.traced,
-               (void *)sx.tr_ring, (void *)sx.sr_ring, sx.r_capacity, sx.n_s0_chunks, sx.epoch, sx.capacity);
-#endif
-    const uint32_t n0 = rp_fq_ld(&st->n0);
-    uint32_t ticket = 0, idle = 0; // (thread 0)
-    bool have_ticket = false;
-    // all threads: appends n entries (LDS) to R; the chunks it completes go to the tracers
-    auto append = [&](const uint32_t *entries, uint32_t n, bool none) {
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the path state and shadow rays of this chunk are in memory before its items are
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            s_base = rp_fq_add(&st->r_tail, n);
-        }
-        __syncthreads();
-        const uint32_t base = s_base;
-        if (base + n > sx.r_capacity) { // (never with the capacity the host allocates: total items of a frame; reported, the frame is cut short)
-            if (threadIdx.x == 0) {
-                rp_fq_add(&st->overflow, 1u);
-                __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) rp_st1<true>(sx.r, base + j, none ? RP_ITEM_NONE : entries[j]);
-        rp_drain_stores();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (uint32_t c = base / RP_CHUNK; c * RP_CHUNK < base + n; ++c) {
-                const uint32_t lo = max(base, c * RP_CHUNK), hi = min(base + n, (c + 1u) * RP_CHUNK);
-                if (rp_fq_add(sx.commit + c, hi - lo) + (hi - lo) == RP_CHUNK) {
-                    rp_fq_add(&st->tr_chunks, 1u);
-                    rp_drain_stores();
-                    rp_st_push(sx.tr_ring, &st->tr_tail, sx.epoch, c * RP_CHUNK, RP_CHUNK / RP_ST_POOL, RP_ST_POOL);
-                }
-            }
-        }
-    };
-#ifdef RP_FRAME_PROF
-    long long pt[5] = {0, 0, 0, 0, 0};
-    const long long pt_begin = wall_clock64();
-    long long pt0 = pt_begin;
-#define RP_SP(k) { const long long t_ = wall_clock64(); pt[k] += t_ - pt0; pt0 = t_; }
-#else
-#define RP_SP(k)
-#endif
-    for (;;) {
-        __syncthreads();
-        RP_SP(3)
-        if (threadIdx.x == 0) { // the next chunk: this block's ticket of the shader ring
-            uint32_t chunk = RP_ITEM_NONE;
-            for (;;) {
-                if (!have_ticket) {
-                    ticket = rp_fq_add(&st->sr_head, 1u);
-                    have_ticket = true;
-                }
-                const unsigned long long e = __hip_atomic_load(sx.sr_ring + ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(e >> 48) == sx.epoch) {
-                    have_ticket = false;
-                    chunk = (uint32_t)e;
-                    idle = 0;
-                    break;
-                }
-                if (rp_fq_ld(&st->complete) != 0u) break;
-                if (++idle > (1u << 21) || ((idle & 255u) == 0u && rp_fq_ld(&st->timeout) != 0u)) {
-                    rp_fq_add(&st->timeout, 1u);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            s_chunk = chunk;
-            s_n = 0;
-        }
-        __syncthreads();
-        const uint32_t chunk = s_chunk;
-        RP_SP(0)
-        if (chunk == RP_ITEM_NONE) break;
-        const bool first = chunk < sx.n_s0_chunks;
-        uint32_t n = 0, base = 0;
-        if (first) {
-            base = chunk * RP_CHUNK;
-            n = min((uint32_t)RP_CHUNK, n0 - base);
-        } else { // the paths of the chunk that go on: their continuation rays have been traced
-            const uint32_t r0 = (chunk - sx.n_s0_chunks) * RP_CHUNK;
-            for (uint32_t j = threadIdx.x; j < RP_CHUNK; j += blockDim.x) {
-                const uint32_t e = rp_ld1<true>(sx.r, r0 + j);
-                const bool go = e != RP_ITEM_NONE && (e & RP_ITEM_CONT) != 0u;
-                const uint32_t at = rp_wave_append(&s_n, go);
-                if (go) s_ids[at] = e & RP_ITEM_PATH;
-            }
-            __syncthreads();
-            n = s_n;
-        }
-        uint32_t *next = nullptr, *shadow = nullptr;
-        uint32_t n_next = 0, n_shadow = 0;
-        RP_SP(1)
-        if (n > 0u) {
-            if (first)
-                rp_shade_body<VARIANT, true, LIGHTS, TEX, true, TABLE, true, true, true>(sc, f, ps, sq, nullptr, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow, n_shadow,
-                                                                                         base, &lds);
-            else
-                rp_shade_body<VARIANT, false, LIGHTS, TEX, true, TABLE, true, true, true>(sc, f, ps, sq, s_ids, n, nullptr, nullptr, nullptr, ctr, next, n_next, shadow,
-                                                                                          n_shadow, 0u, &lds);
-        }
-        rp_drain_stores();
-        __syncthreads();
-        RP_SP(2)
-        if (n_next > 0u) append(s_ids, n_next, false);
-        __syncthreads();
-        // this chunk is shaded. Is it the last one that was in flight?
-        if (threadIdx.x == 0) {
-            rp_drain_stores();
-            const uint32_t sh = rp_fq_add(&st->shaded, 1u) + 1u;
-            rp_drain_stores();
-            uint32_t seal = 0u;
-            if (sh == sx.n_s0_chunks + rp_fq_ld(&st->tr_chunks)) { // every chunk ever handed out is shaded: nobody appends any more
-                const uint32_t t = rp_fq_ld(&st->r_tail);
-                if (t % RP_CHUNK != 0u) {
-                    seal = RP_CHUNK - t % RP_CHUNK;
-                    rp_fq_add(&st->seals, 1u);
-                } else
-                    __hip_atomic_store(&st->complete, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_seal = seal;
-        }
-        __syncthreads();
-        if (s_seal > 0u) append(nullptr, s_seal, true); // pads the last chunk: that completes it and sends it to the tracers
-    }
-#ifdef RP_FRAME_PROF
-    if (threadIdx.x == 0) {
-        atomicAdd(&st->t_wait, (unsigned long long)pt[0]);
-        atomicAdd(&st->t_load, (unsigned long long)pt[1]);
-        atomicAdd(&st->t_shade, (unsigned long long)pt[2]);
-        atomicAdd(&st->t_append, (unsigned long long)pt[3]);
-        atomicAdd(&st->t_total, (unsigned long long)(wall_clock64() - pt_begin));
-    }
-#endif
-#undef RP_SP
 }
 
 // rp_kernarg (above) reads RpScene / RpFrame at the offsets they have as the FIRST TWO by-value arguments of a kernel: both kernels that run
@@ -1643,7 +862,5 @@ struct rp_args_start_with_scene_and_frame : std::false_type {};
 template <class... Rest>
 struct rp_args_start_with_scene_and_frame<void (*)(RpScene, RpFrame, Rest...)> : std::true_type {};
 static_assert(rp_args_start_with_scene_and_frame<decltype(&rp_k_shade<RPTR_VARIANT_SIMPLE, true, false, false, false>)>::value &&
-                  rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value &&
-                  rp_args_start_with_scene_and_frame<decltype(&rp_k_frame<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value &&
-                  rp_args_start_with_scene_and_frame<decltype(&rp_k_stream_shade<RPTR_VARIANT_SIMPLE, false, false, false>)>::value,
-              "rp_k_shade / rp_k_tail / rp_k_frame / rp_k_stream_shade: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");
+                  rp_args_start_with_scene_and_frame<decltype(&rp_k_tail<RPTR_VARIANT_SIMPLE, false, false, false, true, false>)>::value,
+              "rp_k_shade / rp_k_tail: (RpScene, RpFrame, ...) must come first (kernels.h rp_kernarg)");

@@ -36,10 +36,6 @@ void rp_launch_connect(const RpLaunch &l, bool count, bool alpha, bool single, c
 hipError_t rp_extend_blocks_per_cu(int *out);
 hipError_t rp_connect_blocks_per_cu(int single, int *out);
 hipError_t rp_extend_later_blocks_per_cu(int *out);
-// the tracer of the streaming frame (kernels.h rp_k_stream_trace)
-void rp_launch_stream_trace(const RpLaunch &l, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps, const RpShadowRays &sq,
-                            const RpStream &sx, int *gstack);
-hipError_t rp_stream_trace_blocks_per_cu(int *out);
 #ifdef RP_PROF
 hipError_t rp_prof_exchange(unsigned long long out[16]); // reads and clears the -DRP_PROF counters of rp_k_extend / rp_k_connect
 #endif // occupancy of the traversal kernels (they all fit the same budget)
@@ -50,12 +46,7 @@ hipError_t rp_prof_exchange(unsigned long long out[16]); // reads and clears the
                               const RpShadowRays &sq, const uint32_t *order, const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count,     \
                               uint32_t *shadow_count, RpCounters *ctr);                                                                                  \
     void rp_launch_tail_v##V(const RpLaunch &l, bool lights, bool full, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,  \
-                             const RpShadowRays &sq, const uint32_t *queue, RpCounters *ctr, int first_bounce, int *gstack);                             \
-    void rp_launch_frame_v##V(const RpLaunch &l, bool lights, bool full, bool single, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps, \
-                              const RpShadowRays &sq, const RpFrameQueues &fq, RpCounters *ctr, int *gstack);                                            \
-    hipError_t rp_frame_blocks_per_cu_v##V(bool lights, bool full, int *out);                                                                            \
-    void rp_launch_stream_shade_v##V(const RpLaunch &l, bool lights, bool tex, bool table, const RpScene &sc, const RpFrame &f, const RpPathState &ps,     \
-                                     const RpShadowRays &sq, const RpStream &sx, RpCounters *ctr);
+                             const RpShadowRays &sq, const uint32_t *queue, RpCounters *ctr, int first_bounce, int *gstack);
 RP_DECLARE_VARIANT(0)
 RP_DECLARE_VARIANT(1)
 RP_DECLARE_VARIANT(2)
@@ -78,29 +69,5 @@ static inline void rp_launch_tail(int variant, const RpLaunch &l, A... args) {
         rp_launch_tail_v2(l, args...);
     else
         rp_launch_tail_v0(l, args...);
-}
-// k_frame.hip: the whole frame in one launch (kernels.h rp_k_frame)
-template <class... A>
-static inline void rp_launch_frame(int variant, const RpLaunch &l, A... args) {
-    if (variant == RPTR_VARIANT_SIMPLE)
-        rp_launch_frame_v1(l, args...);
-    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
-        rp_launch_frame_v2(l, args...);
-    else
-        rp_launch_frame_v0(l, args...);
-}
-template <class... A>
-static inline void rp_launch_stream_shade(int variant, const RpLaunch &l, A... args) {
-    if (variant == RPTR_VARIANT_SIMPLE)
-        rp_launch_stream_shade_v1(l, args...);
-    else if (variant == RPTR_VARIANT_GLTF_TRANSMISSION)
-        rp_launch_stream_shade_v2(l, args...);
-    else
-        rp_launch_stream_shade_v0(l, args...);
-}
-static inline hipError_t rp_frame_blocks_per_cu(int variant, bool lights, bool full, int *out) {
-    if (variant == RPTR_VARIANT_SIMPLE) return rp_frame_blocks_per_cu_v1(lights, full, out);
-    if (variant == RPTR_VARIANT_GLTF_TRANSMISSION) return rp_frame_blocks_per_cu_v2(lights, full, out);
-    return rp_frame_blocks_per_cu_v0(lights, full, out);
 }
 static_assert(RPTR_VARIANT_GLTF == 0 && RPTR_VARIANT_SIMPLE == 1 && RPTR_VARIANT_GLTF_TRANSMISSION == 2, "k_shade.hip / k_tail.hip are built per variant number");

@@ -115,20 +115,6 @@ struct FrameCtx {
     RpCounters earlier_batches; // counters of the batches that were already synchronised (spp > max_batch_spp)
     int launches_extend = 0, launches_connect = 0, spp_after = 0;
     int tail_from = 0; // the bounce at which this context's last frame handed over to the tail kernel (= max depth: no tail)
-    // the one-launch frame (kernels.h rp_k_frame): global queues per published bounce, their control words, a pinned copy of those
-    RpFrameQueues fq = {};
-    RpPathState ps_fk = {};       // the frame kernel's path state: what crosses workgroups lives in fine-grained memory, the rest is c.ps's
-    size_t fq_words = 0;          // control words + per-slot commit counters: zeroed before every frame
-    RpFqState *host_fq = nullptr; // pinned
-    int fq_pub_used = 0;          // bounces with global queues in the frame in flight (0: it ran as stage launches)
-    // the streaming frame (kernels.h rp_k_stream_trace + rp_k_stream_shade): item stream, chunk counters, the two rings, a second stream
-    RpStream sx = {};
-    size_t sx_words = 0;          // state + chunk counters: zeroed before every frame
-    size_t sx_tr_entries = 0, sx_sr_entries = 0;
-    RpStState *host_sx = nullptr; // pinned
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
-    bool streamed = false;        // the frame in flight ran as the streaming pair
     size_t gstack_threads = 0;    // threads the stack scratch is sized for
     // multi-GPU gather (host_comm.h): the image this context produced is being sent; its next frame waits for that on the device
     hipEvent_t ev_gather = nullptr;
@@ -137,9 +123,122 @@ struct FrameCtx {
 
 } // namespace
 
+// ------------------------------------------------------------------ options (include/rptr_hip.h "Options")
+// Everything that decides how the library builds and schedules, beyond RptrCreateInfo, is an integer option with a name: set through
+// rptr_hip_set_option (h == NULL: the process default new handles start from), read back through rptr_hip_get_option. Each option also
+// has an environment variable -- the experimenter's override: when it is set, its value wins over the default AND over rptr_hip_set_option
+// (A/B runs of an unmodified host, tools/ab.sh) -- read once per handle, in rptr_hip_create. Nothing else in the library reads the
+// environment (GPU_MAX_HW_QUEUES is the HIP runtime's variable, RPTR_FRAMES_IN_FLIGHT overrides RptrCreateInfo.frames_in_flight).
+enum RpOpt : int {
+    OPT_FLATTEN, OPT_FLATTEN_MAX_TRIS, OPT_BVH_BUILDER, OPT_DEVICE_BUILD_MIN_TRIS, OPT_REBRAID, OPT_TLAS_COLLAPSE, OPT_COLLAPSE, OPT_PRESPLIT_DENSITY,
+    OPT_PRESPLIT_BUDGET_PCT, OPT_HOST_PLOC, OPT_PLOC_TOP, OPT_PLOC_LEAF, OPT_TRAVERSE_NODE_MIN, OPT_TRAVERSE_REFILL_MIN, OPT_LDS_TOP, OPT_SINGLE_INSTANCE,
+    OPT_MAX_BATCH_FRAMES, OPT_MAX_BATCH_SPP, OPT_PATH_BUDGET_MB, OPT_BLOCKS_PER_CU, OPT_SIDE_CONNECT, OPT_AOVS, OPT_TAIL_BOUNCE, OPT_TAIL_THRESHOLD,
+    OPT_STAGE_TIMING, OPT_REGROUP, OPT_COMM_TRANSPORT, OPT_COMM_PRIORITY, OPT_COMM_SELF, OPT_QUIET, OPT_COUNT
+};
+struct RpOptDesc {
+    const char *key, *env; // env: atoll of the variable unless parse_option_env knows better (names, pairs)
+    long long def, lo, hi;
+};
+static const RpOptDesc g_opt_desc[OPT_COUNT] = {
+    {"flatten", "RPTR_FLATTEN", -1, -1, 1},                       // -1 auto: static multi-instance scenes become ONE world-space tree; 0 never; 1 = auto (kept for old hosts)
+    {"flatten_max_tris", "RPTR_FLATTEN_MAX_TRIS", 1ll << 26, 0, 1ll << 31}, // ... up to this many instanced triangles (~150 bytes each)
+    {"bvh_builder", "RPTR_BVH_BUILDER", 0, 0, 2},                 // 0 auto, 1 host (binned SAH), 2 device (PLOC)
+    {"device_build_min_tris", "RPTR_DEVICE_BUILD_MIN_TRIS", 2ll << 20, 0, 1ll << 31},
+    {"rebraid", "RPTR_REBRAID", 0, 0, 64},                        // instance records per instance in the top level; 0 auto (4 from 16 instances on)
+    {"tlas_collapse", "RPTR_TLAS_COLLAPSE", 0, 0, 2},             // rptr::COLLAPSE_* of the top level
+    {"collapse", "RPTR_COLLAPSE", -1, -1, 2},                     // rptr::COLLAPSE_* of the bottom-level trees; -1: per tree (bvh_build.h)
+    {"presplit_density", "RPTR_PRESPLIT", 0, 0, 1 << 30},         // triangle pre-splitting of host-built static trees (0 off)
+    {"presplit_budget_pct", nullptr, 100, 0, 10000},              // ... extra references allowed, % of the triangle count
+    {"host_ploc", "RPTR_HOST_PLOC", 0, 0, 1024},                  // > 0: the host states the device builder's clustering with this radius
+    {"ploc_top", "RPTR_PLOC_TOP", 0, 0, 1ll << 31},               // clusters at which the PLOC clustering stops (0: RP_PLOC_TOP)
+    {"ploc_leaf", "RPTR_PLOC_LEAF", 0, 0, 7},
+    {"traverse_node_min", "RPTR_TRAVERSE_PRESET", -1, -1, 64},    // dtraverse.h thresholds; -1: chosen per scene at set_scene
+    {"traverse_refill_min", nullptr, -1, -1, 64},
+    {"lds_top", "RPTR_LDS_TOP", 0, 0, 1},
+    {"single_instance", "RPTR_NO_SINGLE_INSTANCE", 1, 0, 1},      // queries of scenes with one instance record start inside it
+    {"max_batch_frames", "RPTR_MAX_BATCH_FRAMES", 8, 1, 16},      // frames (output images) a launch sequence may hold          [initialize]
+    {"max_batch_spp", "RPTR_MAX_BATCH_SPP", 0, 0, 64},            // sample slots in flight per frame context; 0: from the budget [initialize]
+    {"path_budget_mb", "RPTR_PATH_BUDGET_MB", 6144, 1, 1 << 20},  // path state per frame context                                [initialize]
+    {"blocks_per_cu", "RPTR_BLOCKS_PER_CU", 0, 0, 16},            // persistent traversal blocks per CU; 0: occupancy / contexts [initialize]
+    {"side_connect", "RPTR_SIDE_CONNECT", -1, -1, 1},             // connect(b) beside extend(b+1); -1: on for one frame context [initialize]
+    {"aovs", "RPTR_AOVS", 1, 0, 1},                               //                                                             [initialize]
+    {"tail_bounce", "RPTR_TAIL_BOUNCE", -1, -1, RP_MAX_BOUNCES},  // -1 adaptive, 0 no tail kernel, k: from bounce k
+    {"tail_threshold", "RPTR_TAIL_THRESHOLD", 65536, 0, 1 << 30},
+    {"stage_timing", "RPTR_STAGE_TIMING", 2, 0, 2},
+    {"regroup_materials", "RPTR_REGROUP", 0, 0, 1},
+    {"comm_transport", "RPTR_COMM_TRANSPORT", 0, 0, 3},           // 0 auto, 1 rccl, 2 copy, 3 peer                              [comm init]
+    {"comm_priority", "RPTR_COMM_PRIORITY", 1, 0, 1},
+    {"comm_self", "RPTR_COMM_SELF", 0, 0, 1},
+    {"quiet", "RPTR_QUIET", 0, 0, 1},
+};
+struct RpOptions {
+    long long v[OPT_COUNT];
+    bool from_env[OPT_COUNT];
+};
+static RpOptions &process_default_options() {
+    static RpOptions o = [] {
+        RpOptions d;
+        for (int k = 0; k < OPT_COUNT; ++k) {
+            d.v[k] = g_opt_desc[k].def;
+            d.from_env[k] = false;
+        }
+        return d;
+    }();
+    return o;
+}
+static int find_option(const char *key) {
+    if (!key) return -1;
+    for (int k = 0; k < OPT_COUNT; ++k)
+        if (!strcmp(key, g_opt_desc[k].key)) return k;
+    return -1;
+}
+static long long clamp_option(int k, long long v) { return std::max(g_opt_desc[k].lo, std::min(g_opt_desc[k].hi, v)); }
+// the environment's word on every option (names and pairs where the variable always took them)
+static void apply_option_env(RpOptions &o) {
+    auto set = [&](int k, long long v) {
+        o.v[k] = clamp_option(k, v);
+        o.from_env[k] = true;
+    };
+    auto collapse_rule = [](const char *e) -> long long {
+        if (!strcmp(e, "even")) return 1;
+        if (!strcmp(e, "dp") || !strcmp(e, "optimal")) return 2;
+        if (!strcmp(e, "greedy")) return 0;
+        return atoll(e);
+    };
+    for (int k = 0; k < OPT_COUNT; ++k) {
+        const char *e = g_opt_desc[k].env ? getenv(g_opt_desc[k].env) : nullptr;
+        if (!e) continue;
+        switch (k) {
+        case OPT_BVH_BUILDER: set(k, !strcmp(e, "host") ? 1 : !strcmp(e, "device") ? 2 : !strcmp(e, "auto") ? 0 : atoll(e)); break;
+        case OPT_TLAS_COLLAPSE: set(k, collapse_rule(e)); break;
+        case OPT_COLLAPSE: set(k, !strcmp(e, "") ? -1 : collapse_rule(e)); break;
+        case OPT_PRESPLIT_DENSITY: // "density[,budget]"
+            set(k, (long long)atof(e));
+            if (const char *c = strchr(e, ',')) set(OPT_PRESPLIT_BUDGET_PCT, (long long)(atof(c + 1) * 100.0 + 0.5));
+            break;
+        case OPT_TRAVERSE_NODE_MIN: // "node_min,refill_min"
+            set(k, atoll(e));
+            if (const char *c = strchr(e, ',')) set(OPT_TRAVERSE_REFILL_MIN, atoll(c + 1));
+            else set(OPT_TRAVERSE_REFILL_MIN, 0);
+            break;
+        case OPT_SINGLE_INSTANCE: set(k, 0); break; // RPTR_NO_SINGLE_INSTANCE: its presence switches the shortcut off
+        case OPT_COMM_TRANSPORT: set(k, !strcmp(e, "rccl") ? 1 : !strcmp(e, "copy") ? 2 : !strcmp(e, "peer") ? 3 : atoll(e)); break;
+        default: set(k, atoll(e)); break;
+        }
+    }
+}
+// what a handle-less entry point (rptr_hip_build_bvh_host) works with: the process defaults under the environment
+static RpOptions effective_default_options() {
+    RpOptions o = process_default_options();
+    apply_option_env(o);
+    return o;
+}
+
+
 struct RptrComm; // host_comm.h
 
 struct rptr_hip {
+    RpOptions opt; // rptr_hip_set_option / the environment's overrides (rptr_hip_create)
     RptrComm *comm = nullptr; // communicator rank of this handle (rptr_hip_comm_init_rank / _init_all), NULL on a single GPU
     std::string last_error;
     int device = 0;
@@ -206,7 +305,7 @@ struct rptr_hip {
     int next_ctx = 0;
     int output_ctx = -1;            // frames_in_flight > 1: the context whose image read-backs return (last waited frame)
     int output_index = 0;           // ... and which frame of that context's batch
-    int max_batch_frames = 4;       // RPTR_MAX_BATCH_FRAMES: per-frame output images a context keeps (rptr_hip_render_batch_async)
+    int max_batch_frames = 8;       // option "max_batch_frames": per-frame output images a context keeps (rptr_hip_render_batch_async)
     int aov_ctx = 0;                // the context whose AOV images readback_aov returns (last finished frame)
     bool output_overwritten = false; // a newer frame was submitted on output_ctx / aov_ctx: its resolve rewrites the images a read-back
     bool aov_overwritten = false;    // would return, so read-backs fail until that frame has been waited for
@@ -214,22 +313,11 @@ struct rptr_hip {
     int tail_adaptive = 1 << 30;    // adaptive choice for the next frame (from the queue lengths of the last finished frame)
     int tail_blocks = 0;
     int tail_threshold = 65536;     // RPTR_TAIL_THRESHOLD: queue length below which a bounce goes to the tail kernel
-    // the frame as ONE launch driven from device-side queues (kernels.h rp_k_frame; rptr_hip_set_frame_schedule, RPTR_FRAME_KERNEL)
-    int frame_kernel = 0;           // 0: stage launches, 1: one launch per frame (rp_k_frame), 2: a tracer and a shader kernel side by side (streaming)
-    int stream_trace_per_cu = 0, stream_shade_per_cu = 0; // RPTR_STREAM_TRACE_BLOCKS / RPTR_STREAM_SHADE_BLOCKS per CU (0: 4 and 1)
-    int frame_pub_mode = -1;        // RPTR_FRAME_PUB: -1 adaptive, k >= 1: bounces 0 .. k-1 have global queues
-    int frame_pub_max = 4;          // RPTR_FRAME_PUB_MAX: global queues a frame context may hold (path_capacity entries each)
-    int frame_pub_adaptive = 2;     // the next frame's choice (from the queue lengths of the last finished frame)
-    int frame_local_threshold = 262144; // RPTR_FRAME_LOCAL_THRESHOLD: a bounce whose PARENT queue is shorter stays with its blocks
-    int frame_k0 = 0;               // RPTR_FRAME_K0: slots of bounce 0 a block takes at a time (0: from the frame size)
-    int frame_blocks_per_cu = 0;    // RPTR_FRAME_BLOCKS_PER_CU (0: what the occupancy query says)
     // ray queries on device buffers (enable_ray_queries / render_ray_queries: the reference's ray_query_buffer / ray_result_buffer)
     RptrRenderRayQuery *rq_queries = nullptr;
     float4 *rq_results = nullptr;
     size_t rq_capacity = 0;
-    bool cams_general = getenv("RPTR_CAMS_GENERAL") && atoi(getenv("RPTR_CAMS_GENERAL")) != 0; // A/B knob, see render: per-frame cameras through the general kernels
     bool lights_disabled = false;   // light_sampling_variant == LIGHT_SAMPLING_VARIANT_NONE: no area-light NEE (rptr_hip_set_light_sampling_variant)
-    int frame_fine_grained = 0;     // RPTR_FRAME_FINE_GRAINED (measured: no effect; the release fences do the work): path state + queue ids of the frame kernel in fine-grained device memory
     bool aovs = true;               // the reference writes its AOV images with every frame (ENABLE_AOV_BUFFERS, render_vulkan.cpp:2083-2086)
     RptrCamera prev_camera;         // the previous frame's view (VP_reference)
     bool have_prev_camera = false;
@@ -265,6 +353,13 @@ int fail(rptr_hip *h, int code, const char *fmt, ...) {
     if (h) h->last_error = buf;
     g_last_error = buf;
     return code;
+}
+
+// the members the frame loop reads per frame follow the options (the rest is read where it takes effect: initialize, set_scene, comm init)
+void sync_options(rptr_hip *h) {
+    h->tail_mode = (int)h->opt.v[OPT_TAIL_BOUNCE];
+    h->tail_threshold = (int)h->opt.v[OPT_TAIL_THRESHOLD];
+    h->stage_timing = (int)h->opt.v[OPT_STAGE_TIMING];
 }
 
 // Hardware queues. Every frame context renders on a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
@@ -312,7 +407,7 @@ static void ensure_hw_queues(int frames_in_flight) {
             snprintf(buf, sizeof buf, "%d", want);
             setenv("GPU_MAX_HW_QUEUES", buf, 1);
             g_hw_queues_set_by_library = true;
-        } else if (!getenv("RPTR_QUIET") || atoi(getenv("RPTR_QUIET")) == 0) {
+        } else if (effective_default_options().v[OPT_QUIET] == 0) {
             static bool warned = false;
             if (!warned)
                 fprintf(stderr, "rptr_hip: GPU_MAX_HW_QUEUES=%d but %d frame contexts want %d hardware queues (streams that share a queue serialise); "
@@ -329,13 +424,11 @@ static void ensure_hw_queues(int frames_in_flight) {
         if (_e != hipSuccess) return fail(h, RPTR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-// fine: device memory that is coherent INSIDE a launch (hipDeviceMallocFinegrained: not held in the per-XCD L2s) -- what one workgroup of the
-// frame kernel writes for another to read (kernels.h rp_k_frame)
 template <class T>
-int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track, bool fine = false) {
+int dev_alloc(rptr_hip *h, T **out, size_t count, std::vector<void *> *track) {
     void *p = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    hipError_t e = fine ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+    hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(h, RPTR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     (track == &h->scene_allocs ? h->bytes_scene : h->bytes_frame) += bytes;
     h->bytes_allocated = h->bytes_scene + h->bytes_frame;
@@ -429,7 +522,7 @@ struct HostBvh {
     int device_iterations = 0;
 };
 
-// RPTR_FLATTEN=1: a static scene with several instances is built as ONE bottom-level tree over all instanced triangles,
+// Flattening (option "flatten", default auto): a static scene with several instances is built as ONE bottom-level tree over all instanced triangles,
 // pre-transformed to world space (a 10 M-triangle forest is 0.6 GB of triangles and nodes: nothing on a 288 GB device). Rays then
 // meet one well-separated tree instead of a thousand overlapping instance boxes, each with its own ray transform. Hits are
 // found on the world-space triangles, so t / u / v may differ from the two-level walk by rounding; shading still reads the
@@ -476,11 +569,12 @@ static std::string validate_scene_tables(const RptrSceneDesc *s) {
     return std::string();
 }
 
-static bool want_flatten(const RptrSceneDesc *s) {
-    const char *e = getenv("RPTR_FLATTEN");
-    if (!e || atoi(e) == 0 || s->num_instances < 2) return false;
-    size_t limit = (size_t)1 << 26;
-    if (const char *m = getenv("RPTR_FLATTEN_MAX_TRIS")) limit = (size_t)atoll(m);
+static bool want_flatten(const RptrSceneDesc *s, const RpOptions &o) {
+    // option "flatten": -1 / 1 = every static multi-instance scene that fits "flatten_max_tris" (the default: the library knows which
+    // meshes are dynamic -- RptrMeshDesc.dynamic, the reference's per-mesh build intent, vulkan/render_vulkan.cpp:942-952 -- and a flattened
+    // tree is 1.5-1.6 x faster to trace than the two-level one); 0 = never
+    if (o.v[OPT_FLATTEN] == 0 || s->num_instances < 2) return false;
+    const size_t limit = (size_t)o.v[OPT_FLATTEN_MAX_TRIS];
     size_t total = 0;
     for (uint32_t i = 0; i < s->num_instances; ++i) {
         const RptrMeshDesc &mesh = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh].mesh];
@@ -608,7 +702,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
     uint32_t host_totals[2] = {n, n}; // clusters, nodes made so far (ids below n are the triangles)
     DB_TRY(hipMemcpyAsync(totals, host_totals, sizeof(host_totals), hipMemcpyHostToDevice, st));
     size_t top_k = RP_PLOC_TOP;
-    if (const char *e = getenv("RPTR_PLOC_TOP")) top_k = std::max<size_t>(1, (size_t)atoll(e));
+    if (h->opt.v[OPT_PLOC_TOP] > 0) top_k = (size_t)h->opt.v[OPT_PLOC_TOP];
     uint32_t m = n, nodes_before = n;
     int iterations = 0;
     while (m > top_k && m > 1) {
@@ -788,7 +882,7 @@ static bool device_build_tree(rptr_hip *h, const std::vector<RpBuildSegment> &se
 #undef DB_ALLOC
 }
 
-static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuildCtx *dev = nullptr) {
+static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &opt, const DeviceBuildCtx *dev = nullptr) {
     // instanceCustomIndex of every parameterized mesh = number of geometries before it (render_vulkan.cpp:2748-2850)
     std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
     {
@@ -845,18 +939,17 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
             off += nt;
         }
     }
-    const bool flatten = want_flatten(s);
+    const bool flatten = want_flatten(s, opt);
+    rptr::build_tuning().collapse_rule = (int)opt.v[OPT_COLLAPSE];
+    rptr::build_tuning().ploc_top = (size_t)opt.v[OPT_PLOC_TOP];
+    rptr::build_tuning().ploc_leaf = (int)opt.v[OPT_PLOC_LEAF];
     // spatial splits for static geometry (bvh_build.h presplit_triangles): RPTR_PRESPLIT="density[,budget]". Off unless asked for:
     // on the 10 M-triangle forest they buy 16 % fewer triangle tests for 7 % more node visits and twice the references
     // (profiles/r03_notes.md), on height fields nothing
-    float split_density = 0.0f, split_budget = 1.0f;
-    if (const char *e = getenv("RPTR_PRESPLIT")) {
-        split_density = (float)atof(e);
-        if (const char *c = strchr(e, ',')) split_budget = (float)atof(c + 1);
-    }
-    // who builds a bottom-level tree: RPTR_BVH_BUILDER = auto (the device for large static triangle sets, the host otherwise), host, device
-    int builder_mode = 0;
-    if (const char *e = getenv("RPTR_BVH_BUILDER")) builder_mode = !strcmp(e, "host") ? 1 : (!strcmp(e, "device") ? 2 : 0);
+    const float split_density = (float)opt.v[OPT_PRESPLIT_DENSITY], split_budget = (float)opt.v[OPT_PRESPLIT_BUDGET_PCT] * 0.01f;
+    // who builds a bottom-level tree: option "bvh_builder" = 0 auto (the device for large static triangle sets, the host otherwise), 1 host, 2 device
+    const int builder_mode = (int)opt.v[OPT_BVH_BUILDER];
+    const int host_ploc = (int)opt.v[OPT_HOST_PLOC];
     auto on_device = [&](size_t n_tris) {
         return dev && dev->build && builder_mode != 1 && n_tris >= 2 && n_tris < ((size_t)1 << 28) && (builder_mode == 2 || n_tris >= dev->min_tris) &&
                !(split_density > 0.0f && split_budget > 0.0f);
@@ -955,8 +1048,8 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
         if (split_density > 0.0f && split_budget > 0.0f) rptr::presplit_triangles(verts.data(), (uint32_t)verts.size(), split_density, split_budget, 256, 0, prims, ref_tri);
         std::vector<rptr::TriVerts>().swap(verts);
         rptr::BuiltTree tree;
-        if (const char *e = getenv("RPTR_HOST_PLOC")) // experiment: the clustering of the device builder, stated on the host
-            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), std::max(1, atoi(e)), RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
+        if (host_ploc > 0) // experiment: the clustering of the device builder, stated on the host
+            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), host_ploc, RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
         else
             rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
@@ -1066,15 +1159,15 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
         std::vector<uint32_t> ref_tri;
         if (split_mesh) rptr::presplit_triangles(verts.data(), (uint32_t)verts.size(), split_density, split_budget, 256, 0, prims, ref_tri);
         rptr::BuiltTree tree;
-        if (const char *e = getenv("RPTR_HOST_PLOC")) // experiment: the clustering of the device builder, stated on the host
-            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), std::max(1, atoi(e)), RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
+        if (host_ploc > 0) // experiment: the clustering of the device builder, stated on the host
+            rptr::build_bvh2_ploc(prims.data(), (uint32_t)prims.size(), host_ploc, RPTR_BVH_MAX_LEAF_TRIS, 0, tree);
         else
             rptr::build_bvh2(prims.data(), (uint32_t)prims.size(), RPTR_BVH_MAX_LEAF_TRIS, 48, 0, tree);
         rptr::Wide4Tree wide;
         // (the meshes of a scene whose instances get several sub-roots each -- partial re-braiding below -- keep the greedy collapse: the cut
         // through the top of the tree wants the balanced nodes it makes; with the area-optimal collapse the instanced forest needs 38.5
         // instead of 36.8 node visits per ray)
-        rptr::collapse_bvh4(tree, wide, -1, (s->num_instances >= 16 && !getenv("RPTR_HOST_PLOC")) ? rptr::COLLAPSE_GREEDY : rptr::COLLAPSE_OPTIMAL); // (the device builder and its host statement: always the optimal one)
+        rptr::collapse_bvh4(tree, wide, -1, (s->num_instances >= 16 && host_ploc <= 0) ? rptr::COLLAPSE_GREEDY : rptr::COLLAPSE_OPTIMAL); // (the device builder and its host statement: always the optimal one)
         mr.node_base = (int)blas_nodes.size();
         mr.node_count = (int)wide.nodes.size();
         mr.node_capacity = mr.dynamic ? std::max(mr.node_count, (int)mtris.size()) : mr.node_count;
@@ -1100,7 +1193,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
     // sub-roots of its bottom-level tree (the cut is opened largest box first, only through nodes whose children are all
     // inner nodes), each with the world box of its own subtree.
     int braid = s->num_instances >= 16 ? 4 : 1;
-    if (const char *e = getenv("RPTR_REBRAID")) braid = std::max(1, std::min(64, atoi(e)));
+    if (opt.v[OPT_REBRAID] > 0) braid = (int)opt.v[OPT_REBRAID];
     if (flatten) braid = 1;
     std::vector<rptr::BuildPrim> iprims;
     std::vector<RptrBvhInstance> insts;
@@ -1207,8 +1300,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const DeviceBuild
     // (the top level keeps the greedy rule: over the heavily overlapping instance boxes of a forest the area-optimal collapse needs 38.5 node
     // visits per ray where the greedy one needs 36.8 -- there the area of a box says little about what a ray does inside it;
     // RPTR_TLAS_COLLAPSE=optimal to try)
-    int tlas_rule = rptr::COLLAPSE_GREEDY;
-    if (const char *e = getenv("RPTR_TLAS_COLLAPSE")) tlas_rule = !strcmp(e, "optimal") || !strcmp(e, "dp") ? rptr::COLLAPSE_OPTIMAL : !strcmp(e, "even") ? rptr::COLLAPSE_EVEN : rptr::COLLAPSE_GREEDY;
+    const int tlas_rule = (int)opt.v[OPT_TLAS_COLLAPSE]; // (rptr::COLLAPSE_*: 0 greedy)
     rptr::collapse_bvh4(tlas, tlas_wide, tlas_rule);
     for (int k = 0; k < 3; ++k) {
         B.scene_lo[k] = std::isfinite(tlas.lo[k]) ? tlas.lo[k] : 0.0f;
@@ -1341,23 +1433,11 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         // connect(b) -- the shadow rays of bounce b -- on a side stream beside extend(b + 1): both only depend on shade(b). With ONE frame
         // context nothing else fills the ramp-down of a launch: a single frame gets 2-4 % shorter (C2 2.07 -> 2.04 ms, C3 6.52 -> 6.31, a 1/8
         // frame 0.83 -> 0.80, profiles/r03_notes.md). With frames in flight the extra stream only gets in the way of the other frames' launches
-        // (+5 % pipelined): off there. RPTR_SIDE_CONNECT=0|1 overrides.
-        h->side_connect = fif == 1 ? 1 : 0;
-        if (const char *s = getenv("RPTR_SIDE_CONNECT")) h->side_connect = atoi(s) != 0 ? 1 : 0;
+        // (+5 % pipelined): off there. Option "side_connect" = 0 | 1 overrides (the side streams are made by rptr_hip_initialize).
         h->ctx.resize((size_t)fif);
-        if (const char *s = getenv("RPTR_AOVS")) h->aovs = atoi(s) != 0;
-        if (const char *s = getenv("RPTR_TAIL_BOUNCE")) h->tail_mode = atoi(s);
-        if (const char *s = getenv("RPTR_TAIL_THRESHOLD")) h->tail_threshold = std::max(0, atoi(s));
-        if (const char *s = getenv("RPTR_MAX_BATCH_FRAMES")) h->max_batch_frames = std::max(1, std::min(16, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_KERNEL")) h->frame_kernel = std::max(0, std::min(2, atoi(s)));
-        if (const char *s = getenv("RPTR_STREAM_TRACE_BLOCKS")) h->stream_trace_per_cu = std::max(0, std::min(8, atoi(s)));
-        if (const char *s = getenv("RPTR_STREAM_SHADE_BLOCKS")) h->stream_shade_per_cu = std::max(0, std::min(8, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_PUB")) h->frame_pub_mode = atoi(s);
-        if (const char *s = getenv("RPTR_FRAME_PUB_MAX")) h->frame_pub_max = std::max(1, std::min(RP_FQ_MAX, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_LOCAL_THRESHOLD")) h->frame_local_threshold = std::max(0, atoi(s));
-        if (const char *s = getenv("RPTR_FRAME_K0")) h->frame_k0 = std::max(0, std::min(16, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_BLOCKS_PER_CU")) h->frame_blocks_per_cu = std::max(0, std::min(8, atoi(s)));
-        if (const char *s = getenv("RPTR_FRAME_FINE_GRAINED")) h->frame_fine_grained = atoi(s) != 0 ? 1 : 0;
+        h->opt = process_default_options();
+        apply_option_env(h->opt);
+        sync_options(h);
         for (FrameCtx &c : h->ctx) {
             memset(&c.ps, 0, sizeof(c.ps));
             memset(&c.sq, 0, sizeof(c.sq));
@@ -1377,18 +1457,10 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
             (void)hipEventCreateWithFlags(&c.ev_resolved, hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&c.ev_side, hipEventDisableTiming);
-            if (h->side_connect && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) {
-                delete h;
-                return fail(nullptr, RPTR_E_HIP, "hipStreamCreate failed");
-            }
-            if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void **)&c.host_fq, sizeof(RpFqState), hipHostMallocDefault) != hipSuccess ||
-                hipHostMalloc((void **)&c.host_sx, sizeof(RpStState), hipHostMallocDefault) != hipSuccess) {
+            if (hipHostMalloc((void **)&c.host_counters, sizeof(RpCounters), hipHostMallocDefault) != hipSuccess) {
                 delete h;
                 return fail(nullptr, RPTR_E_NOMEM, "hipHostMalloc failed");
             }
-            memset(c.host_fq, 0, sizeof(RpFqState));
-            memset(c.host_sx, 0, sizeof(RpStState));
         }
     }
     // defaults of RenderParams / LightSamplingConfig (librender/render_params.glsl.h:123-155)
@@ -1409,7 +1481,6 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
     h->scene_params.sun_cos_angle = 0.99998933f;
     h->scene_params.sun_radiance[3] = 1.0f;
     h->scene_params.normal_z_scale = 1.0f;
-    if (const char *s = getenv("RPTR_STAGE_TIMING")) h->stage_timing = std::max(0, std::min(2, atoi(s)));
     *out = h;
     return RPTR_OK;
 }
@@ -1433,14 +1504,6 @@ void rptr_hip_destroy(rptr_hip_t *h) {
         for (hipEvent_t e : {c.ev_begin, c.ev_end, c.ev_dep, c.ev_resolved, c.ev_fork, c.ev_side, c.ev_gather})
             if (e) (void)hipEventDestroy(e);
         if (c.host_counters) (void)hipHostFree(c.host_counters);
-        if (c.host_fq) (void)hipHostFree(c.host_fq);
-        if (c.host_sx) (void)hipHostFree(c.host_sx);
-        if (c.stream2) {
-            (void)hipStreamSynchronize(c.stream2);
-            (void)hipStreamDestroy(c.stream2);
-        }
-        for (hipEvent_t e : {c.ev_fork2, c.ev_join2})
-            if (e) (void)hipEventDestroy(e);
         if (c.own_stream) (void)hipStreamDestroy(c.stream);
     }
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1489,20 +1552,28 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->npix_padded = h->tiles_x * h->tiles_y * 64;
     // sample slots in flight: as many as fit a ~6 GiB path-state budget per frame context (288 GB of HBM), at most 16
     const size_t bytes_per_path = 16 * 5 + 8 + 2 * 16 + 5 * 4;
-    size_t budget = (size_t)6 << 30;
-    if (const char *s = getenv("RPTR_PATH_BUDGET_MB")) budget = (size_t)atoll(s) << 20;
+    // (options "path_budget_mb", "max_batch_spp", "max_batch_frames", "aovs", "side_connect", "blocks_per_cu" take effect here)
+    sync_options(h);
+    const size_t budget = (size_t)h->opt.v[OPT_PATH_BUDGET_MB] << 20;
     int mb = (int)std::min<size_t>(16, std::max<size_t>(1, budget / (bytes_per_path * (size_t)h->npix_padded)));
-    if (const char *s = getenv("RPTR_MAX_BATCH_SPP")) mb = std::max(1, atoi(s));
+    if (h->opt.v[OPT_MAX_BATCH_SPP] > 0) mb = (int)h->opt.v[OPT_MAX_BATCH_SPP];
     h->max_batch_spp = mb;
+    h->max_batch_frames = (int)h->opt.v[OPT_MAX_BATCH_FRAMES];
+    h->aovs = h->opt.v[OPT_AOVS] != 0;
+    h->side_connect = h->opt.v[OPT_SIDE_CONNECT] >= 0 ? (int)h->opt.v[OPT_SIDE_CONNECT] : (h->ctx.size() == 1 ? 1 : 0);
+    for (FrameCtx &c : h->ctx) {
+        if (h->side_connect && !c.side) HIP_TRY(h, hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+        if (!h->side_connect && c.side) {
+            (void)hipStreamSynchronize(c.side);
+            (void)hipStreamDestroy(c.side);
+            c.side = nullptr;
+        }
+        c.gstack_side = nullptr; // (frame-sized: freed above, made again below when there is a side stream)
+    }
     const size_t cap = (size_t)h->npix_padded * mb;
     h->path_capacity = cap;
     int rc;
     for (FrameCtx &c : h->ctx) {
-        memset(&c.fq, 0, sizeof(c.fq)); // (freed with the other frame-sized allocations above; made again by the first frame that wants them)
-        memset(&c.ps_fk, 0, sizeof(c.ps_fk));
-        memset(&c.sx, 0, sizeof(c.sx));
-        c.sx_words = 0;
-        c.fq_words = 0;
         if ((rc = dev_alloc(h, &c.ps.ray_o, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.ray_d, cap, nullptr))) return rc;
         if ((rc = dev_alloc(h, &c.ps.thr, cap, nullptr))) return rc;
@@ -1551,7 +1622,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     // fit, so that the kernels of the other frames find room next to it (measured, profiles/r01_notes.md: 3 contexts 5 -> 4 blocks
     // 1.50 -> 1.49 ms per full frame; 11 contexts 5 -> 1 blocks 0.30 -> 0.25 ms per 1/8 frame)
     if (h->ctx.size() > 1) occ = std::max(1, std::min(occ, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
-    if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ = std::max(1, atoi(s));
+    if (h->opt.v[OPT_BLOCKS_PER_CU] > 0) occ = (int)h->opt.v[OPT_BLOCKS_PER_CU];
     h->persistent_blocks = h->num_cus * occ;
     // the shadow-ray kernels may be compiled for more waves per SIMD than the closest-hit kernels (RP_CONNECT_WAVES): their launches get the
     // blocks THEY can have resident (the same cap with frames in flight)
@@ -1560,14 +1631,14 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         HIP_TRY(h, rp_connect_blocks_per_cu(sg, &occ_c));
         occ_c = std::max(1, std::min(occ_c, 8));
         if (h->ctx.size() > 1) occ_c = std::max(1, std::min(occ_c, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
-        if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ_c = std::max(1, atoi(s));
+        if (h->opt.v[OPT_BLOCKS_PER_CU] > 0) occ_c = (int)h->opt.v[OPT_BLOCKS_PER_CU];
         h->connect_blocks[sg] = h->num_cus * occ_c;
     }
     int occ_l = 0;
     HIP_TRY(h, rp_extend_later_blocks_per_cu(&occ_l));
     occ_l = std::max(1, std::min(occ_l, 8));
     if (h->ctx.size() > 1) occ_l = std::max(1, std::min(occ_l, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
-    if (const char *s = getenv("RPTR_BLOCKS_PER_CU")) occ_l = std::max(1, atoi(s));
+    if (h->opt.v[OPT_BLOCKS_PER_CU] > 0) occ_l = (int)h->opt.v[OPT_BLOCKS_PER_CU];
     h->extend_later_blocks = h->num_cus * occ_l;
     h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
     const size_t stack_threads = (size_t)std::max(std::max(h->persistent_blocks, h->extend_later_blocks), std::max(h->connect_blocks[0], h->connect_blocks[1])) * RP_TRAVERSE_BLOCK;
@@ -1773,7 +1844,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         DeviceBuildCtx ctx;
         ctx.d_qpos = &d_qpos;
         ctx.geoms = &geoms;
-        if (const char *e = getenv("RPTR_DEVICE_BUILD_MIN_TRIS")) ctx.min_tris = (size_t)atoll(e);
+        ctx.min_tris = (size_t)h->opt.v[OPT_DEVICE_BUILD_MIN_TRIS];
         int device_failures = 0;
         std::string device_failure;
         ctx.build = [&](const std::vector<RpBuildSegment> &segs, uint32_t n, DeviceTree &out) {
@@ -1787,8 +1858,8 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             return ok;
         };
         const auto t_build = std::chrono::steady_clock::now();
-        build_host_bvh(s, B, &ctx);
-        if (device_failures && (!getenv("RPTR_QUIET") || atoi(getenv("RPTR_QUIET")) == 0))
+        build_host_bvh(s, B, h->opt, &ctx);
+        if (device_failures && h->opt.v[OPT_QUIET] == 0)
             fprintf(stderr, "rptr_hip: note: %d device-side BVH build(s) failed (%s); the host builder built those trees instead\n", device_failures,
                     device_failure.c_str());
         h->bvh_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
@@ -1964,7 +2035,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_lights = (int)s->num_lights;
     h->master.dscene.num_materials = (int)s->num_materials;
     h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
-    h->master.dscene.single_instance = (h->num_tlas_insts == 1 && !getenv("RPTR_NO_SINGLE_INSTANCE")) ? 1 : 0;
+    h->master.dscene.single_instance = (h->num_tlas_insts == 1 && h->opt.v[OPT_SINGLE_INSTANCE] != 0) ? 1 : 0;
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
     h->master.dscene.srgb_lut = d_srgb_lut;
@@ -2021,13 +2092,13 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             node_min = 16;
             refill_min = 32;
         }
-        if (const char *e = getenv("RPTR_TRAVERSE_PRESET")) {
-            node_min = atoi(e);
-            if (const char *c = strchr(e, ',')) refill_min = atoi(c + 1);
+        if (h->opt.v[OPT_TRAVERSE_NODE_MIN] >= 0) { // options "traverse_node_min" / "traverse_refill_min" (0, 0: the compile-time defaults)
+            node_min = (int)h->opt.v[OPT_TRAVERSE_NODE_MIN];
+            refill_min = (int)std::max(0ll, h->opt.v[OPT_TRAVERSE_REFILL_MIN]);
         }
         h->master.dscene.node_min = std::max(0, std::min(64, node_min));
         h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
-        h->master.dscene.lds_top = (getenv("RPTR_LDS_TOP") && atoi(getenv("RPTR_LDS_TOP")) != 0) ? 1 : 0;
+        h->master.dscene.lds_top = h->opt.v[OPT_LDS_TOP] != 0 ? 1 : 0;
     }
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
@@ -2426,101 +2497,12 @@ static inline void pick(bool v, F &&f) {
         f(std::false_type());
 }
 
-// the one-launch frame's buffers, made by the first frame that wants them (frame-sized: initialize frees them with the rest): the control
-// words + one commit counter per slot of every published bounce (one allocation, one memset per frame), an id array per published bounce
-// >= 1, and stack scratch for the frame kernel's grid
-static int ensure_frame_queues(rptr_hip *h, FrameCtx &c, int grid_blocks) {
-    int rc;
-    const size_t slots = h->path_capacity / RP_CHUNK + 2;
-    if (!c.fq.st) {
-        const size_t words = sizeof(RpFqState) / sizeof(uint32_t) + (size_t)(RP_FQ_MAX - 1) * slots;
-        uint32_t *base = nullptr;
-        if ((rc = dev_alloc(h, &base, words, nullptr))) return rc;
-        c.fq.st = reinterpret_cast<RpFqState *>(base);
-        c.fq.commit = base + sizeof(RpFqState) / sizeof(uint32_t);
-        c.fq.slots = (uint32_t)slots;
-        c.fq.capacity = (uint32_t)h->path_capacity;
-        c.fq_words = words;
-        const bool fine = h->frame_fine_grained != 0;
-        if ((rc = dev_alloc(h, &c.fq.ids, (size_t)std::max(1, h->frame_pub_max - 1) * h->path_capacity, nullptr, fine))) return rc;
-        c.ps_fk = c.ps;
-        if (fine) {
-            const size_t cap = h->path_capacity;
-            if ((rc = dev_alloc(h, &c.ps_fk.ray_o, cap, nullptr, true))) return rc;
-            if ((rc = dev_alloc(h, &c.ps_fk.ray_d, cap, nullptr, true))) return rc;
-            if ((rc = dev_alloc(h, &c.ps_fk.thr, cap, nullptr, true))) return rc;
-            if ((rc = dev_alloc(h, &c.ps_fk.illum, cap, nullptr, true))) return rc;
-            c.ps_fk.alpha_rng = nullptr; // (made below when the handle has them: set_scene / set_rng_variant may add them later)
-            c.ps_fk.footprint = nullptr;
-        }
-        const size_t ring_entries = (size_t)RP_FQ_MAX * slots + 8192; // (every block of the grid holds a ticket beyond the last entry)
-        if ((rc = dev_alloc(h, &c.fq.ring, ring_entries, nullptr))) return rc;
-        HIP_TRY(h, hipMemsetAsync(c.fq.ring, 0, ring_entries * sizeof(unsigned long long), c.stream)); // epoch 0: no frame's
-        c.fq.epoch = 0;
-    }
-    {
-        const bool fine = h->frame_fine_grained != 0;
-        if (c.ps.alpha_rng && !c.ps_fk.alpha_rng) {
-            if (!fine) c.ps_fk.alpha_rng = c.ps.alpha_rng;
-            else if ((rc = dev_alloc(h, &c.ps_fk.alpha_rng, h->path_capacity, nullptr, true))) return rc;
-        }
-        if (c.ps.footprint && !c.ps_fk.footprint) {
-            if (!fine) c.ps_fk.footprint = c.ps.footprint;
-            else if ((rc = dev_alloc(h, &c.ps_fk.footprint, h->path_capacity, nullptr, true))) return rc;
-        }
-    }
-    const size_t threads = (size_t)grid_blocks * RP_TRAVERSE_BLOCK;
-    if (threads > c.gstack_threads) { // (the old scratch stays allocated until the next initialize: frames in flight may still use it)
-        if ((rc = dev_alloc(h, &c.gstack, threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
-        c.gstack_threads = threads;
-    }
-    return RPTR_OK;
-}
-
-// the streaming frame's buffers (frame-sized, made by the first frame that wants them)
-static int ensure_stream(rptr_hip *h, FrameCtx &c, int trace_blocks) {
-    int rc;
-    if (!c.sx.st) {
-        const size_t cap = h->path_capacity;
-        const size_t r_capacity = ((std::min<size_t>(3 * cap, (size_t)0x7FFF0000u) + RP_CHUNK - 1) / RP_CHUNK) * RP_CHUNK; // items of all later bounces of a frame
-        const size_t r_chunks = r_capacity / RP_CHUNK, s0_chunks = cap / RP_CHUNK + 2;
-        const size_t words = sizeof(RpStState) / sizeof(uint32_t) + r_chunks + (s0_chunks + r_chunks);
-        uint32_t *base = nullptr;
-        if ((rc = dev_alloc(h, &base, words, nullptr))) return rc;
-        c.sx.st = reinterpret_cast<RpStState *>(base);
-        c.sx.commit = base + sizeof(RpStState) / sizeof(uint32_t);
-        c.sx.traced = c.sx.commit + r_chunks;
-        c.sx_words = words;
-        c.sx.r_capacity = (uint32_t)r_capacity;
-        c.sx.capacity = (uint32_t)cap;
-        if ((rc = dev_alloc(h, &c.sx.r, r_capacity, nullptr))) return rc;
-        c.sx_tr_entries = r_chunks * (RP_CHUNK / RP_ST_POOL) + 65536; // (+ a ticket per tracer wave beyond the last entry)
-        c.sx_sr_entries = s0_chunks + r_chunks + 8192;
-        if ((rc = dev_alloc(h, &c.sx.tr_ring, c.sx_tr_entries, nullptr))) return rc;
-        if ((rc = dev_alloc(h, &c.sx.sr_ring, c.sx_sr_entries, nullptr))) return rc;
-        HIP_TRY(h, hipMemsetAsync(c.sx.tr_ring, 0, c.sx_tr_entries * sizeof(unsigned long long), c.stream));
-        HIP_TRY(h, hipMemsetAsync(c.sx.sr_ring, 0, c.sx_sr_entries * sizeof(unsigned long long), c.stream));
-        c.sx.epoch = 0;
-    }
-    if (!c.stream2) {
-        HIP_TRY(h, hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
-        HIP_TRY(h, hipEventCreateWithFlags(&c.ev_fork2, hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&c.ev_join2, hipEventDisableTiming));
-    }
-    const size_t threads = (size_t)trace_blocks * RP_TRAVERSE_BLOCK;
-    if (threads > c.gstack_threads) {
-        if ((rc = dev_alloc(h, &c.gstack, threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
-        c.gstack_threads = threads;
-    }
-    return RPTR_OK;
-}
-
 static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &scene, const RpFrame &f, const uint32_t *order, int bounce, int out) {
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
     rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures,
-                    f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0 || (bounce == 0 && f.per_frame_cams != 0 && h->cams_general), scene, f, c.ps, c.sq, order,
+                    f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0, scene, f, c.ps, c.sq, order,
                     (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
                     &c.counters->bounce[bounce].shadow_count, c.counters);
 }
@@ -2628,44 +2610,7 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
     }
     h->aov_ctx = (int)(&c - h->ctx.data());
     h->aov_overwritten = false;
-    if (h->local_rows > 0 && c.streamed && (c.host_sx->timeout != 0u || c.host_sx->overflow != 0u))
-        return fail(h, RPTR_E_HIP, "the streaming frame stalled or overflowed (timeouts %u, overflow %u; S0 %u of %u, R tail %u, tracer ring %u/%u, shader ring %u/%u, R chunks out %u, "
-                                   "shaded %u, seals %u)", c.host_sx->timeout, c.host_sx->overflow, c.host_sx->s0_head, c.host_sx->n0, c.host_sx->r_tail, c.host_sx->tr_head,
-                    c.host_sx->tr_tail, c.host_sx->sr_head, c.host_sx->sr_tail, c.host_sx->tr_chunks, c.host_sx->shaded, c.host_sx->seals);
-#ifdef RP_FRAME_PROF
-    if (c.streamed) {
-        const RpStState &q = *c.host_sx;
-        const double tot = std::max(1.0, (double)q.t_total);
-        fprintf(stderr, "[RP_FRAME_PROF] shader blocks: %.3f ms x blocks: wait for a chunk %.3f, load entries %.3f, shade %.3f, append + bookkeeping %.3f | chunks %u seals %u\n", tot * 1e-5,
-                q.t_wait / tot, q.t_load / tot, q.t_shade / tot, q.t_append / tot, q.shaded, q.seals);
-    }
-    if (c.fq_pub_used > 0) {
-        const RpFqState &q = *c.host_fq;
-        const double tot = std::max(1.0, (double)q.t_total);
-        fprintf(stderr, "[RP_FRAME_PROF] block time %.3f ms x blocks: claim %.3f extend %.3f shade %.3f connect %.3f publish %.3f (fence %.4f) | polls %u idle %u\n",
-                tot * 1e-5, q.t_claim / tot, q.t_extend / tot, q.t_shade / tot, q.t_connect / tot, q.t_publish / tot, q.t_fence / tot, q.polls, q.idle_polls);
-    }
-#endif
-    if (h->local_rows > 0 && c.fq_pub_used > 0 && c.host_fq->bad_ids != 0u)
-        return fail(h, RPTR_E_HIP, "the frame kernel read %u queue entries that name no path", c.host_fq->bad_ids);
-    if (h->local_rows > 0 && c.fq_pub_used > 0 && c.host_fq->timeout != 0u)
-        return fail(h, RPTR_E_HIP, "the frame kernel's queue protocol stalled (%u blocks gave up waiting; tail %u %u %u %u done %u %u %u %u final %u %u %u %u ring %u/%u)",
-                    c.host_fq->timeout, c.host_fq->tail[0], c.host_fq->tail[1], c.host_fq->tail[2], c.host_fq->tail[3], c.host_fq->done[0], c.host_fq->done[1],
-                    c.host_fq->done[2], c.host_fq->done[3], c.host_fq->final[0], c.host_fq->final[1], c.host_fq->final[2], c.host_fq->final[3],
-                    c.host_fq->ring_head, c.host_fq->ring_tail);
-    if (h->local_rows > 0 && c.fq_pub_used > 0) {
-        // how many bounces of the next one-launch frame get global queues: bounce b does when its PARENT queue was long (its survivors are
-        // then worth redistributing over all blocks); lengths are known for the bounces that were published, so the number grows by one per
-        // frame at most
-        const RpFqState &q = *c.host_fq;
-        int next = c.fq_pub_used + 1;
-        for (int b = 1; b <= c.fq_pub_used; ++b)
-            if (q.tail[b - 1] <= (uint32_t)h->frame_local_threshold) {
-                next = b;
-                break;
-            }
-        h->frame_pub_adaptive = std::max(1, std::min(next, h->frame_pub_max));
-    } else if (h->local_rows > 0) {
+    if (h->local_rows > 0) {
         // where the next frame hands over to the tail kernel: the first bounce whose queue was short in this frame. Queue
         // lengths are known up to the bounce the tail took over at (it does not publish its block-local lists), so the
         // hand-over moves later by one bounce per frame at most
@@ -2724,7 +2669,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
         return fail(h, RPTR_E_INVALID, "a launch sequence holds at most %d frames with cameras of their own", RP_BATCH_CAMS);
     if (n_frames > 1) {
         if (h->ctx.size() < 2) return fail(h, RPTR_E_INVALID, "batches of frames need frames_in_flight >= 2 (every frame of a batch keeps its own image)");
-        if (n_frames > h->max_batch_frames) return fail(h, RPTR_E_INVALID, "a batch holds at most %d frames (RPTR_MAX_BATCH_FRAMES)", h->max_batch_frames);
+        if (n_frames > h->max_batch_frames) return fail(h, RPTR_E_INVALID, "a batch holds at most %d frames (option \"max_batch_frames\", read by rptr_hip_initialize)", h->max_batch_frames);
         if (n_frames * spp > h->max_batch_spp)
             return fail(h, RPTR_E_INVALID, "%d frames of %d samples do not fit the %d sample slots in flight (RPTR_PATH_BUDGET_MB)", n_frames, spp, h->max_batch_spp);
         if (h->freeze_frame) return fail(h, RPTR_E_INVALID, "a frozen frame cannot be batched with others");
@@ -2815,7 +2760,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     // measured on C3 with 48 textured materials it costs 6 % of the shade time and gains nothing (every material runs the same BSDF code),
     // so it is off unless asked for. The separate counting-sort pass of rounds 1-2 (rp_k_sort_*: three launches per bounce, one frame
     // context only, 0.4 ms per frame) lost on every configuration and is gone (profiles/r03_notes.md section 6).
-    f.regroup_materials = (getenv("RPTR_REGROUP") && atoi(getenv("RPTR_REGROUP")) != 0) ? 1 : 0;
+    f.regroup_materials = h->opt.v[OPT_REGROUP] != 0 ? 1 : 0;
     size_t ev_cursor = 0;
     c.spans.clear();
     auto timed_on = [&](hipStream_t st, int kind, auto &&launch) {
@@ -2851,9 +2796,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     };
     // the general instantiation of the path stages: a table point set, or a screen jitter (raster TAA) -- the shipped path carries neither
     const bool table_rng_later = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
-    // (RPTR_CAMS_GENERAL=1, an A/B knob: frames with cameras of their own go through the general instantiation of the launches that make
-    // camera rays, as they did when the feature went in)
-    const bool table_rng = table_rng_later || (per_frame_cameras && h->cams_general);
+    const bool table_rng = table_rng_later;
     const bool side = c.side != nullptr;
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
@@ -2903,89 +2846,12 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             const uint32_t first_count = (uint32_t)((size_t)batch * h->npix_padded);
             const uint32_t *first_ids = nullptr;
             HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.counters->bounce[0].queue_count, (int)first_count, 1, c.stream));
-            // the frame as a tracer and a shader kernel that run side by side for its whole length (kernels.h rp_k_stream_*); counting and
-            // alpha-tested scenes keep the stage launches
-            c.fq_pub_used = 0;
-            c.streamed = false;
-            if (h->frame_kernel == 2 && !count_traversal && !h->uses_alpha) {
-                const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
-                int tpc = h->stream_trace_per_cu, spc = h->stream_shade_per_cu > 0 ? h->stream_shade_per_cu : 1;
-                if (tpc <= 0) {
-                    HIP_TRY(h, rp_stream_trace_blocks_per_cu(&tpc));
-                    tpc = std::max(1, std::min(tpc, 4)); // (four tracer blocks leave a CU's fifth wave slot per SIMD -- and its last 128 registers -- to the shader)
-                }
-                const int tblocks = h->num_cus * tpc, sblocks = h->num_cus * spc;
-                int rcs = ensure_stream(h, c, tblocks);
-                if (rcs) return rcs;
-                HIP_TRY(h, hipMemsetAsync(c.sx.st, 0, c.sx_words * sizeof(uint32_t), c.stream));
-                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.sx.st->n0, (int)first_count, 1, c.stream));
-                c.sx.epoch = c.sx.epoch >= 65535u ? 1u : c.sx.epoch + 1u;
-                if (c.sx.epoch == 1u && h->next_ticket > 1) {
-                    HIP_TRY(h, hipMemsetAsync(c.sx.tr_ring, 0, c.sx_tr_entries * sizeof(unsigned long long), c.stream));
-                    HIP_TRY(h, hipMemsetAsync(c.sx.sr_ring, 0, c.sx_sr_entries * sizeof(unsigned long long), c.stream));
-                }
-                RpStream sx = c.sx;
-                sx.n_s0_chunks = (first_count + RP_CHUNK - 1) / RP_CHUNK;
-                HIP_TRY(h, hipEventRecord(c.ev_fork2, c.stream));
-                HIP_TRY(h, hipStreamWaitEvent(c.stream2, c.ev_fork2, 0));
-                if (getenv("RPTR_STREAM_DBG"))
-                    fprintf(stderr, "[stream] st %p r %p commit %p traced %p tr %p sr %p cap %u chunks0 %u epoch %u words %zu sizeof(RpStream) %zu RpFrame %zu RpScene %zu\n", (void *)sx.st,
-                            (void *)sx.r, (void *)sx.commit, (void *)sx.traced, (void *)sx.tr_ring, (void *)sx.sr_ring, sx.r_capacity, sx.n_s0_chunks, sx.epoch, c.sx_words,
-                            sizeof(RpStream), sizeof(RpFrame), sizeof(RpScene));
-                const int sdbg = getenv("RPTR_STREAM_DBG") ? atoi(getenv("RPTR_STREAM_DBG")) : 0; // experiments: 1 tracer only, 2 shader only (both end in the watchdog)
-                if (sdbg != 2) rp_launch_stream_trace(timed_launch(c.stream, 3, (unsigned)tblocks), single, table_rng, scn.dscene, f, c.ps, c.sq, sx, c.gstack);
-                if (sdbg != 1)
-                    rp_launch_stream_shade(variant, RpLaunch{(unsigned)sblocks, c.stream2, nullptr, nullptr}, lights, h->uses_textures, table_rng, scn.dscene, f, c.ps, c.sq, sx,
-                                           c.counters);
-                HIP_TRY(h, hipEventRecord(c.ev_join2, c.stream2));
-                HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_join2, 0));
-                HIP_TRY(h, hipMemcpyAsync(c.host_sx, c.sx.st, sizeof(RpStState), hipMemcpyDeviceToHost, c.stream));
-                c.streamed = true;
-                c.fq_pub_used = -1;
-                c.tail_from = 0;
-            }
-            // the whole frame in ONE launch (kernels.h rp_k_frame); counting keeps the stand-alone kernels
-            if (h->frame_kernel == 1 && !count_traversal) {
-                const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
-                const bool full = h->uses_textures || h->uses_alpha;
-                int per_cu = h->frame_blocks_per_cu;
-                if (per_cu <= 0) {
-                    HIP_TRY(h, rp_frame_blocks_per_cu(variant, lights, full, &per_cu));
-                    per_cu = std::max(1, std::min(per_cu, 8)); // (the ring holds 8192 tickets beyond its entries: 8 blocks per CU at most)
-                    // frames in flight share the CUs (as the traversal launches of the staged schedule do)
-                    if (h->ctx.size() > 1) per_cu = std::max(1, std::min(per_cu, (int)((8 + h->ctx.size() / 2) / h->ctx.size())));
-                }
-                const int blocks = h->num_cus * per_cu;
-                int n_pub = h->frame_pub_mode > 0 ? h->frame_pub_mode : h->frame_pub_adaptive;
-                n_pub = std::max(1, std::min(std::min(n_pub, h->frame_pub_max), std::min(h->params.max_path_depth, (int)RP_FQ_MAX)));
-                int rcq = ensure_frame_queues(h, c, blocks);
-                if (rcq) return rcq;
-                const uint32_t slots0 = (first_count + RP_CHUNK - 1) / RP_CHUNK;
-                // slots of bounce 0 a block takes at a time: enough rays to keep refilling its lanes, few enough that every block gets several turns
-                int k0 = h->frame_k0 > 0 ? h->frame_k0 : (int)std::max<uint32_t>(1u, std::min<uint32_t>(4u, slots0 / (4u * (uint32_t)blocks)));
-                if (n_pub == 1) k0 = 1; // the survivors stay with the block: one chunk at a time (kernels.h)
-                HIP_TRY(h, hipMemsetAsync(c.fq.st, 0, c.fq_words * sizeof(uint32_t), c.stream));
-                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.fq.st->tail[0], (int)first_count, 1, c.stream));
-                HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)&c.fq.st->final[0], 1, 1, c.stream));
-                c.fq.epoch = c.fq.epoch >= 65535u ? 1u : c.fq.epoch + 1u;
-                if (c.fq.epoch == 1u && h->next_ticket > 1) // the tags wrap: forget the old ones
-                    HIP_TRY(h, hipMemsetAsync(c.fq.ring, 0, ((size_t)RP_FQ_MAX * c.fq.slots + 8192) * sizeof(unsigned long long), c.stream));
-                RpFrameQueues fq = c.fq;
-                fq.n_pub = n_pub;
-                fq.k0 = k0;
-                fq.dbg = getenv("RPTR_FRAME_DBG") ? (uint32_t)atoi(getenv("RPTR_FRAME_DBG")) : 0u;
-                rp_launch_frame(variant, timed_launch(c.stream, 3, (unsigned)blocks), lights, full, single, table_rng, scn.dscene, f, c.ps_fk, c.sq, fq, c.counters,
-                                c.gstack);
-                HIP_TRY(h, hipMemcpyAsync(c.host_fq, c.fq.st, sizeof(RpFqState), hipMemcpyDeviceToHost, c.stream));
-                c.fq_pub_used = n_pub;
-                c.tail_from = 0;
-            }
             // the late bounces in one launch (kernels.h rp_k_tail); counting keeps the stand-alone kernels
             int tail_from = h->params.max_path_depth;
             if (h->tail_mode != 0 && !count_traversal)
                 tail_from = std::max(1, std::min(h->params.max_path_depth, h->tail_mode > 0 ? h->tail_mode : h->tail_adaptive));
-            if (!c.fq_pub_used) c.tail_from = tail_from;
-            for (int b = 0; b < h->params.max_path_depth && c.fq_pub_used == 0; ++b) {
+            c.tail_from = tail_from;
+            for (int b = 0; b < h->params.max_path_depth; ++b) {
                 const int in = b & 1, out = in ^ 1;
                 RpBounceCounters *bc = &c.counters->bounce[b];
                 if (b == tail_from) {
@@ -3023,7 +2889,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
             if (multi && h->last_resolved && h->last_resolved != c.ev_resolved) HIP_TRY(h, hipStreamWaitEvent(c.stream, h->last_resolved, 0));
             {
                 const size_t npix = (size_t)h->width * h->local_rows;
-                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.fq_pub_used > 0 ? c.ps_fk : c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
+                timed_kernel(c.stream, 4, rp_k_resolve, dim3(grid_for(h, npix)), dim3(256), f, c.ps, h->accum, h->fb, c.out_accum, c.out_fb);
             }
             if (multi) { // (the resolve also kept a copy of the image this frame produced: the next frame's resolve overwrites the shared buffers)
                 HIP_TRY(h, hipEventRecord(c.ev_resolved, c.stream));
@@ -3086,30 +2952,6 @@ int rptr_hip_bvh_rebuild_count(const rptr_hip_t *h, uint64_t *out_rebuilds) {
     return RPTR_OK;
 }
 
-int rptr_hip_set_frame_schedule(rptr_hip_t *h, int one_launch_per_frame) {
-    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
-    h->frame_kernel = std::max(0, std::min(2, one_launch_per_frame)); // 2: the streaming pair (rp_k_stream_trace + rp_k_stream_shade)
-    return RPTR_OK;
-}
-int rptr_hip_get_frame_schedule(const rptr_hip_t *h, int32_t *out_one_launch, int32_t *out_published_bounces, uint32_t *out_queue_lengths, int cap) {
-    if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
-    if (out_one_launch) *out_one_launch = h->frame_kernel;
-    const FrameCtx &c = h->ctx[(size_t)std::max(0, h->aov_ctx)];
-    if (out_published_bounces) *out_published_bounces = c.fq_pub_used;
-    for (int b = 0; out_queue_lengths && b < cap; ++b) out_queue_lengths[b] = (b < RP_FQ_MAX && b < c.fq_pub_used) ? c.host_fq->tail[b] : 0u;
-    if (c.streamed && out_queue_lengths && cap >= 4) { // the streaming frame: camera paths, later items, chunks sealed at the end, chunks shaded
-        out_queue_lengths[0] = c.host_sx->n0;
-        out_queue_lengths[1] = c.host_sx->r_tail;
-        out_queue_lengths[2] = c.host_sx->seals;
-        out_queue_lengths[3] = c.host_sx->shaded;
-    }
-    if (out_queue_lengths && cap > RP_FQ_MAX + 1) { // diagnostics behind the lengths: claim attempts, attempts that found nothing
-        out_queue_lengths[RP_FQ_MAX] = c.host_fq->polls;
-        out_queue_lengths[RP_FQ_MAX + 1] = c.host_fq->idle_polls;
-    }
-    return RPTR_OK;
-}
-
 int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     h->freeze_frame = freeze_frame != 0;
@@ -3146,9 +2988,34 @@ int rptr_hip_set_rng_variant(rptr_hip_t *h, int rng_variant, const void *table, 
 int rptr_hip_set_stage_timing(rptr_hip_t *h, int level) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (level < 0 || level > 2) return fail(h, RPTR_E_INVALID, "stage timing level %d (0 none, 1 extend only, 2 all stages)", level);
+    h->opt.v[OPT_STAGE_TIMING] = level;
     h->stage_timing = level;
     return RPTR_OK;
 }
+
+// ---- options (the table at the top of this file)
+int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value) {
+    const int k = find_option(key);
+    if (k < 0) return fail(h, RPTR_E_INVALID, "rptr_hip_set_option: unknown option \"%s\"", key ? key : "(null)");
+    if (value < g_opt_desc[k].lo || value > g_opt_desc[k].hi)
+        return fail(h, RPTR_E_INVALID, "rptr_hip_set_option: %s = %lld is outside [%lld, %lld]", key, (long long)value, g_opt_desc[k].lo, g_opt_desc[k].hi);
+    if (!h) { // the process default: what new handles (and the handle-less rptr_hip_build_bvh_host) start from
+        process_default_options().v[k] = value;
+        return RPTR_OK;
+    }
+    if (h->opt.from_env[k]) return RPTR_OK; // the environment variable of this option is set: the experimenter's override stands (rptr_hip_get_option tells)
+    h->opt.v[k] = value;
+    sync_options(h);
+    return RPTR_OK;
+}
+int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value) {
+    const int k = find_option(key);
+    if (k < 0 || !out_value) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_get_option: unknown option \"%s\" or NULL result", key ? key : "(null)");
+    *out_value = h ? h->opt.v[k] : effective_default_options().v[k];
+    return RPTR_OK;
+}
+int rptr_hip_option_count(void) { return OPT_COUNT; }
+const char *rptr_hip_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_opt_desc[index].key : nullptr; }
 
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
@@ -3433,7 +3300,7 @@ int rptr_hip_build_bvh_host(const RptrSceneDesc *scene, void *nodes, size_t *n_n
         if (!bad.empty()) return fail(nullptr, RPTR_E_INVALID, "%s", bad.c_str());
     }
     HostBvh B;
-    build_host_bvh(scene, B);
+    build_host_bvh(scene, B, effective_default_options());
     if (nodes && n_nodes && *n_nodes >= B.nodes.size()) memcpy(nodes, B.nodes.data(), B.nodes.size() * sizeof(RptrBvh4Node));
     if (tris && n_tris && *n_tris >= B.tris.size()) memcpy(tris, B.tris.data(), B.tris.size() * sizeof(RptrBvhTri));
     if (instances && n_instances && *n_instances >= B.insts.size()) memcpy(instances, B.insts.data(), B.insts.size() * sizeof(RptrBvhInstance));

@@ -57,6 +57,44 @@ def test_abi_version_is_checked_before_anything_else():
     assert abi.TextureDesc.mip_levels.offset == 20 and C.sizeof(abi.TextureDesc) == 24
 
 
+def test_options_are_part_of_the_c_abi_and_the_environment_only_overrides():
+    """include/rptr_hip.h "Options" (what decides the benchmarked numbers was read with getenv and absent from the ABI): every
+    switch is a named integer reachable through rptr_hip_set_option / _get_option -- handle-less here, as the process default --, unknown
+    keys and values out of range are refused, the header's table names every key, and an option's environment variable wins over the
+    default. The default of "flatten" is auto: rptr_hip_build_bvh_host (what set_scene does, on the host) flattens a static multi-instance
+    scene without being told to."""
+    import subprocess
+    import sys
+    L = backend.load_library()
+    hdr = open(os.path.join(ROOT, "include", "rptr_hip.h")).read()
+    n = L.rptr_hip_option_count()
+    keys = [L.rptr_hip_option_name(i).decode() for i in range(n)]
+    assert n >= 20 and L.rptr_hip_option_name(n) is None and len(set(keys)) == n
+    for k in keys:
+        assert re.search(r"\b%s\b" % k, hdr), "include/rptr_hip.h does not document option %s" % k
+    v = C.c_int64(7)
+    assert L.rptr_hip_get_option(None, b"flatten", C.byref(v)) == 0 and v.value == int(os.environ.get("RPTR_FLATTEN", "-1"))
+    assert L.rptr_hip_get_option(None, b"max_batch_frames", C.byref(v)) == 0 and v.value == 8
+    assert L.rptr_hip_set_option(None, b"no_such_option", 1) == abi.RPTR_E_INVALID and b"no_such_option" in L.rptr_hip_last_error(None)
+    assert L.rptr_hip_set_option(None, b"flatten", 5) == abi.RPTR_E_INVALID
+    assert L.rptr_hip_get_option(None, b"nope", C.byref(v)) == abi.RPTR_E_INVALID
+    # a fresh process: default auto-flatten, the process default switched off through the ABI, and the environment's last word
+    probe = ("import sys; sys.path.insert(0, %r)\n"
+             "import numpy as np\n"
+             "from realtimepathtracingresearchframework_amd import backend, scenes\n"
+             "L = backend.load_library(); s = scenes.two_level_test()\n"
+             "def flat():\n"
+             "    return int((np.frombuffer(np.ascontiguousarray(backend.build_bvh_host(s)[1]).tobytes(), np.uint32).reshape(-1, 12)[:, 11] >> 8).max() > 0)\n"
+             "a = flat(); L.rptr_hip_set_option(None, b'flatten', 0); b = flat(); L.rptr_hip_set_option(None, b'flatten', -1); c = flat()\n"
+             "print(a, b, c)") % ROOT
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RPTR_")}
+    env["RPTR_SKIP_TORCH_PRELOAD"] = "1"
+    out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "0", "1"]
+    out = subprocess.run([sys.executable, "-c", probe], env=dict(env, RPTR_FLATTEN="0"), capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["0", "0", "0"]
+
+
 def test_library_asks_for_enough_hardware_queues_when_nobody_did():
     """GPU_MAX_HW_QUEUES (one hardware queue per frame context's stream: DESIGN.md section 3): loading the library in a process that has
     not set the variable sets it, so the C++ hosts get the schedule the benchmark measures; a value the host chose is left alone"""

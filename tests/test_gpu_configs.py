@@ -422,12 +422,12 @@ def _moved(cam, k):
     return c
 
 
-@pytest.mark.parametrize("scene_name,reset_rest,one_launch", [("grid", True, False), ("grid", False, False), ("textured_test", True, False), ("grid", True, True)])
-def test_batched_frames_with_a_camera_per_frame_equal_frames_rendered_one_by_one(scene_name, reset_rest, one_launch):
+@pytest.mark.parametrize("scene_name,reset_rest", [("grid", True), ("grid", False), ("textured_test", True)])
+def test_batched_frames_with_a_camera_per_frame_equal_frames_rendered_one_by_one(scene_name, reset_rest):
     """rptr_hip_render_batch_cameras_async: the reference's loop may move the camera every frame (app.cpp:350-469); a launch sequence
     of 4 frames x 2 spp with four different views gives, frame by frame, the image -- and for the last frame the AOV images, whose
     motion vectors are against the third frame's view -- of the same frames submitted alone. Textured scene: the footprint of the
-    camera rays follows the frame's camera too. one_launch: through the frame kernel."""
+    camera rays follows the frame's camera too."""
     s = scenes.grid(120, 60, with_emitters=True) if scene_name == "grid" else scenes.textured_test()
     W, H, spp, n = 168, 96, 2, 4
     cams = [_moved(s.camera_params(), k) for k in range(n + 1)]
@@ -436,7 +436,6 @@ def test_batched_frames_with_a_camera_per_frame_equal_frames_rendered_one_by_one
         r = backend.RenderHip(frames_in_flight=2)
         r.initialize(W, H)
         r.set_scene(s)
-        r.set_frame_schedule(one_launch)
         out = []
 
         def collect(t):
