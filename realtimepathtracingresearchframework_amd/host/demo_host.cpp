@@ -117,7 +117,47 @@ int main() {
             b2.readback_framebuffer(img2.size(), img2.data());
         }
         std::printf("light sampling NONE: image %s\n", std::memcmp(img.data(), img2.data(), img.size() * 4) == 0 ? "unchanged" : "CHANGED");
-        return std::memcmp(img.data(), img2.data(), img.size() * 4) == 0 ? 0 : 11;
+        if (std::memcmp(img.data(), img2.data(), img.size() * 4) != 0) return 11;
+        // ---- the reference's frame loop (app.cpp:453-469): begin_frame / draw_frame / end_frame with the application's CommandStream*.
+        // Eight frames, the camera moves for the first five (every move restarts the accumulation), then three frames accumulate: through a
+        // command stream (asynchronous: two frames in flight, statistics two frames late) and with nullptr (synchronous) -- same images.
+        auto loop = [&](bool asynchronous, std::vector<float> &out5, std::vector<float> &out8, int &delay_seen, int &valid_after, int &spp_end) {
+            rptr::RenderHip b;
+            b.initialize(64, 64);
+            b.set_scene(scene);
+            b.update_config(sp);
+            b.params.batch_spp = 2;
+            rptr::CommandStream display_stream;
+            rptr::CommandStream *cs = asynchronous ? &display_stream : nullptr;
+            delay_seen = 0;
+            valid_after = -1;
+            for (int f = 0; f < 8; ++f) {
+                rptr::RenderConfiguration c = cfg;
+                c.camera.pos[0] = 0.05f * float(f < 5 ? f : 4);
+                c.reset_accumulation = f <= 4;
+                c.active_swap_buffer_count = asynchronous ? -1 : 1; // app.cpp:386-389
+                b.begin_frame(cs, c);
+                b.draw_frame(cs, c.active_variant);
+                b.end_frame(cs, c.active_variant);
+                const rptr::RenderStats s = b.stats();
+                if (s.has_valid_frame_stats && valid_after < 0) valid_after = f;
+                delay_seen = s.frame_stats_delay;
+                spp_end = s.spp;
+                if (f == 4) {
+                    out5.resize(img.size());
+                    if (b.readback_framebuffer(out5.size(), out5.data()) != out5.size()) return false;
+                }
+            }
+            out8.resize(img.size());
+            return b.readback_framebuffer(out8.size(), out8.data()) == out8.size();
+        };
+        std::vector<float> a5, a8, s5, s8;
+        int a_delay = 0, a_valid = 0, a_spp = 0, s_delay = 0, s_valid = 0, s_spp = 0;
+        if (!loop(true, a5, a8, a_delay, a_valid, a_spp) || !loop(false, s5, s8, s_delay, s_valid, s_spp)) return 12;
+        const bool loop_same = std::memcmp(a5.data(), s5.data(), a5.size() * 4) == 0 && std::memcmp(a8.data(), s8.data(), a8.size() * 4) == 0;
+        std::printf("frame loop through a CommandStream: images %s the synchronous loop's; frame_stats_delay %d / %d, first valid stats at frame %d / %d, spp %d / %d\n",
+                    loop_same ? "=" : "!=", a_delay, s_delay, a_valid, s_valid, a_spp, s_spp);
+        return loop_same && a_delay == 2 && s_delay == 0 && a_valid == 2 && s_valid == 0 && a_spp == 8 && s_spp == 8 ? 0 : 13;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 3;

@@ -14,7 +14,7 @@ namespace rptr {
 class RenderGroup {
 public:
     // devices: HIP ordinals, one rank each (the same ordinal may appear several times: a test rig on one GPU)
-    RenderGroup(const std::vector<int> &devices, int stripe_rows = 8, int frames_in_flight = 1) {
+    RenderGroup(const std::vector<int> &devices, int stripe_rows = 8, int frames_in_flight = RenderHip::MAX_SWAP_BUFFERS) {
         const int n = (int)devices.size();
         if (n < 1) throw std::runtime_error("RenderGroup: no devices");
         for (int i = 0; i < n; ++i) ranks_.emplace_back(new RenderHip(devices[(size_t)i], i, n, stripe_rows, nullptr, frames_in_flight));
@@ -57,6 +57,28 @@ public:
     void set_bvh_policy(bool force_bvh_rebuild, int rebuild_triangle_budget) {
         for (auto &r : ranks_) r->set_bvh_policy(force_bvh_rebuild, rebuild_triangle_budget);
     }
+    void set_option(const char *key, int64_t value) { // before initialize / set_scene (include/rptr_hip.h "Options")
+        for (auto &r : ranks_) r->set_option(key, value);
+    }
+    // The reference's frame loop (app.cpp:453-469) on ONE device: begin_frame / draw_frame / end_frame with the application's CommandStream*
+    // (render_hip.hpp: non-null = submitted, two frames in flight, statistics two frames late). A group of several devices renders such a
+    // frame synchronously (its gather follows the frame).
+    RenderStats frame(CommandStream *cmd_stream, const RenderConfiguration &config) {
+        if (size() > 1 || !cmd_stream) return render(config);
+        RenderHip &r = *ranks_[0];
+        r.begin_frame(cmd_stream, config);
+        r.draw_frame(cmd_stream, config.active_variant);
+        r.end_frame(cmd_stream, config.active_variant);
+        const RenderStats s = r.stats();
+        if (s.has_valid_frame_stats && r.stats_serial() != counted_serial_) { // (the timings of the frame two submissions ago: counted once)
+            rays_ += double(r.rays_of_last_stats());
+            counted_serial_ = r.stats_serial();
+        }
+        return s;
+    }
+    void flush_pipeline() {
+        for (auto &r : ranks_) r->flush_pipeline();
+    }
     // one frame on all GPUs: every rank renders its stripes (asynchronously, side by side), then the tiles are gathered to rank 0
     RenderStats render(const RenderConfiguration &config, int spp = 0) {
         std::vector<uint64_t> tickets;
@@ -90,6 +112,35 @@ public:
         q.frames = n_frames;
         for (auto &r : ranks_) q.tickets.push_back(n_frames > 1 ? r->render_batch_async(config, spp, n_frames, reset_rest) : std::vector<uint64_t>{r->render_async(config, spp)});
         return q;
+    }
+    // ... with a camera per frame: configs[k] is frame k's (rptr_hip_render_batch_cameras_async; the application's loop may move the camera
+    // every frame, app.cpp:350-469)
+    Sequence submit(const std::vector<RenderConfiguration> &configs, int spp, bool reset_rest = true) {
+        Sequence q;
+        q.frames = (int)configs.size();
+        for (auto &r : ranks_)
+            q.tickets.push_back(q.frames > 1 ? r->render_batch_cameras_async(configs.data(), q.frames, spp, reset_rest) : std::vector<uint64_t>{r->render_async(configs[0], spp)});
+        return q;
+    }
+    // one frame of a sequence at a time (hosts that act between the frames: an image per keyframe): the tickets of frame k on every rank,
+    // the gather when it is the sequence's last (all its frames in one collective)
+    RenderStats collect_frame(const Sequence &q, int k) {
+        RenderStats total{};
+        total.has_valid_frame_stats = false;
+        for (size_t i = 0; i < ranks_.size(); ++i) {
+            const RenderStats s = ranks_[i]->wait(q.tickets[i][(size_t)k]);
+            total.render_time = std::max(total.render_time, s.render_time);
+            total.has_valid_frame_stats = total.has_valid_frame_stats || s.has_valid_frame_stats;
+            rays_ += s.has_valid_frame_stats ? double(s.rays_per_second) * s.render_time * 1e-3 : 0.0;
+            total.spp = s.spp;
+            total.total_device_bytes_allocated += s.total_device_bytes_allocated;
+        }
+        if (size() > 1 && k == q.frames - 1) {
+            std::vector<rptr_hip_t *> hs;
+            for (auto &r : ranks_) hs.push_back(r->handle());
+            if (rptr_hip_gather_all_batch(hs.data(), size(), q.frames) != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_gather_all_batch: ") + last_error());
+        }
+        return total;
     }
     std::vector<RenderStats> collect(const Sequence &q, bool per_frame_gather = false) {
         std::vector<RenderStats> out;
@@ -159,6 +210,7 @@ private:
     std::vector<std::unique_ptr<RenderHip>> ranks_;
     int width_ = 0, height_ = 0;
     double rays_ = 0.0;
+    uint64_t counted_serial_ = 0;
 };
 
 } // namespace rptr

@@ -3,7 +3,7 @@
 //   <scene> = the reference's .vks file (textures in <name>_textures/) or the flat dump scenes.py writes (.rpsc)
 //   rptr_hip <scene> --validation <prefix> [--validation-spp n] [--img w h] [--pfm]
 //   rptr_hip <scene.rpsc> --profiling <csv prefix> [--profiling-fps f] [--profiling-img <prefix>] [--profiling-frames n]
-//            [--animate-wave amplitude kx]
+//            [--animate-wave amplitude kx] [--synchronous] [--fly-through] [--frames-in-flight n [--frames-per-launch b]]
 //   common:  [--eye x y z] [--center x y z] [--up x y z] [--fov deg] [--variant gltf|diffuse|gltf-transmission] [--batch-spp k] [--every-frame]
 //            [--config file.ini]... [--keyframe [<seconds>:]file.ini]... [--camera n] [--freeze-frame] [--upscale n] [--backend hip]
 //            [--sky-data <dir with the Hosek-Wilkie data headers>]   (Sun settings of the .ini files refit the sky: host/sky_fit.hpp; also RPTR_SKY_DATA)
@@ -24,6 +24,13 @@
 //    second of animation time. The run ends at its last keyframe (--keyframe [len:]file.ini ...); without keyframes the reference
 //    stops after its first frame (imstate.cpp:890-898) and so does this host unless --profiling-count n (its own flag) asks for n
 //    frames, a keyframe then being one second. --profiling-frames is the reference's old spelling of --profiling-fps.
+//    The loop is the reference's (app.cpp:453-469): begin_frame / draw_frame / end_frame with a command stream -- two frames in flight,
+//    render_time_ms of a row = the statistics the backend has at that point, i.e. of the frame two submissions earlier
+//    (RenderStats::frame_stats_delay, vulkan/render_vulkan.cpp:2229-2243) -- unless --synchronous (the application's "force synchronous
+//    rendering": cmd_stream = nullptr) is given. --frames-in-flight n [--frames-per-launch b] (this host's) queues deeper than the reference's
+//    two swap buffers: launch sequences of b frames, each frame with its own camera, n sequences in flight -- bench.py's schedule;
+//    keyframes and --fly-through (this host's: the camera path of bench.py, yaw 0.002 rad and 2 cm sideways per frame over 64 frames, a
+//    moved camera restarts the accumulation) work in every schedule.
 //  * --animate-wave a k (profiling mode, scenes whose mesh 0 is dynamic): y = y0 + a sin(k x + 2 pi t) on geometry 0 before
 //    every frame, followed by rptr_hip_refit -- SURVEY 8d C5 (the reference animates with a compute shader,
 //    render_vulkan.cpp:2834-2840; per-frame BLAS update + TLAS refit :1323-1354).
@@ -137,7 +144,8 @@ int main(int argc, char **argv) {
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
     int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
     std::string bn_table_path, dump_scene_path, sky_data;
-    int upscale = 0, stripe_rows = 8, frames_in_flight = 1, frames_per_launch = 1;
+    int upscale = 0, stripe_rows = 8, frames_in_flight = 0, frames_per_launch = 1; // frames_in_flight 0: the reference's loop (two swap buffers)
+    bool synchronous = false, fly_through = false;
     std::vector<int> devices{0};
     std::vector<std::string> config_inis;
     struct Keyframe {
@@ -166,7 +174,9 @@ int main(int argc, char **argv) {
         else if (a == "--profiling-frames") { // the reference's old spelling of --profiling-fps (cmdline.cpp:397-403)
             need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; have_profiling_options = true; }
         else if (a == "--frames-in-flight") { need(1); frames_in_flight = std::max(1, std::min(16, std::atoi(argv[++i]))); }   // (this host's: the pipelined schedule of bench.py)
-        else if (a == "--frames-per-launch") { need(1); frames_per_launch = std::max(1, std::min(4, std::atoi(argv[++i]))); }
+        else if (a == "--frames-per-launch") { need(1); frames_per_launch = std::max(1, std::min(8, std::atoi(argv[++i]))); }
+        else if (a == "--synchronous") synchronous = true;   // AppState::synchronous_rendering ("force synchronous rendering", libapp/app_state.cpp:145)
+        else if (a == "--fly-through") fly_through = true;   // (this host's: bench.py's camera path)
         else if (a == "--profiling-count") { need(1); profiling_frames = std::atoi(argv[++i]); have_profiling_options = true; } // (this host's: frames of a run without keyframes)
         else if (a == "--animate-wave") { need(2); wave_amp = (float)std::atof(argv[++i]); wave_k = (float)std::atof(argv[++i]); }
         else if (a == "--img") { need(2); width = std::atoi(argv[++i]); height = std::atoi(argv[++i]); }
@@ -318,7 +328,7 @@ int main(int argc, char **argv) {
     if (want_help) scene_path.clear(); // prints the usage
     if (scene_path.empty() || (int)validation + (int)profiling + (int)data_capture != 1 || batch_spp < 1 || width < 1 || height < 1 || (profiling && profiling_frames < 1)) {
         std::fprintf(stderr, "usage: rptr_hip <scene.rpsc> (--validation <prefix> [--validation-spp n] | --profiling <csv prefix> [--profiling-fps f] "
-                             "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--frames-in-flight n [--frames-per-launch b]] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
+                             "[--profiling-img <prefix>] [--keyframe [len:]file.ini ...] [--profiling-count n] [--synchronous] [--fly-through] [--frames-in-flight n [--frames-per-launch b]] [--animate-wave a k]) [--img w h] [--eye x y z] [--center x y z] "
                              "[--up x y z] [--fov deg] [--variant gltf|diffuse] [--batch-spp k] [--every-frame] [--exr|--pfm|--png] [--config file.ini ...] [--sky-data <dir of the Hosek-Wilkie data headers>]\n"
                              "       rptr_hip <scene.rpsc> --data-capture <prefix> [--data-capture-spp n] [--data-capture-no-rgba] [--data-capture-no-aovs] "
                              "[--data-capture-albedo-roughness] [--data-capture-normal-depth] [--data-capture-motion] [--keyframe ...]   (EXR images per keyframe)\n"
@@ -388,7 +398,8 @@ int main(int argc, char **argv) {
         if (!got_batch_spp) batch_spp = std::max(1, base.params.batch_spp);
         if (!got_variant && base.variant >= 0) variant = base.variant;
         if (upscale >= 1) base.params.render_upscale_factor = upscale;
-        rptr::RenderGroup backend(devices, stripe_rows, frames_in_flight);
+        if (frames_in_flight == 1) synchronous = true; // (one frame context: nothing to overlap)
+        rptr::RenderGroup backend(devices, stripe_rows, std::max(frames_in_flight, (int)rptr::RenderHip::MAX_SWAP_BUFFERS));
         backend.initialize(width, height);
         backend.set_scene(scene.desc());
         base.params.batch_spp = batch_spp;
@@ -434,6 +445,40 @@ int main(int argc, char **argv) {
         if (validation) {
             int accumulated = 0;
             double gpu_ms = 0.0;
+            const auto v0 = std::chrono::steady_clock::now();
+            // The frames of an accumulation are independent launch chains that only meet in the running mean: they are queued as launch
+            // sequences of up to 16 samples (rptr_hip_render_batch_async, reset_rest = 0: frame k continues the accumulation of frame k - 1;
+            // every frame bit-identical to the frame rendered on its own) with two sequences in flight, and collected in order -- the images
+            // are written at the same sample counts, with the same bits, as by the loop of synchronous frames below (--synchronous; a frozen
+            // frame repeats its samples and cannot share a sequence).
+            if (!synchronous && !freeze_frame && (backend.size() == 1 || !every_frame)) { // (a group's gather assembles the LAST frame of a sequence)
+                const int total_frames = (target_spp + batch_spp - 1) / batch_spp;
+                const int per_seq = std::max(1, std::min(8, 16 / std::max(1, batch_spp)));
+                struct Pending {
+                    rptr::RenderGroup::Sequence q;
+                    int first_frame;
+                };
+                std::vector<Pending> queue;
+                int submitted = 0;
+                auto collect_one = [&] {
+                    const Pending p = queue.front();
+                    queue.erase(queue.begin());
+                    for (int k = 0; k < p.q.frames; ++k) {
+                        const rptr::RenderStats st = backend.collect_frame(p.q, k);
+                        accumulated = st.spp;
+                        gpu_ms += st.render_time;
+                        if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
+                    }
+                };
+                while (submitted < total_frames) {
+                    const int n = std::min(per_seq, total_frames - submitted);
+                    cfg.reset_accumulation = submitted == 0;
+                    queue.push_back({backend.submit(cfg, batch_spp, n, /*reset_rest=*/false), submitted});
+                    submitted += n;
+                    if (queue.size() >= 2) collect_one();
+                }
+                while (!queue.empty()) collect_one();
+            }
             while (accumulated < target_spp) {
                 const rptr::RenderStats st = backend.render(cfg); // params.batch_spp samples
                 cfg.reset_accumulation = false;
@@ -441,6 +486,7 @@ int main(int argc, char **argv) {
                 gpu_ms += st.render_time;
                 if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
             }
+            std::printf("%s: wall %.3f ms\n", backend.name().c_str(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - v0).count());
             std::printf("%s: %d spp in %.3f ms GPU time -> %s_%04d.%s\n", backend.name().c_str(), accumulated, gpu_ms, validation_prefix.c_str(), accumulated,
                         format == FORMAT_PFM ? "pfm" : format == FORMAT_PNG ? "png" : "exr");
             return 0;
@@ -503,7 +549,6 @@ int main(int argc, char **argv) {
         std::fprintf(csv, "frames_total,keyframe,frames_accumulated,render_time_ms,app_time_ms\n");
         const float dt = 1.f / profiling_fps;
         double current_time = 0.0, gpu_ms = 0.0;
-        int frames_accumulated = 0;
         // keyframes: each is held for its length on the animation timeline (default one second = profiling_fps frames); without
         // keyframes the run lasts --profiling-frames frames of the base configuration
         std::vector<double> key_end;
@@ -512,92 +557,191 @@ int main(int argc, char **argv) {
             for (double hsec : holds) key_end.push_back(t += std::max(hsec, (double)dt));
             profiling_frames = std::max(1, (int)std::floor(key_end.back() * profiling_fps + 0.5));
         }
-        int active_key = -1;
         auto last = std::chrono::steady_clock::now();
-        // ---- the pipelined schedule (--frames-in-flight n [--frames-per-launch b]; a static view, no keyframes): launch sequences of b frames,
-        // n of them in flight, every frame restarts the accumulation -- exactly what bench.py times (the library asks the HIP runtime for a
-        // hardware queue per frame context itself: csrc/rptr_hip.hip ensure_hw_queues). One CSV line per frame as it is collected.
-        if (frames_in_flight > 1 && frames.empty() && rest.empty()) {
-            frames_per_launch = std::min(frames_per_launch, std::max(1, 16 / std::max(1, batch_spp)));
-            std::vector<rptr::RenderGroup::Sequence> queue;
-            for (int w = 0; w < 2; ++w) { // warm-up: every context renders once, the adaptive tail hand-over settles
-                for (int k = 0; k < frames_in_flight; ++k) {
-                    cfg.reset_accumulation = true;
-                    queue.push_back(backend.submit(cfg, batch_spp, frames_per_launch));
+        // ---- the plan: per frame its keyframe, its view, whether it restarts the accumulation and whether its keyframe ends with it
+        // (libapp/app_state.cpp:484-493: an image once per keyframe, at its end; without keyframe files a keyframe is one second)
+        struct FramePlan {
+            int key = -1;            // index into `frames` (-1: the base configuration)
+            int keyframe_no = 1;     // the CSV's keyframe column
+            int accumulated = 1;     // the CSV's frames_accumulated column
+            bool reset = false, key_ends = false;
+            double time = 0.0;
+            rptr::RenderCameraParams camera;
+        };
+        // --fly-through: bench.py's camera path (camera_of): frame k looks along the view yawed by 0.002 rad x (k mod 64) about its up axis from
+        // 2 cm x (k mod 64) further to the right; evaluated in double as numpy does, rounded to float once
+        const rptr::RenderCameraParams base_camera = cfg.camera;
+        auto fly_camera = [&](int k) {
+            rptr::RenderCameraParams c = base_camera;
+            const int s = k % 64;
+            const double a = 0.002 * s;
+            const double d[3] = {base_camera.dir[0], base_camera.dir[1], base_camera.dir[2]}, u[3] = {base_camera.up[0], base_camera.up[1], base_camera.up[2]};
+            double r[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2], d[0] * u[1] - d[1] * u[0]};
+            const double rl = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            for (double &x : r) x /= rl;
+            double nd[3];
+            for (int i = 0; i < 3; ++i) nd[i] = std::cos(a) * d[i] + std::sin(a) * r[i];
+            const double nl = std::sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+            for (int i = 0; i < 3; ++i) {
+                c.pos[i] = (float)(double(base_camera.pos[i]) + 0.02 * s * r[i]);
+                c.dir[i] = (float)(nd[i] / nl);
+            }
+            return c;
+        };
+        std::vector<FramePlan> plan((size_t)profiling_frames);
+        {
+            int active_key = -1, acc = 0;
+            rptr::RenderCameraParams cam = cfg.camera;
+            for (int frame = 0; frame < profiling_frames; ++frame) {
+                FramePlan &p = plan[(size_t)frame];
+                p.reset = frame == 0;
+                if (!frames.empty()) { // the keyframe this frame belongs to; a change applies its state and restarts the accumulation
+                    int k = 0;
+                    while (k + 1 < (int)key_end.size() && current_time >= key_end[(size_t)k] - 1e-9) ++k;
+                    if (k != active_key) {
+                        active_key = k;
+                        const rptr::HostConfig &st = frames[(size_t)k];
+                        std::memcpy(cam.pos, st.camera.pos, 12);
+                        std::memcpy(cam.dir, st.camera.dir, 12);
+                        std::memcpy(cam.up, st.camera.up, 12);
+                        p.reset = true;
+                    }
                 }
-                for (const auto &q : queue) backend.collect(q);
-                queue.clear();
+                if (!rest.empty()) p.reset = true; // the geometry moves: the accumulation starts over
+                p.camera = cam;
+                if (fly_through) { // a moved camera restarts the accumulation (the application resets when the view changes)
+                    p.camera = fly_camera(frame);
+                    p.reset = true;
+                }
+                p.key = active_key;
+                p.time = current_time;
+                acc = p.reset ? 1 : acc + 1;
+                p.accumulated = acc;
+                p.keyframe_no = frames.empty() ? (int)std::floor(current_time) + 1 : active_key + 1;
+                p.key_ends = frames.empty() ? (current_time + dt) >= std::ceil(current_time + 1e-9) : (current_time + dt) >= key_end[(size_t)active_key] - 1e-9;
+                if (!freeze_frame) current_time += dt; // --freeze-frame keeps repeating the same frame (app.cpp:339-345)
+                else if (!frames.empty() && frame + 1 >= (int)std::floor(key_end[(size_t)active_key] * profiling_fps + 0.5)) current_time = key_end[(size_t)active_key];
+            }
+        }
+        int applied_key = -1;
+        auto apply_key = [&](int k) { // the state of keyframe k: parameters, sky, variant (what is submitted from here on uses it)
+            if (k < 0 || k == applied_key) return;
+            applied_key = k;
+            rptr::HostConfig st = frames[(size_t)k];
+            st.params.batch_spp = batch_spp;
+            if (upscale >= 1) st.params.render_upscale_factor = upscale;
+            backend.set_params(st.params, st.lighting);
+            if (st.sun_changed || st.bump_scale > 0.f) backend.update_config(sky_of(st));
+            if (!got_variant && st.variant >= 0) cfg.active_variant = st.variant;
+        };
+        auto config_of = [&](const FramePlan &p) {
+            rptr::RenderConfiguration c = cfg;
+            c.camera = p.camera;
+            c.reset_accumulation = p.reset;
+            c.time = p.time;
+            return c;
+        };
+        // ---- queued deeper than the reference's two swap buffers (--frames-in-flight n [--frames-per-launch b]): launch sequences of up to b
+        // frames of one keyframe, every frame with its own view (rptr_hip_render_batch_cameras_async), n sequences in flight -- the schedule
+        // bench.py times (the library asks the HIP runtime for a hardware queue per frame context itself: csrc/rptr_hip.hip
+        // ensure_hw_queues). One CSV row per frame as it is collected; render_time_ms is the frame's share of its sequence.
+        if (frames_in_flight > 1 && rest.empty() && !freeze_frame) {
+            frames_per_launch = std::min(frames_per_launch, std::max(1, 16 / std::max(1, batch_spp)));
+            struct Pending {
+                rptr::RenderGroup::Sequence q;
+                int first;
+            };
+            std::vector<Pending> queue;
+            apply_key(plan[0].key);
+            for (int w = 0; w < 2; ++w) { // warm-up: every context renders once, the adaptive tail hand-over settles
+                std::vector<rptr::RenderGroup::Sequence> warm;
+                for (int k = 0; k < frames_in_flight; ++k) {
+                    rptr::RenderConfiguration c = config_of(plan[0]);
+                    c.reset_accumulation = true;
+                    warm.push_back(backend.submit(c, batch_spp, frames_per_launch));
+                }
+                for (const auto &q : warm) backend.collect(q);
             }
             const auto t0 = std::chrono::steady_clock::now();
             const double rays0 = backend.rays_traced();
             last = t0;
             int submitted = 0, collected = 0;
             auto drain_one = [&] {
-                const std::vector<rptr::RenderStats> sts = backend.collect(queue.front());
+                const Pending p = queue.front();
                 queue.erase(queue.begin());
-                for (const rptr::RenderStats &st : sts) {
+                for (int k = 0; k < p.q.frames; ++k) {
+                    const FramePlan &fp = plan[(size_t)(p.first + k)];
+                    const rptr::RenderStats st = backend.collect_frame(p.q, k);
                     gpu_ms += st.render_time;
                     const auto now = std::chrono::steady_clock::now();
-                    std::fprintf(csv, "%d,%d,%d,%g,%g\n", ++collected, 1, 1, st.render_time, std::chrono::duration<double, std::milli>(now - last).count());
+                    std::fprintf(csv, "%d,%d,%d,%g,%g\n", ++collected, fp.keyframe_no, fp.accumulated, st.render_time, std::chrono::duration<double, std::milli>(now - last).count());
                     last = now;
+                    // (an image per keyframe: of a one-device group, or of the frame a group's gather assembled last)
+                    if (!profiling_img_prefix.empty() && fp.key_ends && (backend.size() == 1 || k == p.q.frames - 1))
+                        save_image(backend, format, profiling_img_prefix, fp.keyframe_no, "", width, height, img);
                 }
             };
             while (submitted < profiling_frames) {
-                const int n = std::min(frames_per_launch, profiling_frames - submitted);
-                cfg.reset_accumulation = true;
-                queue.push_back(backend.submit(cfg, batch_spp, n));
+                // the next sequence: frames of ONE keyframe whose later frames all restart the accumulation or all continue it
+                int n = 1;
+                const FramePlan &f0 = plan[(size_t)submitted];
+                while (n < frames_per_launch && submitted + n < profiling_frames && plan[(size_t)(submitted + n)].key == f0.key &&
+                       plan[(size_t)(submitted + n)].reset == plan[(size_t)(submitted + 1)].reset && !(n >= 1 && plan[(size_t)(submitted + n - 1)].key_ends && !profiling_img_prefix.empty() && backend.size() > 1))
+                    ++n;
+                apply_key(f0.key);
+                std::vector<rptr::RenderConfiguration> cs;
+                for (int k = 0; k < n; ++k) cs.push_back(config_of(plan[(size_t)(submitted + k)]));
+                queue.push_back({backend.submit(cs, batch_spp, n > 1 ? plan[(size_t)(submitted + 1)].reset : true), submitted});
                 submitted += n;
                 if ((int)queue.size() >= frames_in_flight) drain_one();
             }
             while (!queue.empty()) drain_one();
             const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::fclose(csv);
-            if (!profiling_img_prefix.empty()) save_image(backend, format, profiling_img_prefix, 1, "", width, height, img);
-            std::printf("%s: %d frames, %d in flight x %d per launch sequence: %.4f ms per frame (wall), %.1f Mrays/s -> %s\n", backend.name().c_str(), profiling_frames,
-                        frames_in_flight, frames_per_launch, wall_ms / profiling_frames, (backend.rays_traced() - rays0) / wall_ms * 1e-3, csv_path.c_str());
+            std::printf("%s: %d frames, %d in flight x %d per launch sequence%s: %.4f ms per frame (wall), %.1f Mrays/s -> %s\n", backend.name().c_str(), profiling_frames,
+                        frames_in_flight, frames_per_launch, fly_through ? ", a camera per frame" : "", wall_ms / profiling_frames, (backend.rays_traced() - rays0) / wall_ms * 1e-3,
+                        csv_path.c_str());
             return 0;
         }
-        for (int frame = 0; frame < profiling_frames; ++frame) {
-            if (!frames.empty()) { // the keyframe this frame belongs to; a change applies its state and restarts the accumulation
-                int k = 0;
-                while (k + 1 < (int)key_end.size() && current_time >= key_end[(size_t)k] - 1e-9) ++k;
-                if (k != active_key) {
-                    active_key = k;
-                    rptr::HostConfig st = frames[(size_t)k];
-                    st.params.batch_spp = batch_spp;
-                    if (upscale >= 1) st.params.render_upscale_factor = upscale;
-                    backend.set_params(st.params, st.lighting);
-                    if (st.sun_changed || st.bump_scale > 0.f) backend.update_config(sky_of(st));
-                    std::memcpy(cfg.camera.pos, st.camera.pos, 12);
-                    std::memcpy(cfg.camera.dir, st.camera.dir, 12);
-                    std::memcpy(cfg.camera.up, st.camera.up, 12);
-                    if (!got_variant && st.variant >= 0) cfg.active_variant = st.variant;
-                    cfg.reset_accumulation = true;
-                }
+        // ---- the reference's loop (app.cpp:453-469): begin_frame / draw_frame / end_frame per frame, with the display's command stream (two
+        // frames in flight, statistics two frames late) or, --synchronous, without one
+        rptr::CommandStream display_stream;
+        rptr::CommandStream *const cmd_stream = synchronous ? nullptr : &display_stream;
+        if (!rest.empty() || fly_through) { // (a short warm-up when the run is a measurement: the adaptive tail hand-over settles in two frames)
+            apply_key(plan[0].key);
+            for (int w = 0; w < 4; ++w) {
+                rptr::RenderConfiguration c = config_of(plan[0]);
+                c.reset_accumulation = true;
+                backend.frame(cmd_stream, c);
             }
+            backend.flush_pipeline();
+        }
+        const auto loop_t0 = std::chrono::steady_clock::now();
+        const double loop_rays0 = backend.rays_traced();
+        last = loop_t0;
+        for (int frame = 0; frame < profiling_frames; ++frame) {
+            const FramePlan &fp = plan[(size_t)frame];
+            apply_key(fp.key);
             if (!rest.empty()) { // the geometry moves: new vertices, refit, and the accumulation starts over
-                const float phase = 6.283185307179586f * (float)current_time;
+                const float phase = 6.283185307179586f * (float)fp.time;
                 for (size_t v = 0; v < rest.size() / 3; ++v) cur[3 * v + 1] = rest[3 * v + 1] + wave_amp * std::sin(wave_k * rest[3 * v] + phase);
                 backend.update_vertices(scene.meshes[0].first_geometry, cur.data(), (uint32_t)(cur.size() / 3));
                 backend.refit();
-                cfg.reset_accumulation = true;
             }
-            if (cfg.reset_accumulation) frames_accumulated = 0;
-            const rptr::RenderStats st = backend.render(cfg);
-            cfg.reset_accumulation = false;
-            ++frames_accumulated;
+            const rptr::RenderStats st = backend.frame(cmd_stream, config_of(fp));
             gpu_ms += st.render_time;
             const auto now = std::chrono::steady_clock::now();
             const double app_ms = std::chrono::duration<double, std::milli>(now - last).count();
             last = now;
-            const int keyframe = frames.empty() ? (int)std::floor(current_time) + 1 : active_key + 1;
-            std::fprintf(csv, "%d,%d,%d,%g,%g\n", frame + 1, keyframe, frames_accumulated, st.render_time, app_ms);
-            // once per keyframe, at its end (libapp/app_state.cpp:484-493): without keyframe files a keyframe is one second
-            const bool key_ends = frames.empty() ? (current_time + dt) >= std::ceil(current_time + 1e-9)
-                                                 : (current_time + dt) >= key_end[(size_t)active_key] - 1e-9;
-            if (!profiling_img_prefix.empty() && key_ends) save_image(backend, format, profiling_img_prefix, keyframe, "", width, height, img);
-            if (!freeze_frame) current_time += dt; // --freeze-frame keeps repeating the same frame (app.cpp:339-345)
-            else if (!frames.empty() && frame + 1 >= (int)std::floor(key_end[(size_t)active_key] * profiling_fps + 0.5)) current_time = key_end[(size_t)active_key];
+            std::fprintf(csv, "%d,%d,%d,%g,%g\n", frame + 1, fp.keyframe_no, fp.accumulated, st.render_time, app_ms);
+            if (!profiling_img_prefix.empty() && fp.key_ends) save_image(backend, format, profiling_img_prefix, fp.keyframe_no, "", width, height, img); // (a read-back finishes what is in flight)
+        }
+        backend.flush_pipeline();
+        {
+            const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - loop_t0).count();
+            std::printf("%s: frame loop %s: %.4f ms per frame (wall), %.1f Mrays/s\n", backend.name().c_str(),
+                        cmd_stream ? "through a command stream (two frames in flight)" : "synchronous", wall_ms / profiling_frames,
+                        (backend.rays_traced() - loop_rays0) / wall_ms * 1e-3);
         }
         std::fclose(csv);
         std::printf("%s: %d frames at %.3g fps animation time, %.3f ms GPU time per frame -> %s\n", backend.name().c_str(), profiling_frames, profiling_fps,

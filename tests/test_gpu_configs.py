@@ -494,7 +494,7 @@ def test_batch_limits_and_gather_of_batched_frames():
         r.initialize(W, H)
         r.set_scene(s)
     with pytest.raises(backend.BackendError):
-        rs[0].render_batch_async(cfg, spp=2, n_frames=5)             # more than RPTR_MAX_BATCH_FRAMES
+        rs[0].render_batch_async(cfg, spp=1, n_frames=9)             # more than option "max_batch_frames" (8)
     with pytest.raises(backend.BackendError):
         rs[0].render_batch_async(cfg, spp=8, n_frames=3)             # 24 sample slots do not fit
     backend.RenderHip.comm_init_all(rs)

@@ -48,3 +48,6 @@ def test_cpp_host_renders_on_gpu(tmp_path):
     # the adapter surface beyond frames: device-resident ray queries (enable_ray_queries / render_ray_queries), the RaytraceBackend-shaped
     # class, light_sampling_variant NONE
     assert "ray queries: device buffers = host arrays" in p.stdout and "same hits" in p.stdout and "light sampling NONE: image unchanged" in p.stdout, p.stdout
+    # the reference's begin_frame / draw_frame / end_frame loop with a CommandStream (two frames in flight, statistics two frames late,
+    # read-backs of the newest frame) gives the images of the synchronous loop (the adapter only reached the synchronous call)
+    assert "frame loop through a CommandStream: images = the synchronous loop's; frame_stats_delay 2 / 0, first valid stats at frame 2 / 0, spp 8 / 8" in p.stdout, p.stdout

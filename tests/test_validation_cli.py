@@ -204,6 +204,32 @@ def test_validation_pfm_matches_backend_and_oracle(tmp_path):
     assert same and rmse < RMSE_TOL
 
 
+@pytest.mark.gpu
+def test_validation_accumulates_in_launch_sequences_with_the_bits_of_synchronous_frames(tmp_path):
+    """--validation queues its frames as launch sequences of up to 16 samples, two sequences in flight (reset_rest = 0: a
+    frame continues the accumulation of the one before it), instead of one synchronous frame per batch_spp samples: every image it writes
+    -- with --every-frame one per frame, at the same sample counts -- has the bits the synchronous loop writes (--synchronous), for a
+    target that is not a multiple of the sequence length and for frames of several samples."""
+    exe = _build_cli(tmp_path)
+    s = scenes.grid(60, 30, with_emitters=True)
+    path = str(tmp_path / "grid.rpsc")
+    s.dump(path)
+    W, H = 120, 72
+    for batch_spp, target in ((1, 37), (3, 30)):
+        outs = {}
+        for mode, extra in (("queued", []), ("sync", ["--synchronous"])):
+            prefix = str(tmp_path / ("val_%s_%d" % (mode, batch_spp)))
+            p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", str(target), "--batch-spp", str(batch_spp), "--img", str(W), str(H), "--pfm",
+                                "--every-frame"] + extra, capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            outs[mode] = prefix
+        counts = list(range(batch_spp, target + batch_spp, batch_spp))
+        assert counts[-1] >= target
+        for k in counts:
+            a, b = read_pfm("%s_%04d.pfm" % (outs["queued"], k)), read_pfm("%s_%04d.pfm" % (outs["sync"], k))
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (batch_spp, k)
+
+
 def test_cli_rejects_bad_mode_combinations(tmp_path):
     exe = _build_cli(tmp_path)
     path = str(tmp_path / "c.rpsc")
@@ -253,8 +279,20 @@ def test_profiling_mode_csv_images_and_camera_flags(tmp_path):
     assert [int(v[0]) for v in vals] == list(range(1, 9))
     assert [int(v[1]) for v in vals] == [1, 1, 1, 1, 2, 2, 2, 2]          # a keyframe = one second = 4 frames
     assert [int(v[2]) for v in vals] == list(range(1, 9))                   # static scene: the frames accumulate
-    assert all(float(v[3]) > 0 for v in vals)
+    # the reference's loop: frames go through a command stream, two in flight, and a row's render_time_ms is what the backend's stats() holds
+    # then -- the timings of the frame two submissions earlier (RenderStats::frame_stats_delay, vulkan/render_vulkan.cpp:2229-2243): none yet
+    # for the first two frames (a read-back -- the image after frame 4 -- finishes what is in flight: frame 5 already sees frame 4's)
+    assert [float(v[3]) > 0 for v in vals] == [False, False, True, True, True, True, True, True]
+    assert "through a command stream (two frames in flight)" in p.stdout
     assert os.path.exists(img_prefix + "_0001.pfm") and os.path.exists(img_prefix + "_0002.pfm")
+    # --synchronous (the application's "force synchronous rendering": cmd_stream = nullptr): every row has its own frame's time, same images
+    p2 = subprocess.run([exe, path, "--profiling", csv_prefix + "_s", "--profiling-fps", "4", "--profiling-count", "8", "--profiling-img", img_prefix + "_s",
+                         "--img", str(W), str(H), "--eye", "0.5", "0.2", "3.0", "--center", "0", "0", "0", "--fov", "50", "--pfm", "--synchronous"],
+                        capture_output=True, text=True)
+    assert p2.returncode == 0, p2.stderr
+    assert all(float(r.split(",")[3]) > 0 for r in open(csv_prefix + "_s.csv").read().strip().split("\n")[1:]) and "synchronous" in p2.stdout
+    for k in (1, 2):
+        assert np.array_equal(read_pfm(img_prefix + "_%04d.pfm" % k).view(np.uint32), read_pfm(img_prefix + "_s_%04d.pfm" % k).view(np.uint32))
     # the last image holds 8 accumulated samples from the moved camera
     img = read_pfm(img_prefix + "_0002.pfm")
     cam = s.camera_params()
@@ -1103,6 +1141,17 @@ def test_cli_profiling_reproduces_the_benchmarks_schedule(tmp_path):
     bench_ms = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])["ms_per_step"]
     print("C2 ms per frame: bin/rptr_hip --profiling %.4f, bench.py %.4f (ratio %.3f)" % (cli_ms, bench_ms, cli_ms / bench_ms))
     assert abs(cli_ms / bench_ms - 1.0) < 0.05
+    # the same with the camera MOVING every frame (bench.py's path: --fly-through; a camera per frame inside a launch
+    # sequence, rptr_hip_render_batch_cameras_async) -- and bench.py's own `boundary` leg reports the drop-in's figures beside `value`
+    p = subprocess.run([exe, path, "--profiling", str(tmp_path / "prof2"), "--profiling-count", "200", "--frames-in-flight", "11", "--frames-per-launch", "4",
+                        "--img", "1920", "1080", "--batch-spp", "4", "--variant", "diffuse", "--fly-through"], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr
+    assert "a camera per frame" in p.stdout
+    fly_ms = float(re.search(r"([0-9.]+) ms per frame \(wall\)", p.stdout).group(1))
+    print("... with the fly-through: %.4f (ratio %.3f)" % (fly_ms, fly_ms / bench_ms))
+    assert abs(fly_ms / bench_ms - 1.0) < 0.05
+    bd = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1]).get("boundary")
+    assert bd and bd["full_schedule"]["ms_per_frame"] < 1.1 * bench_ms and bd["swap_buffers_2"]["ms_per_frame"] < bd["synchronous"]["ms_per_frame"]
 
 
 def _partitioned_scene():
