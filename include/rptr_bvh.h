@@ -72,6 +72,9 @@ typedef struct RptrBvhTri {
 #define RPTR_BVH_TRI_ALPHA 1u
 #define RPTR_BVH_TRI_INSTANCE(flags) ((uint32_t)(flags) >> 8)
 #define RPTR_BVH_INSTANCE_FLAT 1 /* RptrBvhInstance.flags: the one record a flattened scene's top level refers to */
+#define RPTR_BVH_INSTANCE_OWN_MATERIALS 2 /* ... an instance of a parameterized mesh other than the FIRST one of its mesh: the per-triangle shading
+                                            records of the mesh carry the first one's material ids, this instance resolves its own through its
+                                            geometry records (csrc/dshade.h RpShadeTri) */
 
 /* 128 bytes */
 typedef struct RptrBvhInstance {

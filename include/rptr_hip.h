@@ -459,7 +459,9 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   quiet                    0         -                 no notes on stderr                                                        RPTR_QUIET
  *   builder experiments (measured, not adopted; profiles/r03_notes.md): tlas_collapse, collapse (0 greedy, 1 even, 2 optimal; -1 per tree),
  *   presplit_density, presplit_budget_pct, host_ploc, ploc_top, ploc_leaf -- RPTR_TLAS_COLLAPSE, RPTR_COLLAPSE, RPTR_PRESPLIT=d[,b],
- *   RPTR_HOST_PLOC, RPTR_PLOC_TOP, RPTR_PLOC_LEAF. rptr_hip_option_count / rptr_hip_option_name enumerate the keys. */
+ *   RPTR_HOST_PLOC, RPTR_PLOC_TOP, RPTR_PLOC_LEAF. rptr_hip_option_count / rptr_hip_option_name enumerate the keys.
+ *   Read-only through rptr_hip_get_option: "bvh_rebuild_failures" -- device-side rebuilds of dynamic meshes that could not start (no memory for
+ *   their work space); such a mesh is refitted on its old topology, the frame is rendered, the next refit tries again. */
 int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value);
 int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value);
 int rptr_hip_option_count(void);

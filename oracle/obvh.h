@@ -47,7 +47,13 @@ struct TraceCounters {
     uint64_t nodes = 0, tris = 0;
 };
 // optional per-node visit histogram (diagnostics: which part of the tree is hot)
+// ORC_BASELINE (oracle/Makefile libcpu_baseline.so): the same restatement built as the CPU baseline of bench.py -- -O3 -march=native, no
+// diagnostics: the node histogram, the ray log and the visit counters are compiled out (constant null pointers / false).
+#ifdef ORC_BASELINE
+static uint32_t *const g_node_hist = nullptr;
+#else
 static uint32_t *g_node_hist = nullptr;
+#endif
 
 static inline bool hit_key_less(int inst, int geom, int prim, const Hit &h) {
     if (h.inst < 0) return true;

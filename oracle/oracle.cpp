@@ -193,6 +193,9 @@ struct PathCounters {
 static float *g_ray_log = nullptr;
 static size_t g_ray_log_cap = 0, g_ray_log_n = 0;
 static inline void log_ray(const Ray &r, bool any) {
+#ifdef ORC_BASELINE
+    return;
+#endif
     if (!g_ray_log || g_ray_log_n >= g_ray_log_cap) return;
     float *p = g_ray_log + 9 * g_ray_log_n++;
     p[0] = r.o.x; p[1] = r.o.y; p[2] = r.o.z; p[3] = r.tmin;
@@ -880,7 +883,11 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
     f.rp = a->params;
     f.sp = a->scene_params;
     f.lc = a->lighting;
+#ifdef ORC_BASELINE
+    f.count = false;
+#else
     f.count = a->count_traversal != 0;
+#endif
     compute_view(a->camera, a->width, a->height, f.vp);
     f.vp.frame_offset = a->frame_offset;
     f.vp.frame_id = uint32_t(a->sample_begin);
@@ -891,10 +898,17 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
         if (s->view.desc->materials[m].normal_map != -1 && (uint32_t)s->view.desc->materials[m].normal_map >= s->view.desc->num_textures) return -4;
     int nt = a->n_threads > 0 ? a->n_threads : (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
+#ifdef ORC_BASELINE
+    // the CPU baseline: tiles of 32 x 32 pixels over the host's threads, handed out through one atomic counter
+    const int TILE = 32;
+    const int tiles_x = (a->width + TILE - 1) / TILE, tiles_y = (a->row_end - a->row_begin + TILE - 1) / TILE;
+    const long long n_items = (long long)tiles_x * tiles_y;
+#else
     // work items: 64-pixel segments of a row, handed out through one atomic counter
     const int SEG = 64;
     const int segs_per_row = (a->width + SEG - 1) / SEG;
     const long long n_items = (long long)(a->row_end - a->row_begin) * segs_per_row;
+#endif
     std::atomic<long long> next_item(0);
     std::vector<PathCounters> pcs(nt);
     auto t0 = std::chrono::steady_clock::now();
@@ -903,8 +917,15 @@ static int render_impl(void *p, const OrcRenderArgs *a, float *accum, OrcRenderS
         for (;;) {
             const long long item = next_item.fetch_add(1);
             if (item >= n_items) break;
+#ifdef ORC_BASELINE
+            const int ty = int(item / tiles_x), tx = int(item % tiles_x);
+            const int x0 = tx * TILE, x1 = std::min(a->width, x0 + TILE);
+            const int y0 = a->row_begin + ty * TILE, y1 = std::min(a->row_end, y0 + TILE);
+            for (int y = y0; y < y1; ++y)
+#else
             const int y = a->row_begin + int(item / segs_per_row);
             const int x0 = int(item % segs_per_row) * SEG, x1 = std::min(a->width, x0 + SEG);
+#endif
             for (int x = x0; x < x1; ++x) {
                 float *px = accum + 4 * ((size_t)y * a->width + x);
                 for (int si = 0; si < a->spp; ++si) {
@@ -1193,7 +1214,11 @@ void orc_footprint_probe(const float *dir, const float *dpdx, const float *dpdy,
     out[10] = R[0][0]; out[11] = R[0][1]; out[12] = R[1][0]; out[13] = R[1][1];
 }
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
+#ifdef ORC_BASELINE
+void orc_set_node_hist(uint32_t *) {}
+#else
 void orc_set_node_hist(uint32_t *hist) { g_node_hist = hist; }
+#endif
 void orc_set_dead_visit_counter(unsigned long long *c) { g_dead_visits = c; } // c[3]: dead visits, stale node pops, stale leaf pops
 // every ray of the following single-threaded orc_render calls is appended to buf (9 floats each); returns the count so far
 size_t orc_set_ray_log(float *buf, size_t cap_rays) {

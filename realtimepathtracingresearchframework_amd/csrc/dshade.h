@@ -35,6 +35,29 @@ struct RpGeomRecord { // 64 bytes
     uint32_t flags;
 };
 
+// One shading record per BVH triangle, in the order of RpScene::tris (= leaf order: rays that hit neighbouring triangles read neighbouring
+// records), 64 bytes on a 64-byte boundary: what a hit needs of its triangle in ONE cache line, four 16-byte loads that depend on
+// nothing but the hit record. Round 4's shade kernels went hit record -> instance record -> geometry record -> qpos[3] + qnrm_uv[3] + a
+// material byte (three arrays of 24-byte records that straddle 64-byte lines two times in eight: ~3.5 lines for 49 bytes behind two dependent
+// round trips) and waited on memory for 68 % of their wave-cycles (profiles/r04m_*). The record holds
+//   pos      the three vertices AS rp_geom_tri RETURNS THEM: float(q) * scaling + offset, evaluated once by the same device function
+//            (hit.glsl:41-47, dequantize.glsl:8-21: the same IEEE operations on the same operands -- the shaded values keep their bits); for a
+//            dynamic mesh its float positions, rewritten by the refit (kernels_misc.h rp_k_refit_tris)
+//   qnu      the three qnrm_uv words (oct normal | uv), decoded per hit as before (dequantize.glsl:23-48)
+//   material bits 0..27 the material id (hit.glsl:49-56, resolved for the parameterized mesh the record was made for: an instance of
+//            ANOTHER parameterized mesh of the same mesh is flagged RP_INST_OWN_MATERIALS and resolves it through its geometry record),
+//            bit 30 / 31 the geometry has normals / uvs
+// Built on the device after the acceleration structure (kernels_misc.h rp_k_build_shade_tris) and again for a mesh whose tree was rebuilt.
+struct alignas(64) RpShadeTri {
+    float pos[9];
+    uint32_t qnu[6];
+    uint32_t material;
+};
+#define RP_SHADE_MATERIAL_MASK 0x0FFFFFFFu
+#define RP_SHADE_HAS_NORMALS 0x40000000u
+#define RP_SHADE_HAS_UVS 0x80000000u
+#define RP_INST_OWN_MATERIALS RPTR_BVH_INSTANCE_OWN_MATERIALS
+
 struct RpTexture { // RptrTextureDesc on the device
     const uchar4 *texels;
     int width, height;
@@ -47,6 +70,7 @@ struct RpScene {
     const RptrBvhTri *tris;
     const RptrBvhInstance *insts;
     const RpGeomRecord *geoms;
+    const RpShadeTri *shade; // one per entry of `tris`
     const RptrBaseMaterial *materials;
     const RptrTriLightData *lights; // padded with one zeroed bin
     int32_t num_lights;
@@ -456,23 +480,15 @@ RP_DEV V2 rp_hit_uv(const RpGeomRecord &g, uint32_t prim, float bu, float bv) {
     const V2 uva = rp_dequantize_uv(uint32_t(q[0] >> 32)), uvb = rp_dequantize_uv(uint32_t(q[1] >> 32)), uvc = rp_dequantize_uv(uint32_t(q[2] >> 32));
     return v2((uva.x * bary.x + uvb.x * bary.y) + uvc.x * bary.z, (uva.y * bary.x + uvb.y * bary.y) + uvc.y * bary.z);
 }
-// rendering/rt/hit.glsl:58-128 via the quantised overload :162-203
-RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t prim, float bu, float bv, const M3 &normals_to_world) {
+// rendering/rt/hit.glsl:58-128 via the quantised overload :162-203; the vertices va / vb / vc and the three qnrm_uv words come from the
+// triangle's shading record (RpShadeTri: the values rp_geom_tri and the qnrm_uv stream hold)
+RP_DEV RpHit rp_calc_hit_attributes(V3 va, V3 vb, V3 vc, uint64_t qa, uint64_t qb, uint64_t qc, bool has_normals, bool has_uvs, int material_id, float ray_t,
+                                    float bu, float bv, const M3 &normals_to_world) {
     RpHit h;
     h.dist = ray_t;
-    V3 va, vb, vc;
-    rp_geom_tri(g, prim, va, vb, vc);
     V3 gn = cross3(vb - va, vc - va);
     V3 n = gn;
     const V3 bary = v3(1.f - bu - bv, bu, bv);
-    const bool has_normals = (g.flags & RP_GEOM_HAS_NORMALS) != 0, has_uvs = (g.flags & RP_GEOM_HAS_UVS) != 0;
-    uint64_t qa = 0, qb = 0, qc = 0;
-    if (has_normals || has_uvs) {
-        const uint64_t *q = g.qnrm_uv + 3ull * prim;
-        qa = q[0];
-        qb = q[1];
-        qc = q[2];
-    }
     if (has_normals) {
         M3 nm{rp_dequantize_normal(uint32_t(qa)), rp_dequantize_normal(uint32_t(qb)), rp_dequantize_normal(uint32_t(qc))};
         n = mul(nm, bary);
@@ -480,7 +496,7 @@ RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t
     }
     h.geo_normal = gn * 0.5f;
     h.normal = n;
-    h.material_id = rp_hit_material_id(g, prim);
+    h.material_id = material_id;
     bool requires_tangent = true;
     h.geo_normal = mul(normals_to_world, h.geo_normal);
     h.normal = norm3(mul(normals_to_world, h.normal));
@@ -509,6 +525,28 @@ RP_DEV RpHit rp_calc_hit_attributes(const RpGeomRecord &g, float ray_t, uint32_t
         h.bitangent_l = 1.0f;
     }
     return h;
+}
+// the shading record of one BVH triangle from the scene tables (what rp_k_build_shade_tris stores)
+RP_DEV RpShadeTri rp_make_shade_tri(const RpGeomRecord &g, uint32_t prim) {
+    RpShadeTri r;
+    V3 a, b, c;
+    rp_geom_tri(g, prim, a, b, c);
+    r.pos[0] = a.x, r.pos[1] = a.y, r.pos[2] = a.z;
+    r.pos[3] = b.x, r.pos[4] = b.y, r.pos[5] = b.z;
+    r.pos[6] = c.x, r.pos[7] = c.y, r.pos[8] = c.z;
+    const bool has_normals = (g.flags & RP_GEOM_HAS_NORMALS) != 0, has_uvs = (g.flags & RP_GEOM_HAS_UVS) != 0;
+    uint64_t qa = 0, qb = 0, qc = 0;
+    if (has_normals || has_uvs) {
+        const uint64_t *q = g.qnrm_uv + 3ull * prim;
+        qa = q[0];
+        qb = q[1];
+        qc = q[2];
+    }
+    r.qnu[0] = uint32_t(qa), r.qnu[1] = uint32_t(qa >> 32);
+    r.qnu[2] = uint32_t(qb), r.qnu[3] = uint32_t(qb >> 32);
+    r.qnu[4] = uint32_t(qc), r.qnu[5] = uint32_t(qc >> 32);
+    r.material = (uint32_t(rp_hit_material_id(g, prim)) & RP_SHADE_MATERIAL_MASK) | (has_normals ? RP_SHADE_HAS_NORMALS : 0u) | (has_uvs ? RP_SHADE_HAS_UVS : 0u);
+    return r;
 }
 
 // ------------------------------------------------------------------ materials (a9)

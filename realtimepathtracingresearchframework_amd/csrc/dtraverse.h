@@ -45,10 +45,14 @@
 #define RP_TRAVERSE_WAVES 6
 #endif
 #define RP_TRAVERSE_BOUNDS __launch_bounds__(RP_TRAVERSE_BLOCK, RP_TRAVERSE_WAVES)
-// the shadow-ray kernels carry less per lane (no hit record to keep): compiled for six waves per SIMD they fit 80 VGPRs with 12 bytes of
-// scratch and a launch that has the GPU to itself runs six blocks per CU (6 x 24 KB of LDS stacks). Measured (tools/ab.sh, build variants,
-// one box; profiles/r04_notes.md section 5): connect launches -4 % on C2, -6 % on C4; the closest-hit kernels at six waves lose 1.5 % on C2.
-// Only the instantiations for scenes with one instance record get it (kernels.h rp_k_connect): the two-level walk spills 72-80 bytes at 80 VGPRs.
+// the shadow-ray kernels carry less per lane (no hit record to keep). The instantiation for scenes with ONE instance record and no alpha test
+// (kernels.h rp_k_connect<., false, true>) is compiled for the register budget of EIGHT waves per SIMD: it uses 64 VGPRs without scratch
+// (tools/kernel_regs.sh; round 4: 67 at a budget of 64 -- the hit record of round 5 carries two words less), and the LDS stacks (20 entries x
+// 256 lanes x 4 bytes = 20 KB per block) let a CU hold seven such blocks: the host sizes a stand-alone launch's grid from that
+// instantiation's own occupancy (rptr_hip.hip connect_blocks[1]). The two-level and the alpha-tested instantiations keep RP_TRAVERSE_WAVES
+// (they spill 72-80 bytes at this budget: two-level C4 connect 2.5 -> 3.2 ms, profiles/r04_notes.md section 5); their grid (connect_blocks[0])
+// comes from the two-level instantiation without alpha test -- an alpha-tested scene is launched with the same grid: persistent waves pull
+// from one cursor, a few blocks more than fit only wait their turn.
 #ifndef RP_CONNECT_WAVES
 #define RP_CONNECT_WAVES 8
 #endif
@@ -78,9 +82,8 @@
 
 struct RpHitRec {
     float t, u, v;
-    int prim;
+    int tri;      // index of the hit triangle in RpScene::tris (its shading record: RpScene::shade[tri]; its primitive / geometry index: tris[tri])
     int inst_idx; // index into RpScene::insts (TLAS leaf order), -1 = miss
-    int geom;     // geometry index inside the mesh
 };
 
 struct RpStack {
@@ -241,7 +244,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     RpHitRec best;
     best.t = 0.f;
     best.u = best.v = 0.f;
-    best.prim = best.inst_idx = best.geom = -1;
+    best.tri = best.inst_idx = -1;
     int best_inst_id = -1, cur_inst = -1, cur_inst_id = -1;
     auto push = [&](int v) {
         if (sp < RP_LDS_STACK)
@@ -304,7 +307,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     if (load(my_i, ro, rd, tmin, tmax)) { // false: the entry names no ray (tile padding of the first queue): the lane stays idle
                     best.t = tmax;
                     best.u = best.v = 0.0f;
-                    best.prim = best.geom = best.inst_idx = -1;
+                    best.tri = best.inst_idx = -1;
                     best_inst_id = -1;
                     sp = 0;
                     push(RP_EXIT);
@@ -520,6 +523,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             } else {
                 // BLAS leaf: canonical Moeller-Trumbore = oracle/obvh.h mt_intersect, same operations bit for bit
                 bool any_hit = false;
+                int tri_at = first; // index of triangle `qa` in RpScene::tris
 #pragma unroll 1
                 for (;;) {
 #pragma unroll
@@ -547,13 +551,14 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                 const int tri_rec = (int)RPTR_BVH_TRI_INSTANCE(__float_as_uint(q2.w));
                                 const int hit_inst = tri_rec ? tri_rec : cur_inst, hit_inst_id = tri_rec ? tri_rec - 1 : cur_inst_id;
                                 bool accept = t < best.t;
-                                if (!accept && t == best.t && best.inst_idx >= 0) {
+                                if (!accept && t == best.t && best.inst_idx >= 0) { // a tie (rare): the smaller (instance, geometry, primitive) wins
                                     if (hit_inst_id != best_inst_id)
                                         accept = hit_inst_id < best_inst_id;
-                                    else if (geom != best.geom)
-                                        accept = geom < best.geom;
-                                    else
-                                        accept = prim < best.prim;
+                                    else { // (the best hit's indices are not carried in registers: two words of its triangle record)
+                                        const int *bt = reinterpret_cast<const int *>(tri_base + (size_t)(uint32_t)best.tri * 48u + 36u);
+                                        const int best_prim = bt[0], best_geom = bt[1];
+                                        accept = geom != best_geom ? geom < best_geom : prim < best_prim;
+                                    }
                                 }
                                 if (ALPHA) {
                                     if (accept && (__float_as_uint(q2.w) & RPTR_BVH_TRI_ALPHA) != 0u)
@@ -563,8 +568,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                     best.t = t;
                                     best.u = un * inv_det;
                                     best.v = vn * inv_det;
-                                    best.prim = prim;
-                                    best.geom = geom;
+                                    best.tri = tri_at + j;
                                     best.inst_idx = hit_inst;
                                     best_inst_id = hit_inst_id;
                                     any_hit = true;
@@ -575,6 +579,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     count -= 2;
                     if (count <= 0 || (ANY && any_hit)) break;
                     lp += 96; // leaves with more than two triangles: next pair
+                    tri_at += 2;
                     qa0 = *reinterpret_cast<const float4 *>(lp);
                     qa1 = *reinterpret_cast<const float4 *>(lp + 16);
                     qa2 = *reinterpret_cast<const float4 *>(lp + 32);

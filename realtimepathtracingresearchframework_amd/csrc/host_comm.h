@@ -119,6 +119,7 @@ struct RptrComm {
     hipEvent_t ev_copied = nullptr;
     // COMM_IPC: rank 0 owns `ipc_flags`; the other ranks hold rank 0's buffers mapped into their address space
     RptrIpcFlags *ipc_flags = nullptr;
+    uint32_t *ipc_gave_up = nullptr;  // a peer's own word: its gate wait timed out, the scatter and the done flag of that gather are skipped
     float4 *ipc_frame[2] = {nullptr, nullptr};
     bool ipc_mapped = false;          // (this rank opened the handles: close them on release)
     hipEvent_t ev_gate = nullptr;     // (rank 0, peer writes) what rank 0's communication stream held when a gather began: the peers' writes into the slot wait for it
@@ -145,8 +146,10 @@ __global__ __launch_bounds__(256) void rp_k_assemble(float4 *frame, const float4
 }
 
 // the peer-write transport: the rows of rank `rank` (packed top to bottom) go to their places in the frame, which may live on another device
+// skip (COMM_IPC): this rank's gate wait gave up -- rank 0 may still be reading the slot: nothing is written
 __global__ __launch_bounds__(256) void rp_k_scatter_rows(float4 *frame, const float4 *rows, int width, int height, int local_rows, int stripe_rows, int world,
-                                                         int rank, int nb) {
+                                                         int rank, int nb, const uint32_t *skip = nullptr) {
+    if (skip && *skip != 0u) return;
     const size_t per = (size_t)width * local_rows, n = per * (size_t)nb;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
         const size_t k = j / per, i = j - k * per;
@@ -158,11 +161,16 @@ __global__ __launch_bounds__(256) void rp_k_scatter_rows(float4 *frame, const fl
 }
 
 // COMM_IPC flag kernels (one lane each). The flag block is uncached device memory of rank 0; a peer reaches it through its IPC mapping.
-__global__ void rp_k_flag_set(uint32_t *flag, uint32_t value) {
+// skip: see rp_k_scatter_rows -- a rank that did not write its rows does not say it did (rank 0's wait for it then times out and reports)
+__global__ void rp_k_flag_set(uint32_t *flag, uint32_t value, const uint32_t *skip = nullptr) {
+    if (skip && *skip != 0u) return;
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // (behind the kernels queued before it: stream order)
 }
 // waits until flags[i * stride] >= value for i = 0..n-1; gives up after ~30 s (a rank that died must not wedge the others' GPUs) and says so
-__global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_t value, uint32_t *timed_out) {
+// (timed_out: a counter in rank 0's flag block, read back by the host -- rptr_hip_comm_stats / the gathered read-backs fail when it is not 0;
+// gave_up: a word of THIS rank's own memory that makes the rest of its gather a no-op)
+__global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_t value, uint32_t *timed_out, uint32_t *gave_up = nullptr) {
+    if (gave_up) *gave_up = 0u;
     for (int i = 0; i < n; ++i) {
         const uint32_t *f = flags + (size_t)i * stride;
         const long long t0 = wall_clock64();
@@ -171,6 +179,7 @@ __global__ void rp_k_flag_wait(const uint32_t *flags, int n, int stride, uint32_
             __builtin_amdgcn_s_sleep(32);
             if (wall_clock64() - t0 > 3000000000ll) { // 30 s of the 100 MHz counter
                 if (timed_out) atomicAdd(timed_out, 1u);
+                if (gave_up) *gave_up = 1u;
                 return;
             }
         }
@@ -259,6 +268,7 @@ void comm_release(rptr_hip *h) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (void *p : {(void *)c->recv[0], (void *)c->recv[1], (void *)c->gathered[0], (void *)c->gathered[1], (void *)c->d_offsets})
         if (p) (void)hipFree(p);
+    if (c->ipc_gave_up) (void)hipFree(c->ipc_gave_up);
     if (c->ipc_mapped) {
         for (void *p : {(void *)c->ipc_frame[0], (void *)c->ipc_frame[1], (void *)c->ipc_flags})
             if (p) (void)hipIpcCloseMemHandle(p);
@@ -491,7 +501,14 @@ int rptr_hip_comm_ipc_init(rptr_hip_t *h, const void *bytes) {
     int rc = comm_setup_local(h, COMM_IPC);
     if (rc) return rc;
     RptrComm *c = h->comm;
-    if (c->max_batch > blob.max_batch) c->max_batch = blob.max_batch; // (rank 0's frames hold that many images)
+    // every rank moves the same number of frames per gather, and the ranks count their gathers themselves: the limit is rank 0's for all of
+    // them (a rank that could hold fewer refuses here instead of failing a gather on its own later and falling out of step)
+    if (c->max_batch < blob.max_batch)
+        return fail(h, RPTR_E_INVALID, "this rank holds %d frames per launch sequence, rank 0's frame buffers %d: create every rank with the same "
+                                       "\"max_batch_frames\"", c->max_batch, blob.max_batch);
+    c->max_batch = blob.max_batch;
+    HIP_TRY(h, hipMalloc((void **)&c->ipc_gave_up, sizeof(uint32_t)));
+    HIP_TRY(h, hipMemset(c->ipc_gave_up, 0, sizeof(uint32_t)));
     c->ipc_mapped = true;
     HIP_TRY(h, hipIpcOpenMemHandle((void **)&c->ipc_frame[0], blob.frame[0], hipIpcMemLazyEnablePeerAccess));
     HIP_TRY(h, hipIpcOpenMemHandle((void **)&c->ipc_frame[1], blob.frame[1], hipIpcMemLazyEnablePeerAccess));
@@ -520,17 +537,18 @@ int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames) {
         const uint32_t g = (uint32_t)(c->gathers + 1); // the same number on every rank: a gather is a collective
         const int slot = comm_slot(c);
         const int rows = local_row_count(h->height, h->stripe_rows, h->rank, h->world);
-        uint32_t *timed_out = &c->ipc_flags->_pad[0]; // (rank 0's block: a diagnostic counter shared by all ranks)
-        if (h->rank == 0) hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->gate, g);
-        else hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->gate, 1, 1, g, timed_out);
+        uint32_t *timed_out = &c->ipc_flags->_pad[0]; // (rank 0's block: counts the waits that gave up, on any rank; the hosts read it back)
+        const uint32_t *skip = h->rank == 0 ? nullptr : c->ipc_gave_up;
+        if (h->rank == 0) hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->gate, g, (const uint32_t *)nullptr);
+        else hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->gate, 1, 1, g, timed_out, c->ipc_gave_up);
         if (rows > 0)
             hipLaunchKernelGGL(rp_k_scatter_rows, dim3(grid_for(h, (size_t)h->width * rows * nb)), dim3(256), 0, c->stream, c->ipc_frame[slot], src, h->width, h->height,
-                               rows, h->stripe_rows, h->world, h->rank, nb);
+                               rows, h->stripe_rows, h->world, h->rank, nb, skip);
         if (h->rank == 0) {
             if (h->world > 1)
-                hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->done[1], h->world - 1, 1, g, timed_out);
+                hipLaunchKernelGGL(rp_k_flag_wait, dim3(1), dim3(1), 0, c->stream, (const uint32_t *)&c->ipc_flags->done[1], h->world - 1, 1, g, timed_out, (uint32_t *)nullptr);
         } else
-            hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->done[h->rank], g);
+            hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, &c->ipc_flags->done[h->rank], g, skip);
         HIP_TRY(h, hipGetLastError());
         return comm_end(h, src, owner, nb);
     }
@@ -631,6 +649,21 @@ int rptr_hip_gathered_frame(rptr_hip_t *h, const void **out_device_rgba32f) {
     return RPTR_OK;
 }
 
+extern "C++" {
+// COMM_IPC: waits of the flag protocol that gave up (a rank that died or fell out of step) since the communicator was made -- the gathers
+// they belonged to delivered stale or missing rows. Called once the communication stream has been waited for.
+static int comm_ipc_check(rptr_hip *h) {
+    RptrComm *c = h->comm;
+    if (!c || c->transport != COMM_IPC || !c->ipc_flags) return RPTR_OK;
+    uint32_t n = 0;
+    HIP_TRY(h, hipMemcpy(&n, &c->ipc_flags->_pad[0], sizeof(n), hipMemcpyDeviceToHost));
+    if (n != 0u)
+        return fail(h, RPTR_E_HIP, "the IPC gather's flag protocol timed out %u time(s) (30 s each): a rank died or the ranks fell out of step; the assembled "
+                                   "frames since then are incomplete -- make the communicator again (rptr_hip_comm_ipc_export / _ipc_init)", n);
+    return RPTR_OK;
+}
+}
+
 int rptr_hip_readback_gathered_frame_f32(rptr_hip_t *h, int index, float *rgba, size_t n_floats) {
     if (!h || !rgba) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (!h->comm || h->rank != 0) return fail(h, RPTR_E_INVALID, "the assembled frame lives on rank 0 of a communicator");
@@ -641,7 +674,7 @@ int rptr_hip_readback_gathered_frame_f32(rptr_hip_t *h, int index, float *rgba, 
     HIP_TRY(h, hipMemcpyAsync(rgba, h->comm->gathered[h->comm->last_slot] + (size_t)index * ((size_t)h->width * h->height), need * sizeof(float), hipMemcpyDeviceToHost,
                               h->comm->stream));
     HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
-    return RPTR_OK;
+    return comm_ipc_check(h);
 }
 
 int rptr_hip_readback_gathered_f32(rptr_hip_t *h, float *rgba, size_t n_floats) {
@@ -656,6 +689,10 @@ int rptr_hip_comm_stats(rptr_hip_t *h, uint64_t *out_gathers, float *out_mean_ga
     comm_collect_timing(h->comm, true);
     if (out_gathers) *out_gathers = h->comm->gathers;
     if (out_mean_gather_ms) *out_mean_gather_ms = h->comm->timed ? (float)(h->comm->total_ms / (double)h->comm->timed) : 0.0f;
+    if (h->comm->transport == COMM_IPC) { // (any rank can tell: the counter lives in rank 0's flag block, which every rank has mapped)
+        HIP_TRY(h, hipStreamSynchronize(h->comm->stream));
+        return comm_ipc_check(h);
+    }
     return RPTR_OK;
 }
 

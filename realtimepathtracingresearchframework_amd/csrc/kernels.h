@@ -33,8 +33,8 @@ struct RpPathState {
     float4 *illum;   // illum.xyz, bits(bounce)
     float4 *footprint; // the texture footprint (2 x 2, column major) of paths through scenes with textures (else NULL)
     uint32_t *alpha_rng; // the alpha-test generator of closest-hit queries when the point set is not the uniform one (else NULL)
-    float4 *hit_tuv; // t, u, v, bits(prim)
-    int2 *hit_ids;   // inst_idx, geom
+    float4 *hit_tuv; // t, u, v of the closest hit (.w unused)
+    int2 *hit_ids;   // index of the hit instance record (-1 = miss), index of the hit triangle in RpScene::tris (= of its shading record, dshade.h RpShadeTri)
 };
 // shadow rays live at the slot of their path (at most one per path and bounce);
 // the shadow queue itself only carries path ids
@@ -196,8 +196,8 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     };
     auto done = [&](uint32_t, const RpHitRec &h) {
         const uint32_t p = lane_p;
-        ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-        ps.hit_ids[p] = make_int2(h.inst_idx, h.geom);
+        ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, 0.0f);
+        ps.hit_ids[p] = make_int2(h.inst_idx, h.tri);
         if (ALPHA) {
             if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {
                 if (FIRST || lane_rng != lane_rng_in) ps.alpha_rng[p] = lane_rng;
@@ -407,10 +407,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             __syncthreads();
             for (uint32_t il = threadIdx.x; il < chunk_hits; il += 256) {
                 const uint32_t pp = s_list[il];
-                const int2 ids = ps.hit_ids[pp];
-                const int prim = __float_as_int(ps.hit_tuv[pp].w);
-                const RpGeomRecord &g = sc.geoms[sc.insts[ids.x].geometry_base + ids.y];
-                const uint32_t key = (uint32_t)rp_hit_material_id(g, (uint32_t)prim) & 63u;
+                const uint32_t key = sc.shade[ps.hit_ids[pp].y].material & 63u;
                 s_key[il] = (unsigned char)key;
                 atomicAdd(&s_bin[key], 1u);
             }
@@ -507,9 +504,10 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         tex_fp = M2{v2(fp.x, fp.y), v2(fp.z, fp.w)};
                     }
                 }
-                const float4 hit4 = ps.hit_tuv[p];
-                const int2 ids = ps.hit_ids[p];
-                if (ids.x < 0) {
+                // (the regrouping put the chunk's hits first: a miss lane needs no hit record)
+                const int2 hid = il >= chunk_hits ? make_int2(-1, -1) : ps.hit_ids[p];
+                const int hit_inst = hid.x;
+                if (hit_inst < 0) {
                     // miss: pt_megakernel.glsl:480-489
                     illum = illum + throughput * rp_compute_sky_illum(f, ray_dir, prev_bounce_pdf);
                     ps.illum[p] = f4(illum, __int_as_float(bounce));
@@ -520,15 +518,29 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 } else {
                     hit_lane = true;
                     my_hits++;
-                    // ---- hit attributes, pt_megakernel.glsl:495-572
-                    const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + ids.x);
+                    // ---- hit attributes, pt_megakernel.glsl:495-572. Everything the hit needs of its triangle is ONE 64-byte record named by
+                    // the hit record itself (dshade.h RpShadeTri): its four loads, the instance's rows and -- one step behind -- the material
+                    // are in flight together; nothing waits for a geometry record any more.
+                    const float4 hit4 = ps.hit_tuv[p];
+                    const uint32_t tri_index = uint32_t(hid.y);
+                    const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri_index);
+                    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+                    const float4 *ip = reinterpret_cast<const float4 *>(sc.insts + hit_inst);
                     const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
                     const int4 meta = *reinterpret_cast<const int4 *>(ip + 3);
-                    const RpGeomRecord g = sc.geoms[meta.y + ids.y];
-                    const uint32_t prim = uint32_t(__float_as_int(hit4.w));
+                    const uint32_t mword = __float_as_uint(s3.w);
+                    int material_id = int(mword & RP_SHADE_MATERIAL_MASK);
+                    if (meta.w & RP_INST_OWN_MATERIALS) { // (an instance of another parameterized mesh of the same mesh: its own material table)
+                        const int *tr = reinterpret_cast<const int *>(sc.tris + tri_index); // prim, geom: words 9 and 10
+                        material_id = rp_hit_material_id(sc.geoms[meta.y + tr[10]], uint32_t(tr[9]));
+                    }
+                    const RptrBaseMaterial mp = sc.materials[material_id];
                     // transpose(mat3(world_to_object)): its columns are the rows of world_to_object
                     const M3 n2w{v3(r0.x, r0.y, r0.z), v3(r1.x, r1.y, r1.z), v3(r2.x, r2.y, r2.z)};
-                    RpHit hit = rp_calc_hit_attributes(g, hit4.x, prim, hit4.y, hit4.z, n2w);
+                    const uint64_t qa = uint64_t(__float_as_uint(s2.y)) | (uint64_t(__float_as_uint(s2.z)) << 32), qb = uint64_t(__float_as_uint(s2.w)) | (uint64_t(__float_as_uint(s3.x)) << 32),
+                                   qc = uint64_t(__float_as_uint(s3.y)) | (uint64_t(__float_as_uint(s3.z)) << 32);
+                    RpHit hit = rp_calc_hit_attributes(v3(s0.x, s0.y, s0.z), v3(s0.w, s1.x, s1.y), v3(s1.z, s1.w, s2.x), qa, qb, qc, (mword & RP_SHADE_HAS_NORMALS) != 0u,
+                                                       (mword & RP_SHADE_HAS_UVS) != 0u, material_id, hit4.x, hit4.y, hit4.z, n2w);
                     // :578-580
                     float approx_tri_solid_angle = len3(hit.geo_normal);
                     hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
@@ -541,7 +553,6 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     ip_p = ray_origin + hit.dist * ray_dir;
                     gn = hit.geo_normal;
                     nn = hit.normal;
-                    const RptrBaseMaterial mp = sc.materials[hit.material_id];
                     // :624-633
                     if (dot3(w_o, gn) < 0.0f) {
                         if ((mp.flags & RPTR_BASE_MATERIAL_VOLUME) != 0) {

@@ -153,7 +153,8 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
             r = make_float4(-1.0f, -1.0f, __int_as_float(-1), __int_as_float(-1));
         else {
             const int geometry_base = reinterpret_cast<const int *>(sc.insts + h.inst_idx)[13];
-            r = make_float4(h.u, h.v, __int_as_float(geometry_base + h.geom), __int_as_float(h.prim));
+            const int *tr = reinterpret_cast<const int *>(sc.tris + h.tri); // prim, geom: words 9 and 10 of the triangle record
+            r = make_float4(h.u, h.v, __int_as_float(geometry_base + tr[10]), __int_as_float(tr[9]));
         }
         results[i] = r;
     };
@@ -166,12 +167,15 @@ __global__ RP_TRAVERSE_BOUNDS void rp_k_trace(RpScene sc, const RptrRenderRayQue
 // enqueue_refit): triangles are re-derived from the float vertex buffer, node boxes are recomputed
 // bottom-up one height level per launch, instance bounds from the BLAS roots, then the TLAS levels.
 // tri_box: bounds of the three VERTICES (what the builder bounds, bvh_build.cpp), kept for the node pass
-__global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *tri_box, uint32_t begin, uint32_t count,
+// shade: the triangles' shading records (dshade.h RpShadeTri) get the same new vertices
+__global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *tri_box, RpShadeTri *shade, uint32_t begin, uint32_t count,
                                                        const float *const *geom_dyn) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
         RptrBvhTri t = tris[begin + i];
         const float *p = geom_dyn[t.geom] + 9ull * t.prim;
         float *b = tri_box + 6ull * (begin + i);
+        float *sp = shade[begin + i].pos;
+        for (int k = 0; k < 9; ++k) sp[k] = p[k];
         for (int k = 0; k < 3; ++k) {
             t.v0[k] = p[k];
             t.e1[k] = p[3 + k] - p[k];
@@ -180,6 +184,16 @@ __global__ __launch_bounds__(256) void rp_k_refit_tris(RptrBvhTri *tris, float *
             b[3 + k] = fmaxf(p[k], fmaxf(p[3 + k], p[6 + k]));
         }
         tris[begin + i] = t;
+    }
+}
+// The shading records of the BVH triangles [begin, begin + count) (dshade.h RpShadeTri): after set_scene built or uploaded the triangles,
+// and after a device-side rebuild reordered a mesh's. geometry_base >= 0: the triangles of one mesh, records of the parameterized mesh whose
+// geometry records start there; < 0: a flattened scene, every triangle names its own instance record.
+__global__ __launch_bounds__(256) void rp_k_build_shade_tris(RpScene sc, RpShadeTri *shade, uint32_t begin, uint32_t count, int geometry_base) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const RptrBvhTri t = sc.tris[begin + i];
+        const int gb = geometry_base >= 0 ? geometry_base : sc.insts[RPTR_BVH_TRI_INSTANCE(t.flags)].geometry_base;
+        shade[begin + i] = rp_make_shade_tri(sc.geoms[gb + (int)t.geom], t.prim);
     }
 }
 // one height level of nodes: child boxes from the triangle / instance bounds (leaves) or from the exact float

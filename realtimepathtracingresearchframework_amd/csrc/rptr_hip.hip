@@ -56,6 +56,7 @@ struct SceneCopy {
     RpScene dscene;                        // what the kernels get (static arrays are shared between all copies)
     RptrBvh4Node *nodes = nullptr;
     RptrBvhTri *tris = nullptr;
+    RpShadeTri *shade = nullptr;            // one shading record per triangle (dshade.h): a refit rewrites the positions of dynamic meshes' records
     float *node_box = nullptr, *tri_box = nullptr, *inst_box = nullptr;
     std::vector<float *> dynpos;            // per global geometry: float positions (9 per triangle) or NULL
     std::vector<const float **> mesh_dyn;   // per mesh: device table of its geometries' dynpos pointers
@@ -289,12 +290,15 @@ struct rptr_hip {
     uint2 *d_refit_levels = nullptr;        // the same pairs on the device
     bool refit_top_all = false;             // instance bounds + top-level levels fit one single-block launch (rp_k_refit_top)
     bool has_dynamic = false;               // some mesh is dynamic
+    std::vector<int> mesh_geometry_base;    // per mesh: first geometry record of the FIRST parameterized mesh that uses it (-1: none does)
+    bool flattened = false;                 // the scene was built as one world-space tree (option "flatten")
     // BVH policy (RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget, librender/render_params.glsl.h:61,90-93)
     bool bvh_force_rebuild = false;
     long long bvh_budget = 0, bvh_credit = 0; // triangles a refit call may rebuild; what has been saved up
     std::vector<uint64_t> rebuild_epoch;    // per mesh: bumped when the policy asks for a rebuild of its tree
     int rebuild_cursor = 0;                 // round robin over the dynamic meshes
     uint64_t rebuilds_done = 0;
+    uint64_t rebuild_failures = 0;          // device-side rebuilds that could not start (their meshes were refitted instead)
     bool host_bvh_stale = false;
     uint64_t vertex_updates = 0, vertex_updates_refitted = 0;
     bool master_refit_pending = false; // rptr_hip_refit with frame contexts that own their sets: the master tree is refitted on demand
@@ -1264,6 +1268,11 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
             own_records.push_back(r);
         }
     }
+    // the shading records of a mesh's triangles carry the material ids of the FIRST parameterized mesh that uses the mesh (set_scene builds
+    // them): instances of any other one resolve theirs through their geometry records
+    std::vector<int> first_pmesh_of_mesh(s->num_meshes, -1);
+    for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p)
+        if (first_pmesh_of_mesh[s->parameterized_meshes[p].mesh] < 0) first_pmesh_of_mesh[s->parameterized_meshes[p].mesh] = (int)p;
     for (uint32_t i = 0; i < s->num_instances && !flatten; ++i) {
         const RptrInstanceDesc &in = s->instances[i];
         const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
@@ -1273,6 +1282,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
         invert_affine(in.transform, bi.world_to_object);
         bi.geometry_base = pmesh_base[in.parameterized_mesh];
         bi.instance_id = (int)i;
+        if (first_pmesh_of_mesh[pm.mesh] != (int)in.parameterized_mesh) bi.flags |= RPTR_BVH_INSTANCE_OWN_MATERIALS;
         for (int sub : mesh_cut[pm.mesh]) {
             bi.blas_root = sub; // relocated below
             insts.push_back(bi);
@@ -1353,6 +1363,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
 }
 
 static int drain(rptr_hip *h);
+static int build_shade_records(rptr_hip *h, SceneCopy &sc, int only_mesh, hipStream_t st);
 }
 
 extern "C" {
@@ -2100,6 +2111,19 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
         h->master.dscene.lds_top = h->opt.v[OPT_LDS_TOP] != 0 ? 1 : 0;
     }
+    // ---- one shading record per BVH triangle (dshade.h RpShadeTri), made on the device from what was just uploaded: per mesh with the
+    // geometry records of the first parameterized mesh that uses it, or -- a flattened scene -- per triangle through the instance it names
+    {
+        RpShadeTri *d_shade = nullptr;
+        if ((rc = dev_alloc(h, &d_shade, h->h_tris.size() + 1, &h->scene_allocs))) return rc;
+        h->master.shade = d_shade;
+        h->master.dscene.shade = d_shade;
+        h->mesh_geometry_base.assign(s->num_meshes, -1);
+        for (uint32_t p = s->num_parameterized_meshes; p-- > 0;) h->mesh_geometry_base[s->parameterized_meshes[p].mesh] = pmesh_base[p];
+        h->flattened = !h->h_insts.empty() && (h->h_insts[0].flags & RPTR_BVH_INSTANCE_FLAT) != 0;
+        if ((rc = build_shade_records(h, h->master, -1, h->stream))) return rc;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     h->num_lights = (int)s->num_lights;
     h->num_materials = (int)s->num_materials;
     // ---- dynamic scene + frames in flight: every frame context gets its own set of what a refit rewrites
@@ -2114,6 +2138,8 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             sc.mesh_dyn.assign(s->num_meshes, nullptr);
             if ((rc = dev_alloc(h, &sc.nodes, h->h_nodes.size(), &h->scene_allocs))) return rc;
             if ((rc = dev_alloc(h, &sc.tris, h->h_tris.size() + 2, &h->scene_allocs))) return rc;
+            if ((rc = dev_alloc(h, &sc.shade, h->h_tris.size() + 1, &h->scene_allocs))) return rc;
+            if (!h->h_tris.empty()) HIP_TRY(h, hipMemcpy(sc.shade, h->master.shade, h->h_tris.size() * sizeof(RpShadeTri), hipMemcpyDeviceToDevice));
             if ((rc = dev_alloc(h, &sc.node_box, (size_t)6 * h->h_nodes.size(), &h->scene_allocs))) return rc;
             if ((rc = dev_alloc(h, &sc.tri_box, (size_t)6 * h->h_tris.size(), &h->scene_allocs))) return rc;
             if ((rc = dev_alloc(h, &sc.inst_box, (size_t)6 * h->h_insts.size(), &h->scene_allocs))) return rc;
@@ -2152,6 +2178,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             if (!cgeoms.empty()) HIP_TRY(h, hipMemcpy(cg, cgeoms.data(), cgeoms.size() * sizeof(RpGeomRecord), hipMemcpyHostToDevice));
             sc.dscene.nodes = sc.nodes;
             sc.dscene.tris = sc.tris;
+            sc.dscene.shade = sc.shade;
             sc.dscene.geoms = cg;
             sc.version = h->refit_version;
             if ((rc = make_refit_tables(sc))) return rc;
@@ -2196,6 +2223,22 @@ int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const floa
 // (render_vulkan.cpp:1323-1354, executed at the top of draw_frame :2165): topology is kept, triangles and all
 // boxes are recomputed on the device, level by level from the leaves up.
 extern "C++" {
+// the shading records (dshade.h RpShadeTri) of one scene copy's triangles: of mesh `only_mesh`, or (-1) of every mesh
+static int build_shade_records(rptr_hip *h, SceneCopy &sc, int only_mesh, hipStream_t st) {
+    if (h->flattened) { // one tree over all instanced triangles: every triangle names its instance record
+        const size_t n = h->h_tris.size();
+        if (n) hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, n)), dim3(256), 0, st, sc.dscene, sc.shade, 0u, (uint32_t)n, -1);
+    } else
+        for (size_t m = 0; m < h->meshes.size(); ++m) {
+            const MeshRt &mr = h->meshes[m];
+            if ((only_mesh >= 0 && (int)m != only_mesh) || mr.tri_count <= 0 || h->mesh_geometry_base[m] < 0) continue;
+            hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.dscene, sc.shade, (uint32_t)mr.tri_base,
+                               (uint32_t)mr.tri_count, h->mesh_geometry_base[m]);
+        }
+    HIP_TRY(h, hipGetLastError());
+    return RPTR_OK;
+}
+
 // the depth levels of dynamic mesh m of one scene copy, deepest first: a launch per deep level, the shallow ones (at most 4^5 + ... + 1
 // nodes) in the single-block kernel, which also does the instance bounds and the top level when `with_top`
 static void refit_mesh_levels(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t st, bool with_top) {
@@ -2329,14 +2372,15 @@ static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipSt
         const MeshRt &mr = h->meshes[m];
         const bool with_top = h->refit_top_all && k + 1 == todo.size();
         if (mr.tri_count)
-            hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.tris, sc.tri_box, (uint32_t)mr.tri_base,
+            hipLaunchKernelGGL(rp_k_refit_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.tris, sc.tri_box, sc.shade, (uint32_t)mr.tri_base,
                                (uint32_t)mr.tri_count, sc.mesh_dyn[m]);
         sc.mesh_dirty[m] = 0;
         if (sc.built_epoch[m] != h->rebuild_epoch[m]) {
             const int rc = lbvh_rebuild(h, sc, m, st, with_top);
-            if (rc == RPTR_OK)
+            if (rc == RPTR_OK) {
                 sc.built_epoch[m] = h->rebuild_epoch[m];
-            else {
+                (void)build_shade_records(h, sc, (int)m, st); // the rebuild reordered the mesh's triangles: its shading records follow
+            } else {
                 if (err && *err == RPTR_OK) *err = rc;
                 refit_mesh_levels(h, sc, m, st, with_top);
             }
@@ -2818,8 +2862,9 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
         (void)refit_scene_copy(h, scn, true, c.stream, &err);
         scn.version = h->refit_version;
         // a rebuild that could not start (no memory for its work space): the tree was refitted on its old topology, so this context is
-        // consistent and the frame is rendered on it; the handle's last error says why no rebuild happened, and the next refit tries again
-        (void)err;
+        // consistent and the frame is rendered on it; the next refit tries again. The caller can tell: rptr_hip_bvh_rebuild_count does not
+        // advance, and the failures are counted (rptr_hip_get_option(h, "bvh_rebuild_failures"))
+        if (err != RPTR_OK) h->rebuild_failures++;
     }
     if (c.gather_pending) { // the image this context produced last is still being sent to rank 0 (host_comm.h)
         HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_gather, 0));
@@ -3009,6 +3054,10 @@ int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value) {
     return RPTR_OK;
 }
 int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value) {
+    if (h && key && out_value && !strcmp(key, "bvh_rebuild_failures")) { // (read-only: a counter, not a switch)
+        *out_value = (int64_t)h->rebuild_failures;
+        return RPTR_OK;
+    }
     const int k = find_option(key);
     if (k < 0 || !out_value) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_get_option: unknown option \"%s\" or NULL result", key ? key : "(null)");
     *out_value = h ? h->opt.v[k] : effective_default_options().v[k];

@@ -43,10 +43,37 @@ def build(force=False):
     subprocess.check_call(["make", "-C", ORACLE_DIR] + (["-B"] if force else []) + ["liboracle.so"], stdout=subprocess.DEVNULL)
 
 
+BASELINE_LIB_PATH = os.path.join(ORACLE_DIR, "libcpu_baseline.so")
+
+
+def build_baseline(native_dir=None):
+    """The CPU baseline of bench.py: the oracle's own sources built -O3 without diagnostics (oracle/Makefile libcpu_baseline.so). With
+    native_dir: a copy built -march=native for THIS host into that directory (None when no compiler is at hand); without: the portable
+    x86-64-v3 copy that travels with the repository."""
+    if native_dir is not None:
+        try:
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-B", "libcpu_baseline.so", "BASELINE_MARCH=native", "BASELINE_OUT=" + native_dir],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return os.path.join(native_dir, "libcpu_baseline.so")
+        except (OSError, subprocess.CalledProcessError):
+            return None
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "libcpu_baseline.so"], stdout=subprocess.DEVNULL)
+    return BASELINE_LIB_PATH
+
+
+def use_library(path=None):
+    """Switches the library behind lib() / OracleScene (None: back to oracle/liboracle.so). Scenes made before the switch belong to the old one."""
+    global _lib, LIB_PATH
+    _lib = None
+    LIB_PATH = path or os.path.join(ORACLE_DIR, "liboracle.so")
+    return lib()
+
+
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if LIB_PATH == os.path.join(ORACLE_DIR, "liboracle.so"):
+            build()
         L = C.CDLL(LIB_PATH)
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]

@@ -10,13 +10,6 @@ from realtimepathtracingresearchframework_amd import backend, scenes
 EMPTY = np.int32(-2147483646)  # RPTR_BVH4_EMPTY
 
 
-@pytest.fixture(autouse=True)
-def _two_level_unless_asked(monkeypatch):
-    """The library flattens static multi-instance scenes by default (option "flatten" = auto, include/rptr_hip.h): hits are then found on
-    world-space triangles and t / u / v differ from the object-space walk by rounding. This module pins the two-level form of the host
-    builder bit for bit against the oracle's brute force (tests of the flattened form ask for it: RPTR_FLATTEN=1)."""
-    monkeypatch.setenv("RPTR_FLATTEN", "0")
-
 NODE_DT = np.dtype([("origin", "<f4", 3), ("exp", "u1", 3), ("pad0", "u1"), ("qlo", "u1", (3, 4)), ("qhi", "u1", (3, 4)),
                     ("child", "<i4", 4), ("pad1", "<u4", 2)])
 TRI_DT = np.dtype([("v0", "<f4", 3), ("e1", "<f4", 3), ("e2", "<f4", 3), ("prim", "<u4"), ("geom", "<u4"), ("pad", "<u4")])

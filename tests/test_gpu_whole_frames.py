@@ -83,32 +83,42 @@ def test_c2_whole_frame_1m_triangles_1080p_4spp_diffuse():
 
 
 # ---------------------------------------------------------------- C3
-@pytest.mark.parametrize("flatten", [0, 1])
+@pytest.mark.library_defaults
+@pytest.mark.parametrize("flatten", [0, None])
 def test_c3_whole_frame_gltf_area_lights_1080p_8spp(flatten, monkeypatch):
-    """flatten=1 is what bench.py times: the height field and the emitter mesh (two identity instances) in ONE tree instead of a top level
-    over two bottom-level trees. An identity transform moves no vertex, so the oracle's own tree finds the same hits either way."""
-    monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
+    """flatten=None: the library's default, which is what bench.py times -- the height field and the emitter mesh (two identity instances)
+    in ONE tree instead of a top level over two bottom-level trees, without the host asking for it (option "flatten" = auto). An identity
+    transform moves no vertex, so the oracle's own tree finds the same hits either way."""
+    if flatten is not None:
+        monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
     s = scenes.grid_1m_lights()
     assert s.num_tris() == 1_000_512 and len(s.lights) >= 512 and len(s.instances) == 2
     W, H, spp = 1920, 1080, 8
     got, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
     info = r.bvh_build_info()
+    flat = bool(np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)[0, 15] & 1)   # RPTR_BVH_INSTANCE_FLAT on record 0
+    assert flat == (flatten is None) and r.get_option("flatten") == (-1 if flatten is None else 0)
     r.close()
-    print("C3 flatten=%d: %s" % (flatten, info))
+    print("C3 flatten=%s: %s" % (flatten, info))
     osc = O.OracleScene(s)
     osc.build_bvh()
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF)
-    compare_whole_frame("C3 grid-1M glTF + 512 emitters (%s)" % ("one flattened tree" if flatten else "two-level"), got, ref, st, ost)
+    compare_whole_frame("C3 grid-1M glTF + 512 emitters (%s)" % ("one flattened tree" if flatten is None else "two-level"), got, ref, st, ost)
 
 
 # ---------------------------------------------------------------- C4
-@pytest.mark.parametrize("flatten", [0, 1])
+@pytest.mark.library_defaults
+@pytest.mark.parametrize("flatten", [0, None])
 def test_c4_whole_frame_forest_10m_instanced_triangles_1080p_4spp(flatten, monkeypatch):
-    monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
+    """flatten=None: the library's default -- a static forest is flattened (and built on the device) without the host asking for it"""
+    if flatten is not None:
+        monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
+    flatten = 1 if flatten is None else 0
     s = scenes.forest()
     assert s.num_instanced_tris() == 10_000_002 and len(s.instances) == 1001
     W, H, spp = 1920, 1080, 4
     got, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
+    assert bool(np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)[0, 15] & 1) == bool(flatten)
     osc = O.OracleScene(s)
     if flatten:
         # hits are found on world-space triangles: the oracle walks the very tree the device walked (t / u / v bit for bit)

@@ -666,3 +666,25 @@ def test_footprint_functions():
         assert abs(np.dot(px, d)) < 1e-5 and abs(np.dot(py, d)) < 1e-5 and abs(np.dot(px, py)) < 1e-4
         assert np.isclose(abs(np.dot(px / np.linalg.norm(px), a)), 1.0, atol=2e-3)
         assert np.allclose(np.sort(np.linalg.eigvalsh(R.astype(np.float64))), ev, rtol=2e-3)
+
+
+def test_cpu_baseline_build_of_the_oracle_renders_the_same_bits():
+    """bench.py's cpu_baseline is the oracle's own sources built -O3 without their diagnostics (oracle/Makefile libcpu_baseline.so:
+    -DORC_BASELINE, 32 x 32 tiles instead of row segments): same image bit for bit, same ray counts -- a glTF scene with emitters and a
+    two-level scene -- and faster than the instrumented build."""
+    import oracle_lib as O
+    from realtimepathtracingresearchframework_amd import abi, scenes
+    out = {}
+    try:
+        for name, path in (("oracle", None), ("baseline", O.build_baseline())):
+            O.use_library(path)
+            for key, s in (("grid", scenes.grid(60, 30, with_emitters=True)), ("two_level", scenes.two_level_test())):
+                osc = O.OracleScene(s)
+                osc.build_bvh()
+                img, st = osc.render(96, 64, 2, variant=abi.VARIANT_GLTF, threads=4)
+                out[(name, key)] = (img, int(st.rays_closest), int(st.rays_shadow), st.seconds)
+    finally:
+        O.use_library(None)
+    for key in ("grid", "two_level"):
+        a, b = out[("oracle", key)], out[("baseline", key)]
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and a[1:3] == b[1:3]
