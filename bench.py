@@ -36,13 +36,14 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 11 frame contexts + th
 
 # record sizes of the algorithmic-bytes model (DESIGN.md "Roofline model")
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
-HIT_BYTES = 24      # hit_tuv (float4) + hit_ids (int2) written per closest query
+HIT_BYTES = 8       # hit_ids (int2: instance, triangle) written per closest query, read per shaded vertex
+HIT_TUV_BYTES = 16  # ... + hit_tuv (float4) for a query that hits (round 5: a miss stores and loads no t / u / v)
 QUEUE_BYTES = 4     # path id read from the ray queue (not for the first bounce: its queue is computed)
 NODE_BYTES = 64     # RptrBvh4Node (an instance record, 128 B, counts as two)
 TRI_BYTES = 48      # RptrBvhTri
 SHADOW_RESULT_BYTES = 16 + 16 + 16  # contribution read + illum read-modify-write for a visible shadow ray
 PATH_READ_BYTES, PATH_WRITE_BYTES = 64, 72    # shade: path state in (ray_o, ray_d, thr, illum; not on the first bounce) / out per vertex (the same + two queue words; rounds 1-3: 72 / 80 with the separate generator / path-length array)
-VERTEX_BYTES, MATERIAL_BYTES = 48, 80         # 3 x (qpos + qnrm_uv), RptrBaseMaterial
+VERTEX_BYTES, MATERIAL_BYTES = 64, 80         # the triangle's 64-byte shading record (csrc/dshade.h RpShadeTri; rounds 1-4: 48 = 3 x (qpos + qnrm_uv) from two streams), RptrBaseMaterial
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md "HBM")
 MAX_CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: max clock 2400 MHz
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth (MI355X_MICROARCH.md "L2 (per XCD)"): the ceiling of bytes served by the cache hierarchy
@@ -95,6 +96,9 @@ def parse_args():
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--rccl-probe", action="store_true", help="(internal) run as the probe child of a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dynamic-meshes", type=int, default=0,
+                    help="mark the first k meshes of the scene RPTR_MESH_DYNAMIC (they are never moved): the forest with one dynamic tree mesh is the "
+                         "partially flattened scene of round 5 (static instances in one world-space tree beside the dynamic mesh's instance records)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the `boundary` leg (bin/rptr_hip, the C++ host over the C ABI, on the same workload)")
     ap.add_argument("--static-camera", action="store_true",
                     help="every frame through the same camera (rounds 1-3). Default: the camera MOVES every frame, as the reference's loop lets it "
@@ -306,7 +310,7 @@ def boundary_leg(args, scene, W, H, spp, fif, batch_frames, bench_ms):
 
 def workload_key(args, world=1):
     """the BASELINE workload a command line names, as tools/pmc_workloads.sh keys its counter passes (None: not one of them)"""
-    if world != 1 or args.emulate_world > 1 or args.grid != "1000x500" or args.rebuild_budget != 0:
+    if world != 1 or args.emulate_world > 1 or args.grid != "1000x500" or args.rebuild_budget != 0 or args.dynamic_meshes:
         return None
     size = (args.width, args.height, args.spp)
     flat = args.flatten if args.flatten >= 0 else (0 if args.animate else 1)
@@ -334,7 +338,7 @@ def load_valu_peak():
     instructions / s at 8 waves per SIMD): of plain full-rate instructions (v_fma_f32 / v_mul_f32 / v_add_u32: one per 2 clocks per
     SIMD, MI355X_MICROARCH.md) and of the instruction mix of the BVH4 node step (v_cvt_f32_ubyte, v_pk_fma_f32, min / max issue at half
     that rate). None when the file is absent."""
-    for name in ("r04_valu_issue.json", "r03a_valu_issue.json"):
+    for name in ("r05_valu_issue.json", "r04_valu_issue.json", "r03a_valu_issue.json"):
         try:
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
             best = {}
@@ -422,6 +426,8 @@ def main():
     else:
         scene = scenes.grid(nx, nz, with_emitters=args.lights, name="grid-%dk" % (2 * nx * nz // 1000),
                             deform_t=0.0 if args.animate else None)
+    for m_ in scene.meshes[:max(0, args.dynamic_meshes)]:
+        m_.dynamic = True
     t_scene = time.time() - t0
     variant = abi.VARIANT_SIMPLE if args.variant == "diffuse" else abi.VARIANT_GLTF
     W, H, spp = args.width, args.height, args.spp
@@ -813,15 +819,15 @@ def main():
     # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share.
     # All durations below are EXCLUSIVE: HIP events on the dispatch packets of frames rendered one at a time (nothing else on the GPU).
     primary = r.local_pixel_count() * spp  # the first launch computes its camera rays and its queue instead of reading them
-    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * (RAY_BYTES + QUEUE_BYTES) + cnt_ext["nodes_closest"] * NODE_BYTES
-                 + cnt_ext["tris_closest"] * TRI_BYTES)
+    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt_ext["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES)
+                 + cnt_ext["nodes_closest"] * NODE_BYTES + cnt_ext["tris_closest"] * TRI_BYTES)
     con_bytes = (cnt_con["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt_con["nodes_shadow"] * NODE_BYTES
                  + cnt_con["tris_shadow"] * TRI_BYTES)
     shade_vertices = cnt_ext["rays_closest"]       # one shade invocation per closest-hit query of the stand-alone bounces
     shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES)
-                   + cnt_ext["hits"] * (VERTEX_BYTES + MATERIAL_BYTES))
+                   + cnt_ext["hits"] * (HIT_TUV_BYTES + VERTEX_BYTES + MATERIAL_BYTES))
     # all bounces of a frame (the tail kernel's included), counted on the instrumented frame
-    total_alg_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) - primary * (RAY_BYTES + QUEUE_BYTES) + cnt["nodes_closest"] * NODE_BYTES
+    total_alg_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + 2 * cnt["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES) + cnt["nodes_closest"] * NODE_BYTES
                        + cnt["tris_closest"] * TRI_BYTES + cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
                        + cnt["tris_shadow"] * TRI_BYTES + cnt["rays_closest"] * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES)
                        - primary * (QUEUE_BYTES + PATH_READ_BYTES) + cnt["hits"] * (VERTEX_BYTES + MATERIAL_BYTES) + r.local_pixel_count() * (16 * spp + 36))
@@ -867,7 +873,7 @@ def main():
                 vi = sum(parts) / len(parts)
         e["valu_insts_per_launch"] = int(vi) if vi is not None else None
         e["valu_ginst_s"] = round(vi / (launch_ms * 1e-3) / 1e9, 1) if (vi is not None and launch_ms > 0) else None
-        # the ceiling of THIS kernel's instruction mix: its static VALU histogram run through the issue microbenchmark (profiles/r04_kernel_mix.json);
+        # the ceiling of THIS kernel's instruction mix: its static VALU histogram run through the issue microbenchmark (profiles/r05_kernel_mix.json);
         # the traversal kernels spend their time in the node step, whose hand-counted mix has its own measurement (the lower of the two is used)
         op = own_peak(mix_labels)
         peak = min(op, valu_peak) if (op is not None and node_step) else (op if op is not None else valu_peak)
@@ -880,7 +886,7 @@ def main():
                 e[fld] = round(sum(parts) / len(parts), 4) if all(v is not None for v in parts) else None
         return e
 
-    single = len(scene.instances) == 1 or (bool(flatten) and not args.animate)   # (a flattened scene is one identity instance over one tree)
+    single = len(scene.instances) == 1 or (bool(flatten) and not args.animate and not args.dynamic_meshes)   # (a flattened scene is one identity instance over one tree)
     sfx = ", false, %s" % ("true" if single else "false")   # (COUNT, FIRST,) ALPHA, SINGLE [, TABLE]
     var_id = "1" if variant == abi.VARIANT_SIMPLE else "0"
     k_ext = kernel_entry("rp_k_extend<COUNT=false, FIRST, ALPHA=false, SINGLE=%s>: first bounce FIRST=true, later bounces FIRST=false" % str(single).lower(),

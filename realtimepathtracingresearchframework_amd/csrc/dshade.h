@@ -81,7 +81,9 @@ struct RpScene {
     const RpTexture *textures;
     const float *srgb_lut; // 256 entries: sRGB-encoded byte -> linear float (computed on the host)
     int32_t node_min, refill_min; // scheduling thresholds of the traversal for this scene (dtraverse.h), 0 = the compile-time defaults
-    int32_t lds_top, _pad_lds;    // RPTR_LDS_TOP=1: launch the traversal instantiations that stage the top of the tree in LDS (k_extend.hip)
+    int32_t lds_top;      // option "lds_top": launch the traversal instantiations that stage the top of the tree in LDS (k_extend.hip)
+    int32_t flat_id_bias; // a world-space triangle of a flattened tree names instance record r = bias + instance id (1; partially flattened
+                          // scenes: 1 + the number of instance records of the dynamic meshes)
 };
 
 // Division of a 31-bit number by a frame constant (tiles per row, rows per stripe, padded pixels per sample slot) without the ~25

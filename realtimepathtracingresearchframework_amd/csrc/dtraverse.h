@@ -549,7 +549,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                 // a triangle of a flattened scene names its own instance record (rptr_bvh.h), any other one
                                 // belongs to the instance being traversed
                                 const int tri_rec = (int)RPTR_BVH_TRI_INSTANCE(__float_as_uint(q2.w));
-                                const int hit_inst = tri_rec ? tri_rec : cur_inst, hit_inst_id = tri_rec ? tri_rec - 1 : cur_inst_id;
+                                const int hit_inst = tri_rec ? tri_rec : cur_inst, hit_inst_id = tri_rec ? tri_rec - sc.flat_id_bias : cur_inst_id;
                                 bool accept = t < best.t;
                                 if (!accept && t == best.t && best.inst_idx >= 0) { // a tie (rare): the smaller (instance, geometry, primitive) wins
                                     if (hit_inst_id != best_inst_id)

@@ -196,7 +196,7 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
     };
     auto done = [&](uint32_t, const RpHitRec &h) {
         const uint32_t p = lane_p;
-        ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, 0.0f);
+        if (h.inst_idx >= 0) ps.hit_tuv[p] = make_float4(h.t, h.u, h.v, 0.0f); // (nobody reads t / u / v of a miss: 16 bytes less per ray that leaves the scene)
         ps.hit_ids[p] = make_int2(h.inst_idx, h.tri);
         if (ALPHA) {
             if (TABLE && f.rng_variant != RPTR_RNG_VARIANT_UNIFORM) {

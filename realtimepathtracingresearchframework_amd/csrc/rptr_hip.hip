@@ -291,7 +291,7 @@ struct rptr_hip {
     bool refit_top_all = false;             // instance bounds + top-level levels fit one single-block launch (rp_k_refit_top)
     bool has_dynamic = false;               // some mesh is dynamic
     std::vector<int> mesh_geometry_base;    // per mesh: first geometry record of the FIRST parameterized mesh that uses it (-1: none does)
-    bool flattened = false;                 // the scene was built as one world-space tree (option "flatten")
+    size_t flat_tris = 0, flat_nodes = 0;   // the scene's static instances were built as one world-space tree (option "flatten"): its triangles / nodes come first
     // BVH policy (RenderBackendOptions::force_bvh_rebuild / rebuild_triangle_budget, librender/render_params.glsl.h:61,90-93)
     bool bvh_force_rebuild = false;
     long long bvh_budget = 0, bvh_credit = 0; // triangles a refit call may rebuild; what has been saved up
@@ -521,6 +521,8 @@ struct HostBvh {
     int num_tlas_insts = 0; // instance records the top level refers to (a flattened scene keeps the scene's own records behind them)
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
     int stack_need = 0;
+    size_t flat_tris = 0, flat_nodes = 0; // a (partially) flattened scene: triangles / nodes of its one world-space tree (they come first)
+    int flat_id_bias = 0;                 // ... and where its triangles' own instance records start (record = bias + instance id)
     bool device_built = false; // some bottom-level tree came from the device builder (ploc.h)
     double device_ms = 0.0;
     int device_iterations = 0;
@@ -573,19 +575,29 @@ static std::string validate_scene_tables(const RptrSceneDesc *s) {
     return std::string();
 }
 
-static bool want_flatten(const RptrSceneDesc *s, const RpOptions &o) {
+// 0: two-level; 1: the whole scene is one world-space tree (every instanced mesh is static); 2: PARTIAL -- the scene has dynamic meshes: the
+// instances of its static meshes are flattened into one tree, which the top level holds as one identity instance beside the records of the
+// dynamic meshes' instances (round 5: a forest with one animated character used to fall back to the two-level walk as a whole: 1.5 x)
+static int want_flatten(const RptrSceneDesc *s, const RpOptions &o) {
     // option "flatten": -1 / 1 = every static multi-instance scene that fits "flatten_max_tris" (the default: the library knows which
     // meshes are dynamic -- RptrMeshDesc.dynamic, the reference's per-mesh build intent, vulkan/render_vulkan.cpp:942-952 -- and a flattened
     // tree is 1.5-1.6 x faster to trace than the two-level one); 0 = never
-    if (o.v[OPT_FLATTEN] == 0 || s->num_instances < 2) return false;
+    if (o.v[OPT_FLATTEN] == 0 || s->num_instances < 2) return 0;
     const size_t limit = (size_t)o.v[OPT_FLATTEN_MAX_TRIS];
     size_t total = 0;
+    uint32_t n_static = 0, n_dynamic = 0;
     for (uint32_t i = 0; i < s->num_instances; ++i) {
         const RptrMeshDesc &mesh = s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh].mesh];
-        if (mesh.dynamic) return false;
+        if (mesh.dynamic) {
+            ++n_dynamic;
+            continue;
+        }
+        ++n_static;
         for (uint32_t j = 0; j < mesh.num_geometries; ++j) total += s->geometries[mesh.first_geometry + j].num_tris;
     }
-    return total <= limit && s->num_instances < (1u << 24) - 1;
+    if (total > limit || total == 0 || (uint64_t)s->num_instances + n_dynamic + 2 >= (1u << 24)) return 0;
+    if (n_dynamic == 0) return 1;
+    return n_static >= 2 ? 2 : 0;
 }
 
 // ------------------------------------------------------------------ device-side build of one bottom-level tree (ploc.h)
@@ -943,7 +955,15 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
             off += nt;
         }
     }
-    const bool flatten = want_flatten(s, opt);
+    const int flatten_mode = want_flatten(s, opt);
+    const bool flatten = flatten_mode != 0, partial = flatten_mode == 2;
+    // where a flattened triangle's OWN instance record lies in the instance array: behind the records the top level refers to (one for the
+    // flat tree; PARTIAL: + one per instance of a dynamic mesh), at flat_bias + its instance id
+    uint32_t n_dynamic_insts = 0;
+    auto instance_is_dynamic = [&](uint32_t i) { return s->meshes[s->parameterized_meshes[s->instances[i].parameterized_mesh].mesh].dynamic != 0; };
+    for (uint32_t i = 0; i < s->num_instances; ++i) n_dynamic_insts += (partial && instance_is_dynamic(i)) ? 1u : 0u;
+    const uint32_t flat_bias = 1u + n_dynamic_insts;
+    B.flat_id_bias = flatten ? (int)flat_bias : 0;
     rptr::build_tuning().collapse_rule = (int)opt.v[OPT_COLLAPSE];
     rptr::build_tuning().ploc_top = (size_t)opt.v[OPT_PLOC_TOP];
     rptr::build_tuning().ploc_leaf = (int)opt.v[OPT_PLOC_LEAF];
@@ -966,6 +986,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
             const RptrInstanceDesc &in = s->instances[i];
             const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
             const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+            if (mesh.dynamic) continue; // (PARTIAL: its instances keep their own records and trees)
             for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
                 const RptrGeometryDesc &gd = s->geometries[mesh.first_geometry + j];
                 if (!gd.num_tris) continue;
@@ -982,7 +1003,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
                 memcpy(sg.transform, in.transform, 48);
                 sg.count = gd.num_tris;
                 sg.geom = j;
-                sg.flags_hi = (i + 1u) << 8;
+                sg.flags_hi = (flat_bias + i) << 8;
                 sg.has_transform = 1;
                 segs.push_back(sg);
                 total += gd.num_tris;
@@ -990,6 +1011,8 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
         }
         DeviceTree dt;
         if (on_device(total) && dev->build(segs, (uint32_t)total, dt)) {
+            B.flat_tris = dt.tris.size();
+            B.flat_nodes = dt.nodes.size();
             for (MeshRt &mr : B.meshes) {
                 mr.node_base = 0;
                 mr.node_count = 0;
@@ -1015,6 +1038,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
             const RptrInstanceDesc &in = s->instances[i];
             const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
             const RptrMeshDesc &mesh = s->meshes[pm.mesh];
+            if (mesh.dynamic) continue;
             const float *M = in.transform;
             size_t off = 0;
             for (uint32_t j = 0; j < mesh.num_geometries; ++j) {
@@ -1038,7 +1062,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
                     const bool alpha = mid >= 0 && mid < (int64_t)s->num_materials && (s->materials[mid].flags & RPTR_BASE_MATERIAL_NOALPHA) == 0;
                     tri.prim = t;
                     tri.geom = j;
-                    tri.flags = (alpha ? RPTR_BVH_TRI_ALPHA : 0u) | ((i + 1u) << 8); // its instance: record i + 1 of the instance array
+                    tri.flags = (alpha ? RPTR_BVH_TRI_ALPHA : 0u) | ((flat_bias + i) << 8); // its instance: record flat_bias + i of the instance array
                     mtris.push_back(tri);
                     prims.push_back(bp);
                     rptr::TriVerts tv;
@@ -1069,9 +1093,12 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
         B.tris.reserve(tree.order.size());
         for (uint32_t id : tree.order) B.tris.push_back(mtris[ref_tri.empty() ? id : ref_tri[id]]);
         encode_tree(wide, 0, 0, blas_nodes, blas_boxes);
+        B.flat_tris = B.tris.size();
+        B.flat_nodes = blas_nodes.size();
     }
-    for (uint32_t m = 0; m < s->num_meshes && !flatten; ++m) {
+    for (uint32_t m = 0; m < s->num_meshes && (!flatten || partial); ++m) {
         const RptrMeshDesc &mesh = s->meshes[m];
+        if (partial && !mesh.dynamic) continue; // (its instances are part of the flat tree)
         {
             size_t total = 0;
             for (uint32_t j = 0; j < mesh.num_geometries; ++j) total += s->geometries[mesh.first_geometry + j].num_tris;
@@ -1198,7 +1225,7 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
     // inner nodes), each with the world box of its own subtree.
     int braid = s->num_instances >= 16 ? 4 : 1;
     if (opt.v[OPT_REBRAID] > 0) braid = (int)opt.v[OPT_REBRAID];
-    if (flatten) braid = 1;
+    if (flatten) braid = 1; // (PARTIAL: the dynamic meshes' instances keep one record each: flat_bias counts on it)
     std::vector<rptr::BuildPrim> iprims;
     std::vector<RptrBvhInstance> insts;
     iprims.reserve((size_t)s->num_instances * braid);
@@ -1247,7 +1274,9 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
         memcpy(bi.world_to_object, identity, 48);
         bi.blas_root = 0; // relocated below
         bi.instance_id = -1;
-        bi.flags = RPTR_BVH_INSTANCE_FLAT;
+        // (FLAT promises ONE top-level record -- queries start inside it, csrc/dtraverse.h SINGLE, oracle/obvh.h --; the flat tree of a
+        // partially flattened scene is an ordinary identity instance of the top level whose triangles name their own records)
+        bi.flags = partial ? 0 : RPTR_BVH_INSTANCE_FLAT;
         insts.push_back(bi);
         rptr::BuildPrim bp;
         const std::array<float, 6> &mb = blas_boxes[0];
@@ -1273,9 +1302,10 @@ static void build_host_bvh(const RptrSceneDesc *s, HostBvh &B, const RpOptions &
     std::vector<int> first_pmesh_of_mesh(s->num_meshes, -1);
     for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p)
         if (first_pmesh_of_mesh[s->parameterized_meshes[p].mesh] < 0) first_pmesh_of_mesh[s->parameterized_meshes[p].mesh] = (int)p;
-    for (uint32_t i = 0; i < s->num_instances && !flatten; ++i) {
+    for (uint32_t i = 0; i < s->num_instances && (!flatten || partial); ++i) {
         const RptrInstanceDesc &in = s->instances[i];
         const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[in.parameterized_mesh];
+        if (partial && !s->meshes[pm.mesh].dynamic) continue;
         RptrBvhInstance bi;
         memset(&bi, 0, sizeof(bi));
         memcpy(bi.object_to_world, in.transform, 48);
@@ -1891,6 +1921,8 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->meshes = std::move(B.meshes);
     h->mesh_root = std::move(B.mesh_root);
     h->num_tlas_nodes = B.num_tlas_nodes;
+    h->flat_tris = B.flat_tris;
+    h->flat_nodes = B.flat_nodes;
     memcpy(h->scene_lo, B.scene_lo, 12);
     memcpy(h->scene_hi, B.scene_hi, 12);
     // ---- refit: the top level by height (children before parents); the bottom-level trees of dynamic meshes are refitted bottom-up
@@ -1982,7 +2014,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         const uint32_t small = 4096;
         std::vector<uint2> lv;
         for (auto &l : h->refit_levels_tlas) lv.push_back(make_uint2(l[0], l[1]));
-        h->refit_top_all = h->h_insts.size() <= 4 * small;
+        h->refit_top_all = (size_t)h->num_tlas_insts <= 4 * small; // (only the records the top level refers to have bounds: a flattened tree's triangles name the others)
         for (auto &l : h->refit_levels_tlas) h->refit_top_all = h->refit_top_all && l[1] - l[0] <= small;
         h->d_refit_levels = nullptr;
         if (!lv.empty()) {
@@ -2046,6 +2078,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_lights = (int)s->num_lights;
     h->master.dscene.num_materials = (int)s->num_materials;
     h->master.dscene.num_nodes = (uint32_t)h->h_nodes.size();
+    h->master.dscene.flat_id_bias = B.flat_id_bias > 0 ? B.flat_id_bias : 1;
     h->master.dscene.single_instance = (h->num_tlas_insts == 1 && h->opt.v[OPT_SINGLE_INSTANCE] != 0) ? 1 : 0;
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
@@ -2067,8 +2100,9 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         };
         for (size_t m = 0; m < h->meshes.size(); ++m) {
             const MeshRt &mr = h->meshes[m];
-            const size_t root = (size_t)h->mesh_root[m], count = (size_t)(mr.node_count > 0 ? mr.node_count : (m == 0 ? (int)h->h_nodes.size() - h->num_tlas_nodes : 0));
-            const size_t tris_m = mr.tri_count > 0 ? (size_t)mr.tri_count : (m == 0 ? h->h_tris.size() : 0);
+            // (a mesh without a tree of its own is part of the flattened tree, which lies first: counted once, for mesh 0)
+            const size_t root = (size_t)h->mesh_root[m], count = (size_t)(mr.node_count > 0 ? mr.node_count : (m == 0 ? (int)h->flat_nodes : 0));
+            const size_t tris_m = mr.tri_count > 0 ? (size_t)mr.tri_count : (m == 0 ? h->flat_tris : 0);
             if (!count || tris_m < best_tris || root >= h->h_nodes.size()) continue;
             const double a0 = half_area(root);
             if (!(a0 > 0.0)) continue;
@@ -2120,7 +2154,6 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         h->master.dscene.shade = d_shade;
         h->mesh_geometry_base.assign(s->num_meshes, -1);
         for (uint32_t p = s->num_parameterized_meshes; p-- > 0;) h->mesh_geometry_base[s->parameterized_meshes[p].mesh] = pmesh_base[p];
-        h->flattened = !h->h_insts.empty() && (h->h_insts[0].flags & RPTR_BVH_INSTANCE_FLAT) != 0;
         if ((rc = build_shade_records(h, h->master, -1, h->stream))) return rc;
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
@@ -2225,16 +2258,14 @@ int rptr_hip_update_vertices_device(rptr_hip_t *h, uint32_t geometry, const floa
 extern "C++" {
 // the shading records (dshade.h RpShadeTri) of one scene copy's triangles: of mesh `only_mesh`, or (-1) of every mesh
 static int build_shade_records(rptr_hip *h, SceneCopy &sc, int only_mesh, hipStream_t st) {
-    if (h->flattened) { // one tree over all instanced triangles: every triangle names its instance record
-        const size_t n = h->h_tris.size();
-        if (n) hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, n)), dim3(256), 0, st, sc.dscene, sc.shade, 0u, (uint32_t)n, -1);
-    } else
-        for (size_t m = 0; m < h->meshes.size(); ++m) {
-            const MeshRt &mr = h->meshes[m];
-            if ((only_mesh >= 0 && (int)m != only_mesh) || mr.tri_count <= 0 || h->mesh_geometry_base[m] < 0) continue;
-            hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.dscene, sc.shade, (uint32_t)mr.tri_base,
-                               (uint32_t)mr.tri_count, h->mesh_geometry_base[m]);
-        }
+    if (h->flat_tris && only_mesh < 0) // the world-space tree over the static instances' triangles: every triangle names its instance record
+        hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, h->flat_tris)), dim3(256), 0, st, sc.dscene, sc.shade, 0u, (uint32_t)h->flat_tris, -1);
+    for (size_t m = 0; m < h->meshes.size(); ++m) { // meshes with trees of their own (a mesh inside the flattened tree has none)
+        const MeshRt &mr = h->meshes[m];
+        if ((only_mesh >= 0 && (int)m != only_mesh) || mr.tri_count <= 0 || h->mesh_geometry_base[m] < 0) continue;
+        hipLaunchKernelGGL(rp_k_build_shade_tris, dim3(grid_for(h, (size_t)mr.tri_count)), dim3(256), 0, st, sc.dscene, sc.shade, (uint32_t)mr.tri_base,
+                           (uint32_t)mr.tri_count, h->mesh_geometry_base[m]);
+    }
     HIP_TRY(h, hipGetLastError());
     return RPTR_OK;
 }
@@ -2260,7 +2291,7 @@ static void refit_mesh_levels(rptr_hip *h, SceneCopy &sc, size_t m, hipStream_t 
     RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
     hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, sc.blas_list,
                        dev_levels + (RP_REFIT_LEVELS - n_top), n_top, h->d_refit_list, h->d_refit_levels, with_top ? (int)h->refit_levels_tlas.size() : 0, insts,
-                       with_top ? (uint32_t)h->h_insts.size() : 0u);
+                       with_top ? (uint32_t)h->num_tlas_insts : 0u);
 }
 
 // device-side rebuild of the bottom-level tree of dynamic mesh m of one scene copy (lbvh.h), on stream `st`. The triangles of the mesh
@@ -2390,7 +2421,7 @@ static bool refit_scene_copy(rptr_hip *h, SceneCopy &sc, bool all_dynamic, hipSt
     }
     if (!top_done) { // instance bounds, then the top level
         RptrBvhInstance *insts = const_cast<RptrBvhInstance *>(sc.dscene.insts);
-        const uint32_t ni = (uint32_t)h->h_insts.size();
+        const uint32_t ni = (uint32_t)h->num_tlas_insts;
         if (h->refit_top_all)
             hipLaunchKernelGGL(rp_k_refit_top, dim3(1), dim3(1024), 0, st, sc.nodes, sc.node_box, sc.tri_box, sc.inst_box, sc.blas_list, sc.blas_levels, 0,
                                h->d_refit_list, h->d_refit_levels, (int)h->refit_levels_tlas.size(), insts, ni);

@@ -278,3 +278,43 @@ def _rebuild(s, monkeypatch, rule):
     b = backend.build_bvh_host(s)[0].tobytes()
     monkeypatch.delenv("RPTR_COLLAPSE")
     return b
+
+
+def test_partially_flattened_scene_on_the_host(monkeypatch):
+    """Round 5: a scene with a dynamic mesh keeps that mesh's instances two-level and flattens the instances of its STATIC meshes into one
+    world-space tree, held by the top level as one identity instance (option "flatten" = auto; before, one dynamic mesh sent the whole scene
+    down the two-level walk). Layout: the top level refers to 1 + (instances of dynamic meshes) records, none of them flagged
+    RPTR_BVH_INSTANCE_FLAT; the scene's own records follow, record bias + i for instance i; the flat tree's triangles name them, the
+    dynamic mesh's triangles name none. The oracle walks it: the hits of its own two-level walk (ids; t up to the rounding of the
+    pre-transformed triangles)."""
+    s = scenes.forest(n_meshes=3, tris_per_tree=300, n_instances=25, name="f")
+    s.meshes[0].dynamic = True
+    n_dyn = sum(1 for i in s.instances if s.pmeshes[i.pmesh].mesh == 0)
+    assert 0 < n_dyn < len(s.instances) - 1
+    monkeypatch.setenv("RPTR_FLATTEN", "-1")
+    nodes, tris, insts, need = backend.build_bvh_host(s)
+    monkeypatch.setenv("RPTR_FLATTEN", "0")
+    nodes2, tris2, insts2, _ = backend.build_bvh_host(s)
+    t = np.frombuffer(np.ascontiguousarray(tris).tobytes(), dtype=np.uint32).reshape(-1, 12)
+    recs = np.frombuffer(np.ascontiguousarray(insts).tobytes(), dtype=np.int32).reshape(-1, 32)
+    n_inst, bias = len(s.instances), 1 + n_dyn
+    assert len(recs) == bias + n_inst and not (recs[:bias, 15] & 1).any()
+    assert sorted(recs[:bias, 14].tolist()) == sorted([-1] + [k for k, i in enumerate(s.instances) if s.pmeshes[i.pmesh].mesh == 0])
+    assert recs[bias:, 14].tolist() == list(range(n_inst))
+    rec = t[:, 11] >> 8
+    static = [k for k, i in enumerate(s.instances) if s.pmeshes[i.pmesh].mesh != 0]
+    assert set(np.unique(rec[rec > 0]).tolist()) == {bias + k for k in static}
+    dyn_tris = sum(g.num_tris for g in s.geometries[s.meshes[0].first_geometry:][:s.meshes[0].num_geometries])
+    assert int((rec == 0).sum()) == dyn_tris                      # the dynamic mesh: ONE object-space tree, shared by its instances
+    osc = O.OracleScene(s)
+    o, d = _rays(6000, 5, -6, 6)
+    osc.import_bvh(nodes2, tris2, insts2)
+    tuv2, ids2 = osc.trace_ex(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+    osc.import_bvh(nodes, tris, insts)
+    tuv, ids, visits = osc.trace_ex_counts(o, d, 1e-4, 1e20, bvh_mode=O.BVH_IMPORTED)
+    same = (ids == ids2).all(axis=1)
+    assert same.mean() > 0.999 and (ids2[:, 0] >= 0).sum() > 500
+    hit = same & (ids2[:, 0] >= 0)
+    assert np.allclose(tuv[hit, 0], tuv2[hit, 0], rtol=2e-5, atol=1e-6)
+    dyn_hit = hit & np.isin(ids2[:, 0], [k for k in range(n_inst) if k not in static])
+    assert dyn_hit.sum() > 10 and np.array_equal(tuv[dyn_hit].view(np.uint32), tuv2[dyn_hit].view(np.uint32))   # object-space triangles: the same bits

@@ -523,3 +523,72 @@ def test_subtly_dynamic_meshes_are_refitted_never_rebuilt():
     r.refit()
     assert r.bvh_rebuild_count() == 0
     r.close()
+
+
+@pytest.mark.library_defaults
+@pytest.mark.parametrize("fif", [1, 3])
+def test_partially_flattened_scene_with_a_dynamic_mesh(fif, monkeypatch):
+    """Round 5 ("partial flattening"): a forest whose first tree mesh is dynamic. On the library's defaults the instances
+    of the static meshes become ONE world-space tree beside the dynamic mesh's instance records (before: one dynamic mesh sent the whole
+    scene down the two-level walk, 1.5 x slower on C4). Against the two-level build of the same scene (RPTR_FLATTEN=0): the same hit ids for
+    ray queries -- bit-identical records where the dynamic mesh is hit, t equal up to the rounding of pre-transformed triangles elsewhere --
+    before and after the mesh moves (update_vertices + refit, then a device-side rebuild), the oracle's image within the tolerance, and
+    frames in flight on per-context scene copies (fif = 3) bit-identical to frames rendered one at a time."""
+    s = scenes.forest(n_meshes=3, tris_per_tree=600, n_instances=40, name="partial-forest")
+    s.meshes[0].dynamic = True
+    dyn_insts = [k for k, i in enumerate(s.instances) if s.pmeshes[i.pmesh].mesh == 0]
+    assert 0 < len(dyn_insts) < len(s.instances) - 1
+    q = random_queries(np.random.default_rng(9), 40000, -12, 12)
+    q[:, 1] = np.abs(q[:, 1]) * 0.2 + 0.1
+    g0 = s.geometries[s.meshes[0].first_geometry]
+    P0 = scenes.dequantize_positions(g0.qpos, g0.scaling, g0.offset).astype(np.float32)
+    P1 = P0.copy()
+    P1[:, 1] *= 1.25   # the tree grows
+    W, H, spp = 160, 96, 2
+
+    def run(flatten):
+        if flatten is not None:
+            monkeypatch.setenv("RPTR_FLATTEN", str(flatten))
+        else:
+            monkeypatch.delenv("RPTR_FLATTEN", raising=False)
+        r = backend.RenderHip(frames_in_flight=fif)
+        r.initialize(W, H)
+        r.set_scene(s)
+        recs = np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)
+        out = {"records": len(recs), "flat_flag": bool((recs[:, 15] & 1).any()), "hits": [], "imgs": []}
+        cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_GLTF, reset_accumulation=True)
+        for step, (P, force) in enumerate(((None, False), (P1, False), (P0, True))):
+            if P is not None:
+                r.set_bvh_policy(force_bvh_rebuild=force)
+                r.update_vertices(s.meshes[0].first_geometry, P)
+                r.refit()
+            out["hits"].append(r.render_ray_queries(q).copy())
+            if fif == 1:
+                r.render(cfg, spp=spp)
+            else:   # three frames in flight on three scene copies; the last one is the image
+                for t in [r.render_async(cfg, spp=spp) for _ in range(3)]:
+                    r.wait(t)
+            img = np.zeros((H, W, 4), np.float32)
+            r.readback_framebuffer(img)
+            out["imgs"].append(img)
+        out["rebuilds"] = r.bvh_rebuild_count()
+        r.close()
+        return out
+
+    part, two = run(None), run(0)
+    assert part["records"] == 1 + len(dyn_insts) + len(s.instances) and not part["flat_flag"] and two["records"] < part["records"]
+    assert part["rebuilds"] >= 1 and two["rebuilds"] >= 1
+    for a, b in zip(part["hits"], two["hits"]):
+        ids_a, ids_b = a[:, 2:].view(np.int32), b[:, 2:].view(np.int32)
+        same = (ids_a == ids_b).all(axis=1)
+        assert same.mean() > 0.999 and (ids_b[:, 1] >= 0).sum() > 1000
+        hit = same & (ids_b[:, 1] >= 0)
+        assert np.allclose(a[hit, :2], b[hit, :2], rtol=0, atol=2e-4)        # barycentrics
+    for a, b in zip(part["imgs"], two["imgs"]):
+        rmse, _, _ = image_error(a, b)
+        assert rmse < RMSE_TOL
+    if fif == 1:   # and against the oracle, after the last move (P0 again: the scene as loaded)
+        osc = O.OracleScene(s)
+        ref, _ = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, frame_offset=2 * spp)
+        rmse, _, _ = image_error(part["imgs"][2], ref)
+        assert rmse < RMSE_TOL

@@ -1,5 +1,5 @@
 """Static VALU instruction mix of the path kernels (disassembly of the built library), by issue class, for the issue-rate microbenchmark:
-tools/kernel_mix.py [lib.so] [--flags] -> profiles/r04_kernel_mix.json; --flags prints the -D options tools/microbench/valu_issue.hip is
+tools/kernel_mix.py [lib.so] [--flags] -> profiles/r05_kernel_mix.json; --flags prints the -D options tools/microbench/valu_issue.hip is
 compiled with so that it measures the issue ceiling of EACH kernel's own mix (the shade kernel was held against the
 traversal's ceiling and came out above 1)."""
 import json, os, re, subprocess, sys, collections
@@ -11,7 +11,7 @@ KERNELS = [
     ("connect", "_Z12rp_k_connectILb0ELb0ELb1EE"),
     ("shade_first_lambert", "_Z10rp_k_shadeILi1ELb1ELb0ELb0ELb0EE"), ("shade_lambert", "_Z10rp_k_shadeILi1ELb0ELb0ELb0ELb0EE"),
     ("shade_first_gltf_lights", "_Z10rp_k_shadeILi0ELb1ELb1ELb0ELb0EE"), ("shade_gltf_lights", "_Z10rp_k_shadeILi0ELb0ELb1ELb0ELb0EE"),
-    ("tail_lambert", "_Z9rp_k_tailILi1ELb0ELb0ELb0ELb1ELb0EE"), ("frame_lambert", "_Z10rp_k_frameILi1ELb0ELb0ELb0ELb1ELb0EE"),
+    ("tail_lambert", "_Z9rp_k_tailILi1ELb0ELb0ELb0ELb1ELb0EE"),
     ("resolve", "_Z12rp_k_resolve"),
 ]
 CLASSES = ["fma", "int", "pk", "cvt", "minmax", "cnd", "cmp", "trans", "mullo", "lane"]
@@ -83,7 +83,7 @@ def main():
                                  "mix_of_96": cnt, "top_opcodes": dict(ops.most_common(12))}
         rows.append((label, [cnt[c] for c in CLASSES]))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    json.dump(doc, open(os.path.join(ROOT, "profiles", "r04_kernel_mix.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(ROOT, "profiles", "r05_kernel_mix.json"), "w"), indent=1)
     # tools/microbench/kmix_gen.h: one loop body per kernel, the classes interleaved evenly (a run of one class would measure that
     # class's back-to-back behaviour, e.g. v_cndmask on one mask register, not the mix)
     macro = {"fma": "I_FMA", "int": "I_ADDU", "pk": "I_PKFMA", "cvt": "I_CVT", "minmax": "I_MIN3", "cnd": "I_CND", "cmp": "I_CMP", "trans": "I_RCP",
