@@ -399,7 +399,10 @@ int main(int argc, char **argv) {
         if (!got_variant && base.variant >= 0) variant = base.variant;
         if (upscale >= 1) base.params.render_upscale_factor = upscale;
         if (frames_in_flight == 1) synchronous = true; // (one frame context: nothing to overlap)
-        rptr::RenderGroup backend(devices, stripe_rows, std::max(frames_in_flight, (int)rptr::RenderHip::MAX_SWAP_BUFFERS));
+        // frame contexts: the reference's two swap buffers; what --frames-in-flight asks for; four for a queued --validation accumulation
+        // (its launch sequences are independent of the display: the deeper queue is what fills the GPU)
+        const int contexts = std::max(frames_in_flight, (validation && !synchronous && !freeze_frame) ? 4 : (int)rptr::RenderHip::MAX_SWAP_BUFFERS);
+        rptr::RenderGroup backend(devices, stripe_rows, contexts);
         backend.initialize(width, height);
         backend.set_scene(scene.desc());
         base.params.batch_spp = batch_spp;
@@ -444,11 +447,11 @@ int main(int argc, char **argv) {
 
         if (validation) {
             int accumulated = 0;
-            double gpu_ms = 0.0;
+            double gpu_ms = 0.0, image_ms = 0.0; // (image_ms: read-back + file)
             const auto v0 = std::chrono::steady_clock::now();
             // The frames of an accumulation are independent launch chains that only meet in the running mean: they are queued as launch
             // sequences of up to 16 samples (rptr_hip_render_batch_async, reset_rest = 0: frame k continues the accumulation of frame k - 1;
-            // every frame bit-identical to the frame rendered on its own) with two sequences in flight, and collected in order -- the images
+            // every frame bit-identical to the frame rendered on its own) with four sequences in flight, and collected in order -- the images
             // are written at the same sample counts, with the same bits, as by the loop of synchronous frames below (--synchronous; a frozen
             // frame repeats its samples and cannot share a sequence).
             if (!synchronous && !freeze_frame && (backend.size() == 1 || !every_frame)) { // (a group's gather assembles the LAST frame of a sequence)
@@ -467,7 +470,11 @@ int main(int argc, char **argv) {
                         const rptr::RenderStats st = backend.collect_frame(p.q, k);
                         accumulated = st.spp;
                         gpu_ms += st.render_time;
-                        if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
+                        if (accumulated >= target_spp || every_frame) {
+                            const auto w0 = std::chrono::steady_clock::now();
+                            save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
+                            image_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                        }
                     }
                 };
                 while (submitted < total_frames) {
@@ -475,7 +482,7 @@ int main(int argc, char **argv) {
                     cfg.reset_accumulation = submitted == 0;
                     queue.push_back({backend.submit(cfg, batch_spp, n, /*reset_rest=*/false), submitted});
                     submitted += n;
-                    if (queue.size() >= 2) collect_one();
+                    if ((int)queue.size() >= contexts) collect_one();
                 }
                 while (!queue.empty()) collect_one();
             }
@@ -484,9 +491,16 @@ int main(int argc, char **argv) {
                 cfg.reset_accumulation = false;
                 accumulated = freeze_frame ? accumulated + batch_spp : st.spp; // (a frozen frame repeats its samples: the application counts, app_state.cpp)
                 gpu_ms += st.render_time;
-                if (accumulated >= target_spp || every_frame) save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
+                if (accumulated >= target_spp || every_frame) {
+                    const auto w0 = std::chrono::steady_clock::now();
+                    save_image(backend, format, validation_prefix, accumulated, "", width, height, img);
+                    image_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                }
             }
-            std::printf("%s: wall %.3f ms\n", backend.name().c_str(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - v0).count());
+            {
+                const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - v0).count();
+                std::printf("%s: wall %.3f ms rendering + %.3f ms images (read-back and files)\n", backend.name().c_str(), wall - image_ms, image_ms);
+            }
             std::printf("%s: %d spp in %.3f ms GPU time -> %s_%04d.%s\n", backend.name().c_str(), accumulated, gpu_ms, validation_prefix.c_str(), accumulated,
                         format == FORMAT_PFM ? "pfm" : format == FORMAT_PNG ? "png" : "exr");
             return 0;

@@ -576,7 +576,7 @@ def test_partially_flattened_scene_with_a_dynamic_mesh(fif, monkeypatch):
         return out
 
     part, two = run(None), run(0)
-    assert part["records"] == 1 + len(dyn_insts) + len(s.instances) and not part["flat_flag"] and two["records"] < part["records"]
+    assert part["records"] == 1 + len(dyn_insts) + len(s.instances) and not part["flat_flag"] and not two["flat_flag"]
     assert part["rebuilds"] >= 1 and two["rebuilds"] >= 1
     for a, b in zip(part["hits"], two["hits"]):
         ids_a, ids_b = a[:, 2:].view(np.int32), b[:, 2:].view(np.int32)
