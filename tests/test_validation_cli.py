@@ -883,6 +883,35 @@ def test_compare_tool_reads_piz_compressed_validation_images(tmp_path):
         assert r.returncode == 255 and "isn't the same" in r.stderr
 
 
+def test_compare_tool_refuses_corrupt_piz_streams_without_crashing(tmp_path):
+    """the PIZ decoder (host/read_image.hpp) on streams that are not what an encoder wrote -- a file cut off inside a block, a
+    block whose Huffman table / bitmap / code stream has flipped bytes, a block length that points beyond the file: the tool must end with
+    its error exit code (255: unreadable or different), never with a signal, never hang"""
+    import glob
+    exe = _build_compare(tmp_path)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "piz")
+    rng = np.random.default_rng(7)
+    n_runs = 0
+    for path in sorted(glob.glob(os.path.join(gold, "*.exr"))):
+        raw = open(path, "rb").read()
+        variants = {"cut_half": raw[:len(raw) // 2], "cut_tail": raw[:len(raw) - 7]}
+        for k in range(12):   # flipped bytes at random places behind the header (offset table, block headers, tables, code streams)
+            b = bytearray(raw)
+            lo = min(len(b) - 1, 400)
+            for _ in range(1 + k % 4):
+                i = int(rng.integers(lo, len(b)))
+                b[i] ^= int(rng.integers(1, 256))
+            variants["flip%d" % k] = bytes(b)
+        variants["zeros"] = raw[:300] + bytes(len(raw) - 300)
+        for name, data in variants.items():
+            bad = str(tmp_path / (name + ".exr"))
+            open(bad, "wb").write(data)
+            r = subprocess.run([exe, path, bad], capture_output=True, text=True, timeout=60)
+            assert r.returncode in (0, 255), (path, name, r.returncode, r.stderr[-200:])   # (0: the flip hit padding or an unused table entry)
+            n_runs += 1
+    assert n_runs >= 40
+
+
 @pytest.mark.gpu
 def test_validation_images_through_the_compare_tool(tmp_path):
     """the reference's regression workflow end to end: two --validation runs of the same configuration compare equal (exit 0), a run with
