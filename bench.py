@@ -38,6 +38,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # up to 11 frame contexts + th
 RAY_BYTES = 32      # ray_o + ray_d (2 x float4) read per query
 HIT_BYTES = 8       # hit_ids (int2: instance, triangle) written per closest query, read per shaded vertex
 HIT_TUV_BYTES = 16  # ... + hit_tuv (float4) for a query that hits (round 5: a miss stores and loads no t / u / v)
+FIRST_RAY_BYTES = 16  # round 5: the first extend stores the camera ray's direction + generator state (ray_d), the first shade loads it
 QUEUE_BYTES = 4     # path id read from the ray queue (not for the first bounce: its queue is computed)
 NODE_BYTES = 64     # RptrBvh4Node (an instance record, 128 B, counts as two)
 TRI_BYTES = 48      # RptrBvhTri
@@ -821,18 +822,18 @@ def main():
     # ---- roofline of the dominant kernel: rp_k_extend (closest-hit BVH4 traversal), rank 0's share.
     # All durations below are EXCLUSIVE: HIP events on the dispatch packets of frames rendered one at a time (nothing else on the GPU).
     primary = r.local_pixel_count() * spp  # the first launch computes its camera rays and its queue instead of reading them
-    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt_ext["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES)
+    ext_bytes = (cnt_ext["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + cnt_ext["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES - FIRST_RAY_BYTES)
                  + cnt_ext["nodes_closest"] * NODE_BYTES + cnt_ext["tris_closest"] * TRI_BYTES)
     con_bytes = (cnt_con["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt_con["nodes_shadow"] * NODE_BYTES
                  + cnt_con["tris_shadow"] * TRI_BYTES)
     shade_vertices = cnt_ext["rays_closest"]       # one shade invocation per closest-hit query of the stand-alone bounces
-    shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES)
+    shade_bytes = (shade_vertices * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES) - primary * (QUEUE_BYTES + PATH_READ_BYTES - FIRST_RAY_BYTES)
                    + cnt_ext["hits"] * (HIT_TUV_BYTES + VERTEX_BYTES + MATERIAL_BYTES))
     # all bounces of a frame (the tail kernel's included), counted on the instrumented frame
-    total_alg_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + 2 * cnt["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES) + cnt["nodes_closest"] * NODE_BYTES
+    total_alg_bytes = (cnt["rays_closest"] * (QUEUE_BYTES + RAY_BYTES + HIT_BYTES) + 2 * cnt["hits"] * HIT_TUV_BYTES - primary * (RAY_BYTES + QUEUE_BYTES - FIRST_RAY_BYTES) + cnt["nodes_closest"] * NODE_BYTES
                        + cnt["tris_closest"] * TRI_BYTES + cnt["rays_shadow"] * (QUEUE_BYTES + RAY_BYTES + SHADOW_RESULT_BYTES) + cnt["nodes_shadow"] * NODE_BYTES
                        + cnt["tris_shadow"] * TRI_BYTES + cnt["rays_closest"] * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES)
-                       - primary * (QUEUE_BYTES + PATH_READ_BYTES) + cnt["hits"] * (VERTEX_BYTES + MATERIAL_BYTES) + r.local_pixel_count() * (16 * spp + 36))
+                       - primary * (QUEUE_BYTES + PATH_READ_BYTES - FIRST_RAY_BYTES) + cnt["hits"] * (VERTEX_BYTES + MATERIAL_BYTES) + r.local_pixel_count() * (16 * spp + 36))
     wkey = workload_key(args, world)
     pmc = load_pmc_traffic(wkey)   # the committed counter passes of THIS workload (profiles/pmc_traffic.json), None for anything else
     n_launch = max(launches_extend, 1)

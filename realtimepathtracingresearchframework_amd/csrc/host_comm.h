@@ -530,7 +530,13 @@ int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames) {
     const float4 *src = nullptr;
     FrameCtx *owner = nullptr;
     int rc = comm_begin(h, src, owner, nb);
-    if (rc) return rc;
+    if (rc) {
+        // (COMM_IPC: the ranks count their gathers themselves. A rank that cannot take part in gather g -- a caller error on this rank only --
+        // still counts it, so that gather g + 1 means the same slot and the same flag values on every rank again; rank 0's wait for this
+        // rank's part of gather g times out and is reported, csrc/host_comm.h comm_ipc_check)
+        if (h->comm && h->comm->transport == COMM_IPC) h->comm->gathers++;
+        return rc;
+    }
     if (h->comm->transport == COMM_IPC) {
         RptrComm *c = h->comm;
         if (!c->ipc_flags || !c->ipc_frame[0]) return fail(h, RPTR_E_INVALID, "rptr_hip_comm_ipc_init has not been called on this handle");

@@ -157,6 +157,16 @@ RP_DEV bool rp_primary_ray(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir, V3
     return rp_primary_ray_ex<TABLE>(f, p, rng, dir, lx, ly, sslot, origin);
 }
 
+// Round 5: the first extend STORES the camera ray's direction and generator state (ray_d[p], 16 bytes) and the first shade loads them instead
+// of making the camera ray a second time (generator seeding, the pixel jitter, an IEEE normalisation, the tile -> pixel arithmetic: ~150 of the
+// 910 instructions a first-bounce shade wave executes; the pipeline is bound by instruction issue, HBM carries 0.17 of its peak) -- the same
+// float bits either way. Not for table point sets (TABLE: the generator's other fields would have to travel too). -DRP_FIRST_RAY_STORED=0: as before.
+#ifndef RP_FIRST_RAY_STORED
+#define RP_FIRST_RAY_STORED 1
+#endif
+// hit_ids.x of a slot of the first queue that names no pixel sample (tile padding): neither a hit nor a miss
+#define RP_HIT_PADDING (-2)
+
 // ------------------------------------------------------------------ extend (closest hit), persistent waves
 // FIRST: bounce 0, the rays are the camera rays (computed, not loaded)
 // ALPHA: the scene has alpha-tested materials. The test of a candidate may draw from the path's generator
@@ -176,10 +186,11 @@ RP_DEV void rp_extend_body(const RpScene &sc, const RpFrame &f, const RpPathStat
         if (FIRST) {
             RpRng rng;
             rd = v3(0.0f, 0.0f, 1.0f);
-            if (!rp_primary_ray<TABLE>(f, p, rng, rd, ro)) { // tile padding: no such pixel sample. A miss is recorded (the regrouping pass reads it)
-                ps.hit_ids[p] = make_int2(-1, -1);
+            if (!rp_primary_ray<TABLE>(f, p, rng, rd, ro)) { // tile padding: no such pixel sample (the first shade's regrouping pass skips it)
+                ps.hit_ids[p] = make_int2(RP_HIT_PADDING, -1);
                 return false;
             }
+            if (RP_FIRST_RAY_STORED && !TABLE) ps.ray_d[p] = f4(rd, __uint_as_float(rng.s)); // (an alpha test that draws from the generator stores its new state in done())
             tmin = 0.0f;
             tmax = 2.e32f;
             if (ALPHA) lane_rng = (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) ? rng.s : rp_alpha_seed(f, p);
@@ -381,12 +392,14 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
 #pragma unroll 1
         for (uint32_t kk = 0; kk < RP_CHUNK / 256; ++kk) {
             const uint32_t i = chunk * RP_CHUNK + kk * 256 + threadIdx.x;
-            const bool valid = i < n;
+            bool valid = i < n;
             uint32_t pp = 0;
             bool is_hit = false;
             if (valid) {
                 pp = (FIRST && !order) ? i : order[i];
-                is_hit = ps.hit_ids[pp].x >= 0;
+                const int hx = ps.hit_ids[pp].x;
+                is_hit = hx >= 0;
+                if (FIRST && hx == RP_HIT_PADDING) valid = false; // tile padding of the first queue: no pixel sample
             }
             const uint32_t ah = rp_wave_append(&s_nhit, valid && is_hit);
             if (valid && is_hit) s_list[ah] = pp;
@@ -463,13 +476,35 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
             V3 first_du_dv[2] = {v3s(0.f), v3s(0.f)}; // FIRST && TEX: the image-plane axes of the path's camera
             if (present) {
                 p = il < chunk_hits ? s_list[il] : s_list[RP_CHUNK - 1 - (il - chunk_hits)];
-                // bounce 0: the camera ray again; ids of tile padding name no pixel sample (the first queue is the identity)
-                if (FIRST) present = rp_primary_ray_ex<TABLE>(f, p, rng, ray_dir, first_lx, first_ly, first_sslot, ray_origin, TEX ? first_du_dv : nullptr);
+                // bounce 0: the camera ray -- as the first extend stored it (direction, generator state; the origin is the frame's camera), or made
+                // again (table point sets). Ids of tile padding were dropped by the regrouping pass.
+                if (FIRST && RP_FIRST_RAY_STORED && !TABLE) {
+                    const float4 rd4 = ps.ray_d[p];
+                    ray_dir = xyz(rd4);
+                    rng.s = __float_as_uint(rd4.w);
+                    first_sslot = rp_div(p, f.div_npix_padded);
+                    ray_origin = ld3(f.cam_pos);
+                    const bool need_pixel = f.aov_albedo_roughness != nullptr; // (the AOV images are written by the first sample of the frame)
+                    if (f.per_frame_cams != 0 || TEX) {
+                        const RpSlotFrame sf0 = rp_slot_frame(f, first_sslot);
+                        V3 du = ld3(f.cam_du), dv = ld3(f.cam_dv);
+                        if (f.per_frame_cams != 0) {
+                            const RpCam &cm = f.cams[min(sf0.frame, (uint32_t)(RP_BATCH_CAMS - 1))];
+                            ray_origin = ld3(cm.pos);
+                            du = ld3(cm.du);
+                            dv = ld3(cm.dv);
+                        }
+                        first_du_dv[0] = du;
+                        first_du_dv[1] = dv;
+                    }
+                    if (need_pixel) (void)rp_slot_to_local(f, p - first_sslot * uint32_t(f.npix_padded), first_lx, first_ly);
+                } else if (FIRST)
+                    present = rp_primary_ray_ex<TABLE>(f, p, rng, ray_dir, first_lx, first_ly, first_sslot, ray_origin, TEX ? first_du_dv : nullptr);
             }
             if (present) {
                 my_closest++;
                 if (FIRST) { // init_shading_sample_state (shading_interface.glsl:20-22)
-                    if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM))
+                    if (f.alpha_test && (!TABLE || f.rng_variant == RPTR_RNG_VARIANT_UNIFORM) && !(RP_FIRST_RAY_STORED && !TABLE))
                         rng.s = (reinterpret_cast<const uint32_t *>(ps.ray_d))[4u * p + 3u]; // alpha tests of the first extend may have drawn from it
                     if (f.aov_albedo_roughness) { // the first sample of the (last) frame (of the batch) writes the AOVs
                         const RpSlotFrame sf = rp_slot_frame(f, first_sslot);
