@@ -144,6 +144,7 @@ int main(int argc, char **argv) {
     bool freeze_frame = false, got_batch_spp = false, got_variant = false;
     int rng_variant = -1, force_bvh_rebuild = -1, rebuild_triangle_budget = -1; // -1: as the configuration files say
     std::string bn_table_path, dump_scene_path, sky_data;
+    bool got_frames_per_launch = false;
     int upscale = 0, stripe_rows = 8, frames_in_flight = 0, frames_per_launch = 1; // frames_in_flight 0: the reference's loop (two swap buffers)
     bool synchronous = false, fly_through = false;
     std::vector<int> devices{0};
@@ -174,7 +175,7 @@ int main(int argc, char **argv) {
         else if (a == "--profiling-frames") { // the reference's old spelling of --profiling-fps (cmdline.cpp:397-403)
             need(1); profiling_fps = (float)std::atof(argv[++i]); if (profiling_fps <= 1) profiling_fps = 1; have_profiling_options = true; }
         else if (a == "--frames-in-flight") { need(1); frames_in_flight = std::max(1, std::min(16, std::atoi(argv[++i]))); }   // (this host's: the pipelined schedule of bench.py)
-        else if (a == "--frames-per-launch") { need(1); frames_per_launch = std::max(1, std::min(8, std::atoi(argv[++i]))); }
+        else if (a == "--frames-per-launch") { need(1); frames_per_launch = std::max(1, std::min(8, std::atoi(argv[++i]))); got_frames_per_launch = true; }
         else if (a == "--synchronous") synchronous = true;   // AppState::synchronous_rendering ("force synchronous rendering", libapp/app_state.cpp:145)
         else if (a == "--fly-through") fly_through = true;   // (this host's: bench.py's camera path)
         else if (a == "--profiling-count") { need(1); profiling_frames = std::atoi(argv[++i]); have_profiling_options = true; } // (this host's: frames of a run without keyframes)
@@ -456,7 +457,7 @@ int main(int argc, char **argv) {
             // frame repeats its samples and cannot share a sequence).
             if (!synchronous && !freeze_frame && (backend.size() == 1 || !every_frame)) { // (a group's gather assembles the LAST frame of a sequence)
                 const int total_frames = (target_spp + batch_spp - 1) / batch_spp;
-                const int per_seq = std::max(1, std::min(8, 16 / std::max(1, batch_spp)));
+                const int per_seq = got_frames_per_launch ? frames_per_launch : std::max(1, std::min(8, 16 / std::max(1, batch_spp)));
                 struct Pending {
                     rptr::RenderGroup::Sequence q;
                     int first_frame;
