@@ -2631,6 +2631,7 @@ static int finish_frame(rptr_hip *h, FrameCtx &c, RptrStats *out_stats, int whic
         fprintf(stderr, "[RP_PROF] time: node %.3g leaf+done %.3g refill %.3g | per phase: tri lanes %.2f (in %.2f of phases) instance lanes %.2f (in %.2f of phases)\n",
                 double(pr[0]), double(pr[4]), double(pr[8]), double(pr[9]) / double(pr[3] ? pr[3] : 1), double(pr[11]) / double(pr[3] ? pr[3] : 1),
                 double(pr[10]) / double(pr[3] ? pr[3] : 1), double(pr[12]) / double(pr[3] ? pr[3] : 1));
+        fprintf(stderr, "[RP_PROF] leaf items: %llu triangle leaves, %llu instance entries (lane counts; per ray: divide by the frame's ray count)\n", pr[9], pr[10]);
         fprintf(stderr, "[RP_PROF] node iterations on the generic stack path (some lane within 3 entries of the end of its LDS stack): %.4f\n",
                 double(pr[13]) / double(pr[1] ? pr[1] : 1));
     }
