@@ -752,11 +752,16 @@ def main():
     # sees it and it says nothing about clocks under load); and, for comparison, the same with a camera that stands still
     sustained, static_leg = None, None   # (after the latency legs: they are taken on a GPU that has just finished the timed region, as in rounds 1-3)
     if args.sustained_seconds > 0 and world == 1:
+        # ONE uninterrupted run of the schedule (its length from the timed region's rate), not chunks: every call of timed_steps drains
+        # the queue at its end, and a chunk of 8 frames with 7 in flight (C5) was mostly fill and drain (round 5: "sustained" 3.2 ms
+        # against 2.75 timed for that reason alone)
+        est_ms = max(elapsed * 1e3 / max(args.steps, 1), 1e-3)
         chunk = max(batch_frames * fif, 8)
         n_s, t_s = 0, time.perf_counter()
-        while time.perf_counter() - t_s < args.sustained_seconds:
-            timed_steps(chunk, lambda st: None)
-            n_s += chunk
+        while n_s == 0 or time.perf_counter() - t_s < 0.9 * args.sustained_seconds:
+            n_run = max(chunk, int((args.sustained_seconds - (time.perf_counter() - t_s)) * 1e3 / est_ms) // batch_frames * batch_frames)
+            timed_steps(n_run, lambda st: None)
+            n_s += n_run
         torch.cuda.synchronize()
         dt = time.perf_counter() - t_s
         sustained = {"ms_per_step": round(dt * 1e3 / n_s, 4), "steps": n_s, "seconds": round(dt, 3)}
@@ -765,9 +770,10 @@ def main():
             timed_steps(chunk, lambda st: None)
             torch.cuda.synchronize()
             n_c, t_c = 0, time.perf_counter()
-            while time.perf_counter() - t_c < min(0.5, args.sustained_seconds):
-                timed_steps(chunk, lambda st: None)
-                n_c += chunk
+            while n_c == 0 or time.perf_counter() - t_c < 0.9 * min(0.5, args.sustained_seconds):
+                n_run = max(chunk, int((min(0.5, args.sustained_seconds) - (time.perf_counter() - t_c)) * 1e3 / est_ms) // batch_frames * batch_frames)
+                timed_steps(n_run, lambda st: None)
+                n_c += n_run
             torch.cuda.synchronize()
             static_leg = {"ms_per_step": round((time.perf_counter() - t_c) * 1e3 / n_c, 4), "steps": n_c,
                           "what": "the same schedule with ONE camera for all frames (what rounds 1-3 timed)"}
