@@ -27,6 +27,7 @@ struct abi_vec4 { float v[4]; };
 #include "rendering/pathspace.h"
 #include "rendering/pointsets/bn_data.h"
 #include "rendering/pointsets/sobol_data.h"
+#include "librender/halton.h" // the (2, 3) Halton table behind view_params.screen_jitter (vulkan/render_vulkan.cpp:2917-2926)
 
 static std::string g_json;
 static void put(const char *k, double v) {
@@ -97,6 +98,13 @@ extern "C" const char *ref_abi_json() {
         put("texture_handle_1234_2", (double)h);
         put("texture_handle_id", (double)GET_TEXTURE_ID(h));
         put("texture_handle_channel", (double)GET_TEXTURE_CHANNEL(h));
+    }
+    for (int k = 0; k < 16; ++k) { // the 16 entries the jitter cycles through
+        char key[32];
+        snprintf(key, sizeof(key), "halton_23_%d_x", k);
+        put(key, (double)halton_23[k][0]);
+        snprintf(key, sizeof(key), "halton_23_%d_y", k);
+        put(key, (double)halton_23[k][1]);
     }
     g_json += "}";
     return g_json.c_str();

@@ -173,6 +173,11 @@ def test_boundary_structs_and_constants_against_the_references_headers():
         assert define("RPTR_RNG_VARIANT_" + k) == getattr(abi, "RNG_VARIANT_" + k) == ref["RNG_VARIANT_" + k]
     for k in ("NOALPHA", "ONESIDED", "VOLUME", "EXTENDED"):
         assert define("RPTR_BASE_MATERIAL_" + k) == ref["BASE_MATERIAL_" + k]
+    # the (2, 3) Halton table of the raster-TAA jitter (librender/halton.h compiled where it lies) against the oracle's regenerated one
+    import oracle_lib as O
+    for k in range(16):
+        h = O.halton23(k)
+        assert h[0] == np.float32(ref["halton_23_%d_x" % k]) and h[1] == np.float32(ref["halton_23_%d_y" % k]), k
     assert define("RPTR_SOBOL_TABLE_BYTES") == abi.SOBOL_TABLE_BYTES == ref["sizeof_SobolData"]
     assert ref["offsetof_SobolData_tile_invert_1_0"] == 1024 * 32 * 4
     assert define("RPTR_BN_TABLE_MIN_BYTES") == abi.BN_TABLE_MIN_BYTES == ref["offsetof_BNData_tile_scrambling_yx_d_4spp"]     # the 1 spp prefix of BNData

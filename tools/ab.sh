@@ -7,6 +7,6 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); s=d['roofline']['stage_ms_per_step']
-        print('%-40s ms/step %.3f  Mrays/s %.0f | one frame at a time: total %.3f extend %.3f connect %.3f shade %.3f tail %.3f resolve %.3f' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['gpu_total'], s['extend'], s['connect'], s['shade'], s['tail'], s['resolve']))
+        print('%-40s ms/step %.3f  Mrays/s %.0f | one frame at a time: total %.3f extend %.3f connect %.3f shade %.3f tail %.3f resolve %.3f | latency 1 / 2 in flight %.3f / %s' % ('$(basename $lib)', d['ms_per_step'], d['value'], s['gpu_total'], s['extend'], s['connect'], s['shade'], s['tail'], s['resolve'], d['roofline']['latency']['1']['ms_per_frame'], (d['roofline']['latency'].get('2') or {}).get('ms_per_frame')))
 "
 done
