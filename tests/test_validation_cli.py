@@ -217,7 +217,8 @@ def test_validation_accumulates_in_launch_sequences_with_the_bits_of_synchronous
     W, H = 120, 72
     for batch_spp, target in ((1, 37), (3, 30)):
         outs = {}
-        for mode, extra in (("queued", []), ("sync", ["--synchronous"])):
+        # ("short": --frames-per-launch 2 --frames-in-flight 6, launch sequences of two frames with six in flight)
+        for mode, extra in (("queued", []), ("sync", ["--synchronous"]), ("short", ["--frames-per-launch", "2", "--frames-in-flight", "6"])):
             prefix = str(tmp_path / ("val_%s_%d" % (mode, batch_spp)))
             p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", str(target), "--batch-spp", str(batch_spp), "--img", str(W), str(H), "--pfm",
                                 "--every-frame"] + extra, capture_output=True, text=True)
@@ -228,6 +229,8 @@ def test_validation_accumulates_in_launch_sequences_with_the_bits_of_synchronous
         for k in counts:
             a, b = read_pfm("%s_%04d.pfm" % (outs["queued"], k)), read_pfm("%s_%04d.pfm" % (outs["sync"], k))
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (batch_spp, k)
+            c = read_pfm("%s_%04d.pfm" % (outs["short"], k))
+            assert np.array_equal(c.view(np.uint32), b.view(np.uint32)), ("frames per launch 2", batch_spp, k)
 
 
 def test_cli_rejects_bad_mode_combinations(tmp_path):
