@@ -430,7 +430,9 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   key                      default   takes effect      meaning                                                                   environment
  *   flatten                  -1        set_scene         -1 / 1: a static scene with >= 2 instances (no RPTR_MESH_DYNAMIC mesh) is   RPTR_FLATTEN
  *                                                        built as ONE world-space tree (~150 bytes per instanced triangle; 1.5 x
- *                                                        faster to trace than instance records); 0: always two-level
+ *                                                        faster to trace than instance records; hits are found on the pre-transformed
+ *                                                        triangles: t / u / v agree with the instance walk to rounding, not bit for
+ *                                                        bit); 0: always two-level
  *   flatten_max_tris         1 << 26   set_scene         ... up to this many instanced triangles                                   RPTR_FLATTEN_MAX_TRIS
  *   bvh_builder              0         set_scene         0 auto, 1 host (binned SAH), 2 device (PLOC) for static trees             RPTR_BVH_BUILDER=auto|host|device
  *   device_build_min_tris    2 << 20   set_scene         auto: triangle sets of at least this size are built on the device        RPTR_DEVICE_BUILD_MIN_TRIS
