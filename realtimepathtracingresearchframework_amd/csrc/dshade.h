@@ -187,17 +187,31 @@ RP_DEV RpSlotFrame rp_slot_frame(const RpFrame &f, uint32_t sslot) {
 }
 #endif
 
-// local tiled slot -> local pixel; false for padding lanes
+// local tiled slot -> local pixel; false for padding lanes. Tiles are numbered in BLOCKS of RP_TILE_BLOCK x RP_TILE_BLOCK (RpFrame::tiles_x / tiles_y are
+// multiples of it, div_tiles_x divides by tiles_x / RP_TILE_BLOCK). 2 x 2 (round 5): the four consecutive tiles a traversal wave takes as one pool
+// are a 16 x 16 pixel square instead of a 32 x 8 strip -- its rays share more of the tree: closest-hit launches -2...4 % (C2, C3, C5), a
+// 1/8 frame's -10 %, one frame at a time 1.86 -> 1.80 ms; 4 x 4 blocks (with or without Z order inside) and 8 x 8: no better than row-major
+// (profiles/r05_notes.md section 17). -DRP_TILE_BLOCK=1: row-major tiles, rounds 1-5.
+#ifndef RP_TILE_BLOCK
+#define RP_TILE_BLOCK 2
+#endif
 RP_DEV bool rp_slot_to_local(const RpFrame &f, uint32_t slot, int &lx, int &ly) {
     uint32_t tile = slot >> 6, in = slot & 63u;
-    const uint32_t tyu = rp_div(tile, f.div_tiles_x);
-    int tx = int(tile - tyu * uint32_t(f.tiles_x)), ty = int(tyu);
+    const uint32_t blk = tile / uint32_t(RP_TILE_BLOCK * RP_TILE_BLOCK), t_in = tile % uint32_t(RP_TILE_BLOCK * RP_TILE_BLOCK);
+    const uint32_t by = rp_div(blk, f.div_tiles_x);
+    const uint32_t bx = blk - by * (uint32_t(f.tiles_x) / uint32_t(RP_TILE_BLOCK));
+    const uint32_t tix = t_in % uint32_t(RP_TILE_BLOCK), tiy = t_in / uint32_t(RP_TILE_BLOCK);
+    const int tx = int(bx * uint32_t(RP_TILE_BLOCK) + tix), ty = int(by * uint32_t(RP_TILE_BLOCK) + tiy);
     lx = tx * 8 + int(in & 7u);
     ly = ty * 8 + int(in >> 3);
     return lx < f.width && ly < f.local_rows;
 }
 RP_DEV uint32_t rp_local_to_slot(const RpFrame &f, int lx, int ly) {
-    return (uint32_t(ly >> 3) * uint32_t(f.tiles_x) + uint32_t(lx >> 3)) * 64u + uint32_t((ly & 7) * 8 + (lx & 7));
+    const uint32_t tx = uint32_t(lx >> 3), ty = uint32_t(ly >> 3);
+    const uint32_t blk = (ty / uint32_t(RP_TILE_BLOCK)) * (uint32_t(f.tiles_x) / uint32_t(RP_TILE_BLOCK)) + tx / uint32_t(RP_TILE_BLOCK);
+    const uint32_t t_in = (ty % uint32_t(RP_TILE_BLOCK)) * uint32_t(RP_TILE_BLOCK) + tx % uint32_t(RP_TILE_BLOCK);
+    const uint32_t tile = blk * uint32_t(RP_TILE_BLOCK * RP_TILE_BLOCK) + t_in;
+    return tile * 64u + uint32_t((ly & 7) * 8 + (lx & 7));
 }
 // local row -> frame row (stripe s of `stripe_rows` rows belongs to rank s % world)
 RP_DEV int rp_local_row_to_global(const RpFrame &f, int ly) {

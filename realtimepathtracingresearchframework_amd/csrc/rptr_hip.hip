@@ -1588,8 +1588,9 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->width = fb_width;
     h->height = fb_height;
     h->local_rows = local_row_count(fb_height, h->stripe_rows, h->rank, h->world);
-    h->tiles_x = (fb_width + 7) / 8;
-    h->tiles_y = (std::max(h->local_rows, 1) + 7) / 8;
+    // (8 x 8 pixel tiles, numbered in blocks of RP_TILE_BLOCK x RP_TILE_BLOCK: dshade.h rp_slot_to_local)
+    h->tiles_x = ((fb_width + 7) / 8 + RP_TILE_BLOCK - 1) / RP_TILE_BLOCK * RP_TILE_BLOCK;
+    h->tiles_y = ((std::max(h->local_rows, 1) + 7) / 8 + RP_TILE_BLOCK - 1) / RP_TILE_BLOCK * RP_TILE_BLOCK;
     h->npix_padded = h->tiles_x * h->tiles_y * 64;
     // sample slots in flight: as many as fit a ~6 GiB path-state budget per frame context (288 GB of HBM), at most 16
     const size_t bytes_per_path = 16 * 5 + 8 + 2 * 16 + 5 * 4;
@@ -2821,7 +2822,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     f.world = h->world;
     f.stripe_rows = h->stripe_rows;
     f.div_npix_padded = rp_make_div((uint32_t)h->npix_padded);
-    f.div_tiles_x = rp_make_div((uint32_t)h->tiles_x);
+    f.div_tiles_x = rp_make_div((uint32_t)(h->tiles_x / RP_TILE_BLOCK));
     f.div_stripe_rows = rp_make_div((uint32_t)h->stripe_rows);
     f.div_width = rp_make_div((uint32_t)h->width);
     f.num_bins = (h->num_lights + (h->lighting.bin_size - 1)) / h->lighting.bin_size;
