@@ -1000,6 +1000,7 @@ def main():
                    "bvh": {"built_on": "device (csrc/ploc.h)" if bvh_on_device else "host (csrc/bvh_build.cpp)", "acceleration_structure_step_ms": round(bvh_step_ms, 1),
                            "device_ms": round(bvh_device_ms, 2), "area_cost": round(bvh_area_cost, 1),
                            "traversal_thresholds": {"node_min": trav_node_min or 10, "refill_min": trav_refill_min or 48,
+                                                    "pool_entries": int(os.environ.get("RPTR_TRAVERSE_FETCH", "0")) or (256 if trav_node_min else 384),
                                                     "preset": "dense (area cost >= 24)" if trav_node_min else "default"}}},
         "roofline": roofline,
     }

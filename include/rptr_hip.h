@@ -459,6 +459,8 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   comm_priority            1         comm init         the communication stream has the highest stream priority                 RPTR_COMM_PRIORITY
  *   comm_self                0         comm init         diagnostic: rank 0's own rows travel through the transport too            RPTR_COMM_SELF
  *   quiet                    0         -                 no notes on stderr                                                        RPTR_QUIET
+ *   traverse_fetch           0         set_scene         queue entries a traversal wave takes per pool at most (multiple of 64);   RPTR_TRAVERSE_FETCH
+ *                                                        0: chosen with the thresholds above (384, dense trees 256)
  *   builder experiments (measured, not adopted; profiles/r03_notes.md): tlas_collapse, collapse (0 greedy, 1 even, 2 optimal; -1 per tree),
  *   presplit_density, presplit_budget_pct, host_ploc, ploc_top, ploc_leaf -- RPTR_TLAS_COLLAPSE, RPTR_COLLAPSE, RPTR_PRESPLIT=d[,b],
  *   RPTR_HOST_PLOC, RPTR_PLOC_TOP, RPTR_PLOC_LEAF. rptr_hip_option_count / rptr_hip_option_name enumerate the keys.

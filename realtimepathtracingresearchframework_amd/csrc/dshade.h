@@ -84,6 +84,8 @@ struct RpScene {
     int32_t lds_top;      // option "lds_top": launch the traversal instantiations that stage the top of the tree in LDS (k_extend.hip)
     int32_t flat_id_bias; // a world-space triangle of a flattened tree names instance record r = bias + instance id (1; partially flattened
                           // scenes: 1 + the number of instance records of the dynamic meshes)
+    int32_t fetch_max;    // option "traverse_fetch": queue entries a traversal wave takes per pool at most (dtraverse.h RP_FETCH), 0 = the compile-time default
+    int32_t _pad_fetch;
 };
 
 // Division of a 31-bit number by a frame constant (tiles per row, rows per stripe, padded pixels per sample slot) without the ~25

@@ -231,7 +231,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     // to the block's own waves, `cursor` is a word in LDS
     const uint32_t nwaves = LOCAL ? (blockDim.x >> 6) : (gstride >> 6);
     const uint32_t fetch =
-        LOCAL ? 64u : min((uint32_t)RP_FETCH, max(64u, ((n + nwaves * RP_FETCH_DIV - 1u) / (nwaves * RP_FETCH_DIV) + 63u) & ~63u));
+        LOCAL ? 64u : min(sc.fetch_max > 0 ? (uint32_t)sc.fetch_max : (uint32_t)RP_FETCH, max(64u, ((n + nwaves * RP_FETCH_DIV - 1u) / (nwaves * RP_FETCH_DIV) + 63u) & ~63u));
     uint32_t pool_next = ((LOCAL ? tid : (blockIdx.x * blockDim.x + tid)) >> 6) * fetch;
     uint32_t pool_end = min(n, pool_next + fetch);
     bool more = pool_next < n; // the shared cursor starts behind every static pool

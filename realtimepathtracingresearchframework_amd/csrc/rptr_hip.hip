@@ -134,7 +134,7 @@ enum RpOpt : int {
     OPT_FLATTEN, OPT_FLATTEN_MAX_TRIS, OPT_BVH_BUILDER, OPT_DEVICE_BUILD_MIN_TRIS, OPT_REBRAID, OPT_TLAS_COLLAPSE, OPT_COLLAPSE, OPT_PRESPLIT_DENSITY,
     OPT_PRESPLIT_BUDGET_PCT, OPT_HOST_PLOC, OPT_PLOC_TOP, OPT_PLOC_LEAF, OPT_TRAVERSE_NODE_MIN, OPT_TRAVERSE_REFILL_MIN, OPT_LDS_TOP, OPT_SINGLE_INSTANCE,
     OPT_MAX_BATCH_FRAMES, OPT_MAX_BATCH_SPP, OPT_PATH_BUDGET_MB, OPT_BLOCKS_PER_CU, OPT_SIDE_CONNECT, OPT_AOVS, OPT_TAIL_BOUNCE, OPT_TAIL_THRESHOLD,
-    OPT_STAGE_TIMING, OPT_REGROUP, OPT_COMM_TRANSPORT, OPT_COMM_PRIORITY, OPT_COMM_SELF, OPT_QUIET, OPT_COUNT
+    OPT_STAGE_TIMING, OPT_REGROUP, OPT_COMM_TRANSPORT, OPT_COMM_PRIORITY, OPT_COMM_SELF, OPT_QUIET, OPT_TRAVERSE_FETCH, OPT_COUNT
 };
 struct RpOptDesc {
     const char *key, *env; // env: atoll of the variable unless parse_option_env knows better (names, pairs)
@@ -171,6 +171,7 @@ static const RpOptDesc g_opt_desc[OPT_COUNT] = {
     {"comm_priority", "RPTR_COMM_PRIORITY", 1, 0, 1},
     {"comm_self", "RPTR_COMM_SELF", 0, 0, 1},
     {"quiet", "RPTR_QUIET", 0, 0, 1},
+    {"traverse_fetch", "RPTR_TRAVERSE_FETCH", 0, 0, 4096},        // queue entries a traversal wave takes per pool at most (multiple of 64); 0: per scene, with the thresholds
 };
 struct RpOptions {
     long long v[OPT_COUNT];
@@ -2145,6 +2146,10 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         h->master.dscene.node_min = std::max(0, std::min(64, node_min));
         h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
         h->master.dscene.lds_top = h->opt.v[OPT_LDS_TOP] != 0 ? 1 : 0;
+        // ... and the size of a wave's pool of queue entries (dtraverse.h RP_FETCH: 256, four tiles of the first queue): 384 for the trees
+        // of the default preset -- one frame at a time 1.82 -> 1.76 ms, two in flight 1.45 -> 1.38 on C2, pipelined unchanged --, 256 for dense
+        // ones (the forest loses 4 % with 384; profiles/r05_notes.md section 19)
+        h->master.dscene.fetch_max = h->opt.v[OPT_TRAVERSE_FETCH] > 0 ? (int)std::max(64ll, h->opt.v[OPT_TRAVERSE_FETCH] / 64 * 64) : (best_cost >= 24.0 ? 0 : 384);
     }
     // ---- one shading record per BVH triangle (dshade.h RpShadeTri), made on the device from what was just uploaded: per mesh with the
     // geometry records of the first parameterized mesh that uses it, or -- a flattened scene -- per triangle through the instance it names
