@@ -97,6 +97,7 @@ def parse_args():
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--rccl-probe", action="store_true", help="(internal) run as the probe child of a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-leg", type=int, default=0, help="(internal) run as the child that measures the latency leg with this many frames in flight")
     ap.add_argument("--dynamic-meshes", type=int, default=0,
                     help="mark the first k meshes of the scene RPTR_MESH_DYNAMIC (they are never moved): the forest with one dynamic tree mesh is the "
                          "partially flattened scene of round 5 (static instances in one world-space tree beside the dynamic mesh's instance records)")
@@ -472,6 +473,88 @@ def main():
     fif = max(2 if batch_frames > 1 else 1, min(fif, len(sequence_lengths(args.steps))))   # (a batch of frames needs two contexts: every frame keeps its image)
     if args.profile_pass:
         fif = 1   # frames one at a time, every launch at full size (what the exclusive figures of the JSON line measure, on their own handle)
+    cam = scene.camera_params()
+    anim = None
+    if args.animate:
+        # stand-in for the reference's animation compute shader: y = y0 + 0.5 sin(0.4 x + 2 pi t), written by a torch
+        # elementwise kernel on the same stream, then handed over device-to-device
+        g0 = scene.geometries[0]
+        base = torch.from_numpy(scenes.dequantize_positions(g0.qpos, g0.scaling, g0.offset)).cuda()
+        anim = {"base": base, "cur": base.clone(), "frame": 0, "refit_ms": 0.0, "ev": []}
+
+    def submit_on(handle, count=False):
+        if anim is not None:
+            t = 0.02 * anim["frame"]
+            anim["frame"] += 1
+            cur, b = anim["cur"], anim["base"]
+            torch.add(b[:, 1], torch.sin(b[:, 0] * 0.4 + 6.283185307179586 * t), alpha=0.5, out=cur[:, 1])
+            handle.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
+            handle.refit()
+        cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
+        return handle.render_async(cfg, spp=spp, count_traversal=count)
+
+    # ---- latency (SURVEY 8d: ms/frame = GPU time from the first stage launch to the resolve): frames ONE at a time, and TWO in flight
+    # -- what the reference's swap chain holds (RenderGraphic::MAX_SWAP_BUFFERS = 2, util/display/render_graphic.h:19). `value` above is
+    # the throughput of the pipelined schedule (config.frames_in_flight x frames_per_launch_sequence); these are the figures of an
+    # interactive host that cannot queue frames ahead.
+    def latency_of(handle, depth, n_frames):
+        handle.set_stage_timing(0)
+        # warm-up IN THIS MODE for a quarter of a second: a frame at a time leaves the GPU idle between launches, and what the clocks do then
+        # depends on what ran before (round 5: the same leg read 1.95 ms after a 40-step timed region and 1.75 after a 100-step one with two
+        # warm-up frames) -- an interactive host renders continuously, the steady state is the figure
+        t_w, n_w = time.perf_counter(), 0
+        while n_w < 2 or time.perf_counter() - t_w < 0.25:
+            handle.wait(submit_on(handle))
+            n_w += 1
+        torch.cuda.synchronize()
+        t_l, q, rays_l, gpu_l = time.perf_counter(), [], 0, 0.0
+        tails = {}   # stand-alone closest-hit launches of a frame (= the bounce its tail kernel took over at) -> frames
+        for k in range(n_frames + depth):
+            if k < n_frames:
+                q.append(submit_on(handle))
+            if len(q) >= depth or k >= n_frames:
+                if not q:
+                    break
+                stl = handle.wait(q.pop(0)).raw
+                rays_l += int(stl.rays_closest + stl.rays_shadow)
+                gpu_l += stl.render_time_ms
+                tails[int(stl.launches_extend)] = tails.get(int(stl.launches_extend), 0) + 1
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t_l) * 1e3 / n_frames
+        return {"frames_in_flight": depth, "ms_per_frame": round(wall, 4), "mrays_s": round(rays_l / n_frames / wall / 1e3, 1),
+                "gpu_ms_first_launch_to_resolve": round(gpu_l / n_frames, 4), "frames": n_frames,
+                "tail_from_bounce_frames": {str(k): v for k, v in sorted(tails.items())}}
+
+    # The latency legs run in a process of their own with ONE backend handle -- the state of the reference's application -- (N = 1; the
+    # children are started at the end, when this process has closed its handles). In this process, next to the main handle's 5-11 frame
+    # contexts and the handle of the exclusive passes, the same legs read 1.75 or 1.93 ms (one frame at a time) and 1.35 or 1.48 (two in
+    # flight) depending on nothing but how many handles and streams the process had made before (tools/latency_queues.py,
+    # profiles/r05_notes.md section 21: not shared hardware queues -- rocprofv3 shows the contexts on queues of their own --, but
+    # reproducible). N > 1 and the emulated split keep the in-process leg for one frame at a time, taken first.
+    n_lat = max(10, min(40, args.steps))
+    latency = {}
+
+    def latency_handle(depth):
+        rk, wd = (0, args.emulate_world) if args.emulate_world > 1 else (rank, world)
+        rl = backend.RenderHip(device_ordinal=local_rank, rank=rk, world_size=wd, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=depth, options=lib_options)
+        rl.initialize(W, H)
+        rl.set_scene(scene)
+        if args.animate and args.rebuild_budget != 0:
+            rl.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
+        return rl
+
+    if args.latency_leg > 0:  # the child: this leg and nothing else
+        rl = latency_handle(args.latency_leg)
+        print(json.dumps({"latency_leg": latency_of(rl, args.latency_leg, n_lat)}))
+        rl.close()
+        return
+    latency_in_children = world == 1 and args.emulate_world <= 1 and not args.profile_pass
+    if not args.profile_pass and not latency_in_children:
+        rl = latency_handle(1)
+        latency["1"] = latency_of(rl, 1, n_lat)
+        rl.close()
+        if anim is not None:
+            anim["frame"] = 0
     if args.emulate_world > 1:
         r = backend.RenderHip(device_ordinal=local_rank, rank=0, world_size=args.emulate_world, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=fif, options=lib_options)
     else:
@@ -484,7 +567,6 @@ def main():
     bvh_area_cost, trav_node_min, trav_refill_min = r.traversal_preset()
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
-    cam = scene.camera_params()
 
     def camera_of(k):
         """the view of frame k: a fly-through step per frame (yaw 0.002 rad, 2 cm sideways), so that consecutive frames differ the way an
@@ -549,14 +631,6 @@ def main():
             stage = torch.zeros_like(tgather.tile, device="cuda") if on_host else None  # device tile -> host tile
     my_bytes = r.local_pixel_count() * 16
     host_gather_s = [0.0]
-
-    anim = None
-    if args.animate:
-        # stand-in for the reference's animation compute shader: y = y0 + 0.5 sin(0.4 x + 2 pi t), written by a torch
-        # elementwise kernel on the same stream, then handed over device-to-device
-        g0 = scene.geometries[0]
-        base = torch.from_numpy(scenes.dequantize_positions(g0.qpos, g0.scaling, g0.offset)).cuda()
-        anim = {"base": base, "cur": base.clone(), "frame": 0, "refit_ms": 0.0, "ev": []}
 
     def animate():
         t = 0.02 * anim["frame"]
@@ -682,17 +756,6 @@ def main():
     if args.animate and args.rebuild_budget != 0:
         rx.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
 
-    def submit_on(handle, count=False):
-        if anim is not None:
-            t = 0.02 * anim["frame"]
-            anim["frame"] += 1
-            cur, b = anim["cur"], anim["base"]
-            torch.add(b[:, 1], torch.sin(b[:, 0] * 0.4 + 6.283185307179586 * t), alpha=0.5, out=cur[:, 1])
-            handle.update_vertices_device(0, cur.data_ptr(), cur.shape[0])
-            handle.refit()
-        cfg = backend.RenderConfiguration(cam, active_variant=variant, reset_accumulation=True)
-        return handle.render_async(cfg, spp=spp, count_traversal=count)
-
     def step_x(count=False):
         return rx.wait(submit_on(rx, count))
 
@@ -713,44 +776,9 @@ def main():
         serial["gpu"] += st.render_time_ms / n_serial
         serial_launches = int(st.launches_extend)
 
-    # ---- latency (SURVEY 8d: ms/frame = GPU time from the first stage launch to the resolve): frames ONE at a time, and TWO in flight
-    # -- what the reference's swap chain holds (RenderGraphic::MAX_SWAP_BUFFERS = 2, util/display/render_graphic.h:19). `value` above is
-    # the throughput of the pipelined schedule (config.frames_in_flight x frames_per_launch_sequence); these are the figures of an
-    # interactive host that cannot queue frames ahead.
-    def latency_of(handle, depth, n_frames):
-        handle.set_stage_timing(0)
-        for _ in range(2):
-            handle.wait(submit_on(handle))
-        torch.cuda.synchronize()
-        t_l, q, rays_l, gpu_l = time.perf_counter(), [], 0, 0.0
-        for k in range(n_frames + depth):
-            if k < n_frames:
-                q.append(submit_on(handle))
-            if len(q) >= depth or k >= n_frames:
-                if not q:
-                    break
-                stl = handle.wait(q.pop(0)).raw
-                rays_l += int(stl.rays_closest + stl.rays_shadow)
-                gpu_l += stl.render_time_ms
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t_l) * 1e3 / n_frames
-        return {"frames_in_flight": depth, "ms_per_frame": round(wall, 4), "mrays_s": round(rays_l / n_frames / wall / 1e3, 1),
-                "gpu_ms_first_launch_to_resolve": round(gpu_l / n_frames, 4), "frames": n_frames}
-
-    n_lat = max(10, min(40, args.steps))
-    latency = {}
-    for depth in ((1, 2) if (world == 1 and args.emulate_world <= 1) else (1,)):
-        rl = backend.RenderHip(device_ordinal=local_rank, rank=r.rank, world_size=r.world_size, stripe_rows=args.stripe_rows, stream=stream, frames_in_flight=depth, options=lib_options)
-        rl.initialize(W, H)
-        rl.set_scene(scene)
-        if args.animate and args.rebuild_budget != 0:
-            rl.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
-        latency[str(depth)] = latency_of(rl, depth, n_lat)
-        rl.close()
-
     # ---- sustained: the same schedule for at least --sustained-seconds more (the timed region of a 20-step run lasts 26 ms: no sampler
     # sees it and it says nothing about clocks under load); and, for comparison, the same with a camera that stands still
-    sustained, static_leg = None, None   # (after the latency legs: they are taken on a GPU that has just finished the timed region, as in rounds 1-3)
+    sustained, static_leg = None, None
     if args.sustained_seconds > 0 and world == 1:
         # ONE uninterrupted run of the schedule (its length from the timed region's rate), not chunks: every call of timed_steps drains
         # the queue at its end, and a chunk of 8 frames with 7 in flight (C5) was mostly fill and drain (round 5: "sustained" 3.2 ms
@@ -1022,7 +1050,7 @@ def main():
     # adapter host/render_hip.hpp over the C ABI, nothing of this Python file) with bench.py's camera path: (a) the reference's frame loop,
     # begin_frame / draw_frame / end_frame with a command stream = two swap buffers in flight (app.cpp:453-469, util/display/
     # render_graphic.h:19); (b) queued as deep as `value`'s schedule. VERDICT r4: "benchmark the drop-in".
-    if world == 1 and args.emulate_world <= 1 and not args.no_boundary and not args.animate and not args.static_camera:
+    if latency_in_children or (world == 1 and args.emulate_world <= 1 and not args.no_boundary and not args.animate and not args.static_camera):
         # (this process is done with the GPU: its handles go first -- their hardware queues with them: two processes with a dozen streams each
         # oversubscribe the GPU's queues and the driver time-slices them: 3.9 instead of 1.14 ms per frame for the child, measured)
         for hdl in (r, rx):
@@ -1031,6 +1059,17 @@ def main():
             except Exception:
                 pass
         torch.cuda.synchronize()
+    if latency_in_children:
+        import subprocess
+        for depth in (1, 2):
+            cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--latency-leg", str(depth), "--no-probe", "--no-cpu-baseline", "--no-boundary"]
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                line = [l for l in pr.stdout.splitlines() if l.startswith('{"latency_leg"')]
+                latency[str(depth)] = json.loads(line[-1])["latency_leg"] if line else {"note": "the child printed no result (rc %d): %s" % (pr.returncode, pr.stderr[-200:])}
+            except subprocess.TimeoutExpired:
+                latency[str(depth)] = {"note": "timed out"}
+    if world == 1 and args.emulate_world <= 1 and not args.no_boundary and not args.animate and not args.static_camera:
         out["boundary"] = boundary_leg(args, scene, W, H, spp, fif, batch_frames, ms_per_step)
 
     # ---- CPU baseline: the build's own scalar backend -- the oracle's sources (scalar BVH2 traversal + the
