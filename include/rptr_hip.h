@@ -413,8 +413,9 @@ int rptr_hip_set_freeze_frame(rptr_hip_t *h, int freeze_frame);
  * UNIFORM); the library keeps a device copy. Frames in flight are waited for; accumulation is not reset (the caller resets, as
  * the reference does when backend options change). A table that is too short, or a variant outside 0..3, fails with RPTR_E_INVALID. */
 int rptr_hip_set_rng_variant(rptr_hip_t *h, int rng_variant, const void *table, size_t table_bytes);
-/* hipEvent pairs recorded per frame for RptrStats.*_time_ms: 0 none (render_time_ms only), 1 around the closest-hit
- * traversal launches (extend_time_ms), 2 every stage (default; ~0.1 ms per 1080p frame of launch gaps). */
+/* hipEvent pairs recorded per frame for RptrStats.*_time_ms: 0 none (render_time_ms only; the default since round 5 -- the reference's
+ * RenderStats has nothing else), 1 around the closest-hit traversal launches (extend_time_ms), 2 every stage (~0.06 ms per 1080p frame
+ * rendered alone). */
 int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
 
 /* ---- Options: how the library builds and schedules, beyond RptrCreateInfo. The reference expresses such intent per mesh and per backend
@@ -449,11 +450,12 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   blocks_per_cu            0         initialize        persistent traversal blocks per CU; 0: occupancy, shared between the      RPTR_BLOCKS_PER_CU
  *                                                        frame contexts
  *   side_connect             -1        initialize        shadow rays of bounce b on a side stream beside the closest-hit rays of   RPTR_SIDE_CONNECT
- *                                                        b + 1; -1: on with ONE frame context, off with several
+ *                                                        b + 1; -1: with one frame context, and with two for a frame submitted
+ *                                                        while no other is in flight (a synchronous loop); off with more
  *   aovs                     1         initialize        AOV images (rptr_hip_readback_aov)                                        RPTR_AOVS
  *   tail_bounce              -1        next frame        bounce from which ONE launch finishes the frame; -1 adaptive, 0 never     RPTR_TAIL_BOUNCE
  *   tail_threshold           65536     next frame        adaptive: queue length below which a bounce goes to that launch           RPTR_TAIL_THRESHOLD
- *   stage_timing             2         next frame        = rptr_hip_set_stage_timing                                               RPTR_STAGE_TIMING
+ *   stage_timing             0         next frame        = rptr_hip_set_stage_timing                                               RPTR_STAGE_TIMING
  *   regroup_materials        0         next frame        shade orders the hits of a chunk by material id (measured: no gain)       RPTR_REGROUP
  *   comm_transport           0         comm init         0 auto (RCCL between devices), 1 rccl, 2 copy, 3 peer writes              RPTR_COMM_TRANSPORT=rccl|copy|peer
  *   comm_priority            1         comm init         the communication stream has the highest stream priority                 RPTR_COMM_PRIORITY

@@ -165,7 +165,7 @@ static const RpOptDesc g_opt_desc[OPT_COUNT] = {
     {"aovs", "RPTR_AOVS", 1, 0, 1},                               //                                                             [initialize]
     {"tail_bounce", "RPTR_TAIL_BOUNCE", -1, -1, RP_MAX_BOUNCES},  // -1 adaptive, 0 no tail kernel, k: from bounce k
     {"tail_threshold", "RPTR_TAIL_THRESHOLD", 65536, 0, 1 << 30},
-    {"stage_timing", "RPTR_STAGE_TIMING", 2, 0, 2},
+    {"stage_timing", "RPTR_STAGE_TIMING", 0, 0, 2},               // events per stage for RptrStats.*_time_ms: a diagnostic (level 2: ~0.06 ms per 1080p frame)
     {"regroup_materials", "RPTR_REGROUP", 0, 0, 1},
     {"comm_transport", "RPTR_COMM_TRANSPORT", 0, 0, 3},           // 0 auto, 1 rccl, 2 copy, 3 peer                              [comm init]
     {"comm_priority", "RPTR_COMM_PRIORITY", 1, 0, 1},
@@ -333,9 +333,11 @@ struct rptr_hip {
     size_t path_capacity = 0;
     int persistent_blocks = 0;
     int extend_later_blocks = 0;     // grid of a closest-hit launch of bounce >= 1 (RP_EXTEND_LATER_WAVES)
+    int alone_blocks[4] = {0, 0, 0, 0}; // two frame contexts: the grids (first / later closest-hit, shadow rays [two-level, one record]) of a frame that is alone on the GPU
     int connect_blocks[2] = {0, 0};  // grid of a stand-alone shadow-ray launch, [single instance record ? 1 : 0] (RP_CONNECT_WAVES)
 
     // options (environment, read once)
+    bool side_only_alone = false; // side_connect chosen by the library for a handle with two frame contexts: only for a frame that is alone on the GPU
     int side_connect = 0; // connect(b) on a side stream next to extend(b+1): the default for handles with ONE frame context (RPTR_SIDE_CONNECT=0|1 overrides)
     int stage_timing = 2; // hipEvent pairs per frame: 0 none, 1 around the closest-hit traversal launches, 2 every stage
     bool freeze_frame = false; // RenderConfiguration::freeze_frame: frame_offset / frame_id stand still
@@ -1603,7 +1605,10 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     h->max_batch_spp = mb;
     h->max_batch_frames = (int)h->opt.v[OPT_MAX_BATCH_FRAMES];
     h->aovs = h->opt.v[OPT_AOVS] != 0;
-    h->side_connect = h->opt.v[OPT_SIDE_CONNECT] >= 0 ? (int)h->opt.v[OPT_SIDE_CONNECT] : (h->ctx.size() == 1 ? 1 : 0);
+    // (auto: handles with one or two frame contexts have side streams; a frame uses its context's when no other frame of the handle is in
+    // flight at its submission -- the synchronous loop of a host that holds the reference's two swap buffers, rptr_hip_render)
+    h->side_connect = h->opt.v[OPT_SIDE_CONNECT] >= 0 ? (int)h->opt.v[OPT_SIDE_CONNECT] : (h->ctx.size() <= 2 ? 1 : 0);
+    h->side_only_alone = h->opt.v[OPT_SIDE_CONNECT] < 0 && h->ctx.size() > 1;
     for (FrameCtx &c : h->ctx) {
         if (h->side_connect && !c.side) HIP_TRY(h, hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
         if (!h->side_connect && c.side) {
@@ -1661,6 +1666,10 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     int occ = 0;
     HIP_TRY(h, rp_extend_blocks_per_cu(&occ));
     occ = std::max(1, std::min(occ, 8));
+    // (handles with TWO frame contexts -- the reference's swap buffers -- keep the full-size grids as well: a frame submitted while no other
+    // is in flight, the synchronous loop, is launched like a frame of a one-context handle; side_only_alone above)
+    const bool keep_alone = h->ctx.size() == 2 && h->opt.v[OPT_BLOCKS_PER_CU] <= 0;
+    h->alone_blocks[0] = keep_alone ? h->num_cus * occ : 0;
     // frames in flight share the CUs: with n contexts a traversal launch asks for about 12 / n blocks per CU instead of all that
     // fit, so that the kernels of the other frames find room next to it (measured, profiles/r01_notes.md: 3 contexts 5 -> 4 blocks
     // 1.50 -> 1.49 ms per full frame; 11 contexts 5 -> 1 blocks 0.30 -> 0.25 ms per 1/8 frame)
@@ -1673,6 +1682,7 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
         int occ_c = 0;
         HIP_TRY(h, rp_connect_blocks_per_cu(sg, &occ_c));
         occ_c = std::max(1, std::min(occ_c, 8));
+        h->alone_blocks[2 + sg] = keep_alone ? h->num_cus * occ_c : 0;
         if (h->ctx.size() > 1) occ_c = std::max(1, std::min(occ_c, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
         if (h->opt.v[OPT_BLOCKS_PER_CU] > 0) occ_c = (int)h->opt.v[OPT_BLOCKS_PER_CU];
         h->connect_blocks[sg] = h->num_cus * occ_c;
@@ -1680,11 +1690,13 @@ int rptr_hip_initialize(rptr_hip_t *h, int fb_width, int fb_height) {
     int occ_l = 0;
     HIP_TRY(h, rp_extend_later_blocks_per_cu(&occ_l));
     occ_l = std::max(1, std::min(occ_l, 8));
+    h->alone_blocks[1] = keep_alone ? h->num_cus * occ_l : 0;
     if (h->ctx.size() > 1) occ_l = std::max(1, std::min(occ_l, (int)((12 + h->ctx.size() / 2) / h->ctx.size())));
     if (h->opt.v[OPT_BLOCKS_PER_CU] > 0) occ_l = (int)h->opt.v[OPT_BLOCKS_PER_CU];
     h->extend_later_blocks = h->num_cus * occ_l;
     h->tail_blocks = h->num_cus; // one block per CU (the tail kernel's LDS: two traversal stacks + the shade buffers)
-    const size_t stack_threads = (size_t)std::max(std::max(h->persistent_blocks, h->extend_later_blocks), std::max(h->connect_blocks[0], h->connect_blocks[1])) * RP_TRAVERSE_BLOCK;
+    const size_t stack_threads = (size_t)std::max(std::max(std::max(h->persistent_blocks, h->extend_later_blocks), std::max(h->connect_blocks[0], h->connect_blocks[1])),
+                                                  std::max(std::max(h->alone_blocks[0], h->alone_blocks[1]), std::max(h->alone_blocks[2], h->alone_blocks[3]))) * RP_TRAVERSE_BLOCK;
     for (FrameCtx &c : h->ctx) {
         c.gstack_threads = stack_threads;
         if ((rc = dev_alloc(h, &c.gstack, stack_threads * RPTR_BVH_STACK_DEPTH, nullptr))) return rc;
@@ -2879,7 +2891,16 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     // the general instantiation of the path stages: a table point set, or a screen jitter (raster TAA) -- the shipped path carries neither
     const bool table_rng_later = h->rng_variant != RPTR_RNG_VARIANT_UNIFORM || h->params.enable_raster_taa != 0;
     const bool table_rng = table_rng_later;
-    const bool side = c.side != nullptr;
+    bool side = c.side != nullptr, alone = h->ctx.size() == 1;
+    if (h->ctx.size() == 2) {
+        alone = true;
+        for (FrameCtx &o : h->ctx)
+            if (&o != &c && o.pending && !o.synced && hipEventQuery(o.ev_end) != hipSuccess) alone = false; // another frame is in flight: it fills the GPU
+    }
+    if (side && h->side_only_alone && !alone) side = false;
+    const bool full = alone && h->alone_blocks[0] > 0 && !count_traversal;
+    const int blocks_first = full ? h->alone_blocks[0] : h->persistent_blocks, blocks_later = full ? h->alone_blocks[1] : h->extend_later_blocks;
+    const int blocks_connect[2] = {full ? h->alone_blocks[2] : h->connect_blocks[0], full ? h->alone_blocks[3] : h->connect_blocks[1]};
 
     SceneCopy &scn = h->ctx_scene.empty() ? h->master : h->ctx_scene[(size_t)(&c - h->ctx.data())];
     const bool follow = !h->ctx_scene.empty() && scn.version != h->refit_version;
@@ -2945,7 +2966,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
                                    (const uint32_t *)c.queue[in], c.counters, b, c.gstack);
                     break;
                 }
-                rp_launch_extend(timed_launch(c.stream, 0, (unsigned)(b == 0 ? h->persistent_blocks : h->extend_later_blocks)), count_traversal, b == 0, h->uses_alpha, single, b == 0 ? table_rng : table_rng_later, scn.dscene, f, c.ps,
+                rp_launch_extend(timed_launch(c.stream, 0, (unsigned)(b == 0 ? blocks_first : blocks_later)), count_traversal, b == 0, h->uses_alpha, single, b == 0 ? table_rng : table_rng_later, scn.dscene, f, c.ps,
                                  b == 0 ? first_ids : (const uint32_t *)c.queue[in], bc, c.counters, c.gstack);
                 c.launches_extend++;
                 const uint32_t *in_queue = b == 0 ? first_ids : c.queue[in];
@@ -2961,7 +2982,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
                         HIP_TRY(h, hipEventRecord(c.ev_fork, c.stream));
                         HIP_TRY(h, hipStreamWaitEvent(c.side, c.ev_fork, 0));
                     }
-                    rp_launch_connect(timed_launch(cs, 1, (unsigned)h->connect_blocks[single ? 1 : 0]), count_traversal, h->uses_alpha, single, scn.dscene, f, c.ps, c.sq, bc, c.counters,
+                    rp_launch_connect(timed_launch(cs, 1, (unsigned)blocks_connect[single ? 1 : 0]), count_traversal, h->uses_alpha, single, scn.dscene, f, c.ps, c.sq, bc, c.counters,
                                       stack);
                     if (side) HIP_TRY(h, hipEventRecord(c.ev_side, c.side));
                 }

@@ -9,7 +9,7 @@ from realtimepathtracingresearchframework_amd import abi, backend, scenes
 s = scenes.forest()
 for m in s.meshes[:-1]:
     m.dynamic = True
-r = backend.RenderHip()
+r = backend.RenderHip(options={"stage_timing": 2})
 r.initialize(1920, 1080); r.set_scene(s)
 cfg = backend.RenderConfiguration(s.camera_params(), active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True)
 def run(label, force):

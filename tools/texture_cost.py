@@ -44,7 +44,7 @@ def textured(s, size):
 
 
 def time_frames(s, frames=12):
-    r = backend.RenderHip()
+    r = backend.RenderHip(options={"stage_timing": 2})
     r.initialize(1920, 1080)
     r.set_scene(s)
     ms = []
