@@ -97,6 +97,9 @@ def parse_args():
     ap.add_argument("--probe-timeout", type=float, default=150.0)
     ap.add_argument("--rccl-probe", action="store_true", help="(internal) run as the probe child of a rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast-math", type=int, default=-1, choices=[-1, 0, 1],
+                    help="library option fast_math (csrc/dmath.h): 1 = the shading stages' division / square root on the hardware's 1-ulp instructions; -1: the library's default (0, IEEE)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (C3, C4, C5) behind the headline")
     ap.add_argument("--latency-leg", type=int, default=0, help="(internal) run as the child that measures the latency leg with this many frames in flight")
     ap.add_argument("--dynamic-meshes", type=int, default=0,
                     help="mark the first k meshes of the scene RPTR_MESH_DYNAMIC (they are never moved): the forest with one dynamic tree mesh is the "
@@ -335,6 +338,18 @@ def load_pmc_traffic(key):
         return None
 
 
+def library_build_id():
+    """rptr_hip_build_id(): the hash of the sources the loaded library was built from (build.py source_id)"""
+    try:
+        from realtimepathtracingresearchframework_amd import backend
+        L = backend.load_library()
+        import ctypes
+        L.rptr_hip_build_id.restype = ctypes.c_char_p
+        return L.rptr_hip_build_id().decode()
+    except Exception:
+        return None
+
+
 def load_valu_peak():
     """the VALU issue ceiling, MEASURED (tools/microbench/valu_issue.hip -> profiles/r03a_valu_issue.json, chip-wide G wave64
     instructions / s at 8 waves per SIMD): of plain full-rate instructions (v_fma_f32 / v_mul_f32 / v_add_u32: one per 2 clocks per
@@ -441,6 +456,8 @@ def main():
     lib_options = {}
     if args.flatten >= 0:
         lib_options["flatten"] = args.flatten
+    if args.fast_math >= 0:
+        lib_options["fast_math"] = args.fast_math
     flatten = args.flatten if args.flatten >= 0 else (0 if args.animate else 1)
     torch_stream = torch.cuda.Stream()
     torch.cuda.set_stream(torch_stream)
@@ -564,6 +581,7 @@ def main():
     r.set_scene(scene)
     t_build = time.time() - t0
     bvh_on_device, bvh_step_ms, bvh_device_ms = r.bvh_build_info()
+    fast_math_in_force = int(r.get_option("fast_math"))
     bvh_area_cost, trav_node_min, trav_refill_min = r.traversal_preset()
     if args.animate and args.rebuild_budget != 0:
         r.set_bvh_policy(force_bvh_rebuild=args.rebuild_budget < 0, rebuild_triangle_budget=max(args.rebuild_budget, 0))
@@ -869,6 +887,7 @@ def main():
                        + cnt["tris_shadow"] * TRI_BYTES + cnt["rays_closest"] * (QUEUE_BYTES + HIT_BYTES + PATH_READ_BYTES + PATH_WRITE_BYTES)
                        - primary * (QUEUE_BYTES + PATH_READ_BYTES - FIRST_RAY_BYTES) + cnt["hits"] * (VERTEX_BYTES + MATERIAL_BYTES) + r.local_pixel_count() * (16 * spp + 36))
     wkey = workload_key(args, world)
+    lib_build = library_build_id()
     pmc = load_pmc_traffic(wkey)   # the committed counter passes of THIS workload (profiles/pmc_traffic.json), None for anything else
     n_launch = max(launches_extend, 1)
     props = torch.cuda.get_device_properties(local_rank)
@@ -936,15 +955,22 @@ def main():
     hbm_known = k_ext["hbm_gbs"] is not None
     fetches = cnt_ext["nodes_closest"] + cnt_ext["tris_closest"]
     roofline = {
-        # contract fields. The kernel is a dependent-gather kernel whose working set (tree + triangles, tens of MB) is served by L2 /
-        # Infinity Cache: `achieved` / `frac` are what it really moves over the HBM-side fabric (PMC counters), `algorithmic_*` what its
-        # lanes consume, held against the cache hierarchy's bandwidth. Neither bounds it: latency x divergence and VALU issue do
-        # (profiles/r02_notes.md).
-        # the contract's fields, by the contract's recipe: ALGORITHMIC bytes of the dominant kernel per launch / its exclusive
-        # launch duration, against the HBM peak. The tree is cache resident (L2 + 256 MiB Infinity Cache), so this figure can exceed what
-        # HBM could deliver -- `traffic` (counters) says how little of it reaches HBM; it is a statement about work per second, not a bound.
-        "bound": "hbm", "kernel": k_ext["kernel"], "unit": "GB/s", "peak": HBM_PEAK_GBS,
-        "achieved": k_ext["algorithmic_gbs"], "frac": round(k_ext["algorithmic_gbs"] / HBM_PEAK_GBS, 4),
+        # The contract's fields name what BINDS the dominant kernel: VALU instruction issue. `achieved` = wave64 VALU
+        # instructions per second of one stand-alone closest-hit launch (PMC SQ_INSTS_VALU per launch / its exclusive HIP-event duration), `peak` =
+        # the MEASURED issue ceiling of that kernel's instruction mix (tools/microbench/valu_issue.hip), `frac` their ratio; binding_frac is the
+        # same for the whole pipelined frame. The byte view the contract's recipe asks for stays beside it: the kernel's ALGORITHMIC
+        # bytes per launch / its duration against the HBM peak = algorithmic_frac_of_hbm_peak -- it can exceed 1 because the tree (tens of MB) is
+        # served by the L2s and the Infinity Cache: a statement about work per second, not a bound -- and `traffic`, the bytes the counters
+        # really see crossing the HBM-side fabric per launch (hbm_counter: a fraction of the peak).
+        "bound": "valu_issue", "kernel": k_ext["kernel"], "unit": "G wave64 VALU instructions/s", "peak": k_ext["valu_peak_ginst_s"],
+        "achieved": k_ext["valu_ginst_s"], "frac": k_ext["valu_frac"],
+        "algorithmic_frac_of_hbm_peak": round(k_ext["algorithmic_gbs"] / HBM_PEAK_GBS, 4), "hbm_peak_gbs": HBM_PEAK_GBS,
+        "algorithmic_note": "algorithmic bytes of the dominant kernel per launch / exclusive launch duration / 8 TB/s (SURVEY 8d's recipe): cache-served (tree + triangles "
+                            "live in L2 + Infinity Cache), not a bound; `traffic` is what reaches the HBM side",
+        "counters_build": (pmc or {}).get("library_build_id") or (pmc or {}).get("build"), "library_build": lib_build,
+        "counters_stale": (bool(pmc) and (pmc.get("library_build_id") != lib_build)),
+        "counters_note": "traffic / valu.* / wait_any_frac / tcc_hit_rate come from the committed counter passes profiles/pmc_traffic.json (rocprofv3 --pmc cannot run inside "
+                         "this process); counters_stale = they were taken on a library built from other sources than the one loaded now (rptr_hip_build_id)",
         "traffic": k_ext["hbm_bytes_per_launch"],
         "traffic_source": ("profiles/pmc_traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_workloads.sh) of this workload, bytes per launch "
                            "averaged over the stand-alone closest-hit launches of a frame; gfx950 correction 2 x FETCH_SIZE" % wkey) if hbm_known else None,
@@ -1021,7 +1047,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s, %dx%d, %d spp, %s BSDF, sun+sky, max depth 9" % (what, W, H, spp, bsdf),
                    "camera": "one view for all frames" if args.static_camera else "moves every frame (a camera per frame inside a launch sequence)",
-                   "frame_schedule": "stage launches",
+                   "frame_schedule": "stage launches", "fast_math": fast_math_in_force,
                    "frames_in_flight": fif, "frames_per_launch_sequence": batch_frames, "flattened_instances": bool(flatten) and len(scene.instances) > 1,
                    "parallelism": "tile%d" % world if args.emulate_world <= 1 else "rank 0 of an emulated tile%d split" % args.emulate_world, "stripe_rows": args.stripe_rows, "rays_per_step": rays // K,
                    "scene_gen_s": round(t_scene, 2), "bvh_build_s": round(t_build, 2),
@@ -1071,6 +1097,37 @@ def main():
                 latency[str(depth)] = {"note": "timed out"}
     if world == 1 and args.emulate_world <= 1 and not args.no_boundary and not args.animate and not args.static_camera:
         out["boundary"] = boundary_leg(args, scene, W, H, spp, fif, batch_frames, ms_per_step)
+
+    # ---- the other BASELINE configurations, briefly ("let the driver see C3"): after the headline and outside --steps, one
+    # short run of this file per configuration in a child process (its own handles; this process has closed its own) -- the pipelined
+    # schedule (40 steps), two frames in flight (what a reference-shaped host reaches), the exclusive stage split. C3 is the reference's
+    # actual default renderer (glTF BSDF + binned-RIS NEE).
+    if wkey == "c2" and not args.no_other_configs and not args.profile_pass:
+        import subprocess
+        legs = (("c3", ["--lights", "--variant", "gltf", "--spp", "8"]), ("c3_fast_math", ["--lights", "--variant", "gltf", "--spp", "8", "--fast-math", "1"]),
+                ("c4", ["--scene", "forest"]), ("c5", ["--animate", "--width", "3840", "--height", "2160", "--spp", "2"]))
+        out["other_configs"] = {}
+        for name, cfg_args in legs:
+            cmd = [sys.executable, os.path.abspath(__file__)] + cfg_args + ["--steps", "40", "--warmup", "3", "--no-cpu-baseline", "--no-boundary", "--no-other-configs",
+                                                                           "--sustained-seconds", "0"]
+            t_leg = time.time()
+            try:
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                line = [l for l in pr.stdout.splitlines() if l.startswith('{"metric"')]
+                if not line:
+                    out["other_configs"][name] = {"note": "the child printed no result (rc %d): %s" % (pr.returncode, pr.stderr[-200:])}
+                    continue
+                d = json.loads(line[-1])
+                rf = d["roofline"]
+                out["other_configs"][name] = {
+                    "workload": d["config"]["workload"], "camera": d["config"]["camera"], "rays_per_step": d["config"]["rays_per_step"],
+                    "ms_per_step": d["ms_per_step"], "mrays_s": d["value"], "steps": d["steps"],
+                    "frames_in_flight": d["config"]["frames_in_flight"], "frames_per_launch_sequence": d["config"]["frames_per_launch_sequence"],
+                    "two_in_flight_ms": (rf["latency"].get("2") or {}).get("ms_per_frame"), "one_at_a_time_ms": (rf["latency"].get("1") or {}).get("ms_per_frame"),
+                    "exclusive_stage_ms": rf["stage_ms_per_step"], "flattened_instances": d["config"]["flattened_instances"], "fast_math": d["config"]["fast_math"],
+                    "update_vertices_and_refit_ms": rf.get("update_vertices_and_refit_ms"), "seconds": round(time.time() - t_leg, 1)}
+            except subprocess.TimeoutExpired:
+                out["other_configs"][name] = {"note": "timed out"}
 
     # ---- CPU baseline: the build's own scalar backend -- the oracle's sources (scalar BVH2 traversal + the
     # shading restatement) compiled WITHOUT their diagnostics, -O3 -march=native -ffp-contract=off, 32 x 32 screen tiles over the host's

@@ -267,8 +267,16 @@ typedef struct RptrSceneDesc {
 /* Version of this header's struct layouts and field meanings. History: 1 = round 1; 2 = RptrTextureDesc._pad became mip_levels, RptrStats grew
  * the stage split; 3 = RptrCreateInfo._pad became abi_version (checked), rank 0 keeps two assembled frames. rptr_hip_abi_version()
  * returns the library's value. Fields named _pad must be zero. 4 = round 5: rptr_hip_set_option / _get_option; rptr_hip_set_frame_schedule /
- * _get_frame_schedule are gone (the device-driven frame schedules they selected lost to the stage launches and left the product). */
-#define RPTR_HIP_ABI_VERSION 4
+ * _get_frame_schedule are gone (the device-driven frame schedules they selected lost to the stage launches and left the product).
+ * 5 = round 6: RptrCreateInfo.flags (the library no longer touches GPU_MAX_HW_QUEUES unless RPTR_CREATE_SET_HW_QUEUES asks it to),
+ * rptr_hip_build_id, option "fast_math", builder experiments behind the "experimental." key prefix. */
+#define RPTR_HIP_ABI_VERSION 5
+/* RptrCreateInfo.flags */
+#define RPTR_CREATE_SET_HW_QUEUES 1u /* rptr_hip_create may set the HIP runtime's GPU_MAX_HW_QUEUES for the WHOLE host process (setenv) when the
+                                      * variable is unset or smaller than frames_in_flight + 2 -- effective only when the process has made no HIP
+                                      * call yet (the runtime reads the variable once). For hosts that own their process (bin/rptr_hip sets it);
+                                      * an embedded plugin leaves it clear and the library never edits its host's environment: it then notes on
+                                      * stderr, once, when the frame contexts outnumber the hardware queues (option "quiet" silences it). */
 typedef struct RptrCreateInfo {
     int32_t device_ordinal; /* hipSetDevice                                      */
     int32_t rank;
@@ -282,6 +290,8 @@ typedef struct RptrCreateInfo {
     int32_t abi_version;      /* RPTR_HIP_ABI_VERSION of the header the caller was compiled against: rptr_hip_create refuses any other
                                * value (a caller built against an older header would hand over structs whose former padding
                                * fields have since been given a meaning, e.g. RptrTextureDesc.mip_levels) */
+    uint32_t flags;           /* RPTR_CREATE_*; 0: nothing outside the handle is touched */
+    uint32_t _pad;            /* 0 */
 } RptrCreateInfo;
 
 typedef struct RptrStats {
@@ -314,6 +324,9 @@ typedef struct rptr_hip rptr_hip_t;
 /* ---- lifetime (≙ create_backend_function, render_backend.h:118-119) */
 int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out);
 int rptr_hip_abi_version(void);
+/* a hash over the sources, headers and compiler flags this library was built from (build.py source_id; "unknown" for a hand-made build):
+ * measurements that are kept beside the code -- the counter passes of profiles/pmc_traffic.json -- name the build they belong to */
+const char *rptr_hip_build_id(void);
 /* the acceleration-structure step of the last rptr_hip_set_scene (the reference builds and compacts its BLAS / TLAS on the GPU inside
  * set_scene: vulkan/render_vulkan.cpp:476-543, vulkan/vulkanrt_utils.h:83-105). Large static triangle sets -- a flattened instanced scene,
  * static meshes of millions of triangles -- are built on the device (csrc/ploc.h: Morton sort, PLOC clustering, a binned-SAH top over the
@@ -426,7 +439,8 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  * Every option also has an environment variable (right column): the experimenter's override for A/B runs of an unmodified host. When it is set
  * (read once per handle, in rptr_hip_create) its value is in force and rptr_hip_set_option on that key is accepted and ignored. No other
  * environment variable is read by the library (besides RPTR_FRAMES_IN_FLIGHT, which overrides RptrCreateInfo.frames_in_flight, and the HIP
- * runtime's own GPU_MAX_HW_QUEUES). A host that sets NOTHING gets the configuration bench.py measures.
+ * runtime's own GPU_MAX_HW_QUEUES, which it reads -- and writes only under RPTR_CREATE_SET_HW_QUEUES). A host that sets NOTHING gets the
+ * configuration bench.py measures.
  *
  *   key                      default   takes effect      meaning                                                                   environment
  *   flatten                  -1        set_scene         -1 / 1: a static scene with >= 2 instances (no RPTR_MESH_DYNAMIC mesh) is   RPTR_FLATTEN
@@ -437,11 +451,8 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   flatten_max_tris         1 << 26   set_scene         ... up to this many instanced triangles                                   RPTR_FLATTEN_MAX_TRIS
  *   bvh_builder              0         set_scene         0 auto, 1 host (binned SAH), 2 device (PLOC) for static trees             RPTR_BVH_BUILDER=auto|host|device
  *   device_build_min_tris    2 << 20   set_scene         auto: triangle sets of at least this size are built on the device        RPTR_DEVICE_BUILD_MIN_TRIS
- *   rebraid                  0         set_scene         instance records per instance (sub-roots of its tree); 0: 4 from 16       RPTR_REBRAID
- *                                                        instances on, else 1
  *   traverse_node_min /      -1        set_scene         scheduling thresholds of the traversal (rptr_hip_traversal_preset);       RPTR_TRAVERSE_PRESET=n,r
  *   traverse_refill_min                                  -1: chosen from the tree
- *   lds_top                  0         set_scene         1: traversal instantiations with the top 64 nodes staged in LDS           RPTR_LDS_TOP
  *   single_instance          1         set_scene         queries of scenes with one instance record start inside it               RPTR_NO_SINGLE_INSTANCE (set = 0)
  *   max_batch_frames         8         initialize        frames a launch sequence may hold (rptr_hip_render_batch_async)           RPTR_MAX_BATCH_FRAMES
  *   max_batch_spp            0         initialize        sample slots in flight per frame context; 0: min(16, what the budget      RPTR_MAX_BATCH_SPP
@@ -456,18 +467,26 @@ int rptr_hip_set_stage_timing(rptr_hip_t *h, int level);
  *   tail_bounce              -1        next frame        bounce from which ONE launch finishes the frame; -1 adaptive, 0 never     RPTR_TAIL_BOUNCE
  *   tail_threshold           65536     next frame        adaptive: queue length below which a bounce goes to that launch           RPTR_TAIL_THRESHOLD
  *   stage_timing             0         next frame        = rptr_hip_set_stage_timing                                               RPTR_STAGE_TIMING
- *   regroup_materials        0         next frame        shade orders the hits of a chunk by material id (measured: no gain)       RPTR_REGROUP
  *   comm_transport           0         comm init         0 auto (RCCL between devices), 1 rccl, 2 copy, 3 peer writes              RPTR_COMM_TRANSPORT=rccl|copy|peer
  *   comm_priority            1         comm init         the communication stream has the highest stream priority                 RPTR_COMM_PRIORITY
- *   comm_self                0         comm init         diagnostic: rank 0's own rows travel through the transport too            RPTR_COMM_SELF
  *   quiet                    0         -                 no notes on stderr                                                        RPTR_QUIET
  *   traverse_fetch           0         set_scene         queue entries a traversal wave takes per pool at most (multiple of 64);   RPTR_TRAVERSE_FETCH
  *                                                        0: chosen with the thresholds above (384, dense trees 256)
- *   builder experiments (measured, not adopted; profiles/r03_notes.md): tlas_collapse, collapse (0 greedy, 1 even, 2 optimal; -1 per tree),
- *   presplit_density, presplit_budget_pct, host_ploc, ploc_top, ploc_leaf -- RPTR_TLAS_COLLAPSE, RPTR_COLLAPSE, RPTR_PRESPLIT=d[,b],
- *   RPTR_HOST_PLOC, RPTR_PLOC_TOP, RPTR_PLOC_LEAF. rptr_hip_option_count / rptr_hip_option_name enumerate the keys.
+ *   fast_math                0         next frame        the shading stages' division / square root / normalize: 0 IEEE, correctly   RPTR_FAST_MATH
+ *                                                        rounded -- the CPU oracle's operations, what every parity test runs on;
+ *                                                        1 the hardware's 1-ulp v_rcp / v_sqrt / v_rsq (as a GLSL compiler would:
+ *                                                        Vulkan asks 2.5 ulp of `/`): the reference's default renderer (glTF BSDF +
+ *                                                        binned-RIS lights) 6.5 % faster per frame, whole frames within 2.3e-4 RMSE of
+ *                                                        the oracle (IEEE: 1.4e-5; north_star's tolerance 1e-3), coverage and ray
+ *                                                        counts unchanged; csrc/dmath.h. Traversal and camera rays are IEEE either way.
+ *   rptr_hip_option_count / rptr_hip_option_name enumerate these keys. Experiments that were measured and not adopted stay reachable for
+ *   A/B runs under the key prefix "experimental." (and their environment variables), are not enumerated and carry no promise:
+ *   experimental.rebraid, .tlas_collapse, .collapse, .presplit_density, .presplit_budget_pct, .host_ploc, .ploc_top, .ploc_leaf, .lds_top,
+ *   .regroup_materials, .comm_self (profiles/r03_notes.md, r05_notes.md say what each lost by).
  *   Read-only through rptr_hip_get_option: "bvh_rebuild_failures" -- device-side rebuilds of dynamic meshes that could not start (no memory for
- *   their work space); such a mesh is refitted on its old topology, the frame is rendered, the next refit tries again. */
+ *   their work space); such a mesh is refitted on its old topology, the frame is rendered, the next refit tries again; "sample_slots" -- the
+ *   sample slots a frame context holds once rptr_hip_initialize has sized the path state ("max_batch_spp", or what "path_budget_mb" allows:
+ *   16 up to ~2.9 Mpixel per rank, 12 at 1440p, 5 at 4K): a launch sequence of n frames of s samples needs n * s <= sample_slots. */
 int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value);
 int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value);
 int rptr_hip_option_count(void);

@@ -13,7 +13,7 @@ RPTR_E_UNSUPPORTED = -4
 RPTR_E_HIP = -5
 
 VARIANT_GLTF = 0
-ABI_VERSION = 4  # RPTR_HIP_ABI_VERSION (include/rptr_hip.h): rptr_hip_create refuses anything else
+ABI_VERSION = 5  # RPTR_HIP_ABI_VERSION (include/rptr_hip.h): rptr_hip_create refuses anything else
 VARIANT_SIMPLE = 1
 VARIANT_GLTF_TRANSMISSION = 2
 MESH_DYNAMIC, MESH_SUBTLY_DYNAMIC = 1, 2  # RptrMeshDesc.dynamic = Mesh::flags (librender/mesh.h:44-47)
@@ -197,7 +197,10 @@ class SceneDesc(C.Structure):
 
 class CreateInfo(C.Structure):
     _fields_ = [("device_ordinal", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("stripe_rows", C.c_int32),
-                ("stream", C.c_void_p), ("frames_in_flight", C.c_int32), ("abi_version", C.c_int32)]
+                ("stream", C.c_void_p), ("frames_in_flight", C.c_int32), ("abi_version", C.c_int32), ("flags", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+CREATE_SET_HW_QUEUES = 1  # RPTR_CREATE_SET_HW_QUEUES
 
 
 class Stats(C.Structure):
@@ -241,7 +244,7 @@ COMM_ID_BYTES = 128  # RPTR_COMM_ID_BYTES
 COMM_IPC_BYTES = 256  # RPTR_COMM_IPC_BYTES
 
 EXPORTED_SYMBOLS = [
-    "rptr_hip_create", "rptr_hip_abi_version", "rptr_hip_bvh_build_info", "rptr_hip_traversal_preset", "rptr_hip_destroy", "rptr_hip_last_error", "rptr_hip_name", "rptr_hip_set_stream",
+    "rptr_hip_create", "rptr_hip_abi_version", "rptr_hip_build_id", "rptr_hip_bvh_build_info", "rptr_hip_traversal_preset", "rptr_hip_destroy", "rptr_hip_last_error", "rptr_hip_name", "rptr_hip_set_stream",
     "rptr_hip_initialize", "rptr_hip_set_scene", "rptr_hip_update_vertices", "rptr_hip_update_vertices_device", "rptr_hip_refit", "rptr_hip_set_params",
     "rptr_hip_render", "rptr_hip_render_async", "rptr_hip_render_batch_async", "rptr_hip_render_batch_cameras_async", "rptr_hip_wait", "rptr_hip_set_stage_timing", "rptr_hip_set_freeze_frame", "rptr_hip_set_option", "rptr_hip_get_option", "rptr_hip_option_count", "rptr_hip_option_name", "rptr_hip_set_rng_variant", "rptr_hip_set_bvh_policy", "rptr_hip_bvh_rebuild_count", "rptr_hip_get_framebuffer_size", "rptr_hip_readback_f32", "rptr_hip_readback_u8", "rptr_hip_readback_aov",
     "rptr_hip_tile_rows", "rptr_hip_local_pixel_count", "rptr_hip_copy_tile_to_device", "rptr_hip_trace", "rptr_hip_trace_device", "rptr_hip_enable_ray_queries", "rptr_hip_render_ray_queries", "rptr_hip_set_light_sampling_variant", "rptr_hip_trace_counted",

@@ -159,12 +159,12 @@ class RenderConfiguration:  # librender/render_backend.h:33-40
 class RenderHip:
     """Drop-in shaped like `struct RenderBackend` (render_backend.h:68-116)."""
 
-    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None, frames_in_flight=1, options=None):
+    def __init__(self, device_ordinal=0, rank=0, world_size=1, stripe_rows=32, stream=None, frames_in_flight=1, options=None, create_flags=0):
         """stream: a hipStream_t handle shared with the caller (everything the backend queues is ordered with the caller's
         work on it), or None / 0 for a stream the backend owns. torch's *default* stream has handle 0: to share ordering
         with torch, make a torch.cuda.Stream() current and pass its .cuda_stream (bench.py does)."""
         self._L = load_library()
-        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream, frames_in_flight, abi.ABI_VERSION)
+        info = abi.CreateInfo(device_ordinal, rank, world_size, stripe_rows, stream, frames_in_flight, abi.ABI_VERSION, create_flags, 0)
         self.frames_in_flight = max(1, frames_in_flight)
         h = C.c_void_p()
         rc = self._L.rptr_hip_create(C.byref(info), C.byref(h))

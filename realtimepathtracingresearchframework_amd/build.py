@@ -16,8 +16,10 @@ UNITS = [
     ("rptr_hip", "rptr_hip.hip", []),
     ("bvh_build", "bvh_build.cpp", []),
     ("k_extend", "k_extend.hip", []),
-] + [("k_shade_v%d" % v, "k_shade.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)] \
-  + [("k_tail_v%d" % v, "k_tail.hip", ["-DRP_INST_VARIANT=%d" % v]) for v in range(3)]
+] + [("k_shade_v%d%s" % (v, "_fast" if m else ""), "k_shade.hip", ["-DRP_INST_VARIANT=%d" % v, "-DRP_FAST_MATH=%d" % m]) for m in range(2) for v in range(3)] \
+  + [("k_tail_v%d%s" % (v, "_fast" if m else ""), "k_tail.hip", ["-DRP_INST_VARIANT=%d" % v, "-DRP_FAST_MATH=%d" % m]) for m in range(2) for v in range(3)]
+# (k_shade / k_tail: once per gpu-program variant and per build of the shading arithmetic -- IEEE division / square root, the oracle's bits,
+# or the hardware's 1-ulp reciprocal / square root: option "fast_math", csrc/dmath.h)
 SOURCES = sorted({u[1] for u in UNITS})
 HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_comm.h", "lbvh.h", "ploc.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
            "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
@@ -42,6 +44,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP backend cannot be built (there is no CPU fallback)")
 
 
+def source_id():
+    """sha256 (16 hex digits) over everything the library is compiled from -- sources, headers, flags: what rptr_hip_build_id() returns.
+    profiles/pmc_traffic.json records the id of the library its counter passes ran on; bench.py flags counters of another build as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(set(SOURCES + HEADERS)):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    h.update(repr([(n, fl) for n, _, fl in UNITS]).encode())
+    return h.hexdigest()[:16]
+
+
 def _newest_input():
     return max(os.path.getmtime(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
 
@@ -50,19 +65,24 @@ def needs_build(lib_path=LIB_PATH):
     return not os.path.exists(lib_path) or _newest_input() > os.path.getmtime(lib_path)
 
 
-def build_library(force=False, verbose=False, extra_flags=(), lib_path=LIB_PATH, obj_dir=None, jobs=None):
-    """hipcc -c per unit (in parallel), then one link. extra_flags / lib_path / obj_dir: measurement builds (tools/mkvariant.sh)."""
+def build_library(force=False, verbose=False, extra_flags=(), lib_path=LIB_PATH, obj_dir=None, jobs=None, only_units=None):
+    """hipcc -c per unit (in parallel), then one link. extra_flags / lib_path / obj_dir: measurement builds (tools/mkvariant.sh);
+    only_units (a predicate on the unit name): compile just those with the extra flags and link them with the product's other objects."""
     if not force and not needs_build(lib_path):
         return lib_path
     from concurrent.futures import ThreadPoolExecutor
     obj_dir = obj_dir or OBJ_DIR
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
+    build_id = source_id()
 
     def compile_unit(unit):
         name, src, flags = unit
+        if only_units is not None and not only_units(name):
+            return os.path.join(OBJ_DIR, name + ".o"), 0, ""
         obj = os.path.join(obj_dir, name + ".o")
-        cmd = [hipcc] + FLAGS + list(extra_flags) + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + list(extra_flags) + flags + (['-DRP_BUILD_ID="%s%s"' % (build_id, "+" + "".join(extra_flags) if extra_flags else "")] if name == "rptr_hip" else []) \
+            + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

@@ -11,7 +11,9 @@
 namespace rptr {
 
 BuildTuning &build_tuning() {
-    static BuildTuning t;
+    // per THREAD: a caller sets it and builds on the same thread (collapse_bvh4 / build_bvh2_ploc read it before they start their own
+    // workers), so two handles with different options that build side by side -- one host thread per GPU -- never see each other's values
+    static thread_local BuildTuning t;
     return t;
 }
 namespace {

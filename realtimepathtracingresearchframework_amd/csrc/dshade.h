@@ -439,7 +439,7 @@ RP_DEV void rp_ortho_basis(V3 &v_x, V3 &v_y, V3 n) { // rendering/util.glsl:73-8
     v_x = norm3(cross3(v_y, n));
     v_y = norm3(cross3(n, v_x));
 }
-RP_DEV float rp_cos_half_angle(float c) { return (1.0f + c) / sqrtf(2.0f + 2.0f * c); } // util.glsl:120-122
+RP_DEV float rp_cos_half_angle(float c) { return rp_fdiv_sqrt(1.0f + c, 2.0f + 2.0f * c); } // util.glsl:120-122
 RP_DEV float rp_mix_fma(float x, float y, float a) { return fmaf(a, y, fmaf(-a, x, x)); }   // util.glsl:151-153
 RP_DEV float rp_linear_to_srgb(float x) {                                                  // util.glsl:19-28
     return (x <= 0.0031308f) ? 12.92f * x : 1.055f * powf(fmaxf(fabsf(x), 1.192092896e-07f), 1.f / 2.4f) - 0.055f;
@@ -601,8 +601,8 @@ RP_DEV RpMipView rp_mip_view(const RpTexture &t, int level) {
 }
 RP_DEV float4 rp_texel(const RpScene &sc, const RpTexture &t, const RpMipView &v, int ix, int iy) {
     const uchar4 c = v.texels[(size_t)iy * (size_t)v.w + (size_t)ix];
-    if (t.srgb) return make_float4(sc.srgb_lut[c.x], sc.srgb_lut[c.y], sc.srgb_lut[c.z], float(c.w) / 255.0f);
-    return make_float4(float(c.x) / 255.0f, float(c.y) / 255.0f, float(c.z) / 255.0f, float(c.w) / 255.0f);
+    if (t.srgb) return make_float4(sc.srgb_lut[c.x], sc.srgb_lut[c.y], sc.srgb_lut[c.z], rp_fdiv(float(c.w), 255.0f));
+    return make_float4(rp_fdiv(float(c.x), 255.0f), rp_fdiv(float(c.y), 255.0f), rp_fdiv(float(c.z), 255.0f), rp_fdiv(float(c.w), 255.0f));
 }
 RP_DEV int rp_wrap_repeat(int i, int n) {
     if ((n & (n - 1)) == 0) return i & (n - 1); // power-of-two sizes (the usual case): no integer division (~30 instructions each, 4 per tap)
@@ -663,21 +663,21 @@ RP_DEV float4 rp_texture_grad(const RpScene &sc, int tex_id, const RpTexCoord &t
     const RpTexture t = sc.textures[tex_id];
     const float w = float(t.width), h = float(t.height);
     const float mxx = tc.ddx.x * w, mxy = tc.ddx.y * h, myx = tc.ddy.x * w, myy = tc.ddy.y * h;
-    const float rx = sqrtf(mxx * mxx + mxy * mxy), ry = sqrtf(myx * myx + myy * myy);
+    const float rx = rp_fsqrt(mxx * mxx + mxy * mxy), ry = rp_fsqrt(myx * myx + myy * myy);
     const float rmax = fmaxf(rx, ry), rmin = fminf(rx, ry);
     // magnification (the footprint lies inside one texel), or nothing to filter (a 1 x 1 texture): one bilinear tap of level 0
     if (!(rmax > 1.0f) || (t.width == 1 && t.height == 1)) return rp_texture_bilinear(sc, t, 0, tc.uv);
-    const float eta = rmin > 0.0f ? fminf(rmax / rmin, RP_MAX_ANISOTROPY) : RP_MAX_ANISOTROPY;
+    const float eta = rmin > 0.0f ? fminf(rp_fdiv(rmax, rmin), RP_MAX_ANISOTROPY) : RP_MAX_ANISOTROPY;
     const int n = int(ceilf(eta));
-    const RpLodPick pick = rp_pick_levels(t, log2f(rmax / eta));
+    const RpLodPick pick = rp_pick_levels(t, log2f(rp_fdiv(rmax, eta)));
     const V2 major = rx > ry ? tc.ddx : tc.ddy;
     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int i = 1; i <= n; ++i) {
-        const float at = float(i) / float(n + 1) - 0.5f;
+        const float at = rp_fdiv(float(i), float(n + 1)) - 0.5f;
         const float4 c = rp_texture_tap(sc, t, pick, v2(tc.uv.x + major.x * at, tc.uv.y + major.y * at));
         sum = make_float4(sum.x + c.x, sum.y + c.y, sum.z + c.z, sum.w + c.w);
     }
-    const float inv = 1.0f / float(n);
+    const float inv = rp_frcp(float(n));
     return make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
 }
 // ---- the pixel footprint a path carries for its texture lookups (rendering/rt/footprint.glsl; column-major 2 x 2, same operation order
@@ -688,7 +688,7 @@ struct M2 {
 RP_DEV V2 mul2(const M2 &m, V2 v) { return v2(m.c0.x * v.x + m.c1.x * v.y, m.c0.y * v.x + m.c1.y * v.y); }
 RP_DEV M2 mul2(const M2 &a, const M2 &b) { return M2{mul2(a, b.c0), mul2(a, b.c1)}; }
 RP_DEV M2 transpose2(const M2 &m) { return M2{v2(m.c0.x, m.c1.x), v2(m.c0.y, m.c1.y)}; }
-RP_DEV V2 norm2(V2 v) { return v * (1.0f / sqrtf(v.x * v.x + v.y * v.y)); }
+RP_DEV V2 norm2(V2 v) { return v * rp_frsq(v.x * v.x + v.y * v.y); }
 RP_DEV M2 rp_dpdxy_to_footprint(V3 ray_dir, V3 dpdx, V3 dpdy) { // :10-15
     V3 t, b;
     rp_ortho_basis(t, b, ray_dir);
@@ -713,7 +713,7 @@ RP_DEV M2 rp_reflect_footprint(V3 dst_ray_dir, V3 src_ray_dir, const M2 &F) { //
 RP_DEV void rp_footprint_to_dpdxy(V3 &dpdx, V3 &dpdy, V3 ray_dir, const M2 &F) { // :45-63
     const float B = F.c0.x + F.c1.y;
     const float C = F.c0.x * F.c1.y - F.c0.y * F.c1.x;
-    const float D = sqrtf(B * B * 0.25f - C);
+    const float D = rp_fsqrt(B * B * 0.25f - C);
     const V2 ev = v2(0.5f * B - D, 0.5f * B + D);
     M2 X;
     if (fabsf(F.c0.y) > 3.0e-39f) {
@@ -723,7 +723,7 @@ RP_DEV void rp_footprint_to_dpdxy(V3 &dpdx, V3 &dpdy, V3 ray_dir, const M2 &F) {
         X = M2{v2(1.0f, 0.0f), v2(0.0f, 1.0f)};
     V3 t, b;
     rp_ortho_basis(t, b, ray_dir);
-    const V2 x0 = norm2(X.c0) * sqrtf(ev.x), x1 = norm2(X.c1) * sqrtf(ev.y);
+    const V2 x0 = norm2(X.c0) * rp_fsqrt(ev.x), x1 = norm2(X.c1) * rp_fsqrt(ev.y);
     dpdx = t * x0.x + b * x0.y;
     dpdy = t * x1.x + b * x1.y;
 }
@@ -733,7 +733,7 @@ RP_DEV RpTexCoord rp_hit_texcoord(V2 uv, const M2 &footprint, V3 ray_dir, V3 geo
     rp_footprint_to_dpdxy(dpdx, dpdy, ray_dir, footprint);
     const V3 dir_tangent_un = ray_dir - geo_normal * dot3(ray_dir, geo_normal);
     const float cosTheta2 = fmaxf(1.0f - dot3(dir_tangent_un, dir_tangent_un), 0.0f);
-    const V3 dir_tangent_elong = dir_tangent_un / (sqrtf(cosTheta2) + cosTheta2);
+    const V3 dir_tangent_elong = dir_tangent_un / (rp_fsqrt(cosTheta2) + cosTheta2);
     const V3 dpdx_ = dpdx + dir_tangent_elong * dot3(dpdx, dir_tangent_un);
     const V3 dpdy_ = dpdy + dir_tangent_elong * dot3(dpdy, dir_tangent_un);
     const V3 bitangent = bitangent_l * cross3(geo_normal, norm3(tangent));
@@ -823,7 +823,7 @@ RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_rad
             else {
                 m.transmission_color = m.base_color;
                 m.transmission_roughness = m.roughness;
-                m.roughness = sqrtf(TEX ? rp_textured_scalar_param(sc, cache, p.clearcoat_gloss, uv) : p.clearcoat_gloss);
+                m.roughness = rp_fsqrt(TEX ? rp_textured_scalar_param(sc, cache, p.clearcoat_gloss, uv) : p.clearcoat_gloss);
             }
         }
     }
@@ -834,14 +834,14 @@ RP_DEV void rp_unpack_material(const RpScene &sc, RpMaterial &m, V3 &emitter_rad
 RP_DEV float rp_schlick_weight(float c) { return pow5f(clamp1(1.f - c, 0.f, 1.f)); }                     // :172-174
 RP_DEV float rp_gtr_2(float cos_theta_h, float alpha) {                                                  // :194-198
     float a2 = alpha * alpha;
-    return RP_1_PI * a2 / pow2f(1.f + (a2 - 1.f) * cos_theta_h * cos_theta_h);
+    return rp_fdiv(RP_1_PI * a2, pow2f(1.f + (a2 - 1.f) * cos_theta_h * cos_theta_h));
 }
-RP_DEV float rp_smith_den1(float n_dot_o, float a2) { return fabsf(n_dot_o) + sqrtf(a2 + (1.0f - a2) * n_dot_o * n_dot_o); } // :200-202
+RP_DEV float rp_smith_den1(float n_dot_o, float a2) { return fabsf(n_dot_o) + rp_fsqrt(a2 + (1.0f - a2) * n_dot_o * n_dot_o); } // :200-202
 RP_DEV float rp_smith_ggx(float n_dot_o, float n_dot_i, float alpha_g) {                                 // :207-212
     float a = alpha_g * alpha_g;
     float den_shad = rp_smith_den1(n_dot_i, a);
     float den_mask = rp_smith_den1(n_dot_o, a);
-    return 1.f / (den_shad * den_mask);
+    return rp_frcp(den_shad * den_mask);
 }
 RP_DEV V3 rp_to_pipe_sample(V2 U) { // :216-222
     float phi = 2.0f * RP_PI * U.x;
@@ -849,13 +849,13 @@ RP_DEV V3 rp_to_pipe_sample(V2 U) { // :216-222
 }
 RP_DEV V3 rp_sample_sphere(V3 UP) { // :225-229
     float cos_theta = UP.z * 2.0f - 1.0f;
-    float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float sin_theta = rp_fsqrt(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
     return v3(sin_theta * UP.x, sin_theta * UP.y, cos_theta);
 }
 RP_DEV V3 rp_sample_gtr_2_vndf(V3 w_o_local, float alpha, V3 UP) { // :233-250
     V3 wiStd = norm3(v3(alpha * w_o_local.x, alpha * w_o_local.y, w_o_local.z));
     float z = fmaf((1.0f - UP.z), (1.0f + wiStd.z), -wiStd.z);
-    float sinTheta = sqrtf(clamp1(1.0f - z * z, 0.0f, 1.0f));
+    float sinTheta = rp_fsqrt(clamp1(1.0f - z * z, 0.0f, 1.0f));
     float x = sinTheta * UP.x;
     float y = sinTheta * UP.y;
     V3 wmStd = v3(x, y, z) + wiStd;
@@ -864,26 +864,26 @@ RP_DEV V3 rp_sample_gtr_2_vndf(V3 w_o_local, float alpha, V3 UP) { // :233-250
     return wm / wmL;
 }
 RP_DEV float rp_gtr_2_vndf_pdf(float n_dot_o, float cos_theta_h, float alpha) { // :253-257
-    return rp_gtr_2(cos_theta_h, alpha) * (0.5f / rp_smith_den1(n_dot_o, alpha * alpha));
+    return rp_gtr_2(cos_theta_h, alpha) * rp_fdiv(0.5f, rp_smith_den1(n_dot_o, alpha * alpha));
 }
 RP_DEV V3 rp_gltf_diffuse_basecolor(const RpMaterial &m) { return (1.0f - m.metallic) * m.base_color; } // :259-261
 RP_DEV V3 rp_gltf_specular_basecolor(const RpMaterial &m, float ior) {                                  // :263-273
-    V3 dielectric_base = v3s(pow2f((ior - 1.0f) / (ior + 1.0f)));
+    V3 dielectric_base = v3s(pow2f(rp_fdiv(ior - 1.0f, ior + 1.0f)));
     return mix3(dielectric_base, m.base_color, m.metallic);
 }
 RP_DEV float rp_gltf_specular_alpha(const RpMaterial &m) { return fmaxf(m.roughness * m.roughness, 0.002f); } // :275-277
 RP_DEV float rp_gltf_schlick_weight(float local_o_dot_h, float ior) {                                       // :284-292
     float f_weight = rp_schlick_weight(local_o_dot_h);
     if (ior < 1.0f) {
-        float cos_critical = sqrtf(1.0f - ior * ior);
-        f_weight = mixf(f_weight, 1.0f, fminf((1.0f - local_o_dot_h) / (1.0f - cos_critical), 1.0f));
+        float cos_critical = rp_fsqrt(1.0f - ior * ior);
+        f_weight = mixf(f_weight, 1.0f, fminf(rp_fdiv(1.0f - local_o_dot_h, 1.0f - cos_critical), 1.0f));
     }
     return f_weight;
 }
 RP_DEV V3 rp_gltf_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :294-359
     float i_dot_n = dot3(n, w_i);
     float o_dot_n = dot3(n, w_o);
-    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    float ior = o_dot_n < 0.0f ? rp_frcp(m.ior) : m.ior;
     if (i_dot_n * o_dot_n < 0.0f) return v3s(0.0f);
     V3 w_h = norm3(w_i + w_o);
     float o_dot_h = dot3(w_o, w_h);
@@ -915,8 +915,8 @@ RP_DEV RpLobes rp_gltf_component_sampler(const RpMaterial &m, float o_dot_h_x, f
     weight_sum += c.w0;
     weight_sum += c.w1;
     if (weight_sum > 0.0f) {
-        c.w0 /= weight_sum;
-        c.w1 /= weight_sum;
+        c.w0 = rp_fdiv(c.w0, weight_sum);
+        c.w1 = rp_fdiv(c.w1, weight_sum);
     } else
         c.w0 = 1.0f;
     return c;
@@ -931,7 +931,7 @@ RP_DEV float rp_gltf_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :414-4
         float o_dot_h = dot3(w_o, w_h);
         float cos_theta_h = dot3(w_h, n);
         float specular_alpha = rp_gltf_specular_alpha(m);
-        float vis_y = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, specular_alpha * specular_alpha);
+        float vis_y = rp_fdiv(2.0f * fabsf(i_dot_n), rp_smith_den1(i_dot_n, specular_alpha * specular_alpha));
         RpLobes c = rp_gltf_component_sampler(m, fabsf(o_dot_h), fabsf(o_dot_h), 1.0f, vis_y);
         float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
         pdf *= c.w0;
@@ -961,7 +961,7 @@ RP_DEV V3 rp_sample_gltf_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, float 
         w_h_specular_local = rp_sample_gtr_2_vndf(w_o_local, specular_alpha, UP);
         float odh_y = dot3(w_o_local, w_h_specular_local);
         float spec_i_dot_n_local = reflect3(-w_o_local, w_h_specular_local).z;
-        float vis_y = spec_i_dot_n_local > 0.0f ? 2.0f * spec_i_dot_n_local / rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha) : 0.0f;
+        float vis_y = spec_i_dot_n_local > 0.0f ? rp_fdiv(2.0f * spec_i_dot_n_local, rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha)) : 0.0f;
         lobes = rp_gltf_component_sampler(m, odh_x, odh_y, 1.0f, vis_y);
         // glft_sample_reuse_component (:395-409), 2 components, only the index is used afterwards
         float rnd = fresnel_sample.x;
@@ -1005,13 +1005,13 @@ RP_DEV V3 rp_refract3(V3 I, V3 N, float eta) { // GLSL refract
     const float d = dot3(N, I);
     const float k = 1.0f - (eta * eta) * (1.0f - d * d);
     if (k < 0.0f) return v3s(0.0f);
-    return eta * I - (eta * d + sqrtf(k)) * N;
+    return eta * I - (eta * d + rp_fsqrt(k)) * N;
 }
 RP_DEV float rp_gltf_transmission_alpha(const RpMaterial &m) { return fmaxf(m.transmission_roughness * m.transmission_roughness, 0.002f); } // :278-282
 RP_DEV V3 rp_gltf_t_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :294-359
     float i_dot_n = dot3(n, w_i);
     float o_dot_n = dot3(n, w_o);
-    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    float ior = o_dot_n < 0.0f ? rp_frcp(m.ior) : m.ior;
     const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
     V3 w_h;
     if (i_dot_n * o_dot_n < 0.0f) {
@@ -1039,7 +1039,7 @@ RP_DEV V3 rp_gltf_t_bsdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :294-35
             diffuse = v3s(0.0f);
             specular = ((specular_refl * (1.f - m.metallic)) * m.specular_transmission) * m.transmission_color * (v3s(1.0f) - F);
             if (onesided) { // transmission angle compression
-                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                float angle_compression = rp_fdiv(2.0f * o_dot_h, i_dot_h * ior + o_dot_h);
                 specular = specular * (angle_compression * angle_compression);
             }
         } else {
@@ -1068,9 +1068,9 @@ RP_DEV RpLobes3 rp_gltf_t_component_sampler(const RpMaterial &m, float ior, floa
     weight_sum += c.w1;
     weight_sum += c.w2;
     if (weight_sum > 0.0f) {
-        c.w0 /= weight_sum;
-        c.w1 /= weight_sum;
-        c.w2 /= weight_sum;
+        c.w0 = rp_fdiv(c.w0, weight_sum);
+        c.w1 = rp_fdiv(c.w1, weight_sum);
+        c.w2 = rp_fdiv(c.w2, weight_sum);
     } else
         c.w0 = 1.0f;
     return c;
@@ -1078,7 +1078,7 @@ RP_DEV RpLobes3 rp_gltf_t_component_sampler(const RpMaterial &m, float ior, floa
 RP_DEV float rp_gltf_t_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :414-494
     float i_dot_n = dot3(n, w_i);
     float o_dot_n = dot3(n, w_o);
-    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    float ior = o_dot_n < 0.0f ? rp_frcp(m.ior) : m.ior;
     const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
     float pdf = RP_1_PI * fabsf(i_dot_n);
     if (m.ior > 1.0f) {
@@ -1096,19 +1096,19 @@ RP_DEV float rp_gltf_t_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) { // :414
         float o_dot_h = dot3(w_o, w_h), i_dot_h = dot3(w_i, w_h);
         float cos_theta_h = dot3(w_h, n);
         float specular_alpha = rp_gltf_specular_alpha(m);
-        float vis_y = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, specular_alpha * specular_alpha);
+        float vis_y = rp_fdiv(2.0f * fabsf(i_dot_n), rp_smith_den1(i_dot_n, specular_alpha * specular_alpha));
         float vis_z = vis_y;
         float transmission_alpha = specular_alpha;
         if (m.specular_transmission > 0.f) {
             transmission_alpha = rp_gltf_transmission_alpha(m);
-            vis_z = 2.0f * fabsf(i_dot_n) / rp_smith_den1(i_dot_n, transmission_alpha * transmission_alpha);
+            vis_z = rp_fdiv(2.0f * fabsf(i_dot_n), rp_smith_den1(i_dot_n, transmission_alpha * transmission_alpha));
         }
         RpLobes3 c = rp_gltf_t_component_sampler(m, ior, fabsf(o_dot_h), fabsf(o_dot_h), fabsf(o_dot_h), 1.0f, vis_y, vis_z);
         if (i_dot_n * o_dot_n < 0.0f) specular_alpha = transmission_alpha;
         float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
         if (i_dot_n * o_dot_n < 0.0f) {
             if (onesided) {
-                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                float angle_compression = rp_fdiv(2.0f * o_dot_h, i_dot_h * ior + o_dot_h);
                 specular *= angle_compression * angle_compression;
             }
             pdf = specular * c.w2;
@@ -1124,7 +1124,7 @@ RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, floa
     M3 frame{v_x, v_y, n};
     V3 w_o_local = mul_t(frame, w_o);
     float o_dot_n = w_o_local.z;
-    float ior = o_dot_n < 0.0f ? 1.0f / m.ior : m.ior;
+    float ior = o_dot_n < 0.0f ? rp_frcp(m.ior) : m.ior;
     const bool onesided = (m.flags & RPTR_BASE_MATERIAL_ONESIDED) != 0u;
     mis_wpdf = 0.0f;
     if (o_dot_n < 0.0f) w_o_local.z = -w_o_local.z;
@@ -1140,7 +1140,7 @@ RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, floa
         w_h_specular_local = rp_sample_gtr_2_vndf(w_o_local, specular_alpha, UP);
         float odh_y = dot3(w_o_local, w_h_specular_local);
         float spec_i_dot_n_local = reflect3(-w_o_local, w_h_specular_local).z;
-        float vis_y = spec_i_dot_n_local > 0.0f ? 2.0f * spec_i_dot_n_local / rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha) : 0.0f;
+        float vis_y = spec_i_dot_n_local > 0.0f ? rp_fdiv(2.0f * spec_i_dot_n_local, rp_smith_den1(spec_i_dot_n_local, specular_alpha * specular_alpha)) : 0.0f;
         float transmission_alpha = specular_alpha;
         w_h_transmission_local = w_h_specular_local;
         float odh_z = odh_y;
@@ -1151,10 +1151,10 @@ RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, floa
             w_h_transmission_local = rp_sample_gtr_2_vndf(w_o_local, transmission_alpha, UP);
             odh_z = dot3(w_o_local, w_h_transmission_local);
             if (onesided)
-                trans_i_dot_n_local = -rp_refract3(-w_o_local, w_h_transmission_local, 1.0f / ior).z;
+                trans_i_dot_n_local = -rp_refract3(-w_o_local, w_h_transmission_local, rp_frcp(ior)).z;
             else
                 trans_i_dot_n_local = reflect3(-w_o_local, w_h_transmission_local).z;
-            vis_z = trans_i_dot_n_local > 0.0f ? 2.0f * trans_i_dot_n_local / rp_smith_den1(trans_i_dot_n_local, transmission_alpha * transmission_alpha) : 0.0f;
+            vis_z = trans_i_dot_n_local > 0.0f ? rp_fdiv(2.0f * trans_i_dot_n_local, rp_smith_den1(trans_i_dot_n_local, transmission_alpha * transmission_alpha)) : 0.0f;
         }
         lobes = rp_gltf_t_component_sampler(m, ior, odh_x, odh_y, odh_z, 1.0f, vis_y, vis_z);
         // glft_sample_reuse_component (:395-409), 3 components, only the index is used afterwards
@@ -1184,7 +1184,7 @@ RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, floa
         i_dot_h = o_dot_h = dot3(w_o, w_h);
         if (component != 1) {
             if (onesided) {
-                w_i = rp_refract3(-w_o, w_h, 1.0f / ior);
+                w_i = rp_refract3(-w_o, w_h, rp_frcp(ior));
                 i_dot_h = dot3(w_i, w_h);
             } else
                 w_i = reflect3(reflect3(-w_o, w_h), n);
@@ -1202,7 +1202,7 @@ RP_DEV V3 rp_sample_gltf_t_brdf(const RpMaterial &m, V3 n, V3 w_o, V3 &w_i, floa
         float specular = rp_gtr_2_vndf_pdf(o_dot_n, cos_theta_h, specular_alpha);
         if (i_dot_n * o_dot_n < 0.0f) {
             if (onesided) {
-                float angle_compression = 2.0f * o_dot_h / (i_dot_h * ior + o_dot_h);
+                float angle_compression = rp_fdiv(2.0f * o_dot_h, i_dot_h * ior + o_dot_h);
                 specular *= angle_compression * angle_compression;
             }
             pdf = specular * lobes.w2;
@@ -1233,7 +1233,7 @@ RP_DEV float rp_simple_pdf(V3 n, V3 w_o, V3 w_i) { // :68-83
 RP_DEV V3 rp_sample_simple_brdf(const RpMaterial &m, V3 n, V3 &w_i, float &pdf, float &mis_pdf, V2 rnd) { // :61-66,85-94
     float phi = 2.0f * RP_PI * rnd.x;
     float cos_theta = rnd.y * 2.0f - 1.0f;
-    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float sin_theta = rp_fsqrt(1.0f - cos_theta * cos_theta);
     V3 sph = v3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
     w_i = norm3(n + sph);
     float i_dot_n = dot3(n, w_i);
@@ -1256,7 +1256,7 @@ RP_DEV float rp_eval_bsdf_wpdf(const RpMaterial &m, V3 n, V3 w_o, V3 w_i) {
 // ------------------------------------------------------------------ triangle lights (a12), rendering/lights/tri.glsl
 RP_DEV float rp_fast_positive_atan(float y) { // :58-74
     float rx, ry, rz;
-    rx = (fabsf(y) > 1.0f) ? (1.0f / fabsf(y)) : fabsf(y);
+    rx = (fabsf(y) > 1.0f) ? rp_frcp(fabsf(y)) : fabsf(y);
     ry = rx * rx;
     rz = fmaf(ry, 0.02083509974181652f, -0.08513300120830536f);
     rz = fmaf(ry, rz, 0.18014100193977356f);
@@ -1269,7 +1269,7 @@ RP_DEV float rp_fast_positive_atan(float y) { // :58-74
 }
 RP_DEV float rp_half_tri_solid_angle_tan(V3 v0, V3 v1, V3 v2, V3 &tp) { // :83-113
     float householder_sign = (v0.x > 0.0f) ? -1.0f : 1.0f;
-    float hs = 1.0f / (fabsf(v0.x) + 1.0f);
+    float hs = rp_frcp(fabsf(v0.x) + 1.0f);
     float hy = v0.y * hs, hz = v0.z * hs;
     float dot_0_1 = dot3(v0, v1);
     float dot_0_2 = dot3(v1, v2);
@@ -1282,19 +1282,19 @@ RP_DEV float rp_half_tri_solid_angle_tan(V3 v0, V3 v1, V3 v2, V3 &tp) { // :83-1
     float dot_0_2_plus_1_2 = dot_0_2 + dot_1_2;
     float one_plus_dot_0_1 = 1.0f + dot_0_1;
     tp = v3(simplex_volume, dot_0_2_plus_1_2, one_plus_dot_0_1);
-    return simplex_volume / (one_plus_dot_0_1 + dot_0_2_plus_1_2);
+    return rp_fdiv(simplex_volume, one_plus_dot_0_1 + dot_0_2_plus_1_2);
 }
 RP_DEV V3 rp_sample_solid_angle_polygon(V3 v0, V3 v1, V3 v2, float solid_angle, V3 params, V2 rnd) { // :132-152
     float sub = solid_angle * rnd.x;
     V3 vert0 = v1, vert1 = v0, vert2 = v2;
     float cs = cosf(0.5f * sub), sn = sinf(0.5f * sub);
     V3 offset = vert0 * (params.x * cs - params.y * sn) + vert2 * (params.z * sn);
-    float k = 2.0f * (dot3(vert0, offset) / dot3(offset, offset));
+    float k = 2.0f * rp_fdiv(dot3(vert0, offset), dot3(offset, offset));
     V3 new_vertex_2 = v3(fmaf(k, offset.x, -vert0.x), fmaf(k, offset.y, -vert0.y), fmaf(k, offset.z, -vert0.z));
     float s2 = dot3(vert1, new_vertex_2);
     float s = rp_mix_fma(1.0f, s2, rnd.y);
     float denominator = fmaf(-s2, s2, 1.0f);
-    float t_normed = sqrtf(fmaf(-s, s, 1.0f) / denominator);
+    float t_normed = rp_fsqrt(rp_fdiv(fmaf(-s, s, 1.0f), denominator));
     t_normed = (denominator > 0.0f) ? t_normed : rnd.y;
     return fmaf(-t_normed, s2, s) * vert1 + t_normed * new_vertex_2;
 }
@@ -1321,7 +1321,7 @@ RP_DEV RpLightBin rp_choose_light_bin(const RpScene &sc, const RpFrame &f, float
     int bin_id = int(uint32_t(sel_x));
     bin_id = min(bin_id, num_bins - 1);
     RpLightBin b;
-    b.sel_p = 1.0f / float(num_bins);
+    b.sel_p = rp_frcp(float(num_bins));
     b.bin_begin = f.lc.bin_size * bin_id;
     b.bin_end = min(f.lc.bin_size * (bin_id + 1), sc.num_lights);
     return b;
@@ -1368,7 +1368,7 @@ RP_DEV V3 rp_finish_tri_light_sample(const RpScene &sc, const RpFrame &f, const 
             if (!(light_id < bin.bin_end)) {
                 done = true;
             } else {
-                p = contribution(i) / total_contrib;
+                p = rp_fdiv(contribution(i), total_contrib);
                 t += p;
                 if (sel_y < t) done = true;
             }
@@ -1383,12 +1383,12 @@ RP_DEV V3 rp_finish_tri_light_sample(const RpScene &sc, const RpFrame &f, const 
     V3 tp;
     float polygon_solid_angle = 2.0f * rp_fast_positive_atan(rp_half_tri_solid_angle_tan(d0, d1, d2, tp));
     light_dir = rp_sample_solid_angle_polygon(d0, d1, d2, polygon_solid_angle, tp, dir_sample);
-    pdf = 1.0f / polygon_solid_angle;
+    pdf = rp_frcp(polygon_solid_angle);
     V3 e_n = cross3(l1 - l0, l2 - l0);
-    light_dist = dot3(l0 - hit_p, e_n) / dot3(light_dir, e_n);
-    mis_wpdf = 2.0f * light_dist * light_dist / fabsf(dot3(light_dir, e_n));
+    light_dist = rp_fdiv(dot3(l0 - hit_p, e_n), dot3(light_dir, e_n));
+    mis_wpdf = rp_fdiv(2.0f * light_dist * light_dist, fabsf(dot3(light_dir, e_n)));
     pdf *= sel_p;
-    mis_wpdf /= float(f.num_bins);
+    mis_wpdf = rp_fdiv(mis_wpdf, float(f.num_bins));
     return 1.0f * lrad / pdf;
 }
 
@@ -1396,14 +1396,14 @@ RP_DEV V3 rp_finish_tri_light_sample(const RpScene &sc, const RpFrame &f, const 
 RP_DEV V3 rp_sample_sun_dir(V3 sun_dir, float cos_radius, V2 s) { // rendering/lights/sun.glsl:9-15
     float phi = 2.0f * RP_PI * s.x;
     float cosTheta = mixf(1.0f, cos_radius, s.y);
-    float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    float sinTheta = rp_fsqrt(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     V3 vx, vy;
     rp_ortho_basis(vx, vy, sun_dir);
     M3 fr{vx, vy, sun_dir};
     return mul(fr, v3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta));
 }
-RP_DEV float rp_sun_dir_pdf(float cos_radius) { return 1.0f / (2.0f * RP_PI * (1.0f - cos_radius)); } // sun.glsl:17-20
-RP_DEV float rp_nee_mis(float pdf_f, float pdf_g) { return pdf_f / (pdf_f + pdf_g); }                 // nee_interface.glsl:11-15 (n=1)
+RP_DEV float rp_sun_dir_pdf(float cos_radius) { return rp_frcp(2.0f * RP_PI * (1.0f - cos_radius)); } // sun.glsl:17-20
+RP_DEV float rp_nee_mis(float pdf_f, float pdf_g) { return rp_fdiv(pdf_f, pdf_f + pdf_g); }                 // nee_interface.glsl:11-15 (n=1)
 
 // rendering/lights/sky_model_arhosek/sky_model.glsl:40-59
 RP_DEV V3 rp_skymodel_radiance(const RptrSkyModelParams &st, V3 sun_dir, V3 view_dir) {
@@ -1416,9 +1416,9 @@ RP_DEV V3 rp_skymodel_radiance(const RptrSkyModelParams &st, V3 sun_dir, V3 view
     float rayM = cosGamma * cosGamma;
     V3 c8 = RP_CFG(8);
     V3 mie_base = v3s(1.0f) + c8 * c8 - 2.0f * c8 * cosGamma;
-    V3 mie_den = v3(mie_base.x * sqrtf(mie_base.x), mie_base.y * sqrtf(mie_base.y), mie_base.z * sqrtf(mie_base.z));
+    V3 mie_den = v3(mie_base.x * rp_fsqrt(mie_base.x), mie_base.y * rp_fsqrt(mie_base.y), mie_base.z * rp_fsqrt(mie_base.z));
     V3 mieM = v3s(1.0f + cosGamma * cosGamma) / mie_den;
-    float zenith = sqrtf(cosTheta);
+    float zenith = rp_fsqrt(cosTheta);
     V3 c1d = RP_CFG(1) / (cosTheta + 0.01f);
     V3 e1 = v3(expf(c1d.x), expf(c1d.y), expf(c1d.z));
     V3 coeffs = (v3s(1.0f) + RP_CFG(0) * e1) * ((((RP_CFG(2) + RP_CFG(3) * expM) + RP_CFG(5) * rayM) + RP_CFG(6) * mieM) + RP_CFG(7) * zenith);
@@ -1445,4 +1445,4 @@ RP_DEV V3 rp_compute_sky_illum(const RpFrame &f, V3 ray_dir, float prev_bsdf_pdf
     return illum;
 }
 // vulkan/geometry.glsl:76-78
-RP_DEV float rp_geometry_scale_to_tmin(V3 orig, float geometry_scale) { return (len3(orig) + geometry_scale) * RPTR_RAY_EPSILON; }
+RP_DEV float rp_geometry_scale_to_tmin(V3 orig, float geometry_scale) { return (len3_ieee(orig) + geometry_scale) * RPTR_RAY_EPSILON; } // (IEEE in both builds: dmath.h)

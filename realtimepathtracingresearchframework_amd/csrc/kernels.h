@@ -123,7 +123,7 @@ RP_DEV bool rp_primary_ray_ex(const RpFrame &f, uint32_t p, RpRng &rng, V3 &dir,
         du_dv[0] = du;
         du_dv[1] = dv;
     }
-    dir = norm3(point.x * du + point.y * dv + tl);
+    dir = norm3_ieee(point.x * du + point.y * dv + tl); // (IEEE in both builds of the shading stages: the first extend and a first shade that makes the ray again agree)
     return true;
 }
 // the generator of path p at a later bounce: index / pixel recomputed, the state `s` from the path state
@@ -579,7 +579,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     // :578-580
                     float approx_tri_solid_angle = len3(hit.geo_normal);
                     hit.geo_normal = hit.geo_normal / approx_tri_solid_angle;
-                    approx_tri_solid_angle *= fabsf(dot3(hit.geo_normal, ray_dir)) / (hit.dist * hit.dist);
+                    approx_tri_solid_angle *= rp_fdiv(fabsf(dot3(hit.geo_normal, ray_dir)), hit.dist * hit.dist);
                     // :582-606
                     total_t += hit.dist;
                     const RpTexCoord tc = TEX ? rp_hit_texcoord(hit.uv, tex_fp, ray_dir, hit.geo_normal, hit.tangent, hit.bitangent_l, total_t) : rp_texcoord(hit.uv);
@@ -606,7 +606,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         t_y = t_y * hit.bitangent_l;
                         const float4 tx = rp_texture_lod(sc, mp.normal_map, hit.uv, float(bounce)); // :642-648
                         V3 map_nrm = v3(2.0f * tx.x - 1.0f, 2.0f * tx.y - 1.0f, 1.0f * tx.z - 0.0f);
-                        map_nrm.z = sqrtf(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
+                        map_nrm.z = rp_fsqrt(fmaxf(1.0f - map_nrm.x * map_nrm.x - map_nrm.y * map_nrm.y, 0.0f));
                         const V3 t_z = f.sp.normal_z_scale * nn;
                         nn = norm3((t_x * map_nrm.x + t_y * map_nrm.y) + t_z * map_nrm.z);
                     }
@@ -615,7 +615,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         const float nw = dot3(w_o, nn);
                         const float gnw = dot3(w_o, gn);
                         if (nw * gnw <= 0.0f) {
-                            const float blend = gnw / (gnw - nw);
+                            const float blend = rp_fdiv(gnw, gnw - nw);
                             nn = norm3(mix3(gn, nn, blend - RP_EPSILON));
                         }
                     }
@@ -633,7 +633,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     }
                     if (output_channel == 0 && !eq3(emit, v3s(0.0f))) {
                         // wpdf_direct_light, nee_interface.glsl:52-61 + lights_linear.glsl:129-137
-                        const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * (1.0f / (float(f.num_bins) * approx_tri_solid_angle));
+                        const float light_pdf = (1.0f - f.sp.sun_radiance[3]) * rp_frcp(float(f.num_bins) * approx_tri_solid_angle);
                         const float w = rp_nee_mis(prev_bounce_pdf, light_pdf);
                         illum = illum + w * scatter_throughput * emit;
                     }
@@ -654,7 +654,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                         sel_sample = rp_draw2<TABLE>(f, rng, rp_bounce_dim(bounce));      // DIM_LIGHT_SEL_1
                         if (LIGHTS && !(sel_sample.x <= sun_w)) {
                             nee_tri = true;
-                            sel_sample.x = (sel_sample.x - sun_w) / (1.0f - sun_w);
+                            sel_sample.x = rp_fdiv(sel_sample.x - sun_w, 1.0f - sun_w);
                             bin = rp_choose_light_bin(sc, f, sel_sample.x);
                         }
                     }
@@ -703,7 +703,7 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                 V3 light_dir = v3s(0.0f);
                 float light_dist = 2.e16f, light_pdf = 0.0f, mis_pdf = 0.0f;
                 if (!nee_tri) {
-                    sel_sample.x /= sun_w;
+                    sel_sample.x = rp_fdiv(sel_sample.x, sun_w);
                     light_dir = rp_sample_sun_dir(ld3(f.sp.sun_dir), f.sp.sun_cos_angle, dir_sample);
                     light_pdf = rp_sun_dir_pdf(f.sp.sun_cos_angle);
                     nee_l = nee_l + (v3s(1.0f) / v3s(light_pdf)) * (ld3(f.sp.sun_radiance) / sun_w);
@@ -841,7 +841,9 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
 #endif
 template <int VARIANT, bool LIGHTS, bool TEX, bool TABLE>
 constexpr int rp_shade_waves() { return (VARIANT == RPTR_VARIANT_SIMPLE && !LIGHTS && !TEX && !TABLE) ? RP_SHADE_WAVES_LEAN : RP_SHADE_WAVES; }
-template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool TABLE>
+// MATH: the build of the shading arithmetic (dmath.h RP_FAST_MATH) -- part of the kernel's NAME only, so that the IEEE and the fast build of
+// one instantiation (k_shade.hip / k_tail.hip compiled twice) are two symbols of the library
+template <int VARIANT, bool FIRST, bool LIGHTS, bool TEX, bool TABLE, int MATH = RP_FAST_MATH>
 __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>())) void rp_k_shade(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *order,
                                                   const uint32_t *count_ptr, uint32_t *next_queue, uint32_t *next_count, uint32_t *shadow_count,
                                                   RpCounters *ctr) {
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(256, (rp_shade_waves<VARIANT, LIGHTS, TEX, TABLE>()
 // them to the end -- extend, shade, connect per bounce on block-local lists in LDS, the same device code as the stand-alone
 // kernels (results are bit-identical, tests/test_gpu_parity.py) -- before it takes the next chunk.
 #define RP_TAIL_CHUNK 256
-template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE>
+template <int VARIANT, bool LIGHTS, bool TEX, bool ALPHA, bool SINGLE, bool TABLE, int MATH = RP_FAST_MATH>
 __global__ __launch_bounds__(256, 1) void rp_k_tail(RpScene sc, RpFrame f, RpPathState ps, RpShadowRays sq, const uint32_t *queue, RpCounters *ctr,
                                                     int first_bounce, int *gstack) {
     // One arena for the phases that take turns (round 4): the LDS stacks of the closest-hit traversal, the shade phase's

@@ -18,6 +18,7 @@
 #include <array>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -131,10 +132,15 @@ struct FrameCtx {
 // (A/B runs of an unmodified host, tools/ab.sh) -- read once per handle, in rptr_hip_create. Nothing else in the library reads the
 // environment (GPU_MAX_HW_QUEUES is the HIP runtime's variable, RPTR_FRAMES_IN_FLIGHT overrides RptrCreateInfo.frames_in_flight).
 enum RpOpt : int {
-    OPT_FLATTEN, OPT_FLATTEN_MAX_TRIS, OPT_BVH_BUILDER, OPT_DEVICE_BUILD_MIN_TRIS, OPT_REBRAID, OPT_TLAS_COLLAPSE, OPT_COLLAPSE, OPT_PRESPLIT_DENSITY,
-    OPT_PRESPLIT_BUDGET_PCT, OPT_HOST_PLOC, OPT_PLOC_TOP, OPT_PLOC_LEAF, OPT_TRAVERSE_NODE_MIN, OPT_TRAVERSE_REFILL_MIN, OPT_LDS_TOP, OPT_SINGLE_INSTANCE,
-    OPT_MAX_BATCH_FRAMES, OPT_MAX_BATCH_SPP, OPT_PATH_BUDGET_MB, OPT_BLOCKS_PER_CU, OPT_SIDE_CONNECT, OPT_AOVS, OPT_TAIL_BOUNCE, OPT_TAIL_THRESHOLD,
-    OPT_STAGE_TIMING, OPT_REGROUP, OPT_COMM_TRANSPORT, OPT_COMM_PRIORITY, OPT_COMM_SELF, OPT_QUIET, OPT_TRAVERSE_FETCH, OPT_COUNT
+    // supported: documented in include/rptr_hip.h "Options", enumerated by rptr_hip_option_count / rptr_hip_option_name
+    OPT_FLATTEN, OPT_FLATTEN_MAX_TRIS, OPT_BVH_BUILDER, OPT_DEVICE_BUILD_MIN_TRIS, OPT_TRAVERSE_NODE_MIN, OPT_TRAVERSE_REFILL_MIN, OPT_SINGLE_INSTANCE, OPT_MAX_BATCH_FRAMES,
+    OPT_MAX_BATCH_SPP, OPT_PATH_BUDGET_MB, OPT_BLOCKS_PER_CU, OPT_SIDE_CONNECT, OPT_AOVS, OPT_TAIL_BOUNCE, OPT_TAIL_THRESHOLD,
+    OPT_STAGE_TIMING, OPT_COMM_TRANSPORT, OPT_COMM_PRIORITY, OPT_QUIET, OPT_TRAVERSE_FETCH, OPT_FAST_MATH,
+    OPT_PUBLIC_COUNT,
+    // experiments that were measured and not adopted (profiles/r03_notes.md, r05_notes.md): reachable as "experimental.<key>" and through their
+    // environment variables, not enumerated, no promise that they stay
+    OPT_REBRAID = OPT_PUBLIC_COUNT, OPT_TLAS_COLLAPSE, OPT_COLLAPSE, OPT_PRESPLIT_DENSITY, OPT_PRESPLIT_BUDGET_PCT, OPT_HOST_PLOC, OPT_PLOC_TOP, OPT_PLOC_LEAF, OPT_LDS_TOP, OPT_REGROUP, OPT_COMM_SELF,
+    OPT_COUNT
 };
 struct RpOptDesc {
     const char *key, *env; // env: atoll of the variable unless parse_option_env knows better (names, pairs)
@@ -145,17 +151,8 @@ static const RpOptDesc g_opt_desc[OPT_COUNT] = {
     {"flatten_max_tris", "RPTR_FLATTEN_MAX_TRIS", 1ll << 26, 0, 1ll << 31}, // ... up to this many instanced triangles (~150 bytes each)
     {"bvh_builder", "RPTR_BVH_BUILDER", 0, 0, 2},                 // 0 auto, 1 host (binned SAH), 2 device (PLOC)
     {"device_build_min_tris", "RPTR_DEVICE_BUILD_MIN_TRIS", 2ll << 20, 0, 1ll << 31},
-    {"rebraid", "RPTR_REBRAID", 0, 0, 64},                        // instance records per instance in the top level; 0 auto (4 from 16 instances on)
-    {"tlas_collapse", "RPTR_TLAS_COLLAPSE", 0, 0, 2},             // rptr::COLLAPSE_* of the top level
-    {"collapse", "RPTR_COLLAPSE", -1, -1, 2},                     // rptr::COLLAPSE_* of the bottom-level trees; -1: per tree (bvh_build.h)
-    {"presplit_density", "RPTR_PRESPLIT", 0, 0, 1 << 30},         // triangle pre-splitting of host-built static trees (0 off)
-    {"presplit_budget_pct", nullptr, 100, 0, 10000},              // ... extra references allowed, % of the triangle count
-    {"host_ploc", "RPTR_HOST_PLOC", 0, 0, 1024},                  // > 0: the host states the device builder's clustering with this radius
-    {"ploc_top", "RPTR_PLOC_TOP", 0, 0, 1ll << 31},               // clusters at which the PLOC clustering stops (0: RP_PLOC_TOP)
-    {"ploc_leaf", "RPTR_PLOC_LEAF", 0, 0, 7},
     {"traverse_node_min", "RPTR_TRAVERSE_PRESET", -1, -1, 64},    // dtraverse.h thresholds; -1: chosen per scene at set_scene
     {"traverse_refill_min", nullptr, -1, -1, 64},
-    {"lds_top", "RPTR_LDS_TOP", 0, 0, 1},
     {"single_instance", "RPTR_NO_SINGLE_INSTANCE", 1, 0, 1},      // queries of scenes with one instance record start inside it
     {"max_batch_frames", "RPTR_MAX_BATCH_FRAMES", 8, 1, 16},      // frames (output images) a launch sequence may hold          [initialize]
     {"max_batch_spp", "RPTR_MAX_BATCH_SPP", 0, 0, 64},            // sample slots in flight per frame context; 0: from the budget [initialize]
@@ -166,18 +163,35 @@ static const RpOptDesc g_opt_desc[OPT_COUNT] = {
     {"tail_bounce", "RPTR_TAIL_BOUNCE", -1, -1, RP_MAX_BOUNCES},  // -1 adaptive, 0 no tail kernel, k: from bounce k
     {"tail_threshold", "RPTR_TAIL_THRESHOLD", 65536, 0, 1 << 30},
     {"stage_timing", "RPTR_STAGE_TIMING", 0, 0, 2},               // events per stage for RptrStats.*_time_ms: a diagnostic (level 2: ~0.06 ms per 1080p frame)
-    {"regroup_materials", "RPTR_REGROUP", 0, 0, 1},
     {"comm_transport", "RPTR_COMM_TRANSPORT", 0, 0, 3},           // 0 auto, 1 rccl, 2 copy, 3 peer                              [comm init]
     {"comm_priority", "RPTR_COMM_PRIORITY", 1, 0, 1},
-    {"comm_self", "RPTR_COMM_SELF", 0, 0, 1},
     {"quiet", "RPTR_QUIET", 0, 0, 1},
     {"traverse_fetch", "RPTR_TRAVERSE_FETCH", 0, 0, 4096},        // queue entries a traversal wave takes per pool at most (multiple of 64); 0: per scene, with the thresholds
+    {"fast_math", "RPTR_FAST_MATH", 0, 0, 1},                     // the shading stages' division / square root: 0 IEEE (the oracle's bits), 1 the hardware's 1-ulp rcp / sqrt / rsq (dmath.h)
+    // ---- experimental.<key>
+    {"rebraid", "RPTR_REBRAID", 0, 0, 64},                        // instance records per instance in the top level; 0 auto (4 from 16 instances on)
+    {"tlas_collapse", "RPTR_TLAS_COLLAPSE", 0, 0, 2},             // rptr::COLLAPSE_* of the top level
+    {"collapse", "RPTR_COLLAPSE", -1, -1, 2},                     // rptr::COLLAPSE_* of the bottom-level trees; -1: per tree (bvh_build.h)
+    {"presplit_density", "RPTR_PRESPLIT", 0, 0, 1 << 30},         // triangle pre-splitting of host-built static trees (0 off)
+    {"presplit_budget_pct", nullptr, 100, 0, 10000},              // ... extra references allowed, % of the triangle count
+    {"host_ploc", "RPTR_HOST_PLOC", 0, 0, 1024},                  // > 0: the host states the device builder's clustering with this radius
+    {"ploc_top", "RPTR_PLOC_TOP", 0, 0, 1ll << 31},               // clusters at which the PLOC clustering stops (0: RP_PLOC_TOP)
+    {"ploc_leaf", "RPTR_PLOC_LEAF", 0, 0, 7},
+    {"lds_top", "RPTR_LDS_TOP", 0, 0, 1},
+    {"regroup_materials", "RPTR_REGROUP", 0, 0, 1},
+    {"comm_self", "RPTR_COMM_SELF", 0, 0, 1},
 };
 struct RpOptions {
     long long v[OPT_COUNT];
     bool from_env[OPT_COUNT];
 };
-static RpOptions &process_default_options() {
+// the process defaults (rptr_hip_set_option(NULL, ..)): hosts with one thread per GPU create handles side by side, so reads and writes go
+// through one lock and readers get a copy
+static std::mutex &process_default_lock() {
+    static std::mutex m;
+    return m;
+}
+static RpOptions &process_default_storage() {
     static RpOptions o = [] {
         RpOptions d;
         for (int k = 0; k < OPT_COUNT; ++k) {
@@ -188,9 +202,19 @@ static RpOptions &process_default_options() {
     }();
     return o;
 }
+static RpOptions process_default_options() {
+    std::lock_guard<std::mutex> g(process_default_lock());
+    return process_default_storage();
+}
+static void set_process_default_option(int k, long long value) {
+    std::lock_guard<std::mutex> g(process_default_lock());
+    process_default_storage().v[k] = value;
+}
 static int find_option(const char *key) {
     if (!key) return -1;
-    for (int k = 0; k < OPT_COUNT; ++k)
+    const bool experimental = !strncmp(key, "experimental.", 13);
+    if (experimental) key += 13;
+    for (int k = experimental ? (int)OPT_PUBLIC_COUNT : 0; k < (experimental ? (int)OPT_COUNT : (int)OPT_PUBLIC_COUNT); ++k)
         if (!strcmp(key, g_opt_desc[k].key)) return k;
     return -1;
 }
@@ -372,22 +396,11 @@ void sync_options(rptr_hip *h) {
 // Hardware queues. Every frame context renders on a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
 // queues (default 4): streams that share a queue serialise, and the schedule bench.py measures (11 contexts) needs one queue per
 // context + the caller's stream + the communication stream. The runtime reads the variable ONCE, when the process makes its first HIP
-// call -- so the library sets it (a) when it is loaded (constructor below: 16, only if the variable is unset) and (b) raises it in the
-// first rptr_hip_create when more contexts are asked for, which still works when that create is the process's first HIP call (the C++
-// hosts: bin/rptr_hip, host/render_group.hpp). When the host initialised HIP before loading the library with fewer queues than the
-// contexts need, the create says so once on stderr (RPTR_QUIET=1 silences it); nothing else can be done from here.
+// call. The variable belongs to the HOST: the library edits it only when the host says so (RptrCreateInfo.flags &
+// RPTR_CREATE_SET_HW_QUEUES: bin/rptr_hip does; round 5 did it from a load-time constructor, a surprise for an embedding host), and then
+// only in a create that may still be the process's first HIP call. Otherwise it reads the variable and says once on stderr when the frame
+// contexts outnumber the queues (option "quiet" silences it).
 static bool g_hw_queues_set_by_library = false;
-static int g_hw_queues_at_load = -1; // what the variable held before this library touched it (-1: unset = the runtime's default of 4)
-__attribute__((constructor)) static void rptr_hip_set_default_hw_queues() {
-    // NOTE: a process-global side effect of loading this library (INTEGRATION.md "Hardware queues"): the variable is set for the whole host
-    // process, and only takes effect when the process has not made a HIP call yet
-    const char *e = getenv("GPU_MAX_HW_QUEUES");
-    g_hw_queues_at_load = e ? atoi(e) : -1;
-    if (!e) {
-        setenv("GPU_MAX_HW_QUEUES", "16", 0);
-        g_hw_queues_set_by_library = true;
-    }
-}
 // did the host initialise HIP before this library could set the variable? hipGetDeviceCount-style calls do not tell; what does: whether a
 // primary context is already active on device 0 when the first handle is created
 static bool hip_was_initialised_before_us() {
@@ -396,29 +409,31 @@ static bool hip_was_initialised_before_us() {
     return hipDevicePrimaryCtxGetState(0, &flags, &active) == hipSuccess && active != 0;
 }
 
-static void ensure_hw_queues(int frames_in_flight) {
+// may_set: RptrCreateInfo.flags & RPTR_CREATE_SET_HW_QUEUES -- the host lets this create edit the process's environment. Without it the
+// library only reads the variable and says (once, on stderr) when the contexts outnumber the queues.
+static void ensure_hw_queues(int frames_in_flight, bool may_set) {
     static bool first_create = true;
     if (const char *s = getenv("RPTR_FRAMES_IN_FLIGHT")) frames_in_flight = atoi(s);
     const int want = std::max(1, std::min(frames_in_flight, 16)) + 2; // + the caller's stream + the communication stream
     const char *e = getenv("GPU_MAX_HW_QUEUES");
-    int have = e ? atoi(e) : 4;
-    // the library's own setenv only counts when the runtime had not read the variable yet: a host that initialised HIP first (torch,
-    // bench.py) runs with what the variable held BEFORE this library was loaded
-    if (first_create && g_hw_queues_set_by_library && hip_was_initialised_before_us()) {
-        have = g_hw_queues_at_load > 0 ? g_hw_queues_at_load : 4;
-        g_hw_queues_set_by_library = false; // (nothing of ours to raise any more)
-    }
+    const int have = e ? atoi(e) : 4;
     if (have < want) {
-        if (first_create && (g_hw_queues_set_by_library || !e)) { // ours to raise; effective when no HIP call has been made yet
+        // ours to raise when the host said so and the variable is unset (or was set by an earlier create of this library). The setenv comes
+        // BEFORE any HIP call of this create: the first one makes the runtime read the variable.
+        if (may_set && first_create && (!e || g_hw_queues_set_by_library)) {
             char buf[16];
-            snprintf(buf, sizeof buf, "%d", want);
+            snprintf(buf, sizeof buf, "%d", std::max(want, 16));
             setenv("GPU_MAX_HW_QUEUES", buf, 1);
             g_hw_queues_set_by_library = true;
-        } else if (effective_default_options().v[OPT_QUIET] == 0) {
+            if (hip_was_initialised_before_us() && effective_default_options().v[OPT_QUIET] == 0)
+                fprintf(stderr, "rptr_hip: RPTR_CREATE_SET_HW_QUEUES came too late -- the process already uses HIP with GPU_MAX_HW_QUEUES=%d; %d frame contexts "
+                                "want %d hardware queues (streams that share a queue serialise)\n", have, want - 2, want);
+        } else if (frames_in_flight > 1 && effective_default_options().v[OPT_QUIET] == 0) {
             static bool warned = false;
             if (!warned)
                 fprintf(stderr, "rptr_hip: GPU_MAX_HW_QUEUES=%d but %d frame contexts want %d hardware queues (streams that share a queue serialise); "
-                                "set GPU_MAX_HW_QUEUES>=%d before the process's first HIP call\n", have, want - 2, want, want);
+                                "set GPU_MAX_HW_QUEUES>=%d before the process's first HIP call%s\n", have, want - 2, want, want,
+                        may_set ? "" : ", or pass RPTR_CREATE_SET_HW_QUEUES in RptrCreateInfo.flags from a process that has not used HIP yet");
             warned = true;
         }
     }
@@ -1407,6 +1422,11 @@ const char *rptr_hip_last_error(const rptr_hip_t *h) { return h ? h->last_error.
 
 int rptr_hip_abi_version(void) { return RPTR_HIP_ABI_VERSION; }
 
+#ifndef RP_BUILD_ID
+#define RP_BUILD_ID "unknown"
+#endif
+const char *rptr_hip_build_id(void) { return RP_BUILD_ID; }
+
 int rptr_hip_bvh_build_info(rptr_hip_t *h, int32_t *out_device_built, float *out_build_ms, float *out_device_ms) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");
     if (out_device_built) *out_device_built = h->bvh_device_built ? 1 : 0;
@@ -1430,7 +1450,7 @@ int rptr_hip_create(const RptrCreateInfo *info, rptr_hip_t **out) {
         return fail(nullptr, RPTR_E_INVALID, "rptr_hip_create: RptrCreateInfo.abi_version is %d, this library implements version %d of include/rptr_hip.h "
                                              "(set abi_version = RPTR_HIP_ABI_VERSION; struct fields that used to be padding carry meaning now)",
                     info->abi_version, RPTR_HIP_ABI_VERSION);
-    ensure_hw_queues(info ? info->frames_in_flight : 1);
+    ensure_hw_queues(info ? info->frames_in_flight : 1, info && (info->flags & RPTR_CREATE_SET_HW_QUEUES) != 0u);
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
     if (e != hipSuccess || n_dev <= 0)
@@ -2594,7 +2614,7 @@ static void launch_shade(rptr_hip *h, FrameCtx &c, int variant, const RpScene &s
     // without emissive triangles and with all NEE probability on the sun the light-sampling branch is dead code
     const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
     const RpLaunch l = {(unsigned)grid_for(h, h->path_capacity), c.stream, nullptr, nullptr};
-    rp_launch_shade(variant, l, bounce == 0, lights, h->uses_textures,
+    rp_launch_shade(variant, h->opt.v[OPT_FAST_MATH] != 0, l, bounce == 0, lights, h->uses_textures,
                     f.rng_variant != RPTR_RNG_VARIANT_UNIFORM || f.rp.enable_raster_taa != 0, scene, f, c.ps, c.sq, order,
                     (const uint32_t *)&c.counters->bounce[bounce].queue_count, c.queue[out], &c.counters->bounce[bounce + 1].queue_count,
                     &c.counters->bounce[bounce].shadow_count, c.counters);
@@ -2962,7 +2982,7 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
                     if (side && b > 0) HIP_TRY(h, hipStreamWaitEvent(c.stream, c.ev_side, 0)); // join: connect(b-1) on the side stream
                     const bool lights = (h->num_lights > 0 && !h->lights_disabled) || f.sp.sun_radiance[3] < 1.0f;
                     const bool full = h->uses_textures || h->uses_alpha; // one instantiation serves textured and alpha-tested scenes
-                    rp_launch_tail(variant, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng_later, scn.dscene, f, c.ps, c.sq,
+                    rp_launch_tail(variant, h->opt.v[OPT_FAST_MATH] != 0, timed_launch(c.stream, 3, (unsigned)h->tail_blocks), lights, full, single, table_rng_later, scn.dscene, f, c.ps, c.sq,
                                    (const uint32_t *)c.queue[in], c.counters, b, c.gstack);
                     break;
                 }
@@ -3104,7 +3124,7 @@ int rptr_hip_set_option(rptr_hip_t *h, const char *key, int64_t value) {
     if (value < g_opt_desc[k].lo || value > g_opt_desc[k].hi)
         return fail(h, RPTR_E_INVALID, "rptr_hip_set_option: %s = %lld is outside [%lld, %lld]", key, (long long)value, g_opt_desc[k].lo, g_opt_desc[k].hi);
     if (!h) { // the process default: what new handles (and the handle-less rptr_hip_build_bvh_host) start from
-        process_default_options().v[k] = value;
+        set_process_default_option(k, value);
         return RPTR_OK;
     }
     if (h->opt.from_env[k]) return RPTR_OK; // the environment variable of this option is set: the experimenter's override stands (rptr_hip_get_option tells)
@@ -3117,13 +3137,17 @@ int rptr_hip_get_option(const rptr_hip_t *h, const char *key, int64_t *out_value
         *out_value = (int64_t)h->rebuild_failures;
         return RPTR_OK;
     }
+    if (h && key && out_value && !strcmp(key, "sample_slots")) { // (read-only: the sample slots a frame context holds once initialize has sized
+        *out_value = (int64_t)h->max_batch_spp;                  // the path state -- "max_batch_spp" or what the budget allows; 0 before initialize)
+        return RPTR_OK;
+    }
     const int k = find_option(key);
     if (k < 0 || !out_value) return fail(nullptr, RPTR_E_INVALID, "rptr_hip_get_option: unknown option \"%s\" or NULL result", key ? key : "(null)");
     *out_value = h ? h->opt.v[k] : effective_default_options().v[k];
     return RPTR_OK;
 }
-int rptr_hip_option_count(void) { return OPT_COUNT; }
-const char *rptr_hip_option_name(int index) { return index >= 0 && index < OPT_COUNT ? g_opt_desc[index].key : nullptr; }
+int rptr_hip_option_count(void) { return OPT_PUBLIC_COUNT; }
+const char *rptr_hip_option_name(int index) { return index >= 0 && index < OPT_PUBLIC_COUNT ? g_opt_desc[index].key : nullptr; }
 
 int rptr_hip_wait(rptr_hip_t *h, uint64_t ticket, RptrStats *out_stats) {
     if (!h) return fail(nullptr, RPTR_E_INVALID, "NULL handle");

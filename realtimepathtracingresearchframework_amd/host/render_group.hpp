@@ -14,10 +14,10 @@ namespace rptr {
 class RenderGroup {
 public:
     // devices: HIP ordinals, one rank each (the same ordinal may appear several times: a test rig on one GPU)
-    RenderGroup(const std::vector<int> &devices, int stripe_rows = 8, int frames_in_flight = RenderHip::MAX_SWAP_BUFFERS) {
+    RenderGroup(const std::vector<int> &devices, int stripe_rows = 8, int frames_in_flight = RenderHip::MAX_SWAP_BUFFERS, uint32_t create_flags = 0u) {
         const int n = (int)devices.size();
         if (n < 1) throw std::runtime_error("RenderGroup: no devices");
-        for (int i = 0; i < n; ++i) ranks_.emplace_back(new RenderHip(devices[(size_t)i], i, n, stripe_rows, nullptr, frames_in_flight));
+        for (int i = 0; i < n; ++i) ranks_.emplace_back(new RenderHip(devices[(size_t)i], i, n, stripe_rows, nullptr, frames_in_flight, create_flags));
     }
     int size() const { return (int)ranks_.size(); }
     RenderHip &rank(int i) { return *ranks_[(size_t)i]; }
@@ -59,6 +59,11 @@ public:
     }
     void set_option(const char *key, int64_t value) { // before initialize / set_scene (include/rptr_hip.h "Options")
         for (auto &r : ranks_) r->set_option(key, value);
+    }
+    int64_t get_option(const char *key) const { // the smallest value over the ranks (limits: "sample_slots")
+        int64_t v = ranks_[0]->get_option(key);
+        for (auto &r : ranks_) v = std::min(v, r->get_option(key));
+        return v;
     }
     // The reference's frame loop (app.cpp:453-469) on ONE device: begin_frame / draw_frame / end_frame with the application's CommandStream*
     // (render_hip.hpp: non-null = submitted, two frames in flight, statistics two frames late). A group of several devices renders such a

@@ -58,9 +58,11 @@ public:
     // frames_in_flight: the library's frame contexts. The reference's backend owns MAX_SWAP_BUFFERS sets of per-frame resources whatever the
     // application does with them (vulkan/render_vulkan.h:128-131); so does this one by default: draw_frame(cmd_stream != nullptr) then has
     // two frames in flight, draw_frame(nullptr) renders one at a time on the same handle.
+    // create_flags: RPTR_CREATE_*. 0 (an embedded plugin): the library touches nothing outside its handle; a host that owns its process
+    // (bin/rptr_hip) passes RPTR_CREATE_SET_HW_QUEUES so that every frame context's stream gets a hardware queue (INTEGRATION.md "Hardware queues").
     explicit RenderHip(int device_ordinal = 0, int rank = 0, int world_size = 1, int stripe_rows = 32, void *hip_stream = nullptr,
-                       int frames_in_flight = MAX_SWAP_BUFFERS) {
-        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream, frames_in_flight, RPTR_HIP_ABI_VERSION};
+                       int frames_in_flight = MAX_SWAP_BUFFERS, uint32_t create_flags = 0u) {
+        RptrCreateInfo info{device_ordinal, rank, world_size, stripe_rows, hip_stream, frames_in_flight, RPTR_HIP_ABI_VERSION, create_flags, 0u};
         int rc = rptr_hip_create(&info, &h_);
         if (rc != RPTR_OK) throw std::runtime_error(std::string("rptr_hip_create: ") + rptr_hip_last_error(nullptr));
         contexts_ = frames_in_flight < 1 ? 1 : (frames_in_flight > 16 ? 16 : frames_in_flight);

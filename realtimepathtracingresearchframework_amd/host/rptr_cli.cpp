@@ -403,7 +403,7 @@ int main(int argc, char **argv) {
         // frame contexts: the reference's two swap buffers; what --frames-in-flight asks for; four for a queued --validation accumulation
         // (its launch sequences are independent of the display: the deeper queue is what fills the GPU)
         const int contexts = std::max(frames_in_flight, (validation && !synchronous && !freeze_frame) ? 4 : (int)rptr::RenderHip::MAX_SWAP_BUFFERS);
-        rptr::RenderGroup backend(devices, stripe_rows, contexts);
+        rptr::RenderGroup backend(devices, stripe_rows, contexts, RPTR_CREATE_SET_HW_QUEUES); // (this program owns its process: a hardware queue per frame context)
         backend.initialize(width, height);
         backend.set_scene(scene.desc());
         base.params.batch_spp = batch_spp;
@@ -457,7 +457,11 @@ int main(int argc, char **argv) {
             // frame repeats its samples and cannot share a sequence).
             if (!synchronous && !freeze_frame && (backend.size() == 1 || !every_frame)) { // (a group's gather assembles the LAST frame of a sequence)
                 const int total_frames = (target_spp + batch_spp - 1) / batch_spp;
-                const int per_seq = got_frames_per_launch ? frames_per_launch : std::max(1, std::min(8, 16 / std::max(1, batch_spp)));
+                // (a launch sequence must fit the sample slots the handle holds: 16 up to ~2.9 Mpixel per rank, fewer above -- 12 at 1440p, 5 at 4K,
+                // rptr_hip_get_option "sample_slots"; a frame of more samples than that is split by the library itself, one frame per sequence)
+                const int slots = (int)std::max<int64_t>(1, backend.get_option("sample_slots"));
+                const int fit = std::max(1, slots / std::max(1, batch_spp));
+                const int per_seq = std::min(fit, got_frames_per_launch ? frames_per_launch : std::max(1, std::min(8, 16 / std::max(1, batch_spp))));
                 struct Pending {
                     rptr::RenderGroup::Sequence q;
                     int first_frame;

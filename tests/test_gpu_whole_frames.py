@@ -10,6 +10,10 @@ tests of rounds 1-2 compared bands of 12-16 rows of 1080; the oracle renders a w
       world-space tree against the oracle walking the exported tree
   C5  animated 1 M-triangle scene, 3840x2160, 2 spp, after the last of several per-frame refits
 
+Every configuration is rendered by BOTH builds of the shading arithmetic (option "fast_math", csrc/dmath.h): 0 = IEEE division / square root
+(the default: the oracle's operations statement by statement), 1 = the hardware's 1-ulp reciprocal / square root. Both against the same
+oracle image and to the same assertions; the IEEE build additionally to RMSE < 1e-4 (it measures 1e-8 ... 6e-5).
+
 Every test prints RMSE / max-abs / the number of pixels off by more than 1e-3 and asserts: RMSE < 1e-3 (north_star's tolerance) over
 the whole frame, identical NaN masks, identical coverage (the alpha channel: 0 where the camera ray left the scene), and equal ray
 counts up to the branch flips an ulp of libm causes (1e-3 relative)."""
@@ -27,7 +31,15 @@ from realtimepathtracingresearchframework_amd import abi, backend, scenes
 pytestmark = pytest.mark.gpu
 
 
-def compare_whole_frame(tag, got, ref, st=None, ost=None, coverage=True):
+MATH_BUILDS = [0, 1]   # option "fast_math"
+IEEE_RMSE_TOL = 1e-4    # the IEEE build (same operations as the oracle up to libm's transcendental functions)
+
+
+def math_tag(m):
+    return "fast_math=%d (%s)" % (m, "hardware rcp / sqrt / rsq" if m else "IEEE")
+
+
+def compare_whole_frame(tag, got, ref, st=None, ost=None, coverage=True, rmse_tol=RMSE_TOL):
     rmse, same_nan, maxabs = image_error(got, ref)
     d = np.abs(got[..., :3] - ref[..., :3])
     off = int((np.nan_to_num(d, nan=0.0).max(axis=2) > 1e-3).sum())
@@ -37,7 +49,7 @@ def compare_whole_frame(tag, got, ref, st=None, ost=None, coverage=True):
         line += "  | rays closest %d / %d, shadow %d / %d (GPU / oracle)" % (st.raw.rays_closest, ost.rays_closest, st.raw.rays_shadow, ost.rays_shadow)
     print(line)
     assert same_nan, tag + ": NaN masks differ"
-    assert rmse < RMSE_TOL, line
+    assert rmse < rmse_tol, line
     if coverage:
         assert np.array_equal(got[..., 3], ref[..., 3]), tag + ": coverage (alpha) differs in %d pixels" % int((got[..., 3] != ref[..., 3]).sum())
     if st is not None and ost is not None:
@@ -67,7 +79,16 @@ def test_c1_cornell_256x256_1spp_through_the_validation_cli(tmp_path):
     # the PFM holds RGB; coverage comes from the same backend through the Python mirror, which must hold the very same RGB bits
     got, st, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF)
     assert np.array_equal(img.view(np.uint32), np.ascontiguousarray(got[..., :3]).view(np.uint32))
-    compare_whole_frame("C1 cornell-32", got, ref, st, ost)
+    compare_whole_frame("C1 cornell-32", got, ref, st, ost, rmse_tol=IEEE_RMSE_TOL)
+    # ... and the other build of the shading arithmetic, through the same program (the option's environment override)
+    prefix = str(tmp_path / "c1f")
+    p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", "1", "--img", str(W), str(H), "--pfm"], capture_output=True, text=True,
+                       env=dict(os.environ, RPTR_FAST_MATH="1"))
+    assert p.returncode == 0, p.stderr
+    imgf = read_pfm(sorted(glob.glob(prefix + "_*.pfm"))[0])
+    gotf, stf, _ = gpu_render(s, W, H, 1, abi.VARIANT_GLTF, options={"fast_math": 1})
+    assert np.array_equal(imgf.view(np.uint32), np.ascontiguousarray(gotf[..., :3]).view(np.uint32))
+    compare_whole_frame("C1 cornell-32, " + math_tag(1), gotf, ref, stf, ost)
 
 
 # ---------------------------------------------------------------- C2
@@ -75,11 +96,12 @@ def test_c2_whole_frame_1m_triangles_1080p_4spp_diffuse():
     s = scenes.grid_1m()
     assert s.num_tris() == 1_000_000
     W, H, spp = 1920, 1080, 4
-    got, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_SIMPLE)
     osc = O.OracleScene(s)
     osc.build_bvh()
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE)
-    compare_whole_frame("C2 grid-1M diffuse", got, ref, st, ost)
+    for m in MATH_BUILDS:
+        got, st, _ = gpu_render(s, W, H, spp, abi.VARIANT_SIMPLE, options={"fast_math": m})
+        compare_whole_frame("C2 grid-1M diffuse, " + math_tag(m), got, ref, st, ost, rmse_tol=RMSE_TOL if m else IEEE_RMSE_TOL)
 
 
 # ---------------------------------------------------------------- C3
@@ -94,16 +116,18 @@ def test_c3_whole_frame_gltf_area_lights_1080p_8spp(flatten, monkeypatch):
     s = scenes.grid_1m_lights()
     assert s.num_tris() == 1_000_512 and len(s.lights) >= 512 and len(s.instances) == 2
     W, H, spp = 1920, 1080, 8
-    got, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True)
-    info = r.bvh_build_info()
-    flat = bool(np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)[0, 15] & 1)   # RPTR_BVH_INSTANCE_FLAT on record 0
-    assert flat == (flatten is None) and r.get_option("flatten") == (-1 if flatten is None else 0)
-    r.close()
-    print("C3 flatten=%s: %s" % (flatten, info))
     osc = O.OracleScene(s)
     osc.build_bvh()
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF)
-    compare_whole_frame("C3 grid-1M glTF + 512 emitters (%s)" % ("one flattened tree" if flatten is None else "two-level"), got, ref, st, ost)
+    for m in MATH_BUILDS:
+        got, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True, options={"fast_math": m} if m else None)   # (m = 0: nothing set at all)
+        info = r.bvh_build_info()
+        flat = bool(np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)[0, 15] & 1)   # RPTR_BVH_INSTANCE_FLAT on record 0
+        assert flat == (flatten is None) and r.get_option("flatten") == (-1 if flatten is None else 0) and r.get_option("fast_math") == m
+        r.close()
+        print("C3 flatten=%s: %s" % (flatten, info))
+        compare_whole_frame("C3 grid-1M glTF + 512 emitters (%s), %s" % ("one flattened tree" if flatten is None else "two-level", math_tag(m)), got, ref, st, ost,
+                            rmse_tol=RMSE_TOL if m else IEEE_RMSE_TOL)
 
 
 # ---------------------------------------------------------------- C4
@@ -129,7 +153,11 @@ def test_c4_whole_frame_forest_10m_instanced_triangles_1080p_4spp(flatten, monke
         mode = O.BVH_OWN
     r.close()
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, bvh_mode=mode)
-    compare_whole_frame("C4 forest-10M %s" % ("flattened, oracle on the exported tree" if flatten else "two-level, oracle on its own tree"), got, ref, st, ost)
+    what = "flattened, oracle on the exported tree" if flatten else "two-level, oracle on its own tree"
+    compare_whole_frame("C4 forest-10M %s, %s" % (what, math_tag(0)), got, ref, st, ost, rmse_tol=IEEE_RMSE_TOL)
+    # (the device-built tree of the flattened forest is deterministic: the second handle walks the tree the oracle imported)
+    gotf, stf, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, options={"fast_math": 1})
+    compare_whole_frame("C4 forest-10M %s, %s" % (what, math_tag(1)), gotf, ref, stf, ost)
 
 
 # ---------------------------------------------------------------- C5
@@ -140,27 +168,31 @@ def test_c5_whole_frame_animated_4k_2spp_after_the_last_refit():
     assert s.num_tris() == 1_000_000
     W, H, spp = 3840, 2160, 2
     times = [k / 60 for k in range(1, 5)]
-    r = backend.RenderHip(frames_in_flight=3)
-    r.initialize(W, H)
-    r.set_scene(s)
-    cam = s.camera_params()
-    queue, last, st = [], np.zeros((H, W, 4), np.float32), None
-    for t in times:   # every frame: new vertices on the device, refit, render (frames in flight as bench.py --animate runs them)
-        buf = torch.from_numpy(np.ascontiguousarray(scenes.grid_positions(NX, NZ, t), dtype=np.float32)).cuda()
-        torch.cuda.synchronize()
-        r.update_vertices_device(0, buf.data_ptr(), buf.shape[0])
-        r.refit()
-        queue.append(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=spp))
-        torch.cuda.synchronize()   # (the buffer is borrowed until the copy has run)
-        if len(queue) >= 3:
-            st = r.wait(queue.pop(0))
-    for ticket in queue:
-        st = r.wait(ticket)
-    assert r.readback_framebuffer(last) == W * H * 4
-    r.close()
+    images = {}
+    for m in MATH_BUILDS:
+        r = backend.RenderHip(frames_in_flight=3, options={"fast_math": m})
+        r.initialize(W, H)
+        r.set_scene(s)
+        cam = s.camera_params()
+        queue, last, st = [], np.zeros((H, W, 4), np.float32), None
+        for t in times:   # every frame: new vertices on the device, refit, render (frames in flight as bench.py --animate runs them)
+            buf = torch.from_numpy(np.ascontiguousarray(scenes.grid_positions(NX, NZ, t), dtype=np.float32)).cuda()
+            torch.cuda.synchronize()
+            r.update_vertices_device(0, buf.data_ptr(), buf.shape[0])
+            r.refit()
+            queue.append(r.render_async(backend.RenderConfiguration(cam, active_variant=abi.VARIANT_SIMPLE, reset_accumulation=True), spp=spp))
+            torch.cuda.synchronize()   # (the buffer is borrowed until the copy has run)
+            if len(queue) >= 3:
+                st = r.wait(queue.pop(0))
+        for ticket in queue:
+            st = r.wait(ticket)
+        assert r.readback_framebuffer(last) == W * H * 4
+        r.close()
+        images[m] = (last, st)
     osc = O.OracleScene(s)
     osc.set_dynamic_vertices(0, scenes.grid_positions(NX, NZ, times[-1]))
     osc.build_bvh()
     # the 4th reset of the handle: frame_offset = 3 frames x 2 samples (begin_frame's rule, render_vulkan.cpp:1937-1941)
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_SIMPLE, frame_offset=(len(times) - 1) * spp)
-    compare_whole_frame("C5 animated grid-1M, frame %d" % len(times), last, ref, st, ost)
+    for m in MATH_BUILDS:
+        compare_whole_frame("C5 animated grid-1M, frame %d, %s" % (len(times), math_tag(m)), images[m][0], ref, images[m][1], ost, rmse_tol=RMSE_TOL if m else IEEE_RMSE_TOL)

@@ -29,6 +29,17 @@ def read(tag, counter):
     return out
 
 
+def library_build_id():
+    """rptr_hip_build_id() of the library the passes ran on (the one in the tree, or RPTR_HIP_LIB): bench.py flags counters of another build"""
+    import ctypes
+    try:
+        lib = ctypes.CDLL(os.environ.get("RPTR_HIP_LIB") or os.path.join(ROOT, "realtimepathtracingresearchframework_amd", "librptr_hip.so"))
+        lib.rptr_hip_build_id.restype = ctypes.c_char_p
+        return lib.rptr_hip_build_id().decode()
+    except Exception:
+        return None
+
+
 def main():
     """make_traffic.py <build tag> [<workload key> [<bench args>]]: the passes gpurun_out/pmc_<key>_{fetch,write,insts,cycles,tcc} -> the
     entry `workloads[<key>]` of profiles/pmc_traffic.json (the other workloads' entries are kept)"""
@@ -46,7 +57,7 @@ def main():
     doc = {"bench_args": bench_args,
            "source": "rocprofv3 --kernel-trace --pmc <counters> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* | SQ_*_CYCLES) over "
                      "bench.py --profile-pass --steps 3 --warmup 1 <bench_args> (frames one at a time, RPTR_TAIL_BOUNCE=2); tools/pmc.sh + tools/make_traffic.py",
-           "build": tag,
+           "build": tag, "library_build_id": library_build_id(),
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE reads 1/2, MI355X_MICROARCH.md)", "kernels": {}}
     for k in fetch:
         calls, f = fetch[k]
