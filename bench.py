@@ -396,6 +396,51 @@ def valu_frame(pmc, ms_per_step, valu_peak, launches):
             "pipelined_frac": round(total / (ms_per_step * 1e-3) / 1e9 / valu_peak, 4)}
 
 
+SERIAL_KEYS = ("ext", "con", "shade", "tail", "resolve", "other", "gpu")
+
+
+def combine_ranks(dist, elapsed, ext_ms, gather_host_ms, serial, rays, latency_1_ms):
+    """The N > 1 bookkeeping of the contract, over the control-plane group (gloo: CPU tensors; tests/test_tiles_gloo.py runs it with two and three
+    ranks): the timed region is the SLOWEST rank's (MAX), and so are the exclusive stage times; rays are SUMMED (value = all ranks' rays / that
+    time); every rank's one-frame-at-a-time latency of its own share travels to rank 0 as a list (a frame is done when its slowest rank is).
+    Returns (elapsed, ext_ms, gather_host_ms, serial, rays, [latency.1 of rank 0, 1, ...])."""
+    import torch
+    t = torch.tensor([elapsed, ext_ms, gather_host_ms] + [serial[k] for k in SERIAL_KEYS], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    vals = [float(v) for v in t]
+    elapsed, ext_ms, gather_host_ms = vals[:3]
+    serial = dict(serial)
+    for k, v in zip(SERIAL_KEYS, vals[3:]):
+        serial[k] = v
+    tr = torch.tensor([float(rays)], dtype=torch.float64)
+    dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+    lat = torch.zeros(dist.get_world_size(), dtype=torch.float64)
+    lat[dist.get_rank()] = float(latency_1_ms or 0.0)
+    dist.all_reduce(lat, op=dist.ReduceOp.SUM)
+    return elapsed, ext_ms, gather_host_ms, serial, int(tr[0]), [round(float(x), 4) for x in lat]
+
+
+def gather_report(gather_mode, gather_transport, probe, batch_frames, batched_gather, gather_gpu_ms, gather_host_ms, gathers_timed, bytes_per_step, note,
+                  latency_1_per_rank):
+    """the `gather` object of an N > 1 line: which data plane ran (and what the probe found), how many frames one collective moves, what it cost,
+    and every rank's latency of its own share"""
+    return {"transport": gather_transport,
+            "mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h); --gather ipc: every rank writes its rows into rank 0's frame through hipIpc-mapped memory",
+                     "torch": "tile copy + torch.distributed.gather (nccl group) + index_select",
+                     "host": "tile copy + torch.distributed.gather (gloo, tiles staged through the host) + index_select"}[gather_mode],
+            "probe": probe,
+            "frames_per_gather": (batch_frames if (batched_gather and gather_transport is not None) else 1),
+            "frames_per_gather_note": "the library's gather moves the frames of a launch sequence in ONE collective (rptr_hip_gather_batch); BENCH_GATHER_PER_FRAME=1: one per frame",
+            "gather_ms": round(gather_gpu_ms, 4) if gather_gpu_ms is not None else None,
+            "gather_ms_note": "mean GPU time of one gather on rank 0's communication stream (receive of N-1 tiles + assembly); asynchronous: it runs "
+                              "beside the frames in flight, inside the timed region",
+            "host_ms_per_step": round(gather_host_ms, 4), "gathers": gathers_timed,
+            "bytes_per_step": bytes_per_step, "note": note,
+            "latency_1_ms_per_rank": latency_1_per_rank,
+            "latency_1_note": "one frame at a time, every rank its own share of the frame (before the gather): a frame is as late as its slowest rank -- the "
+                              "figure that scales a real-time renderer, next to `value`'s throughput with frames queued ahead"}
+
+
 def main():
     args = parse_args()
     if args.rccl_probe:
@@ -851,18 +896,10 @@ def main():
     else:
         cnt_ext = cnt_con = cnt
 
-    if world > 1:
-        rdev = "cpu"   # (the control plane is a gloo group)
-        t = torch.tensor([elapsed, ext_ms, gather_host_ms] + [serial[k] for k in ("ext", "con", "shade", "tail", "resolve", "other", "gpu")],
-                         dtype=torch.float64, device=rdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        vals = [float(v) for v in t]
-        elapsed, ext_ms, gather_host_ms = vals[:3]
-        for k, v in zip(("ext", "con", "shade", "tail", "resolve", "other", "gpu"), vals[3:]):
-            serial[k] = v
-        tr = torch.tensor([float(rays)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
-        rays = int(tr[0])
+    latency_1_per_rank = None
+    if world > 1:   # (the control plane is a gloo group)
+        elapsed, ext_ms, gather_host_ms, serial, rays, latency_1_per_rank = combine_ranks(dist, elapsed, ext_ms, gather_host_ms, serial, rays,
+                                                                                             (latency.get("1") or {}).get("ms_per_frame"))
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -1059,18 +1096,8 @@ def main():
         "roofline": roofline,
     }
     if world > 1:
-        out["gather"] = {"transport": gather_transport,
-                         "mode": {"native": "library: grouped ncclSend/ncclRecv on a communication stream + assembly kernel (csrc/host_comm.h); --gather ipc: every rank writes its rows into rank 0's frame through hipIpc-mapped memory",
-                                  "torch": "tile copy + torch.distributed.gather (nccl group) + index_select",
-                                  "host": "tile copy + torch.distributed.gather (gloo, tiles staged through the host) + index_select"}[gather_mode],
-                         "probe": probe,
-                         "frames_per_gather": (batch_frames if (batched_gather and gather_transport is not None) else 1),
-                         "frames_per_gather_note": "the library's gather moves the frames of a launch sequence in ONE collective (rptr_hip_gather_batch); BENCH_GATHER_PER_FRAME=1: one per frame",
-                         "gather_ms": round(gather_gpu_ms, 4) if gather_gpu_ms is not None else None,
-                         "gather_ms_note": "mean GPU time of one gather on rank 0's communication stream (receive of N-1 tiles + assembly); asynchronous: it runs "
-                                           "beside the frames in flight, inside the timed region",
-                         "host_ms_per_step": round(gather_host_ms, 4), "gathers": gathers_timed,
-                         "bytes_per_step": W * H * 16 - my_bytes, "note": gather_note}
+        out["gather"] = gather_report(gather_mode, gather_transport, probe, batch_frames, batched_gather, gather_gpu_ms, gather_host_ms, gathers_timed,
+                                      W * H * 16 - my_bytes, gather_note, latency_1_per_rank)
 
     # ---- boundary: the same workload through the drop-in's own host code -- bin/rptr_hip (host/rptr_cli.cpp: C++, the RenderBackend-shaped
     # adapter host/render_hip.hpp over the C ABI, nothing of this Python file) with bench.py's camera path: (a) the reference's frame loop,

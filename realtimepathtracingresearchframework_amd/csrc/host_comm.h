@@ -529,17 +529,29 @@ int rptr_hip_gather_batch(rptr_hip_t *h, int n_frames) {
     const int nb = n_frames;
     const float4 *src = nullptr;
     FrameCtx *owner = nullptr;
+    if (h->comm->transport == COMM_IPC && (!h->comm->ipc_flags || !h->comm->ipc_frame[0]))
+        return fail(h, RPTR_E_INVALID, "rptr_hip_comm_ipc_init has not been called on this handle"); // (before anything is counted or begun)
     int rc = comm_begin(h, src, owner, nb);
     if (rc) {
         // (COMM_IPC: the ranks count their gathers themselves. A rank that cannot take part in gather g -- a caller error on this rank only --
-        // still counts it, so that gather g + 1 means the same slot and the same flag values on every rank again; rank 0's wait for this
-        // rank's part of gather g times out and is reported, csrc/host_comm.h comm_ipc_check)
-        if (h->comm && h->comm->transport == COMM_IPC) h->comm->gathers++;
+        // still counts it, so that gather g + 1 means the same slot and the same flag values on every rank again, AND still publishes its flag
+        // of gather g: rank 0 its gate -- the peers would otherwise spin in rp_k_flag_wait until the poll's own 30 s time-out, and their next
+        // wait could then pass on gate g + 1 and scatter into a slot rank 0 is still reading --, a peer its done word, so that rank 0 assembles
+        // the frame without this rank's rows instead of waiting for them. The error is this rank's return code.)
+        RptrComm *c = h->comm;
+        if (c && c->transport == COMM_IPC) {
+            const uint32_t g = (uint32_t)(c->gathers + 1);
+            if (c->stream) {
+                uint32_t *flag = h->rank == 0 ? &c->ipc_flags->gate : &c->ipc_flags->done[h->rank];
+                hipLaunchKernelGGL(rp_k_flag_set, dim3(1), dim3(1), 0, c->stream, flag, g, (const uint32_t *)nullptr);
+                (void)hipGetLastError();
+            }
+            c->gathers++;
+        }
         return rc;
     }
     if (h->comm->transport == COMM_IPC) {
         RptrComm *c = h->comm;
-        if (!c->ipc_flags || !c->ipc_frame[0]) return fail(h, RPTR_E_INVALID, "rptr_hip_comm_ipc_init has not been called on this handle");
         const uint32_t g = (uint32_t)(c->gathers + 1); // the same number on every rank: a gather is a collective
         const int slot = comm_slot(c);
         const int rows = local_row_count(h->height, h->stripe_rows, h->rank, h->world);

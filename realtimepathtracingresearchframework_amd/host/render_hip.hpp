@@ -279,7 +279,6 @@ public:
     // ray_result_buffer. ray_query_buffer() / ray_result_buffer() are the device addresses.
     void enable_ray_queries(const int max_queries, const int max_queries_per_pixel = 0) {
         check(rptr_hip_enable_ray_queries(h_, max_queries, max_queries_per_pixel, &ray_query_buffer_, &ray_result_buffer_));
-        max_queries_ = max_queries;
     }
     void *ray_query_buffer() const { return ray_query_buffer_; }
     void *ray_result_buffer() const { return ray_result_buffer_; }
@@ -291,7 +290,7 @@ public:
     // convenience over HOST arrays (tests, tools): rptr_hip_trace uploads, traces, reads back
     bool render_ray_queries(const RptrRenderRayQuery *queries, int num_queries, float *results4) {
         if (num_queries < 0) return false;
-        if (num_queries > max_queries_) max_queries_ = num_queries; // (host arrays: rptr_hip_trace sizes its own staging; the budget only bounds the device buffers)
+        // (rptr_hip_trace sizes its own staging: the budget of enable_ray_queries only bounds the device buffers)
         check(rptr_hip_trace(h_, queries, num_queries, results4));
         return true;
     }
@@ -345,7 +344,6 @@ private:
     RptrSceneParams scene_params_{};
     bool have_scene_params_ = false;
     int variant_ = RPTR_VARIANT_GLTF;
-    int max_queries_ = 512 * 512;
     void *ray_query_buffer_ = nullptr, *ray_result_buffer_ = nullptr;
     RptrStats last_{};
 };

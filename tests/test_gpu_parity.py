@@ -537,6 +537,7 @@ def test_bench_n_ranks_with_the_ipc_gather_on_one_device():
     g = d["gather"]
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["value"] > 0
     assert g["transport"] == "ipc" and g["frames_per_gather"] == 4 and g["gathers"] == 2 and g["mode"].startswith("library")
+    assert len(g["latency_1_ms_per_rank"]) == 2 and all(x > 0 for x in g["latency_1_ms_per_rank"])     # every rank's own share, one frame at a time
 
 
 # ---------------------------------------------------------------- fuzz
@@ -809,19 +810,20 @@ def test_tail_kernel_is_bit_identical_to_the_standalone_launches(scene_name, var
 
 
 # ---------------------------------------------------------------- flattened instances (RPTR_FLATTEN)
+@pytest.mark.library_defaults
 @pytest.mark.parametrize("scene_name", ["two_level_test", "alpha_test"])
 def test_flattened_scene_matches_the_oracle_on_the_same_tree(scene_name):
-    """one world-space tree over all instanced triangles: every ray walks it like the oracle does (results and visit counts), the
-    image agrees with the oracle on that tree, hits name the right instance (shading reads the mesh streams through it), and the
-    two-level walk of the same scene is matched up to the rounding of the pre-transformed triangles"""
-    import os
+    """THE LIBRARY'S DEFAULTS (no option, no environment variable: ADVICE r5 -- the configuration a host that sets nothing gets) on
+    multi-instance scenes with several parameterized meshes per mesh (two_level_test: instances that resolve their materials through their
+    own geometry records) and with alpha-tested materials (alpha_test): one world-space tree over all instanced triangles; every ray walks
+    it like the oracle does (results and visit counts), the image agrees with the oracle on that tree, hits name the right instance, primitive
+    and material (shading reads the mesh streams through the instance record), and the two-level walk of the same scene is matched up to the
+    rounding of the pre-transformed triangles"""
     s = getattr(scenes, scene_name)()
     W, H, spp = 128, 96, 2
-    os.environ["RPTR_FLATTEN"] = "1"
-    try:
-        img, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True, count=True)
-    finally:
-        del os.environ["RPTR_FLATTEN"]
+    img, st, r = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, keep=True, count=True)
+    assert r.get_option("flatten") == -1 and r.get_option("fast_math") == 0        # nothing was set
+    assert bool(np.frombuffer(np.ascontiguousarray(r.export_bvh()[2]).tobytes(), np.int32).reshape(-1, 32)[0, 15] & 1)   # RPTR_BVH_INSTANCE_FLAT
     osc = _oracle_on_device_tree(s, r)
     ref, ost = osc.render(W, H, spp, variant=abi.VARIANT_GLTF, bvh_mode=O.BVH_IMPORTED, count=True)
     rmse, same, _ = image_error(img, ref)
@@ -842,7 +844,7 @@ def test_flattened_scene_matches_the_oracle_on_the_same_tree(scene_name):
     assert np.allclose(res[both, :2], brute[both, :2], atol=2e-4)
     r.close()
     # and the scene rendered through the two-level tree looks the same
-    img2, _, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF)
+    img2, _, _ = gpu_render(s, W, H, spp, abi.VARIANT_GLTF, options={"flatten": 0})
     if scene_name == "alpha_test":     # fractional alphas draw from the path's generator in candidate order: another tree, other draws
         assert abs(float(np.nanmean(img[..., :3])) - float(np.nanmean(img2[..., :3]))) < 0.03 * float(np.nanmean(img2[..., :3]))
     else:
