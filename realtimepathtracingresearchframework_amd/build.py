@@ -21,7 +21,7 @@ UNITS = [
 # (k_shade / k_tail: once per gpu-program variant and per build of the shading arithmetic -- IEEE division / square root, the oracle's bits,
 # or the hardware's 1-ulp reciprocal / square root: option "fast_math", csrc/dmath.h)
 SOURCES = sorted({u[1] for u in UNITS})
-HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_comm.h", "lbvh.h", "ploc.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
+HEADERS = ["kernels.h", "kernels_misc.h", "launch.h", "host_state.h", "host_bvh.inl", "host_scene.inl", "host_frame.inl", "host_access.inl", "host_comm.h", "lbvh.h", "ploc.h", "dtraverse.h", "bvh4.h", "dshade.h", "dmath.h", "bvh_build.h",
            "../../include/rptr_hip.h", "../../include/rptr_bvh.h"]
 OBJ_DIR = os.path.join(CSRC, "obj")
 
