@@ -1213,6 +1213,48 @@ void orc_footprint_probe(const float *dir, const float *dpdx, const float *dpdy,
     const mat2 R = reflect_footprint(vec3(dst_dir[0], dst_dir[1], dst_dir[2]), d, F);
     out[10] = R[0][0]; out[11] = R[0][1]; out[12] = R[1][0]; out[13] = R[1][1];
 }
+// calc_hit_attributes (hit.glsl:58-128 through the quantised overload :162-203) on one triangle: verts9 = va, vb, vc; nuv3 = the three
+// (oct normal | uv) words; n2w9 = normals_to_world column by column; mat_ids = four per-triangle ids (material_in < 0) -> out[0..2] normal,
+// [3..5] geo_normal, [6..8] tangent, [9] dist, [10] bitangent_l, [11..12] uv; returns the material id
+int orc_hit_attributes_probe(const float *verts9, const uint64_t *nuv3, int has_normals, int has_uvs, const float *n2w9, float t, float bu, float bv, int material_in,
+                             const uint8_t *mat_ids, float *out13) {
+    const mat3 verts(vec3(verts9[0], verts9[1], verts9[2]), vec3(verts9[3], verts9[4], verts9[5]), vec3(verts9[6], verts9[7], verts9[8]));
+    const mat3 n2w(vec3(n2w9[0], n2w9[1], n2w9[2]), vec3(n2w9[3], n2w9[4], n2w9[5]), vec3(n2w9[6], n2w9[7], n2w9[8]));
+    mat3 normals(vec3(0, 0, 0), vec3(0, 0, 0), vec3(0, 0, 0));
+    if (has_normals) normals = mat3(dequantize_normal(uint32_t(nuv3[0])), dequantize_normal(uint32_t(nuv3[1])), dequantize_normal(uint32_t(nuv3[2])));
+    mat3x2 uvs;
+    uvs.c[0] = uvs.c[1] = uvs.c[2] = vec2(0, 0);
+    if (has_uvs) {
+        uvs.c[0] = dequantize_uv(uint32_t(nuv3[0] >> 32));
+        uvs.c[1] = dequantize_uv(uint32_t(nuv3[1] >> 32));
+        uvs.c[2] = dequantize_uv(uint32_t(nuv3[2] >> 32));
+    }
+    const RTHit h = calc_hit_attributes(t, 0u, vec2(bu, bv), verts, n2w, normals, has_normals != 0, uvs, has_uvs != 0, material_in, mat_ids);
+    const float v[13] = {h.normal.x, h.normal.y, h.normal.z, h.geo_normal.x, h.geo_normal.y, h.geo_normal.z, h.tangent.x, h.tangent.y, h.tangent.z, h.dist, h.bitangent_l,
+                         h.uv.x, h.uv.y};
+    memcpy(out13, v, sizeof v);
+    return h.material_id;
+}
+// the Lambert BSDF (simple_bsdf.glsl:44-94): sample at u2, evaluate at wi_eval
+void orc_simple_probe(const float base_color[3], const float n3[3], const float wo3[3], const float u2[2], const float wi_eval3[3], float *wi3, float *weight3, float *pdf,
+                      float *mis_pdf, float *f3, float *wpdf) {
+    SimpleMaterial m;
+    m.base_color = vec3(base_color[0], base_color[1], base_color[2]);
+    m.roughness = 1.0f;
+    m.ior = 1.0f;
+    m.flags = 0u;
+    const vec3 n(n3[0], n3[1], n3[2]), wo(wo3[0], wo3[1], wo3[2]), wie(wi_eval3[0], wi_eval3[1], wi_eval3[2]);
+    vec3 wi(0, 0, 0);
+    const vec3 w = sample_simple_brdf(m, n, wo, wi, *pdf, *mis_pdf, vec2(u2[0], u2[1]));
+    const vec3 f = simple_bsdf(m, n, wo, wie);
+    *wpdf = simple_pdf(m, n, wo, wie);
+    wi3[0] = wi.x; wi3[1] = wi.y; wi3[2] = wi.z;
+    weight3[0] = w.x; weight3[1] = w.y; weight3[2] = w.z;
+    f3[0] = f.x; f3[1] = f.y; f3[2] = f.z;
+}
+void orc_linear_to_srgb(const float *x, int n, float *out) {
+    for (int i = 0; i < n; ++i) out[i] = linear_to_srgb(x[i]);
+}
 void orc_set_debug_pixel(int x, int y) { g_debug_px = x; g_debug_py = y; }
 #ifdef ORC_BASELINE
 void orc_set_node_hist(uint32_t *) {}
