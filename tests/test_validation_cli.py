@@ -1151,7 +1151,7 @@ def test_cli_renders_several_scene_files_like_the_merged_scene(tmp_path):
 @pytest.mark.gpu
 def test_cli_profiling_reproduces_the_benchmarks_schedule(tmp_path):
     """the C++ host gets the schedule bench.py measures -- 11 frame contexts x 4 frames per launch sequence, a hardware queue
-    per context (the library sets GPU_MAX_HW_QUEUES itself when nobody did: csrc/rptr_hip.hip ensure_hw_queues) -- and with it bench.py's
+    per context (bin/rptr_hip passes RPTR_CREATE_SET_HW_QUEUES: its first create sets GPU_MAX_HW_QUEUES when nobody did, csrc/host_state.h ensure_hw_queues) -- and with it bench.py's
     ms per frame on C2 (1 M triangles, 1080p, 4 spp, diffuse), within a few percent."""
     import json
     import re
