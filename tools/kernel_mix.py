@@ -9,9 +9,9 @@ LIB = next((a for a in sys.argv[1:] if a.endswith(".so")), os.path.join(ROOT, "r
 KERNELS = [
     ("extend_first", "_Z11rp_k_extendILb0ELb1ELb0ELb1ELb0EE"), ("extend", "_Z11rp_k_extendILb0ELb0ELb0ELb1ELb0EE"),
     ("connect", "_Z12rp_k_connectILb0ELb0ELb1EE"),
-    ("shade_first_lambert", "_Z10rp_k_shadeILi1ELb1ELb0ELb0ELb0EE"), ("shade_lambert", "_Z10rp_k_shadeILi1ELb0ELb0ELb0ELb0EE"),
-    ("shade_first_gltf_lights", "_Z10rp_k_shadeILi0ELb1ELb1ELb0ELb0EE"), ("shade_gltf_lights", "_Z10rp_k_shadeILi0ELb0ELb1ELb0ELb0EE"),
-    ("tail_lambert", "_Z9rp_k_tailILi1ELb0ELb0ELb0ELb1ELb0EE"),
+    ("shade_first_lambert", "_Z10rp_k_shadeILi1ELb1ELb0ELb0ELb0ELi0EE"), ("shade_lambert", "_Z10rp_k_shadeILi1ELb0ELb0ELb0ELb0ELi0EE"),
+    ("shade_first_gltf_lights", "_Z10rp_k_shadeILi0ELb1ELb1ELb0ELb0ELi0EE"), ("shade_gltf_lights", "_Z10rp_k_shadeILi0ELb0ELb1ELb0ELb0ELi0EE"),
+    ("tail_lambert", "_Z9rp_k_tailILi1ELb0ELb0ELb0ELb1ELb0ELi0EE"),
     ("resolve", "_Z12rp_k_resolve"),
 ]
 CLASSES = ["fma", "int", "pk", "cvt", "minmax", "cnd", "cmp", "trans", "mullo", "lane"]

@@ -34,7 +34,7 @@ python3 - $O <<'PY'
 import json,sys,glob,os
 for f in sorted(glob.glob(sys.argv[1]+"/bench_*.json")):
     try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); rf=d["roofline"]
+        d=json.JSONDecoder().raw_decode(open(f).read().strip().splitlines()[-1])[0]; rf=d["roofline"]   # (raw_decode: a profiler may append its own words to the line)
         print("%-36s ms/step %.3f Mrays/s %7.0f | excl extend %.3f ms valu_frac %s hbm_counter_frac %s algorithmic bytes over HBM peak %s | frame valu %s | latency 1/2 in flight %s / %s ms | bvh %s" % (
             os.path.basename(f), d["ms_per_step"], d["value"], rf["exclusive_ms_per_step"], rf["valu"]["frac"], rf["hbm_frac"], rf.get("algorithmic_frac_of_hbm_peak"), (rf["valu"]["frame"] or {}).get("pipelined_frac"),
             rf["latency"]["1"]["ms_per_frame"], (rf["latency"].get("2") or {}).get("ms_per_frame"), d["config"].get("bvh", {}).get("built_on")))
