@@ -61,16 +61,16 @@ namespace simple {
 #include "rendering/bsdfs/simple_bsdf.glsl"
 }
 
-static const int num_lights = 40;
-static TriLightData lights[num_lights + 16] = {}; // (padded with a zeroed bin: sample_tri_lights may read light_id == bin_end)
+static const int global_num_lights = 40; // (not `num_lights`: sample_tri_lights has a local of that name which these macros initialise, compile.cpp:21)
+static TriLightData lights[global_num_lights + 16] = {}; // (padded with a zeroed bin: sample_tri_lights may read light_id == bin_end)
 static int bin_size = 16;
 
 #define SCENE_GET_LIGHT_SOURCE(light_id) decode_tri_light(lights[light_id])
-#define SCENE_GET_LIGHT_SOURCE_COUNT() int(num_lights)
+#define SCENE_GET_LIGHT_SOURCE_COUNT() int(global_num_lights)
 // the megakernel's definitions (vulkan/pt_megakernel.glsl:101-103) over this driver's table
 #define BINNED_LIGHTS_BIN_MAX_SIZE 16
 #define BINNED_LIGHTS_BIN_SIZE int(bin_size)
-#define SCENE_GET_BINNED_LIGHTS_BIN_COUNT() ((int(num_lights) + (bin_size - 1)) / int(bin_size))
+#define SCENE_GET_BINNED_LIGHTS_BIN_COUNT() ((int(global_num_lights) + (bin_size - 1)) / int(bin_size))
 
 namespace binned {
 #include "rendering/mc/lights_linear.glsl"
@@ -288,7 +288,7 @@ int main() {
     }
     std::printf("],\n");
     // ---- triangle lights: a table of small emitters above the origin, queries below them
-    for (int k = 0; k < num_lights; ++k) {
+    for (int k = 0; k < global_num_lights; ++k) {
         const glm::vec3 c(6.0f * U(gen) - 3.0f, 2.0f + U(gen), 6.0f * U(gen) - 3.0f);
         const glm::vec3 a = c + 0.3f * unit(), b = c + 0.3f * unit(), d = c + 0.3f * unit();
         TriLightData &t = lights[k];
@@ -296,10 +296,10 @@ int main() {
         t.radiance_x = 1.0f + 9.0f * U(gen); t.radiance_y = 1.0f + 9.0f * U(gen); t.radiance_z = 1.0f + 9.0f * U(gen);
     }
     std::printf("\"lights\": [");
-    for (int k = 0; k < num_lights; ++k)
+    for (int k = 0; k < global_num_lights; ++k)
         std::printf("[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g]%s", lights[k].v0_x, lights[k].v0_y, lights[k].v0_z, lights[k].v1_x,
                     lights[k].v1_y, lights[k].v1_z, lights[k].v2_x, lights[k].v2_y, lights[k].v2_z, lights[k].radiance_x, lights[k].radiance_y, lights[k].radiance_z,
-                    k + 1 < num_lights ? ", " : "");
+                    k + 1 < global_num_lights ? ", " : "");
     std::printf("],\n\"tri_lights\": [\n");
     const int n_lights_q = 256;
     for (int i = 0; i < n_lights_q; ++i) {
