@@ -723,7 +723,11 @@ RP_DEV void rp_shade_body(const RpScene &sc, const RpFrame &f, const RpPathState
                     const float bsdf_pdf = rp_eval_bsdf_wpdf<VARIANT>(mat, nn, w_o, light_dir);
                     const float epsilon = rp_geometry_scale_to_tmin(ip_p, geometry_scale);
                     const bool needs_ray = (light_dist - 2.f * epsilon > 0.0f); // pt_megakernel.glsl:222-227
-                    if (needs_ray) my_shadow++; // the reference traces it even when bsdf_pdf < 0
+                    // rays_shadow counts the reference's visibility QUERY (nee.glsl:72-75 traces before it looks at the BSDF's pdf). The device only
+                    // queues a shadow ray when bsdf_pdf >= 0 -- a negative pdf contributes nothing either way -- so the counter would exceed the
+                    // traced rays by the negative-pdf samples; neither shipped BSDF returns one (rp_simple_pdf, rp_gltf_wpdf >= 0), so today the
+                    // two are equal and RptrStats.rays_shadow is exact.
+                    if (needs_ray) my_shadow++;
                     if (bsdf_pdf >= 0.0f) {
                         const V3 bsdf = rp_eval_bsdf<VARIANT>(mat, nn, w_o, light_dir);
                         const float w = rp_nee_mis(mis_pdf, bsdf_pdf);
