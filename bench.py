@@ -1127,7 +1127,7 @@ def main():
 
     # ---- the other BASELINE configurations, briefly ("let the driver see C3"): after the headline and outside --steps, one
     # short run of this file per configuration in a child process (its own handles; this process has closed its own) -- the pipelined
-    # schedule (40 steps), two frames in flight (what a reference-shaped host reaches), the exclusive stage split. C3 is the reference's
+    # schedule (100 steps), two frames in flight (what a reference-shaped host reaches), the exclusive stage split. C3 is the reference's
     # actual default renderer (glTF BSDF + binned-RIS NEE).
     if wkey == "c2" and not args.no_other_configs and not args.profile_pass:
         import subprocess
@@ -1135,7 +1135,7 @@ def main():
                 ("c4", ["--scene", "forest"]), ("c5", ["--animate", "--width", "3840", "--height", "2160", "--spp", "2"]))
         out["other_configs"] = {}
         for name, cfg_args in legs:
-            cmd = [sys.executable, os.path.abspath(__file__)] + cfg_args + ["--steps", "40", "--warmup", "3", "--no-cpu-baseline", "--no-boundary", "--no-other-configs",
+            cmd = [sys.executable, os.path.abspath(__file__)] + cfg_args + ["--steps", "100", "--warmup", "4", "--no-cpu-baseline", "--no-boundary", "--no-other-configs",
                                                                            "--sustained-seconds", "0.4"]   # (sustained + static-camera legs: C4's moving views cost 20 % more than its configuration's)
             t_leg = time.time()
             try:
