@@ -233,6 +233,31 @@ def test_validation_accumulates_in_launch_sequences_with_the_bits_of_synchronous
             assert np.array_equal(c.view(np.uint32), b.view(np.uint32)), ("frames per launch 2", batch_spp, k)
 
 
+@pytest.mark.gpu
+def test_queued_validation_fits_its_launch_sequences_to_the_sample_slots_of_a_large_frame(tmp_path):
+    """above ~2.9 Mpixel per rank a frame context holds fewer than 16 sample slots (rptr_hip_get_option "sample_slots": 5 at 4K with
+    the default path budget), and the queued --validation run used to ask for sequences of 16 samples regardless -- RPTR_E_INVALID, no image.
+    The CLI now clamps a sequence to the slots: a 4K run with 2-sample frames completes, and writes the synchronous loop's bits."""
+    exe = _build_cli(tmp_path)
+    path = str(tmp_path / "c.rpsc")
+    scenes.cornell32().dump(path)
+    W, H = 3840, 2160
+    outs = {}
+    for mode, extra in (("queued", []), ("sync", ["--synchronous"])):
+        prefix = str(tmp_path / ("big_" + mode))
+        p = subprocess.run([exe, path, "--validation", prefix, "--validation-spp", "8", "--batch-spp", "2", "--img", str(W), str(H), "--pfm"] + extra,
+                           capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-600:]
+        outs[mode] = read_pfm(prefix + "_0008.pfm")
+    assert outs["queued"].shape == (H, W, 3) and np.array_equal(outs["queued"].view(np.uint32), outs["sync"].view(np.uint32))
+    from realtimepathtracingresearchframework_amd import backend
+    r = backend.RenderHip()
+    assert r.get_option("sample_slots") == 0            # (sized by initialize)
+    r.initialize(W, H)
+    assert 1 <= r.get_option("sample_slots") < 16
+    r.close()
+
+
 def test_cli_rejects_bad_mode_combinations(tmp_path):
     exe = _build_cli(tmp_path)
     path = str(tmp_path / "c.rpsc")
