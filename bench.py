@@ -1139,7 +1139,7 @@ def main():
                                                                            "--sustained-seconds", "0.4"]   # (sustained + static-camera legs: C4's moving views cost 20 % more than its configuration's)
             t_leg = time.time()
             try:
-                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+                pr = subprocess.run(cmd, capture_output=True, text=True, timeout=180)   # (a leg takes ~12 s; a hung child must not hold the headline back)
                 line = [l for l in pr.stdout.splitlines() if l.startswith('{"metric"')]
                 if not line:
                     out["other_configs"][name] = {"note": "the child printed no result (rc %d): %s" % (pr.returncode, pr.stderr[-200:])}
