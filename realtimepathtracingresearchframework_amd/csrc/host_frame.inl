@@ -235,9 +235,8 @@ int rptr_hip_render_batch_cameras_async(rptr_hip_t *h, const RptrCamera *cameras
 
 extern "C++" {
 // camera: ONE camera for all frames of the sequence, or (per_frame_cameras) n_frames of them
-static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
-                             int count_traversal, uint64_t *out_tickets) {
-    const int reset_accumulation = reset_first;
+// what a render call may ask of this handle (RPTR_E_INVALID with the reason otherwise)
+static int check_render_arguments(rptr_hip_t *h, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames) {
     if (!h || !camera) return fail(h, RPTR_E_INVALID, "NULL argument");
     if (n_frames < 1) return fail(h, RPTR_E_INVALID, "n_frames must be >= 1");
     if (per_frame_cameras && n_frames > RP_BATCH_CAMS)
@@ -254,25 +253,11 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     if (variant != RPTR_VARIANT_GLTF && variant != RPTR_VARIANT_SIMPLE && variant != RPTR_VARIANT_GLTF_TRANSMISSION)
         return fail(h, RPTR_E_INVALID, "unknown variant %d", variant);
     if (spp < 1) return fail(h, RPTR_E_INVALID, "spp must be >= 1");
-    HIP_TRY(h, hipSetDevice(h->device));
-    FrameCtx &c = h->ctx[(size_t)h->next_ctx];
-    if (c.pending)
-        return fail(h, RPTR_E_INVALID, "all %zu frames in flight are busy: rptr_hip_wait for ticket %llu first", h->ctx.size(),
-                    (unsigned long long)c.ticket);
-    h->next_ctx = (h->next_ctx + 1) % (int)h->ctx.size();
-    const bool multi = h->ctx.size() > 1;
-    if (multi) { // this context's images are about to be rewritten: what was queued on the backend's stream so far still sees the old
-                 // ones (ev_dep below), a read-back issued after this submission would not
-        if ((int)(&c - h->ctx.data()) == h->output_ctx) h->output_overwritten = true;
-        if ((int)(&c - h->ctx.data()) == h->aov_ctx) h->aov_overwritten = true;
-    }
-    // begin_frame: render_vulkan.cpp:1937-1941
-    if (reset_accumulation) {
-        if (!h->freeze_frame) h->frame_offset += h->frame_id;
-        h->frame_id = 0;
-    }
-    const uint32_t frame_id_before = h->frame_id;
-    RpFrame f;
+    return RPTR_OK;
+}
+// the frame constants of a launch sequence (RpFrame: render / scene / lighting parameters, the camera basis of frame 0 and -- per_frame_cameras --
+// of every frame, the AOV view of the last frame, tiling and divisors, light bins); frame_id / sample bookkeeping is the caller's
+static void fill_frame_constants(rptr_hip_t *h, FrameCtx &c, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames, int reset_rest, RpFrame &f) {
     memset(&f, 0, sizeof(f));
     f.rp = h->params;
     f.sp = h->scene_params;
@@ -336,6 +321,34 @@ static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_f
     // so it is off unless asked for. The separate counting-sort pass of rounds 1-2 (rp_k_sort_*: three launches per bounce, one frame
     // context only, 0.4 ms per frame) lost on every configuration and is gone (profiles/r03_notes.md section 6).
     f.regroup_materials = h->opt.v[OPT_REGROUP] != 0 ? 1 : 0;
+}
+static int render_batch_impl(rptr_hip_t *h, const RptrCamera *camera, bool per_frame_cameras, int variant, int spp, int n_frames, int reset_first, int reset_rest,
+                             int count_traversal, uint64_t *out_tickets) {
+    const int reset_accumulation = reset_first;
+    {
+        const int rc_args = check_render_arguments(h, camera, per_frame_cameras, variant, spp, n_frames);
+        if (rc_args) return rc_args;
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    FrameCtx &c = h->ctx[(size_t)h->next_ctx];
+    if (c.pending)
+        return fail(h, RPTR_E_INVALID, "all %zu frames in flight are busy: rptr_hip_wait for ticket %llu first", h->ctx.size(),
+                    (unsigned long long)c.ticket);
+    h->next_ctx = (h->next_ctx + 1) % (int)h->ctx.size();
+    const bool multi = h->ctx.size() > 1;
+    if (multi) { // this context's images are about to be rewritten: what was queued on the backend's stream so far still sees the old
+                 // ones (ev_dep below), a read-back issued after this submission would not
+        if ((int)(&c - h->ctx.data()) == h->output_ctx) h->output_overwritten = true;
+        if ((int)(&c - h->ctx.data()) == h->aov_ctx) h->aov_overwritten = true;
+    }
+    // begin_frame: render_vulkan.cpp:1937-1941
+    if (reset_accumulation) {
+        if (!h->freeze_frame) h->frame_offset += h->frame_id;
+        h->frame_id = 0;
+    }
+    const uint32_t frame_id_before = h->frame_id;
+    RpFrame f;
+    fill_frame_constants(h, c, camera, per_frame_cameras, variant, spp, n_frames, reset_rest, f);
     size_t ev_cursor = 0;
     c.spans.clear();
     auto timed_on = [&](hipStream_t st, int kind, auto &&launch) {

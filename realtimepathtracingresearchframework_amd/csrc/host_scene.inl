@@ -1,22 +1,9 @@
 // host_scene.inl -- rptr_hip_set_scene (upload, device tables, shading records, per-context scene copies), vertex updates, refit and device rebuild
 // Part of the ONE translation unit rptr_hip.hip (included there, in this order: host_state.h, host_bvh.inl, host_scene.inl,
 // host_frame.inl, host_access.inl, host_comm.h): the host runtime split along its seams; no symbol changed.
-int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
-    if (!h || !s) return fail(h, RPTR_E_INVALID, "NULL argument");
-    HIP_TRY(h, hipSetDevice(h->device));
-    {
-        int rc0 = drain(h);
-        if (rc0) return rc0;
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (void *p : h->scene_allocs) {
-        (void)hipFree(p);
-    }
-    h->scene_allocs.clear();
-    h->bytes_scene = 0;
-    h->bytes_allocated = h->bytes_frame;
-    h->have_scene = false;
-    // ---- validation (what the reference host rejects or this build does not cover yet)
+// ---- set_scene, step by step (each returns RPTR_OK or the error it reported through fail())
+// what the reference host rejects or this build does not cover yet; sets uses_textures / uses_alpha
+static int scene_validate(rptr_hip *h, const RptrSceneDesc *s) {
     {
         const std::string bad = validate_scene_tables(s);
         if (!bad.empty()) return fail(h, RPTR_E_INVALID, "%s", bad.c_str());
@@ -51,15 +38,18 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
                 return fail(h, RPTR_E_INVALID, "material %u: textured parameter refers to texture %u of %u", m, RPTR_TEXTURE_ID(u), s->num_textures);
         }
     }
+    return RPTR_OK;
+}
+// textures (RGBA8, mip levels back to back) + the sRGB decode table
+static int scene_upload_textures(rptr_hip *h, const RptrSceneDesc *s, RpTexture *&d_textures, float *&d_srgb_lut) {
     int rc;
-    // ---- textures (RGBA8) + the sRGB decode table
+    d_textures = nullptr;
+    d_srgb_lut = nullptr;
     // paths through a scene with textures carry their texture footprint (kernels.h TEX; the tail kernel's textured instantiation also serves
     // alpha-tested scenes)
     if ((h->uses_textures || h->uses_alpha) && h->path_capacity)
         for (FrameCtx &c : h->ctx)
             if (!c.ps.footprint && (rc = dev_alloc(h, &c.ps.footprint, h->path_capacity, nullptr))) return rc;
-    RpTexture *d_textures = nullptr;
-    float *d_srgb_lut = nullptr;
     {
         std::vector<RpTexture> tex(s->num_textures);
         for (uint32_t t = 0; t < s->num_textures; ++t) {
@@ -86,8 +76,13 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
         if ((rc = dev_alloc(h, &d_srgb_lut, 256, &h->scene_allocs))) return rc;
         HIP_TRY(h, hipMemcpy(d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
     }
-    // ---- upload vertex streams, one allocation per stream
-    std::vector<const uint64_t *> d_qpos(s->num_geometries, nullptr), d_qnu(s->num_geometries, nullptr);
+    return RPTR_OK;
+}
+// the quantised vertex streams, one allocation per stream; dynamic meshes keep full-precision float positions next to them
+static int scene_upload_vertex_streams(rptr_hip *h, const RptrSceneDesc *s, std::vector<const uint64_t *> &d_qpos, std::vector<const uint64_t *> &d_qnu) {
+    int rc;
+    d_qpos.assign(s->num_geometries, nullptr);
+    d_qnu.assign(s->num_geometries, nullptr);
     for (uint32_t g = 0; g < s->num_geometries; ++g) {
         const RptrGeometryDesc &gd = s->geometries[g];
         uint64_t *dp = nullptr;
@@ -132,9 +127,14 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             h->master.mesh_dirty[m] = 2;
         }
     }
-    // ---- geometry records per (parameterized mesh, geometry): instanced_geometry[] (render_vulkan.cpp:2748-2850)
-    std::vector<RpGeomRecord> geoms;
-    std::vector<int> pmesh_base(s->num_parameterized_meshes, 0);
+    return RPTR_OK;
+}
+// geometry records per (parameterized mesh, geometry): instanced_geometry[] (render_vulkan.cpp:2748-2850)
+static int scene_geometry_records(rptr_hip *h, const RptrSceneDesc *s, const std::vector<const uint64_t *> &d_qpos, const std::vector<const uint64_t *> &d_qnu,
+                                  std::vector<RpGeomRecord> &geoms, std::vector<int> &pmesh_base) {
+    int rc;
+    geoms.clear();
+    pmesh_base.assign(s->num_parameterized_meshes, 0);
     for (uint32_t p = 0; p < s->num_parameterized_meshes; ++p) {
         const RptrParameterizedMeshDesc &pm = s->parameterized_meshes[p];
         const RptrMeshDesc &mesh = s->meshes[pm.mesh];
@@ -165,8 +165,10 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             prim_offset += gd.num_tris;
         }
     }
-    // ---- acceleration structure (host part, no device involved)
-    HostBvh B;
+    return RPTR_OK;
+}
+// the acceleration structure: per-mesh trees (host binned SAH, or the device's PLOC builder for large static sets), top level, encoding
+static int scene_build_acceleration_structure(rptr_hip *h, const RptrSceneDesc *s, std::vector<const uint64_t *> &d_qpos, std::vector<RpGeomRecord> &geoms, HostBvh &B) {
     {
         // large static triangle sets are built on the device (csrc/ploc.h) from the vertex streams uploaded above
         std::vector<uint8_t> mat_alpha(s->num_materials, 0);
@@ -202,27 +204,19 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             return fail(h, RPTR_E_UNSUPPORTED, "the acceleration structure of this scene needs a traversal stack of %d entries (limit %d)",
                         B.stack_need, capacity);
     }
-    h->h_nodes = std::move(B.nodes);
-    h->h_node_box = std::move(B.node_box);
-    h->h_tris = std::move(B.tris);
-    h->h_insts = std::move(B.insts);
-    h->num_tlas_insts = B.num_tlas_insts;
-    h->meshes = std::move(B.meshes);
-    h->mesh_root = std::move(B.mesh_root);
-    h->num_tlas_nodes = B.num_tlas_nodes;
-    h->flat_tris = B.flat_tris;
-    h->flat_nodes = B.flat_nodes;
-    memcpy(h->scene_lo, B.scene_lo, 12);
-    memcpy(h->scene_hi, B.scene_hi, 12);
-    // ---- refit: the top level by height (children before parents); the bottom-level trees of dynamic meshes are refitted bottom-up
-    // with arrival counters (lbvh.h rp_k_refit_up): per node its parent and the number of its inner children
-    std::vector<uint32_t> refit_list;
+    return RPTR_OK;
+}
+// refit tables: the top level by height (children before parents); the depth levels of every dynamic mesh's tree
+static int scene_refit_tables(rptr_hip *h, std::vector<uint32_t> &refit_list, std::vector<uint32_t> &h_blas_list, std::vector<std::array<uint2, RP_REFIT_LEVELS>> &h_levels) {
+    refit_list.clear();
+    h_blas_list.assign(h->h_nodes.size(), 0u);
+    h_levels.assign(h->meshes.size(), std::array<uint2, RP_REFIT_LEVELS>());
+    // (the bottom-level trees of dynamic meshes are refitted bottom-up with arrival counters, lbvh.h rp_k_refit_up: per node its parent and the
+    // number of its inner children)
     h->refit_levels_tlas.clear();
     h->has_dynamic = false;
     for (const MeshRt &mr : h->meshes) h->has_dynamic = h->has_dynamic || mr.dynamic;
     // depth levels of every dynamic mesh's tree (slot RP_REFIT_LEVELS - 1 - depth: ascending slot = deepest first)
-    std::vector<uint32_t> h_blas_list(h->h_nodes.size(), 0u);
-    std::vector<std::array<uint2, RP_REFIT_LEVELS>> h_levels(h->meshes.size());
     {
         const size_t nn = h->h_nodes.size();
         std::vector<int> height(nn, -1);
@@ -274,6 +268,122 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
             }
         }
     }
+    return RPTR_OK;
+}
+// the traversal's scheduling thresholds and pool size for this scene's trees (RpScene.node_min / refill_min / fetch_max)
+static void scene_traversal_preset(rptr_hip *h) {
+    // Scheduling thresholds of the traversal (dtraverse.h): a wave refills its idle lanes together once `refill_min` of them have finished,
+    // and leaves a node phase for a leaf phase once fewer than `node_min` lanes are at inner nodes. The defaults (48 / 10) were tuned on the
+    // height field; in a dense soup of overlapping primitive boxes -- the forest: 26 node visits per ray, node-phase lane utilisation 0.55
+    // instead of 0.67, a quarter of the lane slots waiting for a refill -- 32 / 16 are 5 % faster (C4 5.89 -> 5.61 ms) and 1.4 % slower on the
+    // height field (profiles/r03_notes.md section 7). The choice follows the tree: the surface-area cost of its largest bottom-level tree
+    // (sum of the inner children's box areas over the root's: 11 for the height field, 92 for the flattened forest). RPTR_TRAVERSE_PRESET=
+    // "node_min,refill_min" overrides (0,0 = the compile-time defaults).
+    {
+        double best_cost = 0.0;
+        size_t best_tris = 0;
+        auto half_area = [&](size_t n) {
+            const std::array<float, 6> &b = h->h_node_box[n];
+            const double dx = std::max(0.0f, b[3] - b[0]), dy = std::max(0.0f, b[4] - b[1]), dz = std::max(0.0f, b[5] - b[2]);
+            return dx * dy + dy * dz + dz * dx;
+        };
+        for (size_t m = 0; m < h->meshes.size(); ++m) {
+            const MeshRt &mr = h->meshes[m];
+            // (a mesh without a tree of its own is part of the flattened tree, which lies first: counted once, for mesh 0)
+            const size_t root = (size_t)h->mesh_root[m], count = (size_t)(mr.node_count > 0 ? mr.node_count : (m == 0 ? (int)h->flat_nodes : 0));
+            const size_t tris_m = mr.tri_count > 0 ? (size_t)mr.tri_count : (m == 0 ? h->flat_tris : 0);
+            if (!count || tris_m < best_tris || root >= h->h_nodes.size()) continue;
+            const double a0 = half_area(root);
+            if (!(a0 > 0.0)) continue;
+            double sum = 0.0;
+            for (size_t n = root; n < std::min(root + count, h->h_nodes.size()); ++n)
+                for (int k = 0; k < 4; ++k)
+                    if (h->h_nodes[n].child[k] >= 0) sum += half_area((size_t)h->h_nodes[n].child[k]);
+            best_cost = sum / a0;
+            best_tris = tris_m;
+        }
+        // ... times the same measure of the top level (all child boxes of its nodes, instance boxes included, over the scene's box: 1 for a
+        // single instance, ~ 6 for the forest's 1001 overlapping instances: the two-level forest gains the same 5 %, 8.38 -> 7.95 ms)
+        double tlas_cost = 1.0;
+        if (h->num_tlas_nodes > 0 && h->num_tlas_insts > 1) {
+            const double a0 = half_area(0);
+            double sum = 0.0;
+            for (int n = 0; n < h->num_tlas_nodes; ++n) {
+                const RptrBvh4Node &nd = h->h_nodes[(size_t)n];
+                for (int k = 0; k < 4; ++k) {
+                    if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
+                    double d[3];
+                    for (int a = 0; a < 3; ++a) d[a] = std::max(0.0, (double)((int)nd.qhi[a][k] - (int)nd.qlo[a][k])) * std::ldexp(1.0, (int)nd.exp[a] - 127);
+                    sum += d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+                }
+            }
+            if (a0 > 0.0) tlas_cost = std::max(1.0, sum / a0);
+        }
+        best_cost *= tlas_cost;
+        h->bvh_area_cost = best_cost;
+        int node_min = 0, refill_min = 0;
+        if (best_cost >= 24.0) { // (height fields: 10-12; the small forests of the tests: 29-35; C4: 90 flattened, 250-280 two-level)
+            node_min = 16;
+            refill_min = 32;
+        }
+        if (h->opt.v[OPT_TRAVERSE_NODE_MIN] >= 0) { // options "traverse_node_min" / "traverse_refill_min" (0, 0: the compile-time defaults)
+            node_min = (int)h->opt.v[OPT_TRAVERSE_NODE_MIN];
+            refill_min = (int)std::max(0ll, h->opt.v[OPT_TRAVERSE_REFILL_MIN]);
+        }
+        h->master.dscene.node_min = std::max(0, std::min(64, node_min));
+        h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
+        h->master.dscene.lds_top = h->opt.v[OPT_LDS_TOP] != 0 ? 1 : 0;
+        // ... and the size of a wave's pool of queue entries (dtraverse.h RP_FETCH: 256, four tiles of the first queue): 384 for the trees
+        // of the default preset -- one frame at a time 1.82 -> 1.76 ms, two in flight 1.45 -> 1.38 on C2, pipelined unchanged --, 256 for dense
+        // ones (the forest loses 4 % with 384; profiles/r05_notes.md section 19)
+        h->master.dscene.fetch_max = h->opt.v[OPT_TRAVERSE_FETCH] > 0 ? (int)std::max(64ll, h->opt.v[OPT_TRAVERSE_FETCH] / 64 * 64) : (best_cost >= 24.0 ? 0 : 384);
+    }
+}
+int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
+    if (!h || !s) return fail(h, RPTR_E_INVALID, "NULL argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    {
+        int rc0 = drain(h);
+        if (rc0) return rc0;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (void *p : h->scene_allocs) {
+        (void)hipFree(p);
+    }
+    h->scene_allocs.clear();
+    h->bytes_scene = 0;
+    h->bytes_allocated = h->bytes_frame;
+    h->have_scene = false;
+    int rc;
+    if ((rc = scene_validate(h, s))) return rc;
+    // ---- uploads: textures, vertex streams, geometry records
+    RpTexture *d_textures = nullptr;
+    float *d_srgb_lut = nullptr;
+    if ((rc = scene_upload_textures(h, s, d_textures, d_srgb_lut))) return rc;
+    std::vector<const uint64_t *> d_qpos, d_qnu;
+    if ((rc = scene_upload_vertex_streams(h, s, d_qpos, d_qnu))) return rc;
+    std::vector<RpGeomRecord> geoms;
+    std::vector<int> pmesh_base;
+    if ((rc = scene_geometry_records(h, s, d_qpos, d_qnu, geoms, pmesh_base))) return rc;
+    // ---- acceleration structure
+    HostBvh B;
+    if ((rc = scene_build_acceleration_structure(h, s, d_qpos, geoms, B))) return rc;
+    h->h_nodes = std::move(B.nodes);
+    h->h_node_box = std::move(B.node_box);
+    h->h_tris = std::move(B.tris);
+    h->h_insts = std::move(B.insts);
+    h->num_tlas_insts = B.num_tlas_insts;
+    h->meshes = std::move(B.meshes);
+    h->mesh_root = std::move(B.mesh_root);
+    h->num_tlas_nodes = B.num_tlas_nodes;
+    h->flat_tris = B.flat_tris;
+    h->flat_nodes = B.flat_nodes;
+    memcpy(h->scene_lo, B.scene_lo, 12);
+    memcpy(h->scene_hi, B.scene_hi, 12);
+    // ---- refit tables
+    std::vector<uint32_t> refit_list, h_blas_list;
+    std::vector<std::array<uint2, RP_REFIT_LEVELS>> h_levels;
+    if ((rc = scene_refit_tables(h, refit_list, h_blas_list, h_levels))) return rc;
     h->rebuild_epoch.assign(h->meshes.size(), 0);
     h->bvh_credit = 0;
     h->rebuild_cursor = 0;
@@ -372,72 +482,7 @@ int rptr_hip_set_scene(rptr_hip_t *h, const RptrSceneDesc *s) {
     h->master.dscene.num_textures = (int)s->num_textures;
     h->master.dscene.textures = d_textures;
     h->master.dscene.srgb_lut = d_srgb_lut;
-    // Scheduling thresholds of the traversal (dtraverse.h): a wave refills its idle lanes together once `refill_min` of them have finished,
-    // and leaves a node phase for a leaf phase once fewer than `node_min` lanes are at inner nodes. The defaults (48 / 10) were tuned on the
-    // height field; in a dense soup of overlapping primitive boxes -- the forest: 26 node visits per ray, node-phase lane utilisation 0.55
-    // instead of 0.67, a quarter of the lane slots waiting for a refill -- 32 / 16 are 5 % faster (C4 5.89 -> 5.61 ms) and 1.4 % slower on the
-    // height field (profiles/r03_notes.md section 7). The choice follows the tree: the surface-area cost of its largest bottom-level tree
-    // (sum of the inner children's box areas over the root's: 11 for the height field, 92 for the flattened forest). RPTR_TRAVERSE_PRESET=
-    // "node_min,refill_min" overrides (0,0 = the compile-time defaults).
-    {
-        double best_cost = 0.0;
-        size_t best_tris = 0;
-        auto half_area = [&](size_t n) {
-            const std::array<float, 6> &b = h->h_node_box[n];
-            const double dx = std::max(0.0f, b[3] - b[0]), dy = std::max(0.0f, b[4] - b[1]), dz = std::max(0.0f, b[5] - b[2]);
-            return dx * dy + dy * dz + dz * dx;
-        };
-        for (size_t m = 0; m < h->meshes.size(); ++m) {
-            const MeshRt &mr = h->meshes[m];
-            // (a mesh without a tree of its own is part of the flattened tree, which lies first: counted once, for mesh 0)
-            const size_t root = (size_t)h->mesh_root[m], count = (size_t)(mr.node_count > 0 ? mr.node_count : (m == 0 ? (int)h->flat_nodes : 0));
-            const size_t tris_m = mr.tri_count > 0 ? (size_t)mr.tri_count : (m == 0 ? h->flat_tris : 0);
-            if (!count || tris_m < best_tris || root >= h->h_nodes.size()) continue;
-            const double a0 = half_area(root);
-            if (!(a0 > 0.0)) continue;
-            double sum = 0.0;
-            for (size_t n = root; n < std::min(root + count, h->h_nodes.size()); ++n)
-                for (int k = 0; k < 4; ++k)
-                    if (h->h_nodes[n].child[k] >= 0) sum += half_area((size_t)h->h_nodes[n].child[k]);
-            best_cost = sum / a0;
-            best_tris = tris_m;
-        }
-        // ... times the same measure of the top level (all child boxes of its nodes, instance boxes included, over the scene's box: 1 for a
-        // single instance, ~ 6 for the forest's 1001 overlapping instances: the two-level forest gains the same 5 %, 8.38 -> 7.95 ms)
-        double tlas_cost = 1.0;
-        if (h->num_tlas_nodes > 0 && h->num_tlas_insts > 1) {
-            const double a0 = half_area(0);
-            double sum = 0.0;
-            for (int n = 0; n < h->num_tlas_nodes; ++n) {
-                const RptrBvh4Node &nd = h->h_nodes[(size_t)n];
-                for (int k = 0; k < 4; ++k) {
-                    if (nd.child[k] == RPTR_BVH4_EMPTY) continue;
-                    double d[3];
-                    for (int a = 0; a < 3; ++a) d[a] = std::max(0.0, (double)((int)nd.qhi[a][k] - (int)nd.qlo[a][k])) * std::ldexp(1.0, (int)nd.exp[a] - 127);
-                    sum += d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
-                }
-            }
-            if (a0 > 0.0) tlas_cost = std::max(1.0, sum / a0);
-        }
-        best_cost *= tlas_cost;
-        h->bvh_area_cost = best_cost;
-        int node_min = 0, refill_min = 0;
-        if (best_cost >= 24.0) { // (height fields: 10-12; the small forests of the tests: 29-35; C4: 90 flattened, 250-280 two-level)
-            node_min = 16;
-            refill_min = 32;
-        }
-        if (h->opt.v[OPT_TRAVERSE_NODE_MIN] >= 0) { // options "traverse_node_min" / "traverse_refill_min" (0, 0: the compile-time defaults)
-            node_min = (int)h->opt.v[OPT_TRAVERSE_NODE_MIN];
-            refill_min = (int)std::max(0ll, h->opt.v[OPT_TRAVERSE_REFILL_MIN]);
-        }
-        h->master.dscene.node_min = std::max(0, std::min(64, node_min));
-        h->master.dscene.refill_min = std::max(0, std::min(64, refill_min));
-        h->master.dscene.lds_top = h->opt.v[OPT_LDS_TOP] != 0 ? 1 : 0;
-        // ... and the size of a wave's pool of queue entries (dtraverse.h RP_FETCH: 256, four tiles of the first queue): 384 for the trees
-        // of the default preset -- one frame at a time 1.82 -> 1.76 ms, two in flight 1.45 -> 1.38 on C2, pipelined unchanged --, 256 for dense
-        // ones (the forest loses 4 % with 384; profiles/r05_notes.md section 19)
-        h->master.dscene.fetch_max = h->opt.v[OPT_TRAVERSE_FETCH] > 0 ? (int)std::max(64ll, h->opt.v[OPT_TRAVERSE_FETCH] / 64 * 64) : (best_cost >= 24.0 ? 0 : 384);
-    }
+    scene_traversal_preset(h);
     // ---- one shading record per BVH triangle (dshade.h RpShadeTri), made on the device from what was just uploaded: per mesh with the
     // geometry records of the first parameterized mesh that uses it, or -- a flattened scene -- per triangle through the instance it names
     {
