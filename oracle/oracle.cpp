@@ -1177,6 +1177,70 @@ void orc_sample_tri_lights(void *p, const RptrLightSamplingConfig *cfg, const fl
         dist[i] = d; pdf[i] = pd; mis_wpdf[i] = mw;
     }
 }
+// sample_direct_light (nee.glsl:32-90) for n shading points over one glTF material: interaction = (p, gn, n; v_x / v_y from ortho_basis(n)),
+// scene parameters from sp (sun direction / cone / radiance + sun weight), the scene's light table with cfg's bins; the visibility query traces
+// the scene's geometry (brute force): a test that wants every sample "visible" hands over a scene whose geometry is out of the way
+void orc_sample_direct_light(void *p, const RptrSceneParams *sp, const RptrLightSamplingConfig *cfg, const RptrBaseMaterial *m, const float *p3, const float *gn3,
+                             const float *n3, const float *wo3, const float *u4, int n, float *illum3) {
+    Scene *s = (Scene *)p;
+    Frame f;
+    memset(&f.rp, 0, sizeof(f.rp));
+    f.vp = ViewParams();
+    f.sc = s;
+    f.bvh = nullptr;
+    f.sp = *sp;
+    f.lc = *cfg;
+    f.count = false;
+    GLTFMaterial mat;
+    vec3 emit;
+    static const TextureTable no_textures;
+    unpack_material(no_textures, mat, emit, *m, vec2(0, 0));
+    for (int i = 0; i < n; ++i) {
+        InteractionPoint hit;
+        hit.p = vec3(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
+        hit.gn = vec3(gn3[3 * i], gn3[3 * i + 1], gn3[3 * i + 2]);
+        hit.n = vec3(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]);
+        ortho_basis(hit.v_x, hit.v_y, hit.n);
+        PathCounters pc;
+        const vec3 L = sample_direct_light(f, 1.0f, mat, hit, vec3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), vec2(u4[4 * i], u4[4 * i + 1]), vec2(u4[4 * i + 2], u4[4 * i + 3]), pc);
+        illum3[3 * i] = L.x; illum3[3 * i + 1] = L.y; illum3[3 * i + 2] = L.z;
+    }
+}
+// one shading step, shade_base_material (rendering/mc/shade_base_material.glsl:14-96) over the glTF material, for n independent path vertices:
+//   fin[26 i ..]  p, gn, n, v_x, v_y, w_o (3 each), prev_bounce_pdf, approx_solid_angle, illum (3), path_throughput (3)
+//   iin[5 i ..]   material index into mats, bounce, output_channel, glossy_only_mode, generator state (uniform point set; bit pattern of a uint32)
+//   iout[3 i ..]  result code, bounce after, generator state after;   fout[10 i ..]  illum, w_i, path_throughput, prev_bounce_pdf after
+// max_path_depth / rr_path_depth from rp; lights, bins and textures from the scene; visibility traces the scene's geometry (see above)
+void orc_shade_base_material(void *p, const RptrRenderParams *rp, const RptrSceneParams *sp, const RptrLightSamplingConfig *cfg, const RptrBaseMaterial *mats,
+                             const float *fin, const int32_t *iin, int n, int32_t *iout, float *fout) {
+    Scene *s = (Scene *)p;
+    Frame f;
+    f.rp = *rp;
+    f.vp = ViewParams();
+    f.sc = s;
+    f.bvh = nullptr;
+    f.sp = *sp;
+    f.lc = *cfg;
+    f.count = false;
+    auto v3 = [](const float *q) { return vec3(q[0], q[1], q[2]); };
+    for (int i = 0; i < n; ++i) {
+        const float *q = fin + 26 * i;
+        const int32_t *k = iin + 5 * i;
+        InteractionPoint ip;
+        ip.p = v3(q), ip.gn = v3(q + 3), ip.n = v3(q + 6), ip.v_x = v3(q + 9), ip.v_y = v3(q + 12);
+        const vec3 w_o = v3(q + 15);
+        ShadingSampleState st{k[1], k[2], q[18]};
+        vec3 illum = v3(q + 20), thr = v3(q + 23), w_i(0.0f);
+        f.rp.glossy_only_mode = k[3];
+        RandomState rng;
+        rng.lcg.state = (uint32_t)k[4];
+        PathCounters pc;
+        const int r = shade_base_material<GLTFMaterial>(f, 1.0f, st, illum, thr, mats[k[0]], TexCoord(vec2(0, 0), vec2(0, 0), vec2(0, 0)), q[19], w_o, ip, rng, w_i, pc);
+        iout[3 * i] = r, iout[3 * i + 1] = st.bounce, iout[3 * i + 2] = (int32_t)rng.lcg.state;
+        float *o = fout + 10 * i;
+        o[0] = illum.x, o[1] = illum.y, o[2] = illum.z, o[3] = w_i.x, o[4] = w_i.y, o[5] = w_i.z, o[6] = thr.x, o[7] = thr.y, o[8] = thr.z, o[9] = st.prev_bounce_pdf;
+    }
+}
 void orc_camera_basis(const RptrCamera *c, int W, int H, float *out12 /*pos,du,dv,top_left*/) {
     ViewParams vp;
     compute_view(*c, W, H, vp);

@@ -5,7 +5,8 @@
 // reference's files WHERE THEY LIE (no copies, no stand-in headers: without GLM it does not build, and the recipe says so), calls the
 // functions that decide a pixel on seeded inputs and prints inputs + outputs as JSON: the golden vectors that pin the oracle
 // (oracle/oshade.h) and, through it, the device code (csrc/dshade.h). SURVEY.md section 8(c) lists twelve vector groups; this driver makes
-// ten of them, the other two are pinned elsewhere against the reference's own compiled code:
+// ten of them and the NEE half of the eleventh (the whole eleventh -- one shading step of the megakernel -- is ref_shade_driver.cpp, a separate program because it
+// needs the megakernel's macro state); the other two are pinned elsewhere against the reference's own compiled code:
 //    (1) "rng"            get_lcg_rng / lcg_randomf (rendering/pointsets/lcg_rng.glsl): 64 (index, frame offset, pixel) tuples -> state + 8 draws,
 //                         in the order the draws are made (section 7.2-2: every vector below lists its random numbers left to right)
 //    (2) "dequant"        DEQUANTIZE_POSITION / dequantize_normal / dequantize_uv (librender/dequantize.glsl) on 256 words
@@ -20,8 +21,9 @@
 //   (10) "srgb"           linear_to_srgb (util.glsl:25-28) on 256 values (the running mean of vulkan/accumulate.glsl is GLSL-only: images pin it)
 //   (11) equalize_emitter_bins: needs librender's Scene; its Halton table is pinned by tests/test_oracle.py against librender/halton.h compiled
 //   (12) vkr_quantize_transform / dequantize: tests/test_vks.py against ext/libvkr/src/vkr.c compiled unmodified (oracle/_ref/libvkr_ref.so)
-//    (9) shade_base_material end to end needs the megakernel's globals (scene_params, SCENE_GET_* macros, sampler stubs: compile.cpp:26-39 shows
-//        the technique) and is NOT made here: whole frames against the oracle are what holds the driver of the shading code together.
+//    (9) "nee"           of shade_base_material's end-to-end chain the part that needs no texture unit: sample_direct_light (mc/nee.glsl:32-90 -- sun or
+//                         triangle lights, MIS, strict normals; visibility stubbed "visible" as compile.cpp:39 does). unpack_material + the BSDF
+//                         sample + the termination tests around it need the megakernel's sampler / SCENE_GET_* / DIM_* environment: ref_shade_driver.cpp.
 // Output: tests/golden/ref_shaders.json (written by `make ref_shaders`); read by tests/test_ref_shaders.py on the CPU (oracle) and, -m gpu,
 // through images. Until that file exists those tests skip with this reason.
 //
@@ -72,8 +74,21 @@ static int bin_size = 16;
 #define BINNED_LIGHTS_BIN_SIZE int(bin_size)
 #define SCENE_GET_BINNED_LIGHTS_BIN_COUNT() ((int(global_num_lights) + (bin_size - 1)) / int(bin_size))
 
+// next-event estimation end to end (rendering/mc/nee.glsl:32-90 sample_direct_light: sun / triangle-light choice, MIS weight, strict normals,
+// the visibility query -- answered "visible" here, as rendering/tests/compile.cpp:39 does) over the glTF material; nee.glsl pulls in
+// lights_sun.glsl, lights_linear.glsl (the binned-RIS sampler, with the macros above) and nee_interface.glsl
 namespace binned {
-#include "rendering/mc/lights_linear.glsl"
+struct SceneParamsOfTheDriver { // the members nee.glsl / nee_interface.glsl read of the megakernel's scene_params (vulkan/gpu_params.glsl:120-131)
+    glm::vec4 sun_radiance;     // .w: the probability of sampling the sun
+    glm::vec3 sun_dir;
+    float sun_cos_angle;
+};
+static SceneParamsOfTheDriver scene_params;
+#define MATERIAL_TYPE gltf::GLTFMaterial
+#define eval_bsdf(mat, hit, w_o, w_i) gltf::gltf_bsdf(mat, hit.n, w_o, w_i, hit.v_x, hit.v_y)
+#define eval_bsdf_wpdf(mat, hit, w_o, w_i) gltf::gltf_wpdf(mat, hit.n, w_o, w_i, hit.v_x, hit.v_y)
+#include "rendering/mc/nee.glsl"
+inline bool raytrace_test_visibility(const vec3 from, const vec3 dir, float dist) { return true; }
 }
 
 } // namespace ref_shaders
@@ -317,7 +332,48 @@ int main() {
         p3("radiance_over_pdf", L); p3("dir", ld);
         std::printf("\"dist\": %.9g, \"pdf\": %.9g, \"mis_wpdf\": %.9g}%s\n", dist, pdf, mis, i + 1 < n_lights_q ? "," : "");
     }
-    std::printf("],\n\"approx_tri_lights_pdf\": [");
+    // ---- (9, the part that needs no texture unit) next-event estimation end to end: which light, MIS, strict normals; every shadow ray "visible"
+    std::printf("],\n\"nee\": {");
+    binned::scene_params.sun_dir = normalize(glm::vec3(0.3f, 0.8f, 0.5f));
+    binned::scene_params.sun_cos_angle = std::cos(0.00465f * 4.0f);
+    binned::scene_params.sun_radiance = glm::vec4(31000.0f, 29000.0f, 25000.0f, 0.5f);
+    p3("sun_dir", binned::scene_params.sun_dir);
+    std::printf("\"sun_cos_angle\": %.9g, \"sun_radiance\": [%.9g, %.9g, %.9g, %.9g], \"samples\": [\n", binned::scene_params.sun_cos_angle, binned::scene_params.sun_radiance.x,
+                binned::scene_params.sun_radiance.y, binned::scene_params.sun_radiance.z, binned::scene_params.sun_radiance.w);
+    const int n_nee = 256;
+    bin_size = 16;
+    for (int i = 0; i < n_nee; ++i) {
+        gltf::GLTFMaterial m = {};
+        m.base_color = glm::vec3(U(gen), U(gen), U(gen));
+        m.metallic = (i % 3 == 0) ? 0.0f : (i % 3 == 1 ? 1.0f : U(gen));
+        m.specular = U(gen);
+        m.roughness = 0.1f + 0.9f * U(gen);
+        m.ior = 1.0f + U(gen);
+        m.flags = 0u;
+        binned::InteractionPoint hit; // (bsdfs/hit_point.glsl is first included inside that namespace)
+        hit.p = glm::vec3(4.0f * U(gen) - 2.0f, 0.5f * U(gen), 4.0f * U(gen) - 2.0f);
+        hit.n = unit();
+        if (hit.n.y < 0.0f) hit.n = -hit.n;
+        hit.gn = normalize(hit.n + 0.2f * unit()); // (a geometric normal near the shading normal: the strict-normals test has something to reject)
+        ortho_basis(hit.v_x, hit.v_y, hit.n);
+        hit.primitiveId = hit.instanceId = 0;
+        glm::vec3 wo = unit();
+        if (dot(wo, hit.n) < 0.0f) wo = -wo;
+        const glm::vec2 u_dir(U(gen), U(gen)), u_sel(U(gen), U(gen));
+        binned::NEEQueryAux aux;
+        aux.light_dir = glm::vec3(0.0f);
+        aux.light_dist = 0.0f;
+        aux.mis_pdf = 0.0f;
+        const glm::vec3 L = binned::sample_direct_light(m, hit, wo, u_dir, u_sel, aux);
+        std::printf("{");
+        p3("base_color", m.base_color);
+        std::printf("\"metallic\": %.9g, \"specular\": %.9g, \"roughness\": %.9g, \"ior\": %.9g, ", m.metallic, m.specular, m.roughness, m.ior);
+        p3("p", hit.p); p3("n", hit.n); p3("gn", hit.gn); p3("wo", wo);
+        std::printf("\"u\": [%.9g, %.9g, %.9g, %.9g], ", u_dir.x, u_dir.y, u_sel.x, u_sel.y);
+        p3("illum", L);
+        std::printf("\"mis_pdf\": %.9g}%s\n", aux.mis_pdf, i + 1 < n_nee ? "," : "");
+    }
+    std::printf("]},\n\"approx_tri_lights_pdf\": [");
     bin_size = 16;
     for (int i = 0; i < 16; ++i) {
         const float sa = 1e-4f * float(1 << i);

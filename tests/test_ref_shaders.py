@@ -3,7 +3,8 @@
 
 Ten of SURVEY 8(c)'s twelve vector groups come out of that one command (generator table, dequantisation, hit attributes, footprints, glTF and
 Lambert BSDF, binned-RIS lights, sun cone, sky radiance, display transfer function; vkr transforms and the emitter bins' Halton table are
-pinned by tests/test_vks.py / tests/test_oracle.py against the reference's own compiled code; shade_base_material end to end is not made).
+pinned by tests/test_vks.py / tests/test_oracle.py against the reference's own compiled code), plus next-event estimation end to end; the same
+command writes tests/golden/ref_shade.json from oracle/ref_shade_driver.cpp: one whole shading step of the megakernel, shade_base_material.
 This is the pin the oracle lacks for the functions that decide a pixel ("parity unpinned" for BSDFs and light
 sampling). The build image has no GLM and the rules forbid stand-in headers, so the fixture cannot be produced here: until somebody runs
 the one command on a machine that has GLM, every test in this file SKIPS with that reason. With the fixture present they need no GLM, no
@@ -94,7 +95,7 @@ def test_binned_ris_light_sampling_against_the_references_function(ref):
     assert bad <= len(rows) // 100, "%d of %d light samples differ" % (bad, len(rows))
 
 
-# ---------------------------------------------------------------- the other vector groups of SURVEY 8(c) (round 6: the driver makes ten of twelve)
+# ---------------------------------------------------------------- the other vector groups of SURVEY 8(c) (round 6: the two drivers make eleven of twelve)
 def test_rng_table_state_and_draw_order(ref):
     for r in ref["rng_table"]:
         state, draws = O.rng_probe(r["index"], r["frame_offset"], r["pixel"][0], r["pixel"][1], r["dims"][0], n=8)
@@ -187,3 +188,90 @@ def test_approx_tri_lights_pdf(ref):
     # lights_linear.glsl:129-137 with the driver's table: 40 lights in bins of 16 -> 3 bins
     for sa, pdf in ref["approx_tri_lights_pdf"]:
         assert np.isclose(np.float32(1.0) / (np.float32(3.0) * np.float32(sa)), pdf, rtol=1e-6)
+
+
+def test_next_event_estimation_end_to_end(ref):
+    """sample_direct_light (mc/nee.glsl:32-90): sun or triangle lights by the selection sample, the light's sample, MIS against the glTF BSDF's pdf,
+    strict normals; every visibility query "visible" (the driver's stub = compile.cpp:39; here: the scene's geometry moved out of the way)"""
+    L = O.lib()
+    L.orc_sample_direct_light.argtypes = None
+    nee = ref["nee"]
+    s = scenes.cornell32()
+    for inst in s.instances:
+        inst.transform = inst.transform.copy()
+        inst.transform[:, 3] += np.float32(1.0e4)
+    s.lights = np.array(ref["lights"], np.float32).reshape(-1, 4, 3)
+    osc = O.OracleScene(s)
+    sp = abi.SceneParams()
+    sp.sun_dir[:] = nee["sun_dir"]
+    sp.sun_cos_angle = nee["sun_cos_angle"]
+    sp.sun_radiance[:] = nee["sun_radiance"]
+    cfg = abi.LightSamplingConfig(0.0, 16, 15.0, 0.0)
+    bad = 0
+    for r in nee["samples"]:
+        m = abi.BaseMaterial()
+        m.base_color[:] = r["base_color"]
+        m.normal_map = -1
+        m.flags = abi.BASE_MATERIAL_NOALPHA
+        m.metallic, m.specular, m.roughness, m.ior = r["metallic"], r["specular"], r["roughness"], r["ior"]
+        a = {k: np.array([r[k]], np.float32) for k in ("p", "gn", "n", "wo", "u")}
+        out = np.zeros((1, 3), np.float32)
+        L.orc_sample_direct_light(C.c_void_p(osc.h), C.byref(sp), C.byref(cfg), C.byref(m), _p(a["p"]), _p(a["gn"]), _p(a["n"]), _p(a["wo"]), _p(a["u"]), 1, _p(out))
+        bad += 0 if _close(out[0], r["illum"]).all() else 1
+    assert bad <= len(nee["samples"]) // 100, "%d of %d NEE samples differ (a selection at a bin / sun boundary is the only excuse)" % (bad, len(nee["samples"]))
+
+
+SHADE_FIXTURE = os.path.join(os.path.dirname(FIXTURE), "ref_shade.json")
+
+
+@pytest.mark.skipif(not os.path.exists(SHADE_FIXTURE), reason="tests/golden/ref_shade.json absent: written by the same `make -C oracle ref_shaders GLM_ROOT=...` "
+                    "(oracle/ref_shade_driver.cpp: the megakernel's shading step compiled from the reference's files)")
+def test_one_shading_step_end_to_end():
+    """SURVEY 8(c) group (9): shade_megakernel -> shade_base_material (mc/shade_base_material.glsl:14-96) in the megakernel's configuration: unpack_material
+    over the unrolled standard textures (1 x 1 texels = the literals handed to the oracle), direct emitter hit + MIS weight, path-depth cut, AOV channels,
+    next-event estimation, glossy-only cut, BSDF sample, termination tests, throughput / prev_bounce_pdf, and the generator's state after the step --
+    i.e. the NUMBER and ORDER of the draws (section 7.2-2)."""
+    ref = json.load(open(SHADE_FIXTURE))
+    L = O.lib()
+    L.orc_shade_base_material.argtypes = None
+    s = scenes.cornell32()
+    for inst in s.instances:
+        inst.transform = inst.transform.copy()
+        inst.transform[:, 3] += np.float32(1.0e4)
+    s.lights = np.array(ref["lights"], np.float32).reshape(-1, 4, 3)
+    osc = O.OracleScene(s)
+    sp = abi.SceneParams()
+    sp.sun_dir[:] = ref["sun_dir"]
+    sp.sun_cos_angle = ref["sun_cos_angle"]
+    sp.sun_radiance[:] = ref["sun_radiance"]
+    cfg = abi.LightSamplingConfig(ref["light_mis_angle"], int(ref["bin_size"]), ref["min_perceived_receiver_dist"], ref["min_radiance"])
+    rp = abi.RenderParams.default()
+    mats = (abi.BaseMaterial * len(ref["materials"]))()
+    for m, r in zip(mats, ref["materials"]):
+        m.base_color[:] = r["base_color"]
+        m.normal_map = -1
+        m.flags = abi.BASE_MATERIAL_NOALPHA
+        m.metallic, m.specular, m.roughness, m.ior, m.emission_intensity = r["metallic"], r["specular"], r["roughness"], r["ior"], r["emission_intensity"]
+    rows = ref["samples"]
+    n = len(rows)
+    fin = np.zeros((n, 26), np.float32)
+    iin = np.zeros((n, 5), np.int32)
+    for i, r in enumerate(rows):
+        fin[i, :18] = np.concatenate([r[k] for k in ("p", "gn", "n", "v_x", "v_y", "w_o")])
+        fin[i, 18], fin[i, 19] = r["prev_bounce_pdf"], r["approx_solid_angle"]
+        fin[i, 20:23], fin[i, 23:26] = r["illum_in"], r["throughput_in"]
+        iin[i] = (r["material"], r["bounce"], r["output_channel"], r["glossy_only_mode"], np.uint32(r["rng"]).astype(np.int32))
+    iout = np.zeros((n, 3), np.int32)
+    fout = np.zeros((n, 10), np.float32)
+    L.orc_shade_base_material(C.c_void_p(osc.h), C.byref(rp), C.byref(sp), C.byref(cfg), mats, _p(fin), _p(iin), n, _p(iout), _p(fout))
+    bad, seen = 0, set()
+    for i, r in enumerate(rows):
+        ok = int(iout[i, 0]) == r["result"] and int(iout[i, 1]) == r["bounce_out"] and int(np.int32(iout[i, 2]).astype(np.uint32)) == r["rng_out"]
+        ok = ok and _close(fout[i, 0:3], r["illum"]).all()
+        if ok and r["result"] == 1:
+            ok = _close(fout[i, 3:6], r["w_i"]).all() and _close(fout[i, 6:9], r["throughput"]).all() and _close(fout[i, 9], r["prev_bounce_pdf_out"])
+        bad += 0 if ok else 1
+        # the generator never depends on a floating-point decision before the BSDF sample: its state must agree on every vector that is not cut earlier
+        seen.add((r["result"], r["output_channel"] != 0, r["glossy_only_mode"], mats[r["material"]].emission_intensity > 0, r["bounce"] + 1 >= rp.max_path_depth))
+    assert bad <= n // 100, "%d of %d shading steps differ (a lobe / light selection at a boundary or GGX at grazing incidence are the only excuses)" % (bad, n)
+    assert len(seen) >= 8, "the vectors no longer cover the step's branches: %r" % (seen,)
