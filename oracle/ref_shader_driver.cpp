@@ -19,7 +19,8 @@
 //    (8) "sky"            skymodel_radiance on a direction grid for the printed SkyModelParams (lights/sky_model_arhosek/sky_model.glsl); the FIT
 //                         that makes such parameters is pinned by oracle/ref_sky_driver.cpp (sky_model.cpp compiled unmodified: tests/test_sky_fit.py)
 //   (10) "srgb"           linear_to_srgb (util.glsl:25-28) on 256 values (the running mean of vulkan/accumulate.glsl is GLSL-only: images pin it)
-//   (11) equalize_emitter_bins: needs librender's Scene; its Halton table is pinned by tests/test_oracle.py against librender/halton.h compiled
+//   (11) equalize_emitter_bins: ref_lights_driver.cpp (librender/lights.cpp compiled unmodified, update_light_sampling on seven emitter sets); its Halton
+//                         table is pinned by tests/test_oracle.py against librender/halton.h compiled
 //   (12) vkr_quantize_transform / dequantize: tests/test_vks.py against ext/libvkr/src/vkr.c compiled unmodified (oracle/_ref/libvkr_ref.so)
 //    (9) "nee"           of shade_base_material's end-to-end chain the part that needs no texture unit: sample_direct_light (mc/nee.glsl:32-90 -- sun or
 //                         triangle lights, MIS, strict normals; visibility stubbed "visible" as compile.cpp:39 does). unpack_material + the BSDF

@@ -122,7 +122,8 @@ inline std::vector<float> estimate_normalized_radiance(const std::vector<RptrTri
         const V3 cen{sum.x / 3.0f, sum.y / 3.0f, sum.z / 3.0f};
         const V3 o = n * min_perceived_receiver_dist;
         const float sa = triangle_solid_angle(normalize((v0 - cen) - o), normalize((v1 - cen) - o), normalize((v2 - cen) - o));
-        out[i] = luminance(e.radiance) * float(double(sa) / (2.0 / 3.14159265358979323846));
+        // `luminance(..) * (solid_angle / M_2_PI)`: M_2_PI is a double, so quotient AND product are doubles, rounded once on the store (lights.cpp:195)
+        out[i] = float(double(luminance(e.radiance)) * (double(sa) / 0.63661977236758134308));
     }
     return out;
 }

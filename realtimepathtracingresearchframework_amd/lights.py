@@ -136,7 +136,8 @@ def estimate_normalized_radiance(emitters, min_perceived_receiver_dist):
         o = (n * d).astype(f32)
         sa = triangle_solid_angle(_normalize((v0 - cen - o).astype(f32)), _normalize((v1 - cen - o).astype(f32)),
                                   _normalize((v2 - cen - o).astype(f32)))
-        out[i] = f32(luminance(rad) * f32(np.float64(sa) / (2.0 / math.pi)))
+        # `luminance(..) * (solid_angle / M_2_PI)`: M_2_PI is a double, so quotient AND product are doubles, rounded once on the store (lights.cpp:195)
+        out[i] = f32(np.float64(luminance(rad)) * (np.float64(sa) / 0.63661977236758134308))
     return out
 
 

@@ -4,7 +4,9 @@
 Ten of SURVEY 8(c)'s twelve vector groups come out of that one command (generator table, dequantisation, hit attributes, footprints, glTF and
 Lambert BSDF, binned-RIS lights, sun cone, sky radiance, display transfer function; vkr transforms and the emitter bins' Halton table are
 pinned by tests/test_vks.py / tests/test_oracle.py against the reference's own compiled code), plus next-event estimation end to end; the same
-command writes tests/golden/ref_shade.json from oracle/ref_shade_driver.cpp: one whole shading step of the megakernel, shade_base_material.
+command writes tests/golden/ref_shade.json from oracle/ref_shade_driver.cpp: one whole shading step of the megakernel, shade_base_material, and
+tests/golden/ref_lights.json from oracle/ref_lights_driver.cpp: librender/lights.cpp compiled unmodified, the emitter table (held against the product's
+own lights.py).
 This is the pin the oracle lacks for the functions that decide a pixel ("parity unpinned" for BSDFs and light
 sampling). The build image has no GLM and the rules forbid stand-in headers, so the fixture cannot be produced here: until somebody runs
 the one command on a machine that has GLM, every test in this file SKIPS with that reason. With the fixture present they need no GLM, no
@@ -275,3 +277,27 @@ def test_one_shading_step_end_to_end():
         seen.add((r["result"], r["output_channel"] != 0, r["glossy_only_mode"], mats[r["material"]].emission_intensity > 0, r["bounce"] + 1 >= rp.max_path_depth))
     assert bad <= n // 100, "%d of %d shading steps differ (a lobe / light selection at a boundary or GGX at grazing incidence are the only excuses)" % (bad, n)
     assert len(seen) >= 8, "the vectors no longer cover the step's branches: %r" % (seen,)
+
+
+LIGHTS_FIXTURE = os.path.join(os.path.dirname(FIXTURE), "ref_lights.json")
+
+
+@pytest.mark.skipif(not os.path.exists(LIGHTS_FIXTURE), reason="tests/golden/ref_lights.json absent: written by the same `make -C oracle ref_shaders GLM_ROOT=...` "
+                    "(oracle/ref_lights_driver.cpp: librender/lights.cpp compiled unmodified)")
+def test_emitter_table_preparation_against_the_references_own_lights_cpp():
+    """SURVEY 8(c) group (11): update_light_sampling = estimate_normalized_radiance -> trim_dim_emitters -> equalize_emitter_bins (librender/lights.cpp:75-90,
+    166-349) on seven seeded emitter sets (equal quads as in C3, radiances over three decades, one bin, bins of 4 / 8, trimming + degenerate triangles,
+    a receiver distance inside the emitters, bin_size 1): the PRODUCT's preparation (lights.py; host/lights.hpp is byte-identical to it,
+    tests/test_validation_cli.py) makes the same table -- the same emitters in the same order with the same split radiances, bit for bit (that table is
+    what the device samples) -- and the same normalised radiances up to the host's atanf."""
+    from realtimepathtracingresearchframework_amd import lights
+    ref = json.load(open(LIGHTS_FIXTURE))
+    assert len(ref["cases"]) >= 7
+    for c in ref["cases"]:
+        em = np.array(c["emitters"], np.float32).reshape(-1, 4, 3)
+        got_e, got_r = lights.update_light_sampling(em, c["min_perceived_receiver_dist"], c["min_radiance"], c["bin_size"])
+        want_e = np.array(c["binned_emitters"], np.float32).reshape(-1, 4, 3)
+        want_r = np.array(c["binned_radiances"], np.float32)
+        assert got_e.shape == want_e.shape, c["name"]
+        assert np.array_equal(got_e.view(np.uint32), want_e.view(np.uint32)), c["name"]
+        assert np.allclose(got_r, want_r, rtol=1e-6, atol=0), c["name"]
