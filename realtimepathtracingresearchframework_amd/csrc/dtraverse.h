@@ -148,6 +148,24 @@ RP_DEV V3 rp_xform_dir(const float4 r0, const float4 r1, const float4 r2, V3 d) 
 #ifndef RP_SLAB_PACKED
 #define RP_SLAB_PACKED 0
 #endif
+// Round 6, node step with fewer instructions (same values, same order of visits; 141 -> 131 VALU per step in the closest-hit kernels. Measured,
+// profiles/r06_notes.md section 9: stand-alone closest-hit launches -2.5 %, one frame at a time -1.3 %, pipelined frames -0.6 % (C2) ... -1.8 % (C3)):
+//   RP_STACK_BYTES the stack pointer is the LDS byte offset of the lane's next free entry (level * 1024 + 4 * thread) rather than the level
+//   RP_ASM_MINMAX  the two min / max that take loop-carried operands (t_min, the best hit's t) are written as instructions: the compiler
+//                 puts a v_max x, x in front of them to quiet a signalling NaN they cannot hold
+//   RP_EXP_SDWA   2^exponent of the node's grid step with one v_lshlrev_b32_sdwa per axis (byte select + shift) instead of shift + and
+#ifndef RP_NODE_TAIL_X2
+#define RP_NODE_TAIL_X2 1
+#endif
+#ifndef RP_STACK_BYTES
+#define RP_STACK_BYTES 1
+#endif
+#ifndef RP_ASM_MINMAX
+#define RP_ASM_MINMAX 1
+#endif
+#ifndef RP_EXP_SDWA
+#define RP_EXP_SDWA 1
+#endif
 #ifndef RP_REFILL_MIN
 #define RP_REFILL_MIN 48
 #endif
@@ -237,7 +255,22 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     bool more = pool_next < n; // the shared cursor starts behind every static pool
     if (!more) return;
     // per-lane traversal state
-    int cur = RP_EXIT, sp = 0;
+    // the stack pointer counts in units of RP_SP_UNIT from sp_empty: entries (RP_STACK_BYTES 0) or LDS bytes (1: sp is the byte
+    // offset of the lane's next free entry in the column layout, level * 1024 + 4 * thread; the level is sp >> 10 because 4 * thread < 1024,
+    // and "level < L" is "sp < L * 1024" for the same reason)
+#if RP_STACK_BYTES
+    static_assert(RP_TRAVERSE_BLOCK * 4 == 1024, "RP_SP_LEVEL shifts by 10");
+#define RP_SP_UNIT (RP_TRAVERSE_BLOCK * 4)
+#define RP_SP_LEVEL(x) ((x) >> 10)
+#define RP_SP_LDS(x) (*reinterpret_cast<int *>(reinterpret_cast<char *>(lds_stack) + (x)))
+    const int sp_empty = (int)(tid * 4u);
+#else
+#define RP_SP_UNIT 1
+#define RP_SP_LEVEL(x) (x)
+#define RP_SP_LDS(x) (lds_stack[(x) * RP_TRAVERSE_BLOCK + tid])
+    const int sp_empty = 0;
+#endif
+    int cur = RP_EXIT, sp = sp_empty;
     bool active = false; // lane holds a ray whose result has not been consumed yet
     uint32_t my_i = 0;
     V3 ro = v3s(0.f), rd = v3s(0.f), o = v3s(0.f), d = v3s(0.f);
@@ -250,19 +283,19 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
     best.tri = best.inst_idx = -1;
     int best_inst_id = -1, cur_inst = -1, cur_inst_id = -1;
     auto push = [&](int v) {
-        if (sp < RP_LDS_STACK)
-            lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = v;
+        if (sp < RP_LDS_STACK * RP_SP_UNIT)
+            RP_SP_LDS(sp) = v;
         else
-            glob[size_t(sp - RP_LDS_STACK) * gstride] = v;
-        ++sp;
+            glob[size_t(RP_SP_LEVEL(sp) - RP_LDS_STACK) * gstride] = v;
+        sp += RP_SP_UNIT;
     };
     auto pop = [&]() -> int {
-        --sp;
+        sp -= RP_SP_UNIT;
         int v;
-        if (sp < RP_LDS_STACK)
-            v = lds_stack[sp * RP_TRAVERSE_BLOCK + tid]; // ds_read_b32; kept apart from the spill path so it is not a flat load
+        if (sp < RP_LDS_STACK * RP_SP_UNIT)
+            v = RP_SP_LDS(sp); // ds_read_b32; kept apart from the spill path so it is not a flat load
         else // an atomic (relaxed) load cannot be merged with the LDS read into one flat load
-            v = __hip_atomic_load(glob + size_t(sp - RP_LDS_STACK) * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            v = __hip_atomic_load(glob + size_t(RP_SP_LEVEL(sp) - RP_LDS_STACK) * gstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         return v;
     };
     auto set_ray = [&](V3 no, V3 nd) {
@@ -325,7 +358,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                     best.u = best.v = 0.0f;
                     best.tri = best.inst_idx = -1;
                     best_inst_id = -1;
-                    sp = 0;
+                    sp = sp_empty;
                     push(RP_EXIT);
                     if (SINGLE) {
                         // one instance record in the whole scene: the query starts inside it, at the root of its bottom-level
@@ -377,12 +410,12 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             prof_it++;
 #endif
             // the whole wave takes the generic stack path when some lane is within 3 entries of the end of its LDS part
-            const bool stack_slow = __any(sp > RP_LDS_STACK - 3);
+            const bool stack_slow = __any(sp >= (RP_LDS_STACK - 2) * RP_SP_UNIT);
 #ifdef RP_PROF
             if (stack_slow && lane == 0) atomicAdd(&rp_prof[13], 1ull);
 #endif
             int top = 0;
-            if (!stack_slow) top = lds_stack[(sp - 1) * RP_TRAVERSE_BLOCK + tid]; // read ahead: the item a miss would pop
+            if (!stack_slow) top = RP_SP_LDS(sp - RP_SP_UNIT); // read ahead: the item a miss would pop
             const char *np = node_base + (uint32_t(cur) << 6);
             float4 n0;  // origin.xyz, exp bytes
             uint4 n1;   // qlo.x qlo.y qlo.z qhi.x (4 children per dword)
@@ -399,13 +432,28 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 n0 = *reinterpret_cast<const float4 *>(np);
                 n1 = *reinterpret_cast<const uint4 *>(np + 16);
                 n2 = *reinterpret_cast<const uint4 *>(np + 32);
+#if RP_NODE_TAIL_X2
+                // child[2], child[3] as ONE 8-byte load the compiler can neither widen nor merge (a relaxed wave-scope atomic load is a plain
+                // global_load_dwordx2): left alone it fetches bytes 48..63 with a fourth dwordx4, 8 bytes of padding per lane and node visit
+                const unsigned long long c23 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(np + 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                n3 = make_uint2((uint32_t)c23, (uint32_t)(c23 >> 32));
+#else
                 n3 = *reinterpret_cast<const uint2 *>(np + 48);
+#endif
             }
             if (COUNT) n_nodes++;
             const uint32_t ex = __float_as_uint(n0.w);
             // plane distance t = q * A + B with A = step / d, B = (origin - o) / d
+#if RP_EXP_SDWA
+            uint32_t ex_x, ex_y, ex_z; // byte k of the word, shifted to the exponent field: the same bits as the shift + and below
+            asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ex_x) : "v"(ex));
+            asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ex_y) : "v"(ex));
+            asm("v_lshlrev_b32_sdwa %0, 23, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ex_z) : "v"(ex));
+            const float ax = __uint_as_float(ex_x) * inv.x, ay = __uint_as_float(ex_y) * inv.y, az = __uint_as_float(ex_z) * inv.z;
+#else
             const float ax = __uint_as_float((ex & 0xFFu) << 23) * inv.x, ay = __uint_as_float((ex & 0xFF00u) << 15) * inv.y,
                         az = __uint_as_float((ex & 0xFF0000u) << 7) * inv.z;
+#endif
             const float bx = (n0.x - o.x) * inv.x, by = (n0.y - o.y) * inv.y, bz = (n0.z - o.z) * inv.z;
             // entry / exit planes by the sign of the direction (= min / max of the two plane distances, since
             // qlo <= qhi and the step is positive), selected once for the four children of a dword
@@ -440,8 +488,18 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 // node visits per ray on the instanced forest, depending on nothing but that). The unclamped value -- how far behind the
                 // origin the box begins -- still tells them apart.
                 const float tn_raw = fmaxf(fmaxf(tx.x, ty.x), tz.x);
+#if RP_ASM_MINMAX
+                // v_max_f32 / v_min_f32 as such: t_min and the best hit's t come around the loop in registers, and the compiler would first
+                // quiet the signalling NaN they never are (v_max x, x: two instructions per node step); for every other operand value the
+                // instruction IS fmaxf / fminf
+                float tn, tfz;
+                asm("v_max_f32 %0, %1, %2" : "=v"(tn) : "v"(tn_raw), "v"(tmin));
+                asm("v_min_f32 %0, %1, %2" : "=v"(tfz) : "v"(tz.y), "v"(tfar_max));
+                const float tf = fminf(fminf(tx.y, ty.y), tfz);
+#else
                 const float tn = fmaxf(tn_raw, tmin);
                 const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tfar_max));
+#endif
                 // entry <= exit with a 1 + 2^-19 slack on the exit, as one fma: gap = entry - 1.0000019 exit <= 0. For an occlusion query the gap
                 // is the order key as well: most negative first = the child the ray spends the longest stretch in, where an occluder is most
                 // likely (flattened forest: 16.3 instead of 18.2 node visits, 3.8 instead of 5.7 triangle tests per shadow ray) -- for free.
@@ -454,16 +512,16 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             // front-to-back order with three comparisons instead of a sorting network over (key, payload) pairs: nearer first inside
             // each pair of slots, then the pair that holds the nearest child first. Against the full sort: +0.5 % node visits on the
             // 10 M-triangle forest, none on the height field (tools/order_probe.py); 18 VALU instructions fewer per node.
-            const bool sw_a = ent[1] < ent[0], sw_b = ent[3] < ent[2], sw_t = fminf(ent[2], ent[3]) < fminf(ent[0], ent[1]);
 #define RP_SWAP_IF(c, i, j)                        \
     {                                              \
         const int ra_ = ref[i], rb_ = ref[j];      \
         ref[i] = (c) ? rb_ : ra_;                  \
         ref[j] = (c) ? ra_ : rb_;                  \
     }
+            const bool sw_a = ent[1] < ent[0], sw_b = ent[3] < ent[2], sw_t = fminf(ent[2], ent[3]) < fminf(ent[0], ent[1]);
             RP_SWAP_IF(sw_a, 0, 1) RP_SWAP_IF(sw_b, 2, 3) RP_SWAP_IF(sw_t, 0, 2) RP_SWAP_IF(sw_t, 1, 3)
-#undef RP_SWAP_IF
             const bool v0 = ref[0] != RPTR_BVH4_EMPTY, v1 = ref[1] != RPTR_BVH4_EMPTY, v2 = ref[2] != RPTR_BVH4_EMPTY, v3 = ref[3] != RPTR_BVH4_EMPTY;
+#undef RP_SWAP_IF
             // the first hit in that order is next; the later ones go on the stack, farthest first
             const bool p3 = v3 && (v0 || v1 || v2), p2 = v2 && (v0 || v1), p1 = v1 && v0;
             int nxt;
@@ -474,14 +532,14 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                 nxt = v0 ? ref[0] : v1 ? ref[1] : v2 ? ref[2] : v3 ? ref[3] : pop();
             } else { // branch-free: write, then advance only for real entries; no child hit = no push, and the entry read ahead
                      // from the top of the stack is the next item
-                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[3];
-                sp += p3 ? 1 : 0;
-                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[2];
-                sp += p2 ? 1 : 0;
-                lds_stack[sp * RP_TRAVERSE_BLOCK + tid] = ref[1];
-                sp += p1 ? 1 : 0;
+                RP_SP_LDS(sp) = ref[3];
+                sp += p3 ? RP_SP_UNIT : 0;
+                RP_SP_LDS(sp) = ref[2];
+                sp += p2 ? RP_SP_UNIT : 0;
+                RP_SP_LDS(sp) = ref[1];
+                sp += p1 ? RP_SP_UNIT : 0;
                 nxt = v0 ? ref[0] : v1 ? ref[1] : v2 ? ref[2] : v3 ? ref[3] : top;
-                sp -= (v0 || v1 || v2 || v3) ? 0 : 1;
+                sp -= (v0 || v1 || v2 || v3) ? 0 : RP_SP_UNIT;
             }
             cur = nxt;
             // the bottom-level tree is done: back to the top level right here (a few instructions for the lanes concerned) instead of
@@ -560,7 +618,8 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         const V3 q = rp_cross_fma(tv, e1);
                         const float vn = rp_dot_fma(d, q);
                         const float ad = fabsf(det);
-                        const bool neg = det < 0.0f || (det == 0.0f && __float_as_int(det) < 0);
+                        // the sign bit of det (negative or -0; round 6: read as such -- a NaN determinant, whatever its sign, fails "ad > 0" below)
+                        const bool neg = __float_as_int(det) < 0;
                         const float us = neg ? -un : un, vs = neg ? -vn : vn;
                         if (us >= 0.0f && vs >= 0.0f && us + vs <= ad && ad > 0.0f) {
                             const float inv_det = 1.0f / det;
