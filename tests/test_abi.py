@@ -208,3 +208,39 @@ def test_boundary_structs_and_constants_against_the_references_headers():
     bits = struct.unpack("<I", struct.pack("<f", abi.textured_param(1234, 2)))[0]
     assert bits == ref["texture_handle_1234_2"] and (bits & 0x1FFFFFFF, (bits >> 29) & 3) == (ref["texture_handle_id"], ref["texture_handle_channel"])
     assert (ref["STANDARD_TEXTURE_NORMAL_SLOT"], ref["STANDARD_TEXTURE_BASECOLOR_SLOT"], ref["STANDARD_TEXTURE_SPECULAR_SLOT"]) == (0, 1, 2)
+
+
+def _tool(*args):
+    import subprocess
+    return subprocess.run(["bash"] + list(args), capture_output=True, text=True, cwd=ROOT, timeout=300).stdout
+
+
+def test_traversal_kernels_keep_their_register_budgets_and_their_node_fetch():
+    """Facts of the built code object the design leans on and a compiler update could silently change (csrc/dtraverse.h):
+    the benchmarked traversal instantiations -- one instance record, no alpha test -- fit the register budgets of seven (closest hit) and eight
+    (shadow rays) waves per SIMD without scratch, hold 20 KB of LDS stacks per block, and fetch a node as 16 + 16 + 16 + 8 bytes (the
+    vectoriser once made the last load 16: 8 bytes of padding per lane and node visit, profiles/r06_notes.md section 9)."""
+    import shutil
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("bash") is None:
+        pytest.skip("no llvm-objdump")
+    if not os.path.exists(build.LIB_PATH):
+        build.build_library()
+    regs = {}
+    for line in _tool("tools/kernel_regs.sh", build.LIB_PATH).splitlines():
+        m = re.match(r"(\S+)\s+vgpr\s+(\d+)\s+sgpr\s+(\d+)\s+scratch\s+(\d+)\s+lds\s+(\d+)", line)
+        if m:
+            regs[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    budgets = {"_Z11rp_k_extendILb0ELb1ELb0ELb1ELb0EE": 72, "_Z11rp_k_extendILb0ELb0ELb0ELb1ELb0EE": 72, "_Z12rp_k_connectILb0ELb0ELb1EE": 64}
+    for prefix, budget in budgets.items():
+        hits = [v for k, v in regs.items() if k.startswith(prefix)]
+        assert len(hits) == 1, (prefix, sorted(regs)[:5])
+        vgpr, _, scratch, lds = hits[0]
+        assert vgpr <= budget and scratch == 0 and lds == 20 * 256 * 4, (prefix, hits[0])
+    isa = _tool("tools/disasm.sh", build.LIB_PATH, "_Z11rp_k_extendILb0ELb0ELb0ELb1ELb0EE")
+    loads = re.findall(r"global_load_(dwordx?\d?)\s+v\[?[0-9:]+\]?, (v\d+), (s\[\d+:\d+\])(?: offset:(\d+))?", isa)
+    # the node fetch: four loads off one 32-bit offset register and one scalar base, at byte 0 / 16 / 32 / 48 of the node
+    by_base = {}
+    for width, vaddr, sbase, off in loads:
+        by_base.setdefault((vaddr, sbase), []).append((int(off or 0), width))
+    node = [sorted(v) for v in by_base.values() if sorted(o for o, _ in v) == [0, 16, 32, 48]]
+    assert node and all(n == [(0, "dwordx4"), (16, "dwordx4"), (32, "dwordx4"), (48, "dwordx2")] for n in node), by_base
