@@ -325,6 +325,24 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
             set_ray(ro, rd);
         cur = pop();
     };
+    // SINGLE (round 6): the one instance record of the scene -- three rows of world_to_object, the root of its tree, its id -- is read ONCE per
+    // wave, into scalar registers, instead of by every refill: the waves are persistent, and five vector loads of a wave-uniform address
+    // returned 3.5 KB per refill through the same L1 path as a node fetch (the same bits enter the same arithmetic).
+#ifndef RP_SINGLE_HOIST
+#define RP_SINGLE_HOIST 1
+#endif
+    float4 sw0 = make_float4(0.f, 0.f, 0.f, 0.f), sw1 = sw0, sw2 = sw0;
+    int s_root = 0, s_inst_id = 0;
+    if (SINGLE && RP_SINGLE_HOIST) {
+        const float4 *ip = reinterpret_cast<const float4 *>(sc.insts);
+        const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], meta = ip[3];
+        auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+        sw0 = make_float4(uni(w0.x), uni(w0.y), uni(w0.z), uni(w0.w));
+        sw1 = make_float4(uni(w1.x), uni(w1.y), uni(w1.z), uni(w1.w));
+        sw2 = make_float4(uni(w2.x), uni(w2.y), uni(w2.z), uni(w2.w));
+        s_root = __builtin_amdgcn_readfirstlane(__float_as_int(meta.x));
+        s_inst_id = __builtin_amdgcn_readfirstlane(__float_as_int(meta.z));
+    }
     const char *const node_base = reinterpret_cast<const char *>(sc.nodes);
     const char *const tri_base = reinterpret_cast<const char *>(sc.tris);
     const char *const inst_base = reinterpret_cast<const char *>(sc.insts);
@@ -364,6 +382,13 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         // one instance record in the whole scene: the query starts inside it, at the root of its bottom-level
                         // tree -- no top-level node, no instance leaf and no sentinel to come back to (same arithmetic as
                         // entering the instance through its leaf; oracle/obvh.h traverse4 takes the same shortcut)
+#if RP_SINGLE_HOIST
+                        if (COUNT) n_nodes++; // the 64 bytes of the instance record, counted per query as the oracle's walk counts them
+                        set_ray(rp_xform_point(sw0, sw1, sw2, ro), rp_xform_dir(sw0, sw1, sw2, rd));
+                        cur_inst = 0;
+                        cur_inst_id = s_inst_id;
+                        cur = s_root;
+#else
                         const float4 *ip = reinterpret_cast<const float4 *>(sc.insts);
                         const float4 w0 = ip[0], w1 = ip[1], w2 = ip[2], meta = ip[3];
                         if (COUNT) n_nodes++; // the 64 bytes of the instance record every query still reads
@@ -371,6 +396,7 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                         cur_inst = 0;
                         cur_inst_id = __float_as_int(meta.z);
                         cur = __float_as_int(meta.x);
+#endif
                     } else {
                         set_ray(ro, rd);
                         if (RP_WORLD_INV_LDS) {
@@ -629,7 +655,9 @@ RP_DEV void rp_wave_trace(const RpScene &sc, const uint32_t n, uint32_t *cursor,
                                 // a triangle of a flattened scene names its own instance record (rptr_bvh.h), any other one
                                 // belongs to the instance being traversed
                                 const int tri_rec = (int)RPTR_BVH_TRI_INSTANCE(__float_as_uint(q2.w));
-                                const int hit_inst = tri_rec ? tri_rec : cur_inst, hit_inst_id = tri_rec ? tri_rec - sc.flat_id_bias : cur_inst_id;
+                                // (SINGLE: the instance being traversed is record 0 with the id read at the top, wave-uniform values)
+                                const int in_inst = (SINGLE && RP_SINGLE_HOIST) ? 0 : cur_inst, in_inst_id = (SINGLE && RP_SINGLE_HOIST) ? s_inst_id : cur_inst_id;
+                                const int hit_inst = tri_rec ? tri_rec : in_inst, hit_inst_id = tri_rec ? tri_rec - sc.flat_id_bias : in_inst_id;
                                 bool accept = t < best.t;
                                 if (!accept && t == best.t && best.inst_idx >= 0) { // a tie (rare): the smaller (instance, geometry, primitive) wins
                                     if (hit_inst_id != best_inst_id)
