@@ -3,7 +3,7 @@
 TAG=${1:-r04}; O=gpurun_out/$TAG; mkdir -p $O
 for rep in 1 2 3; do
 for bf in 1 2 4; do for fif in 3 5 7 11 20; do
-  python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --sustained-seconds 0 --batch-frames $bf --frames-in-flight $fif > $O/s20_bf${bf}_fif${fif}_$rep.json 2>/dev/null
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-boundary --sustained-seconds 0 --batch-frames $bf --frames-in-flight $fif > $O/s20_bf${bf}_fif${fif}_$rep.json 2>/dev/null
 done; done; done
 python3 - $O <<'PY'
 import json,sys,glob,os,collections
