@@ -1018,6 +1018,9 @@ def main():
         # MEASURED issue ceiling of the traversal's instruction mix, see "valu"; one kernel alone additionally waits on memory LATENCY
         # (wait_any_frac of its wave-cycles), which the frames in flight hide
         "binding": "valu_issue", "binding_frac": (valu_frame(pmc, ms_per_step, valu_peak, launches_extend) or {}).get("pipelined_frac") if pmc else None,
+        "binding_note": ("nearest single ceiling, not the only one: 7 % fewer vector instructions per node step moved the pipelined frame by 0.6 %, 8 bytes less per "
+                         "divergent node fetch by 1.9 % (profiles/r06_notes.md section 9) -- issue, the waves' dependent-fetch latency and the L1 return path of "
+                         "the lane fetches lie within a few per cent of one another"),
         "workload_key": wkey,
         "hbm_frac": k_ext["hbm_frac"], "algorithmic_frac": k_ext["algorithmic_frac"],
         "algorithmic_bytes_per_launch": k_ext["algorithmic_bytes_per_launch"], "algorithmic_gbs": k_ext["algorithmic_gbs"],
