@@ -835,6 +835,28 @@ def soup(seed, n_meshes=3, tris_per_mesh=200, n_instances=9, degenerate=True) ->
     return s
 
 
+def book(n_pages=65536) -> Scene:
+    """A stack of n_pages parallel unit quads along z: a ray that crosses the pages hits all four children of every node it descends
+    through, so a 4-wide tree of depth d parks 3 d entries on the traversal stack before the first triangle is tested -- 65536 pages: depth 8,
+    25 entries, more than the 20 the device keeps in LDS (csrc/dtraverse.h RP_LDS_STACK): the scene of the stack-spill parity test."""
+    s = Scene(name="book-%d" % n_pages)
+    s.materials = [abi.make_material((0.7, 0.7, 0.7), roughness=0.8)]
+    T = np.zeros((n_pages, 2, 3, 3), np.float64)
+    T[:, 0] = [[0, 0, 0], [1, 0, 0], [1, 1, 0]]
+    T[:, 1] = [[0, 0, 0], [1, 1, 0], [0, 1, 0]]
+    T[..., 2] = (np.arange(n_pages, dtype=np.float64) / n_pages * 2.0 - 1.0)[:, None, None]
+    T[..., 0:2] -= 0.5
+    T = T.reshape(-1, 3, 3).astype(f32)
+    mesh = _add_mesh(s, T)
+    s.pmeshes.append(ParameterizedMesh(mesh=mesh, material_offsets=np.array([0], np.int32), tri_material_ids=np.zeros(len(T), np.uint8)))
+    s.instances.append(Instance(transform=np.eye(3, 4, dtype=f32), pmesh=0))
+    s.camera = dict(eye=(0.2, 0.1, 5), center=(0, 0, 0), up=(0, 1, 0), fov=20.0)
+    s.config = SceneConfig(**SKY_CONFIGS["low_sun"])
+    s.sky_key = "low_sun"
+    s.prepare_lights()
+    return s
+
+
 # ------------------------------------------------------------------ textured materials (a8 / a9)
 def textured_test(nx=24, nz=24) -> Scene:
     """A bumpy patch and a flat quad whose materials read their parameters from textures: sRGB base colour (checker with a

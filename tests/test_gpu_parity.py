@@ -851,6 +851,48 @@ def test_flattened_scene_matches_the_oracle_on_the_same_tree(scene_name):
         assert image_error(img, img2)[0] < 5 * RMSE_TOL
 
 
+def test_deep_traversal_stacks_spill_to_global_memory_and_stay_exact():
+    """The traversal keeps 20 stack entries per lane in LDS and spills deeper ones to a per-thread slice of global memory (csrc/dtraverse.h: the
+    whole wave takes the generic push / pop path once a lane comes within three entries of the end). No other scene of the suite gets there often
+    (tools/soak_stack_spill.sh forces it with a four-entry build); this one does on the shipped library: 65536 parallel pages, a tree of depth >= 8
+    whose every node has four children a crossing ray hits -- 3 x depth + 1 entries before the first triangle test. Results bit-equal to the
+    oracle's walk of the same tree, node / triangle visits of every closest-hit and occlusion ray of a frame equal to the oracle's walk of the exported tree."""
+    s = scenes.book(65536)
+    r = backend.RenderHip()
+    r.initialize(64, 48)
+    r.set_scene(s)
+    nodes, _, insts = r.export_bvh()[:3]
+    child = np.frombuffer(np.ascontiguousarray(nodes).tobytes(), np.int32).reshape(-1, 16)[:, 10:14]
+    root = int(np.frombuffer(np.ascontiguousarray(insts).tobytes(), np.int32).reshape(-1, 32)[0, 12])
+    depth, level = 0, [root]
+    while level:
+        depth += 1
+        level = [int(c) for n in level for c in child[n] if c >= 0]
+    assert 3 * (depth - 1) + 1 > 20, depth          # the first descent alone parks more than the LDS part holds
+    rng = np.random.default_rng(11)
+    q = np.zeros((20000, 8), np.float32)
+    q[:, 0:2] = rng.uniform(-0.6, 0.6, (len(q), 2))
+    q[:, 2] = np.where(rng.random(len(q)) < 0.5, -3.0, 3.0)
+    d = np.concatenate([rng.normal(scale=0.05, size=(len(q), 2)), -np.sign(q[:, 2:3])], axis=1)
+    q[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    q[:, 7] = 1e20
+    res = np.full((len(q), 4), 3.0, np.float32)
+    r.render_ray_queries(q, res)
+    osc = O.OracleScene(s)
+    osc.import_bvh(*r.export_bvh())
+    ref = np.full((len(q), 4), 3.0, np.float32)
+    osc.trace(q, bvh_mode=O.BVH_IMPORTED, out=ref)
+    assert np.array_equal(res.view(np.uint32), ref.view(np.uint32))           # the same tree: every bit
+    assert (res[:, 0] >= 0).sum() > 10000
+    # another tree (the oracle's own, float boxes) may disagree on a ray that leaves the book exactly through a page's outer edge, where the
+    # triangle's edge IS its box's face (one or two rays in 20000 name the neighbouring page): everywhere else the hit does not depend on the tree
+    own = np.full((len(q), 4), 3.0, np.float32)
+    osc.trace(q, bvh_mode=O.BVH_OWN, out=own)
+    assert (res.view(np.uint32) == own.view(np.uint32)).all(axis=1).mean() > 0.9995
+    assert_ray_visit_parity(r, osc, 64, 48, 1, abi.VARIANT_SIMPLE)
+    r.close()
+
+
 def test_reinitialize_and_new_scene_on_one_handle():
     """initialize() and set_scene() may come again (resize, scene switch: app.cpp:445,150-175): old buffers are released, the
     adaptive tail hand-over starts over, images stay right and the reported device memory is what is allocated now"""
